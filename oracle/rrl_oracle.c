@@ -1,0 +1,459 @@
+/*
+ * rrl_oracle.c -- CPU restatement of the intersected-line robust registration loss.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under a-robust-registration-loss_amd/ may
+ * import, link or call this file; only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg use it, and there only as the checker / timed
+ * CPU baseline.  The product path is the HIP library (include/rrl.h).
+ *
+ * Parity pin: every function below is checked against vectors captured from
+ * the reference itself (imported in the build container by
+ * tests/golden/make_golden.py); see tests/test_oracle_golden.py.
+ *
+ * Each function cites the reference lines it restates (paths relative to the
+ * reference checkout, e.g. code/loss.py:68-112).  The arithmetic that decides
+ * labels is written op-for-op in fp32 in the reference's evaluation order and
+ * this file MUST be compiled with -ffp-contract=off (see oracle/Makefile):
+ * a fused multiply-add anywhere in dist_sq() flips labels.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define RRL_EPS 2e-4f    /* code/loss.py:88  */
+#define RRL_CTHR 1.731f  /* code/loss.py:109 */
+#define MAXH 8           /* oracle keeps up to 8 hits per line and cloud */
+
+#ifdef __GNUC__
+#define CLONES __attribute__((target_clones("avx512f", "avx2", "default")))
+#else
+#define CLONES
+#endif
+
+/* |v| with the reference's order: sqrt((x^2 + y^2) + z^2)  (code/loss.py:96-103) */
+static inline float norm3(float x, float y, float z) {
+    float s = x * x;
+    s = s + y * y;
+    s = s + z * z;
+    return sqrtf(s);
+}
+
+/* Per-triangle hit threshold, code/loss.py:94-110:
+ *   delta = mean(|P1-P0|, |P2-P0|, |P1-P2|);  thr = delta * 1.731 / 2          */
+void rrl_oracle_tri_threshold(const float *tri, int N, float *thr) {
+    for (int f = 0; f < N; ++f) {
+        const float *p = tri + 9 * (size_t)f;
+        float e0 = norm3(p[3] - p[0], p[4] - p[1], p[5] - p[2]);
+        float e1 = norm3(p[6] - p[0], p[7] - p[1], p[8] - p[2]);
+        float e2 = norm3(p[3] - p[6], p[4] - p[7], p[5] - p[8]);
+        float delta = ((e0 + e1) + e2) / 3.0f;
+        float t = delta * RRL_CTHR;
+        thr[f] = t / 2.0f;
+    }
+}
+
+/* Squared point-to-line distance + eps, code/loss.py:84-88 (before the sqrt):
+ *   AC = P - x0;  proj = (sum_c AC_c*dir_c)^2;  dAC = sum_c AC_c^2;
+ *   x = (dAC - proj) + 2e-4.   3-term sums associate as (a0+a1)+a2.            */
+static inline float dist_sq(float px, float py, float pz, const float *ln) {
+    float ax = px - ln[3], ay = py - ln[4], az = pz - ln[5];
+    float dot = ax * ln[0];
+    dot = dot + ay * ln[1];
+    dot = dot + az * ln[2];
+    float proj = dot * dot;
+    float dac = ax * ax;
+    dac = dac + ay * ay;
+    dac = dac + az * az;
+    float x = dac - proj;
+    return x + RRL_EPS;
+}
+
+/*
+ * Dense line<->pseudo-triangle scan, code/loss.py:68-112.
+ * For every line: count of triangles whose three points are all strictly
+ * closer than thr[f] (code/loss.py:107-110), the first `cap` hit indices in
+ * ascending triangle order (== nonzero() order, code/loss.py:125-131) and the
+ * detached weights w_k = d_k / ((d0+d1)+d2) (code/loss.py:92).
+ * label (optional, L*N bytes) receives the dense boolean matrix.
+ * nan_flag is set when any sqrt argument is negative (code/loss.py:89-91).
+ * Triangles are transposed to SoA first so the inner loop vectorises; the
+ * per-element arithmetic is unchanged.
+ */
+CLONES
+static void scan_lines(const float *soa, const float *thr, int N, const float *line, int L,
+                       int32_t *count, int32_t *hit_idx, float *hit_w, int cap,
+                       uint8_t *label, int *nan_flag) {
+    const float *X0 = soa, *Y0 = soa + (size_t)N, *Z0 = soa + 2 * (size_t)N;
+    const float *X1 = soa + 3 * (size_t)N, *Y1 = soa + 4 * (size_t)N, *Z1 = soa + 5 * (size_t)N;
+    const float *X2 = soa + 6 * (size_t)N, *Y2 = soa + 7 * (size_t)N, *Z2 = soa + 8 * (size_t)N;
+    int any_nan = 0;
+#pragma omp parallel for schedule(static) reduction(| : any_nan)
+    for (int l = 0; l < L; ++l) {
+        const float *ln = line + 6 * (size_t)l;
+        uint8_t *hit = (uint8_t *)malloc((size_t)N);
+        int neg = 0;
+        for (int f = 0; f < N; ++f) {
+            float x0 = dist_sq(X0[f], Y0[f], Z0[f], ln);
+            float x1 = dist_sq(X1[f], Y1[f], Z1[f], ln);
+            float x2 = dist_sq(X2[f], Y2[f], Z2[f], ln);
+            float d0 = sqrtf(x0), d1 = sqrtf(x1), d2 = sqrtf(x2);
+            float t = thr[f];
+            hit[f] = (uint8_t)((d0 < t) & (d1 < t) & (d2 < t));
+            neg |= (x0 < 0.0f) | (x1 < 0.0f) | (x2 < 0.0f);
+        }
+        any_nan |= neg;
+        int c = 0;
+        for (int f = 0; f < N; ++f) {
+            if (!hit[f]) continue;
+            if (c < cap) {
+                float d0 = sqrtf(dist_sq(X0[f], Y0[f], Z0[f], ln));
+                float d1 = sqrtf(dist_sq(X1[f], Y1[f], Z1[f], ln));
+                float d2 = sqrtf(dist_sq(X2[f], Y2[f], Z2[f], ln));
+                float s = (d0 + d1) + d2;
+                hit_idx[(size_t)l * cap + c] = f;
+                hit_w[((size_t)l * cap + c) * 3 + 0] = d0 / s;
+                hit_w[((size_t)l * cap + c) * 3 + 1] = d1 / s;
+                hit_w[((size_t)l * cap + c) * 3 + 2] = d2 / s;
+            }
+            ++c;
+        }
+        count[l] = c;
+        if (label) memcpy(label + (size_t)l * N, hit, (size_t)N);
+        free(hit);
+    }
+    if (any_nan) *nan_flag = 1;
+}
+
+static float *to_soa(const float *tri, int N) {
+    float *soa = (float *)malloc(sizeof(float) * 9 * (size_t)(N > 0 ? N : 1));
+    for (int f = 0; f < N; ++f)
+        for (int c = 0; c < 9; ++c) soa[(size_t)c * N + f] = tri[9 * (size_t)f + c];
+    return soa;
+}
+
+void rrl_oracle_scan(const float *tri, int N, const float *line, int L, int32_t *count,
+                     int32_t *hit_idx, float *hit_w, int cap, uint8_t *label, int *nan_flag) {
+    float *thr = (float *)malloc(sizeof(float) * (size_t)(N > 0 ? N : 1));
+    float *soa = to_soa(tri, N);
+    rrl_oracle_tri_threshold(tri, N, thr);
+    scan_lines(soa, thr, N, line, L, count, hit_idx, hit_w, cap, label, nan_flag);
+    free(soa);
+    free(thr);
+}
+
+typedef struct {
+    int32_t n_selected;  /* lines that fall in some (k,j) bucket            */
+    int32_t n_buckets;   /* non-empty buckets (the reference's Flag / i+1)  */
+    int32_t n_values;    /* number of D values that entered the median      */
+    int32_t nan_flag;    /* negative sqrt argument seen (reference exit(0)) */
+    float median;        /* lower median of all D values                    */
+    float loss;
+} rrl_oracle_info;
+
+static int cmp_float(const void *a, const void *b) {
+    float x = *(const float *)a, y = *(const float *)b;
+    return (x > y) - (x < y);
+}
+
+/* Intersection point of a hit, code/loss.py:155-163:
+ *   q = mean_k( w_k * P_k ) -- a mean over the 3 neighbours, i.e. 1/3 of the
+ *   convex combination.                                       */
+static inline void inter_point(const float *tri, int f, const float *w, float *q) {
+    const float *p = tri + 9 * (size_t)f;
+    for (int c = 0; c < 3; ++c) {
+        float s = w[0] * p[c];
+        s = s + w[1] * p[3 + c];
+        s = s + w[2] * p[6 + c];
+        q[c] = s / 3.0f;
+    }
+}
+
+/*
+ * Whole loss for ONE sample (B = 1, which is how every reference caller uses
+ * it): code/loss.py:170-232 forward, and the closed-form gradient of SURVEY.md
+ * section 8a row G (checked against the reference's autograd in the golden
+ * fixtures).  Bucket order k-major, lines ascending, hits ascending.
+ *
+ * D_dump (optional, D_cap floats): the D values in reference concatenation
+ * order.  grad_tri1 / grad_tri2 (optional): dL/dP scaled by grad_out; weights,
+ * median and labels carry no gradient (code/loss.py:112, :224).
+ * Returns 0 when a loss was produced, 1 when no bucket is populated (the
+ * reference returns (None, None, None), code/loss.py:231-232).
+ */
+int rrl_oracle_loss(int s_m, int s_n, int e_m, int e_n, const float *tri1, int N,
+                    const float *tri2, int M, const float *line, int L, float grad_out,
+                    float *grad_tri1, float *grad_tri2, float *D_dump, int D_cap,
+                    rrl_oracle_info *info) {
+    memset(info, 0, sizeof(*info));
+    if (e_m - 1 > MAXH || e_n - 1 > MAXH || s_m < 1 || s_n < 1) return -1;
+    size_t Ls = (size_t)(L > 0 ? L : 1);
+    int32_t *c1 = (int32_t *)calloc(Ls, 4), *c2 = (int32_t *)calloc(Ls, 4);
+    int32_t *h1 = (int32_t *)calloc(Ls * MAXH, 4), *h2 = (int32_t *)calloc(Ls * MAXH, 4);
+    float *w1 = (float *)calloc(Ls * MAXH * 3, 4), *w2 = (float *)calloc(Ls * MAXH * 3, 4);
+    int nan_flag = 0;
+    rrl_oracle_scan(tri1, N, line, L, c1, h1, w1, MAXH, NULL, &nan_flag);
+    rrl_oracle_scan(tri2, M, line, L, c2, h2, w2, MAXH, NULL, &nan_flag);
+    info->nan_flag = nan_flag;
+
+    /* pass 1: D values of every selected line, in reference order */
+    int nk = e_m - s_m, nj = e_n - s_n;
+    if (nk < 0) nk = 0;
+    if (nj < 0) nj = 0;
+    size_t cap_vals = Ls * (size_t)MAXH * MAXH;
+    float *D = (float *)malloc(sizeof(float) * cap_vals);
+    int32_t *sel_line = (int32_t *)malloc(sizeof(int32_t) * Ls * (size_t)(nk * nj > 0 ? 1 : 1));
+    size_t *sel_off = (size_t *)malloc(sizeof(size_t) * Ls);
+    int *bucket_S = (int *)calloc((size_t)(nk * nj > 0 ? nk * nj : 1), sizeof(int));
+    size_t *bucket_start = (size_t *)calloc((size_t)(nk * nj > 0 ? nk * nj : 1), sizeof(size_t));
+    size_t nsel = 0, nval = 0;
+    for (int k = s_m; k < e_m; ++k)
+        for (int j = s_n; j < e_n; ++j) {
+            int bi = (k - s_m) * nj + (j - s_n);
+            bucket_start[bi] = nsel;
+            for (int l = 0; l < L; ++l) {
+                if (c1[l] != k || c2[l] != j) continue;
+                float q1[MAXH][3], q2[MAXH][3];
+                for (int a = 0; a < k; ++a)
+                    inter_point(tri1, h1[(size_t)l * MAXH + a], w1 + ((size_t)l * MAXH + a) * 3, q1[a]);
+                for (int b = 0; b < j; ++b)
+                    inter_point(tri2, h2[(size_t)l * MAXH + b], w2 + ((size_t)l * MAXH + b) * 3, q2[b]);
+                sel_line[nsel] = l;
+                sel_off[nsel] = nval;
+                for (int a = 0; a < k; ++a)
+                    for (int b = 0; b < j; ++b) {
+                        /* code/loss.py:38-52: sum_c (x-y)^2 */
+                        float dx = q1[a][0] - q2[b][0], dy = q1[a][1] - q2[b][1],
+                              dz = q1[a][2] - q2[b][2];
+                        float s = dx * dx;
+                        s = s + dy * dy;
+                        s = s + dz * dz;
+                        D[nval++] = s;
+                    }
+                ++nsel;
+                ++bucket_S[bi];
+            }
+        }
+    info->n_selected = (int32_t)nsel;
+    info->n_values = (int32_t)nval;
+    if (D_dump)
+        for (size_t i = 0; i < nval && i < (size_t)D_cap; ++i) D_dump[i] = D[i];
+    int n_buckets = 0;
+    for (int bi = 0; bi < nk * nj; ++bi) n_buckets += bucket_S[bi] > 0;
+    info->n_buckets = n_buckets;
+    int rc = 1;
+    if (n_buckets > 0) {
+        rc = 0;
+        /* lower median, torch.median semantics: sorted[(n-1)/2] (code/loss.py:223-224) */
+        float *sorted = (float *)malloc(sizeof(float) * nval);
+        memcpy(sorted, D, sizeof(float) * nval);
+        qsort(sorted, nval, sizeof(float), cmp_float);
+        float med = sorted[(nval - 1) / 2];
+        free(sorted);
+        info->median = med;
+        if (grad_tri1) memset(grad_tri1, 0, sizeof(float) * 9 * (size_t)N);
+        if (grad_tri2) memset(grad_tri2, 0, sizeof(float) * 9 * (size_t)M);
+        float loss = 0.0f;
+        for (int k = s_m; k < e_m; ++k)
+            for (int j = s_n; j < e_n; ++j) {
+                int bi = (k - s_m) * nj + (j - s_n);
+                int S = bucket_S[bi];
+                if (S == 0) continue;
+                float wkj = expf(-0.5f * (float)abs(k - j)); /* code/loss.py:215 */
+                double sum_row = 0.0, sum_col = 0.0;
+                for (int s = 0; s < S; ++s) {
+                    size_t si = bucket_start[bi] + (size_t)s;
+                    const float *Dl = D + sel_off[si];
+                    float Wl[MAXH][MAXH];
+                    for (int a = 0; a < k; ++a)
+                        for (int b = 0; b < j; ++b) /* code/loss.py:20-21 Welsch1 */
+                            Wl[a][b] = 1.0f - expf(-(Dl[a * j + b] / med) / 2.0f);
+                    int arg_b[MAXH], arg_a[MAXH]; /* first-occurrence argmin */
+                    for (int a = 0; a < k; ++a) {
+                        int m = 0;
+                        for (int b = 1; b < j; ++b)
+                            if (Wl[a][b] < Wl[a][m]) m = b;
+                        arg_b[a] = m;
+                        sum_row += Wl[a][m];
+                    }
+                    for (int b = 0; b < j; ++b) {
+                        int m = 0;
+                        for (int a = 1; a < k; ++a)
+                            if (Wl[a][b] < Wl[m][b]) m = a;
+                        arg_a[b] = m;
+                        sum_col += Wl[m][b];
+                    }
+                    if (grad_tri1 || grad_tri2) {
+                        int l = sel_line[si];
+                        float q1[MAXH][3], q2[MAXH][3];
+                        for (int a = 0; a < k; ++a)
+                            inter_point(tri1, h1[(size_t)l * MAXH + a],
+                                        w1 + ((size_t)l * MAXH + a) * 3, q1[a]);
+                        for (int b = 0; b < j; ++b)
+                            inter_point(tri2, h2[(size_t)l * MAXH + b],
+                                        w2 + ((size_t)l * MAXH + b) * 3, q2[b]);
+                        double scale = (double)grad_out * wkj / n_buckets;
+                        for (int a = 0; a < k; ++a)
+                            for (int b = 0; b < j; ++b) {
+                                double sel = 0.0;
+                                if (arg_b[a] == b) sel += 1.0 / ((double)S * k);
+                                if (arg_a[b] == a) sel += 1.0 / ((double)S * j);
+                                if (sel == 0.0) continue;
+                                /* dWl/dD = exp(-D/(2 med)) / (2 med) */
+                                double g = scale * sel * exp(-(double)Dl[a * j + b] / (2.0 * med)) /
+                                           (2.0 * med);
+                                for (int c = 0; c < 3; ++c) {
+                                    double gq = 2.0 * ((double)q1[a][c] - (double)q2[b][c]) * g;
+                                    if (grad_tri1) {
+                                        int f = h1[(size_t)l * MAXH + a];
+                                        const float *w = w1 + ((size_t)l * MAXH + a) * 3;
+                                        for (int kk = 0; kk < 3; ++kk)
+                                            grad_tri1[9 * (size_t)f + 3 * kk + c] +=
+                                                (float)(gq * w[kk] / 3.0);
+                                    }
+                                    if (grad_tri2) {
+                                        int f = h2[(size_t)l * MAXH + b];
+                                        const float *w = w2 + ((size_t)l * MAXH + b) * 3;
+                                        for (int kk = 0; kk < 3; ++kk)
+                                            grad_tri2[9 * (size_t)f + 3 * kk + c] -=
+                                                (float)(gq * w[kk] / 3.0);
+                                    }
+                                }
+                            }
+                    }
+                }
+                float term = (float)(sum_row / ((double)S * k)) + (float)(sum_col / ((double)S * j));
+                loss = loss + wkj * term; /* code/loss.py:227-229 */
+            }
+        loss = loss / (float)n_buckets; /* code/loss.py:230 */
+        info->loss = loss;
+    }
+    free(c1); free(c2); free(h1); free(h2); free(w1); free(w2);
+    free(D); free(sel_line); free(sel_off); free(bucket_S); free(bucket_start);
+    return rc;
+}
+
+/* Chamfer monitor, code/loss.py:38-52 + 236-252: per-point min of squared
+ * distances in both directions; the caller takes the mean of all B*(N+M)
+ * values.  First-occurrence argmin is returned for the backward.            */
+void rrl_oracle_chamfer(const float *x, int N, const float *y, int M, float *min_x,
+                        int32_t *arg_x, float *min_y, int32_t *arg_y) {
+    for (int j = 0; j < M; ++j) { min_y[j] = INFINITY; arg_y[j] = 0; }
+    for (int i = 0; i < N; ++i) {
+        float best = INFINITY; int bj = 0;
+        for (int j = 0; j < M; ++j) {
+            float dx = x[3 * i] - y[3 * j], dy = x[3 * i + 1] - y[3 * j + 1],
+                  dz = x[3 * i + 2] - y[3 * j + 2];
+            float s = dx * dx;
+            s = s + dy * dy;
+            s = s + dz * dz;
+            if (s < best) { best = s; bj = j; }
+            if (s < min_y[j]) { min_y[j] = s; arg_y[j] = i; }
+        }
+        min_x[i] = best; arg_x[i] = bj;
+    }
+}
+
+/* Rigid apply, row-vector convention y = x R + T (code/loss.py:460-461) when
+ * transpose_r == 0, and y = x R^T + T, i.e. y = R x + T per point, when
+ * transpose_r == 1 (rpm/common/math_torch/se3.py:67-72, utils.py:32-37).
+ * BLAS accumulates with FMAs in unspecified order, so this is a tolerance
+ * (not bit) oracle: plain double accumulation.                              */
+void rrl_oracle_rigid_apply(const float *x, int n, const float *R, const float *T,
+                            int transpose_r, float *y) {
+    for (int i = 0; i < n; ++i)
+        for (int c = 0; c < 3; ++c) {
+            double s = T[c];
+            for (int r = 0; r < 3; ++r)
+                s += (double)x[3 * i + r] * (transpose_r ? R[3 * c + r] : R[3 * r + c]);
+            y[3 * i + c] = (float)s;
+        }
+}
+
+/* --- random-line sampler ------------------------------------------------- */
+
+static inline void cross3(const float *a, const float *b, float *o) {
+    o[0] = a[1] * b[2] - a[2] * b[1];
+    o[1] = a[2] * b[0] - a[0] * b[2];
+    o[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+/* AABB corners in the reference's order (corner 0 = max, 7 = min),
+ * code/loss.py:325-351, and its 12-triangle face table, code/loss.py:357-358. */
+static const int BOX_FACES[12][3] = {{2, 0, 6}, {0, 4, 6}, {5, 4, 0}, {5, 0, 1},
+                                     {6, 4, 5}, {5, 7, 6}, {3, 0, 2}, {1, 0, 3},
+                                     {3, 2, 6}, {6, 7, 3}, {5, 1, 3}, {3, 7, 5}};
+
+void rrl_oracle_bbox(const float *v, int n, float *bbox /* 8*3 */) {
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = 0; i < n; ++i)
+        for (int c = 0; c < 3; ++c) {
+            if (v[3 * i + c] < mn[c]) mn[c] = v[3 * i + c];
+            if (v[3 * i + c] > mx[c]) mx[c] = v[3 * i + c];
+        }
+    const int pick[8][3] = {{1, 1, 1}, {1, 1, 0}, {1, 0, 1}, {1, 0, 0},
+                            {0, 1, 1}, {0, 1, 0}, {0, 0, 1}, {0, 0, 0}};
+    for (int k = 0; k < 8; ++k)
+        for (int c = 0; c < 3; ++c) bbox[3 * k + c] = pick[k][c] ? mx[c] : mn[c];
+}
+
+/* Number of box triangles a line crosses according to the reference's
+ * barycentric-area test, code/loss.py:265-316:
+ *   t = n.(A - x0) / (n.dir + 1e-12);  I = t*dir + x0;
+ *   hit = |(I-B)x(I-C)| > 0 & |(I-C)x(I-A)| > 0 & |(I-A)x(I-B)| > 0
+ *         & (sum of the three) <= |(B-A)x(C-A)|                              */
+int rrl_oracle_box_hits(const float *bbox, const float *ln) {
+    int hits = 0;
+    for (int t = 0; t < 12; ++t) {
+        const float *A = bbox + 3 * BOX_FACES[t][0], *B = bbox + 3 * BOX_FACES[t][1],
+                    *C = bbox + 3 * BOX_FACES[t][2];
+        float e1[3] = {B[0] - A[0], B[1] - A[1], B[2] - A[2]};
+        float e2[3] = {C[0] - A[0], C[1] - A[1], C[2] - A[2]};
+        float nr[3];
+        cross3(e1, e2, nr);
+        float S = norm3(nr[0], nr[1], nr[2]);
+        float den = S > 1e-12f ? S : 1e-12f; /* F.normalize eps */
+        float nh[3] = {nr[0] / den, nr[1] / den, nr[2] / den};
+        float num = nh[0] * (A[0] - ln[3]);
+        num = num + nh[1] * (A[1] - ln[4]);
+        num = num + nh[2] * (A[2] - ln[5]);
+        float dn = nh[0] * ln[0];
+        dn = dn + nh[1] * ln[1];
+        dn = dn + nh[2] * ln[2];
+        float tt = num / (dn + 1e-12f);
+        float I[3] = {tt * ln[0] + ln[3], tt * ln[1] + ln[4], tt * ln[2] + ln[5]};
+        float ia[3] = {I[0] - A[0], I[1] - A[1], I[2] - A[2]};
+        float ib[3] = {I[0] - B[0], I[1] - B[1], I[2] - B[2]};
+        float ic[3] = {I[0] - C[0], I[1] - C[1], I[2] - C[2]};
+        float c0[3], c1[3], c2[3];
+        cross3(ib, ic, c0);
+        cross3(ic, ia, c1);
+        cross3(ia, ib, c2);
+        float ba = norm3(c0[0], c0[1], c0[2]), bb = norm3(c1[0], c1[1], c1[2]),
+              bc = norm3(c2[0], c2[1], c2[2]);
+        if (ba > 0 && bb > 0 && bc > 0 && ((ba + bb) + bc) <= S) ++hits;
+    }
+    return hits;
+}
+
+/* Candidate lines from four uniform streams, code/loss.py:384-412.
+ * pi32 is float32 pi held as a double (code/loss.py:9 makes torch.pi a Python
+ * float of the fp32 value); rand*2*pi is evaluated in fp32 by torch.          */
+void rrl_oracle_make_lines(const float *a1, const float *u1, const float *a2, const float *u2,
+                           int n, float r, const float *center, float *lines) {
+    const float pi32 = 3.14159274101257324f; /* float32 pi, code/loss.py:9 */
+    for (int i = 0; i < n; ++i) {
+        float al1 = (a1[i] * 2.0f) * pi32, al2 = (a2[i] * 2.0f) * pi32;
+        float v1 = u1[i] * 2.0f - 1.0f, v2 = u2[i] * 2.0f - 1.0f;
+        float s1 = sqrtf(1.0f - v1 * v1), s2 = sqrtf(1.0f - v2 * v2);
+        float q1[3] = {(r * s1) * cosf(al1), (r * sinf(al1)) * s1, r * v1};
+        float q2[3] = {(r * s2) * cosf(al2), (r * sinf(al2)) * s2, r * v2};
+        float d[3] = {q2[0] - q1[0], q2[1] - q1[1], q2[2] - q1[2]};
+        float nn = norm3(d[0], d[1], d[2]);
+        float den = nn > 1e-12f ? nn : 1e-12f;
+        for (int c = 0; c < 3; ++c) {
+            lines[6 * i + c] = d[c] / den;
+            lines[6 * i + 3 + c] = q1[c] + center[c];
+        }
+    }
+}

@@ -1,0 +1,40 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "a-robust-registration-loss_amd")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import rrl_oracle
+    rrl_oracle.build()
+    return rrl_oracle
+
+
+def merge_by_point(tri, grad):
+    """Sum a (N,9) pseudo-triangle gradient over all rows/slots that hold the same 3-D
+    point.  Rows such as [A,B,C] and [B,A,C] (mutual nearest neighbours) give D values
+    that tie up to rounding, and torch.min routes the whole gradient to whichever row
+    wins (SURVEY.md Q11 / hard part 3); the per-point sum -- what a caller that gathers
+    triangles from a cloud receives -- does not depend on the tie-break."""
+    pts = np.asarray(tri, np.float32).reshape(-1, 3)
+    keys, inv = np.unique(pts, axis=0, return_inverse=True)
+    out = np.zeros((len(keys), 3), np.float64)
+    np.add.at(out, inv.reshape(-1), np.asarray(grad, np.float64).reshape(-1, 3))
+    return out

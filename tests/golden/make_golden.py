@@ -1,0 +1,246 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by RUNNING THE REFERENCE.
+
+Run in the build container only (needs /root/reference):
+
+    python tests/golden/make_golden.py
+
+The reference's code/loss.py is imported unmodified; `openmesh`, `trimesh`,
+`cv2`, `igl` are absent here and unused by the path, so empty stub modules are
+registered first.  Only inputs and the reference's
+outputs are stored (npz); no reference source is copied.  The fixtures record
+the torch version and the minimum decision margin of the label test so the
+parity tests are provably non-borderline.
+"""
+import os
+import sys
+import types
+import warnings
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference/code"
+
+for m in ("openmesh", "trimesh", "cv2", "igl"):
+    sys.modules.setdefault(m, types.ModuleType(m))
+sys.path.insert(0, REF)
+warnings.filterwarnings("ignore")
+import torch  # noqa: E402
+import loss as RL  # noqa: E402  (the reference)
+
+sys.path.insert(0, os.path.join(ROOT, "a-robust-registration-loss_amd"))
+from rrl_hip import synth  # noqa: E402
+
+torch.set_default_dtype(torch.float32)
+META = dict(torch_version=torch.__version__, cpu_capability=torch.backends.cpu.get_cpu_capability())
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+
+
+def ref_scan(tri, lines):
+    """Reference dense scan of one cloud -> counts, hit list, weights at hits, margin."""
+    pts, norm_d, label = RL.cal_intersection_batch2_points_with_line(t(tri)[None], t(lines)[None])
+    label = label[0].numpy()
+    norm_d = norm_d.numpy()  # (L, N, 3)
+    count = label.sum(1).astype(np.int32)
+    li, fi = np.nonzero(label)
+    return dict(count=count, hit_line=li.astype(np.int32), hit_tri=fi.astype(np.int32),
+                hit_w=norm_d[li, fi].astype(np.float32), label=label)
+
+
+def margin(tri, lines):
+    """min over (line, triangle) of |max_k d / thr - 1| in float64 (decision margin)."""
+    P = tri.reshape(-1, 3, 3).astype(np.float64)
+    e = (np.linalg.norm(P[:, 1] - P[:, 0], axis=1) + np.linalg.norm(P[:, 2] - P[:, 0], axis=1)
+         + np.linalg.norm(P[:, 1] - P[:, 2], axis=1)) / 3
+    thr = e * 1.731 / 2
+    best = np.inf
+    ln = lines.astype(np.float64)
+    for s in range(0, ln.shape[0], 256):
+        u, x0 = ln[s:s + 256, None, None, :3], ln[s:s + 256, None, None, 3:]
+        a = P[None] - x0
+        d = np.sqrt(np.maximum((a * a).sum(-1) - ((a * u).sum(-1)) ** 2 + 2e-4, 0))
+        best = min(best, np.abs(d.max(-1) / thr[None] - 1).min())
+    return float(best)
+
+
+def ref_loss_case(tri1, tri2, lines, rng):
+    p1 = t(tri1)[None].clone().requires_grad_(True)
+    p2 = t(tri2)[None]
+    ln = t(lines)[None]
+    out = RL.cal_loss_intersection_batch_whole_median_pts_lines(*rng, p1, p2, ln, "cpu")
+    if isinstance(out, tuple):
+        return dict(loss=np.float32(np.nan), empty=True)
+    out.backward()
+    # per-bucket D values in the reference's concatenation order
+    info1 = RL.cal_intersection_batch2_points_with_line(p1.detach(), ln)
+    info2 = RL.cal_intersection_batch2_points_with_line(p2, ln)
+    c1, c2 = info1[2].sum(-1), info2[2].sum(-1)
+    Ds = []
+    for k in range(rng[0], rng[2]):
+        for j in range(rng[1], rng[3]):
+            mask = ((c1 == k) * (c2 == j)).reshape(-1)
+            dm = RL.cal_loss_intersection_batch_m_n_median_pts_lines(
+                k, j, info1, info2, mask, tri1.shape[0], tri2.shape[0])
+            if dm is not None:
+                Ds.append(dm.reshape(-1).numpy())
+    D = np.concatenate(Ds).astype(np.float32)
+    med = torch.median(torch.from_numpy(D)).item()
+    return dict(loss=np.float32(out.item()), empty=False, grad1=p1.grad[0].numpy().copy(),
+                D=D, median=np.float32(med))
+
+
+def save(name, **kw):
+    kw["meta"] = np.array(repr(META))
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **kw)
+    print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def ref_lines(seed, r, center, v1, v2, n):
+    torch.manual_seed(seed)
+    out = RL.Random_uniform_distribution_lines_batch_efficient_resample(
+        torch.tensor([[float(r)]]), t(center).reshape(1, 3), n, t(v1)[None], t(v2)[None], "cpu")
+    return out[0].numpy().astype(np.float32)
+
+
+def loss_fixture(name, tri1, tri2, lines, ranges):
+    s1, s2 = ref_scan(tri1, lines), ref_scan(tri2, lines)
+    kw = dict(tri1=tri1, tri2=tri2, lines=lines,
+              count1=s1["count"], hit_line1=s1["hit_line"], hit_tri1=s1["hit_tri"], hit_w1=s1["hit_w"],
+              count2=s2["count"], hit_line2=s2["hit_line"], hit_tri2=s2["hit_tri"], hit_w2=s2["hit_w"],
+              margin=np.float64(min(margin(tri1, lines), margin(tri2, lines))),
+              ranges=np.array(ranges, np.int32))
+    for i, rng in enumerate(ranges):
+        res = ref_loss_case(tri1, tri2, lines, rng)
+        for k, v in res.items():
+            kw[f"r{i}_{k}"] = v
+        print(f"  range {rng}: loss={res['loss']} nD={len(res.get('D', []))}")
+    print(f"  hits: src {int(s1['count'].sum())}, tar {int(s2['count'].sum())}, margin {kw['margin']:.3e}")
+    save(name, **kw)
+
+
+def read_obj_vertices(path):
+    return np.array([[float(x) for x in ln.split()[1:4]] for ln in open(path) if ln.startswith("v ")],
+                    np.float32)
+
+
+def main():
+    # --- A: synthetic unit-scale pair ------------------------------------------------
+    for seed, (n, m, nl) in ((0, (256, 256, 2000)), (1, (300, 200, 1500))):
+        pr = synth.make_pair(seed, n, m)
+        lines = ref_lines(100 + seed, pr["radius"], pr["center"], pr["src"], pr["tar"], nl)
+        print(f"synth seed {seed}: filled {(np.abs(lines).sum(1) > 0).sum()}/{nl}")
+        loss_fixture(f"loss_synth_s{seed}.npz", pr["src_tri"], pr["tar_tri"], lines,
+                     [(1, 1, 5, 5), (1, 1, 2, 2), (2, 1, 3, 2), (1, 2, 3, 5)])
+
+    # --- B: demo scale (AABB-diagonal radius ~ 11.7), derived from sample pair 0 -----
+    torch.manual_seed(123)
+    np.random.seed(123)
+    v1 = read_obj_vertices(os.path.join(REF, "sample_data/challenge_data/0_src_sample.obj"))
+    v2 = read_obj_vertices(os.path.join(REF, "sample_data/challenge_data/0_tar_sample.obj"))
+    n1 = RL.Sample_neighs(v1).reshape(-1, 9)
+    n2 = RL.Sample_neighs(v2).reshape(-1, 9)
+    c1, c2 = v1.mean(0, keepdims=True), v2.mean(0, keepdims=True)
+    v1, v2 = v1 - c1, v2 - c2
+    n1 = (n1.reshape(-1, 3) - c1).reshape(-1, 9).astype(np.float32)
+    n2 = (n2.reshape(-1, 3) - c2).reshape(-1, 9).astype(np.float32)
+    bb = RL.generate_bbox(t(v2)[None])[0].numpy()
+    rad = float(np.linalg.norm(bb[0] - bb[-1]))
+    lines = ref_lines(7, rad, v2.mean(0), v1, v2, 3000)
+    print(f"demo: N={n1.shape[0]} M={n2.shape[0]} radius={rad:.3f} filled "
+          f"{(np.abs(lines).sum(1) > 0).sum()}/3000")
+    loss_fixture("loss_demo_scale.npz", n1, n2, lines, [(1, 1, 5, 5)])
+
+    # --- C: edge cases ---------------------------------------------------------------
+    pr = synth.make_pair(5, 128, 128)
+    far = np.tile(np.array([[1, 0, 0, 0, 50, 50]], np.float32), (16, 1))  # all-miss lines
+    out = RL.cal_loss_intersection_batch_whole_median_pts_lines(
+        1, 1, 5, 5, t(pr["src_tri"])[None], t(pr["tar_tri"])[None], t(far)[None], "cpu")
+    assert isinstance(out, tuple) and out[0] is None
+    lines = ref_lines(9, pr["radius"], pr["center"], pr["src"], pr["tar"], 600)
+    lines[::7] = 0.0  # zero (unfilled) rows are legal inputs
+    dup = pr["src_tri"].copy()
+    dup[1::2] = dup[0::2]  # duplicate pseudo-triangles -> bit-equal distances (tie case)
+    loss_fixture("loss_edge_zero_dup.npz", dup, pr["tar_tri"], lines, [(1, 1, 5, 5)])
+    save("loss_edge_allmiss.npz", tri1=pr["src_tri"], tri2=pr["tar_tri"], lines=far)
+
+    # --- D: B=2 pooling quirk ---------------------------------------------
+    pa, pb = synth.make_pair(11, 160, 160), synth.make_pair(12, 160, 160)
+    la = ref_lines(21, pa["radius"], pa["center"], pa["src"], pa["tar"], 800)
+    lb = ref_lines(22, pb["radius"], pb["center"], pb["src"], pb["tar"], 800)
+    p1 = torch.stack([t(pa["src_tri"]), t(pb["src_tri"])]).requires_grad_(True)
+    p2 = torch.stack([t(pa["tar_tri"]), t(pb["tar_tri"])])
+    ln = torch.stack([t(la), t(lb)])
+    out = RL.cal_loss_intersection_batch_whole_median_pts_lines(1, 1, 5, 5, p1, p2, ln, "cpu")
+    out.backward()
+    save("loss_b2_quirk.npz", tri1=p1.detach().numpy(), tri2=p2.numpy(), lines=ln.numpy(),
+         loss=np.float32(out.item()), grad1=p1.grad.numpy())
+    print("B=2 quirk loss", out.item())
+
+    # --- E: se(3) exp / log ------------------------------------------------------------
+    rng = np.random.default_rng(3)
+    xis = []
+    for mag in (0.0, 1e-4, 0.0099, 0.0101, 0.5, 3.1):
+        ax = rng.standard_normal(3)
+        ax /= np.linalg.norm(ax)
+        xis.append(np.concatenate([mag * ax, rng.standard_normal(3)]))
+    xis = np.array(xis, np.float32)
+    Rs, ps = RL.se3.exp3(t(xis))
+    g = RL.se3.exp(t(xis))
+    lg = RL.se3.log(g)
+    save("se3_exp_log.npz", xi=xis, R=Rs.numpy(), p=ps.numpy(), g=g.numpy(), log_of_exp=lg.numpy())
+
+    # --- F: Reconstruction_point forward/backward ---------------------------------------
+    np.random.seed(4)
+    rec = RL.Reconstruction_point()
+    with torch.no_grad():
+        rec.parameters_.copy_(t(np.array([0.3, -0.2, 0.1, 0.05, 0.02, -0.04], np.float32)))
+    pr = synth.make_pair(6, 200, 200)
+    pts, nb = rec(t(pr["src"]), t(pr["src_tri"]).reshape(1, -1, 3))
+    gp, gn = torch.randn(pts.shape, generator=torch.Generator().manual_seed(1)), \
+        torch.randn(nb.shape, generator=torch.Generator().manual_seed(2))
+    ((pts * gp).sum() + (nb * gn).sum()).backward()
+    save("reconstruction_point.npz", xi=rec.parameters_.detach().numpy(), src=pr["src"],
+         src_tri=pr["src_tri"], out_pts=pts.detach().numpy(), out_tri=nb.detach().numpy(),
+         g_pts=gp.numpy(), g_tri=gn.numpy(), grad_xi=rec.parameters_.grad.numpy())
+
+    # --- G: chamfer ---------------------------------------------------------------------
+    gx = torch.Generator().manual_seed(8)
+    x = torch.randn(2, 300, 3, generator=gx).requires_grad_(True)
+    y = torch.randn(2, 257, 3, generator=gx)
+    cd = RL.chamfer_dist(x, y)
+    cd.backward()
+    save("chamfer.npz", x=x.detach().numpy(), y=y.numpy(), value=np.float32(cd.item()),
+         grad_x=x.grad.numpy())
+
+    # --- H: sampler ---------------------------------------------------------------------
+    pr = synth.make_pair(2, 96, 80)
+    n = 400
+    seed = 31
+    torch.manual_seed(seed)
+    rands = torch.stack([torch.stack([torch.rand(1, n)[0] for _ in range(4)]) for _ in range(10)])
+    torch.manual_seed(seed)
+    cand0 = RL.Random_uniform_distribution_lines_batch_efficient(
+        torch.tensor([[float(pr["radius"])]]), t(pr["center"]).reshape(1, 3), n, "cpu")[0]
+    fv1 = RL.generate_mesh_by_bbox(RL.generate_bbox(t(pr["src"])[None]), "cpu")
+    fv2 = RL.generate_mesh_by_bbox(RL.generate_bbox(t(pr["tar"])[None]), "cpu")
+    h1 = RL.cal_intersection_batch2_rand_lines(fv1, cand0[None])[0]
+    h2 = RL.cal_intersection_batch2_rand_lines(fv2, cand0[None])[0]
+    final = ref_lines(seed, pr["radius"], pr["center"], pr["src"], pr["tar"], n)
+    # also the full-diagonal radius, which leaves unfilled rows
+    final_big = ref_lines(seed, 4 * pr["radius"], pr["center"], pr["src"], pr["tar"], n)
+    save("sampler.npz", src=pr["src"], tar=pr["tar"], radius=pr["radius"], center=pr["center"],
+         rands=rands.numpy(), cand0=cand0.numpy(), hits1=h1.numpy().astype(np.int32),
+         hits2=h2.numpy().astype(np.int32), final=final, final_big=final_big,
+         bbox1=RL.generate_bbox(t(pr["src"])[None])[0].numpy(), seed=np.int32(seed))
+    print("sampler: accepted round0", int(((h1 * h2) > 0).sum()), "/", n,
+          "filled(big radius)", int((np.abs(final_big).sum(1) > 0).sum()))
+
+
+if __name__ == "__main__":
+    main()
