@@ -1,0 +1,454 @@
+// rrl_geom.hip -- K6 rigid apply, K7 Chamfer monitor, K8 line sampler.
+//   K6 code/loss.py:458-463 (+ the RPM/DCP/FMR layouts, see include/rrl.h)   HBM-bound
+//   K7 code/loss.py:38-52, 236-252                                           VALU-bound, N*M pairs
+//   K8 code/loss.py:265-432                                                  tiny
+#include "rrl_common.h"
+
+typedef const float __attribute__((address_space(4))) * kptr;  // constant AS -> s_load
+
+// ---------------------------------------------------------------------------------------
+// K6 rigid apply
+// ---------------------------------------------------------------------------------------
+struct Mat {
+    float r[9], t[3];
+};
+
+__device__ __forceinline__ Mat load_mat(const float *__restrict__ R, const float *__restrict__ t,
+                                        int b, int transpose_r) {
+    Mat m;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)  // m.r[i*3+j] multiplies x_i into y_j
+            m.r[i * 3 + j] = transpose_r ? R[b * 9 + j * 3 + i] : R[b * 9 + i * 3 + j];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) m.t[j] = t ? t[b * 3 + j] : 0.0f;
+    return m;
+}
+
+template <bool CF>
+__global__ __launch_bounds__(256) void rigid_fwd_kernel(const float *__restrict__ x,
+                                                        const float *__restrict__ R,
+                                                        const float *__restrict__ t,
+                                                        float *__restrict__ y, int n,
+                                                        int transpose_r) {
+    const int b = blockIdx.y;
+    const Mat m = load_mat(R, t, b, transpose_r);
+    const size_t base = (size_t)b * n * 3;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        float v[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[c] = CF ? x[base + (size_t)c * n + i] : x[base + 3 * (size_t)i + c];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            float s = fmaf(v[2], m.r[6 + j], fmaf(v[1], m.r[3 + j], v[0] * m.r[j])) + m.t[j];
+            if (CF) y[base + (size_t)j * n + i] = s; else y[base + 3 * (size_t)i + j] = s;
+        }
+    }
+}
+
+extern "C" int rrl_rigid_apply_fwd(const float *x, const float *R, const float *t, float *y, int B,
+                                   int n, int transpose_r, int channel_first, void *stream) {
+    if (!x || !R || !t || !y || B < 0 || n < 0) return RRL_E_ARG;
+    if (B == 0 || n == 0) return 0;
+    unsigned gx = (unsigned)((n + 255) / 256);
+    if (gx > 2048) gx = 2048;
+    dim3 grid(gx, (unsigned)B);
+    if (channel_first)
+        hipLaunchKernelGGL(rigid_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, R, t,
+                           y, n, transpose_r);
+    else
+        hipLaunchKernelGGL(rigid_fwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, R,
+                           t, y, n, transpose_r);
+    RRL_LAUNCH_CHECK();
+    return 0;
+}
+
+#define RIGID_BWD_PTS 2048  // points per workgroup in the backward reduction
+
+extern "C" int rrl_rigid_bwd_blocks(int n) { return n > 0 ? (n + RIGID_BWD_PTS - 1) / RIGID_BWD_PTS : 0; }
+
+// y_j = sum_i x_i m[i][j] + t_j  =>  gx_i = sum_j gy_j m[i][j],  gm[i][j] = sum x_i gy_j,
+// gt_j = sum gy_j.  Wave shuffle reduction, then a fixed-order cross-wave / cross-block sum
+// (deterministic: no float atomics).
+template <bool CF>
+__global__ __launch_bounds__(256) void rigid_bwd_kernel(const float *__restrict__ x,
+                                                        const float *__restrict__ R,
+                                                        const float *__restrict__ gy,
+                                                        float *__restrict__ gx,
+                                                        float *__restrict__ partial, int n,
+                                                        int transpose_r) {
+    __shared__ float red[4][12];
+    const int b = blockIdx.y;
+    const Mat m = load_mat(R, nullptr, b, transpose_r);
+    const size_t base = (size_t)b * n * 3;
+    float acc[12];
+#pragma unroll
+    for (int q = 0; q < 12; ++q) acc[q] = 0.0f;
+    const int i0 = blockIdx.x * RIGID_BWD_PTS;
+    for (int i = i0 + threadIdx.x; i < min(n, i0 + RIGID_BWD_PTS); i += 256) {
+        float v[3], g[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            v[c] = CF ? x[base + (size_t)c * n + i] : x[base + 3 * (size_t)i + c];
+            g[c] = CF ? gy[base + (size_t)c * n + i] : gy[base + 3 * (size_t)i + c];
+        }
+        if (gx) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float s = fmaf(g[2], m.r[c * 3 + 2], fmaf(g[1], m.r[c * 3 + 1], g[0] * m.r[c * 3]));
+                if (CF) gx[base + (size_t)c * n + i] = s; else gx[base + 3 * (size_t)i + c] = s;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) acc[c * 3 + j] = fmaf(v[c], g[j], acc[c * 3 + j]);
+            acc[9 + c] += g[c];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 12; ++q)
+        for (int o = 32; o > 0; o >>= 1) acc[q] += __shfl_down(acc[q], o);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int q = 0; q < 12; ++q) red[wave][q] = acc[q];
+    __syncthreads();
+    if (threadIdx.x < 12) {
+        float s = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+        partial[((size_t)b * gridDim.x + blockIdx.x) * 12 + threadIdx.x] = s;
+    }
+}
+
+__global__ void rigid_bwd_finalize_kernel(const float *__restrict__ partial, float *__restrict__ gR,
+                                          float *__restrict__ gt, int nblk, int transpose_r) {
+    const int b = blockIdx.x, q = threadIdx.x;
+    if (q >= 12) return;
+    double s = 0.0;
+    for (int k = 0; k < nblk; ++k) s += (double)partial[((size_t)b * nblk + k) * 12 + q];
+    if (q < 9) {
+        int i = q / 3, j = q % 3;  // gm[i][j]; m[i][j] = R[i][j] or R[j][i]
+        gR[b * 9 + (transpose_r ? j * 3 + i : i * 3 + j)] = (float)s;
+    } else {
+        gt[b * 3 + (q - 9)] = (float)s;
+    }
+}
+
+extern "C" int rrl_rigid_apply_bwd(const float *x, const float *R, const float *gy, float *gx,
+                                   float *gR, float *gt, float *partial, int B, int n,
+                                   int transpose_r, int channel_first, void *stream) {
+    if (!x || !R || !gy || !gR || !gt || !partial || B < 0 || n < 0) return RRL_E_ARG;
+    if (B == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const int nblk = rrl_rigid_bwd_blocks(n);
+    if (nblk > 0) {
+        dim3 grid((unsigned)nblk, (unsigned)B);
+        if (channel_first)
+            hipLaunchKernelGGL(rigid_bwd_kernel<true>, grid, dim3(256), 0, s, x, R, gy, gx, partial,
+                               n, transpose_r);
+        else
+            hipLaunchKernelGGL(rigid_bwd_kernel<false>, grid, dim3(256), 0, s, x, R, gy, gx,
+                               partial, n, transpose_r);
+        RRL_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(rigid_bwd_finalize_kernel, dim3((unsigned)B), dim3(64), 0, s, partial, gR, gt,
+                       nblk, transpose_r);
+    RRL_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// K7 Chamfer: nearest target of every query.  Lane = query point (registers), targets are
+// wave-uniform and stream through the scalar cache.  A (query tile, target chunk) workgroup
+// folds its partial result into a u64 key (dist bits << 32 | index) with atomicMin: smallest
+// distance, then smallest index == torch.min's first occurrence; order independent.
+// ---------------------------------------------------------------------------------------
+#define CH_CHUNK 1024
+
+__global__ __launch_bounds__(256) void chamfer_nn_kernel(const float *__restrict__ q,
+                                                         const float *__restrict__ tg,
+                                                         unsigned long long *__restrict__ best,
+                                                         int nq, int nt) {
+    const int b = blockIdx.z;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int j0 = blockIdx.y * CH_CHUNK, j1 = min(nt, j0 + CH_CHUNK);
+    const float *qp = q + ((size_t)b * nq + (i < nq ? i : 0)) * 3;
+    const float qx = qp[0], qy = qp[1], qz = qp[2];
+    kptr tp = (kptr)(uintptr_t)(tg + ((size_t)b * nt + j0) * 3);
+    float bd = INFINITY;
+    int bj = j0;
+    for (int j = j0; j < j1; ++j, tp += 3) {
+        // code/loss.py:51: sum((x - y)**2, -1); (a0 + a1) + a2, no FMA
+        float dx = qx - tp[0], dy = qy - tp[1], dz = qz - tp[2];
+        float s = dx * dx;
+        s = s + dy * dy;
+        s = s + dz * dz;
+        if (s < bd) { bd = s; bj = j; }
+    }
+    if (i < nq && j0 < j1) {
+        unsigned long long key = ((unsigned long long)__float_as_uint(bd) << 32) | (unsigned)bj;
+        atomicMin(&best[(size_t)b * nq + i], key);
+    }
+}
+
+__global__ __launch_bounds__(1024) void chamfer_mean_kernel(const unsigned long long *__restrict__ bx,
+                                                            const unsigned long long *__restrict__ by,
+                                                            float *__restrict__ value, long nx,
+                                                            long ny) {
+    __shared__ double red[1024];
+    double s = 0.0;
+    for (long i = threadIdx.x; i < nx; i += 1024) s += (double)__uint_as_float((unsigned)(bx[i] >> 32));
+    for (long i = threadIdx.x; i < ny; i += 1024) s += (double)__uint_as_float((unsigned)(by[i] >> 32));
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) value[0] = (float)(red[0] / (double)(nx + ny));
+}
+
+extern "C" int rrl_chamfer_fwd(const float *x, const float *y, uint64_t *best_x, uint64_t *best_y,
+                               float *value, int B, int N, int M, void *stream) {
+    if (!x || !y || !best_x || !best_y || !value || B < 0 || N < 0 || M < 0) return RRL_E_ARG;
+    if (B == 0 || N == 0 || M == 0) return RRL_E_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e;
+    if ((e = hipMemsetAsync(best_x, 0xff, sizeof(uint64_t) * (size_t)B * N, s)) != hipSuccess) return (int)e;
+    if ((e = hipMemsetAsync(best_y, 0xff, sizeof(uint64_t) * (size_t)B * M, s)) != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(chamfer_nn_kernel,
+                       dim3((unsigned)((N + 255) / 256), (unsigned)((M + CH_CHUNK - 1) / CH_CHUNK), (unsigned)B),
+                       dim3(256), 0, s, x, y, (unsigned long long *)best_x, N, M);
+    RRL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(chamfer_nn_kernel,
+                       dim3((unsigned)((M + 255) / 256), (unsigned)((N + CH_CHUNK - 1) / CH_CHUNK), (unsigned)B),
+                       dim3(256), 0, s, y, x, (unsigned long long *)best_y, M, N);
+    RRL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(chamfer_mean_kernel, dim3(1), dim3(1024), 0, s,
+                       (const unsigned long long *)best_x, (const unsigned long long *)best_y, value,
+                       (long)B * N, (long)B * M);
+    RRL_LAUNCH_CHECK();
+    return 0;
+}
+
+// d mean / d x_i: every minimum contributes 2 (x_i - y_j) / (B (N + M)) to its two end points
+__global__ __launch_bounds__(256) void chamfer_bwd_kernel(const float *__restrict__ x,
+                                                          const float *__restrict__ y,
+                                                          const unsigned long long *__restrict__ bx,
+                                                          const unsigned long long *__restrict__ by,
+                                                          const float *__restrict__ gval,
+                                                          float *__restrict__ gx,
+                                                          float *__restrict__ gy, int B, int N,
+                                                          int M) {
+    const int b = blockIdx.y;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= N + M) return;
+    int i, j;
+    if (t < N) { i = t; j = (int)(unsigned)bx[(size_t)b * N + i]; }
+    else { j = t - N; i = (int)(unsigned)by[(size_t)b * M + j]; }
+    const float sc = 2.0f * gval[0] / ((float)B * (float)(N + M));
+    const float *xp = x + ((size_t)b * N + i) * 3, *yp = y + ((size_t)b * M + j) * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float g = (xp[c] - yp[c]) * sc;
+        if (gx) atomicAdd(&gx[((size_t)b * N + i) * 3 + c], g);
+        if (gy) atomicAdd(&gy[((size_t)b * M + j) * 3 + c], -g);
+    }
+}
+
+extern "C" int rrl_chamfer_bwd(const float *x, const float *y, const uint64_t *best_x,
+                               const uint64_t *best_y, const float *grad_value, float *gx, float *gy,
+                               int B, int N, int M, void *stream) {
+    if (!x || !y || !best_x || !best_y || !grad_value || B < 0 || N < 0 || M < 0) return RRL_E_ARG;
+    if (B == 0 || N + M == 0) return 0;
+    hipLaunchKernelGGL(chamfer_bwd_kernel, dim3((unsigned)((N + M + 255) / 256), (unsigned)B), dim3(256),
+                       0, (hipStream_t)stream, x, y, (const unsigned long long *)best_x,
+                       (const unsigned long long *)best_y, grad_value, gx, gy, B, N, M);
+    RRL_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// K8 line sampler
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void aabb_kernel(const float *__restrict__ v,
+                                                    float *__restrict__ aabb, int n) {
+    __shared__ float red[16][6];
+    const int b = blockIdx.x;
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = threadIdx.x; i < n; i += 1024)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float f = v[((size_t)b * n + i) * 3 + c];
+            mn[c] = fminf(mn[c], f);
+            mx[c] = fmaxf(mx[c], f);
+        }
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+        for (int o = 32; o > 0; o >>= 1) {
+            mn[c] = fminf(mn[c], __shfl_down(mn[c], o));
+            mx[c] = fmaxf(mx[c], __shfl_down(mx[c], o));
+        }
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            red[threadIdx.x >> 6][c] = mn[c];
+            red[threadIdx.x >> 6][3 + c] = mx[c];
+        }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        float r = red[0][threadIdx.x];
+        for (int w = 1; w < 16; ++w)
+            r = threadIdx.x < 3 ? fminf(r, red[w][threadIdx.x]) : fmaxf(r, red[w][threadIdx.x]);
+        aabb[b * 6 + threadIdx.x] = r;
+    }
+}
+
+extern "C" int rrl_aabb(const float *v, float *aabb, int B, int n, void *stream) {
+    if (!v || !aabb || B < 0 || n <= 0) return RRL_E_ARG;
+    if (B == 0) return 0;
+    hipLaunchKernelGGL(aabb_kernel, dim3((unsigned)B), dim3(1024), 0, (hipStream_t)stream, v, aabb, n);
+    RRL_LAUNCH_CHECK();
+    return 0;
+}
+
+__device__ __forceinline__ void cross3(const float *a, const float *b, float *o) {
+    o[0] = a[1] * b[2] - a[2] * b[1];
+    o[1] = a[2] * b[0] - a[0] * b[2];
+    o[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+// box corner k of the reference's table (code/loss.py:325-351): corner 0 = max, 7 = min
+__device__ __forceinline__ void corner(const float *bb /*min3,max3*/, int k, float *o) {
+    o[0] = (k & 4) ? bb[0] : bb[3];
+    o[1] = (k & 2) ? bb[1] : bb[4];
+    o[2] = (k & 1) ? bb[2] : bb[5];
+}
+
+__constant__ int BOX_FACES[12][3] = {{2, 0, 6}, {0, 4, 6}, {5, 4, 0}, {5, 0, 1}, {6, 4, 5}, {5, 7, 6},
+                                     {3, 0, 2}, {1, 0, 3}, {3, 2, 6}, {6, 7, 3}, {5, 1, 3}, {3, 7, 5}};
+
+// Does the line cross >= 1 of the 12 box triangles by the reference's sub-area test
+// (code/loss.py:265-316)?  hit = all three sub-areas > 0 and their sum <= the triangle area.
+__device__ bool box_hit(const float *bb, const float *ln) {
+    bool any = false;
+    for (int f = 0; f < 12; ++f) {
+        float A[3], Bq[3], C[3];
+        corner(bb, BOX_FACES[f][0], A);
+        corner(bb, BOX_FACES[f][1], Bq);
+        corner(bb, BOX_FACES[f][2], C);
+        float e1[3] = {Bq[0] - A[0], Bq[1] - A[1], Bq[2] - A[2]};
+        float e2[3] = {C[0] - A[0], C[1] - A[1], C[2] - A[2]};
+        float nr[3];
+        cross3(e1, e2, nr);
+        float S = norm3(nr[0], nr[1], nr[2]);
+        float den = fmaxf(S, 1e-12f);  // F.normalize eps
+        float nh[3] = {nr[0] / den, nr[1] / den, nr[2] / den};
+        float num = nh[0] * (A[0] - ln[3]);
+        num = num + nh[1] * (A[1] - ln[4]);
+        num = num + nh[2] * (A[2] - ln[5]);
+        float dn = nh[0] * ln[0];
+        dn = dn + nh[1] * ln[1];
+        dn = dn + nh[2] * ln[2];
+        float tt = num / (dn + 1e-12f);
+        float I[3] = {tt * ln[0] + ln[3], tt * ln[1] + ln[4], tt * ln[2] + ln[5]};
+        float ia[3] = {I[0] - A[0], I[1] - A[1], I[2] - A[2]};
+        float ib[3] = {I[0] - Bq[0], I[1] - Bq[1], I[2] - Bq[2]};
+        float ic[3] = {I[0] - C[0], I[1] - C[1], I[2] - C[2]};
+        float c0[3], c1[3], c2[3];
+        cross3(ib, ic, c0);
+        cross3(ic, ia, c1);
+        cross3(ia, ib, c2);
+        float ba = norm3(c0[0], c0[1], c0[2]), bb2 = norm3(c1[0], c1[1], c1[2]),
+              bc = norm3(c2[0], c2[1], c2[2]);
+        any |= (ba > 0.0f) && (bb2 > 0.0f) && (bc > 0.0f) && (((ba + bb2) + bc) <= S);
+    }
+    return any;
+}
+
+// One 1024-lane workgroup per sample walks rounds x candidate tiles IN ORDER; accepted
+// candidates are compacted with a ballot/prefix scan so slot order == candidate order
+// (code/loss.py:365-381), overflow is truncated, unfilled rows stay zero.
+__global__ __launch_bounds__(1024) void sample_lines_kernel(
+    const float *__restrict__ rands, const float *__restrict__ r, const float *__restrict__ centers,
+    const float *__restrict__ aabb1, const float *__restrict__ aabb2, float *__restrict__ lines,
+    int32_t *__restrict__ filled, int B, int n, int rounds) {
+    __shared__ int wave_cnt[16];
+    __shared__ int s_base;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float rad = r[b];
+    float ctr[3], bb1[6], bb2[6];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) ctr[c] = centers[b * 3 + c];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        bb1[c] = aabb1 ? aabb1[b * 6 + c] : 0.0f;
+        bb2[c] = aabb2 ? aabb2[b * 6 + c] : 0.0f;
+    }
+    const bool filter = aabb1 != nullptr && aabb2 != nullptr;  // NULL boxes: keep every candidate
+    const float pi32 = 3.14159274101257324f;  // torch.pi of code/loss.py:9
+    int count = 0;                            // accepted so far (uniform across the block)
+    for (int rd = 0; rd < rounds; ++rd) {
+        if (count > n) continue;  // code/loss.py:368-369
+        const float *rr = rands + ((size_t)rd * 4 * B + b) * n;  // [rd][s][b][i]
+        const size_t sstride = (size_t)B * n;
+        for (int i0 = 0; i0 < n; i0 += 1024) {
+            const int i = i0 + tid;
+            bool ok = false;
+            float ln[6];
+            if (i < n) {
+                // code/loss.py:394-411
+                float al1 = (rr[i] * 2.0f) * pi32, v1 = rr[sstride + i] * 2.0f - 1.0f;
+                float al2 = (rr[2 * sstride + i] * 2.0f) * pi32, v2 = rr[3 * sstride + i] * 2.0f - 1.0f;
+                float s1 = sqrtf(1.0f - v1 * v1), s2 = sqrtf(1.0f - v2 * v2);
+                float q1[3] = {(rad * s1) * cosf(al1), (rad * sinf(al1)) * s1, rad * v1};
+                float q2[3] = {(rad * s2) * cosf(al2), (rad * sinf(al2)) * s2, rad * v2};
+                float d[3] = {q2[0] - q1[0], q2[1] - q1[1], q2[2] - q1[2]};
+                float den = fmaxf(norm3(d[0], d[1], d[2]), 1e-12f);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { ln[c] = d[c] / den; ln[3 + c] = q1[c] + ctr[c]; }
+                ok = !filter || (box_hit(bb1, ln) && box_hit(bb2, ln));
+            }
+            const unsigned long long mask = __ballot(ok);
+            if (lane == 0) wave_cnt[wave] = __popcll(mask);
+            __syncthreads();
+            if (tid == 0) {
+                int acc = 0;
+                for (int w = 0; w < 16; ++w) { int c = wave_cnt[w]; wave_cnt[w] = acc; acc += c; }
+                s_base = acc;
+            }
+            __syncthreads();
+            if (ok) {
+                int slot = count + wave_cnt[wave] + __popcll(mask & ((1ull << lane) - 1ull));
+                if (slot < n) {
+                    float *dst = lines + ((size_t)b * n + slot) * 6;
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) dst[c] = ln[c];
+                }
+            }
+            count += s_base;
+            __syncthreads();
+        }
+    }
+    for (int s = min(count, n) + tid; s < n; s += 1024) {
+        float *dst = lines + ((size_t)b * n + s) * 6;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) dst[c] = 0.0f;
+    }
+    if (tid == 0) filled[b] = count;
+}
+
+extern "C" int rrl_sample_lines(const float *rands, const float *r, const float *centers,
+                                const float *aabb1, const float *aabb2, float *lines,
+                                int32_t *filled, int B, int n, int rounds, void *stream) {
+    if (!rands || !r || !centers || !lines || !filled) return RRL_E_ARG;
+    if (B < 0 || n < 0 || rounds < 0) return RRL_E_ARG;
+    if (B == 0 || n == 0) return 0;
+    hipLaunchKernelGGL(sample_lines_kernel, dim3((unsigned)B), dim3(1024), 0, (hipStream_t)stream,
+                       rands, r, centers, aabb1, aabb2, lines, filled, B, n, rounds);
+    RRL_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" const char *rrl_version(void) { return "rrl_hip 0.1 (gfx950)"; }

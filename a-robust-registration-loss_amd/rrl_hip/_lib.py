@@ -1,0 +1,66 @@
+"""ctypes binding of librrl_hip.so (C ABI: include/rrl.h).
+
+There is NO fallback: if the library is missing, or no MI355X is visible, every op raises.
+"""
+import ctypes
+import os
+
+from .build import LIB
+
+_c = ctypes
+_P = _c.c_void_p
+_I = _c.c_int
+
+# name -> argtypes (all return int unless noted)
+_SIGS = {
+    "rrl_tri_prepare": [_P, _P, _I, _I, _P],
+    "rrl_loss_begin": [_P, _P, _P, _P, _P, _I, _I, _P],
+    "rrl_line_tri_scan": [_P] * 8 + [_I] * 6 + [_P],
+    "rrl_line_pair_dist": [_P] * 14 + [_I] * 9 + [_P],
+    "rrl_lower_median": [_P, _P, _P, _P, _I, _I, _I, _P],
+    "rrl_welsch_reduce_fwd": [_P, _P, _P, _P, _I, _I, _I, _P],
+    "rrl_loss_finalize": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "rrl_welsch_reduce_bwd": [_P] * 14 + [_I] * 5 + [_P],
+    "rrl_rigid_apply_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "rrl_rigid_bwd_blocks": [_I],
+    "rrl_set_scan_variant": [_I],
+    "rrl_rigid_apply_bwd": [_P] * 7 + [_I] * 4 + [_P],
+    "rrl_chamfer_fwd": [_P] * 5 + [_I] * 3 + [_P],
+    "rrl_chamfer_bwd": [_P] * 7 + [_I] * 3 + [_P],
+    "rrl_aabb": [_P, _P, _I, _I, _P],
+    "rrl_sample_lines": [_P] * 7 + [_I] * 3 + [_P],
+}
+EXPORTS = sorted(list(_SIGS) + ["rrl_version"])
+
+_lib = None
+
+
+class RRLError(RuntimeError):
+    pass
+
+
+def load():
+    """Load librrl_hip.so; raises RRLError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB):
+        raise RRLError(
+            f"{LIB} is missing: build it with `python __graft_entry__.py` (hipcc, gfx950). "
+            "This package has no CPU or PyTorch fallback.")
+    lib = ctypes.CDLL(LIB)
+    for name, args in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = _I
+    lib.rrl_version.restype = ctypes.c_char_p
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc == 0:
+        return
+    if rc < 0:
+        raise RRLError(f"{what}: argument error {rc} (see RRL_E_* in include/rrl.h)")
+    raise RRLError(f"{what}: HIP error {rc}")

@@ -1,0 +1,244 @@
+"""torch.autograd front-ends of the HIP kernels (device memory + streams are PyTorch's;
+all compute is librrl_hip.so).  No fallback path exists: CPU tensors are moved to the
+current GPU, and a missing library / missing GPU raises RRLError.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import RRLError, check
+
+SCAN_STRICT, SCAN_LAZY = 0, 1
+_MODES = {"strict": SCAN_STRICT, "lazy": SCAN_LAZY}
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise RRLError("no MI355X visible (torch.cuda.is_available() is False); "
+                       "this package has no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _prep(t, name, last=None):
+    """fp32, contiguous, on the GPU (callers pass slices / reshaped views)."""
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if last is not None and t.shape[-1] != last:
+        raise ValueError(f"{name}: last dimension must be {last}, got {tuple(t.shape)}")
+    dev = require_gpu()
+    return t.detach().to(device=dev, dtype=torch.float32).contiguous()
+
+
+class LossState:
+    """Device buffers of one loss evaluation (scan outputs, per-line sparse data, sums)."""
+
+    def __init__(self, B, N, M, L, G, dev):
+        i32, f32 = torch.int32, torch.float32
+        e = lambda *s, dtype=f32: torch.empty(*s, dtype=dtype, device=dev)  # noqa: E731
+        self.ptri1, self.ptri2 = e(B, N, 12), e(B, M, 12)
+        self.count1, self.count2 = e(B, L, dtype=i32), e(B, L, dtype=i32)
+        self.hit1, self.hit2 = e(B, L, 4, dtype=i32), e(B, L, 4, dtype=i32)
+        self.status = e(4, dtype=i32)
+        self.kj = e(B, L, dtype=torch.uint8)
+        self.hs1, self.hs2 = e(B, L, 4, dtype=i32), e(B, L, 4, dtype=i32)
+        self.w1, self.w2 = e(B, L, 4, 3), e(B, L, 4, 3)
+        self.D = e(B, L, 16)
+        self.bsum = e(B, 16, 2, dtype=torch.int64)
+        self.bcnt = e(B, 16, dtype=i32)
+        self.med, self.nval = e(G), e(G, dtype=i32)
+        self.loss, self.nbuckets = e(G), e(G, dtype=i32)
+
+
+def loss_forward_raw(tri1, tri2, line, rng=(1, 1, 5, 5), pool=False, mode="strict", chunk=0,
+                     scan_events=None):
+    """Runs K1'..K4 on already-prepared GPU tensors; returns the LossState.
+    scan_events: optional (start, stop) torch.cuda.Event pair recorded around the scan."""
+    lib = _lib.load()
+    B, N, _ = tri1.shape
+    M, L = tri2.shape[1], line.shape[1]
+    G = 1 if pool else B
+    s_m, s_n, e_m, e_n = (int(v) for v in rng)
+    if not (1 <= s_m and 1 <= s_n and e_m <= 5 and e_n <= 5):
+        raise ValueError("bucket range must lie within 1..4 (RRL_MAX_HITS), as every reference "
+                         "caller's (1, 1, 5, 5) does")
+    st = LossState(B, N, M, L, G, tri1.device)
+    s = _stream()
+    check(lib.rrl_tri_prepare(_p(tri1), _p(st.ptri1), B, N, s), "rrl_tri_prepare")
+    check(lib.rrl_tri_prepare(_p(tri2), _p(st.ptri2), B, M, s), "rrl_tri_prepare")
+    check(lib.rrl_loss_begin(_p(st.count1), _p(st.count2), _p(st.status), _p(st.bsum),
+                             _p(st.bcnt), B, L, s), "rrl_loss_begin")
+    if scan_events is not None:
+        scan_events[0].record()
+    check(lib.rrl_line_tri_scan(_p(st.ptri1), _p(st.ptri2), _p(line), _p(st.count1), _p(st.hit1),
+                                _p(st.count2), _p(st.hit2), _p(st.status), B, N, M, L,
+                                _MODES[mode], int(chunk), s), "rrl_line_tri_scan")
+    if scan_events is not None:
+        scan_events[1].record()
+    check(lib.rrl_line_pair_dist(_p(tri1), _p(tri2), _p(line), _p(st.count1), _p(st.hit1),
+                                 _p(st.count2), _p(st.hit2), _p(st.kj), _p(st.hs1), _p(st.hs2),
+                                 _p(st.w1), _p(st.w2), _p(st.D), _p(st.bcnt), B, N, M, L, s_m, s_n,
+                                 e_m, e_n, int(pool), s), "rrl_line_pair_dist")
+    check(lib.rrl_lower_median(_p(st.kj), _p(st.D), _p(st.med), _p(st.nval), B, L, int(pool), s),
+          "rrl_lower_median")
+    check(lib.rrl_welsch_reduce_fwd(_p(st.kj), _p(st.D), _p(st.med), _p(st.bsum), B, L, int(pool),
+                                    s), "rrl_welsch_reduce_fwd")
+    check(lib.rrl_loss_finalize(_p(st.bsum), _p(st.bcnt), _p(st.loss), _p(st.nbuckets), G, s_m,
+                                s_n, e_m, e_n, s), "rrl_loss_finalize")
+    return st
+
+
+class _IntersectionLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, points1, points2, line, rng, pool, mode, chunk, scan_events):
+        tri1, tri2 = _prep(points1, "points1", 9), _prep(points2, "points2", 9)
+        ln = _prep(line, "line", 6)
+        if tri1.dim() != 3 or tri2.dim() != 3 or ln.dim() != 3:
+            raise ValueError("Input is wrong: points1/points2/line must be 3-D (B, n, c)")
+        if not (tri1.shape[0] == tri2.shape[0] == ln.shape[0]):
+            raise ValueError("points1, points2 and line must share the batch dimension")
+        st = loss_forward_raw(tri1, tri2, ln, rng, pool, mode, chunk, scan_events)
+        ctx.st, ctx.tri1, ctx.tri2, ctx.pool = st, tri1, tri2, bool(pool)
+        ctx.in_devs = (points1.device, points2.device)
+        ctx.mark_non_differentiable(st.nbuckets, st.status)
+        return st.loss, st.nbuckets, st.status
+
+    @staticmethod
+    def backward(ctx, g_loss, _g1, _g2):
+        lib = _lib.load()
+        st, tri1, tri2 = ctx.st, ctx.tri1, ctx.tri2
+        B, N, _ = tri1.shape
+        M, L = tri2.shape[1], st.kj.shape[1]
+        g = g_loss.detach().to(device=tri1.device, dtype=torch.float32).contiguous()
+        g1 = torch.zeros_like(tri1)
+        g2 = torch.zeros_like(tri2) if ctx.needs_input_grad[1] else None
+        check(lib.rrl_welsch_reduce_bwd(_p(tri1), _p(tri2), _p(st.kj), _p(st.hs1), _p(st.hs2),
+                                        _p(st.w1), _p(st.w2), _p(st.D), _p(st.med), _p(st.bcnt),
+                                        _p(st.nbuckets), _p(g), _p(g1), _p(g2), B, N, M, L,
+                                        int(ctx.pool), _stream()), "rrl_welsch_reduce_bwd")
+        g1 = g1.to(ctx.in_devs[0]) if ctx.needs_input_grad[0] else None
+        if g2 is not None:
+            g2 = g2.to(ctx.in_devs[1])
+        return g1, g2, None, None, None, None, None, None
+
+
+def intersection_loss(points1, points2, line, rng=(1, 1, 5, 5), pool=False, mode="strict",
+                      chunk=0, scan_events=None):
+    """Batched loss: returns (loss[G], nbuckets[G], status[4]) on the GPU, G = 1 if pool else B.
+    Each sample is an independent loss (the semantics every reference caller obtains by
+    looping B=1 calls); pool=True reproduces the reference's own B>1 behaviour.
+    No host synchronisation happens here."""
+    return _IntersectionLoss.apply(points1, points2, line, tuple(rng), pool, mode, chunk,
+                                   scan_events)
+
+
+# ---------------------------------------------------------------------------------------
+class _RigidApply(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, R, t, transpose_r, channel_first):
+        xs = _prep(x, "x")
+        Rm, tv = _prep(R, "R"), _prep(t, "t")
+        B = Rm.shape[0]
+        n = xs.numel() // (3 * B)
+        y = torch.empty_like(xs)
+        check(_lib.load().rrl_rigid_apply_fwd(_p(xs), _p(Rm), _p(tv), _p(y), B, n,
+                                              int(transpose_r), int(channel_first), _stream()),
+              "rrl_rigid_apply_fwd")
+        ctx.save_for_backward(xs, Rm)
+        ctx.meta = (B, n, int(transpose_r), int(channel_first), x.device, R.device, t.device,
+                    R.shape, t.shape)
+        return y.to(x.device)
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _lib.load()
+        xs, Rm = ctx.saved_tensors
+        B, n, tr, cf, xdev, Rdev, tdev, Rshape, tshape = ctx.meta
+        g = gy.detach().to(device=xs.device, dtype=torch.float32).contiguous()
+        gx = torch.empty_like(xs) if ctx.needs_input_grad[0] else None
+        gR = torch.empty(B, 3, 3, device=xs.device)
+        gt = torch.empty(B, 3, device=xs.device)
+        nblk = lib.rrl_rigid_bwd_blocks(n)
+        partial = torch.empty(B, max(nblk, 1), 12, device=xs.device)
+        check(lib.rrl_rigid_apply_bwd(_p(xs), _p(Rm), _p(g), _p(gx), _p(gR), _p(gt), _p(partial),
+                                      B, n, tr, cf, _stream()), "rrl_rigid_apply_bwd")
+        return (gx.to(xdev) if gx is not None else None, gR.reshape(Rshape).to(Rdev),
+                gt.reshape(tshape).to(tdev), None, None)
+
+
+def rigid_apply(x, R, t, transpose_r=False, channel_first=False):
+    """y = x R + t (transpose_r=False) or y = x R^T + t; x is (B, n, 3) or (B, 3, n)
+    (channel_first); R (B,3,3), t (B,3).  Differentiable in x, R and t."""
+    R3 = R.reshape(-1, 3, 3)
+    B = R3.shape[0]
+    if x.numel() % (3 * B) != 0:
+        raise ValueError("x does not divide into B point sets")
+    return _RigidApply.apply(x, R3, t.reshape(B, 3), transpose_r, channel_first)
+
+
+# ---------------------------------------------------------------------------------------
+class _Chamfer(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y):
+        xs, ys = _prep(x, "points_x", 3), _prep(y, "points_y", 3)
+        if xs.dim() != 3 or ys.dim() != 3 or xs.shape[0] != ys.shape[0]:
+            raise ValueError("chamfer_dist expects (B, M, 3) and (B, N, 3)")
+        B, N, _ = xs.shape
+        M = ys.shape[1]
+        bx = torch.empty(B, N, dtype=torch.int64, device=xs.device)
+        by = torch.empty(B, M, dtype=torch.int64, device=xs.device)
+        val = torch.empty(1, device=xs.device)
+        check(_lib.load().rrl_chamfer_fwd(_p(xs), _p(ys), _p(bx), _p(by), _p(val), B, N, M,
+                                          _stream()), "rrl_chamfer_fwd")
+        ctx.save_for_backward(xs, ys, bx, by)
+        ctx.devs = (x.device, y.device)
+        return val.reshape(()).to(x.device)
+
+    @staticmethod
+    def backward(ctx, gval):
+        xs, ys, bx, by = ctx.saved_tensors
+        B, N, _ = xs.shape
+        M = ys.shape[1]
+        g = gval.detach().to(device=xs.device, dtype=torch.float32).reshape(1).contiguous()
+        gx = torch.zeros_like(xs) if ctx.needs_input_grad[0] else None
+        gy = torch.zeros_like(ys) if ctx.needs_input_grad[1] else None
+        check(_lib.load().rrl_chamfer_bwd(_p(xs), _p(ys), _p(bx), _p(by), _p(g), _p(gx), _p(gy), B,
+                                          N, M, _stream()), "rrl_chamfer_bwd")
+        return (gx.to(ctx.devs[0]) if gx is not None else None,
+                gy.to(ctx.devs[1]) if gy is not None else None)
+
+
+def chamfer(x, y):
+    return _Chamfer.apply(x, y)
+
+
+# ---------------------------------------------------------------------------------------
+def aabb(v):
+    """(B, n, 3) -> (B, 6) = min xyz, max xyz on the GPU."""
+    vs = _prep(v, "vertices", 3)
+    B, n, _ = vs.shape
+    out = torch.empty(B, 6, device=vs.device)
+    check(_lib.load().rrl_aabb(_p(vs), _p(out), B, n, _stream()), "rrl_aabb")
+    return out
+
+
+def sample_lines(rands, r, centers, aabb1, aabb2):
+    """rands (rounds, 4, B, n) uniform draws -> lines (B, n, 6), filled (B,) int32."""
+    rd = _prep(rands, "rands")
+    rounds, four, B, n = rd.shape
+    assert four == 4
+    rr = _prep(r, "r").reshape(B)
+    cc = _prep(centers, "centers").reshape(B, 3)
+    lines = torch.empty(B, n, 6, device=rd.device)
+    filled = torch.empty(B, dtype=torch.int32, device=rd.device)
+    check(_lib.load().rrl_sample_lines(_p(rd), _p(rr), _p(cc), _p(aabb1), _p(aabb2), _p(lines),
+                                       _p(filled), B, n, rounds, _stream()), "rrl_sample_lines")
+    return lines, filled

@@ -26,21 +26,13 @@ def _rotation(axis, deg):
 
 
 def knn_triangles(points, k=3):
-    """(n,3) float32 -> (n, 3*k) rows [P, nn1, nn2]; brute force in blocks (self is nn0)."""
-    p = np.asarray(points, np.float32)
-    n = p.shape[0]
-    out = np.empty((n, 3 * k), np.float32)
-    sq = np.sum(p.astype(np.float64) ** 2, axis=1)
-    step = 2048
-    for s in range(0, n, step):
-        blk = p[s:s + step].astype(np.float64)
-        d = sq[s:s + step, None] - 2.0 * blk @ p.astype(np.float64).T + sq[None, :]
-        d[np.arange(blk.shape[0]), np.arange(s, s + blk.shape[0])] = -1.0  # self first
-        idx = np.argpartition(d, k, axis=1)[:, :k]
-        order = np.argsort(np.take_along_axis(d, idx, 1), axis=1, kind="stable")
-        idx = np.take_along_axis(idx, order, 1)
-        out[s:s + step] = p[idx].reshape(blk.shape[0], 3 * k)
-    return out
+    """(n,3) float32 -> (n, 3*k) rows [P, nn1, nn2] (self is neighbour 0), the row layout of the
+    reference's Sample_neighs.  scipy cKDTree on the host: workload generation only."""
+    from scipy.spatial import cKDTree
+    p = np.ascontiguousarray(points, np.float32)
+    _, idx = cKDTree(p).query(p, k=k)
+    idx[:, 0] = np.arange(p.shape[0])  # duplicates: keep the point itself first
+    return p[idx].reshape(p.shape[0], 3 * k)
 
 
 def make_pair(seed, n, m, crop=False, noise=0.01, rot_deg=20.0):

@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric on MI355X: point-pairs/sec for the intersected-line loss
+fwd+bwd at B=8, N=M=4096 (L=10000 lines, the RPM call-site default), per GPU.
+
+One "step" = rigid apply of the source pseudo-triangles (K6) -> dense line<->triangle scan of
+both clouds (K1) -> per-line distances (K2) -> median (K3) -> Welsch reduce (K4) -> backward
+to points1.grad (K5) -> rigid-apply backward to (dR, dT) -> one fused all-reduce of
+[loss sum, valid count, sum dR, sum dT] over ranks.  Inputs are resident in HBM before the
+timed region; line sampling (K8) and Chamfer (K7) are timed separately and reported as extras.
+pairs per step = B * L * 3 * (N + M) per GPU; value = all ranks' pairs / max
+time over ranks.  Weak scaling: B=8 per GPU (config 3 of BASELINE.json is B=64 over 8 GPUs).
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "a-robust-registration-loss_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+FLOPS_PER_PAIR = 18          # 3 sub, 3+3+1 mul, 2+2+1 add, 1 sub, 1 sqrt-class
+VALU_PEAK_TFLOPS = 78.6      # 157.3 TFLOP/s fp32 vector peak counts FMA as 2 flops; this path is
+                             # contraction-off mul/add (one flop per lane-op) -> half of it
+HBM_PEAK_GBS = 8000.0
+
+
+def make_workload(B, N, M, L, rank, dev):
+    import loss as Lmod
+    from rrl_hip import synth
+    tri1, tri2, src, tar, rad, ctr = [], [], [], [], [], []
+    for b in range(B):
+        pr = synth.make_pair(1000 * rank + b, N, M)
+        tri1.append(pr["src_tri"]); tri2.append(pr["tar_tri"]); src.append(pr["src"])
+        tar.append(pr["tar"]); rad.append(pr["radius"]); ctr.append(pr["center"])
+    to = lambda a: torch.from_numpy(np.stack(a)).to(dev)  # noqa: E731
+    w = dict(tri1=to(tri1), tri2=to(tri2), src=to(src), tar=to(tar))
+    torch.manual_seed(1000 * rank)  # CPU seed selects the sampler's uniform streams
+    t0 = time.perf_counter()
+    w["lines"] = Lmod.Random_uniform_distribution_lines_batch_efficient_resample(
+        torch.tensor(rad).reshape(B, 1), torch.from_numpy(np.stack(ctr)), L, w["src"], w["tar"],
+        dev)
+    torch.cuda.synchronize()
+    w["sample_s"] = time.perf_counter() - t0
+    # per-sample "predicted" transforms (what RPM/DCP/FMR hand to the loss): small rotations
+    gen = torch.Generator().manual_seed(7 + rank)
+    from LieAlgebra import se3
+    R, T = se3.exp3(0.05 * torch.randn(B, 6, generator=gen))
+    w["R"], w["T"] = R.to(dev).requires_grad_(True), T.to(dev).requires_grad_(True)
+    return w
+
+
+def cpu_baseline(N, M, L, budget_s=12.0):
+    """The CPU oracle (C, OpenMP over lines, all host cores) on a bounded sample of the same
+    workload: whole samples of N=M=4096, L=10000, fwd+bwd, until ~budget_s seconds are spent."""
+    from oracle import rrl_oracle
+    from rrl_hip import synth
+    rrl_oracle.build()
+    cores = os.cpu_count() or 1
+    pr = synth.make_pair(500, N, M)
+    rands = synth.uniform_streams(0, 3, L)
+    lines = rrl_oracle.resample_lines(rands, pr["radius"], pr["center"], pr["src"], pr["tar"], L)
+    done, spent = 0, 0.0
+    while spent < budget_s:
+        t0 = time.perf_counter()
+        rrl_oracle.loss(pr["src_tri"], pr["tar_tri"], lines, want_grad=True)
+        spent += time.perf_counter() - t0
+        done += 1
+    pairs = done * L * 3 * (N + M)
+    return {"value": pairs / spent, "unit": "point-pairs/s", "cores": cores, "kind": "port",
+            "sample": f"{done} evaluation(s) of one N=M={N}, L={L} sample, loss fwd+bwd, oracle/rrl_oracle.c "
+                      f"with OpenMP on {cores} threads, {spent:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=8, help="samples per GPU")
+    ap.add_argument("--points", type=int, default=4096)
+    ap.add_argument("--lines", type=int, default=10000)
+    ap.add_argument("--mode", default=os.environ.get("RRL_SCAN_MODE", "strict"))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from rrl_hip import dist as rdist, ops
+    import loss as Lmod
+    rank, world, local = rdist.init_from_env()
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    B, N, M, L = args.batch, args.points, args.points, args.lines
+    w = make_workload(B, N, M, L, rank, dev)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+          for _ in range(args.steps)]
+
+    def step(i=None):
+        w["R"].grad = w["T"].grad = None
+        tri1 = ops.rigid_apply(w["tri1"].reshape(B, -1, 3), w["R"], w["T"], transpose_r=True)
+        loss, nb, _ = ops.intersection_loss(tri1.reshape(B, N, 9), w["tri2"], w["lines"],
+                                            (1, 1, 5, 5), mode=args.mode,
+                                            scan_events=ev[i] if i is not None else None)
+        loss.sum().backward()
+        gR, gT = w["R"].grad.sum(0), w["T"].grad.sum(0)
+        return rdist.reduce_loss(loss, nb > 0, (gR, gT))
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        total, nvalid = step(i)
+    fence()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    scan_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+
+    # extras, outside the timed region
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(5):
+        cd = Lmod.chamfer_dist(w["src"], w["tar"])
+    torch.cuda.synchronize()
+    chamfer_ms = (time.perf_counter() - t1) / 5 * 1e3
+
+    if rank == 0:
+        pairs_step = B * L * 3 * (N + M)
+        value = world * pairs_step * args.steps / dt
+        scan_s = scan_ms * 1e-3
+        alg_bytes = B * (N + M) * 48 + B * L * 24 + 2 * B * L * 4  # ptri + lines + counts
+        pmc = None
+        pmc_file = os.path.join(ROOT, "profiles", "scan_hbm_traffic.json")
+        if os.path.exists(pmc_file):
+            pmc = json.load(open(pmc_file)).get(f"B{B}_N{N}_L{L}_{args.mode}")
+        out = {
+            "metric": "point-pairs/sec for loss fwd+bwd at B=8, N=M=4096",
+            "value": value, "unit": "point-pairs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"B={B}/GPU, N=M={N} pseudo-triangles, L={L} lines, fp32 loss "
+                                   f"fwd+bwd (BASELINE.json configs[1]); scan mode {args.mode}",
+                       "global_batch": B * world, "parallelism": f"batch-shard dp{world}"},
+            "roofline": {
+                "bound": "valu", "kernel": "scan_kernel (K1, line<->triangle scan)",
+                "achieved": FLOPS_PER_PAIR * pairs_step / scan_s / 1e12, "peak": VALU_PEAK_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": FLOPS_PER_PAIR * pairs_step / scan_s / 1e12 / VALU_PEAK_TFLOPS,
+                "launch_ms": scan_ms,
+                "note": "fp32 VALU-bound (no FMA allowed: label parity); peak = 157.3/2 TFLOP/s",
+                "hbm": {"achieved": alg_bytes / scan_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": alg_bytes / scan_s / 1e9 / HBM_PEAK_GBS,
+                        "algorithmic_bytes": alg_bytes},
+                "traffic": pmc,
+            },
+            "extras": {"loss_sum": float(total), "valid": float(nvalid),
+                       "chamfer_ms": chamfer_ms, "chamfer_pairs_per_s": B * N * M / (chamfer_ms * 1e-3),
+                       "chamfer": float(cd), "line_sampling_s": w["sample_s"],
+                       "scan_share_of_step": scan_ms / (dt / args.steps * 1e3)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(N, M, L)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,364 @@
+"""Parity of the HIP path (through the C ABI, via the drop-in loss.py) against the golden
+vectors captured from the reference and against the CPU oracle on identical inputs.
+
+Tolerances (stated per BASELINE.json north_star: loss within 1e-5 rel):
+  labels / counts / hit lists / Chamfer minima      bit-exact
+  hit weights, D values                              bit-exact vs oracle, 2e-5 vs reference
+  loss                                               1e-5 rel vs reference and oracle
+  gradient (per-point sums, see merge_by_point)      1e-4 rel, 1e-5 of max abs
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, merge_by_point
+
+pytestmark = pytest.mark.gpu
+
+LOSS_FIXTURES = ["loss_synth_s0.npz", "loss_synth_s1.npz", "loss_demo_scale.npz",
+                 "loss_edge_zero_dup.npz"]
+
+
+@pytest.fixture(scope="module")
+def L():
+    import loss
+    from rrl_hip import _lib
+    _lib.load()  # fail loudly if the HIP library is missing
+    assert torch.cuda.is_available()
+    return loss
+
+
+def cu(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def run_state(tri1, tri2, lines, rng=(1, 1, 5, 5), pool=False, mode="strict", chunk=0):
+    from rrl_hip import ops
+    t1, t2, ln = cu(tri1), cu(tri2), cu(lines)
+    if t1.dim() == 2:
+        t1, t2, ln = t1[None], t2[None], ln[None]
+    st = ops.loss_forward_raw(t1, t2, ln, rng, pool, mode, chunk)
+    torch.cuda.synchronize()
+    return st
+
+
+# ---------------------------------------------------------------------------------- K1'
+def test_tri_prepare_exact(L, oracle):
+    g = load_golden("loss_demo_scale.npz")
+    st = run_state(g["tri1"], g["tri2"], g["lines"])
+    pt = st.ptri1[0].cpu().numpy()
+    np.testing.assert_array_equal(pt[:, :9], g["tri1"])
+    thr = oracle.tri_threshold(g["tri1"])
+    np.testing.assert_array_equal(pt[:, 10], thr)
+    # thr2 is the smallest float whose correctly rounded sqrt reaches thr
+    thr2 = pt[:, 9]
+    below = np.nextafter(thr2, np.float32(0), dtype=np.float32)
+    assert np.all(np.sqrt(thr2) >= thr) and np.all(np.sqrt(below) < thr)
+
+
+# ---------------------------------------------------------------------------------- K1
+@pytest.mark.parametrize("name", LOSS_FIXTURES)
+@pytest.mark.parametrize("mode", ["strict", "lazy"])
+def test_scan_counts_and_hits(L, oracle, name, mode):
+    g = load_golden(name)
+    st = run_state(g["tri1"], g["tri2"], g["lines"], mode=mode)
+    assert int(st.status[0]) == 0
+    for tag, cnt, hit in (("1", st.count1, st.hit1), ("2", st.count2, st.hit2)):
+        cnt = cnt[0].cpu().numpy()
+        hit = hit[0].cpu().numpy()
+        np.testing.assert_array_equal(cnt, g["count" + tag])  # vs the reference
+        o = oracle.scan(g["tri" + tag], g["lines"], cap=8)
+        for l in np.nonzero((cnt > 0) & (cnt <= 4))[0]:
+            assert sorted(hit[l, :cnt[l]].tolist()) == o["hit_idx"][l, :cnt[l]].tolist()
+
+
+@pytest.mark.parametrize("variant", [1, 2, 4])
+@pytest.mark.parametrize("chunk", [0, 64, 1000])
+def test_scan_variants_identical(L, variant, chunk):
+    from rrl_hip import _lib
+    g = load_golden("loss_synth_s1.npz")
+    lib = _lib.load()
+    try:
+        assert lib.rrl_set_scan_variant(variant) == 0
+        st = run_state(g["tri1"], g["tri2"], g["lines"], chunk=chunk)
+        np.testing.assert_array_equal(st.count1[0].cpu().numpy(), g["count1"])
+        np.testing.assert_array_equal(st.count2[0].cpu().numpy(), g["count2"])
+        np.testing.assert_allclose(st.loss.cpu().numpy()[0], g["r0_loss"], rtol=1e-5)
+    finally:
+        lib.rrl_set_scan_variant(2)
+
+
+# ---------------------------------------------------------------------------------- K2..K4
+@pytest.mark.parametrize("name", LOSS_FIXTURES)
+def test_sparse_stage_vs_oracle(L, oracle, name):
+    g = load_golden(name)
+    for i, rng in enumerate(g["ranges"]):
+        rng = tuple(int(v) for v in rng)
+        st = run_state(g["tri1"], g["tri2"], g["lines"], rng)
+        kj = st.kj[0].cpu().numpy()
+        D = st.D[0].cpu().numpy()
+        k, j = kj & 15, kj >> 4
+        # D values in the reference's concatenation order: bucket-major, then line
+        mine = []
+        for kk in range(rng[0], rng[2]):
+            for jj in range(rng[1], rng[3]):
+                for l in np.nonzero((k == kk) & (j == jj))[0]:
+                    mine.append(D[l, :kk * jj])
+        mine = np.concatenate(mine)
+        o = oracle.loss(g["tri1"], g["tri2"], g["lines"], rng=rng, want_D=True)
+        np.testing.assert_array_equal(mine, o["D"])  # same arithmetic, same bits
+        np.testing.assert_allclose(mine, g[f"r{i}_D"], rtol=2e-5, atol=1e-9)
+        assert float(st.med[0]) == float(o["median"])
+        assert int(st.nval[0]) == o["n_values"] and int(st.nbuckets[0]) == o["n_buckets"]
+        np.testing.assert_allclose(float(st.loss[0]), o["loss"], rtol=2e-6)
+        np.testing.assert_allclose(float(st.loss[0]), g[f"r{i}_loss"], rtol=1e-5)
+
+
+# ---------------------------------------------------------------------------------- W + G
+@pytest.mark.parametrize("name", LOSS_FIXTURES)
+def test_public_loss_and_gradient(L, oracle, name):
+    g = load_golden(name)
+    for i, rng in enumerate(g["ranges"]):
+        p1 = cu(g["tri1"])[None].requires_grad_(True)
+        out = L.cal_loss_intersection_batch_whole_median_pts_lines(
+            *[int(v) for v in rng], p1, cu(g["tri2"])[None], cu(g["lines"])[None], "cuda")
+        assert out.shape == (1,) and out.dtype == torch.float32 and out.is_cuda
+        np.testing.assert_allclose(out.item(), g[f"r{i}_loss"], rtol=1e-5)
+        (3.0 * out).backward()
+        mine = merge_by_point(g["tri1"], p1.grad[0].cpu().numpy() / 3.0)
+        ref = merge_by_point(g["tri1"], g[f"r{i}_grad1"])
+        np.testing.assert_allclose(mine, ref, rtol=1e-4, atol=1e-5 * np.abs(ref).max())
+        o = oracle.loss(g["tri1"], g["tri2"], g["lines"], rng=tuple(int(v) for v in rng))
+        om = merge_by_point(g["tri1"], o["grad1"])
+        np.testing.assert_allclose(mine, om, rtol=1e-4, atol=1e-6 * np.abs(om).max())
+
+
+def test_gradient_wrt_target(L, oracle):
+    g = load_golden("loss_synth_s0.npz")
+    p2 = cu(g["tri2"])[None].requires_grad_(True)
+    out = L.cal_loss_intersection_batch_whole_median_pts_lines(
+        1, 1, 5, 5, cu(g["tri1"])[None], p2, cu(g["lines"])[None], "cuda")
+    out.backward()
+    o = oracle.loss(g["tri1"], g["tri2"], g["lines"], want_grad2=True)
+    mine, om = merge_by_point(g["tri2"], p2.grad[0].cpu().numpy()), merge_by_point(g["tri2"], o["grad2"])
+    np.testing.assert_allclose(mine, om, rtol=1e-4, atol=1e-6 * np.abs(om).max())
+
+
+def test_cpu_inputs_and_result_device(L):
+    """Callers may hand CPU tensors / non-contiguous slices and ask for the result on 'cpu'."""
+    g = load_golden("loss_synth_s1.npz")
+    big = torch.from_numpy(np.stack([g["tri1"], g["tri1"]]))
+    p1 = big[1:2].clone().requires_grad_(True)
+    out = L.cal_loss_intersection_batch_whole_median_pts_lines(
+        1, 1, 5, 5, p1, torch.from_numpy(g["tri2"])[None], torch.from_numpy(g["lines"])[None], "cpu")
+    assert out.device.type == "cpu"
+    np.testing.assert_allclose(out.item(), g["r0_loss"], rtol=1e-5)
+    out.backward()
+    assert p1.grad is not None and p1.grad.device.type == "cpu" and p1.grad.abs().sum() > 0
+
+
+def test_empty_returns_none(L):
+    g = load_golden("loss_edge_allmiss.npz")
+    out = L.cal_loss_intersection_batch_whole_median_pts_lines(
+        1, 1, 5, 5, cu(g["tri1"])[None], cu(g["tri2"])[None], cu(g["lines"])[None], "cuda")
+    assert out is None
+
+
+def test_nan_raises(L):
+    g = load_golden("loss_demo_scale.npz")
+    bad = g["lines"].copy()
+    bad[:, :3] *= 3.0  # non-unit directions -> sqrt of a negative number in the reference
+    with pytest.raises(ValueError, match="NaN"):
+        L.cal_loss_intersection_batch_whole_median_pts_lines(
+            1, 1, 5, 5, cu(g["tri1"])[None], cu(g["tri2"])[None], cu(bad)[None], "cuda")
+
+
+def test_bad_rank_and_range(L):
+    g = load_golden("loss_edge_allmiss.npz")
+    with pytest.raises(ValueError):
+        L.cal_loss_intersection_batch_whole_median_pts_lines(
+            1, 1, 5, 5, cu(g["tri1"]), cu(g["tri2"])[None], cu(g["lines"])[None], "cuda")
+    with pytest.raises(ValueError):
+        L.cal_loss_intersection_batch_whole_median_pts_lines(
+            1, 1, 6, 5, cu(g["tri1"])[None], cu(g["tri2"])[None], cu(g["lines"])[None], "cuda")
+
+
+def test_b2_pooling_quirk(L):
+    """B > 1 through the reference signature pools lines and uses the last sample's median."""
+    g = load_golden("loss_b2_quirk.npz")
+    p1 = cu(g["tri1"]).requires_grad_(True)
+    out = L.cal_loss_intersection_batch_whole_median_pts_lines(
+        1, 1, 5, 5, p1, cu(g["tri2"]), cu(g["lines"]), "cuda")
+    np.testing.assert_allclose(out.item(), g["loss"], rtol=1e-5)
+    out.backward()
+    for b in range(2):
+        mine = merge_by_point(g["tri1"][b], p1.grad[b].cpu().numpy())
+        ref = merge_by_point(g["tri1"][b], g["grad1"][b])
+        np.testing.assert_allclose(mine, ref, rtol=1e-4, atol=1e-5 * np.abs(ref).max())
+
+
+def test_batched_equals_per_sample(L):
+    """Independent-sample semantics: batch result == B single calls, bit for bit."""
+    g = load_golden("loss_b2_quirk.npz")
+    p1, p2, ln = cu(g["tri1"]), cu(g["tri2"]), cu(g["lines"])
+    loss, valid = L.batched_intersection_loss(p1, p2, ln)
+    assert bool(valid.all())
+    for b in range(2):
+        one = L.cal_loss_intersection_batch_whole_median_pts_lines(
+            1, 1, 5, 5, p1[b:b + 1], p2[b:b + 1], ln[b:b + 1], "cuda")
+        assert one.item() == loss[b].item()
+
+
+def test_line_permutation_invariance(L):
+    """Fixed-point bucket sums and the radix-select median are order independent: permuting
+    the lines must not change a single bit of the loss."""
+    g = load_golden("loss_synth_s0.npz")
+    perm = np.random.default_rng(0).permutation(len(g["lines"]))
+    a = run_state(g["tri1"], g["tri2"], g["lines"])
+    b = run_state(g["tri1"], g["tri2"], g["lines"][perm])
+    assert a.loss[0].item() == b.loss[0].item() and a.med[0].item() == b.med[0].item()
+
+
+# ---------------------------------------------------------------------------------- full size
+def test_full_size_sample_vs_oracle(L, oracle):
+    """One BASELINE.json config-2 sample (N=M=4096, L=10000) against the oracle: counts exact,
+    loss 2e-6, plus strict == lazy and batch invariance at B=3."""
+    from rrl_hip import synth
+    pr = synth.make_pair(0, 4096, 4096)
+    rands = synth.uniform_streams(0, 10, 10000)
+    lines = oracle.resample_lines(rands, pr["radius"], pr["center"], pr["src"], pr["tar"], 10000)
+    st = run_state(pr["src_tri"], pr["tar_tri"], lines)
+    o1 = oracle.scan(pr["src_tri"], lines, cap=4)
+    o2 = oracle.scan(pr["tar_tri"], lines, cap=4)
+    np.testing.assert_array_equal(st.count1[0].cpu().numpy(), o1["count"])
+    np.testing.assert_array_equal(st.count2[0].cpu().numpy(), o2["count"])
+    o = oracle.loss(pr["src_tri"], pr["tar_tri"], lines)
+    assert o["n_selected"] > 300
+    np.testing.assert_allclose(float(st.loss[0]), o["loss"], rtol=2e-6)
+    lz = run_state(pr["src_tri"], pr["tar_tri"], lines, mode="lazy")
+    assert float(lz.loss[0]) == float(st.loss[0])
+    t1 = np.stack([pr["src_tri"]] * 3)
+    t1[1] += 0.3  # a different middle sample must not disturb its neighbours
+    bt = run_state(t1, np.stack([pr["tar_tri"]] * 3), np.stack([lines] * 3))
+    assert float(bt.loss[0]) == float(st.loss[0]) == float(bt.loss[2])
+    assert float(bt.loss[1]) != float(st.loss[0])
+
+
+# ---------------------------------------------------------------------------------- K7
+def test_chamfer(L, oracle):
+    g = load_golden("chamfer.npz")
+    x = cu(g["x"]).requires_grad_(True)
+    val = L.chamfer_dist(x, cu(g["y"]))
+    np.testing.assert_allclose(val.item(), g["value"], rtol=1e-6)
+    val.backward()
+    np.testing.assert_allclose(x.grad.cpu().numpy(), g["grad_x"], rtol=1e-5, atol=1e-8)
+
+
+def test_chamfer_minima_bit_exact(L, oracle):
+    from rrl_hip import ops, _lib
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((1, 1500, 3)).astype(np.float32)
+    y = rng.standard_normal((1, 2300, 3)).astype(np.float32)
+    y[0, 7] = y[0, 3]  # duplicate target: first occurrence must win
+    xs, ys = cu(x), cu(y)
+    bx = torch.empty(1, 1500, dtype=torch.int64, device="cuda")
+    by = torch.empty(1, 2300, dtype=torch.int64, device="cuda")
+    val = torch.empty(1, device="cuda")
+    rc = _lib.load().rrl_chamfer_fwd(ops._p(xs), ops._p(ys), ops._p(bx), ops._p(by), ops._p(val),
+                                     1, 1500, 2300, ops._stream())
+    assert rc == 0
+    mx, ax, my, ay = oracle.chamfer_parts(x[0], y[0])
+    kx, ky = bx[0].cpu().numpy().view(np.uint64), by[0].cpu().numpy().view(np.uint64)
+    np.testing.assert_array_equal((kx >> np.uint64(32)).astype(np.uint32).view(np.float32), mx)
+    np.testing.assert_array_equal((kx & np.uint64(0xffffffff)).astype(np.int32), ax)
+    np.testing.assert_array_equal((ky >> np.uint64(32)).astype(np.uint32).view(np.float32), my)
+    np.testing.assert_array_equal((ky & np.uint64(0xffffffff)).astype(np.int32), ay)
+
+
+# ---------------------------------------------------------------------------------- K6 + R
+def test_reconstruction_point(L):
+    g = load_golden("reconstruction_point.npz")
+    rec = L.Reconstruction_point()
+    assert list(rec.state_dict().keys()) == ["parameters_"]
+    with torch.no_grad():
+        rec.parameters_.copy_(torch.from_numpy(g["xi"]))
+    rec = rec.cuda()
+    pts, tri = rec(cu(g["src"]), cu(g["src_tri"]).reshape(1, -1, 3))
+    assert pts.shape == g["out_pts"].shape and tri.shape == g["out_tri"].shape
+    np.testing.assert_allclose(pts.detach().cpu().numpy(), g["out_pts"], atol=2e-6)
+    np.testing.assert_allclose(tri.detach().cpu().numpy(), g["out_tri"], atol=2e-6)
+    ((pts * cu(g["g_pts"])).sum() + (tri * cu(g["g_tri"])).sum()).backward()
+    np.testing.assert_allclose(rec.parameters_.grad.cpu().numpy(), g["grad_xi"], rtol=2e-4,
+                               atol=2e-4)
+
+
+@pytest.mark.parametrize("transpose_r", [False, True])
+@pytest.mark.parametrize("channel_first", [False, True])
+def test_rigid_apply_layouts(L, transpose_r, channel_first):
+    from rrl_hip import ops
+    gen = torch.Generator().manual_seed(3)
+    B, n = 3, 1000
+    x = torch.randn(B, n, 3, generator=gen, dtype=torch.float64)
+    R = torch.linalg.qr(torch.randn(B, 3, 3, generator=gen, dtype=torch.float64))[0]
+    t = torch.randn(B, 3, generator=gen, dtype=torch.float64)
+    gy = torch.randn(B, n, 3, generator=gen, dtype=torch.float64)
+    xr, Rr, tr = (v.clone().requires_grad_(True) for v in (x, R, t))
+    yr = xr @ (Rr.transpose(1, 2) if transpose_r else Rr) + tr[:, None, :]
+    (yr * gy).sum().backward()
+    xin = x.float().cuda()
+    gin = gy.float().cuda()
+    if channel_first:
+        xin, gin = xin.transpose(1, 2).contiguous(), gin.transpose(1, 2).contiguous()
+    xin.requires_grad_(True)
+    Rg, tg = R.float().cuda().requires_grad_(True), t.float().cuda().requires_grad_(True)
+    y = ops.rigid_apply(xin, Rg, tg, transpose_r=transpose_r, channel_first=channel_first)
+    (y * gin).sum().backward()
+    yy = y.transpose(1, 2) if channel_first else y
+    gxx = xin.grad.transpose(1, 2) if channel_first else xin.grad
+    np.testing.assert_allclose(yy.detach().cpu().numpy(), yr.detach().numpy(), atol=2e-6)
+    np.testing.assert_allclose(gxx.cpu().numpy(), xr.grad.numpy(), atol=2e-6)
+    np.testing.assert_allclose(Rg.grad.cpu().numpy(), Rr.grad.numpy(), rtol=1e-4, atol=1e-3)
+    np.testing.assert_allclose(tg.grad.cpu().numpy(), tr.grad.numpy(), rtol=1e-4, atol=1e-3)
+
+
+def test_utils_transform_point_cloud(L):
+    import utils
+    gen = torch.Generator().manual_seed(4)
+    x = torch.randn(2, 3, 500, generator=gen)
+    R = torch.linalg.qr(torch.randn(2, 3, 3, generator=gen))[0]
+    t = torch.randn(2, 3, generator=gen)
+    y = utils.transform_point_cloud(x.cuda(), R.cuda(), t.cuda())
+    ref = torch.matmul(R.double(), x.double()) + t.double().unsqueeze(2)
+    np.testing.assert_allclose(y.cpu().numpy(), ref.numpy(), atol=2e-6)
+
+
+# ---------------------------------------------------------------------------------- K8
+def test_sampler(L, oracle):
+    g = load_golden("sampler.npz")
+    n = g["cand0"].shape[0]
+    torch.manual_seed(int(g["seed"]))
+    cand = L.Random_uniform_distribution_lines_batch_efficient(
+        torch.tensor([[float(g["radius"])]]), torch.from_numpy(g["center"]).reshape(1, 3), n, "cuda")
+    np.testing.assert_allclose(cand[0].cpu().numpy(), g["cand0"], atol=2e-5)
+    np.testing.assert_array_equal(L.generate_bbox(cu(g["src"])[None])[0].numpy(), g["bbox1"])
+    torch.manual_seed(int(g["seed"]))
+    final = L.Random_uniform_distribution_lines_batch_efficient_resample(
+        torch.tensor([[float(g["radius"])]]), torch.from_numpy(g["center"]).reshape(1, 3), n,
+        cu(g["src"])[None], cu(g["tar"])[None], "cuda")[0].cpu().numpy()
+    assert final.shape == (n, 6)
+    mine = oracle.resample_lines(g["rands"], g["radius"], g["center"], g["src"], g["tar"], n)
+    # same candidates in the same order as the oracle wherever both accepted the same set
+    nf = int((np.abs(final).sum(1) > 0).sum())
+    nm = int((np.abs(mine).sum(1) > 0).sum())
+    nr = int((np.abs(g["final"]).sum(1) > 0).sum())
+    assert abs(nf - nm) <= 20 and abs(nf - nr) <= 40
+    d = np.linalg.norm(final[:nf, :3], axis=1)
+    np.testing.assert_allclose(d, 1.0, atol=1e-5)  # unit directions
+    # every kept line is one of the candidates, in candidate order
+    torch.manual_seed(int(g["seed"]))
+    big = L.Random_uniform_distribution_lines_batch_efficient_resample(
+        torch.tensor([[4 * float(g["radius"])]]), torch.from_numpy(g["center"]).reshape(1, 3), n,
+        cu(g["src"])[None], cu(g["tar"])[None], "cuda")[0].cpu().numpy()
+    nb = int((np.abs(big).sum(1) > 0).sum())
+    assert 0 < nb < n and not np.any(big[nb:])  # unfilled rows stay zero at the tail
+    assert abs(nb - int((np.abs(g["final_big"]).sum(1) > 0).sum())) <= 15

@@ -1,0 +1,132 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/rrl.h declares,
+host logic (LieAlgebra, utils, synth), and loud failure without a GPU.  No compute calls."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, load_golden
+
+
+@pytest.fixture(scope="module")
+def libpath():
+    from rrl_hip import build
+    return build.build_lib()  # hipcc cross-compiles gfx950 without a GPU
+
+
+def test_abi_exports_match_header(libpath):
+    header = open(os.path.join(ROOT, "include", "rrl.h")).read()
+    declared = sorted(set(re.findall(r"\b(rrl_[a-z0-9_]+)\s*\(", header)))
+    assert len(declared) >= 17
+    lib = ctypes.CDLL(libpath)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/rrl.h but not exported"
+    from rrl_hip import _lib
+    assert sorted(_lib.EXPORTS) == declared
+    lib.rrl_version.restype = ctypes.c_char_p
+    assert b"gfx950" in lib.rrl_version()
+
+
+def test_abi_argument_errors(libpath):
+    """Argument validation happens on the host before any HIP call."""
+    from rrl_hip import _lib
+    lib = _lib.load()
+    assert lib.rrl_tri_prepare(None, None, 1, 1, None) == -1
+    assert lib.rrl_set_scan_variant(3) == -1
+    assert lib.rrl_rigid_bwd_blocks(5000) == 3
+    assert lib.rrl_loss_finalize(None, None, None, None, 1, 1, 1, 5, 5, None) == -1
+
+
+def test_no_gpu_fails_loudly():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import loss
+    from rrl_hip import RRLError
+    with pytest.raises(RRLError, match="no CPU fallback"):
+        loss.chamfer_dist(torch.zeros(1, 4, 3), torch.zeros(1, 5, 3))
+    with pytest.raises(RRLError):
+        loss.cal_loss_intersection_batch_whole_median_pts_lines(
+            1, 1, 5, 5, torch.zeros(1, 4, 9), torch.zeros(1, 4, 9), torch.zeros(1, 8, 6))
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "a-robust-registration-loss_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "rrl_oracle" not in text and "import oracle" not in text, f
+
+
+def test_lie_algebra_vs_reference():
+    from LieAlgebra import se3, so3
+    g = load_golden("se3_exp_log.npz")
+    xi = torch.from_numpy(g["xi"])
+    R, p = se3.exp3(xi)
+    np.testing.assert_allclose(R.numpy(), g["R"], atol=1e-7)
+    np.testing.assert_allclose(p.numpy(), g["p"], atol=1e-7)
+    np.testing.assert_allclose(se3.exp(xi).numpy(), g["g"], atol=1e-7)
+    np.testing.assert_allclose(se3.log(torch.from_numpy(g["g"])).numpy(), g["log_of_exp"], atol=1e-6)
+    # log(exp(xi)) == xi away from the pi branch
+    np.testing.assert_allclose(se3.log(se3.exp(xi[:5])).numpy(), g["xi"][:5], atol=2e-5)
+    # finite gradient at the identity (the reference's norm() gives NaN there)
+    x = torch.zeros(6, requires_grad=True)
+    R, p = se3.exp3(x)
+    (R.sum() + p.sum()).backward()
+    assert torch.isfinite(x.grad).all()
+    np.testing.assert_allclose(so3.vec(so3.mat(xi[:, :3])).numpy(), g["xi"][:, :3])
+    g4 = se3.exp(xi)
+    eye = g4 @ se3.inverse(g4)
+    np.testing.assert_allclose(eye.numpy(), np.tile(np.eye(4, dtype=np.float32), (6, 1, 1)), atol=2e-6)
+
+
+def test_exp3_gradient_matches_autograd_of_reference_formula():
+    from LieAlgebra import se3
+    g = load_golden("reconstruction_point.npz")
+    xi = torch.from_numpy(g["xi"]).requires_grad_(True)
+    R, T = se3.exp3(xi)
+    pts = torch.from_numpy(g["src"]) @ R[0] + T
+    tri = torch.from_numpy(g["src_tri"]).reshape(-1, 3) @ R[0] + T
+    ((pts * torch.from_numpy(g["g_pts"])).sum()
+     + (tri.reshape(-1, 9) * torch.from_numpy(g["g_tri"])).sum()).backward()
+    np.testing.assert_allclose(xi.grad.numpy(), g["grad_xi"], rtol=1e-4, atol=1e-4)
+
+
+def test_utils_host_helpers(tmp_path):
+    import utils
+    d = {"a": torch.zeros(2), "b": 3}
+    utils.dict_all_to_device(d, "cpu")
+    assert d["b"] == 3 and d["a"].device.type == "cpu"
+    utils.Dict2txt_json(str(tmp_path / "x.json"), {"k": 1.5}, file_type="json")
+    assert open(tmp_path / "x.json").read() == '{"k": 1.5}'
+    utils.Dict2txt_json(str(tmp_path / "x.txt"), {"k": 1.5, "j": 2})
+    assert open(tmp_path / "x.txt").read() == "k:1.5\nj:2\n"
+    utils.mkdir_ifnotexists(str(tmp_path / "sub"))
+    assert os.path.isdir(tmp_path / "sub")
+    v = torch.arange(24.0).reshape(1, 8, 3)
+    f = torch.tensor([[[2, 0, 6], [5, 7, 6]]])
+    fv = utils.makefacevertices(v, f)
+    assert fv.shape == (1, 2, 9)
+    np.testing.assert_array_equal(fv[0, 0].numpy(), np.concatenate([v[0, 2], v[0, 0], v[0, 6]]))
+    q = torch.tensor([[0.0, 0.0, np.sin(0.25), np.cos(0.25)]])
+    np.testing.assert_allclose(utils.npmat2euler(utils.quat2mat(q).numpy())[0],
+                               [np.rad2deg(0.5), 0, 0], atol=1e-4)
+
+
+def test_synth_is_deterministic_and_well_formed():
+    from rrl_hip import synth
+    a, b = synth.make_pair(3, 200, 150), synth.make_pair(3, 200, 150)
+    for k in a:
+        np.testing.assert_array_equal(a[k], b[k])
+    assert a["src_tri"].shape == (200, 9) and a["tar_tri"].shape == (150, 9)
+    np.testing.assert_array_equal(a["src_tri"][:, :3], a["src"])  # P0 is the point itself
+    d1 = np.linalg.norm(a["src_tri"][:, 3:6] - a["src"], axis=1)
+    d2 = np.linalg.norm(a["src_tri"][:, 6:9] - a["src"], axis=1)
+    assert np.all(d1 <= d2 + 1e-7) and np.all(d1 > 0)
+    c = synth.make_pair(4, 256, 128, crop=True)
+    assert c["tar"].shape == (128, 3)
+    r = synth.uniform_streams(5, 2, 7)
+    assert r.shape == (2, 4, 7) and 0 <= r.min() and r.max() < 1
