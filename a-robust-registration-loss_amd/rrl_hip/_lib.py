@@ -5,6 +5,9 @@ There is NO fallback: if the library is missing, or no MI355X is visible, every 
 import ctypes
 import os
 
+import torch  # noqa: F401  -- FIRST: librrl_hip.so must bind to the libamdhip64 PyTorch loaded,
+#                              or its streams / device pointers belong to another HIP runtime
+
 from .build import LIB
 
 _c = ctypes
