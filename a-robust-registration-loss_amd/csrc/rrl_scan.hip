@@ -2,66 +2,99 @@
 // and K1': prepared triangles (code/loss.py:94-110).
 //
 // Decomposition (gfx950, 64-wide waves):
-//   lane  = R lines held in VGPRs (R = 2 -> one packed pair: v_pk_mul_f32 / v_pk_add_f32)
-//   wave  = walks a chunk of triangles; a triangle is WAVE-UNIFORM, so its 12 floats
-//           arrive through the scalar cache (s_load_dwordx8 + x4) into SGPRs and cost no
-//           VGPRs, no LDS and no vector-memory issue slots
+//   lane  = R lines held in VGPRs, two per register pair (v_pk_mul_f32 / v_pk_add_f32)
+//   wave  = walks a chunk of triangles; a triangle is WAVE-UNIFORM, so its 10 floats arrive
+//           through the scalar cache (s_load_dwordx8 + x2) into SGPRs and cost no VGPRs, no
+//           LDS and no vector-memory issue slots
 //   block = 256 lanes (4 waves) x `chunk` triangles; grid = line tiles x chunks x (2 clouds x B)
-// Per (line, triangle): 48 fp32 VALU ops for the three squared distances + 3 integer ops
-// (v_max3_u32, v_cmp_lt_u32, v_max_u32).  A hit is "all three x_k < thr2" which, for
+//
+// strict loop, per (line, triangle): 48 fp32 ops for the three squared distances + 3 integer
+// ops (v_max3_u32, v_cmp_lt_u32, v_max3_u32).  A hit is "all three x_k < thr2" which, for
 // x_k >= 0, is one unsigned compare of max3(x) against thr2 (non-negative floats order like
-// their bit patterns); a negative x_k (the reference's NaN -> exit(0), loss.py:89-91) has
-// its sign bit set, can never hit, and is caught by the running unsigned max.
+// their bit patterns); a negative x_k (the reference's NaN -> exit(0), loss.py:89-91) has its
+// sign bit set, can never hit, and is caught by the running unsigned max.
+//
+// lazy loop: only point 0 (16 fp32 ops) for every pair; points 1 and 2 are evaluated for a
+// register pair only in the rare wave-iterations where some lane's point 0 passes.  The
+// labels are identical by construction ("all three pass" needs "point 0 passes").
+//
+// auto mode (default) picks the lazy loop per wavefront when a NaN is PROVABLY impossible for
+// all of its lines, so strict's NaN detection is preserved exactly (DESIGN.md §"NaN bound"):
+//   with u = 2^-24, |dir|^2 <= 1 + 19.8u and |a|^2 = |P - x0|^2 <= 100:
+//   dAC - proj >= -30u |a|^2 >= -1.8e-4 > -2e-4, hence (dAC - proj) + 2e-4 > 0.
+//
 // Hits are rare (~1e-4 per pair): a lane that finds one bumps count[line] atomically and
 // stores the triangle index in the first free slot; the consumer sorts the <= 4 indices,
 // which restores nonzero() order (loss.py:125-131) deterministically.
 // Nothing of size L*N is ever written: compulsory traffic is a few MB against ~35 GFLOP
 // (B=8, N=M=4096, L=10000), so the kernel is fp32-VALU-bound, not HBM-bound.
-#include "rrl_common.h"
+#include "rrl_ws.h"
 
 // ---------------------------------------------------------------------------------------
-// K1' prepared triangles
+// K1' prepared triangles (+ max |P|^2 per cloud and sample for the auto-mode NaN bound)
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void tri_prepare_kernel(const float *__restrict__ tri,
-                                                          float *__restrict__ ptri, int total) {
-    int f = blockIdx.x * 256 + threadIdx.x;
-    if (f >= total) return;
-    const float *p = tri + 9 * (size_t)f;
-    float c[9];
+__global__ __launch_bounds__(256) void tri_prepare_kernel(const float *__restrict__ tri1,
+                                                          const float *__restrict__ tri2,
+                                                          float *__restrict__ ptri1,
+                                                          float *__restrict__ ptri2,
+                                                          uint32_t *__restrict__ pmax, int B, int N,
+                                                          int M) {
+    const int cloud = blockIdx.z, b = blockIdx.y;
+    const int n = cloud ? M : N;
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    float p2 = 0.0f;
+    if (f < n) {
+        const float *p = (cloud ? tri2 : tri1) + 9 * ((size_t)b * n + f);
+        float c[9];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) c[i] = p[i];
-    // code/loss.py:94-104: delta = mean(|P1-P0|, |P2-P0|, |P1-P2|)
-    float e0 = norm3(c[3] - c[0], c[4] - c[1], c[5] - c[2]);
-    float e1 = norm3(c[6] - c[0], c[7] - c[1], c[8] - c[2]);
-    float e2 = norm3(c[3] - c[6], c[4] - c[7], c[5] - c[8]);
-    float delta = ((e0 + e1) + e2) / 3.0f;
-    float t = delta * RRL_CTHR;  // code/loss.py:109: delta * 1.731 / 2
-    float thr = t / 2.0f;
-    // thr2 = min { x >= 0 : sqrtf(x) >= thr }  (sqrtf correctly rounded and monotone), so
-    // sqrtf(x) < thr  <=>  x < thr2 exactly.  Start at fl(thr*thr) and walk a few ulps.
-    float x = thr * thr;
-    if (thr > 0.0f && x < INFINITY) {
-        for (int it = 0; it < 8 && x > 0.0f && sqrtf(x) >= thr; ++it)
-            x = __uint_as_float(__float_as_uint(x) - 1u);
-        for (int it = 0; it < 16 && sqrtf(x) < thr; ++it)
-            x = __uint_as_float(__float_as_uint(x) + 1u);
-    } else if (!(thr > 0.0f)) {
-        x = 0.0f;  // thr == 0 (degenerate triangle) or NaN: nothing is strictly closer
+        for (int i = 0; i < 9; ++i) c[i] = p[i];
+        // code/loss.py:94-104: delta = mean(|P1-P0|, |P2-P0|, |P1-P2|)
+        float e0 = norm3(c[3] - c[0], c[4] - c[1], c[5] - c[2]);
+        float e1 = norm3(c[6] - c[0], c[7] - c[1], c[8] - c[2]);
+        float e2 = norm3(c[3] - c[6], c[4] - c[7], c[5] - c[8]);
+        float delta = ((e0 + e1) + e2) / 3.0f;
+        float t = delta * RRL_CTHR;  // code/loss.py:109: delta * 1.731 / 2
+        float thr = t / 2.0f;
+        // thr2 = min { x >= 0 : sqrtf(x) >= thr }  (sqrtf correctly rounded and monotone), so
+        // sqrtf(x) < thr  <=>  x < thr2 exactly.  Start at fl(thr*thr) and walk a few ulps.
+        float x = thr * thr;
+        if (thr > 0.0f && x < INFINITY) {
+            for (int it = 0; it < 8 && x > 0.0f && sqrtf(x) >= thr; ++it)
+                x = __uint_as_float(__float_as_uint(x) - 1u);
+            for (int it = 0; it < 16 && sqrtf(x) < thr; ++it)
+                x = __uint_as_float(__float_as_uint(x) + 1u);
+        } else if (!(thr > 0.0f)) {
+            x = 0.0f;  // thr == 0 (degenerate triangle) or NaN: nothing is strictly closer
+        }
+        float *q = (cloud ? ptri2 : ptri1) + PTRI_STRIDE * ((size_t)b * n + f);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) q[i] = c[i];
+        q[9] = x;
+        q[10] = thr;
+        q[11] = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            p2 = fmaxf(p2, c[3 * k] * c[3 * k] + c[3 * k + 1] * c[3 * k + 1] + c[3 * k + 2] * c[3 * k + 2]);
+        if (!(p2 <= 3.0e38f)) p2 = INFINITY;  // NaN/inf coordinates: never "provably safe"
     }
-    float *q = ptri + PTRI_STRIDE * (size_t)f;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) q[i] = c[i];
-    q[9] = x;
-    q[10] = thr;
-    q[11] = 0.0f;
+    for (int o = 32; o > 0; o >>= 1) p2 = fmaxf(p2, __shfl_down(p2, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(&pmax[cloud * B + b], __float_as_uint(p2));
 }
 
-extern "C" int rrl_tri_prepare(const float *tri, float *ptri, int B, int N, void *stream) {
-    if (!tri || !ptri || B < 0 || N < 0) return RRL_E_ARG;
-    long total = (long)B * N;
-    if (total == 0) return 0;
-    hipLaunchKernelGGL(tri_prepare_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
-                       (hipStream_t)stream, tri, ptri, (int)total);
+extern "C" int rrl_tri_prepare(const float *tri1, const float *tri2, void *ws, size_t ws_bytes,
+                               int B, int N, int M, int L, void *stream) {
+    if (!tri1 || !tri2 || !ws || B < 0 || N < 0 || M < 0 || L < 0) return RRL_E_ARG;
+    WsLayout w(B, N, M, L);
+    if (ws_bytes < w.total) return RRL_E_WS;
+    hipStream_t s = (hipStream_t)stream;
+    // one memset clears status, nvals, pmax, count1, count2 (contiguous by construction)
+    hipError_t e = hipMemsetAsync((char *)ws + w.off[RRL_WS_STATUS], 0, w.zero_bytes, s);
+    if (e != hipSuccess) return (int)e;
+    const int nmax = N > M ? N : M;
+    if (B == 0 || nmax == 0) return 0;
+    hipLaunchKernelGGL(tri_prepare_kernel, dim3((unsigned)((nmax + 255) / 256), (unsigned)B, 2),
+                       dim3(256), 0, s, tri1, tri2, w.f32(ws, RRL_WS_PTRI1), w.f32(ws, RRL_WS_PTRI2),
+                       (uint32_t *)w.i32(ws, RRL_WS_PMAX), B, N, M);
     RRL_LAUNCH_CHECK();
     return 0;
 }
@@ -73,6 +106,9 @@ typedef const float __attribute__((address_space(4))) * kptr;  // constant AS ->
 
 __device__ __forceinline__ uint32_t umax3(uint32_t a, uint32_t b, uint32_t c) {
     return max(max(a, b), c);
+}
+__device__ __forceinline__ uint32_t umin3(uint32_t a, uint32_t b, uint32_t c) {
+    return min(min(a, b), c);
 }
 
 template <typename T>
@@ -88,13 +124,117 @@ struct Lanes<v2f> {
     static __device__ __forceinline__ float get(v2f v, int i) { return i ? v.y : v.x; }
 };
 
+template <typename T, int NP>
+struct LineRegs {
+    T ux[NP], uy[NP], uz[NP], ox[NP], oy[NP], oz[NP];
+};
+
+struct HitSink {
+    int32_t *cnt, *hit;
+    int lbase, L;
+    __device__ __forceinline__ void commit(int r, int t) const {
+        const int l = lbase + r * 256;
+        if (l < L) {
+            int pos = atomicAdd(&cnt[l], 1);
+            if (pos < RRL_MAX_HITS) hit[(size_t)l * RRL_MAX_HITS + pos] = t;
+        }
+    }
+};
+
+#define DSQ(px, py, pz, i) dist_sq<T>(px, py, pz, r.ux[i], r.uy[i], r.uz[i], r.ox[i], r.oy[i], r.oz[i])
+
+// every (line, triangle) pair fully evaluated; returns the running unsigned max (NaN witness)
+template <typename T, int NP>
+__device__ __forceinline__ uint32_t scan_strict(const LineRegs<T, NP> &r, kptr tp, int t0, int t1,
+                                                const HitSink &sink) {
+    constexpr int W = Lanes<T>::W, R = W * NP;
+    uint32_t nanacc = 0;
+    for (int t = t0; t < t1; ++t, tp += PTRI_STRIDE) {
+        const float p0x = tp[0], p0y = tp[1], p0z = tp[2];
+        const float p1x = tp[3], p1y = tp[4], p1z = tp[5];
+        const float p2x = tp[6], p2y = tp[7], p2z = tp[8];
+        const uint32_t thr2 = __float_as_uint(tp[9]);
+        bool any = false;
+        uint32_t m[R];
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            T x0 = DSQ(p0x, p0y, p0z, i), x1 = DSQ(p1x, p1y, p1z, i), x2 = DSQ(p2x, p2y, p2z, i);
+#pragma unroll
+            for (int w = 0; w < W; ++w) {
+                uint32_t mm = umax3(f2u(Lanes<T>::get(x0, w)), f2u(Lanes<T>::get(x1, w)),
+                                    f2u(Lanes<T>::get(x2, w)));
+                m[i * W + w] = mm;
+                nanacc = max(nanacc, mm);
+                any |= mm < thr2;
+            }
+        }
+        if (__builtin_expect(any, 0)) {
+#pragma unroll
+            for (int q = 0; q < R; ++q)
+                if (m[q] < thr2) sink.commit(q, t);
+        }
+    }
+    return nanacc;
+}
+
+// point 0 for every pair; points 1, 2 per register pair only where some lane's point 0 passes
+template <typename T, int NP, bool TRACK_NAN>
+__device__ __forceinline__ uint32_t scan_lazy(const LineRegs<T, NP> &r, kptr tp, int t0, int t1,
+                                              const HitSink &sink) {
+    constexpr int W = Lanes<T>::W, R = W * NP;
+    uint32_t nanacc = 0;
+    for (int t = t0; t < t1; ++t, tp += PTRI_STRIDE) {
+        const float p0x = tp[0], p0y = tp[1], p0z = tp[2];
+        const uint32_t thr2 = __float_as_uint(tp[9]);
+        uint32_t m[R];
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            T x0 = DSQ(p0x, p0y, p0z, i);
+#pragma unroll
+            for (int w = 0; w < W; ++w) m[i * W + w] = f2u(Lanes<T>::get(x0, w));
+        }
+        // one compare per triangle: the smallest point-0 value of the lane's R lines
+        uint32_t lo = m[0];
+        if constexpr (TRACK_NAN) {
+            uint32_t hi = m[0];
+#pragma unroll
+            for (int q = 1; q < R; ++q) { lo = min(lo, m[q]); hi = max(hi, m[q]); }
+            nanacc = max(nanacc, hi);
+        } else {
+#pragma unroll
+            for (int q = 1; q + 1 < R; q += 2) lo = umin3(lo, m[q], m[q + 1]);
+            if constexpr ((R & 1) == 0) lo = min(lo, m[R - 1]);
+        }
+        if (__builtin_expect(__any(lo < thr2), 0)) {
+            const float p1x = tp[3], p1y = tp[4], p1z = tp[5];
+            const float p2x = tp[6], p2y = tp[7], p2z = tp[8];
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                bool pass = false;
+#pragma unroll
+                for (int w = 0; w < W; ++w) pass |= m[i * W + w] < thr2;
+                if (!__any(pass)) continue;
+                T x1 = DSQ(p1x, p1y, p1z, i), x2 = DSQ(p2x, p2y, p2z, i);
+#pragma unroll
+                for (int w = 0; w < W; ++w) {
+                    uint32_t mm = umax3(m[i * W + w], f2u(Lanes<T>::get(x1, w)),
+                                        f2u(Lanes<T>::get(x2, w)));
+                    if constexpr (TRACK_NAN) nanacc = max(nanacc, mm);
+                    if (mm < thr2) sink.commit(i * W + w, t);
+                }
+            }
+        }
+    }
+    return nanacc;
+}
+
 // T = float (1 line per register) or v2f (2 lines per register pair); NP registers per lane.
-template <typename T, int NP, bool LAZY>
+template <typename T, int NP>
 __global__ __launch_bounds__(256) void scan_kernel(
     const float *__restrict__ ptri1, const float *__restrict__ ptri2,
     const float *__restrict__ line, int32_t *__restrict__ count1, int32_t *__restrict__ hit1,
     int32_t *__restrict__ count2, int32_t *__restrict__ hit2, int32_t *__restrict__ status,
-    int B, int N, int M, int L, int chunk) {
+    const uint32_t *__restrict__ pmax, int B, int N, int M, int L, int chunk, int mode) {
     constexpr int W = Lanes<T>::W;
     constexpr int R = W * NP;  // lines per lane
     const int z = blockIdx.z;
@@ -105,180 +245,132 @@ __global__ __launch_bounds__(256) void scan_kernel(
     if (t0 >= n) return;
     const int t1 = min(n, t0 + chunk);
     const float *tri = (cloud ? ptri2 : ptri1) + (size_t)b * n * PTRI_STRIDE;
-    int32_t *cnt = (cloud ? count2 : count1) + (size_t)b * L;
-    int32_t *hit = (cloud ? hit2 : hit1) + (size_t)b * L * RRL_MAX_HITS;
     const float *ln = line + (size_t)b * L * 6;
-
+    HitSink sink;
+    sink.cnt = (cloud ? count2 : count1) + (size_t)b * L;
+    sink.hit = (cloud ? hit2 : hit1) + (size_t)b * L * RRL_MAX_HITS;
+    sink.L = L;
     // lines of this lane: l = tile*256*R + r*256 + tid (adjacent lanes = adjacent lines)
-    const int lbase = blockIdx.x * (256 * R) + threadIdx.x;
-    T ux[NP], uy[NP], uz[NP], ox[NP], oy[NP], oz[NP];
+    sink.lbase = blockIdx.x * (256 * R) + threadIdx.x;
+
+    LineRegs<T, NP> r;
+    bool safe = true;
+    const float pm = __uint_as_float(pmax[cloud * B + b]);
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
         float v[W][6];
 #pragma unroll
         for (int w = 0; w < W; ++w) {
-            int l = lbase + (i * W + w) * 256;
-            // out-of-range lanes scan the all-zero line (legal input) and never write
+            int l = sink.lbase + (i * W + w) * 256;
+            // out-of-range lanes scan the all-zero line (a legal input) and never write
             const float *q = ln + 6 * (size_t)(l < L ? l : 0);
             float keep = l < L ? 1.0f : 0.0f;
 #pragma unroll
             for (int c = 0; c < 6; ++c) v[w][c] = q[c] * keep;
+            // NaN-impossibility bound (see header): |dir|^2 <= 1+1e-6, (|x0| + max|P|)^2 <= 100
+            float s = v[w][0] * v[w][0] + v[w][1] * v[w][1] + v[w][2] * v[w][2];
+            float o2 = v[w][3] * v[w][3] + v[w][4] * v[w][4] + v[w][5] * v[w][5];
+            float a2 = o2 + pm + 2.0f * sqrtf(o2 * pm);
+            safe &= (s <= 1.000001f) && (a2 <= 100.0f);
         }
         if constexpr (W == 1) {
-            ux[i] = v[0][0]; uy[i] = v[0][1]; uz[i] = v[0][2];
-            ox[i] = v[0][3]; oy[i] = v[0][4]; oz[i] = v[0][5];
+            r.ux[i] = v[0][0]; r.uy[i] = v[0][1]; r.uz[i] = v[0][2];
+            r.ox[i] = v[0][3]; r.oy[i] = v[0][4]; r.oz[i] = v[0][5];
         } else {
-            ux[i] = (v2f){v[0][0], v[1][0]}; uy[i] = (v2f){v[0][1], v[1][1]};
-            uz[i] = (v2f){v[0][2], v[1][2]}; ox[i] = (v2f){v[0][3], v[1][3]};
-            oy[i] = (v2f){v[0][4], v[1][4]}; oz[i] = (v2f){v[0][5], v[1][5]};
+            r.ux[i] = (v2f){v[0][0], v[1][0]}; r.uy[i] = (v2f){v[0][1], v[1][1]};
+            r.uz[i] = (v2f){v[0][2], v[1][2]}; r.ox[i] = (v2f){v[0][3], v[1][3]};
+            r.oy[i] = (v2f){v[0][4], v[1][4]}; r.oz[i] = (v2f){v[0][5], v[1][5]};
         }
     }
 
-    uint32_t nanacc = 0;
     kptr tp = (kptr)(uintptr_t)(tri + (size_t)t0 * PTRI_STRIDE);
-    for (int t = t0; t < t1; ++t, tp += PTRI_STRIDE) {
-        const float p0x = tp[0], p0y = tp[1], p0z = tp[2];
-        const float p1x = tp[3], p1y = tp[4], p1z = tp[5];
-        const float p2x = tp[6], p2y = tp[7], p2z = tp[8];
-        const uint32_t thr2 = __float_as_uint(tp[9]);
-        if constexpr (!LAZY) {
-            bool any = false;
-            uint32_t m[R];
-#pragma unroll
-            for (int i = 0; i < NP; ++i) {
-                T x0 = dist_sq<T>(p0x, p0y, p0z, ux[i], uy[i], uz[i], ox[i], oy[i], oz[i]);
-                T x1 = dist_sq<T>(p1x, p1y, p1z, ux[i], uy[i], uz[i], ox[i], oy[i], oz[i]);
-                T x2 = dist_sq<T>(p2x, p2y, p2z, ux[i], uy[i], uz[i], ox[i], oy[i], oz[i]);
-#pragma unroll
-                for (int w = 0; w < W; ++w) {
-                    uint32_t mm = umax3(f2u(Lanes<T>::get(x0, w)), f2u(Lanes<T>::get(x1, w)),
-                                        f2u(Lanes<T>::get(x2, w)));
-                    m[i * W + w] = mm;
-                    nanacc = max(nanacc, mm);
-                    any |= mm < thr2;
-                }
-            }
-            if (__builtin_expect(any, 0)) {
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    int l = lbase + r * 256;
-                    if (m[r] < thr2 && l < L) {
-                        int pos = atomicAdd(&cnt[l], 1);
-                        if (pos < RRL_MAX_HITS) hit[(size_t)l * RRL_MAX_HITS + pos] = t;
-                    }
-                }
-            }
-        } else {
-            // lazy: point 0 first; points 1 and 2 only in waves where some lane passed
-            bool any0 = false;
-            uint32_t m[R];
-#pragma unroll
-            for (int i = 0; i < NP; ++i) {
-                T x0 = dist_sq<T>(p0x, p0y, p0z, ux[i], uy[i], uz[i], ox[i], oy[i], oz[i]);
-#pragma unroll
-                for (int w = 0; w < W; ++w) {
-                    uint32_t mm = f2u(Lanes<T>::get(x0, w));
-                    m[i * W + w] = mm;
-                    nanacc = max(nanacc, mm);
-                    any0 |= mm < thr2;
-                }
-            }
-            if (__builtin_expect(__any(any0), 0)) {
-                bool any = false;
-#pragma unroll
-                for (int i = 0; i < NP; ++i) {
-                    T x1 = dist_sq<T>(p1x, p1y, p1z, ux[i], uy[i], uz[i], ox[i], oy[i], oz[i]);
-                    T x2 = dist_sq<T>(p2x, p2y, p2z, ux[i], uy[i], uz[i], ox[i], oy[i], oz[i]);
-#pragma unroll
-                    for (int w = 0; w < W; ++w) {
-                        uint32_t mm = umax3(m[i * W + w], f2u(Lanes<T>::get(x1, w)),
-                                            f2u(Lanes<T>::get(x2, w)));
-                        m[i * W + w] = mm;
-                        nanacc = max(nanacc, mm);
-                        any |= mm < thr2;
-                    }
-                }
-                if (any) {
-#pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        int l = lbase + r * 256;
-                        if (m[r] < thr2 && l < L) {
-                            int pos = atomicAdd(&cnt[l], 1);
-                            if (pos < RRL_MAX_HITS) hit[(size_t)l * RRL_MAX_HITS + pos] = t;
-                        }
-                    }
-                }
-            }
-        }
-    }
-    if (nanacc >= 0x80000000u) atomicOr(&status[RRL_STATUS_NAN], 1);
+    uint32_t nanacc;
+    if (mode == RRL_SCAN_STRICT || (mode == RRL_SCAN_AUTO && !__all(safe)))
+        nanacc = scan_strict<T, NP>(r, tp, t0, t1, sink);
+    else if (mode == RRL_SCAN_AUTO)
+        nanacc = scan_lazy<T, NP, false>(r, tp, t0, t1, sink);  // provably NaN-free
+    else
+        nanacc = scan_lazy<T, NP, true>(r, tp, t0, t1, sink);
+    if (nanacc >= 0x80000000u) atomicOr(&status[0], 1);
 }
 
-extern "C" int rrl_loss_begin(int32_t *count1, int32_t *count2, int32_t *status, int64_t *bsum,
-                              int32_t *bcnt, int B, int L, void *stream) {
-    if (!count1 || !count2 || !status || !bsum || !bcnt || B < 0 || L < 0) return RRL_E_ARG;
-    hipStream_t s = (hipStream_t)stream;
-    size_t nb = sizeof(int32_t) * (size_t)B * L;
-    hipError_t e;
-    if (nb) {
-        if ((e = hipMemsetAsync(count1, 0, nb, s)) != hipSuccess) return (int)e;
-        if ((e = hipMemsetAsync(count2, 0, nb, s)) != hipSuccess) return (int)e;
-    }
-    if ((e = hipMemsetAsync(status, 0, sizeof(int32_t) * RRL_STATUS_WORDS, s)) != hipSuccess)
-        return (int)e;
-    if (B) {
-        if ((e = hipMemsetAsync(bsum, 0, sizeof(int64_t) * 32 * (size_t)B, s)) != hipSuccess)
-            return (int)e;
-        if ((e = hipMemsetAsync(bcnt, 0, sizeof(int32_t) * 16 * (size_t)B, s)) != hipSuccess)
-            return (int)e;
-    }
-    return 0;
-}
-
-static int g_scan_variant = -1;  // RRL_SCAN_VARIANT: 1 = scalar R=1, 2 = packed R=2, 4 = packed R=4
+static int g_scan_variant = 0;  // 0 = default; else lines per lane (1, 2, 4, 8)
 
 extern "C" int rrl_set_scan_variant(int lines_per_lane) {
-    if (lines_per_lane != 1 && lines_per_lane != 2 && lines_per_lane != 4) return RRL_E_ARG;
+    if (lines_per_lane != 0 && lines_per_lane != 1 && lines_per_lane != 2 && lines_per_lane != 4 &&
+        lines_per_lane != 8)
+        return RRL_E_ARG;
     g_scan_variant = lines_per_lane;
     return 0;
 }
 
-extern "C" int rrl_line_tri_scan(const float *ptri1, const float *ptri2, const float *line,
-                                 int32_t *count1, int32_t *hit1, int32_t *count2, int32_t *hit2,
-                                 int32_t *status, int B, int N, int M, int L, int mode, int chunk,
-                                 void *stream) {
-    if (!ptri1 || !ptri2 || !line || !count1 || !hit1 || !count2 || !hit2 || !status)
-        return RRL_E_ARG;
-    if (B < 0 || N < 0 || M < 0 || L < 0 || chunk < 0) return RRL_E_ARG;
-    if (mode != RRL_SCAN_STRICT && mode != RRL_SCAN_LAZY) return RRL_E_ARG;
+// ---- optional scan timing ring -----------------------------------------------------------
+#define TIMING_RING 1024
+static int g_timing_on = 0, g_timing_n = 0;
+static hipEvent_t g_ev[TIMING_RING][2];
+static bool g_ev_made = false;
+
+extern "C" int rrl_scan_timing_enable(int on) {
+    if (on && !g_ev_made) {
+        for (int i = 0; i < TIMING_RING; ++i)
+            for (int k = 0; k < 2; ++k) {
+                hipError_t e = hipEventCreate(&g_ev[i][k]);
+                if (e != hipSuccess) return (int)e;
+            }
+        g_ev_made = true;
+    }
+    g_timing_on = on ? 1 : 0;
+    g_timing_n = 0;
+    return 0;
+}
+
+extern "C" int rrl_scan_timing_collect(float *ms, int max_n) {
+    int n = g_timing_n < TIMING_RING ? g_timing_n : TIMING_RING;
+    if (n > max_n) n = max_n;
+    for (int i = 0; i < n; ++i) {
+        if (hipEventSynchronize(g_ev[i][1]) != hipSuccess) return 0;
+        if (hipEventElapsedTime(&ms[i], g_ev[i][0], g_ev[i][1]) != hipSuccess) return 0;
+    }
+    g_timing_n = 0;
+    return n;
+}
+
+extern "C" int rrl_line_tri_scan(const float *line, void *ws, size_t ws_bytes, int B, int N, int M,
+                                 int L, int mode, int chunk, void *stream) {
+    if (!line || !ws || B < 0 || N < 0 || M < 0 || L < 0 || chunk < 0) return RRL_E_ARG;
+    if (mode != RRL_SCAN_STRICT && mode != RRL_SCAN_LAZY && mode != RRL_SCAN_AUTO) return RRL_E_ARG;
+    WsLayout w(B, N, M, L);
+    if (ws_bytes < w.total) return RRL_E_WS;
     if (B == 0 || L == 0 || (N == 0 && M == 0)) return 0;
-    if (g_scan_variant < 0) {
+    int R = g_scan_variant;
+    if (R == 0) {
         const char *v = getenv("RRL_SCAN_VARIANT");
-        g_scan_variant = v ? atoi(v) : 2;
-        if (g_scan_variant != 1 && g_scan_variant != 2 && g_scan_variant != 4) g_scan_variant = 2;
+        R = v ? atoi(v) : 0;
+        if (R != 1 && R != 2 && R != 4 && R != 8) R = mode == RRL_SCAN_STRICT ? 2 : 4;
     }
     if (chunk == 0) {
         const char *c = getenv("RRL_SCAN_CHUNK");
-        chunk = c ? atoi(c) : 256;
-        if (chunk <= 0) chunk = 256;
+        chunk = c ? atoi(c) : 0;
+        if (chunk <= 0) chunk = mode == RRL_SCAN_STRICT ? 256 : 128;
     }
-    const int R = g_scan_variant;
     const int nmax = N > M ? N : M;
     dim3 grid((unsigned)((L + 256 * R - 1) / (256 * R)), (unsigned)((nmax + chunk - 1) / chunk),
               (unsigned)(2 * B));
     hipStream_t s = (hipStream_t)stream;
-#define RRL_SCAN_LAUNCH(T, NP, LZ)                                                              \
-    hipLaunchKernelGGL((scan_kernel<T, NP, LZ>), grid, dim3(256), 0, s, ptri1, ptri2, line,     \
-                       count1, hit1, count2, hit2, status, B, N, M, L, chunk)
-    const bool lazy = mode == RRL_SCAN_LAZY;
-    if (R == 1) {
-        if (lazy) RRL_SCAN_LAUNCH(float, 1, true); else RRL_SCAN_LAUNCH(float, 1, false);
-    } else if (R == 2) {
-        if (lazy) RRL_SCAN_LAUNCH(v2f, 1, true); else RRL_SCAN_LAUNCH(v2f, 1, false);
-    } else {
-        if (lazy) RRL_SCAN_LAUNCH(v2f, 2, true); else RRL_SCAN_LAUNCH(v2f, 2, false);
-    }
+    const bool timed = g_timing_on && g_timing_n < TIMING_RING;
+    if (timed) (void)hipEventRecord(g_ev[g_timing_n][0], s);
+#define RRL_SCAN_LAUNCH(T, NP)                                                                   \
+    hipLaunchKernelGGL((scan_kernel<T, NP>), grid, dim3(256), 0, s, w.f32(ws, RRL_WS_PTRI1),     \
+                       w.f32(ws, RRL_WS_PTRI2), line, w.i32(ws, RRL_WS_COUNT1),                  \
+                       w.i32(ws, RRL_WS_HIT1), w.i32(ws, RRL_WS_COUNT2), w.i32(ws, RRL_WS_HIT2), \
+                       w.i32(ws, RRL_WS_STATUS), (const uint32_t *)w.i32(ws, RRL_WS_PMAX), B, N, \
+                       M, L, chunk, mode)
+    if (R == 1) RRL_SCAN_LAUNCH(float, 1);
+    else if (R == 2) RRL_SCAN_LAUNCH(v2f, 1);
+    else if (R == 4) RRL_SCAN_LAUNCH(v2f, 2);
+    else RRL_SCAN_LAUNCH(v2f, 4);
 #undef RRL_SCAN_LAUNCH
+    if (timed) (void)hipEventRecord(g_ev[g_timing_n++][1], s);
     RRL_LAUNCH_CHECK();
     return 0;
 }

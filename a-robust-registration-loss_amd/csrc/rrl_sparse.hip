@@ -1,19 +1,19 @@
-// rrl_sparse.hip -- K2..K5: everything after the dense scan.
+// rrl_sparse.hip -- everything after the dense scan, plus the fused forward/backward entries.
 //   K2 line_pair_dist   code/loss.py:115-167   (one lane per line, <= 4x4 block in registers)
-//   K3 lower_median     code/loss.py:223-224   (radix select, one workgroup per sample)
-//   K4 welsch_reduce    code/loss.py:20-21, 226-230
+//   K3+K4 loss_reduce   code/loss.py:223-230   (radix-select median + Welsch min/mean, one
+//                                               workgroup per sample, fixed-point bucket sums)
 //   K5 backward         autograd of code/loss.py:170-232
-// About 9 % of the lines are selected; these kernels touch O(L) data and are launch/latency
-// bound (a few microseconds each) next to the O(L*(N+M)) scan.
-#include "rrl_common.h"
+// About 9 % of the lines are selected; these kernels touch O(L) data and are latency bound
+// (a few microseconds each) next to the O(L*(N+M)) scan.
+#include "rrl_ws.h"
 
 #define FIX_SHIFT 40  // bucket sums in 2^-40 fixed point: order-independent, bit-deterministic
 
 // sqrt(dist_sq) of the three points of triangle f and the detached weights of
 // code/loss.py:92: w_k = d_k / ((d0 + d1) + d2).  Same arithmetic as the scan, so the
 // distances are bit-identical to the ones that decided the label.
-__device__ __forceinline__ void hit_weights(const float *__restrict__ tri, int f,
-                                            const float *ln, float *w) {
+__device__ __forceinline__ void hit_weights(const float *__restrict__ tri, int f, const float *ln,
+                                            float *w) {
     const float *p = tri + 9 * (size_t)f;
     float d[3];
 #pragma unroll
@@ -52,8 +52,8 @@ __global__ __launch_bounds__(256) void line_pair_dist_kernel(
     const int32_t *__restrict__ count2, const int32_t *__restrict__ hit2,
     uint8_t *__restrict__ kj, int32_t *__restrict__ hs1, int32_t *__restrict__ hs2,
     float *__restrict__ w1, float *__restrict__ w2, float *__restrict__ D,
-    int32_t *__restrict__ bcnt, int B, int N, int M, int L, int s_m, int s_n, int e_m, int e_n,
-    int pool) {
+    float *__restrict__ vals, int32_t *__restrict__ nvals, int B, int N, int M, int L, int s_m,
+    int s_n, int e_m, int e_n, int pool) {
     const int l = blockIdx.x * 256 + threadIdx.x;
     const int b = blockIdx.y;
     if (l >= L) return;
@@ -94,6 +94,11 @@ __global__ __launch_bounds__(256) void line_pair_dist_kernel(
             for (int c = 0; c < 3; ++c) w2[(gl * RRL_MAX_HITS + a) * 3 + c] = w[c];
         }
     }
+    // the median's input: all of this sample's D values, any order (reference B>1 quirk:
+    // only the LAST sample's values define the median)
+    const bool feeds_median = !pool || b == B - 1;
+    int pos = feeds_median ? atomicAdd(&nvals[b], k * j) : 0;
+    float *vb = vals + (size_t)b * L * 16;
     // D[a][b] = sum_c (q1 - q2)^2, code/loss.py:38-52
 #pragma unroll
     for (int a = 0; a < RRL_MAX_HITS; ++a)
@@ -106,113 +111,31 @@ __global__ __launch_bounds__(256) void line_pair_dist_kernel(
                 s = s + dy * dy;
                 s = s + dz * dz;
                 D[gl * 16 + a * j + bb] = s;
+                if (feeds_median) vb[pos + a * j + bb] = s;
             }
-    atomicAdd(&bcnt[(pool ? 0 : b) * 16 + (k - 1) * 4 + (j - 1)], 1);
 }
 
 extern "C" int rrl_line_pair_dist(const float *tri1, const float *tri2, const float *line,
-                                  const int32_t *count1, const int32_t *hit1,
-                                  const int32_t *count2, const int32_t *hit2, uint8_t *kj,
-                                  int32_t *hs1, int32_t *hs2, float *w1, float *w2, float *D,
-                                  int32_t *bcnt, int B, int N, int M, int L, int s_m, int s_n,
-                                  int e_m, int e_n, int pool, void *stream) {
-    if (!tri1 || !tri2 || !line || !count1 || !hit1 || !count2 || !hit2 || !kj || !hs1 || !hs2 ||
-        !w1 || !w2 || !D || !bcnt)
-        return RRL_E_ARG;
-    if (B < 0 || N < 0 || M < 0 || L < 0) return RRL_E_ARG;
+                                  void *ws, size_t ws_bytes, int B, int N, int M, int L, int s_m,
+                                  int s_n, int e_m, int e_n, int pool, void *stream) {
+    if (!tri1 || !tri2 || !line || !ws || B < 0 || N < 0 || M < 0 || L < 0) return RRL_E_ARG;
     if (s_m < 1 || s_n < 1 || e_m > RRL_MAX_HITS + 1 || e_n > RRL_MAX_HITS + 1) return RRL_E_RANGE;
+    WsLayout w(B, N, M, L);
+    if (ws_bytes < w.total) return RRL_E_WS;
     if (B == 0 || L == 0) return 0;
     hipLaunchKernelGGL(line_pair_dist_kernel, dim3((unsigned)((L + 255) / 256), (unsigned)B),
-                       dim3(256), 0, (hipStream_t)stream, tri1, tri2, line, count1, hit1, count2,
-                       hit2, kj, hs1, hs2, w1, w2, D, bcnt, B, N, M, L, s_m, s_n, e_m, e_n, pool);
+                       dim3(256), 0, (hipStream_t)stream, tri1, tri2, line,
+                       w.i32(ws, RRL_WS_COUNT1), w.i32(ws, RRL_WS_HIT1), w.i32(ws, RRL_WS_COUNT2),
+                       w.i32(ws, RRL_WS_HIT2), w.u8(ws, RRL_WS_KJ), w.i32(ws, RRL_WS_HS1),
+                       w.i32(ws, RRL_WS_HS2), w.f32(ws, RRL_WS_W1), w.f32(ws, RRL_WS_W2),
+                       w.f32(ws, RRL_WS_D), w.f32(ws, RRL_WS_VALS), w.i32(ws, RRL_WS_NVALS), B, N, M,
+                       L, s_m, s_n, e_m, e_n, pool);
     RRL_LAUNCH_CHECK();
     return 0;
 }
 
 // ---------------------------------------------------------------------------------------
-// K3 lower median: 4-pass MSB-first radix select on the bit patterns (D >= 0, so unsigned
-// order == float order).  One 1024-lane workgroup per sample.
-// ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void lower_median_kernel(const uint8_t *__restrict__ kj,
-                                                            const float *__restrict__ D,
-                                                            float *__restrict__ med,
-                                                            int32_t *__restrict__ nval, int B,
-                                                            int L, int pool) {
-    __shared__ unsigned hist[256];
-    __shared__ unsigned s_prefix, s_rank, s_total;
-    const int g = blockIdx.x;
-    const int b = pool ? B - 1 : g;  // reference B>1 quirk: the last sample's median (Q2)
-    const uint8_t *kjb = kj + (size_t)b * L;
-    const float *Db = D + (size_t)b * L * 16;
-    const int tid = threadIdx.x;
-    // total number of values
-    if (tid < 256) hist[tid] = 0;
-    __syncthreads();
-    unsigned mine = 0;
-    for (int l = tid; l < L; l += 1024) {
-        unsigned c = kjb[l];
-        mine += (c & 15u) * (c >> 4);
-    }
-    for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o);
-    if ((tid & 63) == 0) atomicAdd(&hist[0], mine);
-    __syncthreads();
-    if (tid == 0) {
-        s_total = hist[0];
-        s_rank = hist[0] ? (hist[0] - 1) / 2 : 0;  // torch.median: sorted[(n-1)/2]
-        s_prefix = 0;
-    }
-    __syncthreads();
-    const unsigned total = s_total;
-    if (total == 0) {
-        if (tid == 0) { med[g] = 0.0f; nval[g] = 0; }
-        return;
-    }
-    for (int pass = 0; pass < 4; ++pass) {
-        const int shift = 24 - 8 * pass;
-        const unsigned himask = pass ? (0xffffffffu << (shift + 8)) : 0u;
-        const unsigned prefix = s_prefix;
-        __syncthreads();
-        if (tid < 256) hist[tid] = 0;
-        __syncthreads();
-        for (int l = tid; l < L; l += 1024) {
-            unsigned c = kjb[l];
-            int nv = (int)((c & 15u) * (c >> 4));
-            for (int i = 0; i < nv; ++i) {
-                unsigned u = __float_as_uint(Db[(size_t)l * 16 + i]);
-                if ((u & himask) == prefix) atomicAdd(&hist[(u >> shift) & 255u], 1u);
-            }
-        }
-        __syncthreads();
-        if (tid == 0) {
-            unsigned r = s_rank, acc = 0;
-            int bin = 0;
-            for (; bin < 256; ++bin) {
-                if (acc + hist[bin] > r) break;
-                acc += hist[bin];
-            }
-            s_rank = r - acc;
-            s_prefix = prefix | ((unsigned)bin << shift);
-        }
-        __syncthreads();
-    }
-    if (tid == 0) {
-        med[g] = __uint_as_float(s_prefix);
-        nval[g] = (int32_t)total;
-    }
-}
-
-extern "C" int rrl_lower_median(const uint8_t *kj, const float *D, float *med, int32_t *nval,
-                                int B, int L, int pool, void *stream) {
-    if (!kj || !D || !med || !nval || B < 0 || L < 0) return RRL_E_ARG;
-    if (B == 0) return 0;
-    hipLaunchKernelGGL(lower_median_kernel, dim3((unsigned)(pool ? 1 : B)), dim3(1024), 0,
-                       (hipStream_t)stream, kj, D, med, nval, B, L, pool);
-    RRL_LAUNCH_CHECK();
-    return 0;
-}
-
-// ---------------------------------------------------------------------------------------
-// K4 Welsch + symmetric min/mean
+// K3+K4: one 1024-lane workgroup per sample
 // ---------------------------------------------------------------------------------------
 // Welsch1(x, c) = 1 - exp(-(x / c) / 2), code/loss.py:20-21
 __device__ __forceinline__ float welsch(float d, float med) {
@@ -220,9 +143,10 @@ __device__ __forceinline__ float welsch(float d, float med) {
 }
 
 // Row/column minima of the k x j Welsch block with first-occurrence argmin (torch.min,
-// SURVEY.md Q11).  Wl[a*4+b].
-__device__ __forceinline__ void welsch_block(const float *__restrict__ Dl, int k, int j,
-                                             float med, float *Wl, int *arg_b, int *arg_a) {
+// SURVEY.md Q11).  All indices static after unrolling (no scratch).
+__device__ __forceinline__ void welsch_block(const float *__restrict__ Dl, int k, int j, float med,
+                                             float *rowmin, float *colmin, int *arg_b, int *arg_a) {
+    float Wl[16];
 #pragma unroll
     for (int a = 0; a < RRL_MAX_HITS; ++a)
 #pragma unroll
@@ -230,96 +154,150 @@ __device__ __forceinline__ void welsch_block(const float *__restrict__ Dl, int k
             Wl[a * 4 + b] = (a < k && b < j) ? welsch(Dl[a * j + b], med) : INFINITY;
 #pragma unroll
     for (int a = 0; a < RRL_MAX_HITS; ++a) {
+        float best = Wl[a * 4];
         int m = 0;
 #pragma unroll
         for (int b = 1; b < RRL_MAX_HITS; ++b)
-            if (Wl[a * 4 + b] < Wl[a * 4 + m]) m = b;
+            if (Wl[a * 4 + b] < best) { best = Wl[a * 4 + b]; m = b; }
+        rowmin[a] = best;
         arg_b[a] = m;
     }
 #pragma unroll
     for (int b = 0; b < RRL_MAX_HITS; ++b) {
+        float best = Wl[b];
         int m = 0;
 #pragma unroll
         for (int a = 1; a < RRL_MAX_HITS; ++a)
-            if (Wl[a * 4 + b] < Wl[m * 4 + b]) m = a;
+            if (Wl[a * 4 + b] < best) { best = Wl[a * 4 + b]; m = a; }
+        colmin[b] = best;
         arg_a[b] = m;
     }
 }
 
-__global__ __launch_bounds__(256) void welsch_fwd_kernel(const uint8_t *__restrict__ kj,
-                                                         const float *__restrict__ D,
-                                                         const float *__restrict__ med,
-                                                         int64_t *__restrict__ bsum, int B, int L,
-                                                         int pool) {
-    const int l = blockIdx.x * 256 + threadIdx.x;
-    const int b = blockIdx.y;
-    if (l >= L) return;
-    const size_t gl = (size_t)b * L + l;
-    const unsigned c = kj[gl];
-    if (!c) return;
-    const int k = c & 15, j = c >> 4, g = pool ? 0 : b;
-    float Wl[16];
-    int arg_b[4], arg_a[4];
-    welsch_block(D + gl * 16, k, j, med[g], Wl, arg_b, arg_a);
-    float row = 0.0f, col = 0.0f;
-#pragma unroll
-    for (int a = 0; a < RRL_MAX_HITS; ++a)
-        if (a < k) row += Wl[a * 4 + arg_b[a]];
-#pragma unroll
-    for (int bb = 0; bb < RRL_MAX_HITS; ++bb)
-        if (bb < j) col += Wl[arg_a[bb] * 4 + bb];
-    // Wl in [0,1]; <= 4 terms; 2^-40 fixed point keeps 2^-38 relative resolution per line
-    const int bi = (k - 1) * 4 + (j - 1);
-    long long fr = (long long)((double)row * (double)(1ll << FIX_SHIFT) + 0.5);
-    long long fc = (long long)((double)col * (double)(1ll << FIX_SHIFT) + 0.5);
-    atomicAdd((unsigned long long *)&bsum[((size_t)g * 16 + bi) * 2 + 0], (unsigned long long)fr);
-    atomicAdd((unsigned long long *)&bsum[((size_t)g * 16 + bi) * 2 + 1], (unsigned long long)fc);
-}
+__global__ __launch_bounds__(1024) void loss_reduce_kernel(
+    const uint8_t *__restrict__ kj, const float *__restrict__ D, const float *__restrict__ vals,
+    const int32_t *__restrict__ nvals, float *__restrict__ med_out, int32_t *__restrict__ bcnt_out,
+    int64_t *__restrict__ bsum_out, int32_t *__restrict__ info, float *__restrict__ loss, int B,
+    int L, int s_m, int s_n, int e_m, int e_n, int pool) {
+    __shared__ unsigned hist[256];
+    __shared__ unsigned wave_tot[4];
+    __shared__ unsigned s_prefix, s_rank;
+    __shared__ unsigned long long s_sum[32];
+    __shared__ int s_cnt[16];
+    const int g = blockIdx.x, tid = threadIdx.x;
+    const int bm = pool ? B - 1 : g;  // whose values define the median
+    const float *v = vals + (size_t)bm * L * 16;
+    const unsigned n = (unsigned)nvals[bm];
 
-extern "C" int rrl_welsch_reduce_fwd(const uint8_t *kj, const float *D, const float *med,
-                                     int64_t *bsum, int B, int L, int pool, void *stream) {
-    if (!kj || !D || !med || !bsum || B < 0 || L < 0) return RRL_E_ARG;
-    if (B == 0 || L == 0) return 0;
-    hipLaunchKernelGGL(welsch_fwd_kernel, dim3((unsigned)((L + 255) / 256), (unsigned)B),
-                       dim3(256), 0, (hipStream_t)stream, kj, D, med, bsum, B, L, pool);
-    RRL_LAUNCH_CHECK();
-    return 0;
-}
-
-// loss = ( sum_{non-empty (k,j), k-major} exp(-0.5|k-j|) * (mean_row + mean_col) ) / C
-// code/loss.py:215-217, 226-230
-__global__ void loss_finalize_kernel(const int64_t *__restrict__ bsum,
-                                     const int32_t *__restrict__ bcnt, float *__restrict__ loss,
-                                     int32_t *__restrict__ nbuckets, int G, int s_m, int s_n,
-                                     int e_m, int e_n) {
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= G) return;
-    float acc = 0.0f;
-    int C = 0;
-    for (int k = s_m; k < e_m; ++k)
-        for (int j = s_n; j < e_n; ++j) {
-            const int bi = (k - 1) * 4 + (j - 1);
-            const int S = bcnt[g * 16 + bi];
-            if (S == 0) continue;
-            const double sc = 1.0 / (double)(1ll << FIX_SHIFT);
-            float mrow = (float)((double)bsum[((size_t)g * 16 + bi) * 2 + 0] * sc / ((double)S * k));
-            float mcol = (float)((double)bsum[((size_t)g * 16 + bi) * 2 + 1] * sc / ((double)S * j));
-            float wkj = expf(-0.5f * (float)abs(k - j));
-            acc = acc + wkj * (mrow + mcol);
-            ++C;
+    // ---- lower median: 4-pass MSB-first radix select on the bit patterns (D >= 0, so the
+    //      unsigned order is the float order); rank (n-1)/2 == torch.median
+    if (tid == 0) { s_prefix = 0; s_rank = n ? (n - 1) / 2 : 0; }
+    if (tid < 32) s_sum[tid] = 0ull;
+    if (tid < 16) s_cnt[tid] = 0;
+    for (int pass = 0; pass < 4 && n > 0; ++pass) {
+        const int shift = 24 - 8 * pass;
+        const unsigned himask = pass ? (0xffffffffu << (shift + 8)) : 0u;
+        if (tid < 256) hist[tid] = 0;
+        __syncthreads();
+        const unsigned prefix = s_prefix;
+        for (unsigned i = tid; i < n; i += 1024) {
+            unsigned u = __float_as_uint(v[i]);
+            if ((u & himask) == prefix) atomicAdd(&hist[(u >> shift) & 255u], 1u);
         }
-    nbuckets[g] = C;
-    loss[g] = C ? acc / (float)C : 0.0f;
+        __syncthreads();
+        // parallel search of the bin holding the rank: inclusive scan over 256 bins
+        const unsigned r = s_rank;  // read before the barrier below; rewritten after it
+        unsigned c = 0, inc = 0;
+        if (tid < 256) {
+            c = hist[tid];
+            inc = c;
+            for (int o = 1; o < 64; o <<= 1) {
+                unsigned t = __shfl_up(inc, o);
+                if ((tid & 63) >= o) inc += t;
+            }
+            if ((tid & 63) == 63) wave_tot[tid >> 6] = inc;
+        }
+        __syncthreads();
+        if (tid < 256) {
+            unsigned base = 0;
+            for (int w = 0; w < (tid >> 6); ++w) base += wave_tot[w];
+            inc += base;
+            if (inc - c <= r && r < inc) {  // exactly one bin satisfies this
+                s_rank = r - (inc - c);
+                s_prefix = prefix | ((unsigned)tid << shift);
+            }
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    const float med = n ? __uint_as_float(s_prefix) : 0.0f;
+
+    // ---- Welsch + symmetric min per selected line, bucket sums in LDS (fixed point)
+    const int b0 = pool ? 0 : g, b1 = pool ? B : g + 1;
+    for (int b = b0; b < b1; ++b)
+        for (int l = tid; l < L; l += 1024) {
+            const size_t gl = (size_t)b * L + l;
+            const unsigned c = kj[gl];
+            if (!c) continue;
+            const int k = c & 15, j = c >> 4;
+            float rowmin[4], colmin[4];
+            int arg_b[4], arg_a[4];
+            welsch_block(D + gl * 16, k, j, med, rowmin, colmin, arg_b, arg_a);
+            float row = 0.0f, col = 0.0f;
+#pragma unroll
+            for (int a = 0; a < RRL_MAX_HITS; ++a)
+                if (a < k) row += rowmin[a];
+#pragma unroll
+            for (int bb = 0; bb < RRL_MAX_HITS; ++bb)
+                if (bb < j) col += colmin[bb];
+            // Wl in [0,1], <= 4 terms: 2^-40 fixed point keeps ~2^-38 relative resolution
+            const int bi = (k - 1) * 4 + (j - 1);
+            atomicAdd(&s_sum[bi * 2 + 0], (unsigned long long)((double)row * (double)(1ll << FIX_SHIFT) + 0.5));
+            atomicAdd(&s_sum[bi * 2 + 1], (unsigned long long)((double)col * (double)(1ll << FIX_SHIFT) + 0.5));
+            atomicAdd(&s_cnt[bi], 1);
+        }
+    __syncthreads();
+
+    // ---- loss = ( sum_{non-empty (k,j), k-major} exp(-|k-j|/2) (mean_row + mean_col) ) / C
+    if (tid < 16) bcnt_out[g * 16 + tid] = s_cnt[tid];
+    if (tid < 32) bsum_out[(size_t)g * 32 + tid] = (int64_t)s_sum[tid];
+    if (tid == 0) {
+        float acc = 0.0f;
+        int C = 0, nsel = 0;
+        for (int k = s_m; k < e_m; ++k)
+            for (int j = s_n; j < e_n; ++j) {
+                const int bi = (k - 1) * 4 + (j - 1);
+                const int S = s_cnt[bi];
+                if (S == 0) continue;
+                const double sc = 1.0 / (double)(1ll << FIX_SHIFT);
+                float mrow = (float)((double)s_sum[bi * 2 + 0] * sc / ((double)S * k));
+                float mcol = (float)((double)s_sum[bi * 2 + 1] * sc / ((double)S * j));
+                float wkj = expf(-0.5f * (float)abs(k - j));  // code/loss.py:215
+                acc = acc + wkj * (mrow + mcol);
+                ++C;
+                nsel += S;
+            }
+        med_out[g] = med;
+        loss[g] = C ? acc / (float)C : 0.0f;  // code/loss.py:230
+        info[g * 4 + 0] = C;
+        info[g * 4 + 1] = nsel;
+        info[g * 4 + 2] = (int)n;
+        info[g * 4 + 3] = 0;
+    }
 }
 
-extern "C" int rrl_loss_finalize(const int64_t *bsum, const int32_t *bcnt, float *loss,
-                                 int32_t *nbuckets, int G, int s_m, int s_n, int e_m, int e_n,
-                                 void *stream) {
-    if (!bsum || !bcnt || !loss || !nbuckets || G < 0) return RRL_E_ARG;
+extern "C" int rrl_loss_reduce(void *ws, size_t ws_bytes, float *loss, int B, int N, int M, int L,
+                               int s_m, int s_n, int e_m, int e_n, int pool, void *stream) {
+    if (!ws || !loss || B < 0 || N < 0 || M < 0 || L < 0) return RRL_E_ARG;
     if (s_m < 1 || s_n < 1 || e_m > RRL_MAX_HITS + 1 || e_n > RRL_MAX_HITS + 1) return RRL_E_RANGE;
-    if (G == 0) return 0;
-    hipLaunchKernelGGL(loss_finalize_kernel, dim3((unsigned)((G + 63) / 64)), dim3(64), 0,
-                       (hipStream_t)stream, bsum, bcnt, loss, nbuckets, G, s_m, s_n, e_m, e_n);
+    WsLayout w(B, N, M, L);
+    if (ws_bytes < w.total) return RRL_E_WS;
+    if (B == 0) return 0;
+    hipLaunchKernelGGL(loss_reduce_kernel, dim3((unsigned)(pool ? 1 : B)), dim3(1024), 0,
+                       (hipStream_t)stream, w.u8(ws, RRL_WS_KJ), w.f32(ws, RRL_WS_D),
+                       w.f32(ws, RRL_WS_VALS), w.i32(ws, RRL_WS_NVALS), w.f32(ws, RRL_WS_MED),
+                       w.i32(ws, RRL_WS_BCNT), w.i64(ws, RRL_WS_BSUM), w.i32(ws, RRL_WS_INFO), loss,
+                       B, L, s_m, s_n, e_m, e_n, pool);
     RRL_LAUNCH_CHECK();
     return 0;
 }
@@ -330,11 +308,11 @@ extern "C" int rrl_loss_finalize(const int64_t *bsum, const int32_t *bcnt, float
 // dL/dq1[a] = sum_b 2 (q1_a - q2_b) dL/dD;  dL/dP1[f_a][kk] += w_kk / 3 * dL/dq1[a];
 // weights, median and labels carry no gradient (code/loss.py:112, 224).
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void welsch_bwd_kernel(
+__global__ __launch_bounds__(256) void loss_bwd_kernel(
     const float *__restrict__ tri1, const float *__restrict__ tri2, const uint8_t *__restrict__ kj,
     const int32_t *__restrict__ hs1, const int32_t *__restrict__ hs2, const float *__restrict__ w1,
     const float *__restrict__ w2, const float *__restrict__ D, const float *__restrict__ med,
-    const int32_t *__restrict__ bcnt, const int32_t *__restrict__ nbuckets,
+    const int32_t *__restrict__ bcnt, const int32_t *__restrict__ info,
     const float *__restrict__ grad_loss, float *__restrict__ g1, float *__restrict__ g2, int B,
     int N, int M, int L, int pool) {
     const int l = blockIdx.x * 256 + threadIdx.x;
@@ -344,12 +322,12 @@ __global__ __launch_bounds__(256) void welsch_bwd_kernel(
     const unsigned c = kj[gl];
     if (!c) return;
     const int k = c & 15, j = c >> 4, g = pool ? 0 : b;
-    const int C = nbuckets[g];
+    const int C = info[g * 4];
     if (C == 0) return;
     const float m = med[g];
-    float Wl[16];
+    float rowmin[4], colmin[4];
     int arg_b[4], arg_a[4];
-    welsch_block(D + gl * 16, k, j, m, Wl, arg_b, arg_a);
+    welsch_block(D + gl * 16, k, j, m, rowmin, colmin, arg_b, arg_a);
     const int S = bcnt[g * 16 + (k - 1) * 4 + (j - 1)];
     const float wkj = expf(-0.5f * (float)abs(k - j));
     const float scale = grad_loss[g] * wkj / (float)C;
@@ -370,7 +348,7 @@ __global__ __launch_bounds__(256) void welsch_bwd_kernel(
             if (a < k && bb < j) {
                 float sel = (arg_b[a] == bb ? inv_row : 0.0f) + (arg_a[bb] == a ? inv_col : 0.0f);
                 if (sel != 0.0f) {
-                    // dWl/dD = exp(-D/(2 med)) / (2 med) = (1 - Wl) / (2 med)
+                    // dWl/dD = exp(-D/(2 med)) / (2 med)
                     float gD = scale * sel * expf(-(D[gl * 16 + a * j + bb] / m) / 2.0f) / (2.0f * m);
 #pragma unroll
                     for (int cc = 0; cc < 3; ++cc) {
@@ -403,20 +381,54 @@ __global__ __launch_bounds__(256) void welsch_bwd_kernel(
     }
 }
 
-extern "C" int rrl_welsch_reduce_bwd(const float *tri1, const float *tri2, const uint8_t *kj,
-                                     const int32_t *hs1, const int32_t *hs2, const float *w1,
-                                     const float *w2, const float *D, const float *med,
-                                     const int32_t *bcnt, const int32_t *nbuckets,
-                                     const float *grad_loss, float *grad_tri1, float *grad_tri2,
-                                     int B, int N, int M, int L, int pool, void *stream) {
-    if (!tri1 || !tri2 || !kj || !hs1 || !hs2 || !w1 || !w2 || !D || !med || !bcnt || !nbuckets ||
-        !grad_loss || !grad_tri1)
-        return RRL_E_ARG;
+extern "C" int rrl_loss_backward(const float *tri1, const float *tri2, const void *ws,
+                                 size_t ws_bytes, const float *grad_loss, float *grad_tri1,
+                                 float *grad_tri2, int B, int N, int M, int L, int pool,
+                                 void *stream) {
+    if (!tri1 || !tri2 || !ws || !grad_loss || !grad_tri1) return RRL_E_ARG;
     if (B < 0 || N < 0 || M < 0 || L < 0) return RRL_E_ARG;
+    WsLayout w(B, N, M, L);
+    if (ws_bytes < w.total) return RRL_E_WS;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e;
+    if ((size_t)B * N && (e = hipMemsetAsync(grad_tri1, 0, sizeof(float) * 9 * (size_t)B * N, s)) != hipSuccess)
+        return (int)e;
+    if (grad_tri2 && (size_t)B * M &&
+        (e = hipMemsetAsync(grad_tri2, 0, sizeof(float) * 9 * (size_t)B * M, s)) != hipSuccess)
+        return (int)e;
     if (B == 0 || L == 0) return 0;
-    hipLaunchKernelGGL(welsch_bwd_kernel, dim3((unsigned)((L + 255) / 256), (unsigned)B),
-                       dim3(256), 0, (hipStream_t)stream, tri1, tri2, kj, hs1, hs2, w1, w2, D, med,
-                       bcnt, nbuckets, grad_loss, grad_tri1, grad_tri2, B, N, M, L, pool);
+    hipLaunchKernelGGL(loss_bwd_kernel, dim3((unsigned)((L + 255) / 256), (unsigned)B), dim3(256), 0,
+                       s, tri1, tri2, w.u8(ws, RRL_WS_KJ), w.i32(ws, RRL_WS_HS1),
+                       w.i32(ws, RRL_WS_HS2), w.f32(ws, RRL_WS_W1), w.f32(ws, RRL_WS_W2),
+                       w.f32(ws, RRL_WS_D), w.f32(ws, RRL_WS_MED), w.i32(ws, RRL_WS_BCNT),
+                       w.i32(ws, RRL_WS_INFO), grad_loss, grad_tri1, grad_tri2, B, N, M, L, pool);
     RRL_LAUNCH_CHECK();
     return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// workspace + fused forward
+// ---------------------------------------------------------------------------------------
+extern "C" size_t rrl_workspace_bytes(int B, int N, int M, int L) { return WsLayout(B, N, M, L).total; }
+
+extern "C" int rrl_workspace_layout(int B, int N, int M, int L, size_t *offsets) {
+    if (!offsets || B < 0 || N < 0 || M < 0 || L < 0) return RRL_E_ARG;
+    WsLayout w(B, N, M, L);
+    for (int i = 0; i < RRL_WS_FIELDS; ++i) offsets[i] = w.off[i];
+    return 0;
+}
+
+extern "C" int rrl_loss_forward(const float *tri1, const float *tri2, const float *line, void *ws,
+                                size_t ws_bytes, float *loss, int B, int N, int M, int L, int s_m,
+                                int s_n, int e_m, int e_n, int pool, int mode, int chunk,
+                                void *stream) {
+    if (!tri1 || !tri2 || !line || !ws || !loss) return RRL_E_ARG;
+    if (s_m < 1 || s_n < 1 || e_m > RRL_MAX_HITS + 1 || e_n > RRL_MAX_HITS + 1) return RRL_E_RANGE;
+    int rc;
+    if ((rc = rrl_tri_prepare(tri1, tri2, ws, ws_bytes, B, N, M, L, stream))) return rc;
+    if ((rc = rrl_line_tri_scan(line, ws, ws_bytes, B, N, M, L, mode, chunk, stream))) return rc;
+    if ((rc = rrl_line_pair_dist(tri1, tri2, line, ws, ws_bytes, B, N, M, L, s_m, s_n, e_m, e_n,
+                                 pool, stream)))
+        return rc;
+    return rrl_loss_reduce(ws, ws_bytes, loss, B, N, M, L, s_m, s_n, e_m, e_n, pool, stream);
 }

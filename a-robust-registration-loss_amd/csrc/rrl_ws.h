@@ -1,0 +1,51 @@
+// rrl_ws.h -- layout of the caller-allocated workspace (fields: include/rrl.h RRL_WS_*).
+// The first five fields (status, nvals, pmax, count1, count2) are contiguous so that one
+// hipMemsetAsync clears all per-call state.  Every field starts on a 256-byte boundary.
+#pragma once
+#include "rrl_common.h"
+
+struct WsLayout {
+    size_t off[RRL_WS_FIELDS];
+    size_t total, zero_bytes;
+
+    __host__ WsLayout(int B, int N, int M, int L) {
+        const size_t b = (size_t)(B > 0 ? B : 0), n = (size_t)(N > 0 ? N : 0),
+                     m = (size_t)(M > 0 ? M : 0), l = (size_t)(L > 0 ? L : 0);
+        const size_t bytes[RRL_WS_FIELDS] = {
+            4 * 4,               // STATUS
+            4 * b,               // NVALS
+            4 * 2 * b,           // PMAX
+            4 * b * l,           // COUNT1
+            4 * b * l,           // COUNT2
+            4 * b * l * 4,       // HIT1
+            4 * b * l * 4,       // HIT2
+            4 * b * n * 12,      // PTRI1
+            4 * b * m * 12,      // PTRI2
+            b * l,               // KJ
+            4 * b * l * 4,       // HS1
+            4 * b * l * 4,       // HS2
+            4 * b * l * 12,      // W1
+            4 * b * l * 12,      // W2
+            4 * b * l * 16,      // D
+            4 * b * l * 16,      // VALS
+            4 * b,               // MED   (G <= B)
+            4 * b * 16,          // BCNT
+            8 * b * 32,          // BSUM
+            4 * b * 4,           // INFO
+        };
+        size_t o = 0;
+        for (int i = 0; i < RRL_WS_FIELDS; ++i) {
+            off[i] = o;
+            o += (bytes[i] + 255) & ~(size_t)255;
+            if (i == RRL_WS_COUNT2) zero_bytes = o;
+        }
+        total = o;
+    }
+    __host__ float *f32(void *ws, int f) const { return (float *)((char *)ws + off[f]); }
+    __host__ int32_t *i32(void *ws, int f) const { return (int32_t *)((char *)ws + off[f]); }
+    __host__ uint8_t *u8(void *ws, int f) const { return (uint8_t *)((char *)ws + off[f]); }
+    __host__ int64_t *i64(void *ws, int f) const { return (int64_t *)((char *)ws + off[f]); }
+    __host__ const float *f32(const void *ws, int f) const { return (const float *)((const char *)ws + off[f]); }
+    __host__ const int32_t *i32(const void *ws, int f) const { return (const int32_t *)((const char *)ws + off[f]); }
+    __host__ const uint8_t *u8(const void *ws, int f) const { return (const uint8_t *)((const char *)ws + off[f]); }
+};

@@ -56,14 +56,15 @@ def cal_loss_intersection_batch_whole_median_pts_lines(s_m, s_n, e_m, e_n, point
 
     Raises ValueError on a NaN distance (non-unit line direction), where the reference prints
     "Exit the systerm" and exits with status 0 (code/loss.py:89-91).
-    mode: "strict" (default) | "lazy" (see include/rrl.h), or env RRL_SCAN_MODE.
+    mode: "auto" (default: strict semantics, lazy evaluation where a NaN is provably
+    impossible) | "strict" | "lazy" (see include/rrl.h), or env RRL_SCAN_MODE.
     """
     if points1.dim() != 3 or line.dim() != 3 or points2.dim() != 3:
         raise ValueError("Input is wrong")  # code/loss.py:69-71
     pool = points1.shape[0] > 1
-    loss, nbuckets, status = _ops.intersection_loss(points1, points2, line, (s_m, s_n, e_m, e_n),
-                                                    pool=pool, mode=_scan_mode(mode), chunk=chunk)
-    flags = torch.stack([nbuckets[0], status[0]]).tolist()  # the call's single host sync
+    loss, info, status = _ops.intersection_loss(points1, points2, line, (s_m, s_n, e_m, e_n),
+                                                pool=pool, mode=_scan_mode(mode), chunk=chunk)
+    flags = torch.stack([info[0, 0], status[0]]).tolist()  # the call's single host sync
     if flags[1]:
         raise ValueError("NaN point-to-line distance: line[..., :3] must be unit length or "
                          "all zero (reference: 'Exit the systerm', code/loss.py:88-91)")
@@ -77,16 +78,16 @@ def batched_intersection_loss(points1, points2, line, rng=(1, 1, 5, 5), *, mode=
     with `for j in range(B): loss += cal_loss_...(…[j:j+1]…)` (rpm/Train_RPM.py:226-231,
     dcp/Train_DCP.py:266-270, fmr/model.py:302-306).  Returns (loss (B,), valid (B,) bool) on
     the GPU without any host synchronisation; loss[b] is 0 where valid[b] is False."""
-    loss, nbuckets, _ = _ops.intersection_loss(points1, points2, line, rng, pool=False,
-                                               mode=_scan_mode(mode), chunk=chunk)
-    return loss, nbuckets > 0
+    loss, info, _ = _ops.intersection_loss(points1, points2, line, rng, pool=False,
+                                           mode=_scan_mode(mode), chunk=chunk)
+    return loss, info[:, 0] > 0
 
 
 def _scan_mode(mode):
     import os
-    mode = mode or os.environ.get("RRL_SCAN_MODE", "strict")
-    if mode not in ("strict", "lazy"):
-        raise ValueError("mode must be 'strict' or 'lazy'")
+    mode = mode or os.environ.get("RRL_SCAN_MODE", "auto")
+    if mode not in ("strict", "lazy", "auto"):
+        raise ValueError("mode must be 'auto', 'strict' or 'lazy'")
     return mode
 
 

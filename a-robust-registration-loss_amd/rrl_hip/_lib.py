@@ -15,25 +15,27 @@ _P = _c.c_void_p
 _I = _c.c_int
 
 # name -> argtypes (all return int unless noted)
+_Z = _c.c_size_t
 _SIGS = {
-    "rrl_tri_prepare": [_P, _P, _I, _I, _P],
-    "rrl_loss_begin": [_P, _P, _P, _P, _P, _I, _I, _P],
-    "rrl_line_tri_scan": [_P] * 8 + [_I] * 6 + [_P],
-    "rrl_line_pair_dist": [_P] * 14 + [_I] * 9 + [_P],
-    "rrl_lower_median": [_P, _P, _P, _P, _I, _I, _I, _P],
-    "rrl_welsch_reduce_fwd": [_P, _P, _P, _P, _I, _I, _I, _P],
-    "rrl_loss_finalize": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
-    "rrl_welsch_reduce_bwd": [_P] * 14 + [_I] * 5 + [_P],
+    "rrl_workspace_layout": [_I, _I, _I, _I, _P],
+    "rrl_loss_forward": [_P, _P, _P, _P, _Z, _P] + [_I] * 11 + [_P],
+    "rrl_loss_backward": [_P, _P, _P, _Z, _P, _P, _P] + [_I] * 5 + [_P],
+    "rrl_tri_prepare": [_P, _P, _P, _Z, _I, _I, _I, _I, _P],
+    "rrl_line_tri_scan": [_P, _P, _Z] + [_I] * 6 + [_P],
+    "rrl_line_pair_dist": [_P, _P, _P, _P, _Z] + [_I] * 9 + [_P],
+    "rrl_loss_reduce": [_P, _Z, _P] + [_I] * 9 + [_P],
+    "rrl_set_scan_variant": [_I],
+    "rrl_scan_timing_enable": [_I],
+    "rrl_scan_timing_collect": [_P, _I],
     "rrl_rigid_apply_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "rrl_rigid_bwd_blocks": [_I],
-    "rrl_set_scan_variant": [_I],
     "rrl_rigid_apply_bwd": [_P] * 7 + [_I] * 4 + [_P],
     "rrl_chamfer_fwd": [_P] * 5 + [_I] * 3 + [_P],
     "rrl_chamfer_bwd": [_P] * 7 + [_I] * 3 + [_P],
     "rrl_aabb": [_P, _P, _I, _I, _P],
     "rrl_sample_lines": [_P] * 7 + [_I] * 3 + [_P],
 }
-EXPORTS = sorted(list(_SIGS) + ["rrl_version"])
+EXPORTS = sorted(list(_SIGS) + ["rrl_version", "rrl_workspace_bytes"])
 
 _lib = None
 
@@ -57,6 +59,8 @@ def load():
         fn.argtypes = args
         fn.restype = _I
     lib.rrl_version.restype = ctypes.c_char_p
+    lib.rrl_workspace_bytes.argtypes = [_I, _I, _I, _I]
+    lib.rrl_workspace_bytes.restype = _Z
     _lib = lib
     return lib
 

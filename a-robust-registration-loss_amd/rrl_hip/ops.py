@@ -9,8 +9,33 @@ import torch
 from . import _lib
 from ._lib import RRLError, check
 
-SCAN_STRICT, SCAN_LAZY = 0, 1
-_MODES = {"strict": SCAN_STRICT, "lazy": SCAN_LAZY}
+SCAN_STRICT, SCAN_LAZY, SCAN_AUTO = 0, 1, 2
+_MODES = {"strict": SCAN_STRICT, "lazy": SCAN_LAZY, "auto": SCAN_AUTO}
+
+# workspace fields, in the order of include/rrl.h's RRL_WS_* enum: (name, dtype, shape)
+_WS_FIELDS = [
+    ("status", torch.int32, lambda B, N, M, L, G: (4,)),
+    ("nvals", torch.int32, lambda B, N, M, L, G: (B,)),
+    ("pmax", torch.float32, lambda B, N, M, L, G: (2, B)),
+    ("count1", torch.int32, lambda B, N, M, L, G: (B, L)),
+    ("count2", torch.int32, lambda B, N, M, L, G: (B, L)),
+    ("hit1", torch.int32, lambda B, N, M, L, G: (B, L, 4)),
+    ("hit2", torch.int32, lambda B, N, M, L, G: (B, L, 4)),
+    ("ptri1", torch.float32, lambda B, N, M, L, G: (B, N, 12)),
+    ("ptri2", torch.float32, lambda B, N, M, L, G: (B, M, 12)),
+    ("kj", torch.uint8, lambda B, N, M, L, G: (B, L)),
+    ("hs1", torch.int32, lambda B, N, M, L, G: (B, L, 4)),
+    ("hs2", torch.int32, lambda B, N, M, L, G: (B, L, 4)),
+    ("w1", torch.float32, lambda B, N, M, L, G: (B, L, 4, 3)),
+    ("w2", torch.float32, lambda B, N, M, L, G: (B, L, 4, 3)),
+    ("D", torch.float32, lambda B, N, M, L, G: (B, L, 16)),
+    ("vals", torch.float32, lambda B, N, M, L, G: (B, 16 * L)),
+    ("med", torch.float32, lambda B, N, M, L, G: (G,)),
+    ("bcnt", torch.int32, lambda B, N, M, L, G: (G, 16)),
+    ("bsum", torch.int64, lambda B, N, M, L, G: (G, 16, 2)),
+    ("info", torch.int32, lambda B, N, M, L, G: (G, 4)),
+]
+_layout_cache = {}
 
 
 def require_gpu():
@@ -38,106 +63,126 @@ def _prep(t, name, last=None):
     return t.detach().to(device=dev, dtype=torch.float32).contiguous()
 
 
+def _layout(B, N, M, L):
+    key = (B, N, M, L)
+    if key not in _layout_cache:
+        lib = _lib.load()
+        offs = (ctypes.c_size_t * len(_WS_FIELDS))()
+        check(lib.rrl_workspace_layout(B, N, M, L, offs), "rrl_workspace_layout")
+        _layout_cache[key] = (int(lib.rrl_workspace_bytes(B, N, M, L)), [int(o) for o in offs])
+    return _layout_cache[key]
+
+
 class LossState:
-    """Device buffers of one loss evaluation (scan outputs, per-line sparse data, sums)."""
+    """One loss evaluation: the single device workspace (include/rrl.h RRL_WS_*) that carries
+    every intermediate from forward to backward, plus loss[G].  Named fields are lazy views."""
 
     def __init__(self, B, N, M, L, G, dev):
-        i32, f32 = torch.int32, torch.float32
-        e = lambda *s, dtype=f32: torch.empty(*s, dtype=dtype, device=dev)  # noqa: E731
-        self.ptri1, self.ptri2 = e(B, N, 12), e(B, M, 12)
-        self.count1, self.count2 = e(B, L, dtype=i32), e(B, L, dtype=i32)
-        self.hit1, self.hit2 = e(B, L, 4, dtype=i32), e(B, L, 4, dtype=i32)
-        self.status = e(4, dtype=i32)
-        self.kj = e(B, L, dtype=torch.uint8)
-        self.hs1, self.hs2 = e(B, L, 4, dtype=i32), e(B, L, 4, dtype=i32)
-        self.w1, self.w2 = e(B, L, 4, 3), e(B, L, 4, 3)
-        self.D = e(B, L, 16)
-        self.bsum = e(B, 16, 2, dtype=torch.int64)
-        self.bcnt = e(B, 16, dtype=i32)
-        self.med, self.nval = e(G), e(G, dtype=i32)
-        self.loss, self.nbuckets = e(G), e(G, dtype=i32)
+        self.dims = (B, N, M, L, G)
+        self.nbytes, self.offsets = _layout(B, N, M, L)
+        self.ws = torch.empty(self.nbytes, dtype=torch.uint8, device=dev)
+        self.loss = torch.empty(G, dtype=torch.float32, device=dev)
+
+    def __getattr__(self, name):
+        for i, (fname, dtype, shape) in enumerate(_WS_FIELDS):
+            if fname == name:
+                shp = shape(*self.dims)
+                n = 1
+                for d in shp:
+                    n *= d
+                nb = n * torch.empty((), dtype=dtype).element_size()
+                return self.ws[self.offsets[i]:self.offsets[i] + nb].view(dtype).reshape(shp)
+        raise AttributeError(name)
+
+    @property
+    def nbuckets(self):
+        return self.info[:, 0]
 
 
-def loss_forward_raw(tri1, tri2, line, rng=(1, 1, 5, 5), pool=False, mode="strict", chunk=0,
-                     scan_events=None):
-    """Runs K1'..K4 on already-prepared GPU tensors; returns the LossState.
-    scan_events: optional (start, stop) torch.cuda.Event pair recorded around the scan."""
-    lib = _lib.load()
-    B, N, _ = tri1.shape
-    M, L = tri2.shape[1], line.shape[1]
-    G = 1 if pool else B
+def _check_range(rng):
     s_m, s_n, e_m, e_n = (int(v) for v in rng)
     if not (1 <= s_m and 1 <= s_n and e_m <= 5 and e_n <= 5):
         raise ValueError("bucket range must lie within 1..4 (RRL_MAX_HITS), as every reference "
                          "caller's (1, 1, 5, 5) does")
+    return s_m, s_n, e_m, e_n
+
+
+def loss_forward_raw(tri1, tri2, line, rng=(1, 1, 5, 5), pool=False, mode="auto", chunk=0,
+                     staged=False):
+    """Forward on already-prepared GPU tensors; returns the LossState.  staged=True issues the
+    four stages through their individual C entry points instead of the fused one."""
+    lib = _lib.load()
+    B, N, _ = tri1.shape
+    M, L = tri2.shape[1], line.shape[1]
+    G = 1 if pool else B
+    s_m, s_n, e_m, e_n = _check_range(rng)
     st = LossState(B, N, M, L, G, tri1.device)
-    s = _stream()
-    check(lib.rrl_tri_prepare(_p(tri1), _p(st.ptri1), B, N, s), "rrl_tri_prepare")
-    check(lib.rrl_tri_prepare(_p(tri2), _p(st.ptri2), B, M, s), "rrl_tri_prepare")
-    check(lib.rrl_loss_begin(_p(st.count1), _p(st.count2), _p(st.status), _p(st.bsum),
-                             _p(st.bcnt), B, L, s), "rrl_loss_begin")
-    if scan_events is not None:
-        scan_events[0].record()
-    check(lib.rrl_line_tri_scan(_p(st.ptri1), _p(st.ptri2), _p(line), _p(st.count1), _p(st.hit1),
-                                _p(st.count2), _p(st.hit2), _p(st.status), B, N, M, L,
-                                _MODES[mode], int(chunk), s), "rrl_line_tri_scan")
-    if scan_events is not None:
-        scan_events[1].record()
-    check(lib.rrl_line_pair_dist(_p(tri1), _p(tri2), _p(line), _p(st.count1), _p(st.hit1),
-                                 _p(st.count2), _p(st.hit2), _p(st.kj), _p(st.hs1), _p(st.hs2),
-                                 _p(st.w1), _p(st.w2), _p(st.D), _p(st.bcnt), B, N, M, L, s_m, s_n,
-                                 e_m, e_n, int(pool), s), "rrl_line_pair_dist")
-    check(lib.rrl_lower_median(_p(st.kj), _p(st.D), _p(st.med), _p(st.nval), B, L, int(pool), s),
-          "rrl_lower_median")
-    check(lib.rrl_welsch_reduce_fwd(_p(st.kj), _p(st.D), _p(st.med), _p(st.bsum), B, L, int(pool),
-                                    s), "rrl_welsch_reduce_fwd")
-    check(lib.rrl_loss_finalize(_p(st.bsum), _p(st.bcnt), _p(st.loss), _p(st.nbuckets), G, s_m,
-                                s_n, e_m, e_n, s), "rrl_loss_finalize")
+    s, ws, nb = _stream(), _p(st.ws), st.nbytes
+    if not staged:
+        check(lib.rrl_loss_forward(_p(tri1), _p(tri2), _p(line), ws, nb, _p(st.loss), B, N, M, L,
+                                   s_m, s_n, e_m, e_n, int(pool), _MODES[mode], int(chunk), s),
+              "rrl_loss_forward")
+        return st
+    check(lib.rrl_tri_prepare(_p(tri1), _p(tri2), ws, nb, B, N, M, L, s), "rrl_tri_prepare")
+    check(lib.rrl_line_tri_scan(_p(line), ws, nb, B, N, M, L, _MODES[mode], int(chunk), s),
+          "rrl_line_tri_scan")
+    check(lib.rrl_line_pair_dist(_p(tri1), _p(tri2), _p(line), ws, nb, B, N, M, L, s_m, s_n, e_m,
+                                 e_n, int(pool), s), "rrl_line_pair_dist")
+    check(lib.rrl_loss_reduce(ws, nb, _p(st.loss), B, N, M, L, s_m, s_n, e_m, e_n, int(pool), s),
+          "rrl_loss_reduce")
     return st
 
 
 class _IntersectionLoss(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, points1, points2, line, rng, pool, mode, chunk, scan_events):
+    def forward(ctx, points1, points2, line, rng, pool, mode, chunk):
         tri1, tri2 = _prep(points1, "points1", 9), _prep(points2, "points2", 9)
         ln = _prep(line, "line", 6)
         if tri1.dim() != 3 or tri2.dim() != 3 or ln.dim() != 3:
             raise ValueError("Input is wrong: points1/points2/line must be 3-D (B, n, c)")
         if not (tri1.shape[0] == tri2.shape[0] == ln.shape[0]):
             raise ValueError("points1, points2 and line must share the batch dimension")
-        st = loss_forward_raw(tri1, tri2, ln, rng, pool, mode, chunk, scan_events)
+        st = loss_forward_raw(tri1, tri2, ln, rng, pool, mode, chunk)
         ctx.st, ctx.tri1, ctx.tri2, ctx.pool = st, tri1, tri2, bool(pool)
         ctx.in_devs = (points1.device, points2.device)
-        ctx.mark_non_differentiable(st.nbuckets, st.status)
-        return st.loss, st.nbuckets, st.status
+        info, status = st.info, st.status
+        ctx.mark_non_differentiable(info, status)
+        return st.loss, info, status
 
     @staticmethod
     def backward(ctx, g_loss, _g1, _g2):
         lib = _lib.load()
         st, tri1, tri2 = ctx.st, ctx.tri1, ctx.tri2
         B, N, _ = tri1.shape
-        M, L = tri2.shape[1], st.kj.shape[1]
+        M, L = tri2.shape[1], st.dims[3]
         g = g_loss.detach().to(device=tri1.device, dtype=torch.float32).contiguous()
-        g1 = torch.zeros_like(tri1)
-        g2 = torch.zeros_like(tri2) if ctx.needs_input_grad[1] else None
-        check(lib.rrl_welsch_reduce_bwd(_p(tri1), _p(tri2), _p(st.kj), _p(st.hs1), _p(st.hs2),
-                                        _p(st.w1), _p(st.w2), _p(st.D), _p(st.med), _p(st.bcnt),
-                                        _p(st.nbuckets), _p(g), _p(g1), _p(g2), B, N, M, L,
-                                        int(ctx.pool), _stream()), "rrl_welsch_reduce_bwd")
+        g1 = torch.empty_like(tri1)  # zeroed by rrl_loss_backward
+        g2 = torch.empty_like(tri2) if ctx.needs_input_grad[1] else None
+        check(lib.rrl_loss_backward(_p(tri1), _p(tri2), _p(st.ws), st.nbytes, _p(g), _p(g1), _p(g2),
+                                    B, N, M, L, int(ctx.pool), _stream()), "rrl_loss_backward")
         g1 = g1.to(ctx.in_devs[0]) if ctx.needs_input_grad[0] else None
         if g2 is not None:
             g2 = g2.to(ctx.in_devs[1])
-        return g1, g2, None, None, None, None, None, None
+        return g1, g2, None, None, None, None, None
 
 
-def intersection_loss(points1, points2, line, rng=(1, 1, 5, 5), pool=False, mode="strict",
-                      chunk=0, scan_events=None):
-    """Batched loss: returns (loss[G], nbuckets[G], status[4]) on the GPU, G = 1 if pool else B.
-    Each sample is an independent loss (the semantics every reference caller obtains by
-    looping B=1 calls); pool=True reproduces the reference's own B>1 behaviour.
-    No host synchronisation happens here."""
-    return _IntersectionLoss.apply(points1, points2, line, tuple(rng), pool, mode, chunk,
-                                   scan_events)
+def intersection_loss(points1, points2, line, rng=(1, 1, 5, 5), pool=False, mode="auto", chunk=0):
+    """Batched loss: returns (loss[G], info[G,4] = (nbuckets, nselected, nvalues, 0), status[4])
+    on the GPU, G = 1 if pool else B.  Each sample is an independent loss (what every reference
+    caller obtains by looping B=1 calls); pool=True reproduces the reference's own B>1 behaviour
+    (SURVEY Q2).  No host synchronisation happens here."""
+    return _IntersectionLoss.apply(points1, points2, line, tuple(rng), pool, mode, chunk)
+
+
+def scan_timing(enable):
+    """Profiling hook: bracket every scan launch with HIP events (include/rrl.h)."""
+    check(_lib.load().rrl_scan_timing_enable(int(bool(enable))), "rrl_scan_timing_enable")
+
+
+def scan_timing_collect(max_n=1024):
+    buf = (ctypes.c_float * max_n)()
+    n = _lib.load().rrl_scan_timing_collect(buf, max_n)
+    return [float(buf[i]) for i in range(n)]
 
 
 # ---------------------------------------------------------------------------------------

@@ -11,7 +11,8 @@
  *
  * Conventions
  *   - every pointer is a DEVICE pointer owned by the caller (PyTorch's
- *     allocator); the library allocates nothing and never synchronises;
+ *     allocator); the library allocates no device memory and never
+ *     synchronises (the optional scan-timing hook owns a few hipEvents);
  *   - `stream` is a hipStream_t (pass torch's current stream);
  *   - return value: 0 ok, <0 argument error (RRL_E_*), >0 a hipError_t;
  *   - all floating-point data is fp32, dense and contiguous;
@@ -20,7 +21,9 @@
  * Layouts
  *   tri   [B][N][9]   pseudo-triangles, row = P0 P1 P2 (xyz interleaved)
  *   line  [B][L][6]   dir(3) (unit length, or all zero), x0(3)
- *   ptri  [B][N][12]  prepared triangles: 9 coords, thr2, thr, 0
+ *   ws    one caller-allocated workspace of rrl_workspace_bytes() bytes that
+ *         carries every intermediate from forward to backward; field offsets
+ *         come from rrl_workspace_layout().
  */
 #ifndef RRL_H
 #define RRL_H
@@ -35,83 +38,111 @@ extern "C" {
 #define RRL_MAX_HITS 4 /* hits kept per line and cloud: callers use buckets 1..4 */
 #define RRL_E_ARG (-1)
 #define RRL_E_RANGE (-2) /* bucket range outside 1..RRL_MAX_HITS */
-
-/* status word indices (int32 status[RRL_STATUS_WORDS], zeroed by rrl_loss_begin) */
-#define RRL_STATUS_NAN 0 /* negative sqrt argument seen: reference exit(0), loss.py:89-91 */
-#define RRL_STATUS_WORDS 4
+#define RRL_E_WS (-3)    /* workspace too small */
 
 /* scan modes */
-#define RRL_SCAN_STRICT 0 /* evaluate all 3 points of every (line, triangle): exact NaN flag */
-#define RRL_SCAN_LAZY 1   /* points 1,2 only where point 0 passes; same labels, NaN flag
-                             covers evaluated points only */
+#define RRL_SCAN_STRICT 0 /* all 3 points of every (line, triangle) are evaluated */
+#define RRL_SCAN_LAZY 1   /* points 1,2 only where point 0 passes: same labels; a NaN (negative
+                             sqrt argument) is reported only if it occurs in an evaluated pair */
+#define RRL_SCAN_AUTO 2   /* per wavefront: lazy where a NaN is provably impossible for its
+                             lines (|dir|^2 <= 1+4e-7 and (|x0| + max|P|)^2 <= 150), else strict.
+                             Same results AND same NaN detection as strict.  Default. */
+
+/* workspace fields (indices into rrl_workspace_layout's offset array) */
+enum {
+    RRL_WS_STATUS = 0, /* int32[4]   [0] = NaN seen (reference exit(0), loss.py:89-91)      */
+    RRL_WS_NVALS,      /* int32[B]   D values appended per sample                           */
+    RRL_WS_PMAX,       /* uint32[2][B] bits of max |P|^2 per cloud and sample                */
+    RRL_WS_COUNT1,     /* int32[B][L] hit count, cloud 1 (loss.py:185)                      */
+    RRL_WS_COUNT2,     /* int32[B][L]                                                      */
+    RRL_WS_HIT1,       /* int32[B][L][4] unordered hit indices                              */
+    RRL_WS_HIT2,
+    RRL_WS_PTRI1,      /* float[B][N][12] 9 coords, thr2, thr, 0                            */
+    RRL_WS_PTRI2,      /* float[B][M][12]                                                   */
+    RRL_WS_KJ,         /* uint8[B][L]  k | j<<4, 0 = line not selected                      */
+    RRL_WS_HS1,        /* int32[B][L][4] ascending hit indices (nonzero() order)            */
+    RRL_WS_HS2,
+    RRL_WS_W1,         /* float[B][L][4][3] weights d / sum d (loss.py:92)                  */
+    RRL_WS_W2,
+    RRL_WS_D,          /* float[B][L][16] k x j block of |q1-q2|^2 (loss.py:165-166)        */
+    RRL_WS_VALS,       /* float[B][16 L] compacted D values (median input)                  */
+    RRL_WS_MED,        /* float[G]  lower median (loss.py:223-224)                          */
+    RRL_WS_BCNT,       /* int32[G][16] lines per (k,j) bucket                               */
+    RRL_WS_BSUM,       /* int64[G][16][2] bucket sums of row / column minima, 2^-40 fixed pt */
+    RRL_WS_INFO,       /* int32[G][4] nbuckets, nselected, nvalues, 0                       */
+    RRL_WS_FIELDS
+};
 
 const char *rrl_version(void);
 
-/* Prepared triangles: per-triangle threshold thr = mean edge * 1.731 / 2
- * (code/loss.py:94-110) and thr2 = the smallest fp32 x with sqrt(x) >= thr, so
- * that "sqrt(x) < thr" (loss.py:107-110) is decided exactly by "x < thr2". */
-int rrl_tri_prepare(const float *tri, float *ptri, int B, int N, void *stream);
+size_t rrl_workspace_bytes(int B, int N, int M, int L);
+/* offsets[RRL_WS_FIELDS] in bytes from the workspace base */
+int rrl_workspace_layout(int B, int N, int M, int L, size_t *offsets);
 
-/* Zero the per-call state (count1/count2, status, bucket sums). */
-int rrl_loss_begin(int32_t *count1, int32_t *count2, int32_t *status, int64_t *bsum,
-                   int32_t *bcnt, int B, int L, void *stream);
+/* ---- fused entry points (what loss.py calls) ------------------------------------------ */
 
-/* Dense line <-> pseudo-triangle scan of both clouds in one launch
- * (code/loss.py:68-112 for points1 and points2, :181-186).  Emits per line the
- * hit count and the (unordered) indices of the first RRL_MAX_HITS hits; nothing
- * of size L*N is materialised.  count/hit must have been zeroed by rrl_loss_begin.
- * chunk = triangles per workgroup (0 = default). */
-int rrl_line_tri_scan(const float *ptri1, const float *ptri2, const float *line,
-                      int32_t *count1, int32_t *hit1, int32_t *count2, int32_t *hit2,
-                      int32_t *status, int B, int N, int M, int L, int mode, int chunk,
-                      void *stream);
+/* Forward of cal_loss_intersection_batch_whole_median_pts_lines (code/loss.py:170-232) for
+ * B samples in 4 launches: prepare -> scan -> per-line distances -> median + Welsch reduce.
+ *   loss [G], G = pool ? 1 : B.  pool != 0 reproduces the reference's own B>1 behaviour
+ *   (all lines pooled, LAST sample's median: SURVEY.md Q2); pool == 0 gives B independent
+ *   losses (what the reference's callers compute by looping B = 1 calls).
+ *   loss[g] is 0 and INFO[g][0] == 0 where no (k,j) bucket is populated (the reference
+ *   returns (None, None, None), loss.py:231-232).
+ * chunk = triangles per workgroup of the scan (0 = default). */
+int rrl_loss_forward(const float *tri1, const float *tri2, const float *line, void *ws,
+                     size_t ws_bytes, float *loss, int B, int N, int M, int L, int s_m, int s_n,
+                     int e_m, int e_n, int pool, int mode, int chunk, void *stream);
 
-/* Tuning/testing knob: lines per lane of the scan kernel (1 = scalar fp32, 2 / 4 = one / two
- * packed v_pk_*_f32 pairs).  All variants produce identical results.  Default 2, or env
- * RRL_SCAN_VARIANT. */
+/* Closed-form backward (autograd of code/loss.py:170-232).
+ * grad_loss [G]; grad_tri1 [B][N][9] is zeroed then accumulated; grad_tri2 may be NULL. */
+int rrl_loss_backward(const float *tri1, const float *tri2, const void *ws, size_t ws_bytes,
+                      const float *grad_loss, float *grad_tri1, float *grad_tri2, int B, int N,
+                      int M, int L, int pool, void *stream);
+
+/* ---- the four forward stages, individually (tests, profiling) ------------------------- */
+
+/* K1': prepared triangles for both clouds + zeroing of the per-call state.
+ * thr = mean edge * 1.731 / 2 (code/loss.py:94-110); thr2 = the smallest fp32 x with
+ * sqrt(x) >= thr, so that "sqrt(x) < thr" (loss.py:107-110) is decided exactly by x < thr2. */
+int rrl_tri_prepare(const float *tri1, const float *tri2, void *ws, size_t ws_bytes, int B, int N,
+                    int M, int L, void *stream);
+
+/* K1: dense line <-> pseudo-triangle scan of both clouds in one launch
+ * (code/loss.py:68-112 for points1 and points2, :181-186).  Emits per line the hit count and
+ * the (unordered) indices of the first RRL_MAX_HITS hits; nothing of size L*N is written. */
+int rrl_line_tri_scan(const float *line, void *ws, size_t ws_bytes, int B, int N, int M, int L,
+                      int mode, int chunk, void *stream);
+
+/* K2: per-line sparse stage (code/loss.py:115-167): for lines whose two hit counts fall in
+ * [s_m,e_m) x [s_n,e_n): hits sorted ascending (nonzero() order), weights w = d / sum d
+ * (loss.py:92), intersection points q = mean_k w_k P_k (loss.py:155-163),
+ * D[a][b] = |q1_a - q2_b|^2 (loss.py:165-166), and the D values appended to VALS. */
+int rrl_line_pair_dist(const float *tri1, const float *tri2, const float *line, void *ws,
+                       size_t ws_bytes, int B, int N, int M, int L, int s_m, int s_n, int e_m,
+                       int e_n, int pool, void *stream);
+
+/* K3+K4: lower median (torch.median: sorted[(n-1)/2], loss.py:223-224), Welsch weighting
+ * 1 - exp(-(D/med)/2) with symmetric min/mean per bucket (loss.py:20-21, 226-229), bucket
+ * weights exp(-|k-j|/2) and the final division by the number of non-empty buckets
+ * (loss.py:215-217, 230).  One workgroup per sample; bucket sums in 2^-40 fixed point, so
+ * the result does not depend on summation order. */
+int rrl_loss_reduce(void *ws, size_t ws_bytes, float *loss, int B, int N, int M, int L, int s_m,
+                    int s_n, int e_m, int e_n, int pool, void *stream);
+
+/* Tuning/testing knobs.  rrl_set_scan_variant: lines per lane of the scan (1 = scalar fp32,
+ * 2 / 4 / 8 = one / two / four packed v_pk_*_f32 pairs); 0 = default.  All variants give
+ * identical results.  Env RRL_SCAN_VARIANT / RRL_SCAN_CHUNK override the defaults. */
 int rrl_set_scan_variant(int lines_per_lane);
 
-/* Per-line sparse stage (code/loss.py:115-167): for lines whose two hit counts
- * fall in [s_m,e_m) x [s_n,e_n): sort hits ascending (nonzero() order), weights
- * w = d / sum d (loss.py:92), intersection points q = mean_k w_k P_k
- * (loss.py:155-163) and D[a][b] = |q1_a - q2_b|^2 (loss.py:165-166).
- *   kj   [B][L]       k | j<<4, 0 = line not selected
- *   hs1  [B][L][4]    sorted hit indices (cloud 1), hs2 likewise
- *   w1   [B][L][4][3] weights, w2 likewise
- *   D    [B][L][16]   row-major k x j block
- *   bcnt [G][16]      lines per bucket (G = pool ? 1 : B)                    */
-int rrl_line_pair_dist(const float *tri1, const float *tri2, const float *line,
-                       const int32_t *count1, const int32_t *hit1, const int32_t *count2,
-                       const int32_t *hit2, uint8_t *kj, int32_t *hs1, int32_t *hs2, float *w1,
-                       float *w2, float *D, int32_t *bcnt, int B, int N, int M, int L, int s_m,
-                       int s_n, int e_m, int e_n, int pool, void *stream);
+/* Profiling hook: when enabled, every scan launch is bracketed by a hipEvent pair (ring of
+ * 1024) recorded on the launch stream; collect() synchronises them, writes up to max_n
+ * durations in milliseconds and resets the ring.  Returns the number written. */
+int rrl_scan_timing_enable(int on);
+int rrl_scan_timing_collect(float *ms, int max_n);
 
-/* Lower median (torch.median: sorted[(n-1)/2]) of all selected D values per sample
- * (code/loss.py:223-224).  pool != 0 reproduces the reference's B>1 behaviour:
- * one median, taken over the LAST sample's values.
- *   med [G], nval [G] */
-int rrl_lower_median(const uint8_t *kj, const float *D, float *med, int32_t *nval, int B, int L,
-                     int pool, void *stream);
-
-/* Welsch weighting + symmetric min/mean reduction (code/loss.py:20-21, 226-230).
- * Bucket sums are accumulated in 2^-40 fixed point (bit-deterministic);
- * rrl_loss_finalize turns them into loss[G], nbuckets[G]. */
-int rrl_welsch_reduce_fwd(const uint8_t *kj, const float *D, const float *med, int64_t *bsum,
-                          int B, int L, int pool, void *stream);
-int rrl_loss_finalize(const int64_t *bsum, const int32_t *bcnt, float *loss, int32_t *nbuckets,
-                      int G, int s_m, int s_n, int e_m, int e_n, void *stream);
-
-/* Closed-form backward of the whole loss (autograd of code/loss.py:170-232;
- * SURVEY.md section 8a row G).  grad_tri1 [B][N][9] must be zeroed by the caller;
- * grad_tri2 may be NULL.  grad_loss [G]. */
-int rrl_welsch_reduce_bwd(const float *tri1, const float *tri2, const uint8_t *kj,
-                          const int32_t *hs1, const int32_t *hs2, const float *w1, const float *w2,
-                          const float *D, const float *med, const int32_t *bcnt,
-                          const int32_t *nbuckets, const float *grad_loss, float *grad_tri1,
-                          float *grad_tri2, int B, int N, int M, int L, int pool, void *stream);
-
-/* Rigid apply (code/loss.py:460-461; rpm/common/math_torch/se3.py:67-72;
- * code/utils.py:32-37; fmr/se_math/se3.py:110-124).
+/* ---- rigid apply ----------------------------------------------------------------------- */
+/* code/loss.py:460-461; rpm/common/math_torch/se3.py:67-72; code/utils.py:32-37;
+ * fmr/se_math/se3.py:110-124.
  *   transpose_r = 0: y = x R + t   (row-vector convention of Reconstruction_point)
  *   transpose_r = 1: y = x R^T + t (= R x + t per point: RPM/DCP/FMR)
  *   channel_first = 0: x,y are [B][n][3];  1: [B][3][n] (DCP)
@@ -125,21 +156,21 @@ int rrl_rigid_apply_bwd(const float *x, const float *R, const float *gy, float *
                         float *gt, float *partial, int B, int n, int transpose_r,
                         int channel_first, void *stream);
 
-/* Chamfer monitor (code/loss.py:38-52, 236-252).  best_x [B][N], best_y [B][M] are
- * u64 keys (dist bits << 32 | argmin), set to all-ones by the call itself.
- * value[0] = mean of all B*(N+M) minima. */
+/* ---- Chamfer monitor (code/loss.py:38-52, 236-252) -------------------------------------- */
+/* best_x [B][N], best_y [B][M] are u64 keys (dist bits << 32 | argmin), set to all-ones by
+ * the call itself.  value[0] = mean of all B*(N+M) minima. */
 int rrl_chamfer_fwd(const float *x, const float *y, uint64_t *best_x, uint64_t *best_y,
                     float *value, int B, int N, int M, void *stream);
 int rrl_chamfer_bwd(const float *x, const float *y, const uint64_t *best_x,
                     const uint64_t *best_y, const float *grad_value, float *gx, float *gy, int B,
                     int N, int M, void *stream);
 
-/* Line sampler (code/loss.py:265-432).
- * rrl_aabb: per-sample min/max -> aabb [B][6] = min xyz, max xyz (loss.py:325-351).
+/* ---- line sampler (code/loss.py:265-432) ------------------------------------------------- */
+/* rrl_aabb: per-sample min/max -> aabb [B][6] = min xyz, max xyz (loss.py:325-351).
  * rrl_sample_lines: all `rounds` rejection rounds in one launch.
  *   rands [rounds][4][B][n] uniform [0,1) draws in the reference's stream order
  *   r [B], centers [B][3], aabb1/aabb2 [B][6] (both NULL: keep every candidate, loss.py:384-412)
- *   lines [B][n][6] (zeroed by the call), filled [B] = accepted so far (may exceed n) */
+ *   lines [B][n][6] (unfilled rows zeroed by the call), filled [B] = accepted (may exceed n) */
 int rrl_aabb(const float *v, float *aabb, int B, int n, void *stream);
 int rrl_sample_lines(const float *rands, const float *r, const float *centers, const float *aabb1,
                      const float *aabb2, float *lines, int32_t *filled, int B, int n, int rounds,

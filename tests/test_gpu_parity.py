@@ -32,12 +32,12 @@ def cu(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
-def run_state(tri1, tri2, lines, rng=(1, 1, 5, 5), pool=False, mode="strict", chunk=0):
+def run_state(tri1, tri2, lines, rng=(1, 1, 5, 5), pool=False, mode="auto", chunk=0, staged=False):
     from rrl_hip import ops
     t1, t2, ln = cu(tri1), cu(tri2), cu(lines)
     if t1.dim() == 2:
         t1, t2, ln = t1[None], t2[None], ln[None]
-    st = ops.loss_forward_raw(t1, t2, ln, rng, pool, mode, chunk)
+    st = ops.loss_forward_raw(t1, t2, ln, rng, pool, mode, chunk, staged)
     torch.cuda.synchronize()
     return st
 
@@ -58,7 +58,7 @@ def test_tri_prepare_exact(L, oracle):
 
 # ---------------------------------------------------------------------------------- K1
 @pytest.mark.parametrize("name", LOSS_FIXTURES)
-@pytest.mark.parametrize("mode", ["strict", "lazy"])
+@pytest.mark.parametrize("mode", ["strict", "lazy", "auto"])
 def test_scan_counts_and_hits(L, oracle, name, mode):
     g = load_golden(name)
     st = run_state(g["tri1"], g["tri2"], g["lines"], mode=mode)
@@ -72,20 +72,39 @@ def test_scan_counts_and_hits(L, oracle, name, mode):
             assert sorted(hit[l, :cnt[l]].tolist()) == o["hit_idx"][l, :cnt[l]].tolist()
 
 
-@pytest.mark.parametrize("variant", [1, 2, 4])
+@pytest.mark.parametrize("variant", [1, 2, 4, 8])
 @pytest.mark.parametrize("chunk", [0, 64, 1000])
-def test_scan_variants_identical(L, variant, chunk):
+@pytest.mark.parametrize("mode", ["strict", "lazy"])
+def test_scan_variants_identical(L, variant, chunk, mode):
     from rrl_hip import _lib
     g = load_golden("loss_synth_s1.npz")
     lib = _lib.load()
     try:
         assert lib.rrl_set_scan_variant(variant) == 0
-        st = run_state(g["tri1"], g["tri2"], g["lines"], chunk=chunk)
+        st = run_state(g["tri1"], g["tri2"], g["lines"], chunk=chunk, mode=mode, staged=True)
         np.testing.assert_array_equal(st.count1[0].cpu().numpy(), g["count1"])
         np.testing.assert_array_equal(st.count2[0].cpu().numpy(), g["count2"])
         np.testing.assert_allclose(st.loss.cpu().numpy()[0], g["r0_loss"], rtol=1e-5)
     finally:
-        lib.rrl_set_scan_variant(2)
+        lib.rrl_set_scan_variant(0)
+
+
+def test_auto_mode_picks_lazy_only_when_nan_is_impossible(L):
+    """Unit-scale data: auto == lazy == strict bit for bit.  Demo-scale data ((|x0|+|P|)^2 > 100)
+    and non-unit directions must take the strict loop, so the NaN flag is still raised."""
+    g = load_golden("loss_synth_s0.npz")
+    a, s_, z = (run_state(g["tri1"], g["tri2"], g["lines"], mode=m) for m in ("auto", "strict", "lazy"))
+    assert a.loss[0].item() == s_.loss[0].item() == z.loss[0].item()
+    assert float(a.pmax.max()) < 4.0
+    d = load_golden("loss_demo_scale.npz")
+    bad = d["lines"].copy()
+    bad[5, :3] *= 1.5  # one non-unit direction among thousands of good lines
+    assert int(run_state(d["tri1"], d["tri2"], bad, mode="strict").status[0]) == 1
+    assert int(run_state(d["tri1"], d["tri2"], bad, mode="auto").status[0]) == 1
+    bad2 = g["lines"].copy()
+    bad2[77, :3] *= 40.0
+    assert int(run_state(g["tri1"], g["tri2"], bad2, mode="strict").status[0]) == 1
+    assert int(run_state(g["tri1"], g["tri2"], bad2, mode="auto").status[0]) == 1
 
 
 # ---------------------------------------------------------------------------------- K2..K4
@@ -109,7 +128,8 @@ def test_sparse_stage_vs_oracle(L, oracle, name):
         np.testing.assert_array_equal(mine, o["D"])  # same arithmetic, same bits
         np.testing.assert_allclose(mine, g[f"r{i}_D"], rtol=2e-5, atol=1e-9)
         assert float(st.med[0]) == float(o["median"])
-        assert int(st.nval[0]) == o["n_values"] and int(st.nbuckets[0]) == o["n_buckets"]
+        assert int(st.info[0, 2]) == o["n_values"] and int(st.nbuckets[0]) == o["n_buckets"]
+        assert int(st.info[0, 1]) == o["n_selected"]
         np.testing.assert_allclose(float(st.loss[0]), o["loss"], rtol=2e-6)
         np.testing.assert_allclose(float(st.loss[0]), g[f"r{i}_loss"], rtol=1e-5)
 

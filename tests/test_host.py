@@ -34,10 +34,18 @@ def test_abi_argument_errors(libpath):
     """Argument validation happens on the host before any HIP call."""
     from rrl_hip import _lib
     lib = _lib.load()
-    assert lib.rrl_tri_prepare(None, None, 1, 1, None) == -1
+    assert lib.rrl_tri_prepare(None, None, None, 0, 1, 1, 1, 1, None) == -1
     assert lib.rrl_set_scan_variant(3) == -1
     assert lib.rrl_rigid_bwd_blocks(5000) == 3
-    assert lib.rrl_loss_finalize(None, None, None, None, 1, 1, 1, 5, 5, None) == -1
+    assert lib.rrl_loss_reduce(None, 0, None, 1, 1, 1, 1, 1, 1, 5, 5, 0, None) == -1
+    # workspace layout: 256-byte aligned, monotone, inside the reported size
+    import ctypes as C
+    offs = (C.c_size_t * 20)()
+    assert lib.rrl_workspace_layout(8, 4096, 4096, 10000, offs) == 0
+    total = lib.rrl_workspace_bytes(8, 4096, 4096, 10000)
+    o = [int(v) for v in offs]
+    assert o[0] == 0 and o == sorted(o) and all(v % 256 == 0 for v in o) and o[-1] < total
+    assert total < 64 << 20
 
 
 def test_no_gpu_fails_loudly():

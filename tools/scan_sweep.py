@@ -28,37 +28,32 @@ def main():
         torch.tensor([float(p["radius"]) for p in prs]).reshape(B, 1),
         torch.from_numpy(np.stack([p["center"] for p in prs])), Lines, src, tar, dev)
     lib = _lib.load()
-    st = ops.loss_forward_raw(tri1, tri2, lines)
+    st = ops.loss_forward_raw(tri1, tri2, lines, mode="strict")
     torch.cuda.synchronize()
     base = (st.count1.sum().item(), st.count2.sum().item(), st.loss.tolist())
     print(json.dumps({"hits1": base[0], "hits2": base[1], "loss": base[2]}))
     pairs = B * Lines * 3 * 2 * N
-    s = ops._stream()
-    for variant in (1, 2, 4):
+    s, ws, nb = ops._stream(), ops._p(st.ws), st.nbytes
+    variants = [int(v) for v in os.environ.get("SWEEP_VARIANTS", "2,4,8").split(",")]
+    chunks = [int(v) for v in os.environ.get("SWEEP_CHUNKS", "64,128,256,512").split(",")]
+    ops.scan_timing(True)
+    for variant in variants:
         lib.rrl_set_scan_variant(variant)
-        for mode in (0, 1):
-            for chunk in (64, 128, 256, 512, 1024, 4096):
-                ts = []
+        for mode in (0, 1, 2):
+            for chunk in chunks:
                 for it in range(8):
-                    lib.rrl_loss_begin(ops._p(st.count1), ops._p(st.count2), ops._p(st.status),
-                                       ops._p(st.bsum), ops._p(st.bcnt), B, Lines, s)
-                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    a.record()
-                    rc = lib.rrl_line_tri_scan(ops._p(st.ptri1), ops._p(st.ptri2), ops._p(lines),
-                                               ops._p(st.count1), ops._p(st.hit1), ops._p(st.count2),
-                                               ops._p(st.hit2), ops._p(st.status), B, N, N, Lines,
-                                               mode, chunk, s)
-                    b.record()
-                    assert rc == 0
-                    torch.cuda.synchronize()
-                    ts.append(a.elapsed_time(b))
+                    assert lib.rrl_tri_prepare(ops._p(tri1), ops._p(tri2), ws, nb, B, N, N, Lines, s) == 0
+                    assert lib.rrl_line_tri_scan(ops._p(lines), ws, nb, B, N, N, Lines, mode, chunk, s) == 0
+                torch.cuda.synchronize()
+                ts = ops.scan_timing_collect()
                 ok = (st.count1.sum().item(), st.count2.sum().item()) == base[:2]
                 ms = float(np.median(ts[2:]))
-                print(json.dumps({"variant": variant, "mode": "lazy" if mode else "strict",
+                print(json.dumps({"variant": variant, "mode": ["strict", "lazy", "auto"][mode],
                                   "chunk": chunk, "ms": round(ms, 4), "min_ms": round(min(ts), 4),
                                   "Gpairs_s": round(pairs / ms / 1e6, 1),
                                   "TFLOPs": round(18 * pairs / ms / 1e9, 2), "same_counts": ok}))
-    lib.rrl_set_scan_variant(2)
+    ops.scan_timing(False)
+    lib.rrl_set_scan_variant(0)
 
 
 if __name__ == "__main__":
