@@ -2,7 +2,7 @@
 //   K6 code/loss.py:458-463 (+ the RPM/DCP/FMR layouts, see include/rrl.h)   HBM-bound
 //   K7 code/loss.py:38-52, 236-252                                           VALU-bound, N*M pairs
 //   K8 code/loss.py:265-432                                                  tiny
-#include "rrl_common.h"
+#include "rrl_ws.h"
 
 typedef const float __attribute__((address_space(4))) * kptr;  // constant AS -> s_load
 
@@ -447,6 +447,36 @@ extern "C" int rrl_sample_lines(const float *rands, const float *r, const float 
     if (B == 0 || n == 0) return 0;
     hipLaunchKernelGGL(sample_lines_kernel, dim3((unsigned)B), dim3(1024), 0, (hipStream_t)stream,
                        rands, r, centers, aabb1, aabb2, lines, filled, B, n, rounds);
+    RRL_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// batch-shard payload: what one rank contributes to the all-reduce
+// ---------------------------------------------------------------------------------------
+__global__ void shard_payload_kernel(const float *__restrict__ loss, const int32_t *__restrict__ info,
+                                     const float *__restrict__ gR, const float *__restrict__ gt,
+                                     float *__restrict__ out, int B) {
+    const int q = threadIdx.x;
+    if (q >= 14) return;
+    double s = 0.0;
+    for (int b = 0; b < B; ++b) {
+        if (q == 0) s += info[b * 4] > 0 ? (double)loss[b] : 0.0;
+        else if (q == 1) s += info[b * 4] > 0 ? 1.0 : 0.0;
+        else if (q < 11) s += gR ? (double)gR[b * 9 + (q - 2)] : 0.0;
+        else s += gt ? (double)gt[b * 3 + (q - 11)] : 0.0;
+    }
+    out[q] = (float)s;
+}
+
+extern "C" int rrl_shard_payload(const float *loss, const void *ws, size_t ws_bytes, const float *gR,
+                                 const float *gt, float *out, int B, int N, int M, int L,
+                                 void *stream) {
+    if (!loss || !ws || !out || B < 0) return RRL_E_ARG;
+    WsLayout w(B, N, M, L);
+    if (ws_bytes < w.total) return RRL_E_WS;
+    hipLaunchKernelGGL(shard_payload_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, loss,
+                       w.i32(ws, RRL_WS_INFO), gR, gt, out, B);
     RRL_LAUNCH_CHECK();
     return 0;
 }

@@ -46,22 +46,50 @@ __device__ __forceinline__ void sort4(int *h, int n) {  // ascending, n <= 4
             if (j < n && h[j] < h[j - 1]) { int t = h[j]; h[j] = h[j - 1]; h[j - 1] = t; }
 }
 
-__global__ __launch_bounds__(256) void line_pair_dist_kernel(
+// 1024 lines per workgroup.  Phase 1: every lane classifies its line and the selected ones
+// (~9 %) are compacted through LDS, so that phase 2 -- the gather-heavy part -- runs on dense
+// wavefronts; the compacted line ids also go to SEL[b] for the reduce and backward kernels.
+__global__ __launch_bounds__(1024) void line_pair_dist_kernel(
     const float *__restrict__ tri1, const float *__restrict__ tri2, const float *__restrict__ line,
     const int32_t *__restrict__ count1, const int32_t *__restrict__ hit1,
     const int32_t *__restrict__ count2, const int32_t *__restrict__ hit2,
-    uint8_t *__restrict__ kj, int32_t *__restrict__ hs1, int32_t *__restrict__ hs2,
-    float *__restrict__ w1, float *__restrict__ w2, float *__restrict__ D,
-    float *__restrict__ vals, int32_t *__restrict__ nvals, int B, int N, int M, int L, int s_m,
-    int s_n, int e_m, int e_n, int pool) {
-    const int l = blockIdx.x * 256 + threadIdx.x;
+    uint8_t *__restrict__ kj, int32_t *__restrict__ sel_out, int32_t *__restrict__ nsel,
+    int32_t *__restrict__ hs1, int32_t *__restrict__ hs2, float *__restrict__ w1,
+    float *__restrict__ w2, float *__restrict__ D, float *__restrict__ vals,
+    int32_t *__restrict__ nvals, int B, int N, int M, int L, int s_m, int s_n, int e_m, int e_n,
+    int pool) {
+    __shared__ int s_list[1024];
+    __shared__ int s_wave[16];
+    __shared__ int s_total, s_base;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.y;
-    if (l >= L) return;
+    {
+        const int l = blockIdx.x * 1024 + tid;
+        bool sel = false;
+        if (l < L) {
+            const size_t gl = (size_t)b * L + l;
+            const int k = count1[gl], j = count2[gl];
+            sel = k >= s_m && k < e_m && j >= s_n && j < e_n;
+            kj[gl] = sel ? (uint8_t)(k | (j << 4)) : (uint8_t)0;
+        }
+        const unsigned long long mask = __ballot(sel);
+        if (lane == 0) s_wave[wave] = __popcll(mask);
+        __syncthreads();
+        if (tid == 0) {
+            int acc = 0;
+            for (int w = 0; w < 16; ++w) { int c = s_wave[w]; s_wave[w] = acc; acc += c; }
+            s_total = acc;
+            s_base = acc ? atomicAdd(&nsel[b], acc) : 0;
+        }
+        __syncthreads();
+        if (sel) s_list[s_wave[wave] + __popcll(mask & ((1ull << lane) - 1ull))] = l;
+        __syncthreads();
+    }
+    if (tid >= s_total) return;
+    const int l = s_list[tid];
+    sel_out[(size_t)b * L + s_base + tid] = l;
     const size_t gl = (size_t)b * L + l;
     const int k = count1[gl], j = count2[gl];
-    const bool sel = k >= s_m && k < e_m && j >= s_n && j < e_n;
-    kj[gl] = sel ? (uint8_t)(k | (j << 4)) : (uint8_t)0;
-    if (!sel) return;
     float ln[6];
 #pragma unroll
     for (int c = 0; c < 6; ++c) ln[c] = line[gl * 6 + c];
@@ -123,13 +151,14 @@ extern "C" int rrl_line_pair_dist(const float *tri1, const float *tri2, const fl
     WsLayout w(B, N, M, L);
     if (ws_bytes < w.total) return RRL_E_WS;
     if (B == 0 || L == 0) return 0;
-    hipLaunchKernelGGL(line_pair_dist_kernel, dim3((unsigned)((L + 255) / 256), (unsigned)B),
-                       dim3(256), 0, (hipStream_t)stream, tri1, tri2, line,
+    hipLaunchKernelGGL(line_pair_dist_kernel, dim3((unsigned)((L + 1023) / 1024), (unsigned)B),
+                       dim3(1024), 0, (hipStream_t)stream, tri1, tri2, line,
                        w.i32(ws, RRL_WS_COUNT1), w.i32(ws, RRL_WS_HIT1), w.i32(ws, RRL_WS_COUNT2),
-                       w.i32(ws, RRL_WS_HIT2), w.u8(ws, RRL_WS_KJ), w.i32(ws, RRL_WS_HS1),
-                       w.i32(ws, RRL_WS_HS2), w.f32(ws, RRL_WS_W1), w.f32(ws, RRL_WS_W2),
-                       w.f32(ws, RRL_WS_D), w.f32(ws, RRL_WS_VALS), w.i32(ws, RRL_WS_NVALS), B, N, M,
-                       L, s_m, s_n, e_m, e_n, pool);
+                       w.i32(ws, RRL_WS_HIT2), w.u8(ws, RRL_WS_KJ), w.i32(ws, RRL_WS_SEL),
+                       w.i32(ws, RRL_WS_NSEL), w.i32(ws, RRL_WS_HS1), w.i32(ws, RRL_WS_HS2),
+                       w.f32(ws, RRL_WS_W1), w.f32(ws, RRL_WS_W2), w.f32(ws, RRL_WS_D),
+                       w.f32(ws, RRL_WS_VALS), w.i32(ws, RRL_WS_NVALS), B, N, M, L, s_m, s_n, e_m,
+                       e_n, pool);
     RRL_LAUNCH_CHECK();
     return 0;
 }
@@ -174,71 +203,57 @@ __device__ __forceinline__ void welsch_block(const float *__restrict__ Dl, int k
     }
 }
 
+#define MED_REGS 8  // values cached in registers per lane (n <= 8192); the rest is re-read
+
 __global__ __launch_bounds__(1024) void loss_reduce_kernel(
-    const uint8_t *__restrict__ kj, const float *__restrict__ D, const float *__restrict__ vals,
-    const int32_t *__restrict__ nvals, float *__restrict__ med_out, int32_t *__restrict__ bcnt_out,
-    int64_t *__restrict__ bsum_out, int32_t *__restrict__ info, float *__restrict__ loss, int B,
-    int L, int s_m, int s_n, int e_m, int e_n, int pool) {
-    __shared__ unsigned hist[256];
-    __shared__ unsigned wave_tot[4];
-    __shared__ unsigned s_prefix, s_rank;
+    const uint8_t *__restrict__ kj, const int32_t *__restrict__ sel, const int32_t *__restrict__ nsel,
+    const float *__restrict__ D, const float *__restrict__ vals, const int32_t *__restrict__ nvals,
+    float *__restrict__ med_out, int32_t *__restrict__ bcnt_out, int64_t *__restrict__ bsum_out,
+    int32_t *__restrict__ info, float *__restrict__ loss, int B, int L, int s_m, int s_n, int e_m,
+    int e_n, int pool) {
+    __shared__ unsigned s_bit[32];
     __shared__ unsigned long long s_sum[32];
     __shared__ int s_cnt[16];
     const int g = blockIdx.x, tid = threadIdx.x;
     const int bm = pool ? B - 1 : g;  // whose values define the median
     const float *v = vals + (size_t)bm * L * 16;
     const unsigned n = (unsigned)nvals[bm];
-
-    // ---- lower median: 4-pass MSB-first radix select on the bit patterns (D >= 0, so the
-    //      unsigned order is the float order); rank (n-1)/2 == torch.median
-    if (tid == 0) { s_prefix = 0; s_rank = n ? (n - 1) / 2 : 0; }
-    if (tid < 32) s_sum[tid] = 0ull;
+    if (tid < 32) { s_bit[tid] = 0; s_sum[tid] = 0ull; }
     if (tid < 16) s_cnt[tid] = 0;
-    for (int pass = 0; pass < 4 && n > 0; ++pass) {
-        const int shift = 24 - 8 * pass;
-        const unsigned himask = pass ? (0xffffffffu << (shift + 8)) : 0u;
-        if (tid < 256) hist[tid] = 0;
-        __syncthreads();
-        const unsigned prefix = s_prefix;
-        for (unsigned i = tid; i < n; i += 1024) {
-            unsigned u = __float_as_uint(v[i]);
-            if ((u & himask) == prefix) atomicAdd(&hist[(u >> shift) & 255u], 1u);
-        }
-        __syncthreads();
-        // parallel search of the bin holding the rank: inclusive scan over 256 bins
-        const unsigned r = s_rank;  // read before the barrier below; rewritten after it
-        unsigned c = 0, inc = 0;
-        if (tid < 256) {
-            c = hist[tid];
-            inc = c;
-            for (int o = 1; o < 64; o <<= 1) {
-                unsigned t = __shfl_up(inc, o);
-                if ((tid & 63) >= o) inc += t;
-            }
-            if ((tid & 63) == 63) wave_tot[tid >> 6] = inc;
-        }
-        __syncthreads();
-        if (tid < 256) {
-            unsigned base = 0;
-            for (int w = 0; w < (tid >> 6); ++w) base += wave_tot[w];
-            inc += base;
-            if (inc - c <= r && r < inc) {  // exactly one bin satisfies this
-                s_rank = r - (inc - c);
-                s_prefix = prefix | ((unsigned)tid << shift);
-            }
-        }
-        __syncthreads();
-    }
     __syncthreads();
-    const float med = n ? __uint_as_float(s_prefix) : 0.0f;
+
+    // ---- lower median = element of rank (n-1)/2 (torch.median).  Bitwise MSB-first select on
+    //      the bit patterns (D >= 0: unsigned order == float order).  Per bit: count the values
+    //      that agree with the prefix and have the bit clear; counting is ballot/shuffle based,
+    //      one LDS atomic per wave and ONE barrier per bit (no contended histogram).
+    unsigned u[MED_REGS];
+#pragma unroll
+    for (int i = 0; i < MED_REGS; ++i) {
+        unsigned idx = (unsigned)tid + 1024u * i;
+        u[i] = idx < n ? __float_as_uint(v[idx]) : 0xffffffffu;  // all-ones never matches a prefix
+    }
+    unsigned prefix = 0, rank = n ? (n - 1) / 2 : 0;
+    for (int bit = 30; bit >= 0 && n > 0; --bit) {  // bit 31 (sign) is clear for every D
+        unsigned c = 0;
+#pragma unroll
+        for (int i = 0; i < MED_REGS; ++i) c += ((u[i] ^ prefix) >> bit) == 0u;
+        for (unsigned idx = (unsigned)tid + 1024u * MED_REGS; idx < n; idx += 1024u)
+            c += ((__float_as_uint(v[idx]) ^ prefix) >> bit) == 0u;
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
+        if ((tid & 63) == 0 && c) atomicAdd(&s_bit[bit], c);
+        __syncthreads();
+        const unsigned zeros = s_bit[bit];
+        if (rank >= zeros) { rank -= zeros; prefix |= 1u << bit; }
+    }
+    const float med = n ? __uint_as_float(prefix) : 0.0f;
 
     // ---- Welsch + symmetric min per selected line, bucket sums in LDS (fixed point)
     const int b0 = pool ? 0 : g, b1 = pool ? B : g + 1;
-    for (int b = b0; b < b1; ++b)
-        for (int l = tid; l < L; l += 1024) {
-            const size_t gl = (size_t)b * L + l;
+    for (int b = b0; b < b1; ++b) {
+        const int ns = nsel[b];
+        for (int i = tid; i < ns; i += 1024) {
+            const size_t gl = (size_t)b * L + sel[(size_t)b * L + i];
             const unsigned c = kj[gl];
-            if (!c) continue;
             const int k = c & 15, j = c >> 4;
             float rowmin[4], colmin[4];
             int arg_b[4], arg_a[4];
@@ -256,6 +271,7 @@ __global__ __launch_bounds__(1024) void loss_reduce_kernel(
             atomicAdd(&s_sum[bi * 2 + 1], (unsigned long long)((double)col * (double)(1ll << FIX_SHIFT) + 0.5));
             atomicAdd(&s_cnt[bi], 1);
         }
+    }
     __syncthreads();
 
     // ---- loss = ( sum_{non-empty (k,j), k-major} exp(-|k-j|/2) (mean_row + mean_col) ) / C
@@ -263,7 +279,7 @@ __global__ __launch_bounds__(1024) void loss_reduce_kernel(
     if (tid < 32) bsum_out[(size_t)g * 32 + tid] = (int64_t)s_sum[tid];
     if (tid == 0) {
         float acc = 0.0f;
-        int C = 0, nsel = 0;
+        int C = 0, nselected = 0;
         for (int k = s_m; k < e_m; ++k)
             for (int j = s_n; j < e_n; ++j) {
                 const int bi = (k - 1) * 4 + (j - 1);
@@ -275,12 +291,12 @@ __global__ __launch_bounds__(1024) void loss_reduce_kernel(
                 float wkj = expf(-0.5f * (float)abs(k - j));  // code/loss.py:215
                 acc = acc + wkj * (mrow + mcol);
                 ++C;
-                nsel += S;
+                nselected += S;
             }
         med_out[g] = med;
         loss[g] = C ? acc / (float)C : 0.0f;  // code/loss.py:230
         info[g * 4 + 0] = C;
-        info[g * 4 + 1] = nsel;
+        info[g * 4 + 1] = nselected;
         info[g * 4 + 2] = (int)n;
         info[g * 4 + 3] = 0;
     }
@@ -294,10 +310,11 @@ extern "C" int rrl_loss_reduce(void *ws, size_t ws_bytes, float *loss, int B, in
     if (ws_bytes < w.total) return RRL_E_WS;
     if (B == 0) return 0;
     hipLaunchKernelGGL(loss_reduce_kernel, dim3((unsigned)(pool ? 1 : B)), dim3(1024), 0,
-                       (hipStream_t)stream, w.u8(ws, RRL_WS_KJ), w.f32(ws, RRL_WS_D),
-                       w.f32(ws, RRL_WS_VALS), w.i32(ws, RRL_WS_NVALS), w.f32(ws, RRL_WS_MED),
-                       w.i32(ws, RRL_WS_BCNT), w.i64(ws, RRL_WS_BSUM), w.i32(ws, RRL_WS_INFO), loss,
-                       B, L, s_m, s_n, e_m, e_n, pool);
+                       (hipStream_t)stream, w.u8(ws, RRL_WS_KJ), w.i32(ws, RRL_WS_SEL),
+                       w.i32(ws, RRL_WS_NSEL), w.f32(ws, RRL_WS_D), w.f32(ws, RRL_WS_VALS),
+                       w.i32(ws, RRL_WS_NVALS), w.f32(ws, RRL_WS_MED), w.i32(ws, RRL_WS_BCNT),
+                       w.i64(ws, RRL_WS_BSUM), w.i32(ws, RRL_WS_INFO), loss, B, L, s_m, s_n, e_m,
+                       e_n, pool);
     RRL_LAUNCH_CHECK();
     return 0;
 }
@@ -310,17 +327,17 @@ extern "C" int rrl_loss_reduce(void *ws, size_t ws_bytes, float *loss, int B, in
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void loss_bwd_kernel(
     const float *__restrict__ tri1, const float *__restrict__ tri2, const uint8_t *__restrict__ kj,
+    const int32_t *__restrict__ sel, const int32_t *__restrict__ nsel,
     const int32_t *__restrict__ hs1, const int32_t *__restrict__ hs2, const float *__restrict__ w1,
     const float *__restrict__ w2, const float *__restrict__ D, const float *__restrict__ med,
     const int32_t *__restrict__ bcnt, const int32_t *__restrict__ info,
     const float *__restrict__ grad_loss, float *__restrict__ g1, float *__restrict__ g2, int B,
     int N, int M, int L, int pool) {
-    const int l = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.x * 256 + threadIdx.x;
     const int b = blockIdx.y;
-    if (l >= L) return;
-    const size_t gl = (size_t)b * L + l;
+    if (i >= nsel[b]) return;  // dense wavefronts over the compacted selected lines
+    const size_t gl = (size_t)b * L + sel[(size_t)b * L + i];
     const unsigned c = kj[gl];
-    if (!c) return;
     const int k = c & 15, j = c >> 4, g = pool ? 0 : b;
     const int C = info[g * 4];
     if (C == 0) return;
@@ -398,8 +415,9 @@ extern "C" int rrl_loss_backward(const float *tri1, const float *tri2, const voi
         return (int)e;
     if (B == 0 || L == 0) return 0;
     hipLaunchKernelGGL(loss_bwd_kernel, dim3((unsigned)((L + 255) / 256), (unsigned)B), dim3(256), 0,
-                       s, tri1, tri2, w.u8(ws, RRL_WS_KJ), w.i32(ws, RRL_WS_HS1),
-                       w.i32(ws, RRL_WS_HS2), w.f32(ws, RRL_WS_W1), w.f32(ws, RRL_WS_W2),
+                       s, tri1, tri2, w.u8(ws, RRL_WS_KJ), w.i32(ws, RRL_WS_SEL),
+                       w.i32(ws, RRL_WS_NSEL), w.i32(ws, RRL_WS_HS1), w.i32(ws, RRL_WS_HS2),
+                       w.f32(ws, RRL_WS_W1), w.f32(ws, RRL_WS_W2),
                        w.f32(ws, RRL_WS_D), w.f32(ws, RRL_WS_MED), w.i32(ws, RRL_WS_BCNT),
                        w.i32(ws, RRL_WS_INFO), grad_loss, grad_tri1, grad_tri2, B, N, M, L, pool);
     RRL_LAUNCH_CHECK();

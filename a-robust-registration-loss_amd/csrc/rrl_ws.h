@@ -1,5 +1,5 @@
 // rrl_ws.h -- layout of the caller-allocated workspace (fields: include/rrl.h RRL_WS_*).
-// The first five fields (status, nvals, pmax, count1, count2) are contiguous so that one
+// The first six fields (status, nvals, nsel, pmax, count1, count2) are contiguous so that one
 // hipMemsetAsync clears all per-call state.  Every field starts on a 256-byte boundary.
 #pragma once
 #include "rrl_common.h"
@@ -14,6 +14,7 @@ struct WsLayout {
         const size_t bytes[RRL_WS_FIELDS] = {
             4 * 4,               // STATUS
             4 * b,               // NVALS
+            4 * b,               // NSEL
             4 * 2 * b,           // PMAX
             4 * b * l,           // COUNT1
             4 * b * l,           // COUNT2
@@ -22,6 +23,7 @@ struct WsLayout {
             4 * b * n * 12,      // PTRI1
             4 * b * m * 12,      // PTRI2
             b * l,               // KJ
+            4 * b * l,           // SEL
             4 * b * l * 4,       // HS1
             4 * b * l * 4,       // HS2
             4 * b * l * 12,      // W1

@@ -56,6 +56,14 @@ def reduce_loss(local_loss, local_valid, shared_grads=(), group=None):
     return buf[0], buf[1]
 
 
+def reduce_payload(payload, group=None):
+    """Sum all-reduce of the 14-float shard payload built by ops.shard_payload (HIP, one launch):
+    [loss sum, #valid, sum dR (9), sum dT (3)].  One collective per step."""
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(payload, op=dist.ReduceOp.SUM, group=group)
+    return payload
+
+
 def sharded_batch_loss(points1, points2, line, rng=(1, 1, 5, 5), loss_fn=None, group=None):
     """points1/points2/line hold the GLOBAL batch on every rank (or identical seeds); each rank
     evaluates its shard and the result is the global (loss_sum, n_valid).  loss_fn(p1, p2, ln,

@@ -16,6 +16,7 @@ _MODES = {"strict": SCAN_STRICT, "lazy": SCAN_LAZY, "auto": SCAN_AUTO}
 _WS_FIELDS = [
     ("status", torch.int32, lambda B, N, M, L, G: (4,)),
     ("nvals", torch.int32, lambda B, N, M, L, G: (B,)),
+    ("nsel", torch.int32, lambda B, N, M, L, G: (B,)),
     ("pmax", torch.float32, lambda B, N, M, L, G: (2, B)),
     ("count1", torch.int32, lambda B, N, M, L, G: (B, L)),
     ("count2", torch.int32, lambda B, N, M, L, G: (B, L)),
@@ -24,6 +25,7 @@ _WS_FIELDS = [
     ("ptri1", torch.float32, lambda B, N, M, L, G: (B, N, 12)),
     ("ptri2", torch.float32, lambda B, N, M, L, G: (B, M, 12)),
     ("kj", torch.uint8, lambda B, N, M, L, G: (B, L)),
+    ("sel", torch.int32, lambda B, N, M, L, G: (B, L)),
     ("hs1", torch.int32, lambda B, N, M, L, G: (B, L, 4)),
     ("hs2", torch.int32, lambda B, N, M, L, G: (B, L, 4)),
     ("w1", torch.float32, lambda B, N, M, L, G: (B, L, 4, 3)),
@@ -147,6 +149,7 @@ class _IntersectionLoss(torch.autograd.Function):
         ctx.in_devs = (points1.device, points2.device)
         info, status = st.info, st.status
         ctx.mark_non_differentiable(info, status)
+        _IntersectionLoss.last_state = st  # for shard_payload(): the newest evaluation
         return st.loss, info, status
 
     @staticmethod
@@ -172,6 +175,20 @@ def intersection_loss(points1, points2, line, rng=(1, 1, 5, 5), pool=False, mode
     caller obtains by looping B=1 calls); pool=True reproduces the reference's own B>1 behaviour
     (SURVEY Q2).  No host synchronisation happens here."""
     return _IntersectionLoss.apply(points1, points2, line, tuple(rng), pool, mode, chunk)
+
+
+def shard_payload(loss, gR=None, gt=None, state=None):
+    """[sum of valid losses, #valid, sum_b gR (9), sum_b gt (3)] as one (14,) tensor in one
+    launch -- the buffer a rank contributes to the all-reduce (rrl_hip.dist).  `state` defaults
+    to the LossState of the latest intersection_loss call."""
+    st = state or _IntersectionLoss.last_state
+    B, N, M, L, G = st.dims
+    out = torch.empty(14, dtype=torch.float32, device=loss.device)
+    gRc = gR.contiguous() if gR is not None else None
+    gtc = gt.contiguous() if gt is not None else None
+    check(_lib.load().rrl_shard_payload(_p(loss.detach()), _p(st.ws), st.nbytes, _p(gRc), _p(gtc),
+                                        _p(out), G, N, M, L, _stream()), "rrl_shard_payload")
+    return out
 
 
 def scan_timing(enable):

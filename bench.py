@@ -103,15 +103,17 @@ def main():
     dev = torch.device("cuda", local)
     B, N, M, L = args.batch, args.points, args.points, args.lines
     w = make_workload(B, N, M, L, rank, dev)
+    ones = torch.ones(B, device=dev)
+    src_pts = w["tri1"].reshape(B, -1, 3)
 
     def step():
         w["R"].grad = w["T"].grad = None
-        tri1 = ops.rigid_apply(w["tri1"].reshape(B, -1, 3), w["R"], w["T"], transpose_r=True)
+        tri1 = ops.rigid_apply(src_pts, w["R"], w["T"], transpose_r=True)
         loss, info, _ = ops.intersection_loss(tri1.reshape(B, N, 9), w["tri2"], w["lines"],
                                               (1, 1, 5, 5), mode=args.mode)
-        loss.sum().backward()
-        gR, gT = w["R"].grad.sum(0), w["T"].grad.sum(0)
-        return rdist.reduce_loss(loss, info[:, 0] > 0, (gR, gT))
+        torch.autograd.backward([loss], [ones])  # d(sum of losses): no reduction kernel needed
+        # one launch builds [loss sum, #valid, sum dR, sum dT]; one all-reduce shares it
+        return rdist.reduce_payload(ops.shard_payload(loss, w["R"].grad, w["T"].grad))
 
     def fence():
         torch.cuda.synchronize()
@@ -125,7 +127,7 @@ def main():
     ops.scan_timing(True)  # HIP events around the scan kernel, on the launch stream
     t0 = time.perf_counter()
     for i in range(args.steps):
-        total, nvalid = step()
+        payload = step()
     fence()
     dt = time.perf_counter() - t0
     scan_times = ops.scan_timing_collect()
@@ -174,7 +176,7 @@ def main():
                         "algorithmic_bytes": alg_bytes},
                 "traffic": pmc,
             },
-            "extras": {"loss_sum": float(total.detach()), "valid": float(nvalid.detach()),
+            "extras": {"loss_sum": float(payload[0]), "valid": float(payload[1]),
                        "chamfer_ms": chamfer_ms, "chamfer_pairs_per_s": B * N * M / (chamfer_ms * 1e-3),
                        "chamfer": float(cd), "line_sampling_s": w["sample_s"],
                        "scan_share_of_step": scan_ms / (dt / args.steps * 1e3)},

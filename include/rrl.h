@@ -45,13 +45,14 @@ extern "C" {
 #define RRL_SCAN_LAZY 1   /* points 1,2 only where point 0 passes: same labels; a NaN (negative
                              sqrt argument) is reported only if it occurs in an evaluated pair */
 #define RRL_SCAN_AUTO 2   /* per wavefront: lazy where a NaN is provably impossible for its
-                             lines (|dir|^2 <= 1+4e-7 and (|x0| + max|P|)^2 <= 150), else strict.
+                             lines (|dir|^2 <= 1+1e-6 and (|x0| + max|P|)^2 <= 100), else strict.
                              Same results AND same NaN detection as strict.  Default. */
 
 /* workspace fields (indices into rrl_workspace_layout's offset array) */
 enum {
     RRL_WS_STATUS = 0, /* int32[4]   [0] = NaN seen (reference exit(0), loss.py:89-91)      */
     RRL_WS_NVALS,      /* int32[B]   D values appended per sample                           */
+    RRL_WS_NSEL,       /* int32[B]   selected lines per sample (length of SEL[b])           */
     RRL_WS_PMAX,       /* uint32[2][B] bits of max |P|^2 per cloud and sample                */
     RRL_WS_COUNT1,     /* int32[B][L] hit count, cloud 1 (loss.py:185)                      */
     RRL_WS_COUNT2,     /* int32[B][L]                                                      */
@@ -60,6 +61,7 @@ enum {
     RRL_WS_PTRI1,      /* float[B][N][12] 9 coords, thr2, thr, 0                            */
     RRL_WS_PTRI2,      /* float[B][M][12]                                                   */
     RRL_WS_KJ,         /* uint8[B][L]  k | j<<4, 0 = line not selected                      */
+    RRL_WS_SEL,        /* int32[B][L]  indices of the selected lines, compacted (any order)  */
     RRL_WS_HS1,        /* int32[B][L][4] ascending hit indices (nonzero() order)            */
     RRL_WS_HS2,
     RRL_WS_W1,         /* float[B][L][4][3] weights d / sum d (loss.py:92)                  */
@@ -139,6 +141,12 @@ int rrl_set_scan_variant(int lines_per_lane);
  * durations in milliseconds and resets the ring.  Returns the number written. */
 int rrl_scan_timing_enable(int on);
 int rrl_scan_timing_collect(float *ms, int max_n);
+
+/* Batch-shard payload: out[14] = { sum of valid losses, number of valid
+ * samples, sum_b gR[b] (9), sum_b gt[b] (3) } in one launch, fixed summation order; this is
+ * the buffer a rank hands to the RCCL all-reduce.  gR / gt may be NULL (zeros). */
+int rrl_shard_payload(const float *loss, const void *ws, size_t ws_bytes, const float *gR,
+                      const float *gt, float *out, int B, int N, int M, int L, void *stream);
 
 /* ---- rigid apply ----------------------------------------------------------------------- */
 /* code/loss.py:460-461; rpm/common/math_torch/se3.py:67-72; code/utils.py:32-37;

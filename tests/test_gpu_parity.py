@@ -229,6 +229,24 @@ def test_batched_equals_per_sample(L):
         assert one.item() == loss[b].item()
 
 
+def test_shard_payload(L):
+    from rrl_hip import ops
+    g = load_golden("loss_b2_quirk.npz")
+    p1 = cu(g["tri1"]).requires_grad_(True)
+    loss, info, _ = ops.intersection_loss(p1, cu(g["tri2"]), cu(g["lines"]))
+    gR = torch.arange(18.0, device="cuda").reshape(2, 3, 3)
+    gT = torch.arange(6.0, device="cuda").reshape(2, 3)
+    out = ops.shard_payload(loss, gR, gT).cpu().numpy()
+    np.testing.assert_allclose(out[0], loss.sum().item(), rtol=1e-6)
+    assert out[1] == 2.0
+    np.testing.assert_allclose(out[2:11], gR.sum(0).reshape(-1).cpu().numpy())
+    np.testing.assert_allclose(out[11:], gT.sum(0).cpu().numpy())
+    sel = ops._IntersectionLoss.last_state
+    n0 = int(sel.nsel[0])
+    assert n0 == int(info[0, 1]) and sorted(sel.sel[0, :n0].tolist()) == \
+        torch.nonzero(sel.kj[0]).reshape(-1).tolist()
+
+
 def test_line_permutation_invariance(L):
     """Fixed-point bucket sums and the radix-select median are order independent: permuting
     the lines must not change a single bit of the loss."""
