@@ -1,0 +1,86 @@
+"""World-size-2 gloo test of the batch-shard path on CPU: shard bounds, the fused all-reduce of
+loss / valid count / shared gradients, and that the sharded sum equals the unsharded one.
+The per-sample loss is plugged with the CPU oracle (tests may use it; the product never does)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import PKG, ROOT, load_golden
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _oracle_loss_fn(p1, p2, ln, rng):
+    from oracle import rrl_oracle
+    vals, ok = [], []
+    for b in range(p1.shape[0]):
+        r = rrl_oracle.loss(p1[b].numpy(), p2[b].numpy(), ln[b].numpy(), rng=tuple(rng), want_grad=False)
+        vals.append(0.0 if r["loss"] is None else float(r["loss"]))
+        ok.append(r["loss"] is not None)
+    return torch.tensor(vals, dtype=torch.float32), torch.tensor(ok)
+
+
+def _worker(rank, world, port, out):
+    import sys
+    for p in (ROOT, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from rrl_hip import dist as rdist
+    r, w, _ = rdist.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+    g = load_golden("loss_b2_quirk.npz")
+    far = load_golden("loss_edge_allmiss.npz")
+    # global batch of 3: two real samples and one whose lines miss everything (invalid)
+    n = g["tri1"].shape[1]
+    p1 = torch.from_numpy(np.stack([g["tri1"][0], g["tri1"][1], g["tri1"][0]]))
+    p2 = torch.from_numpy(np.stack([g["tri2"][0], g["tri2"][1], g["tri2"][0]]))
+    ln = torch.from_numpy(np.stack([g["lines"][0], g["lines"][1],
+                                    np.resize(far["lines"], g["lines"][0].shape)]))
+    total, nvalid = rdist.sharded_batch_loss(p1, p2, ln, loss_fn=_oracle_loss_fn)
+    # shared-parameter gradients are summed in the same collective
+    shared = torch.full((6,), float(rank + 1))
+    lo, hi = rdist.shard_bounds(3, rank, world)
+    l, v = _oracle_loss_fn(p1[lo:hi], p2[lo:hi], ln[lo:hi], (1, 1, 5, 5))
+    t2, n2 = rdist.reduce_loss(l, v, (shared,))
+    payload = rdist.reduce_payload(torch.arange(14.0) * (rank + 1))
+    if rank == 0:
+        torch.save(dict(total=total, nvalid=nvalid, t2=t2, n2=n2, shared=shared, payload=payload, n=n), out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_bounds():
+    from rrl_hip.dist import shard_bounds
+    for total in (0, 1, 7, 8, 64):
+        for world in (1, 2, 3, 8):
+            parts = [shard_bounds(total, r, world) for r in range(world)]
+            assert parts[0][0] == 0 and parts[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
+            sizes = [hi - lo for lo, hi in parts]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_world2_gloo(tmp_path, oracle):
+    out = str(tmp_path / "r0.pt")
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    res = torch.load(out)
+    g = load_golden("loss_b2_quirk.npz")
+    want = sum(float(oracle.loss(g["tri1"][b], g["tri2"][b], g["lines"][b])["loss"]) for b in (0, 1))
+    assert float(res["nvalid"]) == 2.0 and float(res["n2"]) == 2.0
+    np.testing.assert_allclose(float(res["total"]), want, rtol=1e-6)
+    np.testing.assert_allclose(float(res["t2"]), want, rtol=1e-6)
+    np.testing.assert_allclose(res["shared"].numpy(), np.full(6, 3.0))
+    np.testing.assert_allclose(res["payload"].numpy(), np.arange(14.0) * 3)
