@@ -46,3 +46,38 @@ __device__ __forceinline__ float norm3(float x, float y, float z) {
 }
 
 __device__ __forceinline__ uint32_t f2u(float x) { return __float_as_uint(x); }
+
+// Per-triangle threshold of code/loss.py:94-110 and its exact squared form:
+//   thr  = mean(|P1-P0|, |P2-P0|, |P1-P2|) * 1.731 / 2
+//   thr2 = min { x >= 0 : sqrtf(x) >= thr }  (sqrtf correctly rounded and monotone), so that
+//          sqrtf(x) < thr  <=>  x < thr2 exactly.  Start at fl(thr*thr) and walk a few ulps.
+__device__ __forceinline__ void tri_thresholds(const float *c, float *thr_out, float *thr2_out) {
+    float e0 = norm3(c[3] - c[0], c[4] - c[1], c[5] - c[2]);
+    float e1 = norm3(c[6] - c[0], c[7] - c[1], c[8] - c[2]);
+    float e2 = norm3(c[3] - c[6], c[4] - c[7], c[5] - c[8]);
+    float delta = ((e0 + e1) + e2) / 3.0f;
+    float t = delta * RRL_CTHR;
+    float thr = t / 2.0f;
+    float x = thr * thr;
+    if (thr > 0.0f && x < INFINITY) {
+        for (int it = 0; it < 8 && x > 0.0f && sqrtf(x) >= thr; ++it)
+            x = __uint_as_float(__float_as_uint(x) - 1u);
+        for (int it = 0; it < 16 && sqrtf(x) < thr; ++it)
+            x = __uint_as_float(__float_as_uint(x) + 1u);
+    } else if (!(thr > 0.0f)) {
+        x = 0.0f;  // thr == 0 (degenerate triangle) or NaN: nothing is strictly closer
+    }
+    *thr_out = thr;
+    *thr2_out = x;
+}
+
+// NaN-impossibility bound of a line v = (dir, x0) against a cloud with max |P|^2 = pm
+// (DESIGN.md "NaN bound"): |dir|^2 <= 1 + 1e-6 and (|x0| + max|P|)^2 <= 100.
+__device__ __forceinline__ bool rrl_line_safe(const float *v, float pm) {
+    float s = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+    float o2 = v[3] * v[3] + v[4] * v[4] + v[5] * v[5];
+    float a2 = o2 + pm + 2.0f * sqrtf(o2 * pm);
+    return (s <= 1.000001f) && (a2 <= 100.0f);
+}
+
+#define RRL_SCAN_UNSAFE_TILES 4  // internal: strict loop, only for 512-line tiles that fail the bound

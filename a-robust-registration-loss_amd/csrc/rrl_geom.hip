@@ -64,7 +64,7 @@ extern "C" int rrl_rigid_apply_fwd(const float *x, const float *R, const float *
     return 0;
 }
 
-#define RIGID_BWD_PTS 2048  // points per workgroup in the backward reduction
+#define RIGID_BWD_PTS 16384  // points per 1024-lane workgroup in the backward reduction
 
 extern "C" int rrl_rigid_bwd_blocks(int n) { return n > 0 ? (n + RIGID_BWD_PTS - 1) / RIGID_BWD_PTS : 0; }
 
@@ -72,13 +72,15 @@ extern "C" int rrl_rigid_bwd_blocks(int n) { return n > 0 ? (n + RIGID_BWD_PTS -
 // gt_j = sum gy_j.  Wave shuffle reduction, then a fixed-order cross-wave / cross-block sum
 // (deterministic: no float atomics).
 template <bool CF>
-__global__ __launch_bounds__(256) void rigid_bwd_kernel(const float *__restrict__ x,
-                                                        const float *__restrict__ R,
-                                                        const float *__restrict__ gy,
-                                                        float *__restrict__ gx,
-                                                        float *__restrict__ partial, int n,
-                                                        int transpose_r) {
-    __shared__ float red[4][12];
+__global__ __launch_bounds__(1024) void rigid_bwd_kernel(const float *__restrict__ x,
+                                                         const float *__restrict__ R,
+                                                         const float *__restrict__ gy,
+                                                         float *__restrict__ gx,
+                                                         float *__restrict__ partial,
+                                                         float *__restrict__ gR,
+                                                         float *__restrict__ gt, int n,
+                                                         int transpose_r) {
+    __shared__ float red[16][12];
     const int b = blockIdx.y;
     const Mat m = load_mat(R, nullptr, b, transpose_r);
     const size_t base = (size_t)b * n * 3;
@@ -86,7 +88,7 @@ __global__ __launch_bounds__(256) void rigid_bwd_kernel(const float *__restrict_
 #pragma unroll
     for (int q = 0; q < 12; ++q) acc[q] = 0.0f;
     const int i0 = blockIdx.x * RIGID_BWD_PTS;
-    for (int i = i0 + threadIdx.x; i < min(n, i0 + RIGID_BWD_PTS); i += 256) {
+    for (int i = i0 + threadIdx.x; i < min(n, i0 + RIGID_BWD_PTS); i += 1024) {
         float v[3], g[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -116,8 +118,17 @@ __global__ __launch_bounds__(256) void rigid_bwd_kernel(const float *__restrict_
         for (int q = 0; q < 12; ++q) red[wave][q] = acc[q];
     __syncthreads();
     if (threadIdx.x < 12) {
-        float s = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
-        partial[((size_t)b * gridDim.x + blockIdx.x) * 12 + threadIdx.x] = s;
+        const int q = threadIdx.x;
+        float s = 0.0f;
+        for (int w = 0; w < 16; ++w) s += red[w][q];  // fixed order
+        if (gridDim.x > 1) {
+            partial[((size_t)b * gridDim.x + blockIdx.x) * 12 + q] = s;
+        } else if (q < 9) {  // single workgroup per sample: write the result directly
+            int i = q / 3, j = q % 3;
+            gR[b * 9 + (transpose_r ? j * 3 + i : i * 3 + j)] = s;
+        } else {
+            gt[b * 3 + (q - 9)] = s;
+        }
     }
 }
 
@@ -145,16 +156,18 @@ extern "C" int rrl_rigid_apply_bwd(const float *x, const float *R, const float *
     if (nblk > 0) {
         dim3 grid((unsigned)nblk, (unsigned)B);
         if (channel_first)
-            hipLaunchKernelGGL(rigid_bwd_kernel<true>, grid, dim3(256), 0, s, x, R, gy, gx, partial,
-                               n, transpose_r);
+            hipLaunchKernelGGL(rigid_bwd_kernel<true>, grid, dim3(1024), 0, s, x, R, gy, gx, partial,
+                               gR, gt, n, transpose_r);
         else
-            hipLaunchKernelGGL(rigid_bwd_kernel<false>, grid, dim3(256), 0, s, x, R, gy, gx,
-                               partial, n, transpose_r);
+            hipLaunchKernelGGL(rigid_bwd_kernel<false>, grid, dim3(1024), 0, s, x, R, gy, gx,
+                               partial, gR, gt, n, transpose_r);
         RRL_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(rigid_bwd_finalize_kernel, dim3((unsigned)B), dim3(64), 0, s, partial, gR, gt,
-                       nblk, transpose_r);
-    RRL_LAUNCH_CHECK();
+    if (nblk != 1) {  // 0 blocks: zeros; > 1: fixed-order sum of the per-block partials
+        hipLaunchKernelGGL(rigid_bwd_finalize_kernel, dim3((unsigned)B), dim3(64), 0, s, partial, gR,
+                           gt, nblk, transpose_r);
+        RRL_LAUNCH_CHECK();
+    }
     return 0;
 }
 

@@ -33,7 +33,7 @@
 // ---------------------------------------------------------------------------------------
 // K1' prepared triangles (+ max |P|^2 per cloud and sample for the auto-mode NaN bound)
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void tri_prepare_kernel(const float *__restrict__ tri1,
+__global__ __launch_bounds__(64) void tri_prepare_kernel(const float *__restrict__ tri1,
                                                           const float *__restrict__ tri2,
                                                           float *__restrict__ ptri1,
                                                           float *__restrict__ ptri2,
@@ -41,37 +41,21 @@ __global__ __launch_bounds__(256) void tri_prepare_kernel(const float *__restric
                                                           int M) {
     const int cloud = blockIdx.z, b = blockIdx.y;
     const int n = cloud ? M : N;
-    const int f = blockIdx.x * 256 + threadIdx.x;
+    const int f = blockIdx.x * 64 + threadIdx.x;
     float p2 = 0.0f;
     if (f < n) {
         const float *p = (cloud ? tri2 : tri1) + 9 * ((size_t)b * n + f);
         float c[9];
 #pragma unroll
         for (int i = 0; i < 9; ++i) c[i] = p[i];
-        // code/loss.py:94-104: delta = mean(|P1-P0|, |P2-P0|, |P1-P2|)
-        float e0 = norm3(c[3] - c[0], c[4] - c[1], c[5] - c[2]);
-        float e1 = norm3(c[6] - c[0], c[7] - c[1], c[8] - c[2]);
-        float e2 = norm3(c[3] - c[6], c[4] - c[7], c[5] - c[8]);
-        float delta = ((e0 + e1) + e2) / 3.0f;
-        float t = delta * RRL_CTHR;  // code/loss.py:109: delta * 1.731 / 2
-        float thr = t / 2.0f;
-        // thr2 = min { x >= 0 : sqrtf(x) >= thr }  (sqrtf correctly rounded and monotone), so
-        // sqrtf(x) < thr  <=>  x < thr2 exactly.  Start at fl(thr*thr) and walk a few ulps.
-        float x = thr * thr;
-        if (thr > 0.0f && x < INFINITY) {
-            for (int it = 0; it < 8 && x > 0.0f && sqrtf(x) >= thr; ++it)
-                x = __uint_as_float(__float_as_uint(x) - 1u);
-            for (int it = 0; it < 16 && sqrtf(x) < thr; ++it)
-                x = __uint_as_float(__float_as_uint(x) + 1u);
-        } else if (!(thr > 0.0f)) {
-            x = 0.0f;  // thr == 0 (degenerate triangle) or NaN: nothing is strictly closer
-        }
+        float thr, x;
+        tri_thresholds(c, &thr, &x);
         float *q = (cloud ? ptri2 : ptri1) + PTRI_STRIDE * ((size_t)b * n + f);
 #pragma unroll
         for (int i = 0; i < 9; ++i) q[i] = c[i];
         q[9] = x;
         q[10] = thr;
-        q[11] = 0.0f;
+        q[11] = __int_as_float(f);  // original index (identity order on this path)
 #pragma unroll
         for (int k = 0; k < 3; ++k)
             p2 = fmaxf(p2, c[3 * k] * c[3 * k] + c[3 * k + 1] * c[3 * k + 1] + c[3 * k + 2] * c[3 * k + 2]);
@@ -81,21 +65,28 @@ __global__ __launch_bounds__(256) void tri_prepare_kernel(const float *__restric
     if ((threadIdx.x & 63) == 0) atomicMax(&pmax[cloud * B + b], __float_as_uint(p2));
 }
 
+int rrl_launch_tri_sort(void *ws, const WsLayout &w, int B, int N, int M, hipStream_t s);
+int rrl_launch_cull_scan(const float *line, void *ws, const WsLayout &w, int B, int N, int M, int L,
+                         hipStream_t s);
+int rrl_sort_capacity(void);
+
 extern "C" int rrl_tri_prepare(const float *tri1, const float *tri2, void *ws, size_t ws_bytes,
                                int B, int N, int M, int L, void *stream) {
     if (!tri1 || !tri2 || !ws || B < 0 || N < 0 || M < 0 || L < 0) return RRL_E_ARG;
     WsLayout w(B, N, M, L);
     if (ws_bytes < w.total) return RRL_E_WS;
     hipStream_t s = (hipStream_t)stream;
-    // one memset clears status, nvals, pmax, count1, count2 (contiguous by construction)
+    const int nmax = N > M ? N : M;
+    // one memset clears status, nvals, nsel, pmax, count1, count2 (contiguous by construction)
     hipError_t e = hipMemsetAsync((char *)ws + w.off[RRL_WS_STATUS], 0, w.zero_bytes, s);
     if (e != hipSuccess) return (int)e;
-    const int nmax = N > M ? N : M;
     if (B == 0 || nmax == 0) return 0;
-    hipLaunchKernelGGL(tri_prepare_kernel, dim3((unsigned)((nmax + 255) / 256), (unsigned)B, 2),
-                       dim3(256), 0, s, tri1, tri2, w.f32(ws, RRL_WS_PTRI1), w.f32(ws, RRL_WS_PTRI2),
+    hipLaunchKernelGGL(tri_prepare_kernel, dim3((unsigned)((nmax + 63) / 64), (unsigned)B, 2),
+                       dim3(64), 0, s, tri1, tri2, w.f32(ws, RRL_WS_PTRI1), w.f32(ws, RRL_WS_PTRI2),
                        (uint32_t *)w.i32(ws, RRL_WS_PMAX), B, N, M);
     RRL_LAUNCH_CHECK();
+    // Morton order + group spheres for the culled scan
+    if (nmax <= rrl_sort_capacity()) return rrl_launch_tri_sort(ws, w, B, N, M, s);
     return 0;
 }
 
@@ -171,7 +162,7 @@ __device__ __forceinline__ uint32_t scan_strict(const LineRegs<T, NP> &r, kptr t
         if (__builtin_expect(any, 0)) {
 #pragma unroll
             for (int q = 0; q < R; ++q)
-                if (m[q] < thr2) sink.commit(q, t);
+                if (m[q] < thr2) sink.commit(q, __float_as_int(tp[11]));
         }
     }
     return nanacc;
@@ -220,7 +211,7 @@ __device__ __forceinline__ uint32_t scan_lazy(const LineRegs<T, NP> &r, kptr tp,
                     uint32_t mm = umax3(m[i * W + w], f2u(Lanes<T>::get(x1, w)),
                                         f2u(Lanes<T>::get(x2, w)));
                     if constexpr (TRACK_NAN) nanacc = max(nanacc, mm);
-                    if (mm < thr2) sink.commit(i * W + w, t);
+                    if (mm < thr2) sink.commit(i * W + w, __float_as_int(tp[11]));
                 }
             }
         }
@@ -267,11 +258,7 @@ __global__ __launch_bounds__(256) void scan_kernel(
             float keep = l < L ? 1.0f : 0.0f;
 #pragma unroll
             for (int c = 0; c < 6; ++c) v[w][c] = q[c] * keep;
-            // NaN-impossibility bound (see header): |dir|^2 <= 1+1e-6, (|x0| + max|P|)^2 <= 100
-            float s = v[w][0] * v[w][0] + v[w][1] * v[w][1] + v[w][2] * v[w][2];
-            float o2 = v[w][3] * v[w][3] + v[w][4] * v[w][4] + v[w][5] * v[w][5];
-            float a2 = o2 + pm + 2.0f * sqrtf(o2 * pm);
-            safe &= (s <= 1.000001f) && (a2 <= 100.0f);
+            safe &= rrl_line_safe(v[w], pm);  // NaN-impossibility bound (see header)
         }
         if constexpr (W == 1) {
             r.ux[i] = v[0][0]; r.uy[i] = v[0][1]; r.uz[i] = v[0][2];
@@ -285,7 +272,11 @@ __global__ __launch_bounds__(256) void scan_kernel(
 
     kptr tp = (kptr)(uintptr_t)(tri + (size_t)t0 * PTRI_STRIDE);
     uint32_t nanacc;
-    if (mode == RRL_SCAN_STRICT || (mode == RRL_SCAN_AUTO && !__all(safe)))
+    if (mode == RRL_SCAN_UNSAFE_TILES) {
+        // companion of cull_scan_kernel: only 512-line tiles with a line that fails the bound
+        if (__syncthreads_and(safe)) return;
+        nanacc = scan_strict<T, NP>(r, tp, t0, t1, sink);
+    } else if (mode == RRL_SCAN_STRICT || (mode == RRL_SCAN_AUTO && !__all(safe)))
         nanacc = scan_strict<T, NP>(r, tp, t0, t1, sink);
     else if (mode == RRL_SCAN_AUTO)
         nanacc = scan_lazy<T, NP, false>(r, tp, t0, t1, sink);  // provably NaN-free
@@ -306,7 +297,7 @@ extern "C" int rrl_set_scan_variant(int lines_per_lane) {
 
 // ---- optional scan timing ring -----------------------------------------------------------
 #define TIMING_RING 1024
-static int g_timing_on = 0, g_timing_n = 0;
+static int g_timing_on = 0, g_timing_n = 0, g_timing_seen = 0;
 static hipEvent_t g_ev[TIMING_RING][2];
 static bool g_ev_made = false;
 
@@ -319,8 +310,8 @@ extern "C" int rrl_scan_timing_enable(int on) {
             }
         g_ev_made = true;
     }
-    g_timing_on = on ? 1 : 0;
-    g_timing_n = 0;
+    g_timing_on = on > 0 ? on : 0;  // on = k: bracket every k-th scan launch
+    g_timing_n = g_timing_seen = 0;
     return 0;
 }
 
@@ -338,11 +329,21 @@ extern "C" int rrl_scan_timing_collect(float *ms, int max_n) {
 extern "C" int rrl_line_tri_scan(const float *line, void *ws, size_t ws_bytes, int B, int N, int M,
                                  int L, int mode, int chunk, void *stream) {
     if (!line || !ws || B < 0 || N < 0 || M < 0 || L < 0 || chunk < 0) return RRL_E_ARG;
-    if (mode != RRL_SCAN_STRICT && mode != RRL_SCAN_LAZY && mode != RRL_SCAN_AUTO) return RRL_E_ARG;
+    if (mode != RRL_SCAN_STRICT && mode != RRL_SCAN_LAZY && mode != RRL_SCAN_AUTO &&
+        mode != RRL_SCAN_CULL)
+        return RRL_E_ARG;
     WsLayout w(B, N, M, L);
     if (ws_bytes < w.total) return RRL_E_WS;
     if (B == 0 || L == 0 || (N == 0 && M == 0)) return 0;
+    const int nmax0 = N > M ? N : M;
+    if (mode == RRL_SCAN_CULL && nmax0 > rrl_sort_capacity()) mode = RRL_SCAN_AUTO;
     int R = g_scan_variant;
+    const bool cull = mode == RRL_SCAN_CULL;
+    if (cull) {  // the strict companion runs packed pairs over 512-line tiles, fat chunks
+        R = 2;
+        mode = RRL_SCAN_UNSAFE_TILES;
+        if (chunk == 0) chunk = 1024;
+    }
     if (R == 0) {
         const char *v = getenv("RRL_SCAN_VARIANT");
         R = v ? atoi(v) : 0;
@@ -357,8 +358,12 @@ extern "C" int rrl_line_tri_scan(const float *line, void *ws, size_t ws_bytes, i
     dim3 grid((unsigned)((L + 256 * R - 1) / (256 * R)), (unsigned)((nmax + chunk - 1) / chunk),
               (unsigned)(2 * B));
     hipStream_t s = (hipStream_t)stream;
-    const bool timed = g_timing_on && g_timing_n < TIMING_RING;
+    const bool timed = g_timing_on && (g_timing_seen++ % g_timing_on) == 0 && g_timing_n < TIMING_RING;
     if (timed) (void)hipEventRecord(g_ev[g_timing_n][0], s);
+    if (cull) {
+        int rc = rrl_launch_cull_scan(line, ws, w, B, N, M, L, s);
+        if (rc) return rc;
+    }
 #define RRL_SCAN_LAUNCH(T, NP)                                                                   \
     hipLaunchKernelGGL((scan_kernel<T, NP>), grid, dim3(256), 0, s, w.f32(ws, RRL_WS_PTRI1),     \
                        w.f32(ws, RRL_WS_PTRI2), line, w.i32(ws, RRL_WS_COUNT1),                  \

@@ -22,6 +22,12 @@ struct WsLayout {
             4 * b * l * 4,       // HIT2
             4 * b * n * 12,      // PTRI1
             4 * b * m * 12,      // PTRI2
+            16 * b * ((n + 15) / 16) * 16,  // P0S1
+            16 * b * ((m + 15) / 16) * 16,  // P0S2
+            4 * b * ((n + 15) / 16) * 16,   // IDX1
+            4 * b * ((m + 15) / 16) * 16,   // IDX2
+            16 * b * ((n + 15) / 16),       // GRP1
+            16 * b * ((m + 15) / 16),       // GRP2
             b * l,               // KJ
             4 * b * l,           // SEL
             4 * b * l * 4,       // HS1

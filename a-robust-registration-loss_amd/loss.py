@@ -56,8 +56,8 @@ def cal_loss_intersection_batch_whole_median_pts_lines(s_m, s_n, e_m, e_n, point
 
     Raises ValueError on a NaN distance (non-unit line direction), where the reference prints
     "Exit the systerm" and exits with status 0 (code/loss.py:89-91).
-    mode: "auto" (default: strict semantics, lazy evaluation where a NaN is provably
-    impossible) | "strict" | "lazy" (see include/rrl.h), or env RRL_SCAN_MODE.
+    mode: "cull" (default: strict semantics; sphere-culled, lazy evaluation where a NaN is
+    provably impossible) | "auto" | "strict" | "lazy" (see include/rrl.h), or env RRL_SCAN_MODE.
     """
     if points1.dim() != 3 or line.dim() != 3 or points2.dim() != 3:
         raise ValueError("Input is wrong")  # code/loss.py:69-71
@@ -85,9 +85,9 @@ def batched_intersection_loss(points1, points2, line, rng=(1, 1, 5, 5), *, mode=
 
 def _scan_mode(mode):
     import os
-    mode = mode or os.environ.get("RRL_SCAN_MODE", "auto")
-    if mode not in ("strict", "lazy", "auto"):
-        raise ValueError("mode must be 'auto', 'strict' or 'lazy'")
+    mode = mode or os.environ.get("RRL_SCAN_MODE", "cull")
+    if mode not in ("strict", "lazy", "auto", "cull"):
+        raise ValueError("mode must be 'cull', 'auto', 'strict' or 'lazy'")
     return mode
 
 

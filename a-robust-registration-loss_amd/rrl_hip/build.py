@@ -13,7 +13,7 @@ PKG = os.path.dirname(HERE)
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "librrl_hip.so")
-SOURCES = ["rrl_scan.hip", "rrl_sparse.hip", "rrl_geom.hip"]
+SOURCES = ["rrl_scan.hip", "rrl_cull.hip", "rrl_sparse.hip", "rrl_geom.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
          "-Wall", "-Wno-unused-function"]
 
@@ -38,7 +38,8 @@ def build_lib(force=False, verbose=False):
     objs = []
     for src in SOURCES:
         obj = os.path.join(LIBDIR, src.replace(".hip", ".o"))
-        cmd = [_hipcc(), *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        extra = ["-fno-slp-vectorize"] if src == "rrl_cull.hip" else []  # see the file header
+        cmd = [_hipcc(), *FLAGS, *extra, "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

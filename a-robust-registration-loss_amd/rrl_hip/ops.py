@@ -9,8 +9,8 @@ import torch
 from . import _lib
 from ._lib import RRLError, check
 
-SCAN_STRICT, SCAN_LAZY, SCAN_AUTO = 0, 1, 2
-_MODES = {"strict": SCAN_STRICT, "lazy": SCAN_LAZY, "auto": SCAN_AUTO}
+SCAN_STRICT, SCAN_LAZY, SCAN_AUTO, SCAN_CULL = 0, 1, 2, 3
+_MODES = {"strict": SCAN_STRICT, "lazy": SCAN_LAZY, "auto": SCAN_AUTO, "cull": SCAN_CULL}
 
 # workspace fields, in the order of include/rrl.h's RRL_WS_* enum: (name, dtype, shape)
 _WS_FIELDS = [
@@ -24,6 +24,12 @@ _WS_FIELDS = [
     ("hit2", torch.int32, lambda B, N, M, L, G: (B, L, 4)),
     ("ptri1", torch.float32, lambda B, N, M, L, G: (B, N, 12)),
     ("ptri2", torch.float32, lambda B, N, M, L, G: (B, M, 12)),
+    ("p0s1", torch.float32, lambda B, N, M, L, G: (B, (N + 15) // 16 * 16, 4)),
+    ("p0s2", torch.float32, lambda B, N, M, L, G: (B, (M + 15) // 16 * 16, 4)),
+    ("idx1", torch.int32, lambda B, N, M, L, G: (B, (N + 15) // 16 * 16)),
+    ("idx2", torch.int32, lambda B, N, M, L, G: (B, (M + 15) // 16 * 16)),
+    ("grp1", torch.float32, lambda B, N, M, L, G: (B, (N + 15) // 16, 4)),
+    ("grp2", torch.float32, lambda B, N, M, L, G: (B, (M + 15) // 16, 4)),
     ("kj", torch.uint8, lambda B, N, M, L, G: (B, L)),
     ("sel", torch.int32, lambda B, N, M, L, G: (B, L)),
     ("hs1", torch.int32, lambda B, N, M, L, G: (B, L, 4)),
@@ -109,7 +115,7 @@ def _check_range(rng):
     return s_m, s_n, e_m, e_n
 
 
-def loss_forward_raw(tri1, tri2, line, rng=(1, 1, 5, 5), pool=False, mode="auto", chunk=0,
+def loss_forward_raw(tri1, tri2, line, rng=(1, 1, 5, 5), pool=False, mode="cull", chunk=0,
                      staged=False):
     """Forward on already-prepared GPU tensors; returns the LossState.  staged=True issues the
     four stages through their individual C entry points instead of the fused one."""
@@ -149,11 +155,14 @@ class _IntersectionLoss(torch.autograd.Function):
         ctx.in_devs = (points1.device, points2.device)
         info, status = st.info, st.status
         ctx.mark_non_differentiable(info, status)
+        ctx.set_materialize_grads(False)  # no zero-filled grads for the integer outputs
         _IntersectionLoss.last_state = st  # for shard_payload(): the newest evaluation
         return st.loss, info, status
 
     @staticmethod
     def backward(ctx, g_loss, _g1, _g2):
+        if g_loss is None:
+            return (None,) * 7
         lib = _lib.load()
         st, tri1, tri2 = ctx.st, ctx.tri1, ctx.tri2
         B, N, _ = tri1.shape
@@ -169,7 +178,7 @@ class _IntersectionLoss(torch.autograd.Function):
         return g1, g2, None, None, None, None, None
 
 
-def intersection_loss(points1, points2, line, rng=(1, 1, 5, 5), pool=False, mode="auto", chunk=0):
+def intersection_loss(points1, points2, line, rng=(1, 1, 5, 5), pool=False, mode="cull", chunk=0):
     """Batched loss: returns (loss[G], info[G,4] = (nbuckets, nselected, nvalues, 0), status[4])
     on the GPU, G = 1 if pool else B.  Each sample is an independent loss (what every reference
     caller obtains by looping B=1 calls); pool=True reproduces the reference's own B>1 behaviour
@@ -191,9 +200,9 @@ def shard_payload(loss, gR=None, gt=None, state=None):
     return out
 
 
-def scan_timing(enable):
-    """Profiling hook: bracket every scan launch with HIP events (include/rrl.h)."""
-    check(_lib.load().rrl_scan_timing_enable(int(bool(enable))), "rrl_scan_timing_enable")
+def scan_timing(every):
+    """Profiling hook: bracket every `every`-th scan launch with HIP events; 0 = off."""
+    check(_lib.load().rrl_scan_timing_enable(int(every)), "rrl_scan_timing_enable")
 
 
 def scan_timing_collect(max_n=1024):

@@ -90,7 +90,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="samples per GPU")
     ap.add_argument("--points", type=int, default=4096)
     ap.add_argument("--lines", type=int, default=10000)
-    ap.add_argument("--mode", default=os.environ.get("RRL_SCAN_MODE", "auto"))
+    ap.add_argument("--mode", default=os.environ.get("RRL_SCAN_MODE", "cull"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -124,14 +124,14 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    ops.scan_timing(True)  # HIP events around the scan kernel, on the launch stream
+    ops.scan_timing(4)  # HIP events around every 4th scan launch, on the launch stream
     t0 = time.perf_counter()
     for i in range(args.steps):
         payload = step()
     fence()
     dt = time.perf_counter() - t0
     scan_times = ops.scan_timing_collect()
-    ops.scan_timing(False)
+    ops.scan_timing(0)
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

@@ -46,7 +46,13 @@ extern "C" {
                              sqrt argument) is reported only if it occurs in an evaluated pair */
 #define RRL_SCAN_AUTO 2   /* per wavefront: lazy where a NaN is provably impossible for its
                              lines (|dir|^2 <= 1+1e-6 and (|x0| + max|P|)^2 <= 100), else strict.
-                             Same results AND same NaN detection as strict.  Default. */
+                             Same results AND same NaN detection as strict. */
+#define RRL_SCAN_CULL 3   /* default.  Triangles are Morton-sorted into groups of 16 with bounding
+                             spheres; a line evaluates (lazily, exactly) only the groups whose
+                             sphere it can reach, found by a conservative test (DESIGN.md
+                             "culling bound").  Tiles of 512 lines that fail the NaN bound are
+                             scanned by the strict loop instead, so results and NaN detection equal
+                             strict's.  Needs N, M <= 16384, else behaves like AUTO. */
 
 /* workspace fields (indices into rrl_workspace_layout's offset array) */
 enum {
@@ -58,8 +64,14 @@ enum {
     RRL_WS_COUNT2,     /* int32[B][L]                                                      */
     RRL_WS_HIT1,       /* int32[B][L][4] unordered hit indices                              */
     RRL_WS_HIT2,
-    RRL_WS_PTRI1,      /* float[B][N][12] 9 coords, thr2, thr, 0                            */
+    RRL_WS_PTRI1,      /* float[B][N][12] 9 coords, thr2, thr, original triangle index (int)  */
     RRL_WS_PTRI2,      /* float[B][M][12]                                                   */
+    RRL_WS_P0S1,       /* float[B][16*NG1][4] P0 + thr2 in Morton order, slot-swizzled per group */
+    RRL_WS_P0S2,       /*   NG = ceil(N/16) groups                                             */
+    RRL_WS_IDX1,       /* int32[B][16*NG1]  original triangle index of each sorted position     */
+    RRL_WS_IDX2,
+    RRL_WS_GRP1,       /* float[B][NG1][4]  group sphere: centre, conservative radius^2        */
+    RRL_WS_GRP2,
     RRL_WS_KJ,         /* uint8[B][L]  k | j<<4, 0 = line not selected                      */
     RRL_WS_SEL,        /* int32[B][L]  indices of the selected lines, compacted (any order)  */
     RRL_WS_HS1,        /* int32[B][L][4] ascending hit indices (nonzero() order)            */
@@ -136,9 +148,9 @@ int rrl_loss_reduce(void *ws, size_t ws_bytes, float *loss, int B, int N, int M,
  * identical results.  Env RRL_SCAN_VARIANT / RRL_SCAN_CHUNK override the defaults. */
 int rrl_set_scan_variant(int lines_per_lane);
 
-/* Profiling hook: when enabled, every scan launch is bracketed by a hipEvent pair (ring of
- * 1024) recorded on the launch stream; collect() synchronises them, writes up to max_n
- * durations in milliseconds and resets the ring.  Returns the number written. */
+/* Profiling hook: enable(k > 0) brackets every k-th scan launch with a hipEvent pair (ring of
+ * 1024) recorded on the launch stream; enable(0) turns it off.  collect() synchronises them,
+ * writes up to max_n durations in milliseconds and resets the ring.  Returns the number written. */
 int rrl_scan_timing_enable(int on);
 int rrl_scan_timing_collect(float *ms, int max_n);
 

@@ -47,6 +47,7 @@ def test_tri_prepare_exact(L, oracle):
     g = load_golden("loss_demo_scale.npz")
     st = run_state(g["tri1"], g["tri2"], g["lines"])
     pt = st.ptri1[0].cpu().numpy()
+    np.testing.assert_array_equal(pt[:, 11].copy().view(np.int32), np.arange(len(pt)))
     np.testing.assert_array_equal(pt[:, :9], g["tri1"])
     thr = oracle.tri_threshold(g["tri1"])
     np.testing.assert_array_equal(pt[:, 10], thr)
@@ -54,11 +55,25 @@ def test_tri_prepare_exact(L, oracle):
     thr2 = pt[:, 9]
     below = np.nextafter(thr2, np.float32(0), dtype=np.float32)
     assert np.all(np.sqrt(thr2) >= thr) and np.all(np.sqrt(below) < thr)
+    # Morton order: a permutation; group spheres contain their 16 P0s with the threshold margin
+    n = len(pt)
+    idx = st.idx1[0].cpu().numpy()[:n]
+    assert sorted(idx.tolist()) == list(range(n))
+    grp = st.grp1[0].cpu().numpy()
+    P0 = pt[idx, :3].astype(np.float64)
+    for gi in range(len(grp)):
+        sl = slice(16 * gi, min(16 * gi + 16, n))
+        d = np.linalg.norm(P0[sl] - grp[gi, :3].astype(np.float64), axis=1) + thr[idx[sl]]
+        assert np.all(d * d <= grp[gi, 3] * (1 + 1e-6))
+    p0s = st.p0s1[0].cpu().numpy()
+    for s_ in (0, 17, n - 1):
+        slot = (s_ & ~15) | ((s_ + (s_ >> 4)) & 15)
+        np.testing.assert_array_equal(p0s[slot], np.append(pt[idx[s_], :3], thr2[idx[s_]]))
 
 
 # ---------------------------------------------------------------------------------- K1
 @pytest.mark.parametrize("name", LOSS_FIXTURES)
-@pytest.mark.parametrize("mode", ["strict", "lazy", "auto"])
+@pytest.mark.parametrize("mode", ["strict", "lazy", "auto", "cull"])
 def test_scan_counts_and_hits(L, oracle, name, mode):
     g = load_golden(name)
     st = run_state(g["tri1"], g["tri2"], g["lines"], mode=mode)
@@ -93,18 +108,25 @@ def test_auto_mode_picks_lazy_only_when_nan_is_impossible(L):
     """Unit-scale data: auto == lazy == strict bit for bit.  Demo-scale data ((|x0|+|P|)^2 > 100)
     and non-unit directions must take the strict loop, so the NaN flag is still raised."""
     g = load_golden("loss_synth_s0.npz")
-    a, s_, z = (run_state(g["tri1"], g["tri2"], g["lines"], mode=m) for m in ("auto", "strict", "lazy"))
-    assert a.loss[0].item() == s_.loss[0].item() == z.loss[0].item()
+    a, s_, z, c = (run_state(g["tri1"], g["tri2"], g["lines"], mode=m)
+                   for m in ("auto", "strict", "lazy", "cull"))
+    assert a.loss[0].item() == s_.loss[0].item() == z.loss[0].item() == c.loss[0].item()
     assert float(a.pmax.max()) < 4.0
     d = load_golden("loss_demo_scale.npz")
     bad = d["lines"].copy()
     bad[5, :3] *= 1.5  # one non-unit direction among thousands of good lines
     assert int(run_state(d["tri1"], d["tri2"], bad, mode="strict").status[0]) == 1
     assert int(run_state(d["tri1"], d["tri2"], bad, mode="auto").status[0]) == 1
+    assert int(run_state(d["tri1"], d["tri2"], bad, mode="cull").status[0]) == 1
     bad2 = g["lines"].copy()
     bad2[77, :3] *= 40.0
     assert int(run_state(g["tri1"], g["tri2"], bad2, mode="strict").status[0]) == 1
     assert int(run_state(g["tri1"], g["tri2"], bad2, mode="auto").status[0]) == 1
+    cs = run_state(g["tri1"], g["tri2"], bad2, mode="cull")
+    ss = run_state(g["tri1"], g["tri2"], bad2, mode="strict")
+    assert int(cs.status[0]) == 1  # the bad line's 512-tile went to the strict loop
+    np.testing.assert_array_equal(cs.count1.cpu().numpy(), ss.count1.cpu().numpy())
+    np.testing.assert_array_equal(cs.count2.cpu().numpy(), ss.count2.cpu().numpy())
 
 
 # ---------------------------------------------------------------------------------- K2..K4
@@ -273,8 +295,11 @@ def test_full_size_sample_vs_oracle(L, oracle):
     o = oracle.loss(pr["src_tri"], pr["tar_tri"], lines)
     assert o["n_selected"] > 300
     np.testing.assert_allclose(float(st.loss[0]), o["loss"], rtol=2e-6)
-    lz = run_state(pr["src_tri"], pr["tar_tri"], lines, mode="lazy")
-    assert float(lz.loss[0]) == float(st.loss[0])
+    for m in ("lazy", "strict", "auto"):
+        other = run_state(pr["src_tri"], pr["tar_tri"], lines, mode=m)
+        assert float(other.loss[0]) == float(st.loss[0])
+        np.testing.assert_array_equal(other.count1.cpu().numpy(), st.count1.cpu().numpy())
+        np.testing.assert_array_equal(other.count2.cpu().numpy(), st.count2.cpu().numpy())
     t1 = np.stack([pr["src_tri"]] * 3)
     t1[1] += 0.3  # a different middle sample must not disturb its neighbours
     bt = run_state(t1, np.stack([pr["tar_tri"]] * 3), np.stack([lines] * 3))

@@ -36,7 +36,7 @@ def test_abi_argument_errors(libpath):
     lib = _lib.load()
     assert lib.rrl_tri_prepare(None, None, None, 0, 1, 1, 1, 1, None) == -1
     assert lib.rrl_set_scan_variant(3) == -1
-    assert lib.rrl_rigid_bwd_blocks(5000) == 3
+    assert lib.rrl_rigid_bwd_blocks(5000) == 1 and lib.rrl_rigid_bwd_blocks(40000) == 3
     assert lib.rrl_loss_reduce(None, 0, None, 1, 1, 1, 1, 1, 1, 5, 5, 0, None) == -1
     # workspace layout: 256-byte aligned, monotone, inside the reported size
     import ctypes as C
@@ -44,7 +44,7 @@ def test_abi_argument_errors(libpath):
     header = open(os.path.join(ROOT, "include", "rrl.h")).read()
     enum = header[header.index("RRL_WS_STATUS = 0"):header.index("RRL_WS_FIELDS")]
     n_fields = len(re.findall(r"RRL_WS_[A-Z0-9]+", enum))
-    assert n_fields == len(ops._WS_FIELDS) == 22  # python view table matches the C enum
+    assert n_fields == len(ops._WS_FIELDS) == 28  # python view table matches the C enum
     offs = (C.c_size_t * n_fields)()
     assert lib.rrl_workspace_layout(8, 4096, 4096, 10000, offs) == 0
     total = lib.rrl_workspace_bytes(8, 4096, 4096, 10000)

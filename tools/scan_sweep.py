@@ -36,7 +36,7 @@ def main():
     s, ws, nb = ops._stream(), ops._p(st.ws), st.nbytes
     variants = [int(v) for v in os.environ.get("SWEEP_VARIANTS", "2,4,8").split(",")]
     chunks = [int(v) for v in os.environ.get("SWEEP_CHUNKS", "64,128,256,512").split(",")]
-    ops.scan_timing(True)
+    ops.scan_timing(1)
     for variant in variants:
         lib.rrl_set_scan_variant(variant)
         for mode in (0, 1, 2):
@@ -52,7 +52,7 @@ def main():
                                   "chunk": chunk, "ms": round(ms, 4), "min_ms": round(min(ts), 4),
                                   "Gpairs_s": round(pairs / ms / 1e6, 1),
                                   "TFLOPs": round(18 * pairs / ms / 1e9, 2), "same_counts": ok}))
-    ops.scan_timing(False)
+    ops.scan_timing(0)
     lib.rrl_set_scan_variant(0)
 
 
