@@ -10,17 +10,18 @@
 //     group of 16 consecutive triangles, a bounding sphere of the P0s: centre c,
 //     rho = max |P0 - c| and the conservative squared radius
 //     R2 = ((rho + max thr)^2)(1 + 1e-4) + 1e-7.
-//   cull_scan_kernel (256 lines per workgroup, lane = one line in phase 1)
-//     per slab of 2048 sorted triangles (staged in LDS):
+//   cull_scan_kernel (lane = one line in phase 1; every wavefront owns 64 lines and a private
+//   LDS queue, so there is no workgroup synchronisation after the tile-safety vote)
 //     phase 1: every lane tests ITS line against each group sphere (wave-uniform sphere, SGPR
-//              operands) with a conservative test and keeps one mask bit per group;
-//     queue:   the (line, group) pairs of all 256 lanes are compacted into an LDS queue
-//              (block prefix sum over popcounts), so that
-//     phase 2: lanes pull pairs round-robin -- every lane does the same number of exact
-//              evaluations however unevenly the pairs are distributed over the lines -- and
-//              run the scan's exact point-0 test (same dist_sq arithmetic, bit-identical) on
-//              the group's 16 triangles; points 1, 2 (global PTRI record) only where point 0
-//              passes.
+//              operands) with a conservative test; the passing (line, group) pairs of the wave
+//              are appended to its queue by ballot/popcount, group by group;
+//     phase 2: lanes pull pairs from the queue, one per lane and step -- every lane does the
+//              same number of exact evaluations however unevenly the pairs are spread over the
+//              lines -- and run the scan's exact point-0 test (same dist_sq arithmetic,
+//              bit-identical) on the group's 16 triangles.  The queue is group-major, so
+//              neighbouring lanes read the same records and the loads coalesce (no LDS staging
+//              of triangles).  Point-0 passes (~1 in 130 tests) are parked and their points 1, 2
+//              (two dependent global loads) resolved densely afterwards.
 //
 // Culling bound (labels can never be lost).  For a line with |dir|^2 <= 1 + 1e-6 and
 // (|x0| + max|P|)^2 <= 100 ("safe", the NaN bound of rrl_scan.hip) let
@@ -37,10 +38,6 @@
 #include "rrl_ws.h"
 
 #define GRP 16           // triangles per group
-#define SLAB_TRIS 2048   // triangles staged in LDS per pass of the cull scan (32 KiB)
-#define SLAB_GROUPS (SLAB_TRIS / GRP)
-#define SLAB_WORDS (SLAB_GROUPS / 32)
-#define QCAP 6144        // (line, group) pairs per queue round (12 KiB of u16)
 #define SORT_CAP 16384   // largest cloud the sort kernel handles (64 KiB of LDS for thr)
 
 __device__ __forceinline__ unsigned spread10(unsigned v) {
@@ -52,9 +49,7 @@ __device__ __forceinline__ unsigned spread10(unsigned v) {
     return v;
 }
 
-// slot of sorted triangle s inside its group's 256-byte row: rotating by the group index keeps
-// lanes that read different groups at the same step on different LDS banks
-__device__ __forceinline__ int p0s_slot(int s) { return (s & ~15) | ((s + (s >> 4)) & 15); }
+__device__ __forceinline__ int p0s_slot(int s) { return s; }  // records in sorted order
 
 #define SORT_CELLS 4096  // 16^3 grid cells in Morton order
 
@@ -195,140 +190,208 @@ __global__ __launch_bounds__(1024) void tri_sort_kernel(
 
 typedef const float __attribute__((address_space(4))) * kptr;  // constant AS -> s_load
 
+#define BGRP 16    // groups per batch: their 16 x 256-byte rows are staged in the wave's LDS
+#define WCCAP 256  // parked point-0 candidates per wave (1 KiB)
+
+struct WaveCtx {
+    const float4 *lines;          // this wave's 64 lines in LDS: [64][2]
+    const float4 *p0s;            // sorted (P0, thr2) records of the cloud
+    const int32_t *idx;           // sorted position -> original triangle index
+    const float *ptri;            // prepared triangles (original order)
+    int32_t *cnt, *hit;           // per-line hit count / slots of the cloud
+    int lbase;                    // first line of this wave
+    float4 *rows;                 // LDS [BGRP][16] staged records of the current batch
+    unsigned short *ent;          // LDS [64] entries of the current batch: line << 4 | batch slot
+    int *bgrp;                    // LDS [BGRP] group index of each batch slot
+    unsigned *cands;              // LDS [WCCAP]
+};
+
+// cand = line_in_wave << 16 | sorted triangle position: evaluate points 1 and 2
+__device__ __forceinline__ void resolve_candidate(const WaveCtx &c, unsigned cand) {
+    const int ll = cand >> 16, spos = cand & 0xffff;
+    const float4 la = c.lines[2 * ll], lb = c.lines[2 * ll + 1];
+    const int f = c.idx[spos];
+    const float *q = c.ptri + PTRI_STRIDE * (size_t)f;
+    const uint32_t thr2 = __float_as_uint(q[9]);
+    const float x1 = dist_sq<float>(q[3], q[4], q[5], la.x, la.y, la.z, la.w, lb.x, lb.y);
+    const float x2 = dist_sq<float>(q[6], q[7], q[8], la.x, la.y, la.z, la.w, lb.x, lb.y);
+    if (max(__float_as_uint(x1), __float_as_uint(x2)) < thr2) {
+        const int l = c.lbase + ll;
+        int pos = atomicAdd(&c.cnt[l], 1);
+        if (pos < RRL_MAX_HITS) c.hit[(size_t)l * RRL_MAX_HITS + pos] = f;
+    }
+}
+
+__device__ __forceinline__ void wave_lds_fence() {
+    // LDS is processed in order per wave; this only stops the compiler from reordering across it
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
+
+// Phase 2 for one batch of a wave: <= 64 (line, group) pairs over <= BGRP groups.  The groups'
+// records are first copied, coalesced, into the wave's LDS rows (slot rotated by the batch slot so
+// lanes on different groups hit different banks); then every lane runs the exact point-0 test of
+// its pair on the 16 triangles.  Point-0 passes (~1 in 130 tests) are parked; their points 1, 2
+// need two dependent global loads and are resolved densely when enough have gathered.
+__device__ __forceinline__ void run_batch(const WaveCtx &c, uint32_t bmask, int nent, int ngrp,
+                                          int &ncand, int lane) {
+    // entries: lane's set bits of bmask (bit k = batch slot k), redistributed over the lanes by a
+    // prefix sum so that every lane evaluates exactly one (line, group) pair
+    {
+        const int mine = __popc(bmask);
+        int inc = mine;
+        for (int o = 1; o < 64; o <<= 1) {
+            int t = __shfl_up(inc, o);
+            if (lane >= o) inc += t;
+        }
+        int pos = inc - mine;
+        uint32_t m = bmask;
+        while (m) {
+            const int k = __ffs(m) - 1;
+            m &= m - 1;
+            c.ent[pos++] = (unsigned short)((lane << 4) | k);
+        }
+    }
+    wave_lds_fence();
+    {
+        const int q = lane >> 4, t = lane & 15;
+#pragma unroll
+        for (int r = 0; r < BGRP / 4; ++r) {
+            const int k = r * 4 + q;
+            if (k < ngrp) c.rows[k * 16 + ((t + k) & 15)] = c.p0s[(size_t)c.bgrp[k] * GRP + t];
+        }
+    }
+    wave_lds_fence();
+    uint32_t passbits = 0;
+    int ll = 0, g = 0;
+    if (lane < nent) {
+        const unsigned e = c.ent[lane];
+        ll = e >> 4;
+        const int k = e & 15;
+        g = c.bgrp[k];
+        const float4 la = c.lines[2 * ll], lb = c.lines[2 * ll + 1];
+        const float4 *row = c.rows + k * 16;
+#pragma unroll
+        for (int t = 0; t < GRP; ++t) {
+            const float4 rec = row[(t + k) & 15];
+            const float x = dist_sq<float>(rec.x, rec.y, rec.z, la.x, la.y, la.z, la.w, lb.x, lb.y);
+            passbits |= (__float_as_uint(x) < __float_as_uint(rec.w) ? 1u : 0u) << t;
+        }
+    }
+    while (__any(passbits != 0)) {
+        const bool has = passbits != 0;
+        const unsigned long long m = __ballot(has);
+        const int t = has ? __ffs(passbits) - 1 : 0;
+        passbits &= passbits - 1;
+        const int pos = ncand + __popcll(m & ((1ull << lane) - 1ull));
+        const unsigned cand = ((unsigned)ll << 16) | (unsigned)(g * GRP + t);
+        if (has) {
+            if (pos < WCCAP) c.cands[pos] = cand;
+            else resolve_candidate(c, cand);
+        }
+        ncand += __popcll(m);
+    }
+    if (ncand > WCCAP - 64) {  // uniform: keep room for the next batch
+        wave_lds_fence();
+        const int nc = min(ncand, WCCAP);
+        for (int i = lane; i < nc; i += 64) resolve_candidate(c, c.cands[i]);
+        ncand = 0;
+    }
+}
+
+// 256 lines per workgroup, but every wavefront works on its own 64 lines with private LDS: after
+// the one barrier of the tile-safety vote there is no workgroup synchronisation.
 __global__ __launch_bounds__(256) void cull_scan_kernel(
     const float *__restrict__ ptri1, const float *__restrict__ ptri2, const float4 *__restrict__ p0s1,
     const float4 *__restrict__ p0s2, const int32_t *__restrict__ idx1, const int32_t *__restrict__ idx2,
     const float4 *__restrict__ grp1, const float4 *__restrict__ grp2, const float *__restrict__ line,
     int32_t *__restrict__ count1, int32_t *__restrict__ hit1, int32_t *__restrict__ count2,
     int32_t *__restrict__ hit2, const uint32_t *__restrict__ pmax, int B, int N, int M, int L) {
-    __shared__ __attribute__((aligned(16))) float4 slab[SLAB_TRIS];       // 32 KiB
-    __shared__ __attribute__((aligned(16))) float4 lines_lds[256][2];     //  8 KiB
-    __shared__ unsigned short queue[QCAP];                                // 12 KiB
-    __shared__ int s_wave[4];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ __attribute__((aligned(16))) float4 lines_lds[4][64][2];    // 8 KiB
+    __shared__ __attribute__((aligned(16))) float4 rows_lds[4][BGRP * 16];  // 16 KiB
+    __shared__ unsigned cands_lds[4][WCCAP];                               // 4 KiB
+    __shared__ unsigned short ent_lds[4][64];
+    __shared__ int bgrp_lds[4][BGRP];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform for the compiler
     const int z = blockIdx.y, cloud = z >= B ? 1 : 0, b = z - cloud * B;
     const int n = cloud ? M : N;
     const int ng = (n + GRP - 1) / GRP;
-    const float4 *p0s = (cloud ? p0s2 : p0s1) + (size_t)b * ng * GRP;
-    const int32_t *idx = (cloud ? idx2 : idx1) + (size_t)b * ng * GRP;
     const float4 *grp = (cloud ? grp2 : grp1) + (size_t)b * ng;
-    const float *ptri = (cloud ? ptri2 : ptri1) + (size_t)b * n * PTRI_STRIDE;
     const float *ln = line + (size_t)b * L * 6;
-    int32_t *cnt = (cloud ? count2 : count1) + (size_t)b * L;
-    int32_t *hit = (cloud ? hit2 : hit1) + (size_t)b * L * RRL_MAX_HITS;
 
-    // this lane's line, and the safety of the whole 512-line tile (this block and its sibling):
-    // unsafe tiles belong to scan_kernel's strict loop
-    const int l0 = blockIdx.x * 256;
-    const int l = l0 + tid;
-    const int ls = (blockIdx.x ^ 1) * 256 + tid;
+    // 64 lines per workgroup; the four wavefronts split the GROUP range between them, which
+    // quadruples the number of independent (latency-bound) wavefronts.
+    // Safety of the whole 512-line tile this block belongs to (each thread checks two of its
+    // lines): unsafe tiles belong to scan_kernel's strict loop.
     const float pm = __uint_as_float(pmax[cloud * B + b]);
-    float v[6], vs[6];
+    bool safe = true;
+    {
+        const int tile0 = (blockIdx.x >> 3) * 512;
 #pragma unroll
-    for (int c = 0; c < 6; ++c) {
-        v[c] = l < L ? ln[6 * (size_t)l + c] : 0.0f;
-        vs[c] = ls < L ? ln[6 * (size_t)ls + c] : 0.0f;
+        for (int h = 0; h < 2; ++h) {
+            const int lt = tile0 + h * 256 + tid;
+            float vt[6];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) vt[c] = lt < L ? ln[6 * (size_t)lt + c] : 0.0f;
+            safe &= rrl_line_safe(vt, pm);
+        }
     }
-    const bool safe = rrl_line_safe(v, pm) && rrl_line_safe(vs, pm);
     if (!__syncthreads_and(safe)) return;
-    lines_lds[tid][0] = make_float4(v[0], v[1], v[2], v[3]);
-    lines_lds[tid][1] = make_float4(v[4], v[5], 0.0f, 0.0f);
+    const int l = blockIdx.x * 64 + lane;
+    float v[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) v[c] = l < L ? ln[6 * (size_t)l + c] : 0.0f;
+    lines_lds[wave][lane][0] = make_float4(v[0], v[1], v[2], v[3]);
+    lines_lds[wave][lane][1] = make_float4(v[4], v[5], 0.0f, 0.0f);
     const float ux = v[0], uy = v[1], uz = v[2], ox = v[3], oy = v[4], oz = v[5];
     const bool live = l < L;
 
-    for (int g0 = 0; g0 < ng; g0 += SLAB_GROUPS) {
-        const int g1 = min(ng, g0 + SLAB_GROUPS);
-        __syncthreads();  // previous slab fully consumed (and lines_lds visible)
-        for (int i = tid; i < (g1 - g0) * GRP; i += 256) slab[i] = p0s[(size_t)g0 * GRP + i];
+    WaveCtx ctx;
+    ctx.lines = &lines_lds[wave][0][0];
+    ctx.p0s = (cloud ? p0s2 : p0s1) + (size_t)b * ng * GRP;
+    ctx.idx = (cloud ? idx2 : idx1) + (size_t)b * ng * GRP;
+    ctx.ptri = (cloud ? ptri2 : ptri1) + (size_t)b * n * PTRI_STRIDE;
+    ctx.cnt = (cloud ? count2 : count1) + (size_t)b * L;
+    ctx.hit = (cloud ? hit2 : hit1) + (size_t)b * L * RRL_MAX_HITS;
+    ctx.lbase = blockIdx.x * 64;
+    ctx.rows = rows_lds[wave];
+    ctx.ent = ent_lds[wave];
+    ctx.bgrp = bgrp_lds[wave];
+    ctx.cands = cands_lds[wave];
 
-        // ---- phase 1: conservative sphere test of every group of the slab
-        uint32_t mw[SLAB_WORDS];
-#pragma unroll
-        for (int w = 0; w < SLAB_WORDS; ++w) {
-            uint32_t m = 0;
-            const int gb = g0 + w * 32;
-            if (gb < g1 && live) {
-                kptr gp = (kptr)(uintptr_t)(grp + gb);
-                const int cntg = min(32, g1 - gb);
-#pragma unroll 8
-                for (int j = 0; j < cntg; ++j) {
-                    const float cx = gp[4 * j], cy = gp[4 * j + 1], cz = gp[4 * j + 2], R2 = gp[4 * j + 3];
-                    float ax = cx - ox, ay = cy - oy, az = cz - oz;
-                    float dot = fmaf(az, uz, fmaf(ay, uy, ax * ux));
-                    float q = fmaf(az, az, fmaf(ay, ay, ax * ax));
-                    float d2 = fmaf(-dot, dot, q);
-                    d2 = fmaf(-4e-6f, q, d2);
-                    m |= (d2 <= R2 ? 1u : 0u) << j;
-                }
+    // ---- phase 1: conservative sphere test of every group; passing (line, group) pairs are
+    //      collected by ballot/popcount into batches that phase 2 consumes at once
+    int nent = 0, ngrp = 0, ncand = 0;  // wave-uniform
+    uint32_t bmask = 0;                 // per lane: bit k = this line passes batch slot k
+    kptr gp = (kptr)(uintptr_t)grp;
+    const int gq = (ng + 3) / 4;
+    const int gend = min(ng, (wave + 1) * gq);
+    for (int g = wave * gq; g < gend; ++g) {
+        const float cx = gp[4 * g], cy = gp[4 * g + 1], cz = gp[4 * g + 2], R2 = gp[4 * g + 3];
+        float ax = cx - ox, ay = cy - oy, az = cz - oz;
+        float dot = fmaf(az, uz, fmaf(ay, uy, ax * ux));
+        float q = fmaf(az, az, fmaf(ay, ay, ax * ax));
+        float d2 = fmaf(-dot, dot, q);
+        d2 = fmaf(-4e-6f, q, d2);
+        const bool pass = live && d2 <= R2;
+        const unsigned long long m = __ballot(pass);
+        if (m) {
+            const int c = __popcll(m);
+            if (nent + c > 64 || ngrp == BGRP) {  // uniform: the batch is full
+                run_batch(ctx, bmask, nent, ngrp, ncand, lane);
+                nent = ngrp = 0;
+                bmask = 0;
             }
-            mw[w] = m;
-        }
-
-        // ---- queue rounds: compact the block's (line, group) pairs, then balanced phase 2
-        for (;;) {
-            int mine = 0;
-#pragma unroll
-            for (int w = 0; w < SLAB_WORDS; ++w) mine += __popc(mw[w]);
-            int inc = mine;  // inclusive scan over the wave
-            for (int o = 1; o < 64; o <<= 1) {
-                int t = __shfl_up(inc, o);
-                if (lane >= o) inc += t;
-            }
-            __syncthreads();  // queue / s_wave of the previous round are no longer read
-            if (lane == 63) s_wave[wave] = inc;
-            __syncthreads();
-            int base = 0, total = 0;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                if (w < wave) base += s_wave[w];
-                total += s_wave[w];
-            }
-            if (total == 0) break;  // uniform
-            int pos = base + inc - mine;  // exclusive offset of this lane's first pair
-#pragma unroll
-            for (int w = 0; w < SLAB_WORDS; ++w) {
-                uint32_t m = mw[w];
-                while (m && pos < QCAP) {
-                    const int j = __ffs(m) - 1;
-                    m &= m - 1;
-                    queue[pos++] = (unsigned short)((tid << 8) | (w * 32 + j));
-                }
-                mw[w] = m;  // what did not fit waits for the next round
-            }
-            __syncthreads();
-            const int nq = min(total, QCAP);
-            // ---- phase 2: exact lazy evaluation, one (line, group) pair per lane and step
-            for (int e = tid; e < nq; e += 256) {
-                const unsigned ent = queue[e];
-                const int ll = ent >> 8, gl = ent & 255;
-                const int g = g0 + gl;
-                const float4 la = lines_lds[ll][0], lb = lines_lds[ll][1];
-                const float4 *row = slab + gl * GRP;
-                uint32_t passbits = 0;
-#pragma unroll
-                for (int t = 0; t < GRP; ++t) {
-                    const float4 rec = row[(t + g) & 15];
-                    const float x = dist_sq<float>(rec.x, rec.y, rec.z, la.x, la.y, la.z, la.w, lb.x, lb.y);
-                    passbits |= (__float_as_uint(x) < __float_as_uint(rec.w) ? 1u : 0u) << t;
-                }
-                while (passbits) {  // rare: point 0 of sorted triangle g*16+t is within thr
-                    const int t = __ffs(passbits) - 1;
-                    passbits &= passbits - 1;
-                    const int f = idx[(size_t)g * GRP + t];
-                    const float *q = ptri + PTRI_STRIDE * (size_t)f;
-                    const uint32_t thr2 = __float_as_uint(q[9]);
-                    const float x1 = dist_sq<float>(q[3], q[4], q[5], la.x, la.y, la.z, la.w, lb.x, lb.y);
-                    const float x2 = dist_sq<float>(q[6], q[7], q[8], la.x, la.y, la.z, la.w, lb.x, lb.y);
-                    if (max(__float_as_uint(x1), __float_as_uint(x2)) < thr2) {
-                        const int gl_line = l0 + ll;
-                        int pos2 = atomicAdd(&cnt[gl_line], 1);
-                        if (pos2 < RRL_MAX_HITS) hit[(size_t)gl_line * RRL_MAX_HITS + pos2] = f;
-                    }
-                }
-            }
-            if (total <= QCAP) break;  // uniform: nothing left over
+            bmask |= (pass ? 1u : 0u) << ngrp;
+            if (lane == 0) ctx.bgrp[ngrp] = g;
+            nent += c;
+            ++ngrp;
         }
     }
+    if (nent) run_batch(ctx, bmask, nent, ngrp, ncand, lane);
+    wave_lds_fence();
+    const int nc = min(ncand, WCCAP);
+    for (int i = lane; i < nc; i += 64) resolve_candidate(ctx, ctx.cands[i]);
 }
 
 // Launchers used by rrl_tri_prepare / rrl_line_tri_scan (rrl_scan.hip)
@@ -345,7 +408,7 @@ int rrl_launch_tri_sort(void *ws, const WsLayout &w, int B, int N, int M, hipStr
 
 int rrl_launch_cull_scan(const float *line, void *ws, const WsLayout &w, int B, int N, int M, int L,
                          hipStream_t s) {
-    hipLaunchKernelGGL(cull_scan_kernel, dim3((unsigned)((L + 255) / 256), (unsigned)(2 * B)), dim3(256), 0,
+    hipLaunchKernelGGL(cull_scan_kernel, dim3((unsigned)((L + 63) / 64), (unsigned)(2 * B)), dim3(256), 0,
                        s, w.f32(ws, RRL_WS_PTRI1), w.f32(ws, RRL_WS_PTRI2),
                        (const float4 *)w.f32(ws, RRL_WS_P0S1), (const float4 *)w.f32(ws, RRL_WS_P0S2),
                        w.i32(ws, RRL_WS_IDX1), w.i32(ws, RRL_WS_IDX2), (const float4 *)w.f32(ws, RRL_WS_GRP1),

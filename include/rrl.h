@@ -66,7 +66,7 @@ enum {
     RRL_WS_HIT2,
     RRL_WS_PTRI1,      /* float[B][N][12] 9 coords, thr2, thr, original triangle index (int)  */
     RRL_WS_PTRI2,      /* float[B][M][12]                                                   */
-    RRL_WS_P0S1,       /* float[B][16*NG1][4] P0 + thr2 in Morton order, slot-swizzled per group */
+    RRL_WS_P0S1,       /* float[B][16*NG1][4] P0 + thr2 in grid-cell (Morton) order            */
     RRL_WS_P0S2,       /*   NG = ceil(N/16) groups                                             */
     RRL_WS_IDX1,       /* int32[B][16*NG1]  original triangle index of each sorted position     */
     RRL_WS_IDX2,

@@ -67,7 +67,7 @@ def test_tri_prepare_exact(L, oracle):
         assert np.all(d * d <= grp[gi, 3] * (1 + 1e-6))
     p0s = st.p0s1[0].cpu().numpy()
     for s_ in (0, 17, n - 1):
-        slot = (s_ & ~15) | ((s_ + (s_ >> 4)) & 15)
+        slot = s_
         np.testing.assert_array_equal(p0s[slot], np.append(pt[idx[s_], :3], thr2[idx[s_]]))
 
 
