@@ -192,6 +192,10 @@ typedef const float __attribute__((address_space(4))) * kptr;  // constant AS ->
 
 #define BGRP 16    // groups per batch: their 16 x 256-byte rows are staged in the wave's LDS
 #define WCCAP 256  // parked point-0 candidates per wave (1 KiB)
+#define ROWS 17    // float4 per staged row: 16 records + 16 bytes of padding (bank spread)
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void glb_void_t;
 
 struct WaveCtx {
     const float4 *lines;          // this wave's 64 lines in LDS: [64][2]
@@ -251,15 +255,9 @@ __device__ __forceinline__ void run_batch(const WaveCtx &c, uint32_t bmask, int 
             c.ent[pos++] = (unsigned short)((lane << 4) | k);
         }
     }
-    wave_lds_fence();
-    {
-        const int q = lane >> 4, t = lane & 15;
-#pragma unroll
-        for (int r = 0; r < BGRP / 4; ++r) {
-            const int k = r * 4 + q;
-            if (k < ngrp) c.rows[k * 16 + ((t + k) & 15)] = c.p0s[(size_t)c.bgrp[k] * GRP + t];
-        }
-    }
+    // the rows of this batch were requested (global -> LDS DMA) as their groups were appended in
+    // phase 1; wait for the stragglers
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     wave_lds_fence();
     uint32_t passbits = 0;
     int ll = 0, g = 0;
@@ -269,10 +267,10 @@ __device__ __forceinline__ void run_batch(const WaveCtx &c, uint32_t bmask, int 
         const int k = e & 15;
         g = c.bgrp[k];
         const float4 la = c.lines[2 * ll], lb = c.lines[2 * ll + 1];
-        const float4 *row = c.rows + k * 16;
+        const float4 *row = c.rows + k * ROWS;
 #pragma unroll
         for (int t = 0; t < GRP; ++t) {
-            const float4 rec = row[(t + k) & 15];
+            const float4 rec = row[t];
             const float x = dist_sq<float>(rec.x, rec.y, rec.z, la.x, la.y, la.z, la.w, lb.x, lb.y);
             passbits |= (__float_as_uint(x) < __float_as_uint(rec.w) ? 1u : 0u) << t;
         }
@@ -307,7 +305,7 @@ __global__ __launch_bounds__(256) void cull_scan_kernel(
     int32_t *__restrict__ count1, int32_t *__restrict__ hit1, int32_t *__restrict__ count2,
     int32_t *__restrict__ hit2, const uint32_t *__restrict__ pmax, int B, int N, int M, int L) {
     __shared__ __attribute__((aligned(16))) float4 lines_lds[4][64][2];    // 8 KiB
-    __shared__ __attribute__((aligned(16))) float4 rows_lds[4][BGRP * 16];  // 16 KiB
+    __shared__ __attribute__((aligned(16))) float4 rows_lds[4][BGRP * ROWS];  // 17 KiB
     __shared__ unsigned cands_lds[4][WCCAP];                               // 4 KiB
     __shared__ unsigned short ent_lds[4][64];
     __shared__ int bgrp_lds[4][BGRP];
@@ -384,6 +382,11 @@ __global__ __launch_bounds__(256) void cull_scan_kernel(
             }
             bmask |= (pass ? 1u : 0u) << ngrp;
             if (lane == 0) ctx.bgrp[ngrp] = g;
+            // asynchronous copy of the group's 16 records into LDS row `ngrp` (lanes 0..15, 16 B
+            // each; the DMA writes wave-uniform base + lane * 16)
+            if (lane < 16)
+                __builtin_amdgcn_global_load_lds((glb_void_t *)(ctx.p0s + (size_t)g * GRP + lane),
+                                                 (lds_void_t *)(ctx.rows + ngrp * ROWS), 16, 0, 0);
             nent += c;
             ++ngrp;
         }
