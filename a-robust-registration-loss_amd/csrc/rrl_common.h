@@ -81,3 +81,29 @@ __device__ __forceinline__ bool rrl_line_safe(const float *v, float pm) {
 }
 
 #define RRL_SCAN_UNSAFE_TILES 4  // internal: strict loop, only for 512-line tiles that fail the bound
+
+// ---- wave64 cross-lane helpers on DPP (no LDS crossbar: ds_bpermute-based __shfl trees cost
+//      hundreds of cycles per step under load, DPP steps cost one VALU issue each) ----------
+// inclusive prefix sum over the 64 lanes (the sequence of LLVM's AMDGPU atomic optimizer):
+// row_shr 1,2,4,8 inside each row of 16, then row_bcast:15 / row_bcast:31 across rows
+__device__ __forceinline__ int wave_incl_scan(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
+    return v;
+}
+// sum over the 64 lanes, returned in every lane (fixed association: deterministic)
+__device__ __forceinline__ float wave_sum(float v) {
+#define RRL_DPP_ADD(ctrl, rm)                                                                   \
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, rm, 0xf, false))
+    RRL_DPP_ADD(0x111, 0xf); RRL_DPP_ADD(0x112, 0xf); RRL_DPP_ADD(0x114, 0xf); RRL_DPP_ADD(0x118, 0xf);
+    RRL_DPP_ADD(0x142, 0xa); RRL_DPP_ADD(0x143, 0xc);
+#undef RRL_DPP_ADD
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+    return __builtin_amdgcn_readlane(wave_incl_scan(v), 63);
+}

@@ -60,7 +60,8 @@ __device__ __forceinline__ int p0s_slot(int s) { return s; }  // records in sort
 __global__ __launch_bounds__(1024) void tri_sort_kernel(
     const float *__restrict__ ptri1, const float *__restrict__ ptri2, float4 *__restrict__ p0s1,
     float4 *__restrict__ p0s2, int32_t *__restrict__ idx1, int32_t *__restrict__ idx2,
-    float4 *__restrict__ grp1, float4 *__restrict__ grp2, int B, int N, int M) {
+    float4 *__restrict__ grp1, float4 *__restrict__ grp2, uint32_t *__restrict__ pmax, int B, int N,
+    int M) {
     extern __shared__ __attribute__((aligned(16))) float thr_s[];  // thr by sorted position
     __shared__ unsigned hist[SORT_CELLS];
     __shared__ float red[16][8];
@@ -74,31 +75,38 @@ __global__ __launch_bounds__(1024) void tri_sort_kernel(
     int32_t *idx = (cloud ? idx2 : idx1) + (size_t)b * ng * GRP;
     float4 *grp = (cloud ? grp2 : grp1) + (size_t)b * ng;
 
-    // ---- AABB of the P0s
-    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    // ---- AABB of the P0s and max |P|^2 over all three points (the NaN bound's input)
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY}, p2 = 0.0f;
     for (int f = tid; f < n; f += 1024) {
         const float *p = ptri + PTRI_STRIDE * (size_t)f;
 #pragma unroll
         for (int c = 0; c < 3; ++c) { mn[c] = fminf(mn[c], p[c]); mx[c] = fmaxf(mx[c], p[c]); }
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            p2 = fmaxf(p2, p[3 * k] * p[3 * k] + p[3 * k + 1] * p[3 * k + 1] + p[3 * k + 2] * p[3 * k + 2]);
     }
+    if (!(p2 <= 3.0e38f)) p2 = INFINITY;  // NaN/inf coordinates: never "provably safe"
 #pragma unroll
     for (int c = 0; c < 3; ++c)
         for (int o = 32; o > 0; o >>= 1) {
             mn[c] = fminf(mn[c], __shfl_down(mn[c], o));
             mx[c] = fmaxf(mx[c], __shfl_down(mx[c], o));
         }
+    for (int o = 32; o > 0; o >>= 1) p2 = fmaxf(p2, __shfl_down(p2, o));
     if (lane == 0) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) { red[wave][c] = mn[c]; red[wave][3 + c] = mx[c]; }
+        red[wave][6] = p2;
     }
     for (int i = tid; i < SORT_CELLS; i += 1024) hist[i] = 0;
     __syncthreads();
-    if (tid < 6) {
+    if (tid < 7) {
         float r = red[0][tid];
         for (int w = 1; w < 16; ++w) r = tid < 3 ? fminf(r, red[w][tid]) : fmaxf(r, red[w][tid]);
         red[0][tid] = r;
     }
     __syncthreads();
+    if (tid == 0) pmax[cloud * B + b] = __float_as_uint(red[0][6]);
     float scale[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -123,11 +131,7 @@ __global__ __launch_bounds__(1024) void tri_sort_kernel(
         unsigned h[4], tsum = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) { h[k] = hist[4 * tid + k]; tsum += h[k]; }
-        unsigned inc = tsum;
-        for (int o = 1; o < 64; o <<= 1) {
-            unsigned t = __shfl_up(inc, o);
-            if (lane >= o) inc += t;
-        }
+        const unsigned inc = (unsigned)wave_incl_scan((int)tsum);
         if (lane == 63) wsum[wave] = inc;
         __syncthreads();
         unsigned base = 0;
@@ -242,12 +246,7 @@ __device__ __forceinline__ void run_batch(const WaveCtx &c, uint32_t bmask, int 
     // prefix sum so that every lane evaluates exactly one (line, group) pair
     {
         const int mine = __popc(bmask);
-        int inc = mine;
-        for (int o = 1; o < 64; o <<= 1) {
-            int t = __shfl_up(inc, o);
-            if (lane >= o) inc += t;
-        }
-        int pos = inc - mine;
+        int pos = wave_incl_scan(mine) - mine;
         uint32_t m = bmask;
         while (m) {
             const int k = __ffs(m) - 1;
@@ -404,7 +403,8 @@ int rrl_launch_tri_sort(void *ws, const WsLayout &w, int B, int N, int M, hipStr
     hipLaunchKernelGGL(tri_sort_kernel, dim3((unsigned)(2 * B)), dim3(1024), lds, s, w.f32(ws, RRL_WS_PTRI1),
                        w.f32(ws, RRL_WS_PTRI2), (float4 *)w.f32(ws, RRL_WS_P0S1),
                        (float4 *)w.f32(ws, RRL_WS_P0S2), w.i32(ws, RRL_WS_IDX1), w.i32(ws, RRL_WS_IDX2),
-                       (float4 *)w.f32(ws, RRL_WS_GRP1), (float4 *)w.f32(ws, RRL_WS_GRP2), B, N, M);
+                       (float4 *)w.f32(ws, RRL_WS_GRP1), (float4 *)w.f32(ws, RRL_WS_GRP2),
+                       (uint32_t *)w.i32(ws, RRL_WS_PMAX), B, N, M);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }

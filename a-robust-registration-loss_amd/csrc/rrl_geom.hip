@@ -110,8 +110,7 @@ __global__ __launch_bounds__(1024) void rigid_bwd_kernel(const float *__restrict
         }
     }
 #pragma unroll
-    for (int q = 0; q < 12; ++q)
-        for (int o = 32; o > 0; o >>= 1) acc[q] += __shfl_down(acc[q], o);
+    for (int q = 0; q < 12; ++q) acc[q] = wave_sum(acc[q]);
     const int wave = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0)
 #pragma unroll

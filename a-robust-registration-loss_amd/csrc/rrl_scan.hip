@@ -33,36 +33,66 @@
 // ---------------------------------------------------------------------------------------
 // K1' prepared triangles (+ max |P|^2 per cloud and sample for the auto-mode NaN bound)
 // ---------------------------------------------------------------------------------------
+// 64 triangles per workgroup, staged through LDS so that both the 36-byte input rows and the
+// 48-byte output records move with fully coalesced accesses.
+// SORTED path (the usual one): max |P|^2 is computed later by tri_sort_kernel and this kernel
+// also clears the per-call state (every field of the zero region except PMAX), so no memset is
+// needed.  LEGACY path (clouds too large to sort): state cleared by a memset, atomicMax on PMAX.
+template <bool LEGACY>
 __global__ __launch_bounds__(64) void tri_prepare_kernel(const float *__restrict__ tri1,
-                                                          const float *__restrict__ tri2,
-                                                          float *__restrict__ ptri1,
-                                                          float *__restrict__ ptri2,
-                                                          uint32_t *__restrict__ pmax, int B, int N,
-                                                          int M) {
-    const int cloud = blockIdx.z, b = blockIdx.y;
-    const int n = cloud ? M : N;
-    const int f = blockIdx.x * 64 + threadIdx.x;
-    float p2 = 0.0f;
-    if (f < n) {
-        const float *p = (cloud ? tri2 : tri1) + 9 * ((size_t)b * n + f);
-        float c[9];
-#pragma unroll
-        for (int i = 0; i < 9; ++i) c[i] = p[i];
-        float thr, x;
-        tri_thresholds(c, &thr, &x);
-        float *q = (cloud ? ptri2 : ptri1) + PTRI_STRIDE * ((size_t)b * n + f);
-#pragma unroll
-        for (int i = 0; i < 9; ++i) q[i] = c[i];
-        q[9] = x;
-        q[10] = thr;
-        q[11] = __int_as_float(f);  // original index (identity order on this path)
-#pragma unroll
-        for (int k = 0; k < 3; ++k)
-            p2 = fmaxf(p2, c[3 * k] * c[3 * k] + c[3 * k + 1] * c[3 * k + 1] + c[3 * k + 2] * c[3 * k + 2]);
-        if (!(p2 <= 3.0e38f)) p2 = INFINITY;  // NaN/inf coordinates: never "provably safe"
+                                                         const float *__restrict__ tri2,
+                                                         float *__restrict__ ptri1,
+                                                         float *__restrict__ ptri2,
+                                                         uint32_t *__restrict__ pmax,
+                                                         uint4 *__restrict__ zero_base,
+                                                         size_t zero_vec4, size_t skip_lo,
+                                                         size_t skip_hi, int B, int N, int M) {
+    __shared__ float sin_[64 * 9];
+    __shared__ float sout[64 * PTRI_STRIDE];
+    const int cloud = blockIdx.z, b = blockIdx.y, tid = threadIdx.x;
+    if constexpr (!LEGACY) {
+        const size_t nblk = (size_t)gridDim.x * gridDim.y * gridDim.z;
+        const size_t me = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        for (size_t i = me * 64 + tid; i < zero_vec4; i += nblk * 64)
+            if (i < skip_lo || i >= skip_hi) zero_base[i] = make_uint4(0, 0, 0, 0);
     }
-    for (int o = 32; o > 0; o >>= 1) p2 = fmaxf(p2, __shfl_down(p2, o));
-    if ((threadIdx.x & 63) == 0) atomicMax(&pmax[cloud * B + b], __float_as_uint(p2));
+    const int n = cloud ? M : N;
+    const int f0 = blockIdx.x * 64;
+    if (f0 >= n) return;
+    const int cnt = min(64, n - f0);
+    const float *src = (cloud ? tri2 : tri1) + 9 * ((size_t)b * n + f0);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const int i = k * 64 + tid;
+        sin_[i] = i < cnt * 9 ? src[i] : 0.0f;
+    }
+    __syncthreads();
+    float c[9], thr, x, p2 = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) c[i] = sin_[tid * 9 + i];
+    tri_thresholds(c, &thr, &x);  // code/loss.py:94-110
+#pragma unroll
+    for (int i = 0; i < 9; ++i) sout[tid * PTRI_STRIDE + i] = c[i];
+    sout[tid * PTRI_STRIDE + 9] = x;
+    sout[tid * PTRI_STRIDE + 10] = thr;
+    sout[tid * PTRI_STRIDE + 11] = __int_as_float(f0 + tid);  // original index
+    __syncthreads();
+    float *dst = (cloud ? ptri2 : ptri1) + PTRI_STRIDE * ((size_t)b * n + f0);
+#pragma unroll
+    for (int k = 0; k < PTRI_STRIDE; ++k) {
+        const int i = k * 64 + tid;
+        if (i < cnt * PTRI_STRIDE) dst[i] = sout[i];
+    }
+    if constexpr (LEGACY) {
+        if (tid < cnt) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                p2 = fmaxf(p2, c[3 * k] * c[3 * k] + c[3 * k + 1] * c[3 * k + 1] + c[3 * k + 2] * c[3 * k + 2]);
+            if (!(p2 <= 3.0e38f)) p2 = INFINITY;  // NaN/inf coordinates: never "provably safe"
+        }
+        for (int o = 32; o > 0; o >>= 1) p2 = fmaxf(p2, __shfl_down(p2, o));
+        if (tid == 0) atomicMax(&pmax[cloud * B + b], __float_as_uint(p2));
+    }
 }
 
 int rrl_launch_tri_sort(void *ws, const WsLayout &w, int B, int N, int M, hipStream_t s);
@@ -77,16 +107,28 @@ extern "C" int rrl_tri_prepare(const float *tri1, const float *tri2, void *ws, s
     if (ws_bytes < w.total) return RRL_E_WS;
     hipStream_t s = (hipStream_t)stream;
     const int nmax = N > M ? N : M;
-    // one memset clears status, nvals, nsel, pmax, count1, count2 (contiguous by construction)
-    hipError_t e = hipMemsetAsync((char *)ws + w.off[RRL_WS_STATUS], 0, w.zero_bytes, s);
-    if (e != hipSuccess) return (int)e;
+    const bool sorted = nmax <= rrl_sort_capacity();
+    uint4 *zb = (uint4 *)((char *)ws + w.off[RRL_WS_STATUS]);
+    if (!sorted || B == 0 || nmax == 0) {
+        // one memset clears status, nvals, nsel, pmax, count1, count2 (contiguous by construction)
+        hipError_t e = hipMemsetAsync(zb, 0, w.zero_bytes, s);
+        if (e != hipSuccess) return (int)e;
+    }
     if (B == 0 || nmax == 0) return 0;
-    hipLaunchKernelGGL(tri_prepare_kernel, dim3((unsigned)((nmax + 63) / 64), (unsigned)B, 2),
-                       dim3(64), 0, s, tri1, tri2, w.f32(ws, RRL_WS_PTRI1), w.f32(ws, RRL_WS_PTRI2),
-                       (uint32_t *)w.i32(ws, RRL_WS_PMAX), B, N, M);
+    dim3 grid((unsigned)((nmax + 63) / 64), (unsigned)B, 2);
+    if (sorted)
+        hipLaunchKernelGGL(tri_prepare_kernel<false>, grid, dim3(64), 0, s, tri1, tri2,
+                           w.f32(ws, RRL_WS_PTRI1), w.f32(ws, RRL_WS_PTRI2),
+                           (uint32_t *)w.i32(ws, RRL_WS_PMAX), zb, w.zero_bytes / 16,
+                           w.off[RRL_WS_PMAX] / 16, w.off[RRL_WS_COUNT1] / 16, B, N, M);
+    else
+        hipLaunchKernelGGL(tri_prepare_kernel<true>, grid, dim3(64), 0, s, tri1, tri2,
+                           w.f32(ws, RRL_WS_PTRI1), w.f32(ws, RRL_WS_PTRI2),
+                           (uint32_t *)w.i32(ws, RRL_WS_PMAX), zb, (size_t)0, (size_t)0, (size_t)0, B,
+                           N, M);
     RRL_LAUNCH_CHECK();
-    // Morton order + group spheres for the culled scan
-    if (nmax <= rrl_sort_capacity()) return rrl_launch_tri_sort(ws, w, B, N, M, s);
+    // grid-cell order + group spheres + max |P|^2 for the culled scan
+    if (sorted) return rrl_launch_tri_sort(ws, w, B, N, M, s);
     return 0;
 }
 

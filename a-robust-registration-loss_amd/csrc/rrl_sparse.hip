@@ -55,9 +55,9 @@ __global__ __launch_bounds__(1024) void line_pair_dist_kernel(
     const int32_t *__restrict__ count2, const int32_t *__restrict__ hit2,
     uint8_t *__restrict__ kj, int32_t *__restrict__ sel_out, int32_t *__restrict__ nsel,
     int32_t *__restrict__ hs1, int32_t *__restrict__ hs2, float *__restrict__ w1,
-    float *__restrict__ w2, float *__restrict__ D, float *__restrict__ vals,
-    int32_t *__restrict__ nvals, int B, int N, int M, int L, int s_m, int s_n, int e_m, int e_n,
-    int pool) {
+    float *__restrict__ w2, float4 *__restrict__ Q1, float4 *__restrict__ Q2, float *__restrict__ D,
+    float *__restrict__ vals, int32_t *__restrict__ nvals, int B, int N, int M, int L, int s_m,
+    int s_n, int e_m, int e_n, int pool) {
     __shared__ int s_list[1024];
     __shared__ int s_wave[16];
     __shared__ int s_total, s_base;
@@ -110,6 +110,7 @@ __global__ __launch_bounds__(1024) void line_pair_dist_kernel(
             hit_weights(t1, h1[a], ln, w);
             inter_point(t1, h1[a], w, q1[a]);
             hs1[gl * RRL_MAX_HITS + a] = h1[a];
+            Q1[gl * RRL_MAX_HITS + a] = make_float4(q1[a][0], q1[a][1], q1[a][2], 0.0f);
 #pragma unroll
             for (int c = 0; c < 3; ++c) w1[(gl * RRL_MAX_HITS + a) * 3 + c] = w[c];
         }
@@ -118,6 +119,7 @@ __global__ __launch_bounds__(1024) void line_pair_dist_kernel(
             hit_weights(t2, h2[a], ln, w);
             inter_point(t2, h2[a], w, q2[a]);
             hs2[gl * RRL_MAX_HITS + a] = h2[a];
+            Q2[gl * RRL_MAX_HITS + a] = make_float4(q2[a][0], q2[a][1], q2[a][2], 0.0f);
 #pragma unroll
             for (int c = 0; c < 3; ++c) w2[(gl * RRL_MAX_HITS + a) * 3 + c] = w[c];
         }
@@ -156,9 +158,9 @@ extern "C" int rrl_line_pair_dist(const float *tri1, const float *tri2, const fl
                        w.i32(ws, RRL_WS_COUNT1), w.i32(ws, RRL_WS_HIT1), w.i32(ws, RRL_WS_COUNT2),
                        w.i32(ws, RRL_WS_HIT2), w.u8(ws, RRL_WS_KJ), w.i32(ws, RRL_WS_SEL),
                        w.i32(ws, RRL_WS_NSEL), w.i32(ws, RRL_WS_HS1), w.i32(ws, RRL_WS_HS2),
-                       w.f32(ws, RRL_WS_W1), w.f32(ws, RRL_WS_W2), w.f32(ws, RRL_WS_D),
-                       w.f32(ws, RRL_WS_VALS), w.i32(ws, RRL_WS_NVALS), B, N, M, L, s_m, s_n, e_m,
-                       e_n, pool);
+                       w.f32(ws, RRL_WS_W1), w.f32(ws, RRL_WS_W2), (float4 *)w.f32(ws, RRL_WS_Q1),
+                       (float4 *)w.f32(ws, RRL_WS_Q2), w.f32(ws, RRL_WS_D), w.f32(ws, RRL_WS_VALS),
+                       w.i32(ws, RRL_WS_NVALS), B, N, M, L, s_m, s_n, e_m, e_n, pool);
     RRL_LAUNCH_CHECK();
     return 0;
 }
@@ -171,16 +173,23 @@ __device__ __forceinline__ float welsch(float d, float med) {
     return 1.0f - expf(-(d / med) / 2.0f);
 }
 
-// Row/column minima of the k x j Welsch block with first-occurrence argmin (torch.min,
-// SURVEY.md Q11).  All indices static after unrolling (no scratch).
-__device__ __forceinline__ void welsch_block(const float *__restrict__ Dl, int k, int j, float med,
-                                             float *rowmin, float *colmin, int *arg_b, int *arg_a) {
-    float Wl[16];
+// The k x j block of D values is stored row-major with stride j; bring it into a 4 x 4
+// register tile (static indices only; entries outside the block are +inf).
+__device__ __forceinline__ void load_block(const float *__restrict__ Dl, int k, int j, float *Dm) {
 #pragma unroll
     for (int a = 0; a < RRL_MAX_HITS; ++a)
 #pragma unroll
-        for (int b = 0; b < RRL_MAX_HITS; ++b)
-            Wl[a * 4 + b] = (a < k && b < j) ? welsch(Dl[a * j + b], med) : INFINITY;
+        for (int b = 0; b < RRL_MAX_HITS; ++b) Dm[a * 4 + b] = (a < k && b < j) ? Dl[a * j + b] : INFINITY;
+}
+
+// Row/column minima of the Welsch-weighted tile with first-occurrence argmin (torch.min,
+// SURVEY.md Q11).  All indices static after unrolling (no scratch).  Welsch1(inf) = 1 - exp(-inf)
+// = 1 would tie with saturated entries, so padding is forced back to +inf.
+__device__ __forceinline__ void welsch_block(const float *Dm, float med, float *rowmin, float *colmin,
+                                             int *arg_b, int *arg_a) {
+    float Wl[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) Wl[q] = Dm[q] < INFINITY ? welsch(Dm[q], med) : INFINITY;
 #pragma unroll
     for (int a = 0; a < RRL_MAX_HITS; ++a) {
         float best = Wl[a * 4];
@@ -211,53 +220,100 @@ __global__ __launch_bounds__(1024) void loss_reduce_kernel(
     float *__restrict__ med_out, int32_t *__restrict__ bcnt_out, int64_t *__restrict__ bsum_out,
     int32_t *__restrict__ info, float *__restrict__ loss, int B, int L, int s_m, int s_n, int e_m,
     int e_n, int pool) {
-    __shared__ unsigned s_bit[32];
+    __shared__ unsigned s_hist[2048];
+    __shared__ unsigned s_wtot[16];
+    __shared__ unsigned s_prefix, s_rank;
     __shared__ unsigned long long s_sum[32];
     __shared__ int s_cnt[16];
+    __shared__ float s_term[16];
     const int g = blockIdx.x, tid = threadIdx.x;
     const int bm = pool ? B - 1 : g;  // whose values define the median
     const float *v = vals + (size_t)bm * L * 16;
     const unsigned n = (unsigned)nvals[bm];
-    if (tid < 32) { s_bit[tid] = 0; s_sum[tid] = 0ull; }
+    if (tid < 32) s_sum[tid] = 0ull;
     if (tid < 16) s_cnt[tid] = 0;
     __syncthreads();
 
-    // ---- lower median = element of rank (n-1)/2 (torch.median).  Bitwise MSB-first select on
-    //      the bit patterns (D >= 0: unsigned order == float order).  Per bit: count the values
-    //      that agree with the prefix and have the bit clear; counting is ballot/shuffle based,
-    //      one LDS atomic per wave and ONE barrier per bit (no contended histogram).
+    // ---- lower median = element of rank (n-1)/2 (torch.median): MSB-first radix select on the
+    //      bit patterns (D >= 0: unsigned order == float order).
     unsigned u[MED_REGS];
 #pragma unroll
     for (int i = 0; i < MED_REGS; ++i) {
         unsigned idx = (unsigned)tid + 1024u * i;
         u[i] = idx < n ? __float_as_uint(v[idx]) : 0xffffffffu;  // all-ones never matches a prefix
     }
-    unsigned prefix = 0, rank = n ? (n - 1) / 2 : 0;
-    for (int bit = 30; bit >= 0 && n > 0; --bit) {  // bit 31 (sign) is clear for every D
-        unsigned c = 0;
+    // the Welsch stage's inputs do not depend on the median: fetch this lane's first line now so
+    // that the nsel -> sel -> (kj, D) chain of dependent loads overlaps the median passes
+    const int b0 = pool ? 0 : g, b1 = pool ? B : g + 1;
+    const int ns0 = nsel[b0];
+    unsigned c_pre = 0;
+    float D_pre[16];
 #pragma unroll
-        for (int i = 0; i < MED_REGS; ++i) c += ((u[i] ^ prefix) >> bit) == 0u;
-        for (unsigned idx = (unsigned)tid + 1024u * MED_REGS; idx < n; idx += 1024u)
-            c += ((__float_as_uint(v[idx]) ^ prefix) >> bit) == 0u;
-        for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
-        if ((tid & 63) == 0 && c) atomicAdd(&s_bit[bit], c);
+    for (int q = 0; q < 16; ++q) D_pre[q] = 0.0f;
+    if (tid < ns0) {
+        const size_t gl = (size_t)b0 * L + sel[(size_t)b0 * L + tid];
+        c_pre = kj[gl];
+        load_block(D + gl * 16, c_pre & 15, c_pre >> 4, D_pre);
+    }
+    // Three passes over digits of 11, 11 and 9 bits (bit 31, the sign, is clear): LDS histogram
+    // of the values that agree with the prefix (wide digits keep the atomics uncontended: even
+    // the first digit spreads over exponent + 3 mantissa bits), block-wide exclusive scan of the
+    // histogram (DPP wave scans + wave totals), pick the bin that holds the rank.
+    unsigned prefix = 0;
+    if (tid == 0) { s_rank = n ? (n - 1) / 2 : 0; }
+    for (int pass = 0; pass < 3 && n > 0; ++pass) {
+        const int sh = pass == 0 ? 20 : (pass == 1 ? 9 : 0);
+        const int width = pass == 2 ? 9 : 11;
+        const unsigned dmask = (1u << width) - 1u;
+        s_hist[tid] = 0;
+        s_hist[tid + 1024] = 0;
         __syncthreads();
-        const unsigned zeros = s_bit[bit];
-        if (rank >= zeros) { rank -= zeros; prefix |= 1u << bit; }
+        const int hi = sh + width;  // bits >= hi must equal the prefix (hi = 31 on the first pass)
+        auto tally = [&](unsigned x) {
+            if (((x ^ prefix) >> hi) == 0u) atomicAdd(&s_hist[(x >> sh) & dmask], 1u);
+        };
+#pragma unroll
+        for (int i = 0; i < MED_REGS; ++i) tally(u[i]);
+        for (unsigned idx = (unsigned)tid + 1024u * MED_REGS; idx < n; idx += 1024u)
+            tally(__float_as_uint(v[idx]));
+        __syncthreads();
+        const unsigned h0 = s_hist[2 * tid], h1 = s_hist[2 * tid + 1];
+        const unsigned incl = (unsigned)wave_incl_scan((int)(h0 + h1));
+        if ((tid & 63) == 63) s_wtot[tid >> 6] = incl;
+        __syncthreads();
+        unsigned base = 0;
+        for (int w = 0; w < (tid >> 6); ++w) base += s_wtot[w];
+        const unsigned excl = base + incl - (h0 + h1), r = s_rank;
+        __syncthreads();  // everybody has read s_rank before the owner of the bin rewrites it
+        if (r >= excl && r < excl + h0 + h1) {  // exactly one lane
+            const unsigned second = r >= excl + h0 ? 1u : 0u;
+            s_prefix = prefix | ((2u * tid + second) << sh);
+            s_rank = r - excl - (second ? h0 : 0u);
+        }
+        __syncthreads();
+        prefix = s_prefix;
     }
     const float med = n ? __uint_as_float(prefix) : 0.0f;
 
     // ---- Welsch + symmetric min per selected line, bucket sums in LDS (fixed point)
-    const int b0 = pool ? 0 : g, b1 = pool ? B : g + 1;
     for (int b = b0; b < b1; ++b) {
-        const int ns = nsel[b];
+        const int ns = b == b0 ? ns0 : nsel[b];
         for (int i = tid; i < ns; i += 1024) {
-            const size_t gl = (size_t)b * L + sel[(size_t)b * L + i];
-            const unsigned c = kj[gl];
+            unsigned c;
+            float Dl[16];
+            if (b == b0 && i == tid) {  // prefetched before the median passes
+                c = c_pre;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) Dl[q] = D_pre[q];
+            } else {
+                const size_t gl = (size_t)b * L + sel[(size_t)b * L + i];
+                c = kj[gl];
+                load_block(D + gl * 16, c & 15, c >> 4, Dl);
+            }
             const int k = c & 15, j = c >> 4;
             float rowmin[4], colmin[4];
             int arg_b[4], arg_a[4];
-            welsch_block(D + gl * 16, k, j, med, rowmin, colmin, arg_b, arg_a);
+            welsch_block(Dl, med, rowmin, colmin, arg_b, arg_a);
             float row = 0.0f, col = 0.0f;
 #pragma unroll
             for (int a = 0; a < RRL_MAX_HITS; ++a)
@@ -277,21 +333,29 @@ __global__ __launch_bounds__(1024) void loss_reduce_kernel(
     // ---- loss = ( sum_{non-empty (k,j), k-major} exp(-|k-j|/2) (mean_row + mean_col) ) / C
     if (tid < 16) bcnt_out[g * 16 + tid] = s_cnt[tid];
     if (tid < 32) bsum_out[(size_t)g * 32 + tid] = (int64_t)s_sum[tid];
+    if (tid < 16) {  // one lane per bucket: the double-precision means
+        const int k = tid / 4 + 1, j = tid % 4 + 1, S = s_cnt[tid];
+        float term = 0.0f;
+        if (S > 0 && k >= s_m && k < e_m && j >= s_n && j < e_n) {
+            const double sc = 1.0 / (double)(1ll << FIX_SHIFT);
+            float mrow = (float)((double)s_sum[tid * 2 + 0] * sc / ((double)S * k));
+            float mcol = (float)((double)s_sum[tid * 2 + 1] * sc / ((double)S * j));
+            float wkj = expf(-0.5f * (float)abs(k - j));  // code/loss.py:215
+            term = wkj * (mrow + mcol);
+        }
+        s_term[tid] = term;
+    }
+    __syncthreads();
     if (tid == 0) {
         float acc = 0.0f;
         int C = 0, nselected = 0;
-        for (int k = s_m; k < e_m; ++k)
+        for (int k = s_m; k < e_m; ++k)      // k-major, the reference's accumulation order
             for (int j = s_n; j < e_n; ++j) {
                 const int bi = (k - 1) * 4 + (j - 1);
-                const int S = s_cnt[bi];
-                if (S == 0) continue;
-                const double sc = 1.0 / (double)(1ll << FIX_SHIFT);
-                float mrow = (float)((double)s_sum[bi * 2 + 0] * sc / ((double)S * k));
-                float mcol = (float)((double)s_sum[bi * 2 + 1] * sc / ((double)S * j));
-                float wkj = expf(-0.5f * (float)abs(k - j));  // code/loss.py:215
-                acc = acc + wkj * (mrow + mcol);
+                if (s_cnt[bi] == 0) continue;
+                acc = acc + s_term[bi];
                 ++C;
-                nselected += S;
+                nselected += s_cnt[bi];
             }
         med_out[g] = med;
         loss[g] = C ? acc / (float)C : 0.0f;  // code/loss.py:230
@@ -326,75 +390,60 @@ extern "C" int rrl_loss_reduce(void *ws, size_t ws_bytes, float *loss, int B, in
 // weights, median and labels carry no gradient (code/loss.py:112, 224).
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void loss_bwd_kernel(
-    const float *__restrict__ tri1, const float *__restrict__ tri2, const uint8_t *__restrict__ kj,
-    const int32_t *__restrict__ sel, const int32_t *__restrict__ nsel,
+    const uint8_t *__restrict__ kj, const int32_t *__restrict__ sel, const int32_t *__restrict__ nsel,
     const int32_t *__restrict__ hs1, const int32_t *__restrict__ hs2, const float *__restrict__ w1,
-    const float *__restrict__ w2, const float *__restrict__ D, const float *__restrict__ med,
-    const int32_t *__restrict__ bcnt, const int32_t *__restrict__ info,
-    const float *__restrict__ grad_loss, float *__restrict__ g1, float *__restrict__ g2, int B,
-    int N, int M, int L, int pool) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const float *__restrict__ w2, const float4 *__restrict__ Q1, const float4 *__restrict__ Q2,
+    const float *__restrict__ D, const float *__restrict__ med, const int32_t *__restrict__ bcnt,
+    const int32_t *__restrict__ info, const float *__restrict__ grad_loss, float *__restrict__ g1,
+    float *__restrict__ g2, int B, int N, int M, int L, int pool) {
+    // one lane per (selected line, side, hit slot): 8 lanes share a line, each owns <= 9 atomics
+    const int t = blockIdx.x * 256 + threadIdx.x;
     const int b = blockIdx.y;
-    if (i >= nsel[b]) return;  // dense wavefronts over the compacted selected lines
+    const int i = t >> 3, side = (t >> 2) & 1, h = t & 3;
+    if (i >= nsel[b] || (side && !g2)) return;
     const size_t gl = (size_t)b * L + sel[(size_t)b * L + i];
     const unsigned c = kj[gl];
     const int k = c & 15, j = c >> 4, g = pool ? 0 : b;
+    if (h >= (side ? j : k)) return;
     const int C = info[g * 4];
     if (C == 0) return;
     const float m = med[g];
-    float rowmin[4], colmin[4];
+    float Dm[16], rowmin[4], colmin[4];
     int arg_b[4], arg_a[4];
-    welsch_block(D + gl * 16, k, j, m, rowmin, colmin, arg_b, arg_a);
+    load_block(D + gl * 16, k, j, Dm);
+    welsch_block(Dm, m, rowmin, colmin, arg_b, arg_a);
     const int S = bcnt[g * 16 + (k - 1) * 4 + (j - 1)];
     const float wkj = expf(-0.5f * (float)abs(k - j));
     const float scale = grad_loss[g] * wkj / (float)C;
     const float inv_row = 1.0f / ((float)S * (float)k), inv_col = 1.0f / ((float)S * (float)j);
-    const float *t1 = tri1 + (size_t)b * N * 9, *t2 = tri2 + (size_t)b * M * 9;
-    float q1[RRL_MAX_HITS][3], q2[RRL_MAX_HITS][3], gq1[RRL_MAX_HITS][3], gq2[RRL_MAX_HITS][3];
+    const float4 mine = (side ? Q2 : Q1)[gl * 4 + h];
+    float gq[3] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
-    for (int a = 0; a < RRL_MAX_HITS; ++a) {
+    for (int o = 0; o < RRL_MAX_HITS; ++o) {
+        if (o >= (side ? k : j)) continue;
+        const int a = side ? o : h, bb = side ? h : o;
+        float sw = 0.0f;
 #pragma unroll
-        for (int cc = 0; cc < 3; ++cc) gq1[a][cc] = gq2[a][cc] = 0.0f;
-        if (a < k) inter_point(t1, hs1[gl * 4 + a], w1 + (gl * 4 + a) * 3, q1[a]);
-        if (a < j) inter_point(t2, hs2[gl * 4 + a], w2 + (gl * 4 + a) * 3, q2[a]);
+        for (int x = 0; x < RRL_MAX_HITS; ++x) {  // static indexing of arg_b / arg_a
+            if (x == a && arg_b[x] == bb) sw += inv_row;
+            if (x == bb && arg_a[x] == a) sw += inv_col;
+        }
+        if (sw == 0.0f) continue;
+        // dWl/dD = exp(-D/(2 med)) / (2 med);  dD/dq1 = 2 (q1 - q2) = -dD/dq2
+        const float gD = scale * sw * expf(-(D[gl * 16 + a * j + bb] / m) / 2.0f) / (2.0f * m);
+        const float4 other = (side ? Q1 : Q2)[gl * 4 + o];
+        gq[0] += 2.0f * (mine.x - other.x) * gD;
+        gq[1] += 2.0f * (mine.y - other.y) * gD;
+        gq[2] += 2.0f * (mine.z - other.z) * gD;
     }
+    const int f = (side ? hs2 : hs1)[gl * 4 + h];
+    const float *w = (side ? w2 : w1) + (gl * 4 + h) * 3;
+    float *dst = (side ? g2 + ((size_t)b * M + f) * 9 : g1 + ((size_t)b * N + f) * 9);
 #pragma unroll
-    for (int a = 0; a < RRL_MAX_HITS; ++a)
+    for (int kk = 0; kk < 3; ++kk) {
+        const float wk = w[kk] / 3.0f;  // q = mean_k(w_k P_k)
 #pragma unroll
-        for (int bb = 0; bb < RRL_MAX_HITS; ++bb)
-            if (a < k && bb < j) {
-                float sel = (arg_b[a] == bb ? inv_row : 0.0f) + (arg_a[bb] == a ? inv_col : 0.0f);
-                if (sel != 0.0f) {
-                    // dWl/dD = exp(-D/(2 med)) / (2 med)
-                    float gD = scale * sel * expf(-(D[gl * 16 + a * j + bb] / m) / 2.0f) / (2.0f * m);
-#pragma unroll
-                    for (int cc = 0; cc < 3; ++cc) {
-                        float t = 2.0f * (q1[a][cc] - q2[bb][cc]) * gD;
-                        gq1[a][cc] += t;
-                        gq2[bb][cc] -= t;
-                    }
-                }
-            }
-#pragma unroll
-    for (int a = 0; a < RRL_MAX_HITS; ++a) {
-        if (a < k) {
-            float *dst = g1 + ((size_t)b * N + hs1[gl * 4 + a]) * 9;
-#pragma unroll
-            for (int kk = 0; kk < 3; ++kk) {
-                float wk = w1[(gl * 4 + a) * 3 + kk] / 3.0f;
-#pragma unroll
-                for (int cc = 0; cc < 3; ++cc) atomicAdd(dst + 3 * kk + cc, wk * gq1[a][cc]);
-            }
-        }
-        if (g2 && a < j) {
-            float *dst = g2 + ((size_t)b * M + hs2[gl * 4 + a]) * 9;
-#pragma unroll
-            for (int kk = 0; kk < 3; ++kk) {
-                float wk = w2[(gl * 4 + a) * 3 + kk] / 3.0f;
-#pragma unroll
-                for (int cc = 0; cc < 3; ++cc) atomicAdd(dst + 3 * kk + cc, wk * gq2[a][cc]);
-            }
-        }
+        for (int cc = 0; cc < 3; ++cc) atomicAdd(dst + 3 * kk + cc, wk * gq[cc]);
     }
 }
 
@@ -414,10 +463,11 @@ extern "C" int rrl_loss_backward(const float *tri1, const float *tri2, const voi
         (e = hipMemsetAsync(grad_tri2, 0, sizeof(float) * 9 * (size_t)B * M, s)) != hipSuccess)
         return (int)e;
     if (B == 0 || L == 0) return 0;
-    hipLaunchKernelGGL(loss_bwd_kernel, dim3((unsigned)((L + 255) / 256), (unsigned)B), dim3(256), 0,
-                       s, tri1, tri2, w.u8(ws, RRL_WS_KJ), w.i32(ws, RRL_WS_SEL),
+    hipLaunchKernelGGL(loss_bwd_kernel, dim3((unsigned)((8 * (size_t)L + 255) / 256), (unsigned)B),
+                       dim3(256), 0, s, w.u8(ws, RRL_WS_KJ), w.i32(ws, RRL_WS_SEL),
                        w.i32(ws, RRL_WS_NSEL), w.i32(ws, RRL_WS_HS1), w.i32(ws, RRL_WS_HS2),
-                       w.f32(ws, RRL_WS_W1), w.f32(ws, RRL_WS_W2),
+                       w.f32(ws, RRL_WS_W1), w.f32(ws, RRL_WS_W2), (const float4 *)w.f32(ws, RRL_WS_Q1),
+                       (const float4 *)w.f32(ws, RRL_WS_Q2),
                        w.f32(ws, RRL_WS_D), w.f32(ws, RRL_WS_MED), w.i32(ws, RRL_WS_BCNT),
                        w.i32(ws, RRL_WS_INFO), grad_loss, grad_tri1, grad_tri2, B, N, M, L, pool);
     RRL_LAUNCH_CHECK();

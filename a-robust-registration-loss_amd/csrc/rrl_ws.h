@@ -34,6 +34,8 @@ struct WsLayout {
             4 * b * l * 4,       // HS2
             4 * b * l * 12,      // W1
             4 * b * l * 12,      // W2
+            4 * b * l * 16,      // Q1
+            4 * b * l * 16,      // Q2
             4 * b * l * 16,      // D
             4 * b * l * 16,      // VALS
             4 * b,               // MED   (G <= B)

@@ -36,6 +36,8 @@ _WS_FIELDS = [
     ("hs2", torch.int32, lambda B, N, M, L, G: (B, L, 4)),
     ("w1", torch.float32, lambda B, N, M, L, G: (B, L, 4, 3)),
     ("w2", torch.float32, lambda B, N, M, L, G: (B, L, 4, 3)),
+    ("Q1", torch.float32, lambda B, N, M, L, G: (B, L, 4, 4)),
+    ("Q2", torch.float32, lambda B, N, M, L, G: (B, L, 4, 4)),
     ("D", torch.float32, lambda B, N, M, L, G: (B, L, 16)),
     ("vals", torch.float32, lambda B, N, M, L, G: (B, 16 * L)),
     ("med", torch.float32, lambda B, N, M, L, G: (G,)),

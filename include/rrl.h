@@ -78,6 +78,8 @@ enum {
     RRL_WS_HS2,
     RRL_WS_W1,         /* float[B][L][4][3] weights d / sum d (loss.py:92)                  */
     RRL_WS_W2,
+    RRL_WS_Q1,         /* float[B][L][4][4] intersection points q (xyz, 0) (loss.py:155-163)  */
+    RRL_WS_Q2,
     RRL_WS_D,          /* float[B][L][16] k x j block of |q1-q2|^2 (loss.py:165-166)        */
     RRL_WS_VALS,       /* float[B][16 L] compacted D values (median input)                  */
     RRL_WS_MED,        /* float[G]  lower median (loss.py:223-224)                          */
