@@ -11,7 +11,7 @@
 //     rho = max |P0 - c| and the conservative squared radius
 //     R2 = ((rho + max thr)^2)(1 + 1e-4) + 1e-7.
 //   cull_scan_kernel (lane = one line in phase 1; every wavefront owns 64 lines and a private
-//   LDS queue, so there is no workgroup synchronisation after the tile-safety vote)
+//   LDS queue, so there is no workgroup synchronisation at all)
 //     phase 1: every lane tests ITS line against each group sphere (wave-uniform sphere, SGPR
 //              operands) with a conservative test; the passing (line, group) pairs of the wave
 //              are appended to its queue by ballot/popcount, group by group;
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(256) void cull_scan_kernel(
     const float4 *__restrict__ p0s2, const int32_t *__restrict__ idx1, const int32_t *__restrict__ idx2,
     const float4 *__restrict__ grp1, const float4 *__restrict__ grp2, const float *__restrict__ line,
     int32_t *__restrict__ count1, int32_t *__restrict__ hit1, int32_t *__restrict__ count2,
-    int32_t *__restrict__ hit2, const uint32_t *__restrict__ pmax, int B, int N, int M, int L) {
+    int32_t *__restrict__ hit2, const int32_t *__restrict__ tsafe, int B, int N, int M, int L) {
     __shared__ __attribute__((aligned(16))) float4 lines_lds[4][64][2];    // 8 KiB
     __shared__ __attribute__((aligned(16))) float4 rows_lds[4][BGRP * ROWS];  // 17 KiB
     __shared__ unsigned cands_lds[4][WCCAP];                               // 4 KiB
@@ -317,23 +317,10 @@ __global__ __launch_bounds__(256) void cull_scan_kernel(
     const float *ln = line + (size_t)b * L * 6;
 
     // 64 lines per workgroup; the four wavefronts split the GROUP range between them, which
-    // quadruples the number of independent (latency-bound) wavefronts.
-    // Safety of the whole 512-line tile this block belongs to (each thread checks two of its
-    // lines): unsafe tiles belong to scan_kernel's strict loop.
-    const float pm = __uint_as_float(pmax[cloud * B + b]);
-    bool safe = true;
-    {
-        const int tile0 = (blockIdx.x >> 3) * 512;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int lt = tile0 + h * 256 + tid;
-            float vt[6];
-#pragma unroll
-            for (int c = 0; c < 6; ++c) vt[c] = lt < L ? ln[6 * (size_t)lt + c] : 0.0f;
-            safe &= rrl_line_safe(vt, pm);
-        }
-    }
-    if (!__syncthreads_and(safe)) return;
+    // quadruples the number of independent (latency-bound) wavefronts.  The 512-line tile this
+    // block belongs to was classified by scan_kernel (launched before): unsafe tiles -- a line
+    // that fails the NaN bound -- were scanned by its strict loop and are skipped here.
+    if (!tsafe[(size_t)z * ((L + 511) / 512) + (blockIdx.x >> 3)]) return;
     const int l = blockIdx.x * 64 + lane;
     float v[6];
 #pragma unroll
@@ -417,7 +404,7 @@ int rrl_launch_cull_scan(const float *line, void *ws, const WsLayout &w, int B, 
                        w.i32(ws, RRL_WS_IDX1), w.i32(ws, RRL_WS_IDX2), (const float4 *)w.f32(ws, RRL_WS_GRP1),
                        (const float4 *)w.f32(ws, RRL_WS_GRP2), line, w.i32(ws, RRL_WS_COUNT1),
                        w.i32(ws, RRL_WS_HIT1), w.i32(ws, RRL_WS_COUNT2), w.i32(ws, RRL_WS_HIT2),
-                       (const uint32_t *)w.i32(ws, RRL_WS_PMAX), B, N, M, L);
+                       w.i32(ws, RRL_WS_TSAFE), B, N, M, L);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }

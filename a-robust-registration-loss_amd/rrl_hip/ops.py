@@ -30,6 +30,7 @@ _WS_FIELDS = [
     ("idx2", torch.int32, lambda B, N, M, L, G: (B, (M + 15) // 16 * 16)),
     ("grp1", torch.float32, lambda B, N, M, L, G: (B, (N + 15) // 16, 4)),
     ("grp2", torch.float32, lambda B, N, M, L, G: (B, (M + 15) // 16, 4)),
+    ("tsafe", torch.int32, lambda B, N, M, L, G: (2, B, (L + 511) // 512)),
     ("kj", torch.uint8, lambda B, N, M, L, G: (B, L)),
     ("sel", torch.int32, lambda B, N, M, L, G: (B, L)),
     ("hs1", torch.int32, lambda B, N, M, L, G: (B, L, 4)),

@@ -72,6 +72,8 @@ enum {
     RRL_WS_IDX2,
     RRL_WS_GRP1,       /* float[B][NG1][4]  group sphere: centre, conservative radius^2        */
     RRL_WS_GRP2,
+    RRL_WS_TSAFE,      /* int32[2][B][ceil(L/512)] 1 = every line of the 512-line tile meets the
+                          NaN bound for that cloud (culled scan), 0 = strict loop took the tile */
     RRL_WS_KJ,         /* uint8[B][L]  k | j<<4, 0 = line not selected                      */
     RRL_WS_SEL,        /* int32[B][L]  indices of the selected lines, compacted (any order)  */
     RRL_WS_HS1,        /* int32[B][L][4] ascending hit indices (nonzero() order)            */

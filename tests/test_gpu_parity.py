@@ -425,3 +425,26 @@ def test_sampler(L, oracle):
     nb = int((np.abs(big).sum(1) > 0).sum())
     assert 0 < nb < n and not np.any(big[nb:])  # unfilled rows stay zero at the tail
     assert abs(nb - int((np.abs(g["final_big"]).sum(1) > 0).sum())) <= 15
+
+
+def test_cull_dense_hits(L, oracle):
+    """Stress the culled scan's overflow paths: a tiny cloud hit by almost every line (every
+    (line, group) pair survives the sphere test) must still match the strict scan and the oracle."""
+    rng = np.random.default_rng(11)
+    pts = rng.standard_normal((200, 3)).astype(np.float32)
+    pts[:, 2] *= 0.02  # a small flat patch: long lines through it graze many pseudo-triangles
+    from rrl_hip import synth
+    tri = synth.knn_triangles(pts)
+    n_lines = 700
+    d = rng.standard_normal((n_lines, 3))
+    d[:, 2] *= 0.01  # nearly in-plane directions
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    x0 = rng.standard_normal((n_lines, 3)) * 0.5
+    x0[:, 2] *= 0.02
+    lines = np.concatenate([d, x0], 1).astype(np.float32)
+    c = run_state(tri, tri, lines, mode="cull")
+    s_ = run_state(tri, tri, lines, mode="strict")
+    o = oracle.scan(tri, lines, cap=4)
+    np.testing.assert_array_equal(c.count1[0].cpu().numpy(), o["count"])
+    np.testing.assert_array_equal(s_.count1[0].cpu().numpy(), o["count"])
+    assert o["count"].max() > 4 and (o["count"] > 0).mean() > 0.5  # really dense
