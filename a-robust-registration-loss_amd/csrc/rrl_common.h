@@ -107,3 +107,31 @@ __device__ __forceinline__ float wave_sum(float v) {
 __device__ __forceinline__ int wave_sum_i(int v) {
     return __builtin_amdgcn_readlane(wave_incl_scan(v), 63);
 }
+
+// all-reduce inside each row of 16 lanes (butterfly on DPP: quad_perm [1,0,3,2], [2,3,0,1],
+// row_half_mirror, row_mirror); every lane of the row receives the result
+#define RRL_DPP_F(v, ctrl) \
+    __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), ctrl, 0xf, 0xf, false))
+__device__ __forceinline__ float row16_min(float v) {
+    v = fminf(v, RRL_DPP_F(v, 0xB1)); v = fminf(v, RRL_DPP_F(v, 0x4E));
+    v = fminf(v, RRL_DPP_F(v, 0x141)); v = fminf(v, RRL_DPP_F(v, 0x140));
+    return v;
+}
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, RRL_DPP_F(v, 0xB1)); v = fmaxf(v, RRL_DPP_F(v, 0x4E));
+    v = fmaxf(v, RRL_DPP_F(v, 0x141)); v = fmaxf(v, RRL_DPP_F(v, 0x140));
+    return v;
+}
+// wave-wide: row results of lanes 0, 16, 32, 48 combined through SGPRs
+__device__ __forceinline__ float wave_min(float v) {
+    v = row16_min(v);
+    const int b = __float_as_int(v);
+    return fminf(fminf(__int_as_float(__builtin_amdgcn_readlane(b, 0)), __int_as_float(__builtin_amdgcn_readlane(b, 16))),
+                 fminf(__int_as_float(__builtin_amdgcn_readlane(b, 32)), __int_as_float(__builtin_amdgcn_readlane(b, 48))));
+}
+__device__ __forceinline__ float wave_max(float v) {
+    v = row16_max(v);
+    const int b = __float_as_int(v);
+    return fmaxf(fmaxf(__int_as_float(__builtin_amdgcn_readlane(b, 0)), __int_as_float(__builtin_amdgcn_readlane(b, 16))),
+                 fmaxf(__int_as_float(__builtin_amdgcn_readlane(b, 32)), __int_as_float(__builtin_amdgcn_readlane(b, 48))));
+}

@@ -77,6 +77,7 @@ __global__ __launch_bounds__(1024) void tri_sort_kernel(
 
     // ---- AABB of the P0s and max |P|^2 over all three points (the NaN bound's input)
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY}, p2 = 0.0f;
+#pragma unroll 4
     for (int f = tid; f < n; f += 1024) {
         const float *p = ptri + PTRI_STRIDE * (size_t)f;
 #pragma unroll
@@ -87,12 +88,8 @@ __global__ __launch_bounds__(1024) void tri_sort_kernel(
     }
     if (!(p2 <= 3.0e38f)) p2 = INFINITY;  // NaN/inf coordinates: never "provably safe"
 #pragma unroll
-    for (int c = 0; c < 3; ++c)
-        for (int o = 32; o > 0; o >>= 1) {
-            mn[c] = fminf(mn[c], __shfl_down(mn[c], o));
-            mx[c] = fmaxf(mx[c], __shfl_down(mx[c], o));
-        }
-    for (int o = 32; o > 0; o >>= 1) p2 = fmaxf(p2, __shfl_down(p2, o));
+    for (int c = 0; c < 3; ++c) { mn[c] = wave_min(mn[c]); mx[c] = wave_max(mx[c]); }
+    p2 = wave_max(p2);
     if (lane == 0) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) { red[wave][c] = mn[c]; red[wave][3 + c] = mx[c]; }
@@ -125,6 +122,7 @@ __global__ __launch_bounds__(1024) void tri_sort_kernel(
     };
 
     // ---- histogram over cells, exclusive scan, scatter
+#pragma unroll 4
     for (int f = tid; f < n; f += 1024) atomicAdd(&hist[cell_of(ptri + PTRI_STRIDE * (size_t)f)], 1u);
     __syncthreads();
     {
@@ -141,6 +139,7 @@ __global__ __launch_bounds__(1024) void tri_sort_kernel(
         for (int k = 0; k < 4; ++k) { hist[4 * tid + k] = run; run += h[k]; }
     }
     __syncthreads();
+#pragma unroll 4
     for (int f = tid; f < n; f += 1024) {
         const float *p = ptri + PTRI_STRIDE * (size_t)f;
         const int s = (int)atomicAdd(&hist[cell_of(p)], 1u);
@@ -164,14 +163,8 @@ __global__ __launch_bounds__(1024) void tri_sort_kernel(
 #pragma unroll
         for (int d = 0; d < 3; ++d) { lo[d] = valid ? c[d] : INFINITY; hi[d] = valid ? c[d] : -INFINITY; }
 #pragma unroll
-        for (int o = 8; o > 0; o >>= 1) {
-#pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                lo[d] = fminf(lo[d], __shfl_xor(lo[d], o, 16));
-                hi[d] = fmaxf(hi[d], __shfl_xor(hi[d], o, 16));
-            }
-            tm = fmaxf(tm, __shfl_xor(tm, o, 16));
-        }
+        for (int d = 0; d < 3; ++d) { lo[d] = row16_min(lo[d]); hi[d] = row16_max(hi[d]); }
+        tm = row16_max(tm);
         float ctr[3], d2 = 0.0f;
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
@@ -180,8 +173,7 @@ __global__ __launch_bounds__(1024) void tri_sort_kernel(
             d2 += e * e;
         }
         if (!valid) d2 = 0.0f;
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) d2 = fmaxf(d2, __shfl_xor(d2, o, 16));
+        d2 = row16_max(d2);
         if ((s & 15) == 0) {
             float rho = sqrtf(d2) * 1.00001f + 1e-7f;
             float R = rho + tm;

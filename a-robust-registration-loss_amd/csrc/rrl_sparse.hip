@@ -500,3 +500,42 @@ extern "C" int rrl_loss_forward(const float *tri1, const float *tri2, const floa
         return rc;
     return rrl_loss_reduce(ws, ws_bytes, loss, B, N, M, L, s_m, s_n, e_m, e_n, pool, stream);
 }
+
+// ---------------------------------------------------------------------------------------
+// fused training op: rigid transform of the source + loss, and its backward to (dR, dt)
+// ---------------------------------------------------------------------------------------
+extern "C" int rrl_registration_forward(const float *src, const float *R, const float *t,
+                                        const float *tri2, const float *line, void *ws,
+                                        size_t ws_bytes, float *loss, int B, int N, int M, int L,
+                                        int transpose_r, int s_m, int s_n, int e_m, int e_n, int mode,
+                                        int chunk, void *stream) {
+    if (!src || !R || !t || !tri2 || !line || !ws || !loss) return RRL_E_ARG;
+    if (B < 0 || N < 0 || M < 0 || L < 0) return RRL_E_ARG;
+    WsLayout w(B, N, M, L);
+    if (ws_bytes < w.total) return RRL_E_WS;
+    float *tri1 = w.f32(ws, RRL_WS_TRI1);
+    int rc = rrl_rigid_apply_fwd(src, R, t, tri1, B, 3 * N, transpose_r, 0, stream);
+    if (rc) return rc;
+    return rrl_loss_forward(tri1, tri2, line, ws, ws_bytes, loss, B, N, M, L, s_m, s_n, e_m, e_n, 0,
+                            mode, chunk, stream);
+}
+
+extern "C" int rrl_registration_backward(const float *src, const float *R, const float *tri2,
+                                         void *ws, size_t ws_bytes, const float *loss,
+                                         const float *grad_loss, float *grad_src, float *gR, float *gt,
+                                         float *payload, int B, int N, int M, int L, int transpose_r,
+                                         void *stream) {
+    if (!src || !R || !tri2 || !ws || !grad_loss || !gR || !gt) return RRL_E_ARG;
+    if (payload && !loss) return RRL_E_ARG;
+    WsLayout w(B, N, M, L);
+    if (ws_bytes < w.total) return RRL_E_WS;
+    float *g1 = w.f32(ws, RRL_WS_G1);
+    int rc = rrl_loss_backward(w.f32(ws, RRL_WS_TRI1), tri2, ws, ws_bytes, grad_loss, g1, nullptr, B,
+                               N, M, L, 0, stream);
+    if (rc) return rc;
+    rc = rrl_rigid_apply_bwd(src, R, g1, grad_src, gR, gt, w.f32(ws, RRL_WS_RPART), B, 3 * N,
+                             transpose_r, 0, stream);
+    if (rc) return rc;
+    if (payload) rc = rrl_shard_payload(loss, ws, ws_bytes, gR, gt, payload, B, N, M, L, stream);
+    return rc;
+}

@@ -43,6 +43,9 @@ struct WsLayout {
             4 * b * 16,          // BCNT
             8 * b * 32,          // BSUM
             4 * b * 4,           // INFO
+            4 * b * n * 9,       // TRI1
+            4 * b * n * 9,       // G1
+            4 * b * 12 * ((3 * n + 16383) / 16384 + 1),  // RPART
         };
         size_t o = 0;
         for (int i = 0; i < RRL_WS_FIELDS; ++i) {

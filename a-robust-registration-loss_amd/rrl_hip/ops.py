@@ -45,14 +45,23 @@ _WS_FIELDS = [
     ("bcnt", torch.int32, lambda B, N, M, L, G: (G, 16)),
     ("bsum", torch.int64, lambda B, N, M, L, G: (G, 16, 2)),
     ("info", torch.int32, lambda B, N, M, L, G: (G, 4)),
+    ("tri1t", torch.float32, lambda B, N, M, L, G: (B, N, 9)),
+    ("g1", torch.float32, lambda B, N, M, L, G: (B, N, 9)),
+    ("rpart", torch.float32, lambda B, N, M, L, G: (B, (3 * N + 16383) // 16384 + 1, 12)),
 ]
 _layout_cache = {}
 
 
+_gpu_ok = False
+
+
 def require_gpu():
-    if not torch.cuda.is_available():
-        raise RRLError("no MI355X visible (torch.cuda.is_available() is False); "
-                       "this package has no CPU fallback")
+    global _gpu_ok
+    if not _gpu_ok:
+        if not torch.cuda.is_available():
+            raise RRLError("no MI355X visible (torch.cuda.is_available() is False); "
+                           "this package has no CPU fallback")
+        _gpu_ok = True
     return torch.device("cuda", torch.cuda.current_device())
 
 
@@ -61,7 +70,8 @@ def _p(t):
 
 
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    # raw hipStream_t of torch's current stream (the Stream object wrapper costs ~15 us per call)
+    return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()))
 
 
 def _prep(t, name, last=None):
@@ -70,6 +80,8 @@ def _prep(t, name, last=None):
         raise TypeError(f"{name} must be a torch.Tensor")
     if last is not None and t.shape[-1] != last:
         raise ValueError(f"{name}: last dimension must be {last}, got {tuple(t.shape)}")
+    if t.is_cuda and t.dtype == torch.float32 and t.is_contiguous():
+        return t.detach()  # the common case: nothing to convert
     dev = require_gpu()
     return t.detach().to(device=dev, dtype=torch.float32).contiguous()
 
@@ -160,7 +172,9 @@ class _IntersectionLoss(torch.autograd.Function):
         ctx.mark_non_differentiable(info, status)
         ctx.set_materialize_grads(False)  # no zero-filled grads for the integer outputs
         _IntersectionLoss.last_state = st  # for shard_payload(): the newest evaluation
-        return st.loss, info, status
+        # return a view: st.loss itself must not become the autograd output, or last_state would
+        # keep the graph (and the AccumulateGrad nodes of the inputs) alive across iterations
+        return st.loss.view(-1), info, status
 
     @staticmethod
     def backward(ctx, g_loss, _g1, _g2):
@@ -201,6 +215,73 @@ def shard_payload(loss, gR=None, gt=None, state=None):
     check(_lib.load().rrl_shard_payload(_p(loss.detach()), _p(st.ws), st.nbytes, _p(gRc), _p(gtc),
                                         _p(out), G, N, M, L, _stream()), "rrl_shard_payload")
     return out
+
+
+class _RegistrationLoss(torch.autograd.Function):
+    """Fused training op: rigid transform of the source pseudo-triangles + loss (one C call
+    each way; the transformed triangles and their gradient live in the workspace)."""
+
+    @staticmethod
+    def forward(ctx, src_tri, R, t, tar_tri, line, rng, transpose_r, mode, chunk, want_payload):
+        src = _prep(src_tri, "src_tri", 9)
+        tri2, ln = _prep(tar_tri, "tar_tri", 9), _prep(line, "line", 6)
+        Rm, tv = _prep(R, "R").reshape(-1, 3, 3), _prep(t, "t").reshape(-1, 3)
+        if src.dim() != 3 or tri2.dim() != 3 or ln.dim() != 3:
+            raise ValueError("src_tri/tar_tri/line must be 3-D (B, n, c)")
+        B, N, _ = src.shape
+        M, L = tri2.shape[1], ln.shape[1]
+        if not (tri2.shape[0] == ln.shape[0] == Rm.shape[0] == tv.shape[0] == B):
+            raise ValueError("batch dimensions differ")
+        s_m, s_n, e_m, e_n = _check_range(rng)
+        st = LossState(B, N, M, L, B, src.device)
+        check(_lib.load().rrl_registration_forward(
+            _p(src), _p(Rm), _p(tv), _p(tri2), _p(ln), _p(st.ws), st.nbytes, _p(st.loss), B, N, M, L,
+            int(transpose_r), s_m, s_n, e_m, e_n, _MODES[mode], int(chunk), _stream()),
+            "rrl_registration_forward")
+        ctx.st, ctx.src, ctx.Rm, ctx.tri2 = st, src, Rm, tri2
+        ctx.meta = (int(transpose_r), bool(want_payload), R.shape, t.shape, src_tri.device)
+        info, status = st.info, st.status
+        ctx.mark_non_differentiable(info, status)
+        ctx.set_materialize_grads(False)
+        _IntersectionLoss.last_state = st
+        return st.loss.view(-1), info, status  # a view: see _IntersectionLoss.forward
+
+    @staticmethod
+    def backward(ctx, g_loss, _g1, _g2):
+        if g_loss is None:
+            return (None,) * 10
+        st, src, Rm, tri2 = ctx.st, ctx.src, ctx.Rm, ctx.tri2
+        tr, want_payload, Rshape, tshape, sdev = ctx.meta
+        B, N, M, L, _ = st.dims
+        g = g_loss if (g_loss.is_cuda and g_loss.is_contiguous()) else \
+            g_loss.to(device=src.device, dtype=torch.float32).contiguous()
+        out = torch.empty(B * 12 + 14, dtype=torch.float32, device=src.device)
+        gR, gt, payload = out[:B * 9], out[B * 9:B * 12], out[B * 12:]
+        gsrc = torch.empty_like(src) if ctx.needs_input_grad[0] else None
+        check(_lib.load().rrl_registration_backward(
+            _p(src), _p(Rm), _p(tri2), _p(st.ws), st.nbytes, _p(st.loss), _p(g), _p(gsrc), _p(gR),
+            _p(gt), _p(payload) if want_payload else None, B, N, M, L, tr, _stream()),
+            "rrl_registration_backward")
+        st.payload = payload if want_payload else None
+        return (gsrc.to(sdev) if gsrc is not None else None, gR.reshape(Rshape), gt.reshape(tshape),
+                None, None, None, None, None, None, None)
+
+
+def registration_loss(src_tri, R, t, tar_tri, line, rng=(1, 1, 5, 5), transpose_r=True,
+                      mode="cull", chunk=0, want_payload=False):
+    """loss[b] of `src_tri[b]` moved by (R[b], t[b]) against `tar_tri[b]` along `line[b]` -- the
+    rigid transform of the training call sites fused with the loss.  transpose_r=True is
+    x R^T + t (R x + t per point: RPM / DCP / FMR), False is x R + t (Reconstruction_point).
+    Returns (loss (B,), info (B,4), status (4,)); differentiable in R, t and src_tri.
+    want_payload=True also builds the 14-float batch-shard payload during backward
+    (LossState.payload of the call, see rrl_hip.dist)."""
+    return _RegistrationLoss.apply(src_tri, R, t, tar_tri, line, tuple(rng), transpose_r, mode,
+                                   chunk, want_payload)
+
+
+def last_state():
+    """LossState of the most recent loss evaluation on this process (workspace views, payload)."""
+    return _IntersectionLoss.last_state
 
 
 def scan_timing(every):

@@ -88,6 +88,9 @@ enum {
     RRL_WS_BCNT,       /* int32[G][16] lines per (k,j) bucket                               */
     RRL_WS_BSUM,       /* int64[G][16][2] bucket sums of row / column minima, 2^-40 fixed pt */
     RRL_WS_INFO,       /* int32[G][4] nbuckets, nselected, nvalues, 0                       */
+    RRL_WS_TRI1,       /* float[B][N][9] transformed source triangles (rrl_registration_*)   */
+    RRL_WS_G1,         /* float[B][N][9] gradient w.r.t. TRI1 (rrl_registration_backward)    */
+    RRL_WS_RPART,      /* float[B][nblk][12] rigid-apply backward partial sums              */
     RRL_WS_FIELDS
 };
 
@@ -116,6 +119,22 @@ int rrl_loss_forward(const float *tri1, const float *tri2, const float *line, vo
 int rrl_loss_backward(const float *tri1, const float *tri2, const void *ws, size_t ws_bytes,
                       const float *grad_loss, float *grad_tri1, float *grad_tri2, int B, int N,
                       int M, int L, int pool, void *stream);
+
+/* Fused training op (the rigid transform of the call sites + the loss: rpm/Train_RPM.py:205-231,
+ * dcp/Train_DCP.py:233-270, fmr/model.py:265-313; code/loss.py:458-463 for the demo): the source
+ * pseudo-triangles src [B][N][9] are moved by per-sample (R [B][3][3], t [B][3]) -- x R + t, or
+ * x R^T + t when transpose_r -- into the workspace (TRI1) and the loss is evaluated against
+ * tri2, all in one call.  The backward returns dL/dR, dL/dt (deterministic reduction), optionally
+ * dL/dsrc (may be NULL), and, when payload != NULL, the 14-float batch-shard payload
+ * { sum of valid losses, #valid, sum_b dR, sum_b dt } for the all-reduce.  pool must be 0. */
+int rrl_registration_forward(const float *src, const float *R, const float *t, const float *tri2,
+                             const float *line, void *ws, size_t ws_bytes, float *loss, int B,
+                             int N, int M, int L, int transpose_r, int s_m, int s_n, int e_m,
+                             int e_n, int mode, int chunk, void *stream);
+int rrl_registration_backward(const float *src, const float *R, const float *tri2, void *ws,
+                              size_t ws_bytes, const float *loss, const float *grad_loss,
+                              float *grad_src, float *gR, float *gt, float *payload, int B, int N,
+                              int M, int L, int transpose_r, void *stream);
 
 /* ---- the four forward stages, individually (tests, profiling) ------------------------- */
 

@@ -448,3 +448,55 @@ def test_cull_dense_hits(L, oracle):
     np.testing.assert_array_equal(c.count1[0].cpu().numpy(), o["count"])
     np.testing.assert_array_equal(s_.count1[0].cpu().numpy(), o["count"])
     assert o["count"].max() > 4 and (o["count"] > 0).mean() > 0.5  # really dense
+
+
+def test_fused_registration_op(L):
+    """rrl_registration_forward/backward == rigid apply + loss + rigid backward, incl. payload."""
+    from rrl_hip import ops
+    from LieAlgebra import se3
+    g = load_golden("loss_b2_quirk.npz")
+    src, tar, ln = cu(g["tri1"]), cu(g["tri2"]), cu(g["lines"])
+    gen = torch.Generator().manual_seed(5)
+    R0, T0 = se3.exp3(0.05 * torch.randn(2, 6, generator=gen))
+    res = {}
+    for fused in (False, True):
+        R, T = R0.cuda().requires_grad_(True), T0.cuda().requires_grad_(True)
+        if fused:
+            loss, info, _ = ops.registration_loss(src, R, T, tar, ln, want_payload=True)
+        else:
+            moved = ops.rigid_apply(src.reshape(2, -1, 3), R, T, transpose_r=True).reshape(src.shape)
+            loss, info, _ = ops.intersection_loss(moved, tar, ln)
+        (loss * torch.tensor([1.0, 2.0], device="cuda")).sum().backward()
+        res[fused] = (loss.detach().cpu().numpy(), R.grad.cpu().numpy(), T.grad.cpu().numpy())
+    np.testing.assert_array_equal(res[True][0], res[False][0])
+    np.testing.assert_allclose(res[True][1], res[False][1], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(res[True][2], res[False][2], rtol=1e-4, atol=1e-6)
+    pay = ops.last_state().payload.cpu().numpy()
+    np.testing.assert_allclose(pay[0], res[True][0].sum(), rtol=1e-6)
+    assert pay[1] == 2.0
+    np.testing.assert_allclose(pay[2:11], res[True][1].sum(0).reshape(-1), rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(pay[11:], res[True][2].sum(0), rtol=1e-5, atol=1e-7)
+
+
+def test_graphed_step_matches_eager(L):
+    from rrl_hip import ops
+    from rrl_hip.graph import GraphedStep
+    g = load_golden("loss_b2_quirk.npz")
+    src, tar, ln = cu(g["tri1"]), cu(g["tri2"]), cu(g["lines"])
+    R = torch.eye(3, device="cuda").repeat(2, 1, 1).requires_grad_(True)
+    T = torch.zeros(2, 3, device="cuda", requires_grad=True)
+    ones = torch.ones(2, device="cuda")
+
+    def fn():
+        R.grad = T.grad = None
+        loss, _, _ = ops.registration_loss(src, R, T, tar, ln, want_payload=True)
+        torch.autograd.backward([loss], [ones])
+        return loss, ops.last_state().payload
+
+    e_loss, e_pay = (t.detach().clone() for t in fn())  # no reference to the eager autograd graph
+    gs = GraphedStep(fn)
+    for _ in range(3):
+        g_loss, g_pay = gs()
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(g_loss.detach().cpu().numpy(), e_loss.cpu().numpy())
+    np.testing.assert_allclose(g_pay.cpu().numpy(), e_pay.cpu().numpy(), rtol=1e-5, atol=1e-7)
