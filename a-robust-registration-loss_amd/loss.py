@@ -177,6 +177,7 @@ class Reconstruction_point(nn.Module):
 def Sample_neighs(points, num_sample=5000, num_neigh=3, device='cpu'):
     """Pseudo-triangle builder (code/loss.py:473-485): farthest-point sample <= num_sample
     points, then each with its num_neigh nearest neighbours -> (3*S, 3) rows [p, nn1, nn2].
-    Preprocessing outside the timed path; provided by rrl_hip.neighbors."""
+    GPU farthest-point sampling + brute-force 3-NN (rrl_hip.neighbors); the FPS start index is
+    drawn with torch.randint from the CPU generator like the reference's."""
     from rrl_hip import neighbors
     return neighbors.sample_neighs(points, num_sample, num_neigh)

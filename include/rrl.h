@@ -219,6 +219,16 @@ int rrl_sample_lines(const float *rands, const float *r, const float *centers, c
                      const float *aabb2, float *lines, int32_t *filled, int B, int n, int rounds,
                      void *stream);
 
+/* ---- pseudo-triangle builder (code/loss.py:473-485 + code/utils.py:275-296) --------------- */
+/* Farthest-point sampling of S <= n points per cloud, starting at start[b] (the reference draws it
+ * with torch.randint): out_idx [B][S] in selection order.  pts [B][n][3]; dist_scratch [B][n]. */
+int rrl_fps(const float *pts, const int32_t *start, int32_t *out_idx, float *dist_scratch, int B,
+            int n, int S, void *stream);
+/* 3 nearest neighbours (itself first) of the points query_idx [B][S] among the n points of their
+ * cloud: nn [B][S][3], ascending distance, ties to the lower index (sklearn KDTree.query, k=3). */
+int rrl_knn3(const float *pts, const int32_t *query_idx, int32_t *nn, int B, int n, int S,
+             void *stream);
+
 #ifdef __cplusplus
 }
 #endif

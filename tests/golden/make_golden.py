@@ -242,5 +242,17 @@ def main():
           "filled(big radius)", int((np.abs(final_big).sum(1) > 0).sum()))
 
 
+def neighs():
+    """Sample_neighs (FPS + KDTree 3-NN) on a synthetic cloud: all points, and a subsample."""
+    pr = synth.make_pair(7, 900, 64)
+    pts = pr["src"]
+    torch.manual_seed(77)
+    full = RL.Sample_neighs(pts)
+    torch.manual_seed(78)
+    sub = RL.Sample_neighs(pts, num_sample=300)
+    save("sample_neighs.npz", points=pts, full=full.astype(np.float32), sub=sub.astype(np.float32))
+
+
 if __name__ == "__main__":
     main()
+    neighs()

@@ -500,3 +500,42 @@ def test_graphed_step_matches_eager(L):
     torch.cuda.synchronize()
     np.testing.assert_array_equal(g_loss.detach().cpu().numpy(), e_loss.cpu().numpy())
     np.testing.assert_allclose(g_pay.cpu().numpy(), e_pay.cpu().numpy(), rtol=1e-5, atol=1e-7)
+
+
+# ---------------------------------------------------------------------------------- Sample_neighs
+def test_sample_neighs_vs_reference(L):
+    """GPU FPS + 3-NN reproduce the reference's Sample_neighs rows for the same torch seed
+    (the FPS start index comes from torch.randint on the CPU generator, like the reference)."""
+    g = load_golden("sample_neighs.npz")
+    torch.manual_seed(77)
+    full = L.Sample_neighs(g["points"])
+    assert full.shape == g["full"].shape and full.dtype == g["points"].dtype
+    np.testing.assert_array_equal(full, g["full"])
+    torch.manual_seed(78)
+    sub = L.Sample_neighs(g["points"], num_sample=300)
+    np.testing.assert_array_equal(sub, g["sub"])
+
+
+def test_fps_and_knn_properties(L):
+    from rrl_hip import neighbors
+    gen = torch.Generator().manual_seed(3)
+    pts = torch.randn(2, 9000, 3, generator=gen)  # > 8192 points: the global-memory FPS path
+    idx = neighbors.fps(pts, 500, start=torch.tensor([5, 7])).cpu().numpy()
+    assert idx.shape == (2, 500) and idx[0, 0] == 5 and idx[1, 0] == 7
+    for b in range(2):
+        assert len(set(idx[b].tolist())) == 500
+        p = pts[b].numpy().astype(np.float32)
+        d = np.full(9000, 1e10, np.float32)
+        cur = idx[b, 0]
+        for it in range(1, 40):  # replay the first steps on the host
+            diff = p - p[cur]
+            s = (diff[:, 0] * diff[:, 0] + diff[:, 1] * diff[:, 1]) + diff[:, 2] * diff[:, 2]
+            d = np.minimum(d, s)
+            cur = int(np.argmax(d))
+            assert cur == idx[b, it]
+    nn = neighbors.knn3(pts, torch.from_numpy(idx)).cpu().numpy()
+    from scipy.spatial import cKDTree
+    for b in range(2):
+        p = pts[b].numpy().astype(np.float64)
+        _, ref = cKDTree(p).query(p[idx[b]], k=3)
+        np.testing.assert_array_equal(nn[b], ref)
