@@ -1,0 +1,125 @@
+"""The loss fragments of the reference's three trainers, each as one call.
+
+Every trainer wraps the loss in the same Python pattern: transform the source cloud and its
+pseudo-triangles with the predicted (R, t), draw lines once from the target's bounding sphere,
+then `for j in range(B): acc += cal_loss_...(…[j:j+1]…)` with a trainer-specific scaling:
+
+  RPM  rpm/Train_RPM.py:204-259   radius = |box diagonal|,     10000 lines, per iteration
+                                  sum_j / num_iter, discount 0.5**(num_iter-ni-1)
+  DCP  dcp/Train_DCP.py:233-270   radius = |box diagonal| / 2, 15000 lines, sum_j (loss/5) / B
+  FMR  fmr/model.py:266-310       radius = |box diagonal| / 2, 15000 lines from the LAST
+                                  estimate, last three estimates, sum_j (loss/5) * discount / B
+
+Here the B per-sample calls and the transforms are ONE fused launch set per predicted
+transform (ops.registration_loss: rigid apply + loss, backward straight to dR / dt), with no
+host synchronisation; a sample whose line set populates no (k, j) bucket contributes 0 (the
+reference would fail on `tensor += (None, None)`).  All functions take and return GPU tensors.
+"""
+import torch
+
+from . import ops as _ops
+
+RNG = (1, 1, 5, 5)  # every reference call site
+
+
+def _mode(mode):
+    import loss as _loss  # the drop-in module next to this package
+    return _loss._scan_mode(mode)
+
+
+def bounding_radius(tar_box, scale=1.0):
+    """|corner 0 - corner 7| * scale of (B, 8, 3) boxes -> (B, 1) (Train_RPM.py:201-203)."""
+    return (torch.norm(tar_box[:, 0, :] - tar_box[:, -1, :], dim=-1, p=2) * scale).reshape(-1, 1)
+
+
+def draw_lines(radius, centers, n_lines, moved_src, tar, device=None):
+    """The trainers' sampler call: (B, n_lines, 6) lines crossing both clouds' boxes."""
+    import loss as _loss
+    device = device or moved_src.device
+    return _loss.Random_uniform_distribution_lines_batch_efficient_resample(
+        radius, centers, n_lines, moved_src, tar, device)
+
+
+def per_sample_loss(src_nb, R, t, tar_tri, lines, mode=None):
+    """loss[b] of the pseudo-triangles `src_nb` (B, 3N, 3) or (B, N, 9) moved by x -> R x + t,
+    against tar_tri (B, M, 9) along lines (B, L, 6).  (loss (B,), valid (B,) bool)."""
+    B = src_nb.shape[0]
+    loss, info, _ = _ops.registration_loss(src_nb.reshape(B, -1, 9), R, t, tar_tri.reshape(B, -1, 9),
+                                           lines, RNG, transpose_r=True, mode=_mode(mode))
+    return loss, info[:, 0] > 0
+
+
+def _split(transform):
+    """(B, 3, 4) [R | t] (RPM's se3 matrices) -> R (B, 3, 3), t (B, 3)."""
+    return transform[..., :3, :3], transform[..., :3, 3]
+
+
+def rpm_intersection_loss(pred_transforms, data, n_lines=10000, lines=None, mode=None):
+    """rpm/Train_RPM.py:188-259.  pred_transforms: list of (B, 3, 4); data: the trainer's dict
+    with 'points_src_sample' (B, N, >=3), 'points_based_neighs_src' (B, 3N, 3),
+    'points_tar_sample' (B, M, 3), 'points_based_neighs_tar' (B, 3M, 3), 'tar_box' (B, 8, 3),
+    'centers' (B, 3).  Returns a dict: 'loss_intersection' (1,), 'loss_chamfer' (scalar,
+    detached), 'per_iter' (list of (1,) tensors, already / num_iter), 'lines', 'valid'."""
+    num_iter = len(pred_transforms)
+    tar = data['points_tar_sample'].contiguous()
+    B = tar.shape[0]
+    tar_tri = data['points_based_neighs_tar'].reshape(B, -1, 9)
+    src = data['points_src_sample'][..., :3]
+    per_iter, chamfers, valid = [], [], []
+    for ni in range(num_iter):
+        R, t = _split(pred_transforms[ni])
+        moved = _ops.rigid_apply(src, R, t, transpose_r=True)
+        if lines is None:
+            lines = draw_lines(bounding_radius(data['tar_box']), data['centers'], n_lines,
+                               moved.detach(), tar)
+        loss, ok = per_sample_loss(data['points_based_neighs_src'], R, t, tar_tri, lines, mode)
+        per_iter.append(loss.sum().reshape(1) / num_iter)
+        chamfers.append(_ops.chamfer(tar, moved).detach())
+        valid.append(ok)
+    disc = [0.5 ** (num_iter - ni - 1) for ni in range(num_iter)]
+    return {'loss_intersection': sum(l * d for l, d in zip(per_iter, disc)),
+            'loss_chamfer': sum(c * d for c, d in zip(chamfers, disc)),
+            'per_iter': per_iter, 'lines': lines, 'valid': torch.stack(valid)}
+
+
+def dcp_intersection_loss(data, rotation_ab_pred, translation_ab_pred, n_lines=15000, lines=None,
+                          mode=None):
+    """dcp/Train_DCP.py:233-270.  The DCP dict holds channel-first clouds: 'points_src_sample'
+    (B, 3, N), 'points_based_neighs_src' (B, 3, 3N), 'points_tar_sample' (B, 3, M),
+    'points_based_neighs_tar' (B, 3, 3M).  Returns (loss_intersection / batch_size (1,),
+    loss_chamfer, lines, valid)."""
+    tar = data['points_tar_sample'].transpose(2, 1).contiguous()
+    B = tar.shape[0]
+    tar_tri = data['points_based_neighs_tar'].transpose(2, 1).reshape(B, -1, 9)
+    moved = _ops.rigid_apply(data['points_src_sample'], rotation_ab_pred, translation_ab_pred,
+                             transpose_r=True, channel_first=True).transpose(2, 1).contiguous()
+    chamfer = _ops.chamfer(moved, tar)
+    if lines is None:
+        lines = draw_lines(bounding_radius(data['tar_box'], 0.5), data['centers'], n_lines,
+                           moved.detach(), tar)
+    src_nb = data['points_based_neighs_src'].transpose(2, 1).contiguous()
+    loss, ok = per_sample_loss(src_nb, rotation_ab_pred, translation_ab_pred, tar_tri, lines, mode)
+    return (loss / 5.0).sum().reshape(1) / B, chamfer, lines, ok
+
+
+def fmr_intersection_loss(g_series, data, n_lines=15000, lines=None, last=3, mode=None):
+    """fmr/model.py:266-310.  g_series: sequence of (B, 4, 4) estimates (self.g_series_gpu), of
+    which the final `last` enter the loss; channel-last clouds as in RPM.  Returns
+    (loss_intersection / batch_size (1,), loss_chamfer of the last estimate, lines, valid)."""
+    maxiter = len(g_series)
+    tar = data['points_tar_sample'].contiguous()
+    B = tar.shape[0]
+    tar_tri = data['points_based_neighs_tar'].reshape(B, -1, 9)
+    src = data['points_src_sample'][..., :3].contiguous()
+    R, t = _split(g_series[maxiter - 1])
+    moved = _ops.rigid_apply(src, R, t, transpose_r=True)
+    if lines is None:
+        lines = draw_lines(bounding_radius(data['tar_box'], 0.5), data['centers'], n_lines,
+                           moved.detach(), tar)
+    total, valid = 0.0, []
+    for i in range(maxiter - last, maxiter):
+        R, t = _split(g_series[i])
+        loss, ok = per_sample_loss(data['points_based_neighs_src'], R, t, tar_tri, lines, mode)
+        total = total + (loss / 5.0).sum().reshape(1) * 0.5 ** (maxiter - i - 1)
+        valid.append(ok)
+    return total / B, _ops.chamfer(moved, tar), lines, torch.stack(valid)

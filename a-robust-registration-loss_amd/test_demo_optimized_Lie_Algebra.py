@@ -1,0 +1,313 @@
+#!/usr/bin/env python3
+"""Single-pair registration by direct optimisation of one se(3) vector -- the MI355X
+counterpart of the reference demo (code/test_demo_optimized_Lie_Algebra.py:27-143).
+
+Same command line (--data_path --device --seed --label1 --Save_path), same data dict, same
+loop: per epoch draw `n_sample_line` lines through both clouds' boxes, move the source with
+Reconstruction_point, evaluate the intersected-line loss, Adam step (lr 2e-2, halved whenever
+epoch % 1000 == 0 -- including epoch 0), Chamfer monitor, and every 10th epoch write
+`<epoch>.obj`, `target.obj`, `model.pkl`, `<epoch>_transform.txt` under Save_path.
+
+Differences, all additive:
+  * OBJ files are read/written by a ten-line parser (no libigl), scalars go to
+    `<Save_path>/log/scalars.csv` (tensorboard's SummaryWriter is used when importable);
+  * `--synthetic N` makes a seeded pair instead of reading OBJ files;
+  * `--graph` replays the whole step (exp map, fused transform + loss, backward, Adam,
+    Chamfer) as one captured hipGraph: one host call per epoch and no host synchronisation
+    except for the progress line every `--print_every` epochs;
+  * `lines_fn(epoch, moved_src)` lets a test inject recorded lines.
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from loss import cal_loss_intersection_batch_whole_median_pts_lines  # noqa: E402
+from loss import Random_uniform_distribution_lines_batch_efficient_resample  # noqa: E402
+from loss import Reconstruction_point, Sample_neighs, chamfer_dist, generate_bbox  # noqa: E402
+from rrl_hip import ops as _ops  # noqa: E402
+from rrl_hip.graph import GraphedStep  # noqa: E402
+
+
+def adjust_learning_rate(optimizer, epoch, lr):
+    """Halve `lr` when epoch % 1000 == 0 (the reference does so at epoch 0 too) and install it."""
+    if epoch % 1000 == 0:
+        lr *= 0.5
+    for group in optimizer.param_groups:
+        group['lr'] = lr
+    return lr
+
+
+# ------------------------------------------------------------------------------- file I/O
+def read_obj_vertices(path):
+    """(V, 3) float32 vertex rows of a Wavefront OBJ (the demo ignores the faces)."""
+    rows = []
+    with open(path) as fh:
+        for ln in fh:
+            if ln.startswith('v '):
+                rows.append([float(x) for x in ln.split()[1:4]])
+    if not rows:
+        raise ValueError(f"{path}: no vertices")
+    return np.asarray(rows, np.float32)
+
+
+def write_obj(path, vertices):
+    """Vertices plus the single degenerate face `igl.write_obj(path, V, zeros((1, 3)))` emits."""
+    with open(path, 'w') as fh:
+        for v in np.asarray(vertices):
+            fh.write(f"v {v[0]:.9g} {v[1]:.9g} {v[2]:.9g}\n")
+        fh.write("f 1 1 1\n")
+
+
+class ScalarLog:
+    """`add_scalar(tag, value, step)` into <log_dir>/scalars.csv (SummaryWriter stand-in)."""
+
+    def __init__(self, log_dir):
+        os.makedirs(log_dir, exist_ok=True)
+        self.fh = open(os.path.join(log_dir, 'scalars.csv'), 'w')
+        self.fh.write("step,tag,value\n")
+
+    def add_scalar(self, tag, value, step):
+        self.fh.write(f"{step},{tag},{value:.9g}\n")
+
+    def close(self):
+        self.fh.close()
+
+
+def make_writer(log_dir):
+    try:
+        from torch.utils.tensorboard import SummaryWriter
+        return SummaryWriter(log_dir=log_dir)
+    except Exception:  # tensorboard is optional
+        return ScalarLog(log_dir)
+
+
+def save_checkpoint(Save_path, epoch, moved, target, model):
+    write_obj(os.path.join(Save_path, f"{epoch}.obj"), moved.detach().cpu().numpy())
+    write_obj(os.path.join(Save_path, "target.obj"), target.detach().cpu().numpy())
+    torch.save(model.state_dict(), os.path.join(Save_path, 'model.pkl'))
+    R, T = model.Transform()
+    transforms = np.ones([3, 4])
+    transforms[:3, :3] = R.detach().cpu().numpy()
+    transforms[:3, 3] = T.detach().cpu().numpy()
+    np.savetxt(os.path.join(Save_path, f"{epoch}_transform.txt"), transforms)
+
+
+# ------------------------------------------------------------------------------ the loop
+class _GatedAdam:
+    """torch.optim.Adam's update (betas 0.9/0.999, eps 1e-8, no weight decay) written with
+    device-side scalars so a captured graph can (a) take a new lr per replay and (b) skip the
+    whole update when the loss was empty, as the reference's `if loss_di is not None` does."""
+
+    def __init__(self, param, lr):
+        self.p = param
+        dev = param.device
+        self.m = torch.zeros_like(param)
+        self.v = torch.zeros_like(param)
+        self.step = torch.zeros((), device=dev)
+        self.lr = torch.full((), lr, device=dev)
+        self.param_groups = [{'lr': lr}]
+
+    def set_lr(self):
+        self.lr.fill_(self.param_groups[0]['lr'])
+
+    def update(self, grad, ok):
+        b1, b2, eps = 0.9, 0.999, 1e-8
+        self.step.add_(ok.to(self.step.dtype))
+        m = self.m * b1 + grad * (1 - b1)
+        v = self.v * b2 + grad * grad * (1 - b2)
+        self.m.copy_(torch.where(ok, m, self.m))
+        self.v.copy_(torch.where(ok, v, self.v))
+        bias1 = 1 - b1 ** self.step
+        bias2 = 1 - b2 ** self.step
+        denom = self.v.sqrt() / bias2.sqrt() + eps
+        delta = (self.lr / bias1) * self.m / denom
+        self.p.data.sub_(torch.where(ok, delta, torch.zeros_like(delta)))
+
+
+def _default_lines(radius, centers, n_sample_line, target, device):
+    def draw(epoch, moved):
+        return Random_uniform_distribution_lines_batch_efficient_resample(
+            radius.reshape(1, 1), centers.reshape(1, -1), n_sample_line, moved.view(1, -1, 3),
+            target.view(1, -1, 3), device).detach().view(-1, 6)
+    return draw
+
+
+def test_one_case(data, Save_path, writer=None, n_epoch=1000, n_sample_line=20000, device='cuda:0',
+                  *, lines_fn=None, graph=False, save_every=10, print_every=1, model=None):
+    """code/test_demo_optimized_Lie_Algebra.py:27-100.  Returns the per-epoch history
+    [(epoch, loss or None, chamfer or None)] (floats; in graph mode filled at the end from
+    device buffers) and the Reconstruction_point module."""
+    dev = torch.device(device)
+    bounding_box = data['bounding_box'].to(dev)
+    src = data['vertics1_tensor'].to(dev)
+    tar = data['vertics2_tensor'].to(dev)
+    src_nb = data['vertics1_faces_tensor'].to(dev)
+    tar_tri = data['vertics2_faces_tensor'].to(dev).reshape(1, -1, 9)
+    centers = data['centers'].to(dev)
+    os.makedirs(Save_path, exist_ok=True)
+    Reconstruction = (model or Reconstruction_point()).to(dev)
+    radius = (bounding_box[0, :] - bounding_box[-1, :]).norm(p=2).reshape(1)
+    draw = lines_fn or _default_lines(radius, centers, n_sample_line, tar, dev)
+    if graph:
+        return _run_graphed(Reconstruction, draw, src, src_nb, tar, tar_tri, Save_path, writer,
+                            n_epoch, save_every, print_every), Reconstruction
+
+    optimize = torch.optim.Adam(Reconstruction.parameters(), lr=2e-2)
+    moved = src
+    history = []
+    for epoch in range(n_epoch):
+        lines = draw(epoch, moved.detach())
+        adjust_learning_rate(optimize, epoch, optimize.param_groups[0]['lr'])
+        moved, moved_tri = Reconstruction(src, src_nb)
+        loss_di = cal_loss_intersection_batch_whole_median_pts_lines(
+            1, 1, 5, 5, moved_tri.reshape(1, -1, 9), tar_tri, lines.reshape(1, -1, 6), dev)
+        if loss_di is None:
+            history.append((epoch, None, None))
+            continue
+        optimize.zero_grad()
+        loss_di.backward()
+        optimize.step()
+        loss_cf = chamfer_dist(moved.reshape(1, -1, 3), tar.reshape(1, -1, 3))
+        di, cf = torch.stack([loss_di.detach().reshape(()), loss_cf.detach()]).tolist()
+        history.append((epoch, di, cf))
+        if print_every and epoch % print_every == 0:
+            print("\033[34mthis is the chamfer loss:{:4f}, loss_intersection{:4f}\033[0m".format(cf, di))
+        if save_every and epoch % save_every == 0:
+            save_checkpoint(Save_path, epoch, moved, tar, Reconstruction)
+        if writer is not None:
+            writer.add_scalar('./loss/chamfer_loss', cf, epoch)
+            writer.add_scalar('./loss/intersection_loss', di, epoch)
+    return history, Reconstruction
+
+
+def _run_graphed(model, draw, src, src_nb, tar, tar_tri, Save_path, writer, n_epoch, save_every,
+                 print_every):
+    dev = src.device
+    xi = model.parameters_
+    opt = _GatedAdam(xi, 2e-2)
+    src_tri = src_nb.reshape(1, -1, 9).contiguous()
+    lines0 = draw(0, src)
+    lines = torch.empty_like(lines0.reshape(1, -1, 6))
+    moved = src.clone().reshape(1, -1, 3)
+    trace = torch.zeros(n_epoch, 3, device=dev)  # loss, chamfer, valid per epoch
+    row = torch.zeros(3, device=dev)
+
+    def step():
+        xi.grad = None
+        R, T = model.Transform()
+        loss, info, _ = _ops.registration_loss(src_tri, R, T, tar_tri, lines, transpose_r=False)
+        loss.sum().backward()
+        ok = info[0, 0] > 0
+        opt.update(xi.grad, ok)
+        with torch.no_grad():
+            moved.copy_(_ops.rigid_apply(src.reshape(1, -1, 3), R.detach(), T.detach()))
+            row[0], row[1], row[2] = loss.detach()[0], _ops.chamfer(moved, tar.reshape(1, -1, 3)), ok
+        return row
+
+    lr = 2e-2
+    stepper = None
+    for epoch in range(n_epoch):
+        lines.copy_((lines0 if epoch == 0 else draw(epoch, moved.reshape(-1, 3))).reshape(1, -1, 6))
+        lr = adjust_learning_rate(opt, epoch, lr)
+        opt.set_lr()
+        if stepper is None:
+            # the warm-up replays inside GraphedStep must not move the state: snapshot, restore
+            keep = [t.clone() for t in (xi.data, opt.m, opt.v, opt.step)]
+            stepper = GraphedStep(step, warmup=2)
+            for t, k in zip((xi.data, opt.m, opt.v, opt.step), keep):
+                t.copy_(k)
+        trace[epoch].copy_(stepper())
+        if print_every and epoch % print_every == 0:
+            di, cf, ok = trace[epoch].tolist()
+            if ok:
+                print("\033[34mthis is the chamfer loss:{:4f}, loss_intersection{:4f}\033[0m".format(cf, di))
+        if save_every and epoch % save_every == 0:
+            save_checkpoint(Save_path, epoch, moved.reshape(-1, 3), tar, model)
+    history = []
+    for epoch, (di, cf, ok) in enumerate(trace.tolist()):
+        history.append((epoch, di, cf) if ok else (epoch, None, None))
+        if ok and writer is not None:
+            writer.add_scalar('./loss/chamfer_loss', cf, epoch)
+            writer.add_scalar('./loss/intersection_loss', di, epoch)
+    return history
+
+
+# -------------------------------------------------------------------------------- driver
+def build_data(vertics1, vertics2, device):
+    """code/test_demo_optimized_Lie_Algebra.py:113-141: pseudo-triangles, centring, the dict."""
+    vertics1 = np.asarray(vertics1, np.float32)
+    vertics2 = np.asarray(vertics2, np.float32)
+    faces_neighs1 = Sample_neighs(vertics1, device=device)
+    faces_neighs2 = Sample_neighs(vertics2, device=device)
+    center1 = vertics1.mean(0)[np.newaxis, :]
+    center2 = vertics2.mean(0)[np.newaxis, :]
+    vertics1, vertics2 = vertics1 - center1, vertics2 - center2
+    faces_neighs1, faces_neighs2 = faces_neighs1 - center1, faces_neighs2 - center2
+    v1 = torch.from_numpy(vertics1.astype(np.float32)).to(device)
+    v2 = torch.from_numpy(vertics2.astype(np.float32)).to(device)
+    return {
+        'bounding_box': generate_bbox(v2[None])[0].to(device),
+        'vertics1_tensor': v1,
+        'vertics2_tensor': v2,
+        'vertics1_faces_tensor': torch.from_numpy(faces_neighs1.astype(np.float32)).to(device).reshape(1, -1, 3),
+        'vertics2_faces_tensor': torch.from_numpy(faces_neighs2.astype(np.float32)).to(device),
+        'centers': v2.mean(0),
+    }
+
+
+def main(args):
+    torch.set_default_dtype(torch.float32)
+    torch.manual_seed(args.seed)
+    np.random.seed(args.seed)
+    _ops.require_gpu()  # no CPU path: fail loudly without a GPU / the HIP library
+    device = torch.device(args.device)
+    if device.type != 'cuda':
+        raise ValueError("--device must be a cuda device (the loss has no CPU implementation)")
+    torch.cuda.set_device(device)
+    if args.synthetic:
+        from rrl_hip import synth
+        pr = synth.make_pair(args.seed, args.synthetic, args.synthetic)
+        vertics1, vertics2 = pr['src'], pr['tar']
+    else:
+        vertics1 = read_obj_vertices(os.path.join(args.data_path, args.label1 + "_src_sample.obj"))
+        vertics2 = read_obj_vertices(os.path.join(args.data_path, args.label1 + "_tar_sample.obj"))
+    data = build_data(vertics1, vertics2, device)
+    writer = make_writer(os.path.join(args.Save_path, 'log'))
+    history, model = test_one_case(data, args.Save_path, writer=writer, n_epoch=args.n_epoch,
+                                   n_sample_line=args.n_sample_line, device=device, graph=args.graph,
+                                   print_every=args.print_every)
+    writer.close()
+    return history, model
+
+
+if __name__ == "__main__":
+    print("Test our case!")
+    parser = argparse.ArgumentParser()
+    parser.add_argument('--data_path', type=str, default="./sample_data/challenge_data")
+    parser.add_argument('--device', type=str, default='cuda:0')
+    parser.add_argument('--seed', type=int, default=123)
+    parser.add_argument('--label1', type=str, default=None)
+    parser.add_argument('--Save_path', type=str, default="./Results")
+    parser.add_argument('--n_epoch', type=int, default=1000)
+    parser.add_argument('--n_sample_line', type=int, default=20000)
+    parser.add_argument('--synthetic', type=int, default=0, metavar='N',
+                        help="use a seeded synthetic pair of N points instead of OBJ files")
+    parser.add_argument('--graph', action='store_true', help="replay the step as one hipGraph")
+    parser.add_argument('--print_every', type=int, default=1)
+    args = parser.parse_args()
+    save_root = args.Save_path
+    if args.synthetic:
+        labels = [args.label1 or 'synthetic']
+    elif args.label1 is not None:
+        labels = [args.label1]
+    else:  # the reference loops over the pairs '0'..'4' of the data directory
+        labels = sorted({f.split('_')[0] for f in os.listdir(args.data_path) if f.endswith('_src_sample.obj')})
+    for label1 in labels:
+        args.label1 = label1
+        args.Save_path = os.path.join(save_root, label1 + "challenge_new_1")
+        os.makedirs(save_root, exist_ok=True)
+        main(args)

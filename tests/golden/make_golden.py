@@ -253,6 +253,160 @@ def neighs():
     save("sample_neighs.npz", points=pts, full=full.astype(np.float32), sub=sub.astype(np.float32))
 
 
+def callsites():
+    """The training call-site fragments (rpm/Train_RPM.py:204-259, dcp/Train_DCP.py:233-270,
+    fmr/model.py:266-310) replayed with the REFERENCE's loss/sampler/chamfer functions on a
+    small synthetic batch: per-sample loop, scalings and discounts as the trainers apply them."""
+    B, n, nl = 3, 256, 3000
+    prs = [synth.make_pair(40 + b, n, n) for b in range(B)]
+    src = torch.stack([t(p["src"]) for p in prs])
+    tar = torch.stack([t(p["tar"]) for p in prs])
+    nb_src = torch.stack([t(p["src_tri"]).reshape(-1, 3) for p in prs])   # (B, 3n, 3)
+    nb_tar = torch.stack([t(p["tar_tri"]).reshape(-1, 3) for p in prs])
+    tar_box = RL.generate_bbox(tar)
+    centers = tar.mean(1)
+    g = torch.Generator().manual_seed(5)
+    num_iter = 3
+    xis = 0.08 * torch.randn(num_iter, B, 6, generator=g)
+    Rs, ps = RL.se3.exp3(xis.reshape(-1, 6))
+    Rs, ps = Rs.reshape(num_iter, B, 3, 3), ps.reshape(num_iter, B, 3)
+    Rs.requires_grad_(True)
+    ps.requires_grad_(True)
+
+    def move(x, R, p):      # R x + p per point, what se3.transform / transform_point_cloud do
+        return x @ R.transpose(-1, -2) + p[:, None, :]
+
+    tar_tri = nb_tar.reshape(B, -1, 9)
+    out = dict(src=src.numpy(), tar=tar.numpy(), nb_src=nb_src.numpy(), nb_tar=nb_tar.numpy(),
+               tar_box=tar_box.numpy(), centers=centers.numpy(), R=Rs.detach().numpy(),
+               t=ps.detach().numpy())
+
+    # ---- RPM: radius = full diagonal, 10000 lines in the trainer (nl here), /num_iter, discount
+    radius = torch.norm(tar_box[:, 0] - tar_box[:, -1], dim=-1).reshape(-1, 1)
+    torch.manual_seed(61)
+    lines = RL.Random_uniform_distribution_lines_batch_efficient_resample(
+        radius, centers, nl, move(src, Rs[0], ps[0]).detach(), tar, "cpu")
+    per_iter, per_sample, chamf = [], [], []
+    for ni in range(num_iter):
+        moved = move(src, Rs[ni], ps[ni])
+        tri = move(nb_src, Rs[ni], ps[ni]).reshape(B, -1, 9)
+        acc = torch.zeros(1)
+        row = []
+        for j in range(B):
+            lj = RL.cal_loss_intersection_batch_whole_median_pts_lines(
+                1, 1, 5, 5, tri[j:j + 1], tar_tri[j:j + 1], lines[j:j + 1], "cpu")
+            row.append(lj.item())
+            acc = acc + lj
+        per_sample.append(row)
+        per_iter.append(acc / num_iter)
+        chamf.append(RL.chamfer_dist(tar, moved).detach())
+    disc = [0.5 ** (num_iter - ni - 1) for ni in range(num_iter)]
+    total = torch.stack([per_iter[i] * disc[i] for i in range(num_iter)]).sum(0)
+    total_cd = torch.stack([chamf[i] * disc[i] for i in range(num_iter)]).sum(0)
+    total.backward()
+    out.update(rpm_lines=lines.numpy(), rpm_per_sample=np.array(per_sample, np.float32),
+               rpm_per_iter=np.array([x.item() for x in per_iter], np.float32),
+               rpm_loss=np.float32(total.item()), rpm_chamfer=np.float32(total_cd.item()),
+               rpm_grad_R=Rs.grad.numpy().copy(), rpm_grad_t=ps.grad.numpy().copy())
+    print("rpm fragment:", total.item(), total_cd.item(), per_sample)
+    Rs.grad = None
+    ps.grad = None
+
+    # ---- DCP: radius = half diagonal, channel-first clouds, /5.0 per sample, /batch_size
+    radius = (torch.norm(tar_box[:, 0] - tar_box[:, -1], dim=-1) * 0.5).reshape(-1, 1)
+    moved = move(src, Rs[0], ps[0])
+    torch.manual_seed(62)
+    lines = RL.Random_uniform_distribution_lines_batch_efficient_resample(
+        radius, centers, nl, moved.detach(), tar, "cpu")
+    tri = move(nb_src, Rs[0], ps[0]).reshape(B, -1, 9)
+    acc = torch.zeros(1)
+    for j in range(B):
+        acc = acc + RL.cal_loss_intersection_batch_whole_median_pts_lines(
+            1, 1, 5, 5, tri[j:j + 1], tar_tri[j:j + 1], lines[j:j + 1], "cpu") / 5.0
+    dcp = acc / B
+    cd = RL.chamfer_dist(moved, tar)
+    dcp.backward()
+    out.update(dcp_lines=lines.numpy(), dcp_loss=np.float32(dcp.item()),
+               dcp_chamfer=np.float32(cd.item()), dcp_grad_R=Rs.grad[0].numpy().copy(),
+               dcp_grad_t=ps.grad[0].numpy().copy())
+    print("dcp fragment:", dcp.item(), cd.item())
+    Rs.grad = None
+    ps.grad = None
+
+    # ---- FMR: half diagonal, lines from the LAST estimate, last three estimates, /5.0,
+    # discount 0.5**(maxiter-i-1), /batch_size
+    torch.manual_seed(63)
+    lines = RL.Random_uniform_distribution_lines_batch_efficient_resample(
+        radius, centers, nl, move(src, Rs[-1], ps[-1]).detach(), tar, "cpu")
+    total = torch.zeros(1)
+    for i in range(num_iter - 3, num_iter):
+        tri = move(nb_src, Rs[i], ps[i]).reshape(B, -1, 9)
+        acc = torch.zeros(1)
+        for j in range(B):
+            acc = acc + RL.cal_loss_intersection_batch_whole_median_pts_lines(
+                1, 1, 5, 5, tri[j:j + 1], tar_tri[j:j + 1], lines[j:j + 1], "cpu") / 5.0
+        total = total + acc * 0.5 ** (num_iter - i - 1)
+    fmr = total / B
+    cd = RL.chamfer_dist(move(src, Rs[-1], ps[-1]), tar)
+    fmr.backward()
+    out.update(fmr_lines=lines.numpy(), fmr_loss=np.float32(fmr.item()),
+               fmr_chamfer=np.float32(cd.item()), fmr_grad_R=Rs.grad.numpy().copy(),
+               fmr_grad_t=ps.grad.numpy().copy())
+    print("fmr fragment:", fmr.item(), cd.item())
+    save("callsites.npz", **out)
+
+
+def demo_trajectory():
+    """test_demo_optimized_Lie_Algebra.py:27-75 (test_one_case) replayed with the reference's
+    modules for a few epochs on a small synthetic pair; the sampled lines of every epoch are
+    recorded so the GPU harness can be driven with the same lines."""
+    n, nl, epochs = 300, 2500, 8
+    pr = synth.make_pair(51, n, n)
+    v1, v2 = t(pr["src"]), t(pr["tar"])
+    f1 = t(pr["src_tri"]).reshape(1, -1, 3)
+    f2 = t(pr["tar_tri"])
+    bbox = RL.generate_bbox(v2[None])[0]
+    centers = v2.mean(0)
+    np.random.seed(9)
+    torch.manual_seed(9)
+    rec = RL.Reconstruction_point()
+    xi0 = rec.parameters_.detach().numpy().copy()
+    opt = torch.optim.Adam(rec.parameters(), lr=2e-2)
+    R = (bbox[0] - bbox[-1]).norm(p=2)
+    cur = v1
+    lines_all, losses, chamfers, xis, lrs = [], [], [], [], []
+    for epoch in range(epochs):
+        lines = RL.Random_uniform_distribution_lines_batch_efficient_resample(
+            torch.FloatTensor([R]).reshape(1, 1), centers.reshape(1, -1), nl,
+            cur.view(1, -1, 3), v2.view(1, -1, 3), "cpu").detach().view(-1, 6)
+        lr = opt.param_groups[0]["lr"]
+        if epoch % 1000 == 0:
+            lr *= 0.5
+        for gparam in opt.param_groups:
+            gparam["lr"] = lr
+        cur, tri = rec(v1, f1)
+        loss = RL.cal_loss_intersection_batch_whole_median_pts_lines(
+            1, 1, 5, 5, tri.reshape(1, -1, 9), f2.reshape(1, -1, 9), lines.reshape(1, -1, 6), "cpu")
+        assert not isinstance(loss, tuple)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        cf = RL.chamfer_dist(cur.reshape(-1, cur.shape[0], 3), v2.reshape(-1, v2.shape[0], 3))
+        lines_all.append(lines.numpy().copy())
+        losses.append(loss.item())
+        chamfers.append(cf.item())
+        xis.append(rec.parameters_.detach().numpy().copy())
+        lrs.append(lr)
+        cur = cur.detach()
+    print("demo trajectory: loss", losses, "chamfer", chamfers)
+    save("demo_trajectory.npz", src=pr["src"], tar=pr["tar"], src_tri=pr["src_tri"],
+         tar_tri=pr["tar_tri"], bbox=bbox.numpy(), centers=centers.numpy(), xi0=xi0,
+         lines=np.array(lines_all, np.float32), loss=np.array(losses, np.float32),
+         chamfer=np.array(chamfers, np.float32), xi=np.array(xis, np.float32),
+         lr=np.array(lrs, np.float64))
+
+
 if __name__ == "__main__":
-    main()
-    neighs()
+    which = sys.argv[1:] or ["main", "neighs", "callsites", "demo_trajectory"]
+    for name in which:
+        globals()[name]()

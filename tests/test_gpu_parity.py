@@ -307,6 +307,38 @@ def test_full_size_sample_vs_oracle(L, oracle):
     assert float(bt.loss[1]) != float(st.loss[0])
 
 
+# BASELINE.json configs[0], [3], [4] (the bench runs configs[1]; [2] is its 8-GPU shard), plus a
+# cloud one past the 16384-triangle limit of the sorted/culled layout (falls back to the dense scan)
+@pytest.mark.parametrize("n,m,nl,crop,noise", [
+    (1024, 1024, 20000, False, 0.01),    # C1 demo
+    (2048, 1024, 10000, True, 0.02),     # C4 partial overlap + noise
+    (16384, 16384, 512, False, 0.01),    # C5 fragments, 512 lines
+    (16385, 1000, 768, False, 0.01),     # beyond the cull limit, ragged N != M
+])
+def test_baseline_configs_vs_oracle(L, oracle, n, m, nl, crop, noise):
+    from rrl_hip import synth
+    pr = synth.make_pair(17, n, m, crop=crop, noise=noise)
+    rands = synth.uniform_streams(17, 10, nl)
+    lines = oracle.resample_lines(rands, pr["radius"], pr["center"], pr["src"], pr["tar"], nl)
+    o = oracle.loss(pr["src_tri"], pr["tar_tri"], lines)
+    o1 = oracle.scan(pr["src_tri"], lines, cap=4)
+    o2 = oracle.scan(pr["tar_tri"], lines, cap=4)
+    assert o["n_selected"] >= 4  # dense clouds have tiny pseudo-triangles: few of 512 lines hit
+    for mode in ("cull", "strict"):
+        st = run_state(pr["src_tri"], pr["tar_tri"], lines, mode=mode)
+        np.testing.assert_array_equal(st.count1[0].cpu().numpy(), o1["count"])
+        np.testing.assert_array_equal(st.count2[0].cpu().numpy(), o2["count"])
+        np.testing.assert_allclose(float(st.loss[0]), o["loss"], rtol=2e-6)
+    p1 = cu(pr["src_tri"])[None].requires_grad_(True)
+    out = L.cal_loss_intersection_batch_whole_median_pts_lines(
+        1, 1, 5, 5, p1, cu(pr["tar_tri"])[None], cu(lines)[None], "cuda")
+    np.testing.assert_allclose(out.item(), o["loss"], rtol=2e-6)
+    out.backward()
+    mine = merge_by_point(pr["src_tri"], p1.grad[0].cpu().numpy())
+    om = merge_by_point(pr["src_tri"], o["grad1"])
+    np.testing.assert_allclose(mine, om, rtol=1e-4, atol=1e-6 * np.abs(om).max())
+
+
 # ---------------------------------------------------------------------------------- K7
 def test_chamfer(L, oracle):
     g = load_golden("chamfer.npz")
