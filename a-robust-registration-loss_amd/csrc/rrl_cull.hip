@@ -376,10 +376,10 @@ __global__ __launch_bounds__(256) void cull_scan_kernel(
 }
 
 // Launchers used by rrl_tri_prepare / rrl_line_tri_scan (rrl_scan.hip)
-int rrl_launch_tri_sort(void *ws, const WsLayout &w, int B, int N, int M, hipStream_t s) {
-    const int nmax = N > M ? N : M;
+int rrl_launch_tri_sort(void *ws, const WsLayout &w, int B, int N, int M, int clouds, hipStream_t s) {
+    const int nmax = clouds == 2 && M > N ? M : N;
     const size_t lds = sizeof(float) * (size_t)((nmax + GRP - 1) / GRP * GRP);
-    hipLaunchKernelGGL(tri_sort_kernel, dim3((unsigned)(2 * B)), dim3(1024), lds, s, w.f32(ws, RRL_WS_PTRI1),
+    hipLaunchKernelGGL(tri_sort_kernel, dim3((unsigned)(clouds * B)), dim3(1024), lds, s, w.f32(ws, RRL_WS_PTRI1),
                        w.f32(ws, RRL_WS_PTRI2), (float4 *)w.f32(ws, RRL_WS_P0S1),
                        (float4 *)w.f32(ws, RRL_WS_P0S2), w.i32(ws, RRL_WS_IDX1), w.i32(ws, RRL_WS_IDX2),
                        (float4 *)w.f32(ws, RRL_WS_GRP1), (float4 *)w.f32(ws, RRL_WS_GRP2),
@@ -389,8 +389,8 @@ int rrl_launch_tri_sort(void *ws, const WsLayout &w, int B, int N, int M, hipStr
 }
 
 int rrl_launch_cull_scan(const float *line, void *ws, const WsLayout &w, int B, int N, int M, int L,
-                         hipStream_t s) {
-    hipLaunchKernelGGL(cull_scan_kernel, dim3((unsigned)((L + 63) / 64), (unsigned)(2 * B)), dim3(256), 0,
+                         int clouds, hipStream_t s) {
+    hipLaunchKernelGGL(cull_scan_kernel, dim3((unsigned)((L + 63) / 64), (unsigned)(clouds * B)), dim3(256), 0,
                        s, w.f32(ws, RRL_WS_PTRI1), w.f32(ws, RRL_WS_PTRI2),
                        (const float4 *)w.f32(ws, RRL_WS_P0S1), (const float4 *)w.f32(ws, RRL_WS_P0S2),
                        w.i32(ws, RRL_WS_IDX1), w.i32(ws, RRL_WS_IDX2), (const float4 *)w.f32(ws, RRL_WS_GRP1),

@@ -95,19 +95,22 @@ __global__ __launch_bounds__(64) void tri_prepare_kernel(const float *__restrict
     }
 }
 
-int rrl_launch_tri_sort(void *ws, const WsLayout &w, int B, int N, int M, hipStream_t s);
+int rrl_launch_tri_sort(void *ws, const WsLayout &w, int B, int N, int M, int clouds, hipStream_t s);
 int rrl_launch_cull_scan(const float *line, void *ws, const WsLayout &w, int B, int N, int M, int L,
-                         hipStream_t s);
+                         int clouds, hipStream_t s);
 int rrl_sort_capacity(void);
 
-extern "C" int rrl_tri_prepare(const float *tri1, const float *tri2, void *ws, size_t ws_bytes,
-                               int B, int N, int M, int L, void *stream) {
+// clouds = 2: both clouds; clouds = 1: the source only (the target's scan results are carried
+// over from an earlier call with the same target and lines, see rrl_loss_forward_cached).  The
+// sorted/legacy decision always looks at both sizes so that a cached call takes the same path.
+int rrl_tri_prepare_clouds(const float *tri1, const float *tri2, void *ws, size_t ws_bytes, int B,
+                           int N, int M, int L, int clouds, void *stream) {
     if (!tri1 || !tri2 || !ws || B < 0 || N < 0 || M < 0 || L < 0) return RRL_E_ARG;
     WsLayout w(B, N, M, L);
     if (ws_bytes < w.total) return RRL_E_WS;
     hipStream_t s = (hipStream_t)stream;
-    const int nmax = N > M ? N : M;
-    const bool sorted = nmax <= rrl_sort_capacity();
+    const bool sorted = (N > M ? N : M) <= rrl_sort_capacity();
+    const int nmax = clouds == 2 && M > N ? M : N;
     uint4 *zb = (uint4 *)((char *)ws + w.off[RRL_WS_STATUS]);
     if (!sorted || B == 0 || nmax == 0) {
         // one memset clears status, nvals, nsel, pmax, count1, count2 (contiguous by construction)
@@ -115,7 +118,7 @@ extern "C" int rrl_tri_prepare(const float *tri1, const float *tri2, void *ws, s
         if (e != hipSuccess) return (int)e;
     }
     if (B == 0 || nmax == 0) return 0;
-    dim3 grid((unsigned)((nmax + 63) / 64), (unsigned)B, 2);
+    dim3 grid((unsigned)((nmax + 63) / 64), (unsigned)B, (unsigned)clouds);
     if (sorted)
         hipLaunchKernelGGL(tri_prepare_kernel<false>, grid, dim3(64), 0, s, tri1, tri2,
                            w.f32(ws, RRL_WS_PTRI1), w.f32(ws, RRL_WS_PTRI2),
@@ -128,8 +131,13 @@ extern "C" int rrl_tri_prepare(const float *tri1, const float *tri2, void *ws, s
                            N, M);
     RRL_LAUNCH_CHECK();
     // grid-cell order + group spheres + max |P|^2 for the culled scan
-    if (sorted) return rrl_launch_tri_sort(ws, w, B, N, M, s);
+    if (sorted) return rrl_launch_tri_sort(ws, w, B, N, M, clouds, s);
     return 0;
+}
+
+extern "C" int rrl_tri_prepare(const float *tri1, const float *tri2, void *ws, size_t ws_bytes,
+                               int B, int N, int M, int L, void *stream) {
+    return rrl_tri_prepare_clouds(tri1, tri2, ws, ws_bytes, B, N, M, L, 2, stream);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -372,15 +380,15 @@ extern "C" int rrl_scan_timing_collect(float *ms, int max_n) {
     return n;
 }
 
-extern "C" int rrl_line_tri_scan(const float *line, void *ws, size_t ws_bytes, int B, int N, int M,
-                                 int L, int mode, int chunk, void *stream) {
+int rrl_line_tri_scan_clouds(const float *line, void *ws, size_t ws_bytes, int B, int N, int M, int L,
+                             int mode, int chunk, int clouds, void *stream) {
     if (!line || !ws || B < 0 || N < 0 || M < 0 || L < 0 || chunk < 0) return RRL_E_ARG;
     if (mode != RRL_SCAN_STRICT && mode != RRL_SCAN_LAZY && mode != RRL_SCAN_AUTO &&
         mode != RRL_SCAN_CULL)
         return RRL_E_ARG;
     WsLayout w(B, N, M, L);
     if (ws_bytes < w.total) return RRL_E_WS;
-    if (B == 0 || L == 0 || (N == 0 && M == 0)) return 0;
+    if (B == 0 || L == 0 || (N == 0 && (M == 0 || clouds == 1))) return 0;
     const int nmax0 = N > M ? N : M;
     if (mode == RRL_SCAN_CULL && nmax0 > rrl_sort_capacity()) mode = RRL_SCAN_AUTO;
     int R = g_scan_variant;
@@ -400,9 +408,9 @@ extern "C" int rrl_line_tri_scan(const float *line, void *ws, size_t ws_bytes, i
         chunk = c ? atoi(c) : 0;
         if (chunk <= 0) chunk = mode == RRL_SCAN_STRICT ? 256 : 128;
     }
-    const int nmax = N > M ? N : M;
+    const int nmax = clouds == 2 && M > N ? M : N;
     dim3 grid((unsigned)((L + 256 * R - 1) / (256 * R)), (unsigned)((nmax + chunk - 1) / chunk),
-              (unsigned)(2 * B));
+              (unsigned)(clouds * B));
     hipStream_t s = (hipStream_t)stream;
     const bool timed = g_timing_on && (g_timing_seen++ % g_timing_on) == 0 && g_timing_n < TIMING_RING;
     if (timed) (void)hipEventRecord(g_ev[g_timing_n][0], s);
@@ -418,10 +426,15 @@ extern "C" int rrl_line_tri_scan(const float *line, void *ws, size_t ws_bytes, i
     else RRL_SCAN_LAUNCH(v2f, 4);
 #undef RRL_SCAN_LAUNCH
     if (cull) {  // after its companion, which classified the tiles
-        int rc = rrl_launch_cull_scan(line, ws, w, B, N, M, L, s);
+        int rc = rrl_launch_cull_scan(line, ws, w, B, N, M, L, clouds, s);
         if (rc) return rc;
     }
     if (timed) (void)hipEventRecord(g_ev[g_timing_n++][1], s);
     RRL_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int rrl_line_tri_scan(const float *line, void *ws, size_t ws_bytes, int B, int N, int M,
+                                 int L, int mode, int chunk, void *stream) {
+    return rrl_line_tri_scan_clouds(line, ws, ws_bytes, B, N, M, L, mode, chunk, 2, stream);
 }

@@ -486,29 +486,60 @@ extern "C" int rrl_workspace_layout(int B, int N, int M, int L, size_t *offsets)
     return 0;
 }
 
-extern "C" int rrl_loss_forward(const float *tri1, const float *tri2, const float *line, void *ws,
-                                size_t ws_bytes, float *loss, int B, int N, int M, int L, int s_m,
-                                int s_n, int e_m, int e_n, int pool, int mode, int chunk,
-                                void *stream) {
+int rrl_tri_prepare_clouds(const float *tri1, const float *tri2, void *ws, size_t ws_bytes, int B,
+                           int N, int M, int L, int clouds, void *stream);
+int rrl_line_tri_scan_clouds(const float *line, void *ws, size_t ws_bytes, int B, int N, int M, int L,
+                             int mode, int chunk, int clouds, void *stream);
+
+// target_ws != NULL: a workspace of the same (B, N, M, L) that already went through a forward with
+// the SAME tri2 and line (RPM / FMR evaluate several source poses against one target and one
+// line set, rpm/Train_RPM.py:204-231): the target's hit counts and hit lists are copied from it
+// and only the source cloud is prepared, sorted and scanned.
+extern "C" int rrl_loss_forward_cached(const float *tri1, const float *tri2, const float *line,
+                                       void *ws, size_t ws_bytes, float *loss, int B, int N, int M,
+                                       int L, int s_m, int s_n, int e_m, int e_n, int pool, int mode,
+                                       int chunk, const void *target_ws, void *stream) {
     if (!tri1 || !tri2 || !line || !ws || !loss) return RRL_E_ARG;
     if (s_m < 1 || s_n < 1 || e_m > RRL_MAX_HITS + 1 || e_n > RRL_MAX_HITS + 1) return RRL_E_RANGE;
+    if (target_ws == ws) return RRL_E_ARG;
+    const int clouds = target_ws ? 1 : 2;
     int rc;
-    if ((rc = rrl_tri_prepare(tri1, tri2, ws, ws_bytes, B, N, M, L, stream))) return rc;
-    if ((rc = rrl_line_tri_scan(line, ws, ws_bytes, B, N, M, L, mode, chunk, stream))) return rc;
+    if ((rc = rrl_tri_prepare_clouds(tri1, tri2, ws, ws_bytes, B, N, M, L, clouds, stream))) return rc;
+    if (target_ws && (size_t)B * L) {  // after the prepare step, which cleared COUNT2
+        WsLayout w(B, N, M, L);
+        hipStream_t s = (hipStream_t)stream;
+        hipError_t e = hipMemcpyAsync(w.i32(ws, RRL_WS_COUNT2), (const char *)target_ws + w.off[RRL_WS_COUNT2],
+                                      sizeof(int32_t) * (size_t)B * L, hipMemcpyDeviceToDevice, s);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(w.i32(ws, RRL_WS_HIT2), (const char *)target_ws + w.off[RRL_WS_HIT2],
+                               sizeof(int32_t) * RRL_MAX_HITS * (size_t)B * L, hipMemcpyDeviceToDevice, s);
+        if (e != hipSuccess) return (int)e;
+    }
+    if ((rc = rrl_line_tri_scan_clouds(line, ws, ws_bytes, B, N, M, L, mode, chunk, clouds, stream)))
+        return rc;
     if ((rc = rrl_line_pair_dist(tri1, tri2, line, ws, ws_bytes, B, N, M, L, s_m, s_n, e_m, e_n,
                                  pool, stream)))
         return rc;
     return rrl_loss_reduce(ws, ws_bytes, loss, B, N, M, L, s_m, s_n, e_m, e_n, pool, stream);
 }
 
+extern "C" int rrl_loss_forward(const float *tri1, const float *tri2, const float *line, void *ws,
+                                size_t ws_bytes, float *loss, int B, int N, int M, int L, int s_m,
+                                int s_n, int e_m, int e_n, int pool, int mode, int chunk,
+                                void *stream) {
+    return rrl_loss_forward_cached(tri1, tri2, line, ws, ws_bytes, loss, B, N, M, L, s_m, s_n, e_m,
+                                   e_n, pool, mode, chunk, nullptr, stream);
+}
+
 // ---------------------------------------------------------------------------------------
 // fused training op: rigid transform of the source + loss, and its backward to (dR, dt)
 // ---------------------------------------------------------------------------------------
-extern "C" int rrl_registration_forward(const float *src, const float *R, const float *t,
-                                        const float *tri2, const float *line, void *ws,
-                                        size_t ws_bytes, float *loss, int B, int N, int M, int L,
-                                        int transpose_r, int s_m, int s_n, int e_m, int e_n, int mode,
-                                        int chunk, void *stream) {
+extern "C" int rrl_registration_forward_cached(const float *src, const float *R, const float *t,
+                                               const float *tri2, const float *line, void *ws,
+                                               size_t ws_bytes, float *loss, int B, int N, int M,
+                                               int L, int transpose_r, int s_m, int s_n, int e_m,
+                                               int e_n, int mode, int chunk, const void *target_ws,
+                                               void *stream) {
     if (!src || !R || !t || !tri2 || !line || !ws || !loss) return RRL_E_ARG;
     if (B < 0 || N < 0 || M < 0 || L < 0) return RRL_E_ARG;
     WsLayout w(B, N, M, L);
@@ -516,8 +547,18 @@ extern "C" int rrl_registration_forward(const float *src, const float *R, const 
     float *tri1 = w.f32(ws, RRL_WS_TRI1);
     int rc = rrl_rigid_apply_fwd(src, R, t, tri1, B, 3 * N, transpose_r, 0, stream);
     if (rc) return rc;
-    return rrl_loss_forward(tri1, tri2, line, ws, ws_bytes, loss, B, N, M, L, s_m, s_n, e_m, e_n, 0,
-                            mode, chunk, stream);
+    return rrl_loss_forward_cached(tri1, tri2, line, ws, ws_bytes, loss, B, N, M, L, s_m, s_n, e_m,
+                                   e_n, 0, mode, chunk, target_ws, stream);
+}
+
+extern "C" int rrl_registration_forward(const float *src, const float *R, const float *t,
+                                        const float *tri2, const float *line, void *ws,
+                                        size_t ws_bytes, float *loss, int B, int N, int M, int L,
+                                        int transpose_r, int s_m, int s_n, int e_m, int e_n, int mode,
+                                        int chunk, void *stream) {
+    return rrl_registration_forward_cached(src, R, t, tri2, line, ws, ws_bytes, loss, B, N, M, L,
+                                           transpose_r, s_m, s_n, e_m, e_n, mode, chunk, nullptr,
+                                           stream);
 }
 
 extern "C" int rrl_registration_backward(const float *src, const float *R, const float *tri2,

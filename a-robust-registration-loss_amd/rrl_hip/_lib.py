@@ -21,6 +21,8 @@ _SIGS = {
     "rrl_loss_forward": [_P, _P, _P, _P, _Z, _P] + [_I] * 11 + [_P],
     "rrl_loss_backward": [_P, _P, _P, _Z, _P, _P, _P] + [_I] * 5 + [_P],
     "rrl_registration_forward": [_P] * 6 + [_Z, _P] + [_I] * 11 + [_P],
+    "rrl_registration_forward_cached": [_P] * 6 + [_Z, _P] + [_I] * 11 + [_P, _P],
+    "rrl_loss_forward_cached": [_P, _P, _P, _P, _Z, _P] + [_I] * 11 + [_P, _P],
     "rrl_registration_backward": [_P] * 4 + [_Z] + [_P] * 6 + [_I] * 5 + [_P],
     "rrl_tri_prepare": [_P, _P, _P, _Z, _I, _I, _I, _I, _P],
     "rrl_line_tri_scan": [_P, _P, _Z] + [_I] * 6 + [_P],

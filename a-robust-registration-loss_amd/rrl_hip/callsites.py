@@ -40,12 +40,15 @@ def draw_lines(radius, centers, n_lines, moved_src, tar, device=None):
         radius, centers, n_lines, moved_src, tar, device)
 
 
-def per_sample_loss(src_nb, R, t, tar_tri, lines, mode=None):
+def per_sample_loss(src_nb, R, t, tar_tri, lines, mode=None, target_from=None):
     """loss[b] of the pseudo-triangles `src_nb` (B, 3N, 3) or (B, N, 9) moved by x -> R x + t,
-    against tar_tri (B, M, 9) along lines (B, L, 6).  (loss (B,), valid (B,) bool)."""
+    against tar_tri (B, M, 9) along lines (B, L, 6).  (loss (B,), valid (B,) bool).
+    target_from: ops.last_state() of an earlier call with the same tar_tri and lines, whose
+    target scan is reused (the iterative trainers keep target and lines fixed across poses)."""
     B = src_nb.shape[0]
     loss, info, _ = _ops.registration_loss(src_nb.reshape(B, -1, 9), R, t, tar_tri.reshape(B, -1, 9),
-                                           lines, RNG, transpose_r=True, mode=_mode(mode))
+                                           lines, RNG, transpose_r=True, mode=_mode(mode),
+                                           target_from=target_from)
     return loss, info[:, 0] > 0
 
 
@@ -66,13 +69,15 @@ def rpm_intersection_loss(pred_transforms, data, n_lines=10000, lines=None, mode
     tar_tri = data['points_based_neighs_tar'].reshape(B, -1, 9)
     src = data['points_src_sample'][..., :3]
     per_iter, chamfers, valid = [], [], []
+    first = None  # LossState of iteration 0: target + lines are the same in every iteration
     for ni in range(num_iter):
         R, t = _split(pred_transforms[ni])
         moved = _ops.rigid_apply(src, R, t, transpose_r=True)
         if lines is None:
             lines = draw_lines(bounding_radius(data['tar_box']), data['centers'], n_lines,
                                moved.detach(), tar)
-        loss, ok = per_sample_loss(data['points_based_neighs_src'], R, t, tar_tri, lines, mode)
+        loss, ok = per_sample_loss(data['points_based_neighs_src'], R, t, tar_tri, lines, mode, first)
+        first = first or _ops.last_state()
         per_iter.append(loss.sum().reshape(1) / num_iter)
         chamfers.append(_ops.chamfer(tar, moved).detach())
         valid.append(ok)
@@ -116,10 +121,11 @@ def fmr_intersection_loss(g_series, data, n_lines=15000, lines=None, last=3, mod
     if lines is None:
         lines = draw_lines(bounding_radius(data['tar_box'], 0.5), data['centers'], n_lines,
                            moved.detach(), tar)
-    total, valid = 0.0, []
+    total, valid, first = 0.0, [], None
     for i in range(maxiter - last, maxiter):
         R, t = _split(g_series[i])
-        loss, ok = per_sample_loss(data['points_based_neighs_src'], R, t, tar_tri, lines, mode)
+        loss, ok = per_sample_loss(data['points_based_neighs_src'], R, t, tar_tri, lines, mode, first)
+        first = first or _ops.last_state()
         total = total + (loss / 5.0).sum().reshape(1) * 0.5 ** (maxiter - i - 1)
         valid.append(ok)
     return total / B, _ops.chamfer(moved, tar), lines, torch.stack(valid)

@@ -130,10 +130,21 @@ def _check_range(rng):
     return s_m, s_n, e_m, e_n
 
 
+def _target_ws(target_from, B, N, M, L):
+    """Workspace pointer of an earlier evaluation whose target scan is carried over."""
+    if target_from is None:
+        return None
+    if tuple(target_from.dims[:4]) != (B, N, M, L):
+        raise ValueError(f"target_from was evaluated at {tuple(target_from.dims[:4])}, not {(B, N, M, L)}")
+    return _p(target_from.ws)
+
+
 def loss_forward_raw(tri1, tri2, line, rng=(1, 1, 5, 5), pool=False, mode="cull", chunk=0,
-                     staged=False):
+                     staged=False, target_from=None):
     """Forward on already-prepared GPU tensors; returns the LossState.  staged=True issues the
-    four stages through their individual C entry points instead of the fused one."""
+    four stages through their individual C entry points instead of the fused one.
+    target_from: LossState of an earlier call with the SAME tri2 and line -- its target scan is
+    reused (rrl_loss_forward_cached)."""
     lib = _lib.load()
     B, N, _ = tri1.shape
     M, L = tri2.shape[1], line.shape[1]
@@ -142,8 +153,9 @@ def loss_forward_raw(tri1, tri2, line, rng=(1, 1, 5, 5), pool=False, mode="cull"
     st = LossState(B, N, M, L, G, tri1.device)
     s, ws, nb = _stream(), _p(st.ws), st.nbytes
     if not staged:
-        check(lib.rrl_loss_forward(_p(tri1), _p(tri2), _p(line), ws, nb, _p(st.loss), B, N, M, L,
-                                   s_m, s_n, e_m, e_n, int(pool), _MODES[mode], int(chunk), s),
+        check(lib.rrl_loss_forward_cached(_p(tri1), _p(tri2), _p(line), ws, nb, _p(st.loss), B, N, M,
+                                          L, s_m, s_n, e_m, e_n, int(pool), _MODES[mode], int(chunk),
+                                          _target_ws(target_from, B, N, M, L), s),
               "rrl_loss_forward")
         return st
     check(lib.rrl_tri_prepare(_p(tri1), _p(tri2), ws, nb, B, N, M, L, s), "rrl_tri_prepare")
@@ -158,14 +170,14 @@ def loss_forward_raw(tri1, tri2, line, rng=(1, 1, 5, 5), pool=False, mode="cull"
 
 class _IntersectionLoss(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, points1, points2, line, rng, pool, mode, chunk):
+    def forward(ctx, points1, points2, line, rng, pool, mode, chunk, target_from=None):
         tri1, tri2 = _prep(points1, "points1", 9), _prep(points2, "points2", 9)
         ln = _prep(line, "line", 6)
         if tri1.dim() != 3 or tri2.dim() != 3 or ln.dim() != 3:
             raise ValueError("Input is wrong: points1/points2/line must be 3-D (B, n, c)")
         if not (tri1.shape[0] == tri2.shape[0] == ln.shape[0]):
             raise ValueError("points1, points2 and line must share the batch dimension")
-        st = loss_forward_raw(tri1, tri2, ln, rng, pool, mode, chunk)
+        st = loss_forward_raw(tri1, tri2, ln, rng, pool, mode, chunk, target_from=target_from)
         ctx.st, ctx.tri1, ctx.tri2, ctx.pool = st, tri1, tri2, bool(pool)
         ctx.in_devs = (points1.device, points2.device)
         info, status = st.info, st.status
@@ -179,7 +191,7 @@ class _IntersectionLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_loss, _g1, _g2):
         if g_loss is None:
-            return (None,) * 7
+            return (None,) * 8
         lib = _lib.load()
         st, tri1, tri2 = ctx.st, ctx.tri1, ctx.tri2
         B, N, _ = tri1.shape
@@ -192,15 +204,16 @@ class _IntersectionLoss(torch.autograd.Function):
         g1 = g1.to(ctx.in_devs[0]) if ctx.needs_input_grad[0] else None
         if g2 is not None:
             g2 = g2.to(ctx.in_devs[1])
-        return g1, g2, None, None, None, None, None
+        return g1, g2, None, None, None, None, None, None
 
 
-def intersection_loss(points1, points2, line, rng=(1, 1, 5, 5), pool=False, mode="cull", chunk=0):
+def intersection_loss(points1, points2, line, rng=(1, 1, 5, 5), pool=False, mode="cull", chunk=0,
+                      target_from=None):
     """Batched loss: returns (loss[G], info[G,4] = (nbuckets, nselected, nvalues, 0), status[4])
     on the GPU, G = 1 if pool else B.  Each sample is an independent loss (what every reference
     caller obtains by looping B=1 calls); pool=True reproduces the reference's own B>1 behaviour
     (SURVEY Q2).  No host synchronisation happens here."""
-    return _IntersectionLoss.apply(points1, points2, line, tuple(rng), pool, mode, chunk)
+    return _IntersectionLoss.apply(points1, points2, line, tuple(rng), pool, mode, chunk, target_from)
 
 
 def shard_payload(loss, gR=None, gt=None, state=None):
@@ -222,7 +235,8 @@ class _RegistrationLoss(torch.autograd.Function):
     each way; the transformed triangles and their gradient live in the workspace)."""
 
     @staticmethod
-    def forward(ctx, src_tri, R, t, tar_tri, line, rng, transpose_r, mode, chunk, want_payload):
+    def forward(ctx, src_tri, R, t, tar_tri, line, rng, transpose_r, mode, chunk, want_payload,
+                target_from=None):
         src = _prep(src_tri, "src_tri", 9)
         tri2, ln = _prep(tar_tri, "tar_tri", 9), _prep(line, "line", 6)
         Rm, tv = _prep(R, "R").reshape(-1, 3, 3), _prep(t, "t").reshape(-1, 3)
@@ -234,10 +248,10 @@ class _RegistrationLoss(torch.autograd.Function):
             raise ValueError("batch dimensions differ")
         s_m, s_n, e_m, e_n = _check_range(rng)
         st = LossState(B, N, M, L, B, src.device)
-        check(_lib.load().rrl_registration_forward(
+        check(_lib.load().rrl_registration_forward_cached(
             _p(src), _p(Rm), _p(tv), _p(tri2), _p(ln), _p(st.ws), st.nbytes, _p(st.loss), B, N, M, L,
-            int(transpose_r), s_m, s_n, e_m, e_n, _MODES[mode], int(chunk), _stream()),
-            "rrl_registration_forward")
+            int(transpose_r), s_m, s_n, e_m, e_n, _MODES[mode], int(chunk),
+            _target_ws(target_from, B, N, M, L), _stream()), "rrl_registration_forward")
         ctx.st, ctx.src, ctx.Rm, ctx.tri2 = st, src, Rm, tri2
         ctx.meta = (int(transpose_r), bool(want_payload), R.shape, t.shape, src_tri.device)
         info, status = st.info, st.status
@@ -249,7 +263,7 @@ class _RegistrationLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_loss, _g1, _g2):
         if g_loss is None:
-            return (None,) * 10
+            return (None,) * 11
         st, src, Rm, tri2 = ctx.st, ctx.src, ctx.Rm, ctx.tri2
         tr, want_payload, Rshape, tshape, sdev = ctx.meta
         B, N, M, L, _ = st.dims
@@ -264,19 +278,21 @@ class _RegistrationLoss(torch.autograd.Function):
             "rrl_registration_backward")
         st.payload = payload if want_payload else None
         return (gsrc.to(sdev) if gsrc is not None else None, gR.reshape(Rshape), gt.reshape(tshape),
-                None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None)
 
 
 def registration_loss(src_tri, R, t, tar_tri, line, rng=(1, 1, 5, 5), transpose_r=True,
-                      mode="cull", chunk=0, want_payload=False):
+                      mode="cull", chunk=0, want_payload=False, target_from=None):
     """loss[b] of `src_tri[b]` moved by (R[b], t[b]) against `tar_tri[b]` along `line[b]` -- the
     rigid transform of the training call sites fused with the loss.  transpose_r=True is
     x R^T + t (R x + t per point: RPM / DCP / FMR), False is x R + t (Reconstruction_point).
     Returns (loss (B,), info (B,4), status (4,)); differentiable in R, t and src_tri.
     want_payload=True also builds the 14-float batch-shard payload during backward
-    (LossState.payload of the call, see rrl_hip.dist)."""
+    (LossState.payload of the call, see rrl_hip.dist).
+    target_from: LossState (ops.last_state()) of an earlier call with the SAME tar_tri and line:
+    the target cloud is not scanned again (RPM / FMR: several poses, one target, one line set)."""
     return _RegistrationLoss.apply(src_tri, R, t, tar_tri, line, tuple(rng), transpose_r, mode,
-                                   chunk, want_payload)
+                                   chunk, want_payload, target_from)
 
 
 def last_state():

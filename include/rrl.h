@@ -131,6 +131,21 @@ int rrl_registration_forward(const float *src, const float *R, const float *t, c
                              const float *line, void *ws, size_t ws_bytes, float *loss, int B,
                              int N, int M, int L, int transpose_r, int s_m, int s_n, int e_m,
                              int e_n, int mode, int chunk, void *stream);
+/* The same two forwards with the TARGET's scan carried over: target_ws is a workspace of equal
+ * (B, N, M, L) that already ran a forward with the same tri2 and line (RPM and FMR evaluate
+ * num_iter source poses against one target and one line set, rpm/Train_RPM.py:204-231,
+ * fmr/model.py:295-310).  Only the source cloud is prepared/sorted/scanned; the target's hit
+ * counts and lists are copied (20 bytes per line).  target_ws == NULL: identical to the plain
+ * call.  The result is bit-identical to the plain call either way. */
+int rrl_loss_forward_cached(const float *tri1, const float *tri2, const float *line, void *ws,
+                            size_t ws_bytes, float *loss, int B, int N, int M, int L, int s_m,
+                            int s_n, int e_m, int e_n, int pool, int mode, int chunk,
+                            const void *target_ws, void *stream);
+int rrl_registration_forward_cached(const float *src, const float *R, const float *t,
+                                    const float *tri2, const float *line, void *ws, size_t ws_bytes,
+                                    float *loss, int B, int N, int M, int L, int transpose_r,
+                                    int s_m, int s_n, int e_m, int e_n, int mode, int chunk,
+                                    const void *target_ws, void *stream);
 int rrl_registration_backward(const float *src, const float *R, const float *tri2, void *ws,
                               size_t ws_bytes, const float *loss, const float *grad_loss,
                               float *grad_src, float *gR, float *gt, float *payload, int B, int N,

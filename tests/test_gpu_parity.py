@@ -307,6 +307,48 @@ def test_full_size_sample_vs_oracle(L, oracle):
     assert float(bt.loss[1]) != float(st.loss[0])
 
 
+@pytest.mark.parametrize("mode", ["cull", "strict", "auto"])
+@pytest.mark.parametrize("n,m", [(300, 200), (200, 300), (16390, 500)])
+def test_target_scan_reuse_is_bit_identical(L, mode, n, m):
+    """rrl_*_forward_cached: a second source pose against the same target and lines, with the
+    target's counts/hits carried over from the first call, equals the full evaluation bit for bit
+    (loss, every workspace field the later stages read, and the gradient)."""
+    from rrl_hip import ops, synth
+    B, nl = 2, 1500
+    prs = [synth.make_pair(60 + b, n, m) for b in range(B)]
+    src = cu(np.stack([p["src_tri"] for p in prs]))
+    tar = cu(np.stack([p["tar_tri"] for p in prs]))
+    g = load_golden("sampler.npz")
+    lines = cu(np.stack([np.resize(g["final"], (nl, 6))] * B))
+    first = ops.loss_forward_raw(src, tar, lines, mode=mode)
+    moved = src + 0.01
+    full = ops.loss_forward_raw(moved, tar, lines, mode=mode)
+    cached = ops.loss_forward_raw(moved, tar, lines, mode=mode, target_from=first)
+    torch.cuda.synchronize()
+    assert float(full.info[:, 1].sum()) > 0
+    for f in ("loss", "count1", "count2", "med", "info", "status"):
+        assert torch.equal(getattr(full, f), getattr(cached, f)), f
+    c2 = full.count2.cpu().numpy()[..., None]  # slots >= count are scratch; > 4 hits: any 4 are kept
+    live = (np.arange(4)[None, None, :] < c2) & (c2 <= 4)
+    hf = np.where(live, full.hit2.cpu().numpy().reshape(live.shape), 1 << 30)
+    hc = np.where(live, cached.hit2.cpu().numpy().reshape(live.shape), 1 << 30)
+    np.testing.assert_array_equal(np.sort(hf, -1), np.sort(hc, -1))
+    # through autograd, fused with the rigid transform
+    R = torch.eye(3, device="cuda").repeat(B, 1, 1).requires_grad_(True)
+    t = torch.full((B, 3), 0.01, device="cuda").requires_grad_(True)
+    outs = []
+    for tf in (None, first):
+        R.grad = t.grad = None
+        loss, _, _ = ops.registration_loss(src, R, t, tar, lines, mode=mode, target_from=tf)
+        loss.sum().backward()
+        outs.append((loss.detach().clone(), R.grad.clone(), t.grad.clone()))
+    assert torch.equal(outs[0][0], outs[1][0])
+    for a, b in zip(outs[0][1:], outs[1][1:]):  # float atomics in the backward: order-dependent bits
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6 * float(a.abs().max()))
+    with pytest.raises(ValueError):
+        ops.loss_forward_raw(moved[:, :-1], tar, lines, mode=mode, target_from=first)
+
+
 # BASELINE.json configs[0], [3], [4] (the bench runs configs[1]; [2] is its 8-GPU shard), plus a
 # cloud one past the 16384-triangle limit of the sorted/culled layout (falls back to the dense scan)
 @pytest.mark.parametrize("n,m,nl,crop,noise", [
