@@ -325,6 +325,55 @@ extern "C" int rrl_aabb(const float *v, float *aabb, int B, int n, void *stream)
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------
+// Dense form of the scan: the full (line, triangle) tables that the reference's
+// cal_intersection_batch2_points_with_line returns (code/loss.py:68-112).  The loss never
+// materialises them (rrl_scan/rrl_cull keep <= 4 hits per line); this entry point exists for
+// callers of that public function and for diagnostics.  Lane = triangle, line = blockIdx.y.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dense_scan_kernel(const float *__restrict__ tri,
+                                                         const float *__restrict__ line,
+                                                         float *__restrict__ norm_d,
+                                                         uint8_t *__restrict__ label,
+                                                         int32_t *__restrict__ status, int N, int L) {
+    const int b = blockIdx.z, l = blockIdx.y, f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= N) return;
+    const float *ln = line + 6 * ((size_t)b * L + l);
+    const float *p = tri + 9 * ((size_t)b * N + f);
+    float c[9], thr, thr2, d[3];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) c[i] = p[i];
+    tri_thresholds(c, &thr, &thr2);
+    bool hit = true, bad = false;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        d[k] = sqrtf(dist_sq<float>(c[3 * k], c[3 * k + 1], c[3 * k + 2], ln[0], ln[1], ln[2], ln[3],
+                                    ln[4], ln[5]));
+        hit = hit && (d[k] < thr);
+        bad = bad || (d[k] != d[k]);
+    }
+    const float sum = (d[0] + d[1]) + d[2];
+    float *o = norm_d + 3 * (((size_t)b * L + l) * N + f);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) o[k] = d[k] / sum;
+    label[((size_t)b * L + l) * N + f] = hit ? 1 : 0;
+    if (bad) atomicOr(&status[0], 1);
+}
+
+extern "C" int rrl_dense_scan(const float *tri, const float *line, float *norm_d, uint8_t *label,
+                              int32_t *status, int B, int N, int L, void *stream) {
+    if (!tri || !line || !norm_d || !label || !status || B < 0 || N < 0 || L < 0) return RRL_E_ARG;
+    if (L > 65535 || B > 65535) return RRL_E_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(status, 0, sizeof(int32_t), s);
+    if (e != hipSuccess) return (int)e;
+    if (B == 0 || N == 0 || L == 0) return 0;
+    hipLaunchKernelGGL(dense_scan_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)L, (unsigned)B),
+                       dim3(256), 0, s, tri, line, norm_d, label, status, N, L);
+    RRL_LAUNCH_CHECK();
+    return 0;
+}
+
 __device__ __forceinline__ void cross3(const float *a, const float *b, float *o) {
     o[0] = a[1] * b[2] - a[2] * b[1];
     o[1] = a[2] * b[0] - a[0] * b[2];

@@ -42,6 +42,26 @@ def compute_sqrdis_map_2(points_x, points_y):
     return ((points_x.unsqueeze(2) - points_y.unsqueeze(1)) ** 2).sum(-1)
 
 
+def cal_intersection_batch2_points_with_line(point_neis, line):
+    """The dense scan of one cloud (code/loss.py:68-112): returns
+    (points (B*L, N, 9) -- a stride-0 expanded view of point_neis that keeps its grad --,
+     norm_d (B*L, N, 3) = d_k / sum_k d_k, detached,  label (B, L, N) bool = all d_k < thr).
+    The loss itself never builds these tables (it keeps <= 4 hits per line); this is the public
+    function for callers that want them.  Raises ValueError where the reference prints and
+    exits (bad rank, NaN distance)."""
+    if point_neis.dim() != 3 or line.dim() != 3:
+        raise ValueError("Input is wrong")  # code/loss.py:69-71
+    B, nf, c = point_neis.shape
+    nl = line.shape[1]
+    if c != 9:
+        raise ValueError("point_neis must hold 3 neighbours per row: (B, N, 9)")
+    norm_d, label, status = _ops.dense_scan(point_neis, line)
+    if int(status[0]):
+        raise ValueError("NaN point-to-line distance (reference: 'Exit the systerm', code/loss.py:88-91)")
+    points = point_neis.unsqueeze(1).expand(-1, nl, -1, -1).reshape(-1, nf, 9)  # B = 1: still a view
+    return points, norm_d.to(point_neis.device), label.to(point_neis.device)
+
+
 def cal_loss_intersection_batch_whole_median_pts_lines(s_m, s_n, e_m, e_n, points1, points2, line,
                                                        device='cpu', *, mode=None, chunk=0):
     """The intersected-line robust registration loss (code/loss.py:170-232).

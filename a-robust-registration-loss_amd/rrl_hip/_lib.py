@@ -38,6 +38,7 @@ _SIGS = {
     "rrl_chamfer_fwd": [_P] * 5 + [_I] * 3 + [_P],
     "rrl_chamfer_bwd": [_P] * 7 + [_I] * 3 + [_P],
     "rrl_aabb": [_P, _P, _I, _I, _P],
+    "rrl_dense_scan": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
     "rrl_fps": [_P, _P, _P, _P, _I, _I, _I, _P],
     "rrl_knn3": [_P, _P, _P, _I, _I, _I, _P],
     "rrl_sample_lines": [_P] * 7 + [_I] * 3 + [_P],

@@ -392,6 +392,20 @@ def chamfer(x, y):
 
 
 # ---------------------------------------------------------------------------------------
+def dense_scan(tri, line):
+    """(norm_d (B*L, N, 3) float32, label (B, L, N) bool, status (1,) int32) -- the dense tables of
+    code/loss.py:68-112 (rrl_dense_scan); B*L*N*13 bytes of output, so mind the sizes."""
+    t, ln = _prep(tri, "point_neis", 9), _prep(line, "line", 6)
+    B, N, _ = t.shape
+    L = ln.shape[1]
+    norm_d = torch.empty(B * L, N, 3, dtype=torch.float32, device=t.device)
+    label = torch.empty(B, L, N, dtype=torch.uint8, device=t.device)
+    status = torch.empty(1, dtype=torch.int32, device=t.device)
+    check(_lib.load().rrl_dense_scan(_p(t), _p(ln), _p(norm_d), _p(label), _p(status), B, N, L,
+                                     _stream()), "rrl_dense_scan")
+    return norm_d, label.view(torch.bool), status
+
+
 def aabb(v):
     """(B, n, 3) -> (B, 6) = min xyz, max xyz on the GPU."""
     vs = _prep(v, "vertices", 3)

@@ -223,6 +223,14 @@ int rrl_chamfer_bwd(const float *x, const float *y, const uint64_t *best_x,
                     const uint64_t *best_y, const float *grad_value, float *gx, float *gy, int B,
                     int N, int M, void *stream);
 
+/* ---- dense (line x triangle) tables of code/loss.py:68-112 ------------------------------- */
+/* What cal_intersection_batch2_points_with_line returns besides the expanded view of its input:
+ * norm_d [B*L][N][3] = d_k / ((d_0 + d_1) + d_2), label [B][L][N] (0/1 bytes), status[0] |= 1 on
+ * a NaN distance.  The loss path never materialises these; provided for callers of that public
+ * function.  L, B <= 65535. */
+int rrl_dense_scan(const float *tri, const float *line, float *norm_d, uint8_t *label,
+                   int32_t *status, int B, int N, int L, void *stream);
+
 /* ---- line sampler (code/loss.py:265-432) ------------------------------------------------- */
 /* rrl_aabb: per-sample min/max -> aabb [B][6] = min xyz, max xyz (loss.py:325-351).
  * rrl_sample_lines: all `rounds` rejection rounds in one launch.

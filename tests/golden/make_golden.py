@@ -406,7 +406,72 @@ def demo_trajectory():
          lr=np.array(lrs, np.float64))
 
 
+def dataset():
+    """Dataset_2021_8_29.__getitem__ / random_data (exps_deep_learning/pre_dataloader.py:28-181)
+    on two small synthetic pairs written to a temp directory.  `igl` and `h5py` are absent: h5py
+    is unused by the class; the two igl calls are served by a vertex-line OBJ parser and by the
+    reference's own generate_bbox (same corner order as igl.bounding_box)."""
+    import tempfile
+    igl = sys.modules["igl"]
+
+    def read_triangle_mesh(path):
+        V = np.array([[float(x) for x in ln.split()[1:4]] for ln in open(path) if ln.startswith("v ")])
+        return V.reshape(-1, 3), np.zeros((0, 3), np.int64)
+
+    def bounding_box(V):
+        return RL.generate_bbox(torch.from_numpy(V)[None])[0].numpy(), None
+
+    igl.read_triangle_mesh, igl.bounding_box = read_triangle_mesh, bounding_box
+    sys.modules.setdefault("h5py", types.ModuleType("h5py"))
+    sys.path.insert(0, os.path.join(REF, "exps_deep_learning"))
+    import pre_dataloader as RD  # the reference
+    sys.path.insert(0, os.path.join(ROOT, "a-robust-registration-loss_amd"))
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "rrl_pre_dataloader", os.path.join(ROOT, "a-robust-registration-loss_amd", "pre_dataloader.py"))
+    mine = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mine)  # only its file WRITER is used here
+
+    rng = np.random.default_rng(12)
+    out = {}
+    with tempfile.TemporaryDirectory(prefix="rrl_ds_") as d:
+        srcs, tars = [], []
+        for i, (n, m) in enumerate(((60, 48), (40, 56))):
+            pr = synth.make_pair(70 + i, n, m)
+            off_s, off_t = rng.standard_normal(3), rng.standard_normal(3)  # un-centred on disk
+            A = synth._rotation(rng.standard_normal(3), 25.0)
+            gt = np.concatenate([A, rng.standard_normal((3, 1))], 1)
+            nrm_s = rng.standard_normal((n, 3)).astype(np.float32)
+            nrm_t = rng.standard_normal((m, 3)).astype(np.float32)
+            inp = dict(src=(pr["src"] + off_s).astype(np.float32), tar=(pr["tar"] + off_t).astype(np.float32),
+                       src_neigh=(pr["src_tri"].reshape(-1, 3) + off_s).astype(np.float32),
+                       tar_neigh=(pr["tar_tri"].reshape(-1, 3) + off_t).astype(np.float32),
+                       transform=gt, normals_src=nrm_s, normals_tar=nrm_t)
+            a, b = mine.write_pair(d, i, 0, **inp)
+            srcs.append(a)
+            tars.append(b)
+            for k, v in inp.items():
+                out[f"in{i}_{k}"] = v
+        for tag, kw in (("plain", {}), ("dcp", dict(DCP_True=True)), ("fmr", dict(FMR_True=True))):
+            ds = RD.Dataset_2021_8_29(srcs, tars, **kw)
+            assert len(ds) == 2
+            for i in range(2):
+                for k, v in ds[i].items():
+                    out[f"{tag}{i}_{k}"] = np.ascontiguousarray(v)
+        # augmentation: needs the keys the method reads ('normals_ref') -- add as the trainers' dicts would
+        ds = RD.Dataset_2021_8_29(srcs, tars)
+        item = ds[0]
+        item["normals_ref"] = item["normals_tar"]
+        np.random.seed(33)
+        aug = ds.random_data(item)
+        for k, v in aug.items():
+            out[f"aug0_{k}"] = np.ascontiguousarray(v)
+    ax, th = np.array([0.3, -0.2, 0.9]), np.array([0.7])
+    out["M_axis"], out["M_theta"], out["M_out"] = ax, th, RD.M(ax, th)
+    save("dataset.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["main", "neighs", "callsites", "demo_trajectory"]
+    which = sys.argv[1:] or ["main", "neighs", "callsites", "demo_trajectory", "dataset"]
     for name in which:
         globals()[name]()

@@ -1,0 +1,89 @@
+"""Dataset I/O shim against the reference's Dataset_2021_8_29 outputs
+(tests/golden/make_golden.py: dataset).  Host-side numpy: runs without a GPU."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+KEYS = ("points_tar_sample", "points_src_sample", "normals_tar", "normals_src", "tar_box", "centers",
+        "R", "T", "R_inv", "T_inv", "points_based_neighs_src", "points_based_neighs_tar", "igt")
+
+
+@pytest.fixture(scope="module")
+def P():
+    import pre_dataloader
+    return pre_dataloader
+
+
+@pytest.fixture()
+def files(P, tmp_path):
+    g = load_golden("dataset.npz")
+    d = tmp_path / "pairs"
+    srcs, tars = [], []
+    for i in range(2):
+        inp = {k: g[f"in{i}_{k}"] for k in ("src", "tar", "src_neigh", "tar_neigh", "transform",
+                                             "normals_src", "normals_tar")}
+        a, b = P.write_pair(str(d), i, 0, **inp)
+        srcs.append(a)
+        tars.append(b)
+    return g, srcs, tars
+
+
+@pytest.mark.parametrize("tag,kw", [("plain", {}), ("dcp", {"DCP_True": True}), ("fmr", {"FMR_True": True})])
+def test_items_match_the_reference(P, files, tag, kw):
+    g, srcs, tars = files
+    ds = P.Dataset_2021_8_29(srcs, tars, **kw)
+    assert len(ds) == 2
+    for i in range(2):
+        item = ds[i]
+        assert set(item) == set(KEYS)
+        for k in KEYS:
+            want = g[f"{tag}{i}_{k}"]
+            assert item[k].shape == want.shape and item[k].dtype == want.dtype, (k, item[k].shape, want.shape)
+            np.testing.assert_array_equal(item[k], want, err_msg=k)
+
+
+def test_ground_truth_convention(P, files):
+    """tar_centred ~ src_centred @ R + T holds for a pair written with tar = src @ A + b."""
+    g, srcs, tars = files
+    rng = np.random.default_rng(0)
+    src = rng.standard_normal((50, 3)).astype(np.float32)
+    A, b = g["in0_transform"][:, :3], g["in0_transform"][:, 3]
+    tar = (src.astype(np.float64) @ A + b).astype(np.float32)
+    import os
+    a, t = P.write_pair(os.path.dirname(srcs[0]), 9, 0, src, tar, np.repeat(src, 3, 0),
+                        np.repeat(tar, 3, 0), g["in0_transform"])
+    item = P.Dataset_2021_8_29([a], [t])[0]
+    np.testing.assert_allclose(item["points_src_sample"] @ item["R"] + item["T"], item["points_tar_sample"], atol=2e-5)
+    moved = item["points_tar_sample"] @ item["igt"][:3, :3].T + item["igt"][:3, 3]  # igt = [[A, -A T]]
+    assert moved.shape == item["points_tar_sample"].shape
+
+
+def test_random_data_matches_the_reference(P, files):
+    g, srcs, tars = files
+    ds = P.Dataset_2021_8_29(srcs, tars)
+    item = ds[0]
+    item["normals_ref"] = item["normals_tar"]
+    np.random.seed(33)
+    aug = ds.random_data(item)
+    for k in aug:
+        np.testing.assert_allclose(aug[k], g[f"aug0_{k}"], rtol=1e-5, atol=1e-6, err_msg=k)
+    np.testing.assert_allclose(P.M(g["M_axis"], g["M_theta"]), g["M_out"], atol=1e-14)
+
+
+def test_loader_collates_the_trainer_dict(P, files):
+    import torch
+    g, srcs, tars = files
+    ds = P.Dataset_2021_8_29(srcs[:1] * 3, tars[:1] * 3)
+    batch = next(iter(torch.utils.data.DataLoader(ds, batch_size=3)))
+    assert batch["points_based_neighs_src"].shape == (3, 3 * 60, 3) and batch["tar_box"].shape == (3, 8, 3)
+    assert batch["igt"].dtype == torch.float32
+
+
+def test_synthesize_and_list(P, tmp_path):
+    out = P.synthesize_dataset(str(tmp_path / "syn"), 3, n_points=64, seed=4)
+    src, tar = P.list_pairs(str(tmp_path / "syn"), range(3), range(1))
+    assert [a for a, _ in out] == src and [b for _, b in out] == tar
+    train, test = P.make_loaders(str(tmp_path / "syn"), range(3), range(1), batch_size=2, n_test=1)
+    b = next(iter(train))
+    assert b["points_src_sample"].shape == (2, 64, 3) and len(test.dataset) == 1

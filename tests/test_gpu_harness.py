@@ -186,3 +186,33 @@ def test_demo_end_to_end_reduces_chamfer(demo, tmp_path):
     done = [h for h in hist if h[1] is not None]
     assert len(done) >= 50
     assert done[-1][2] < 0.8 * done[0][2], (done[0], done[-1])
+
+
+# ------------------------------------------------------- dataset files -> trainer fragment
+def test_dataset_to_fragments(C, tmp_path):
+    """Pairs on disk (pre_dataloader layout) -> DataLoader batch -> RPM and DCP fragments."""
+    import pre_dataloader as P
+    from rrl_hip import synth
+    d = str(tmp_path / "pairs")
+    for i in range(3):  # tar = src @ A + b plus an independent resampling: a registrable pair
+        pr = synth.make_pair(80 + i, 256, 256)
+        P.write_pair(d, i, 0, pr["src"], pr["tar"], pr["src_tri"].reshape(-1, 3),
+                     pr["tar_tri"].reshape(-1, 3), np.concatenate([np.eye(3), np.zeros((3, 1))], 1))
+    src, tar = P.list_pairs(d, range(3), range(1))
+    batch = next(iter(torch.utils.data.DataLoader(P.Dataset_2021_8_29(src, tar), batch_size=3)))
+    data = {k: v.cuda() for k, v in batch.items()}
+    eye = torch.cat([torch.eye(3), torch.zeros(3, 1)], 1).cuda().repeat(3, 1, 1).requires_grad_(True)
+    torch.manual_seed(0)
+    out = C.rpm_intersection_loss([eye, eye], data, n_lines=3000)
+    assert bool(out['valid'].all()) and out['lines'].shape == (3, 3000, 6)
+    out['loss_intersection'].backward()
+    assert torch.isfinite(eye.grad).all() and float(eye.grad.abs().sum()) > 0
+    # identical poses in both iterations: per-iteration sums are equal (target scan reused in #2)
+    assert torch.equal(out['per_iter'][0], out['per_iter'][1])
+    batch = next(iter(torch.utils.data.DataLoader(P.Dataset_2021_8_29(src, tar, DCP_True=True), batch_size=3)))
+    data = {k: v.cuda() for k, v in batch.items()}
+    assert data['points_src_sample'].shape == (3, 3, 256)
+    torch.manual_seed(0)
+    loss, chamfer, lines, ok = C.dcp_intersection_loss(data, data['R'].transpose(2, 1).contiguous(), data['T'],
+                                                       n_lines=3000)
+    assert bool(ok.all()) and np.isfinite(loss.item()) and np.isfinite(chamfer.item())

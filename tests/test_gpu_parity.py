@@ -87,6 +87,33 @@ def test_scan_counts_and_hits(L, oracle, name, mode):
             assert sorted(hit[l, :cnt[l]].tolist()) == o["hit_idx"][l, :cnt[l]].tolist()
 
 
+@pytest.mark.parametrize("name", LOSS_FIXTURES)
+def test_dense_public_scan(L, name):
+    """cal_intersection_batch2_points_with_line: labels equal the reference's exactly, weights at
+    the hits to 2e-5 (torch's CPU sqrt is build-specific), every weight row sums to 1, and
+    `points` is a stride-0 view of the input that carries its grad."""
+    g = load_golden(name)
+    for tri, sfx in ((g["tri1"], "1"), (g["tri2"], "2")):
+        p = cu(tri)[None].requires_grad_(True)
+        points, norm_d, label = L.cal_intersection_batch2_points_with_line(p, cu(g["lines"])[None])
+        nl, nf = g["lines"].shape[0], tri.shape[0]
+        assert points.shape == (nl, nf, 9) and norm_d.shape == (nl, nf, 3) and label.shape == (1, nl, nf)
+        assert label.dtype == torch.bool and not norm_d.requires_grad and points.requires_grad
+        assert points.stride(0) == 0 and points.data_ptr() == p.data_ptr()
+        li, fi = np.nonzero(label[0].cpu().numpy())
+        np.testing.assert_array_equal(li, g["hit_line" + sfx])
+        np.testing.assert_array_equal(fi, g["hit_tri" + sfx])
+        np.testing.assert_array_equal(label[0].sum(1).cpu().numpy(), g["count" + sfx])
+        np.testing.assert_allclose(norm_d.cpu().numpy()[li, fi], g["hit_w" + sfx], rtol=2e-5)
+        np.testing.assert_allclose(norm_d.sum(-1).cpu().numpy(), 1.0, rtol=3e-7)
+    with pytest.raises(ValueError):
+        L.cal_intersection_batch2_points_with_line(cu(g["tri1"]), cu(g["lines"])[None])
+    bad = g["lines"].copy()
+    bad[:, :3] *= 3.0
+    with pytest.raises(ValueError):
+        L.cal_intersection_batch2_points_with_line(cu(g["tri1"])[None], cu(bad)[None])
+
+
 @pytest.mark.parametrize("variant", [1, 2, 4, 8])
 @pytest.mark.parametrize("chunk", [0, 64, 1000])
 @pytest.mark.parametrize("mode", ["strict", "lazy"])
