@@ -33,8 +33,8 @@
 // delta(c) < thr_max + rho for the centre c of the triangle's group.  Phase 1 evaluates
 // d2 = |a_c|^2 - (a_c.dir)^2 with FMAs (error <= 10u |a_c|^2) and keeps the group when
 // d2 - 4e-6 |a_c|^2 <= R2: the slack covers the evaluation error, the |dir|^2 excess and the
-// rounding of rho and R2 with a factor > 2 to spare.  Unsafe lines are not culled at all:
-// tiles of 512 lines containing one are left to the strict loop of scan_kernel.
+// rounding of rho and R2 with a factor > 2 to spare.  Unsafe lines are not culled at all: a
+// 64-line workgroup containing one evaluates all its pairs with the strict loop.
 #include "rrl_ws.h"
 
 #define GRP 16           // triangles per group
@@ -53,38 +53,109 @@ __device__ __forceinline__ int p0s_slot(int s) { return s; }  // records in sort
 
 #define SORT_CELLS 4096  // 16^3 grid cells in Morton order
 
-// Counting sort by grid cell (one 1024-lane workgroup per cloud and sample): cells of a 16^3
-// grid over the P0 bounding box, visited in Morton order; the order inside a cell is arbitrary
-// (it only shapes the groups, never the result).  Three barriers instead of a 78-stage bitonic
-// network.
-__global__ __launch_bounds__(1024) void tri_sort_kernel(
-    const float *__restrict__ ptri1, const float *__restrict__ ptri2, float4 *__restrict__ p0s1,
-    float4 *__restrict__ p0s2, int32_t *__restrict__ idx1, int32_t *__restrict__ idx2,
-    float4 *__restrict__ grp1, float4 *__restrict__ grp2, uint32_t *__restrict__ pmax, int B, int N,
-    int M) {
+// tri_build_kernel: everything the scans need from the raw triangles, one 1024-lane workgroup
+// per cloud and sample, ONE launch (it replaces rigid apply + tri_prepare + tri_sort):
+//   * optionally moves the source cloud by its rigid transform (the fused training op) and
+//     stores the moved triangles (TRI1) for the later stages and the backward;
+//   * thresholds (thr, thr2) and the 48-byte prepared records (PTRI) in original order;
+//   * clears the per-call state of the workspace (and the gradient accumulator G1);
+//   * counting sort by the 16^3 grid cell of P0, cells in Morton order (the order inside a cell
+//     is arbitrary: it only shapes the groups, never the result), group spheres, max |P|^2.
+// NPT > 0: every lane keeps its <= NPT triangles' (P0, thr2, thr) in registers between the
+// passes (n <= 1024 NPT); NPT == 0: they are re-read from the records the lane itself wrote.
+struct BuildArgs {
+    const float *tri1, *tri2;      // raw triangles [B][n][9]; tri1 = source BEFORE the transform
+    const float *R, *t;            // per-sample transform of cloud 0, or NULL
+    float *tri1_out;               // moved source triangles (TRI1), when R != NULL
+    float *ptri1, *ptri2;
+    float4 *p0s1, *p0s2;
+    int32_t *idx1, *idx2;
+    float4 *grp1, *grp2;
+    uint32_t *pmax;
+    uint4 *zero_base;              // per-call state: [0, zero_vec4) except [skip_lo, skip_hi)
+    size_t zero_vec4, skip_lo, skip_hi;
+    uint4 *g1;                     // gradient accumulator to clear (may be NULL)
+    size_t g1_vec4;
+    int B, N, M, transpose_r;
+};
+
+template <int NPT>
+__global__ __launch_bounds__(1024) void tri_build_kernel(const BuildArgs a) {
     extern __shared__ __attribute__((aligned(16))) float thr_s[];  // thr by sorted position
     __shared__ unsigned hist[SORT_CELLS];
     __shared__ float red[16][8];
     __shared__ unsigned wsum[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int B = a.B;
     const int cloud = blockIdx.x >= (unsigned)B ? 1 : 0, b = blockIdx.x - cloud * B;
-    const int n = cloud ? M : N;
-    const float *ptri = (cloud ? ptri2 : ptri1) + (size_t)b * n * PTRI_STRIDE;
+    const int n = cloud ? a.M : a.N;
+    const float *raw = (cloud ? a.tri2 : a.tri1) + (size_t)b * n * 9;
+    float *ptri = (cloud ? a.ptri2 : a.ptri1) + (size_t)b * n * PTRI_STRIDE;
     const int ng = (n + GRP - 1) / GRP;
-    float4 *p0s = (cloud ? p0s2 : p0s1) + (size_t)b * ng * GRP;
-    int32_t *idx = (cloud ? idx2 : idx1) + (size_t)b * ng * GRP;
-    float4 *grp = (cloud ? grp2 : grp1) + (size_t)b * ng;
+    float4 *p0s = (cloud ? a.p0s2 : a.p0s1) + (size_t)b * ng * GRP;
+    int32_t *idx = (cloud ? a.idx2 : a.idx1) + (size_t)b * ng * GRP;
+    float4 *grp = (cloud ? a.grp2 : a.grp1) + (size_t)b * ng;
 
-    // ---- AABB of the P0s and max |P|^2 over all three points (the NaN bound's input)
+    {   // per-call state and gradient accumulator, spread over all workgroups of the launch
+        const size_t nthr = (size_t)gridDim.x * 1024, me = (size_t)blockIdx.x * 1024 + tid;
+        const uint4 z = make_uint4(0, 0, 0, 0);
+        for (size_t i = me; i < a.zero_vec4; i += nthr)
+            if (i < a.skip_lo || i >= a.skip_hi) a.zero_base[i] = z;
+        for (size_t i = me; i < a.g1_vec4; i += nthr) a.g1[i] = z;
+    }
+
+    const bool xf = cloud == 0 && a.R != nullptr;
+    float m[9], tv[3];
+    if (xf) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)  // m[i*3+j] multiplies x_i into y_j (rigid_fwd_kernel)
+                m[i * 3 + j] = a.transpose_r ? a.R[b * 9 + j * 3 + i] : a.R[b * 9 + i * 3 + j];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) tv[j] = a.t[b * 3 + j];
+    }
+    float *moved = xf ? a.tri1_out + (size_t)b * n * 9 : nullptr;
+
+    // ---- pass 1: transform, thresholds, records; AABB of the P0s and max |P|^2
+    constexpr int NR = NPT > 0 ? NPT : 1;
+    float rx[NR], ry[NR], rz[NR], rt2[NR], rth[NR];
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY}, p2 = 0.0f;
-#pragma unroll 4
-    for (int f = tid; f < n; f += 1024) {
-        const float *p = ptri + PTRI_STRIDE * (size_t)f;
+    auto pass1 = [&](int f, int k) {
+        float c[9], thr, x;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) { mn[c] = fminf(mn[c], p[c]); mx[c] = fmaxf(mx[c], p[c]); }
+        for (int i = 0; i < 9; ++i) c[i] = raw[9 * (size_t)f + i];
+        if (xf) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k)
-            p2 = fmaxf(p2, p[3 * k] * p[3 * k] + p[3 * k + 1] * p[3 * k + 1] + p[3 * k + 2] * p[3 * k + 2]);
+            for (int q = 0; q < 3; ++q) {
+                const float v0 = c[3 * q], v1 = c[3 * q + 1], v2 = c[3 * q + 2];
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    c[3 * q + j] = fmaf(v2, m[6 + j], fmaf(v1, m[3 + j], v0 * m[j])) + tv[j];
+            }
+#pragma unroll
+            for (int i = 0; i < 9; ++i) moved[9 * (size_t)f + i] = c[i];
+        }
+        tri_thresholds(c, &thr, &x);  // code/loss.py:94-110
+        float4 *row = (float4 *)(ptri + PTRI_STRIDE * (size_t)f);
+        row[0] = make_float4(c[0], c[1], c[2], c[3]);
+        row[1] = make_float4(c[4], c[5], c[6], c[7]);
+        row[2] = make_float4(c[8], x, thr, __int_as_float(f));
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { mn[d] = fminf(mn[d], c[d]); mx[d] = fmaxf(mx[d], c[d]); }
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+            p2 = fmaxf(p2, c[3 * q] * c[3 * q] + c[3 * q + 1] * c[3 * q + 1] + c[3 * q + 2] * c[3 * q + 2]);
+        if (NPT > 0) { rx[k] = c[0]; ry[k] = c[1]; rz[k] = c[2]; rt2[k] = x; rth[k] = thr; }
+    };
+    if (NPT > 0) {
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+            const int f = tid + 1024 * k;
+            if (f < n) pass1(f, k);
+        }
+    } else {
+        for (int f = tid; f < n; f += 1024) pass1(f, 0);
     }
     if (!(p2 <= 3.0e38f)) p2 = INFINITY;  // NaN/inf coordinates: never "provably safe"
 #pragma unroll
@@ -103,7 +174,7 @@ __global__ __launch_bounds__(1024) void tri_sort_kernel(
         red[0][tid] = r;
     }
     __syncthreads();
-    if (tid == 0) pmax[cloud * B + b] = __float_as_uint(red[0][6]);
+    if (tid == 0) a.pmax[cloud * B + b] = __float_as_uint(red[0][6]);
     float scale[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -111,7 +182,8 @@ __global__ __launch_bounds__(1024) void tri_sort_kernel(
         float ext = red[0][3 + c] - mn[c];
         scale[c] = ext > 0.0f && ext < 3.0e38f ? 15.999f / ext : 0.0f;
     }
-    auto cell_of = [&](const float *p) -> unsigned {
+    auto cell_of = [&](float px, float py, float pz) -> unsigned {
+        const float p[3] = {px, py, pz};
         unsigned q[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -122,8 +194,17 @@ __global__ __launch_bounds__(1024) void tri_sort_kernel(
     };
 
     // ---- histogram over cells, exclusive scan, scatter
-#pragma unroll 4
-    for (int f = tid; f < n; f += 1024) atomicAdd(&hist[cell_of(ptri + PTRI_STRIDE * (size_t)f)], 1u);
+    unsigned cell[NR];
+    if (NPT > 0) {
+#pragma unroll
+        for (int k = 0; k < NR; ++k)
+            if (tid + 1024 * k < n) { cell[k] = cell_of(rx[k], ry[k], rz[k]); atomicAdd(&hist[cell[k]], 1u); }
+    } else {
+        for (int f = tid; f < n; f += 1024) {
+            const float *p = ptri + PTRI_STRIDE * (size_t)f;
+            atomicAdd(&hist[cell_of(p[0], p[1], p[2])], 1u);
+        }
+    }
     __syncthreads();
     {
         unsigned h[4], tsum = 0;
@@ -139,16 +220,28 @@ __global__ __launch_bounds__(1024) void tri_sort_kernel(
         for (int k = 0; k < 4; ++k) { hist[4 * tid + k] = run; run += h[k]; }
     }
     __syncthreads();
-#pragma unroll 4
-    for (int f = tid; f < n; f += 1024) {
-        const float *p = ptri + PTRI_STRIDE * (size_t)f;
-        const int s = (int)atomicAdd(&hist[cell_of(p)], 1u);
-        p0s[p0s_slot(s)] = make_float4(p[0], p[1], p[2], p[9]);
-        idx[s] = f;
-        thr_s[s] = p[10];
+    if (NPT > 0) {
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+            const int f = tid + 1024 * k;
+            if (f < n) {
+                const int s = (int)atomicAdd(&hist[cell[k]], 1u);
+                p0s[s] = make_float4(rx[k], ry[k], rz[k], rt2[k]);
+                idx[s] = f;
+                thr_s[s] = rth[k];
+            }
+        }
+    } else {
+        for (int f = tid; f < n; f += 1024) {
+            const float *p = ptri + PTRI_STRIDE * (size_t)f;
+            const int s = (int)atomicAdd(&hist[cell_of(p[0], p[1], p[2])], 1u);
+            p0s[s] = make_float4(p[0], p[1], p[2], p[9]);
+            idx[s] = f;
+            thr_s[s] = p[10];
+        }
     }
     for (int s = n + tid; s < ng * GRP; s += 1024) {  // pad: thr2 = 0 never passes
-        p0s[p0s_slot(s)] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        p0s[s] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         idx[s] = 0;
         thr_s[s] = 0.0f;
     }
@@ -157,7 +250,7 @@ __global__ __launch_bounds__(1024) void tri_sort_kernel(
     // ---- group spheres (16 consecutive lanes = one group)
     for (int s = tid; s < ng * GRP; s += 1024) {
         const bool valid = s < n;
-        const float4 r4 = p0s[p0s_slot(s)];
+        const float4 r4 = p0s[s];
         const float c[3] = {r4.x, r4.y, r4.z};
         float lo[3], hi[3], tm = thr_s[s];
 #pragma unroll
@@ -294,7 +387,8 @@ __global__ __launch_bounds__(256) void cull_scan_kernel(
     const float4 *__restrict__ p0s2, const int32_t *__restrict__ idx1, const int32_t *__restrict__ idx2,
     const float4 *__restrict__ grp1, const float4 *__restrict__ grp2, const float *__restrict__ line,
     int32_t *__restrict__ count1, int32_t *__restrict__ hit1, int32_t *__restrict__ count2,
-    int32_t *__restrict__ hit2, const int32_t *__restrict__ tsafe, int B, int N, int M, int L) {
+    int32_t *__restrict__ hit2, int32_t *__restrict__ status, const uint32_t *__restrict__ pmax, int B,
+    int N, int M, int L) {
     __shared__ __attribute__((aligned(16))) float4 lines_lds[4][64][2];    // 8 KiB
     __shared__ __attribute__((aligned(16))) float4 rows_lds[4][BGRP * ROWS];  // 17 KiB
     __shared__ unsigned cands_lds[4][WCCAP];                               // 4 KiB
@@ -309,10 +403,7 @@ __global__ __launch_bounds__(256) void cull_scan_kernel(
     const float *ln = line + (size_t)b * L * 6;
 
     // 64 lines per workgroup; the four wavefronts split the GROUP range between them, which
-    // quadruples the number of independent (latency-bound) wavefronts.  The 512-line tile this
-    // block belongs to was classified by scan_kernel (launched before): unsafe tiles -- a line
-    // that fails the NaN bound -- were scanned by its strict loop and are skipped here.
-    if (!tsafe[(size_t)z * ((L + 511) / 512) + (blockIdx.x >> 3)]) return;
+    // quadruples the number of independent (latency-bound) wavefronts.
     const int l = blockIdx.x * 64 + lane;
     float v[6];
 #pragma unroll
@@ -321,6 +412,33 @@ __global__ __launch_bounds__(256) void cull_scan_kernel(
     lines_lds[wave][lane][1] = make_float4(v[4], v[5], 0.0f, 0.0f);
     const float ux = v[0], uy = v[1], uz = v[2], ox = v[3], oy = v[4], oz = v[5];
     const bool live = l < L;
+
+    // Culling (and the lazy evaluation of points 1, 2) is only exact for lines that satisfy the
+    // NaN-impossibility bound.  All four wavefronts hold the same 64 lines, so the vote is
+    // wave-local and uniform over the workgroup: a block with an offending line evaluates ALL
+    // its (line, triangle) pairs strictly instead -- the reference's semantics, NaN included.
+    if (!__all(rrl_line_safe(v, __uint_as_float(pmax[cloud * B + b])))) {
+        kptr tp = (kptr)(uintptr_t)((cloud ? ptri2 : ptri1) + (size_t)b * n * PTRI_STRIDE);
+        int32_t *cnt = (cloud ? count2 : count1) + (size_t)b * L;
+        int32_t *hit = (cloud ? hit2 : hit1) + (size_t)b * L * RRL_MAX_HITS;
+        const int tq = (n + 3) / 4, t1 = min(n, (wave + 1) * tq);
+        uint32_t nanacc = 0;
+        tp += (size_t)wave * tq * PTRI_STRIDE;
+        for (int t = wave * tq; t < t1; ++t, tp += PTRI_STRIDE) {
+            const uint32_t thr2 = __float_as_uint(tp[9]);
+            const uint32_t x0 = __float_as_uint(dist_sq<float>(tp[0], tp[1], tp[2], ux, uy, uz, ox, oy, oz));
+            const uint32_t x1 = __float_as_uint(dist_sq<float>(tp[3], tp[4], tp[5], ux, uy, uz, ox, oy, oz));
+            const uint32_t x2 = __float_as_uint(dist_sq<float>(tp[6], tp[7], tp[8], ux, uy, uz, ox, oy, oz));
+            const uint32_t mm = max(max(x0, x1), x2);  // negative or NaN: sign bit set -> huge
+            nanacc = max(nanacc, mm);
+            if (live && mm < thr2) {
+                const int pos = atomicAdd(&cnt[l], 1);
+                if (pos < RRL_MAX_HITS) hit[(size_t)l * RRL_MAX_HITS + pos] = __float_as_int(tp[11]);
+            }
+        }
+        if (live && nanacc >= 0x80000000u) atomicOr(&status[0], 1);
+        return;
+    }
 
     WaveCtx ctx;
     ctx.lines = &lines_lds[wave][0][0];
@@ -376,14 +494,37 @@ __global__ __launch_bounds__(256) void cull_scan_kernel(
 }
 
 // Launchers used by rrl_tri_prepare / rrl_line_tri_scan (rrl_scan.hip)
-int rrl_launch_tri_sort(void *ws, const WsLayout &w, int B, int N, int M, int clouds, hipStream_t s) {
+int rrl_launch_tri_build(const float *tri1, const float *tri2, void *ws, const WsLayout &w, int B,
+                         int N, int M, int clouds, const RrlXform *xf, hipStream_t s) {
     const int nmax = clouds == 2 && M > N ? M : N;
     const size_t lds = sizeof(float) * (size_t)((nmax + GRP - 1) / GRP * GRP);
-    hipLaunchKernelGGL(tri_sort_kernel, dim3((unsigned)(clouds * B)), dim3(1024), lds, s, w.f32(ws, RRL_WS_PTRI1),
-                       w.f32(ws, RRL_WS_PTRI2), (float4 *)w.f32(ws, RRL_WS_P0S1),
-                       (float4 *)w.f32(ws, RRL_WS_P0S2), w.i32(ws, RRL_WS_IDX1), w.i32(ws, RRL_WS_IDX2),
-                       (float4 *)w.f32(ws, RRL_WS_GRP1), (float4 *)w.f32(ws, RRL_WS_GRP2),
-                       (uint32_t *)w.i32(ws, RRL_WS_PMAX), B, N, M);
+    BuildArgs a;
+    a.tri1 = xf ? xf->src : tri1;
+    a.tri2 = tri2;
+    a.R = xf ? xf->R : nullptr;
+    a.t = xf ? xf->t : nullptr;
+    a.tri1_out = xf ? w.f32(ws, RRL_WS_TRI1) : nullptr;
+    a.ptri1 = w.f32(ws, RRL_WS_PTRI1);
+    a.ptri2 = w.f32(ws, RRL_WS_PTRI2);
+    a.p0s1 = (float4 *)w.f32(ws, RRL_WS_P0S1);
+    a.p0s2 = (float4 *)w.f32(ws, RRL_WS_P0S2);
+    a.idx1 = w.i32(ws, RRL_WS_IDX1);
+    a.idx2 = w.i32(ws, RRL_WS_IDX2);
+    a.grp1 = (float4 *)w.f32(ws, RRL_WS_GRP1);
+    a.grp2 = (float4 *)w.f32(ws, RRL_WS_GRP2);
+    a.pmax = (uint32_t *)w.i32(ws, RRL_WS_PMAX);
+    a.zero_base = (uint4 *)((char *)ws + w.off[RRL_WS_STATUS]);
+    a.zero_vec4 = w.zero_bytes / 16;
+    a.skip_lo = w.off[RRL_WS_PMAX] / 16;
+    a.skip_hi = w.off[RRL_WS_COUNT1] / 16;
+    a.g1 = xf && xf->zero_g1 ? (uint4 *)((char *)ws + w.off[RRL_WS_G1]) : nullptr;
+    a.g1_vec4 = a.g1 ? (w.off[RRL_WS_RPART] - w.off[RRL_WS_G1]) / 16 : 0;
+    a.B = B; a.N = N; a.M = M;
+    a.transpose_r = xf ? xf->transpose_r : 0;
+    if (nmax <= 4096)
+        hipLaunchKernelGGL(tri_build_kernel<4>, dim3((unsigned)(clouds * B)), dim3(1024), lds, s, a);
+    else
+        hipLaunchKernelGGL(tri_build_kernel<0>, dim3((unsigned)(clouds * B)), dim3(1024), lds, s, a);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }
@@ -396,7 +537,7 @@ int rrl_launch_cull_scan(const float *line, void *ws, const WsLayout &w, int B, 
                        w.i32(ws, RRL_WS_IDX1), w.i32(ws, RRL_WS_IDX2), (const float4 *)w.f32(ws, RRL_WS_GRP1),
                        (const float4 *)w.f32(ws, RRL_WS_GRP2), line, w.i32(ws, RRL_WS_COUNT1),
                        w.i32(ws, RRL_WS_HIT1), w.i32(ws, RRL_WS_COUNT2), w.i32(ws, RRL_WS_HIT2),
-                       w.i32(ws, RRL_WS_TSAFE), B, N, M, L);
+                       w.i32(ws, RRL_WS_STATUS), (const uint32_t *)w.i32(ws, RRL_WS_PMAX), B, N, M, L);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }

@@ -170,6 +170,146 @@ extern "C" int rrl_rigid_apply_bwd(const float *x, const float *R, const float *
     return 0;
 }
 
+// Backward tail of the fused training op in ONE launch: rigid-apply backward of the accumulated
+// triangle gradient g1 (cleared again on the way, so the next backward on this workspace starts
+// from zero) over REG_BWD_PTS points per 256-lane workgroup -- a single workgroup per sample is
+// bound by one CU's memory pipe --, per-workgroup partial sums, and, by the LAST workgroup of the
+// launch to finish (ticket counter), the fixed-order reduction to dR / dt per sample and the
+// 14-float shard payload.  Deterministic: no float atomics, fixed summation order.
+#define REG_BWD_PTS 1024
+
+__device__ __forceinline__ float ld_agent(const float *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(256) void reg_bwd_kernel(const float *__restrict__ x,
+                                                      const float *__restrict__ R,
+                                                      float *__restrict__ g1, float *__restrict__ gx,
+                                                      float *__restrict__ partial,
+                                                      float *__restrict__ gR, float *__restrict__ gt,
+                                                      float *__restrict__ payload,
+                                                      const float *__restrict__ loss,
+                                                      const int32_t *__restrict__ info,
+                                                      int32_t *__restrict__ done, int n, int B,
+                                                      int transpose_r) {
+    __shared__ float red[4][12];
+    __shared__ int ticket;
+    __shared__ double psum[14];
+    const int b = blockIdx.y, nblk = gridDim.x;
+    const Mat m = load_mat(R, nullptr, b, transpose_r);
+    const size_t base = (size_t)b * n * 3;
+    float acc[12];
+#pragma unroll
+    for (int q = 0; q < 12; ++q) acc[q] = 0.0f;
+    const int i0 = blockIdx.x * REG_BWD_PTS, i1 = min(n, i0 + REG_BWD_PTS);
+    for (int i = i0 + threadIdx.x; i < i1; i += 256) {
+        float v[3], g[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            v[c] = x[base + 3 * (size_t)i + c];
+            g[c] = g1[base + 3 * (size_t)i + c];
+            g1[base + 3 * (size_t)i + c] = 0.0f;
+        }
+        if (gx) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                gx[base + 3 * (size_t)i + c] =
+                    fmaf(g[2], m.r[c * 3 + 2], fmaf(g[1], m.r[c * 3 + 1], g[0] * m.r[c * 3]));
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) acc[c * 3 + j] = fmaf(v[c], g[j], acc[c * 3 + j]);
+            acc[9 + c] += g[c];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 12; ++q) acc[q] = wave_sum(acc[q]);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int q = 0; q < 12; ++q) red[wave][q] = acc[q];
+    __syncthreads();
+    // Cross-workgroup hand-over WITHOUT __threadfence(): an agent-scope fence writes back the
+    // whole L2 of the XCD (several microseconds here).  Instead the 12 partials go out as
+    // agent-scope (write-through) atomic stores from wave 0, which waits for their completion
+    // before its lane 0 takes the ticket; the last workgroup reads them with agent-scope loads.
+    if (threadIdx.x < 12) {
+        const int q = threadIdx.x;
+        __hip_atomic_store(&partial[((size_t)b * nblk + blockIdx.x) * 12 + q],
+                           (red[0][q] + red[1][q]) + (red[2][q] + red[3][q]), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (threadIdx.x < 64) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (threadIdx.x == 0)
+            ticket = __hip_atomic_fetch_add(done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (threadIdx.x < 14) psum[threadIdx.x] = 0.0;
+    __syncthreads();
+    if (ticket != nblk * B - 1) return;
+    if (threadIdx.x == 0) __hip_atomic_store(done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // the last workgroup: per-sample sums over the workgroups in index order (double accumulator),
+    // then the payload over the samples in index order
+    for (int k0 = 0; k0 < B; k0 += 16) {
+        const int k = k0 + (int)(threadIdx.x / 12), q = threadIdx.x % 12;
+        float r = 0.0f;
+        const bool on = threadIdx.x < 192 && k < B;
+        if (on) {
+            double s = 0.0;
+            for (int j = 0; j < nblk; ++j) s += (double)ld_agent(&partial[((size_t)k * nblk + j) * 12 + q]);
+            r = (float)s;
+            if (q < 9) {
+                int i = q / 3, jj = q % 3;
+                gR[k * 9 + (transpose_r ? jj * 3 + i : i * 3 + jj)] = r;
+            } else {
+                gt[k * 3 + (q - 9)] = r;
+            }
+        }
+        if (payload) {  // samples in index order: 16 per pass, serialised by a single lane per slot
+            __shared__ float stage[16][12];
+            if (on) stage[threadIdx.x / 12][q] = r;
+            __syncthreads();
+            if (threadIdx.x < 12) {
+                double s = psum[2 + threadIdx.x];
+                for (int kk = 0; kk < min(16, B - k0); ++kk) s += (double)stage[kk][threadIdx.x];
+                psum[2 + threadIdx.x] = s;
+            }
+            __syncthreads();
+        }
+    }
+    if (!payload) return;
+    if (threadIdx.x < 2) {
+        double s = 0.0;
+        for (int k = 0; k < B; ++k) s += info[k * 4] > 0 ? (threadIdx.x == 0 ? (double)loss[k] : 1.0) : 0.0;
+        payload[threadIdx.x] = (float)s;
+    } else if (threadIdx.x < 14) {
+        // psum[2..10] = dR entries in (i, j) order of m; the payload wants gR's memory order
+        const int q = threadIdx.x - 2;
+        if (q < 9) {
+            int i = q / 3, jj = q % 3;
+            payload[2 + (transpose_r ? jj * 3 + i : i * 3 + jj)] = (float)psum[2 + q];
+        } else {
+            payload[2 + q] = (float)psum[2 + q];
+        }
+    }
+}
+
+// the fused tail applies when the clouds take the sorted prepare path (whose build kernel clears
+// G1 in the forward)
+int rrl_fused_backward(int B, int N, int M) { return B > 0 && N > 0 && (N > M ? N : M) <= 16384; }
+
+int rrl_launch_reg_bwd(const float *src, const float *R, float *g1, float *grad_src, float *partial,
+                       float *gR, float *gt, float *payload, const float *loss, const int32_t *info,
+                       int32_t *done, int B, int N, int transpose_r, hipStream_t s) {
+    const int n = 3 * N;
+    hipLaunchKernelGGL(reg_bwd_kernel, dim3((unsigned)((n + REG_BWD_PTS - 1) / REG_BWD_PTS), (unsigned)B),
+                       dim3(256), 0, s, src, R, g1, grad_src, partial, gR, gt, payload, loss, info, done, n,
+                       B, transpose_r);
+    RRL_LAUNCH_CHECK();
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------
 // K7 Chamfer: nearest target of every query.  Lane = query point (registers), targets are
 // wave-uniform and stream through the scalar cache.  A (query tile, target chunk) workgroup

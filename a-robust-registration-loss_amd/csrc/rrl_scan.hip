@@ -35,9 +35,9 @@
 // ---------------------------------------------------------------------------------------
 // 64 triangles per workgroup, staged through LDS so that both the 36-byte input rows and the
 // 48-byte output records move with fully coalesced accesses.
-// SORTED path (the usual one): max |P|^2 is computed later by tri_sort_kernel and this kernel
-// also clears the per-call state (every field of the zero region except PMAX), so no memset is
-// needed.  LEGACY path (clouds too large to sort): state cleared by a memset, atomicMax on PMAX.
+// Only the LEGACY instantiation is launched (clouds too large to sort; state cleared by a memset,
+// atomicMax on PMAX): the usual, sorted path builds the records inside tri_build_kernel
+// (rrl_cull.hip) together with the transform, the sort and the group spheres.
 template <bool LEGACY>
 __global__ __launch_bounds__(64) void tri_prepare_kernel(const float *__restrict__ tri1,
                                                          const float *__restrict__ tri2,
@@ -95,7 +95,8 @@ __global__ __launch_bounds__(64) void tri_prepare_kernel(const float *__restrict
     }
 }
 
-int rrl_launch_tri_sort(void *ws, const WsLayout &w, int B, int N, int M, int clouds, hipStream_t s);
+int rrl_launch_tri_build(const float *tri1, const float *tri2, void *ws, const WsLayout &w, int B,
+                         int N, int M, int clouds, const RrlXform *xf, hipStream_t s);
 int rrl_launch_cull_scan(const float *line, void *ws, const WsLayout &w, int B, int N, int M, int L,
                          int clouds, hipStream_t s);
 int rrl_sort_capacity(void);
@@ -103,9 +104,13 @@ int rrl_sort_capacity(void);
 // clouds = 2: both clouds; clouds = 1: the source only (the target's scan results are carried
 // over from an earlier call with the same target and lines, see rrl_loss_forward_cached).  The
 // sorted/legacy decision always looks at both sizes so that a cached call takes the same path.
+// xf != NULL: the source is xf->src moved by (xf->R, xf->t); the moved triangles land in TRI1
+// (`tri1` is ignored).  Sorted path: ONE launch (tri_build_kernel) does transform + records +
+// state clearing + sort + spheres.  Legacy path (a cloud > 16384 triangles): rigid apply,
+// memset, tri_prepare_kernel<LEGACY>.
 int rrl_tri_prepare_clouds(const float *tri1, const float *tri2, void *ws, size_t ws_bytes, int B,
-                           int N, int M, int L, int clouds, void *stream) {
-    if (!tri1 || !tri2 || !ws || B < 0 || N < 0 || M < 0 || L < 0) return RRL_E_ARG;
+                           int N, int M, int L, int clouds, const RrlXform *xf, void *stream) {
+    if ((!tri1 && !xf) || !tri2 || !ws || B < 0 || N < 0 || M < 0 || L < 0) return RRL_E_ARG;
     WsLayout w(B, N, M, L);
     if (ws_bytes < w.total) return RRL_E_WS;
     hipStream_t s = (hipStream_t)stream;
@@ -118,26 +123,24 @@ int rrl_tri_prepare_clouds(const float *tri1, const float *tri2, void *ws, size_
         if (e != hipSuccess) return (int)e;
     }
     if (B == 0 || nmax == 0) return 0;
+    if (sorted) return rrl_launch_tri_build(tri1, tri2, ws, w, B, N, M, clouds, xf, s);
+    if (xf) {
+        tri1 = w.f32(ws, RRL_WS_TRI1);
+        int rc = rrl_rigid_apply_fwd(xf->src, xf->R, xf->t, w.f32(ws, RRL_WS_TRI1), B, 3 * N,
+                                     xf->transpose_r, 0, stream);
+        if (rc) return rc;
+    }
     dim3 grid((unsigned)((nmax + 63) / 64), (unsigned)B, (unsigned)clouds);
-    if (sorted)
-        hipLaunchKernelGGL(tri_prepare_kernel<false>, grid, dim3(64), 0, s, tri1, tri2,
-                           w.f32(ws, RRL_WS_PTRI1), w.f32(ws, RRL_WS_PTRI2),
-                           (uint32_t *)w.i32(ws, RRL_WS_PMAX), zb, w.zero_bytes / 16,
-                           w.off[RRL_WS_PMAX] / 16, w.off[RRL_WS_COUNT1] / 16, B, N, M);
-    else
-        hipLaunchKernelGGL(tri_prepare_kernel<true>, grid, dim3(64), 0, s, tri1, tri2,
-                           w.f32(ws, RRL_WS_PTRI1), w.f32(ws, RRL_WS_PTRI2),
-                           (uint32_t *)w.i32(ws, RRL_WS_PMAX), zb, (size_t)0, (size_t)0, (size_t)0, B,
-                           N, M);
+    hipLaunchKernelGGL(tri_prepare_kernel<true>, grid, dim3(64), 0, s, tri1, tri2,
+                       w.f32(ws, RRL_WS_PTRI1), w.f32(ws, RRL_WS_PTRI2),
+                       (uint32_t *)w.i32(ws, RRL_WS_PMAX), zb, (size_t)0, (size_t)0, (size_t)0, B, N, M);
     RRL_LAUNCH_CHECK();
-    // grid-cell order + group spheres + max |P|^2 for the culled scan
-    if (sorted) return rrl_launch_tri_sort(ws, w, B, N, M, clouds, s);
     return 0;
 }
 
 extern "C" int rrl_tri_prepare(const float *tri1, const float *tri2, void *ws, size_t ws_bytes,
                                int B, int N, int M, int L, void *stream) {
-    return rrl_tri_prepare_clouds(tri1, tri2, ws, ws_bytes, B, N, M, L, 2, stream);
+    return rrl_tri_prepare_clouds(tri1, tri2, ws, ws_bytes, B, N, M, L, 2, nullptr, stream);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -391,13 +394,16 @@ int rrl_line_tri_scan_clouds(const float *line, void *ws, size_t ws_bytes, int B
     if (B == 0 || L == 0 || (N == 0 && (M == 0 || clouds == 1))) return 0;
     const int nmax0 = N > M ? N : M;
     if (mode == RRL_SCAN_CULL && nmax0 > rrl_sort_capacity()) mode = RRL_SCAN_AUTO;
-    int R = g_scan_variant;
-    const bool cull = mode == RRL_SCAN_CULL;
-    if (cull) {  // the strict companion runs packed pairs over 512-line tiles, fat chunks
-        R = 2;
-        mode = RRL_SCAN_UNSAFE_TILES;
-        if (chunk == 0) chunk = 1024;
+    hipStream_t s = (hipStream_t)stream;
+    const bool timed = g_timing_on && (g_timing_seen++ % g_timing_on) == 0 && g_timing_n < TIMING_RING;
+    if (mode == RRL_SCAN_CULL) {  // one launch: sphere-culled scan with an inline strict fallback
+        if (timed) (void)hipEventRecord(g_ev[g_timing_n][0], s);
+        int rc = rrl_launch_cull_scan(line, ws, w, B, N, M, L, clouds, s);
+        if (rc) return rc;
+        if (timed) (void)hipEventRecord(g_ev[g_timing_n++][1], s);
+        return 0;
     }
+    int R = g_scan_variant;
     if (R == 0) {
         const char *v = getenv("RRL_SCAN_VARIANT");
         R = v ? atoi(v) : 0;
@@ -411,8 +417,6 @@ int rrl_line_tri_scan_clouds(const float *line, void *ws, size_t ws_bytes, int B
     const int nmax = clouds == 2 && M > N ? M : N;
     dim3 grid((unsigned)((L + 256 * R - 1) / (256 * R)), (unsigned)((nmax + chunk - 1) / chunk),
               (unsigned)(clouds * B));
-    hipStream_t s = (hipStream_t)stream;
-    const bool timed = g_timing_on && (g_timing_seen++ % g_timing_on) == 0 && g_timing_n < TIMING_RING;
     if (timed) (void)hipEventRecord(g_ev[g_timing_n][0], s);
 #define RRL_SCAN_LAUNCH(T, NP)                                                                   \
     hipLaunchKernelGGL((scan_kernel<T, NP>), grid, dim3(256), 0, s, w.f32(ws, RRL_WS_PTRI1),     \
@@ -425,10 +429,6 @@ int rrl_line_tri_scan_clouds(const float *line, void *ws, size_t ws_bytes, int B
     else if (R == 4) RRL_SCAN_LAUNCH(v2f, 2);
     else RRL_SCAN_LAUNCH(v2f, 4);
 #undef RRL_SCAN_LAUNCH
-    if (cull) {  // after its companion, which classified the tiles
-        int rc = rrl_launch_cull_scan(line, ws, w, B, N, M, L, clouds, s);
-        if (rc) return rc;
-    }
     if (timed) (void)hipEventRecord(g_ev[g_timing_n++][1], s);
     RRL_LAUNCH_CHECK();
     return 0;

@@ -447,17 +447,18 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(
     }
 }
 
-extern "C" int rrl_loss_backward(const float *tri1, const float *tri2, const void *ws,
-                                 size_t ws_bytes, const float *grad_loss, float *grad_tri1,
-                                 float *grad_tri2, int B, int N, int M, int L, int pool,
-                                 void *stream) {
+static int loss_backward_impl(const float *tri1, const float *tri2, const void *ws,
+                              size_t ws_bytes, const float *grad_loss, float *grad_tri1,
+                              float *grad_tri2, int B, int N, int M, int L, int pool, bool zero1,
+                              void *stream) {
     if (!tri1 || !tri2 || !ws || !grad_loss || !grad_tri1) return RRL_E_ARG;
     if (B < 0 || N < 0 || M < 0 || L < 0) return RRL_E_ARG;
     WsLayout w(B, N, M, L);
     if (ws_bytes < w.total) return RRL_E_WS;
     hipStream_t s = (hipStream_t)stream;
     hipError_t e;
-    if ((size_t)B * N && (e = hipMemsetAsync(grad_tri1, 0, sizeof(float) * 9 * (size_t)B * N, s)) != hipSuccess)
+    if (zero1 && (size_t)B * N &&
+        (e = hipMemsetAsync(grad_tri1, 0, sizeof(float) * 9 * (size_t)B * N, s)) != hipSuccess)
         return (int)e;
     if (grad_tri2 && (size_t)B * M &&
         (e = hipMemsetAsync(grad_tri2, 0, sizeof(float) * 9 * (size_t)B * M, s)) != hipSuccess)
@@ -474,6 +475,19 @@ extern "C" int rrl_loss_backward(const float *tri1, const float *tri2, const voi
     return 0;
 }
 
+extern "C" int rrl_loss_backward(const float *tri1, const float *tri2, const void *ws,
+                                 size_t ws_bytes, const float *grad_loss, float *grad_tri1,
+                                 float *grad_tri2, int B, int N, int M, int L, int pool,
+                                 void *stream) {
+    return loss_backward_impl(tri1, tri2, ws, ws_bytes, grad_loss, grad_tri1, grad_tri2, B, N, M, L,
+                              pool, true, stream);
+}
+
+int rrl_fused_backward(int B, int N, int M);
+int rrl_launch_reg_bwd(const float *src, const float *R, float *g1, float *grad_src, float *partial,
+                       float *gR, float *gt, float *payload, const float *loss, const int32_t *info,
+                       int32_t *done, int B, int N, int transpose_r, hipStream_t s);
+
 // ---------------------------------------------------------------------------------------
 // workspace + fused forward
 // ---------------------------------------------------------------------------------------
@@ -487,7 +501,7 @@ extern "C" int rrl_workspace_layout(int B, int N, int M, int L, size_t *offsets)
 }
 
 int rrl_tri_prepare_clouds(const float *tri1, const float *tri2, void *ws, size_t ws_bytes, int B,
-                           int N, int M, int L, int clouds, void *stream);
+                           int N, int M, int L, int clouds, const RrlXform *xf, void *stream);
 int rrl_line_tri_scan_clouds(const float *line, void *ws, size_t ws_bytes, int B, int N, int M, int L,
                              int mode, int chunk, int clouds, void *stream);
 
@@ -495,16 +509,17 @@ int rrl_line_tri_scan_clouds(const float *line, void *ws, size_t ws_bytes, int B
 // the SAME tri2 and line (RPM / FMR evaluate several source poses against one target and one
 // line set, rpm/Train_RPM.py:204-231): the target's hit counts and hit lists are copied from it
 // and only the source cloud is prepared, sorted and scanned.
-extern "C" int rrl_loss_forward_cached(const float *tri1, const float *tri2, const float *line,
-                                       void *ws, size_t ws_bytes, float *loss, int B, int N, int M,
-                                       int L, int s_m, int s_n, int e_m, int e_n, int pool, int mode,
-                                       int chunk, const void *target_ws, void *stream) {
+// xf != NULL: tri1 is the workspace field TRI1, filled by the prepare step from xf->src.
+static int loss_forward_impl(const float *tri1, const float *tri2, const float *line, void *ws,
+                             size_t ws_bytes, float *loss, int B, int N, int M, int L, int s_m,
+                             int s_n, int e_m, int e_n, int pool, int mode, int chunk,
+                             const void *target_ws, const RrlXform *xf, void *stream) {
     if (!tri1 || !tri2 || !line || !ws || !loss) return RRL_E_ARG;
     if (s_m < 1 || s_n < 1 || e_m > RRL_MAX_HITS + 1 || e_n > RRL_MAX_HITS + 1) return RRL_E_RANGE;
     if (target_ws == ws) return RRL_E_ARG;
     const int clouds = target_ws ? 1 : 2;
     int rc;
-    if ((rc = rrl_tri_prepare_clouds(tri1, tri2, ws, ws_bytes, B, N, M, L, clouds, stream))) return rc;
+    if ((rc = rrl_tri_prepare_clouds(tri1, tri2, ws, ws_bytes, B, N, M, L, clouds, xf, stream))) return rc;
     if (target_ws && (size_t)B * L) {  // after the prepare step, which cleared COUNT2
         WsLayout w(B, N, M, L);
         hipStream_t s = (hipStream_t)stream;
@@ -521,6 +536,14 @@ extern "C" int rrl_loss_forward_cached(const float *tri1, const float *tri2, con
                                  pool, stream)))
         return rc;
     return rrl_loss_reduce(ws, ws_bytes, loss, B, N, M, L, s_m, s_n, e_m, e_n, pool, stream);
+}
+
+extern "C" int rrl_loss_forward_cached(const float *tri1, const float *tri2, const float *line,
+                                       void *ws, size_t ws_bytes, float *loss, int B, int N, int M,
+                                       int L, int s_m, int s_n, int e_m, int e_n, int pool, int mode,
+                                       int chunk, const void *target_ws, void *stream) {
+    return loss_forward_impl(tri1, tri2, line, ws, ws_bytes, loss, B, N, M, L, s_m, s_n, e_m, e_n,
+                             pool, mode, chunk, target_ws, nullptr, stream);
 }
 
 extern "C" int rrl_loss_forward(const float *tri1, const float *tri2, const float *line, void *ws,
@@ -544,11 +567,11 @@ extern "C" int rrl_registration_forward_cached(const float *src, const float *R,
     if (B < 0 || N < 0 || M < 0 || L < 0) return RRL_E_ARG;
     WsLayout w(B, N, M, L);
     if (ws_bytes < w.total) return RRL_E_WS;
-    float *tri1 = w.f32(ws, RRL_WS_TRI1);
-    int rc = rrl_rigid_apply_fwd(src, R, t, tri1, B, 3 * N, transpose_r, 0, stream);
-    if (rc) return rc;
-    return rrl_loss_forward_cached(tri1, tri2, line, ws, ws_bytes, loss, B, N, M, L, s_m, s_n, e_m,
-                                   e_n, 0, mode, chunk, target_ws, stream);
+    // the transform runs inside the prepare step; the fused backward (see below) relies on the
+    // prepare step having cleared G1
+    const RrlXform xf = {src, R, t, transpose_r, rrl_fused_backward(B, N, M) ? 1 : 0};
+    return loss_forward_impl(w.f32(ws, RRL_WS_TRI1), tri2, line, ws, ws_bytes, loss, B, N, M, L, s_m,
+                             s_n, e_m, e_n, 0, mode, chunk, target_ws, &xf, stream);
 }
 
 extern "C" int rrl_registration_forward(const float *src, const float *R, const float *t,
@@ -571,6 +594,16 @@ extern "C" int rrl_registration_backward(const float *src, const float *R, const
     WsLayout w(B, N, M, L);
     if (ws_bytes < w.total) return RRL_E_WS;
     float *g1 = w.f32(ws, RRL_WS_G1);
+    if (rrl_fused_backward(B, N, M)) {
+        // G1 was cleared by the forward's build kernel (and is cleared again by reg_bwd_kernel):
+        // two launches -- scatter of the line gradients, then rigid backward + payload
+        int rc = loss_backward_impl(w.f32(ws, RRL_WS_TRI1), tri2, ws, ws_bytes, grad_loss, g1, nullptr,
+                                    B, N, M, L, 0, false, stream);
+        if (rc) return rc;
+        return rrl_launch_reg_bwd(src, R, g1, grad_src, w.f32(ws, RRL_WS_RPART), gR, gt, payload, loss,
+                                  w.i32(ws, RRL_WS_INFO), w.i32(ws, RRL_WS_STATUS) + 3, B, N, transpose_r,
+                                  (hipStream_t)stream);
+    }
     int rc = rrl_loss_backward(w.f32(ws, RRL_WS_TRI1), tri2, ws, ws_bytes, grad_loss, g1, nullptr, B,
                                N, M, L, 0, stream);
     if (rc) return rc;

@@ -45,7 +45,7 @@ struct WsLayout {
             4 * b * 4,           // INFO
             4 * b * n * 9,       // TRI1
             4 * b * n * 9,       // G1
-            4 * b * 12 * ((3 * n + 16383) / 16384 + 1),  // RPART
+            4 * b * 12 * ((3 * n + 1023) / 1024 + 1),    // RPART
         };
         size_t o = 0;
         for (int i = 0; i < RRL_WS_FIELDS; ++i) {
@@ -62,4 +62,12 @@ struct WsLayout {
     __host__ const float *f32(const void *ws, int f) const { return (const float *)((const char *)ws + off[f]); }
     __host__ const int32_t *i32(const void *ws, int f) const { return (const int32_t *)((const char *)ws + off[f]); }
     __host__ const uint8_t *u8(const void *ws, int f) const { return (const uint8_t *)((const char *)ws + off[f]); }
+};
+
+// Rigid transform of the source cloud folded into the prepare step (the fused training op):
+// tri1 = src moved by (R, t) per sample, stored into the workspace field TRI1.
+struct RrlXform {
+    const float *src, *R, *t;
+    int transpose_r;
+    int zero_g1;  // also clear the gradient accumulator G1 (the fused backward then skips its memset)
 };

@@ -20,7 +20,9 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    # under torchrun (RANK set) the group is created even for one rank, so that a 1-GPU launch
+    # exercises the same RCCL path as N > 1
+    if (world > 1 or "RANK" in os.environ) and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
@@ -59,7 +61,7 @@ def reduce_loss(local_loss, local_valid, shared_grads=(), group=None):
 def reduce_payload(payload, group=None):
     """Sum all-reduce of the 14-float shard payload built by ops.shard_payload (HIP, one launch):
     [loss sum, #valid, sum dR (9), sum dT (3)].  One collective per step."""
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_initialized():
         dist.all_reduce(payload, op=dist.ReduceOp.SUM, group=group)
     return payload
 

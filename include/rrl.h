@@ -56,7 +56,7 @@ extern "C" {
 
 /* workspace fields (indices into rrl_workspace_layout's offset array) */
 enum {
-    RRL_WS_STATUS = 0, /* int32[4]   [0] = NaN seen (reference exit(0), loss.py:89-91)      */
+    RRL_WS_STATUS = 0, /* int32[4]   [0] = NaN seen (reference exit(0), loss.py:89-91); [3] = internal ticket */
     RRL_WS_NVALS,      /* int32[B]   D values appended per sample                           */
     RRL_WS_NSEL,       /* int32[B]   selected lines per sample (length of SEL[b])           */
     RRL_WS_PMAX,       /* uint32[2][B] bits of max |P|^2 per cloud and sample                */

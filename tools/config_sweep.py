@@ -1,0 +1,45 @@
+"""Step time (fused forward + backward, hipGraph replay) at the BASELINE.json configs that are not
+the bench line: C1 demo (B=1, N=M=1024, L=20000), C4 (N=2048, M=1024 cropped), C5 (N=M=16384,
+L=512), plus L=4096 / L=20000 at the C2 shape."""
+import json, os, sys, time
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "a-robust-registration-loss_amd"))
+from rrl_hip import ops, synth
+from rrl_hip.graph import GraphedStep
+from oracle import rrl_oracle as o
+o.build()
+
+def run(name, B, N, M, L, crop=False, noise=0.01):
+    prs = [synth.make_pair(b, N, M, crop=crop, noise=noise) for b in range(B)]
+    lines = np.stack([o.resample_lines(synth.uniform_streams(b, 10, L), p["radius"], p["center"], p["src"], p["tar"], L)
+                      for b, p in enumerate(prs)])
+    src = torch.from_numpy(np.stack([p["src_tri"] for p in prs])).cuda()
+    tar = torch.from_numpy(np.stack([p["tar_tri"] for p in prs])).cuda()
+    ln = torch.from_numpy(lines).cuda()
+    R = torch.eye(3, device="cuda").repeat(B, 1, 1).requires_grad_(True)
+    t = torch.zeros(B, 3, device="cuda").requires_grad_(True)
+    ones = torch.ones(B, device="cuda")
+    def f():
+        R.grad = t.grad = None
+        loss, info, _ = ops.registration_loss(src, R, t, tar, ln)
+        torch.autograd.backward([loss], [ones])
+        return loss, info
+    g = GraphedStep(f)
+    for _ in range(5): g()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    n = 200
+    for _ in range(n): g()
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
+    pairs = B * L * 3 * (N + M)
+    print(json.dumps({"config": name, "B": B, "N": N, "M": M, "L": L, "us_per_step": round(dt * 1e6, 1),
+                      "pairs_per_s": pairs / dt, "selected_lines": int(g.out[1][:, 1].sum()),
+                      "loss0": float(g.out[0][0])}))
+
+run("C1 demo", 1, 1024, 1024, 20000)
+run("C2 bench", 8, 4096, 4096, 10000)
+run("C2 L=4096", 8, 4096, 4096, 4096)
+run("C2 L=20000", 8, 4096, 4096, 20000)
+run("C4 partial overlap", 8, 2048, 1024, 10000, crop=True, noise=0.02)
+run("C5 fragments", 1, 16384, 16384, 512)
+run("C5 fragments B=8", 8, 16384, 16384, 512)
