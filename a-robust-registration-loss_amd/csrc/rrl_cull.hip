@@ -1,27 +1,32 @@
-// rrl_cull.hip -- Morton sort of the prepared triangles and K1 with sphere culling
-// (scan mode RRL_SCAN_CULL).  Compiled with -fno-slp-vectorize: packed fp32 issues at half
-// rate on gfx950, so SLP-packing the all-VGPR exact test only adds register shuffling.
+// rrl_cull.hip -- the build kernel (transform + records + cell sort + group spheres) and K1 with
+// sphere culling (scan mode RRL_SCAN_CULL).  Compiled with -fno-slp-vectorize: packed fp32
+// issues at half rate on gfx950, so SLP-packing the all-VGPR exact test only adds register
+// shuffling (the packed code below is explicit).
 //
 // The full scan evaluates every (line, triangle) pair although only ~6e-4 of them can pass even
 // the first point's test.  Here:
-//   tri_sort_kernel (one 1024-lane workgroup per cloud and sample)
+//   tri_build_kernel (one 1024-lane workgroup per cloud and sample)
 //     orders the triangles by the 16^3 grid cell of P0, cells in Morton order (counting sort
-//     in LDS), and writes, in that order, 16-byte (P0, thr2) records (P0S), their original indices (IDX) and, for every
-//     group of 16 consecutive triangles, a bounding sphere of the P0s: centre c,
-//     rho = max |P0 - c| and the conservative squared radius
+//     in LDS), and writes, in that order, 16-byte (P0, thr2) records (P0S), their original
+//     indices (IDX) and, for every group of 16 consecutive triangles, a bounding sphere of the
+//     P0s: centre c, rho = max |P0 - c| and the conservative squared radius
 //     R2 = ((rho + max thr)^2)(1 + 1e-4) + 1e-7.
-//   cull_scan_kernel (lane = one line in phase 1; every wavefront owns 64 lines and a private
-//   LDS queue, so there is no workgroup synchronisation at all)
-//     phase 1: every lane tests ITS line against each group sphere (wave-uniform sphere, SGPR
-//              operands) with a conservative test; the passing (line, group) pairs of the wave
-//              are appended to its queue by ballot/popcount, group by group;
-//     phase 2: lanes pull pairs from the queue, one per lane and step -- every lane does the
-//              same number of exact evaluations however unevenly the pairs are spread over the
-//              lines -- and run the scan's exact point-0 test (same dist_sq arithmetic,
-//              bit-identical) on the group's 16 triangles.  The queue is group-major, so
-//              neighbouring lanes read the same records and the loads coalesce (no LDS staging
-//              of triangles).  Point-0 passes (~1 in 130 tests) are parked and their points 1, 2
-//              (two dependent global loads) resolved densely afterwards.
+//   cull_scan_kernel (128 lines per workgroup, two per lane; its 8 wavefronts hold the same lines
+//   and split the group range; every wavefront has private LDS queues, so there is no workgroup
+//   synchronisation at all)
+//     phase 1: every lane tests ITS two lines (packed fp32) against each group sphere
+//              (wave-uniform sphere, scalar loads) with a conservative test; each passing
+//              (line, group) pair is written straight to its slot of the batch's entry list
+//              (ballot + mbcnt rank: group-major, no per-lane bit masks to unpack later) and the
+//              group's 16 records are DMA-copied (global_load ... lds) into the wave's LDS rows;
+//     phase 2: when 128 pairs or 12 groups have gathered, the lanes take one pair each per pass
+//              -- every lane does the same number of exact evaluations however unevenly the
+//              pairs are spread over the lines -- and run the scan's exact point-0 test (same
+//              dist_sq arithmetic, bit-identical) on the group's 16 records from LDS.  Point-0
+//              passes (~1 in 130 tests) are parked and their points 1, 2 (two dependent global
+//              loads) resolved densely afterwards.
+//   Measured (B=8, N=M=4096, L=10000): phase 1 alone 30 us, both 65 us; per-wave LDS, the batch
+//   geometry (EB, BGRP) and wavefronts per workgroup were swept on the GPU (tools/knob_sweep.sh).
 //
 // Culling bound (labels can never be lost).  For a line with |dir|^2 <= 1 + 1e-6 and
 // (|x0| + max|P|)^2 <= 100 ("safe", the NaN bound of rrl_scan.hip) let
@@ -279,8 +284,15 @@ __global__ __launch_bounds__(1024) void tri_build_kernel(const BuildArgs a) {
 
 typedef const float __attribute__((address_space(4))) * kptr;  // constant AS -> s_load
 
-#define BGRP 16    // groups per batch: their 16 x 256-byte rows are staged in the wave's LDS
+#ifndef BGRP
+#define BGRP 12    // groups per batch (<= 16: 4-bit slot in an entry): their 16 x 256-byte rows are staged in the wave's LDS
+#endif
+#ifndef WCCAP
 #define WCCAP 256  // parked point-0 candidates per wave (1 KiB)
+#endif
+#ifndef WPB
+#define WPB 8      // wavefronts per workgroup: they split the group range of the block's lines
+#endif
 #define ROWS 17    // float4 per staged row: 16 records + 16 bytes of padding (bank spread)
 
 typedef __attribute__((address_space(3))) void lds_void_t;
@@ -320,80 +332,82 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
 
-// Phase 2 for one batch of a wave: <= 64 (line, group) pairs over <= BGRP groups.  The groups'
-// records are first copied, coalesced, into the wave's LDS rows (slot rotated by the batch slot so
-// lanes on different groups hit different banks); then every lane runs the exact point-0 test of
-// its pair on the 16 triangles.  Point-0 passes (~1 in 130 tests) are parked; their points 1, 2
-// need two dependent global loads and are resolved densely when enough have gathered.
-__device__ __forceinline__ void run_batch(const WaveCtx &c, uint32_t bmask, int nent, int ngrp,
-                                          int &ncand, int lane) {
-    // entries: lane's set bits of bmask (bit k = batch slot k), redistributed over the lanes by a
-    // prefix sum so that every lane evaluates exactly one (line, group) pair
-    {
-        const int mine = __popc(bmask);
-        int pos = wave_incl_scan(mine) - mine;
-        uint32_t m = bmask;
-        while (m) {
-            const int k = __ffs(m) - 1;
-            m &= m - 1;
-            c.ent[pos++] = (unsigned short)((lane << 4) | k);
-        }
-    }
+// Phase 2 for one batch of a wave: <= EB (line, group) pairs over <= BGRP groups, listed
+// group-major in c.ent (phase 1 writes every pair at its final position).  The groups' records
+// were copied, coalesced, into the wave's LDS rows (row stride padded so lanes on different
+// groups hit different banks); every lane runs the exact point-0 test of one pair on the 16
+// triangles.  Point-0 passes (~1 in 130 tests) are parked; their points 1, 2 need two dependent
+// global loads and are resolved densely when enough have gathered.
+#ifndef EB
+#define EB 128  // entries per batch (two passes of 64 lanes)
+#endif
+
+__device__ __forceinline__ void run_batch(const WaveCtx &c, int nent, int &ncand, int lane) {
     // the rows of this batch were requested (global -> LDS DMA) as their groups were appended in
     // phase 1; wait for the stragglers
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     wave_lds_fence();
-    uint32_t passbits = 0;
-    int ll = 0, g = 0;
-    if (lane < nent) {
-        const unsigned e = c.ent[lane];
-        ll = e >> 4;
-        const int k = e & 15;
-        g = c.bgrp[k];
-        const float4 la = c.lines[2 * ll], lb = c.lines[2 * ll + 1];
-        const float4 *row = c.rows + k * ROWS;
+#ifdef CULL_SKIP_PHASE2  // timing experiment only: batches are formed but not evaluated
+    return;
+#endif
+    for (int e0 = 0; e0 < nent; e0 += 64) {  // one pass unless a group is hit by > 64 of the lines
+        uint32_t passbits = 0;
+        int ll = 0, g = 0;
+        if (e0 + lane < nent) {
+            const unsigned e = c.ent[e0 + lane];
+            ll = e >> 4;
+            const int k = e & 15;
+            g = c.bgrp[k];
+            const float4 la = c.lines[2 * ll], lb = c.lines[2 * ll + 1];
+            const float4 *row = c.rows + k * ROWS;
 #pragma unroll
-        for (int t = 0; t < GRP; ++t) {
-            const float4 rec = row[t];
-            const float x = dist_sq<float>(rec.x, rec.y, rec.z, la.x, la.y, la.z, la.w, lb.x, lb.y);
-            passbits |= (__float_as_uint(x) < __float_as_uint(rec.w) ? 1u : 0u) << t;
+            for (int t = 0; t < GRP; ++t) {
+                const float4 rec = row[t];
+                const float x = dist_sq<float>(rec.x, rec.y, rec.z, la.x, la.y, la.z, la.w, lb.x, lb.y);
+                passbits |= (__float_as_uint(x) < __float_as_uint(rec.w) ? 1u : 0u) << t;
+            }
         }
-    }
-    while (__any(passbits != 0)) {
-        const bool has = passbits != 0;
-        const unsigned long long m = __ballot(has);
-        const int t = has ? __ffs(passbits) - 1 : 0;
-        passbits &= passbits - 1;
-        const int pos = ncand + __popcll(m & ((1ull << lane) - 1ull));
-        const unsigned cand = ((unsigned)ll << 16) | (unsigned)(g * GRP + t);
-        if (has) {
-            if (pos < WCCAP) c.cands[pos] = cand;
-            else resolve_candidate(c, cand);
+        while (__any(passbits != 0)) {
+            const bool has = passbits != 0;
+            const unsigned long long m = __ballot(has);
+            const int t = has ? __ffs(passbits) - 1 : 0;
+            passbits &= passbits - 1;
+            const int pos = ncand + __popcll(m & ((1ull << lane) - 1ull));
+            const unsigned cand = ((unsigned)ll << 16) | (unsigned)(g * GRP + t);
+            if (has) {
+                if (pos < WCCAP) c.cands[pos] = cand;
+                else resolve_candidate(c, cand);
+            }
+            ncand += __popcll(m);
         }
-        ncand += __popcll(m);
-    }
-    if (ncand > WCCAP - 64) {  // uniform: keep room for the next batch
-        wave_lds_fence();
-        const int nc = min(ncand, WCCAP);
-        for (int i = lane; i < nc; i += 64) resolve_candidate(c, c.cands[i]);
-        ncand = 0;
+        if (ncand > WCCAP - 64) {  // uniform: keep room for the next pass
+            wave_lds_fence();
+            const int nc = min(ncand, WCCAP);
+            for (int i = lane; i < nc; i += 64) resolve_candidate(c, c.cands[i]);
+            ncand = 0;
+        }
     }
 }
 
-// 256 lines per workgroup, but every wavefront works on its own 64 lines with private LDS: after
-// the one barrier of the tile-safety vote there is no workgroup synchronisation.
-__global__ __launch_bounds__(256) void cull_scan_kernel(
+// LPB lines per workgroup (two per lane: packed fp32 in phase 1, and the wave-uniform work of the
+// group loop -- scalar loads, ballots, batch bookkeeping -- is shared by 128 lines).  The four
+// wavefronts hold the SAME lines and split the GROUP range between them, which quadruples the
+// number of independent (latency-bound) wavefronts; each has private LDS queues, so there is no
+// workgroup synchronisation at all.
+#define LPB 128
+
+__global__ __launch_bounds__(64 * WPB) void cull_scan_kernel(
     const float *__restrict__ ptri1, const float *__restrict__ ptri2, const float4 *__restrict__ p0s1,
     const float4 *__restrict__ p0s2, const int32_t *__restrict__ idx1, const int32_t *__restrict__ idx2,
     const float4 *__restrict__ grp1, const float4 *__restrict__ grp2, const float *__restrict__ line,
     int32_t *__restrict__ count1, int32_t *__restrict__ hit1, int32_t *__restrict__ count2,
     int32_t *__restrict__ hit2, int32_t *__restrict__ status, const uint32_t *__restrict__ pmax, int B,
     int N, int M, int L) {
-    __shared__ __attribute__((aligned(16))) float4 lines_lds[4][64][2];    // 8 KiB
-    __shared__ __attribute__((aligned(16))) float4 rows_lds[4][BGRP * ROWS];  // 17 KiB
-    __shared__ unsigned cands_lds[4][WCCAP];                               // 4 KiB
-    __shared__ unsigned short ent_lds[4][64];
-    __shared__ int bgrp_lds[4][BGRP];
+    __shared__ __attribute__((aligned(16))) float4 lines_lds[LPB][2];      // 4 KiB, same in all 4 waves
+    __shared__ __attribute__((aligned(16))) float4 rows_lds[WPB][BGRP * ROWS];  // 17 KiB
+    __shared__ unsigned cands_lds[WPB][WCCAP];                             // 4 KiB
+    __shared__ unsigned short ent_lds[WPB][LPB];
+    __shared__ int bgrp_lds[WPB][BGRP];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform for the compiler
     const int z = blockIdx.y, cloud = z >= B ? 1 : 0, b = z - cloud * B;
@@ -402,81 +416,98 @@ __global__ __launch_bounds__(256) void cull_scan_kernel(
     const float4 *grp = (cloud ? grp2 : grp1) + (size_t)b * ng;
     const float *ln = line + (size_t)b * L * 6;
 
-    // 64 lines per workgroup; the four wavefronts split the GROUP range between them, which
-    // quadruples the number of independent (latency-bound) wavefronts.
-    const int l = blockIdx.x * 64 + lane;
-    float v[6];
+    const int l0 = blockIdx.x * LPB + lane, l1 = l0 + 64;
+    const bool live0 = l0 < L, live1 = l1 < L;
+    float v0[6], v1[6];
 #pragma unroll
-    for (int c = 0; c < 6; ++c) v[c] = l < L ? ln[6 * (size_t)l + c] : 0.0f;
-    lines_lds[wave][lane][0] = make_float4(v[0], v[1], v[2], v[3]);
-    lines_lds[wave][lane][1] = make_float4(v[4], v[5], 0.0f, 0.0f);
-    const float ux = v[0], uy = v[1], uz = v[2], ox = v[3], oy = v[4], oz = v[5];
-    const bool live = l < L;
+    for (int c = 0; c < 6; ++c) {
+        v0[c] = live0 ? ln[6 * (size_t)l0 + c] : 0.0f;
+        v1[c] = live1 ? ln[6 * (size_t)l1 + c] : 0.0f;
+    }
+    // every wavefront stores the same lines: identical values, so no barrier is needed
+    lines_lds[lane][0] = make_float4(v0[0], v0[1], v0[2], v0[3]);
+    lines_lds[lane][1] = make_float4(v0[4], v0[5], 0.0f, 0.0f);
+    lines_lds[64 + lane][0] = make_float4(v1[0], v1[1], v1[2], v1[3]);
+    lines_lds[64 + lane][1] = make_float4(v1[4], v1[5], 0.0f, 0.0f);
 
     // Culling (and the lazy evaluation of points 1, 2) is only exact for lines that satisfy the
-    // NaN-impossibility bound.  All four wavefronts hold the same 64 lines, so the vote is
-    // wave-local and uniform over the workgroup: a block with an offending line evaluates ALL
-    // its (line, triangle) pairs strictly instead -- the reference's semantics, NaN included.
-    if (!__all(rrl_line_safe(v, __uint_as_float(pmax[cloud * B + b])))) {
+    // NaN-impossibility bound.  All four wavefronts hold the same lines, so the vote is wave-local
+    // and uniform over the workgroup: a block with an offending line evaluates ALL its
+    // (line, triangle) pairs strictly instead -- the reference's semantics, NaN included.
+    const float pm = __uint_as_float(pmax[cloud * B + b]);
+    if (!__all(rrl_line_safe(v0, pm) && rrl_line_safe(v1, pm))) {
         kptr tp = (kptr)(uintptr_t)((cloud ? ptri2 : ptri1) + (size_t)b * n * PTRI_STRIDE);
         int32_t *cnt = (cloud ? count2 : count1) + (size_t)b * L;
         int32_t *hit = (cloud ? hit2 : hit1) + (size_t)b * L * RRL_MAX_HITS;
-        const int tq = (n + 3) / 4, t1 = min(n, (wave + 1) * tq);
+        const int tq = (n + WPB - 1) / WPB, t1 = min(n, (wave + 1) * tq);
         uint32_t nanacc = 0;
         tp += (size_t)wave * tq * PTRI_STRIDE;
         for (int t = wave * tq; t < t1; ++t, tp += PTRI_STRIDE) {
             const uint32_t thr2 = __float_as_uint(tp[9]);
-            const uint32_t x0 = __float_as_uint(dist_sq<float>(tp[0], tp[1], tp[2], ux, uy, uz, ox, oy, oz));
-            const uint32_t x1 = __float_as_uint(dist_sq<float>(tp[3], tp[4], tp[5], ux, uy, uz, ox, oy, oz));
-            const uint32_t x2 = __float_as_uint(dist_sq<float>(tp[6], tp[7], tp[8], ux, uy, uz, ox, oy, oz));
-            const uint32_t mm = max(max(x0, x1), x2);  // negative or NaN: sign bit set -> huge
-            nanacc = max(nanacc, mm);
-            if (live && mm < thr2) {
-                const int pos = atomicAdd(&cnt[l], 1);
-                if (pos < RRL_MAX_HITS) hit[(size_t)l * RRL_MAX_HITS + pos] = __float_as_int(tp[11]);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float *v = h ? v1 : v0;
+                const int l = h ? l1 : l0;
+                const uint32_t x0 = __float_as_uint(dist_sq<float>(tp[0], tp[1], tp[2], v[0], v[1], v[2], v[3], v[4], v[5]));
+                const uint32_t x1 = __float_as_uint(dist_sq<float>(tp[3], tp[4], tp[5], v[0], v[1], v[2], v[3], v[4], v[5]));
+                const uint32_t x2 = __float_as_uint(dist_sq<float>(tp[6], tp[7], tp[8], v[0], v[1], v[2], v[3], v[4], v[5]));
+                const uint32_t mm = max(max(x0, x1), x2);  // negative or NaN: sign bit set -> huge
+                if (l < L) {
+                    nanacc = max(nanacc, mm);
+                    if (mm < thr2) {
+                        const int pos = atomicAdd(&cnt[l], 1);
+                        if (pos < RRL_MAX_HITS) hit[(size_t)l * RRL_MAX_HITS + pos] = __float_as_int(tp[11]);
+                    }
+                }
             }
         }
-        if (live && nanacc >= 0x80000000u) atomicOr(&status[0], 1);
+        if (nanacc >= 0x80000000u) atomicOr(&status[0], 1);
         return;
     }
 
     WaveCtx ctx;
-    ctx.lines = &lines_lds[wave][0][0];
+    ctx.lines = &lines_lds[0][0];
     ctx.p0s = (cloud ? p0s2 : p0s1) + (size_t)b * ng * GRP;
     ctx.idx = (cloud ? idx2 : idx1) + (size_t)b * ng * GRP;
     ctx.ptri = (cloud ? ptri2 : ptri1) + (size_t)b * n * PTRI_STRIDE;
     ctx.cnt = (cloud ? count2 : count1) + (size_t)b * L;
     ctx.hit = (cloud ? hit2 : hit1) + (size_t)b * L * RRL_MAX_HITS;
-    ctx.lbase = blockIdx.x * 64;
+    ctx.lbase = blockIdx.x * LPB;
     ctx.rows = rows_lds[wave];
     ctx.ent = ent_lds[wave];
     ctx.bgrp = bgrp_lds[wave];
     ctx.cands = cands_lds[wave];
 
-    // ---- phase 1: conservative sphere test of every group; passing (line, group) pairs are
-    //      collected by ballot/popcount into batches that phase 2 consumes at once
+    // ---- phase 1: conservative sphere test of every group against the lane's two lines (packed
+    //      fp32); passing (line, group) pairs are collected by ballot/popcount into batches that
+    //      phase 2 consumes at once
+    const v2f ux = {v0[0], v1[0]}, uy = {v0[1], v1[1]}, uz = {v0[2], v1[2]};
+    const v2f ox = {v0[3], v1[3]}, oy = {v0[4], v1[4]}, oz = {v0[5], v1[5]};
     int nent = 0, ngrp = 0, ncand = 0;  // wave-uniform
-    uint32_t bmask = 0;                 // per lane: bit k = this line passes batch slot k
     kptr gp = (kptr)(uintptr_t)grp;
-    const int gq = (ng + 3) / 4;
+    const int gq = (ng + WPB - 1) / WPB;
     const int gend = min(ng, (wave + 1) * gq);
     for (int g = wave * gq; g < gend; ++g) {
         const float cx = gp[4 * g], cy = gp[4 * g + 1], cz = gp[4 * g + 2], R2 = gp[4 * g + 3];
-        float ax = cx - ox, ay = cy - oy, az = cz - oz;
-        float dot = fmaf(az, uz, fmaf(ay, uy, ax * ux));
-        float q = fmaf(az, az, fmaf(ay, ay, ax * ax));
-        float d2 = fmaf(-dot, dot, q);
-        d2 = fmaf(-4e-6f, q, d2);
-        const bool pass = live && d2 <= R2;
-        const unsigned long long m = __ballot(pass);
-        if (m) {
-            const int c = __popcll(m);
-            if (nent + c > 64 || ngrp == BGRP) {  // uniform: the batch is full
-                run_batch(ctx, bmask, nent, ngrp, ncand, lane);
+        const v2f ax = cx - ox, ay = cy - oy, az = cz - oz;
+        const v2f dot = __builtin_elementwise_fma(az, uz, __builtin_elementwise_fma(ay, uy, ax * ux));
+        const v2f q = __builtin_elementwise_fma(az, az, __builtin_elementwise_fma(ay, ay, ax * ax));
+        v2f d2 = __builtin_elementwise_fma(-dot, dot, q);
+        d2 = __builtin_elementwise_fma((v2f){-4e-6f, -4e-6f}, q, d2);
+        const bool pass0 = live0 && d2.x <= R2, pass1 = live1 && d2.y <= R2;
+        const unsigned long long m0 = __ballot(pass0), m1 = __ballot(pass1);
+        if (m0 | m1) {
+            const int c0 = __popcll(m0), c = c0 + __popcll(m1);
+            if (nent + c > EB || ngrp == BGRP) {  // uniform: the batch is full
+                run_batch(ctx, nent, ncand, lane);
                 nent = ngrp = 0;
-                bmask = 0;
             }
-            bmask |= (pass ? 1u : 0u) << ngrp;
+            // every passing (line, group) pair goes straight to its slot of the batch's entry
+            // list: group-major, lines in lane order (rank among the passing lanes by mbcnt)
+            if (pass0) ctx.ent[nent + __builtin_amdgcn_mbcnt_hi((unsigned)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m0, 0u))] =
+                (unsigned short)((lane << 4) | ngrp);
+            if (pass1) ctx.ent[nent + c0 + __builtin_amdgcn_mbcnt_hi((unsigned)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m1, 0u))] =
+                (unsigned short)(((64 + lane) << 4) | ngrp);
             if (lane == 0) ctx.bgrp[ngrp] = g;
             // asynchronous copy of the group's 16 records into LDS row `ngrp` (lanes 0..15, 16 B
             // each; the DMA writes wave-uniform base + lane * 16)
@@ -487,7 +518,7 @@ __global__ __launch_bounds__(256) void cull_scan_kernel(
             ++ngrp;
         }
     }
-    if (nent) run_batch(ctx, bmask, nent, ngrp, ncand, lane);
+    if (nent) run_batch(ctx, nent, ncand, lane);
     wave_lds_fence();
     const int nc = min(ncand, WCCAP);
     for (int i = lane; i < nc; i += 64) resolve_candidate(ctx, ctx.cands[i]);
@@ -531,7 +562,7 @@ int rrl_launch_tri_build(const float *tri1, const float *tri2, void *ws, const W
 
 int rrl_launch_cull_scan(const float *line, void *ws, const WsLayout &w, int B, int N, int M, int L,
                          int clouds, hipStream_t s) {
-    hipLaunchKernelGGL(cull_scan_kernel, dim3((unsigned)((L + 63) / 64), (unsigned)(clouds * B)), dim3(256), 0,
+    hipLaunchKernelGGL(cull_scan_kernel, dim3((unsigned)((L + LPB - 1) / LPB), (unsigned)(clouds * B)), dim3(64 * WPB), 0,
                        s, w.f32(ws, RRL_WS_PTRI1), w.f32(ws, RRL_WS_PTRI2),
                        (const float4 *)w.f32(ws, RRL_WS_P0S1), (const float4 *)w.f32(ws, RRL_WS_P0S2),
                        w.i32(ws, RRL_WS_IDX1), w.i32(ws, RRL_WS_IDX2), (const float4 *)w.f32(ws, RRL_WS_GRP1),

@@ -39,6 +39,7 @@ def build_lib(force=False, verbose=False):
     for src in SOURCES:
         obj = os.path.join(LIBDIR, src.replace(".hip", ".o"))
         extra = ["-fno-slp-vectorize"] if src == "rrl_cull.hip" else []  # see the file header
+        extra += os.environ.get("RRL_HIPCC_FLAGS", "").split()  # experiments: -DNAME=value knobs
         cmd = [_hipcc(), *FLAGS, *extra, "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
