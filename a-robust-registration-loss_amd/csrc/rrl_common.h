@@ -80,7 +80,6 @@ __device__ __forceinline__ bool rrl_line_safe(const float *v, float pm) {
     return (s <= 1.000001f) && (a2 <= 100.0f);
 }
 
-#define RRL_SCAN_UNSAFE_TILES 4  // internal: strict loop, only for 512-line tiles that fail the bound
 
 // ---- wave64 cross-lane helpers on DPP (no LDS crossbar: ds_bpermute-based __shfl trees cost
 //      hundreds of cycles per step under load, DPP steps cost one VALU issue each) ----------

@@ -58,79 +58,66 @@ __device__ __forceinline__ int p0s_slot(int s) { return s; }  // records in sort
 
 #define SORT_CELLS 4096  // 16^3 grid cells in Morton order
 
-// tri_build_kernel: everything the scans need from the raw triangles, one 1024-lane workgroup
-// per cloud and sample, ONE launch (it replaces rigid apply + tri_prepare + tri_sort):
-//   * optionally moves the source cloud by its rigid transform (the fused training op) and
-//     stores the moved triangles (TRI1) for the later stages and the backward;
-//   * thresholds (thr, thr2) and the 48-byte prepared records (PTRI) in original order;
-//   * clears the per-call state of the workspace (and the gradient accumulator G1);
-//   * counting sort by the 16^3 grid cell of P0, cells in Morton order (the order inside a cell
+// The build step: everything the scans need from the raw triangles, in two launches.
+//   tri_records_kernel (wide: one lane per triangle, 256-lane workgroups over both clouds)
+//     * optionally moves the source cloud by its rigid transform (the fused training op) and
+//       stores the moved triangles (TRI1) for the later stages and the backward;
+//     * thresholds (thr, thr2), the 48-byte prepared records (PTRI) in original order and a
+//       compact 16-byte (P0, thr2) record (CREC) for the sort;
+//     * per-workgroup partial AABB of the P0s and max |P|^2 (APART);
+//     * clears the per-call state of the workspace (and the gradient accumulator G1).
+//   tri_sort_kernel (one 1024-lane workgroup per cloud and sample; reads only CREC: one
+//   workgroup's memory pipe is the bottleneck here, so it touches 16 bytes per triangle)
+//     counting sort by the 16^3 grid cell of P0, cells in Morton order (the order inside a cell
 //     is arbitrary: it only shapes the groups, never the result), group spheres, max |P|^2.
-// NPT > 0: every lane keeps its <= NPT triangles' (P0, thr2, thr) in registers between the
-// passes (n <= 1024 NPT); NPT == 0: they are re-read from the records the lane itself wrote.
 struct BuildArgs {
     const float *tri1, *tri2;      // raw triangles [B][n][9]; tri1 = source BEFORE the transform
     const float *R, *t;            // per-sample transform of cloud 0, or NULL
     float *tri1_out;               // moved source triangles (TRI1), when R != NULL
     float *ptri1, *ptri2;
+    float4 *crec1, *crec2;         // unsorted (P0, thr2)
+    float *apart;                  // [clouds][B][nblk][8]: min xyz, max xyz, max |P|^2, pad
     float4 *p0s1, *p0s2;
     int32_t *idx1, *idx2;
     float4 *grp1, *grp2;
     uint32_t *pmax;
-    uint4 *zero_base;              // per-call state: [0, zero_vec4) except [skip_lo, skip_hi)
-    size_t zero_vec4, skip_lo, skip_hi;
+    uint4 *zero_base;              // per-call state: [0, zero_vec4)
+    size_t zero_vec4;
     uint4 *g1;                     // gradient accumulator to clear (may be NULL)
     size_t g1_vec4;
-    int B, N, M, transpose_r;
+    int B, N, M, transpose_r, nblk;
 };
 
-template <int NPT>
-__global__ __launch_bounds__(1024) void tri_build_kernel(const BuildArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float thr_s[];  // thr by sorted position
-    __shared__ unsigned hist[SORT_CELLS];
-    __shared__ float red[16][8];
-    __shared__ unsigned wsum[16];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int B = a.B;
-    const int cloud = blockIdx.x >= (unsigned)B ? 1 : 0, b = blockIdx.x - cloud * B;
-    const int n = cloud ? a.M : a.N;
-    const float *raw = (cloud ? a.tri2 : a.tri1) + (size_t)b * n * 9;
-    float *ptri = (cloud ? a.ptri2 : a.ptri1) + (size_t)b * n * PTRI_STRIDE;
-    const int ng = (n + GRP - 1) / GRP;
-    float4 *p0s = (cloud ? a.p0s2 : a.p0s1) + (size_t)b * ng * GRP;
-    int32_t *idx = (cloud ? a.idx2 : a.idx1) + (size_t)b * ng * GRP;
-    float4 *grp = (cloud ? a.grp2 : a.grp1) + (size_t)b * ng;
+#define REC_BLK 256
 
+__global__ __launch_bounds__(REC_BLK) void tri_records_kernel(const BuildArgs a) {
+    __shared__ float red[REC_BLK / 64][8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cloud = blockIdx.z, b = blockIdx.y, B = a.B;
     {   // per-call state and gradient accumulator, spread over all workgroups of the launch
-        const size_t nthr = (size_t)gridDim.x * 1024, me = (size_t)blockIdx.x * 1024 + tid;
+        const size_t nthr = (size_t)gridDim.x * gridDim.y * gridDim.z * REC_BLK;
+        const size_t me = (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * REC_BLK + tid;
         const uint4 z = make_uint4(0, 0, 0, 0);
-        for (size_t i = me; i < a.zero_vec4; i += nthr)
-            if (i < a.skip_lo || i >= a.skip_hi) a.zero_base[i] = z;
+        for (size_t i = me; i < a.zero_vec4; i += nthr) a.zero_base[i] = z;
         for (size_t i = me; i < a.g1_vec4; i += nthr) a.g1[i] = z;
     }
-
-    const bool xf = cloud == 0 && a.R != nullptr;
-    float m[9], tv[3];
-    if (xf) {
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int j = 0; j < 3; ++j)  // m[i*3+j] multiplies x_i into y_j (rigid_fwd_kernel)
-                m[i * 3 + j] = a.transpose_r ? a.R[b * 9 + j * 3 + i] : a.R[b * 9 + i * 3 + j];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) tv[j] = a.t[b * 3 + j];
-    }
-    float *moved = xf ? a.tri1_out + (size_t)b * n * 9 : nullptr;
-
-    // ---- pass 1: transform, thresholds, records; AABB of the P0s and max |P|^2
-    constexpr int NR = NPT > 0 ? NPT : 1;
-    float rx[NR], ry[NR], rz[NR], rt2[NR], rth[NR];
+    const int n = cloud ? a.M : a.N;
+    const int f = blockIdx.x * REC_BLK + tid;
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY}, p2 = 0.0f;
-    auto pass1 = [&](int f, int k) {
+    if (f < n) {
+        const float *raw = (cloud ? a.tri2 : a.tri1) + ((size_t)b * n + f) * 9;
         float c[9], thr, x;
 #pragma unroll
-        for (int i = 0; i < 9; ++i) c[i] = raw[9 * (size_t)f + i];
-        if (xf) {
+        for (int i = 0; i < 9; ++i) c[i] = raw[i];
+        if (cloud == 0 && a.R != nullptr) {
+            float m[9], tv[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j)  // m[i*3+j] multiplies x_i into y_j (rigid_fwd_kernel)
+                    m[i * 3 + j] = a.transpose_r ? a.R[b * 9 + j * 3 + i] : a.R[b * 9 + i * 3 + j];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) tv[j] = a.t[b * 3 + j];
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
                 const float v0 = c[3 * q], v1 = c[3 * q + 1], v2 = c[3 * q + 2];
@@ -138,31 +125,25 @@ __global__ __launch_bounds__(1024) void tri_build_kernel(const BuildArgs a) {
                 for (int j = 0; j < 3; ++j)
                     c[3 * q + j] = fmaf(v2, m[6 + j], fmaf(v1, m[3 + j], v0 * m[j])) + tv[j];
             }
+            float *moved = a.tri1_out + ((size_t)b * n + f) * 9;
 #pragma unroll
-            for (int i = 0; i < 9; ++i) moved[9 * (size_t)f + i] = c[i];
+            for (int i = 0; i < 9; ++i) moved[i] = c[i];
         }
         tri_thresholds(c, &thr, &x);  // code/loss.py:94-110
-        float4 *row = (float4 *)(ptri + PTRI_STRIDE * (size_t)f);
+        float4 *row = (float4 *)((cloud ? a.ptri2 : a.ptri1) + ((size_t)b * n + f) * PTRI_STRIDE);
         row[0] = make_float4(c[0], c[1], c[2], c[3]);
         row[1] = make_float4(c[4], c[5], c[6], c[7]);
         row[2] = make_float4(c[8], x, thr, __int_as_float(f));
+        const int ngp = (n + GRP - 1) / GRP * GRP;
+        ((cloud ? a.crec2 : a.crec1) + (size_t)b * ngp)[f] = make_float4(c[0], c[1], c[2], x);
 #pragma unroll
-        for (int d = 0; d < 3; ++d) { mn[d] = fminf(mn[d], c[d]); mx[d] = fmaxf(mx[d], c[d]); }
+        for (int d = 0; d < 3; ++d) { mn[d] = c[d]; mx[d] = c[d]; }
 #pragma unroll
         for (int q = 0; q < 3; ++q)
             p2 = fmaxf(p2, c[3 * q] * c[3 * q] + c[3 * q + 1] * c[3 * q + 1] + c[3 * q + 2] * c[3 * q + 2]);
-        if (NPT > 0) { rx[k] = c[0]; ry[k] = c[1]; rz[k] = c[2]; rt2[k] = x; rth[k] = thr; }
-    };
-    if (NPT > 0) {
-#pragma unroll
-        for (int k = 0; k < NR; ++k) {
-            const int f = tid + 1024 * k;
-            if (f < n) pass1(f, k);
-        }
-    } else {
-        for (int f = tid; f < n; f += 1024) pass1(f, 0);
+        if (!(p2 <= 3.0e38f)) p2 = INFINITY;  // NaN/inf coordinates: never "provably safe"
     }
-    if (!(p2 <= 3.0e38f)) p2 = INFINITY;  // NaN/inf coordinates: never "provably safe"
+    if (blockIdx.x * REC_BLK >= n) return;  // uniform: this workgroup has no triangle of the cloud
 #pragma unroll
     for (int c = 0; c < 3; ++c) { mn[c] = wave_min(mn[c]); mx[c] = wave_max(mx[c]); }
     p2 = wave_max(p2);
@@ -170,6 +151,59 @@ __global__ __launch_bounds__(1024) void tri_build_kernel(const BuildArgs a) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) { red[wave][c] = mn[c]; red[wave][3 + c] = mx[c]; }
         red[wave][6] = p2;
+    }
+    __syncthreads();
+    if (tid < 7) {
+        float r = red[0][tid];
+        for (int w = 1; w < REC_BLK / 64; ++w) r = tid < 3 ? fminf(r, red[w][tid]) : fmaxf(r, red[w][tid]);
+        a.apart[(((size_t)cloud * B + b) * a.nblk + blockIdx.x) * 8 + tid] = r;
+    }
+}
+
+// NPT > 0: every lane keeps its <= NPT records in registers between the passes (n <= 1024 NPT);
+// NPT == 0: they are re-read (16 B per triangle).
+template <int NPT>
+__global__ __launch_bounds__(1024) void tri_sort_kernel(const BuildArgs a) {
+    // NPT > 0: the sorted records stay in LDS for the sphere pass ([ng*16] float4);
+    // NPT == 0: only the thr bound by sorted position ([ng*16] float), records re-read from P0S
+    extern __shared__ __attribute__((aligned(16))) float dyn_s[];
+    float *thr_s = dyn_s;
+    float4 *srec = (float4 *)dyn_s;
+    __shared__ unsigned hist[SORT_CELLS];
+    __shared__ float red[16][8];
+    __shared__ unsigned wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int B = a.B;
+    const int cloud = blockIdx.x >= (unsigned)B ? 1 : 0, b = blockIdx.x - cloud * B;
+    const int n = cloud ? a.M : a.N;
+    const int ng = (n + GRP - 1) / GRP;
+    const float4 *crec = (cloud ? a.crec2 : a.crec1) + (size_t)b * ng * GRP;
+    float4 *p0s = (cloud ? a.p0s2 : a.p0s1) + (size_t)b * ng * GRP;
+    int32_t *idx = (cloud ? a.idx2 : a.idx1) + (size_t)b * ng * GRP;
+    float4 *grp = (cloud ? a.grp2 : a.grp1) + (size_t)b * ng;
+
+    // ---- AABB of the P0s and max |P|^2 from the per-workgroup partials of tri_records_kernel
+    constexpr int NR = NPT > 0 ? NPT : 1;
+    float4 rec[NR];
+    if (NPT > 0) {  // issue the record loads first: they overlap the reduction
+#pragma unroll
+        for (int k = 0; k < NR; ++k)
+            if (tid + 1024 * k < n) rec[k] = crec[tid + 1024 * k];
+    }
+    {
+        const int nb = (n + REC_BLK - 1) / REC_BLK;
+        const float *ap = a.apart + ((size_t)cloud * B + b) * a.nblk * 8;
+        float v[7];
+#pragma unroll
+        for (int c = 0; c < 7; ++c) v[c] = c < 3 ? INFINITY : (c < 6 ? -INFINITY : 0.0f);
+        for (int j = tid; j < nb; j += 1024)
+#pragma unroll
+            for (int c = 0; c < 7; ++c) v[c] = c < 3 ? fminf(v[c], ap[j * 8 + c]) : fmaxf(v[c], ap[j * 8 + c]);
+#pragma unroll
+        for (int c = 0; c < 7; ++c) v[c] = c < 3 ? wave_min(v[c]) : wave_max(v[c]);
+        if (lane == 0)
+#pragma unroll
+            for (int c = 0; c < 7; ++c) red[wave][c] = v[c];
     }
     for (int i = tid; i < SORT_CELLS; i += 1024) hist[i] = 0;
     __syncthreads();
@@ -180,15 +214,15 @@ __global__ __launch_bounds__(1024) void tri_build_kernel(const BuildArgs a) {
     }
     __syncthreads();
     if (tid == 0) a.pmax[cloud * B + b] = __float_as_uint(red[0][6]);
-    float scale[3];
+    float mn[3], scale[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         mn[c] = red[0][c];
         float ext = red[0][3 + c] - mn[c];
         scale[c] = ext > 0.0f && ext < 3.0e38f ? 15.999f / ext : 0.0f;
     }
-    auto cell_of = [&](float px, float py, float pz) -> unsigned {
-        const float p[3] = {px, py, pz};
+    auto cell_of = [&](const float4 r) -> unsigned {
+        const float p[3] = {r.x, r.y, r.z};
         unsigned q[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -203,12 +237,9 @@ __global__ __launch_bounds__(1024) void tri_build_kernel(const BuildArgs a) {
     if (NPT > 0) {
 #pragma unroll
         for (int k = 0; k < NR; ++k)
-            if (tid + 1024 * k < n) { cell[k] = cell_of(rx[k], ry[k], rz[k]); atomicAdd(&hist[cell[k]], 1u); }
+            if (tid + 1024 * k < n) { cell[k] = cell_of(rec[k]); atomicAdd(&hist[cell[k]], 1u); }
     } else {
-        for (int f = tid; f < n; f += 1024) {
-            const float *p = ptri + PTRI_STRIDE * (size_t)f;
-            atomicAdd(&hist[cell_of(p[0], p[1], p[2])], 1u);
-        }
+        for (int f = tid; f < n; f += 1024) atomicAdd(&hist[cell_of(crec[f])], 1u);
     }
     __syncthreads();
     {
@@ -225,39 +256,41 @@ __global__ __launch_bounds__(1024) void tri_build_kernel(const BuildArgs a) {
         for (int k = 0; k < 4; ++k) { hist[4 * tid + k] = run; run += h[k]; }
     }
     __syncthreads();
+    // thr <= sqrtf(thr2) (1 + 2^-22): thr2 is the smallest float whose rounded root reaches thr
+    auto thr_bound = [](float thr2) { return sqrtf(thr2) * 1.000001f; };
     if (NPT > 0) {
 #pragma unroll
         for (int k = 0; k < NR; ++k) {
             const int f = tid + 1024 * k;
             if (f < n) {
                 const int s = (int)atomicAdd(&hist[cell[k]], 1u);
-                p0s[s] = make_float4(rx[k], ry[k], rz[k], rt2[k]);
+                p0s[s] = rec[k];
                 idx[s] = f;
-                thr_s[s] = rth[k];
+                srec[s] = rec[k];
             }
         }
     } else {
         for (int f = tid; f < n; f += 1024) {
-            const float *p = ptri + PTRI_STRIDE * (size_t)f;
-            const int s = (int)atomicAdd(&hist[cell_of(p[0], p[1], p[2])], 1u);
-            p0s[s] = make_float4(p[0], p[1], p[2], p[9]);
+            const float4 r = crec[f];
+            const int s = (int)atomicAdd(&hist[cell_of(r)], 1u);
+            p0s[s] = r;
             idx[s] = f;
-            thr_s[s] = p[10];
+            thr_s[s] = thr_bound(r.w);
         }
     }
     for (int s = n + tid; s < ng * GRP; s += 1024) {  // pad: thr2 = 0 never passes
         p0s[s] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         idx[s] = 0;
-        thr_s[s] = 0.0f;
+        if (NPT > 0) srec[s] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); else thr_s[s] = 0.0f;
     }
     __syncthreads();  // the block's own global stores are visible to it after the barrier
 
     // ---- group spheres (16 consecutive lanes = one group)
     for (int s = tid; s < ng * GRP; s += 1024) {
         const bool valid = s < n;
-        const float4 r4 = p0s[s];
+        const float4 r4 = NPT > 0 ? srec[s] : p0s[s];
         const float c[3] = {r4.x, r4.y, r4.z};
-        float lo[3], hi[3], tm = thr_s[s];
+        float lo[3], hi[3], tm = NPT > 0 ? thr_bound(r4.w) : thr_s[s];
 #pragma unroll
         for (int d = 0; d < 3; ++d) { lo[d] = valid ? c[d] : INFINITY; hi[d] = valid ? c[d] : -INFINITY; }
 #pragma unroll
@@ -528,7 +561,7 @@ __global__ __launch_bounds__(64 * WPB) void cull_scan_kernel(
 int rrl_launch_tri_build(const float *tri1, const float *tri2, void *ws, const WsLayout &w, int B,
                          int N, int M, int clouds, const RrlXform *xf, hipStream_t s) {
     const int nmax = clouds == 2 && M > N ? M : N;
-    const size_t lds = sizeof(float) * (size_t)((nmax + GRP - 1) / GRP * GRP);
+    const size_t lds = (nmax <= 4096 ? sizeof(float4) : sizeof(float)) * (size_t)((nmax + GRP - 1) / GRP * GRP);
     BuildArgs a;
     a.tri1 = xf ? xf->src : tri1;
     a.tri2 = tri2;
@@ -537,6 +570,9 @@ int rrl_launch_tri_build(const float *tri1, const float *tri2, void *ws, const W
     a.tri1_out = xf ? w.f32(ws, RRL_WS_TRI1) : nullptr;
     a.ptri1 = w.f32(ws, RRL_WS_PTRI1);
     a.ptri2 = w.f32(ws, RRL_WS_PTRI2);
+    a.crec1 = (float4 *)w.f32(ws, RRL_WS_CREC1);
+    a.crec2 = (float4 *)w.f32(ws, RRL_WS_CREC2);
+    a.apart = w.f32(ws, RRL_WS_APART);
     a.p0s1 = (float4 *)w.f32(ws, RRL_WS_P0S1);
     a.p0s2 = (float4 *)w.f32(ws, RRL_WS_P0S2);
     a.idx1 = w.i32(ws, RRL_WS_IDX1);
@@ -546,16 +582,18 @@ int rrl_launch_tri_build(const float *tri1, const float *tri2, void *ws, const W
     a.pmax = (uint32_t *)w.i32(ws, RRL_WS_PMAX);
     a.zero_base = (uint4 *)((char *)ws + w.off[RRL_WS_STATUS]);
     a.zero_vec4 = w.zero_bytes / 16;
-    a.skip_lo = w.off[RRL_WS_PMAX] / 16;
-    a.skip_hi = w.off[RRL_WS_COUNT1] / 16;
     a.g1 = xf && xf->zero_g1 ? (uint4 *)((char *)ws + w.off[RRL_WS_G1]) : nullptr;
     a.g1_vec4 = a.g1 ? (w.off[RRL_WS_RPART] - w.off[RRL_WS_G1]) / 16 : 0;
     a.B = B; a.N = N; a.M = M;
     a.transpose_r = xf ? xf->transpose_r : 0;
+    const int nall = N > M ? N : M;  // APART is laid out for the larger cloud
+    a.nblk = (nall + REC_BLK - 1) / REC_BLK;
+    hipLaunchKernelGGL(tri_records_kernel, dim3((unsigned)((nmax + REC_BLK - 1) / REC_BLK), (unsigned)B, (unsigned)clouds),
+                       dim3(REC_BLK), 0, s, a);
     if (nmax <= 4096)
-        hipLaunchKernelGGL(tri_build_kernel<4>, dim3((unsigned)(clouds * B)), dim3(1024), lds, s, a);
+        hipLaunchKernelGGL(tri_sort_kernel<4>, dim3((unsigned)(clouds * B)), dim3(1024), lds, s, a);
     else
-        hipLaunchKernelGGL(tri_build_kernel<0>, dim3((unsigned)(clouds * B)), dim3(1024), lds, s, a);
+        hipLaunchKernelGGL(tri_sort_kernel<0>, dim3((unsigned)(clouds * B)), dim3(1024), lds, s, a);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }

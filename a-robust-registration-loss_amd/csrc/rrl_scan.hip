@@ -278,7 +278,7 @@ __global__ __launch_bounds__(256) void scan_kernel(
     const float *__restrict__ ptri1, const float *__restrict__ ptri2,
     const float *__restrict__ line, int32_t *__restrict__ count1, int32_t *__restrict__ hit1,
     int32_t *__restrict__ count2, int32_t *__restrict__ hit2, int32_t *__restrict__ status,
-    const uint32_t *__restrict__ pmax, int32_t *__restrict__ tsafe, int B, int N, int M, int L,
+    const uint32_t *__restrict__ pmax, int B, int N, int M, int L,
     int chunk, int mode) {
     constexpr int W = Lanes<T>::W;
     constexpr int R = W * NP;  // lines per lane
@@ -326,14 +326,7 @@ __global__ __launch_bounds__(256) void scan_kernel(
 
     kptr tp = (kptr)(uintptr_t)(tri + (size_t)t0 * PTRI_STRIDE);
     uint32_t nanacc;
-    if (mode == RRL_SCAN_UNSAFE_TILES) {
-        // companion of cull_scan_kernel (launched first): classifies the 512-line tiles for it
-        // and scans, strictly, only the tiles with a line that fails the bound
-        const int tile_safe = __syncthreads_and(safe);
-        if (blockIdx.y == 0 && threadIdx.x == 0) tsafe[z * gridDim.x + blockIdx.x] = tile_safe;
-        if (tile_safe) return;
-        nanacc = scan_strict<T, NP>(r, tp, t0, t1, sink);
-    } else if (mode == RRL_SCAN_STRICT || (mode == RRL_SCAN_AUTO && !__all(safe)))
+    if (mode == RRL_SCAN_STRICT || (mode == RRL_SCAN_AUTO && !__all(safe)))
         nanacc = scan_strict<T, NP>(r, tp, t0, t1, sink);
     else if (mode == RRL_SCAN_AUTO)
         nanacc = scan_lazy<T, NP, false>(r, tp, t0, t1, sink);  // provably NaN-free
@@ -422,8 +415,8 @@ int rrl_line_tri_scan_clouds(const float *line, void *ws, size_t ws_bytes, int B
     hipLaunchKernelGGL((scan_kernel<T, NP>), grid, dim3(256), 0, s, w.f32(ws, RRL_WS_PTRI1),     \
                        w.f32(ws, RRL_WS_PTRI2), line, w.i32(ws, RRL_WS_COUNT1),                  \
                        w.i32(ws, RRL_WS_HIT1), w.i32(ws, RRL_WS_COUNT2), w.i32(ws, RRL_WS_HIT2), \
-                       w.i32(ws, RRL_WS_STATUS), (const uint32_t *)w.i32(ws, RRL_WS_PMAX),       \
-                       w.i32(ws, RRL_WS_TSAFE), B, N, M, L, chunk, mode)
+                       w.i32(ws, RRL_WS_STATUS), (const uint32_t *)w.i32(ws, RRL_WS_PMAX), B, N, \
+                       M, L, chunk, mode)
     if (R == 1) RRL_SCAN_LAUNCH(float, 1);
     else if (R == 2) RRL_SCAN_LAUNCH(v2f, 1);
     else if (R == 4) RRL_SCAN_LAUNCH(v2f, 2);

@@ -28,7 +28,9 @@ struct WsLayout {
             4 * b * ((m + 15) / 16) * 16,   // IDX2
             16 * b * ((n + 15) / 16),       // GRP1
             16 * b * ((m + 15) / 16),       // GRP2
-            4 * 2 * b * ((l + 511) / 512),  // TSAFE
+            16 * b * ((n + 15) / 16) * 16,  // CREC1
+            16 * b * ((m + 15) / 16) * 16,  // CREC2
+            4 * 2 * b * 8 * (((n > m ? n : m) + 255) / 256),  // APART
             b * l,               // KJ
             4 * b * l,           // SEL
             4 * b * l * 4,       // HS1

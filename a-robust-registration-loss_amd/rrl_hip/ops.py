@@ -30,7 +30,9 @@ _WS_FIELDS = [
     ("idx2", torch.int32, lambda B, N, M, L, G: (B, (M + 15) // 16 * 16)),
     ("grp1", torch.float32, lambda B, N, M, L, G: (B, (N + 15) // 16, 4)),
     ("grp2", torch.float32, lambda B, N, M, L, G: (B, (M + 15) // 16, 4)),
-    ("tsafe", torch.int32, lambda B, N, M, L, G: (2, B, (L + 511) // 512)),
+    ("crec1", torch.float32, lambda B, N, M, L, G: (B, (N + 15) // 16 * 16, 4)),
+    ("crec2", torch.float32, lambda B, N, M, L, G: (B, (M + 15) // 16 * 16, 4)),
+    ("apart", torch.float32, lambda B, N, M, L, G: (2, B, (max(N, M) + 255) // 256, 8)),
     ("kj", torch.uint8, lambda B, N, M, L, G: (B, L)),
     ("sel", torch.int32, lambda B, N, M, L, G: (B, L)),
     ("hs1", torch.int32, lambda B, N, M, L, G: (B, L, 4)),
@@ -47,7 +49,7 @@ _WS_FIELDS = [
     ("info", torch.int32, lambda B, N, M, L, G: (G, 4)),
     ("tri1t", torch.float32, lambda B, N, M, L, G: (B, N, 9)),
     ("g1", torch.float32, lambda B, N, M, L, G: (B, N, 9)),
-    ("rpart", torch.float32, lambda B, N, M, L, G: (B, (3 * N + 16383) // 16384 + 1, 12)),
+    ("rpart", torch.float32, lambda B, N, M, L, G: (B, (3 * N + 1023) // 1024 + 1, 12)),
 ]
 _layout_cache = {}
 

@@ -50,8 +50,8 @@ extern "C" {
 #define RRL_SCAN_CULL 3   /* default.  Triangles are Morton-sorted into groups of 16 with bounding
                              spheres; a line evaluates (lazily, exactly) only the groups whose
                              sphere it can reach, found by a conservative test (DESIGN.md
-                             "culling bound").  Tiles of 512 lines that fail the NaN bound are
-                             scanned by the strict loop instead, so results and NaN detection equal
+                             "culling bound").  128-line workgroups with a line that fails the NaN
+                             bound run the strict loop instead, so results and NaN detection equal
                              strict's.  Needs N, M <= 16384, else behaves like AUTO. */
 
 /* workspace fields (indices into rrl_workspace_layout's offset array) */
@@ -72,8 +72,9 @@ enum {
     RRL_WS_IDX2,
     RRL_WS_GRP1,       /* float[B][NG1][4]  group sphere: centre, conservative radius^2        */
     RRL_WS_GRP2,
-    RRL_WS_TSAFE,      /* int32[2][B][ceil(L/512)] 1 = every line of the 512-line tile meets the
-                          NaN bound for that cloud (culled scan), 0 = strict loop took the tile */
+    RRL_WS_CREC1,      /* float[B][16*NG1][4] P0 + thr2 in original order (input of the sort)   */
+    RRL_WS_CREC2,
+    RRL_WS_APART,      /* float[2][B][ceil(max(N,M)/256)][8] per-workgroup AABB / max |P|^2 partials */
     RRL_WS_KJ,         /* uint8[B][L]  k | j<<4, 0 = line not selected                      */
     RRL_WS_SEL,        /* int32[B][L]  indices of the selected lines, compacted (any order)  */
     RRL_WS_HS1,        /* int32[B][L][4] ascending hit indices (nonzero() order)            */
