@@ -46,50 +46,16 @@ __device__ __forceinline__ void sort4(int *h, int n) {  // ascending, n <= 4
             if (j < n && h[j] < h[j - 1]) { int t = h[j]; h[j] = h[j - 1]; h[j - 1] = t; }
 }
 
-// 1024 lines per workgroup.  Phase 1: every lane classifies its line and the selected ones
-// (~9 %) are compacted through LDS, so that phase 2 -- the gather-heavy part -- runs on dense
-// wavefronts; the compacted line ids also go to SEL[b] for the reduce and backward kernels.
-__global__ __launch_bounds__(1024) void line_pair_dist_kernel(
-    const float *__restrict__ tri1, const float *__restrict__ tri2, const float *__restrict__ line,
-    const int32_t *__restrict__ count1, const int32_t *__restrict__ hit1,
-    const int32_t *__restrict__ count2, const int32_t *__restrict__ hit2,
-    uint8_t *__restrict__ kj, int32_t *__restrict__ sel_out, int32_t *__restrict__ nsel,
-    int32_t *__restrict__ hs1, int32_t *__restrict__ hs2, float *__restrict__ w1,
-    float *__restrict__ w2, float4 *__restrict__ Q1, float4 *__restrict__ Q2, float *__restrict__ D,
-    float *__restrict__ vals, int32_t *__restrict__ nvals, int B, int N, int M, int L, int s_m,
-    int s_n, int e_m, int e_n, int pool) {
-    __shared__ int s_list[1024];
-    __shared__ int s_wave[16];
-    __shared__ int s_total, s_base;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.y;
-    {
-        const int l = blockIdx.x * 1024 + tid;
-        bool sel = false;
-        if (l < L) {
-            const size_t gl = (size_t)b * L + l;
-            const int k = count1[gl], j = count2[gl];
-            sel = k >= s_m && k < e_m && j >= s_n && j < e_n;
-            kj[gl] = sel ? (uint8_t)(k | (j << 4)) : (uint8_t)0;
-        }
-        const unsigned long long mask = __ballot(sel);
-        if (lane == 0) s_wave[wave] = __popcll(mask);
-        __syncthreads();
-        if (tid == 0) {
-            int acc = 0;
-            for (int w = 0; w < 16; ++w) { int c = s_wave[w]; s_wave[w] = acc; acc += c; }
-            s_total = acc;
-            s_base = acc ? atomicAdd(&nsel[b], acc) : 0;
-        }
-        __syncthreads();
-        if (sel) s_list[s_wave[wave] + __popcll(mask & ((1ull << lane) - 1ull))] = l;
-        __syncthreads();
-    }
-    if (tid >= s_total) return;
-    const int l = s_list[tid];
-    sel_out[(size_t)b * L + s_base + tid] = l;
-    const size_t gl = (size_t)b * L + l;
-    const int k = count1[gl], j = count2[gl];
+// Phase 2 of line_pair_dist_kernel for one selected line: ascending hits, weights, intersection
+// points, the k x j block of squared distances (and its copy in the median's input list).
+__device__ __forceinline__ void pair_line(const float *__restrict__ tri1, const float *__restrict__ tri2,
+                                          const float *__restrict__ line, const int32_t *__restrict__ hit1,
+                                          const int32_t *__restrict__ hit2, int32_t *__restrict__ hs1,
+                                          int32_t *__restrict__ hs2, float *__restrict__ w1,
+                                          float *__restrict__ w2, float4 *__restrict__ Q1,
+                                          float4 *__restrict__ Q2, float *__restrict__ D,
+                                          float *__restrict__ vals, int b, int N, int M, int L, size_t gl,
+                                          int k, int j, bool feeds_median, int pos) {
     float ln[6];
 #pragma unroll
     for (int c = 0; c < 6; ++c) ln[c] = line[gl * 6 + c];
@@ -124,10 +90,6 @@ __global__ __launch_bounds__(1024) void line_pair_dist_kernel(
             for (int c = 0; c < 3; ++c) w2[(gl * RRL_MAX_HITS + a) * 3 + c] = w[c];
         }
     }
-    // the median's input: all of this sample's D values, any order (reference B>1 quirk:
-    // only the LAST sample's values define the median)
-    const bool feeds_median = !pool || b == B - 1;
-    int pos = feeds_median ? atomicAdd(&nvals[b], k * j) : 0;
     float *vb = vals + (size_t)b * L * 16;
     // D[a][b] = sum_c (q1 - q2)^2, code/loss.py:38-52
 #pragma unroll
@@ -143,6 +105,70 @@ __global__ __launch_bounds__(1024) void line_pair_dist_kernel(
                 D[gl * 16 + a * j + bb] = s;
                 if (feeds_median) vb[pos + a * j + bb] = s;
             }
+}
+
+// 1024 lines per workgroup.  Phase 1: every lane classifies its line and the selected ones
+// (~9 %) are compacted through LDS, so that phase 2 -- the gather-heavy part -- runs on dense
+// wavefronts; the compacted line ids also go to SEL[b] for the reduce and backward kernels.
+__global__ __launch_bounds__(1024) void line_pair_dist_kernel(
+    const float *__restrict__ tri1, const float *__restrict__ tri2, const float *__restrict__ line,
+    const int32_t *__restrict__ count1, const int32_t *__restrict__ hit1,
+    const int32_t *__restrict__ count2, const int32_t *__restrict__ hit2,
+    uint8_t *__restrict__ kj, int32_t *__restrict__ sel_out, int32_t *__restrict__ nsel,
+    int32_t *__restrict__ hs1, int32_t *__restrict__ hs2, float *__restrict__ w1,
+    float *__restrict__ w2, float4 *__restrict__ Q1, float4 *__restrict__ Q2, float *__restrict__ D,
+    float *__restrict__ vals, int32_t *__restrict__ nvals, int B, int N, int M, int L, int s_m,
+    int s_n, int e_m, int e_n, int pool) {
+    __shared__ int s_list[1024];
+    __shared__ int s_wave[16];
+    __shared__ int s_total;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y;
+    int base_reg = 0;
+    {
+        const int l = blockIdx.x * 1024 + tid;
+        bool sel = false;
+        if (l < L) {
+            const size_t gl = (size_t)b * L + l;
+            const int k = count1[gl], j = count2[gl];
+            sel = k >= s_m && k < e_m && j >= s_n && j < e_n;
+            kj[gl] = sel ? (uint8_t)(k | (j << 4)) : (uint8_t)0;
+        }
+        const unsigned long long mask = __ballot(sel);
+        if (lane == 0) s_wave[wave] = __popcll(mask);
+        __syncthreads();
+        if (tid == 0) {
+            int acc = 0;
+            for (int w = 0; w < 16; ++w) { int c = s_wave[w]; s_wave[w] = acc; acc += c; }
+            s_total = acc;
+            // the slot range in SEL[b] is only needed for the last store of the kernel: the
+            // atomic's round trip overlaps the gathers below
+            base_reg = acc ? atomicAdd(&nsel[b], acc) : 0;
+        }
+        __syncthreads();
+        if (sel) s_list[s_wave[wave] + __popcll(mask & ((1ull << lane) - 1ull))] = l;
+        __syncthreads();
+    }
+    const bool active = tid < s_total;
+    const int l = active ? s_list[tid] : 0;
+    const size_t gl = (size_t)b * L + l;
+    const int k = active ? count1[gl] : 0, j = active ? count2[gl] : 0;
+    // the median's input: all of this sample's D values, any order (reference B>1 quirk:
+    // only the LAST sample's values define the median).  Reserved early: the
+    // atomic's latency hides behind the triangle gathers.
+    const bool feeds_median = active && (!pool || b == B - 1);
+    const int pos = feeds_median ? atomicAdd(&nvals[b], k * j) : 0;
+    // SEL[b] gets this workgroup's compacted line ids at the end, written by wavefront 0 alone
+    // (lane 0 holds the slot base returned by the atomic): no barrier, and the atomic's round
+    // trip has long been hidden by the gathers
+    if (!active && wave != 0) return;
+    if (active)
+        pair_line(tri1, tri2, line, hit1, hit2, hs1, hs2, w1, w2, Q1, Q2, D, vals, b, N, M, L, gl, k, j,
+                  feeds_median, pos);
+    if (wave == 0) {
+        const int base = __builtin_amdgcn_readfirstlane(base_reg);
+        for (int i = lane; i < s_total; i += 64) sel_out[(size_t)b * L + base + i] = s_list[i];
+    }
 }
 
 extern "C" int rrl_line_pair_dist(const float *tri1, const float *tri2, const float *line,
@@ -222,25 +248,35 @@ __global__ __launch_bounds__(1024) void loss_reduce_kernel(
     int e_n, int pool) {
     __shared__ unsigned s_hist[2048];
     __shared__ unsigned s_wtot[16];
-    __shared__ unsigned s_prefix, s_rank;
+    __shared__ unsigned s_prefix[3], s_rank[4];  // one slot per pass: no barrier between read and rewrite
     __shared__ unsigned long long s_sum[32];
     __shared__ int s_cnt[16];
     __shared__ float s_term[16];
     const int g = blockIdx.x, tid = threadIdx.x;
     const int bm = pool ? B - 1 : g;  // whose values define the median
     const float *v = vals + (size_t)bm * L * 16;
+    // ---- lower median = element of rank (n-1)/2 (torch.median): MSB-first radix select on the
+    //      bit patterns (D >= 0: unsigned order == float order).
+    // The value loads do not wait for n: they read inside the sample's VALS slab (16 L floats)
+    // whatever it holds and are masked afterwards.
+    float vraw[MED_REGS];
+    const unsigned cap = 16u * (unsigned)L;
+#pragma unroll
+    for (int i = 0; i < MED_REGS; ++i) {
+        const unsigned idx = (unsigned)tid + 1024u * i;
+        vraw[i] = v[idx < cap ? idx : 0u];
+    }
     const unsigned n = (unsigned)nvals[bm];
     if (tid < 32) s_sum[tid] = 0ull;
     if (tid < 16) s_cnt[tid] = 0;
-    __syncthreads();
-
-    // ---- lower median = element of rank (n-1)/2 (torch.median): MSB-first radix select on the
-    //      bit patterns (D >= 0: unsigned order == float order).
+    s_hist[tid] = 0;
+    s_hist[tid + 1024] = 0;
+    if (tid == 0) s_rank[0] = n ? (n - 1) / 2 : 0;
     unsigned u[MED_REGS];
 #pragma unroll
     for (int i = 0; i < MED_REGS; ++i) {
-        unsigned idx = (unsigned)tid + 1024u * i;
-        u[i] = idx < n ? __float_as_uint(v[idx]) : 0xffffffffu;  // all-ones never matches a prefix
+        const unsigned idx = (unsigned)tid + 1024u * i;
+        u[i] = idx < n ? __float_as_uint(vraw[i]) : 0xffffffffu;  // all-ones never matches a prefix
     }
     // the Welsch stage's inputs do not depend on the median: fetch this lane's first line now so
     // that the nsel -> sel -> (kj, D) chain of dependent loads overlaps the median passes
@@ -255,19 +291,17 @@ __global__ __launch_bounds__(1024) void loss_reduce_kernel(
         c_pre = kj[gl];
         load_block(D + gl * 16, c_pre & 15, c_pre >> 4, D_pre);
     }
+    __syncthreads();
     // Three passes over digits of 11, 11 and 9 bits (bit 31, the sign, is clear): LDS histogram
     // of the values that agree with the prefix (wide digits keep the atomics uncontended: even
     // the first digit spreads over exponent + 3 mantissa bits), block-wide exclusive scan of the
-    // histogram (DPP wave scans + wave totals), pick the bin that holds the rank.
+    // histogram (DPP wave scans + wave totals), pick the bin that holds the rank.  Three
+    // barriers per pass: the histogram is cleared for the next pass as it is read.
     unsigned prefix = 0;
-    if (tid == 0) { s_rank = n ? (n - 1) / 2 : 0; }
     for (int pass = 0; pass < 3 && n > 0; ++pass) {
         const int sh = pass == 0 ? 20 : (pass == 1 ? 9 : 0);
         const int width = pass == 2 ? 9 : 11;
         const unsigned dmask = (1u << width) - 1u;
-        s_hist[tid] = 0;
-        s_hist[tid + 1024] = 0;
-        __syncthreads();
         const int hi = sh + width;  // bits >= hi must equal the prefix (hi = 31 on the first pass)
         auto tally = [&](unsigned x) {
             if (((x ^ prefix) >> hi) == 0u) atomicAdd(&s_hist[(x >> sh) & dmask], 1u);
@@ -278,20 +312,21 @@ __global__ __launch_bounds__(1024) void loss_reduce_kernel(
             tally(__float_as_uint(v[idx]));
         __syncthreads();
         const unsigned h0 = s_hist[2 * tid], h1 = s_hist[2 * tid + 1];
+        s_hist[2 * tid] = 0;
+        s_hist[2 * tid + 1] = 0;
         const unsigned incl = (unsigned)wave_incl_scan((int)(h0 + h1));
         if ((tid & 63) == 63) s_wtot[tid >> 6] = incl;
         __syncthreads();
         unsigned base = 0;
         for (int w = 0; w < (tid >> 6); ++w) base += s_wtot[w];
-        const unsigned excl = base + incl - (h0 + h1), r = s_rank;
-        __syncthreads();  // everybody has read s_rank before the owner of the bin rewrites it
+        const unsigned excl = base + incl - (h0 + h1), r = s_rank[pass];
         if (r >= excl && r < excl + h0 + h1) {  // exactly one lane
             const unsigned second = r >= excl + h0 ? 1u : 0u;
-            s_prefix = prefix | ((2u * tid + second) << sh);
-            s_rank = r - excl - (second ? h0 : 0u);
+            s_prefix[pass] = prefix | ((2u * tid + second) << sh);
+            s_rank[pass + 1] = r - excl - (second ? h0 : 0u);
         }
         __syncthreads();
-        prefix = s_prefix;
+        prefix = s_prefix[pass];
     }
     const float med = n ? __uint_as_float(prefix) : 0.0f;
 
@@ -399,22 +434,28 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(
     // one lane per (selected line, side, hit slot): 8 lanes share a line, each owns <= 9 atomics
     const int t = blockIdx.x * 256 + threadIdx.x;
     const int b = blockIdx.y;
-    const int i = t >> 3, side = (t >> 2) & 1, h = t & 3;
-    if (i >= nsel[b] || (side && !g2)) return;
-    const size_t gl = (size_t)b * L + sel[(size_t)b * L + i];
-    const unsigned c = kj[gl];
-    const int k = c & 15, j = c >> 4, g = pool ? 0 : b;
-    if (h >= (side ? j : k)) return;
+    const int i = t >> 3, side = (t >> 2) & 1, h = t & 3, g = pool ? 0 : b;
+    if (i >= L || (side && !g2)) return;
+    // independent loads first (the grid covers every possible slot, ~9 % are live): SEL[i] is
+    // read before nsel is known and clamped, so that kj -- the next link of the chain -- can be
+    // requested one round trip earlier
+    const int ns = nsel[b];
+    int li = sel[(size_t)b * L + i];
     const int C = info[g * 4];
-    if (C == 0) return;
-    const float m = med[g];
+    const float m = med[g], gl_in = grad_loss[g];
+    li = li < 0 ? 0 : (li >= L ? L - 1 : li);
+    const size_t gl = (size_t)b * L + li;
+    const unsigned c = kj[gl];
+    if (i >= ns || C == 0) return;
+    const int k = c & 15, j = c >> 4;
+    if (h >= (side ? j : k)) return;
     float Dm[16], rowmin[4], colmin[4];
     int arg_b[4], arg_a[4];
     load_block(D + gl * 16, k, j, Dm);
     welsch_block(Dm, m, rowmin, colmin, arg_b, arg_a);
     const int S = bcnt[g * 16 + (k - 1) * 4 + (j - 1)];
     const float wkj = expf(-0.5f * (float)abs(k - j));
-    const float scale = grad_loss[g] * wkj / (float)C;
+    const float scale = gl_in * wkj / (float)C;
     const float inv_row = 1.0f / ((float)S * (float)k), inv_col = 1.0f / ((float)S * (float)j);
     const float4 mine = (side ? Q2 : Q1)[gl * 4 + h];
     float gq[3] = {0.0f, 0.0f, 0.0f};
@@ -444,6 +485,162 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(
         const float wk = w[kk] / 3.0f;  // q = mean_k(w_k P_k)
 #pragma unroll
         for (int cc = 0; cc < 3; ++cc) atomicAdd(dst + 3 * kk + cc, wk * gq[cc]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// K5' backward of the fused training op when only dL/dR and dL/dt are wanted (the usual case:
+// the source cloud is data).  The gradient of a moved point y = x m + t contributes x (x) g to
+// dL/dm and g to dL/dt, so every (selected line, hit) lane adds its three points' terms straight
+// into 12 per-lane sums: no scatter into a per-triangle gradient, no float atomics, no pass over
+// the N points afterwards.  Workgroup sums go out as write-through partials; the last live
+// workgroup of the launch (ticket counter) reduces them per sample in index order and builds
+// the 14-float shard payload.  ONE launch for the whole backward, bit-deterministic.
+// ---------------------------------------------------------------------------------------
+#define BWD_LINES 64  // selected lines per 256-lane workgroup (4 hit slots each)
+
+__device__ __forceinline__ int bwd_live_blocks(int ns) { return ns > 0 ? (ns + BWD_LINES - 1) / BWD_LINES : 1; }
+
+__global__ __launch_bounds__(256) void loss_bwd_rt_kernel(
+    const uint8_t *__restrict__ kj, const int32_t *__restrict__ sel, const int32_t *__restrict__ nsel,
+    const int32_t *__restrict__ hs1, const float *__restrict__ w1, const float4 *__restrict__ Q1,
+    const float4 *__restrict__ Q2, const float *__restrict__ D, const float *__restrict__ med,
+    const int32_t *__restrict__ bcnt, const int32_t *__restrict__ info,
+    const float *__restrict__ grad_loss, const float *__restrict__ src, float *__restrict__ bpart,
+    float *__restrict__ gR, float *__restrict__ gt, float *__restrict__ payload,
+    const float *__restrict__ loss, int32_t *__restrict__ done, int B, int N, int L, int transpose_r) {
+    __shared__ float red[4][12];
+    __shared__ int s_ticket, s_live;
+    __shared__ double psum[14];
+    __shared__ float stage[16][12];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y, nblk = gridDim.x;
+    const int ns = nsel[b];
+    if ((int)blockIdx.x >= bwd_live_blocks(ns)) return;  // uniform: nothing selected in this slice
+    if (tid == 0) {  // live workgroups of the whole launch = tickets to wait for
+        int tot = 0;
+        for (int k = 0; k < B; ++k) tot += bwd_live_blocks(nsel[k]);
+        s_live = tot;
+    }
+    const int i = blockIdx.x * BWD_LINES + (tid >> 2), h = tid & 3;
+    float acc[12];
+#pragma unroll
+    for (int q = 0; q < 12; ++q) acc[q] = 0.0f;
+    const int C = info[b * 4];
+    if (i < ns && C > 0) {
+        const size_t gl = (size_t)b * L + sel[(size_t)b * L + i];
+        const unsigned c = kj[gl];
+        const int k = c & 15, j = c >> 4;
+        if (h < k) {
+            const float m = med[b];
+            float Dm[16], rowmin[4], colmin[4];
+            int arg_b[4], arg_a[4];
+            load_block(D + gl * 16, k, j, Dm);
+            welsch_block(Dm, m, rowmin, colmin, arg_b, arg_a);
+            const int S = bcnt[b * 16 + (k - 1) * 4 + (j - 1)];
+            const float wkj = expf(-0.5f * (float)abs(k - j));
+            const float scale = grad_loss[b] * wkj / (float)C;
+            const float inv_row = 1.0f / ((float)S * (float)k), inv_col = 1.0f / ((float)S * (float)j);
+            const float4 mine = Q1[gl * 4 + h];
+            float gq[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int o = 0; o < RRL_MAX_HITS; ++o) {
+                if (o >= j) continue;
+                float sw = 0.0f;
+#pragma unroll
+                for (int x = 0; x < RRL_MAX_HITS; ++x) {  // static indexing of arg_b / arg_a
+                    if (x == h && arg_b[x] == o) sw += inv_row;
+                    if (x == o && arg_a[x] == h) sw += inv_col;
+                }
+                if (sw == 0.0f) continue;
+                // same expressions as loss_bwd_kernel
+                const float gD = scale * sw * expf(-(D[gl * 16 + h * j + o] / m) / 2.0f) / (2.0f * m);
+                const float4 other = Q2[gl * 4 + o];
+                gq[0] += 2.0f * (mine.x - other.x) * gD;
+                gq[1] += 2.0f * (mine.y - other.y) * gD;
+                gq[2] += 2.0f * (mine.z - other.z) * gD;
+            }
+            const int f = hs1[gl * 4 + h];
+            const float *w = w1 + (gl * 4 + h) * 3;
+            const float *x = src + ((size_t)b * N + f) * 9;
+#pragma unroll
+            for (int kk = 0; kk < 3; ++kk) {
+                const float wk = w[kk] / 3.0f;  // q = mean_k(w_k P_k)
+                float gv[3];
+#pragma unroll
+                for (int cc = 0; cc < 3; ++cc) gv[cc] = wk * gq[cc];
+#pragma unroll
+                for (int cc = 0; cc < 3; ++cc) {
+                    const float xc = x[3 * kk + cc];
+#pragma unroll
+                    for (int jj = 0; jj < 3; ++jj) acc[cc * 3 + jj] = fmaf(xc, gv[jj], acc[cc * 3 + jj]);
+                    acc[9 + cc] += gv[cc];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 12; ++q) acc[q] = wave_sum(acc[q]);
+    if (lane == 0)
+#pragma unroll
+        for (int q = 0; q < 12; ++q) red[wave][q] = acc[q];
+    __syncthreads();
+    // hand-over without __threadfence() (see reg_bwd_kernel): write-through stores, wave 0 waits
+    // for them, then its lane 0 takes the ticket
+    if (tid < 12)
+        __hip_atomic_store(&bpart[((size_t)b * nblk + blockIdx.x) * 12 + tid],
+                           (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    if (tid < 64) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid == 0) s_ticket = __hip_atomic_fetch_add(done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (tid < 14) psum[tid] = 0.0;
+    __syncthreads();
+    if (s_ticket != s_live - 1) return;
+    if (tid == 0) __hip_atomic_store(done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // the last workgroup: per-sample sums over the live workgroups in index order, then the
+    // payload over the samples in index order
+    for (int k0 = 0; k0 < B; k0 += 16) {
+        const int k = k0 + tid / 12, q = tid % 12;
+        const bool on = tid < 192 && k < B;
+        float r = 0.0f;
+        if (on) {
+            const int nl = bwd_live_blocks(nsel[k]);
+            double sacc = 0.0;
+            for (int jb = 0; jb < nl; ++jb)
+                sacc += (double)__hip_atomic_load(&bpart[((size_t)k * nblk + jb) * 12 + q], __ATOMIC_RELAXED,
+                                                  __HIP_MEMORY_SCOPE_AGENT);
+            r = (float)sacc;
+            if (q < 9) {
+                const int ii = q / 3, jj = q % 3;
+                gR[k * 9 + (transpose_r ? jj * 3 + ii : ii * 3 + jj)] = r;
+            } else {
+                gt[k * 3 + (q - 9)] = r;
+            }
+            stage[tid / 12][q] = r;
+        }
+        __syncthreads();
+        if (payload && tid < 12) {
+            double sp = psum[2 + tid];
+            for (int kk = 0; kk < min(16, B - k0); ++kk) sp += (double)stage[kk][tid];
+            psum[2 + tid] = sp;
+        }
+        __syncthreads();
+    }
+    if (!payload) return;
+    if (tid < 2) {
+        double sp = 0.0;
+        for (int k = 0; k < B; ++k) sp += info[k * 4] > 0 ? (tid == 0 ? (double)loss[k] : 1.0) : 0.0;
+        payload[tid] = (float)sp;
+    } else if (tid < 14) {
+        const int q = tid - 2;
+        if (q < 9) {
+            const int ii = q / 3, jj = q % 3;
+            payload[2 + (transpose_r ? jj * 3 + ii : ii * 3 + jj)] = (float)psum[2 + q];
+        } else {
+            payload[2 + q] = (float)psum[2 + q];
+        }
     }
 }
 
@@ -567,9 +764,8 @@ extern "C" int rrl_registration_forward_cached(const float *src, const float *R,
     if (B < 0 || N < 0 || M < 0 || L < 0) return RRL_E_ARG;
     WsLayout w(B, N, M, L);
     if (ws_bytes < w.total) return RRL_E_WS;
-    // the transform runs inside the prepare step; the fused backward (see below) relies on the
-    // prepare step having cleared G1
-    const RrlXform xf = {src, R, t, transpose_r, rrl_fused_backward(B, N, M) ? 1 : 0};
+    // the transform runs inside the prepare step
+    const RrlXform xf = {src, R, t, transpose_r, 0};
     return loss_forward_impl(w.f32(ws, RRL_WS_TRI1), tri2, line, ws, ws_bytes, loss, B, N, M, L, s_m,
                              s_n, e_m, e_n, 0, mode, chunk, target_ws, &xf, stream);
 }
@@ -594,15 +790,28 @@ extern "C" int rrl_registration_backward(const float *src, const float *R, const
     WsLayout w(B, N, M, L);
     if (ws_bytes < w.total) return RRL_E_WS;
     float *g1 = w.f32(ws, RRL_WS_G1);
+    hipStream_t s = (hipStream_t)stream;
+    if (!grad_src && B > 0 && L > 0) {
+        // only dL/dR, dL/dt (+ payload): ONE launch, straight from the selected lines
+        hipLaunchKernelGGL(loss_bwd_rt_kernel, dim3((unsigned)((L + BWD_LINES - 1) / BWD_LINES), (unsigned)B),
+                           dim3(256), 0, s, w.u8(ws, RRL_WS_KJ), w.i32(ws, RRL_WS_SEL), w.i32(ws, RRL_WS_NSEL),
+                           w.i32(ws, RRL_WS_HS1), w.f32(ws, RRL_WS_W1), (const float4 *)w.f32(ws, RRL_WS_Q1),
+                           (const float4 *)w.f32(ws, RRL_WS_Q2), w.f32(ws, RRL_WS_D), w.f32(ws, RRL_WS_MED),
+                           w.i32(ws, RRL_WS_BCNT), w.i32(ws, RRL_WS_INFO), grad_loss, src,
+                           w.f32(ws, RRL_WS_BPART), gR, gt, payload, loss, w.i32(ws, RRL_WS_STATUS) + 3, B, N,
+                           L, transpose_r);
+        RRL_LAUNCH_CHECK();
+        return 0;
+    }
     if (rrl_fused_backward(B, N, M)) {
-        // G1 was cleared by the forward's build kernel (and is cleared again by reg_bwd_kernel):
-        // two launches -- scatter of the line gradients, then rigid backward + payload
+        // dL/dsrc wanted too: scatter of the line gradients into G1 (cleared first), then rigid
+        // backward + payload (reg_bwd_kernel)
         int rc = loss_backward_impl(w.f32(ws, RRL_WS_TRI1), tri2, ws, ws_bytes, grad_loss, g1, nullptr,
-                                    B, N, M, L, 0, false, stream);
+                                    B, N, M, L, 0, true, stream);
         if (rc) return rc;
         return rrl_launch_reg_bwd(src, R, g1, grad_src, w.f32(ws, RRL_WS_RPART), gR, gt, payload, loss,
                                   w.i32(ws, RRL_WS_INFO), w.i32(ws, RRL_WS_STATUS) + 3, B, N, transpose_r,
-                                  (hipStream_t)stream);
+                                  s);
     }
     int rc = rrl_loss_backward(w.f32(ws, RRL_WS_TRI1), tri2, ws, ws_bytes, grad_loss, g1, nullptr, B,
                                N, M, L, 0, stream);

@@ -48,6 +48,7 @@ struct WsLayout {
             4 * b * n * 9,       // TRI1
             4 * b * n * 9,       // G1
             4 * b * 12 * ((3 * n + 1023) / 1024 + 1),    // RPART
+            4 * b * 12 * ((l + 63) / 64 + 1),            // BPART
         };
         size_t o = 0;
         for (int i = 0; i < RRL_WS_FIELDS; ++i) {
