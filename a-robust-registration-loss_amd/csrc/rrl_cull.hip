@@ -443,13 +443,17 @@ __global__ __launch_bounds__(64 * WPB) void cull_scan_kernel(
     __shared__ int bgrp_lds[WPB][BGRP];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform for the compiler
-    const int z = blockIdx.y, cloud = z >= B ? 1 : 0, b = z - cloud * B;
+    // XCD-aware mapping: workgroups go to the 8 XCDs round-robin by linear id, and x is the fast
+    // index -- with (cloud, sample) on x, all workgroups of one cloud land on the same XCD (when
+    // 2B is a multiple of 8), so each XCD's L2 holds 1/8 of the records instead of a copy of all
+    const int z = blockIdx.x, cloud = z >= B ? 1 : 0, b = z - cloud * B;
+    const int lblk = blockIdx.y;
     const int n = cloud ? M : N;
     const int ng = (n + GRP - 1) / GRP;
     const float4 *grp = (cloud ? grp2 : grp1) + (size_t)b * ng;
     const float *ln = line + (size_t)b * L * 6;
 
-    const int l0 = blockIdx.x * LPB + lane, l1 = l0 + 64;
+    const int l0 = lblk * LPB + lane, l1 = l0 + 64;
     const bool live0 = l0 < L, live1 = l1 < L;
     float v0[6], v1[6];
 #pragma unroll
@@ -505,7 +509,7 @@ __global__ __launch_bounds__(64 * WPB) void cull_scan_kernel(
     ctx.ptri = (cloud ? ptri2 : ptri1) + (size_t)b * n * PTRI_STRIDE;
     ctx.cnt = (cloud ? count2 : count1) + (size_t)b * L;
     ctx.hit = (cloud ? hit2 : hit1) + (size_t)b * L * RRL_MAX_HITS;
-    ctx.lbase = blockIdx.x * LPB;
+    ctx.lbase = lblk * LPB;
     ctx.rows = rows_lds[wave];
     ctx.ent = ent_lds[wave];
     ctx.bgrp = bgrp_lds[wave];
@@ -600,7 +604,7 @@ int rrl_launch_tri_build(const float *tri1, const float *tri2, void *ws, const W
 
 int rrl_launch_cull_scan(const float *line, void *ws, const WsLayout &w, int B, int N, int M, int L,
                          int clouds, hipStream_t s) {
-    hipLaunchKernelGGL(cull_scan_kernel, dim3((unsigned)((L + LPB - 1) / LPB), (unsigned)(clouds * B)), dim3(64 * WPB), 0,
+    hipLaunchKernelGGL(cull_scan_kernel, dim3((unsigned)(clouds * B), (unsigned)((L + LPB - 1) / LPB)), dim3(64 * WPB), 0,
                        s, w.f32(ws, RRL_WS_PTRI1), w.f32(ws, RRL_WS_PTRI2),
                        (const float4 *)w.f32(ws, RRL_WS_P0S1), (const float4 *)w.f32(ws, RRL_WS_P0S2),
                        w.i32(ws, RRL_WS_IDX1), w.i32(ws, RRL_WS_IDX2), (const float4 *)w.f32(ws, RRL_WS_GRP1),

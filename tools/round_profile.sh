@@ -1,0 +1,57 @@
+#!/bin/bash
+# usage (GPU box, repo root): tools/round_profile.sh <tag>
+# Produces under gpurun_out/: the default bench line, the rocprofv3 --kernel-trace --stats summary of
+# the SAME command, separate PMC passes for FETCH_SIZE / WRITE_SIZE (HBM traffic per kernel, the
+# guide's recipe: own runs, --kernel-trace only) and two SQ counter passes for the scan kernel.
+TAG=${1:-r}
+R=$PWD; O=$R/gpurun_out; mkdir -p $O
+cd /tmp; export TMPDIR=/tmp
+python3 $R/bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_stats -o s -- python3 $R/bench.py --no-cpu-baseline > $O/${TAG}_bench_prof.json 2> $O/${TAG}_bench_prof.err
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/${TAG}_pmc_$c -o p -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-graph > $O/${TAG}_pmc_$c.log 2>&1
+done
+timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $O/${TAG}_pmc_sqa -o p -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-graph > $O/${TAG}_pmc_sqa.log 2>&1
+timeout 300 rocprofv3 --pmc SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS SQ_INSTS_VMEM_WR --kernel-trace --output-format csv -d $O/${TAG}_pmc_sqb -o p -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-graph > $O/${TAG}_pmc_sqb.log 2>&1
+cd $R
+python3 - "$TAG" <<'PY'
+import csv, collections, json, sys, glob
+tag = sys.argv[1]
+O = "gpurun_out"
+def per_kernel(counter_dir):
+    f = glob.glob(f"{O}/{counter_dir}/**/*counter_collection.csv", recursive=True)
+    agg = collections.defaultdict(lambda: collections.defaultdict(lambda: collections.defaultdict(float)))
+    for path in f:
+        for r in csv.DictReader(open(path)):
+            name = r["Kernel_Name"].split("(")[0]
+            agg[name][r["Counter_Name"]][int(r["Dispatch_Id"])] += float(r["Counter_Value"])
+    return {k: {c: sum(d.values()) / len(d) for c, d in v.items()} for k, v in agg.items()}
+out = {"note": "rocprofv3 --pmc, separate passes per counter group (bench.py --no-graph --steps 6); per-launch means. "
+               "FETCH_SIZE / WRITE_SIZE in KB as reported; gfx950 correction for wide (16 B/lane) streaming reads: "
+               "bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (MI355X_MICROARCH.md, HBM section)"}
+hbm = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    for k, v in per_kernel(f"{tag}_pmc_{c}").items():
+        hbm.setdefault(k, {}).update(v)
+for k, v in hbm.items():
+    if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+        v["bytes_corrected"] = (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024
+out["hbm_per_kernel"] = hbm
+sq = {}
+for d in ("sqa", "sqb"):
+    for k, v in per_kernel(f"{tag}_pmc_{d}").items():
+        sq.setdefault(k, {}).update(v)
+out["sq_per_kernel"] = {k: v for k, v in sq.items() if "cull" in k or "tri_" in k or "loss_" in k or "line_pair" in k}
+json.dump(out, open(f"{O}/{tag}_pmc_summary.json", "w"), indent=1)
+rows = list(csv.DictReader(open(glob.glob(f"{O}/{tag}_stats/**/*kernel_stats.csv", recursive=True)[0])))
+for r in rows[:12]:
+    print(f"{r['Name'][:44]:44s} {r['Calls']:>5s} {float(r['AverageNs'])/1e3:9.1f} us")
+c = out["hbm_per_kernel"].get("cull_scan_kernel", {})
+print("cull HBM:", c)
+s = out["sq_per_kernel"].get("cull_scan_kernel", {})
+if s:
+    print("cull SQ: VALU busy %.3f  LDS busy %.3f  wait_any %.3f  wait_inst %.3f of wave cycles; VALU insts %.3g" % (
+        4 * s.get("SQ_ACTIVE_INST_VALU", 0) / max(s.get("SQ_BUSY_CYCLES", 1), 1) , 4 * s.get("SQ_ACTIVE_INST_LDS", 0) / max(s.get("SQ_BUSY_CYCLES", 1), 1),
+        s.get("SQ_WAIT_ANY", 0) / max(s.get("SQ_WAVE_CYCLES", 1), 1), s.get("SQ_WAIT_INST_ANY", 0) / max(s.get("SQ_WAVE_CYCLES", 1), 1), s.get("SQ_INSTS_VALU", 0)))
+PY
+tail -c 1500 $O/${TAG}_bench.json
