@@ -157,7 +157,20 @@ __global__ __launch_bounds__(1024) void line_pair_dist_kernel(
     // only the LAST sample's values define the median).  Reserved early: the
     // atomic's latency hides behind the triangle gathers.
     const bool feeds_median = active && (!pool || b == B - 1);
-    const int pos = feeds_median ? atomicAdd(&nvals[b], k * j) : 0;
+    // one atomic per wavefront (DPP prefix sum of the k*j counts), not one per line: ~900 adds
+    // on the same address per sample serialise in the L2
+    int pos = 0;
+    {
+        const int mine = feeds_median ? k * j : 0;
+        const int incl = wave_incl_scan(mine);
+        const int total = __builtin_amdgcn_readlane(incl, 63);
+        int wbase = 0;
+        if (total) {  // wave-uniform
+            if (lane == 63) wbase = atomicAdd(&nvals[b], total);
+            wbase = __builtin_amdgcn_readlane(wbase, 63);
+        }
+        pos = wbase + incl - mine;
+    }
     // SEL[b] gets this workgroup's compacted line ids at the end, written by wavefront 0 alone
     // (lane 0 holds the slot base returned by the atomic): no barrier, and the atomic's round
     // trip has long been hidden by the gathers
