@@ -12,9 +12,7 @@
 // sqrt(dist_sq) of the three points of triangle f and the detached weights of
 // code/loss.py:92: w_k = d_k / ((d0 + d1) + d2).  Same arithmetic as the scan, so the
 // distances are bit-identical to the ones that decided the label.
-__device__ __forceinline__ void hit_weights(const float *__restrict__ tri, int f, const float *ln,
-                                            float *w) {
-    const float *p = tri + 9 * (size_t)f;
+__device__ __forceinline__ void hit_weights(const float *p, const float *ln, float *w) {
     float d[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k)
@@ -26,9 +24,7 @@ __device__ __forceinline__ void hit_weights(const float *__restrict__ tri, int f
 }
 
 // q = mean_k(w_k * P_k), code/loss.py:155-163 (a mean: 1/3 of the convex combination)
-__device__ __forceinline__ void inter_point(const float *__restrict__ tri, int f, const float *w,
-                                            float *q) {
-    const float *p = tri + 9 * (size_t)f;
+__device__ __forceinline__ void inter_point(const float *p, const float *w, float *q) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         float s = w[0] * p[c];
@@ -36,6 +32,22 @@ __device__ __forceinline__ void inter_point(const float *__restrict__ tri, int f
         s = s + w[2] * p[6 + c];
         q[c] = s / 3.0f;
     }
+}
+
+// the 9 coordinates of triangle f from its 48-byte prepared record: three 16-byte loads instead
+// of nine 4-byte gathers from the 36-byte input rows (a wavefront-level gather costs ~64 cycles
+// of the CU's address path per instruction, whatever its width)
+__device__ __forceinline__ void tri_coords(const float *__restrict__ ptri, int stride, int f, float *c) {
+    if (stride != PTRI_STRIDE) {  // raw 36-byte rows (a target whose records live in another workspace)
+#pragma unroll
+        for (int i = 0; i < 9; ++i) c[i] = ptri[9 * (size_t)f + i];
+        return;
+    }
+    const float4 *row = (const float4 *)(ptri + PTRI_STRIDE * (size_t)f);
+    const float4 r0 = row[0], r1 = row[1], r2 = row[2];
+    c[0] = r0.x; c[1] = r0.y; c[2] = r0.z; c[3] = r0.w;
+    c[4] = r1.x; c[5] = r1.y; c[6] = r1.z; c[7] = r1.w;
+    c[8] = r2.x;
 }
 
 __device__ __forceinline__ void sort4(int *h, int n) {  // ascending, n <= 4
@@ -48,6 +60,8 @@ __device__ __forceinline__ void sort4(int *h, int n) {  // ascending, n <= 4
 
 // Phase 2 of line_pair_dist_kernel for one selected line: ascending hits, weights, intersection
 // points, the k x j block of squared distances (and its copy in the median's input list).
+// tri1 / tri2 with stride 12 are the PREPARED records (PTRI: the same coordinates, 16-byte loads),
+// with stride 9 the raw input rows.
 __device__ __forceinline__ void pair_line(const float *__restrict__ tri1, const float *__restrict__ tri2,
                                           const float *__restrict__ line, const int32_t *__restrict__ hit1,
                                           const int32_t *__restrict__ hit2, int32_t *__restrict__ hs1,
@@ -55,16 +69,23 @@ __device__ __forceinline__ void pair_line(const float *__restrict__ tri1, const 
                                           float *__restrict__ w2, float4 *__restrict__ Q1,
                                           float4 *__restrict__ Q2, float *__restrict__ D,
                                           float *__restrict__ vals, int b, int N, int M, int L, size_t gl,
-                                          int k, int j, bool feeds_median, int pos) {
+                                          int k, int j, bool feeds_median, int pos, int st1, int st2) {
     float ln[6];
-#pragma unroll
-    for (int c = 0; c < 6; ++c) ln[c] = line[gl * 6 + c];
-    const float *t1 = tri1 + (size_t)b * N * 9, *t2 = tri2 + (size_t)b * M * 9;
+    {
+        const float2 *lp = (const float2 *)(line + gl * 6);  // 24-byte rows: 8-byte aligned
+        const float2 a0 = lp[0], a1 = lp[1], a2 = lp[2];
+        ln[0] = a0.x; ln[1] = a0.y; ln[2] = a1.x; ln[3] = a1.y; ln[4] = a2.x; ln[5] = a2.y;
+    }
+    const float *t1 = tri1 + (size_t)b * N * st1, *t2 = tri2 + (size_t)b * M * st2;
     int h1[RRL_MAX_HITS], h2[RRL_MAX_HITS];
+    {
+        const int4 a = ((const int4 *)hit1)[gl], c = ((const int4 *)hit2)[gl];
+        const int r1[4] = {a.x, a.y, a.z, a.w}, r2[4] = {c.x, c.y, c.z, c.w};
 #pragma unroll
-    for (int a = 0; a < RRL_MAX_HITS; ++a) {
-        h1[a] = a < k ? hit1[gl * RRL_MAX_HITS + a] : 0x7fffffff;
-        h2[a] = a < j ? hit2[gl * RRL_MAX_HITS + a] : 0x7fffffff;
+        for (int q = 0; q < RRL_MAX_HITS; ++q) {
+            h1[q] = q < k ? r1[q] : 0x7fffffff;
+            h2[q] = q < j ? r2[q] : 0x7fffffff;
+        }
     }
     sort4(h1, k);  // ascending triangle index == nonzero() order (code/loss.py:125-131)
     sort4(h2, j);
@@ -72,22 +93,24 @@ __device__ __forceinline__ void pair_line(const float *__restrict__ tri1, const 
 #pragma unroll
     for (int a = 0; a < RRL_MAX_HITS; ++a) {
         if (a < k) {
-            float w[3];
-            hit_weights(t1, h1[a], ln, w);
-            inter_point(t1, h1[a], w, q1[a]);
+            float w[3], c[9];
+            tri_coords(t1, st1, h1[a], c);
+            hit_weights(c, ln, w);
+            inter_point(c, w, q1[a]);
             hs1[gl * RRL_MAX_HITS + a] = h1[a];
             Q1[gl * RRL_MAX_HITS + a] = make_float4(q1[a][0], q1[a][1], q1[a][2], 0.0f);
 #pragma unroll
-            for (int c = 0; c < 3; ++c) w1[(gl * RRL_MAX_HITS + a) * 3 + c] = w[c];
+            for (int cc = 0; cc < 3; ++cc) w1[(gl * RRL_MAX_HITS + a) * 3 + cc] = w[cc];
         }
         if (a < j) {
-            float w[3];
-            hit_weights(t2, h2[a], ln, w);
-            inter_point(t2, h2[a], w, q2[a]);
+            float w[3], c[9];
+            tri_coords(t2, st2, h2[a], c);
+            hit_weights(c, ln, w);
+            inter_point(c, w, q2[a]);
             hs2[gl * RRL_MAX_HITS + a] = h2[a];
             Q2[gl * RRL_MAX_HITS + a] = make_float4(q2[a][0], q2[a][1], q2[a][2], 0.0f);
 #pragma unroll
-            for (int c = 0; c < 3; ++c) w2[(gl * RRL_MAX_HITS + a) * 3 + c] = w[c];
+            for (int cc = 0; cc < 3; ++cc) w2[(gl * RRL_MAX_HITS + a) * 3 + cc] = w[cc];
         }
     }
     float *vb = vals + (size_t)b * L * 16;
@@ -118,7 +141,7 @@ __global__ __launch_bounds__(1024) void line_pair_dist_kernel(
     int32_t *__restrict__ hs1, int32_t *__restrict__ hs2, float *__restrict__ w1,
     float *__restrict__ w2, float4 *__restrict__ Q1, float4 *__restrict__ Q2, float *__restrict__ D,
     float *__restrict__ vals, int32_t *__restrict__ nvals, int B, int N, int M, int L, int s_m,
-    int s_n, int e_m, int e_n, int pool) {
+    int s_n, int e_m, int e_n, int pool, int st1, int st2) {
     __shared__ int s_list[1024];
     __shared__ int s_wave[16];
     __shared__ int s_total;
@@ -177,31 +200,42 @@ __global__ __launch_bounds__(1024) void line_pair_dist_kernel(
     if (!active && wave != 0) return;
     if (active)
         pair_line(tri1, tri2, line, hit1, hit2, hs1, hs2, w1, w2, Q1, Q2, D, vals, b, N, M, L, gl, k, j,
-                  feeds_median, pos);
+                  feeds_median, pos, st1, st2);
     if (wave == 0) {
         const int base = __builtin_amdgcn_readfirstlane(base_reg);
         for (int i = lane; i < s_total; i += 64) sel_out[(size_t)b * L + base + i] = s_list[i];
     }
 }
 
-extern "C" int rrl_line_pair_dist(const float *tri1, const float *tri2, const float *line,
-                                  void *ws, size_t ws_bytes, int B, int N, int M, int L, int s_m,
-                                  int s_n, int e_m, int e_n, int pool, void *stream) {
-    if (!tri1 || !tri2 || !line || !ws || B < 0 || N < 0 || M < 0 || L < 0) return RRL_E_ARG;
+// tri2_raw != NULL: the target's prepared records are not in this workspace (its scan was carried
+// over from another one): read its raw rows instead
+static int line_pair_dist_impl(const float *tri2_raw, const float *line, void *ws, size_t ws_bytes, int B,
+                               int N, int M, int L, int s_m, int s_n, int e_m, int e_n, int pool,
+                               void *stream) {
+    if (!line || !ws || B < 0 || N < 0 || M < 0 || L < 0) return RRL_E_ARG;
     if (s_m < 1 || s_n < 1 || e_m > RRL_MAX_HITS + 1 || e_n > RRL_MAX_HITS + 1) return RRL_E_RANGE;
     WsLayout w(B, N, M, L);
     if (ws_bytes < w.total) return RRL_E_WS;
     if (B == 0 || L == 0) return 0;
     hipLaunchKernelGGL(line_pair_dist_kernel, dim3((unsigned)((L + 1023) / 1024), (unsigned)B),
-                       dim3(1024), 0, (hipStream_t)stream, tri1, tri2, line,
+                       dim3(1024), 0, (hipStream_t)stream, w.f32(ws, RRL_WS_PTRI1),
+                       tri2_raw ? tri2_raw : w.f32(ws, RRL_WS_PTRI2), line,
                        w.i32(ws, RRL_WS_COUNT1), w.i32(ws, RRL_WS_HIT1), w.i32(ws, RRL_WS_COUNT2),
                        w.i32(ws, RRL_WS_HIT2), w.u8(ws, RRL_WS_KJ), w.i32(ws, RRL_WS_SEL),
                        w.i32(ws, RRL_WS_NSEL), w.i32(ws, RRL_WS_HS1), w.i32(ws, RRL_WS_HS2),
                        w.f32(ws, RRL_WS_W1), w.f32(ws, RRL_WS_W2), (float4 *)w.f32(ws, RRL_WS_Q1),
                        (float4 *)w.f32(ws, RRL_WS_Q2), w.f32(ws, RRL_WS_D), w.f32(ws, RRL_WS_VALS),
-                       w.i32(ws, RRL_WS_NVALS), B, N, M, L, s_m, s_n, e_m, e_n, pool);
+                       w.i32(ws, RRL_WS_NVALS), B, N, M, L, s_m, s_n, e_m, e_n, pool, PTRI_STRIDE,
+                       tri2_raw ? 9 : PTRI_STRIDE);
     RRL_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int rrl_line_pair_dist(const float *tri1, const float *tri2, const float *line,
+                                  void *ws, size_t ws_bytes, int B, int N, int M, int L, int s_m,
+                                  int s_n, int e_m, int e_n, int pool, void *stream) {
+    if (!tri1 || !tri2) return RRL_E_ARG;  // the prepared records of both (rrl_tri_prepare) are read
+    return line_pair_dist_impl(nullptr, line, ws, ws_bytes, B, N, M, L, s_m, s_n, e_m, e_n, pool, stream);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -742,8 +776,8 @@ static int loss_forward_impl(const float *tri1, const float *tri2, const float *
     }
     if ((rc = rrl_line_tri_scan_clouds(line, ws, ws_bytes, B, N, M, L, mode, chunk, clouds, stream)))
         return rc;
-    if ((rc = rrl_line_pair_dist(tri1, tri2, line, ws, ws_bytes, B, N, M, L, s_m, s_n, e_m, e_n,
-                                 pool, stream)))
+    if ((rc = line_pair_dist_impl(target_ws ? tri2 : nullptr, line, ws, ws_bytes, B, N, M, L, s_m, s_n, e_m,
+                                  e_n, pool, stream)))
         return rc;
     return rrl_loss_reduce(ws, ws_bytes, loss, B, N, M, L, s_m, s_n, e_m, e_n, pool, stream);
 }
