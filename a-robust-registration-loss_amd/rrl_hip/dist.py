@@ -66,6 +66,41 @@ def reduce_payload(payload, group=None):
     return payload
 
 
+class PayloadReducer:
+    """The per-step all-reduce of the 14-float shard payload, overlapped with the NEXT step's
+    kernels: the payload (a static output of the captured step, overwritten by every replay) is
+    copied into a private buffer and reduced asynchronously on RCCL's stream while the compute
+    stream goes on; `submit` first waits for the previous reduction.  The reduced values of step i
+    are returned by `finish()` (call it before the next `submit` to consume every step's sums; a
+    throughput loop only consumes the last) -- one step late, which is all a
+    throughput loop (or an optimiser that applies step i's update while step i+1's forward runs)
+    needs.  xGMI all-reduce latency (tens of microseconds for 56 bytes) is comparable to the
+    step itself, so serialising it would cost a large part of the scaling efficiency."""
+
+    def __init__(self, device, group=None):
+        self.buf = torch.zeros(14, dtype=torch.float32, device=device)
+        self.out = torch.zeros(14, dtype=torch.float32, device=device)
+        self.pending = None
+        self.group = group
+
+    def submit(self, payload):
+        if not dist.is_initialized():
+            self.out = payload
+            return
+        if self.pending is not None:
+            self.pending.wait()          # compute stream waits for the previous reduction
+        self.buf.copy_(payload)
+        self.pending = dist.all_reduce(self.buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def finish(self):
+        """Reduced payload of the last submitted step."""
+        if self.pending is not None:
+            self.pending.wait()
+            self.out.copy_(self.buf)
+            self.pending = None
+        return self.out
+
+
 def sharded_batch_loss(points1, points2, line, rng=(1, 1, 5, 5), loss_fn=None, group=None):
     """points1/points2/line hold the GLOBAL batch on every rank (or identical seeds); each rank
     evaluates its shard and the result is the global (loss_sum, n_valid).  loss_fn(p1, p2, ln,

@@ -6,7 +6,8 @@ One "step" = the fused training op forward + backward, six launches: triangle re
 apply of the source, thresholds, state clearing) -> cell sort + group spheres -> sphere-culled
 line<->triangle scan of both clouds (K1) -> per-line distances (K2) -> median + Welsch reduce
 (K3+K4) -> direct backward to (dR, dT) with the 14-float shard payload (K5') -> one fused
-all-reduce of [loss sum, valid count, sum dR, sum dT] over ranks.  Inputs are resident in HBM before the
+all-reduce of [loss sum, valid count, sum dR, sum dT] over ranks (asynchronous: it overlaps the
+next step's kernels; every reduction completes inside the timed region).  Inputs are resident in HBM before the
 timed region; line sampling (K8) and Chamfer (K7) are timed separately and reported as extras.
 pairs per step = B * L * 3 * (N + M) per GPU; value = all ranks' pairs / max
 time over ranks.  Weak scaling: B=8 per GPU (config 3 of BASELINE.json is B=64 over 8 GPUs).
@@ -125,9 +126,14 @@ def main():
             print(f"[bench] graph capture failed ({type(exc).__name__}: {exc}); eager", file=sys.stderr)
             graphed = None
 
+    reducer = rdist.PayloadReducer(dev)
+
     def step():
         payload = graphed() if graphed is not None else local_step()
-        return rdist.reduce_payload(payload)  # one 14-float all-reduce per step (N > 1)
+        # one 14-float all-reduce per step (N > 1), issued asynchronously: it overlaps the next
+        # step's kernels and is waited for before its buffer is reused (and at the end)
+        reducer.submit(payload)
+        return payload
 
     def fence():
         torch.cuda.synchronize()
@@ -142,7 +148,8 @@ def main():
         ops.scan_timing(4)  # HIP events around every 4th scan launch, on the launch stream
     t0 = time.perf_counter()
     for i in range(args.steps):
-        payload = step()
+        step()
+    payload = reducer.finish()  # the last step's reduction is inside the timed region
     fence()
     dt = time.perf_counter() - t0
     if graphed is not None:
