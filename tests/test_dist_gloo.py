@@ -56,8 +56,17 @@ def _worker(rank, world, port, out):
     l, v = _oracle_loss_fn(p1[lo:hi], p2[lo:hi], ln[lo:hi], (1, 1, 5, 5))
     t2, n2 = rdist.reduce_loss(l, v, (shared,))
     payload = rdist.reduce_payload(torch.arange(14.0) * (rank + 1))
+    # the overlapped reducer used by bench.py: every step's sum arrives, one submit late
+    red = rdist.PayloadReducer(torch.device("cpu"))
+    step_buf = torch.zeros(14)             # stands in for the captured step's static output
+    seen = []
+    for step in range(3):
+        step_buf.copy_(torch.arange(14.0) * (rank + 1) * (step + 1))
+        red.submit(step_buf)
+        seen.append(red.finish().clone())  # consumed before the buffer is overwritten again
     if rank == 0:
-        torch.save(dict(total=total, nvalid=nvalid, t2=t2, n2=n2, shared=shared, payload=payload, n=n), out)
+        torch.save(dict(total=total, nvalid=nvalid, t2=t2, n2=n2, shared=shared, payload=payload, n=n,
+                        seen=torch.stack(seen)), out)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -84,3 +93,5 @@ def test_world2_gloo(tmp_path, oracle):
     np.testing.assert_allclose(float(res["t2"]), want, rtol=1e-6)
     np.testing.assert_allclose(res["shared"].numpy(), np.full(6, 3.0))
     np.testing.assert_allclose(res["payload"].numpy(), np.arange(14.0) * 3)
+    for step in range(3):  # ranks contribute (rank + 1) * (step + 1) * arange
+        np.testing.assert_allclose(res["seen"][step].numpy(), np.arange(14.0) * 3 * (step + 1))
