@@ -21,6 +21,37 @@ typedef float v2f __attribute__((ext_vector_type(2)));
         if (e__ != hipSuccess) return (int)e__;    \
     } while (0)
 
+// Fill / copy as KERNELS.  The library never issues hipMemsetAsync / hipMemcpyAsync: inside a
+// captured hipGraph (the bench and the demo replay their step as one) memset nodes were observed
+// to race with the kernels that follow them on this stack -- the captured demo step
+// intermittently read half-initialised Chamfer keys until the memsets became a kernel.
+static __global__ void rrl_fill_words_kernel(uint32_t *__restrict__ p, uint32_t v, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = v;
+}
+static __global__ void rrl_copy_words_kernel(uint32_t *__restrict__ d, const uint32_t *__restrict__ s, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) d[i] = s[i];
+}
+// nbytes must be a multiple of 4 (every buffer of this library is)
+static inline int rrl_fill(void *p, uint32_t word, size_t nbytes, hipStream_t s) {
+    const size_t n = nbytes / 4;
+    if (n == 0) return 0;
+    size_t nb = (n + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(rrl_fill_words_kernel, dim3((unsigned)nb), dim3(256), 0, s, (uint32_t *)p, word, n);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+static inline int rrl_copy(void *d, const void *src, size_t nbytes, hipStream_t s) {
+    const size_t n = nbytes / 4;
+    if (n == 0) return 0;
+    size_t nb = (n + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(rrl_copy_words_kernel, dim3((unsigned)nb), dim3(256), 0, s, (uint32_t *)d,
+                       (const uint32_t *)src, n);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
 // (dAC - proj) + eps of code/loss.py:84-88 for scalar (T = float) or two lines at
 // once (T = v2f -> v_pk_mul_f32 / v_pk_add_f32, each half rounded like the scalar op).
 template <typename T>

@@ -366,9 +366,10 @@ extern "C" int rrl_chamfer_fwd(const float *x, const float *y, uint64_t *best_x,
     if (!x || !y || !best_x || !best_y || !value || B < 0 || N < 0 || M < 0) return RRL_E_ARG;
     if (B == 0 || N == 0 || M == 0) return RRL_E_ARG;
     hipStream_t s = (hipStream_t)stream;
-    hipError_t e;
-    if ((e = hipMemsetAsync(best_x, 0xff, sizeof(uint64_t) * (size_t)B * N, s)) != hipSuccess) return (int)e;
-    if ((e = hipMemsetAsync(best_y, 0xff, sizeof(uint64_t) * (size_t)B * M, s)) != hipSuccess) return (int)e;
+    // keys start at all-ones (a kernel, never a memset node: see rrl_fill)
+    int rc;
+    if ((rc = rrl_fill(best_x, 0xffffffffu, sizeof(uint64_t) * (size_t)B * N, s))) return rc;
+    if ((rc = rrl_fill(best_y, 0xffffffffu, sizeof(uint64_t) * (size_t)B * M, s))) return rc;
     hipLaunchKernelGGL(chamfer_nn_kernel,
                        dim3((unsigned)((N + 255) / 256), (unsigned)((M + CH_CHUNK - 1) / CH_CHUNK), (unsigned)B),
                        dim3(256), 0, s, x, y, (unsigned long long *)best_x, N, M);
@@ -505,8 +506,8 @@ extern "C" int rrl_dense_scan(const float *tri, const float *line, float *norm_d
     if (!tri || !line || !norm_d || !label || !status || B < 0 || N < 0 || L < 0) return RRL_E_ARG;
     if (L > 65535 || B > 65535) return RRL_E_ARG;
     hipStream_t s = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(status, 0, sizeof(int32_t), s);
-    if (e != hipSuccess) return (int)e;
+    int rc0 = rrl_fill(status, 0u, sizeof(int32_t), s);
+    if (rc0) return rc0;
     if (B == 0 || N == 0 || L == 0) return 0;
     hipLaunchKernelGGL(dense_scan_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)L, (unsigned)B),
                        dim3(256), 0, s, tri, line, norm_d, label, status, N, L);
@@ -568,86 +569,144 @@ __device__ bool box_hit(const float *bb, const float *ln) {
     return any;
 }
 
-// One 1024-lane workgroup per sample walks rounds x candidate tiles IN ORDER; accepted
-// candidates are compacted with a ballot/prefix scan so slot order == candidate order
-// (code/loss.py:365-381), overflow is truncated, unfilled rows stay zero.
-__global__ __launch_bounds__(1024) void sample_lines_kernel(
-    const float *__restrict__ rands, const float *__restrict__ r, const float *__restrict__ centers,
-    const float *__restrict__ aabb1, const float *__restrict__ aabb2, float *__restrict__ lines,
-    int32_t *__restrict__ filled, int B, int n, int rounds) {
-    __shared__ int wave_cnt[16];
-    __shared__ int s_base;
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float rad = r[b];
-    float ctr[3], bb1[6], bb2[6];
+// The reference fills its (N, 6) buffer candidate by candidate, round by round, and skips a round
+// once more than N candidates were accepted (code/loss.py:365-381): slot order == candidate
+// order, overflow truncated, unfilled rows zero.  Two wide launches reproduce that order:
+//   sample_count_kernel: one 1024-lane workgroup per (tile of 1024 candidates, round, sample)
+//     evaluates its candidates and stores how many it accepts;
+//   sample_write_kernel: every workgroup derives its base slot from the tile counts (a walk over
+//     <= rounds x tiles integers, applying the skip rule), re-evaluates its candidates and writes
+//     the accepted ones at base + rank (ballot prefix), then zero-fills its share of the tail.
+// (A single workgroup per sample walking everything in order took 1.9 ms for 10 x 10000
+// candidates; this takes a few tens of microseconds.)
+struct SampleGeom {
+    float rad, ctr[3], bb1[6], bb2[6];
+    bool filter;
+};
+
+__device__ __forceinline__ SampleGeom sample_geom(const float *r, const float *centers, const float *aabb1,
+                                                  const float *aabb2, int b) {
+    SampleGeom g;
+    g.rad = r[b];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) ctr[c] = centers[b * 3 + c];
+    for (int c = 0; c < 3; ++c) g.ctr[c] = centers[b * 3 + c];
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
-        bb1[c] = aabb1 ? aabb1[b * 6 + c] : 0.0f;
-        bb2[c] = aabb2 ? aabb2[b * 6 + c] : 0.0f;
+        g.bb1[c] = aabb1 ? aabb1[b * 6 + c] : 0.0f;
+        g.bb2[c] = aabb2 ? aabb2[b * 6 + c] : 0.0f;
     }
-    const bool filter = aabb1 != nullptr && aabb2 != nullptr;  // NULL boxes: keep every candidate
+    g.filter = aabb1 != nullptr && aabb2 != nullptr;  // NULL boxes: keep every candidate
+    return g;
+}
+
+// candidate i of round rd: code/loss.py:394-411; returns whether it is accepted
+__device__ __forceinline__ bool sample_candidate(const SampleGeom &g, const float *__restrict__ rands, int B,
+                                                 int n, int b, int rd, int i, float *ln) {
     const float pi32 = 3.14159274101257324f;  // torch.pi of code/loss.py:9
-    int count = 0;                            // accepted so far (uniform across the block)
-    for (int rd = 0; rd < rounds; ++rd) {
-        if (count > n) continue;  // code/loss.py:368-369
-        const float *rr = rands + ((size_t)rd * 4 * B + b) * n;  // [rd][s][b][i]
-        const size_t sstride = (size_t)B * n;
-        for (int i0 = 0; i0 < n; i0 += 1024) {
-            const int i = i0 + tid;
-            bool ok = false;
-            float ln[6];
-            if (i < n) {
-                // code/loss.py:394-411
-                float al1 = (rr[i] * 2.0f) * pi32, v1 = rr[sstride + i] * 2.0f - 1.0f;
-                float al2 = (rr[2 * sstride + i] * 2.0f) * pi32, v2 = rr[3 * sstride + i] * 2.0f - 1.0f;
-                float s1 = sqrtf(1.0f - v1 * v1), s2 = sqrtf(1.0f - v2 * v2);
-                float q1[3] = {(rad * s1) * cosf(al1), (rad * sinf(al1)) * s1, rad * v1};
-                float q2[3] = {(rad * s2) * cosf(al2), (rad * sinf(al2)) * s2, rad * v2};
-                float d[3] = {q2[0] - q1[0], q2[1] - q1[1], q2[2] - q1[2]};
-                float den = fmaxf(norm3(d[0], d[1], d[2]), 1e-12f);
+    const float *rr = rands + ((size_t)rd * 4 * B + b) * n;  // [rd][s][b][i]
+    const size_t sstride = (size_t)B * n;
+    float al1 = (rr[i] * 2.0f) * pi32, v1 = rr[sstride + i] * 2.0f - 1.0f;
+    float al2 = (rr[2 * sstride + i] * 2.0f) * pi32, v2 = rr[3 * sstride + i] * 2.0f - 1.0f;
+    float s1 = sqrtf(1.0f - v1 * v1), s2 = sqrtf(1.0f - v2 * v2);
+    float q1[3] = {(g.rad * s1) * cosf(al1), (g.rad * sinf(al1)) * s1, g.rad * v1};
+    float q2[3] = {(g.rad * s2) * cosf(al2), (g.rad * sinf(al2)) * s2, g.rad * v2};
+    float d[3] = {q2[0] - q1[0], q2[1] - q1[1], q2[2] - q1[2]};
+    float den = fmaxf(norm3(d[0], d[1], d[2]), 1e-12f);
 #pragma unroll
-                for (int c = 0; c < 3; ++c) { ln[c] = d[c] / den; ln[3 + c] = q1[c] + ctr[c]; }
-                ok = !filter || (box_hit(bb1, ln) && box_hit(bb2, ln));
+    for (int c = 0; c < 3; ++c) { ln[c] = d[c] / den; ln[3 + c] = q1[c] + g.ctr[c]; }
+    return !g.filter || (box_hit(g.bb1, ln) && box_hit(g.bb2, ln));
+}
+
+__global__ __launch_bounds__(1024) void sample_count_kernel(
+    const float *__restrict__ rands, const float *__restrict__ r, const float *__restrict__ centers,
+    const float *__restrict__ aabb1, const float *__restrict__ aabb2, int32_t *__restrict__ tile_cnt,
+    int B, int n, int rounds) {
+    __shared__ int wave_cnt[16];
+    const int tile = blockIdx.x, rd = blockIdx.y, b = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const SampleGeom g = sample_geom(r, centers, aabb1, aabb2, b);
+    const int i = tile * 1024 + tid;
+    float ln[6];
+    const bool ok = i < n && sample_candidate(g, rands, B, n, b, rd, i, ln);
+    const unsigned long long mask = __ballot(ok);
+    if (lane == 0) wave_cnt[wave] = __popcll(mask);
+    __syncthreads();
+    if (tid == 0) {
+        int acc = 0;
+        for (int w = 0; w < 16; ++w) acc += wave_cnt[w];
+        tile_cnt[((size_t)b * rounds + rd) * gridDim.x + tile] = acc;
+    }
+}
+
+__global__ __launch_bounds__(1024) void sample_write_kernel(
+    const float *__restrict__ rands, const float *__restrict__ r, const float *__restrict__ centers,
+    const float *__restrict__ aabb1, const float *__restrict__ aabb2, const int32_t *__restrict__ tile_cnt,
+    float *__restrict__ lines, int32_t *__restrict__ filled, int B, int n, int rounds) {
+    __shared__ int wave_cnt[16];
+    __shared__ int s_base, s_total, s_skip;
+    const int tile = blockIdx.x, rd = blockIdx.y, b = blockIdx.z, ntiles = gridDim.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    extern __shared__ int s_tc[];  // this sample's tile counts [rounds][ntiles]
+    for (int q = tid; q < rounds * ntiles; q += 1024) s_tc[q] = tile_cnt[(size_t)b * rounds * ntiles + q];
+    __syncthreads();
+    if (tid == 0) {  // the skip rule and this workgroup's base slot from the tile counts
+        int count = 0, base = 0, skip = 0;
+        for (int q = 0; q < rounds; ++q) {
+            const bool skipped = count > n;  // code/loss.py:368-369
+            if (q == rd) { base = count; skip = skipped; }
+            if (skipped) continue;
+            for (int t = 0; t < ntiles; ++t) {
+                if (q == rd && t == tile) base = count;
+                count += s_tc[q * ntiles + t];
             }
-            const unsigned long long mask = __ballot(ok);
-            if (lane == 0) wave_cnt[wave] = __popcll(mask);
-            __syncthreads();
-            if (tid == 0) {
-                int acc = 0;
-                for (int w = 0; w < 16; ++w) { int c = wave_cnt[w]; wave_cnt[w] = acc; acc += c; }
-                s_base = acc;
-            }
-            __syncthreads();
-            if (ok) {
-                int slot = count + wave_cnt[wave] + __popcll(mask & ((1ull << lane) - 1ull));
-                if (slot < n) {
-                    float *dst = lines + ((size_t)b * n + slot) * 6;
+        }
+        s_base = base; s_total = count; s_skip = skip;
+    }
+    const SampleGeom g = sample_geom(r, centers, aabb1, aabb2, b);
+    const int i = tile * 1024 + tid;
+    float ln[6];
+    const bool ok = i < n && sample_candidate(g, rands, B, n, b, rd, i, ln);
+    const unsigned long long mask = __ballot(ok);
+    if (lane == 0) wave_cnt[wave] = __popcll(mask);
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < wave; ++w) woff += wave_cnt[w];
+    if (ok && !s_skip) {
+        const int slot = s_base + woff + __popcll(mask & ((1ull << lane) - 1ull));
+        if (slot < n) {
+            float *dst = lines + ((size_t)b * n + slot) * 6;
 #pragma unroll
-                    for (int c = 0; c < 6; ++c) dst[c] = ln[c];
-                }
-            }
-            count += s_base;
-            __syncthreads();
+            for (int c = 0; c < 6; ++c) dst[c] = ln[c];
         }
     }
-    for (int s = min(count, n) + tid; s < n; s += 1024) {
-        float *dst = lines + ((size_t)b * n + s) * 6;
+    // unfilled rows stay zero: the workgroups of round 0 clear the part of their tile beyond the total
+    if (rd == 0 && i < n && i >= s_total) {
+        float *dst = lines + ((size_t)b * n + i) * 6;
 #pragma unroll
         for (int c = 0; c < 6; ++c) dst[c] = 0.0f;
     }
-    if (tid == 0) filled[b] = count;
+    if (rd == 0 && tile == 0 && tid == 0) filled[b] = s_total;
 }
 
 extern "C" int rrl_sample_lines(const float *rands, const float *r, const float *centers,
                                 const float *aabb1, const float *aabb2, float *lines,
-                                int32_t *filled, int B, int n, int rounds, void *stream) {
-    if (!rands || !r || !centers || !lines || !filled) return RRL_E_ARG;
-    if (B < 0 || n < 0 || rounds < 0) return RRL_E_ARG;
+                                int32_t *filled, int32_t *tile_counts, int B, int n, int rounds,
+                                void *stream) {
+    if (!rands || !r || !centers || !lines || !filled || !tile_counts) return RRL_E_ARG;
+    if (B < 0 || n < 0 || rounds < 0 || rounds > 65535 || B > 65535) return RRL_E_ARG;
     if (B == 0 || n == 0) return 0;
-    hipLaunchKernelGGL(sample_lines_kernel, dim3((unsigned)B), dim3(1024), 0, (hipStream_t)stream,
-                       rands, r, centers, aabb1, aabb2, lines, filled, B, n, rounds);
+    hipStream_t s = (hipStream_t)stream;
+    if (rounds == 0) {
+        int rc = rrl_fill(lines, 0u, sizeof(float) * 6 * (size_t)B * n, s);
+        return rc ? rc : rrl_fill(filled, 0u, sizeof(int32_t) * (size_t)B, s);
+    }
+    const dim3 grid((unsigned)((n + 1023) / 1024), (unsigned)rounds, (unsigned)B);
+    hipLaunchKernelGGL(sample_count_kernel, grid, dim3(1024), 0, s, rands, r, centers, aabb1, aabb2,
+                       tile_counts, B, n, rounds);
+    const size_t lds = sizeof(int32_t) * (size_t)rounds * grid.x;
+    if (lds > 96 * 1024) return RRL_E_ARG;  // > 24576 tiles x rounds: far beyond any caller
+    hipLaunchKernelGGL(sample_write_kernel, grid, dim3(1024), lds, s, rands, r, centers, aabb1, aabb2,
+                       tile_counts, lines, filled, B, n, rounds);
     RRL_LAUNCH_CHECK();
     return 0;
 }

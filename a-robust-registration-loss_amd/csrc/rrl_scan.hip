@@ -118,9 +118,9 @@ int rrl_tri_prepare_clouds(const float *tri1, const float *tri2, void *ws, size_
     const int nmax = clouds == 2 && M > N ? M : N;
     uint4 *zb = (uint4 *)((char *)ws + w.off[RRL_WS_STATUS]);
     if (!sorted || B == 0 || nmax == 0) {
-        // one memset clears status, nvals, nsel, pmax, count1, count2 (contiguous by construction)
-        hipError_t e = hipMemsetAsync(zb, 0, w.zero_bytes, s);
-        if (e != hipSuccess) return (int)e;
+        // one fill clears status, nvals, nsel, pmax, count1, count2 (contiguous by construction)
+        int rc = rrl_fill(zb, 0u, w.zero_bytes, s);
+        if (rc) return rc;
     }
     if (B == 0 || nmax == 0) return 0;
     if (sorted) return rrl_launch_tri_build(tri1, tri2, ws, w, B, N, M, clouds, xf, s);

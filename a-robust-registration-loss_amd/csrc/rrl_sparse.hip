@@ -700,13 +700,9 @@ static int loss_backward_impl(const float *tri1, const float *tri2, const void *
     WsLayout w(B, N, M, L);
     if (ws_bytes < w.total) return RRL_E_WS;
     hipStream_t s = (hipStream_t)stream;
-    hipError_t e;
-    if (zero1 && (size_t)B * N &&
-        (e = hipMemsetAsync(grad_tri1, 0, sizeof(float) * 9 * (size_t)B * N, s)) != hipSuccess)
-        return (int)e;
-    if (grad_tri2 && (size_t)B * M &&
-        (e = hipMemsetAsync(grad_tri2, 0, sizeof(float) * 9 * (size_t)B * M, s)) != hipSuccess)
-        return (int)e;
+    int rc;
+    if (zero1 && (rc = rrl_fill(grad_tri1, 0u, sizeof(float) * 9 * (size_t)B * N, s))) return rc;
+    if (grad_tri2 && (rc = rrl_fill(grad_tri2, 0u, sizeof(float) * 9 * (size_t)B * M, s))) return rc;
     if (B == 0 || L == 0) return 0;
     hipLaunchKernelGGL(loss_bwd_kernel, dim3((unsigned)((8 * (size_t)L + 255) / 256), (unsigned)B),
                        dim3(256), 0, s, w.u8(ws, RRL_WS_KJ), w.i32(ws, RRL_WS_SEL),
@@ -767,12 +763,12 @@ static int loss_forward_impl(const float *tri1, const float *tri2, const float *
     if (target_ws && (size_t)B * L) {  // after the prepare step, which cleared COUNT2
         WsLayout w(B, N, M, L);
         hipStream_t s = (hipStream_t)stream;
-        hipError_t e = hipMemcpyAsync(w.i32(ws, RRL_WS_COUNT2), (const char *)target_ws + w.off[RRL_WS_COUNT2],
-                                      sizeof(int32_t) * (size_t)B * L, hipMemcpyDeviceToDevice, s);
-        if (e == hipSuccess)
-            e = hipMemcpyAsync(w.i32(ws, RRL_WS_HIT2), (const char *)target_ws + w.off[RRL_WS_HIT2],
-                               sizeof(int32_t) * RRL_MAX_HITS * (size_t)B * L, hipMemcpyDeviceToDevice, s);
-        if (e != hipSuccess) return (int)e;
+        if ((rc = rrl_copy(w.i32(ws, RRL_WS_COUNT2), (const char *)target_ws + w.off[RRL_WS_COUNT2],
+                           sizeof(int32_t) * (size_t)B * L, s)))
+            return rc;
+        if ((rc = rrl_copy(w.i32(ws, RRL_WS_HIT2), (const char *)target_ws + w.off[RRL_WS_HIT2],
+                           sizeof(int32_t) * RRL_MAX_HITS * (size_t)B * L, s)))
+            return rc;
     }
     if ((rc = rrl_line_tri_scan_clouds(line, ws, ws_bytes, B, N, M, L, mode, chunk, clouds, stream)))
         return rc;

@@ -129,30 +129,56 @@ def generate_bbox(vertices):
     return torch.where(pick[None], mx[:, None, :], mn[:, None, :]).cpu()
 
 
-def _uniform_rounds(B, n, rounds):
+_pinned = {}
+
+
+def _uniform_rounds(B, n, rounds, device_rng=None):
     """The reference's CPU RNG stream: per round four `torch.rand(B, n)` draws in the order
     alpha1, u1, alpha2, u2 (code/loss.py:394-402), from torch's default CPU generator, so a
-    `torch.manual_seed(s)` before the call selects the same candidates as in the reference."""
-    return torch.stack([torch.stack([torch.rand(B, n) for _ in range(4)]) for _ in range(rounds)])
+    `torch.manual_seed(s)` before the call selects the same candidates as in the reference.
+    One `torch.rand` of the stacked shape consumes the generator exactly like the 4 * rounds
+    separate calls (checked in tests/test_host.py) and lands in a reused pinned buffer, so the
+    upload is one asynchronous copy; the result is on the GPU.  device_rng: a torch.device -> draw on the GPU instead (same
+    distribution, different stream: for training loops, where 4 * rounds * B * n host-generated
+    floats per step would cost more than the loss itself)."""
+    if device_rng is not None:
+        return torch.rand(rounds, 4, B, n, device=device_rng)
+    if B * n < 16:  # torch's scalar path for tiny tensors: keep the reference's call pattern
+        return torch.stack([torch.stack([torch.rand(B, n) for _ in range(4)]) for _ in range(rounds)]).to(
+            _ops.require_gpu())
+    dev = _ops.require_gpu()
+    key = (rounds, B, n)
+    slot = _pinned.get(key)
+    if slot is None:
+        if len(_pinned) > 8:
+            _pinned.clear()
+        slot = _pinned[key] = (torch.empty(rounds, 4, B, n).pin_memory(), torch.cuda.Event())
+    else:
+        slot[1].synchronize()  # the previous upload from this buffer has left the host
+    buf, ev = slot
+    torch.rand(rounds, 4, B, n, out=buf)
+    out = buf.to(dev, non_blocking=True)
+    ev.record()
+    return out
 
 
-def Random_uniform_distribution_lines_batch_efficient(r, centers, N, device='cpu'):
+def Random_uniform_distribution_lines_batch_efficient(r, centers, N, device='cpu', *, device_rng=False):
     """One round of candidate lines: chords between two uniform points of the radius-r sphere
     around `centers` (code/loss.py:384-412).  (B, N, 6) = [unit direction, x0]."""
     B = r.shape[0]
-    rands = _uniform_rounds(B, N, 1)
+    rands = _uniform_rounds(B, N, 1, _ops.require_gpu() if device_rng else None)
     lines, _ = _sample(rands, r, centers, None, None)
     return lines.to(device)
 
 
 def Random_uniform_distribution_lines_batch_efficient_resample(r, centers, N, vertices1, vertices2,
-                                                               device='cpu', *, rounds=10):
+                                                               device='cpu', *, rounds=10, device_rng=False):
     """`rounds` (reference: 10) rejection rounds: a candidate is kept when it crosses the AABB
     of BOTH clouds by the reference's 12-triangle sub-area test; kept candidates fill an
     (B, N, 6) buffer front to back, overflow is dropped, unfilled rows stay all-zero
     (code/loss.py:415-432, 365-381)."""
     B = r.shape[0]
-    rands = _uniform_rounds(B, N, rounds)
+    rands = _uniform_rounds(B, N, rounds, _ops.require_gpu() if device_rng else None)
     lines, _ = _sample(rands, r, centers, _ops.aabb(vertices1), _ops.aabb(vertices2))
     return lines.to(device)
 

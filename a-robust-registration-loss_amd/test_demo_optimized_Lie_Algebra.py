@@ -15,6 +15,8 @@ Differences, all additive:
   * `--graph` replays the whole step (exp map, fused transform + loss, backward, Adam,
     Chamfer) as one captured hipGraph: one host call per epoch and no host synchronisation
     except for the progress line every `--print_every` epochs;
+  * `--device_rng` draws the candidate lines' uniforms on the GPU (the reference's CPU stream
+    costs more host time per epoch than the whole optimisation step);
   * `lines_fn(epoch, moved_src)` lets a test inject recorded lines.
 """
 import argparse
@@ -128,16 +130,17 @@ class _GatedAdam:
         self.p.data.sub_(torch.where(ok, delta, torch.zeros_like(delta)))
 
 
-def _default_lines(radius, centers, n_sample_line, target, device):
+def _default_lines(radius, centers, n_sample_line, target, device, device_rng=False):
     def draw(epoch, moved):
         return Random_uniform_distribution_lines_batch_efficient_resample(
             radius.reshape(1, 1), centers.reshape(1, -1), n_sample_line, moved.view(1, -1, 3),
-            target.view(1, -1, 3), device).detach().view(-1, 6)
+            target.view(1, -1, 3), device, device_rng=device_rng).detach().view(-1, 6)
     return draw
 
 
 def test_one_case(data, Save_path, writer=None, n_epoch=1000, n_sample_line=20000, device='cuda:0',
-                  *, lines_fn=None, graph=False, save_every=10, print_every=1, model=None):
+                  *, lines_fn=None, graph=False, save_every=10, print_every=1, model=None,
+                  device_rng=False):
     """code/test_demo_optimized_Lie_Algebra.py:27-100.  Returns the per-epoch history
     [(epoch, loss or None, chamfer or None)] (floats; in graph mode filled at the end from
     device buffers) and the Reconstruction_point module."""
@@ -151,7 +154,7 @@ def test_one_case(data, Save_path, writer=None, n_epoch=1000, n_sample_line=2000
     os.makedirs(Save_path, exist_ok=True)
     Reconstruction = (model or Reconstruction_point()).to(dev)
     radius = (bounding_box[0, :] - bounding_box[-1, :]).norm(p=2).reshape(1)
-    draw = lines_fn or _default_lines(radius, centers, n_sample_line, tar, dev)
+    draw = lines_fn or _default_lines(radius, centers, n_sample_line, tar, dev, device_rng)
     if graph:
         return _run_graphed(Reconstruction, draw, src, src_nb, tar, tar_tri, Save_path, writer,
                             n_epoch, save_every, print_every), Reconstruction
@@ -279,7 +282,8 @@ def main(args):
     writer = make_writer(os.path.join(args.Save_path, 'log'))
     history, model = test_one_case(data, args.Save_path, writer=writer, n_epoch=args.n_epoch,
                                    n_sample_line=args.n_sample_line, device=device, graph=args.graph,
-                                   print_every=args.print_every)
+                                   print_every=args.print_every, save_every=getattr(args, 'save_every', 10),
+                                   device_rng=getattr(args, 'device_rng', False))
     writer.close()
     return history, model
 
@@ -298,6 +302,9 @@ if __name__ == "__main__":
                         help="use a seeded synthetic pair of N points instead of OBJ files")
     parser.add_argument('--graph', action='store_true', help="replay the step as one hipGraph")
     parser.add_argument('--print_every', type=int, default=1)
+    parser.add_argument('--save_every', type=int, default=10, help="0: no OBJ / transform files")
+    parser.add_argument('--device_rng', action='store_true',
+                        help="draw the lines' uniforms on the GPU instead of torch's CPU generator")
     args = parser.parse_args()
     save_root = args.Save_path
     if args.synthetic:

@@ -236,14 +236,16 @@ int rrl_dense_scan(const float *tri, const float *line, float *norm_d, uint8_t *
 
 /* ---- line sampler (code/loss.py:265-432) ------------------------------------------------- */
 /* rrl_aabb: per-sample min/max -> aabb [B][6] = min xyz, max xyz (loss.py:325-351).
- * rrl_sample_lines: all `rounds` rejection rounds in one launch.
+ * rrl_sample_lines: all `rounds` rejection rounds in two wide launches, slot order == the
+ *   reference's candidate order.
  *   rands [rounds][4][B][n] uniform [0,1) draws in the reference's stream order
  *   r [B], centers [B][3], aabb1/aabb2 [B][6] (both NULL: keep every candidate, loss.py:384-412)
- *   lines [B][n][6] (unfilled rows zeroed by the call), filled [B] = accepted (may exceed n) */
+ *   lines [B][n][6] (unfilled rows zeroed by the call), filled [B] = accepted (may exceed n)
+ *   tile_counts: scratch, int32 [B][rounds][ceil(n/1024)] */
 int rrl_aabb(const float *v, float *aabb, int B, int n, void *stream);
 int rrl_sample_lines(const float *rands, const float *r, const float *centers, const float *aabb1,
-                     const float *aabb2, float *lines, int32_t *filled, int B, int n, int rounds,
-                     void *stream);
+                     const float *aabb2, float *lines, int32_t *filled, int32_t *tile_counts, int B,
+                     int n, int rounds, void *stream);
 
 /* ---- pseudo-triangle builder (code/loss.py:473-485 + code/utils.py:275-296) --------------- */
 /* Farthest-point sampling of S <= n points per cloud, starting at start[b] (the reference draws it

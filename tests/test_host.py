@@ -143,3 +143,15 @@ def test_synth_is_deterministic_and_well_formed():
     assert c["tar"].shape == (128, 3)
     r = synth.uniform_streams(5, 2, 7)
     assert r.shape == (2, 4, 7) and 0 <= r.min() and r.max() < 1
+
+
+def test_stacked_rand_consumes_the_generator_like_separate_calls():
+    """loss._uniform_rounds draws all rounds with ONE torch.rand: same CPU stream as the reference's
+    four `torch.rand(B, n)` calls per round (code/loss.py:394-402)."""
+    import torch
+    for B, n, rounds in ((1, 20000, 10), (3, 777, 10), (2, 8, 3), (8, 10000, 2)):
+        torch.manual_seed(11)
+        seq = torch.stack([torch.stack([torch.rand(B, n) for _ in range(4)]) for _ in range(rounds)])
+        torch.manual_seed(11)
+        one = torch.rand(rounds, 4, B, n)
+        assert torch.equal(seq, one), (B, n, rounds)
