@@ -180,6 +180,14 @@ class _IntersectionLoss(torch.autograd.Function):
             raise ValueError("Input is wrong: points1/points2/line must be 3-D (B, n, c)")
         if not (tri1.shape[0] == tri2.shape[0] == ln.shape[0]):
             raise ValueError("points1, points2 and line must share the batch dimension")
+        if tri1.shape[0] == 0 or ln.shape[1] == 0:  # empty batch / no lines: nothing to launch
+            ctx.st = None
+            ctx.set_materialize_grads(False)
+            dev, G = tri1.device, (1 if pool else tri1.shape[0])
+            out = (torch.zeros(G, device=dev), torch.zeros(G, 4, dtype=torch.int32, device=dev),
+                   torch.zeros(4, dtype=torch.int32, device=dev))
+            ctx.mark_non_differentiable(out[1], out[2])
+            return out
         st = loss_forward_raw(tri1, tri2, ln, rng, pool, mode, chunk, target_from=target_from)
         ctx.st, ctx.tri1, ctx.tri2, ctx.pool = st, tri1, tri2, bool(pool)
         ctx.in_devs = (points1.device, points2.device)
@@ -193,7 +201,7 @@ class _IntersectionLoss(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_loss, _g1, _g2):
-        if g_loss is None:
+        if g_loss is None or ctx.st is None:
             return (None,) * 8
         lib = _lib.load()
         st, tri1, tri2 = ctx.st, ctx.tri1, ctx.tri2
@@ -249,6 +257,15 @@ class _RegistrationLoss(torch.autograd.Function):
         M, L = tri2.shape[1], ln.shape[1]
         if not (tri2.shape[0] == ln.shape[0] == Rm.shape[0] == tv.shape[0] == B):
             raise ValueError("batch dimensions differ")
+        if B == 0 or L == 0:  # empty batch / no lines: nothing to launch, zero loss, zero gradient
+            ctx.st = None
+            ctx.set_materialize_grads(False)
+            dev = src.device
+            out = (torch.zeros(B, device=dev), torch.zeros(B, 4, dtype=torch.int32, device=dev),
+                   torch.zeros(4, dtype=torch.int32, device=dev))
+            _IntersectionLoss.last_state = None
+            ctx.mark_non_differentiable(out[1], out[2])
+            return out
         s_m, s_n, e_m, e_n = _check_range(rng)
         st = LossState(B, N, M, L, B, src.device)
         check(_lib.load().rrl_registration_forward_cached(
@@ -265,7 +282,7 @@ class _RegistrationLoss(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_loss, _g1, _g2):
-        if g_loss is None:
+        if g_loss is None or ctx.st is None:
             return (None,) * 11
         st, src, Rm, tri2 = ctx.st, ctx.src, ctx.Rm, ctx.tri2
         tr, want_payload, Rshape, tshape, sdev = ctx.meta

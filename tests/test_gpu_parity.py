@@ -376,6 +376,66 @@ def test_target_scan_reuse_is_bit_identical(L, mode, n, m):
         ops.loss_forward_raw(moved[:, :-1], tar, lines, mode=mode, target_from=first)
 
 
+@pytest.mark.parametrize("n,m,nl", [(1, 1, 1), (3, 2, 5), (16, 17, 63), (17, 16, 64), (33, 100, 65), (100, 31, 129),
+                                    (250, 250, 1023), (64, 640, 1025), (5, 5, 4000)])
+def test_ragged_sizes_vs_oracle(L, oracle, n, m, nl):
+    """Sizes around every tile boundary of the kernels (16-triangle groups, 64-lane waves, 128-line
+    workgroups, 1024-line tiles): counts exact, loss 2e-6 against the oracle, in the culled and the
+    strict scan, through the fused op as well (B = 2: a real sample next to a shifted copy)."""
+    from rrl_hip import ops, synth
+    pr = synth.make_pair(300 + n + m, max(n, 8), max(m, 8))
+    t1, t2 = pr["src_tri"][:n], pr["tar_tri"][:m]
+    rands = synth.uniform_streams(n * 7 + m, 10, nl)
+    lines = oracle.resample_lines(rands, pr["radius"], pr["center"], pr["src"], pr["tar"], nl)
+    o = oracle.loss(t1, t2, lines)
+    o1, o2 = oracle.scan(t1, lines, cap=4), oracle.scan(t2, lines, cap=4)
+    for mode in ("cull", "strict"):
+        st = run_state(t1, t2, lines, mode=mode)
+        np.testing.assert_array_equal(st.count1[0].cpu().numpy(), o1["count"])
+        np.testing.assert_array_equal(st.count2[0].cpu().numpy(), o2["count"])
+        if o["loss"] is None:
+            assert int(st.info[0, 0]) == 0 and float(st.loss[0]) == 0.0
+        else:
+            np.testing.assert_allclose(float(st.loss[0]), o["loss"], rtol=2e-6)
+    src = cu(np.stack([t1, t1 + 0.02]))
+    tar = cu(np.stack([t2, t2]))
+    ln = cu(np.stack([lines, lines]))
+    R = torch.eye(3, device="cuda").repeat(2, 1, 1).requires_grad_(True)
+    t = torch.zeros(2, 3, device="cuda").requires_grad_(True)
+    loss, info, _ = ops.registration_loss(src, R, t, tar, ln)
+    loss.sum().backward()
+    assert torch.isfinite(R.grad).all() and torch.isfinite(t.grad).all()
+    if o["loss"] is None:
+        assert int(info[0, 0]) == 0 and float(loss.detach()[0]) == 0.0 and float(R.grad[0].abs().sum()) == 0.0
+    else:
+        np.testing.assert_allclose(float(loss.detach()[0]), o["loss"], rtol=2e-6)
+        # dL/dt of the fused op = sum of the per-point gradient of the oracle
+        np.testing.assert_allclose(t.grad[0].cpu().numpy(), np.asarray(o["grad1"], np.float64).reshape(-1, 3).sum(0),
+                                   rtol=2e-3, atol=2e-6)
+
+
+def test_empty_line_set_and_empty_batch(L):
+    """L = 0 lines: nothing selected -> None from the drop-in call, zero loss and gradient from the
+    fused op; B = 0: empty tensors in, empty tensors out."""
+    from rrl_hip import ops, synth
+    pr = synth.make_pair(3, 40, 50)
+    t1, t2 = cu(pr["src_tri"])[None], cu(pr["tar_tri"])[None]
+    none = torch.zeros(1, 0, 6, device="cuda")
+    assert L.cal_loss_intersection_batch_whole_median_pts_lines(1, 1, 5, 5, t1.clone().requires_grad_(True), t2,
+                                                                none, "cuda") is None
+    R = torch.eye(3, device="cuda")[None].requires_grad_(True)
+    t = torch.zeros(1, 3, device="cuda").requires_grad_(True)
+    loss, info, _ = ops.registration_loss(t1, R, t, t2, none, want_payload=True)
+    loss.sum().backward()
+    assert float(loss.detach()[0]) == 0.0 and int(info[0, 0]) == 0 and R.grad is None
+    e = torch.zeros(0, 40, 9, device="cuda")
+    loss, info, _ = ops.intersection_loss(e, torch.zeros(0, 50, 9, device="cuda"), torch.zeros(0, 10, 6, device="cuda"))
+    assert loss.shape == (0,) and info.shape == (0, 4)
+    loss, info, _ = ops.registration_loss(e, torch.zeros(0, 3, 3, device="cuda"), torch.zeros(0, 3, device="cuda"),
+                                          torch.zeros(0, 50, 9, device="cuda"), torch.zeros(0, 10, 6, device="cuda"))
+    assert loss.shape == (0,) and info.shape == (0, 4)
+
+
 # BASELINE.json configs[0], [3], [4] (the bench runs configs[1]; [2] is its 8-GPU shard), plus a
 # cloud one past the 16384-triangle limit of the sorted/culled layout (falls back to the dense scan)
 @pytest.mark.parametrize("n,m,nl,crop,noise", [
