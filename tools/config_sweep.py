@@ -43,3 +43,5 @@ run("C2 L=20000", 8, 4096, 4096, 20000)
 run("C4 partial overlap", 8, 2048, 1024, 10000, crop=True, noise=0.02)
 run("C5 fragments", 1, 16384, 16384, 512)
 run("C5 fragments B=8", 8, 16384, 16384, 512)
+run("C3 whole batch on one GPU (B=64)", 64, 4096, 4096, 10000)
+run("B=32", 32, 4096, 4096, 10000)
