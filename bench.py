@@ -208,7 +208,10 @@ def main():
                 "hbm": {"achieved": alg_bytes / scan_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": alg_bytes / scan_s / 1e9 / HBM_PEAK_GBS,
                         "algorithmic_bytes": alg_bytes},
-                "traffic": pmc,
+                # HBM bytes per launch of that kernel from the PMC counters (separate rocprofv3 --pmc
+                # passes, gfx950-corrected: profiles/scan_hbm_traffic.json), null when not collected
+                "traffic": (pmc or {}).get("bytes"),
+                "traffic_detail": pmc,
             },
             "extras": {"loss_sum": float(payload[0]), "valid": float(payload[1]),
                        "chamfer_ms": chamfer_ms, "chamfer_pairs_per_s": B * N * M / (chamfer_ms * 1e-3),
