@@ -7,16 +7,25 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "a-robust-registration-loss_amd"))
 from rrl_hip import ops, synth
 from rrl_hip.graph import GraphedStep
-from oracle import rrl_oracle as o
-o.build()
+
+
+def product_lines(prs, L):
+    """(B, L, 6) lines for the synthetic pairs from the PRODUCT sampler (CPU RNG stream seeded by the
+    sample index); tools never touch oracle/ (test infrastructure only)."""
+    import loss as Lmod
+    out = []
+    for b, p in enumerate(prs):
+        torch.manual_seed(b)
+        out.append(Lmod.Random_uniform_distribution_lines_batch_efficient_resample(
+            torch.tensor([[float(p["radius"])]]), torch.from_numpy(p["center"]).reshape(1, 3), L,
+            torch.from_numpy(p["src"])[None].cuda(), torch.from_numpy(p["tar"])[None].cuda(), "cuda")[0])
+    return torch.stack(out)
 
 def run(name, B, N, M, L, crop=False, noise=0.01):
     prs = [synth.make_pair(b, N, M, crop=crop, noise=noise) for b in range(B)]
-    lines = np.stack([o.resample_lines(synth.uniform_streams(b, 10, L), p["radius"], p["center"], p["src"], p["tar"], L)
-                      for b, p in enumerate(prs)])
     src = torch.from_numpy(np.stack([p["src_tri"] for p in prs])).cuda()
     tar = torch.from_numpy(np.stack([p["tar_tri"] for p in prs])).cuda()
-    ln = torch.from_numpy(lines).cuda()
+    ln = product_lines(prs, L)
     R = torch.eye(3, device="cuda").repeat(B, 1, 1).requires_grad_(True)
     t = torch.zeros(B, 3, device="cuda").requires_grad_(True)
     ones = torch.ones(B, device="cuda")

@@ -8,12 +8,14 @@ for flags in "$@"; do
 import os, sys, numpy as np, torch
 sys.path.insert(0, "a-robust-registration-loss_amd"); sys.path.insert(0, ".")
 from rrl_hip import ops, synth
-from oracle import rrl_oracle as o
-o.build()
+import loss as Lmod
 B, N, L = 8, 4096, 10000
 prs = [synth.make_pair(b, N, N) for b in range(B)]
-lines = np.stack([o.resample_lines(synth.uniform_streams(b, 10, L), p["radius"], p["center"], p["src"], p["tar"], L) for b, p in enumerate(prs)])
-src = torch.from_numpy(np.stack([p["src_tri"] for p in prs])).cuda(); tar = torch.from_numpy(np.stack([p["tar_tri"] for p in prs])).cuda(); ln = torch.from_numpy(lines).cuda()
+lns = []
+for b, p in enumerate(prs):
+    torch.manual_seed(b)
+    lns.append(Lmod.Random_uniform_distribution_lines_batch_efficient_resample(torch.tensor([[float(p["radius"])]]), torch.from_numpy(p["center"]).reshape(1, 3), L, torch.from_numpy(p["src"])[None].cuda(), torch.from_numpy(p["tar"])[None].cuda(), "cuda")[0])
+src = torch.from_numpy(np.stack([p["src_tri"] for p in prs])).cuda(); tar = torch.from_numpy(np.stack([p["tar_tri"] for p in prs])).cuda(); ln = torch.stack(lns)
 ops.scan_timing(1)
 for _ in range(30): st = ops.loss_forward_raw(src, tar, ln)
 torch.cuda.synchronize()

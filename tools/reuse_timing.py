@@ -10,13 +10,22 @@ sys.path.insert(0, ROOT)
 
 B, N, L = 8, 4096, 10000
 prs = [synth.make_pair(b, N, N) for b in range(B)]
-from oracle import rrl_oracle as o
-o.build()
-lines = np.stack([o.resample_lines(synth.uniform_streams(b, 10, L), p["radius"], p["center"], p["src"], p["tar"], L)
-                  for b, p in enumerate(prs)])
+
+
+def product_lines(prs, L):
+    """(B, L, 6) lines for the synthetic pairs from the PRODUCT sampler (CPU RNG stream seeded by the
+    sample index); tools never touch oracle/ (test infrastructure only)."""
+    import loss as Lmod
+    out = []
+    for b, p in enumerate(prs):
+        torch.manual_seed(b)
+        out.append(Lmod.Random_uniform_distribution_lines_batch_efficient_resample(
+            torch.tensor([[float(p["radius"])]]), torch.from_numpy(p["center"]).reshape(1, 3), L,
+            torch.from_numpy(p["src"])[None].cuda(), torch.from_numpy(p["tar"])[None].cuda(), "cuda")[0])
+    return torch.stack(out)
 src = torch.from_numpy(np.stack([p["src_tri"] for p in prs])).cuda()
 tar = torch.from_numpy(np.stack([p["tar_tri"] for p in prs])).cuda()
-ln = torch.from_numpy(lines).cuda()
+ln = product_lines(prs, L)
 R = torch.eye(3, device="cuda").repeat(B, 1, 1).requires_grad_(True)
 t = torch.zeros(B, 3, device="cuda").requires_grad_(True)
 ones = torch.ones(B, device="cuda")
