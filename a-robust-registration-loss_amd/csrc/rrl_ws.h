@@ -40,7 +40,7 @@ struct WsLayout {
             4 * b * l * 16,      // Q1
             4 * b * l * 16,      // Q2
             4 * b * l * 16,      // D
-            4 * b * l * 16,      // VALS
+            4 * b * ((l + 1023) / 1024) * 1024 * 16,  // VALS (canonical D tiles by compact slot)
             4 * b,               // MED   (G <= B)
             4 * b * 16,          // BCNT
             8 * b * 32,          // BSUM
@@ -49,6 +49,8 @@ struct WsLayout {
             4 * b * n * 9,       // G1
             4 * b * 12 * ((3 * n + 1023) / 1024 + 1),    // RPART
             4 * b * 12 * ((l + 63) / 64 + 1),            // BPART
+            b * ((l + 1023) / 1024) * 1024,              // KJC
+            4 * b * ((l + 1023) / 1024 + 1),             // BLKCNT
         };
         size_t o = 0;
         for (int i = 0; i < RRL_WS_FIELDS; ++i) {

@@ -42,7 +42,7 @@ _WS_FIELDS = [
     ("Q1", torch.float32, lambda B, N, M, L, G: (B, L, 4, 4)),
     ("Q2", torch.float32, lambda B, N, M, L, G: (B, L, 4, 4)),
     ("D", torch.float32, lambda B, N, M, L, G: (B, L, 16)),
-    ("vals", torch.float32, lambda B, N, M, L, G: (B, 16 * L)),
+    ("vals", torch.float32, lambda B, N, M, L, G: (B, (L + 1023) // 1024 * 1024, 16)),
     ("med", torch.float32, lambda B, N, M, L, G: (G,)),
     ("bcnt", torch.int32, lambda B, N, M, L, G: (G, 16)),
     ("bsum", torch.int64, lambda B, N, M, L, G: (G, 16, 2)),
@@ -51,6 +51,8 @@ _WS_FIELDS = [
     ("g1", torch.float32, lambda B, N, M, L, G: (B, N, 9)),
     ("rpart", torch.float32, lambda B, N, M, L, G: (B, (3 * N + 1023) // 1024 + 1, 12)),
     ("bpart", torch.float32, lambda B, N, M, L, G: (B, (L + 63) // 64 + 1, 12)),
+    ("kjc", torch.uint8, lambda B, N, M, L, G: (B, (L + 1023) // 1024 * 1024)),
+    ("blkcnt", torch.int32, lambda B, N, M, L, G: (B * ((L + 1023) // 1024 + 1),)),
 ]
 _layout_cache = {}
 

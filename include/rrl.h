@@ -57,7 +57,7 @@ extern "C" {
 /* workspace fields (indices into rrl_workspace_layout's offset array) */
 enum {
     RRL_WS_STATUS = 0, /* int32[4]   [0] = NaN seen (reference exit(0), loss.py:89-91); [3] = internal ticket */
-    RRL_WS_NVALS,      /* int32[B]   D values appended per sample                           */
+    RRL_WS_NVALS,      /* int32[B]   (unused since the compact-slot layout; kept for ABI stability) */
     RRL_WS_NSEL,       /* int32[B]   selected lines per sample (length of SEL[b])           */
     RRL_WS_PMAX,       /* uint32[2][B] bits of max |P|^2 per cloud and sample                */
     RRL_WS_COUNT1,     /* int32[B][L] hit count, cloud 1 (loss.py:185)                      */
@@ -84,7 +84,9 @@ enum {
     RRL_WS_Q1,         /* float[B][L][4][4] intersection points q (xyz, 0) (loss.py:155-163)  */
     RRL_WS_Q2,
     RRL_WS_D,          /* float[B][L][16] k x j block of |q1-q2|^2 (loss.py:165-166)        */
-    RRL_WS_VALS,       /* float[B][16 L] compacted D values (median input)                  */
+    RRL_WS_VALS,       /* float[B][Lp][16] canonical 4x4 D tiles (+inf padded) of the selected lines
+                          at compact slots: slot = 1024 * x + rank for the x-th 1024-line tile,
+                          Lp = 1024 * ceil(L/1024) (input of the reduce kernel)                */
     RRL_WS_MED,        /* float[G]  lower median (loss.py:223-224)                          */
     RRL_WS_BCNT,       /* int32[G][16] lines per (k,j) bucket                               */
     RRL_WS_BSUM,       /* int64[G][16][2] bucket sums of row / column minima, 2^-40 fixed pt */
@@ -94,6 +96,8 @@ enum {
     RRL_WS_RPART,      /* float[B][nblk][12] rigid-apply backward partial sums              */
     RRL_WS_BPART,      /* float[B][ceil(L/64)+1][12] per-workgroup (dR, dt) partials of the
                           direct backward (rrl_registration_backward without grad_src)       */
+    RRL_WS_KJC,        /* uint8[B][Lp]  k | j<<4 at the compact slots                            */
+    RRL_WS_BLKCNT,     /* int32[B][ceil(L/1024)] selected lines per 1024-line tile               */
     RRL_WS_FIELDS
 };
 
