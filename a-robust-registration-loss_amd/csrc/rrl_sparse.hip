@@ -405,17 +405,17 @@ __global__ __launch_bounds__(1024) void loss_reduce_kernel(
     const float med = n ? __uint_as_float(prefix) : 0.0f;
 
     // ---- Welsch + symmetric min per selected line, bucket sums in LDS (fixed point)
+    // The forward needs the VALUES of the row / column minima only, and Welsch1 is non-decreasing
+    // in D: min_b Welsch(D[a][b]) = Welsch(min_b D[a][b]) -- k + j exponentials instead of 16
+    // (which entry attains the minimum matters to the backward alone: welsch_block there).
     auto accumulate = [&](const float *Dl, int k, int j) {
-        float rowmin[4], colmin[4];
-        int arg_b[4], arg_a[4];
-        welsch_block(Dl, med, rowmin, colmin, arg_b, arg_a);
         float row = 0.0f, col = 0.0f;
 #pragma unroll
         for (int a = 0; a < RRL_MAX_HITS; ++a)
-            if (a < k) row += rowmin[a];
+            if (a < k) row += welsch(fminf(fminf(Dl[a * 4], Dl[a * 4 + 1]), fminf(Dl[a * 4 + 2], Dl[a * 4 + 3])), med);
 #pragma unroll
         for (int bb = 0; bb < RRL_MAX_HITS; ++bb)
-            if (bb < j) col += colmin[bb];
+            if (bb < j) col += welsch(fminf(fminf(Dl[bb], Dl[4 + bb]), fminf(Dl[8 + bb], Dl[12 + bb])), med);
         // Wl in [0,1], <= 4 terms: 2^-40 fixed point keeps ~2^-38 relative resolution
         const int bi = (k - 1) * 4 + (j - 1);
         atomicAdd(&s_sum[bi * 2 + 0], (unsigned long long)((double)row * (double)(1ll << FIX_SHIFT) + 0.5));
