@@ -164,7 +164,9 @@ __global__ __launch_bounds__(REC_BLK) void tri_records_kernel(const BuildArgs a)
 // NPT == 0: they are re-read (16 B per triangle).
 template <int NPT>
 __global__ __launch_bounds__(1024) void tri_sort_kernel(const BuildArgs a) {
-    // NPT > 0: the sorted records stay in LDS for the sphere pass ([ng*16] float4);
+    // NPT > 0: the sorted records and their triangle indices are assembled in LDS ([ng*17] float4,
+    //          one float4 of padding per group: lanes on different groups hit different banks;
+    //          then [ng*16] int) and leave with coalesced stores;
     // NPT == 0: only the thr bound by sorted position ([ng*16] float), records re-read from P0S
     extern __shared__ __attribute__((aligned(16))) float dyn_s[];
     float *thr_s = dyn_s;
@@ -181,6 +183,8 @@ __global__ __launch_bounds__(1024) void tri_sort_kernel(const BuildArgs a) {
     float4 *p0s = (cloud ? a.p0s2 : a.p0s1) + (size_t)b * ng * GRP;
     int32_t *idx = (cloud ? a.idx2 : a.idx1) + (size_t)b * ng * GRP;
     float4 *grp = (cloud ? a.grp2 : a.grp1) + (size_t)b * ng;
+    int *sidx = (int *)(srec + (size_t)ng * 17);
+    auto pad = [](int s) { return s + (s >> 4); };
 
     // ---- AABB of the P0s and max |P|^2 from the per-workgroup partials of tri_records_kernel
     constexpr int NR = NPT > 0 ? NPT : 1;
@@ -259,38 +263,80 @@ __global__ __launch_bounds__(1024) void tri_sort_kernel(const BuildArgs a) {
     // thr <= sqrtf(thr2) (1 + 2^-22): thr2 is the smallest float whose rounded root reaches thr
     auto thr_bound = [](float thr2) { return sqrtf(thr2) * 1.000001f; };
     if (NPT > 0) {
+        // scatter into LDS only; the global arrays are written afterwards, in order
 #pragma unroll
         for (int k = 0; k < NR; ++k) {
             const int f = tid + 1024 * k;
             if (f < n) {
                 const int s = (int)atomicAdd(&hist[cell[k]], 1u);
-                p0s[s] = rec[k];
-                idx[s] = f;
-                srec[s] = rec[k];
+                srec[pad(s)] = rec[k];
+                sidx[s] = f;
             }
         }
-    } else {
-        for (int f = tid; f < n; f += 1024) {
-            const float4 r = crec[f];
-            const int s = (int)atomicAdd(&hist[cell_of(r)], 1u);
-            p0s[s] = r;
-            idx[s] = f;
-            thr_s[s] = thr_bound(r.w);
+        for (int s = n + tid; s < ng * GRP; s += 1024) {  // pad: thr2 = 0 never passes
+            srec[pad(s)] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            sidx[s] = 0;
         }
+        __syncthreads();
+        for (int s = tid; s < ng * GRP; s += 1024) {  // coalesced copy-out
+            p0s[s] = srec[pad(s)];
+            idx[s] = sidx[s];
+        }
+        // ---- group spheres: ONE lane per group walks its 16 records (16x less work than 16 lanes
+        //      reducing each other's values with DPP butterflies; this phase took 5.3 us of the
+        //      kernel's 14.4 on its single CU)
+        for (int g = tid; g < ng; g += 1024) {
+            const float4 *r = srec + (size_t)g * 17;
+            float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY}, tm = 0.0f;
+            float px[GRP], py[GRP], pz[GRP];
+#pragma unroll
+            for (int t = 0; t < GRP; ++t) {
+                const float4 v = r[t];
+                px[t] = v.x; py[t] = v.y; pz[t] = v.z;
+                if (g * GRP + t < n) {
+                    lo[0] = fminf(lo[0], v.x); hi[0] = fmaxf(hi[0], v.x);
+                    lo[1] = fminf(lo[1], v.y); hi[1] = fmaxf(hi[1], v.y);
+                    lo[2] = fminf(lo[2], v.z); hi[2] = fmaxf(hi[2], v.z);
+                    tm = fmaxf(tm, thr_bound(v.w));
+                }
+            }
+            const float cx = 0.5f * lo[0] + 0.5f * hi[0], cy = 0.5f * lo[1] + 0.5f * hi[1],
+                        cz = 0.5f * lo[2] + 0.5f * hi[2];
+            float d2 = 0.0f;
+#pragma unroll
+            for (int t = 0; t < GRP; ++t) {
+                const float ex = px[t] - cx, ey = py[t] - cy, ez = pz[t] - cz;
+                const float e2 = ex * ex + ey * ey + ez * ez;
+                if (g * GRP + t < n) d2 = fmaxf(d2, e2);
+            }
+            const float rho = sqrtf(d2) * 1.00001f + 1e-7f;
+            const float R = rho + tm;
+            float R2 = R * R * 1.0001f + 1e-7f;
+            if (!(R2 < 3.0e38f)) R2 = INFINITY;  // non-finite data: keep the group
+            grp[g] = make_float4(cx, cy, cz, R2);
+        }
+        return;
+    }
+    for (int f = tid; f < n; f += 1024) {
+        const float4 r = crec[f];
+        const int s = (int)atomicAdd(&hist[cell_of(r)], 1u);
+        p0s[s] = r;
+        idx[s] = f;
+        thr_s[s] = thr_bound(r.w);
     }
     for (int s = n + tid; s < ng * GRP; s += 1024) {  // pad: thr2 = 0 never passes
         p0s[s] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         idx[s] = 0;
-        if (NPT > 0) srec[s] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); else thr_s[s] = 0.0f;
+        thr_s[s] = 0.0f;
     }
     __syncthreads();  // the block's own global stores are visible to it after the barrier
 
     // ---- group spheres (16 consecutive lanes = one group)
     for (int s = tid; s < ng * GRP; s += 1024) {
         const bool valid = s < n;
-        const float4 r4 = NPT > 0 ? srec[s] : p0s[s];
+        const float4 r4 = p0s[s];
         const float c[3] = {r4.x, r4.y, r4.z};
-        float lo[3], hi[3], tm = NPT > 0 ? thr_bound(r4.w) : thr_s[s];
+        float lo[3], hi[3], tm = thr_s[s];
 #pragma unroll
         for (int d = 0; d < 3; ++d) { lo[d] = valid ? c[d] : INFINITY; hi[d] = valid ? c[d] : -INFINITY; }
 #pragma unroll
@@ -565,7 +611,8 @@ __global__ __launch_bounds__(64 * WPB) void cull_scan_kernel(
 int rrl_launch_tri_build(const float *tri1, const float *tri2, void *ws, const WsLayout &w, int B,
                          int N, int M, int clouds, const RrlXform *xf, hipStream_t s) {
     const int nmax = clouds == 2 && M > N ? M : N;
-    const size_t lds = (nmax <= 4096 ? sizeof(float4) : sizeof(float)) * (size_t)((nmax + GRP - 1) / GRP * GRP);
+    const size_t ngmax = (size_t)(nmax + GRP - 1) / GRP;
+    const size_t lds = nmax <= 4096 ? ngmax * (17 * sizeof(float4) + GRP * sizeof(int)) : ngmax * GRP * sizeof(float);
     BuildArgs a;
     a.tri1 = xf ? xf->src : tri1;
     a.tri2 = tri2;
