@@ -310,48 +310,49 @@ __device__ __forceinline__ int load_prefix(const int32_t *__restrict__ cnt, int 
     return s_pref[nblk];
 }
 
-__global__ __launch_bounds__(1024) void loss_reduce_kernel(
-    const uint8_t *__restrict__ kjc, const float *__restrict__ dc, const int32_t *__restrict__ blkcnt,
-    float *__restrict__ med_out, int32_t *__restrict__ bcnt_out, int64_t *__restrict__ bsum_out,
-    int32_t *__restrict__ info, float *__restrict__ loss, int B, int nblk, int s_m, int s_n, int e_m,
-    int e_n, int pool) {
-    extern __shared__ int s_pref[];  // nblk + 1
-    __shared__ unsigned s_hist[2048];
-    __shared__ unsigned s_wtot[16];
-    __shared__ unsigned s_prefix[3], s_rank[4];  // one slot per pass: no barrier between read and rewrite
-    __shared__ unsigned s_nvals;
-    __shared__ unsigned long long s_sum[32];
-    __shared__ int s_cnt[16];
-    __shared__ float s_term[16];
-    const int g = blockIdx.x, tid = threadIdx.x;
-    const int bm = pool ? B - 1 : g;  // whose values define the median
-    const int b0 = pool ? 0 : g, b1 = pool ? B : g + 1;
-    const size_t Lp = (size_t)nblk * 1024;
-    if (tid < 32) s_sum[tid] = 0ull;
-    if (tid < 16) s_cnt[tid] = 0;
-    if (tid == 0) s_nvals = 0;
-    s_hist[tid] = 0;
-    s_hist[tid + 1024] = 0;
+struct ReduceLds {
+    int *s_pref;
+    unsigned *s_hist, *s_wtot, *s_prefix, *s_rank, *s_nvals;
+    unsigned long long *s_sum;
+    int *s_cnt;
+};
 
-    // ---- the median sample's lines: this lane's first one stays in registers (canonical tile)
-    const int ns_m = load_prefix(blkcnt + (size_t)bm * nblk, nblk, s_pref, tid);
-    float tile[16];
-    unsigned c0 = 0;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) tile[q] = INFINITY;
+// Median + Welsch sums of one reduce workgroup with the first RT selected lines of every lane kept
+// in registers (RT = 1 covers ns <= 1024, the usual case; RT = 3 up to 3072; beyond that the
+// tiles are re-read).  Returns the median and n (the number of D values) through refs.
+template <int RT>
+__device__ __forceinline__ void reduce_core(const uint8_t *__restrict__ kjc, const float *__restrict__ dc,
+                                            const int32_t *__restrict__ blkcnt, const ReduceLds &L_, int ns_m,
+                                            int B, int nblk, int bm, int b0, int b1, int tid, float &med_o,
+                                            unsigned &n_o) {
+    int *s_pref = L_.s_pref;
+    unsigned *s_hist = L_.s_hist, *s_wtot = L_.s_wtot, *s_prefix = L_.s_prefix, *s_rank = L_.s_rank;
+    unsigned long long *s_sum = L_.s_sum;
+    int *s_cnt = L_.s_cnt;
+    unsigned &s_nvals = *L_.s_nvals;
+    const size_t Lp = (size_t)nblk * 1024;
+    float tile[RT][16];
+    unsigned c0[RT];
     unsigned myvals = 0;
-    if (tid < ns_m) {
-        const size_t slot = (size_t)bm * Lp + slot_of(s_pref, nblk, tid);
-        c0 = kjc[slot];
-        const float4 *row = (const float4 *)(dc + slot * 16);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4 r = row[q];
-            tile[4 * q] = r.x; tile[4 * q + 1] = r.y; tile[4 * q + 2] = r.z; tile[4 * q + 3] = r.w;
+    for (int r = 0; r < RT; ++r) {
+        c0[r] = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) tile[r][q] = INFINITY;
+        const int i = tid + 1024 * r;
+        if (i < ns_m) {
+            const size_t slot = (size_t)bm * Lp + slot_of(s_pref, nblk, i);
+            c0[r] = kjc[slot];
+            const float4 *row = (const float4 *)(dc + slot * 16);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 v = row[q];
+                tile[r][4 * q] = v.x; tile[r][4 * q + 1] = v.y; tile[r][4 * q + 2] = v.z; tile[r][4 * q + 3] = v.w;
+            }
+            myvals += (c0[r] & 15u) * (c0[r] >> 4);
         }
-        myvals = (c0 & 15u) * (c0 >> 4);
     }
-    for (int i = tid + 1024; i < ns_m; i += 1024) {
+    for (int i = tid + 1024 * RT; i < ns_m; i += 1024) {
         const unsigned c = kjc[(size_t)bm * Lp + slot_of(s_pref, nblk, i)];
         myvals += (c & 15u) * (c >> 4);
     }
@@ -379,8 +380,10 @@ __global__ __launch_bounds__(1024) void loss_reduce_kernel(
             if (x != 0x7f800000u && ((x ^ prefix) >> hi) == 0u) atomicAdd(&s_hist[(x >> sh) & dmask], 1u);
         };
 #pragma unroll
-        for (int q = 0; q < 16; ++q) tally(__float_as_uint(tile[q]));
-        for (int i = tid + 1024; i < ns_m; i += 1024) {
+        for (int r = 0; r < RT; ++r)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) tally(__float_as_uint(tile[r][q]));
+        for (int i = tid + 1024 * RT; i < ns_m; i += 1024) {
             const float *row = dc + ((size_t)bm * Lp + slot_of(s_pref, nblk, i)) * 16;
             for (int q = 0; q < 16; ++q) tally(__float_as_uint(row[q]));
         }
@@ -425,10 +428,13 @@ __global__ __launch_bounds__(1024) void loss_reduce_kernel(
     for (int b = b0; b < b1; ++b) {
         int ns = ns_m;
         if (b != bm) ns = load_prefix(blkcnt + (size_t)b * nblk, nblk, s_pref, tid);  // pool mode only
-        for (int i = tid; i < ns; i += 1024) {
-            if (b == bm && i == tid) {
-                accumulate(tile, (int)(c0 & 15u), (int)(c0 >> 4));
-            } else {
+        if (b == bm) {
+#pragma unroll
+            for (int r = 0; r < RT; ++r)
+                if (tid + 1024 * r < ns) accumulate(tile[r], (int)(c0[r] & 15u), (int)(c0[r] >> 4));
+        }
+        for (int i = b == bm ? tid + 1024 * RT : tid; i < ns; i += 1024) {
+            {
                 const size_t slot = (size_t)b * Lp + slot_of(s_pref, nblk, i);
                 const unsigned c = kjc[slot];
                 float Dl[16];
@@ -442,6 +448,38 @@ __global__ __launch_bounds__(1024) void loss_reduce_kernel(
             }
         }
     }
+    med_o = med;
+    n_o = n;
+}
+
+__global__ __launch_bounds__(1024) void loss_reduce_kernel(
+    const uint8_t *__restrict__ kjc, const float *__restrict__ dc, const int32_t *__restrict__ blkcnt,
+    float *__restrict__ med_out, int32_t *__restrict__ bcnt_out, int64_t *__restrict__ bsum_out,
+    int32_t *__restrict__ info, float *__restrict__ loss, int B, int nblk, int s_m, int s_n, int e_m,
+    int e_n, int pool) {
+    extern __shared__ int s_pref[];  // nblk + 1
+    __shared__ unsigned s_hist[2048];
+    __shared__ unsigned s_wtot[16];
+    __shared__ unsigned s_prefix[3], s_rank[4];  // one slot per pass: no barrier between read and rewrite
+    __shared__ unsigned s_nvals;
+    __shared__ unsigned long long s_sum[32];
+    __shared__ int s_cnt[16];
+    __shared__ float s_term[16];
+    const int g = blockIdx.x, tid = threadIdx.x;
+    const int bm = pool ? B - 1 : g;  // whose values define the median
+    const int b0 = pool ? 0 : g, b1 = pool ? B : g + 1;
+    if (tid < 32) s_sum[tid] = 0ull;
+    if (tid < 16) s_cnt[tid] = 0;
+    if (tid == 0) s_nvals = 0;
+    s_hist[tid] = 0;
+    s_hist[tid + 1024] = 0;
+
+    const int ns_m = load_prefix(blkcnt + (size_t)bm * nblk, nblk, s_pref, tid);
+    const ReduceLds lds = {s_pref, s_hist, s_wtot, s_prefix, s_rank, &s_nvals, s_sum, s_cnt};
+    float med;
+    unsigned n;
+    if (ns_m <= 1024) reduce_core<1>(kjc, dc, blkcnt, lds, ns_m, B, nblk, bm, b0, b1, tid, med, n);
+    else reduce_core<3>(kjc, dc, blkcnt, lds, ns_m, B, nblk, bm, b0, b1, tid, med, n);
     __syncthreads();
 
     // ---- loss = ( sum_{non-empty (k,j), k-major} exp(-|k-j|/2) (mean_row + mean_col) ) / C
