@@ -43,7 +43,7 @@
 #include "rrl_ws.h"
 
 #define GRP 16           // triangles per group
-#define SORT_CAP 16384   // largest cloud the sort kernel handles (64 KiB of LDS for thr)
+#define SORT_CAP 65536   // largest cloud of the sorted / culled layout (16-bit sorted positions in the scan)
 
 __device__ __forceinline__ unsigned spread10(unsigned v) {
     v &= 0x3ffu;
@@ -167,9 +167,8 @@ __global__ __launch_bounds__(1024) void tri_sort_kernel(const BuildArgs a) {
     // NPT > 0: the sorted records and their triangle indices are assembled in LDS ([ng*17] float4,
     //          one float4 of padding per group: lanes on different groups hit different banks;
     //          then [ng*16] int) and leave with coalesced stores;
-    // NPT == 0: only the thr bound by sorted position ([ng*16] float), records re-read from P0S
+    // NPT == 0: no dynamic LDS, records re-read from P0S
     extern __shared__ __attribute__((aligned(16))) float dyn_s[];
-    float *thr_s = dyn_s;
     float4 *srec = (float4 *)dyn_s;
     __shared__ unsigned hist[SORT_CELLS];
     __shared__ float red[16][8];
@@ -322,42 +321,43 @@ __global__ __launch_bounds__(1024) void tri_sort_kernel(const BuildArgs a) {
         const int s = (int)atomicAdd(&hist[cell_of(r)], 1u);
         p0s[s] = r;
         idx[s] = f;
-        thr_s[s] = thr_bound(r.w);
     }
     for (int s = n + tid; s < ng * GRP; s += 1024) {  // pad: thr2 = 0 never passes
         p0s[s] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         idx[s] = 0;
-        thr_s[s] = 0.0f;
     }
     __syncthreads();  // the block's own global stores are visible to it after the barrier
 
-    // ---- group spheres (16 consecutive lanes = one group)
-    for (int s = tid; s < ng * GRP; s += 1024) {
-        const bool valid = s < n;
-        const float4 r4 = p0s[s];
-        const float c[3] = {r4.x, r4.y, r4.z};
-        float lo[3], hi[3], tm = thr_s[s];
+    // ---- group spheres: one lane per group, records re-read from P0S (256 contiguous bytes each)
+    for (int g = tid; g < ng; g += 1024) {
+        const float4 *r = p0s + (size_t)g * GRP;
+        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY}, tm = 0.0f;
+        float px[GRP], py[GRP], pz[GRP];
 #pragma unroll
-        for (int d = 0; d < 3; ++d) { lo[d] = valid ? c[d] : INFINITY; hi[d] = valid ? c[d] : -INFINITY; }
-#pragma unroll
-        for (int d = 0; d < 3; ++d) { lo[d] = row16_min(lo[d]); hi[d] = row16_max(hi[d]); }
-        tm = row16_max(tm);
-        float ctr[3], d2 = 0.0f;
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            ctr[d] = 0.5f * lo[d] + 0.5f * hi[d];
-            float e = c[d] - ctr[d];
-            d2 += e * e;
+        for (int t = 0; t < GRP; ++t) {
+            const float4 v = r[t];
+            px[t] = v.x; py[t] = v.y; pz[t] = v.z;
+            if (g * GRP + t < n) {
+                lo[0] = fminf(lo[0], v.x); hi[0] = fmaxf(hi[0], v.x);
+                lo[1] = fminf(lo[1], v.y); hi[1] = fmaxf(hi[1], v.y);
+                lo[2] = fminf(lo[2], v.z); hi[2] = fmaxf(hi[2], v.z);
+                tm = fmaxf(tm, thr_bound(v.w));
+            }
         }
-        if (!valid) d2 = 0.0f;
-        d2 = row16_max(d2);
-        if ((s & 15) == 0) {
-            float rho = sqrtf(d2) * 1.00001f + 1e-7f;
-            float R = rho + tm;
-            float R2 = R * R * 1.0001f + 1e-7f;
-            if (!(R2 < 3.0e38f)) R2 = INFINITY;  // non-finite data: keep the group
-            grp[s >> 4] = make_float4(ctr[0], ctr[1], ctr[2], R2);
+        const float cx = 0.5f * lo[0] + 0.5f * hi[0], cy = 0.5f * lo[1] + 0.5f * hi[1],
+                    cz = 0.5f * lo[2] + 0.5f * hi[2];
+        float d2 = 0.0f;
+#pragma unroll
+        for (int t = 0; t < GRP; ++t) {
+            const float ex = px[t] - cx, ey = py[t] - cy, ez = pz[t] - cz;
+            const float e2 = ex * ex + ey * ey + ez * ez;
+            if (g * GRP + t < n) d2 = fmaxf(d2, e2);
         }
+        const float rho = sqrtf(d2) * 1.00001f + 1e-7f;
+        const float R = rho + tm;
+        float R2 = R * R * 1.0001f + 1e-7f;
+        if (!(R2 < 3.0e38f)) R2 = INFINITY;  // non-finite data: keep the group
+        grp[g] = make_float4(cx, cy, cz, R2);
     }
 }
 
@@ -612,7 +612,7 @@ int rrl_launch_tri_build(const float *tri1, const float *tri2, void *ws, const W
                          int N, int M, int clouds, const RrlXform *xf, hipStream_t s) {
     const int nmax = clouds == 2 && M > N ? M : N;
     const size_t ngmax = (size_t)(nmax + GRP - 1) / GRP;
-    const size_t lds = nmax <= 4096 ? ngmax * (17 * sizeof(float4) + GRP * sizeof(int)) : ngmax * GRP * sizeof(float);
+    const size_t lds = nmax <= 4096 ? ngmax * (17 * sizeof(float4) + GRP * sizeof(int)) : 16;
     BuildArgs a;
     a.tri1 = xf ? xf->src : tri1;
     a.tri2 = tri2;

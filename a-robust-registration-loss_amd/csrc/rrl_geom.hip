@@ -297,7 +297,8 @@ __global__ __launch_bounds__(256) void reg_bwd_kernel(const float *__restrict__ 
 
 // the fused tail applies when the clouds take the sorted prepare path (whose build kernel clears
 // G1 in the forward)
-int rrl_fused_backward(int B, int N, int M) { return B > 0 && N > 0 && (N > M ? N : M) <= 16384; }
+int rrl_sort_capacity(void);
+int rrl_fused_backward(int B, int N, int M) { return B > 0 && N > 0 && (N > M ? N : M) <= rrl_sort_capacity(); }
 
 int rrl_launch_reg_bwd(const float *src, const float *R, float *g1, float *grad_src, float *partial,
                        float *gR, float *gt, float *payload, const float *loss, const int32_t *info,

@@ -106,7 +106,7 @@ int rrl_sort_capacity(void);
 // sorted/legacy decision always looks at both sizes so that a cached call takes the same path.
 // xf != NULL: the source is xf->src moved by (xf->R, xf->t); the moved triangles land in TRI1
 // (`tri1` is ignored).  Sorted path: ONE launch (tri_build_kernel) does transform + records +
-// state clearing + sort + spheres.  Legacy path (a cloud > 16384 triangles): rigid apply,
+// state clearing + sort + spheres.  Legacy path (a cloud > 65536 triangles): rigid apply,
 // memset, tri_prepare_kernel<LEGACY>.
 int rrl_tri_prepare_clouds(const float *tri1, const float *tri2, void *ws, size_t ws_bytes, int B,
                            int N, int M, int L, int clouds, const RrlXform *xf, void *stream) {

@@ -52,7 +52,7 @@ extern "C" {
                              sphere it can reach, found by a conservative test (DESIGN.md
                              "culling bound").  128-line workgroups with a line that fails the NaN
                              bound run the strict loop instead, so results and NaN detection equal
-                             strict's.  Needs N, M <= 16384, else behaves like AUTO. */
+                             strict's.  Needs N, M <= 65536, else behaves like AUTO. */
 
 /* workspace fields (indices into rrl_workspace_layout's offset array) */
 enum {
