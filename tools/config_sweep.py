@@ -1,6 +1,7 @@
 """Step time (fused forward + backward, hipGraph replay) at the BASELINE.json configs that are not
 the bench line: C1 demo (B=1, N=M=1024, L=20000), C4 (N=2048, M=1024 cropped), C5 (N=M=16384,
-L=512), plus L=4096 / L=20000 at the C2 shape."""
+L=512), plus L=4096 / L=20000 at the C2 shape.  With arguments "B,N,M,L" ...
+it times those shapes instead."""
 import json, os, sys, time
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -45,12 +46,18 @@ def run(name, B, N, M, L, crop=False, noise=0.01):
                       "pairs_per_s": pairs / dt, "selected_lines": int(g.out[1][:, 1].sum()),
                       "loss0": float(g.out[0][0])}))
 
-run("C1 demo", 1, 1024, 1024, 20000)
-run("C2 bench", 8, 4096, 4096, 10000)
-run("C2 L=4096", 8, 4096, 4096, 4096)
-run("C2 L=20000", 8, 4096, 4096, 20000)
-run("C4 partial overlap", 8, 2048, 1024, 10000, crop=True, noise=0.02)
-run("C5 fragments", 1, 16384, 16384, 512)
-run("C5 fragments B=8", 8, 16384, 16384, 512)
-run("C3 whole batch on one GPU (B=64)", 64, 4096, 4096, 10000)
-run("B=32", 32, 4096, 4096, 10000)
+if __name__ == "__main__":
+    if len(sys.argv) > 1:  # e.g. tools/config_sweep.py 1,32768,32768,10000 1,65536,65536,10000
+        for spec in sys.argv[1:]:
+            B, N, M, L = (int(x) for x in spec.split(","))
+            run(f"B={B} N={N} M={M} L={L}", B, N, M, L)
+        sys.exit(0)
+    run("C1 demo", 1, 1024, 1024, 20000)
+    run("C2 bench", 8, 4096, 4096, 10000)
+    run("C2 L=4096", 8, 4096, 4096, 4096)
+    run("C2 L=20000", 8, 4096, 4096, 20000)
+    run("C4 partial overlap", 8, 2048, 1024, 10000, crop=True, noise=0.02)
+    run("C5 fragments", 1, 16384, 16384, 512)
+    run("C5 fragments B=8", 8, 16384, 16384, 512)
+    run("C3 whole batch on one GPU (B=64)", 64, 4096, 4096, 10000)
+    run("B=32", 32, 4096, 4096, 10000)
