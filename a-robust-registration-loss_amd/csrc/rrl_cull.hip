@@ -633,8 +633,8 @@ int rrl_launch_tri_build(const float *tri1, const float *tri2, void *ws, const W
     a.pmax = (uint32_t *)w.i32(ws, RRL_WS_PMAX);
     a.zero_base = (uint4 *)((char *)ws + w.off[RRL_WS_STATUS]);
     a.zero_vec4 = w.zero_bytes / 16;
-    a.g1 = xf && xf->zero_g1 ? (uint4 *)((char *)ws + w.off[RRL_WS_G1]) : nullptr;
-    a.g1_vec4 = a.g1 ? (w.off[RRL_WS_RPART] - w.off[RRL_WS_G1]) / 16 : 0;
+    a.g1 = xf && xf->zero_g1 ? (uint4 *)((char *)ws + w.off[RRL_WS_GACC]) : nullptr;  // small: 12 B + 16 floats
+    a.g1_vec4 = a.g1 ? (w.off[RRL_WS_KJC] - w.off[RRL_WS_GACC]) / 16 : 0;
     a.B = B; a.N = N; a.M = M;
     a.transpose_r = xf ? xf->transpose_r : 0;
     const int nall = N > M ? N : M;  // APART is laid out for the larger cloud

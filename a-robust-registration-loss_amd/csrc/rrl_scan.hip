@@ -125,6 +125,10 @@ int rrl_tri_prepare_clouds(const float *tri1, const float *tri2, void *ws, size_
     if (B == 0 || nmax == 0) return 0;
     if (sorted) return rrl_launch_tri_build(tri1, tri2, ws, w, B, N, M, clouds, xf, s);
     if (xf) {
+        if (xf->zero_g1) {
+            int rc = rrl_fill(w.f32(ws, RRL_WS_GACC), 0u, w.off[RRL_WS_KJC] - w.off[RRL_WS_GACC], s);
+            if (rc) return rc;
+        }
         tri1 = w.f32(ws, RRL_WS_TRI1);
         int rc = rrl_rigid_apply_fwd(xf->src, xf->R, xf->t, w.f32(ws, RRL_WS_TRI1), B, 3 * N,
                                      xf->transpose_r, 0, stream);

@@ -609,10 +609,14 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(
 // K5' backward of the fused training op when only dL/dR and dL/dt are wanted (the usual case:
 // the source cloud is data).  The gradient of a moved point y = x m + t contributes x (x) g to
 // dL/dm and g to dL/dt, so every (selected line, hit) lane adds its three points' terms straight
-// into 12 per-lane sums: no scatter into a per-triangle gradient, no float atomics, no pass over
-// the N points afterwards.  Workgroup sums go out as write-through partials; the last live
-// workgroup of the launch (ticket counter) reduces them per sample in index order and builds
-// the 14-float shard payload.  ONE launch for the whole backward, bit-deterministic.
+// into 12 per-lane sums: no scatter into a per-triangle gradient, no pass over the N points
+// afterwards.  Every live workgroup adds its 12 sums to dL/dR, dL/dt of its sample and to the
+// 14-float shard payload with float atomics (26 fire-and-forget adds per workgroup); the outputs
+// must be ZERO on entry (the forward clears the workspace field GACC for this).  ONE launch.
+// Handing the partials to a "last workgroup" for a fixed-order sum (write-through stores, ticket,
+// agent-scope loads: four dependent cross-XCD round trips) cost 5 us more, a second tiny launch
+// for it 2 us more (measured); the price of the atomics is run-to-run rounding noise in the
+// gradient (the loss itself stays bit-deterministic).
 // ---------------------------------------------------------------------------------------
 #define BWD_LINES 64  // selected lines per 256-lane workgroup (4 hit slots each)
 
@@ -623,22 +627,14 @@ __global__ __launch_bounds__(256) void loss_bwd_rt_kernel(
     const int32_t *__restrict__ hs1, const float *__restrict__ w1, const float4 *__restrict__ Q1,
     const float4 *__restrict__ Q2, const float *__restrict__ D, const float *__restrict__ med,
     const int32_t *__restrict__ bcnt, const int32_t *__restrict__ info,
-    const float *__restrict__ grad_loss, const float *__restrict__ src, float *__restrict__ bpart,
-    float *__restrict__ gR, float *__restrict__ gt, float *__restrict__ payload,
-    const float *__restrict__ loss, int32_t *__restrict__ done, int B, int N, int L, int transpose_r) {
+    const float *__restrict__ grad_loss, const float *__restrict__ src, float *__restrict__ gR,
+    float *__restrict__ gt, float *__restrict__ payload, const float *__restrict__ loss, int B, int N,
+    int L, int transpose_r) {
     __shared__ float red[4][12];
-    __shared__ int s_ticket, s_live;
-    __shared__ double psum[14];
-    __shared__ float stage[16][12];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.y, nblk = gridDim.x;
+    const int b = blockIdx.y;
     const int ns = nsel[b];
     if ((int)blockIdx.x >= bwd_live_blocks(ns)) return;  // uniform: nothing selected in this slice
-    if (tid == 0) {  // live workgroups of the whole launch = tickets to wait for
-        int tot = 0;
-        for (int k = 0; k < B; ++k) tot += bwd_live_blocks(nsel[k]);
-        s_live = tot;
-    }
     const int i = blockIdx.x * BWD_LINES + (tid >> 2), h = tid & 3;
     float acc[12];
 #pragma unroll
@@ -702,62 +698,17 @@ __global__ __launch_bounds__(256) void loss_bwd_rt_kernel(
 #pragma unroll
         for (int q = 0; q < 12; ++q) red[wave][q] = acc[q];
     __syncthreads();
-    // hand-over without __threadfence() (see reg_bwd_kernel): write-through stores, wave 0 waits
-    // for them, then its lane 0 takes the ticket
-    if (tid < 12)
-        __hip_atomic_store(&bpart[((size_t)b * nblk + blockIdx.x) * 12 + tid],
-                           (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-    if (tid < 64) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (tid == 0) s_ticket = __hip_atomic_fetch_add(done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid < 12) {
+        const float v = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+        int o = tid;  // m-index (i, j) -> memory order of R
+        if (tid < 9 && transpose_r) o = (tid % 3) * 3 + tid / 3;
+        if (tid < 9) atomicAdd(&gR[b * 9 + o], v); else atomicAdd(&gt[b * 3 + (tid - 9)], v);
+        if (payload) atomicAdd(&payload[2 + o], v);
     }
-    if (tid < 14) psum[tid] = 0.0;
-    __syncthreads();
-    if (s_ticket != s_live - 1) return;
-    if (tid == 0) __hip_atomic_store(done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // the last workgroup: per-sample sums over the live workgroups in index order, then the
-    // payload over the samples in index order
-    for (int k0 = 0; k0 < B; k0 += 16) {
-        const int k = k0 + tid / 12, q = tid % 12;
-        const bool on = tid < 192 && k < B;
-        float r = 0.0f;
-        if (on) {
-            const int nl = bwd_live_blocks(nsel[k]);
-            double sacc = 0.0;
-            for (int jb = 0; jb < nl; ++jb)
-                sacc += (double)__hip_atomic_load(&bpart[((size_t)k * nblk + jb) * 12 + q], __ATOMIC_RELAXED,
-                                                  __HIP_MEMORY_SCOPE_AGENT);
-            r = (float)sacc;
-            if (q < 9) {
-                const int ii = q / 3, jj = q % 3;
-                gR[k * 9 + (transpose_r ? jj * 3 + ii : ii * 3 + jj)] = r;
-            } else {
-                gt[k * 3 + (q - 9)] = r;
-            }
-            stage[tid / 12][q] = r;
-        }
-        __syncthreads();
-        if (payload && tid < 12) {
-            double sp = psum[2 + tid];
-            for (int kk = 0; kk < min(16, B - k0); ++kk) sp += (double)stage[kk][tid];
-            psum[2 + tid] = sp;
-        }
-        __syncthreads();
-    }
-    if (!payload) return;
-    if (tid < 2) {
+    if (payload && blockIdx.x == 0 && b == 0 && tid >= 64 && tid < 66) {  // [sum of valid losses, #valid]
         double sp = 0.0;
-        for (int k = 0; k < B; ++k) sp += info[k * 4] > 0 ? (tid == 0 ? (double)loss[k] : 1.0) : 0.0;
-        payload[tid] = (float)sp;
-    } else if (tid < 14) {
-        const int q = tid - 2;
-        if (q < 9) {
-            const int ii = q / 3, jj = q % 3;
-            payload[2 + (transpose_r ? jj * 3 + ii : ii * 3 + jj)] = (float)psum[2 + q];
-        } else {
-            payload[2 + q] = (float)psum[2 + q];
-        }
+        for (int k = 0; k < B; ++k) sp += info[k * 4] > 0 ? (tid == 64 ? (double)loss[k] : 1.0) : 0.0;
+        payload[tid - 64] = (float)sp;
     }
 }
 
@@ -878,7 +829,7 @@ extern "C" int rrl_registration_forward_cached(const float *src, const float *R,
     WsLayout w(B, N, M, L);
     if (ws_bytes < w.total) return RRL_E_WS;
     // the transform runs inside the prepare step
-    const RrlXform xf = {src, R, t, transpose_r, 0};
+    const RrlXform xf = {src, R, t, transpose_r, 1};  // 1: clear GACC for the backward's atomics
     return loss_forward_impl(w.f32(ws, RRL_WS_TRI1), tri2, line, ws, ws_bytes, loss, B, N, M, L, s_m,
                              s_n, e_m, e_n, 0, mode, chunk, target_ws, &xf, stream);
 }
@@ -905,14 +856,22 @@ extern "C" int rrl_registration_backward(const float *src, const float *R, const
     float *g1 = w.f32(ws, RRL_WS_G1);
     hipStream_t s = (hipStream_t)stream;
     if (!grad_src && B > 0 && L > 0) {
-        // only dL/dR, dL/dt (+ payload): ONE launch, straight from the selected lines
+        // only dL/dR, dL/dt (+ payload): ONE launch, straight from the selected lines; the outputs
+        // are accumulated with atomics -- clear them unless they are the workspace's GACC field,
+        // which the forward left zeroed
+        float *gacc = w.f32(ws, RRL_WS_GACC);
+        if (gR != gacc || gt != gacc + 9 * (size_t)B || (payload && payload != gacc + 12 * (size_t)B)) {
+            int rc;
+            if ((rc = rrl_fill(gR, 0u, sizeof(float) * 9 * (size_t)B, s))) return rc;
+            if ((rc = rrl_fill(gt, 0u, sizeof(float) * 3 * (size_t)B, s))) return rc;
+            if (payload && (rc = rrl_fill(payload, 0u, sizeof(float) * 14, s))) return rc;
+        }
         hipLaunchKernelGGL(loss_bwd_rt_kernel, dim3((unsigned)((L + BWD_LINES - 1) / BWD_LINES), (unsigned)B),
                            dim3(256), 0, s, w.u8(ws, RRL_WS_KJ), w.i32(ws, RRL_WS_SEL), w.i32(ws, RRL_WS_NSEL),
                            w.i32(ws, RRL_WS_HS1), w.f32(ws, RRL_WS_W1), (const float4 *)w.f32(ws, RRL_WS_Q1),
                            (const float4 *)w.f32(ws, RRL_WS_Q2), w.f32(ws, RRL_WS_D), w.f32(ws, RRL_WS_MED),
-                           w.i32(ws, RRL_WS_BCNT), w.i32(ws, RRL_WS_INFO), grad_loss, src,
-                           w.f32(ws, RRL_WS_BPART), gR, gt, payload, loss, w.i32(ws, RRL_WS_STATUS) + 3, B, N,
-                           L, transpose_r);
+                           w.i32(ws, RRL_WS_BCNT), w.i32(ws, RRL_WS_INFO), grad_loss, src, gR, gt, payload, loss,
+                           B, N, L, transpose_r);
         RRL_LAUNCH_CHECK();
         return 0;
     }

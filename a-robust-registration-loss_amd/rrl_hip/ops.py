@@ -51,6 +51,7 @@ _WS_FIELDS = [
     ("g1", torch.float32, lambda B, N, M, L, G: (B, N, 9)),
     ("rpart", torch.float32, lambda B, N, M, L, G: (B, (3 * N + 1023) // 1024 + 1, 12)),
     ("bpart", torch.float32, lambda B, N, M, L, G: (B, (L + 63) // 64 + 1, 12)),
+    ("gacc", torch.float32, lambda B, N, M, L, G: (12 * B + 16,)),
     ("kjc", torch.uint8, lambda B, N, M, L, G: (B, (L + 1023) // 1024 * 1024)),
     ("blkcnt", torch.int32, lambda B, N, M, L, G: (B * ((L + 1023) // 1024 + 1),)),
 ]
@@ -291,8 +292,12 @@ class _RegistrationLoss(torch.autograd.Function):
         B, N, M, L, _ = st.dims
         g = g_loss if (g_loss.is_cuda and g_loss.is_contiguous()) else \
             g_loss.to(device=src.device, dtype=torch.float32).contiguous()
-        out = torch.empty(B * 12 + 14, dtype=torch.float32, device=src.device)
-        gR, gt, payload = out[:B * 9], out[B * 9:B * 12], out[B * 12:]
+        if not ctx.needs_input_grad[0] and not getattr(st, "gacc_used", False):
+            out = st.gacc  # zeroed by the forward; the direct backward accumulates into it
+            st.gacc_used = True
+        else:  # a second backward over the same forward, or the d/dsrc route (which overwrites)
+            out = torch.empty(B * 12 + 14, dtype=torch.float32, device=src.device)
+        gR, gt, payload = out[:B * 9], out[B * 9:B * 12], out[B * 12:B * 12 + 14]
         gsrc = torch.empty_like(src) if ctx.needs_input_grad[0] else None
         check(_lib.load().rrl_registration_backward(
             _p(src), _p(Rm), _p(tri2), _p(st.ws), st.nbytes, _p(st.loss), _p(g), _p(gsrc), _p(gR),

@@ -96,6 +96,8 @@ enum {
     RRL_WS_RPART,      /* float[B][nblk][12] rigid-apply backward partial sums              */
     RRL_WS_BPART,      /* float[B][ceil(L/64)+1][12] per-workgroup (dR, dt) partials of the
                           direct backward (rrl_registration_backward without grad_src)       */
+    RRL_WS_GACC,       /* float[12 B + 16]  dL/dR [B][9], dL/dt [B][3], shard payload [14]: zeroed by
+                          rrl_registration_forward, accumulated by rrl_registration_backward     */
     RRL_WS_KJC,        /* uint8[B][Lp]  k | j<<4 at the compact slots                            */
     RRL_WS_BLKCNT,     /* int32[B][ceil(L/1024)] selected lines per 1024-line tile               */
     RRL_WS_FIELDS
@@ -133,7 +135,10 @@ int rrl_loss_backward(const float *tri1, const float *tri2, const void *ws, size
  * x R^T + t when transpose_r -- into the workspace (TRI1) and the loss is evaluated against
  * tri2, all in one call.  The backward returns dL/dR, dL/dt (deterministic reduction), optionally
  * dL/dsrc (may be NULL), and, when payload != NULL, the 14-float batch-shard payload
- * { sum of valid losses, #valid, sum_b dR, sum_b dt } for the all-reduce.  pool must be 0. */
+ * { sum of valid losses, #valid, sum_b dR, sum_b dt } for the all-reduce.  pool must be 0.
+ * With grad_src == NULL the gradients are accumulated with float atomics in one launch: pass
+ * gR = GACC, gt = GACC + 9 B, payload = GACC + 12 B (the workspace field the forward zeroed) to
+ * avoid three extra clearing launches; any other buffers are cleared by the call first. */
 int rrl_registration_forward(const float *src, const float *R, const float *t, const float *tri2,
                              const float *line, void *ws, size_t ws_bytes, float *loss, int B,
                              int N, int M, int L, int transpose_r, int s_m, int s_n, int e_m,
