@@ -48,7 +48,6 @@ struct WsLayout {
             4 * b * n * 9,       // TRI1
             4 * b * n * 9,       // G1
             4 * b * 12 * ((3 * n + 1023) / 1024 + 1),    // RPART
-            4 * b * 12 * ((l + 63) / 64 + 1),            // BPART
             4 * (b * 12 + 16),                           // GACC (followed by KJC: see rrl_launch_tri_build)
             b * ((l + 1023) / 1024) * 1024,              // KJC
             4 * b * ((l + 1023) / 1024 + 1),             // BLKCNT

@@ -50,7 +50,6 @@ _WS_FIELDS = [
     ("tri1t", torch.float32, lambda B, N, M, L, G: (B, N, 9)),
     ("g1", torch.float32, lambda B, N, M, L, G: (B, N, 9)),
     ("rpart", torch.float32, lambda B, N, M, L, G: (B, (3 * N + 1023) // 1024 + 1, 12)),
-    ("bpart", torch.float32, lambda B, N, M, L, G: (B, (L + 63) // 64 + 1, 12)),
     ("gacc", torch.float32, lambda B, N, M, L, G: (12 * B + 16,)),
     ("kjc", torch.uint8, lambda B, N, M, L, G: (B, (L + 1023) // 1024 * 1024)),
     ("blkcnt", torch.int32, lambda B, N, M, L, G: (B * ((L + 1023) // 1024 + 1),)),

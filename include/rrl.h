@@ -94,8 +94,6 @@ enum {
     RRL_WS_TRI1,       /* float[B][N][9] transformed source triangles (rrl_registration_*)   */
     RRL_WS_G1,         /* float[B][N][9] gradient w.r.t. TRI1 (rrl_registration_backward)    */
     RRL_WS_RPART,      /* float[B][nblk][12] rigid-apply backward partial sums              */
-    RRL_WS_BPART,      /* float[B][ceil(L/64)+1][12] per-workgroup (dR, dt) partials of the
-                          direct backward (rrl_registration_backward without grad_src)       */
     RRL_WS_GACC,       /* float[12 B + 16]  dL/dR [B][9], dL/dt [B][3], shard payload [14]: zeroed by
                           rrl_registration_forward, accumulated by rrl_registration_backward     */
     RRL_WS_KJC,        /* uint8[B][Lp]  k | j<<4 at the compact slots                            */
