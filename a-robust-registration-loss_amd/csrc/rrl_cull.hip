@@ -522,10 +522,12 @@ __global__ __launch_bounds__(64 * WPB) void cull_scan_kernel(
         kptr tp = (kptr)(uintptr_t)((cloud ? ptri2 : ptri1) + (size_t)b * n * PTRI_STRIDE);
         int32_t *cnt = (cloud ? count2 : count1) + (size_t)b * L;
         int32_t *hit = (cloud ? hit2 : hit1) + (size_t)b * L * RRL_MAX_HITS;
-        const int tq = (n + WPB - 1) / WPB, t1 = min(n, (wave + 1) * tq);
+        // this workgroup's slice of the triangles (gridDim.z slices), split over its wavefronts
+        const int nsl = WPB * (int)gridDim.z, sl = (int)blockIdx.z * WPB + wave;
+        const int tq = (n + nsl - 1) / nsl, t0 = min(n, sl * tq), t1 = min(n, t0 + tq);
         uint32_t nanacc = 0;
-        tp += (size_t)wave * tq * PTRI_STRIDE;
-        for (int t = wave * tq; t < t1; ++t, tp += PTRI_STRIDE) {
+        tp += (size_t)t0 * PTRI_STRIDE;
+        for (int t = t0; t < t1; ++t, tp += PTRI_STRIDE) {
             const uint32_t thr2 = __float_as_uint(tp[9]);
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -568,9 +570,12 @@ __global__ __launch_bounds__(64 * WPB) void cull_scan_kernel(
     const v2f ox = {v0[3], v1[3]}, oy = {v0[4], v1[4]}, oz = {v0[5], v1[5]};
     int nent = 0, ngrp = 0, ncand = 0;  // wave-uniform
     kptr gp = (kptr)(uintptr_t)grp;
-    const int gq = (ng + WPB - 1) / WPB;
-    const int gend = min(ng, (wave + 1) * gq);
-    for (int g = wave * gq; g < gend; ++g) {
+    // this workgroup's slice of the groups (gridDim.z slices: few lines against a big cloud would
+    // otherwise leave most CUs idle), split over its wavefronts
+    const int nsl = WPB * (int)gridDim.z, sl = (int)blockIdx.z * WPB + wave;
+    const int gq = (ng + nsl - 1) / nsl;
+    const int gbeg = min(ng, sl * gq), gend = min(ng, gbeg + gq);
+    for (int g = gbeg; g < gend; ++g) {
         const float cx = gp[4 * g], cy = gp[4 * g + 1], cz = gp[4 * g + 2], R2 = gp[4 * g + 3];
         const v2f ax = cx - ox, ay = cy - oy, az = cz - oz;
         const v2f dot = __builtin_elementwise_fma(az, uz, __builtin_elementwise_fma(ay, uy, ax * ux));
@@ -651,7 +656,14 @@ int rrl_launch_tri_build(const float *tri1, const float *tri2, void *ws, const W
 
 int rrl_launch_cull_scan(const float *line, void *ws, const WsLayout &w, int B, int N, int M, int L,
                          int clouds, hipStream_t s) {
-    hipLaunchKernelGGL(cull_scan_kernel, dim3((unsigned)(clouds * B), (unsigned)((L + LPB - 1) / LPB)), dim3(64 * WPB), 0,
+    // group slices: enough workgroups for ~4 per CU, at least 4 groups per wavefront
+    const int tiles = (L + LPB - 1) / LPB, nmax = clouds == 2 && M > N ? M : N;
+    const int ngmax = (nmax + GRP - 1) / GRP;
+    int gsplit = (1024 + tiles * clouds * B - 1) / (tiles * clouds * B);
+    const int cap = ngmax / (4 * WPB);
+    if (gsplit > cap) gsplit = cap;
+    if (gsplit < 1) gsplit = 1;
+    hipLaunchKernelGGL(cull_scan_kernel, dim3((unsigned)(clouds * B), (unsigned)tiles, (unsigned)gsplit), dim3(64 * WPB), 0,
                        s, w.f32(ws, RRL_WS_PTRI1), w.f32(ws, RRL_WS_PTRI2),
                        (const float4 *)w.f32(ws, RRL_WS_P0S1), (const float4 *)w.f32(ws, RRL_WS_P0S2),
                        w.i32(ws, RRL_WS_IDX1), w.i32(ws, RRL_WS_IDX2), (const float4 *)w.f32(ws, RRL_WS_GRP1),
