@@ -85,6 +85,8 @@ struct BuildArgs {
     size_t zero_vec4;
     uint4 *g1;                     // gradient accumulator to clear (may be NULL)
     size_t g1_vec4;
+    uint4 *z2;                     // global cell histogram / cursors of the wide sort (may be NULL)
+    size_t z2_vec4;
     int B, N, M, transpose_r, nblk;
 };
 
@@ -100,6 +102,7 @@ __global__ __launch_bounds__(REC_BLK) void tri_records_kernel(const BuildArgs a)
         const uint4 z = make_uint4(0, 0, 0, 0);
         for (size_t i = me; i < a.zero_vec4; i += nthr) a.zero_base[i] = z;
         for (size_t i = me; i < a.g1_vec4; i += nthr) a.g1[i] = z;
+        for (size_t i = me; i < a.z2_vec4; i += nthr) a.z2[i] = z;
     }
     const int n = cloud ? a.M : a.N;
     const int f = blockIdx.x * REC_BLK + tid;
@@ -359,6 +362,145 @@ __global__ __launch_bounds__(1024) void tri_sort_kernel(const BuildArgs a) {
         if (!(R2 < 3.0e38f)) R2 = INFINITY;  // non-finite data: keep the group
         grp[g] = make_float4(cx, cy, cz, R2);
     }
+}
+
+// ---------------------------------------------------------------------------------------
+// Large clouds (n > 4096): the same sort in three WIDE launches -- one workgroup per cloud is
+// bound by a single CU (48 us for 16384 triangles), and a launch boundary costs ~3 us:
+//   big_hist_kernel     cell of every triangle -> global histogram (atomics), max |P|^2
+//   big_scatter_kernel  every workgroup scans the 4096 bins itself (16 KiB), then places its
+//                       triangles at cell base + a global per-cell cursor (atomic)
+//   big_sphere_kernel   one lane per group of 16 sorted records
+// HISTG = [2B][2][4096] ints (counts, cursors), cleared by tri_records_kernel.
+// ---------------------------------------------------------------------------------------
+struct CellGrid {
+    float mn[3], scale[3], p2;
+};
+
+// AABB / max |P|^2 of one cloud from the per-workgroup partials; every lane gets the result.
+// red: LDS [4][8]; blockDim = 256.
+__device__ __forceinline__ CellGrid load_grid(const BuildArgs &a, int cloud, int b, int n, float (*red)[8]) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nb = (n + REC_BLK - 1) / REC_BLK;
+    const float *ap = a.apart + ((size_t)cloud * a.B + b) * a.nblk * 8;
+    float v[7];
+#pragma unroll
+    for (int c = 0; c < 7; ++c) v[c] = c < 3 ? INFINITY : (c < 6 ? -INFINITY : 0.0f);
+    for (int j = tid; j < nb; j += 256)
+#pragma unroll
+        for (int c = 0; c < 7; ++c) v[c] = c < 3 ? fminf(v[c], ap[j * 8 + c]) : fmaxf(v[c], ap[j * 8 + c]);
+#pragma unroll
+    for (int c = 0; c < 7; ++c) v[c] = c < 3 ? wave_min(v[c]) : wave_max(v[c]);
+    if (lane == 0)
+#pragma unroll
+        for (int c = 0; c < 7; ++c) red[wave][c] = v[c];
+    __syncthreads();
+    CellGrid g;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        g.mn[c] = fminf(fminf(red[0][c], red[1][c]), fminf(red[2][c], red[3][c]));
+        const float hi = fmaxf(fmaxf(red[0][3 + c], red[1][3 + c]), fmaxf(red[2][3 + c], red[3][3 + c]));
+        const float ext = hi - g.mn[c];
+        g.scale[c] = ext > 0.0f && ext < 3.0e38f ? 15.999f / ext : 0.0f;
+    }
+    g.p2 = fmaxf(fmaxf(red[0][6], red[1][6]), fmaxf(red[2][6], red[3][6]));
+    return g;
+}
+
+__device__ __forceinline__ unsigned grid_cell(const CellGrid &g, const float4 r) {
+    const float p[3] = {r.x, r.y, r.z};
+    unsigned q[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float v = (p[c] - g.mn[c]) * g.scale[c];
+        q[c] = v >= 15.0f ? 15u : (v > 0.0f ? (unsigned)v : 0u);
+    }
+    return spread10(q[0]) | (spread10(q[1]) << 1) | (spread10(q[2]) << 2);  // 12 bits
+}
+
+__global__ __launch_bounds__(256) void big_hist_kernel(const BuildArgs a, unsigned *__restrict__ histg) {
+    __shared__ float red[4][8];
+    const int cloud = blockIdx.z, b = blockIdx.y;
+    const int n = cloud ? a.M : a.N;
+    if ((int)blockIdx.x * 256 >= n) return;
+    const int ng = (n + GRP - 1) / GRP;
+    const float4 *crec = (cloud ? a.crec2 : a.crec1) + (size_t)b * ng * GRP;
+    const CellGrid g = load_grid(a, cloud, b, n, red);
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.pmax[cloud * a.B + b] = __float_as_uint(g.p2);
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    if (f < n) atomicAdd(&histg[((size_t)(cloud * a.B + b) * 2) * SORT_CELLS + grid_cell(g, crec[f])], 1u);
+}
+
+__global__ __launch_bounds__(256) void big_scatter_kernel(const BuildArgs a, unsigned *__restrict__ histg) {
+    __shared__ float red[4][8];
+    __shared__ unsigned base[SORT_CELLS];
+    __shared__ unsigned wsum[4];
+    const int cloud = blockIdx.z, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = cloud ? a.M : a.N;
+    if ((int)blockIdx.x * 256 >= n) return;
+    const int ng = (n + GRP - 1) / GRP;
+    const float4 *crec = (cloud ? a.crec2 : a.crec1) + (size_t)b * ng * GRP;
+    float4 *p0s = (cloud ? a.p0s2 : a.p0s1) + (size_t)b * ng * GRP;
+    int32_t *idx = (cloud ? a.idx2 : a.idx1) + (size_t)b * ng * GRP;
+    unsigned *cnt = histg + ((size_t)(cloud * a.B + b) * 2) * SORT_CELLS, *cur = cnt + SORT_CELLS;
+    const int f = blockIdx.x * 256 + tid;
+    const float4 r = f < n ? crec[f] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // in flight during the scan
+    {   // exclusive scan of the 4096 counts (16 per lane)
+        unsigned h[16], tsum = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { h[k] = cnt[16 * tid + k]; tsum += h[k]; }
+        const unsigned inc = (unsigned)wave_incl_scan((int)tsum);
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        unsigned run = inc - tsum;
+        for (int w = 0; w < wave; ++w) run += wsum[w];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { base[16 * tid + k] = run; run += h[k]; }
+    }
+    const CellGrid g = load_grid(a, cloud, b, n, red);  // its barrier also publishes base[]
+    if (f < n) {
+        const unsigned c = grid_cell(g, r);
+        const unsigned s = base[c] + atomicAdd(&cur[c], 1u);
+        p0s[s] = r;
+        idx[s] = f;
+    }
+    if (blockIdx.x == 0)  // pad: thr2 = 0 never passes
+        for (int s = n + tid; s < ng * GRP; s += 256) { p0s[s] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); idx[s] = 0; }
+}
+
+__global__ __launch_bounds__(256) void big_sphere_kernel(const BuildArgs a) {
+    const int cloud = blockIdx.z, b = blockIdx.y;
+    const int n = cloud ? a.M : a.N;
+    const int ng = (n + GRP - 1) / GRP;
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= ng) return;
+    const float4 *r = (cloud ? a.p0s2 : a.p0s1) + ((size_t)b * ng + g) * GRP;
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY}, tm = 0.0f;
+    float px[GRP], py[GRP], pz[GRP];
+#pragma unroll
+    for (int t = 0; t < GRP; ++t) {
+        const float4 v = r[t];
+        px[t] = v.x; py[t] = v.y; pz[t] = v.z;
+        if (g * GRP + t < n) {
+            lo[0] = fminf(lo[0], v.x); hi[0] = fmaxf(hi[0], v.x);
+            lo[1] = fminf(lo[1], v.y); hi[1] = fmaxf(hi[1], v.y);
+            lo[2] = fminf(lo[2], v.z); hi[2] = fmaxf(hi[2], v.z);
+            tm = fmaxf(tm, sqrtf(v.w) * 1.000001f);  // thr <= sqrtf(thr2)
+        }
+    }
+    const float cx = 0.5f * lo[0] + 0.5f * hi[0], cy = 0.5f * lo[1] + 0.5f * hi[1], cz = 0.5f * lo[2] + 0.5f * hi[2];
+    float d2 = 0.0f;
+#pragma unroll
+    for (int t = 0; t < GRP; ++t) {
+        const float ex = px[t] - cx, ey = py[t] - cy, ez = pz[t] - cz;
+        const float e2 = ex * ex + ey * ey + ez * ez;
+        if (g * GRP + t < n) d2 = fmaxf(d2, e2);
+    }
+    const float rho = sqrtf(d2) * 1.00001f + 1e-7f;
+    const float R = rho + tm;
+    float R2 = R * R * 1.0001f + 1e-7f;
+    if (!(R2 < 3.0e38f)) R2 = INFINITY;  // non-finite data: keep the group
+    ((cloud ? a.grp2 : a.grp1) + (size_t)b * ng)[g] = make_float4(cx, cy, cz, R2);
 }
 
 typedef const float __attribute__((address_space(4))) * kptr;  // constant AS -> s_load
@@ -640,16 +782,24 @@ int rrl_launch_tri_build(const float *tri1, const float *tri2, void *ws, const W
     a.zero_vec4 = w.zero_bytes / 16;
     a.g1 = xf && xf->zero_g1 ? (uint4 *)((char *)ws + w.off[RRL_WS_GACC]) : nullptr;  // small: 12 B + 16 floats
     a.g1_vec4 = a.g1 ? (w.off[RRL_WS_KJC] - w.off[RRL_WS_GACC]) / 16 : 0;
+    a.z2 = nmax > 4096 ? (uint4 *)((char *)ws + w.off[RRL_WS_HISTG]) : nullptr;
+    a.z2_vec4 = a.z2 ? (size_t)2 * B * 2 * SORT_CELLS * sizeof(unsigned) / 16 : 0;
     a.B = B; a.N = N; a.M = M;
     a.transpose_r = xf ? xf->transpose_r : 0;
     const int nall = N > M ? N : M;  // APART is laid out for the larger cloud
     a.nblk = (nall + REC_BLK - 1) / REC_BLK;
     hipLaunchKernelGGL(tri_records_kernel, dim3((unsigned)((nmax + REC_BLK - 1) / REC_BLK), (unsigned)B, (unsigned)clouds),
                        dim3(REC_BLK), 0, s, a);
-    if (nmax <= 4096)
+    if (nmax <= 4096) {
         hipLaunchKernelGGL(tri_sort_kernel<4>, dim3((unsigned)(clouds * B)), dim3(1024), lds, s, a);
-    else
-        hipLaunchKernelGGL(tri_sort_kernel<0>, dim3((unsigned)(clouds * B)), dim3(1024), lds, s, a);
+    } else {  // wide three-launch sort (HISTG was cleared by tri_records_kernel)
+        unsigned *histg = (unsigned *)w.i32(ws, RRL_WS_HISTG);
+        const dim3 gt((unsigned)((nmax + 255) / 256), (unsigned)B, (unsigned)clouds);
+        hipLaunchKernelGGL(big_hist_kernel, gt, dim3(256), 0, s, a, histg);
+        hipLaunchKernelGGL(big_scatter_kernel, gt, dim3(256), 0, s, a, histg);
+        const dim3 gs((unsigned)(((nmax + GRP - 1) / GRP + 255) / 256), (unsigned)B, (unsigned)clouds);
+        hipLaunchKernelGGL(big_sphere_kernel, gs, dim3(256), 0, s, a);
+    }
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }

@@ -51,6 +51,7 @@ struct WsLayout {
             4 * (b * 12 + 16),                           // GACC (followed by KJC: see rrl_launch_tri_build)
             b * ((l + 1023) / 1024) * 1024,              // KJC
             4 * b * ((l + 1023) / 1024 + 1),             // BLKCNT
+            (n > 4096 || m > 4096) ? 4 * 2 * b * 2 * 4096 : 16,  // HISTG (wide sort of large clouds)
         };
         size_t o = 0;
         for (int i = 0; i < RRL_WS_FIELDS; ++i) {

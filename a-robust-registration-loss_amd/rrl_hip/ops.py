@@ -53,6 +53,7 @@ _WS_FIELDS = [
     ("gacc", torch.float32, lambda B, N, M, L, G: (12 * B + 16,)),
     ("kjc", torch.uint8, lambda B, N, M, L, G: (B, (L + 1023) // 1024 * 1024)),
     ("blkcnt", torch.int32, lambda B, N, M, L, G: (B * ((L + 1023) // 1024 + 1),)),
+    ("histg", torch.int32, lambda B, N, M, L, G: (2 * B * 2 * 4096 if max(N, M) > 4096 else 4,)),
 ]
 _layout_cache = {}
 

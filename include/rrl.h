@@ -98,6 +98,7 @@ enum {
                           rrl_registration_forward, accumulated by rrl_registration_backward     */
     RRL_WS_KJC,        /* uint8[B][Lp]  k | j<<4 at the compact slots                            */
     RRL_WS_BLKCNT,     /* int32[B][ceil(L/1024)] selected lines per 1024-line tile               */
+    RRL_WS_HISTG,      /* uint32[2 B][2][4096] cell counts and cursors of the wide sort (clouds > 4096) */
     RRL_WS_FIELDS
 };
 
