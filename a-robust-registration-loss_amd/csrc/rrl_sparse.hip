@@ -58,87 +58,77 @@ __device__ __forceinline__ void sort4(int *h, int n) {  // ascending, n <= 4
             if (j < n && h[j] < h[j - 1]) { int t = h[j]; h[j] = h[j - 1]; h[j - 1] = t; }
 }
 
-// Phase 2 of line_pair_dist_kernel for one selected line: ascending hits, weights, intersection
-// points, the k x j block of squared distances (and its copy in the median's input list).
-// tri1 / tri2 with stride 12 are the PREPARED records (PTRI: the same coordinates, 16-byte loads),
-// with stride 9 the raw input rows.
-__device__ __forceinline__ void pair_line(const float *__restrict__ tri1, const float *__restrict__ tri2,
-                                          const float *__restrict__ line, const int32_t *__restrict__ hit1,
-                                          const int32_t *__restrict__ hit2, int32_t *__restrict__ hs1,
-                                          int32_t *__restrict__ hs2, float *__restrict__ w1,
-                                          float *__restrict__ w2, float4 *__restrict__ Q1,
-                                          float4 *__restrict__ Q2, float *__restrict__ D,
-                                          float4 *__restrict__ dc_slot, int b, int N, int M, int L, size_t gl,
-                                          int k, int j, int st1, int st2) {
-    float ln[6];
-    {
-        const float2 *lp = (const float2 *)(line + gl * 6);  // 24-byte rows: 8-byte aligned
-        const float2 a0 = lp[0], a1 = lp[1], a2 = lp[2];
-        ln[0] = a0.x; ln[1] = a0.y; ln[2] = a1.x; ln[3] = a1.y; ln[4] = a2.x; ln[5] = a2.y;
+// Phase 2 of line_pair_dist_kernel: EIGHT lanes per selected line, one per (cloud, hit slot) --
+// a selected line has up to 4 + 4 hits and one lane doing them in turn was the kernel's long pole
+// (8 us of 13).  Each lane gathers its triangle (three 16-byte loads of the prepared record, or
+// the raw row with stride 9), recomputes the hit distances with the scan's arithmetic, the
+// weights and the intersection point, and stores them; the eight lanes then exchange their
+// points through LDS (same wavefront: no barrier) and each fills two entries of the k x j block
+// of squared distances -- by line for the backward kernels and as the canonical 4 x 4 tile
+// (+inf outside the block) at the line's compact slot for the reduce kernel.
+__device__ __forceinline__ void pair_hit(const float *__restrict__ tri1, const float *__restrict__ tri2,
+                                         const float *__restrict__ line, const int32_t *__restrict__ hit1,
+                                         const int32_t *__restrict__ hit2, int32_t *__restrict__ hs1,
+                                         int32_t *__restrict__ hs2, float *__restrict__ w1,
+                                         float *__restrict__ w2, float4 *__restrict__ Q1,
+                                         float4 *__restrict__ Q2, float *__restrict__ D,
+                                         float *__restrict__ dc_slot, float4 *s_q /* LDS [8] of this line */,
+                                         int b, int N, int M, size_t gl, int k, int j, int sub, int st1,
+                                         int st2) {
+    const int cloud = sub >> 2, a = sub & 3;
+    const int cnt = cloud ? j : k;
+    float q[3] = {0.0f, 0.0f, 0.0f};
+    if (a < cnt) {
+        float ln[6];
+        {
+            const float2 *lp = (const float2 *)(line + gl * 6);  // 24-byte rows: 8-byte aligned
+            const float2 a0 = lp[0], a1 = lp[1], a2 = lp[2];
+            ln[0] = a0.x; ln[1] = a0.y; ln[2] = a1.x; ln[3] = a1.y; ln[4] = a2.x; ln[5] = a2.y;
+        }
+        int h[RRL_MAX_HITS];
+        {
+            const int4 r = ((const int4 *)(cloud ? hit2 : hit1))[gl];
+            const int rr[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+            for (int t = 0; t < RRL_MAX_HITS; ++t) h[t] = t < cnt ? rr[t] : 0x7fffffff;
+        }
+        sort4(h, cnt);  // ascending triangle index == nonzero() order (code/loss.py:125-131)
+        const int f = a == 0 ? h[0] : (a == 1 ? h[1] : (a == 2 ? h[2] : h[3]));
+        const float *tb = cloud ? tri2 + (size_t)b * M * st2 : tri1 + (size_t)b * N * st1;
+        float w[3], c[9];
+        tri_coords(tb, cloud ? st2 : st1, f, c);
+        hit_weights(c, ln, w);
+        inter_point(c, w, q);
+        (cloud ? hs2 : hs1)[gl * RRL_MAX_HITS + a] = f;
+        (cloud ? Q2 : Q1)[gl * RRL_MAX_HITS + a] = make_float4(q[0], q[1], q[2], 0.0f);
+        float *wd = (cloud ? w2 : w1) + (gl * RRL_MAX_HITS + a) * 3;
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) wd[cc] = w[cc];
     }
-    const float *t1 = tri1 + (size_t)b * N * st1, *t2 = tri2 + (size_t)b * M * st2;
-    int h1[RRL_MAX_HITS], h2[RRL_MAX_HITS];
-    {
-        const int4 a = ((const int4 *)hit1)[gl], c = ((const int4 *)hit2)[gl];
-        const int r1[4] = {a.x, a.y, a.z, a.w}, r2[4] = {c.x, c.y, c.z, c.w};
+    s_q[sub] = make_float4(q[0], q[1], q[2], 0.0f);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the 8 lanes share a wavefront: LDS is in order
+    // D[a][b] = sum_c (q1 - q2)^2, code/loss.py:38-52: entries 2 sub and 2 sub + 1 of the 4 x 4 tile
+    float t2[2];
 #pragma unroll
-        for (int q = 0; q < RRL_MAX_HITS; ++q) {
-            h1[q] = q < k ? r1[q] : 0x7fffffff;
-            h2[q] = q < j ? r2[q] : 0x7fffffff;
+    for (int e = 0; e < 2; ++e) {
+        const int ee = 2 * sub + e, ra = ee >> 2, rb = ee & 3;
+        t2[e] = INFINITY;
+        if (ra < k && rb < j) {
+            const float4 p1 = s_q[ra], p2 = s_q[4 + rb];
+            float dx = p1.x - p2.x, dy = p1.y - p2.y, dz = p1.z - p2.z;
+            float sq = dx * dx;
+            sq = sq + dy * dy;
+            sq = sq + dz * dz;
+            D[gl * 16 + ra * j + rb] = sq;
+            t2[e] = sq;
         }
     }
-    sort4(h1, k);  // ascending triangle index == nonzero() order (code/loss.py:125-131)
-    sort4(h2, j);
-    float q1[RRL_MAX_HITS][3], q2[RRL_MAX_HITS][3];
-#pragma unroll
-    for (int a = 0; a < RRL_MAX_HITS; ++a) {
-        if (a < k) {
-            float w[3], c[9];
-            tri_coords(t1, st1, h1[a], c);
-            hit_weights(c, ln, w);
-            inter_point(c, w, q1[a]);
-            hs1[gl * RRL_MAX_HITS + a] = h1[a];
-            Q1[gl * RRL_MAX_HITS + a] = make_float4(q1[a][0], q1[a][1], q1[a][2], 0.0f);
-#pragma unroll
-            for (int cc = 0; cc < 3; ++cc) w1[(gl * RRL_MAX_HITS + a) * 3 + cc] = w[cc];
-        }
-        if (a < j) {
-            float w[3], c[9];
-            tri_coords(t2, st2, h2[a], c);
-            hit_weights(c, ln, w);
-            inter_point(c, w, q2[a]);
-            hs2[gl * RRL_MAX_HITS + a] = h2[a];
-            Q2[gl * RRL_MAX_HITS + a] = make_float4(q2[a][0], q2[a][1], q2[a][2], 0.0f);
-#pragma unroll
-            for (int cc = 0; cc < 3; ++cc) w2[(gl * RRL_MAX_HITS + a) * 3 + cc] = w[cc];
-        }
-    }
-    // D[a][b] = sum_c (q1 - q2)^2, code/loss.py:38-52: row-major k x j block by line (the backward
-    // kernels), and the canonical 4 x 4 tile (+inf outside the block) at the line's compact slot
-    // (the reduce kernel: no index chain, no k x j dependent addressing)
-    float tile[16];
-#pragma unroll
-    for (int a = 0; a < RRL_MAX_HITS; ++a)
-#pragma unroll
-        for (int bb = 0; bb < RRL_MAX_HITS; ++bb) {
-            tile[a * 4 + bb] = INFINITY;
-            if (a < k && bb < j) {
-                float dx = q1[a][0] - q2[bb][0], dy = q1[a][1] - q2[bb][1],
-                      dz = q1[a][2] - q2[bb][2];
-                float s = dx * dx;
-                s = s + dy * dy;
-                s = s + dz * dz;
-                D[gl * 16 + a * j + bb] = s;
-                tile[a * 4 + bb] = s;
-            }
-        }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) dc_slot[q] = make_float4(tile[4 * q], tile[4 * q + 1], tile[4 * q + 2], tile[4 * q + 3]);
+    ((float2 *)dc_slot)[sub] = make_float2(t2[0], t2[1]);
 }
 
 // 1024 lines per workgroup.  Phase 1: every lane classifies its line and the selected ones
 // (~9 %) are compacted through LDS, so that phase 2 -- the gather-heavy part -- runs on dense
-// wavefronts; the compacted line ids also go to SEL[b] for the reduce and backward kernels.
+// wavefronts, eight lanes per line; the compacted line ids also go to SEL[b] for the backward.
 __global__ __launch_bounds__(1024) void line_pair_dist_kernel(
     const float *__restrict__ tri1, const float *__restrict__ tri2, const float *__restrict__ line,
     const int32_t *__restrict__ count1, const int32_t *__restrict__ hit1,
@@ -151,6 +141,7 @@ __global__ __launch_bounds__(1024) void line_pair_dist_kernel(
     __shared__ int s_list[1024];
     __shared__ int s_wave[16];
     __shared__ int s_total;
+    __shared__ float4 s_q[128][8];  // intersection points of the lines of one pass
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.y;
     int base_reg = 0;
@@ -178,27 +169,29 @@ __global__ __launch_bounds__(1024) void line_pair_dist_kernel(
         if (sel) s_list[s_wave[wave] + __popcll(mask & ((1ull << lane) - 1ull))] = l;
         __syncthreads();
     }
-    const bool active = tid < s_total;
-    const int l = active ? s_list[tid] : 0;
-    const size_t gl = (size_t)b * L + l;
-    const int k = active ? count1[gl] : 0, j = active ? count2[gl] : 0;
     // Compact copies for the reduce kernel live at slot = 1024 * (this workgroup) + rank: no global
     // counter is needed to place them (BLKCNT[b][x] tells the consumer how many each workgroup
     // wrote), so nothing here waits for an atomic.  SEL[b] (dense list of the selected line ids,
     // for the backward kernels) is written at the end by wavefront 0 alone: lane 0 holds the base
     // returned by the nsel atomic, whose round trip has long been hidden by the gathers.
     const size_t Lp = (size_t)gridDim.x * 1024;
-    if (tid == 0) blkcnt[(size_t)b * gridDim.x + blockIdx.x] = s_total;
-    if (!active && wave != 0) return;
-    if (active) {
-        const size_t slot = (size_t)b * Lp + (size_t)blockIdx.x * 1024 + tid;
-        kjc[slot] = (uint8_t)(k | (j << 4));
-        pair_line(tri1, tri2, line, hit1, hit2, hs1, hs2, w1, w2, Q1, Q2, D, (float4 *)(dc + slot * 16), b, N, M,
-                  L, gl, k, j, st1, st2);
+    const int total = s_total;
+    if (tid == 0) blkcnt[(size_t)b * gridDim.x + blockIdx.x] = total;
+    for (int r0 = 0; r0 < total; r0 += 128) {  // 128 selected lines per pass, 8 lanes each
+        const int rank = r0 + (tid >> 3), sub = tid & 7;
+        if (rank < total) {
+            const int l = s_list[rank];
+            const size_t gl = (size_t)b * L + l;
+            const int k = count1[gl], j = count2[gl];
+            const size_t slot = (size_t)b * Lp + (size_t)blockIdx.x * 1024 + rank;
+            if (sub == 0) kjc[slot] = (uint8_t)(k | (j << 4));
+            pair_hit(tri1, tri2, line, hit1, hit2, hs1, hs2, w1, w2, Q1, Q2, D, dc + slot * 16, s_q[tid >> 3], b,
+                     N, M, gl, k, j, sub, st1, st2);
+        }
     }
     if (wave == 0) {
         const int base = __builtin_amdgcn_readfirstlane(base_reg);
-        for (int i = lane; i < s_total; i += 64) sel_out[(size_t)b * L + base + i] = s_list[i];
+        for (int i = lane; i < total; i += 64) sel_out[(size_t)b * L + base + i] = s_list[i];
     }
 }
 
