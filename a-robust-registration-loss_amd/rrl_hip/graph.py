@@ -24,7 +24,9 @@ class GraphedStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # thread-local capture mode: other threads of the process (the RCCL watchdog of a
+        # multi-GPU run) may touch the HIP runtime while this stream is capturing
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.out = fn()
 
     def __call__(self):
