@@ -117,21 +117,37 @@ def main():
         torch.autograd.backward([loss], [ones])  # d(sum of losses): no reduction kernel needed
         return ops.last_state().payload
 
-    graphed = None
-    if not args.no_graph:
-        try:
-            from rrl_hip.graph import GraphedStep
-            graphed = GraphedStep(local_step)
-        except Exception as exc:  # capture unsupported: fall back to eager launches
-            print(f"[bench] graph capture failed ({type(exc).__name__}: {exc}); eager", file=sys.stderr)
-            graphed = None
+    from rrl_hip import rccl as rrccl
+    reducer = rrccl.make_reducer(dev)
+    direct = hasattr(reducer, "allreduce_inline")  # direct RCCL binding available
 
-    reducer = rdist.PayloadReducer(dev)
+    graphed, inline = None, False
+    if not args.no_graph:
+        from rrl_hip.graph import GraphedStep
+        if direct and os.environ.get("RRL_AR_INLINE", "1") != "0":
+            try:  # the all-reduce as the last node of the captured step (in place on the payload)
+                graphed = GraphedStep(lambda: reducer.allreduce_inline(local_step()))
+                inline = True
+            except Exception as exc:
+                print(f"[bench] capture with in-graph all-reduce failed ({type(exc).__name__}: {exc})", file=sys.stderr)
+                graphed = None
+        if graphed is None:
+            try:
+                graphed = GraphedStep(local_step)
+            except Exception as exc:  # capture unsupported: fall back to eager launches
+                print(f"[bench] graph capture failed ({type(exc).__name__}: {exc}); eager", file=sys.stderr)
+                graphed = None
+
+    last = [None]
 
     def step():
+        # one 14-float all-reduce per step (N > 1): a node of the captured step when the direct
+        # RCCL binding is up; otherwise issued asynchronously so that it overlaps the next step's
+        # kernels (waited for before its buffer is reused and at the end)
+        if inline:
+            last[0] = graphed()
+            return last[0]
         payload = graphed() if graphed is not None else local_step()
-        # one 14-float all-reduce per step (N > 1), issued asynchronously: it overlaps the next
-        # step's kernels and is waited for before its buffer is reused (and at the end)
         reducer.submit(payload)
         return payload
 
@@ -149,7 +165,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         step()
-    payload = reducer.finish()  # the last step's reduction is inside the timed region
+    payload = last[0] if inline else reducer.finish()  # the last reduction is inside the timed region
     fence()
     dt = time.perf_counter() - t0
     if graphed is not None:
@@ -193,7 +209,7 @@ def main():
             "config": {"workload": f"B={B}/GPU, N=M={N} pseudo-triangles, L={L} lines, fp32 loss "
                                    f"fwd+bwd (BASELINE.json configs[1]); scan mode {args.mode}; "
                                    + ("hipGraph replay" if graphed is not None else "eager launches"),
-                       "global_batch": B * world, "parallelism": f"batch-shard dp{world}"},
+                       "global_batch": B * world, "parallelism": f"batch-shard dp{world}", "allreduce": type(reducer).__name__ + (" (in-graph)" if inline else "")},
             "roofline": {
                 "bound": "valu", "kernel": "K1 line<->triangle scan (cull_scan_kernel)",
                 "achieved": FLOPS_PER_PAIR * pairs_step / scan_s / 1e12, "peak": VALU_PEAK_TFLOPS,
@@ -221,6 +237,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(N, M, L)
         print(json.dumps(out))
+    if hasattr(reducer, "close"):
+        reducer.close()
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
