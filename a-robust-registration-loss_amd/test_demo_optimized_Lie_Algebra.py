@@ -157,7 +157,8 @@ def test_one_case(data, Save_path, writer=None, n_epoch=1000, n_sample_line=2000
     draw = lines_fn or _default_lines(radius, centers, n_sample_line, tar, dev, device_rng)
     if graph:
         return _run_graphed(Reconstruction, draw, src, src_nb, tar, tar_tri, Save_path, writer,
-                            n_epoch, save_every, print_every), Reconstruction
+                            n_epoch, save_every, print_every,
+                            draw_in_graph=device_rng and lines_fn is None), Reconstruction
 
     optimize = torch.optim.Adam(Reconstruction.parameters(), lr=2e-2)
     moved = src
@@ -188,7 +189,10 @@ def test_one_case(data, Save_path, writer=None, n_epoch=1000, n_sample_line=2000
 
 
 def _run_graphed(model, draw, src, src_nb, tar, tar_tri, Save_path, writer, n_epoch, save_every,
-                 print_every):
+                 print_every, draw_in_graph=False):
+    """draw_in_graph: the line sampler is part of the captured step (possible when its uniforms come
+    from the GPU generator): ONE graph launch per epoch and nothing else on the stream -- every eager
+    kernel between two graph launches costs more than it computes."""
     dev = src.device
     xi = model.parameters_
     opt = _GatedAdam(xi, 2e-2)
@@ -196,10 +200,14 @@ def _run_graphed(model, draw, src, src_nb, tar, tar_tri, Save_path, writer, n_ep
     lines0 = draw(0, src)
     lines = torch.empty_like(lines0.reshape(1, -1, 6))
     moved = src.clone().reshape(1, -1, 3)
-    trace = torch.zeros(n_epoch, 3, device=dev)  # loss, chamfer, valid per epoch
+    WARM = 2  # eager warm-up runs of the step before its capture
+    trace = torch.zeros(n_epoch + WARM, 3, device=dev)  # loss, chamfer, valid per epoch (+ warm-up scratch rows)
     row = torch.zeros(3, device=dev)
+    slot = torch.zeros(1, dtype=torch.long, device=dev)  # epoch counter on the device
 
     def step():
+        if draw_in_graph:  # lines from the previous epoch's moved source, like the reference loop
+            lines.copy_(draw(0, moved.reshape(-1, 3)).reshape(1, -1, 6))
         xi.grad = None
         R, T = model.Transform()
         loss, info, _ = _ops.registration_loss(src_tri, R, T, tar_tri, lines, transpose_r=False)
@@ -209,21 +217,31 @@ def _run_graphed(model, draw, src, src_nb, tar, tar_tri, Save_path, writer, n_ep
         with torch.no_grad():
             moved.copy_(_ops.rigid_apply(src.reshape(1, -1, 3), R.detach(), T.detach()))
             row[0], row[1], row[2] = loss.detach()[0], _ops.chamfer(moved, tar.reshape(1, -1, 3)), ok
+            if draw_in_graph:  # the trace row is written inside the graph too
+                trace.index_copy_(0, slot, row[None])
+                slot.add_(1)
         return row
 
     lr = 2e-2
     stepper = None
     for epoch in range(n_epoch):
-        lines.copy_((lines0 if epoch == 0 else draw(epoch, moved.reshape(-1, 3))).reshape(1, -1, 6))
-        lr = adjust_learning_rate(opt, epoch, lr)
-        opt.set_lr()
+        if not draw_in_graph:
+            lines.copy_((lines0 if epoch == 0 else draw(epoch, moved.reshape(-1, 3))).reshape(1, -1, 6))
+        new_lr = adjust_learning_rate(opt, epoch, lr)
+        if new_lr != lr or epoch == 0:
+            opt.set_lr()
+        lr = new_lr
         if stepper is None:
-            # the warm-up replays inside GraphedStep must not move the state: snapshot, restore
-            keep = [t.clone() for t in (xi.data, opt.m, opt.v, opt.step)]
-            stepper = GraphedStep(step, warmup=2)
-            for t, k in zip((xi.data, opt.m, opt.v, opt.step), keep):
+            # the warm-up runs inside GraphedStep must not move the state: snapshot, restore
+            state = (xi.data, opt.m, opt.v, opt.step, moved, slot)
+            keep = [t.clone() for t in state]
+            slot.fill_(n_epoch)  # warm-up rows land in the scratch rows
+            stepper = GraphedStep(step, warmup=WARM)
+            for t, k in zip(state, keep):
                 t.copy_(k)
-        trace[epoch].copy_(stepper())
+        out = stepper()
+        if not draw_in_graph:
+            trace[epoch].copy_(out)
         if print_every and epoch % print_every == 0:
             di, cf, ok = trace[epoch].tolist()
             if ok:
@@ -231,7 +249,7 @@ def _run_graphed(model, draw, src, src_nb, tar, tar_tri, Save_path, writer, n_ep
         if save_every and epoch % save_every == 0:
             save_checkpoint(Save_path, epoch, moved.reshape(-1, 3), tar, model)
     history = []
-    for epoch, (di, cf, ok) in enumerate(trace.tolist()):
+    for epoch, (di, cf, ok) in enumerate(trace[:n_epoch].tolist()):
         history.append((epoch, di, cf) if ok else (epoch, None, None))
         if ok and writer is not None:
             writer.add_scalar('./loss/chamfer_loss', cf, epoch)

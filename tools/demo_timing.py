@@ -8,7 +8,7 @@ import importlib
 demo = importlib.import_module("test_demo_optimized_Lie_Algebra")
 for graph, device_rng, save_every in ((False, False, 10), (True, False, 10), (True, True, 10), (True, True, 0)):
     with tempfile.TemporaryDirectory() as d:
-        args = argparse.Namespace(data_path=None, device="cuda:0", seed=1, label1="s", Save_path=d, n_epoch=300,
+        args = argparse.Namespace(data_path=None, device="cuda:0", seed=1, label1="s", Save_path=d, n_epoch=300 if not graph else 3000,
                                   n_sample_line=20000, synthetic=1024, graph=graph, print_every=0,
                                   device_rng=device_rng, save_every=save_every)
         torch.cuda.synchronize(); t0 = time.perf_counter()
