@@ -1,32 +1,33 @@
-// rrl_cull.hip -- the build kernel (transform + records + cell sort + group spheres) and K1 with
-// sphere culling (scan mode RRL_SCAN_CULL).  Compiled with -fno-slp-vectorize: packed fp32
-// issues at half rate on gfx950, so SLP-packing the all-VGPR exact test only adds register
-// shuffling (the packed code below is explicit).
+// rrl_cull.hip -- the build kernels (transform + records + cell sort + sphere tree) and K1 with
+// hierarchical sphere culling (scan mode RRL_SCAN_CULL).  Compiled with -fno-slp-vectorize:
+// packed fp32 issues at half rate on gfx950, so SLP-packing the all-VGPR exact test only adds
+// register shuffling (the packed code below is explicit).
 //
 // The full scan evaluates every (line, triangle) pair although only ~6e-4 of them can pass even
 // the first point's test.  Here:
-//   tri_build_kernel (one 1024-lane workgroup per cloud and sample)
-//     orders the triangles by the 16^3 grid cell of P0, cells in Hilbert-curve order (counting sort
-//     in LDS), and writes, in that order, 16-byte (P0, thr2) records (P0S), their original
-//     indices (IDX) and, for every group of 16 consecutive triangles, a bounding sphere of the
-//     P0s: centre c, rho = max |P0 - c| and the conservative squared radius
-//     R2 = ((rho + max thr)^2)(1 + 1e-4) + 1e-7.
-//   cull_scan_kernel (128 lines per workgroup, two per lane; its 8 wavefronts hold the same lines
-//   and split the group range; every wavefront has private LDS queues, so there is no workgroup
-//   synchronisation at all)
-//     phase 1: every lane tests ITS two lines (packed fp32) against each group sphere
-//              (wave-uniform sphere, scalar loads) with a conservative test; each passing
-//              (line, group) pair is written straight to its slot of the batch's entry list
-//              (ballot + mbcnt rank: group-major, no per-lane bit masks to unpack later) and the
-//              group's 16 records are DMA-copied (global_load ... lds) into the wave's LDS rows;
-//     phase 2: when 128 pairs or 12 groups have gathered, the lanes take one pair each per pass
-//              -- every lane does the same number of exact evaluations however unevenly the
-//              pairs are spread over the lines -- and run the scan's exact point-0 test (same
-//              dist_sq arithmetic, bit-identical) on the group's 16 records from LDS.  Point-0
-//              passes (~1 in 130 tests) are parked and their points 1, 2 (two dependent global
-//              loads) resolved densely afterwards.
-//   Measured (B=8, N=M=4096, L=10000): phase 1 alone 30 us, both 65 us; per-wave LDS, the batch
-//   geometry (EB, BGRP) and wavefronts per workgroup were swept on the GPU (tools/knob_sweep.sh).
+//   build (tri_records_kernel + tri_sort_kernel, or the wide big_* kernels beyond 4096 triangles)
+//     orders the triangles by the 16^3 grid cell of P0, cells along a Hilbert curve (counting
+//     sort), and writes, in that order, 16-byte (P0, thr2) records (P0S), their original indices
+//     (IDX) and a three-level SPHERE TREE over consecutive sorted records: per supergroup of 64
+//     triangles one node of 13 float4 = its own sphere, the spheres of its 4 groups of 16 and of
+//     their 8 halves of 8.  Every sphere bounds the P0s of its records: centre c, rho = max |P0-c|
+//     and the conservative squared radius R2 = ((rho + max thr)^2)(1 + 1e-4) + 1e-7.
+//   cull_scan_kernel: a workgroup = one slice of <= SPW supergroups of one cloud (records and
+//   tree nodes staged in LDS once, ~10 KiB) x WPB wavefronts of 128 lines each.  Every wavefront
+//   walks the tree level by level through private LDS queues, with no workgroup synchronisation
+//   after the staging barrier:
+//     level A  every lane tests ITS two lines (packed fp32) against each supergroup sphere
+//              (wave-uniform sphere, scalar loads); passing (line, supergroup) pairs -> queue A;
+//     level B  the lanes pop one (line, supergroup) pair each and test its 4 group spheres
+//              -> queue B;   level C: (line, group) -> the 2 half spheres -> queue C;
+//     level D  the lanes pop one (line, half) pair each and run the scan's exact point-0 test
+//              (same dist_sq arithmetic, bit-identical) on the half's 8 records.  Point-0 passes
+//              are parked and their points 1, 2 (two dependent global loads) resolved densely.
+//   Below level A every lane works on a different tree node at the same time, and a level only
+//   runs when 64 pairs are waiting (or at the end), so the lanes stay full however unevenly the
+//   pairs are spread over the lines.  Per line and cloud at the bench shape: 64 + 8.1 x 4 + 10.2 x 2
+//   sphere tests and 10.2 x 8 exact tests, against 256 sphere tests + 10.2 x 16 exact tests of the
+//   single-level version of this kernel (17.1 x 16 in Morton order).
 //
 // Culling bound (labels can never be lost).  For a line with |dir|^2 <= 1 + 1e-6 and
 // (|x0| + max|P|)^2 <= 100 ("safe", the NaN bound of rrl_scan.hip) let
@@ -35,14 +36,18 @@
 // The reference value x0_ref = fl((dAC - proj) + 2e-4) satisfies
 // |x0_ref - (delta(P0)^2 + 2e-4)| <= 30u |a|^2 <= 1.8e-4 (u = 2^-24), so a hit
 // (x0_ref < thr2 <= thr^2 (1 + 2u)) implies delta(P0) < thr and therefore
-// delta(c) < thr_max + rho for the centre c of the triangle's group.  Phase 1 evaluates
-// d2 = |a_c|^2 - (a_c.dir)^2 with FMAs (error <= 10u |a_c|^2) and keeps the group when
+// delta(c) < thr_max + rho for the centre c of ANY sphere that bounds the triangle's P0 -- its
+// half, its group and its supergroup alike, so a hit survives every level.  A sphere test
+// evaluates d2 = |a_c|^2 - (a_c.dir)^2 with FMAs (error <= 10u |a_c|^2) and keeps the node when
 // d2 - 4e-6 |a_c|^2 <= R2: the slack covers the evaluation error, the |dir|^2 excess and the
 // rounding of rho and R2 with a factor > 2 to spare.  Unsafe lines are not culled at all: a
-// 64-line workgroup containing one evaluates all its pairs with the strict loop.
+// wavefront holding one evaluates all its (line, triangle) pairs of the slice with the strict loop.
 #include "rrl_ws.h"
 
 #define GRP 16           // triangles per group
+#define SGG 4            // groups per supergroup
+#define SGT (GRP * SGG)  // triangles per supergroup
+#define NODE 13          // float4 per supergroup in the sphere tree: [0] supergroup, [1..4] groups, [5..12] halves
 #define SORT_CAP 65536   // largest cloud of the sorted / culled layout (16-bit sorted positions in the scan)
 
 // Position of the 16^3 grid cell (q0, q1, q2) along a 3-D Hilbert curve (12 bits).  Consecutive
@@ -51,7 +56,7 @@
 // 10.2 group spheres per cloud instead of 17.1 (same cells, same sort).  Axes -> transposed index
 // by the standard inversion / exchange sweep from the top bit down, Gray decode, then bit
 // interleave.  Any permutation of the cells gives the same labels; only the group shapes change.
-__device__ __forceinline__ unsigned hilbert_cell(unsigned q0, unsigned q1, unsigned q2) {
+__host__ __device__ constexpr unsigned hilbert_cell(unsigned q0, unsigned q1, unsigned q2) {
     unsigned x[3] = {q0, q1, q2};
 #pragma unroll
     for (unsigned q = 8u; q > 1u; q >>= 1) {
@@ -78,7 +83,101 @@ __device__ __forceinline__ unsigned hilbert_cell(unsigned q0, unsigned q1, unsig
     return key;
 }
 
-__device__ __forceinline__ int p0s_slot(int s) { return s; }  // records in sorted order
+// The same map as a table indexed by q0 | q1 << 4 | q2 << 8 (8 KiB, built at compile time): the
+// single-workgroup sort is bound by ONE CU, where ~90 integer ops per triangle cost 1.4 us.
+struct HilbertLut {
+    unsigned short v[4096];
+};
+constexpr HilbertLut make_hilbert_lut() {
+    HilbertLut t{};
+    for (unsigned q2 = 0; q2 < 16; ++q2)
+        for (unsigned q1 = 0; q1 < 16; ++q1)
+            for (unsigned q0 = 0; q0 < 16; ++q0) t.v[q0 | (q1 << 4) | (q2 << 8)] = (unsigned short)hilbert_cell(q0, q1, q2);
+    return t;
+}
+__device__ const HilbertLut HILBERT_LUT = make_hilbert_lut();
+
+// ---- sphere tree ------------------------------------------------------------------------
+__device__ __forceinline__ float4 finish_sphere(float cx, float cy, float cz, float d2, float tm, bool any) {
+    if (!any) return make_float4(0.0f, 0.0f, 0.0f, -1.0f);  // empty node: never passes
+    const float rho = sqrtf(d2) * 1.00001f + 1e-7f;
+    const float R = rho + tm;
+    float R2 = R * R * 1.0001f + 1e-7f;
+    if (!(R2 < 3.0e38f)) R2 = INFINITY;  // non-finite data: keep the node
+    return make_float4(cx, cy, cz, R2);
+}
+
+#define QUAD_MIN(v) do { v = fminf(v, RRL_DPP_F(v, 0xB1)); v = fminf(v, RRL_DPP_F(v, 0x4E)); } while (0)
+#define QUAD_MAX(v) do { v = fmaxf(v, RRL_DPP_F(v, 0xB1)); v = fmaxf(v, RRL_DPP_F(v, 0x4E)); } while (0)
+
+// Tree nodes of one group: ONE lane walks the group's 16 sorted records (rec(s) -> (P0, thr2))
+// and derives the spheres of its two halves and of the group; the four lanes of an aligned quad
+// hold the four groups of a supergroup and combine their boxes with quad-permute DPP, so the
+// supergroup sphere costs no extra pass and no barrier.  ALL lanes of a quad must call (groups
+// past the end of the cloud contribute nothing).  n = number of real records.
+template <class Get>
+__device__ __forceinline__ void group_tree(Get rec, int g, int n, float4 *__restrict__ tree) {
+    const int nv = min(max(n - g * GRP, 0), GRP);
+    float px[GRP], py[GRP], pz[GRP];
+    float lo[2][3], hi[2][3], tm[2] = {0.0f, 0.0f};
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { lo[h][c] = INFINITY; hi[h][c] = -INFINITY; }
+    // thr <= sqrtf(thr2) (1 + 2^-22): thr2 is the smallest float whose rounded root reaches thr
+#pragma unroll
+    for (int t = 0; t < GRP; ++t) {
+        const int h = t >> 3;
+        if (t < nv) {
+            const float4 v = rec(g * GRP + t);
+            px[t] = v.x; py[t] = v.y; pz[t] = v.z;
+            lo[h][0] = fminf(lo[h][0], v.x); hi[h][0] = fmaxf(hi[h][0], v.x);
+            lo[h][1] = fminf(lo[h][1], v.y); hi[h][1] = fmaxf(hi[h][1], v.y);
+            lo[h][2] = fminf(lo[h][2], v.z); hi[h][2] = fmaxf(hi[h][2], v.z);
+            tm[h] = fmaxf(tm[h], sqrtf(v.w) * 1.000001f);
+        } else {
+            px[t] = py[t] = pz[t] = 0.0f;
+        }
+    }
+    auto radius2 = [&](float cx, float cy, float cz, int t0, int t1) {
+        float d2 = 0.0f;
+#pragma unroll
+        for (int t = t0; t < t1; ++t) {
+            const float ex = px[t] - cx, ey = py[t] - cy, ez = pz[t] - cz;
+            const float e2 = ex * ex + ey * ey + ez * ez;
+            if (t < nv) d2 = fmaxf(d2, e2);
+        }
+        return d2;
+    };
+    float4 *node = tree + (size_t)(g / SGG) * NODE;
+    const int gi = g % SGG;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const float cx = 0.5f * lo[h][0] + 0.5f * hi[h][0], cy = 0.5f * lo[h][1] + 0.5f * hi[h][1],
+                    cz = 0.5f * lo[h][2] + 0.5f * hi[h][2];
+        node[5 + 2 * gi + h] = finish_sphere(cx, cy, cz, radius2(cx, cy, cz, 8 * h, 8 * h + 8), tm[h], nv > 8 * h);
+    }
+    float glo[3], ghi[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { glo[c] = fminf(lo[0][c], lo[1][c]); ghi[c] = fmaxf(hi[0][c], hi[1][c]); }
+    float gtm = fmaxf(tm[0], tm[1]);
+    {
+        const float cx = 0.5f * glo[0] + 0.5f * ghi[0], cy = 0.5f * glo[1] + 0.5f * ghi[1],
+                    cz = 0.5f * glo[2] + 0.5f * ghi[2];
+        node[1 + gi] = finish_sphere(cx, cy, cz, radius2(cx, cy, cz, 0, GRP), gtm, nv > 0);
+    }
+    // supergroup: box / max thr / population over the quad, then the farthest of all 64 P0s
+    float anyv = nv > 0 ? 1.0f : 0.0f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { QUAD_MIN(glo[c]); QUAD_MAX(ghi[c]); }
+    QUAD_MAX(gtm);
+    QUAD_MAX(anyv);
+    const float cx = 0.5f * glo[0] + 0.5f * ghi[0], cy = 0.5f * glo[1] + 0.5f * ghi[1],
+                cz = 0.5f * glo[2] + 0.5f * ghi[2];
+    float d2 = nv > 0 ? radius2(cx, cy, cz, 0, GRP) : 0.0f;
+    QUAD_MAX(d2);
+    if (gi == 0) node[0] = finish_sphere(cx, cy, cz, d2, gtm, anyv > 0.0f);
+}
 
 #define SORT_CELLS 4096  // 16^3 grid cells in Hilbert-curve order
 
@@ -187,17 +286,16 @@ __global__ __launch_bounds__(REC_BLK) void tri_records_kernel(const BuildArgs a)
     }
 }
 
-// NPT > 0: every lane keeps its <= NPT records in registers between the passes (n <= 1024 NPT);
-// NPT == 0: they are re-read (16 B per triangle).
+// Every lane keeps its <= NPT records in registers between the passes (n <= 1024 NPT).
 template <int NPT>
 __global__ __launch_bounds__(1024) void tri_sort_kernel(const BuildArgs a) {
-    // NPT > 0: the sorted records and their triangle indices are assembled in LDS ([ng*17] float4,
-    //          one float4 of padding per group: lanes on different groups hit different banks;
-    //          then [ng*16] int) and leave with coalesced stores;
-    // NPT == 0: no dynamic LDS, records re-read from P0S
+    // the sorted records and their triangle indices are assembled in LDS ([ngp*17] float4, one
+    // float4 of padding per group: lanes on different groups hit different banks; then [ngp*16]
+    // int) and leave with coalesced stores; ngp = groups padded to whole supergroups
     extern __shared__ __attribute__((aligned(16))) float dyn_s[];
     float4 *srec = (float4 *)dyn_s;
     __shared__ unsigned hist[SORT_CELLS];
+    __shared__ __attribute__((aligned(16))) unsigned short hlut[SORT_CELLS];
     __shared__ float red[16][8];
     __shared__ unsigned wsum[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -205,21 +303,20 @@ __global__ __launch_bounds__(1024) void tri_sort_kernel(const BuildArgs a) {
     const int cloud = blockIdx.x >= (unsigned)B ? 1 : 0, b = blockIdx.x - cloud * B;
     const int n = cloud ? a.M : a.N;
     const int ng = (n + GRP - 1) / GRP;
+    const int nsg = (n + SGT - 1) / SGT, ngp = nsg * SGG, npad = nsg * SGT;
     const float4 *crec = (cloud ? a.crec2 : a.crec1) + (size_t)b * ng * GRP;
-    float4 *p0s = (cloud ? a.p0s2 : a.p0s1) + (size_t)b * ng * GRP;
-    int32_t *idx = (cloud ? a.idx2 : a.idx1) + (size_t)b * ng * GRP;
-    float4 *grp = (cloud ? a.grp2 : a.grp1) + (size_t)b * ng;
-    int *sidx = (int *)(srec + (size_t)ng * 17);
+    float4 *p0s = (cloud ? a.p0s2 : a.p0s1) + (size_t)b * npad;
+    int32_t *idx = (cloud ? a.idx2 : a.idx1) + (size_t)b * npad;
+    float4 *tree = (cloud ? a.grp2 : a.grp1) + (size_t)b * nsg * NODE;
+    int *sidx = (int *)(srec + (size_t)ngp * 17);
     auto pad = [](int s) { return s + (s >> 4); };
 
     // ---- AABB of the P0s and max |P|^2 from the per-workgroup partials of tri_records_kernel
-    constexpr int NR = NPT > 0 ? NPT : 1;
-    float4 rec[NR];
-    if (NPT > 0) {  // issue the record loads first: they overlap the reduction
+    float4 rec[NPT];
 #pragma unroll
-        for (int k = 0; k < NR; ++k)
-            if (tid + 1024 * k < n) rec[k] = crec[tid + 1024 * k];
-    }
+    for (int k = 0; k < NPT; ++k)  // issue the record loads first: they overlap the reduction
+        if (tid + 1024 * k < n) rec[k] = crec[tid + 1024 * k];
+    ((uint2 *)hlut)[tid] = ((const uint2 *)HILBERT_LUT.v)[tid];
     {
         const int nb = (n + REC_BLK - 1) / REC_BLK;
         const float *ap = a.apart + ((size_t)cloud * B + b) * a.nblk * 8;
@@ -259,18 +356,14 @@ __global__ __launch_bounds__(1024) void tri_sort_kernel(const BuildArgs a) {
             float v = (p[c] - mn[c]) * scale[c];
             q[c] = v >= 15.0f ? 15u : (v > 0.0f ? (unsigned)v : 0u);
         }
-        return hilbert_cell(q[0], q[1], q[2]);  // 12 bits
+        return hlut[q[0] | (q[1] << 4) | (q[2] << 8)];  // 12 bits, == hilbert_cell(q0, q1, q2)
     };
 
     // ---- histogram over cells, exclusive scan, scatter
-    unsigned cell[NR];
-    if (NPT > 0) {
+    unsigned cell[NPT];
 #pragma unroll
-        for (int k = 0; k < NR; ++k)
-            if (tid + 1024 * k < n) { cell[k] = cell_of(rec[k]); atomicAdd(&hist[cell[k]], 1u); }
-    } else {
-        for (int f = tid; f < n; f += 1024) atomicAdd(&hist[cell_of(crec[f])], 1u);
-    }
+    for (int k = 0; k < NPT; ++k)
+        if (tid + 1024 * k < n) { cell[k] = cell_of(rec[k]); atomicAdd(&hist[cell[k]], 1u); }
     __syncthreads();
     {
         unsigned h[4], tsum = 0;
@@ -286,106 +379,29 @@ __global__ __launch_bounds__(1024) void tri_sort_kernel(const BuildArgs a) {
         for (int k = 0; k < 4; ++k) { hist[4 * tid + k] = run; run += h[k]; }
     }
     __syncthreads();
-    // thr <= sqrtf(thr2) (1 + 2^-22): thr2 is the smallest float whose rounded root reaches thr
-    auto thr_bound = [](float thr2) { return sqrtf(thr2) * 1.000001f; };
-    if (NPT > 0) {
-        // scatter into LDS only; the global arrays are written afterwards, in order
+    // scatter into LDS only; the global arrays are written afterwards, in order
 #pragma unroll
-        for (int k = 0; k < NR; ++k) {
-            const int f = tid + 1024 * k;
-            if (f < n) {
-                const int s = (int)atomicAdd(&hist[cell[k]], 1u);
-                srec[pad(s)] = rec[k];
-                sidx[s] = f;
-            }
+    for (int k = 0; k < NPT; ++k) {
+        const int f = tid + 1024 * k;
+        if (f < n) {
+            const int s = (int)atomicAdd(&hist[cell[k]], 1u);
+            srec[pad(s)] = rec[k];
+            sidx[s] = f;
         }
-        for (int s = n + tid; s < ng * GRP; s += 1024) {  // pad: thr2 = 0 never passes
-            srec[pad(s)] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            sidx[s] = 0;
-        }
-        __syncthreads();
-        for (int s = tid; s < ng * GRP; s += 1024) {  // coalesced copy-out
-            p0s[s] = srec[pad(s)];
-            idx[s] = sidx[s];
-        }
-        // ---- group spheres: ONE lane per group walks its 16 records (16x less work than 16 lanes
-        //      reducing each other's values with DPP butterflies; this phase took 5.3 us of the
-        //      kernel's 14.4 on its single CU)
-        for (int g = tid; g < ng; g += 1024) {
-            const float4 *r = srec + (size_t)g * 17;
-            float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY}, tm = 0.0f;
-            float px[GRP], py[GRP], pz[GRP];
-#pragma unroll
-            for (int t = 0; t < GRP; ++t) {
-                const float4 v = r[t];
-                px[t] = v.x; py[t] = v.y; pz[t] = v.z;
-                if (g * GRP + t < n) {
-                    lo[0] = fminf(lo[0], v.x); hi[0] = fmaxf(hi[0], v.x);
-                    lo[1] = fminf(lo[1], v.y); hi[1] = fmaxf(hi[1], v.y);
-                    lo[2] = fminf(lo[2], v.z); hi[2] = fmaxf(hi[2], v.z);
-                    tm = fmaxf(tm, thr_bound(v.w));
-                }
-            }
-            const float cx = 0.5f * lo[0] + 0.5f * hi[0], cy = 0.5f * lo[1] + 0.5f * hi[1],
-                        cz = 0.5f * lo[2] + 0.5f * hi[2];
-            float d2 = 0.0f;
-#pragma unroll
-            for (int t = 0; t < GRP; ++t) {
-                const float ex = px[t] - cx, ey = py[t] - cy, ez = pz[t] - cz;
-                const float e2 = ex * ex + ey * ey + ez * ez;
-                if (g * GRP + t < n) d2 = fmaxf(d2, e2);
-            }
-            const float rho = sqrtf(d2) * 1.00001f + 1e-7f;
-            const float R = rho + tm;
-            float R2 = R * R * 1.0001f + 1e-7f;
-            if (!(R2 < 3.0e38f)) R2 = INFINITY;  // non-finite data: keep the group
-            grp[g] = make_float4(cx, cy, cz, R2);
-        }
-        return;
     }
-    for (int f = tid; f < n; f += 1024) {
-        const float4 r = crec[f];
-        const int s = (int)atomicAdd(&hist[cell_of(r)], 1u);
-        p0s[s] = r;
-        idx[s] = f;
+    for (int s = n + tid; s < npad; s += 1024) {  // pad: thr2 = 0 never passes
+        srec[pad(s)] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        sidx[s] = 0;
     }
-    for (int s = n + tid; s < ng * GRP; s += 1024) {  // pad: thr2 = 0 never passes
-        p0s[s] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        idx[s] = 0;
+    __syncthreads();
+    for (int s = tid; s < npad; s += 1024) {  // coalesced copy-out
+        p0s[s] = srec[pad(s)];
+        idx[s] = sidx[s];
     }
-    __syncthreads();  // the block's own global stores are visible to it after the barrier
-
-    // ---- group spheres: one lane per group, records re-read from P0S (256 contiguous bytes each)
-    for (int g = tid; g < ng; g += 1024) {
-        const float4 *r = p0s + (size_t)g * GRP;
-        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY}, tm = 0.0f;
-        float px[GRP], py[GRP], pz[GRP];
-#pragma unroll
-        for (int t = 0; t < GRP; ++t) {
-            const float4 v = r[t];
-            px[t] = v.x; py[t] = v.y; pz[t] = v.z;
-            if (g * GRP + t < n) {
-                lo[0] = fminf(lo[0], v.x); hi[0] = fmaxf(hi[0], v.x);
-                lo[1] = fminf(lo[1], v.y); hi[1] = fmaxf(hi[1], v.y);
-                lo[2] = fminf(lo[2], v.z); hi[2] = fmaxf(hi[2], v.z);
-                tm = fmaxf(tm, thr_bound(v.w));
-            }
-        }
-        const float cx = 0.5f * lo[0] + 0.5f * hi[0], cy = 0.5f * lo[1] + 0.5f * hi[1],
-                    cz = 0.5f * lo[2] + 0.5f * hi[2];
-        float d2 = 0.0f;
-#pragma unroll
-        for (int t = 0; t < GRP; ++t) {
-            const float ex = px[t] - cx, ey = py[t] - cy, ez = pz[t] - cz;
-            const float e2 = ex * ex + ey * ey + ez * ez;
-            if (g * GRP + t < n) d2 = fmaxf(d2, e2);
-        }
-        const float rho = sqrtf(d2) * 1.00001f + 1e-7f;
-        const float R = rho + tm;
-        float R2 = R * R * 1.0001f + 1e-7f;
-        if (!(R2 < 3.0e38f)) R2 = INFINITY;  // non-finite data: keep the group
-        grp[g] = make_float4(cx, cy, cz, R2);
-    }
+    // ---- sphere tree: ONE lane per group walks its 16 records (16 lanes reducing each other's
+    //      values with DPP butterflies took 5.3 us of this kernel's former 14.4 on its single CU)
+    for (int g = tid; g < ngp; g += 1024)
+        group_tree([&](int s_) { return srec[pad(s_)]; }, g, n, tree);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -464,8 +480,9 @@ __global__ __launch_bounds__(256) void big_scatter_kernel(const BuildArgs a, uns
     if ((int)blockIdx.x * 256 >= n) return;
     const int ng = (n + GRP - 1) / GRP;
     const float4 *crec = (cloud ? a.crec2 : a.crec1) + (size_t)b * ng * GRP;
-    float4 *p0s = (cloud ? a.p0s2 : a.p0s1) + (size_t)b * ng * GRP;
-    int32_t *idx = (cloud ? a.idx2 : a.idx1) + (size_t)b * ng * GRP;
+    const int npad = (n + SGT - 1) / SGT * SGT;
+    float4 *p0s = (cloud ? a.p0s2 : a.p0s1) + (size_t)b * npad;
+    int32_t *idx = (cloud ? a.idx2 : a.idx1) + (size_t)b * npad;
     unsigned *cnt = histg + ((size_t)(cloud * a.B + b) * 2) * SORT_CELLS, *cur = cnt + SORT_CELLS;
     const int f = blockIdx.x * 256 + tid;
     const float4 r = f < n ? crec[f] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // in flight during the scan
@@ -489,77 +506,60 @@ __global__ __launch_bounds__(256) void big_scatter_kernel(const BuildArgs a, uns
         idx[s] = f;
     }
     if (blockIdx.x == 0)  // pad: thr2 = 0 never passes
-        for (int s = n + tid; s < ng * GRP; s += 256) { p0s[s] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); idx[s] = 0; }
+        for (int s = n + tid; s < npad; s += 256) { p0s[s] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); idx[s] = 0; }
 }
 
 __global__ __launch_bounds__(256) void big_sphere_kernel(const BuildArgs a) {
     const int cloud = blockIdx.z, b = blockIdx.y;
     const int n = cloud ? a.M : a.N;
-    const int ng = (n + GRP - 1) / GRP;
-    const int g = blockIdx.x * 256 + threadIdx.x;
-    if (g >= ng) return;
-    const float4 *r = (cloud ? a.p0s2 : a.p0s1) + ((size_t)b * ng + g) * GRP;
-    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY}, tm = 0.0f;
-    float px[GRP], py[GRP], pz[GRP];
-#pragma unroll
-    for (int t = 0; t < GRP; ++t) {
-        const float4 v = r[t];
-        px[t] = v.x; py[t] = v.y; pz[t] = v.z;
-        if (g * GRP + t < n) {
-            lo[0] = fminf(lo[0], v.x); hi[0] = fmaxf(hi[0], v.x);
-            lo[1] = fminf(lo[1], v.y); hi[1] = fmaxf(hi[1], v.y);
-            lo[2] = fminf(lo[2], v.z); hi[2] = fmaxf(hi[2], v.z);
-            tm = fmaxf(tm, sqrtf(v.w) * 1.000001f);  // thr <= sqrtf(thr2)
-        }
-    }
-    const float cx = 0.5f * lo[0] + 0.5f * hi[0], cy = 0.5f * lo[1] + 0.5f * hi[1], cz = 0.5f * lo[2] + 0.5f * hi[2];
-    float d2 = 0.0f;
-#pragma unroll
-    for (int t = 0; t < GRP; ++t) {
-        const float ex = px[t] - cx, ey = py[t] - cy, ez = pz[t] - cz;
-        const float e2 = ex * ex + ey * ey + ez * ez;
-        if (g * GRP + t < n) d2 = fmaxf(d2, e2);
-    }
-    const float rho = sqrtf(d2) * 1.00001f + 1e-7f;
-    const float R = rho + tm;
-    float R2 = R * R * 1.0001f + 1e-7f;
-    if (!(R2 < 3.0e38f)) R2 = INFINITY;  // non-finite data: keep the group
-    ((cloud ? a.grp2 : a.grp1) + (size_t)b * ng)[g] = make_float4(cx, cy, cz, R2);
+    const int nsg = (n + SGT - 1) / SGT;
+    const int g = blockIdx.x * 256 + threadIdx.x;  // 256 = 64 whole quads
+    if (g >= nsg * SGG) return;
+    const float4 *r = (cloud ? a.p0s2 : a.p0s1) + (size_t)b * nsg * SGT;
+    group_tree([&](int s_) { return r[s_]; }, g, n, (cloud ? a.grp2 : a.grp1) + (size_t)b * nsg * NODE);
 }
 
 typedef const float __attribute__((address_space(4))) * kptr;  // constant AS -> s_load
+typedef const int __attribute__((address_space(4))) * kiptr;
 
-#ifndef BGRP
-#define BGRP 12    // groups per batch (<= 16: 4-bit slot in an entry): their 16 x 256-byte rows are staged in the wave's LDS
-#endif
-#ifndef WCCAP
-#define WCCAP 256  // parked point-0 candidates per wave (1 KiB)
+#ifndef SPW
+#define SPW 8      // supergroups per slice (<= 8: 3-bit slot in a queue-A entry); staged once per workgroup
 #endif
 #ifndef WPB
-#define WPB 8      // wavefronts per workgroup: they split the group range of the block's lines
+#define WPB 8      // wavefronts per workgroup: same slice, LPW lines each
 #endif
-#define ROWS 17    // float4 per staged row: 16 records + 16 bytes of padding (bank spread)
-
-typedef __attribute__((address_space(3))) void lds_void_t;
-typedef const __attribute__((address_space(1))) void glb_void_t;
+#define LPW 128    // lines per wavefront (two per lane in level A)
+#define ROWS 17    // float4 per staged group row: 16 records + 16 bytes of padding (bank spread)
+#ifndef WCCAP
+#define WCCAP 128  // parked point-0 candidates per wave
+#endif
+// queue capacities: a level only runs on full 64-entry passes until the end, so a queue holds
+// at most 63 left-over entries plus one push round (128 / 256 / 128)
+#define QA_CAP 192
+#define QB_CAP 320
+#define QC_CAP 192
 
 struct WaveCtx {
-    const float4 *lines;          // this wave's 64 lines in LDS: [64][2]
-    const float4 *p0s;            // sorted (P0, thr2) records of the cloud
+    const float4 *la;             // this wave's lines in LDS: (dir, x0.x) and (x0.y, x0.z)
+    const float2 *lb;
+    const float4 *recs;           // LDS: staged records of the slice, [group][ROWS]
+    const float4 *nodes;          // LDS: staged tree nodes of the slice, [supergroup][NODE]
+    unsigned short *qa, *qb, *qc; // LDS queues: line << 3 | sg, line << 5 | group, line << 6 | half (slice-local)
+    unsigned *cands;              // LDS [WCCAP]
     const int32_t *idx;           // sorted position -> original triangle index
     const float *ptri;            // prepared triangles (original order)
     int32_t *cnt, *hit;           // per-line hit count / slots of the cloud
     int lbase;                    // first line of this wave
-    float4 *rows;                 // LDS [BGRP][16] staged records of the current batch
-    unsigned short *ent;          // LDS [64] entries of the current batch: line << 4 | batch slot
-    int *bgrp;                    // LDS [BGRP] group index of each batch slot
-    unsigned *cands;              // LDS [WCCAP]
+    int pos0;                     // sorted position of the slice's first record
+    int na, nb, nc, ncand;        // wave-uniform fill levels
+    int lane;
 };
 
 // cand = line_in_wave << 16 | sorted triangle position: evaluate points 1 and 2
 __device__ __forceinline__ void resolve_candidate(const WaveCtx &c, unsigned cand) {
     const int ll = cand >> 16, spos = cand & 0xffff;
-    const float4 la = c.lines[2 * ll], lb = c.lines[2 * ll + 1];
+    const float4 la = c.la[ll];
+    const float2 lb = c.lb[ll];
     const int f = c.idx[spos];
     const float *q = c.ptri + PTRI_STRIDE * (size_t)f;
     const uint32_t thr2 = __float_as_uint(q[9]);
@@ -577,36 +577,45 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
 
-// Phase 2 for one batch of a wave: <= EB (line, group) pairs over <= BGRP groups, listed
-// group-major in c.ent (phase 1 writes every pair at its final position).  The groups' records
-// were copied, coalesced, into the wave's LDS rows (row stride padded so lanes on different
-// groups hit different banks); every lane runs the exact point-0 test of one pair on the 16
-// triangles.  Point-0 passes (~1 in 130 tests) are parked; their points 1, 2 need two dependent
-// global loads and are resolved densely when enough have gathered.
-#ifndef EB
-#define EB 128  // entries per batch (two passes of 64 lanes)
-#endif
+__device__ __forceinline__ int lane_rank(unsigned long long m) {  // set bits of m below this lane
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
 
-__device__ __forceinline__ void run_batch(const WaveCtx &c, int nent, int &ncand, int lane) {
-    // the rows of this batch were requested (global -> LDS DMA) as their groups were appended in
-    // phase 1; wait for the stragglers
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+// conservative sphere test of one line against one tree node (see the culling bound above)
+__device__ __forceinline__ bool sphere_pass(const float4 nd, const float4 la, const float2 lb) {
+    const float ax = nd.x - la.w, ay = nd.y - lb.x, az = nd.z - lb.y;
+    const float dot = fmaf(az, la.z, fmaf(ay, la.y, ax * la.x));
+    const float q = fmaf(az, az, fmaf(ay, ay, ax * ax));
+    float d2 = fmaf(-dot, dot, q);
+    d2 = fmaf(-4e-6f, q, d2);
+    return d2 <= nd.w;
+}
+
+__device__ __forceinline__ void flush_cands(WaveCtx &c) {
     wave_lds_fence();
-#ifdef CULL_SKIP_PHASE2  // timing experiment only: batches are formed but not evaluated
-    return;
-#endif
-    for (int e0 = 0; e0 < nent; e0 += 64) {  // one pass unless a group is hit by > 64 of the lines
+    const int nc = min(c.ncand, WCCAP);
+    for (int i = c.lane; i < nc; i += 64) resolve_candidate(c, c.cands[i]);
+    c.ncand = 0;
+}
+
+// level D: pops (line, half) pairs, one per lane, and runs the exact point-0 test on the half's
+// 8 records.  all = false: only full passes.
+__device__ __forceinline__ void proc_c(WaveCtx &c, bool all) {
+    while (c.nc >= 64 || (all && c.nc > 0)) {
+        const int take = min(c.nc, 64), base = c.nc - take;
+        c.nc = base;
+        wave_lds_fence();
         uint32_t passbits = 0;
-        int ll = 0, g = 0;
-        if (e0 + lane < nent) {
-            const unsigned e = c.ent[e0 + lane];
-            ll = e >> 4;
-            const int k = e & 15;
-            g = c.bgrp[k];
-            const float4 la = c.lines[2 * ll], lb = c.lines[2 * ll + 1];
-            const float4 *row = c.rows + k * ROWS;
+        int ll = 0, h = 0;
+        if (c.lane < take) {
+            const unsigned e = c.qc[base + c.lane];
+            ll = e >> 6;
+            h = e & 63;
+            const float4 la = c.la[ll];
+            const float2 lb = c.lb[ll];
+            const float4 *row = c.recs + (h >> 1) * ROWS + (h & 1) * 8;
 #pragma unroll
-            for (int t = 0; t < GRP; ++t) {
+            for (int t = 0; t < 8; ++t) {
                 const float4 rec = row[t];
                 const float x = dist_sq<float>(rec.x, rec.y, rec.z, la.x, la.y, la.z, la.w, lb.x, lb.y);
                 passbits |= (__float_as_uint(x) < __float_as_uint(rec.w) ? 1u : 0u) << t;
@@ -617,55 +626,108 @@ __device__ __forceinline__ void run_batch(const WaveCtx &c, int nent, int &ncand
             const unsigned long long m = __ballot(has);
             const int t = has ? __ffs(passbits) - 1 : 0;
             passbits &= passbits - 1;
-            const int pos = ncand + __popcll(m & ((1ull << lane) - 1ull));
-            const unsigned cand = ((unsigned)ll << 16) | (unsigned)(g * GRP + t);
+            const int pos = c.ncand + lane_rank(m);
+            const unsigned cand = ((unsigned)ll << 16) | (unsigned)(c.pos0 + h * 8 + t);
             if (has) {
                 if (pos < WCCAP) c.cands[pos] = cand;
                 else resolve_candidate(c, cand);
             }
-            ncand += __popcll(m);
+            c.ncand += __popcll(m);
         }
-        if (ncand > WCCAP - 64) {  // uniform: keep room for the next pass
-            wave_lds_fence();
-            const int nc = min(ncand, WCCAP);
-            for (int i = lane; i < nc; i += 64) resolve_candidate(c, c.cands[i]);
-            ncand = 0;
+        if (c.ncand > WCCAP - 64) flush_cands(c);  // uniform: keep room for the next pass
+    }
+}
+
+// level C: pops (line, group) pairs and tests the group's two half spheres
+__device__ __forceinline__ void proc_b(WaveCtx &c, bool all) {
+    while (c.nb >= 64 || (all && c.nb > 0)) {
+        if (c.nc > QC_CAP - 128) proc_c(c, false);
+        const int take = min(c.nb, 64), base = c.nb - take;
+        c.nb = base;
+        wave_lds_fence();
+        bool p0 = false, p1 = false;
+        unsigned e2 = 0;
+        if (c.lane < take) {
+            const unsigned e = c.qb[base + c.lane];
+            const int ll = e >> 5, g = e & 31;
+            const float4 la = c.la[ll];
+            const float2 lb = c.lb[ll];
+            const float4 *nd = c.nodes + (g >> 2) * NODE + 5 + 2 * (g & 3);
+            p0 = sphere_pass(nd[0], la, lb);
+            p1 = sphere_pass(nd[1], la, lb);
+            e2 = ((unsigned)ll << 6) | (unsigned)(2 * g);
+        }
+        const unsigned long long m0 = __ballot(p0), m1 = __ballot(p1);
+        const int c0 = __popcll(m0);
+        if (p0) c.qc[c.nc + lane_rank(m0)] = (unsigned short)e2;
+        if (p1) c.qc[c.nc + c0 + lane_rank(m1)] = (unsigned short)(e2 | 1u);
+        c.nc += c0 + __popcll(m1);
+    }
+}
+
+// level B: pops (line, supergroup) pairs and tests the supergroup's four group spheres
+__device__ __forceinline__ void proc_a(WaveCtx &c, bool all) {
+    while (c.na >= 64 || (all && c.na > 0)) {
+        if (c.nb > QB_CAP - 256) proc_b(c, false);
+        const int take = min(c.na, 64), base = c.na - take;
+        c.na = base;
+        wave_lds_fence();
+        bool p[SGG] = {false, false, false, false};
+        unsigned e2 = 0;
+        if (c.lane < take) {
+            const unsigned e = c.qa[base + c.lane];
+            const int ll = e >> 3, sg = e & 7;
+            const float4 la = c.la[ll];
+            const float2 lb = c.lb[ll];
+            const float4 *nd = c.nodes + sg * NODE + 1;
+#pragma unroll
+            for (int k = 0; k < SGG; ++k) p[k] = sphere_pass(nd[k], la, lb);
+            e2 = ((unsigned)ll << 5) | (unsigned)(SGG * sg);
+        }
+#pragma unroll
+        for (int k = 0; k < SGG; ++k) {
+            const unsigned long long m = __ballot(p[k]);
+            if (p[k]) c.qb[c.nb + lane_rank(m)] = (unsigned short)(e2 | (unsigned)k);
+            c.nb += __popcll(m);
         }
     }
 }
 
-// LPB lines per workgroup (two per lane: packed fp32 in phase 1, and the wave-uniform work of the
-// group loop -- scalar loads, ballots, batch bookkeeping -- is shared by 128 lines).  The four
-// wavefronts hold the SAME lines and split the GROUP range between them, which quadruples the
-// number of independent (latency-bound) wavefronts; each has private LDS queues, so there is no
-// workgroup synchronisation at all.
-#define LPB 128
-
 __global__ __launch_bounds__(64 * WPB) void cull_scan_kernel(
     const float *__restrict__ ptri1, const float *__restrict__ ptri2, const float4 *__restrict__ p0s1,
     const float4 *__restrict__ p0s2, const int32_t *__restrict__ idx1, const int32_t *__restrict__ idx2,
-    const float4 *__restrict__ grp1, const float4 *__restrict__ grp2, const float *__restrict__ line,
+    const float4 *__restrict__ tree1, const float4 *__restrict__ tree2, const float *__restrict__ line,
     int32_t *__restrict__ count1, int32_t *__restrict__ hit1, int32_t *__restrict__ count2,
     int32_t *__restrict__ hit2, int32_t *__restrict__ status, const uint32_t *__restrict__ pmax, int B,
-    int N, int M, int L) {
-    __shared__ __attribute__((aligned(16))) float4 lines_lds[LPB][2];      // 4 KiB, same in all 4 waves
-    __shared__ __attribute__((aligned(16))) float4 rows_lds[WPB][BGRP * ROWS];  // 17 KiB
-    __shared__ unsigned cands_lds[WPB][WCCAP];                             // 4 KiB
-    __shared__ unsigned short ent_lds[WPB][LPB];
-    __shared__ int bgrp_lds[WPB][BGRP];
+    int N, int M, int L, int spw) {
+    __shared__ __attribute__((aligned(16))) float4 la_lds[WPB][LPW];          // 16 KiB
+    __shared__ __attribute__((aligned(16))) float2 lb_lds[WPB][LPW];          //  8 KiB
+    __shared__ __attribute__((aligned(16))) float4 rec_lds[SPW * SGG * ROWS]; //  8.5 KiB
+    __shared__ __attribute__((aligned(16))) float4 node_lds[SPW * NODE];      //  1.6 KiB
+    __shared__ unsigned short qa_lds[WPB][QA_CAP], qb_lds[WPB][QB_CAP], qc_lds[WPB][QC_CAP];
+    __shared__ unsigned cands_lds[WPB][WCCAP];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform for the compiler
     // XCD-aware mapping: workgroups go to the 8 XCDs round-robin by linear id, and x is the fast
     // index -- with (cloud, sample) on x, all workgroups of one cloud land on the same XCD (when
     // 2B is a multiple of 8), so each XCD's L2 holds 1/8 of the records instead of a copy of all
     const int z = blockIdx.x, cloud = z >= B ? 1 : 0, b = z - cloud * B;
-    const int lblk = blockIdx.y;
     const int n = cloud ? M : N;
-    const int ng = (n + GRP - 1) / GRP;
-    const float4 *grp = (cloud ? grp2 : grp1) + (size_t)b * ng;
-    const float *ln = line + (size_t)b * L * 6;
+    const int nsg = (n + SGT - 1) / SGT;
+    const int sg0 = (int)blockIdx.z * spw;
+    if (sg0 >= nsg) return;  // uniform: the smaller cloud has fewer slices
+    const int nsl = min(spw, nsg - sg0);
+    const float4 *p0s = (cloud ? p0s2 : p0s1) + (size_t)b * nsg * SGT;
+    const float4 *tree = (cloud ? tree2 : tree1) + (size_t)b * nsg * NODE;
 
-    const int l0 = lblk * LPB + lane, l1 = l0 + 64;
+    // ---- stage the slice: records (padded rows) and tree nodes
+    for (int i = tid; i < nsl * SGT; i += blockDim.x) rec_lds[(i >> 4) * ROWS + (i & 15)] = p0s[(size_t)sg0 * SGT + i];
+    for (int i = tid; i < nsl * NODE; i += blockDim.x) node_lds[i] = tree[(size_t)sg0 * NODE + i];
+
+    // ---- this wave's lines
+    const float *ln = line + (size_t)b * L * 6;
+    const int lw0 = ((int)blockIdx.y * (int)(blockDim.x >> 6) + wave) * LPW;
+    const int l0 = lw0 + lane, l1 = l0 + 64;
     const bool live0 = l0 < L, live1 = l1 < L;
     float v0[6], v1[6];
 #pragma unroll
@@ -673,27 +735,29 @@ __global__ __launch_bounds__(64 * WPB) void cull_scan_kernel(
         v0[c] = live0 ? ln[6 * (size_t)l0 + c] : 0.0f;
         v1[c] = live1 ? ln[6 * (size_t)l1 + c] : 0.0f;
     }
-    // every wavefront stores the same lines: identical values, so no barrier is needed
-    lines_lds[lane][0] = make_float4(v0[0], v0[1], v0[2], v0[3]);
-    lines_lds[lane][1] = make_float4(v0[4], v0[5], 0.0f, 0.0f);
-    lines_lds[64 + lane][0] = make_float4(v1[0], v1[1], v1[2], v1[3]);
-    lines_lds[64 + lane][1] = make_float4(v1[4], v1[5], 0.0f, 0.0f);
+    la_lds[wave][lane] = make_float4(v0[0], v0[1], v0[2], v0[3]);
+    lb_lds[wave][lane] = make_float2(v0[4], v0[5]);
+    la_lds[wave][64 + lane] = make_float4(v1[0], v1[1], v1[2], v1[3]);
+    lb_lds[wave][64 + lane] = make_float2(v1[4], v1[5]);
+    __syncthreads();
+    if (lw0 >= L) return;  // wave without lines (after the only barrier)
+
+    const int32_t *idx = (cloud ? idx2 : idx1) + (size_t)b * nsg * SGT;
+    const float *ptri = (cloud ? ptri2 : ptri1) + (size_t)b * n * PTRI_STRIDE;
+    int32_t *cnt = (cloud ? count2 : count1) + (size_t)b * L;
+    int32_t *hit = (cloud ? hit2 : hit1) + (size_t)b * L * RRL_MAX_HITS;
 
     // Culling (and the lazy evaluation of points 1, 2) is only exact for lines that satisfy the
-    // NaN-impossibility bound.  All four wavefronts hold the same lines, so the vote is wave-local
-    // and uniform over the workgroup: a block with an offending line evaluates ALL its
-    // (line, triangle) pairs strictly instead -- the reference's semantics, NaN included.
+    // NaN-impossibility bound.  A wavefront with an offending line evaluates ALL pairs of its
+    // lines with the slice's triangles strictly instead -- the reference's semantics, NaN included.
     const float pm = __uint_as_float(pmax[cloud * B + b]);
     if (!__all(rrl_line_safe(v0, pm) && rrl_line_safe(v1, pm))) {
-        kptr tp = (kptr)(uintptr_t)((cloud ? ptri2 : ptri1) + (size_t)b * n * PTRI_STRIDE);
-        int32_t *cnt = (cloud ? count2 : count1) + (size_t)b * L;
-        int32_t *hit = (cloud ? hit2 : hit1) + (size_t)b * L * RRL_MAX_HITS;
-        // this workgroup's slice of the triangles (gridDim.z slices), split over its wavefronts
-        const int nsl = WPB * (int)gridDim.z, sl = (int)blockIdx.z * WPB + wave;
-        const int tq = (n + nsl - 1) / nsl, t0 = min(n, sl * tq), t1 = min(n, t0 + tq);
+        kptr tp0 = (kptr)(uintptr_t)ptri;
+        kiptr ik = (kiptr)(uintptr_t)idx;
+        const int s0 = sg0 * SGT, s1 = min(n, s0 + nsl * SGT);  // real records sit at sorted positions [0, n)
         uint32_t nanacc = 0;
-        tp += (size_t)t0 * PTRI_STRIDE;
-        for (int t = t0; t < t1; ++t, tp += PTRI_STRIDE) {
+        for (int sp = s0; sp < s1; ++sp) {
+            kptr tp = tp0 + (size_t)ik[sp] * PTRI_STRIDE;
             const uint32_t thr2 = __float_as_uint(tp[9]);
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -717,32 +781,30 @@ __global__ __launch_bounds__(64 * WPB) void cull_scan_kernel(
     }
 
     WaveCtx ctx;
-    ctx.lines = &lines_lds[0][0];
-    ctx.p0s = (cloud ? p0s2 : p0s1) + (size_t)b * ng * GRP;
-    ctx.idx = (cloud ? idx2 : idx1) + (size_t)b * ng * GRP;
-    ctx.ptri = (cloud ? ptri2 : ptri1) + (size_t)b * n * PTRI_STRIDE;
-    ctx.cnt = (cloud ? count2 : count1) + (size_t)b * L;
-    ctx.hit = (cloud ? hit2 : hit1) + (size_t)b * L * RRL_MAX_HITS;
-    ctx.lbase = lblk * LPB;
-    ctx.rows = rows_lds[wave];
-    ctx.ent = ent_lds[wave];
-    ctx.bgrp = bgrp_lds[wave];
+    ctx.la = la_lds[wave];
+    ctx.lb = lb_lds[wave];
+    ctx.recs = rec_lds;
+    ctx.nodes = node_lds;
+    ctx.qa = qa_lds[wave];
+    ctx.qb = qb_lds[wave];
+    ctx.qc = qc_lds[wave];
     ctx.cands = cands_lds[wave];
+    ctx.idx = idx;
+    ctx.ptri = ptri;
+    ctx.cnt = cnt;
+    ctx.hit = hit;
+    ctx.lbase = lw0;
+    ctx.pos0 = sg0 * SGT;
+    ctx.na = ctx.nb = ctx.nc = ctx.ncand = 0;
+    ctx.lane = lane;
 
-    // ---- phase 1: conservative sphere test of every group against the lane's two lines (packed
-    //      fp32); passing (line, group) pairs are collected by ballot/popcount into batches that
-    //      phase 2 consumes at once
+    // ---- level A: conservative sphere test of every supergroup of the slice against the lane's
+    //      two lines (packed fp32, wave-uniform sphere through the scalar cache)
     const v2f ux = {v0[0], v1[0]}, uy = {v0[1], v1[1]}, uz = {v0[2], v1[2]};
     const v2f ox = {v0[3], v1[3]}, oy = {v0[4], v1[4]}, oz = {v0[5], v1[5]};
-    int nent = 0, ngrp = 0, ncand = 0;  // wave-uniform
-    kptr gp = (kptr)(uintptr_t)grp;
-    // this workgroup's slice of the groups (gridDim.z slices: few lines against a big cloud would
-    // otherwise leave most CUs idle), split over its wavefronts
-    const int nsl = WPB * (int)gridDim.z, sl = (int)blockIdx.z * WPB + wave;
-    const int gq = (ng + nsl - 1) / nsl;
-    const int gbeg = min(ng, sl * gq), gend = min(ng, gbeg + gq);
-    for (int g = gbeg; g < gend; ++g) {
-        const float cx = gp[4 * g], cy = gp[4 * g + 1], cz = gp[4 * g + 2], R2 = gp[4 * g + 3];
+    kptr gp = (kptr)(uintptr_t)(tree + (size_t)sg0 * NODE);
+    for (int s = 0; s < nsl; ++s) {
+        const float cx = gp[4 * NODE * s], cy = gp[4 * NODE * s + 1], cz = gp[4 * NODE * s + 2], R2 = gp[4 * NODE * s + 3];
         const v2f ax = cx - ox, ay = cy - oy, az = cz - oz;
         const v2f dot = __builtin_elementwise_fma(az, uz, __builtin_elementwise_fma(ay, uy, ax * ux));
         const v2f q = __builtin_elementwise_fma(az, az, __builtin_elementwise_fma(ay, ay, ax * ax));
@@ -751,39 +813,25 @@ __global__ __launch_bounds__(64 * WPB) void cull_scan_kernel(
         const bool pass0 = live0 && d2.x <= R2, pass1 = live1 && d2.y <= R2;
         const unsigned long long m0 = __ballot(pass0), m1 = __ballot(pass1);
         if (m0 | m1) {
-            const int c0 = __popcll(m0), c = c0 + __popcll(m1);
-            if (nent + c > EB || ngrp == BGRP) {  // uniform: the batch is full
-                run_batch(ctx, nent, ncand, lane);
-                nent = ngrp = 0;
-            }
-            // every passing (line, group) pair goes straight to its slot of the batch's entry
-            // list: group-major, lines in lane order (rank among the passing lanes by mbcnt)
-            if (pass0) ctx.ent[nent + __builtin_amdgcn_mbcnt_hi((unsigned)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m0, 0u))] =
-                (unsigned short)((lane << 4) | ngrp);
-            if (pass1) ctx.ent[nent + c0 + __builtin_amdgcn_mbcnt_hi((unsigned)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m1, 0u))] =
-                (unsigned short)(((64 + lane) << 4) | ngrp);
-            if (lane == 0) ctx.bgrp[ngrp] = g;
-            // asynchronous copy of the group's 16 records into LDS row `ngrp` (lanes 0..15, 16 B
-            // each; the DMA writes wave-uniform base + lane * 16)
-            if (lane < 16)
-                __builtin_amdgcn_global_load_lds((glb_void_t *)(ctx.p0s + (size_t)g * GRP + lane),
-                                                 (lds_void_t *)(ctx.rows + ngrp * ROWS), 16, 0, 0);
-            nent += c;
-            ++ngrp;
+            if (ctx.na > QA_CAP - 128) proc_a(ctx, false);
+            const int c0 = __popcll(m0);
+            if (pass0) ctx.qa[ctx.na + lane_rank(m0)] = (unsigned short)((lane << 3) | s);
+            if (pass1) ctx.qa[ctx.na + c0 + lane_rank(m1)] = (unsigned short)(((64 + lane) << 3) | s);
+            ctx.na += c0 + __popcll(m1);
         }
     }
-    if (nent) run_batch(ctx, nent, ncand, lane);
-    wave_lds_fence();
-    const int nc = min(ncand, WCCAP);
-    for (int i = lane; i < nc; i += 64) resolve_candidate(ctx, ctx.cands[i]);
+    proc_a(ctx, true);
+    proc_b(ctx, true);
+    proc_c(ctx, true);
+    flush_cands(ctx);
 }
 
 // Launchers used by rrl_tri_prepare / rrl_line_tri_scan (rrl_scan.hip)
 int rrl_launch_tri_build(const float *tri1, const float *tri2, void *ws, const WsLayout &w, int B,
                          int N, int M, int clouds, const RrlXform *xf, hipStream_t s) {
     const int nmax = clouds == 2 && M > N ? M : N;
-    const size_t ngmax = (size_t)(nmax + GRP - 1) / GRP;
-    const size_t lds = nmax <= 4096 ? ngmax * (17 * sizeof(float4) + GRP * sizeof(int)) : 16;
+    const size_t ngpmax = (size_t)(nmax + SGT - 1) / SGT * SGG;  // groups, padded to whole supergroups
+    const size_t lds = nmax <= 4096 ? ngpmax * (17 * sizeof(float4) + GRP * sizeof(int)) : 16;
     BuildArgs a;
     a.tri1 = xf ? xf->src : tri1;
     a.tri2 = tri2;
@@ -821,7 +869,7 @@ int rrl_launch_tri_build(const float *tri1, const float *tri2, void *ws, const W
         const dim3 gt((unsigned)((nmax + 255) / 256), (unsigned)B, (unsigned)clouds);
         hipLaunchKernelGGL(big_hist_kernel, gt, dim3(256), 0, s, a, histg);
         hipLaunchKernelGGL(big_scatter_kernel, gt, dim3(256), 0, s, a, histg);
-        const dim3 gs((unsigned)(((nmax + GRP - 1) / GRP + 255) / 256), (unsigned)B, (unsigned)clouds);
+        const dim3 gs((unsigned)((ngpmax + 255) / 256), (unsigned)B, (unsigned)clouds);
         hipLaunchKernelGGL(big_sphere_kernel, gs, dim3(256), 0, s, a);
     }
     hipError_t e = hipGetLastError();
@@ -830,20 +878,25 @@ int rrl_launch_tri_build(const float *tri1, const float *tri2, void *ws, const W
 
 int rrl_launch_cull_scan(const float *line, void *ws, const WsLayout &w, int B, int N, int M, int L,
                          int clouds, hipStream_t s) {
-    // group slices: enough workgroups for ~4 per CU, at least 4 groups per wavefront
-    const int tiles = (L + LPB - 1) / LPB, nmax = clouds == 2 && M > N ? M : N;
-    const int ngmax = (nmax + GRP - 1) / GRP;
-    int gsplit = (1024 + tiles * clouds * B - 1) / (tiles * clouds * B);
-    const int cap = ngmax / (4 * WPB);
-    if (gsplit > cap) gsplit = cap;
-    if (gsplit < 1) gsplit = 1;
-    hipLaunchKernelGGL(cull_scan_kernel, dim3((unsigned)(clouds * B), (unsigned)tiles, (unsigned)gsplit), dim3(64 * WPB), 0,
+    // a workgroup = (cloud and sample, tile of <= WPB x 128 lines, slice of spw supergroups).  With
+    // few lines or small clouds: fewer wavefronts per workgroup and thinner slices, so that the
+    // launch still has ~1024 workgroups to spread over the 256 CUs
+    const int nmax = clouds == 2 && M > N ? M : N;
+    const int nsgmax = (nmax + SGT - 1) / SGT;
+    const int lw = (L + LPW - 1) / LPW;  // wavefronts' worth of lines
+    int waves = lw < WPB ? lw : WPB, spw = SPW;
+    auto wgs = [&]() { return (long)clouds * B * ((lw + waves - 1) / waves) * ((nsgmax + spw - 1) / spw); };
+    while (wgs() < 1024 && spw > 2) spw >>= 1;
+    while (wgs() < 1024 && waves > 2) waves >>= 1;
+    if (wgs() < 512 && spw > 1) spw = 1;
+    const int tiles = (lw + waves - 1) / waves, slices = (nsgmax + spw - 1) / spw;
+    hipLaunchKernelGGL(cull_scan_kernel, dim3((unsigned)(clouds * B), (unsigned)tiles, (unsigned)slices), dim3(64 * waves), 0,
                        s, w.f32(ws, RRL_WS_PTRI1), w.f32(ws, RRL_WS_PTRI2),
                        (const float4 *)w.f32(ws, RRL_WS_P0S1), (const float4 *)w.f32(ws, RRL_WS_P0S2),
                        w.i32(ws, RRL_WS_IDX1), w.i32(ws, RRL_WS_IDX2), (const float4 *)w.f32(ws, RRL_WS_GRP1),
                        (const float4 *)w.f32(ws, RRL_WS_GRP2), line, w.i32(ws, RRL_WS_COUNT1),
                        w.i32(ws, RRL_WS_HIT1), w.i32(ws, RRL_WS_COUNT2), w.i32(ws, RRL_WS_HIT2),
-                       w.i32(ws, RRL_WS_STATUS), (const uint32_t *)w.i32(ws, RRL_WS_PMAX), B, N, M, L);
+                       w.i32(ws, RRL_WS_STATUS), (const uint32_t *)w.i32(ws, RRL_WS_PMAX), B, N, M, L, spw);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }

@@ -22,12 +22,12 @@ struct WsLayout {
             4 * b * l * 4,       // HIT2
             4 * b * n * 12,      // PTRI1
             4 * b * m * 12,      // PTRI2
-            16 * b * ((n + 15) / 16) * 16,  // P0S1
-            16 * b * ((m + 15) / 16) * 16,  // P0S2
-            4 * b * ((n + 15) / 16) * 16,   // IDX1
-            4 * b * ((m + 15) / 16) * 16,   // IDX2
-            16 * b * ((n + 15) / 16),       // GRP1
-            16 * b * ((m + 15) / 16),       // GRP2
+            16 * b * ((n + 63) / 64) * 64,  // P0S1 (padded to whole supergroups of 64)
+            16 * b * ((m + 63) / 64) * 64,  // P0S2
+            4 * b * ((n + 63) / 64) * 64,   // IDX1
+            4 * b * ((m + 63) / 64) * 64,   // IDX2
+            16 * b * ((n + 63) / 64) * 13,  // GRP1 (sphere tree: 13 float4 per supergroup)
+            16 * b * ((m + 63) / 64) * 13,  // GRP2
             16 * b * ((n + 15) / 16) * 16,  // CREC1
             16 * b * ((m + 15) / 16) * 16,  // CREC2
             4 * 2 * b * 8 * (((n > m ? n : m) + 255) / 256),  // APART

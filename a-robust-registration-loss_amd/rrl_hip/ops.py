@@ -24,12 +24,12 @@ _WS_FIELDS = [
     ("hit2", torch.int32, lambda B, N, M, L, G: (B, L, 4)),
     ("ptri1", torch.float32, lambda B, N, M, L, G: (B, N, 12)),
     ("ptri2", torch.float32, lambda B, N, M, L, G: (B, M, 12)),
-    ("p0s1", torch.float32, lambda B, N, M, L, G: (B, (N + 15) // 16 * 16, 4)),
-    ("p0s2", torch.float32, lambda B, N, M, L, G: (B, (M + 15) // 16 * 16, 4)),
-    ("idx1", torch.int32, lambda B, N, M, L, G: (B, (N + 15) // 16 * 16)),
-    ("idx2", torch.int32, lambda B, N, M, L, G: (B, (M + 15) // 16 * 16)),
-    ("grp1", torch.float32, lambda B, N, M, L, G: (B, (N + 15) // 16, 4)),
-    ("grp2", torch.float32, lambda B, N, M, L, G: (B, (M + 15) // 16, 4)),
+    ("p0s1", torch.float32, lambda B, N, M, L, G: (B, (N + 63) // 64 * 64, 4)),
+    ("p0s2", torch.float32, lambda B, N, M, L, G: (B, (M + 63) // 64 * 64, 4)),
+    ("idx1", torch.int32, lambda B, N, M, L, G: (B, (N + 63) // 64 * 64)),
+    ("idx2", torch.int32, lambda B, N, M, L, G: (B, (M + 63) // 64 * 64)),
+    ("grp1", torch.float32, lambda B, N, M, L, G: (B, (N + 63) // 64, 13, 4)),  # sphere tree
+    ("grp2", torch.float32, lambda B, N, M, L, G: (B, (M + 63) // 64, 13, 4)),
     ("crec1", torch.float32, lambda B, N, M, L, G: (B, (N + 15) // 16 * 16, 4)),
     ("crec2", torch.float32, lambda B, N, M, L, G: (B, (M + 15) // 16 * 16, 4)),
     ("apart", torch.float32, lambda B, N, M, L, G: (2, B, (max(N, M) + 255) // 256, 8)),

@@ -66,12 +66,12 @@ enum {
     RRL_WS_HIT2,
     RRL_WS_PTRI1,      /* float[B][N][12] 9 coords, thr2, thr, original triangle index (int)  */
     RRL_WS_PTRI2,      /* float[B][M][12]                                                   */
-    RRL_WS_P0S1,       /* float[B][16*NG1][4] P0 + thr2 in grid-cell (Morton) order            */
-    RRL_WS_P0S2,       /*   NG = ceil(N/16) groups                                             */
-    RRL_WS_IDX1,       /* int32[B][16*NG1]  original triangle index of each sorted position     */
+    RRL_WS_P0S1,       /* float[B][64*NSG1][4] P0 + thr2 in grid-cell (Hilbert curve) order; NSG = ceil(N/64) */
+    RRL_WS_P0S2,       /*   supergroups of 64 sorted triangles; pad records have thr2 = 0 (never hit)           */
+    RRL_WS_IDX1,       /* int32[B][64*NSG1]  original triangle index of each sorted position     */
     RRL_WS_IDX2,
-    RRL_WS_GRP1,       /* float[B][NG1][4]  group sphere: centre, conservative radius^2        */
-    RRL_WS_GRP2,
+    RRL_WS_GRP1,       /* float[B][NSG1][13][4] sphere tree (centre, conservative radius^2; -1 = empty): per  */
+    RRL_WS_GRP2,       /*   supergroup [0] its own sphere, [1..4] its groups of 16, [5..12] their halves of 8   */
     RRL_WS_CREC1,      /* float[B][16*NG1][4] P0 + thr2 in original order (input of the sort)   */
     RRL_WS_CREC2,
     RRL_WS_APART,      /* float[2][B][ceil(max(N,M)/256)][8] per-workgroup AABB / max |P|^2 partials */

@@ -55,16 +55,24 @@ def test_tri_prepare_exact(L, oracle):
     thr2 = pt[:, 9]
     below = np.nextafter(thr2, np.float32(0), dtype=np.float32)
     assert np.all(np.sqrt(thr2) >= thr) and np.all(np.sqrt(below) < thr)
-    # Morton order: a permutation; group spheres contain their 16 P0s with the threshold margin
+    # cell order: a permutation; every node of the sphere tree (supergroup of 64, groups of 16,
+    # halves of 8) contains the P0s of its sorted records with the threshold margin
     n = len(pt)
     idx = st.idx1[0].cpu().numpy()[:n]
     assert sorted(idx.tolist()) == list(range(n))
-    grp = st.grp1[0].cpu().numpy()
+    tree = st.grp1[0].cpu().numpy()
+    assert tree.shape == ((n + 63) // 64, 13, 4)
     P0 = pt[idx, :3].astype(np.float64)
-    for gi in range(len(grp)):
-        sl = slice(16 * gi, min(16 * gi + 16, n))
-        d = np.linalg.norm(P0[sl] - grp[gi, :3].astype(np.float64), axis=1) + thr[idx[sl]]
-        assert np.all(d * d <= grp[gi, 3] * (1 + 1e-6))
+    for sg in range(len(tree)):
+        nodes = [(0, 64 * sg, 64)] + [(1 + k, 64 * sg + 16 * k, 16) for k in range(4)] + \
+                [(5 + k, 64 * sg + 8 * k, 8) for k in range(8)]
+        for slot, s0, cnt in nodes:
+            sl = slice(s0, min(s0 + cnt, n))
+            if sl.start >= n:
+                assert tree[sg, slot, 3] < 0  # empty node: never passes
+                continue
+            d = np.linalg.norm(P0[sl] - tree[sg, slot, :3].astype(np.float64), axis=1) + thr[idx[sl]]
+            assert np.all(d * d <= tree[sg, slot, 3] * (1 + 1e-6))
     p0s = st.p0s1[0].cpu().numpy()
     for s_ in (0, 17, n - 1):
         slot = s_
