@@ -42,6 +42,9 @@
 // d2 - 4e-6 |a_c|^2 <= R2: the slack covers the evaluation error, the |dir|^2 excess and the
 // rounding of rho and R2 with a factor > 2 to spare.  Unsafe lines are not culled at all: a
 // wavefront holding one evaluates all its (line, triangle) pairs of the slice with the strict loop.
+#include <stdio.h>
+#include <stdlib.h>
+
 #include "rrl_ws.h"
 
 #define GRP 16           // triangles per group
@@ -533,8 +536,8 @@ typedef const int __attribute__((address_space(4))) * kiptr;
 #ifndef WCCAP
 #define WCCAP 128  // parked point-0 candidates per wave
 #endif
-// queue capacities: a level only runs on full 64-entry passes until the end, so a queue holds
-// at most 63 left-over entries plus one push round (128 / 256 / 128)
+// queue capacities: a level only runs while >= 64 entries wait (until the final drain), so a
+// queue holds at most 63 left-over entries plus one push round (128 / 256 / 128)
 #define QA_CAP 192
 #define QB_CAP 320
 #define QC_CAP 192
@@ -560,7 +563,7 @@ __device__ __forceinline__ void resolve_candidate(const WaveCtx &c, unsigned can
     const int ll = cand >> 16, spos = cand & 0xffff;
     const float4 la = c.la[ll];
     const float2 lb = c.lb[ll];
-    const int f = c.idx[spos];
+    const int f = c.idx[spos];  // (staging the slice's indices in LDS measured 0.8 us slower)
     const float *q = c.ptri + PTRI_STRIDE * (size_t)f;
     const uint32_t thr2 = __float_as_uint(q[9]);
     const float x1 = dist_sq<float>(q[3], q[4], q[5], la.x, la.y, la.z, la.w, lb.x, lb.y);
@@ -592,25 +595,37 @@ __device__ __forceinline__ bool sphere_pass(const float4 nd, const float4 la, co
 }
 
 __device__ __forceinline__ void flush_cands(WaveCtx &c) {
+#ifdef CULL_NO_RESOLVE
+    c.ncand = 0;
+    return;
+#endif
     wave_lds_fence();
     const int nc = min(c.ncand, WCCAP);
     for (int i = c.lane; i < nc; i += 64) resolve_candidate(c, c.cands[i]);
     c.ncand = 0;
 }
 
-// level D: pops (line, half) pairs, one per lane, and runs the exact point-0 test on the half's
-// 8 records.  all = false: only full passes.
+// Level C below takes up to 128 queue entries at a time, TWO per lane: the two
+// dependent chains (entry -> line + node -> arithmetic -> ballot) are independent of each other,
+// which doubles the instruction-level parallelism of these latency-bound passes.
+// all = false: only while at least 64 entries wait (full lanes); all = true: drain.
+
+// level D: pops (line, half) pairs, ONE per lane (8 records = 32 registers in flight), and runs
+// the exact point-0 test on the half's 8 records
 __device__ __forceinline__ void proc_c(WaveCtx &c, bool all) {
+#ifdef CULL_STOP_C  // timing experiments only (tools/knob_sweep.sh): the level is formed but not run
+    c.nc = 0;
+    return;
+#endif
     while (c.nc >= 64 || (all && c.nc > 0)) {
         const int take = min(c.nc, 64), base = c.nc - take;
         c.nc = base;
         wave_lds_fence();
         uint32_t passbits = 0;
-        int ll = 0, h = 0;
+        unsigned lh = 0;  // line << 16 | first sorted position of the half
         if (c.lane < take) {
             const unsigned e = c.qc[base + c.lane];
-            ll = e >> 6;
-            h = e & 63;
+            const int ll = e >> 6, h = e & 63;
             const float4 la = c.la[ll];
             const float2 lb = c.lb[ll];
             const float4 *row = c.recs + (h >> 1) * ROWS + (h & 1) * 8;
@@ -620,6 +635,7 @@ __device__ __forceinline__ void proc_c(WaveCtx &c, bool all) {
                 const float x = dist_sq<float>(rec.x, rec.y, rec.z, la.x, la.y, la.z, la.w, lb.x, lb.y);
                 passbits |= (__float_as_uint(x) < __float_as_uint(rec.w) ? 1u : 0u) << t;
             }
+            lh = ((unsigned)ll << 16) | (unsigned)(c.pos0 + h * 8);
         }
         while (__any(passbits != 0)) {
             const bool has = passbits != 0;
@@ -627,7 +643,7 @@ __device__ __forceinline__ void proc_c(WaveCtx &c, bool all) {
             const int t = has ? __ffs(passbits) - 1 : 0;
             passbits &= passbits - 1;
             const int pos = c.ncand + lane_rank(m);
-            const unsigned cand = ((unsigned)ll << 16) | (unsigned)(c.pos0 + h * 8 + t);
+            const unsigned cand = lh + (unsigned)t;
             if (has) {
                 if (pos < WCCAP) c.cands[pos] = cand;
                 else resolve_candidate(c, cand);
@@ -640,35 +656,52 @@ __device__ __forceinline__ void proc_c(WaveCtx &c, bool all) {
 
 // level C: pops (line, group) pairs and tests the group's two half spheres
 __device__ __forceinline__ void proc_b(WaveCtx &c, bool all) {
+#ifdef CULL_STOP_B
+    c.nb = 0;
+    return;
+#endif
     while (c.nb >= 64 || (all && c.nb > 0)) {
-        if (c.nc > QC_CAP - 128) proc_c(c, false);
-        const int take = min(c.nb, 64), base = c.nb - take;
+        const int take = min(c.nb, 128), base = c.nb - take;
         c.nb = base;
         wave_lds_fence();
-        bool p0 = false, p1 = false;
-        unsigned e2 = 0;
-        if (c.lane < take) {
-            const unsigned e = c.qb[base + c.lane];
-            const int ll = e >> 5, g = e & 31;
-            const float4 la = c.la[ll];
-            const float2 lb = c.lb[ll];
-            const float4 *nd = c.nodes + (g >> 2) * NODE + 5 + 2 * (g & 3);
-            p0 = sphere_pass(nd[0], la, lb);
-            p1 = sphere_pass(nd[1], la, lb);
-            e2 = ((unsigned)ll << 6) | (unsigned)(2 * g);
+        bool p[2][2] = {{false, false}, {false, false}};
+        unsigned e2[2] = {0, 0};
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (u == 1 && take <= 64) break;  // uniform
+            if (c.lane + 64 * u < take) {
+                const unsigned e = c.qb[base + 64 * u + c.lane];
+                const int ll = e >> 5, g = e & 31;
+                const float4 la = c.la[ll];
+                const float2 lb = c.lb[ll];
+                const float4 *nd = c.nodes + (g >> 2) * NODE + 5 + 2 * (g & 3);
+                p[u][0] = sphere_pass(nd[0], la, lb);
+                p[u][1] = sphere_pass(nd[1], la, lb);
+                e2[u] = ((unsigned)ll << 6) | (unsigned)(2 * g);
+            }
         }
-        const unsigned long long m0 = __ballot(p0), m1 = __ballot(p1);
-        const int c0 = __popcll(m0);
-        if (p0) c.qc[c.nc + lane_rank(m0)] = (unsigned short)e2;
-        if (p1) c.qc[c.nc + c0 + lane_rank(m1)] = (unsigned short)(e2 | 1u);
-        c.nc += c0 + __popcll(m1);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (u == 1 && take <= 64) break;
+            if (c.nc > QC_CAP - 128) proc_c(c, false);  // room for <= 128 entries on top of < 64 left-overs
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const unsigned long long m = __ballot(p[u][k]);
+                if (p[u][k]) c.qc[c.nc + lane_rank(m)] = (unsigned short)(e2[u] | (unsigned)k);
+                c.nc += __popcll(m);
+            }
+        }
     }
 }
 
-// level B: pops (line, supergroup) pairs and tests the supergroup's four group spheres
+// level B: pops (line, supergroup) pairs, one per lane, and tests the supergroup's four group spheres
 __device__ __forceinline__ void proc_a(WaveCtx &c, bool all) {
+#ifdef CULL_STOP_A
+    c.na = 0;
+    return;
+#endif
     while (c.na >= 64 || (all && c.na > 0)) {
-        if (c.nb > QB_CAP - 256) proc_b(c, false);
+        if (c.nb > QB_CAP - 256) proc_b(c, false);  // room for <= 256 entries on top of < 64 left-overs
         const int take = min(c.na, 64), base = c.na - take;
         c.na = base;
         wave_lds_fence();
@@ -741,6 +774,9 @@ __global__ __launch_bounds__(64 * WPB) void cull_scan_kernel(
     lb_lds[wave][64 + lane] = make_float2(v1[4], v1[5]);
     __syncthreads();
     if (lw0 >= L) return;  // wave without lines (after the only barrier)
+#ifdef CULL_STOP_STAGE
+    return;
+#endif
 
     const int32_t *idx = (cloud ? idx2 : idx1) + (size_t)b * nsg * SGT;
     const float *ptri = (cloud ? ptri2 : ptri1) + (size_t)b * n * PTRI_STRIDE;
@@ -879,16 +915,20 @@ int rrl_launch_tri_build(const float *tri1, const float *tri2, void *ws, const W
 int rrl_launch_cull_scan(const float *line, void *ws, const WsLayout &w, int B, int N, int M, int L,
                          int clouds, hipStream_t s) {
     // a workgroup = (cloud and sample, tile of <= WPB x 128 lines, slice of spw supergroups).  With
-    // few lines or small clouds: fewer wavefronts per workgroup and thinner slices, so that the
-    // launch still has ~1024 workgroups to spread over the 256 CUs
+    // few lines or small clouds the slices get thinner, so that the launch still has ~1000
+    // workgroups for the 256 CUs (measured with tools/geom_sweep.sh: thinner slices cost little,
+    // fewer wavefronts per workgroup cost more -- they are only reduced as a last resort)
     const int nmax = clouds == 2 && M > N ? M : N;
     const int nsgmax = (nmax + SGT - 1) / SGT;
     const int lw = (L + LPW - 1) / LPW;  // wavefronts' worth of lines
     int waves = lw < WPB ? lw : WPB, spw = SPW;
     auto wgs = [&]() { return (long)clouds * B * ((lw + waves - 1) / waves) * ((nsgmax + spw - 1) / spw); };
-    while (wgs() < 1024 && spw > 2) spw >>= 1;
-    while (wgs() < 1024 && waves > 2) waves >>= 1;
-    if (wgs() < 512 && spw > 1) spw = 1;
+    while (wgs() < 768 && spw > 1) spw >>= 1;
+    while (wgs() < 256 && waves > 2) waves >>= 1;
+    if (const char *e = getenv("RRL_CULL_GEOM")) {  // experiments: "waves,spw"
+        int w_ = 0, s_ = 0;
+        if (sscanf(e, "%d,%d", &w_, &s_) == 2 && w_ >= 1 && w_ <= WPB && s_ >= 1 && s_ <= SPW) { waves = w_ < lw ? w_ : lw; spw = s_; }
+    }
     const int tiles = (lw + waves - 1) / waves, slices = (nsgmax + spw - 1) / spw;
     hipLaunchKernelGGL(cull_scan_kernel, dim3((unsigned)(clouds * B), (unsigned)tiles, (unsigned)slices), dim3(64 * waves), 0,
                        s, w.f32(ws, RRL_WS_PTRI1), w.f32(ws, RRL_WS_PTRI2),
