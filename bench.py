@@ -3,7 +3,7 @@
 fwd+bwd at B=8, N=M=4096 (L=10000 lines, the RPM call-site default), per GPU.
 
 One "step" = the fused training op forward + backward, six launches: triangle records (rigid
-apply of the source, thresholds, state clearing) -> cell sort + group spheres -> sphere-culled
+apply of the source, thresholds, state clearing) -> cell sort + sphere tree -> tree-culled
 line<->triangle scan of both clouds (K1) -> per-line distances (K2) -> median + Welsch reduce
 (K3+K4) -> direct backward to (dR, dT) with the 14-float shard payload (K5') -> one fused
 all-reduce of [loss sum, valid count, sum dR, sum dT] over ranks (asynchronous: it overlaps the
@@ -219,8 +219,9 @@ def main():
                 "note": "fp32 VALU-bound (no FMA allowed: label parity); peak = 157.3/2 TFLOP/s. "
                         "achieved counts the ALGORITHMIC flops of the dense formulation (18 per "
                         "(line, point) pair, SURVEY 8d); the kernel culls exactly, so frac > 1 "
-                        "means work skipped, not the VALU beaten: executed VALU issue is ~46 % busy "
-                        "(profiles/, SQ_INSTS_VALU)",
+                        "means work skipped, not the VALU beaten (a three-level sphere tree rejects all "
+                        "but ~1 % of the pairs): the executed instruction stream keeps the VALU ~35 % "
+                        "busy (1.47e7 VALU wave-instructions per launch, profiles/r01s5_pmc_summary.json)",
                 "hbm": {"achieved": alg_bytes / scan_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": alg_bytes / scan_s / 1e9 / HBM_PEAK_GBS,
                         "algorithmic_bytes": alg_bytes},
