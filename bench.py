@@ -87,8 +87,8 @@ def cpu_baseline(N, M, L, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=300)  # 80 us each: the closing fence costs ~3 us/step at 30
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=8, help="samples per GPU")
     ap.add_argument("--points", type=int, default=4096)
     ap.add_argument("--lines", type=int, default=10000)
