@@ -113,73 +113,76 @@ __device__ __forceinline__ float4 finish_sphere(float cx, float cy, float cz, fl
 #define QUAD_MIN(v) do { v = fminf(v, RRL_DPP_F(v, 0xB1)); v = fminf(v, RRL_DPP_F(v, 0x4E)); } while (0)
 #define QUAD_MAX(v) do { v = fmaxf(v, RRL_DPP_F(v, 0xB1)); v = fmaxf(v, RRL_DPP_F(v, 0x4E)); } while (0)
 
-// Tree nodes of one group: ONE lane walks the group's 16 sorted records (rec(s) -> (P0, thr2))
-// and derives the spheres of its two halves and of the group; the four lanes of an aligned quad
-// hold the four groups of a supergroup and combine their boxes with quad-permute DPP, so the
-// supergroup sphere costs no extra pass and no barrier.  ALL lanes of a quad must call (groups
-// past the end of the cloud contribute nothing).  n = number of real records.
+#define OCT_MIN(v) do { QUAD_MIN(v); v = fminf(v, RRL_DPP_F(v, 0x141)); } while (0)  // 8 aligned lanes
+#define OCT_MAX(v) do { QUAD_MAX(v); v = fmaxf(v, RRL_DPP_F(v, 0x141)); } while (0)
+
+// Tree nodes: ONE lane per half walks its 8 sorted records (rec(s) -> (P0, thr2)); the two lanes of
+// a group and the eight aligned lanes of a supergroup combine their boxes and farthest-point
+// distances with DPP (quad_perm xor 1, xor 2, row_half_mirror), so every level costs one pass
+// over the lane's own 8 records in registers and no barrier.  (One lane per GROUP, walking 16
+// records and deriving three spheres, kept only 4 wavefronts of the single-CU sort kernel busy:
+// 3.5 us of its 11.)  ALL 8 lanes of a supergroup must call (halves past the end of the cloud
+// contribute nothing).  n = number of real records.
 template <class Get>
-__device__ __forceinline__ void group_tree(Get rec, int g, int n, float4 *__restrict__ tree) {
-    const int nv = min(max(n - g * GRP, 0), GRP);
-    float px[GRP], py[GRP], pz[GRP];
-    float lo[2][3], hi[2][3], tm[2] = {0.0f, 0.0f};
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) { lo[h][c] = INFINITY; hi[h][c] = -INFINITY; }
+__device__ __forceinline__ void half_tree(Get rec, int hh, int n, float4 *__restrict__ tree) {
+    constexpr int H = GRP / 2;
+    const int nv = min(max(n - hh * H, 0), H);
+    float px[H], py[H], pz[H];
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY}, tm = 0.0f;
     // thr <= sqrtf(thr2) (1 + 2^-22): thr2 is the smallest float whose rounded root reaches thr
 #pragma unroll
-    for (int t = 0; t < GRP; ++t) {
-        const int h = t >> 3;
+    for (int t = 0; t < H; ++t) {
         if (t < nv) {
-            const float4 v = rec(g * GRP + t);
+            const float4 v = rec(hh * H + t);
             px[t] = v.x; py[t] = v.y; pz[t] = v.z;
-            lo[h][0] = fminf(lo[h][0], v.x); hi[h][0] = fmaxf(hi[h][0], v.x);
-            lo[h][1] = fminf(lo[h][1], v.y); hi[h][1] = fmaxf(hi[h][1], v.y);
-            lo[h][2] = fminf(lo[h][2], v.z); hi[h][2] = fmaxf(hi[h][2], v.z);
-            tm[h] = fmaxf(tm[h], sqrtf(v.w) * 1.000001f);
+            lo[0] = fminf(lo[0], v.x); hi[0] = fmaxf(hi[0], v.x);
+            lo[1] = fminf(lo[1], v.y); hi[1] = fmaxf(hi[1], v.y);
+            lo[2] = fminf(lo[2], v.z); hi[2] = fmaxf(hi[2], v.z);
+            tm = fmaxf(tm, sqrtf(v.w) * 1.000001f);
         } else {
             px[t] = py[t] = pz[t] = 0.0f;
         }
     }
-    auto radius2 = [&](float cx, float cy, float cz, int t0, int t1) {
+    auto radius2 = [&](float cx, float cy, float cz) {
         float d2 = 0.0f;
 #pragma unroll
-        for (int t = t0; t < t1; ++t) {
+        for (int t = 0; t < H; ++t) {
             const float ex = px[t] - cx, ey = py[t] - cy, ez = pz[t] - cz;
             const float e2 = ex * ex + ey * ey + ez * ez;
             if (t < nv) d2 = fmaxf(d2, e2);
         }
         return d2;
     };
-    float4 *node = tree + (size_t)(g / SGG) * NODE;
-    const int gi = g % SGG;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const float cx = 0.5f * lo[h][0] + 0.5f * hi[h][0], cy = 0.5f * lo[h][1] + 0.5f * hi[h][1],
-                    cz = 0.5f * lo[h][2] + 0.5f * hi[h][2];
-        node[5 + 2 * gi + h] = finish_sphere(cx, cy, cz, radius2(cx, cy, cz, 8 * h, 8 * h + 8), tm[h], nv > 8 * h);
+    float4 *node = tree + (size_t)(hh / (2 * SGG)) * NODE;
+    const int hi_ = hh % (2 * SGG);  // half within the supergroup
+    float any = nv > 0 ? 1.0f : 0.0f;
+    {   // the half itself
+        const float cx = 0.5f * lo[0] + 0.5f * hi[0], cy = 0.5f * lo[1] + 0.5f * hi[1], cz = 0.5f * lo[2] + 0.5f * hi[2];
+        node[5 + hi_] = finish_sphere(cx, cy, cz, radius2(cx, cy, cz), tm, nv > 0);
     }
-    float glo[3], ghi[3];
+    {   // the group: this lane and its xor-1 neighbour
 #pragma unroll
-    for (int c = 0; c < 3; ++c) { glo[c] = fminf(lo[0][c], lo[1][c]); ghi[c] = fmaxf(hi[0][c], hi[1][c]); }
-    float gtm = fmaxf(tm[0], tm[1]);
-    {
-        const float cx = 0.5f * glo[0] + 0.5f * ghi[0], cy = 0.5f * glo[1] + 0.5f * ghi[1],
-                    cz = 0.5f * glo[2] + 0.5f * ghi[2];
-        node[1 + gi] = finish_sphere(cx, cy, cz, radius2(cx, cy, cz, 0, GRP), gtm, nv > 0);
+        for (int c = 0; c < 3; ++c) { lo[c] = fminf(lo[c], RRL_DPP_F(lo[c], 0xB1)); hi[c] = fmaxf(hi[c], RRL_DPP_F(hi[c], 0xB1)); }
+        tm = fmaxf(tm, RRL_DPP_F(tm, 0xB1));
+        any = fmaxf(any, RRL_DPP_F(any, 0xB1));
+        const float cx = 0.5f * lo[0] + 0.5f * hi[0], cy = 0.5f * lo[1] + 0.5f * hi[1], cz = 0.5f * lo[2] + 0.5f * hi[2];
+        float d2 = nv > 0 ? radius2(cx, cy, cz) : 0.0f;
+        d2 = fmaxf(d2, RRL_DPP_F(d2, 0xB1));
+        if ((hi_ & 1) == 0) node[1 + (hi_ >> 1)] = finish_sphere(cx, cy, cz, d2, tm, any > 0.0f);
     }
-    // supergroup: box / max thr / population over the quad, then the farthest of all 64 P0s
-    float anyv = nv > 0 ? 1.0f : 0.0f;
+    {   // the supergroup: the 8 aligned lanes (pairs already combined: xor 2, then the half mirror)
 #pragma unroll
-    for (int c = 0; c < 3; ++c) { QUAD_MIN(glo[c]); QUAD_MAX(ghi[c]); }
-    QUAD_MAX(gtm);
-    QUAD_MAX(anyv);
-    const float cx = 0.5f * glo[0] + 0.5f * ghi[0], cy = 0.5f * glo[1] + 0.5f * ghi[1],
-                cz = 0.5f * glo[2] + 0.5f * ghi[2];
-    float d2 = nv > 0 ? radius2(cx, cy, cz, 0, GRP) : 0.0f;
-    QUAD_MAX(d2);
-    if (gi == 0) node[0] = finish_sphere(cx, cy, cz, d2, gtm, anyv > 0.0f);
+        for (int c = 0; c < 3; ++c) {
+            lo[c] = fminf(lo[c], RRL_DPP_F(lo[c], 0x4E)); lo[c] = fminf(lo[c], RRL_DPP_F(lo[c], 0x141));
+            hi[c] = fmaxf(hi[c], RRL_DPP_F(hi[c], 0x4E)); hi[c] = fmaxf(hi[c], RRL_DPP_F(hi[c], 0x141));
+        }
+        tm = fmaxf(tm, RRL_DPP_F(tm, 0x4E)); tm = fmaxf(tm, RRL_DPP_F(tm, 0x141));
+        any = fmaxf(any, RRL_DPP_F(any, 0x4E)); any = fmaxf(any, RRL_DPP_F(any, 0x141));
+        const float cx = 0.5f * lo[0] + 0.5f * hi[0], cy = 0.5f * lo[1] + 0.5f * hi[1], cz = 0.5f * lo[2] + 0.5f * hi[2];
+        float d2 = nv > 0 ? radius2(cx, cy, cz) : 0.0f;
+        OCT_MAX(d2);
+        if (hi_ == 0) node[0] = finish_sphere(cx, cy, cz, d2, tm, any > 0.0f);
+    }
 }
 
 #define SORT_CELLS 4096  // 16^3 grid cells in Hilbert-curve order
@@ -299,7 +302,6 @@ __global__ __launch_bounds__(1024) void tri_sort_kernel(const BuildArgs a) {
     float4 *srec = (float4 *)dyn_s;
     __shared__ unsigned hist[SORT_CELLS];
     __shared__ __attribute__((aligned(16))) unsigned short hlut[SORT_CELLS];
-    __shared__ float red[16][8];
     __shared__ unsigned wsum[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int B = a.B;
@@ -320,35 +322,34 @@ __global__ __launch_bounds__(1024) void tri_sort_kernel(const BuildArgs a) {
     for (int k = 0; k < NPT; ++k)  // issue the record loads first: they overlap the reduction
         if (tid + 1024 * k < n) rec[k] = crec[tid + 1024 * k];
     ((uint2 *)hlut)[tid] = ((const uint2 *)HILBERT_LUT.v)[tid];
+    // every row of 16 lanes reduces the <= 16 per-workgroup partials itself (DPP): no LDS round
+    // trip and no barrier for the AABB
+    float bb[7];
     {
-        const int nb = (n + REC_BLK - 1) / REC_BLK;
+        const int nb = (n + REC_BLK - 1) / REC_BLK;  // <= 16 for n <= 4096
         const float *ap = a.apart + ((size_t)cloud * B + b) * a.nblk * 8;
-        float v[7];
+        // lanes 0..15 of each wavefront load one 32-byte partial row each (two 16-byte loads: the
+        // kernel is bound by its single CU's memory pipe), reduce across the row, broadcast
+        float4 p0 = make_float4(INFINITY, INFINITY, INFINITY, -INFINITY), p1 = make_float4(-INFINITY, -INFINITY, 0.0f, 0.0f);
+        if (lane < 16 && lane < nb) { p0 = ((const float4 *)ap)[2 * lane]; p1 = ((const float4 *)ap)[2 * lane + 1]; }
+        const float v[7] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z};
 #pragma unroll
-        for (int c = 0; c < 7; ++c) v[c] = c < 3 ? INFINITY : (c < 6 ? -INFINITY : 0.0f);
-        for (int j = tid; j < nb; j += 1024)
-#pragma unroll
-            for (int c = 0; c < 7; ++c) v[c] = c < 3 ? fminf(v[c], ap[j * 8 + c]) : fmaxf(v[c], ap[j * 8 + c]);
-#pragma unroll
-        for (int c = 0; c < 7; ++c) v[c] = c < 3 ? wave_min(v[c]) : wave_max(v[c]);
-        if (lane == 0)
-#pragma unroll
-            for (int c = 0; c < 7; ++c) red[wave][c] = v[c];
+        for (int c = 0; c < 7; ++c) {
+            const float r = c < 3 ? row16_min(v[c]) : row16_max(v[c]);
+            bb[c] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(r)));
+        }
     }
     for (int i = tid; i < SORT_CELLS; i += 1024) hist[i] = 0;
     __syncthreads();
-    if (tid < 7) {
-        float r = red[0][tid];
-        for (int w = 1; w < 16; ++w) r = tid < 3 ? fminf(r, red[w][tid]) : fmaxf(r, red[w][tid]);
-        red[0][tid] = r;
-    }
-    __syncthreads();
-    if (tid == 0) a.pmax[cloud * B + b] = __float_as_uint(red[0][6]);
+#if defined(SORT_STOP) && SORT_STOP == 1  // timing experiments only
+    return;
+#endif
+    if (tid == 0) a.pmax[cloud * B + b] = __float_as_uint(bb[6]);
     float mn[3], scale[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        mn[c] = red[0][c];
-        float ext = red[0][3 + c] - mn[c];
+        mn[c] = bb[c];
+        float ext = bb[3 + c] - mn[c];
         scale[c] = ext > 0.0f && ext < 3.0e38f ? 15.999f / ext : 0.0f;
     }
     auto cell_of = [&](const float4 r) -> unsigned {
@@ -368,6 +369,9 @@ __global__ __launch_bounds__(1024) void tri_sort_kernel(const BuildArgs a) {
     for (int k = 0; k < NPT; ++k)
         if (tid + 1024 * k < n) { cell[k] = cell_of(rec[k]); atomicAdd(&hist[cell[k]], 1u); }
     __syncthreads();
+#if defined(SORT_STOP) && SORT_STOP == 2  // timing experiments only
+    return;
+#endif
     {
         unsigned h[4], tsum = 0;
 #pragma unroll
@@ -382,6 +386,9 @@ __global__ __launch_bounds__(1024) void tri_sort_kernel(const BuildArgs a) {
         for (int k = 0; k < 4; ++k) { hist[4 * tid + k] = run; run += h[k]; }
     }
     __syncthreads();
+#if defined(SORT_STOP) && SORT_STOP == 3  // timing experiments only
+    return;
+#endif
     // scatter into LDS only; the global arrays are written afterwards, in order
 #pragma unroll
     for (int k = 0; k < NPT; ++k) {
@@ -397,14 +404,19 @@ __global__ __launch_bounds__(1024) void tri_sort_kernel(const BuildArgs a) {
         sidx[s] = 0;
     }
     __syncthreads();
+#if defined(SORT_STOP) && SORT_STOP == 4  // timing experiments only
+    return;
+#endif
     for (int s = tid; s < npad; s += 1024) {  // coalesced copy-out
         p0s[s] = srec[pad(s)];
         idx[s] = sidx[s];
     }
-    // ---- sphere tree: ONE lane per group walks its 16 records (16 lanes reducing each other's
-    //      values with DPP butterflies took 5.3 us of this kernel's former 14.4 on its single CU)
-    for (int g = tid; g < ngp; g += 1024)
-        group_tree([&](int s_) { return srec[pad(s_)]; }, g, n, tree);
+#if defined(SORT_STOP) && SORT_STOP == 5
+    return;
+#endif
+    // ---- sphere tree: one lane per half of 8 records
+    for (int hh = tid; hh < 2 * ngp; hh += 1024)
+        half_tree([&](int s_) { return srec[pad(s_)]; }, hh, n, tree);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -516,10 +528,10 @@ __global__ __launch_bounds__(256) void big_sphere_kernel(const BuildArgs a) {
     const int cloud = blockIdx.z, b = blockIdx.y;
     const int n = cloud ? a.M : a.N;
     const int nsg = (n + SGT - 1) / SGT;
-    const int g = blockIdx.x * 256 + threadIdx.x;  // 256 = 64 whole quads
-    if (g >= nsg * SGG) return;
+    const int hh = blockIdx.x * 256 + threadIdx.x;  // 256 = 32 whole supergroups
+    if (hh >= nsg * 2 * SGG) return;
     const float4 *r = (cloud ? a.p0s2 : a.p0s1) + (size_t)b * nsg * SGT;
-    group_tree([&](int s_) { return r[s_]; }, g, n, (cloud ? a.grp2 : a.grp1) + (size_t)b * nsg * NODE);
+    half_tree([&](int s_) { return r[s_]; }, hh, n, (cloud ? a.grp2 : a.grp1) + (size_t)b * nsg * NODE);
 }
 
 typedef const float __attribute__((address_space(4))) * kptr;  // constant AS -> s_load
@@ -905,7 +917,7 @@ int rrl_launch_tri_build(const float *tri1, const float *tri2, void *ws, const W
         const dim3 gt((unsigned)((nmax + 255) / 256), (unsigned)B, (unsigned)clouds);
         hipLaunchKernelGGL(big_hist_kernel, gt, dim3(256), 0, s, a, histg);
         hipLaunchKernelGGL(big_scatter_kernel, gt, dim3(256), 0, s, a, histg);
-        const dim3 gs((unsigned)((ngpmax + 255) / 256), (unsigned)B, (unsigned)clouds);
+        const dim3 gs((unsigned)((2 * ngpmax + 255) / 256), (unsigned)B, (unsigned)clouds);
         hipLaunchKernelGGL(big_sphere_kernel, gs, dim3(256), 0, s, a);
     }
     hipError_t e = hipGetLastError();
