@@ -317,15 +317,21 @@ int rrl_launch_reg_bwd(const float *src, const float *R, float *g1, float *grad_
 // folds its partial result into a u64 key (dist bits << 32 | index) with atomicMin: smallest
 // distance, then smallest index == torch.min's first occurrence; order independent.
 // ---------------------------------------------------------------------------------------
-#define CH_CHUNK 1024
-
-__global__ __launch_bounds__(256) void chamfer_nn_kernel(const float *__restrict__ q,
-                                                         const float *__restrict__ tg,
-                                                         unsigned long long *__restrict__ best,
-                                                         int nq, int nt) {
-    const int b = blockIdx.z;
+// Both directions run in ONE launch (blockIdx.z = 2 b + direction) and the target chunk adapts to
+// the problem: the demo shape (B=1, 1024 x 1024) used to be 4 workgroups walking 1024 targets
+// each, 81 us per direction; with 32-target chunks it is 256 workgroups and a few microseconds.
+__global__ __launch_bounds__(256) void chamfer_nn_kernel(const float *__restrict__ x,
+                                                         const float *__restrict__ y,
+                                                         unsigned long long *__restrict__ best_x,
+                                                         unsigned long long *__restrict__ best_y,
+                                                         int N, int M, int chunk) {
+    const int b = blockIdx.z >> 1, dir = blockIdx.z & 1;
+    const float *q = dir ? y : x, *tg = dir ? x : y;
+    unsigned long long *best = dir ? best_y : best_x;
+    const int nq = dir ? M : N, nt = dir ? N : M;
     const int i = blockIdx.x * 256 + threadIdx.x;
-    const int j0 = blockIdx.y * CH_CHUNK, j1 = min(nt, j0 + CH_CHUNK);
+    const int j0 = blockIdx.y * chunk, j1 = min(nt, j0 + chunk);
+    if ((int)blockIdx.x * 256 >= nq || j0 >= nt) return;  // uniform: the grid covers the larger side
     const float *qp = q + ((size_t)b * nq + (i < nq ? i : 0)) * 3;
     const float qx = qp[0], qy = qp[1], qz = qp[2];
     kptr tp = (kptr)(uintptr_t)(tg + ((size_t)b * nt + j0) * 3);
@@ -339,7 +345,7 @@ __global__ __launch_bounds__(256) void chamfer_nn_kernel(const float *__restrict
         s = s + dz * dz;
         if (s < bd) { bd = s; bj = j; }
     }
-    if (i < nq && j0 < j1) {
+    if (i < nq) {
         unsigned long long key = ((unsigned long long)__float_as_uint(bd) << 32) | (unsigned)bj;
         atomicMin(&best[(size_t)b * nq + i], key);
     }
@@ -371,17 +377,178 @@ extern "C" int rrl_chamfer_fwd(const float *x, const float *y, uint64_t *best_x,
     int rc;
     if ((rc = rrl_fill(best_x, 0xffffffffu, sizeof(uint64_t) * (size_t)B * N, s))) return rc;
     if ((rc = rrl_fill(best_y, 0xffffffffu, sizeof(uint64_t) * (size_t)B * M, s))) return rc;
+    // target chunk: as large as still gives ~2048 workgroups (32 <= chunk <= 1024)
+    const int big = N > M ? N : M;
+    const long qblocks = (long)2 * B * ((big + 255) / 256);
+    int chunk = 1024;
+    while (chunk > 32 && qblocks * ((big + chunk - 1) / chunk) < 2048) chunk >>= 1;
     hipLaunchKernelGGL(chamfer_nn_kernel,
-                       dim3((unsigned)((N + 255) / 256), (unsigned)((M + CH_CHUNK - 1) / CH_CHUNK), (unsigned)B),
-                       dim3(256), 0, s, x, y, (unsigned long long *)best_x, N, M);
-    RRL_LAUNCH_CHECK();
-    hipLaunchKernelGGL(chamfer_nn_kernel,
-                       dim3((unsigned)((M + 255) / 256), (unsigned)((N + CH_CHUNK - 1) / CH_CHUNK), (unsigned)B),
-                       dim3(256), 0, s, y, x, (unsigned long long *)best_y, M, N);
+                       dim3((unsigned)((big + 255) / 256), (unsigned)((big + chunk - 1) / chunk), (unsigned)(2 * B)),
+                       dim3(256), 0, s, x, y, (unsigned long long *)best_x, (unsigned long long *)best_y, N, M, chunk);
     RRL_LAUNCH_CHECK();
     hipLaunchKernelGGL(chamfer_mean_kernel, dim3(1), dim3(1024), 0, s,
                        (const unsigned long long *)best_x, (const unsigned long long *)best_y, value,
                        (long)B * N, (long)B * M);
+    RRL_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// K9 pose kernels of the single-pair demo (code/loss.py:437-463 Reconstruction_point.Transform,
+// code/LieAlgebra/se3.py:83-106 exp3, sinc.py:5-17, 91-103, 120-132; torch.optim.Adam as the demo
+// uses it, test_demo_optimized_Lie_Algebra.py:35, 63-66).  The captured demo step spent ~330 of
+// its ~350 graph nodes in the exponential map, its autograd and Adam written as torch ops on 6
+// floats; here they are three launches.
+//   xi = (w, v);  t = |w|;  W = [w]x;  R = I + s1 W + s2 W^2;  V = I + s2 W + s3 W^2;  T = V v
+//   s1 = sin t / t, s2 = (1 - cos t) / t^2, s3 = (t - sin t) / t^3; the reference's Taylor
+//   polynomials in t^2 inside |t| < 0.01.
+// The backward evaluates the same formulas on dual numbers, one lane per (sample, parameter): the
+// derivative is exact for whichever branch the value takes, with no hand-derived Jacobian.
+// ---------------------------------------------------------------------------------------
+struct Dual {
+    float v, d;
+};
+__device__ __forceinline__ Dual operator+(Dual a, Dual b) { return {a.v + b.v, a.d + b.d}; }
+__device__ __forceinline__ Dual operator-(Dual a, Dual b) { return {a.v - b.v, a.d - b.d}; }
+__device__ __forceinline__ Dual operator-(Dual a) { return {-a.v, -a.d}; }
+__device__ __forceinline__ Dual operator*(Dual a, Dual b) { return {a.v * b.v, a.d * b.v + a.v * b.d}; }
+__device__ __forceinline__ Dual operator/(Dual a, Dual b) { return {a.v / b.v, (a.d * b.v - a.v * b.d) / (b.v * b.v)}; }
+__device__ __forceinline__ Dual dconst(float c) { return {c, 0.0f}; }
+__device__ __forceinline__ Dual dsqrt(Dual a) { const float r = sqrtf(a.v); return {r, a.d / (2.0f * r)}; }
+__device__ __forceinline__ Dual dsin(Dual a) { return {sinf(a.v), cosf(a.v) * a.d}; }
+__device__ __forceinline__ Dual dcos(Dual a) { return {cosf(a.v), -sinf(a.v) * a.d}; }
+
+__device__ __forceinline__ float sc_val(float a) { return a; }
+__device__ __forceinline__ float sc_val(Dual a) { return a.v; }
+__device__ __forceinline__ float mk(float, float c) { return c; }
+__device__ __forceinline__ Dual mk(Dual, float c) { return dconst(c); }
+__device__ __forceinline__ float sc_sqrt(float a) { return sqrtf(a); }
+__device__ __forceinline__ Dual sc_sqrt(Dual a) { return dsqrt(a); }
+__device__ __forceinline__ float sc_sin(float a) { return sinf(a); }
+__device__ __forceinline__ Dual sc_sin(Dual a) { return dsin(a); }
+__device__ __forceinline__ float sc_cos(float a) { return cosf(a); }
+__device__ __forceinline__ Dual sc_cos(Dual a) { return dcos(a); }
+
+// R (row-major 3x3) and T from xi; S = float (value) or Dual (value + one directional derivative)
+template <typename S>
+__device__ __forceinline__ void se3_exp3(const S *xi, S *R, S *T) {
+    const S one = mk(xi[0], 1.0f), zero = mk(xi[0], 0.0f);
+    const S a = xi[0], b = xi[1], c = xi[2];
+    const S n2 = a * a + b * b + c * c;
+    // |w| with a finite derivative at w = 0 (LieAlgebra/so3.py _angle)
+    const S t = sc_val(n2) > 0.0f ? sc_sqrt(n2) : zero;
+    const S t2 = t * t;
+    S s1, s2, s3;
+    if (fabsf(sc_val(t)) < 0.01f) {  // code/LieAlgebra/sinc.py:14, 100, 129
+        s1 = one - t2 / mk(t, 6.0f) * (one - t2 / mk(t, 20.0f) * (one - t2 / mk(t, 42.0f)));
+        s2 = mk(t, 0.5f) * (one - t2 / mk(t, 12.0f) * (one - t2 / mk(t, 30.0f) * (one - t2 / mk(t, 56.0f))));
+        s3 = (one / mk(t, 6.0f)) * (one - t2 / mk(t, 20.0f) * (one - t2 / mk(t, 42.0f) * (one - t2 / mk(t, 72.0f))));
+    } else {
+        const S sn = sc_sin(t), cs = sc_cos(t);
+        s1 = sn / t;
+        s2 = (one - cs) / (t * t);
+        s3 = (t - sn) / (t * t * t);
+    }
+    // W = [[0,-c,b],[c,0,-a],[-b,a,0]] (so3.mat), Sq = W W
+    const S W[9] = {zero, -c, b, c, zero, -a, -b, a, zero};
+    S Sq[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) Sq[3 * i + j] = W[3 * i] * W[j] + W[3 * i + 1] * W[3 + j] + W[3 * i + 2] * W[6 + j];
+    S V[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const S id = (i == 0 || i == 4 || i == 8) ? one : zero;
+        R[i] = id + s1 * W[i] + s2 * Sq[i];
+        V[i] = id + s2 * W[i] + s3 * Sq[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) T[i] = V[3 * i] * xi[3] + V[3 * i + 1] * xi[4] + V[3 * i + 2] * xi[5];
+}
+
+__global__ __launch_bounds__(64) void se3_exp_kernel(const float *__restrict__ xi, float *__restrict__ R,
+                                                     float *__restrict__ T, int B) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    float x[6], r[9], t[3];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) x[i] = xi[b * 6 + i];
+    se3_exp3<float>(x, r, t);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R[b * 9 + i] = r[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) T[b * 3 + i] = t[i];
+}
+
+__global__ __launch_bounds__(64) void se3_exp_bwd_kernel(const float *__restrict__ xi, const float *__restrict__ gR,
+                                                         const float *__restrict__ gT, float *__restrict__ gxi, int B) {
+    const int t_ = blockIdx.x * 64 + threadIdx.x;
+    const int b = t_ / 6, k = t_ % 6;
+    if (b >= B) return;
+    Dual x[6], r[9], t[3];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) x[i] = {xi[b * 6 + i], i == k ? 1.0f : 0.0f};
+    se3_exp3<Dual>(x, r, t);
+    float g = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) g += (gR ? gR[b * 9 + i] : 0.0f) * r[i].d;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) g += (gT ? gT[b * 3 + i] : 0.0f) * t[i].d;
+    gxi[b * 6 + k] = g;
+}
+
+extern "C" int rrl_se3_exp(const float *xi, float *R, float *T, int B, void *stream) {
+    if (!xi || !R || !T || B < 0) return RRL_E_ARG;
+    if (B == 0) return 0;
+    hipLaunchKernelGGL(se3_exp_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, (hipStream_t)stream, xi, R, T, B);
+    RRL_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int rrl_se3_exp_bwd(const float *xi, const float *gR, const float *gT, float *gxi, int B, void *stream) {
+    if (!xi || !gxi || B < 0) return RRL_E_ARG;
+    if (B == 0) return 0;
+    hipLaunchKernelGGL(se3_exp_bwd_kernel, dim3((unsigned)((6 * B + 63) / 64)), dim3(64), 0, (hipStream_t)stream, xi,
+                       gR, gT, gxi, B);
+    RRL_LAUNCH_CHECK();
+    return 0;
+}
+
+// torch.optim.Adam's update (no weight decay, no amsgrad) with every scalar on the device, so a
+// captured graph takes a new learning rate per replay and skips the update when gate[0] <= 0 (the
+// demo's `if loss_di is not None`, gate = the loss's bucket count).  state = [step]; one lane per
+// parameter; lane 0 advances the step AFTER all lanes of the (single) workgroup have read it.
+__global__ __launch_bounds__(256) void adam_gated_kernel(float *__restrict__ p, const float *__restrict__ g,
+                                                         float *__restrict__ m, float *__restrict__ v,
+                                                         float *__restrict__ state, const float *__restrict__ lr,
+                                                         const int32_t *__restrict__ gate, int n, float b1, float b2,
+                                                         float eps) {
+    const int i = threadIdx.x;
+    const bool ok = gate == nullptr || gate[0] > 0;
+    const float step = state[0] + (ok ? 1.0f : 0.0f);
+    __syncthreads();
+    if (ok) {
+        for (int q = i; q < n; q += 256) {
+            const float gi = g[q];
+            const float mi = m[q] * b1 + gi * (1.0f - b1);
+            const float vi = v[q] * b2 + gi * gi * (1.0f - b2);
+            m[q] = mi;
+            v[q] = vi;
+            const float bias1 = 1.0f - powf(b1, step), bias2 = 1.0f - powf(b2, step);
+            const float denom = sqrtf(vi) / sqrtf(bias2) + eps;
+            p[q] = p[q] - (lr[0] / bias1) * mi / denom;
+        }
+    }
+    if (i == 0) state[0] = step;
+}
+
+extern "C" int rrl_adam_gated(float *p, const float *g, float *m, float *v, float *state, const float *lr,
+                              const int32_t *gate, int n, float b1, float b2, float eps, void *stream) {
+    if (!p || !g || !m || !v || !state || !lr || n < 0) return RRL_E_ARG;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(adam_gated_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, p, g, m, v, state, lr, gate, n,
+                       b1, b2, eps);
     RRL_LAUNCH_CHECK();
     return 0;
 }

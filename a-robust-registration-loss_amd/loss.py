@@ -211,6 +211,8 @@ class Reconstruction_point(nn.Module):
         self.parameters_ = nn.Parameter(init)
 
     def Transform(self):
+        if self.parameters_.is_cuda:  # one launch each way instead of ~40 / ~100 torch kernels
+            return _ops.se3_exp(self.parameters_)
         return se3.exp3(self.parameters_)
 
     def forward(self, points, points_neighbors):

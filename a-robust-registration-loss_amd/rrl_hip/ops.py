@@ -383,6 +383,47 @@ def rigid_apply(x, R, t, transpose_r=False, channel_first=False):
 
 
 # ---------------------------------------------------------------------------------------
+class _Se3Exp(torch.autograd.Function):
+    """se(3) exponential map xi (B,6) -> R (B,3,3), T (B,3) as ONE launch each way
+    (code/LieAlgebra/se3.py:83-106; as torch ops it is ~40 tiny kernels forward, ~100 backward)."""
+
+    @staticmethod
+    def forward(ctx, xi):
+        x = _prep(xi, "xi").reshape(-1, 6)
+        B = x.shape[0]
+        R = torch.empty(B, 3, 3, device=x.device)
+        T = torch.empty(B, 3, device=x.device)
+        check(_lib.load().rrl_se3_exp(_p(x), _p(R), _p(T), B, _stream()), "rrl_se3_exp")
+        ctx.save_for_backward(x)
+        ctx.meta = (xi.shape, xi.device)
+        return R, T
+
+    @staticmethod
+    def backward(ctx, gR, gT):
+        (x,) = ctx.saved_tensors
+        shape, dev = ctx.meta
+        B = x.shape[0]
+        gRc = gR.contiguous() if gR is not None else None
+        gTc = gT.contiguous() if gT is not None else None
+        gxi = torch.empty(B, 6, device=x.device)
+        check(_lib.load().rrl_se3_exp_bwd(_p(x), _p(gRc), _p(gTc), _p(gxi), B, _stream()), "rrl_se3_exp_bwd")
+        return gxi.reshape(shape).to(dev)
+
+
+def se3_exp(xi):
+    """(R (B,3,3), T (B,3)) = exp3(xi) on the GPU, differentiable in xi; xi is (6,) or (B,6)."""
+    return _Se3Exp.apply(xi)
+
+
+def adam_gated(param, grad, m, v, state, lr, gate=None, betas=(0.9, 0.999), eps=1e-8):
+    """In-place torch.optim.Adam step on `param` (fp32, contiguous, GPU) with device-side scalars:
+    state (1,) = step count, lr (1,) ; skipped when gate (int32 tensor) has gate[0] <= 0."""
+    n = param.numel()
+    check(_lib.load().rrl_adam_gated(_p(param), _p(grad), _p(m), _p(v), _p(state), _p(lr), _p(gate), n,
+                                     float(betas[0]), float(betas[1]), float(eps), _stream()), "rrl_adam_gated")
+
+
+# ---------------------------------------------------------------------------------------
 class _Chamfer(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, y):

@@ -100,34 +100,26 @@ def save_checkpoint(Save_path, epoch, moved, target, model):
 
 # ------------------------------------------------------------------------------ the loop
 class _GatedAdam:
-    """torch.optim.Adam's update (betas 0.9/0.999, eps 1e-8, no weight decay) written with
-    device-side scalars so a captured graph can (a) take a new lr per replay and (b) skip the
-    whole update when the loss was empty, as the reference's `if loss_di is not None` does."""
+    """torch.optim.Adam's update (betas 0.9/0.999, eps 1e-8, no weight decay) with device-side
+    scalars so a captured graph can (a) take a new lr per replay and (b) skip the whole update
+    when the loss was empty, as the reference's `if loss_di is not None` does.  One launch
+    (rrl_adam_gated); written as torch ops it was ~25 kernels on 6 floats."""
 
     def __init__(self, param, lr):
         self.p = param
         dev = param.device
         self.m = torch.zeros_like(param)
         self.v = torch.zeros_like(param)
-        self.step = torch.zeros((), device=dev)
-        self.lr = torch.full((), lr, device=dev)
+        self.step = torch.zeros(1, device=dev)
+        self.lr = torch.full((1,), lr, device=dev)
         self.param_groups = [{'lr': lr}]
 
     def set_lr(self):
         self.lr.fill_(self.param_groups[0]['lr'])
 
-    def update(self, grad, ok):
-        b1, b2, eps = 0.9, 0.999, 1e-8
-        self.step.add_(ok.to(self.step.dtype))
-        m = self.m * b1 + grad * (1 - b1)
-        v = self.v * b2 + grad * grad * (1 - b2)
-        self.m.copy_(torch.where(ok, m, self.m))
-        self.v.copy_(torch.where(ok, v, self.v))
-        bias1 = 1 - b1 ** self.step
-        bias2 = 1 - b2 ** self.step
-        denom = self.v.sqrt() / bias2.sqrt() + eps
-        delta = (self.lr / bias1) * self.m / denom
-        self.p.data.sub_(torch.where(ok, delta, torch.zeros_like(delta)))
+    def update(self, grad, gate):
+        """gate: int32 tensor whose first element > 0 enables the step (the loss's bucket count)."""
+        _ops.adam_gated(self.p.data, grad, self.m, self.v, self.step, self.lr, gate)
 
 
 def _default_lines(radius, centers, n_sample_line, target, device, device_rng=False):
@@ -205,18 +197,24 @@ def _run_graphed(model, draw, src, src_nb, tar, tar_tri, Save_path, writer, n_ep
     row = torch.zeros(3, device=dev)
     slot = torch.zeros(1, dtype=torch.long, device=dev)  # epoch counter on the device
 
+    ones = torch.ones(1, device=dev)
+    src_pts = src.reshape(1, -1, 3).contiguous()
+    tar_pts = tar.reshape(1, -1, 3).contiguous()
+
     def step():
+        # the whole epoch in ~25 launches: sampler (rand, 2 AABBs, 2 sample kernels), exp map, the
+        # loss's 5 + 1, exp-map backward, Adam, rigid apply, Chamfer (4), trace row (4)
         if draw_in_graph:  # lines from the previous epoch's moved source, like the reference loop
             lines.copy_(draw(0, moved.reshape(-1, 3)).reshape(1, -1, 6))
         xi.grad = None
-        R, T = model.Transform()
+        R, T = _ops.se3_exp(xi)  # == model.Transform() (LieAlgebra.se3.exp3), one launch each way
         loss, info, _ = _ops.registration_loss(src_tri, R, T, tar_tri, lines, transpose_r=False)
-        loss.sum().backward()
-        ok = info[0, 0] > 0
-        opt.update(xi.grad, ok)
+        torch.autograd.backward([loss], [ones])
+        opt.update(xi.grad, info)  # skipped on the device when no bucket is populated
         with torch.no_grad():
-            moved.copy_(_ops.rigid_apply(src.reshape(1, -1, 3), R.detach(), T.detach()))
-            row[0], row[1], row[2] = loss.detach()[0], _ops.chamfer(moved, tar.reshape(1, -1, 3)), ok
+            moved.copy_(_ops.rigid_apply(src_pts, R.detach(), T.detach()))
+            cf = _ops.chamfer(moved, tar_pts)
+            row.copy_(torch.cat([loss.detach(), cf.reshape(1), info[0, :1].to(torch.float32)]))
             if draw_in_graph:  # the trace row is written inside the graph too
                 trace.index_copy_(0, slot, row[None])
                 slot.add_(1)

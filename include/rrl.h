@@ -225,6 +225,18 @@ int rrl_rigid_apply_bwd(const float *x, const float *R, const float *gy, float *
                         float *gt, float *partial, int B, int n, int transpose_r,
                         int channel_first, void *stream);
 
+/* ---- pose kernels of the single-pair demo ------------------------------------------------- */
+/* code/loss.py:437-463 (Reconstruction_point.Transform), code/LieAlgebra/se3.py:83-106 (exp3),
+ * sinc.py:5-17, 91-103, 120-132.  xi [B][6] = (w, v) -> R [B][3][3] (row-major), T [B][3].
+ * rrl_se3_exp_bwd: gxi [B][6] = d<gR, R> + d<gT, T> / dxi (gR or gT may be NULL = zero). */
+int rrl_se3_exp(const float *xi, float *R, float *T, int B, void *stream);
+int rrl_se3_exp_bwd(const float *xi, const float *gR, const float *gT, float *gxi, int B, void *stream);
+/* torch.optim.Adam's step (test_demo_optimized_Lie_Algebra.py:35, 63-66) on p [n] with device-side
+ * scalars: state[0] = step count (float), lr[0]; the update is skipped when gate != NULL and
+ * gate[0] <= 0 (the demo's `if loss_di is not None`; gate = INFO[0] of the loss). */
+int rrl_adam_gated(float *p, const float *g, float *m, float *v, float *state, const float *lr,
+                   const int32_t *gate, int n, float b1, float b2, float eps, void *stream);
+
 /* ---- Chamfer monitor (code/loss.py:38-52, 236-252) -------------------------------------- */
 /* best_x [B][N], best_y [B][M] are u64 keys (dist bits << 32 | argmin), set to all-ones by
  * the call itself.  value[0] = mean of all B*(N+M) minima. */

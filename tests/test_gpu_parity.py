@@ -528,6 +528,61 @@ def test_reconstruction_point(L):
                                atol=2e-4)
 
 
+def test_se3_exp_kernel_vs_host_lie_algebra(L):
+    """rrl_se3_exp / rrl_se3_exp_bwd against the host LieAlgebra package (itself pinned to the
+    reference by tests/golden/se3_exp_log.npz): values and the gradient of a random contraction,
+    across the Taylor boundary |w| = 0.01 and at w = 0."""
+    from LieAlgebra import se3
+    from rrl_hip import ops
+    gen = torch.Generator().manual_seed(5)
+    dirs = torch.randn(7, 3, generator=gen)
+    dirs = dirs / dirs.norm(dim=1, keepdim=True)
+    mags = torch.tensor([0.0, 1e-4, 0.0099, 0.0101, 0.5, 3.1, 1e-3]).reshape(-1, 1)
+    xi = torch.cat([dirs * mags, torch.randn(7, 3, generator=gen)], dim=1)
+    cR, cT = torch.randn(7, 3, 3, generator=gen), torch.randn(7, 3, generator=gen)
+    xh = xi.clone().requires_grad_(True)
+    Rh, Th = se3.exp3(xh)
+    ((Rh * cR).sum() + (Th * cT).sum()).backward()
+    xg = xi.clone().cuda().requires_grad_(True)
+    Rg, Tg = ops.se3_exp(xg)
+    ((Rg * cR.cuda()).sum() + (Tg * cT.cuda()).sum()).backward()
+    np.testing.assert_allclose(Rg.detach().cpu().numpy(), Rh.detach().numpy(), rtol=0, atol=3e-7)
+    np.testing.assert_allclose(Tg.detach().cpu().numpy(), Th.detach().numpy(), rtol=2e-6, atol=3e-7)
+    np.testing.assert_allclose(xg.grad.cpu().numpy(), xh.grad.numpy(), rtol=2e-5, atol=2e-6)
+    # a single twist of shape (6,), only T used (gR is None in the backward)
+    x1 = xi[4].clone().cuda().requires_grad_(True)
+    R1, T1 = ops.se3_exp(x1)
+    T1.sum().backward()
+    x1h = xi[4].clone().requires_grad_(True)
+    se3.exp3(x1h)[1].sum().backward()
+    np.testing.assert_allclose(x1.grad.cpu().numpy(), x1h.grad.numpy(), rtol=2e-5, atol=2e-6)
+
+
+def test_adam_gated_kernel_vs_torch_adam(L):
+    """rrl_adam_gated against torch.optim.Adam(lr, betas 0.9/0.999, eps 1e-8) over 30 steps with a
+    learning-rate change, skipping the steps whose gate is 0 (the demo's `loss_di is None`)."""
+    from rrl_hip import ops
+    gen = torch.Generator().manual_seed(3)
+    p0 = torch.randn(6, generator=gen)
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([ref], lr=2e-2)
+    p = p0.clone().cuda()
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    state, lr = torch.zeros(1, device="cuda"), torch.full((1,), 2e-2, device="cuda")
+    for it in range(30):
+        g = torch.randn(6, generator=gen) * (0.1 + it)
+        gate = 0 if it in (3, 4, 17) else 2
+        if it == 10:
+            opt.param_groups[0]["lr"] = 1e-2
+            lr.fill_(1e-2)
+        if gate:
+            ref.grad = g.clone()
+            opt.step()
+        ops.adam_gated(p, g.cuda(), m, v, state, lr, torch.tensor([gate, 0, 0, 0], dtype=torch.int32, device="cuda"))
+        np.testing.assert_allclose(p.cpu().numpy(), ref.detach().numpy(), rtol=2e-5, atol=2e-7)
+    assert float(state[0]) == 27.0
+
+
 @pytest.mark.parametrize("transpose_r", [False, True])
 @pytest.mark.parametrize("channel_first", [False, True])
 def test_rigid_apply_layouts(L, transpose_r, channel_first):
