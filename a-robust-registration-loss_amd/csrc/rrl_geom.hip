@@ -701,20 +701,36 @@ __constant__ int BOX_FACES[12][3] = {{2, 0, 6}, {0, 4, 6}, {5, 4, 0}, {5, 0, 1},
 
 // Does the line cross >= 1 of the 12 box triangles by the reference's sub-area test
 // (code/loss.py:265-316)?  hit = all three sub-areas > 0 and their sum <= the triangle area.
-__device__ bool box_hit(const float *bb, const float *ln) {
+// Everything that depends on the box alone -- corners, unit normal, area of each face: a cross
+// product, a correctly rounded sqrt and three divisions per face -- is computed ONCE per workgroup
+// into an LDS table by 24 lanes (same expressions, same rounding as evaluating it per candidate,
+// which made the sampler's two kernels 35 us each at 10 x 20000 candidates).
+#define FACE_FLOATS 16  // A[3] B[3] C[3] nh[3] S pad[3]
+
+__device__ __forceinline__ void face_entry(const float *bb, int f, float *o) {
+    float A[3], Bq[3], C[3];
+    corner(bb, BOX_FACES[f][0], A);
+    corner(bb, BOX_FACES[f][1], Bq);
+    corner(bb, BOX_FACES[f][2], C);
+    float e1[3] = {Bq[0] - A[0], Bq[1] - A[1], Bq[2] - A[2]};
+    float e2[3] = {C[0] - A[0], C[1] - A[1], C[2] - A[2]};
+    float nr[3];
+    cross3(e1, e2, nr);
+    float S = norm3(nr[0], nr[1], nr[2]);
+    float den = fmaxf(S, 1e-12f);  // F.normalize eps
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { o[c] = A[c]; o[3 + c] = Bq[c]; o[6 + c] = C[c]; o[9 + c] = nr[c] / den; }
+    o[12] = S;
+}
+
+// tab: [12][FACE_FLOATS] in LDS
+__device__ bool box_hit(const float *tab, const float *ln) {
     bool any = false;
     for (int f = 0; f < 12; ++f) {
-        float A[3], Bq[3], C[3];
-        corner(bb, BOX_FACES[f][0], A);
-        corner(bb, BOX_FACES[f][1], Bq);
-        corner(bb, BOX_FACES[f][2], C);
-        float e1[3] = {Bq[0] - A[0], Bq[1] - A[1], Bq[2] - A[2]};
-        float e2[3] = {C[0] - A[0], C[1] - A[1], C[2] - A[2]};
-        float nr[3];
-        cross3(e1, e2, nr);
-        float S = norm3(nr[0], nr[1], nr[2]);
-        float den = fmaxf(S, 1e-12f);  // F.normalize eps
-        float nh[3] = {nr[0] / den, nr[1] / den, nr[2] / den};
+        const float4 t0 = ((const float4 *)tab)[4 * f], t1 = ((const float4 *)tab)[4 * f + 1],
+                     t2 = ((const float4 *)tab)[4 * f + 2], t3 = ((const float4 *)tab)[4 * f + 3];
+        const float A[3] = {t0.x, t0.y, t0.z}, Bq[3] = {t0.w, t1.x, t1.y}, C[3] = {t1.z, t1.w, t2.x};
+        const float nh[3] = {t2.y, t2.z, t2.w}, S = t3.x;
         float num = nh[0] * (A[0] - ln[3]);
         num = num + nh[1] * (A[1] - ln[4]);
         num = num + nh[2] * (A[2] - ln[5]);
@@ -741,10 +757,11 @@ __device__ bool box_hit(const float *bb, const float *ln) {
 // once more than N candidates were accepted (code/loss.py:365-381): slot order == candidate
 // order, overflow truncated, unfilled rows zero.  Two wide launches reproduce that order:
 //   sample_count_kernel: one 1024-lane workgroup per (tile of 1024 candidates, round, sample)
-//     evaluates its candidates and stores how many it accepts;
+//     evaluates its candidates and stores how many it accepts and which (one ballot per wave);
 //   sample_write_kernel: every workgroup derives its base slot from the tile counts (a walk over
-//     <= rounds x tiles integers, applying the skip rule), re-evaluates its candidates and writes
-//     the accepted ones at base + rank (ballot prefix), then zero-fills its share of the tail.
+//     <= rounds x tiles integers, applying the skip rule), rebuilds the ACCEPTED candidates' lines
+//     (no box test: the ballots say which) and writes them at base + rank (ballot prefix), then
+//     zero-fills its share of the tail.
 // (A single workgroup per sample walking everything in order took 1.9 ms for 10 x 10000
 // candidates; this takes a few tens of microseconds.)
 struct SampleGeom {
@@ -767,9 +784,9 @@ __device__ __forceinline__ SampleGeom sample_geom(const float *r, const float *c
     return g;
 }
 
-// candidate i of round rd: code/loss.py:394-411; returns whether it is accepted
-__device__ __forceinline__ bool sample_candidate(const SampleGeom &g, const float *__restrict__ rands, int B,
-                                                 int n, int b, int rd, int i, float *ln) {
+// candidate i of round rd: code/loss.py:394-411
+__device__ __forceinline__ void sample_line(const SampleGeom &g, const float *__restrict__ rands, int B, int n,
+                                            int b, int rd, int i, float *ln) {
     const float pi32 = 3.14159274101257324f;  // torch.pi of code/loss.py:9
     const float *rr = rands + ((size_t)rd * 4 * B + b) * n;  // [rd][s][b][i]
     const size_t sstride = (size_t)B * n;
@@ -782,22 +799,31 @@ __device__ __forceinline__ bool sample_candidate(const SampleGeom &g, const floa
     float den = fmaxf(norm3(d[0], d[1], d[2]), 1e-12f);
 #pragma unroll
     for (int c = 0; c < 3; ++c) { ln[c] = d[c] / den; ln[3 + c] = q1[c] + g.ctr[c]; }
-    return !g.filter || (box_hit(g.bb1, ln) && box_hit(g.bb2, ln));
 }
 
 __global__ __launch_bounds__(1024) void sample_count_kernel(
     const float *__restrict__ rands, const float *__restrict__ r, const float *__restrict__ centers,
     const float *__restrict__ aabb1, const float *__restrict__ aabb2, int32_t *__restrict__ tile_cnt,
-    int B, int n, int rounds) {
+    unsigned long long *__restrict__ accept, int B, int n, int rounds) {
     __shared__ int wave_cnt[16];
+    __shared__ __attribute__((aligned(16))) float faces[2][12][FACE_FLOATS];
     const int tile = blockIdx.x, rd = blockIdx.y, b = blockIdx.z;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const SampleGeom g = sample_geom(r, centers, aabb1, aabb2, b);
+    if (g.filter && tid < 24) face_entry(tid < 12 ? g.bb1 : g.bb2, tid % 12, faces[tid / 12][tid % 12]);
+    __syncthreads();
     const int i = tile * 1024 + tid;
-    float ln[6];
-    const bool ok = i < n && sample_candidate(g, rands, B, n, b, rd, i, ln);
+    bool ok = i < n;
+    if (ok && g.filter) {
+        float ln[6];
+        sample_line(g, rands, B, n, b, rd, i, ln);
+        ok = box_hit(&faces[0][0][0], ln) && box_hit(&faces[1][0][0], ln);
+    }
     const unsigned long long mask = __ballot(ok);
-    if (lane == 0) wave_cnt[wave] = __popcll(mask);
+    if (lane == 0) {
+        wave_cnt[wave] = __popcll(mask);
+        accept[(((size_t)b * rounds + rd) * gridDim.x + tile) * 16 + wave] = mask;
+    }
     __syncthreads();
     if (tid == 0) {
         int acc = 0;
@@ -809,13 +835,17 @@ __global__ __launch_bounds__(1024) void sample_count_kernel(
 __global__ __launch_bounds__(1024) void sample_write_kernel(
     const float *__restrict__ rands, const float *__restrict__ r, const float *__restrict__ centers,
     const float *__restrict__ aabb1, const float *__restrict__ aabb2, const int32_t *__restrict__ tile_cnt,
-    float *__restrict__ lines, int32_t *__restrict__ filled, int B, int n, int rounds) {
-    __shared__ int wave_cnt[16];
+    const unsigned long long *__restrict__ accept, float *__restrict__ lines, int32_t *__restrict__ filled,
+    int B, int n, int rounds) {
     __shared__ int s_base, s_total, s_skip;
     const int tile = blockIdx.x, rd = blockIdx.y, b = blockIdx.z, ntiles = gridDim.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     extern __shared__ int s_tc[];  // this sample's tile counts [rounds][ntiles]
     for (int q = tid; q < rounds * ntiles; q += 1024) s_tc[q] = tile_cnt[(size_t)b * rounds * ntiles + q];
+    const unsigned long long *am = accept + (((size_t)b * rounds + rd) * ntiles + tile) * 16;
+    const unsigned long long mask = am[wave];
+    int woff = 0;
+    for (int w = 0; w < wave; ++w) woff += __popcll(am[w]);
     __syncthreads();
     if (tid == 0) {  // the skip rule and this workgroup's base slot from the tile counts
         int count = 0, base = 0, skip = 0;
@@ -830,18 +860,15 @@ __global__ __launch_bounds__(1024) void sample_write_kernel(
         }
         s_base = base; s_total = count; s_skip = skip;
     }
-    const SampleGeom g = sample_geom(r, centers, aabb1, aabb2, b);
-    const int i = tile * 1024 + tid;
-    float ln[6];
-    const bool ok = i < n && sample_candidate(g, rands, B, n, b, rd, i, ln);
-    const unsigned long long mask = __ballot(ok);
-    if (lane == 0) wave_cnt[wave] = __popcll(mask);
     __syncthreads();
-    int woff = 0;
-    for (int w = 0; w < wave; ++w) woff += wave_cnt[w];
+    const int i = tile * 1024 + tid;
+    const bool ok = (mask >> lane) & 1ull;
     if (ok && !s_skip) {
         const int slot = s_base + woff + __popcll(mask & ((1ull << lane) - 1ull));
         if (slot < n) {
+            const SampleGeom g = sample_geom(r, centers, aabb1, aabb2, b);
+            float ln[6];
+            sample_line(g, rands, B, n, b, rd, i, ln);
             float *dst = lines + ((size_t)b * n + slot) * 6;
 #pragma unroll
             for (int c = 0; c < 6; ++c) dst[c] = ln[c];
@@ -869,12 +896,15 @@ extern "C" int rrl_sample_lines(const float *rands, const float *r, const float 
         return rc ? rc : rrl_fill(filled, 0u, sizeof(int32_t) * (size_t)B, s);
     }
     const dim3 grid((unsigned)((n + 1023) / 1024), (unsigned)rounds, (unsigned)B);
+    // scratch: tile counts, then (8-byte aligned) one 64-bit accept ballot per wavefront
+    const size_t ntc = (size_t)B * rounds * grid.x;
+    unsigned long long *accept = (unsigned long long *)(tile_counts + ((ntc + 1) & ~(size_t)1));
     hipLaunchKernelGGL(sample_count_kernel, grid, dim3(1024), 0, s, rands, r, centers, aabb1, aabb2,
-                       tile_counts, B, n, rounds);
+                       tile_counts, accept, B, n, rounds);
     const size_t lds = sizeof(int32_t) * (size_t)rounds * grid.x;
     if (lds > 96 * 1024) return RRL_E_ARG;  // > 24576 tiles x rounds: far beyond any caller
     hipLaunchKernelGGL(sample_write_kernel, grid, dim3(1024), lds, s, rands, r, centers, aabb1, aabb2,
-                       tile_counts, lines, filled, B, n, rounds);
+                       tile_counts, accept, lines, filled, B, n, rounds);
     RRL_LAUNCH_CHECK();
     return 0;
 }
