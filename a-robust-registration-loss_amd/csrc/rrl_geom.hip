@@ -756,10 +756,10 @@ __device__ bool box_hit(const float *tab, const float *ln) {
 // The reference fills its (N, 6) buffer candidate by candidate, round by round, and skips a round
 // once more than N candidates were accepted (code/loss.py:365-381): slot order == candidate
 // order, overflow truncated, unfilled rows zero.  Two wide launches reproduce that order:
-//   sample_count_kernel: one 1024-lane workgroup per (tile of 1024 candidates, round, sample)
-//     evaluates its candidates and stores how many it accepts and which (one ballot per wave);
-//   sample_write_kernel: every workgroup derives its base slot from the tile counts (a walk over
-//     <= rounds x tiles integers, applying the skip rule), rebuilds the ACCEPTED candidates' lines
+//   sample_count_kernel: evaluates the candidates of every (tile of 1024, round, sample) and stores
+//     which are accepted (one 64-bit ballot per wavefront);
+//   sample_write_kernel: every workgroup counts the ballots per tile, derives its base slot from the
+//     tile counts (a walk over <= rounds x tiles integers, applying the skip rule), rebuilds the ACCEPTED candidates' lines
 //     (no box test: the ballots say which) and writes them at base + rank (ballot prefix), then
 //     zero-fills its share of the tail.
 // (A single workgroup per sample walking everything in order took 1.9 ms for 10 x 10000
@@ -801,18 +801,20 @@ __device__ __forceinline__ void sample_line(const SampleGeom &g, const float *__
     for (int c = 0; c < 3; ++c) { ln[c] = d[c] / den; ln[3 + c] = q1[c] + g.ctr[c]; }
 }
 
-__global__ __launch_bounds__(1024) void sample_count_kernel(
+// 256-lane workgroups, four per tile of 1024 candidates: with one 1024-lane workgroup per tile the
+// demo shape (10 rounds x 20 tiles) kept 200 of the 256 CUs busy with one long serial chain of
+// square roots and divisions each (37 us); the quarter tiles spread over all CUs.
+__global__ __launch_bounds__(256) void sample_count_kernel(
     const float *__restrict__ rands, const float *__restrict__ r, const float *__restrict__ centers,
-    const float *__restrict__ aabb1, const float *__restrict__ aabb2, int32_t *__restrict__ tile_cnt,
+    const float *__restrict__ aabb1, const float *__restrict__ aabb2,
     unsigned long long *__restrict__ accept, int B, int n, int rounds) {
-    __shared__ int wave_cnt[16];
     __shared__ __attribute__((aligned(16))) float faces[2][12][FACE_FLOATS];
-    const int tile = blockIdx.x, rd = blockIdx.y, b = blockIdx.z;
+    const int qt = blockIdx.x, rd = blockIdx.y, b = blockIdx.z;  // quarter tile
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const SampleGeom g = sample_geom(r, centers, aabb1, aabb2, b);
     if (g.filter && tid < 24) face_entry(tid < 12 ? g.bb1 : g.bb2, tid % 12, faces[tid / 12][tid % 12]);
     __syncthreads();
-    const int i = tile * 1024 + tid;
+    const int i = qt * 256 + tid;
     bool ok = i < n;
     if (ok && g.filter) {
         float ln[6];
@@ -820,28 +822,26 @@ __global__ __launch_bounds__(1024) void sample_count_kernel(
         ok = box_hit(&faces[0][0][0], ln) && box_hit(&faces[1][0][0], ln);
     }
     const unsigned long long mask = __ballot(ok);
-    if (lane == 0) {
-        wave_cnt[wave] = __popcll(mask);
-        accept[(((size_t)b * rounds + rd) * gridDim.x + tile) * 16 + wave] = mask;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        int acc = 0;
-        for (int w = 0; w < 16; ++w) acc += wave_cnt[w];
-        tile_cnt[((size_t)b * rounds + rd) * gridDim.x + tile] = acc;
-    }
+    // ballot of wave w of tile t sits at [b][rd][t][w]; 4 waves per quarter tile
+    if (lane == 0) accept[((size_t)b * rounds + rd) * (gridDim.x * 4) + qt * 4 + wave] = mask;
 }
 
 __global__ __launch_bounds__(1024) void sample_write_kernel(
     const float *__restrict__ rands, const float *__restrict__ r, const float *__restrict__ centers,
-    const float *__restrict__ aabb1, const float *__restrict__ aabb2, const int32_t *__restrict__ tile_cnt,
+    const float *__restrict__ aabb1, const float *__restrict__ aabb2,
     const unsigned long long *__restrict__ accept, float *__restrict__ lines, int32_t *__restrict__ filled,
     int B, int n, int rounds) {
     __shared__ int s_base, s_total, s_skip;
     const int tile = blockIdx.x, rd = blockIdx.y, b = blockIdx.z, ntiles = gridDim.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    extern __shared__ int s_tc[];  // this sample's tile counts [rounds][ntiles]
-    for (int q = tid; q < rounds * ntiles; q += 1024) s_tc[q] = tile_cnt[(size_t)b * rounds * ntiles + q];
+    extern __shared__ int s_tc[];  // this sample's tile counts [rounds][ntiles], from the ballots
+    for (int q = tid; q < rounds * ntiles; q += 1024) {
+        const unsigned long long *aq = accept + ((size_t)b * rounds * ntiles + q) * 16;
+        int c = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) c += __popcll(aq[w]);
+        s_tc[q] = c;
+    }
     const unsigned long long *am = accept + (((size_t)b * rounds + rd) * ntiles + tile) * 16;
     const unsigned long long mask = am[wave];
     int woff = 0;
@@ -896,15 +896,15 @@ extern "C" int rrl_sample_lines(const float *rands, const float *r, const float 
         return rc ? rc : rrl_fill(filled, 0u, sizeof(int32_t) * (size_t)B, s);
     }
     const dim3 grid((unsigned)((n + 1023) / 1024), (unsigned)rounds, (unsigned)B);
-    // scratch: tile counts, then (8-byte aligned) one 64-bit accept ballot per wavefront
-    const size_t ntc = (size_t)B * rounds * grid.x;
-    unsigned long long *accept = (unsigned long long *)(tile_counts + ((ntc + 1) & ~(size_t)1));
-    hipLaunchKernelGGL(sample_count_kernel, grid, dim3(1024), 0, s, rands, r, centers, aabb1, aabb2,
-                       tile_counts, accept, B, n, rounds);
+    // scratch: one 64-bit accept ballot per wavefront of every tile (16 per tile)
+    unsigned long long *accept = (unsigned long long *)tile_counts;
+    if (((uintptr_t)accept & 7) != 0) return RRL_E_ARG;
+    hipLaunchKernelGGL(sample_count_kernel, dim3(grid.x * 4, grid.y, grid.z), dim3(256), 0, s, rands, r, centers,
+                       aabb1, aabb2, accept, B, n, rounds);
     const size_t lds = sizeof(int32_t) * (size_t)rounds * grid.x;
     if (lds > 96 * 1024) return RRL_E_ARG;  // > 24576 tiles x rounds: far beyond any caller
     hipLaunchKernelGGL(sample_write_kernel, grid, dim3(1024), lds, s, rands, r, centers, aabb1, aabb2,
-                       tile_counts, accept, lines, filled, B, n, rounds);
+                       accept, lines, filled, B, n, rounds);
     RRL_LAUNCH_CHECK();
     return 0;
 }

@@ -492,7 +492,7 @@ def sample_lines(rands, r, centers, aabb1, aabb2):
     cc = _prep(centers, "centers").reshape(B, 3)
     lines = torch.empty(B, n, 6, device=rd.device)
     filled = torch.empty(B, dtype=torch.int32, device=rd.device)
-    scratch = torch.empty(B * max(rounds, 1) * ((n + 1023) // 1024) * 33 + 2, dtype=torch.int32, device=rd.device)
+    scratch = torch.empty(B * max(rounds, 1) * ((n + 1023) // 1024) * 32, dtype=torch.int32, device=rd.device)
     check(_lib.load().rrl_sample_lines(_p(rd), _p(rr), _p(cc), _p(aabb1), _p(aabb2), _p(lines),
                                        _p(filled), _p(scratch), B, n, rounds, _stream()), "rrl_sample_lines")
     return lines, filled

@@ -261,8 +261,8 @@ int rrl_dense_scan(const float *tri, const float *line, float *norm_d, uint8_t *
  *   rands [rounds][4][B][n] uniform [0,1) draws in the reference's stream order
  *   r [B], centers [B][3], aabb1/aabb2 [B][6] (both NULL: keep every candidate, loss.py:384-412)
  *   lines [B][n][6] (unfilled rows zeroed by the call), filled [B] = accepted (may exceed n)
- *   tile_counts: scratch, int32 [B * rounds * ceil(n/1024) * 33 + 2] (tile counts, then one 64-bit
- *     accept ballot per wavefront of every tile; 8-byte aligned base) */
+ *   tile_counts: scratch, 8-byte aligned, int32 [B * rounds * ceil(n/1024) * 32] (one 64-bit accept
+ *     ballot per wavefront of every tile of 1024 candidates) */
 int rrl_aabb(const float *v, float *aabb, int B, int n, void *stream);
 int rrl_sample_lines(const float *rands, const float *r, const float *centers, const float *aabb1,
                      const float *aabb2, float *lines, int32_t *filled, int32_t *tile_counts, int B,
