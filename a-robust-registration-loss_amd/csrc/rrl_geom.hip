@@ -396,7 +396,7 @@ extern "C" int rrl_chamfer_fwd(const float *x, const float *y, uint64_t *best_x,
 // ---------------------------------------------------------------------------------------
 // K9 pose kernels of the single-pair demo (code/loss.py:437-463 Reconstruction_point.Transform,
 // code/LieAlgebra/se3.py:83-106 exp3, sinc.py:5-17, 91-103, 120-132; torch.optim.Adam as the demo
-// uses it, test_demo_optimized_Lie_Algebra.py:35, 63-66).  The captured demo step spent ~330 of
+// uses it, test_demo_optimized_Lie_Algebra.py:42, 64-66).  The captured demo step spent ~330 of
 // its ~350 graph nodes in the exponential map, its autograd and Adam written as torch ops on 6
 // floats; here they are three launches.
 //   xi = (w, v);  t = |w|;  W = [w]x;  R = I + s1 W + s2 W^2;  V = I + s2 W + s3 W^2;  T = V v

@@ -231,7 +231,7 @@ int rrl_rigid_apply_bwd(const float *x, const float *R, const float *gy, float *
  * rrl_se3_exp_bwd: gxi [B][6] = d<gR, R> + d<gT, T> / dxi (gR or gT may be NULL = zero). */
 int rrl_se3_exp(const float *xi, float *R, float *T, int B, void *stream);
 int rrl_se3_exp_bwd(const float *xi, const float *gR, const float *gT, float *gxi, int B, void *stream);
-/* torch.optim.Adam's step (test_demo_optimized_Lie_Algebra.py:35, 63-66) on p [n] with device-side
+/* torch.optim.Adam's step (test_demo_optimized_Lie_Algebra.py:42, 64-66) on p [n] with device-side
  * scalars: state[0] = step count (float), lr[0]; the update is skipped when gate != NULL and
  * gate[0] <= 0 (the demo's `if loss_di is not None`; gate = INFO[0] of the loss). */
 int rrl_adam_gated(float *p, const float *g, float *m, float *v, float *state, const float *lr,
