@@ -819,7 +819,13 @@ __global__ __launch_bounds__(256) void sample_count_kernel(
     if (ok && g.filter) {
         float ln[6];
         sample_line(g, rands, B, n, b, rd, i, ln);
+#if defined(SAMPLE_KNOB) && SAMPLE_KNOB == 1  // timing experiments only
+        ok = ln[0] > -2.0f;
+#elif defined(SAMPLE_KNOB) && SAMPLE_KNOB == 2
+        ok = box_hit(&faces[0][0][0], ln);
+#else
         ok = box_hit(&faces[0][0][0], ln) && box_hit(&faces[1][0][0], ln);
+#endif
     }
     const unsigned long long mask = __ballot(ok);
     // ballot of wave w of tile t sits at [b][rd][t][w]; 4 waves per quarter tile
