@@ -851,8 +851,19 @@ __global__ __launch_bounds__(64 * WPB) void cull_scan_kernel(
     const v2f ux = {v0[0], v1[0]}, uy = {v0[1], v1[1]}, uz = {v0[2], v1[2]};
     const v2f ox = {v0[3], v1[3]}, oy = {v0[4], v1[4]}, oz = {v0[5], v1[5]};
     kptr gp = (kptr)(uintptr_t)(tree + (size_t)sg0 * NODE);
-    for (int s = 0; s < nsl; ++s) {
-        const float cx = gp[4 * NODE * s], cy = gp[4 * NODE * s + 1], cz = gp[4 * NODE * s + 2], R2 = gp[4 * NODE * s + 3];
+    // all SPW supergroup spheres are requested up front (one scalar-load latency instead of one per
+    // iteration: the loop body is ~25 instructions); slots past the slice re-read its last node
+    float sgs[SPW][4];
+#pragma unroll
+    for (int s = 0; s < SPW; ++s) {
+        const int sc = s < nsl ? s : nsl - 1;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) sgs[s][c] = gp[4 * NODE * sc + c];
+    }
+#pragma unroll
+    for (int s = 0; s < SPW; ++s) {
+        if (s >= nsl) break;  // uniform
+        const float cx = sgs[s][0], cy = sgs[s][1], cz = sgs[s][2], R2 = sgs[s][3];
         const v2f ax = cx - ox, ay = cy - oy, az = cz - oz;
         const v2f dot = __builtin_elementwise_fma(az, uz, __builtin_elementwise_fma(ay, uy, ax * ux));
         const v2f q = __builtin_elementwise_fma(az, az, __builtin_elementwise_fma(ay, ay, ax * ax));
