@@ -553,6 +553,30 @@ extern "C" int rrl_adam_gated(float *p, const float *g, float *m, float *v, floa
     return 0;
 }
 
+// One row of the demo's scalar log inside a captured step: table[cursor[0]] = (loss[0], value[0],
+// info[0] > 0), then cursor[0] += 1 -- as torch ops (cast, cat, index_copy_, add_) four launches.
+__global__ void log_row_kernel(const float *__restrict__ loss, const float *__restrict__ value,
+                               const int32_t *__restrict__ info, float *__restrict__ table,
+                               long long *__restrict__ cursor, long long nrows, float *__restrict__ row) {
+    if (threadIdx.x != 0) return;
+    const long long at = cursor[0];
+    const float r[3] = {loss[0], value[0], info[0] > 0 ? 1.0f : 0.0f};
+    for (int c = 0; c < 3; ++c) {
+        if (row) row[c] = r[c];
+        if (at >= 0 && at < nrows) table[at * 3 + c] = r[c];
+    }
+    cursor[0] = at + 1;
+}
+
+extern "C" int rrl_log_row(const float *loss, const float *value, const int32_t *info, float *table,
+                           long long *cursor, long long nrows, float *row, void *stream) {
+    if (!loss || !value || !info || !table || !cursor || nrows < 0) return RRL_E_ARG;
+    hipLaunchKernelGGL(log_row_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, loss, value, info, table, cursor,
+                       nrows, row);
+    RRL_LAUNCH_CHECK();
+    return 0;
+}
+
 // d mean / d x_i: every minimum contributes 2 (x_i - y_j) / (B (N + M)) to its two end points
 __global__ __launch_bounds__(256) void chamfer_bwd_kernel(const float *__restrict__ x,
                                                           const float *__restrict__ y,

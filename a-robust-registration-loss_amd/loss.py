@@ -172,21 +172,26 @@ def Random_uniform_distribution_lines_batch_efficient(r, centers, N, device='cpu
 
 
 def Random_uniform_distribution_lines_batch_efficient_resample(r, centers, N, vertices1, vertices2,
-                                                               device='cpu', *, rounds=10, device_rng=False):
+                                                               device='cpu', *, rounds=10, device_rng=False,
+                                                               out=None, box2=None):
     """`rounds` (reference: 10) rejection rounds: a candidate is kept when it crosses the AABB
     of BOTH clouds by the reference's 12-triangle sub-area test; kept candidates fill an
     (B, N, 6) buffer front to back, overflow is dropped, unfilled rows stay all-zero
-    (code/loss.py:415-432, 365-381)."""
+    (code/loss.py:415-432, 365-381).
+    Keyword-only extras for loops that call this every step: out = a (B, N, 6) fp32 GPU tensor to
+    fill in place, box2 = the (B, 6) AABB of `vertices2` from rrl_hip.ops.aabb when that cloud does
+    not move."""
     B = r.shape[0]
     rands = _uniform_rounds(B, N, rounds, _ops.require_gpu() if device_rng else None)
-    lines, _ = _sample(rands, r, centers, _ops.aabb(vertices1), _ops.aabb(vertices2))
-    return lines.to(device)
+    bb2 = box2 if box2 is not None else _ops.aabb(vertices2)
+    lines, _ = _sample(rands, r, centers, _ops.aabb(vertices1), bb2, out)
+    return lines if out is not None else lines.to(device)
 
 
-def _sample(rands, r, centers, bb1, bb2):
+def _sample(rands, r, centers, bb1, bb2, out=None):
     B = rands.shape[2]
     rr = r.reshape(B, -1)[:, 0]
-    return _ops.sample_lines(rands, rr, centers.reshape(B, 3), bb1, bb2)
+    return _ops.sample_lines(rands, rr, centers.reshape(B, 3), bb1, bb2, out)
 
 
 # ----------------------------------------------------------------- rigid transform module

@@ -38,6 +38,7 @@ _SIGS = {
     "rrl_chamfer_fwd": [_P] * 5 + [_I] * 3 + [_P],
     "rrl_chamfer_bwd": [_P] * 7 + [_I] * 3 + [_P],
     "rrl_aabb": [_P, _P, _I, _I, _P],
+    "rrl_log_row": [_P, _P, _P, _P, _P, _c.c_longlong, _P, _P],
     "rrl_se3_exp": [_P, _P, _P, _I, _P],
     "rrl_se3_exp_bwd": [_P, _P, _P, _P, _I, _P],
     "rrl_adam_gated": [_P] * 7 + [_I, _c.c_float, _c.c_float, _c.c_float, _P],

@@ -483,16 +483,39 @@ def aabb(v):
     return out
 
 
-def sample_lines(rands, r, centers, aabb1, aabb2):
-    """rands (rounds, 4, B, n) uniform draws -> lines (B, n, 6), filled (B,) int32."""
+def sample_lines(rands, r, centers, aabb1, aabb2, out=None):
+    """rands (rounds, 4, B, n) uniform draws -> lines (B, n, 6), filled (B,) int32.
+    out: a contiguous fp32 (B, n, 6) GPU tensor to write the lines into (no extra copy)."""
     rd = _prep(rands, "rands")
     rounds, four, B, n = rd.shape
     assert four == 4
     rr = _prep(r, "r").reshape(B)
     cc = _prep(centers, "centers").reshape(B, 3)
-    lines = torch.empty(B, n, 6, device=rd.device)
+    if out is None:
+        lines = torch.empty(B, n, 6, device=rd.device)
+    else:
+        if not (out.is_cuda and out.dtype == torch.float32 and out.is_contiguous() and out.numel() == B * n * 6):
+            raise ValueError("out must be a contiguous fp32 GPU tensor of B * n * 6 elements")
+        lines = out
     filled = torch.empty(B, dtype=torch.int32, device=rd.device)
     scratch = torch.empty(B * max(rounds, 1) * ((n + 1023) // 1024) * 32, dtype=torch.int32, device=rd.device)
     check(_lib.load().rrl_sample_lines(_p(rd), _p(rr), _p(cc), _p(aabb1), _p(aabb2), _p(lines),
                                        _p(filled), _p(scratch), B, n, rounds, _stream()), "rrl_sample_lines")
     return lines, filled
+
+
+def rigid_apply_into(x, R, t, out, transpose_r=False):
+    """out[...] = x R + t (or x R^T + t) without autograd and without a temporary: x, out contiguous
+    fp32 (B, n, 3) on the GPU."""
+    Rm, tv = _prep(R, "R").reshape(-1, 3, 3), _prep(t, "t").reshape(-1, 3)
+    B = Rm.shape[0]
+    n = x.numel() // (3 * B)
+    check(_lib.load().rrl_rigid_apply_fwd(_p(x), _p(Rm), _p(tv), _p(out), B, n, int(transpose_r), 0, _stream()),
+          "rrl_rigid_apply_fwd")
+    return out
+
+
+def log_row(loss, value, info, table, cursor, row=None):
+    """table[cursor[0]] = (loss[0], value[0], info[0] > 0); cursor[0] += 1 -- one launch, on the device."""
+    check(_lib.load().rrl_log_row(_p(loss), _p(value), _p(info), _p(table), _p(cursor), table.shape[0], _p(row),
+                                  _stream()), "rrl_log_row")

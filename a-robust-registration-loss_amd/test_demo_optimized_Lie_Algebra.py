@@ -123,10 +123,15 @@ class _GatedAdam:
 
 
 def _default_lines(radius, centers, n_sample_line, target, device, device_rng=False):
-    def draw(epoch, moved):
-        return Random_uniform_distribution_lines_batch_efficient_resample(
+    box2 = []  # the target does not move: its AABB is computed once
+
+    def draw(epoch, moved, out=None):
+        if not box2:
+            box2.append(_ops.aabb(target.view(1, -1, 3)))
+        lines = Random_uniform_distribution_lines_batch_efficient_resample(
             radius.reshape(1, 1), centers.reshape(1, -1), n_sample_line, moved.view(1, -1, 3),
-            target.view(1, -1, 3), device, device_rng=device_rng).detach().view(-1, 6)
+            target.view(1, -1, 3), device, device_rng=device_rng, out=out, box2=box2[0])
+        return lines.detach().view(-1, 6)
     return draw
 
 
@@ -196,28 +201,27 @@ def _run_graphed(model, draw, src, src_nb, tar, tar_tri, Save_path, writer, n_ep
     trace = torch.zeros(n_epoch + WARM, 3, device=dev)  # loss, chamfer, valid per epoch (+ warm-up scratch rows)
     row = torch.zeros(3, device=dev)
     slot = torch.zeros(1, dtype=torch.long, device=dev)  # epoch counter on the device
+    scratch_row = torch.zeros(1, 3, device=dev)  # log_row's table when the host keeps the trace
 
     ones = torch.ones(1, device=dev)
     src_pts = src.reshape(1, -1, 3).contiguous()
     tar_pts = tar.reshape(1, -1, 3).contiguous()
 
     def step():
-        # the whole epoch in ~25 launches: sampler (rand, 2 AABBs, 2 sample kernels), exp map, the
-        # loss's 5 + 1, exp-map backward, Adam, rigid apply, Chamfer (4), trace row (4)
+        # the whole epoch in ~21 launches: sampler (rand, AABB, 2 sample kernels), exp map, the
+        # loss's 5 + 1, exp-map backward, Adam, rigid apply, Chamfer (4), log row
         if draw_in_graph:  # lines from the previous epoch's moved source, like the reference loop
-            lines.copy_(draw(0, moved.reshape(-1, 3)).reshape(1, -1, 6))
+            draw(0, moved.reshape(-1, 3), out=lines)
         xi.grad = None
         R, T = _ops.se3_exp(xi)  # == model.Transform() (LieAlgebra.se3.exp3), one launch each way
         loss, info, _ = _ops.registration_loss(src_tri, R, T, tar_tri, lines, transpose_r=False)
         torch.autograd.backward([loss], [ones])
         opt.update(xi.grad, info)  # skipped on the device when no bucket is populated
         with torch.no_grad():
-            moved.copy_(_ops.rigid_apply(src_pts, R.detach(), T.detach()))
+            _ops.rigid_apply_into(src_pts, R, T, moved)
             cf = _ops.chamfer(moved, tar_pts)
-            row.copy_(torch.cat([loss.detach(), cf.reshape(1), info[0, :1].to(torch.float32)]))
-            if draw_in_graph:  # the trace row is written inside the graph too
-                trace.index_copy_(0, slot, row[None])
-                slot.add_(1)
+            # loss, Chamfer, valid -> row (and, with the sampler in the graph, the trace table)
+            _ops.log_row(loss, cf.reshape(1), info, trace if draw_in_graph else scratch_row, slot, row)
         return row
 
     lr = 2e-2

@@ -237,6 +237,13 @@ int rrl_se3_exp_bwd(const float *xi, const float *gR, const float *gT, float *gx
 int rrl_adam_gated(float *p, const float *g, float *m, float *v, float *state, const float *lr,
                    const int32_t *gate, int n, float b1, float b2, float eps, void *stream);
 
+/* One row of the demo's per-epoch log (code/test_demo_optimized_Lie_Algebra.py:72-82 prints / logs
+ * loss and Chamfer) written on the device, so a captured step needs no host read-back:
+ * table[cursor[0]][0..2] = (loss[0], value[0], info[0] > 0 ? 1 : 0), cursor[0] += 1; rows outside
+ * [0, nrows) are dropped; row (3 floats, may be NULL) receives a copy. */
+int rrl_log_row(const float *loss, const float *value, const int32_t *info, float *table,
+                long long *cursor, long long nrows, float *row, void *stream);
+
 /* ---- Chamfer monitor (code/loss.py:38-52, 236-252) -------------------------------------- */
 /* best_x [B][N], best_y [B][M] are u64 keys (dist bits << 32 | argmin), set to all-ones by
  * the call itself.  value[0] = mean of all B*(N+M) minima. */
