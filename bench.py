@@ -200,6 +200,18 @@ def main():
         pmc_file = os.path.join(ROOT, "profiles", "scan_hbm_traffic.json")
         if os.path.exists(pmc_file):
             pmc = json.load(open(pmc_file)).get(f"B{B}_N{N}_L{L}_{args.mode}")
+        # executed (not algorithmic) VALU work of the same kernel from the SQ counters of the round
+        # profile: wave-instructions x 64 lanes against the same peak, over the live launch time
+        executed = None
+        sq_file = os.path.join(ROOT, "profiles", "r01s5_pmc_summary.json")
+        if os.path.exists(sq_file) and (B, N, L, args.mode) == (8, 4096, 10000, "cull"):
+            sq = json.load(open(sq_file)).get("sq_per_kernel", {}).get("cull_scan_kernel", {})
+            if "SQ_INSTS_VALU" in sq:
+                executed = {"valu_wave_insts": sq["SQ_INSTS_VALU"], "salu_wave_insts": sq.get("SQ_INSTS_SALU"),
+                            "lds_wave_insts": sq.get("SQ_INSTS_LDS"),
+                            "valu_lane_ops_per_s": sq["SQ_INSTS_VALU"] * 64 / scan_s,
+                            "frac_of_valu_peak": sq["SQ_INSTS_VALU"] * 64 / scan_s / (VALU_PEAK_TFLOPS * 1e12),
+                            "source": "profiles/r01s5_pmc_summary.json (rocprofv3 --pmc SQ_INSTS_*, own pass)"}
         out = {
             "metric": "point-pairs/sec for loss fwd+bwd at B=8, N=M=4096",
             "value": value, "unit": "point-pairs/s", "n_gpus": world, "steps": args.steps,
@@ -229,6 +241,7 @@ def main():
                 # passes, gfx950-corrected: profiles/scan_hbm_traffic.json), null when not collected
                 "traffic": (pmc or {}).get("bytes"),
                 "traffic_detail": pmc,
+                "executed": executed,
             },
             "extras": {"loss_sum": float(payload[0]), "valid": float(payload[1]),
                        "chamfer_ms": chamfer_ms, "chamfer_pairs_per_s": B * N * M / (chamfer_ms * 1e-3),
