@@ -2,6 +2,8 @@
 //   K6 code/loss.py:458-463 (+ the RPM/DCP/FMR layouts, see include/rrl.h)   HBM-bound
 //   K7 code/loss.py:38-52, 236-252                                           VALU-bound, N*M pairs
 //   K8 code/loss.py:265-432                                                  tiny
+#include <stdlib.h>
+
 #include "rrl_ws.h"
 
 typedef const float __attribute__((address_space(4))) * kptr;  // constant AS -> s_load
@@ -747,34 +749,58 @@ __device__ __forceinline__ void face_entry(const float *bb, int f, float *o) {
     o[12] = S;
 }
 
-// tab: [12][FACE_FLOATS] in LDS
-__device__ bool box_hit(const float *tab, const float *ln) {
-    bool any = false;
-    for (int f = 0; f < 12; ++f) {
-        const float4 t0 = ((const float4 *)tab)[4 * f], t1 = ((const float4 *)tab)[4 * f + 1],
-                     t2 = ((const float4 *)tab)[4 * f + 2], t3 = ((const float4 *)tab)[4 * f + 3];
-        const float A[3] = {t0.x, t0.y, t0.z}, Bq[3] = {t0.w, t1.x, t1.y}, C[3] = {t1.z, t1.w, t2.x};
-        const float nh[3] = {t2.y, t2.z, t2.w}, S = t3.x;
-        float num = nh[0] * (A[0] - ln[3]);
-        num = num + nh[1] * (A[1] - ln[4]);
-        num = num + nh[2] * (A[2] - ln[5]);
-        float dn = nh[0] * ln[0];
-        dn = dn + nh[1] * ln[1];
-        dn = dn + nh[2] * ln[2];
-        float tt = num / (dn + 1e-12f);
-        float I[3] = {tt * ln[0] + ln[3], tt * ln[1] + ln[4], tt * ln[2] + ln[5]};
-        float ia[3] = {I[0] - A[0], I[1] - A[1], I[2] - A[2]};
-        float ib[3] = {I[0] - Bq[0], I[1] - Bq[1], I[2] - Bq[2]};
-        float ic[3] = {I[0] - C[0], I[1] - C[1], I[2] - C[2]};
-        float c0[3], c1[3], c2[3];
-        cross3(ib, ic, c0);
-        cross3(ic, ia, c1);
-        cross3(ia, ib, c2);
-        float ba = norm3(c0[0], c0[1], c0[2]), bb2 = norm3(c1[0], c1[1], c1[2]),
-              bc = norm3(c2[0], c2[1], c2[2]);
-        any |= (ba > 0.0f) && (bb2 > 0.0f) && (bc > 0.0f) && (((ba + bb2) + bc) <= S);
+// one face: tab = its FACE_FLOATS entry in LDS
+__device__ __forceinline__ bool face_hit(const float *tab, const float *ln) {
+    const float4 t0 = ((const float4 *)tab)[0], t1 = ((const float4 *)tab)[1], t2 = ((const float4 *)tab)[2],
+                 t3 = ((const float4 *)tab)[3];
+    const float A[3] = {t0.x, t0.y, t0.z}, Bq[3] = {t0.w, t1.x, t1.y}, C[3] = {t1.z, t1.w, t2.x};
+    const float nh[3] = {t2.y, t2.z, t2.w}, S = t3.x;
+    float num = nh[0] * (A[0] - ln[3]);
+    num = num + nh[1] * (A[1] - ln[4]);
+    num = num + nh[2] * (A[2] - ln[5]);
+    float dn = nh[0] * ln[0];
+    dn = dn + nh[1] * ln[1];
+    dn = dn + nh[2] * ln[2];
+    float tt = num / (dn + 1e-12f);
+    float I[3] = {tt * ln[0] + ln[3], tt * ln[1] + ln[4], tt * ln[2] + ln[5]};
+    float ia[3] = {I[0] - A[0], I[1] - A[1], I[2] - A[2]};
+    float ib[3] = {I[0] - Bq[0], I[1] - Bq[1], I[2] - Bq[2]};
+    float ic[3] = {I[0] - C[0], I[1] - C[1], I[2] - C[2]};
+    float c0[3], c1[3], c2[3];
+    cross3(ib, ic, c0);
+    cross3(ic, ia, c1);
+    cross3(ia, ib, c2);
+    float ba = norm3(c0[0], c0[1], c0[2]), bb2 = norm3(c1[0], c1[1], c1[2]), bc = norm3(c2[0], c2[1], c2[2]);
+    return (ba > 0.0f) && (bb2 > 0.0f) && (bc > 0.0f) && (((ba + bb2) + bc) <= S);
+}
+
+// Conservative pre-test: false ONLY when the line certainly stays outside the box inflated by
+// pad_a = 1e-3 extent_a + 1e-5 max extent per axis (slab method on the infinite line).  Such a line
+// can never pass the reference's test: the point I where it meets a face's plane lies on the line
+// (to rounding), hence outside the face rectangle by >= pad along an in-plane axis, so the three
+// sub-areas exceed the triangle's area by >= 0.5 * edge * pad >= 5e-6 size^2 relative to a rounding
+// error of ~1e-7 size^2 in the cross products (far-away I: the sub-areas dwarf S outright; I from a
+// near-zero denominator is inf/NaN and fails every comparison).  With the demo's radius (the full
+// box diagonal) ~85 % of the candidates end here, for ~40 instructions instead of ~4000.
+__device__ __forceinline__ bool slab_maybe(const float *bb, const float *ln) {
+    const float ext[3] = {bb[3] - bb[0], bb[4] - bb[1], bb[5] - bb[2]};
+    const float big = fmaxf(fmaxf(ext[0], ext[1]), ext[2]);
+    if (!(big < 3.0e38f)) return true;  // non-finite box: decide by the full test
+    float tlo = -INFINITY, thi = INFINITY;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float pad = 1e-3f * ext[a] + 1e-5f * big + 1e-30f;
+        const float lo = bb[a] - pad, hi = bb[3 + a] + pad, o = ln[3 + a], u = ln[a];
+        if (fabsf(u) < 1e-12f) {
+            if (o < lo || o > hi) return false;
+        } else {
+            float t1 = (lo - o) / u, t2 = (hi - o) / u;
+            if (t1 > t2) { const float t = t1; t1 = t2; t2 = t; }
+            tlo = fmaxf(tlo, t1);
+            thi = fminf(thi, t2);
+        }
     }
-    return any;
+    return !(tlo > thi + 1e-5f * (fabsf(tlo) + fabsf(thi)));  // NaN: keep
 }
 
 // The reference fills its (N, 6) buffer candidate by candidate, round by round, and skips a round
@@ -825,35 +851,64 @@ __device__ __forceinline__ void sample_line(const SampleGeom &g, const float *__
     for (int c = 0; c < 3; ++c) { ln[c] = d[c] / den; ln[3 + c] = q1[c] + g.ctr[c]; }
 }
 
-// 256-lane workgroups, four per tile of 1024 candidates: with one 1024-lane workgroup per tile the
-// demo shape (10 rounds x 20 tiles) kept 200 of the 256 CUs busy with one long serial chain of
-// square roots and divisions each (37 us); the quarter tiles spread over all CUs.
-__global__ __launch_bounds__(256) void sample_count_kernel(
+// One 1024-lane workgroup per (tile of 1024 candidates, round, sample):
+//   1. every lane builds its candidate line and runs the conservative slab pre-test on both boxes;
+//      the survivors (~15 % at the demo's radius) are compacted into LDS;
+//   2. the exact test runs as (survivor, face) TASKS, one per lane per pass -- 24 independent faces
+//      per survivor instead of one lane walking a chain of 24 x ~165 dependent instructions (that
+//      chain made this kernel 37 us at 10 x 20000 candidates whatever the launch geometry);
+//   3. accepted = some face of box 1 AND some face of box 2 (code/loss.py:415-432); one 64-bit
+//      ballot per wavefront is stored for the write pass.
+// prefilter = 0 sends every candidate through step 2 (tests: identical ballots).
+__global__ __launch_bounds__(1024) void sample_count_kernel(
     const float *__restrict__ rands, const float *__restrict__ r, const float *__restrict__ centers,
     const float *__restrict__ aabb1, const float *__restrict__ aabb2,
-    unsigned long long *__restrict__ accept, int B, int n, int rounds) {
-    __shared__ __attribute__((aligned(16))) float faces[2][12][FACE_FLOATS];
-    const int qt = blockIdx.x, rd = blockIdx.y, b = blockIdx.z;  // quarter tile
+    unsigned long long *__restrict__ accept, int B, int n, int rounds, int prefilter) {
+    __shared__ __attribute__((aligned(16))) float faces[24][FACE_FLOATS];
+    __shared__ float lines_c[1024][6];
+    __shared__ unsigned short surv[1024];
+    __shared__ unsigned hits[1024];
+    __shared__ unsigned char flag[1024];
+    __shared__ int wave_cnt[16];
+    const int tile = blockIdx.x, rd = blockIdx.y, b = blockIdx.z;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const SampleGeom g = sample_geom(r, centers, aabb1, aabb2, b);
-    if (g.filter && tid < 24) face_entry(tid < 12 ? g.bb1 : g.bb2, tid % 12, faces[tid / 12][tid % 12]);
-    __syncthreads();
-    const int i = qt * 256 + tid;
+    const int i = tile * 1024 + tid;
     bool ok = i < n;
-    if (ok && g.filter) {
+    if (g.filter) {  // uniform
+        if (tid < 24) face_entry(tid < 12 ? g.bb1 : g.bb2, tid % 12, faces[tid]);
         float ln[6];
-        sample_line(g, rands, B, n, b, rd, i, ln);
-#if defined(SAMPLE_KNOB) && SAMPLE_KNOB == 1  // timing experiments only
-        ok = ln[0] > -2.0f;
-#elif defined(SAMPLE_KNOB) && SAMPLE_KNOB == 2
-        ok = box_hit(&faces[0][0][0], ln);
-#else
-        ok = box_hit(&faces[0][0][0], ln) && box_hit(&faces[1][0][0], ln);
-#endif
+        bool pre = false;
+        if (ok) {
+            sample_line(g, rands, B, n, b, rd, i, ln);
+            pre = !prefilter || (slab_maybe(g.bb1, ln) && slab_maybe(g.bb2, ln));
+        }
+        const unsigned long long m = __ballot(pre);
+        if (lane == 0) wave_cnt[wave] = __popcll(m);
+        hits[tid] = 0;
+        flag[tid] = 0;
+        __syncthreads();
+        int woff = 0, total = 0;
+        for (int w = 0; w < 16; ++w) { woff += w < wave ? wave_cnt[w] : 0; total += wave_cnt[w]; }
+        if (pre) {
+            const int k = woff + __popcll(m & ((1ull << lane) - 1ull));
+            surv[k] = (unsigned short)tid;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) lines_c[k][c] = ln[c];
+        }
+        __syncthreads();
+        for (int t = tid; t < total * 24; t += 1024) {
+            const int k = t / 24, f = t % 24;
+            if (face_hit(faces[f], lines_c[k])) atomicOr(&hits[k], f < 12 ? 1u : 2u);
+        }
+        __syncthreads();
+        if (tid < total && hits[tid] == 3u) flag[surv[tid]] = 1;
+        __syncthreads();
+        ok = flag[tid] != 0;
     }
     const unsigned long long mask = __ballot(ok);
-    // ballot of wave w of tile t sits at [b][rd][t][w]; 4 waves per quarter tile
-    if (lane == 0) accept[((size_t)b * rounds + rd) * (gridDim.x * 4) + qt * 4 + wave] = mask;
+    // ballot of wave w of tile t sits at [b][rd][t][w]
+    if (lane == 0) accept[(((size_t)b * rounds + rd) * gridDim.x + tile) * 16 + wave] = mask;
 }
 
 __global__ __launch_bounds__(1024) void sample_write_kernel(
@@ -929,8 +984,9 @@ extern "C" int rrl_sample_lines(const float *rands, const float *r, const float 
     // scratch: one 64-bit accept ballot per wavefront of every tile (16 per tile)
     unsigned long long *accept = (unsigned long long *)tile_counts;
     if (((uintptr_t)accept & 7) != 0) return RRL_E_ARG;
-    hipLaunchKernelGGL(sample_count_kernel, dim3(grid.x * 4, grid.y, grid.z), dim3(256), 0, s, rands, r, centers,
-                       aabb1, aabb2, accept, B, n, rounds);
+    static const int prefilter = [] { const char *e = getenv("RRL_SAMPLER_PREFILTER"); return e && e[0] == '0' ? 0 : 1; }();
+    hipLaunchKernelGGL(sample_count_kernel, grid, dim3(1024), 0, s, rands, r, centers, aabb1, aabb2, accept, B, n,
+                       rounds, prefilter);
     const size_t lds = sizeof(int32_t) * (size_t)rounds * grid.x;
     if (lds > 96 * 1024) return RRL_E_ARG;  // > 24576 tiles x rounds: far beyond any caller
     hipLaunchKernelGGL(sample_write_kernel, grid, dim3(1024), lds, s, rands, r, centers, aabb1, aabb2,

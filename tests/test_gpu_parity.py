@@ -655,6 +655,30 @@ def test_sampler(L, oracle):
     assert abs(nb - int((np.abs(g["final_big"]).sum(1) > 0).sum())) <= 15
 
 
+def test_sampler_prefilter_is_exact(tmp_path):
+    """The conservative slab pre-test of the sampler's count pass never changes the result: the
+    same lines bit-for-bit with RRL_SAMPLER_PREFILTER=0 (every candidate through the exact test),
+    over regular, flat, single-point and far-from-origin boxes at several radii."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    outs = []
+    for flag in ("1", "0"):
+        path = str(tmp_path / f"s{flag}.npz")
+        env = dict(os.environ, RRL_SAMPLER_PREFILTER=flag)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "sampler_check.py"), path],
+                           capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+        outs.append(np.load(path))
+    assert sorted(outs[0].files) == sorted(outs[1].files) and len(outs[0].files) == 24
+    filled = 0
+    for name in outs[0].files:
+        np.testing.assert_array_equal(outs[0][name], outs[1][name])
+        filled += int((np.abs(outs[0][name]).sum(1) > 0).sum())
+    assert filled > 10000  # the cases are not degenerate: lines were accepted
+
+
 def test_cull_dense_hits(L, oracle):
     """Stress the culled scan's overflow paths: a tiny cloud hit by almost every line (every
     (line, group) pair survives the sphere test) must still match the strict scan and the oracle."""
