@@ -306,6 +306,8 @@ __device__ __forceinline__ int load_prefix(const int32_t *__restrict__ cnt, int 
 struct ReduceLds {
     int *s_pref;
     unsigned *s_hist, *s_wtot, *s_prefix, *s_rank, *s_nvals;
+    unsigned *s_cand;   // [0] population of the bin chosen by pass 0, [1] gather cursor (zero between uses)
+    unsigned *s_whist;  // [128] histogram of the wave-private passes
     unsigned long long *s_sum;
     int *s_cnt;
 };
@@ -359,12 +361,15 @@ __device__ __forceinline__ void reduce_core(const uint8_t *__restrict__ kjc, con
     __syncthreads();
 
     // ---- lower median = element of rank (n-1)/2 (torch.median): MSB-first radix select on the
-    //      bit patterns (D >= 0: unsigned order == float order).  Three passes over digits of 11,
-    //      11 and 9 bits (bit 31, the sign, is clear): LDS histogram of the values that agree with
-    //      the prefix, block-wide exclusive scan (DPP wave scans + wave totals), pick the bin that
-    //      holds the rank.  Three barriers per pass: the histogram is cleared as it is read.
+    //      bit patterns (D >= 0: unsigned order == float order).  Pass 0 (bits 30..20) is
+    //      workgroup-wide: LDS histogram, block-wide exclusive scan (DPP wave scans + wave
+    //      totals), pick the bin that holds the rank; the histogram is cleared as it is read.
+    //      The values of that bin (~n/20 of them) are then gathered into LDS and ONE wavefront
+    //      finishes the remaining 20 bits in three wave-private passes (7 + 7 + 6 bits, 128-bin
+    //      histogram, no workgroup barrier): 5 barriers in all instead of 9.  More than 2048
+    //      values in the bin (near-identical D values): the workgroup-wide passes 1, 2 as before.
     unsigned prefix = 0;
-    for (int pass = 0; pass < 3 && n > 0; ++pass) {
+    auto wg_pass = [&](int pass) {
         const int sh = pass == 0 ? 20 : (pass == 1 ? 9 : 0);
         const int width = pass == 2 ? 9 : 11;
         const unsigned dmask = (1u << width) - 1u;
@@ -394,9 +399,84 @@ __device__ __forceinline__ void reduce_core(const uint8_t *__restrict__ kjc, con
             const unsigned second = r >= excl + h0 ? 1u : 0u;
             s_prefix[pass] = prefix | ((2u * tid + second) << sh);
             s_rank[pass + 1] = r - excl - (second ? h0 : 0u);
+            if (pass == 0) L_.s_cand[0] = second ? h1 : h0;  // population of the chosen bin
         }
         __syncthreads();
         prefix = s_prefix[pass];
+    };
+    if (n > 0) {
+        wg_pass(0);
+        const unsigned ncand = L_.s_cand[0];
+        if (ncand <= 2048u) {
+            // gather the bin's values into s_hist (all zero now, free until the next evaluation)
+            auto in_bin = [&](unsigned x) { return x != 0x7f800000u && ((x ^ prefix) >> 20) == 0u; };
+            unsigned mine = 0;
+#pragma unroll
+            for (int r = 0; r < RT; ++r)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) mine += in_bin(__float_as_uint(tile[r][q])) ? 1u : 0u;
+            for (int i = tid + 1024 * RT; i < ns_m; i += 1024) {
+                const float *row = dc + ((size_t)bm * Lp + slot_of(s_pref, nblk, i)) * 16;
+                for (int q = 0; q < 16; ++q) mine += in_bin(__float_as_uint(row[q])) ? 1u : 0u;
+            }
+            const unsigned incl = (unsigned)wave_incl_scan((int)mine);
+            unsigned wbase = 0;
+            if ((tid & 63) == 63 && incl) wbase = atomicAdd(&L_.s_cand[1], incl);  // one atomic per wavefront
+            wbase = (unsigned)__builtin_amdgcn_readlane((int)wbase, 63);
+            unsigned at = wbase + incl - mine;
+#pragma unroll
+            for (int r = 0; r < RT; ++r)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const unsigned x = __float_as_uint(tile[r][q]);
+                    if (in_bin(x)) s_hist[at++] = x;
+                }
+            for (int i = tid + 1024 * RT; i < ns_m; i += 1024) {
+                const float *row = dc + ((size_t)bm * Lp + slot_of(s_pref, nblk, i)) * 16;
+                for (int q = 0; q < 16; ++q) {
+                    const unsigned x = __float_as_uint(row[q]);
+                    if (in_bin(x)) s_hist[at++] = x;
+                }
+            }
+            __syncthreads();
+            if (tid < 64) {  // wave 0 alone: LDS operations of one wavefront execute in order
+                unsigned pre = prefix, rk = s_rank[1];
+                unsigned *wh = L_.s_whist;
+#pragma unroll
+                for (int wp = 0; wp < 3; ++wp) {
+                    const int sh = wp == 0 ? 13 : (wp == 1 ? 6 : 0);
+                    const int width = wp == 2 ? 6 : 7;
+                    const unsigned dmask = (1u << width) - 1u;
+                    const int hi = sh + width;
+                    wh[2 * tid] = 0;
+                    wh[2 * tid + 1] = 0;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    for (unsigned i = tid; i < ncand; i += 64) {
+                        const unsigned x = s_hist[i];
+                        if (((x ^ pre) >> hi) == 0u) atomicAdd(&wh[(x >> sh) & dmask], 1u);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    const unsigned h0 = wh[2 * tid], h1 = wh[2 * tid + 1];
+                    const unsigned inc2 = (unsigned)wave_incl_scan((int)(h0 + h1));
+                    const unsigned excl = inc2 - (h0 + h1);
+                    const bool here = rk >= excl && rk < excl + h0 + h1;  // exactly one lane
+                    const unsigned second = rk >= excl + h0 ? 1u : 0u;
+                    const unsigned long long who = __ballot(here);
+                    const int src = __ffsll((long long)who) - 1;
+                    pre |= (unsigned)__builtin_amdgcn_readlane((int)((2u * tid + second) << sh), src);
+                    rk = (unsigned)__builtin_amdgcn_readlane((int)(rk - excl - (second ? h0 : 0u)), src);
+                }
+                if (tid == 0) s_prefix[2] = pre;
+            }
+            __syncthreads();
+            prefix = s_prefix[2];
+            // the gathered values leave s_hist non-zero: clear it for the next use (pool mode, later samples)
+            for (unsigned i = tid; i < ncand; i += 1024) s_hist[i] = 0;
+            if (tid == 0) L_.s_cand[1] = 0;
+        } else {
+            wg_pass(1);
+            wg_pass(2);
+        }
     }
     const float med = n ? __uint_as_float(prefix) : 0.0f;
 
@@ -455,6 +535,7 @@ __global__ __launch_bounds__(1024) void loss_reduce_kernel(
     __shared__ unsigned s_wtot[16];
     __shared__ unsigned s_prefix[3], s_rank[4];  // one slot per pass: no barrier between read and rewrite
     __shared__ unsigned s_nvals;
+    __shared__ unsigned s_cand[2], s_whist[128];
     __shared__ unsigned long long s_sum[32];
     __shared__ int s_cnt[16];
     __shared__ float s_term[16];
@@ -463,12 +544,12 @@ __global__ __launch_bounds__(1024) void loss_reduce_kernel(
     const int b0 = pool ? 0 : g, b1 = pool ? B : g + 1;
     if (tid < 32) s_sum[tid] = 0ull;
     if (tid < 16) s_cnt[tid] = 0;
-    if (tid == 0) s_nvals = 0;
+    if (tid == 0) { s_nvals = 0; s_cand[0] = 0; s_cand[1] = 0; }
     s_hist[tid] = 0;
     s_hist[tid + 1024] = 0;
 
     const int ns_m = load_prefix(blkcnt + (size_t)bm * nblk, nblk, s_pref, tid);
-    const ReduceLds lds = {s_pref, s_hist, s_wtot, s_prefix, s_rank, &s_nvals, s_sum, s_cnt};
+    const ReduceLds lds = {s_pref, s_hist, s_wtot, s_prefix, s_rank, &s_nvals, s_cand, s_whist, s_sum, s_cnt};
     float med;
     unsigned n;
     if (ns_m <= 1024) reduce_core<1>(kjc, dc, blkcnt, lds, ns_m, B, nblk, bm, b0, b1, tid, med, n);

@@ -702,6 +702,25 @@ def test_cull_dense_hits(L, oracle):
     assert o["count"].max() > 4 and (o["count"] > 0).mean() > 0.5  # really dense
 
 
+@pytest.mark.parametrize("n_lines,spread", [(3000, 0.0), (3000, 1e-4), (600, 0.0), (9000, 1e-5)])
+def test_median_with_crowded_bins(L, oracle, n_lines, spread):
+    """The median's radix select hands the values of one 11-bit bin to a single wavefront when
+    there are at most 2048 of them and otherwise runs its workgroup-wide passes: thousands of
+    (nearly) identical D values exercise both routes and the rank bookkeeping inside the bin."""
+    rng = np.random.default_rng(5)
+    base = np.array([[0.0, 0.0, 0.0, 0.05, 0.0, 0.0, 0.0, 0.05, 0.0]], np.float32)
+    tri1 = np.concatenate([base, base + np.float32(3.0)]).astype(np.float32)          # second triangle far away
+    tri2 = (tri1 + np.array([0.004, -0.003, 0.002] * 3, np.float32)).astype(np.float32)
+    d = np.tile(np.array([[0.0, 0.0, 1.0]]), (n_lines, 1))
+    x0 = np.tile(np.array([[0.012, 0.011, -1.0]]), (n_lines, 1)) + spread * rng.standard_normal((n_lines, 3))
+    lines = np.concatenate([d, x0], 1).astype(np.float32)
+    ref = oracle.loss(tri1, tri2, lines, want_grad=False)
+    assert ref["n_selected"] > 0.9 * n_lines  # nearly every line is selected: > 2048 values in one bin for 3000+
+    st = run_state(tri1, tri2, lines, mode="cull")
+    np.testing.assert_array_equal(st.med.cpu().numpy().view(np.uint32), np.float32(ref["median"]).reshape(1).view(np.uint32))
+    np.testing.assert_allclose(st.loss.cpu().numpy()[0], ref["loss"], rtol=1e-5)
+
+
 def test_fused_registration_op(L):
     """rrl_registration_forward/backward == rigid apply + loss + rigid backward, incl. payload."""
     from rrl_hip import ops
