@@ -863,15 +863,34 @@ __device__ __forceinline__ void sample_line(const SampleGeom &g, const float *__
 __global__ __launch_bounds__(1024) void sample_count_kernel(
     const float *__restrict__ rands, const float *__restrict__ r, const float *__restrict__ centers,
     const float *__restrict__ aabb1, const float *__restrict__ aabb2,
-    unsigned long long *__restrict__ accept, int B, int n, int rounds, int prefilter) {
+    unsigned long long *__restrict__ accept, int B, int n, int rounds, int prefilter, int rd0) {
     __shared__ __attribute__((aligned(16))) float faces[24][FACE_FLOATS];
     __shared__ float lines_c[1024][6];
     __shared__ unsigned short surv[1024];
     __shared__ unsigned hits[1024];
     __shared__ unsigned char flag[1024];
     __shared__ int wave_cnt[16];
-    const int tile = blockIdx.x, rd = blockIdx.y, b = blockIdx.z;
+    const int tile = blockIdx.x, rd = rd0 + (int)blockIdx.y, b = blockIdx.z;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (rd0 > 0) {
+        // Rounds rd0.. run as a second launch: the reference skips every round once more than n
+        // candidates were accepted (code/loss.py:368-369), and the earlier launch's ballots say
+        // exactly how many were (sum over rounds < rd0 > n  <=>  round rd0 and all later ones are
+        // skipped).  With the trainers' radius two rounds fill the buffer: 3 of 10 rounds are evaluated.
+        int c = 0;
+        const unsigned long long *aq = accept + (size_t)b * rounds * gridDim.x * 16;
+        for (int q = tid; q < rd0 * (int)gridDim.x * 16; q += 1024) c += __popcll(aq[q]);
+        c = wave_sum_i(c);
+        if (lane == 0) wave_cnt[wave] = c;
+        __syncthreads();
+        int before = 0;
+        for (int w = 0; w < 16; ++w) before += wave_cnt[w];
+        __syncthreads();
+        if (before > n) {  // uniform
+            if (lane == 0) accept[(((size_t)b * rounds + rd) * gridDim.x + tile) * 16 + wave] = 0ull;
+            return;
+        }
+    }
     const SampleGeom g = sample_geom(r, centers, aabb1, aabb2, b);
     const int i = tile * 1024 + tid;
     bool ok = i < n;
@@ -985,8 +1004,16 @@ extern "C" int rrl_sample_lines(const float *rands, const float *r, const float 
     unsigned long long *accept = (unsigned long long *)tile_counts;
     if (((uintptr_t)accept & 7) != 0) return RRL_E_ARG;
     static const int prefilter = [] { const char *e = getenv("RRL_SAMPLER_PREFILTER"); return e && e[0] == '0' ? 0 : 1; }();
-    hipLaunchKernelGGL(sample_count_kernel, grid, dim3(1024), 0, s, rands, r, centers, aabb1, aabb2, accept, B, n,
-                       rounds, prefilter);
+    // Big calls (>= 512 workgroups: the trainers' B x 10 rounds x 10 tiles): rounds [0, 3) first, the
+    // rest as a second launch that starts by checking whether they are skipped (92 -> ~30 us at B=8,
+    // 10 x 10000 candidates, radius = half the box diagonal).  Small calls (the demo: 200 workgroups,
+    // never full) stay one launch: two latency-bound launches cost it 10 us of 15.
+    const int first = (rounds < 3 || (size_t)grid.x * rounds * B < 512) ? rounds : 3;
+    hipLaunchKernelGGL(sample_count_kernel, dim3(grid.x, (unsigned)first, grid.z), dim3(1024), 0, s, rands, r, centers,
+                       aabb1, aabb2, accept, B, n, rounds, prefilter, 0);
+    if (rounds > first)
+        hipLaunchKernelGGL(sample_count_kernel, dim3(grid.x, (unsigned)(rounds - first), grid.z), dim3(1024), 0, s, rands,
+                           r, centers, aabb1, aabb2, accept, B, n, rounds, prefilter, first);
     const size_t lds = sizeof(int32_t) * (size_t)rounds * grid.x;
     if (lds > 96 * 1024) return RRL_E_ARG;  // > 24576 tiles x rounds: far beyond any caller
     hipLaunchKernelGGL(sample_write_kernel, grid, dim3(1024), lds, s, rands, r, centers, aabb1, aabb2,
