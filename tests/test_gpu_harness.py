@@ -189,11 +189,15 @@ def test_demo_skips_empty_steps(demo, tmp_path):
         np.testing.assert_array_equal(model.parameters_.detach().cpu().numpy(), g["xi0"])
 
 
-def test_demo_end_to_end_reduces_chamfer(demo, tmp_path):
-    """Synthetic pair, the script's own sampler and Sample_neighs, 60 graphed epochs."""
+@pytest.mark.parametrize("device_rng", [False, True])
+def test_demo_end_to_end_reduces_chamfer(demo, tmp_path, device_rng):
+    """Synthetic pair, the script's own sampler and Sample_neighs, 60 graphed epochs.  device_rng:
+    the sampler (GPU generator, lines written in place), the exp map, Adam and the log row are all
+    inside the captured step -- one graph launch per epoch."""
     import argparse
     args = argparse.Namespace(data_path=None, device='cuda:0', seed=5, label1='s', Save_path=str(tmp_path),
-                              n_epoch=60, n_sample_line=4000, synthetic=400, graph=True, print_every=0)
+                              n_epoch=60, n_sample_line=4000, synthetic=400, graph=True, print_every=0,
+                              device_rng=device_rng, save_every=0 if device_rng else 10)
     hist, model = demo.main(args)
     done = [h for h in hist if h[1] is not None]
     assert len(done) >= 50
