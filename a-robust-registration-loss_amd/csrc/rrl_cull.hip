@@ -29,19 +29,40 @@
 //   sphere tests and 10.2 x 8 exact tests, against 256 sphere tests + 10.2 x 16 exact tests of the
 //   single-level version of this kernel (17.1 x 16 in Morton order).
 //
-// Culling bound (labels can never be lost).  For a line with |dir|^2 <= 1 + 1e-6 and
-// (|x0| + max|P|)^2 <= 100 ("safe", the NaN bound of rrl_scan.hip) let
-// delta(P)^2 = |a|^2 - (a.dir)^2, a = P - x0, in exact arithmetic.  delta is a seminorm of a
-// (|dir| <= 1) and hence 1-Lipschitz in P; the 1e-6 excess of |dir|^2 adds at most 1e-6 |a|^2.
-// The reference value x0_ref = fl((dAC - proj) + 2e-4) satisfies
-// |x0_ref - (delta(P0)^2 + 2e-4)| <= 30u |a|^2 <= 1.8e-4 (u = 2^-24), so a hit
-// (x0_ref < thr2 <= thr^2 (1 + 2u)) implies delta(P0) < thr and therefore
-// delta(c) < thr_max + rho for the centre c of ANY sphere that bounds the triangle's P0 -- its
-// half, its group and its supergroup alike, so a hit survives every level.  A sphere test
-// evaluates d2 = |a_c|^2 - (a_c.dir)^2 with FMAs (error <= 10u |a_c|^2) and keeps the node when
-// d2 - 4e-6 |a_c|^2 <= R2: the slack covers the evaluation error, the |dir|^2 excess and the
-// rounding of rho and R2 with a factor > 2 to spare.  Unsafe lines are not culled at all: a
-// wavefront holding one evaluates all its (line, triangle) pairs of the slice with the strict loop.
+// Culling bound (labels can never be lost) -- valid at ANY finite data scale.
+// Line = (d, x0) with s = |d|^2 <= 1 + 1e-6 as evaluated in fp32; a = P - x0; A >= |a| for every
+// point of the cloud (A = |x0| + max|P|); u = 2^-24.  Exact-arithmetic quantities:
+//   Q(P) = |a|^2 - (a.d)^2        what the reference evaluates (code/loss.py:84-88)
+//   p(P) = distance of P to the line through x0 along d/|d| -- a seminorm of a, 1-Lipschitz in P
+//   Q = p^2 - eta (a.d/|d|)^2,  eta = |d|^2 - 1   (|d| <= 1: Q itself is a squared seminorm >= p^2)
+// The reference's fp32 value x_ref = fl((dAC - proj) + 2e-4) satisfies
+//   |x_ref - (Q(P) + 2e-4)| <= 30u |a|^2   (3u dAC, 7.1u proj, 1u difference, 4u rounding of a; ~2x spare)
+// A hit needs x_ref(P0) < thr2 <= thr^2 (1 + 2u) =: T, hence
+//   Q(P0) < T + g+,            g = 30u A^2 - 2e-4   (g <= 0: the 2e-4 dominates the rounding noise)
+//   p(P0)^2 < T + g+ + x,      x = eta+ A^2         (only needed when |d| > 1)
+// and, because x_ref >= 2e-4 - 30u A^2 for every pair, a hit with g <= 0 also needs T > -g.  So with
+//   se = sqrt(g + x)                          when g > 0
+//   se = min( sqrt(x), x / (2 sqrt(-g)) )     when g <= 0    (sqrt(T + x) - sqrt(T) <= x / (2 sqrt T))
+// a hit implies  p(P0) < thr (1 + u) + se  (|d| > 1)  or  sqrt(Q(P0)) < thr (1 + u) + se  (|d| <= 1),
+// and by the Lipschitz property the same function of the CENTRE c of any sphere that bounds the
+// triangle's P0 (its half, its group and its supergroup alike) is < thr_max (1 + u) + rho + se; in both
+// cases Q(c) is <= that square.  A node stores Rs >= (rho + thr_max)(1 + 5e-5) and the test keeps it when
+//   d2 - 4e-6 |a_c|^2 <= (Rs + se_w)^2,   d2 = fl(Q(c)) by FMAs (error <= 14u |a_c|^2),
+// se_w = the largest se of the wavefront's 128 lines (x 1.0001).  At unit scale with normalised
+// directions se_w ~ 6e-5 (0.06 % of a typical radius); at the demo's scale (radius 11.7,
+// A^2 ~ 300: g ~ 3.4e-4) se_w ~ 0.02, some 5 % of the radii there -- the reference's own labels are
+// that noisy at this scale.  Lines with s > 1 + 1e-6 or non-finite data are never culled: a wavefront
+// that holds one evaluates all its (line, triangle) pairs of the slice with the strict loop
+// (status[1] counts such wavefronts).
+//
+// NaN (negative sqrt argument; the reference prints and exits, code/loss.py:88-91): provably
+// impossible when g <= 0 for every line of the wavefront (A^2 < 111; all unit-scale training data).
+// Otherwise (g > 0, e.g. the demo's full-diagonal radius) it is detected on every EVALUATED pair:
+// point 0 of every triangle whose half sphere the line reaches -- which includes every triangle
+// whose point 0 could produce one (x_ref(P0) < 0 needs Q(P0) < g, a "hit" with T = 0) -- and points
+// 1, 2 of the triangles whose point 0 passes.  A negative argument at point 1 or 2 of a triangle
+// whose point 0 does not pass is not evaluated, as in RRL_SCAN_LAZY; it needs rounding noise above
+// 2e-4 + Q, which at the demo's scale means > 11u |a|^2 of the 15u worst case (never observed).
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -101,13 +122,15 @@ constexpr HilbertLut make_hilbert_lut() {
 __device__ const HilbertLut HILBERT_LUT = make_hilbert_lut();
 
 // ---- sphere tree ------------------------------------------------------------------------
+// Node = (centre, Rs): Rs = (rho + max thr) (1 + 5e-5) + 1e-7 with rho = max |P0 - c| rounded up --
+// a conservative RADIUS; the scan compares against (Rs + se)^2 with its per-wavefront slack se
+// (see "Culling bound").  Empty node: Rs = NaN, which fails every comparison.
 __device__ __forceinline__ float4 finish_sphere(float cx, float cy, float cz, float d2, float tm, bool any) {
-    if (!any) return make_float4(0.0f, 0.0f, 0.0f, -1.0f);  // empty node: never passes
+    if (!any) return make_float4(0.0f, 0.0f, 0.0f, __builtin_nanf(""));  // empty node: never passes
     const float rho = sqrtf(d2) * 1.00001f + 1e-7f;
-    const float R = rho + tm;
-    float R2 = R * R * 1.0001f + 1e-7f;
-    if (!(R2 < 3.0e38f)) R2 = INFINITY;  // non-finite data: keep the node
-    return make_float4(cx, cy, cz, R2);
+    float Rs = (rho + tm) * 1.00005f + 1e-7f;
+    if (!(Rs < 1.0e18f)) Rs = 1.0e18f;  // non-finite / huge data: keep the node ((Rs + se)^2 stays finite or +inf)
+    return make_float4(cx, cy, cz, Rs);
 }
 
 #define QUAD_MIN(v) do { v = fminf(v, RRL_DPP_F(v, 0xB1)); v = fminf(v, RRL_DPP_F(v, 0x4E)); } while (0)
@@ -566,8 +589,14 @@ struct WaveCtx {
     int32_t *cnt, *hit;           // per-line hit count / slots of the cloud
     int lbase;                    // first line of this wave
     int pos0;                     // sorted position of the slice's first record
+    int n;                        // real records of the cloud (sorted positions [0, n))
     int na, nb, nc, ncand;        // wave-uniform fill levels
     int lane;
+    // executed-work counters of the COUNT instantiation (wave-uniform; see rrl_scan_counters)
+    unsigned tb, tc, td, tcand;   // level-B / level-C sphere tests, exact point-0 tests, resolved candidates
+    float se;                     // wave-uniform slack added to every node radius (cull_line_slack)
+    int32_t *status;              // NaN flag of the call
+    bool track;                   // wave-uniform: a NaN is not provably impossible for these lines
 };
 
 // cand = line_in_wave << 16 | sorted triangle position: evaluate points 1 and 2
@@ -580,6 +609,8 @@ __device__ __forceinline__ void resolve_candidate(const WaveCtx &c, unsigned can
     const uint32_t thr2 = __float_as_uint(q[9]);
     const float x1 = dist_sq<float>(q[3], q[4], q[5], la.x, la.y, la.z, la.w, lb.x, lb.y);
     const float x2 = dist_sq<float>(q[6], q[7], q[8], la.x, la.y, la.z, la.w, lb.x, lb.y);
+    // a negative sqrt argument is the reference's NaN (code/loss.py:88-91); candidates are rare
+    if ((__float_as_uint(x1) | __float_as_uint(x2)) >= 0x80000000u) atomicOr(&c.status[0], 1);
     if (max(__float_as_uint(x1), __float_as_uint(x2)) < thr2) {
         const int l = c.lbase + ll;
         int pos = atomicAdd(&c.cnt[l], 1);
@@ -596,16 +627,39 @@ __device__ __forceinline__ int lane_rank(unsigned long long m) {  // set bits of
     return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
 }
 
+// Per-line slack of the culling bound (header).  ok = false: the line cannot be culled (|d|^2 above
+// 1 + 1e-6, or non-finite data).  nanfree: a negative sqrt argument is provably impossible.
+struct LineSlack {
+    bool ok, nanfree;
+    float se;
+};
+__device__ __forceinline__ LineSlack cull_line_slack(const float *v, float pm) {
+    const float s = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+    const float o2 = v[3] * v[3] + v[4] * v[4] + v[5] * v[5];
+    const float A2 = (o2 + pm + 2.0f * sqrtf(o2 * pm)) * 1.00001f;  // (|x0| + max|P|)^2, rounded up
+    LineSlack r;
+    r.ok = (s <= 1.000001f) && (A2 <= 1.0e12f);  // a NaN anywhere fails both
+    const float eta = fmaxf(s - 1.0f, 0.0f) + 2.5e-7f;  // |d|^2 - 1 incl. the rounding of s (<= 3u s)
+    const float x = eta * A2;
+    const float g = 1.8e-6f * A2 - 2e-4f;  // 30u = 1.788e-6
+    r.nanfree = g <= 0.0f;
+    const float se = g > 0.0f ? sqrtf(g + x) : fminf(sqrtf(x), x / (2.0f * sqrtf(-0.999f * g)));
+    r.se = se * 1.0001f + 1e-12f;
+    return r;
+}
+
 // conservative sphere test of one line against one tree node (see the culling bound above)
-__device__ __forceinline__ bool sphere_pass(const float4 nd, const float4 la, const float2 lb) {
+__device__ __forceinline__ bool sphere_pass(const float4 nd, const float4 la, const float2 lb, float se) {
     const float ax = nd.x - la.w, ay = nd.y - lb.x, az = nd.z - lb.y;
     const float dot = fmaf(az, la.z, fmaf(ay, la.y, ax * la.x));
     const float q = fmaf(az, az, fmaf(ay, ay, ax * ax));
     float d2 = fmaf(-dot, dot, q);
     d2 = fmaf(-4e-6f, q, d2);
-    return d2 <= nd.w;
+    const float t = nd.w + se;  // NaN (empty node) fails the comparison
+    return d2 <= t * t;
 }
 
+template <bool COUNT>
 __device__ __forceinline__ void flush_cands(WaveCtx &c) {
 #ifdef CULL_NO_RESOLVE
     c.ncand = 0;
@@ -613,6 +667,7 @@ __device__ __forceinline__ void flush_cands(WaveCtx &c) {
 #endif
     wave_lds_fence();
     const int nc = min(c.ncand, WCCAP);
+    if constexpr (COUNT) c.tcand += (unsigned)c.ncand;  // entries past WCCAP were resolved inline: counted here too
     for (int i = c.lane; i < nc; i += 64) resolve_candidate(c, c.cands[i]);
     c.ncand = 0;
 }
@@ -624,6 +679,7 @@ __device__ __forceinline__ void flush_cands(WaveCtx &c) {
 
 // level D: pops (line, half) pairs, ONE per lane (8 records = 32 registers in flight), and runs
 // the exact point-0 test on the half's 8 records
+template <bool COUNT>
 __device__ __forceinline__ void proc_c(WaveCtx &c, bool all) {
 #ifdef CULL_STOP_C  // timing experiments only (tools/knob_sweep.sh): the level is formed but not run
     c.nc = 0;
@@ -632,6 +688,7 @@ __device__ __forceinline__ void proc_c(WaveCtx &c, bool all) {
     while (c.nc >= 64 || (all && c.nc > 0)) {
         const int take = min(c.nc, 64), base = c.nc - take;
         c.nc = base;
+        if constexpr (COUNT) c.td += 8u * (unsigned)take;
         wave_lds_fence();
         uint32_t passbits = 0;
         unsigned lh = 0;  // line << 16 | first sorted position of the half
@@ -641,11 +698,23 @@ __device__ __forceinline__ void proc_c(WaveCtx &c, bool all) {
             const float4 la = c.la[ll];
             const float2 lb = c.lb[ll];
             const float4 *row = c.recs + (h >> 1) * ROWS + (h & 1) * 8;
+            if (!c.track) {  // uniform: the usual case, a NaN is provably impossible
 #pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                const float4 rec = row[t];
-                const float x = dist_sq<float>(rec.x, rec.y, rec.z, la.x, la.y, la.z, la.w, lb.x, lb.y);
-                passbits |= (__float_as_uint(x) < __float_as_uint(rec.w) ? 1u : 0u) << t;
+                for (int t = 0; t < 8; ++t) {
+                    const float4 rec = row[t];
+                    const float x = dist_sq<float>(rec.x, rec.y, rec.z, la.x, la.y, la.z, la.w, lb.x, lb.y);
+                    passbits |= (__float_as_uint(x) < __float_as_uint(rec.w) ? 1u : 0u) << t;
+                }
+            } else {  // also watch for a negative sqrt argument (sign bit) among the evaluated pairs
+                uint32_t neg = 0;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const float4 rec = row[t];
+                    const float x = dist_sq<float>(rec.x, rec.y, rec.z, la.x, la.y, la.z, la.w, lb.x, lb.y);
+                    passbits |= (__float_as_uint(x) < __float_as_uint(rec.w) ? 1u : 0u) << t;
+                    if (c.pos0 + h * 8 + t < c.n) neg |= __float_as_uint(x);  // pad records are not points
+                }
+                if (neg >= 0x80000000u) atomicOr(&c.status[0], 1);
             }
             lh = ((unsigned)ll << 16) | (unsigned)(c.pos0 + h * 8);
         }
@@ -662,11 +731,12 @@ __device__ __forceinline__ void proc_c(WaveCtx &c, bool all) {
             }
             c.ncand += __popcll(m);
         }
-        if (c.ncand > WCCAP - 64) flush_cands(c);  // uniform: keep room for the next pass
+        if (c.ncand > WCCAP - 64) flush_cands<COUNT>(c);  // uniform: keep room for the next pass
     }
 }
 
 // level C: pops (line, group) pairs and tests the group's two half spheres
+template <bool COUNT>
 __device__ __forceinline__ void proc_b(WaveCtx &c, bool all) {
 #ifdef CULL_STOP_B
     c.nb = 0;
@@ -675,6 +745,7 @@ __device__ __forceinline__ void proc_b(WaveCtx &c, bool all) {
     while (c.nb >= 64 || (all && c.nb > 0)) {
         const int take = min(c.nb, 128), base = c.nb - take;
         c.nb = base;
+        if constexpr (COUNT) c.tc += 2u * (unsigned)take;
         wave_lds_fence();
         bool p[2][2] = {{false, false}, {false, false}};
         unsigned e2[2] = {0, 0};
@@ -687,15 +758,15 @@ __device__ __forceinline__ void proc_b(WaveCtx &c, bool all) {
                 const float4 la = c.la[ll];
                 const float2 lb = c.lb[ll];
                 const float4 *nd = c.nodes + (g >> 2) * NODE + 5 + 2 * (g & 3);
-                p[u][0] = sphere_pass(nd[0], la, lb);
-                p[u][1] = sphere_pass(nd[1], la, lb);
+                p[u][0] = sphere_pass(nd[0], la, lb, c.se);
+                p[u][1] = sphere_pass(nd[1], la, lb, c.se);
                 e2[u] = ((unsigned)ll << 6) | (unsigned)(2 * g);
             }
         }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             if (u == 1 && take <= 64) break;
-            if (c.nc > QC_CAP - 128) proc_c(c, false);  // room for <= 128 entries on top of < 64 left-overs
+            if (c.nc > QC_CAP - 128) proc_c<COUNT>(c, false);  // room for <= 128 entries on top of < 64 left-overs
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
                 const unsigned long long m = __ballot(p[u][k]);
@@ -707,15 +778,17 @@ __device__ __forceinline__ void proc_b(WaveCtx &c, bool all) {
 }
 
 // level B: pops (line, supergroup) pairs, one per lane, and tests the supergroup's four group spheres
+template <bool COUNT>
 __device__ __forceinline__ void proc_a(WaveCtx &c, bool all) {
 #ifdef CULL_STOP_A
     c.na = 0;
     return;
 #endif
     while (c.na >= 64 || (all && c.na > 0)) {
-        if (c.nb > QB_CAP - 256) proc_b(c, false);  // room for <= 256 entries on top of < 64 left-overs
+        if (c.nb > QB_CAP - 256) proc_b<COUNT>(c, false);  // room for <= 256 entries on top of < 64 left-overs
         const int take = min(c.na, 64), base = c.na - take;
         c.na = base;
+        if constexpr (COUNT) c.tb += (unsigned)SGG * (unsigned)take;
         wave_lds_fence();
         bool p[SGG] = {false, false, false, false};
         unsigned e2 = 0;
@@ -726,7 +799,7 @@ __device__ __forceinline__ void proc_a(WaveCtx &c, bool all) {
             const float2 lb = c.lb[ll];
             const float4 *nd = c.nodes + sg * NODE + 1;
 #pragma unroll
-            for (int k = 0; k < SGG; ++k) p[k] = sphere_pass(nd[k], la, lb);
+            for (int k = 0; k < SGG; ++k) p[k] = sphere_pass(nd[k], la, lb, c.se);
             e2 = ((unsigned)ll << 5) | (unsigned)(SGG * sg);
         }
 #pragma unroll
@@ -738,13 +811,20 @@ __device__ __forceinline__ void proc_a(WaveCtx &c, bool all) {
     }
 }
 
+// COUNT = true: the same kernel with executed-work counters (one u64 atomic per counter and
+// wavefront at exit) -- launched instead of the plain one while rrl_scan_counters() holds a buffer:
+//   counters[0] level-A sphere tests (line x supergroup)   [1] level-B (line x group)
+//           [2] level-C (line x half)                      [3] exact point-0 tests (line x record)
+//           [4] candidates resolved (points 1, 2)          [5] wavefronts that ran
+//           [6] wavefronts that took the strict fallback   [7] (line, triangle) pairs of the fallback
+template <bool COUNT>
 __global__ __launch_bounds__(64 * WPB) void cull_scan_kernel(
     const float *__restrict__ ptri1, const float *__restrict__ ptri2, const float4 *__restrict__ p0s1,
     const float4 *__restrict__ p0s2, const int32_t *__restrict__ idx1, const int32_t *__restrict__ idx2,
     const float4 *__restrict__ tree1, const float4 *__restrict__ tree2, const float *__restrict__ line,
     int32_t *__restrict__ count1, int32_t *__restrict__ hit1, int32_t *__restrict__ count2,
     int32_t *__restrict__ hit2, int32_t *__restrict__ status, const uint32_t *__restrict__ pmax, int B,
-    int N, int M, int L, int spw) {
+    int N, int M, int L, int spw, unsigned long long *__restrict__ counters) {
     __shared__ __attribute__((aligned(16))) float4 la_lds[WPB][LPW];          // 16 KiB
     __shared__ __attribute__((aligned(16))) float2 lb_lds[WPB][LPW];          //  8 KiB
     __shared__ __attribute__((aligned(16))) float4 rec_lds[SPW * SGG * ROWS]; //  8.5 KiB
@@ -799,7 +879,8 @@ __global__ __launch_bounds__(64 * WPB) void cull_scan_kernel(
     // NaN-impossibility bound.  A wavefront with an offending line evaluates ALL pairs of its
     // lines with the slice's triangles strictly instead -- the reference's semantics, NaN included.
     const float pm = __uint_as_float(pmax[cloud * B + b]);
-    if (!__all(rrl_line_safe(v0, pm) && rrl_line_safe(v1, pm))) {
+    const LineSlack ls0 = cull_line_slack(v0, pm), ls1 = cull_line_slack(v1, pm);
+    if (!__all(ls0.ok && ls1.ok)) {
         kptr tp0 = (kptr)(uintptr_t)ptri;
         kiptr ik = (kiptr)(uintptr_t)idx;
         const int s0 = sg0 * SGT, s1 = min(n, s0 + nsl * SGT);  // real records sit at sorted positions [0, n)
@@ -825,6 +906,14 @@ __global__ __launch_bounds__(64 * WPB) void cull_scan_kernel(
             }
         }
         if (nanacc >= 0x80000000u) atomicOr(&status[0], 1);
+        if (lane == 0) {
+            atomicAdd(&status[1], 1);  // always on: wavefronts that left the culled path
+            if constexpr (COUNT) {
+                atomicAdd(&counters[5], 1ull);
+                atomicAdd(&counters[6], 1ull);
+                atomicAdd(&counters[7], (unsigned long long)(s1 - s0) * (unsigned long long)min(LPW, L - lw0));
+            }
+        }
         return;
     }
 
@@ -845,6 +934,11 @@ __global__ __launch_bounds__(64 * WPB) void cull_scan_kernel(
     ctx.pos0 = sg0 * SGT;
     ctx.na = ctx.nb = ctx.nc = ctx.ncand = 0;
     ctx.lane = lane;
+    ctx.tb = ctx.tc = ctx.td = ctx.tcand = 0;
+    ctx.n = n;
+    ctx.status = status;
+    ctx.se = wave_max(fmaxf(ls0.se, ls1.se));
+    ctx.track = !__all(ls0.nanfree && ls1.nanfree);
 
     // ---- level A: conservative sphere test of every supergroup of the slice against the lane's
     //      two lines (packed fp32, wave-uniform sphere through the scalar cache)
@@ -863,7 +957,8 @@ __global__ __launch_bounds__(64 * WPB) void cull_scan_kernel(
 #pragma unroll
     for (int s = 0; s < SPW; ++s) {
         if (s >= nsl) break;  // uniform
-        const float cx = sgs[s][0], cy = sgs[s][1], cz = sgs[s][2], R2 = sgs[s][3];
+        const float cx = sgs[s][0], cy = sgs[s][1], cz = sgs[s][2];
+        const float Rt = sgs[s][3] + ctx.se, R2 = Rt * Rt;  // NaN (empty node) fails both comparisons
         const v2f ax = cx - ox, ay = cy - oy, az = cz - oz;
         const v2f dot = __builtin_elementwise_fma(az, uz, __builtin_elementwise_fma(ay, uy, ax * ux));
         const v2f q = __builtin_elementwise_fma(az, az, __builtin_elementwise_fma(ay, ay, ax * ax));
@@ -872,17 +967,35 @@ __global__ __launch_bounds__(64 * WPB) void cull_scan_kernel(
         const bool pass0 = live0 && d2.x <= R2, pass1 = live1 && d2.y <= R2;
         const unsigned long long m0 = __ballot(pass0), m1 = __ballot(pass1);
         if (m0 | m1) {
-            if (ctx.na > QA_CAP - 128) proc_a(ctx, false);
+            if (ctx.na > QA_CAP - 128) proc_a<COUNT>(ctx, false);
             const int c0 = __popcll(m0);
             if (pass0) ctx.qa[ctx.na + lane_rank(m0)] = (unsigned short)((lane << 3) | s);
             if (pass1) ctx.qa[ctx.na + c0 + lane_rank(m1)] = (unsigned short)(((64 + lane) << 3) | s);
             ctx.na += c0 + __popcll(m1);
         }
     }
-    proc_a(ctx, true);
-    proc_b(ctx, true);
-    proc_c(ctx, true);
-    flush_cands(ctx);
+    proc_a<COUNT>(ctx, true);
+    proc_b<COUNT>(ctx, true);
+    proc_c<COUNT>(ctx, true);
+    flush_cands<COUNT>(ctx);
+    if constexpr (COUNT) {
+        if (lane == 0) {
+            atomicAdd(&counters[0], (unsigned long long)nsl * (unsigned long long)min(LPW, L - lw0));
+            atomicAdd(&counters[1], (unsigned long long)ctx.tb);
+            atomicAdd(&counters[2], (unsigned long long)ctx.tc);
+            atomicAdd(&counters[3], (unsigned long long)ctx.td);
+            atomicAdd(&counters[4], (unsigned long long)ctx.tcand);
+            atomicAdd(&counters[5], 1ull);
+        }
+    }
+}
+
+// Executed-work counters (profiling; include/rrl.h rrl_scan_counters): while a buffer is set,
+// culled scans launch the COUNT instantiation and add to it.
+static unsigned long long *g_cull_counters = nullptr;
+extern "C" int rrl_scan_counters(uint64_t *dev_counters) {
+    g_cull_counters = (unsigned long long *)dev_counters;
+    return 0;
 }
 
 // Launchers used by rrl_tri_prepare / rrl_line_tri_scan (rrl_scan.hip)
@@ -953,13 +1066,18 @@ int rrl_launch_cull_scan(const float *line, void *ws, const WsLayout &w, int B, 
         if (sscanf(e, "%d,%d", &w_, &s_) == 2 && w_ >= 1 && w_ <= WPB && s_ >= 1 && s_ <= SPW) { waves = w_ < lw ? w_ : lw; spw = s_; }
     }
     const int tiles = (lw + waves - 1) / waves, slices = (nsgmax + spw - 1) / spw;
-    hipLaunchKernelGGL(cull_scan_kernel, dim3((unsigned)(clouds * B), (unsigned)tiles, (unsigned)slices), dim3(64 * waves), 0,
-                       s, w.f32(ws, RRL_WS_PTRI1), w.f32(ws, RRL_WS_PTRI2),
-                       (const float4 *)w.f32(ws, RRL_WS_P0S1), (const float4 *)w.f32(ws, RRL_WS_P0S2),
-                       w.i32(ws, RRL_WS_IDX1), w.i32(ws, RRL_WS_IDX2), (const float4 *)w.f32(ws, RRL_WS_GRP1),
-                       (const float4 *)w.f32(ws, RRL_WS_GRP2), line, w.i32(ws, RRL_WS_COUNT1),
-                       w.i32(ws, RRL_WS_HIT1), w.i32(ws, RRL_WS_COUNT2), w.i32(ws, RRL_WS_HIT2),
-                       w.i32(ws, RRL_WS_STATUS), (const uint32_t *)w.i32(ws, RRL_WS_PMAX), B, N, M, L, spw);
+#define RRL_CULL_LAUNCH(COUNT)                                                                              \
+    hipLaunchKernelGGL(cull_scan_kernel<COUNT>, dim3((unsigned)(clouds * B), (unsigned)tiles, (unsigned)slices),    \
+                       dim3(64 * waves), 0, s, w.f32(ws, RRL_WS_PTRI1), w.f32(ws, RRL_WS_PTRI2),             \
+                       (const float4 *)w.f32(ws, RRL_WS_P0S1), (const float4 *)w.f32(ws, RRL_WS_P0S2),       \
+                       w.i32(ws, RRL_WS_IDX1), w.i32(ws, RRL_WS_IDX2), (const float4 *)w.f32(ws, RRL_WS_GRP1), \
+                       (const float4 *)w.f32(ws, RRL_WS_GRP2), line, w.i32(ws, RRL_WS_COUNT1),               \
+                       w.i32(ws, RRL_WS_HIT1), w.i32(ws, RRL_WS_COUNT2), w.i32(ws, RRL_WS_HIT2),             \
+                       w.i32(ws, RRL_WS_STATUS), (const uint32_t *)w.i32(ws, RRL_WS_PMAX), B, N, M, L, spw,  \
+                       g_cull_counters)
+    if (g_cull_counters) RRL_CULL_LAUNCH(true);
+    else RRL_CULL_LAUNCH(false);
+#undef RRL_CULL_LAUNCH
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }

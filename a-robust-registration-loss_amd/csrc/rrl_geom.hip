@@ -709,11 +709,18 @@ extern "C" int rrl_dense_scan(const float *tri, const float *line, float *norm_d
     return 0;
 }
 
+// torch.cross and torch.norm / F.normalize as PyTorch's CPU kernels evaluate them (their vectorised
+// loops are compiled with FP contraction): cross_i = fma(a_j, b_k, -(a_k b_j)), the second product
+// rounded first; |v| = sqrt(fma(z, z, fma(y, y, x x))).  With exactly these the sub-area test below
+// reproduces the reference's accept decisions on tests/golden/sampler.npz bit for bit (unfused
+// products: 17 of 400 differ -- the test is a knife-edge equality).  The library is compiled with
+// -ffp-contract=off, so only these explicit fmaf calls fuse.
 __device__ __forceinline__ void cross3(const float *a, const float *b, float *o) {
-    o[0] = a[1] * b[2] - a[2] * b[1];
-    o[1] = a[2] * b[0] - a[0] * b[2];
-    o[2] = a[0] * b[1] - a[1] * b[0];
+    o[0] = fmaf(a[1], b[2], -(a[2] * b[1]));
+    o[1] = fmaf(a[2], b[0], -(a[0] * b[2]));
+    o[2] = fmaf(a[0], b[1], -(a[1] * b[0]));
 }
+__device__ __forceinline__ float norm3f(float x, float y, float z) { return sqrtf(fmaf(z, z, fmaf(y, y, x * x))); }
 
 // box corner k of the reference's table (code/loss.py:325-351): corner 0 = max, 7 = min
 __device__ __forceinline__ void corner(const float *bb /*min3,max3*/, int k, float *o) {
@@ -742,7 +749,7 @@ __device__ __forceinline__ void face_entry(const float *bb, int f, float *o) {
     float e2[3] = {C[0] - A[0], C[1] - A[1], C[2] - A[2]};
     float nr[3];
     cross3(e1, e2, nr);
-    float S = norm3(nr[0], nr[1], nr[2]);
+    float S = norm3f(nr[0], nr[1], nr[2]);
     float den = fmaxf(S, 1e-12f);  // F.normalize eps
 #pragma unroll
     for (int c = 0; c < 3; ++c) { o[c] = A[c]; o[3 + c] = Bq[c]; o[6 + c] = C[c]; o[9 + c] = nr[c] / den; }
@@ -770,7 +777,7 @@ __device__ __forceinline__ bool face_hit(const float *tab, const float *ln) {
     cross3(ib, ic, c0);
     cross3(ic, ia, c1);
     cross3(ia, ib, c2);
-    float ba = norm3(c0[0], c0[1], c0[2]), bb2 = norm3(c1[0], c1[1], c1[2]), bc = norm3(c2[0], c2[1], c2[2]);
+    float ba = norm3f(c0[0], c0[1], c0[2]), bb2 = norm3f(c1[0], c1[1], c1[2]), bc = norm3f(c2[0], c2[1], c2[2]);
     return (ba > 0.0f) && (bb2 > 0.0f) && (bc > 0.0f) && (((ba + bb2) + bc) <= S);
 }
 
@@ -801,6 +808,51 @@ __device__ __forceinline__ bool slab_maybe(const float *bb, const float *ln) {
         }
     }
     return !(tlo > thi + 1e-5f * (fabsf(tlo) + fabsf(thi)));  // NaN: keep
+}
+
+// The accept test on CALLER-SUPPLIED lines (include/rrl.h rrl_box_accept): the same face table, the same
+// face_hit and the same slab pre-test as the sampler kernels below, one lane per line walking the 24
+// faces.  It is the seam through which tests compare the decision with the CPU oracle and with
+// the reference's own label1 / label2 on identical candidates, and a public helper for callers
+// that bring their own lines.
+__global__ __launch_bounds__(256) void box_accept_kernel(const float *__restrict__ lines,
+                                                         const float *__restrict__ aabb1,
+                                                         const float *__restrict__ aabb2,
+                                                         uint8_t *__restrict__ mask, int32_t *__restrict__ hits,
+                                                         int n) {
+    __shared__ __attribute__((aligned(16))) float faces[24][FACE_FLOATS];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    float bb1[6], bb2[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) { bb1[c] = aabb1[b * 6 + c]; bb2[c] = aabb2[b * 6 + c]; }
+    if (tid < 24) face_entry(tid < 12 ? bb1 : bb2, tid % 12, faces[tid]);
+    __syncthreads();
+    const int i = blockIdx.x * 256 + tid;
+    if (i >= n) return;
+    float ln[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) ln[c] = lines[((size_t)b * n + i) * 6 + c];
+    int h1 = 0, h2 = 0;
+    for (int f = 0; f < 12; ++f) {
+        h1 += face_hit(faces[f], ln) ? 1 : 0;
+        h2 += face_hit(faces[12 + f], ln) ? 1 : 0;
+    }
+    const bool slab = slab_maybe(bb1, ln) && slab_maybe(bb2, ln);
+    mask[(size_t)b * n + i] = (uint8_t)((h1 > 0 ? 1 : 0) | (h2 > 0 ? 2 : 0) | (slab ? 4 : 0));
+    if (hits) {
+        hits[((size_t)b * n + i) * 2] = h1;
+        hits[((size_t)b * n + i) * 2 + 1] = h2;
+    }
+}
+
+extern "C" int rrl_box_accept(const float *lines, const float *aabb1, const float *aabb2, uint8_t *mask,
+                              int32_t *hits, int B, int n, void *stream) {
+    if (!lines || !aabb1 || !aabb2 || !mask || B < 0 || n < 0 || B > 65535) return RRL_E_ARG;
+    if (B == 0 || n == 0) return 0;
+    hipLaunchKernelGGL(box_accept_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)B), dim3(256), 0,
+                       (hipStream_t)stream, lines, aabb1, aabb2, mask, hits, n);
+    RRL_LAUNCH_CHECK();
+    return 0;
 }
 
 // The reference fills its (N, 6) buffer candidate by candidate, round by round, and skips a round
@@ -846,7 +898,7 @@ __device__ __forceinline__ void sample_line(const SampleGeom &g, const float *__
     float q1[3] = {(g.rad * s1) * cosf(al1), (g.rad * sinf(al1)) * s1, g.rad * v1};
     float q2[3] = {(g.rad * s2) * cosf(al2), (g.rad * sinf(al2)) * s2, g.rad * v2};
     float d[3] = {q2[0] - q1[0], q2[1] - q1[1], q2[2] - q1[2]};
-    float den = fmaxf(norm3(d[0], d[1], d[2]), 1e-12f);
+    float den = fmaxf(norm3f(d[0], d[1], d[2]), 1e-12f);  // F.normalize
 #pragma unroll
     for (int c = 0; c < 3; ++c) { ln[c] = d[c] / den; ln[3 + c] = q1[c] + g.ctr[c]; }
 }

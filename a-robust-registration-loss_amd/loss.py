@@ -132,7 +132,7 @@ def generate_bbox(vertices):
 _pinned = {}
 
 
-def _uniform_rounds(B, n, rounds, device_rng=None):
+def _uniform_rounds(B, n, rounds, device_rng=None, dev=None):
     """The reference's CPU RNG stream: per round four `torch.rand(B, n)` draws in the order
     alpha1, u1, alpha2, u2 (code/loss.py:394-402), from torch's default CPU generator, so a
     `torch.manual_seed(s)` before the call selects the same candidates as in the reference.
@@ -143,11 +143,10 @@ def _uniform_rounds(B, n, rounds, device_rng=None):
     floats per step would cost more than the loss itself)."""
     if device_rng is not None:
         return torch.rand(rounds, 4, B, n, device=device_rng)
+    dev = dev if dev is not None else _ops.require_gpu()
     if B * n < 16:  # torch's scalar path for tiny tensors: keep the reference's call pattern
-        return torch.stack([torch.stack([torch.rand(B, n) for _ in range(4)]) for _ in range(rounds)]).to(
-            _ops.require_gpu())
-    dev = _ops.require_gpu()
-    key = (rounds, B, n)
+        return torch.stack([torch.stack([torch.rand(B, n) for _ in range(4)]) for _ in range(rounds)]).to(dev)
+    key = (rounds, B, n, dev.index)
     slot = _pinned.get(key)
     if slot is None:
         if len(_pinned) > 8:
@@ -157,8 +156,9 @@ def _uniform_rounds(B, n, rounds, device_rng=None):
         slot[1].synchronize()  # the previous upload from this buffer has left the host
     buf, ev = slot
     torch.rand(rounds, 4, B, n, out=buf)
-    out = buf.to(dev, non_blocking=True)
-    ev.record()
+    with torch.cuda.device(dev):
+        out = buf.to(dev, non_blocking=True)
+        ev.record()
     return out
 
 
@@ -182,7 +182,8 @@ def Random_uniform_distribution_lines_batch_efficient_resample(r, centers, N, ve
     fill in place, box2 = the (B, 6) AABB of `vertices2` from rrl_hip.ops.aabb when that cloud does
     not move."""
     B = r.shape[0]
-    rands = _uniform_rounds(B, N, rounds, _ops.require_gpu() if device_rng else None)
+    dev = _ops._home(out, vertices1, vertices2)  # the lines are built where the clouds live
+    rands = _uniform_rounds(B, N, rounds, dev if device_rng else None, dev)
     bb2 = box2 if box2 is not None else _ops.aabb(vertices2)
     lines, _ = _sample(rands, r, centers, _ops.aabb(vertices1), bb2, out)
     return lines if out is not None else lines.to(device)

@@ -32,12 +32,14 @@ _SIGS = {
     "rrl_set_scan_variant": [_I],
     "rrl_scan_timing_enable": [_I],
     "rrl_scan_timing_collect": [_P, _I],
+    "rrl_scan_counters": [_P],
     "rrl_rigid_apply_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "rrl_rigid_bwd_blocks": [_I],
     "rrl_rigid_apply_bwd": [_P] * 7 + [_I] * 4 + [_P],
     "rrl_chamfer_fwd": [_P] * 5 + [_I] * 3 + [_P],
     "rrl_chamfer_bwd": [_P] * 7 + [_I] * 3 + [_P],
     "rrl_aabb": [_P, _P, _I, _I, _P],
+    "rrl_box_accept": [_P, _P, _P, _P, _P, _I, _I, _P],
     "rrl_log_row": [_P, _P, _P, _P, _P, _c.c_longlong, _P, _P],
     "rrl_se3_exp": [_P, _P, _P, _I, _P],
     "rrl_se3_exp_bwd": [_P, _P, _P, _P, _I, _P],

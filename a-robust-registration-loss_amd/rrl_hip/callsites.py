@@ -32,16 +32,17 @@ def bounding_radius(tar_box, scale=1.0):
     return (torch.norm(tar_box[:, 0, :] - tar_box[:, -1, :], dim=-1, p=2) * scale).reshape(-1, 1)
 
 
-DEVICE_RNG = True  # draw the candidate lines' uniforms on the GPU (see draw_lines)
+DEVICE_RNG = False  # True: draw the candidate lines' uniforms on the GPU (opt-in, see draw_lines)
 
 
 def draw_lines(radius, centers, n_lines, moved_src, tar, device=None, device_rng=None):
     """The trainers' sampler call: (B, n_lines, 6) lines crossing both clouds' boxes.
     The reference draws 4 * 10 * B * n_lines uniforms from torch's CPU generator per call (3.2 M
     floats at B = 8, n = 10000: milliseconds of host time and a 13 MB upload, against 0.12 ms for
-    the loss).  Here they come from the GPU generator by default (same distribution, seeded by
-    torch.cuda.manual_seed); device_rng=False (or callsites.DEVICE_RNG = False) restores the
-    reference's CPU stream, reproducible under torch.manual_seed."""
+    the loss).  DEFAULT = the reference's behaviour: the CPU stream, reproducible under
+    torch.manual_seed exactly like the reference's trainers.  device_rng=True (or
+    callsites.DEVICE_RNG = True) draws them from the GPU generator instead (same distribution,
+    seeded by torch.cuda.manual_seed) -- the fast path for training loops."""
     import loss as _loss
     device = device or moved_src.device
     if device_rng is None:

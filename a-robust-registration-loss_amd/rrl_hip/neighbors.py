@@ -3,15 +3,13 @@ utils.farthest_point_sample, code/utils.py:275-296, and sklearn's KDTree).  SURV
 import numpy as np
 import torch
 
-from . import _lib
-from ._lib import check
-from .ops import _p, _stream, require_gpu
+from .ops import _home, _p, _run
 
 
 def fps(points, num_sample, start=None):
     """points (B, n, 3) tensor -> (B, S) int32 indices in farthest-point order.  `start` (B,)
     defaults to torch.randint(0, n, (B,)) from the CPU generator, like the reference."""
-    dev = require_gpu()
+    dev = _home(points)
     pts = points.detach().to(device=dev, dtype=torch.float32).contiguous()
     B, n, _ = pts.shape
     S = min(int(num_sample), n)
@@ -20,19 +18,19 @@ def fps(points, num_sample, start=None):
     st = start.to(device=dev, dtype=torch.int32).contiguous()
     out = torch.empty(B, S, dtype=torch.int32, device=dev)
     scratch = torch.empty(B, n, dtype=torch.float32, device=dev)
-    check(_lib.load().rrl_fps(_p(pts), _p(st), _p(out), _p(scratch), B, n, S, _stream()), "rrl_fps")
+    _run(dev, "rrl_fps", _p(pts), _p(st), _p(out), _p(scratch), B, n, S)
     return out
 
 
 def knn3(points, query_idx):
     """points (B, n, 3), query_idx (B, S) -> (B, S, 3) int32: the 3 nearest points (itself first)."""
-    dev = require_gpu()
+    dev = _home(points, query_idx)
     pts = points.detach().to(device=dev, dtype=torch.float32).contiguous()
     qi = query_idx.to(device=dev, dtype=torch.int32).contiguous()
     B, n, _ = pts.shape
     S = qi.shape[1]
     nn = torch.empty(B, S, 3, dtype=torch.int32, device=dev)
-    check(_lib.load().rrl_knn3(_p(pts), _p(qi), _p(nn), B, n, S, _stream()), "rrl_knn3")
+    _run(dev, "rrl_knn3", _p(pts), _p(qi), _p(nn), B, n, S)
     return nn
 
 

@@ -75,20 +75,57 @@ def _p(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
-def _stream():
-    # raw hipStream_t of torch's current stream (the Stream object wrapper costs ~15 us per call)
-    return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()))
+def _stream(dev=None):
+    # raw hipStream_t of torch's current stream ON THE DEVICE THE DATA LIVES ON (the Stream object
+    # wrapper costs ~15 us per call)
+    return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(
+        dev.index if dev is not None else torch.cuda.current_device()))
 
 
-def _prep(t, name, last=None):
-    """fp32, contiguous, on the GPU (callers pass slices / reshaped views)."""
+class _NoGuard:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
+_NOGUARD = _NoGuard()
+
+
+def _guard(dev):
+    """Context that makes `dev` the current HIP device for the C calls inside: a kernel must be
+    launched on a stream of the device that owns its pointers.  Free when it already is."""
+    if dev.index == torch.cuda.current_device():
+        return _NOGUARD
+    return torch.cuda.device(dev)
+
+
+def _run(dev, name, *args):
+    """One C entry point on `dev`'s current stream (every entry takes the stream last)."""
+    with _guard(dev):
+        check(getattr(_lib.load(), name)(*args, _stream(dev)), name)
+
+
+def _home(*tensors):
+    """The device an op runs on: that of its first GPU argument, else the current GPU."""
+    for t in tensors:
+        if isinstance(t, torch.Tensor) and t.is_cuda:
+            return t.device
+    return require_gpu()
+
+
+def _prep(t, name, last=None, dev=None):
+    """fp32, contiguous, on the op's GPU `dev` (callers pass slices / reshaped views and CPU
+    tensors; a tensor on another GPU is copied over)."""
     if not isinstance(t, torch.Tensor):
         raise TypeError(f"{name} must be a torch.Tensor")
     if last is not None and t.shape[-1] != last:
         raise ValueError(f"{name}: last dimension must be {last}, got {tuple(t.shape)}")
-    if t.is_cuda and t.dtype == torch.float32 and t.is_contiguous():
+    if t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and (dev is None or t.device == dev):
         return t.detach()  # the common case: nothing to convert
-    dev = require_gpu()
+    if dev is None:
+        dev = t.device if t.is_cuda else require_gpu()
     return t.detach().to(device=dev, dtype=torch.float32).contiguous()
 
 
@@ -156,29 +193,35 @@ def loss_forward_raw(tri1, tri2, line, rng=(1, 1, 5, 5), pool=False, mode="cull"
     M, L = tri2.shape[1], line.shape[1]
     G = 1 if pool else B
     s_m, s_n, e_m, e_n = _check_range(rng)
-    st = LossState(B, N, M, L, G, tri1.device)
-    s, ws, nb = _stream(), _p(st.ws), st.nbytes
-    if not staged:
-        check(lib.rrl_loss_forward_cached(_p(tri1), _p(tri2), _p(line), ws, nb, _p(st.loss), B, N, M,
-                                          L, s_m, s_n, e_m, e_n, int(pool), _MODES[mode], int(chunk),
-                                          _target_ws(target_from, B, N, M, L), s),
-              "rrl_loss_forward")
-        return st
-    check(lib.rrl_tri_prepare(_p(tri1), _p(tri2), ws, nb, B, N, M, L, s), "rrl_tri_prepare")
-    check(lib.rrl_line_tri_scan(_p(line), ws, nb, B, N, M, L, _MODES[mode], int(chunk), s),
-          "rrl_line_tri_scan")
-    check(lib.rrl_line_pair_dist(_p(tri1), _p(tri2), _p(line), ws, nb, B, N, M, L, s_m, s_n, e_m,
-                                 e_n, int(pool), s), "rrl_line_pair_dist")
-    check(lib.rrl_loss_reduce(ws, nb, _p(st.loss), B, N, M, L, s_m, s_n, e_m, e_n, int(pool), s),
-          "rrl_loss_reduce")
+    dev = tri1.device
+    if tri2.device != dev or line.device != dev:
+        raise ValueError("tri1, tri2 and line must live on the same GPU")
+    st = LossState(B, N, M, L, G, dev)
+    ws, nb = _p(st.ws), st.nbytes
+    with _guard(dev):
+        s = _stream(dev)
+        if not staged:
+            check(lib.rrl_loss_forward_cached(_p(tri1), _p(tri2), _p(line), ws, nb, _p(st.loss), B, N, M,
+                                              L, s_m, s_n, e_m, e_n, int(pool), _MODES[mode], int(chunk),
+                                              _target_ws(target_from, B, N, M, L), s),
+                  "rrl_loss_forward")
+            return st
+        check(lib.rrl_tri_prepare(_p(tri1), _p(tri2), ws, nb, B, N, M, L, s), "rrl_tri_prepare")
+        check(lib.rrl_line_tri_scan(_p(line), ws, nb, B, N, M, L, _MODES[mode], int(chunk), s),
+              "rrl_line_tri_scan")
+        check(lib.rrl_line_pair_dist(_p(tri1), _p(tri2), _p(line), ws, nb, B, N, M, L, s_m, s_n, e_m,
+                                     e_n, int(pool), s), "rrl_line_pair_dist")
+        check(lib.rrl_loss_reduce(ws, nb, _p(st.loss), B, N, M, L, s_m, s_n, e_m, e_n, int(pool), s),
+              "rrl_loss_reduce")
     return st
 
 
 class _IntersectionLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, points1, points2, line, rng, pool, mode, chunk, target_from=None):
-        tri1, tri2 = _prep(points1, "points1", 9), _prep(points2, "points2", 9)
-        ln = _prep(line, "line", 6)
+        dev = _home(points1, points2, line)
+        tri1, tri2 = _prep(points1, "points1", 9, dev), _prep(points2, "points2", 9, dev)
+        ln = _prep(line, "line", 6, dev)
         if tri1.dim() != 3 or tri2.dim() != 3 or ln.dim() != 3:
             raise ValueError("Input is wrong: points1/points2/line must be 3-D (B, n, c)")
         if not (tri1.shape[0] == tri2.shape[0] == ln.shape[0]):
@@ -213,8 +256,9 @@ class _IntersectionLoss(torch.autograd.Function):
         g = g_loss.detach().to(device=tri1.device, dtype=torch.float32).contiguous()
         g1 = torch.empty_like(tri1)  # zeroed by rrl_loss_backward
         g2 = torch.empty_like(tri2) if ctx.needs_input_grad[1] else None
-        check(lib.rrl_loss_backward(_p(tri1), _p(tri2), _p(st.ws), st.nbytes, _p(g), _p(g1), _p(g2),
-                                    B, N, M, L, int(ctx.pool), _stream()), "rrl_loss_backward")
+        with _guard(tri1.device):
+            check(lib.rrl_loss_backward(_p(tri1), _p(tri2), _p(st.ws), st.nbytes, _p(g), _p(g1), _p(g2),
+                                        B, N, M, L, int(ctx.pool), _stream(tri1.device)), "rrl_loss_backward")
         g1 = g1.to(ctx.in_devs[0]) if ctx.needs_input_grad[0] else None
         if g2 is not None:
             g2 = g2.to(ctx.in_devs[1])
@@ -236,11 +280,13 @@ def shard_payload(loss, gR=None, gt=None, state=None):
     to the LossState of the latest intersection_loss call."""
     st = state or _IntersectionLoss.last_state
     B, N, M, L, G = st.dims
-    out = torch.empty(14, dtype=torch.float32, device=loss.device)
-    gRc = gR.contiguous() if gR is not None else None
-    gtc = gt.contiguous() if gt is not None else None
-    check(_lib.load().rrl_shard_payload(_p(loss.detach()), _p(st.ws), st.nbytes, _p(gRc), _p(gtc),
-                                        _p(out), G, N, M, L, _stream()), "rrl_shard_payload")
+    dev = st.ws.device
+    out = torch.empty(14, dtype=torch.float32, device=dev)
+    gRc = _prep(gR, "gR", None, dev) if gR is not None else None
+    gtc = _prep(gt, "gt", None, dev) if gt is not None else None
+    with _guard(dev):
+        check(_lib.load().rrl_shard_payload(_p(_prep(loss, "loss", None, dev)), _p(st.ws), st.nbytes, _p(gRc),
+                                            _p(gtc), _p(out), G, N, M, L, _stream(dev)), "rrl_shard_payload")
     return out
 
 
@@ -251,9 +297,10 @@ class _RegistrationLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, src_tri, R, t, tar_tri, line, rng, transpose_r, mode, chunk, want_payload,
                 target_from=None):
-        src = _prep(src_tri, "src_tri", 9)
-        tri2, ln = _prep(tar_tri, "tar_tri", 9), _prep(line, "line", 6)
-        Rm, tv = _prep(R, "R").reshape(-1, 3, 3), _prep(t, "t").reshape(-1, 3)
+        dev = _home(src_tri, tar_tri, line, R, t)
+        src = _prep(src_tri, "src_tri", 9, dev)
+        tri2, ln = _prep(tar_tri, "tar_tri", 9, dev), _prep(line, "line", 6, dev)
+        Rm, tv = _prep(R, "R", None, dev).reshape(-1, 3, 3), _prep(t, "t", None, dev).reshape(-1, 3)
         if src.dim() != 3 or tri2.dim() != 3 or ln.dim() != 3:
             raise ValueError("src_tri/tar_tri/line must be 3-D (B, n, c)")
         B, N, _ = src.shape
@@ -271,12 +318,13 @@ class _RegistrationLoss(torch.autograd.Function):
             return out
         s_m, s_n, e_m, e_n = _check_range(rng)
         st = LossState(B, N, M, L, B, src.device)
-        check(_lib.load().rrl_registration_forward_cached(
-            _p(src), _p(Rm), _p(tv), _p(tri2), _p(ln), _p(st.ws), st.nbytes, _p(st.loss), B, N, M, L,
-            int(transpose_r), s_m, s_n, e_m, e_n, _MODES[mode], int(chunk),
-            _target_ws(target_from, B, N, M, L), _stream()), "rrl_registration_forward")
+        with _guard(dev):
+            check(_lib.load().rrl_registration_forward_cached(
+                _p(src), _p(Rm), _p(tv), _p(tri2), _p(ln), _p(st.ws), st.nbytes, _p(st.loss), B, N, M, L,
+                int(transpose_r), s_m, s_n, e_m, e_n, _MODES[mode], int(chunk),
+                _target_ws(target_from, B, N, M, L), _stream(dev)), "rrl_registration_forward")
         ctx.st, ctx.src, ctx.Rm, ctx.tri2 = st, src, Rm, tri2
-        ctx.meta = (int(transpose_r), bool(want_payload), R.shape, t.shape, src_tri.device)
+        ctx.meta = (int(transpose_r), bool(want_payload), R.shape, t.shape, src_tri.device, R.device, t.device)
         info, status = st.info, st.status
         ctx.mark_non_differentiable(info, status)
         ctx.set_materialize_grads(False)
@@ -288,9 +336,9 @@ class _RegistrationLoss(torch.autograd.Function):
         if g_loss is None or ctx.st is None:
             return (None,) * 11
         st, src, Rm, tri2 = ctx.st, ctx.src, ctx.Rm, ctx.tri2
-        tr, want_payload, Rshape, tshape, sdev = ctx.meta
+        tr, want_payload, Rshape, tshape, sdev, Rdev, tdev = ctx.meta
         B, N, M, L, _ = st.dims
-        g = g_loss if (g_loss.is_cuda and g_loss.is_contiguous()) else \
+        g = g_loss if (g_loss.device == src.device and g_loss.is_contiguous()) else \
             g_loss.to(device=src.device, dtype=torch.float32).contiguous()
         if not ctx.needs_input_grad[0] and not getattr(st, "gacc_used", False):
             out = st.gacc  # zeroed by the forward; the direct backward accumulates into it
@@ -299,13 +347,14 @@ class _RegistrationLoss(torch.autograd.Function):
             out = torch.empty(B * 12 + 14, dtype=torch.float32, device=src.device)
         gR, gt, payload = out[:B * 9], out[B * 9:B * 12], out[B * 12:B * 12 + 14]
         gsrc = torch.empty_like(src) if ctx.needs_input_grad[0] else None
-        check(_lib.load().rrl_registration_backward(
-            _p(src), _p(Rm), _p(tri2), _p(st.ws), st.nbytes, _p(st.loss), _p(g), _p(gsrc), _p(gR),
-            _p(gt), _p(payload) if want_payload else None, B, N, M, L, tr, _stream()),
-            "rrl_registration_backward")
+        with _guard(src.device):
+            check(_lib.load().rrl_registration_backward(
+                _p(src), _p(Rm), _p(tri2), _p(st.ws), st.nbytes, _p(st.loss), _p(g), _p(gsrc), _p(gR),
+                _p(gt), _p(payload) if want_payload else None, B, N, M, L, tr, _stream(src.device)),
+                "rrl_registration_backward")
         st.payload = payload if want_payload else None
-        return (gsrc.to(sdev) if gsrc is not None else None, gR.reshape(Rshape), gt.reshape(tshape),
-                None, None, None, None, None, None, None, None)
+        return (gsrc.to(sdev) if gsrc is not None else None, gR.reshape(Rshape).to(Rdev),
+                gt.reshape(tshape).to(tdev), None, None, None, None, None, None, None, None)
 
 
 def registration_loss(src_tri, R, t, tar_tri, line, rng=(1, 1, 5, 5), transpose_r=True,
@@ -338,18 +387,35 @@ def scan_timing_collect(max_n=1024):
     return [float(buf[i]) for i in range(n)]
 
 
+_counter_buf = None
+
+
+def scan_counters(on):
+    """Profiling hook: on=True -> subsequent culled scans run the instrumented kernel and add to a
+    fresh device buffer; on=False -> back to the plain kernel.  Returns the buffer (uint64-as-int64
+    [8], see include/rrl.h rrl_scan_counters) of the period that just ended, or None."""
+    global _counter_buf
+    prev = _counter_buf
+    if on:
+        _counter_buf = torch.zeros(8, dtype=torch.int64, device=require_gpu())
+        check(_lib.load().rrl_scan_counters(_p(_counter_buf)), "rrl_scan_counters")
+    else:
+        _counter_buf = None
+        check(_lib.load().rrl_scan_counters(None), "rrl_scan_counters")
+    return prev
+
+
 # ---------------------------------------------------------------------------------------
 class _RigidApply(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, R, t, transpose_r, channel_first):
-        xs = _prep(x, "x")
-        Rm, tv = _prep(R, "R"), _prep(t, "t")
+        dev = _home(x, R, t)
+        xs = _prep(x, "x", None, dev)
+        Rm, tv = _prep(R, "R", None, dev), _prep(t, "t", None, dev)
         B = Rm.shape[0]
         n = xs.numel() // (3 * B)
         y = torch.empty_like(xs)
-        check(_lib.load().rrl_rigid_apply_fwd(_p(xs), _p(Rm), _p(tv), _p(y), B, n,
-                                              int(transpose_r), int(channel_first), _stream()),
-              "rrl_rigid_apply_fwd")
+        _run(dev, "rrl_rigid_apply_fwd", _p(xs), _p(Rm), _p(tv), _p(y), B, n, int(transpose_r), int(channel_first))
         ctx.save_for_backward(xs, Rm)
         ctx.meta = (B, n, int(transpose_r), int(channel_first), x.device, R.device, t.device,
                     R.shape, t.shape)
@@ -366,8 +432,7 @@ class _RigidApply(torch.autograd.Function):
         gt = torch.empty(B, 3, device=xs.device)
         nblk = lib.rrl_rigid_bwd_blocks(n)
         partial = torch.empty(B, max(nblk, 1), 12, device=xs.device)
-        check(lib.rrl_rigid_apply_bwd(_p(xs), _p(Rm), _p(g), _p(gx), _p(gR), _p(gt), _p(partial),
-                                      B, n, tr, cf, _stream()), "rrl_rigid_apply_bwd")
+        _run(xs.device, "rrl_rigid_apply_bwd", _p(xs), _p(Rm), _p(g), _p(gx), _p(gR), _p(gt), _p(partial), B, n, tr, cf)
         return (gx.to(xdev) if gx is not None else None, gR.reshape(Rshape).to(Rdev),
                 gt.reshape(tshape).to(tdev), None, None)
 
@@ -393,7 +458,7 @@ class _Se3Exp(torch.autograd.Function):
         B = x.shape[0]
         R = torch.empty(B, 3, 3, device=x.device)
         T = torch.empty(B, 3, device=x.device)
-        check(_lib.load().rrl_se3_exp(_p(x), _p(R), _p(T), B, _stream()), "rrl_se3_exp")
+        _run(x.device, "rrl_se3_exp", _p(x), _p(R), _p(T), B)
         ctx.save_for_backward(x)
         ctx.meta = (xi.shape, xi.device)
         return R, T
@@ -403,10 +468,10 @@ class _Se3Exp(torch.autograd.Function):
         (x,) = ctx.saved_tensors
         shape, dev = ctx.meta
         B = x.shape[0]
-        gRc = gR.contiguous() if gR is not None else None
-        gTc = gT.contiguous() if gT is not None else None
+        gRc = _prep(gR, "gR", None, x.device) if gR is not None else None
+        gTc = _prep(gT, "gT", None, x.device) if gT is not None else None
         gxi = torch.empty(B, 6, device=x.device)
-        check(_lib.load().rrl_se3_exp_bwd(_p(x), _p(gRc), _p(gTc), _p(gxi), B, _stream()), "rrl_se3_exp_bwd")
+        _run(x.device, "rrl_se3_exp_bwd", _p(x), _p(gRc), _p(gTc), _p(gxi), B)
         return gxi.reshape(shape).to(dev)
 
 
@@ -419,15 +484,16 @@ def adam_gated(param, grad, m, v, state, lr, gate=None, betas=(0.9, 0.999), eps=
     """In-place torch.optim.Adam step on `param` (fp32, contiguous, GPU) with device-side scalars:
     state (1,) = step count, lr (1,) ; skipped when gate (int32 tensor) has gate[0] <= 0."""
     n = param.numel()
-    check(_lib.load().rrl_adam_gated(_p(param), _p(grad), _p(m), _p(v), _p(state), _p(lr), _p(gate), n,
-                                     float(betas[0]), float(betas[1]), float(eps), _stream()), "rrl_adam_gated")
+    _run(param.device, "rrl_adam_gated", _p(param), _p(grad), _p(m), _p(v), _p(state), _p(lr), _p(gate), n,
+         float(betas[0]), float(betas[1]), float(eps))
 
 
 # ---------------------------------------------------------------------------------------
 class _Chamfer(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, y):
-        xs, ys = _prep(x, "points_x", 3), _prep(y, "points_y", 3)
+        dev = _home(x, y)
+        xs, ys = _prep(x, "points_x", 3, dev), _prep(y, "points_y", 3, dev)
         if xs.dim() != 3 or ys.dim() != 3 or xs.shape[0] != ys.shape[0]:
             raise ValueError("chamfer_dist expects (B, M, 3) and (B, N, 3)")
         B, N, _ = xs.shape
@@ -435,8 +501,7 @@ class _Chamfer(torch.autograd.Function):
         bx = torch.empty(B, N, dtype=torch.int64, device=xs.device)
         by = torch.empty(B, M, dtype=torch.int64, device=xs.device)
         val = torch.empty(1, device=xs.device)
-        check(_lib.load().rrl_chamfer_fwd(_p(xs), _p(ys), _p(bx), _p(by), _p(val), B, N, M,
-                                          _stream()), "rrl_chamfer_fwd")
+        _run(dev, "rrl_chamfer_fwd", _p(xs), _p(ys), _p(bx), _p(by), _p(val), B, N, M)
         ctx.save_for_backward(xs, ys, bx, by)
         ctx.devs = (x.device, y.device)
         return val.reshape(()).to(x.device)
@@ -449,8 +514,7 @@ class _Chamfer(torch.autograd.Function):
         g = gval.detach().to(device=xs.device, dtype=torch.float32).reshape(1).contiguous()
         gx = torch.zeros_like(xs) if ctx.needs_input_grad[0] else None
         gy = torch.zeros_like(ys) if ctx.needs_input_grad[1] else None
-        check(_lib.load().rrl_chamfer_bwd(_p(xs), _p(ys), _p(bx), _p(by), _p(g), _p(gx), _p(gy), B,
-                                          N, M, _stream()), "rrl_chamfer_bwd")
+        _run(xs.device, "rrl_chamfer_bwd", _p(xs), _p(ys), _p(bx), _p(by), _p(g), _p(gx), _p(gy), B, N, M)
         return (gx.to(ctx.devs[0]) if gx is not None else None,
                 gy.to(ctx.devs[1]) if gy is not None else None)
 
@@ -463,14 +527,14 @@ def chamfer(x, y):
 def dense_scan(tri, line):
     """(norm_d (B*L, N, 3) float32, label (B, L, N) bool, status (1,) int32) -- the dense tables of
     code/loss.py:68-112 (rrl_dense_scan); B*L*N*13 bytes of output, so mind the sizes."""
-    t, ln = _prep(tri, "point_neis", 9), _prep(line, "line", 6)
+    dev = _home(tri, line)
+    t, ln = _prep(tri, "point_neis", 9, dev), _prep(line, "line", 6, dev)
     B, N, _ = t.shape
     L = ln.shape[1]
     norm_d = torch.empty(B * L, N, 3, dtype=torch.float32, device=t.device)
     label = torch.empty(B, L, N, dtype=torch.uint8, device=t.device)
     status = torch.empty(1, dtype=torch.int32, device=t.device)
-    check(_lib.load().rrl_dense_scan(_p(t), _p(ln), _p(norm_d), _p(label), _p(status), B, N, L,
-                                     _stream()), "rrl_dense_scan")
+    _run(dev, "rrl_dense_scan", _p(t), _p(ln), _p(norm_d), _p(label), _p(status), B, N, L)
     return norm_d, label.view(torch.bool), status
 
 
@@ -479,43 +543,60 @@ def aabb(v):
     vs = _prep(v, "vertices", 3)
     B, n, _ = vs.shape
     out = torch.empty(B, 6, device=vs.device)
-    check(_lib.load().rrl_aabb(_p(vs), _p(out), B, n, _stream()), "rrl_aabb")
+    _run(vs.device, "rrl_aabb", _p(vs), _p(out), B, n)
     return out
+
+
+def box_accept(lines, aabb1, aabb2):
+    """The resampler's accept test on given lines (B, n, 6) against two AABBs (B, 6) each (ops.aabb):
+    returns (mask (B, n) uint8 -- bit 0 / 1: box 1 / 2 crossed by the reference's sub-area test, bit 2:
+    the conservative slab pre-test passes; accepted == (mask & 3) == 3 --, hits (B, n, 2) int32 =
+    the reference's label1, label2 counts)."""
+    dev = _home(lines, aabb1, aabb2)
+    ln = _prep(lines, "lines", 6, dev)
+    b1, b2 = _prep(aabb1, "aabb1", 6, dev), _prep(aabb2, "aabb2", 6, dev)
+    B, n, _ = ln.shape
+    mask = torch.empty(B, n, dtype=torch.uint8, device=dev)
+    hits = torch.empty(B, n, 2, dtype=torch.int32, device=dev)
+    _run(dev, "rrl_box_accept", _p(ln), _p(b1), _p(b2), _p(mask), _p(hits), B, n)
+    return mask, hits
 
 
 def sample_lines(rands, r, centers, aabb1, aabb2, out=None):
     """rands (rounds, 4, B, n) uniform draws -> lines (B, n, 6), filled (B,) int32.
     out: a contiguous fp32 (B, n, 6) GPU tensor to write the lines into (no extra copy)."""
-    rd = _prep(rands, "rands")
+    dev = _home(out, rands, aabb1, aabb2)
+    rd = _prep(rands, "rands", None, dev)
     rounds, four, B, n = rd.shape
     assert four == 4
-    rr = _prep(r, "r").reshape(B)
-    cc = _prep(centers, "centers").reshape(B, 3)
+    rr = _prep(r, "r", None, dev).reshape(B)
+    cc = _prep(centers, "centers", None, dev).reshape(B, 3)
+    aabb1 = _prep(aabb1, "aabb1", 6, dev) if aabb1 is not None else None
+    aabb2 = _prep(aabb2, "aabb2", 6, dev) if aabb2 is not None else None
     if out is None:
         lines = torch.empty(B, n, 6, device=rd.device)
     else:
-        if not (out.is_cuda and out.dtype == torch.float32 and out.is_contiguous() and out.numel() == B * n * 6):
+        if not (out.is_cuda and out.device == dev and out.dtype == torch.float32 and out.is_contiguous()
+                and out.numel() == B * n * 6):
             raise ValueError("out must be a contiguous fp32 GPU tensor of B * n * 6 elements")
         lines = out
     filled = torch.empty(B, dtype=torch.int32, device=rd.device)
     scratch = torch.empty(B * max(rounds, 1) * ((n + 1023) // 1024) * 32, dtype=torch.int32, device=rd.device)
-    check(_lib.load().rrl_sample_lines(_p(rd), _p(rr), _p(cc), _p(aabb1), _p(aabb2), _p(lines),
-                                       _p(filled), _p(scratch), B, n, rounds, _stream()), "rrl_sample_lines")
+    _run(dev, "rrl_sample_lines", _p(rd), _p(rr), _p(cc), _p(aabb1), _p(aabb2), _p(lines), _p(filled), _p(scratch),
+         B, n, rounds)
     return lines, filled
 
 
 def rigid_apply_into(x, R, t, out, transpose_r=False):
     """out[...] = x R + t (or x R^T + t) without autograd and without a temporary: x, out contiguous
     fp32 (B, n, 3) on the GPU."""
-    Rm, tv = _prep(R, "R").reshape(-1, 3, 3), _prep(t, "t").reshape(-1, 3)
+    Rm, tv = _prep(R, "R", None, x.device).reshape(-1, 3, 3), _prep(t, "t", None, x.device).reshape(-1, 3)
     B = Rm.shape[0]
     n = x.numel() // (3 * B)
-    check(_lib.load().rrl_rigid_apply_fwd(_p(x), _p(Rm), _p(tv), _p(out), B, n, int(transpose_r), 0, _stream()),
-          "rrl_rigid_apply_fwd")
+    _run(x.device, "rrl_rigid_apply_fwd", _p(x), _p(Rm), _p(tv), _p(out), B, n, int(transpose_r), 0)
     return out
 
 
 def log_row(loss, value, info, table, cursor, row=None):
     """table[cursor[0]] = (loss[0], value[0], info[0] > 0); cursor[0] += 1 -- one launch, on the device."""
-    check(_lib.load().rrl_log_row(_p(loss), _p(value), _p(info), _p(table), _p(cursor), table.shape[0], _p(row),
-                                  _stream()), "rrl_log_row")
+    _run(table.device, "rrl_log_row", _p(loss), _p(value), _p(info), _p(table), _p(cursor), table.shape[0], _p(row))

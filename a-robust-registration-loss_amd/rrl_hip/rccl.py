@@ -32,9 +32,22 @@ def _load_rccl():
     lib.ncclAllReduce.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int,
                                   ctypes.c_void_p, ctypes.c_void_p]
     lib.ncclCommDestroy.argtypes = [ctypes.c_void_p]
-    for f in (lib.ncclGetUniqueId, lib.ncclCommInitRank, lib.ncclAllReduce, lib.ncclCommDestroy):
+    lib.ncclCommCount.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]
+    lib.ncclCommUserRank.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]
+    lib.ncclGetVersion.argtypes = [ctypes.POINTER(ctypes.c_int)]
+    for f in (lib.ncclGetUniqueId, lib.ncclCommInitRank, lib.ncclAllReduce, lib.ncclCommDestroy,
+              lib.ncclCommCount, lib.ncclCommUserRank, lib.ncclGetVersion):
         f.restype = ctypes.c_int
     return lib
+
+
+def _all_ok(ok, device):
+    """Collective AND over the ranks of the default process group: every rank takes the same branch
+    afterwards (a set-up step that fails on one rank must fail on all, or the ranks end up issuing
+    different collectives and hang)."""
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return bool(flag.item())
 
 
 class RcclReducer:
@@ -42,18 +55,33 @@ class RcclReducer:
     overlapping whatever the compute stream does next; finish(): the last submitted step's sums."""
 
     def __init__(self, device):
-        self.lib = _load_rccl()
+        """COLLECTIVE over the default process group: every rank must call it, and it either
+        succeeds on all ranks or raises on all ranks (each local step that can fail is followed by
+        an all-reduced success flag before the next collective is issued)."""
         rank, world = dist.get_rank(), dist.get_world_size()
-        uid = _UniqueId()
-        if rank == 0 and self.lib.ncclGetUniqueId(ctypes.byref(uid)) != 0:
-            raise RuntimeError("ncclGetUniqueId failed")
-        t = torch.frombuffer(bytearray(bytes(uid.internal)), dtype=torch.uint8).clone().to(device)
-        dist.broadcast(t, src=0)  # the id travels over the existing process group
-        ctypes.memmove(ctypes.byref(uid), bytes(t.cpu().numpy().tobytes()), 128)
         self.comm = ctypes.c_void_p()
+        self.lib, err = None, None
+        try:
+            self.lib = _load_rccl()
+        except (OSError, AttributeError) as exc:
+            err = exc
+        if not _all_ok(self.lib is not None, device):
+            raise RuntimeError(f"librccl could not be bound on every rank ({err})")
+        uid = _UniqueId()
+        got = rank != 0 or self.lib.ncclGetUniqueId(ctypes.byref(uid)) == 0
+        # the id travels over the existing process group together with rank 0's success flag: the
+        # broadcast is issued by every rank whether or not ncclGetUniqueId worked
+        t = torch.frombuffer(bytearray(bytes(uid.internal) + bytes([1 if got else 0])), dtype=torch.uint8).clone().to(device)
+        dist.broadcast(t, src=0)
+        raw = bytes(t.cpu().numpy().tobytes())
+        if raw[128] != 1:
+            raise RuntimeError("ncclGetUniqueId failed on rank 0")
+        ctypes.memmove(ctypes.byref(uid), raw[:128], 128)
         with torch.cuda.device(device):
-            if self.lib.ncclCommInitRank(ctypes.byref(self.comm), world, uid, rank) != 0:
-                raise RuntimeError("ncclCommInitRank failed")
+            rc = self.lib.ncclCommInitRank(ctypes.byref(self.comm), world, uid, rank)
+        if not _all_ok(rc == 0, device):
+            self.close()
+            raise RuntimeError(f"ncclCommInitRank failed on some rank (here: {rc})")
         self.stream = torch.cuda.Stream(device=device)
         self.buf = torch.zeros(16, dtype=torch.float32, device=device)
         self.out = torch.zeros(14, dtype=torch.float32, device=device)
@@ -128,6 +156,16 @@ class RcclReducer:
         self.pending = False
         return self.out
 
+    def evidence(self):
+        """What the communicator itself reports: {"nranks", "rank", "version"} (ncclCommCount,
+        ncclCommUserRank, ncclGetVersion) -- bench.py prints it so that a run record shows how many
+        ranks RCCL saw."""
+        n, r, v = ctypes.c_int(-1), ctypes.c_int(-1), ctypes.c_int(-1)
+        self.lib.ncclCommCount(self.comm, ctypes.byref(n))
+        self.lib.ncclCommUserRank(self.comm, ctypes.byref(r))
+        self.lib.ncclGetVersion(ctypes.byref(v))
+        return {"nranks": n.value, "rank": r.value, "version": v.value}
+
     def close(self):
         if self.comm:
             torch.cuda.synchronize()
@@ -136,13 +174,22 @@ class RcclReducer:
 
 
 def make_reducer(device):
-    """RcclReducer when a NCCL(=RCCL) process group is up and the direct binding initialises,
-    else the torch.distributed based PayloadReducer."""
+    """RcclReducer when a NCCL(=RCCL) process group is up and the direct binding initialises ON
+    EVERY RANK, else the torch.distributed based PayloadReducer on every rank.  Collective: all
+    ranks must call it.  RRL_DIRECT_RCCL=0 (set identically on all ranks) skips the binding."""
     if dist.is_initialized() and dist.get_backend() == "nccl" and os.environ.get("RRL_DIRECT_RCCL", "1") != "0":
         try:
-            return RcclReducer(device)
-        except Exception as exc:  # any set-up problem: keep the portable path
+            return RcclReducer(device)   # raises on all ranks or on none
+        except RuntimeError as exc:
             import sys
-            print(f"[rrl_hip.rccl] direct RCCL unavailable ({type(exc).__name__}: {exc}); using torch.distributed",
-                  file=sys.stderr)
+            print(f"[rrl_hip.rccl] direct RCCL unavailable ({exc}); using torch.distributed", file=sys.stderr)
     return PayloadReducer(device)
+
+
+def agree(ok, device):
+    """all-ranks AND of a local success flag (True without a process group): lets a caller choose
+    between two collective patterns -- e.g. the in-graph all-reduce vs the overlapped one -- the
+    same way on every rank."""
+    if not dist.is_initialized():
+        return bool(ok)
+    return _all_ok(ok, device)

@@ -2,20 +2,31 @@
 """bench.py -- BASELINE.json's metric on MI355X: point-pairs/sec for the intersected-line loss
 fwd+bwd at B=8, N=M=4096 (L=10000 lines, the RPM call-site default), per GPU.
 
-One "step" = the fused training op forward + backward, six launches: triangle records (rigid
-apply of the source, thresholds, state clearing) -> cell sort + sphere tree -> tree-culled
-line<->triangle scan of both clouds (K1) -> per-line distances (K2) -> median + Welsch reduce
-(K3+K4) -> direct backward to (dR, dT) with the 14-float shard payload (K5') -> one fused
-all-reduce of [loss sum, valid count, sum dR, sum dT] over ranks (asynchronous: it overlaps the
-next step's kernels; every reduction completes inside the timed region).  Inputs are resident in HBM before the
-timed region; line sampling (K8) and Chamfer (K7) are timed separately and reported as extras.
-pairs per step = B * L * 3 * (N + M) per GPU; value = all ranks' pairs / max
-time over ranks.  Weak scaling: B=8 per GPU (config 3 of BASELINE.json is B=64 over 8 GPUs).
+One "step" (the timed one) = the fused training op forward + backward, six launches: triangle
+records (rigid apply of the source, thresholds, state clearing) -> cell sort + sphere tree ->
+tree-culled line<->triangle scan of both clouds (K1) -> per-line distances (K2) -> median + Welsch
+reduce (K3+K4) -> backward to (dR, dT) with the 14-float shard payload (K5') -> one all-reduce of
+[loss sum, valid count, sum dR, sum dT] over the ranks (a node of the captured step).  Inputs are
+resident in HBM before the timed region.  pairs per step = B * L * 3 * (N + M) per GPU (SURVEY.md
+§8d) -- DENSE-EQUIVALENT pairs: the culled scan decides every one of them exactly but evaluates
+~1 %; value = all ranks' pairs / max time over ranks.
+
+Measured in the same run, outside the timed region, and printed in the same JSON line:
+  * `variants.points1_grad`: SURVEY §8(d)'s definition through the DROP-IN callables chained by
+    autograd -- rigid apply -> loss -> backward to points1.grad (B, N, 9) and on to (dR, dT);
+  * `roofline`: the strict scan (every pair evaluated: the kernel that performs all 18 counted
+    flops per pair) against the non-FMA fp32 VALU peak, HIP-event timed on the launch stream; and
+    for the default culled kernel its launch time, the work it EXECUTED (in-kernel counters of an
+    instrumented instantiation, rrl_scan_counters) and the ratio to the dense work;
+  * `cpu_baseline`: the C/OpenMP port and the reference-equivalent torch-eager formulation on the
+    host cores, on bounded samples of the same workload.
+Weak scaling by default (B = 8 per GPU); --global-batch 64 fixes the total (BASELINE configs[2]).
 
     python bench.py [--gpus N --steps K --warmup W]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -35,6 +46,20 @@ FLOPS_PER_PAIR = 18          # 3 sub, 3+3+1 mul, 2+2+1 add, 1 su
 VALU_PEAK_TFLOPS = 78.6      # 157.3 TFLOP/s fp32 vector peak counts FMA as 2 flops; this path is
                              # contraction-off mul/add (one flop per lane-op) -> half of it
 HBM_PEAK_GBS = 8000.0
+# arithmetic of one test of the culled scan, in lane-ops (an FMA counted once, like every VALU op):
+# sphere test = 3 sub + 3 (dot) + 3 (|a|^2) + 2 fma + add + mul; exact test = dist_sq's 16;
+# a resolved candidate = points 1 and 2; a fallback pair = 3 points
+OPS_SPHERE, OPS_EXACT, OPS_CAND, OPS_FALLBACK = 13, 16, 32, 48
+
+
+def csrc_sha():
+    """Hash of the kernel sources: profile-derived numbers (HBM traffic from PMC passes) are only
+    attached to the line when they were collected for exactly this build."""
+    h = hashlib.sha256()
+    d = os.path.join(PKG, "csrc")
+    for f in sorted(os.listdir(d)) + ["../../include/rrl.h"]:
+        h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def make_workload(B, N, M, L, rank, dev):
@@ -62,10 +87,14 @@ def make_workload(B, N, M, L, rank, dev):
     return w
 
 
-def cpu_baseline(N, M, L, budget_s=12.0):
-    """The CPU oracle (C, OpenMP over lines, all host cores) on a bounded sample of the same
-    workload: whole samples of N=M=4096, L=10000, fwd+bwd, until ~budget_s seconds are spent."""
-    from oracle import rrl_oracle
+def cpu_baseline(N, M, L, budget_s=12.0, eager_budget_s=8.0):
+    """Two CPU legs on bounded samples of the same workload, host cores of this box:
+    (a) oracle/rrl_oracle.c (C, OpenMP over lines): whole samples of N=M, L lines, fwd+bwd, until
+        ~budget_s seconds are spent -- the headline `cpu_baseline` (kind "port");
+    (b) oracle/torch_eager.py: the reference's own op sequence (materialised (L, N, 3, 3)
+        temporaries, per-bucket gathers, autograd backward) in torch CPU ops on a line subset of one
+        sample sized to ~eager_budget_s -- reported inside as `torch_eager`."""
+    from oracle import rrl_oracle, torch_eager
     from rrl_hip import synth
     rrl_oracle.build()
     cores = os.cpu_count() or 1
@@ -75,13 +104,38 @@ def cpu_baseline(N, M, L, budget_s=12.0):
     done, spent = 0, 0.0
     while spent < budget_s:
         t0 = time.perf_counter()
-        rrl_oracle.loss(pr["src_tri"], pr["tar_tri"], lines, want_grad=True)
+        ref = rrl_oracle.loss(pr["src_tri"], pr["tar_tri"], lines, want_grad=True)
         spent += time.perf_counter() - t0
         done += 1
     pairs = done * L * 3 * (N + M)
-    return {"value": pairs / spent, "unit": "point-pairs/s", "cores": cores, "kind": "port",
-            "sample": f"{done} evaluation(s) of one N=M={N}, L={L} sample, loss fwd+bwd, oracle/rrl_oracle.c "
-                      f"with OpenMP on {cores} threads, {spent:.1f} s"}
+    out = {"value": pairs / spent, "unit": "point-pairs/s", "cores": cores, "kind": "port",
+           "sample": f"{done} evaluation(s) of one N=M={N}, L={L} sample, loss fwd+bwd, oracle/rrl_oracle.c "
+                     f"with OpenMP on {cores} threads, {spent:.1f} s"}
+    try:
+        torch.set_num_threads(cores)
+        t2 = torch.from_numpy(pr["tar_tri"])
+        ln = torch.from_numpy(lines)
+
+        def run(nl):
+            t1 = torch.from_numpy(pr["src_tri"]).clone().requires_grad_(True)
+            t0 = time.perf_counter()
+            val = torch_eager.loss(t1, t2, ln[:nl], max_lines=256)
+            if val is not None:
+                val.backward()
+            return time.perf_counter() - t0, val
+        probe = min(L, 256)
+        tp, _ = run(probe)
+        nl = int(max(probe, min(L, probe * eager_budget_s / max(tp, 1e-3))))
+        te, val = run(nl)
+        out["torch_eager"] = {
+            "value": nl * 3 * (N + M) / te, "unit": "point-pairs/s", "cores": cores, "kind": "port",
+            "sample": f"one N=M={N} sample, first {nl} of its {L} lines, loss fwd+bwd by autograd, "
+                      f"oracle/torch_eager.py (the reference's materialising op sequence, code/loss.py:68-232) "
+                      f"with torch.set_num_threads({cores}), {te:.1f} s",
+            "loss_full_sample_c_port": float(ref["loss"]) if ref["loss"] is not None else None}
+    except Exception as exc:  # the C leg stands on its own
+        out["torch_eager"] = {"error": f"{type(exc).__name__}: {exc}"}
+    return out
 
 
 def main():
@@ -89,12 +143,20 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)  # 80 us each: the closing fence costs ~3 us/step at 30
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--batch", type=int, default=8, help="samples per GPU")
+    ap.add_argument("--batch", type=int, default=8, help="samples per GPU (weak scaling)")
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="total samples over all GPUs (strong scaling, BASELINE configs[2]: 64); overrides --batch")
     ap.add_argument("--points", type=int, default=4096)
     ap.add_argument("--lines", type=int, default=10000)
     ap.add_argument("--mode", default=os.environ.get("RRL_SCAN_MODE", "cull"))
+    ap.add_argument("--reducer", default=os.environ.get("RRL_REDUCER", "auto"),
+                    choices=["auto", "inline", "overlap", "torch"],
+                    help="all-reduce of the shard payload: a node of the captured step (inline), overlapped "
+                         "with the next step on a second stream (overlap), torch.distributed (torch); auto "
+                         "measures inline vs overlap during warm-up when there is more than one rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--no-extras", action="store_true", help="skip the strict / counter / drop-in passes")
     args = ap.parse_args()
 
     from rrl_hip import dist as rdist, ops
@@ -104,52 +166,60 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    B, N, M, L = args.batch, args.points, args.points, args.lines
+    strong = args.global_batch > 0
+    if strong:
+        lo, hi = rdist.shard_bounds(args.global_batch, rank, world)
+        B = hi - lo
+        if B <= 0:
+            raise SystemExit("--global-batch smaller than the number of ranks")
+    else:
+        B = args.batch
+    N, M, L = args.points, args.points, args.lines
     w = make_workload(B, N, M, L, rank, dev)
     ones = torch.ones(B, device=dev)
 
-    def local_step():
+    def local_step(mode=args.mode):
         # transform + loss forward, backward to (dR, dt), and the 14-float shard payload
         w["R"].grad = w["T"].grad = None
         loss, info, _ = ops.registration_loss(w["tri1"], w["R"], w["T"], w["tri2"], w["lines"],
-                                              (1, 1, 5, 5), transpose_r=True, mode=args.mode,
+                                              (1, 1, 5, 5), transpose_r=True, mode=mode,
                                               want_payload=True)
         torch.autograd.backward([loss], [ones])  # d(sum of losses): no reduction kernel needed
         return ops.last_state().payload
 
     from rrl_hip import rccl as rrccl
-    reducer = rrccl.make_reducer(dev)
-    direct = hasattr(reducer, "allreduce_inline")  # direct RCCL binding available
+    if args.reducer == "torch":
+        os.environ["RRL_DIRECT_RCCL"] = "0"
+    reducer = rrccl.make_reducer(dev)   # collective: the same class on every rank
+    direct = hasattr(reducer, "allreduce_inline")
+    evidence = reducer.evidence() if direct else None
 
-    graphed, inline = None, False
-    if not args.no_graph:
-        from rrl_hip.graph import GraphedStep
-        if direct and os.environ.get("RRL_AR_INLINE", "1") != "0":
-            try:  # the all-reduce as the last node of the captured step (in place on the payload)
-                graphed = GraphedStep(lambda: reducer.allreduce_inline(local_step()))
-                inline = True
-            except Exception as exc:
-                print(f"[bench] capture with in-graph all-reduce failed ({type(exc).__name__}: {exc})", file=sys.stderr)
-                graphed = None
-        if graphed is None:
+    from rrl_hip.graph import GraphedStep
+
+    def build(inline):
+        """(callable step, finish) for one all-reduce placement; capture success is agreed on by
+        all ranks, so nobody replays a graph with a collective the others do not have."""
+        g, err = None, None
+        if not args.no_graph:
             try:
-                graphed = GraphedStep(local_step)
-            except Exception as exc:  # capture unsupported: fall back to eager launches
-                print(f"[bench] graph capture failed ({type(exc).__name__}: {exc}); eager", file=sys.stderr)
-                graphed = None
-
-    last = [None]
-
-    def step():
-        # one 14-float all-reduce per step (N > 1): a node of the captured step when the direct
-        # RCCL binding is up; otherwise issued asynchronously so that it overlaps the next step's
-        # kernels (waited for before its buffer is reused and at the end)
+                g = GraphedStep((lambda: reducer.allreduce_inline(local_step())) if inline else local_step)
+            except Exception as exc:
+                err = exc
+            if not rrccl.agree(g is not None, dev):
+                if rank == 0:
+                    print(f"[bench] graph capture failed on some rank ({err}); eager launches", file=sys.stderr)
+                g = None
+                if inline:
+                    return None
+        last = [None]
         if inline:
-            last[0] = graphed()
-            return last[0]
-        payload = graphed() if graphed is not None else local_step()
-        reducer.submit(payload)
-        return payload
+            def step():
+                last[0] = g() if g is not None else reducer.allreduce_inline(local_step())
+            return g, step, (lambda: last[0])
+
+        def step():
+            reducer.submit(g() if g is not None else local_step())
+        return g, step, reducer.finish
 
     def fence():
         torch.cuda.synchronize()
@@ -157,96 +227,204 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed(step, n):
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step()
+        return t0
+
+    # ---- choose the all-reduce placement (identically on every rank)
+    choice_note = None
+    cands = []
+    if direct and args.reducer in ("auto", "inline"):
+        c = build(True)
+        if c is not None:
+            cands.append(("inline", c))
+    if args.reducer in ("overlap", "torch") or (args.reducer == "auto" and world > 1) or not cands:
+        cands.append(("overlap", build(False)))
+    if len(cands) > 1:  # measure both during warm-up; max over ranks -> the same decision everywhere
+        probe = {}
+        for name, (g, step, finish) in cands:
+            for _ in range(5):
+                step()
+            t0 = timed(step, 20)
+            finish()
+            fence()
+            tt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            probe[name] = float(tt.item()) / 20 * 1e3
+        best = min(probe, key=probe.get)
+        choice_note = {k: round(v, 4) for k, v in probe.items()}
+        cands = [(n, c) for n, c in cands if n == best]
+    placement, (graphed, step, finish) = cands[0]
+
     for _ in range(args.warmup):
         step()
-    fence()
-    if graphed is None:
-        ops.scan_timing(4)  # HIP events around every 4th scan launch, on the launch stream
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step()
-    payload = last[0] if inline else reducer.finish()  # the last reduction is inside the timed region
+    finish()
+    t0 = timed(step, args.steps)
+    payload = finish()  # the last reduction is inside the timed region
     fence()
     dt = time.perf_counter() - t0
-    if graphed is not None:
-        # events cannot be read back from inside a replayed graph: time the dominant kernel in an
-        # eager pass of the same step right after the timed region
-        ops.scan_timing(1)
-        for i in range(min(args.steps, 20)):
-            local_step()
-        torch.cuda.synchronize()
-    scan_times = ops.scan_timing_collect()
-    ops.scan_timing(0)
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if dist.is_initialized():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
-    scan_ms = float(np.mean(scan_times))
+    payload = payload.clone()
 
-    # extras, outside the timed region
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    for _ in range(5):
-        cd = Lmod.chamfer_dist(w["src"], w["tar"])
-    torch.cuda.synchronize()
-    chamfer_ms = (time.perf_counter() - t1) / 5 * 1e3
+    # ---- everything below is outside the timed region -----------------------------------------
+    def scan_launch_ms(mode, n):
+        """HIP events around the scan launch of an eager pass of the same step (events cannot be
+        read back from inside a replayed graph), on the launch stream."""
+        ops.scan_timing(1)
+        for _ in range(n):
+            local_step(mode)
+        torch.cuda.synchronize()
+        t = ops.scan_timing_collect()
+        ops.scan_timing(0)
+        return float(np.mean(t[1:] if len(t) > 2 else t)), len(t)
+
+    extras, variants, roof_default, roof_dense = {}, {}, None, None
+    pairs_step = B * L * 3 * (N + M)
+    dense_flops = FLOPS_PER_PAIR * pairs_step
+    do_extras = rank == 0 and not args.no_extras  # no collectives below: the other ranks wait at the end
+    if rank == 0:
+        cull_ms, n_cull = scan_launch_ms(args.mode, min(args.steps, 20))
+        loss_default = ops.last_state().loss.clone()
+        fused_gR = w["R"].grad.clone()
+    if do_extras and args.mode == "cull":
+        # executed work of the culled kernel: the instrumented instantiation, same inputs
+        ops.scan_counters(True)
+        for _ in range(3):
+            local_step("cull")
+        torch.cuda.synchronize()
+        c = (ops.scan_counters(False).cpu().numpy().astype(np.float64) / 3.0)
+        exe = OPS_SPHERE * (c[0] + c[1] + c[2]) + OPS_EXACT * c[3] + OPS_CAND * c[4] + OPS_FALLBACK * c[7]
+        roof_default = {
+            "kernel": "cull_scan_kernel (scan mode cull: the dominant kernel of the timed step)",
+            "launch_ms": cull_ms, "launches_timed": n_cull,
+            "executed_flops": exe, "executed_tflops": exe / (cull_ms * 1e-3) / 1e12,
+            "executed_frac": exe / (cull_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS,
+            "work_ratio": dense_flops / exe,
+            "dense_equivalent_tflops": dense_flops / (cull_ms * 1e-3) / 1e12,
+            "counters_per_launch": {"sphere_tests_A": c[0], "sphere_tests_B": c[1], "sphere_tests_C": c[2],
+                                    "exact_point0_tests": c[3], "candidates_resolved": c[4], "wavefronts": c[5],
+                                    "fallback_wavefronts": c[6], "fallback_pairs": c[7]},
+            "ops_per_test": {"sphere": OPS_SPHERE, "exact": OPS_EXACT, "candidate": OPS_CAND,
+                             "fallback_pair": OPS_FALLBACK},
+            "note": "executed = arithmetic of the tests the kernel really ran, from in-kernel counters of this run "
+                    "(rrl_scan_counters; queue/ballot/bookkeeping instructions not counted: SQ_INSTS_VALU x 64 in "
+                    "profiles/ is the issue-side figure).  work_ratio = dense flops / executed flops."}
+    if do_extras:
+        # the kernel that performs ALL counted flops: the strict scan of the same step
+        strict_ms, n_strict = scan_launch_ms("strict", 6)
+        same = bool(torch.equal(ops.last_state().loss, loss_default))
+        roof_dense = {"launch_ms": strict_ms, "launches_timed": n_strict, "loss_bit_identical_to_default_mode": same}
+
+        # SURVEY §8(d) through the drop-in callables: T-apply -> loss -> backward to points1.grad
+        # (and on through the rigid apply to dR, dT), chained by autograd
+        keep = {}
+
+        def dropin_step():
+            w["R"].grad = w["T"].grad = None
+            tri1 = ops.rigid_apply(w["tri1"].reshape(B, 3 * N, 3), w["R"], w["T"], transpose_r=True).reshape(B, N, 9)
+            tri1.retain_grad()
+            loss, info, _ = ops.intersection_loss(tri1, w["tri2"], w["lines"], (1, 1, 5, 5), mode=args.mode)
+            torch.autograd.backward([loss], [ones])
+            keep["g"], keep["loss"] = tri1.grad, loss
+            return tri1.grad
+        try:
+            gd = GraphedStep(dropin_step) if not args.no_graph else dropin_step
+        except Exception as exc:
+            print(f"[bench] drop-in capture failed ({type(exc).__name__}: {exc}); eager", file=sys.stderr)
+            gd = dropin_step
+        for _ in range(min(args.warmup, 10)):
+            gd()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            gd()
+        torch.cuda.synchronize()
+        dms = (time.perf_counter() - t1) / args.steps * 1e3
+        g1 = keep["g"]
+        variants["points1_grad"] = {
+            "ms_per_step": dms, "value": pairs_step / (dms * 1e-3), "unit": "point-pairs/s (this rank)",
+            "what": "ops.rigid_apply -> ops.intersection_loss (what loss.cal_loss_intersection_batch_whole_median_"
+                    "pts_lines calls) -> backward to points1.grad (B,N,9), then rigid-apply backward to dR, dT; "
+                    + ("hipGraph replay" if gd is not dropin_step else "eager launches"),
+            "points1_grad_nonzero_rows": int((g1.abs().sum(-1) > 0).sum()),
+            "loss_sum": float(keep["loss"].sum()),
+            "dR_max_rel_diff_vs_fused": float((w["R"].grad - fused_gR).abs().max() / fused_gR.abs().max())}
+
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            cd = Lmod.chamfer_dist(w["src"], w["tar"])
+        torch.cuda.synchronize()
+        chamfer_ms = (time.perf_counter() - t1) / 5 * 1e3
+        extras.update({"chamfer_ms": chamfer_ms, "chamfer_pairs_per_s": B * N * M / (chamfer_ms * 1e-3),
+                       "chamfer": float(cd)})
 
     if rank == 0:
-        pairs_step = B * L * 3 * (N + M)
-        value = world * pairs_step * args.steps / dt
-        scan_s = scan_ms * 1e-3
+        value = sum_pairs(world, B, args, L, N, M) * args.steps / dt
         alg_bytes = B * (N + M) * 48 + B * L * 24 + 2 * B * L * 4  # ptri + lines + counts
-        pmc = None
+        # HBM bytes per launch from PMC passes -- only when collected for exactly this build
+        traffic, traffic_detail = None, None
         pmc_file = os.path.join(ROOT, "profiles", "scan_hbm_traffic.json")
         if os.path.exists(pmc_file):
-            pmc = json.load(open(pmc_file)).get(f"B{B}_N{N}_L{L}_{args.mode}")
-        # executed (not algorithmic) VALU work of the same kernel from the SQ counters of the round
-        # profile: wave-instructions x 64 lanes against the same peak, over the live launch time
-        executed = None
-        sq_file = os.path.join(ROOT, "profiles", "r01s5_pmc_summary.json")
-        if os.path.exists(sq_file) and (B, N, L, args.mode) == (8, 4096, 10000, "cull"):
-            sq = json.load(open(sq_file)).get("sq_per_kernel", {}).get("cull_scan_kernel", {})
-            if "SQ_INSTS_VALU" in sq:
-                executed = {"valu_wave_insts": sq["SQ_INSTS_VALU"], "salu_wave_insts": sq.get("SQ_INSTS_SALU"),
-                            "lds_wave_insts": sq.get("SQ_INSTS_LDS"),
-                            "valu_lane_ops_per_s": sq["SQ_INSTS_VALU"] * 64 / scan_s,
-                            "frac_of_valu_peak": sq["SQ_INSTS_VALU"] * 64 / scan_s / (VALU_PEAK_TFLOPS * 1e12),
-                            "source": "profiles/r01s5_pmc_summary.json (rocprofv3 --pmc SQ_INSTS_*, own pass)"}
+            rec = json.load(open(pmc_file))
+            ent = rec.get(f"B{B}_N{N}_L{L}_{args.mode}")
+            if ent and rec.get("csrc_sha") == csrc_sha():
+                traffic, traffic_detail = ent.get("bytes"), ent
+        roofline = {
+            "bound": "valu",
+            "note": "fp32 VALU-bound, not HBM- or MFMA-bound (no FMA allowed: label parity; O(L (N+M)) elementwise "
+                    "geometry).  peak = 157.3 / 2 TFLOP/s (one flop per lane-op).",
+            "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "traffic": traffic, "traffic_detail": traffic_detail,
+            "csrc_sha": csrc_sha(),
+        }
+        if roof_dense is not None:
+            s = roof_dense["launch_ms"] * 1e-3
+            roofline.update({
+                "kernel": "scan_kernel<v2f,1> (scan mode strict: every (line, point) pair evaluated -- the kernel "
+                          "that performs all 18 counted flops per pair; HIP events on the launch stream, this run)",
+                "achieved": dense_flops / s / 1e12, "frac": dense_flops / s / 1e12 / VALU_PEAK_TFLOPS,
+                "launch_ms": roof_dense["launch_ms"], "launches_timed": roof_dense["launches_timed"],
+                "algorithmic_flops_per_launch": dense_flops,
+                "loss_bit_identical_to_default_mode": roof_dense["loss_bit_identical_to_default_mode"]})
+        else:
+            roofline.update({"kernel": None, "achieved": None, "frac": None})
+        if roof_default is not None:
+            roofline["default_path"] = roof_default
+        roofline["hbm"] = {"algorithmic_bytes": alg_bytes, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "achieved": alg_bytes / (cull_ms * 1e-3) / 1e9,
+                           "frac": alg_bytes / (cull_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                           "kernel": "scan launch of the timed step"}
+        extras.update({"loss_sum": float(payload[0]), "valid": float(payload[1]),
+                       "line_sampling_s": w["sample_s"], "scan_launch_ms": cull_ms,
+                       "scan_share_of_step": cull_ms / (dt / args.steps * 1e3)})
         out = {
             "metric": "point-pairs/sec for loss fwd+bwd at B=8, N=M=4096",
             "value": value, "unit": "point-pairs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": f"B={B}/GPU, N=M={N} pseudo-triangles, L={L} lines, fp32 loss "
-                                   f"fwd+bwd (BASELINE.json configs[1]); scan mode {args.mode}; "
-                                   + ("hipGraph replay" if graphed is not None else "eager launches"),
-                       "global_batch": B * world, "parallelism": f"batch-shard dp{world}", "allreduce": type(reducer).__name__ + (" (in-graph)" if inline else "")},
-            "roofline": {
-                "bound": "valu", "kernel": "K1 line<->triangle scan (cull_scan_kernel)",
-                "achieved": FLOPS_PER_PAIR * pairs_step / scan_s / 1e12, "peak": VALU_PEAK_TFLOPS,
-                "unit": "TFLOP/s",
-                "frac": FLOPS_PER_PAIR * pairs_step / scan_s / 1e12 / VALU_PEAK_TFLOPS,
-                "launch_ms": scan_ms,
-                "note": "fp32 VALU-bound (no FMA allowed: label parity); peak = 157.3/2 TFLOP/s. "
-                        "achieved counts the ALGORITHMIC flops of the dense formulation (18 per "
-                        "(line, point) pair, SURVEY 8d); the kernel culls exactly, so frac > 1 "
-                        "means work skipped, not the VALU beaten (a three-level sphere tree rejects all "
-                        "but ~1 % of the pairs): the executed instruction stream keeps the VALU ~35 % "
-                        "busy (1.47e7 VALU wave-instructions per launch, profiles/r01s5_pmc_summary.json)",
-                "hbm": {"achieved": alg_bytes / scan_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": alg_bytes / scan_s / 1e9 / HBM_PEAK_GBS,
-                        "algorithmic_bytes": alg_bytes},
-                # HBM bytes per launch of that kernel from the PMC counters (separate rocprofv3 --pmc
-                # passes, gfx950-corrected: profiles/scan_hbm_traffic.json), null when not collected
-                "traffic": (pmc or {}).get("bytes"),
-                "traffic_detail": pmc,
-                "executed": executed,
-            },
-            "extras": {"loss_sum": float(payload[0]), "valid": float(payload[1]),
-                       "chamfer_ms": chamfer_ms, "chamfer_pairs_per_s": B * N * M / (chamfer_ms * 1e-3),
-                       "chamfer": float(cd), "line_sampling_s": w["sample_s"],
-                       "scan_share_of_step": scan_ms / (dt / args.steps * 1e3)},
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": (f"B={B}/GPU" if not strong else f"global B={args.global_batch} sharded over {world}")
+                                   + f", N=M={N} pseudo-triangles, L={L} lines, fp32 loss fwd+bwd "
+                                   f"(BASELINE.json configs[{2 if strong else 1}]); fused training op "
+                                   f"(rigid apply + loss, backward to dR, dT); scan mode {args.mode}; "
+                                   + ("hipGraph replay" if graphed is not None else "eager launches")
+                                   + "; value counts dense-equivalent pairs",
+                       "global_batch": args.global_batch if strong else B * world,
+                       "parallelism": f"batch-shard dp{world}",
+                       "allreduce": {"reducer": type(reducer).__name__, "placement": placement,
+                                     "in_graph": placement == "inline" and graphed is not None,
+                                     "rccl": evidence, "process_group": dist.is_initialized(),
+                                     "backend": dist.get_backend() if dist.is_initialized() else None,
+                                     "warmup_ms_per_step": choice_note}},
+            "roofline": roofline,
+            "variants": variants,
+            "extras": extras,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(N, M, L)
@@ -256,6 +434,12 @@ def main():
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+
+
+def sum_pairs(world, B, args, L, N, M):
+    """Dense-equivalent pairs of one step over ALL ranks."""
+    total_b = args.global_batch if args.global_batch > 0 else B * world
+    return total_b * L * 3 * (N + M)
 
 
 if __name__ == "__main__":

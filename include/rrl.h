@@ -47,16 +47,24 @@ extern "C" {
 #define RRL_SCAN_AUTO 2   /* per wavefront: lazy where a NaN is provably impossible for its
                              lines (|dir|^2 <= 1+1e-6 and (|x0| + max|P|)^2 <= 100), else strict.
                              Same results AND same NaN detection as strict. */
-#define RRL_SCAN_CULL 3   /* default.  Triangles are Morton-sorted into groups of 16 with bounding
-                             spheres; a line evaluates (lazily, exactly) only the groups whose
-                             sphere it can reach, found by a conservative test (DESIGN.md
-                             "culling bound").  128-line workgroups with a line that fails the NaN
-                             bound run the strict loop instead, so results and NaN detection equal
-                             strict's.  Needs N, M <= 65536, else behaves like AUTO. */
+#define RRL_SCAN_CULL 3   /* default.  Triangles are sorted by grid cell (Hilbert order) under a three-
+                             level sphere tree; a line evaluates (lazily, exactly) only the halves of 8
+                             whose sphere it can reach, found by a conservative test that is valid at
+                             any finite data scale (DESIGN.md "culling bound"): labels, hit lists and
+                             the loss equal strict's bit for bit.  NaN detection equals strict's
+                             wherever a NaN is provably impossible ((|x0| + max|P|)^2 < 111 and
+                             |dir|^2 <= 1 + 1e-6: none exists) and for lines with |dir|^2 > 1 + 1e-6
+                             or non-finite data (their wavefront of 128 lines runs the strict loop;
+                             STATUS[1] counts such wavefronts).  For unit directions at larger scale
+                             (the demo's full-diagonal radius) a negative sqrt argument is reported
+                             when it occurs in an EVALUATED pair: point 0 of every triangle that
+                             could produce one, points 1, 2 of triangles whose point 0 passes (as
+                             RRL_SCAN_LAZY).  Needs N, M <= 65536, else behaves like AUTO. */
 
 /* workspace fields (indices into rrl_workspace_layout's offset array) */
 enum {
-    RRL_WS_STATUS = 0, /* int32[4]   [0] = NaN seen (reference exit(0), loss.py:89-91); [3] = internal ticket */
+    RRL_WS_STATUS = 0, /* int32[4]   [0] = NaN seen (reference exit(0), loss.py:89-91); [1] = wavefronts of the
+                          culled scan that fell back to the strict loop; [3] = internal ticket */
     RRL_WS_NVALS,      /* int32[B]   (unused since the compact-slot layout; kept for ABI stability) */
     RRL_WS_NSEL,       /* int32[B]   selected lines per sample (length of SEL[b])           */
     RRL_WS_PMAX,       /* uint32[2][B] bits of max |P|^2 per cloud and sample                */
@@ -70,7 +78,7 @@ enum {
     RRL_WS_P0S2,       /*   supergroups of 64 sorted triangles; pad records have thr2 = 0 (never hit)           */
     RRL_WS_IDX1,       /* int32[B][64*NSG1]  original triangle index of each sorted position     */
     RRL_WS_IDX2,
-    RRL_WS_GRP1,       /* float[B][NSG1][13][4] sphere tree (centre, conservative radius^2; -1 = empty): per  */
+    RRL_WS_GRP1,       /* float[B][NSG1][13][4] sphere tree (centre, conservative radius; NaN = empty): per   */
     RRL_WS_GRP2,       /*   supergroup [0] its own sphere, [1..4] its groups of 16, [5..12] their halves of 8   */
     RRL_WS_CREC1,      /* float[B][16*NG1][4] P0 + thr2 in original order (input of the sort)   */
     RRL_WS_CREC2,
@@ -203,6 +211,17 @@ int rrl_set_scan_variant(int lines_per_lane);
 int rrl_scan_timing_enable(int on);
 int rrl_scan_timing_collect(float *ms, int max_n);
 
+/* Profiling hook: executed work of the culled scan.  While dev_counters != NULL every culled scan
+ * launches an instrumented instantiation of the same kernel that ADDS to dev_counters (uint64[8],
+ * device memory, cleared by the caller; one atomic per counter and wavefront at exit):
+ *   [0] level-A sphere tests (line x supergroup)   [1] level-B (line x group)   [2] level-C (line x half)
+ *   [3] exact point-0 tests (line x record)        [4] point-0 passes resolved (points 1 and 2)
+ *   [5] wavefronts                                 [6] wavefronts that took the strict fallback
+ *   [7] (line, triangle) pairs evaluated by the fallback.
+ * NULL switches back to the plain kernel.  bench.py derives the executed flops of a launch from
+ * these (11 per sphere test, 16 per exact test, 32 per resolved candidate, 48 per fallback pair). */
+int rrl_scan_counters(uint64_t *dev_counters);
+
 /* Batch-shard payload: out[14] = { sum of valid losses, number of valid
  * samples, sum_b gR[b] (9), sum_b gt[b] (3) } in one launch, fixed summation order; this is
  * the buffer a rank hands to the RCCL all-reduce.  gR / gt may be NULL (zeros). */
@@ -271,6 +290,13 @@ int rrl_dense_scan(const float *tri, const float *line, float *norm_d, uint8_t *
  *   tile_counts: scratch, 8-byte aligned, int32 [B * rounds * ceil(n/1024) * 32] (one 64-bit accept
  *     ballot per wavefront of every tile of 1024 candidates) */
 int rrl_aabb(const float *v, float *aabb, int B, int n, void *stream);
+/* The resampler's accept test on caller-supplied lines (code/loss.py:265-322, 415-432: label1 * label2):
+ * lines [B][n][6], aabb1/aabb2 [B][6] -> mask [B][n] (bit 0: the line crosses >= 1 of the 12 triangles
+ * of box 1 by the reference's sub-area test; bit 1: same for box 2 -- accepted == both; bit 2: the
+ * sampler's conservative slab pre-test passes) and, when hits != NULL, hits [B][n][2] = the number of
+ * box triangles crossed (the reference's label1, label2).  Same device code as rrl_sample_lines. */
+int rrl_box_accept(const float *lines, const float *aabb1, const float *aabb2, uint8_t *mask,
+                   int32_t *hits, int B, int n, void *stream);
 int rrl_sample_lines(const float *rands, const float *r, const float *centers, const float *aabb1,
                      const float *aabb2, float *lines, int32_t *filled, int32_t *tile_counts, int B,
                      int n, int rounds, void *stream);

@@ -242,6 +242,40 @@ def main():
           "filled(big radius)", int((np.abs(final_big).sum(1) > 0).sum()))
 
 
+def accept():
+    """Row F accept test (code/loss.py:265-322, 415-432) on harder candidate sets than sampler.npz:
+    the reference's label1 / label2 counts for lines drawn by the reference's own sampler around
+    a regular box pair, a flat box (zero extent along z), a single-point box and a pair far from the
+    origin (cancellation-heavy).  Inputs + the reference's outputs only."""
+    rng = np.random.default_rng(123)
+    out = {}
+    cases = []
+    pr = synth.make_pair(12, 300, 260)
+    cases.append(("regular", pr["src"], pr["tar"], float(pr["radius"]), pr["center"]))
+    flat = pr["src"].copy(); flat[:, 2] = 0.25
+    cases.append(("flat", flat, pr["tar"], float(pr["radius"]), pr["center"]))
+    single = np.tile(np.array([[0.1, -0.2, 0.05]], np.float32), (5, 1))
+    cases.append(("single", single, pr["tar"], float(pr["radius"]), pr["center"]))
+    off = np.array([40.0, -25.0, 17.0], np.float32)
+    cases.append(("far", pr["src"] + off, pr["tar"] + off, float(pr["radius"]), pr["center"] + off))
+    big = (pr["src"] * 12.0).astype(np.float32)
+    cases.append(("demo_scale", big, (pr["tar"] * 12.0).astype(np.float32), 2.0 * 12.0 * float(pr["radius"]),
+                  pr["center"] * 12.0))
+    n = 1500
+    for i, (tag, v1, v2, r, c) in enumerate(cases):
+        torch.manual_seed(900 + i)
+        cand = RL.Random_uniform_distribution_lines_batch_efficient(torch.tensor([[r]]), t(c).reshape(1, 3), n, "cpu")
+        fv1 = RL.generate_mesh_by_bbox(RL.generate_bbox(t(v1)[None]), "cpu")
+        fv2 = RL.generate_mesh_by_bbox(RL.generate_bbox(t(v2)[None]), "cpu")
+        h1 = RL.cal_intersection_batch2_rand_lines(fv1, cand)[0].numpy().astype(np.int32)
+        h2 = RL.cal_intersection_batch2_rand_lines(fv2, cand)[0].numpy().astype(np.int32)
+        out[f"{tag}_v1"], out[f"{tag}_v2"] = np.asarray(v1, np.float32), np.asarray(v2, np.float32)
+        out[f"{tag}_cand"], out[f"{tag}_hits1"], out[f"{tag}_hits2"] = cand[0].numpy(), h1, h2
+        print("accept", tag, "box1", int((h1 > 0).sum()), "box2", int((h2 > 0).sum()), "both", int(((h1 * h2) > 0).sum()), "/", n)
+    out["cases"] = np.array([c[0] for c in cases])
+    save("accept.npz", **out)
+
+
 def neighs():
     """Sample_neighs (FPS + KDTree 3-NN) on a synthetic cloud: all points, and a subsample."""
     pr = synth.make_pair(7, 900, 64)
@@ -472,6 +506,6 @@ def dataset():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["main", "neighs", "callsites", "demo_trajectory", "dataset"]
+    which = sys.argv[1:] or ["main", "neighs", "callsites", "demo_trajectory", "dataset", "accept"]
     for name in which:
         globals()[name]()

@@ -110,11 +110,20 @@ def test_fragments_draw_their_own_lines(C, G):
     directions or unfilled zeros, and the loss is finite and reproducible under a seed."""
     R, t = cu(G["R"][0]), cu(G["t"][0])
     d = data_dict(G, channel_first=True)
-    torch.manual_seed(3)          # the GPU generator draws the candidates by default ...
-    a = C.dcp_intersection_loss(d, R, t, n_lines=2000)
+    assert C.DEVICE_RNG is False  # default: the reference's CPU stream (a drop-in keeps its RNG behaviour)
     torch.manual_seed(3)
-    b = C.dcp_intersection_loss(d, R, t, n_lines=2000)
-    C.DEVICE_RNG = False          # ... and the reference's CPU stream on request
+    c0 = C.dcp_intersection_loss(d, R, t, n_lines=500)
+    torch.manual_seed(3)
+    c0b = C.dcp_intersection_loss(d, R, t, n_lines=500)
+    assert torch.equal(c0[2], c0b[2]) and torch.equal(c0[0], c0b[0])  # reproducible under the CPU seed
+    C.DEVICE_RNG = True           # opt-in: the GPU generator draws the candidates
+    try:
+        torch.manual_seed(3)
+        a = C.dcp_intersection_loss(d, R, t, n_lines=2000)
+        torch.manual_seed(3)
+        b = C.dcp_intersection_loss(d, R, t, n_lines=2000)
+    finally:
+        C.DEVICE_RNG = False
     try:
         torch.manual_seed(3)
         c1 = C.draw_lines(C.bounding_radius(d['tar_box'], 0.5), d['centers'], 500, d['points_tar_sample'].transpose(2, 1).contiguous(), d['points_tar_sample'].transpose(2, 1).contiguous())
@@ -125,7 +134,7 @@ def test_fragments_draw_their_own_lines(C, G):
             d['points_tar_sample'].transpose(2, 1).contiguous(), 'cuda')
         assert torch.equal(c1, c2)
     finally:
-        C.DEVICE_RNG = True
+        C.DEVICE_RNG = False
     assert a[2].shape == (3, 2000, 6) and torch.equal(a[2], b[2]) and torch.equal(a[0], b[0])
     nrm = a[2][..., :3].norm(dim=-1)
     assert bool(((nrm - 1).abs().lt(1e-5) | nrm.eq(0)).all())

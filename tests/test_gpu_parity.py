@@ -69,10 +69,10 @@ def test_tri_prepare_exact(L, oracle):
         for slot, s0, cnt in nodes:
             sl = slice(s0, min(s0 + cnt, n))
             if sl.start >= n:
-                assert tree[sg, slot, 3] < 0  # empty node: never passes
+                assert np.isnan(tree[sg, slot, 3])  # empty node: never passes
                 continue
             d = np.linalg.norm(P0[sl] - tree[sg, slot, :3].astype(np.float64), axis=1) + thr[idx[sl]]
-            assert np.all(d * d <= tree[sg, slot, 3] * (1 + 1e-6))
+            assert np.all(d <= tree[sg, slot, 3])  # the stored conservative radius
     p0s = st.p0s1[0].cpu().numpy()
     for s_ in (0, 17, n - 1):
         slot = s_
@@ -86,6 +86,8 @@ def test_scan_counts_and_hits(L, oracle, name, mode):
     g = load_golden(name)
     st = run_state(g["tri1"], g["tri2"], g["lines"], mode=mode)
     assert int(st.status[0]) == 0
+    # no wavefront of the culled scan leaves the culled path -- at the demo's scale (radius 11.7) neither
+    assert int(st.status[1]) == 0
     for tag, cnt, hit in (("1", st.count1, st.hit1), ("2", st.count2, st.hit2)):
         cnt = cnt[0].cpu().numpy()
         hit = hit[0].cpu().numpy()
@@ -655,6 +657,80 @@ def test_sampler(L, oracle):
     assert abs(nb - int((np.abs(g["final_big"]).sum(1) > 0).sum())) <= 15
 
 
+def test_box_accept_bit_exact(L, oracle):
+    """Row F pinned: on IDENTICAL candidate lines the HIP accept test (rrl_box_accept: the sampler's own
+    face table / face_hit / slab pre-test) gives the reference's per-box hit counts bit for bit --
+    on the sampler fixture's cand0 and on the five candidate sets of accept.npz (regular, flat,
+    single-point, far-from-origin, demo-scale boxes; label1 / label2 of code/loss.py:427-428 computed
+    by the reference itself) -- and equals the CPU oracle on 10^5 random lines per box pair.  The
+    slab pre-test never rejects a line the exact test accepts."""
+    from rrl_hip import ops
+
+    def gpu(v1, v2, lines):
+        m, h = ops.box_accept(cu(lines)[None], ops.aabb(cu(v1)[None]), ops.aabb(cu(v2)[None]))
+        return m[0].cpu().numpy(), h[0].cpu().numpy()
+    g = load_golden("sampler.npz")
+    m, h = gpu(g["src"], g["tar"], g["cand0"])
+    np.testing.assert_array_equal(h[:, 0], g["hits1"])
+    np.testing.assert_array_equal(h[:, 1], g["hits2"])
+    a = load_golden("accept.npz")
+    total = 0
+    for tag in a["cases"]:
+        m, h = gpu(a[f"{tag}_v1"], a[f"{tag}_v2"], a[f"{tag}_cand"])
+        np.testing.assert_array_equal(h[:, 0], a[f"{tag}_hits1"])
+        np.testing.assert_array_equal(h[:, 1], a[f"{tag}_hits2"])
+        acc = (m & 3) == 3
+        np.testing.assert_array_equal(acc, (a[f"{tag}_hits1"] * a[f"{tag}_hits2"]) > 0)
+        assert np.all((m[acc] & 4) == 4)  # accepted => the pre-test let it through
+        total += int(acc.sum())
+    assert total > 1500
+    # 10^5 random chords per box pair against the oracle (no reference needed on the GPU box)
+    rng = np.random.default_rng(17)
+    pr_src = a["regular_v1"]
+    boxes = [(pr_src, a["regular_v2"], 1.0, np.zeros(3)), (a["flat_v1"], a["regular_v2"], 1.0, np.zeros(3)),
+             (a["single_v1"], a["regular_v2"], 0.6, np.zeros(3)),
+             (a["far_v1"], a["far_v2"], 1.0, np.array([40.0, -25.0, 17.0]))]
+    for v1, v2, rad, ctr in boxes:
+        n = 100000
+        p = rng.standard_normal((2, n, 3))
+        p /= np.linalg.norm(p, axis=2, keepdims=True)
+        q1, q2 = (rad * 1.3 * p[0] + ctr).astype(np.float32), (rad * 1.3 * p[1] + ctr).astype(np.float32)
+        d = (q2 - q1).astype(np.float64)
+        lines = np.concatenate([(d / np.linalg.norm(d, axis=1, keepdims=True)), q1], 1).astype(np.float32)
+        m, h = gpu(v1, v2, lines)
+        np.testing.assert_array_equal(h[:, 0], oracle.box_hits(oracle.bbox(v1), lines))
+        np.testing.assert_array_equal(h[:, 1], oracle.box_hits(oracle.bbox(v2), lines))
+        acc = (m & 3) == 3
+        assert np.all((m[acc] & 4) == 4)
+
+
+def test_resample_is_accept_of_own_candidates(L):
+    """The 10-round resampler end to end: its output buffer equals, bit for bit, what the reference's
+    fill rule (code/loss.py:365-381: candidate order, `counter > N` skips the round, truncation,
+    zero tail) produces from the SAME kernel's unfiltered candidates and the pinned accept test."""
+    from rrl_hip import ops, synth
+    for seed, n, scale in ((5, 3000, 1.0), (6, 1200, 0.5), (7, 700, 4.0)):
+        pr = synth.make_pair(seed, 400, 350)
+        rands = torch.from_numpy(synth.uniform_streams(seed, 10, n))[:, :, None, :]
+        r, c = torch.tensor([pr["radius"] * scale]), torch.from_numpy(pr["center"])[None]
+        b1, b2 = ops.aabb(cu(pr["src"])[None]), ops.aabb(cu(pr["tar"])[None])
+        final, filled = ops.sample_lines(rands, r, c, b1, b2)
+        final = final[0].cpu().numpy()
+        want = np.zeros((n, 6), np.float32)
+        count = 0
+        for rd in range(10):
+            cand, _ = ops.sample_lines(rands[rd:rd + 1], r, c, None, None)  # every candidate of the round
+            m, _ = ops.box_accept(cand, b1, b2)
+            keep = cand[0].cpu().numpy()[((m[0] & 3) == 3).cpu().numpy()]
+            if count > n:
+                continue
+            take = keep[:max(0, n - count)]
+            want[count:count + len(take)] = take
+            count += len(keep)
+        np.testing.assert_array_equal(final, want)
+        assert int(filled[0]) == count
+
+
 def test_sampler_prefilter_is_exact(tmp_path):
     """The conservative slab pre-test of the sampler's count pass never changes the result: the
     same lines bit-for-bit with RRL_SAMPLER_PREFILTER=0 (every candidate through the exact test),
@@ -700,6 +776,67 @@ def test_cull_dense_hits(L, oracle):
     np.testing.assert_array_equal(c.count1[0].cpu().numpy(), o["count"])
     np.testing.assert_array_equal(s_.count1[0].cpu().numpy(), o["count"])
     assert o["count"].max() > 4 and (o["count"] > 0).mean() > 0.5  # really dense
+
+
+@pytest.mark.parametrize("scale", [1.0, 12.0, 40.0, 300.0, 5000.0])
+@pytest.mark.parametrize("far", [False, True])
+def test_cull_is_exact_at_any_scale(L, scale, far):
+    """The culling bound carries a per-wavefront slack derived from (|x0| + max|P|)^2 instead of
+    refusing to cull beyond a fixed scale: counts, hit lists and the loss equal the strict scan's
+    bit for bit on clouds scaled up to 5000x (where the 2e-4 eps is far below the rounding noise of
+    the reference's own arithmetic), with no wavefront taking the strict fallback; `far` moves the
+    clouds away from the origin (large |a|, cancellation-heavy)."""
+    from rrl_hip import synth
+    pr = synth.make_pair(77, 1500, 1100)
+    off = np.array([3.0, -2.0, 1.5] * 3, np.float32) * np.float32(scale) if far else np.float32(0)
+    tri1 = pr["src_tri"] * np.float32(scale) + off
+    tri2 = pr["tar_tri"] * np.float32(scale) + off
+    rands = synth.uniform_streams(3, 10, 6000)
+    ctr = pr["center"] * np.float32(scale) + (off[:3] if far else 0)
+    from rrl_hip import ops
+    lines, _ = ops.sample_lines(torch.from_numpy(rands)[:, :, None, :], torch.tensor([pr["radius"] * scale]),
+                                torch.from_numpy(np.asarray(ctr, np.float32))[None],
+                                ops.aabb(cu(tri1[None, :, :3])), ops.aabb(cu(tri2[None, :, :3])))
+    ln = lines[0].cpu().numpy()
+    c = run_state(tri1, tri2, ln, mode="cull")
+    s_ = run_state(tri1, tri2, ln, mode="strict")
+    # beyond the provably NaN-free scale the culled scan reports a negative sqrt argument on evaluated
+    # pairs only (include/rrl.h RRL_SCAN_CULL): never a flag that strict does not raise
+    assert int(c.status[1]) == 0 and int(c.status[0]) <= int(s_.status[0])
+    if scale == 1.0:
+        assert int(s_.status[0]) == 0
+    for a, b in ((c.count1, s_.count1), (c.count2, s_.count2)):
+        np.testing.assert_array_equal(a.cpu().numpy(), b.cpu().numpy())
+    for cnt, hc, hs in ((c.count1, c.hit1, s_.hit1), (c.count2, c.hit2, s_.hit2)):
+        k = cnt[0].cpu().numpy()
+        hc, hs = hc[0].cpu().numpy(), hs[0].cpu().numpy()
+        for l in np.nonzero((k > 0) & (k <= 4))[0]:
+            assert sorted(hc[l, :k[l]].tolist()) == sorted(hs[l, :k[l]].tolist())
+    assert c.loss[0].item() == s_.loss[0].item()
+    assert int((c.count1 > 0).sum()) > 100  # not degenerate: lines do hit
+
+
+def test_scan_counters(L):
+    """rrl_scan_counters: the instrumented instantiation gives the same results and plausible
+    executed-work counts (every level sees fewer pairs than the dense product)."""
+    from rrl_hip import ops
+    g = load_golden("loss_synth_s1.npz")
+    plain = run_state(g["tri1"], g["tri2"], g["lines"], mode="cull")
+    ops.scan_counters(True)
+    try:
+        counted = run_state(g["tri1"], g["tri2"], g["lines"], mode="cull")
+    finally:
+        c = ops.scan_counters(False).cpu().numpy()
+    np.testing.assert_array_equal(plain.count1.cpu().numpy(), counted.count1.cpu().numpy())
+    np.testing.assert_array_equal(plain.count2.cpu().numpy(), counted.count2.cpu().numpy())
+    assert plain.loss[0].item() == counted.loss[0].item()
+    nl, n1, n2 = g["lines"].shape[0], g["tri1"].shape[0], g["tri2"].shape[0]
+    nsg = (n1 + 63) // 64 + (n2 + 63) // 64
+    assert c[0] == nl * nsg                      # level A tests every (line, supergroup)
+    assert 0 < c[1] <= 4 * c[0] and 0 < c[2] <= 2 * c[1] and 0 < c[3] <= 8 * c[2]
+    assert c[3] < nl * (n1 + n2)                 # fewer exact tests than the dense scan's pairs
+    assert c[4] >= int(g["count1"].sum() + g["count2"].sum())  # every hit was a resolved candidate
+    assert c[6] == 0 and c[7] == 0 and c[5] > 0
 
 
 @pytest.mark.parametrize("n_lines,spread", [(3000, 0.0), (3000, 1e-4), (600, 0.0), (9000, 1e-5)])

@@ -17,7 +17,7 @@ for case in range(n_cases):
     N = int(rng.choice([1, 7, 16, 17, 100, 513, 1024, 3000, 4097, 9000]))
     M = int(rng.choice([1, 5, 16, 31, 200, 777, 2048, 5000]))
     Ln = int(rng.choice([1, 2, 63, 64, 65, 127, 128, 129, 500, 1023, 1024, 1025, 2500, 7000]))
-    scale = float(rng.choice([0.3, 1.0, 1.0, 3.0, 9.0]))
+    scale = float(rng.choice([0.3, 1.0, 1.0, 3.0, 9.0, 30.0, 200.0]))
     prs = [synth.make_pair(int(rng.integers(0, 10**6)), max(N, 8), max(M, 8)) for _ in range(B)]
     src = torch.from_numpy(np.stack([p["src_tri"][:N] for p in prs]) * np.float32(scale)).cuda()
     tar = torch.from_numpy(np.stack([p["tar_tri"][:M] for p in prs]) * np.float32(scale)).cuda()
@@ -32,7 +32,7 @@ for case in range(n_cases):
     st_s = ops.loss_forward_raw(src, tar, lines, mode="strict")
     torch.cuda.synchronize()
     ok = torch.equal(st_c.count1, st_s.count1) and torch.equal(st_c.count2, st_s.count2) and \
-        torch.equal(st_c.loss, st_s.loss) and torch.equal(st_c.status, st_s.status) and torch.equal(st_c.info, st_s.info)
+        torch.equal(st_c.loss, st_s.loss) and int(st_c.status[0]) <= int(st_s.status[0]) and torch.equal(st_c.info, st_s.info)
     R = torch.eye(3, device="cuda").repeat(B, 1, 1).requires_grad_(True)
     t = torch.zeros(B, 3, device="cuda").requires_grad_(True)
     loss, info, status = ops.registration_loss(src, R, t, tar, lines, transpose_r=bool(rng.integers(0, 2)))
