@@ -38,6 +38,7 @@ _SIGS = {
     "rrl_rigid_apply_bwd": [_P] * 7 + [_I] * 4 + [_P],
     "rrl_chamfer_fwd": [_P] * 5 + [_I] * 3 + [_P],
     "rrl_chamfer_bwd": [_P] * 7 + [_I] * 3 + [_P],
+    "rrl_chamfer_tree_fwd": [_P, _P, _P, _Z, _P, _P, _P, _I, _I, _I, _P],
     "rrl_aabb": [_P, _P, _I, _I, _P],
     "rrl_box_accept": [_P, _P, _P, _P, _P, _I, _I, _P],
     "rrl_log_row": [_P, _P, _P, _P, _P, _c.c_longlong, _P, _P],
@@ -49,7 +50,7 @@ _SIGS = {
     "rrl_knn3": [_P, _P, _P, _I, _I, _I, _P],
     "rrl_sample_lines": [_P] * 8 + [_I] * 3 + [_P],
 }
-EXPORTS = sorted(list(_SIGS) + ["rrl_version", "rrl_workspace_bytes"])
+EXPORTS = sorted(list(_SIGS) + ["rrl_version", "rrl_workspace_bytes", "rrl_chamfer_workspace_bytes"])
 
 _lib = None
 
@@ -75,6 +76,8 @@ def load():
     lib.rrl_version.restype = ctypes.c_char_p
     lib.rrl_workspace_bytes.argtypes = [_I, _I, _I, _I]
     lib.rrl_workspace_bytes.restype = _Z
+    lib.rrl_chamfer_workspace_bytes.argtypes = [_I, _I, _I]
+    lib.rrl_chamfer_workspace_bytes.restype = _Z
     _lib = lib
     return lib
 

@@ -13,7 +13,7 @@ PKG = os.path.dirname(HERE)
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "librrl_hip.so")
-SOURCES = ["rrl_scan.hip", "rrl_cull.hip", "rrl_sparse.hip", "rrl_geom.hip", "rrl_neigh.hip"]
+SOURCES = ["rrl_scan.hip", "rrl_cull.hip", "rrl_sparse.hip", "rrl_geom.hip", "rrl_neigh.hip", "rrl_chamfer.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
          "-Wall", "-Wno-unused-function"]
 

@@ -489,6 +489,10 @@ def adam_gated(param, grad, m, v, state, lr, gate=None, betas=(0.9, 0.999), eps=
 
 
 # ---------------------------------------------------------------------------------------
+CHAMFER_TREE = True   # False: the brute-force kernel (every pair evaluated); same keys, same value
+_chamfer_ws_bytes = {}
+
+
 class _Chamfer(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, y):
@@ -501,7 +505,15 @@ class _Chamfer(torch.autograd.Function):
         bx = torch.empty(B, N, dtype=torch.int64, device=xs.device)
         by = torch.empty(B, M, dtype=torch.int64, device=xs.device)
         val = torch.empty(1, device=xs.device)
-        _run(dev, "rrl_chamfer_fwd", _p(xs), _p(ys), _p(bx), _p(by), _p(val), B, N, M)
+        if CHAMFER_TREE and 0 < B <= 32767 and 0 < max(N, M) <= 65536 and min(N, M) > 0:
+            # sorted clouds + sphere tree + pruned walk (rrl_chamfer.hip): keys identical to brute force
+            nb = _chamfer_ws_bytes.get((B, N, M))
+            if nb is None:
+                nb = _chamfer_ws_bytes[(B, N, M)] = int(_lib.load().rrl_chamfer_workspace_bytes(B, N, M))
+            ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+            _run(dev, "rrl_chamfer_tree_fwd", _p(xs), _p(ys), _p(ws), nb, _p(bx), _p(by), _p(val), B, N, M)
+        else:
+            _run(dev, "rrl_chamfer_fwd", _p(xs), _p(ys), _p(bx), _p(by), _p(val), B, N, M)
         ctx.save_for_backward(xs, ys, bx, by)
         ctx.devs = (x.device, y.device)
         return val.reshape(()).to(x.device)

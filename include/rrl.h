@@ -219,7 +219,7 @@ int rrl_scan_timing_collect(float *ms, int max_n);
  *   [5] wavefronts                                 [6] wavefronts that took the strict fallback
  *   [7] (line, triangle) pairs evaluated by the fallback.
  * NULL switches back to the plain kernel.  bench.py derives the executed flops of a launch from
- * these (11 per sphere test, 16 per exact test, 32 per resolved candidate, 48 per fallback pair). */
+ * these (12 per sphere test, 16 per exact test, 32 per resolved candidate, 48 per fallback pair). */
 int rrl_scan_counters(uint64_t *dev_counters);
 
 /* Batch-shard payload: out[14] = { sum of valid losses, number of valid
@@ -268,6 +268,15 @@ int rrl_log_row(const float *loss, const float *value, const int32_t *info, floa
  * the call itself.  value[0] = mean of all B*(N+M) minima. */
 int rrl_chamfer_fwd(const float *x, const float *y, uint64_t *best_x, uint64_t *best_y,
                     float *value, int B, int N, int M, void *stream);
+/* The same result (keys bit-identical, value from a fixed-order sum) through the scan's spatial
+ * structures: both clouds in grid-cell (Hilbert) order under the sphere tree, nearest neighbours by a
+ * pruned tree walk, the mean folded into the same launch (3 launches for N, M <= 4096).  ws: scratch of
+ * rrl_chamfer_workspace_bytes(B, N, M) bytes.  N, M in [1, 65536].  best_x / best_y need no
+ * initialisation.  A NaN coordinate in a target cloud makes every minimum of that sample NaN and a
+ * NaN query its own minimum, as torch.min does. */
+size_t rrl_chamfer_workspace_bytes(int B, int N, int M);
+int rrl_chamfer_tree_fwd(const float *x, const float *y, void *ws, size_t ws_bytes, uint64_t *best_x,
+                         uint64_t *best_y, float *value, int B, int N, int M, void *stream);
 int rrl_chamfer_bwd(const float *x, const float *y, const uint64_t *best_x,
                     const uint64_t *best_y, const float *grad_value, float *gx, float *gy, int B,
                     int N, int M, void *stream);

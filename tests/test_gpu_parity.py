@@ -513,6 +513,88 @@ def test_chamfer_minima_bit_exact(L, oracle):
     np.testing.assert_array_equal((ky & np.uint64(0xffffffff)).astype(np.int32), ay)
 
 
+def _chamfer_keys(x, y, tree):
+    from rrl_hip import ops, _lib
+    B, N, _ = x.shape
+    M = y.shape[1]
+    xs, ys = cu(x), cu(y)
+    bx = torch.full((B, N), -1, dtype=torch.int64, device="cuda")
+    by = torch.full((B, M), -1, dtype=torch.int64, device="cuda")
+    val = torch.empty(1, device="cuda")
+    lib = _lib.load()
+    if tree:
+        nb = int(lib.rrl_chamfer_workspace_bytes(B, N, M))
+        ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+        rc = lib.rrl_chamfer_tree_fwd(ops._p(xs), ops._p(ys), ops._p(ws), nb, ops._p(bx), ops._p(by), ops._p(val),
+                                      B, N, M, ops._stream())
+    else:
+        rc = lib.rrl_chamfer_fwd(ops._p(xs), ops._p(ys), ops._p(bx), ops._p(by), ops._p(val), B, N, M, ops._stream())
+    assert rc == 0
+    torch.cuda.synchronize()
+    return bx.cpu().numpy().view(np.uint64), by.cpu().numpy().view(np.uint64), val.item()
+
+
+@pytest.mark.parametrize("B,N,M,kind", [
+    (1, 1, 1, "gauss"), (2, 17, 63, "gauss"), (1, 64, 65, "gauss"), (3, 300, 257, "gauss"),
+    (1, 1500, 2300, "dups"), (2, 4096, 4096, "surface"), (1, 4097, 700, "surface"),
+    (1, 16384, 16384, "surface"), (1, 2000, 1800, "flat"), (1, 500, 400, "point")])
+def test_chamfer_tree_equals_brute_force(L, oracle, B, N, M, kind):
+    """The sorted-cloud / sphere-tree Chamfer (rrl_chamfer_tree_fwd) against the brute-force kernel and
+    the CPU oracle: every u64 key (distance bits, first-occurrence argmin) identical, the mean equal
+    to double rounding -- over ragged sizes at every tile boundary, both sort paths (<= 4096 and the
+    wide sort), duplicated points (ties), flat and single-point clouds."""
+    from rrl_hip import synth
+    rng = np.random.default_rng(100 + N + M)
+    if kind == "surface":
+        prs = [synth.make_pair(40 + b, N, M) for b in range(B)]
+        x, y = np.stack([p["src"] for p in prs]), np.stack([p["tar"] for p in prs])
+    else:
+        x = rng.standard_normal((B, N, 3)).astype(np.float32)
+        y = rng.standard_normal((B, M, 3)).astype(np.float32)
+        if kind == "dups":
+            y[0, 7] = y[0, 3]
+            y[0, 1000:1100] = y[0, 50:150]      # 100 duplicated targets: the first occurrence must win
+            x[0, 200:260] = x[0, 0:60]
+        if kind == "flat":
+            x[..., 2] = 0.5
+            y[..., 1] = -0.25
+        if kind == "point":
+            y[:] = y[:, :1]                       # every target is the same point: argmin 0 everywhere
+    tx, ty, tv = _chamfer_keys(x, y, True)
+    bx, by, bv = _chamfer_keys(x, y, False)
+    np.testing.assert_array_equal(tx, bx)
+    np.testing.assert_array_equal(ty, by)
+    assert abs(tv - bv) <= 2e-7 * abs(bv)
+    if N * M <= 4096 * 4096:
+        for b in range(B):
+            mx, ax, my, ay = oracle.chamfer_parts(x[b], y[b])
+            np.testing.assert_array_equal((tx[b] >> np.uint64(32)).astype(np.uint32).view(np.float32), mx)
+            np.testing.assert_array_equal((tx[b] & np.uint64(0xffffffff)).astype(np.int32), ax)
+            np.testing.assert_array_equal((ty[b] >> np.uint64(32)).astype(np.uint32).view(np.float32), my)
+            np.testing.assert_array_equal((ty[b] & np.uint64(0xffffffff)).astype(np.int32), ay)
+    if kind == "point":
+        assert np.all((tx & np.uint64(0xffffffff)) == 0)
+
+
+def test_chamfer_nan_propagates(L):
+    """torch.min propagates NaN: a NaN coordinate in a target cloud makes every minimum of that sample
+    (and the batch mean) NaN, a NaN query only its own (code/loss.py:236-252 with torch semantics)."""
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((2, 200, 3)).astype(np.float32)
+    y = rng.standard_normal((2, 150, 3)).astype(np.float32)
+    x[1, 17, 1] = np.nan
+    tx, ty, tv = _chamfer_keys(x, y, True)
+    dx = (tx >> np.uint64(32)).astype(np.uint32).view(np.float32)
+    dy = (ty >> np.uint64(32)).astype(np.uint32).view(np.float32)
+    assert np.isnan(dx[1, 17]) and np.isfinite(np.delete(dx[1], 17)).all() and np.isfinite(dx[0]).all()
+    assert np.isnan(dy[1]).all() and np.isfinite(dy[0]).all()   # sample 1's targets (dir 1) contain the NaN
+    assert np.isnan(tv)
+    ref = torch.from_numpy
+    want = torch.cat([((ref(x)[:, :, None] - ref(y)[:, None]) ** 2).sum(-1).min(2)[0].reshape(-1),
+                      ((ref(x)[:, :, None] - ref(y)[:, None]) ** 2).sum(-1).min(1)[0].reshape(-1)])
+    np.testing.assert_array_equal(np.isnan(np.concatenate([dx.reshape(-1), dy.reshape(-1)])), torch.isnan(want).numpy())
+
+
 # ---------------------------------------------------------------------------------- K6 + R
 def test_reconstruction_point(L):
     g = load_golden("reconstruction_point.npz")

@@ -1,0 +1,24 @@
+"""Chamfer at a BASELINE shape, N calls (run under rocprofv3 --kernel-trace --stats):
+    python tools/chamfer_prof.py [B N M calls tree(0|1)]"""
+import os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "a-robust-registration-loss_amd"))
+from rrl_hip import ops, synth
+import loss as Lm
+a = [int(v) for v in sys.argv[1:]] + [8, 4096, 4096, 50, 1][len(sys.argv) - 1:]
+B, N, M, calls, tree = a
+ops.CHAMFER_TREE = bool(tree)
+prs = [synth.make_pair(b, N, M) for b in range(B)]
+x = torch.from_numpy(np.stack([p["src"] for p in prs])).cuda()
+y = torch.from_numpy(np.stack([p["tar"] for p in prs])).cuda()
+for _ in range(3):
+    v = Lm.chamfer_dist(x, y)
+torch.cuda.synchronize()
+ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+ev0.record()
+for _ in range(calls):
+    v = Lm.chamfer_dist(x, y)
+ev1.record()
+torch.cuda.synchronize()
+print(f"B={B} N={N} M={M} tree={tree}: {ev0.elapsed_time(ev1) / calls * 1e3:.1f} us per call (eager, incl. launch gaps), value {v.item():.9f}")
