@@ -405,6 +405,18 @@ def scan_counters(on):
     return prev
 
 
+_cham_counter_buf = None
+
+
+def chamfer_counters(on):
+    """Like scan_counters, for the tree Chamfer (include/rrl.h rrl_chamfer_counters)."""
+    global _cham_counter_buf
+    prev = _cham_counter_buf
+    _cham_counter_buf = torch.zeros(16, dtype=torch.int64, device=require_gpu()) if on else None
+    check(_lib.load().rrl_chamfer_counters(_p(_cham_counter_buf)), "rrl_chamfer_counters")
+    return prev
+
+
 # ---------------------------------------------------------------------------------------
 class _RigidApply(torch.autograd.Function):
     @staticmethod

@@ -112,14 +112,17 @@ def cpu_baseline(N, M, L, budget_s=12.0, eager_budget_s=8.0):
            "sample": f"{done} evaluation(s) of one N=M={N}, L={L} sample, loss fwd+bwd, oracle/rrl_oracle.c "
                      f"with OpenMP on {cores} threads, {spent:.1f} s"}
     try:
-        torch.set_num_threads(cores)
+        # torch's intra-op pool degrades badly beyond a few dozen threads on these small per-chunk ops
+        # (gpurun_out/r02b_threads.txt: 256 lines take 0.02 s on 32 threads, 0.2 s on 128, 29 s on 256)
+        eth = min(cores, 32)
+        torch.set_num_threads(eth)
         t2 = torch.from_numpy(pr["tar_tri"])
         ln = torch.from_numpy(lines)
 
         def run(nl):
             t1 = torch.from_numpy(pr["src_tri"]).clone().requires_grad_(True)
             t0 = time.perf_counter()
-            val = torch_eager.loss(t1, t2, ln[:nl], max_lines=256)
+            val = torch_eager.loss(t1, t2, ln[:nl], max_lines=64)
             if val is not None:
                 val.backward()
             return time.perf_counter() - t0, val
@@ -128,10 +131,10 @@ def cpu_baseline(N, M, L, budget_s=12.0, eager_budget_s=8.0):
         nl = int(max(probe, min(L, probe * eager_budget_s / max(tp, 1e-3))))
         te, val = run(nl)
         out["torch_eager"] = {
-            "value": nl * 3 * (N + M) / te, "unit": "point-pairs/s", "cores": cores, "kind": "port",
+            "value": nl * 3 * (N + M) / te, "unit": "point-pairs/s", "cores": eth, "kind": "port",
             "sample": f"one N=M={N} sample, first {nl} of its {L} lines, loss fwd+bwd by autograd, "
                       f"oracle/torch_eager.py (the reference's materialising op sequence, code/loss.py:68-232) "
-                      f"with torch.set_num_threads({cores}), {te:.1f} s",
+                      f"with torch.set_num_threads({eth}) (of {cores} host threads), {te:.1f} s",
             "loss_full_sample_c_port": float(ref["loss"]) if ref["loss"] is not None else None}
     except Exception as exc:  # the C leg stands on its own
         out["torch_eager"] = {"error": f"{type(exc).__name__}: {exc}"}

@@ -21,4 +21,38 @@ for _ in range(calls):
     v = Lm.chamfer_dist(x, y)
 ev1.record()
 torch.cuda.synchronize()
+if tree:
+    ops.chamfer_counters(True)
+    Lm.chamfer_dist(x, y)
+    torch.cuda.synchronize()
+    c = ops.chamfer_counters(False).cpu().numpy()
+    print(f"  counters: patch-level tests/wave {c[0]/c[4]:.1f}, leaf tests/wave {c[1]/c[4]:.1f}, leaves evaluated/wave {c[2]/c[4]:.1f}, "
+          f"pairs {c[3]:.3g} = {c[3]/(B*N*M*2):.4f} of dense, waves {c[4]}")
+    # aligned clouds (target = source + small noise): what a converged registration looks like
+    y2 = x[:, :M] + 0.003 * torch.randn_like(x[:, :M]) if M <= N else None
+    if y2 is not None:
+        ops.chamfer_counters(True)
+        Lm.chamfer_dist(x, y2)
+        torch.cuda.synchronize()
+        c = ops.chamfer_counters(False).cpu().numpy()
+        ev0.record()
+        for _ in range(calls):
+            Lm.chamfer_dist(x, y2)
+        ev1.record()
+        torch.cuda.synchronize()
+        print(f"  aligned clouds: {ev0.elapsed_time(ev1) / calls * 1e3:.1f} us per call; leaves evaluated/wave {c[2]/c[4]:.1f}, pairs {c[3]/(B*N*M*2):.4f} of dense")
+from rrl_hip.graph import GraphedStep
+g = GraphedStep(lambda: Lm.chamfer_dist(x, y))
+g(); torch.cuda.synchronize()
+ev0.record()
+for _ in range(calls):
+    v = g()
+ev1.record()
+torch.cuda.synchronize()
+print(f"B={B} N={N} M={M} tree={tree}: hipGraph replay {ev0.elapsed_time(ev1) / calls * 1e3:.1f} us per call")
+ev0.record()
+for _ in range(calls):
+    v = Lm.chamfer_dist(x, y)
+ev1.record()
+torch.cuda.synchronize()
 print(f"B={B} N={N} M={M} tree={tree}: {ev0.elapsed_time(ev1) / calls * 1e3:.1f} us per call (eager, incl. launch gaps), value {v.item():.9f}")
