@@ -21,6 +21,18 @@ typedef float v2f __attribute__((ext_vector_type(2)));
         if (e__ != hipSuccess) return (int)e__;    \
     } while (0)
 
+// roctx ranges around the stages of a step (host-side markers for rocprofv3 --marker-trace): active
+// only with RRL_ROCTX=1 in the environment, in which case librocprofiler-sdk-roctx.so (or libroctx64.so)
+// is dlopen'ed on first use -- no link-time dependency, no cost otherwise.  Defined in rrl_scan.hip.
+void rrl_range_push(const char *name);
+void rrl_range_pop(void);
+struct RrlRange {
+    explicit RrlRange(const char *name) { rrl_range_push(name); }
+    ~RrlRange() { rrl_range_pop(); }
+    RrlRange(const RrlRange &) = delete;
+    RrlRange &operator=(const RrlRange &) = delete;
+};
+
 // Fill / copy as KERNELS.  The library never issues hipMemsetAsync / hipMemcpyAsync: inside a
 // captured hipGraph (the bench and the demo replay their step as one) memset nodes were observed
 // to race with the kernels that follow them on this stack -- the captured demo step

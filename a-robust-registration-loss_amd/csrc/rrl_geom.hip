@@ -236,6 +236,12 @@ __global__ __launch_bounds__(256) void reg_bwd_kernel(const float *__restrict__ 
     // whole L2 of the XCD (several microseconds here).  Instead the 12 partials go out as
     // agent-scope (write-through) atomic stores from wave 0, which waits for their completion
     // before its lane 0 takes the ticket; the last workgroup reads them with agent-scope loads.
+    // This is NOT the HIP memory model's release/acquire pairing: it relies on gfx9 behaviour (stores
+    // are counted by vmcnt, agent-scope accesses are served by the device-coherent level), hence the
+    // target check; tests/test_gpu_parity.py stresses the d/dsrc path over many runs.
+#if !defined(__gfx950__) && !defined(__gfx942__) && defined(__HIP_DEVICE_COMPILE__)
+#error "reg_bwd_kernel's ticket hand-over is written for gfx942 / gfx950 (vmcnt-counted stores)"
+#endif
     if (threadIdx.x < 12) {
         const int q = threadIdx.x;
         __hip_atomic_store(&partial[((size_t)b * nblk + blockIdx.x) * 12 + q],

@@ -28,7 +28,36 @@
 // which restores nonzero() order (loss.py:125-131) deterministically.
 // Nothing of size L*N is ever written: compulsory traffic is a few MB against ~35 GFLOP
 // (B=8, N=M=4096, L=10000), so the kernel is fp32-VALU-bound, not HBM-bound.
+#include <dlfcn.h>
+#include <stdlib.h>
+
 #include "rrl_ws.h"
+
+// ---- roctx ranges (rrl_common.h) ----------------------------------------------------------------
+typedef int (*roctx_push_fn)(const char *);
+typedef int (*roctx_pop_fn)(void);
+static roctx_push_fn g_roctx_push = nullptr;
+static roctx_pop_fn g_roctx_pop = nullptr;
+static int g_roctx_state = -1;  // -1 unknown, 0 off, 1 on
+static void roctx_init() {
+    g_roctx_state = 0;
+    const char *e = getenv("RRL_ROCTX");
+    if (!e || e[0] != '1') return;
+    for (const char *lib : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
+        void *h = dlopen(lib, RTLD_NOW | RTLD_GLOBAL);
+        if (!h) continue;
+        g_roctx_push = (roctx_push_fn)dlsym(h, "roctxRangePushA");
+        g_roctx_pop = (roctx_pop_fn)dlsym(h, "roctxRangePop");
+        if (g_roctx_push && g_roctx_pop) { g_roctx_state = 1; return; }
+    }
+}
+void rrl_range_push(const char *name) {
+    if (g_roctx_state < 0) roctx_init();
+    if (g_roctx_state == 1) g_roctx_push(name);
+}
+void rrl_range_pop(void) {
+    if (g_roctx_state == 1) g_roctx_pop();
+}
 
 // ---------------------------------------------------------------------------------------
 // K1' prepared triangles (+ max |P|^2 per cloud and sample for the auto-mode NaN bound)

@@ -5,6 +5,8 @@
 //   K5 backward         autograd of code/loss.py:170-232
 // About 9 % of the lines are selected; these kernels touch O(L) data and are latency bound
 // (a few microseconds each) next to the O(L*(N+M)) scan.
+#include <stdlib.h>
+
 #include "rrl_ws.h"
 
 #define FIX_SHIFT 40  // bucket sums in 2^-40 fixed point: order-independent, bit-deterministic
@@ -310,6 +312,7 @@ struct ReduceLds {
     unsigned *s_whist;  // [128] histogram of the wave-private passes
     unsigned long long *s_sum;
     int *s_cnt;
+    int *s_bad;  // a Welsch term was not finite (median 0: identical clouds): the loss is NaN like the reference's
 };
 
 // Median + Welsch sums of one reduce workgroup with the first RT selected lines of every lane kept
@@ -492,7 +495,9 @@ __device__ __forceinline__ void reduce_core(const uint8_t *__restrict__ kjc, con
 #pragma unroll
         for (int bb = 0; bb < RRL_MAX_HITS; ++bb)
             if (bb < j) col += welsch(fminf(fminf(Dl[bb], Dl[4 + bb]), fminf(Dl[8 + bb], Dl[12 + bb])), med);
-        // Wl in [0,1], <= 4 terms: 2^-40 fixed point keeps ~2^-38 relative resolution
+        // Wl in [0,1], <= 4 terms: 2^-40 fixed point keeps ~2^-38 relative resolution.  A NaN term (0 / 0 with
+        // median 0, code/loss.py:20-21 gives NaN there too) cannot be carried by the fixed-point sums: flag it
+        if (!(row <= 4.0f) || !(col <= 4.0f)) { atomicOr(L_.s_bad, 1); row = col = 0.0f; }
         const int bi = (k - 1) * 4 + (j - 1);
         atomicAdd(&s_sum[bi * 2 + 0], (unsigned long long)((double)row * (double)(1ll << FIX_SHIFT) + 0.5));
         atomicAdd(&s_sum[bi * 2 + 1], (unsigned long long)((double)col * (double)(1ll << FIX_SHIFT) + 0.5));
@@ -538,18 +543,19 @@ __global__ __launch_bounds__(1024) void loss_reduce_kernel(
     __shared__ unsigned s_cand[2], s_whist[128];
     __shared__ unsigned long long s_sum[32];
     __shared__ int s_cnt[16];
+    __shared__ int s_bad;
     __shared__ float s_term[16];
     const int g = blockIdx.x, tid = threadIdx.x;
     const int bm = pool ? B - 1 : g;  // whose values define the median
     const int b0 = pool ? 0 : g, b1 = pool ? B : g + 1;
     if (tid < 32) s_sum[tid] = 0ull;
     if (tid < 16) s_cnt[tid] = 0;
-    if (tid == 0) { s_nvals = 0; s_cand[0] = 0; s_cand[1] = 0; }
+    if (tid == 0) { s_nvals = 0; s_cand[0] = 0; s_cand[1] = 0; s_bad = 0; }
     s_hist[tid] = 0;
     s_hist[tid + 1024] = 0;
 
     const int ns_m = load_prefix(blkcnt + (size_t)bm * nblk, nblk, s_pref, tid);
-    const ReduceLds lds = {s_pref, s_hist, s_wtot, s_prefix, s_rank, &s_nvals, s_cand, s_whist, s_sum, s_cnt};
+    const ReduceLds lds = {s_pref, s_hist, s_wtot, s_prefix, s_rank, &s_nvals, s_cand, s_whist, s_sum, s_cnt, &s_bad};
     float med;
     unsigned n;
     if (ns_m <= 1024) reduce_core<1>(kjc, dc, blkcnt, lds, ns_m, B, nblk, bm, b0, b1, tid, med, n);
@@ -584,7 +590,7 @@ __global__ __launch_bounds__(1024) void loss_reduce_kernel(
                 nselected += s_cnt[bi];
             }
         med_out[g] = med;
-        loss[g] = C ? acc / (float)C : 0.0f;  // code/loss.py:230
+        loss[g] = s_bad ? __builtin_nanf("") : (C ? acc / (float)C : 0.0f);  // code/loss.py:230
         info[g * 4 + 0] = C;
         info[g * 4 + 1] = nselected;
         info[g * 4 + 2] = (int)n;
@@ -696,6 +702,10 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(
 
 __device__ __forceinline__ int bwd_live_blocks(int ns) { return ns > 0 ? (ns + BWD_LINES - 1) / BWD_LINES : 1; }
 
+// DET = true (rrl_set_deterministic): instead of the atomics every workgroup stores its 12 sums to
+// part[b][workgroup][12] and loss_bwd_rt_finalize_kernel adds them in index order; the assignment of
+// lines to workgroups is fixed too (see below) -- bit-reproducible from run to run, one more (tiny) launch.
+template <bool DET>
 __global__ __launch_bounds__(256) void loss_bwd_rt_kernel(
     const uint8_t *__restrict__ kj, const int32_t *__restrict__ sel, const int32_t *__restrict__ nsel,
     const int32_t *__restrict__ hs1, const float *__restrict__ w1, const float4 *__restrict__ Q1,
@@ -703,19 +713,57 @@ __global__ __launch_bounds__(256) void loss_bwd_rt_kernel(
     const int32_t *__restrict__ bcnt, const int32_t *__restrict__ info,
     const float *__restrict__ grad_loss, const float *__restrict__ src, float *__restrict__ gR,
     float *__restrict__ gt, float *__restrict__ payload, const float *__restrict__ loss, int B, int N,
-    int L, int transpose_r) {
+    int L, int transpose_r, float *__restrict__ part) {
     __shared__ float red[4][12];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.y;
-    const int ns = nsel[b];
-    if ((int)blockIdx.x >= bwd_live_blocks(ns)) return;  // uniform: nothing selected in this slice
-    const int i = blockIdx.x * BWD_LINES + (tid >> 2), h = tid & 3;
+    const int h = tid & 3;
+    int li = -1;  // this lane's selected line (index within the sample), or none
+    if constexpr (DET) {
+        // SEL lists the selected lines in the order the pair kernel's workgroups happened to reserve their
+        // slots (an atomic): grouping lines into workgroups by SEL position would change the rounding of
+        // the partial sums from run to run.  Here workgroup (tile, sub) takes the selected lines of its
+        // 1024-line tile with rank 64 sub .. 64 sub + 63 in a FIXED order (round r, then thread), found
+        // from the KJ bytes of the tile.
+        __shared__ int s_line[BWD_LINES];
+        __shared__ int s_wc[4][4];
+        const int tile = blockIdx.x >> 4, sub = blockIdx.x & 15;
+        bool sl[4];
+        unsigned long long bm[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int l = tile * 1024 + r * 256 + tid;
+            sl[r] = l < L && kj[(size_t)b * L + l] != 0;
+            bm[r] = __ballot(sl[r]);
+            if (lane == 0) s_wc[r][wave] = __popcll(bm[r]);
+        }
+        if (tid < BWD_LINES) s_line[tid] = -1;
+        __syncthreads();
+        int before = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            int mine = before;
+            for (int w = 0; w < 4; ++w) {
+                if (w < wave) mine += s_wc[r][w];
+                before += s_wc[r][w];
+            }
+            const int rel = mine + __popcll(bm[r] & ((1ull << lane) - 1ull)) - BWD_LINES * sub;
+            if (sl[r] && rel >= 0 && rel < BWD_LINES) s_line[rel] = tile * 1024 + r * 256 + tid;
+        }
+        __syncthreads();
+        li = s_line[tid >> 2];
+    } else {
+        const int ns = nsel[b];
+        if ((int)blockIdx.x >= bwd_live_blocks(ns)) return;  // uniform: nothing selected in this slice
+        const int i = blockIdx.x * BWD_LINES + (tid >> 2);
+        if (i < ns) li = sel[(size_t)b * L + i];
+    }
     float acc[12];
 #pragma unroll
     for (int q = 0; q < 12; ++q) acc[q] = 0.0f;
     const int C = info[b * 4];
-    if (i < ns && C > 0) {
-        const size_t gl = (size_t)b * L + sel[(size_t)b * L + i];
+    if (li >= 0 && C > 0) {
+        const size_t gl = (size_t)b * L + li;
         const unsigned c = kj[gl];
         const int k = c & 15, j = c >> 4;
         if (h < k) {
@@ -776,14 +824,60 @@ __global__ __launch_bounds__(256) void loss_bwd_rt_kernel(
         const float v = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
         int o = tid;  // m-index (i, j) -> memory order of R
         if (tid < 9 && transpose_r) o = (tid % 3) * 3 + tid / 3;
-        if (tid < 9) atomicAdd(&gR[b * 9 + o], v); else atomicAdd(&gt[b * 3 + (tid - 9)], v);
-        if (payload) atomicAdd(&payload[2 + o], v);
+        if constexpr (DET) {
+            part[((size_t)b * gridDim.x + blockIdx.x) * 12 + o] = v;
+        } else {
+            if (tid < 9) atomicAdd(&gR[b * 9 + o], v); else atomicAdd(&gt[b * 3 + (tid - 9)], v);
+            if (payload) atomicAdd(&payload[2 + o], v);
+        }
     }
-    if (payload && blockIdx.x == 0 && b == 0 && tid >= 64 && tid < 66) {  // [sum of valid losses, #valid]
+    if (!DET && payload && blockIdx.x == 0 && b == 0 && tid >= 64 && tid < 66) {  // [sum of valid losses, #valid]
         double sp = 0.0;
         for (int k = 0; k < B; ++k) sp += info[k * 4] > 0 ? (tid == 64 ? (double)loss[k] : 1.0) : 0.0;
         payload[tid - 64] = (float)sp;
     }
+}
+
+// Fixed-order tail of the deterministic direct backward: one lane per (sample, entry) adds the live
+// workgroups' partials in index order (double accumulator), then 14 lanes build the payload over the
+// samples in index order.  One workgroup; B * 12 <= a few hundred sums of <= L / 64 terms.
+__global__ __launch_bounds__(256) void loss_bwd_rt_finalize_kernel(const float *__restrict__ part,
+                                                                   const int32_t *__restrict__ info,
+                                                                   const float *__restrict__ loss, float *__restrict__ gR,
+                                                                   float *__restrict__ gt, float *__restrict__ payload,
+                                                                   int B, int nblk) {
+    for (int e = threadIdx.x; e < B * 12; e += 256) {
+        const int b = e / 12, o = e % 12;
+        double s = 0.0;
+        for (int k = 0; k < nblk; ++k) s += (double)part[((size_t)b * nblk + k) * 12 + o];
+        if (o < 9) gR[b * 9 + o] = (float)s; else gt[b * 3 + (o - 9)] = (float)s;
+    }
+    if (!payload) return;
+    __syncthreads();  // gR / gt of every sample are written (same workgroup)
+    if (threadIdx.x < 14) {
+        const int q = threadIdx.x;
+        double s = 0.0;
+        for (int b = 0; b < B; ++b) {
+            if (q == 0) s += info[b * 4] > 0 ? (double)loss[b] : 0.0;
+            else if (q == 1) s += info[b * 4] > 0 ? 1.0 : 0.0;
+            else if (q < 11) s += (double)gR[b * 9 + (q - 2)];
+            else s += (double)gt[b * 3 + (q - 11)];
+        }
+        payload[q] = (float)s;
+    }
+}
+
+static int g_deterministic = -1;  // -1: read RRL_DETERMINISTIC once
+extern "C" int rrl_set_deterministic(int on) {
+    g_deterministic = on ? 1 : 0;
+    return 0;
+}
+static bool rrl_deterministic() {
+    if (g_deterministic < 0) {
+        const char *e = getenv("RRL_DETERMINISTIC");
+        g_deterministic = (e && e[0] == '1') ? 1 : 0;
+    }
+    return g_deterministic == 1;
 }
 
 static int loss_backward_impl(const float *tri1, const float *tri2, const void *ws,
@@ -854,7 +948,11 @@ static int loss_forward_impl(const float *tri1, const float *tri2, const float *
     if (target_ws == ws) return RRL_E_ARG;
     const int clouds = target_ws ? 1 : 2;
     int rc;
-    if ((rc = rrl_tri_prepare_clouds(tri1, tri2, ws, ws_bytes, B, N, M, L, clouds, xf, stream))) return rc;
+    RrlRange step("rrl forward");
+    {
+        RrlRange r("K1' records + sort + tree");
+        if ((rc = rrl_tri_prepare_clouds(tri1, tri2, ws, ws_bytes, B, N, M, L, clouds, xf, stream))) return rc;
+    }
     if (target_ws && (size_t)B * L) {  // after the prepare step, which cleared COUNT2
         WsLayout w(B, N, M, L);
         hipStream_t s = (hipStream_t)stream;
@@ -865,11 +963,17 @@ static int loss_forward_impl(const float *tri1, const float *tri2, const float *
                            sizeof(int32_t) * RRL_MAX_HITS * (size_t)B * L, s)))
             return rc;
     }
-    if ((rc = rrl_line_tri_scan_clouds(line, ws, ws_bytes, B, N, M, L, mode, chunk, clouds, stream)))
-        return rc;
-    if ((rc = line_pair_dist_impl(target_ws ? tri2 : nullptr, line, ws, ws_bytes, B, N, M, L, s_m, s_n, e_m,
-                                  e_n, pool, stream)))
-        return rc;
+    {
+        RrlRange r("K1 line<->triangle scan");
+        if ((rc = rrl_line_tri_scan_clouds(line, ws, ws_bytes, B, N, M, L, mode, chunk, clouds, stream))) return rc;
+    }
+    {
+        RrlRange r("K2 per-line distances");
+        if ((rc = line_pair_dist_impl(target_ws ? tri2 : nullptr, line, ws, ws_bytes, B, N, M, L, s_m, s_n, e_m,
+                                      e_n, pool, stream)))
+            return rc;
+    }
+    RrlRange r("K3+K4 median + Welsch reduce");
     return rrl_loss_reduce(ws, ws_bytes, loss, B, N, M, L, s_m, s_n, e_m, e_n, pool, stream);
 }
 
@@ -929,23 +1033,38 @@ extern "C" int rrl_registration_backward(const float *src, const float *R, const
     if (ws_bytes < w.total) return RRL_E_WS;
     float *g1 = w.f32(ws, RRL_WS_G1);
     hipStream_t s = (hipStream_t)stream;
+    RrlRange step("K5 rrl backward");
     if (!grad_src && B > 0 && L > 0) {
         // only dL/dR, dL/dt (+ payload): ONE launch, straight from the selected lines; the outputs
         // are accumulated with atomics -- clear them unless they are the workspace's GACC field,
         // which the forward left zeroed
         float *gacc = w.f32(ws, RRL_WS_GACC);
+        const int nblk = rrl_deterministic() ? 16 * ((L + 1023) / 1024) : (L + BWD_LINES - 1) / BWD_LINES;
+#define RRL_BWD_RT(DET, PART)                                                                                  \
+        hipLaunchKernelGGL(loss_bwd_rt_kernel<DET>, dim3((unsigned)nblk, (unsigned)B), dim3(256), 0, s,            \
+                           w.u8(ws, RRL_WS_KJ), w.i32(ws, RRL_WS_SEL), w.i32(ws, RRL_WS_NSEL), w.i32(ws, RRL_WS_HS1), \
+                           w.f32(ws, RRL_WS_W1), (const float4 *)w.f32(ws, RRL_WS_Q1),                             \
+                           (const float4 *)w.f32(ws, RRL_WS_Q2), w.f32(ws, RRL_WS_D), w.f32(ws, RRL_WS_MED),       \
+                           w.i32(ws, RRL_WS_BCNT), w.i32(ws, RRL_WS_INFO), grad_loss, src, gR, gt, payload, loss,  \
+                           B, N, L, transpose_r, PART)
+        if (rrl_deterministic()) {
+            // partials in VALS (the reduce kernel's input tiles: dead after the forward; B * Lp * 16 floats
+            // >= B * 16 ceil(L / 1024) * 12), fixed-order sums by a second launch: nothing to clear
+            float *part = w.f32(ws, RRL_WS_VALS);
+            RRL_BWD_RT(true, part);
+            hipLaunchKernelGGL(loss_bwd_rt_finalize_kernel, dim3(1), dim3(256), 0, s, part, w.i32(ws, RRL_WS_INFO), loss,
+                               gR, gt, payload, B, nblk);
+            RRL_LAUNCH_CHECK();
+            return 0;
+        }
         if (gR != gacc || gt != gacc + 9 * (size_t)B || (payload && payload != gacc + 12 * (size_t)B)) {
             int rc;
             if ((rc = rrl_fill(gR, 0u, sizeof(float) * 9 * (size_t)B, s))) return rc;
             if ((rc = rrl_fill(gt, 0u, sizeof(float) * 3 * (size_t)B, s))) return rc;
             if (payload && (rc = rrl_fill(payload, 0u, sizeof(float) * 14, s))) return rc;
         }
-        hipLaunchKernelGGL(loss_bwd_rt_kernel, dim3((unsigned)((L + BWD_LINES - 1) / BWD_LINES), (unsigned)B),
-                           dim3(256), 0, s, w.u8(ws, RRL_WS_KJ), w.i32(ws, RRL_WS_SEL), w.i32(ws, RRL_WS_NSEL),
-                           w.i32(ws, RRL_WS_HS1), w.f32(ws, RRL_WS_W1), (const float4 *)w.f32(ws, RRL_WS_Q1),
-                           (const float4 *)w.f32(ws, RRL_WS_Q2), w.f32(ws, RRL_WS_D), w.f32(ws, RRL_WS_MED),
-                           w.i32(ws, RRL_WS_BCNT), w.i32(ws, RRL_WS_INFO), grad_loss, src, gR, gt, payload, loss,
-                           B, N, L, transpose_r);
+        RRL_BWD_RT(false, nullptr);
+#undef RRL_BWD_RT
         RRL_LAUNCH_CHECK();
         return 0;
     }

@@ -45,7 +45,7 @@ def build_lib(force=False, verbose=False):
             print(" ".join(cmd))
         subprocess.check_call(cmd)
         objs.append(obj)
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, "-ldl"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

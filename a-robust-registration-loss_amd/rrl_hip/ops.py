@@ -371,6 +371,12 @@ def registration_loss(src_tri, R, t, tar_tri, line, rng=(1, 1, 5, 5), transpose_
                                    chunk, want_payload, target_from)
 
 
+def set_deterministic(on):
+    """Bit-reproducible direct backward of registration_loss (fixed-order partial sums, one more tiny
+    launch) instead of float atomics; include/rrl.h rrl_set_deterministic.  Process-wide."""
+    check(_lib.load().rrl_set_deterministic(int(bool(on))), "rrl_set_deterministic")
+
+
 def last_state():
     """LossState of the most recent loss evaluation on this process (workspace views, payload)."""
     return _IntersectionLoss.last_state

@@ -160,11 +160,27 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-extras", action="store_true", help="skip the strict / counter / drop-in passes")
+    ap.add_argument("--no-dist", action="store_true",
+                    help="single process without a process group (default: even a plain 1-GPU run creates a 1-rank "
+                         "RCCL group, so that the timed step carries the same in-graph all-reduce as N > 1)")
     args = ap.parse_args()
+    if "RANK" not in os.environ and not args.no_dist and args.gpus == 1:
+        # not under torchrun: a standalone 1-rank group on a free local port
+        import socket
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
 
     from rrl_hip import dist as rdist, ops
     import loss as Lmod
-    rank, world, local = rdist.init_from_env()
+    try:
+        rank, world, local = rdist.init_from_env()
+    except Exception as exc:  # no usable RCCL / rendezvous for the standalone group: measure without one
+        if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+            raise
+        print(f"[bench] process group unavailable ({type(exc).__name__}: {exc}); running without one", file=sys.stderr)
+        rank, world, local = 0, 1, 0
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local)

@@ -165,6 +165,11 @@ int rrl_registration_forward_cached(const float *src, const float *R, const floa
                                     float *loss, int B, int N, int M, int L, int transpose_r,
                                     int s_m, int s_n, int e_m, int e_n, int mode, int chunk,
                                     const void *target_ws, void *stream);
+/* Opt-in bit-reproducible direct backward (grad_src == NULL): on != 0 replaces the float atomics of
+ * rrl_registration_backward by per-workgroup partial sums added in a fixed order by a second, tiny
+ * launch (the reference's CPU autograd is deterministic).  Env RRL_DETERMINISTIC=1 sets the initial
+ * state.  The forward, and the d/dsrc route, are deterministic either way. */
+int rrl_set_deterministic(int on);
 int rrl_registration_backward(const float *src, const float *R, const float *tri2, void *ws,
                               size_t ws_bytes, const float *loss, const float *grad_loss,
                               float *grad_src, float *gR, float *gt, float *payload, int B, int N,

@@ -1019,6 +1019,74 @@ def test_fused_registration_backward_paths(L, n, m, transpose_r):
                 np.testing.assert_allclose(ma, mb, rtol=1e-4, atol=1e-6 * (np.abs(mb).max() + 1e-12))
 
 
+def test_deterministic_direct_backward(L):
+    """rrl_set_deterministic: the direct (dR, dt) backward with fixed-order partial sums is bit-reproducible
+    run to run (the default accumulates with float atomics: equal to rounding noise only) and agrees
+    with the default and with the d/dsrc route."""
+    from rrl_hip import ops, synth
+    from LieAlgebra import se3
+    B, N, M, nl = 3, 1500, 1300, 5000
+    prs = [synth.make_pair(60 + b, N, M) for b in range(B)]
+    src = cu(np.stack([p["src_tri"] for p in prs]))
+    tar = cu(np.stack([p["tar_tri"] for p in prs]))
+    torch.manual_seed(2)
+    lines = L.Random_uniform_distribution_lines_batch_efficient_resample(
+        torch.tensor([[p["radius"]] for p in prs]), torch.from_numpy(np.stack([p["center"] for p in prs])), nl,
+        src.reshape(B, -1, 3), tar.reshape(B, -1, 3), "cuda")
+    R0, T0 = se3.exp3(0.05 * torch.randn(B, 6, generator=torch.Generator().manual_seed(1)))
+
+    def grads():
+        R, t = R0.cuda().requires_grad_(True), T0.cuda().requires_grad_(True)
+        loss, _, _ = ops.registration_loss(src, R, t, tar, lines, transpose_r=True, want_payload=True)
+        loss.sum().backward()
+        return R.grad.clone(), t.grad.clone(), ops.last_state().payload.clone(), loss.detach().clone()
+    ref = grads()
+    ops.set_deterministic(True)
+    try:
+        runs = [grads() for _ in range(12)]
+    finally:
+        ops.set_deterministic(False)
+    for r in runs[1:]:
+        for a, b in zip(runs[0], r):
+            assert torch.equal(a, b)
+    for a, b in zip(runs[0], ref):
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=2e-5, atol=1e-7)
+    assert float(runs[0][0].abs().sum()) > 0 and float(runs[0][2][1]) == B
+
+
+def test_identity_registration_is_nan_like_the_reference(L, oracle):
+    """src == tar: every D is 0, the median is 0 and Welsch1(0, 0) = 1 - exp(-(0/0)/2) is NaN in the
+    reference (code/loss.py:20-21, 223-229; the oracle and the torch-eager restatement agree): the loss must
+    be NaN, not a finite under-count."""
+    g = load_golden("loss_synth_s0.npz")
+    assert np.isnan(oracle.loss(g["tri1"], g["tri1"], g["lines"], want_grad=False)["loss"])
+    st = run_state(g["tri1"], g["tri1"], g["lines"], mode="cull")
+    assert int(st.info[0, 0]) > 0 and float(st.med[0]) == 0.0
+    assert np.isnan(st.loss.cpu().numpy()[0])
+    out = L.cal_loss_intersection_batch_whole_median_pts_lines(1, 1, 5, 5, cu(g["tri1"])[None], cu(g["tri1"])[None],
+                                                                cu(g["lines"])[None], "cuda")
+    assert out is not None and torch.isnan(out).all()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs")
+def test_inputs_on_a_non_current_device(L):
+    """Every op launches on the device that owns its data (ops._guard), whatever the current device is."""
+    from rrl_hip import ops
+    g = load_golden("loss_synth_s1.npz")
+    d1 = torch.device("cuda", 1)
+    torch.cuda.set_device(0)
+    t1, t2, ln = (torch.from_numpy(g[k])[None].to(d1) for k in ("tri1", "tri2", "lines"))
+    p = t1.clone().requires_grad_(True)
+    out = L.cal_loss_intersection_batch_whole_median_pts_lines(1, 1, 5, 5, p, t2, ln, d1)
+    np.testing.assert_allclose(out.item(), g["r0_loss"], rtol=1e-5)
+    out.backward()
+    assert p.grad.device == d1 and torch.isfinite(p.grad).all()
+    assert L.chamfer_dist(t1[..., :3], t2[..., :3]).device == d1
+    lines = L.Random_uniform_distribution_lines_batch_efficient_resample(
+        torch.tensor([[1.0]]), torch.zeros(1, 3), 500, t1[..., :3], t2[..., :3], d1)
+    assert lines.device == d1 and torch.cuda.current_device() == 0
+
+
 def test_graphed_step_matches_eager(L):
     from rrl_hip import ops
     from rrl_hip.graph import GraphedStep

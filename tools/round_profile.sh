@@ -8,15 +8,23 @@ R=$PWD; O=$R/gpurun_out; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 python3 $R/bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_stats -o s -- python3 $R/bench.py --no-cpu-baseline > $O/${TAG}_bench_prof.json 2> $O/${TAG}_bench_prof.err
+# the timed step alone (no strict / counter / drop-in / Chamfer passes): per-kernel averages of the headline path
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_stats_step -o s -- python3 $R/bench.py --no-cpu-baseline --no-extras > /dev/null 2> $O/${TAG}_bench_step.err
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/${TAG}_pmc_$c -o p -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-graph > $O/${TAG}_pmc_$c.log 2>&1
+  timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/${TAG}_pmc_$c -o p -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-graph --no-extras --no-dist > $O/${TAG}_pmc_$c.log 2>&1
 done
-timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $O/${TAG}_pmc_sqa -o p -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-graph > $O/${TAG}_pmc_sqa.log 2>&1
-timeout 300 rocprofv3 --pmc SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS SQ_INSTS_VMEM_WR --kernel-trace --output-format csv -d $O/${TAG}_pmc_sqb -o p -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-graph > $O/${TAG}_pmc_sqb.log 2>&1
+timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $O/${TAG}_pmc_sqa -o p -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-graph --no-extras --no-dist > $O/${TAG}_pmc_sqa.log 2>&1
+timeout 300 rocprofv3 --pmc SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS SQ_INSTS_VMEM_WR --kernel-trace --output-format csv -d $O/${TAG}_pmc_sqb -o p -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-graph --no-extras --no-dist > $O/${TAG}_pmc_sqb.log 2>&1
 cd $R
 python3 - "$TAG" <<'PY'
-import csv, collections, json, sys, glob
+import csv, collections, json, sys, glob, hashlib, os
 tag = sys.argv[1]
+def csrc_sha():  # == bench.py csrc_sha(): the profile is only attached to a bench line of the same build
+    h = hashlib.sha256()
+    d = "a-robust-registration-loss_amd/csrc"
+    for f in sorted(x for x in os.listdir(d) if x.endswith((".hip", ".h"))) + ["../../include/rrl.h"]:
+        h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 O = "gpurun_out"
 def per_kernel(counter_dir):
     f = glob.glob(f"{O}/{counter_dir}/**/*counter_collection.csv", recursive=True)
@@ -26,7 +34,7 @@ def per_kernel(counter_dir):
             name = r["Kernel_Name"].split("(")[0]
             agg[name][r["Counter_Name"]][int(r["Dispatch_Id"])] += float(r["Counter_Value"])
     return {k: {c: sum(d.values()) / len(d) for c, d in v.items()} for k, v in agg.items()}
-out = {"note": "rocprofv3 --pmc, separate passes per counter group (bench.py --no-graph --steps 6); per-launch means. "
+out = {"csrc_sha": csrc_sha(), "note": "rocprofv3 --pmc, separate passes per counter group (bench.py --no-graph --steps 6); per-launch means. "
                "FETCH_SIZE / WRITE_SIZE in KB as reported; gfx950 correction for wide (16 B/lane) streaming reads: "
                "bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (MI355X_MICROARCH.md, HBM section)"}
 hbm = {}
@@ -45,13 +53,13 @@ out["sq_per_kernel"] = {k: v for k, v in sq.items() if "cull" in k or "tri_" in 
 json.dump(out, open(f"{O}/{tag}_pmc_summary.json", "w"), indent=1)
 c_ = out["hbm_per_kernel"].get("cull_scan_kernel", {})
 if "FETCH_SIZE" in c_ and "WRITE_SIZE" in c_:  # the object bench.py reports as roofline.traffic
-    json.dump({"B8_N4096_L10000_cull": {
+    json.dump({"csrc_sha": csrc_sha(), "B8_N4096_L10000_cull": {
         "kernel": "cull_scan_kernel", "fetch_kb_raw": c_["FETCH_SIZE"], "write_kb_raw": c_["WRITE_SIZE"],
         "bytes": int(c_["bytes_corrected"]),
         "correction": "FETCH_SIZE x2 (gfx950 wide-read undercount), WRITE_SIZE as reported",
         "source": f"profiles/{tag}_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, "
                   "bench.py --no-graph --steps 6)"}}, open(f"{O}/{tag}_scan_hbm_traffic.json", "w"), indent=1)
-rows = list(csv.DictReader(open(glob.glob(f"{O}/{tag}_stats/**/*kernel_stats.csv", recursive=True)[0])))
+rows = list(csv.DictReader(open(glob.glob(f"{O}/{tag}_stats_step/**/*kernel_stats.csv", recursive=True)[0])))
 for r in rows[:12]:
     print(f"{r['Name'][:44]:44s} {r['Calls']:>5s} {float(r['AverageNs'])/1e3:9.1f} us")
 c = out["hbm_per_kernel"].get("cull_scan_kernel", {})
