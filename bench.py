@@ -142,6 +142,10 @@ def cpu_baseline(N, M, L, budget_s=12.0, eager_budget_s=8.0):
 
 
 def main():
+    # ONE JSON line on stdout is the contract: RCCL prints a version banner to fd 1 when a communicator
+    # comes up (and libraries may print whatever they like), so everything but the final line goes to stderr
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)  # 80 us each: the closing fence costs ~3 us/step at 30
@@ -461,7 +465,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(N, M, L)
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if hasattr(reducer, "close"):
         reducer.close()
     if dist.is_initialized():

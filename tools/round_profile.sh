@@ -17,7 +17,7 @@ timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ
 timeout 300 rocprofv3 --pmc SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS SQ_INSTS_VMEM_WR --kernel-trace --output-format csv -d $O/${TAG}_pmc_sqb -o p -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-graph --no-extras --no-dist > $O/${TAG}_pmc_sqb.log 2>&1
 cd $R
 python3 - "$TAG" <<'PY'
-import csv, collections, json, sys, glob, hashlib, os
+import csv, collections, json, sys, glob, hashlib, os, re
 tag = sys.argv[1]
 def csrc_sha():  # == bench.py csrc_sha(): the profile is only attached to a bench line of the same build
     h = hashlib.sha256()
@@ -31,7 +31,7 @@ def per_kernel(counter_dir):
     agg = collections.defaultdict(lambda: collections.defaultdict(lambda: collections.defaultdict(float)))
     for path in f:
         for r in csv.DictReader(open(path)):
-            name = r["Kernel_Name"].split("(")[0]
+            name = re.sub(r"^void ", "", r["Kernel_Name"]).split("(")[0].split("<")[0]
             agg[name][r["Counter_Name"]][int(r["Dispatch_Id"])] += float(r["Counter_Value"])
     return {k: {c: sum(d.values()) / len(d) for c, d in v.items()} for k, v in agg.items()}
 out = {"csrc_sha": csrc_sha(), "note": "rocprofv3 --pmc, separate passes per counter group (bench.py --no-graph --steps 6); per-launch means. "
