@@ -433,12 +433,12 @@ int rrl_line_tri_scan_clouds(const float *line, void *ws, size_t ws_bytes, int B
     if (R == 0) {
         const char *v = getenv("RRL_SCAN_VARIANT");
         R = v ? atoi(v) : 0;
-        if (R != 1 && R != 2 && R != 4 && R != 8) R = mode == RRL_SCAN_STRICT ? 2 : 4;
+        if (R != 1 && R != 2 && R != 4 && R != 8) R = 4;  // measured best for every mode (profiles/r02_scan_sweep.jsonl)
     }
     if (chunk == 0) {
         const char *c = getenv("RRL_SCAN_CHUNK");
         chunk = c ? atoi(c) : 0;
-        if (chunk <= 0) chunk = mode == RRL_SCAN_STRICT ? 256 : 128;
+        if (chunk <= 0) chunk = mode == RRL_SCAN_STRICT ? 64 : 128;
     }
     const int nmax = clouds == 2 && M > N ? M : N;
     dim3 grid((unsigned)((L + 256 * R - 1) / (256 * R)), (unsigned)((nmax + chunk - 1) / chunk),

@@ -56,6 +56,9 @@ _WS_FIELDS = [
     ("histg", torch.int32, lambda B, N, M, L, G: (2 * B * 2 * 4096 if max(N, M) > 4096 else 4,)),
 ]
 _layout_cache = {}
+_FIELD_INDEX = {name: i for i, (name, _, _) in enumerate(_WS_FIELDS)}
+_ITEMSIZE = {torch.int32: 4, torch.float32: 4, torch.uint8: 1, torch.int64: 8}
+_spec_cache = {}  # (dims) -> {field: (offset, nbytes, dtype, shape)}
 
 
 _gpu_ok = False
@@ -150,15 +153,22 @@ class LossState:
         self.loss = torch.empty(G, dtype=torch.float32, device=dev)
 
     def __getattr__(self, name):
-        for i, (fname, dtype, shape) in enumerate(_WS_FIELDS):
-            if fname == name:
-                shp = shape(*self.dims)
-                n = 1
-                for d in shp:
-                    n *= d
-                nb = n * torch.empty((), dtype=dtype).element_size()
-                return self.ws[self.offsets[i]:self.offsets[i] + nb].view(dtype).reshape(shp)
-        raise AttributeError(name)
+        i = _FIELD_INDEX.get(name)
+        if i is None:
+            raise AttributeError(name)
+        specs = _spec_cache.get(self.dims)
+        if specs is None:
+            specs = _spec_cache[self.dims] = {}
+        spec = specs.get(name)
+        if spec is None:
+            _, dtype, shape = _WS_FIELDS[i]
+            shp = shape(*self.dims)
+            n = 1
+            for d in shp:
+                n *= d
+            spec = specs[name] = (self.offsets[i], n * _ITEMSIZE[dtype], dtype, shp)
+        off, nb, dtype, shp = spec
+        return self.ws[off:off + nb].view(dtype).reshape(shp)
 
     @property
     def nbuckets(self):

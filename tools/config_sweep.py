@@ -10,7 +10,7 @@ from rrl_hip import ops, synth
 from rrl_hip.graph import GraphedStep
 
 
-def product_lines(prs, L):
+def product_lines(prs, L, radius_scale=1.0):
     """(B, L, 6) lines for the synthetic pairs from the PRODUCT sampler (CPU RNG stream seeded by the
     sample index); tools never touch oracle/ (test infrastructure only)."""
     import loss as Lmod
@@ -18,21 +18,30 @@ def product_lines(prs, L):
     for b, p in enumerate(prs):
         torch.manual_seed(b)
         out.append(Lmod.Random_uniform_distribution_lines_batch_efficient_resample(
-            torch.tensor([[float(p["radius"])]]), torch.from_numpy(p["center"]).reshape(1, 3), L,
+            torch.tensor([[float(p["radius"]) * radius_scale]]), torch.from_numpy(p["center"]).reshape(1, 3), L,
             torch.from_numpy(p["src"])[None].cuda(), torch.from_numpy(p["tar"])[None].cuda(), "cuda")[0])
     return torch.stack(out)
 
-def run(name, B, N, M, L, crop=False, noise=0.01):
+def run(name, B, N, M, L, crop=False, noise=0.01, diag=None):
+    """diag: rescale every pair so that the target's AABB diagonal is `diag` and sample the lines with
+    radius = the FULL diagonal -- the reference demo's convention and data scale
+    (test_demo_optimized_Lie_Algebra.py:45; 11.7 on sample_data/challenge_data)."""
     prs = [synth.make_pair(b, N, M, crop=crop, noise=noise) for b in range(B)]
+    if diag is not None:
+        for p in prs:
+            sc = np.float32(diag / (2.0 * float(p["radius"])))
+            for k in ("src", "tar", "src_tri", "tar_tri", "center"):
+                p[k] = (p[k] * sc).astype(np.float32)
+            p["radius"] = float(p["radius"]) * float(sc)
     src = torch.from_numpy(np.stack([p["src_tri"] for p in prs])).cuda()
     tar = torch.from_numpy(np.stack([p["tar_tri"] for p in prs])).cuda()
-    ln = product_lines(prs, L)
+    ln = product_lines(prs, L, 2.0 if diag is not None else 1.0)
     R = torch.eye(3, device="cuda").repeat(B, 1, 1).requires_grad_(True)
     t = torch.zeros(B, 3, device="cuda").requires_grad_(True)
     ones = torch.ones(B, device="cuda")
     def f():
         R.grad = t.grad = None
-        loss, info, _ = ops.registration_loss(src, R, t, tar, ln)
+        loss, info, _ = ops.registration_loss(src, R, t, tar, ln, mode=os.environ.get("RRL_SCAN_MODE", "cull"))
         torch.autograd.backward([loss], [ones])
         return loss, info
     g = GraphedStep(f)
@@ -42,9 +51,10 @@ def run(name, B, N, M, L, crop=False, noise=0.01):
     for _ in range(n): g()
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
     pairs = B * L * 3 * (N + M)
-    print(json.dumps({"config": name, "B": B, "N": N, "M": M, "L": L, "us_per_step": round(dt * 1e6, 1),
+    print(json.dumps({"mode": os.environ.get("RRL_SCAN_MODE", "cull"), "config": name, "B": B, "N": N, "M": M, "L": L, "us_per_step": round(dt * 1e6, 1),
                       "pairs_per_s": pairs / dt, "selected_lines": int(g.out[1][:, 1].sum()),
-                      "loss0": float(g.out[0][0])}))
+                      "loss0": float(g.out[0][0]), "filled_lines": int((ln.abs().sum(-1) > 0).sum()),
+                      "fallback_wavefronts": int(ops.last_state().status[1])}))
 
 if __name__ == "__main__":
     if len(sys.argv) > 1:  # e.g. tools/config_sweep.py 1,32768,32768,10000 1,65536,65536,10000
@@ -53,6 +63,7 @@ if __name__ == "__main__":
             run(f"B={B} N={N} M={M} L={L}", B, N, M, L)
         sys.exit(0)
     run("C1 demo", 1, 1024, 1024, 20000)
+    run("C1 demo at the reference's data scale (AABB diagonal 11.7, radius = full diagonal)", 1, 1024, 1024, 20000, diag=11.7)
     run("C2 bench", 8, 4096, 4096, 10000)
     run("C2 L=4096", 8, 4096, 4096, 4096)
     run("C2 L=20000", 8, 4096, 4096, 20000)
