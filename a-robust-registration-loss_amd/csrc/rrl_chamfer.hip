@@ -4,9 +4,10 @@
 // The brute-force kernel (rrl_geom.hip chamfer_nn_kernel) evaluates all N x M pairs in both
 // directions: 2.7e8 pair evaluations at B=8, 4096 x 4096, 79 us + 19 us for the mean, at the issue
 // limit of VALU ops with a scalar operand.  Here both clouds are put in grid-cell (Hilbert) order under
-// the sphere tree of rrl_tree.h -- the sort kernels of rrl_cull.hip, unchanged, fed with (x, y, z, index)
-// records -- and a workgroup = one PATCH of 64 consecutive sorted queries (one supergroup of the query
-// cloud) walks the target's tree with wave-uniform control flow, NNW wavefronts sharing the patch
+// the sphere tree of rrl_tree.h -- the sort kernels of rrl_cull.hip, fed with (x, y, z, index) records
+// (built inside the sort kernel for clouds <= 4096 points) -- and a workgroup = one PATCH of 64
+// consecutive sorted queries (one supergroup of the query cloud) walks the target's tree with
+// wave-uniform control flow, NNW wavefronts sharing the patch
 // (every wavefront holds all 64 queries in its lanes; of every target supergroup wavefront k owns leaf
 // k = group k of 16 records for NNW = 4):
 //   seed      the target supergroup whose centre is nearest to the patch centre is evaluated first
@@ -37,9 +38,9 @@
 
 typedef const float __attribute__((address_space(4))) * kptr;  // constant AS -> s_load
 
-int rrl_launch_cloud_sort(float4 *crec1, float4 *crec2, float *apart, int nblk, float4 *p0s1, float4 *p0s2,
-                          int32_t *idx1, int32_t *idx2, float4 *grp1, float4 *grp2, uint32_t *pmax,
-                          unsigned *histg, int B, int N, int M, hipStream_t s);
+int rrl_launch_cloud_sort(const float *raw1, const float *raw2, float4 *crec1, float4 *crec2, float *apart, int nblk,
+                          float4 *p0s1, float4 *p0s2, int32_t *idx1, int32_t *idx2, float4 *grp1, float4 *grp2,
+                          uint32_t *pmax, unsigned *histg, int B, int N, int M, hipStream_t s);
 int rrl_sort_capacity(void);
 
 struct ChamLayout {
@@ -152,6 +153,9 @@ __device__ __forceinline__ float root_of_best(const NNWave &w) {
 #define LEAF (SGT / NNW)
 static_assert(NNW == 8 || NNW == 4, "a wavefront owns a half (8 records) or a group (16) of every supergroup");
 #define LEAF_NODE(k) (NNW == 8 ? 5 + (k) : 1 + (k))
+#ifndef TB
+#define TB 1  // per-lane leaf tests per loop iteration (2, 4: no faster -- the kernel is VALU-issue bound, see notes)
+#endif
 
 // The `cnt` (<= LEAF) records of one leaf, wave-uniform, through the scalar cache in ONE request (the
 // arrays are padded to whole supergroups, so all LEAF rows exist); the keys are independent and
@@ -278,25 +282,40 @@ __global__ __launch_bounds__(64 * NNW) void chamfer_tree_kernel(
             }
             unsigned long long m = __ballot(cand);
             if constexpr (COUNT) c_sg += (unsigned)min(64, nsgt - j0);
+            // prune 2, TB candidates per iteration (tests inside a batch use the bound from before the batch)
             while (m) {
-                const int sl = __ffsll((long long)m) - 1, s = j0 + sl;
-                m &= m - 1;
-                const int cnt = min(LEAF, nt - s * SGT - wave * LEAF);
-                if (cnt <= 0) continue;  // uniform
-                // the leaf node was fetched by lane sl above: broadcast it (no dependent load per candidate)
-                const float gx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gn.x), sl));
-                const float gy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gn.y), sl));
-                const float gz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gn.z), sl));
-                const float gr = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gn.w), sl));
-                if constexpr (COUNT) ++c_gt;
-                {   // prune 2, per lane: |q - c| <= sqrt(bd) + R, squared; NaN anywhere: visit
+                int sl[TB];
+                bool need[TB];
+#pragma unroll
+                for (int u = 0; u < TB; ++u) {
+                    sl[u] = m ? __ffsll((long long)m) - 1 : -1;
+                    if (m) m &= m - 1;
+                }
+#pragma unroll
+                for (int u = 0; u < TB; ++u) {
+                    need[u] = false;
+                    if (sl[u] < 0) continue;  // uniform
+                    const int cnt = min(LEAF, nt - (j0 + sl[u]) * SGT - wave * LEAF);
+                    if (cnt <= 0) continue;  // uniform: empty leaf
+                    // the leaf node was fetched by lane sl above: broadcast it (no dependent load per candidate)
+                    const float gx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gn.x), sl[u]));
+                    const float gy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gn.y), sl[u]));
+                    const float gz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gn.z), sl[u]));
+                    const float gr = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gn.w), sl[u]));
+                    if constexpr (COUNT) ++c_gt;
+                    // per lane: |q - c| <= sqrt(bd) + R, squared; NaN anywhere: visit
                     const float dx = w.qx - gx, dy = w.qy - gy, dz = w.qz - gz;
                     const float d2 = dx * dx + dy * dy + dz * dz, t = sb + gr;
-                    if (!__any(w.valid && !(d2 * LB_SCALE > t * t))) continue;
+                    need[u] = __any(w.valid && !(d2 * LB_SCALE > t * t));
                 }
-                eval_leaf(w, s * SGT + wave * LEAF, cnt);
+#pragma unroll
+                for (int u = 0; u < TB; ++u) {
+                    if (!need[u]) continue;  // uniform
+                    const int s = j0 + sl[u], cnt = min(LEAF, nt - s * SGT - wave * LEAF);
+                    eval_leaf(w, s * SGT + wave * LEAF, cnt);
+                    if constexpr (COUNT) { ++c_ge; c_pairs += 64u * (unsigned)cnt; }
+                }
                 sb = root_of_best(w);
-                if constexpr (COUNT) { ++c_ge; c_pairs += 64u * (unsigned)cnt; }
             }
         }
         s_best[wave][lane] = w.best;
@@ -363,10 +382,12 @@ extern "C" int rrl_chamfer_tree_fwd(const float *x, const float *y, void *ws, si
     hipStream_t s = (hipStream_t)stream;
     char *w = (char *)ws;
     const int nmax = N > M ? N : M;
-    hipLaunchKernelGGL(pts_records_kernel, dim3((unsigned)((nmax + 255) / 256), (unsigned)B, 2u), dim3(256), 0, s, x, y,
-                       (float4 *)(w + L.crec1), (float4 *)(w + L.crec2), (float *)(w + L.apart),
-                       (uint4 *)(w + L.histg), (L.total - L.histg) / 16, B, N, M, L.nblk);
-    int rc = rrl_launch_cloud_sort((float4 *)(w + L.crec1), (float4 *)(w + L.crec2), (float *)(w + L.apart), L.nblk,
+    const bool small = nmax <= 4096;  // the sort kernel reads the points itself: no records launch
+    if (!small)
+        hipLaunchKernelGGL(pts_records_kernel, dim3((unsigned)((nmax + 255) / 256), (unsigned)B, 2u), dim3(256), 0, s, x,
+                           y, (float4 *)(w + L.crec1), (float4 *)(w + L.crec2), (float *)(w + L.apart),
+                           (uint4 *)(w + L.histg), (L.total - L.histg) / 16, B, N, M, L.nblk);
+    int rc = rrl_launch_cloud_sort(small ? x : nullptr, small ? y : nullptr, (float4 *)(w + L.crec1), (float4 *)(w + L.crec2), (float *)(w + L.apart), L.nblk,
                                    (float4 *)(w + L.p0s1), (float4 *)(w + L.p0s2), (int32_t *)(w + L.idx1),
                                    (int32_t *)(w + L.idx2), (float4 *)(w + L.grp1), (float4 *)(w + L.grp2),
                                    (uint32_t *)(w + L.pmax), (unsigned *)(w + L.histg), B, N, M, s);

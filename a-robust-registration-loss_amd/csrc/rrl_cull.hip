@@ -177,7 +177,11 @@ __global__ __launch_bounds__(REC_BLK) void tri_records_kernel(const BuildArgs a)
 }
 
 // Every lane keeps its <= NPT records in registers between the passes (n <= 1024 NPT).
-template <int NPT>
+// RAW = true (the Chamfer path, clouds <= 4096 points): tri1 / tri2 are POINT clouds [B][n][3]; the
+// kernel builds its (x, y, z, original index) records, the AABB and the NaN flag (slot 7 of the APART
+// row, read by chamfer_tree_kernel) itself -- no records launch in front of it.  12 bytes per point
+// through the single CU's memory pipe: the same traffic as the 16-byte CREC records.
+template <int NPT, bool RAW>
 __global__ __launch_bounds__(1024) void tri_sort_kernel(const BuildArgs a) {
     // the sorted records and their triangle indices are assembled in LDS ([ngp*17] float4, one
     // float4 of padding per group: lanes on different groups hit different banks; then [ngp*16]
@@ -202,14 +206,78 @@ __global__ __launch_bounds__(1024) void tri_sort_kernel(const BuildArgs a) {
 
     // ---- AABB of the P0s and max |P|^2 from the per-workgroup partials of tri_records_kernel
     float4 rec[NPT];
-#pragma unroll
-    for (int k = 0; k < NPT; ++k)  // issue the record loads first: they overlap the reduction
-        if (tid + 1024 * k < n) rec[k] = crec[tid + 1024 * k];
-    ((uint2 *)hlut)[tid] = ((const uint2 *)HILBERT_LUT.v)[tid];
-    // every row of 16 lanes reduces the <= 16 per-workgroup partials itself (DPP): no LDS round
-    // trip and no barrier for the AABB
     float bb[7];
-    {
+    if constexpr (RAW) {
+        __shared__ __attribute__((aligned(16))) float s_bb[16][8];
+        const float *pts = (cloud ? a.tri2 : a.tri1) + (size_t)b * n * 3;
+        float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY}, p2 = 0.0f;
+        bool bad = false;
+        // the 12-byte rows are fetched as one flat, coalesced stream of 16-byte loads into the (still
+        // unused) LDS region of the sorted records and picked up per point from there: 3-dword loads with
+        // a stride of 12 bytes cost the single CU's memory pipe 16.1 us for the whole kernel against 13.8 us
+        // for a records launch + this kernel reading 16-byte records
+        float *flat = dyn_s;
+        {
+            const int nf = 3 * n, nv = nf >> 2;
+            const bool al = (((uintptr_t)pts) & 15) == 0;  // uniform; sample offsets of 12 n bytes may break it
+            if (al) {
+                for (int i = tid; i < nv; i += 1024) ((float4 *)flat)[i] = ((const float4 *)pts)[i];
+                for (int i = 4 * nv + tid; i < nf; i += 1024) flat[i] = pts[i];
+            } else {
+                for (int i = tid; i < nf; i += 1024) flat[i] = pts[i];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NPT; ++k) {
+            const int f = tid + 1024 * k;
+            if (f < n) {
+                const float c0 = flat[3 * f], c1 = flat[3 * f + 1], c2 = flat[3 * f + 2];
+                rec[k] = make_float4(c0, c1, c2, __int_as_float(f));
+                mn[0] = fminf(mn[0], c0); mx[0] = fmaxf(mx[0], c0);
+                mn[1] = fminf(mn[1], c1); mx[1] = fmaxf(mx[1], c1);
+                mn[2] = fminf(mn[2], c2); mx[2] = fmaxf(mx[2], c2);
+                float q = c0 * c0 + c1 * c1 + c2 * c2;
+                if (!(q <= 3.0e38f)) q = INFINITY;
+                p2 = fmaxf(p2, q);
+                bad |= (c0 != c0) || (c1 != c1) || (c2 != c2);
+            }
+        }
+        ((uint2 *)hlut)[tid] = ((const uint2 *)HILBERT_LUT.v)[tid];
+        const float anybad = __any(bad) ? 1.0f : 0.0f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { mn[c] = wave_min(mn[c]); mx[c] = wave_max(mx[c]); }
+        p2 = wave_max(p2);
+        if (lane == 0) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { s_bb[wave][c] = mn[c]; s_bb[wave][3 + c] = mx[c]; }
+            s_bb[wave][6] = p2;
+            s_bb[wave][7] = anybad;
+        }
+        __syncthreads();
+        // every row of 16 lanes reduces the 16 wavefront rows itself (two 16-byte LDS reads + DPP), like the
+        // partial rows of the records kernel below
+        float any7;
+        {
+            const float4 p0 = ((const float4 *)s_bb[lane & 15])[0], p1 = ((const float4 *)s_bb[lane & 15])[1];
+            const float v[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+#pragma unroll
+            for (int c = 0; c < 7; ++c) {
+                const float r = c < 3 ? row16_min(v[c]) : row16_max(v[c]);
+                bb[c] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(r)));
+            }
+            any7 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(row16_max(v[7]))));
+        }
+        // the NN kernel ORs slot 7 over the ceil(n / 256) partial rows of the cloud: row 0 carries the flag
+        const int nb = (n + REC_BLK - 1) / REC_BLK;
+        if (tid < nb) a.apart[(((size_t)cloud * B + b) * a.nblk + tid) * 8 + 7] = tid == 0 ? any7 : 0.0f;
+    } else {
+#pragma unroll
+        for (int k = 0; k < NPT; ++k)  // issue the record loads first: they overlap the reduction
+            if (tid + 1024 * k < n) rec[k] = crec[tid + 1024 * k];
+        ((uint2 *)hlut)[tid] = ((const uint2 *)HILBERT_LUT.v)[tid];
+        // every row of 16 lanes reduces the <= 16 per-workgroup partials itself (DPP): no LDS round
+        // trip and no barrier for the AABB
         const int nb = (n + REC_BLK - 1) / REC_BLK;  // <= 16 for n <= 4096
         const float *ap = a.apart + ((size_t)cloud * B + b) * a.nblk * 8;
         // lanes 0..15 of each wavefront load one 32-byte partial row each (two 16-byte loads: the
@@ -896,7 +964,7 @@ int rrl_launch_tri_build(const float *tri1, const float *tri2, void *ws, const W
     hipLaunchKernelGGL(tri_records_kernel, dim3((unsigned)((nmax + REC_BLK - 1) / REC_BLK), (unsigned)B, (unsigned)clouds),
                        dim3(REC_BLK), 0, s, a);
     if (nmax <= 4096) {
-        hipLaunchKernelGGL(tri_sort_kernel<4>, dim3((unsigned)(clouds * B)), dim3(1024), lds, s, a);
+        hipLaunchKernelGGL((tri_sort_kernel<4, false>), dim3((unsigned)(clouds * B)), dim3(1024), lds, s, a);
     } else {  // wide three-launch sort (HISTG was cleared by tri_records_kernel)
         unsigned *histg = (unsigned *)w.i32(ws, RRL_WS_HISTG);
         const dim3 gt((unsigned)((nmax + 255) / 256), (unsigned)B, (unsigned)clouds);
@@ -909,17 +977,19 @@ int rrl_launch_tri_build(const float *tri1, const float *tri2, void *ws, const W
     return e == hipSuccess ? 0 : (int)e;
 }
 
-// Sort + sphere tree of clouds whose (x, y, z, w) records (CREC layout) and per-256-record AABB
-// partials (APART layout, nblk rows per cloud and sample) already exist: the same kernels as above,
-// for callers outside the loss workspace (the Chamfer path, rrl_chamfer.hip).  histg (cleared by the
-// caller) is only used beyond 4096 records.
-int rrl_launch_cloud_sort(float4 *crec1, float4 *crec2, float *apart, int nblk, float4 *p0s1, float4 *p0s2,
-                          int32_t *idx1, int32_t *idx2, float4 *grp1, float4 *grp2, uint32_t *pmax,
-                          unsigned *histg, int B, int N, int M, hipStream_t s) {
+// Sort + sphere tree for callers outside the loss workspace (the Chamfer path, rrl_chamfer.hip): the same
+// kernels as above.  Clouds of <= 4096 points given as raw1 / raw2 ([B][n][3]) are sorted straight from
+// the points (tri_sort_kernel<4, true>: records, AABB and NaN flag built in the kernel); otherwise the
+// (x, y, z, w) records (CREC layout) and per-256-record AABB partials (APART layout, nblk rows per cloud
+// and sample) must already exist and histg (cleared by the caller) is used beyond 4096 records.
+int rrl_launch_cloud_sort(const float *raw1, const float *raw2, float4 *crec1, float4 *crec2, float *apart, int nblk,
+                          float4 *p0s1, float4 *p0s2, int32_t *idx1, int32_t *idx2, float4 *grp1, float4 *grp2,
+                          uint32_t *pmax, unsigned *histg, int B, int N, int M, hipStream_t s) {
     const int nmax = M > N ? M : N;
     if (nmax > SORT_CAP || B <= 0 || nmax <= 0) return RRL_E_ARG;
     const size_t ngpmax = (size_t)(nmax + SGT - 1) / SGT * SGG;
     BuildArgs a = {};
+    a.tri1 = raw1; a.tri2 = raw2;  // point clouds [B][n][3]: only read by the RAW sort (nmax <= 4096)
     a.crec1 = crec1; a.crec2 = crec2;
     a.apart = apart; a.nblk = nblk;
     a.p0s1 = p0s1; a.p0s2 = p0s2;
@@ -929,7 +999,8 @@ int rrl_launch_cloud_sort(float4 *crec1, float4 *crec2, float *apart, int nblk, 
     a.B = B; a.N = N; a.M = M;
     if (nmax <= 4096) {
         const size_t lds = ngpmax * (17 * sizeof(float4) + GRP * sizeof(int));
-        hipLaunchKernelGGL(tri_sort_kernel<4>, dim3((unsigned)(2 * B)), dim3(1024), lds, s, a);
+        if (raw1 && raw2) hipLaunchKernelGGL((tri_sort_kernel<4, true>), dim3((unsigned)(2 * B)), dim3(1024), lds, s, a);
+        else hipLaunchKernelGGL((tri_sort_kernel<4, false>), dim3((unsigned)(2 * B)), dim3(1024), lds, s, a);
     } else {
         const dim3 gt((unsigned)((nmax + 255) / 256), (unsigned)B, 2u);
         hipLaunchKernelGGL(big_hist_kernel, gt, dim3(256), 0, s, a, histg);

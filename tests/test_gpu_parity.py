@@ -482,6 +482,45 @@ def test_baseline_configs_vs_oracle(L, oracle, n, m, nl, crop, noise):
     np.testing.assert_allclose(mine, om, rtol=1e-4, atol=1e-6 * np.abs(om).max())
 
 
+def test_config3_global_batch_64(L, oracle):
+    """BASELINE.json configs[2]: B = 64 at N = M = 4096, L = 10000 -- what the eight ranks of a node hold
+    together, here as ONE batch on one GPU (the shards are independent, so rank r's result is rows
+    8r .. 8r+7 of this batch: `bench.py --global-batch 64`).  The fused op on the whole batch equals the
+    per-shard evaluation bit for bit (loss, valid flags; dR / dt to atomics' rounding noise), the 14-float
+    payload is the sum of the shard payloads, and three samples spread over the batch match the oracle."""
+    from rrl_hip import ops, synth
+    from LieAlgebra import se3
+    B, N, M, nl = 64, 4096, 4096, 10000
+    prs = [synth.make_pair(300 + b, N, M) for b in range(B)]
+    src = cu(np.stack([p["src_tri"] for p in prs]))
+    tar = cu(np.stack([p["tar_tri"] for p in prs]))
+    lines = torch.stack([L.Random_uniform_distribution_lines_batch_efficient_resample(
+        torch.tensor([[p["radius"]]]), torch.from_numpy(p["center"])[None], nl, cu(p["src"])[None], cu(p["tar"])[None],
+        "cuda", device_rng=True)[0] for p in prs])
+    R0, T0 = se3.exp3(0.03 * torch.randn(B, 6, generator=torch.Generator().manual_seed(9)))
+
+    def run(lo, hi):
+        R, t = R0[lo:hi].cuda().requires_grad_(True), T0[lo:hi].cuda().requires_grad_(True)
+        loss, info, _ = ops.registration_loss(src[lo:hi], R, t, tar[lo:hi], lines[lo:hi], transpose_r=True,
+                                              want_payload=True)
+        loss.sum().backward()
+        return loss.detach().clone(), (info[:, 0] > 0).clone(), R.grad.clone(), t.grad.clone(), ops.last_state().payload.clone()
+    whole = run(0, B)
+    pay = torch.zeros(14, device="cuda")
+    for r in range(8):
+        sh = run(8 * r, 8 * r + 8)
+        assert torch.equal(sh[0], whole[0][8 * r:8 * r + 8]) and torch.equal(sh[1], whole[1][8 * r:8 * r + 8])
+        np.testing.assert_allclose(sh[2].cpu().numpy(), whole[2][8 * r:8 * r + 8].cpu().numpy(), rtol=2e-5, atol=1e-7)
+        np.testing.assert_allclose(sh[3].cpu().numpy(), whole[3][8 * r:8 * r + 8].cpu().numpy(), rtol=2e-5, atol=1e-7)
+        pay += sh[4]
+    np.testing.assert_allclose(pay.cpu().numpy(), whole[4].cpu().numpy(), rtol=2e-5, atol=1e-6)
+    assert float(whole[4][1]) == B
+    moved = ops.rigid_apply(src.reshape(B, -1, 3), R0.cuda(), T0.cuda(), transpose_r=True).reshape(B, N, 9).cpu().numpy()
+    for b in (0, 29, 63):
+        o = oracle.loss(moved[b], prs[b]["tar_tri"], lines[b].cpu().numpy(), want_grad=False)
+        np.testing.assert_allclose(float(whole[0][b]), o["loss"], rtol=1e-5)
+
+
 # ---------------------------------------------------------------------------------- K7
 def test_chamfer(L, oracle):
     g = load_golden("chamfer.npz")

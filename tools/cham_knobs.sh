@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU box: rebuild with -D knobs, time the tree Chamfer (graph replay) and take rocprof kernel stats (experiments)
 R=$PWD
-for k in "-DNNW=4" "-DNNW=8" "$@"; do
+for k in "-DNNW=4 -DTB=4" "-DNNW=4 -DTB=2" "-DNNW=4 -DTB=1" "-DNNW=8 -DTB=4" "$@"; do
   RRL_HIPCC_FLAGS="$k" python3 a-robust-registration-loss_amd/rrl_hip/build.py > /dev/null 2>&1
   echo "== $k"
   python3 tools/chamfer_prof.py 8 4096 4096 50 1 2>&1 | grep -v amdgpu.ids
