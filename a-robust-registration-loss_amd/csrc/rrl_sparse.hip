@@ -533,8 +533,8 @@ __device__ __forceinline__ void reduce_core(const uint8_t *__restrict__ kjc, con
 __global__ __launch_bounds__(1024) void loss_reduce_kernel(
     const uint8_t *__restrict__ kjc, const float *__restrict__ dc, const int32_t *__restrict__ blkcnt,
     float *__restrict__ med_out, int32_t *__restrict__ bcnt_out, int64_t *__restrict__ bsum_out,
-    int32_t *__restrict__ info, float *__restrict__ loss, int B, int nblk, int s_m, int s_n, int e_m,
-    int e_n, int pool) {
+    int32_t *__restrict__ info, float *__restrict__ loss, const int32_t *__restrict__ status, int B, int nblk,
+    int s_m, int s_n, int e_m, int e_n, int pool) {
     extern __shared__ int s_pref[];  // nblk + 1
     __shared__ unsigned s_hist[2048];
     __shared__ unsigned s_wtot[16];
@@ -594,7 +594,7 @@ __global__ __launch_bounds__(1024) void loss_reduce_kernel(
         info[g * 4 + 0] = C;
         info[g * 4 + 1] = nselected;
         info[g * 4 + 2] = (int)n;
-        info[g * 4 + 3] = 0;
+        info[g * 4 + 3] = status[0];  // the scan's NaN flag next to the bucket count: one 16-byte read-back decides the call
     }
 }
 
@@ -609,8 +609,8 @@ extern "C" int rrl_loss_reduce(void *ws, size_t ws_bytes, float *loss, int B, in
     hipLaunchKernelGGL(loss_reduce_kernel, dim3((unsigned)(pool ? 1 : B)), dim3(1024),
                        sizeof(int) * (size_t)(nblk + 1), (hipStream_t)stream, w.u8(ws, RRL_WS_KJC),
                        w.f32(ws, RRL_WS_VALS), w.i32(ws, RRL_WS_BLKCNT), w.f32(ws, RRL_WS_MED),
-                       w.i32(ws, RRL_WS_BCNT), w.i64(ws, RRL_WS_BSUM), w.i32(ws, RRL_WS_INFO), loss, B, nblk,
-                       s_m, s_n, e_m, e_n, pool);
+                       w.i32(ws, RRL_WS_BCNT), w.i64(ws, RRL_WS_BSUM), w.i32(ws, RRL_WS_INFO), loss,
+                       w.i32(ws, RRL_WS_STATUS), B, nblk, s_m, s_n, e_m, e_n, pool);
     RRL_LAUNCH_CHECK();
     return 0;
 }

@@ -84,8 +84,8 @@ def cal_loss_intersection_batch_whole_median_pts_lines(s_m, s_n, e_m, e_n, point
     pool = points1.shape[0] > 1
     loss, info, status = _ops.intersection_loss(points1, points2, line, (s_m, s_n, e_m, e_n),
                                                 pool=pool, mode=_scan_mode(mode), chunk=chunk)
-    flags = torch.stack([info[0, 0], status[0]]).tolist()  # the call's single host sync
-    if flags[1]:
+    flags = info[0].tolist()  # the call's single host sync: (nbuckets, nselected, nvalues, NaN flag) in one 16-byte copy
+    if flags[3]:
         raise ValueError("NaN point-to-line distance: line[..., :3] must be unit length or "
                          "all zero (reference: 'Exit the systerm', code/loss.py:88-91)")
     if flags[0] == 0:

@@ -277,7 +277,7 @@ class _IntersectionLoss(torch.autograd.Function):
 
 def intersection_loss(points1, points2, line, rng=(1, 1, 5, 5), pool=False, mode="cull", chunk=0,
                       target_from=None):
-    """Batched loss: returns (loss[G], info[G,4] = (nbuckets, nselected, nvalues, 0), status[4])
+    """Batched loss: returns (loss[G], info[G,4] = (nbuckets, nselected, nvalues, NaN flag), status[4])
     on the GPU, G = 1 if pool else B.  Each sample is an independent loss (what every reference
     caller obtains by looping B=1 calls); pool=True reproduces the reference's own B>1 behaviour
     (SURVEY Q2).  No host synchronisation happens here."""

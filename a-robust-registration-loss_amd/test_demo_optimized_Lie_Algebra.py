@@ -295,6 +295,10 @@ def main(args):
         from rrl_hip import synth
         pr = synth.make_pair(args.seed, args.synthetic, args.synthetic)
         vertics1, vertics2 = pr['src'], pr['tar']
+        diag = getattr(args, 'synthetic_diag', 0.0)
+        if diag:  # the data scale of the reference's sample_data/challenge_data: AABB diagonal 11.7
+            sc = np.float32(diag / (2.0 * float(pr['radius'])))
+            vertics1, vertics2 = vertics1 * sc, vertics2 * sc
     else:
         vertics1 = read_obj_vertices(os.path.join(args.data_path, args.label1 + "_src_sample.obj"))
         vertics2 = read_obj_vertices(os.path.join(args.data_path, args.label1 + "_tar_sample.obj"))
@@ -320,6 +324,8 @@ if __name__ == "__main__":
     parser.add_argument('--n_sample_line', type=int, default=20000)
     parser.add_argument('--synthetic', type=int, default=0, metavar='N',
                         help="use a seeded synthetic pair of N points instead of OBJ files")
+    parser.add_argument('--synthetic_diag', type=float, default=0.0, metavar='D',
+                        help="rescale the synthetic pair to an AABB diagonal of D (the reference's sample data: 11.7)")
     parser.add_argument('--graph', action='store_true', help="replay the step as one hipGraph")
     parser.add_argument('--print_every', type=int, default=1)
     parser.add_argument('--save_every', type=int, default=10, help="0: no OBJ / transform files")

@@ -98,7 +98,7 @@ enum {
     RRL_WS_MED,        /* float[G]  lower median (loss.py:223-224)                          */
     RRL_WS_BCNT,       /* int32[G][16] lines per (k,j) bucket                               */
     RRL_WS_BSUM,       /* int64[G][16][2] bucket sums of row / column minima, 2^-40 fixed pt */
-    RRL_WS_INFO,       /* int32[G][4] nbuckets, nselected, nvalues, 0                       */
+    RRL_WS_INFO,       /* int32[G][4] nbuckets, nselected, nvalues, STATUS[0] (the scan's NaN flag)  */
     RRL_WS_TRI1,       /* float[B][N][9] transformed source triangles (rrl_registration_*)   */
     RRL_WS_G1,         /* float[B][N][9] gradient w.r.t. TRI1 (rrl_registration_backward)    */
     RRL_WS_RPART,      /* float[B][nblk][12] rigid-apply backward partial sums              */
