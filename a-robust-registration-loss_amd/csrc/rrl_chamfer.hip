@@ -6,18 +6,20 @@
 // limit of VALU ops with a scalar operand.  Here both clouds are put in grid-cell (Hilbert) order under
 // the sphere tree of rrl_tree.h -- the sort kernels of rrl_cull.hip, fed with (x, y, z, index) records
 // (built inside the sort kernel for clouds <= 4096 points) -- and a workgroup = one PATCH of 64
-// consecutive sorted queries (one supergroup of the query cloud) walks the target's tree with
-// wave-uniform control flow, NNW wavefronts sharing the patch
-// (every wavefront holds all 64 queries in its lanes; of every target supergroup wavefront k owns leaf
-// k = group k of 16 records for NNW = 4):
-//   seed      the target supergroup whose centre is nearest to the patch centre is evaluated first
-//             (wavefront k its leaf k, minima exchanged through LDS): a good upper bound bd per query;
+// consecutive sorted queries (one supergroup of the query cloud) walks the target's tree, NNW x SPLIT
+// wavefronts sharing the patch (wavefront (k, c) owns leaf k = group k of 16 records of every target
+// supergroup j with j % SPLIT == c):
+//   seed      the target supergroup whose centre is nearest to the patch centre is evaluated first for all
+//             64 queries (minima folded into LDS): a good upper bound bd per query;
 //   prune 1   lane-parallel over the target supergroups: lane j tests this wavefront's leaf of supergroup
 //             j against each of the patch's four query-group spheres with that group's largest bound;
-//   prune 2   per surviving leaf every lane tests ITS query against the leaf sphere; the leaf is
-//             evaluated when some lane's bound allows it (one ballot);
-//   leaves    the records of a leaf arrive through the scalar cache in one request (wave-uniform),
-//             11 VALU ops per (query, target) pair, keys reduced as a tree.
+//   stage     the surviving leaves' records go to LDS, CHK leaves per round (coalesced loads);
+//   prune 2   per staged leaf every lane tests ITS query against the leaf sphere with its CURRENT bound and
+//             pushes a (query, leaf) entry into the wavefront's LDS queue when it needs the leaf;
+//   passes    whenever 64 entries wait every lane pops one and evaluates "its" 16 records for "its" query
+//             (11 VALU ops per pair, keys reduced as a tree), folding the key into the query's minimum with
+//             an LDS atomicMin -- all lanes busy on pairs that are actually needed (3.7 % of the dense pairs
+//             on the bench clouds against 10.5 % when a leaf is evaluated for the whole wavefront).
 // Exactness: a distance is evaluated with the reference's arithmetic ((dx^2 + dy^2) + dz^2, no FMA);
 // every pruning test is |q - c|^2 (1 - 1e-4) > (sqrt(bd) (1 + 1e-5) + R)^2 with the tree's conservative
 // radii, so a leaf is skipped only if every point in it is STRICTLY farther than the lane's current
@@ -25,15 +27,19 @@
 // resolve to the smallest index in any visiting order == torch.min's first occurrence.  Keys are
 // bit-identical to the brute-force kernel's (tests/test_gpu_parity.py).  NaN: a NaN coordinate in the
 // target cloud makes every minimum of that sample NaN, a NaN query its own minimum (torch semantics:
-// min propagates NaN) -- decided from per-workgroup flags of the records kernel, at no cost in the
+// min propagates NaN) -- decided from per-workgroup flags of the records / sort kernel, at no cost in the
 // inner loop.  The mean: per-patch double partials, summed in a fixed order by a tiny second launch.
 //
-// Measured on the way (B=8, 4096 x 4096, profiles/r02_chamfer_notes.txt): one wavefront per patch 88 us;
-// a release fence per workgroup for a "last workgroup sums" hand-over +30 us (1024 write-backs of an
-// XCD's L2), relaxed tickets on one address +5 us (same-address device atomics serialise at ~12 ns);
-// patches of one (sample, direction) spread over all XCDs +10 us; broadcasting the targets through LDS
-// (all lanes reading the same 16 bytes costs the full 1 KiB of LDS bandwidth) or with v_readlane: no
-// better than the scalar cache; a running u64 minimum instead of the key tree: same.
+// What bounds it (profiles/r02_chamfer_notes.txt): every wavefront starts within 0.5 us and lives ~10 us
+// (a chain of dependent memory / LDS round trips and short serial steps), but the kernel lasts as long as
+// its SLOWEST patch -- on misaligned clouds the queries far from the target see most of the tree (mean
+// lifetime 11 us, last end 25.7 us with 4 wavefronts per patch).  SPLIT = 2 halves that tail: 26.5 -> 22 us.
+// Also measured: a release fence per workgroup for a "last workgroup sums" hand-over +30 us (1024
+// write-backs of an XCD's L2), relaxed tickets on one address +5 us (same-address device atomics
+// serialise at ~12 ns); patches of one (sample, direction) spread over all XCDs +10 us; evaluating a leaf
+// for the whole wavefront with the targets broadcast through LDS, v_readlane or the scalar cache: 25-27 us
+// each; instrumenting with same-address atomics distorts every memory latency in the kernel (use the
+// per-wavefront rows of rrl_chamfer_counters).
 #include "rrl_tree.h"
 
 typedef const float __attribute__((address_space(4))) * kptr;  // constant AS -> s_load
@@ -132,24 +138,17 @@ struct NNWave {
     unsigned long long best;  // (distance bits << 32) | original target index
 };
 
-__device__ __forceinline__ unsigned long long point_key(const NNWave &w, float tx, float ty, float tz, float ti) {
-    // code/loss.py:51: sum((x - y)**2, -1); (a0 + a1) + a2, no FMA
-    const float dx = w.qx - tx, dy = w.qy - ty, dz = w.qz - tz;
-    float s = dx * dx;
-    s = s + dy * dy;
-    s = s + dz * dz;
-    // NaN bits (> +inf bits) never win: handled by the flags
-    return ((unsigned long long)__float_as_uint(s) << 32) | (unsigned)__float_as_int(ti);
-}
 __device__ __forceinline__ unsigned long long kmin(unsigned long long a, unsigned long long b) { return b < a ? b : a; }
-// sqrt(current best distance) rounded up; NaN bits (no target seen yet) give NaN: every test then visits
-__device__ __forceinline__ float root_of_best(const NNWave &w) {
-    return __builtin_amdgcn_sqrtf(__uint_as_float((unsigned)(w.best >> 32))) * 1.00001f;
-}
 
 #ifndef NNW
 #define NNW 4  // wavefronts per patch: 4 (leaf = group of 16) or 8 (leaf = half of 8)
 #endif
+#ifndef SPLIT
+#define SPLIT 2  // the candidate supergroups of a patch are dealt to SPLIT sets of NNW wavefronts (j % SPLIT): the kernel's
+                 // duration is the time of its SLOWEST patch (misaligned clouds: queries far from the target see
+                 // most of the tree), and both the per-lane tests and the entry passes of a patch split this way
+#endif
+#define NWV (NNW * SPLIT)  // wavefronts per workgroup
 #define LEAF (SGT / NNW)
 static_assert(NNW == 8 || NNW == 4, "a wavefront owns a half (8 records) or a group (16) of every supergroup");
 #define LEAF_NODE(k) (NNW == 8 ? 5 + (k) : 1 + (k))
@@ -157,41 +156,75 @@ static_assert(NNW == 8 || NNW == 4, "a wavefront owns a half (8 records) or a gr
 #define TB 1  // per-lane leaf tests per loop iteration (2, 4: no faster -- the kernel is VALU-issue bound, see notes)
 #endif
 
-// The `cnt` (<= LEAF) records of one leaf, wave-uniform, through the scalar cache in ONE request (the
-// arrays are padded to whole supergroups, so all LEAF rows exist); the keys are independent and
-// reduced as a tree.
-__device__ __forceinline__ void eval_leaf(NNWave &w, int pos0, int cnt) {
-    kptr tp = (kptr)(uintptr_t)(w.T + pos0);
-    if (cnt == LEAF) {  // uniform
-        float r[4 * LEAF];
-#pragma unroll
-        for (int i = 0; i < 4 * LEAF; ++i) r[i] = tp[i];
+// ---- per-lane leaf evaluation (round 2, v9) -------------------------------------------------------
+// Evaluating a leaf for the whole wavefront whenever ANY of its 64 queries needs it wastes ~2/3 of the pair
+// evaluations (a leaf is typically needed by ~14 of the 64 lanes).  Instead, like the culled scan's levels:
+// a wavefront stages its candidate leaves in LDS (CHK at a time, coalesced loads, one memory latency), every
+// lane tests ITS query against each staged leaf and pushes (query, leaf slot) ENTRIES into the wavefront's LDS
+// queue (ballot + rank); whenever 64 entries wait, every lane pops one and evaluates "its" 16 records
+// for "its" query -- all lanes busy on pairs that are actually needed -- and folds the key into the
+// query's minimum with an LDS atomicMin on the u64 key (several lanes may hold the same query).
+#ifndef CHK
+#define CHK 12                 // candidate leaves staged per round and wavefront (12: 32 KiB of LDS per 8-wavefront workgroup -> 4 per CU)
+#endif
+#define LROW (LEAF + 1)        // float4 per staged leaf row: +1 of padding spreads the rows over the banks
+#define QCAP (64 + 63)         // entries: < 64 left-overs + one push round
+
+struct NNShared {
+    float4 *q;                   // [64] the patch's queries (xyz, original index)
+    unsigned long long *best;    // [64] u64 keys, LDS atomicMin
+    float4 *rec;                 // this wavefront's staged leaves [CHK][LROW]
+    int *pos;                    // this wavefront's staged leaf positions [CHK] (sorted position of record 0)
+    unsigned *queue;             // this wavefront's entries: query << 8 | slot
+};
+
+// pops up to 64 entries [base, base + take) and evaluates them, one per lane
+__device__ __forceinline__ void eval_entries(const NNShared &sh, int base, int take, int nt, int lane) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (lane < take) {
+        const unsigned e = sh.queue[base + lane];
+        const int q = (int)(e >> 8), slot = (int)(e & 255u);
+        const float4 qv = sh.q[q];
+        const int cnt = min(LEAF, nt - sh.pos[slot]);
+        const float4 *row = sh.rec + slot * LROW;
         unsigned long long key[LEAF];
 #pragma unroll
-        for (int t = 0; t < LEAF; ++t) key[t] = point_key(w, r[4 * t], r[4 * t + 1], r[4 * t + 2], r[4 * t + 3]);
+        for (int t = 0; t < LEAF; ++t) {
+            const float4 r = row[t];
+            // code/loss.py:51: sum((x - y)**2, -1); (a0 + a1) + a2, no FMA
+            const float dx = qv.x - r.x, dy = qv.y - r.y, dz = qv.z - r.z;
+            float s = dx * dx;
+            s = s + dy * dy;
+            s = s + dz * dz;
+            key[t] = t < cnt ? (((unsigned long long)__float_as_uint(s) << 32) | (unsigned)__float_as_int(r.w)) : ~0ull;
+        }
 #pragma unroll
         for (int o = LEAF / 2; o > 0; o >>= 1)
 #pragma unroll
             for (int t = 0; t < o; ++t) key[t] = kmin(key[t], key[t + o]);
-        w.best = kmin(w.best, key[0]);
-    } else {  // the ragged last leaf of a cloud
-        for (int t = 0; t < cnt; ++t, tp += 4) w.best = kmin(w.best, point_key(w, tp[0], tp[1], tp[2], tp[3]));
+        atomicMin(&sh.best[q], key[0]);
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
 
 // COUNT: executed-work counters (rrl_chamfer_counters): [0] patch-level leaf tests (lane-parallel),
-// [1] per-lane leaf sphere tests (wave x leaf), [2] leaves evaluated, [3] (query, target) pairs evaluated,
-// [4] wavefronts.
+// [1] per-lane leaf sphere tests (wave x leaf), [2] (query, leaf) entries evaluated, [3] (query, target)
+// pairs evaluated, [4] wavefronts.
 template <bool COUNT>
-__global__ __launch_bounds__(64 * NNW) void chamfer_tree_kernel(
+__global__ __launch_bounds__(64 * NWV) void chamfer_tree_kernel(
     const float4 *__restrict__ p0s1, const float4 *__restrict__ p0s2, const float4 *__restrict__ grp1,
     const float4 *__restrict__ grp2, const float *__restrict__ apart, int nblk,
     unsigned long long *__restrict__ best_x, unsigned long long *__restrict__ best_y,
     double *__restrict__ partial, int B, int N, int M, unsigned long long *__restrict__ counters) {
-    __shared__ unsigned long long s_best[NNW][64];
+    __shared__ unsigned long long s_best[64];
+    __shared__ __attribute__((aligned(16))) float4 s_q[64];
+    __shared__ __attribute__((aligned(16))) float4 s_rec[NWV][CHK * LROW];
+    __shared__ int s_pos[NWV][CHK];
+    __shared__ unsigned s_queue[NWV][QCAP + 1];
     __shared__ double red[64];
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // wavefront of the workgroup
+    const int wave = wv % NNW, cls = wv / NNW;                  // its leaf within a supergroup, its supergroup class
     // XCD-aware: workgroups go to the 8 XCDs round-robin by linear id; with (sample, direction) on the fast
     // index every XCD's L2 holds the records and trees of 2 B / 8 of the (cloud pair, direction) combinations only
     const int b = blockIdx.x >> 1, dir = blockIdx.x & 1;
@@ -200,6 +233,10 @@ __global__ __launch_bounds__(64 * NNW) void chamfer_tree_kernel(
     const int sgq = (int)blockIdx.y;
     double mine = 0.0;
     unsigned c_sg = 0, c_gt = 0, c_ge = 0, c_pairs = 0;
+    long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_stage = 0, t_test = 0, t_pass = 0;  // COUNT: phase clocks
+#define RRL_NOW() (COUNT ? (long long)__builtin_readcyclecounter() : 0ll)
+    tk[0] = RRL_NOW();
+    const long long wall0 = COUNT ? (long long)wall_clock64() : 0ll;
     if (sgq < nsgq) {  // workgroup-uniform
         const float4 *Q = (dir ? p0s2 : p0s1) + (size_t)b * nsgq * SGT;
         const float4 *treeQ = (dir ? grp2 : grp1) + (size_t)b * nsgq * NODE;
@@ -212,6 +249,8 @@ __global__ __launch_bounds__(64 * NNW) void chamfer_tree_kernel(
         const float4 qr = Q[qi];  // pad records exist up to the supergroup boundary
         w.qx = qr.x; w.qy = qr.y; w.qz = qr.z;
         w.best = ~0ull;
+        if (wv == 0) { s_q[lane] = qr; s_best[lane] = ~0ull; }
+        const NNShared sh = {s_q, s_best, s_rec[wv], s_pos[wv], s_queue[wv]};
         kptr qn = (kptr)(uintptr_t)(treeQ + (size_t)sgq * NODE);
         const float cqx = qn[0], cqy = qn[1], cqz = qn[2];
         float qg[SGG][4];  // the patch's four query-group spheres (wave-uniform)
@@ -221,14 +260,16 @@ __global__ __launch_bounds__(64 * NNW) void chamfer_tree_kernel(
             for (int c = 0; c < 4; ++c) qg[g][c] = qn[4 * (1 + g) + c];
         // does the TARGET cloud hold a NaN coordinate (slot 7 of its AABB partial rows)?
         bool tnan = false;
-        if (wave == 0) {
+        if (wv == 0) {
             const int ct = dir ? 0 : 1, nb = (nt + 255) / 256;
             const float *ap = apart + ((size_t)ct * B + b) * nblk * 8;
             for (int j = lane; j < nb; j += 64) tnan |= ap[j * 8 + 7] != 0.0f;
             tnan = __any(tnan);
         }
 
-        // ---- seed: the target supergroup nearest to the patch centre; wavefront k evaluates its leaf k
+        tk[1] = RRL_NOW();
+        // ---- seed: the target supergroup nearest to the patch centre; wavefront k evaluates its leaf k for
+        //      all 64 queries (every query needs a bound; the records arrive through the scalar cache)
         float dmin = INFINITY;
         int jmin = 0;
         for (int j = lane; j < nsgt; j += 64) {
@@ -240,26 +281,30 @@ __global__ __launch_bounds__(64 * NNW) void chamfer_tree_kernel(
         const float wmin = wave_min(dmin);
         const unsigned long long who = __ballot(dmin == wmin);
         const int seed = who ? __builtin_amdgcn_readlane(jmin, __ffsll((long long)who) - 1) : 0;  // all NaN: 0
-        {
+        tk[2] = RRL_NOW();
+        __syncthreads();  // s_q / s_best initialised by wavefront 0
+        {   // every query needs a bound: 64 entries (lane, slot 0) on this wavefront's leaf of the seed supergroup
             const int cnt = min(LEAF, nt - seed * SGT - wave * LEAF);
-            if (cnt > 0) {
-                eval_leaf(w, seed * SGT + wave * LEAF, cnt);
-                if constexpr (COUNT) { ++c_ge; c_pairs += 64u * (unsigned)cnt; }
+            if (cnt > 0 && cls == 0) {
+                if (lane == 0) sh.pos[0] = seed * SGT + wave * LEAF;
+                if (lane < LEAF) sh.rec[lane] = w.T[seed * SGT + wave * LEAF + lane];
+                sh.queue[lane] = (unsigned)lane << 8;
+                eval_entries(sh, 0, nq - sgq * SGT < 64 ? nq - sgq * SGT : 64, nt, lane);
+                if constexpr (COUNT) { c_ge += 64u; c_pairs += 64u * (unsigned)cnt; }
             }
         }
-        s_best[wave][lane] = w.best;
+        tk[3] = RRL_NOW();
         __syncthreads();
-#pragma unroll
-        for (int k = 0; k < NNW; ++k) w.best = kmin(w.best, s_best[k][lane]);
-        __syncthreads();
+        tk[4] = RRL_NOW();
 
         // ---- the other supergroups
-        float sb = root_of_best(w);
+        int nq_e = 0;  // entries waiting in this wavefront's queue (uniform)
         for (int j0 = 0; j0 < nsgt; j0 += 64) {
             const int j = j0 + lane;
             // prune 1, lane-parallel over the target supergroups: this wavefront's leaf of supergroup j against
             // each of the patch's four query GROUPS (16 consecutive lanes = one group of the query tree) with
             // that group's largest bound -- |cg - cj| <= sqrt(bd_g) + Rg + Rj, squared
+            float sb = __builtin_amdgcn_sqrtf(__uint_as_float((unsigned)(s_best[lane] >> 32))) * 1.00001f;
             float sbg[SGG];
             {
                 const float rowmax = row16_max(w.valid ? sb : 0.0f);  // fmaxf drops a NaN: see `blind`
@@ -270,59 +315,82 @@ __global__ __launch_bounds__(64 * NNW) void chamfer_tree_kernel(
             const bool blind = __any(w.valid && sb != sb);  // some query has no bound yet: no patch-level pruning
             bool cand = false;
             float4 gn = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (j < nsgt && j != seed) {
+            if (j < nsgt && j != seed && (j % SPLIT) == cls && nt - j * SGT - wave * LEAF > 0) {  // (an empty leaf is no candidate)
                 gn = w.tree[(size_t)j * NODE + LEAF_NODE(wave)];
                 cand = blind;
 #pragma unroll
                 for (int g = 0; g < SGG; ++g) {
                     const float dx = qg[g][0] - gn.x, dy = qg[g][1] - gn.y, dz = qg[g][2] - gn.z;
                     const float d2 = dx * dx + dy * dy + dz * dz, t = sbg[g] + qg[g][3] + gn.w;
-                    cand = cand || !(d2 * LB_SCALE > t * t);  // NaN radius (empty query group / leaf): kept; cnt <= 0 below
+                    cand = cand || !(d2 * LB_SCALE > t * t);  // NaN radius (empty query group): kept
                 }
             }
             unsigned long long m = __ballot(cand);
             if constexpr (COUNT) c_sg += (unsigned)min(64, nsgt - j0);
-            // prune 2, TB candidates per iteration (tests inside a batch use the bound from before the batch)
             while (m) {
-                int sl[TB];
-                bool need[TB];
-#pragma unroll
-                for (int u = 0; u < TB; ++u) {
-                    sl[u] = m ? __ffsll((long long)m) - 1 : -1;
-                    if (m) m &= m - 1;
+                const long long ts0 = RRL_NOW();
+                // ---- stage the next <= CHK candidate leaves of this wavefront (one round of coalesced loads)
+                const int nc = min(CHK, __popcll(m));
+                {
+                    const int rk = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                    if (cand && ((m >> lane) & 1ull) && rk < nc) sh.pos[rk] = (j0 + lane) * SGT + wave * LEAF;
                 }
-#pragma unroll
-                for (int u = 0; u < TB; ++u) {
-                    need[u] = false;
-                    if (sl[u] < 0) continue;  // uniform
-                    const int cnt = min(LEAF, nt - (j0 + sl[u]) * SGT - wave * LEAF);
-                    if (cnt <= 0) continue;  // uniform: empty leaf
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                for (int i = lane; i < nc * LEAF; i += 64) {
+                    const int slot = i / LEAF, t = i % LEAF;
+                    sh.rec[slot * LROW + t] = w.T[sh.pos[slot] + t];  // rows exist up to the supergroup boundary
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                if constexpr (COUNT) { (void)sh.rec[lane].x; }
+                const long long ts1 = RRL_NOW();
+                t_stage += ts1 - ts0;
+                // ---- per staged leaf: prune 2 per lane, entries for the lanes that need it
+                for (int c = 0; c < nc; ++c) {
+                    const int sl = __ffsll((long long)m) - 1;
+                    m &= m - 1;
                     // the leaf node was fetched by lane sl above: broadcast it (no dependent load per candidate)
-                    const float gx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gn.x), sl[u]));
-                    const float gy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gn.y), sl[u]));
-                    const float gz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gn.z), sl[u]));
-                    const float gr = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gn.w), sl[u]));
+                    const float gx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gn.x), sl));
+                    const float gy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gn.y), sl));
+                    const float gz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gn.z), sl));
+                    const float gr = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gn.w), sl));
                     if constexpr (COUNT) ++c_gt;
-                    // per lane: |q - c| <= sqrt(bd) + R, squared; NaN anywhere: visit
+                    // |q - c| <= sqrt(bd) + R, squared, with the query's CURRENT bound (all wavefronts fold into it);
+                    // NaN anywhere: visit
+                    sb = __builtin_amdgcn_sqrtf(__uint_as_float((unsigned)(s_best[lane] >> 32))) * 1.00001f;
                     const float dx = w.qx - gx, dy = w.qy - gy, dz = w.qz - gz;
                     const float d2 = dx * dx + dy * dy + dz * dz, t = sb + gr;
-                    need[u] = __any(w.valid && !(d2 * LB_SCALE > t * t));
+                    const bool need = w.valid && !(d2 * LB_SCALE > t * t);
+                    const unsigned long long nm = __ballot(need);
+                    if (need) {
+                        const int rk = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(nm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)nm, 0u));
+                        sh.queue[nq_e + rk] = ((unsigned)lane << 8) | (unsigned)c;
+                    }
+                    nq_e += __popcll(nm);
+                    if (nq_e >= 64) {  // uniform: a full pass
+                        nq_e -= 64;
+                        const long long tp0 = RRL_NOW();
+                        eval_entries(sh, nq_e, 64, nt, lane);
+                        t_pass += RRL_NOW() - tp0;
+                        if constexpr (COUNT) { c_ge += 64u; c_pairs += 64u * (unsigned)LEAF; }
+                    }
                 }
-#pragma unroll
-                for (int u = 0; u < TB; ++u) {
-                    if (!need[u]) continue;  // uniform
-                    const int s = j0 + sl[u], cnt = min(LEAF, nt - s * SGT - wave * LEAF);
-                    eval_leaf(w, s * SGT + wave * LEAF, cnt);
-                    if constexpr (COUNT) { ++c_ge; c_pairs += 64u * (unsigned)cnt; }
+                // the staged rows are overwritten by the next round: drain the queue
+                const long long tp0 = RRL_NOW();
+                if (nq_e > 0) {
+                    eval_entries(sh, 0, nq_e, nt, lane);
+                    if constexpr (COUNT) { c_ge += (unsigned)nq_e; c_pairs += (unsigned)nq_e * (unsigned)LEAF; }
+                    nq_e = 0;
                 }
-                sb = root_of_best(w);
+                const long long tp1 = RRL_NOW();
+                t_pass += tp1 - tp0;
+                t_test += tp1 - ts1;
             }
         }
-        s_best[wave][lane] = w.best;
+        tk[5] = RRL_NOW();
         __syncthreads();
-        if (wave == 0 && w.valid) {
-#pragma unroll
-            for (int k = 1; k < NNW; ++k) w.best = kmin(w.best, s_best[k][lane]);
+        tk[6] = RRL_NOW();
+        if (wv == 0 && w.valid) {
+            w.best = s_best[lane];
             const bool qnan = (w.qx != w.qx) || (w.qy != w.qy) || (w.qz != w.qz);
             if (qnan || tnan)  // torch.min propagates NaN
                 w.best = ((unsigned long long)0x7fc00000u << 32) | (unsigned)(w.best & 0xffffffffu);
@@ -331,15 +399,22 @@ __global__ __launch_bounds__(64 * NNW) void chamfer_tree_kernel(
         }
     }
     if constexpr (COUNT) {
+        // one 16-slot row per wavefront, plain stores (same-address atomics from 4096 wavefronts would
+        // saturate the memory system and distort the very clocks recorded here); the host adds the rows
         if (lane == 0 && sgq < nsgq) {
-            atomicAdd(&counters[0], (unsigned long long)c_sg);
-            atomicAdd(&counters[1], (unsigned long long)c_gt);
-            atomicAdd(&counters[2], (unsigned long long)c_ge);
-            atomicAdd(&counters[3], (unsigned long long)c_pairs);
-            atomicAdd(&counters[4], 1ull);
+            unsigned long long *row = counters + 16 * ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * NWV + wv);
+            row[0] = c_sg; row[1] = c_gt; row[2] = c_ge; row[3] = c_pairs; row[4] = 1;
+            row[5] = (unsigned long long)t_stage;
+            row[6] = (unsigned long long)(t_test - t_pass);
+            row[7] = (unsigned long long)t_pass;
+            row[8] = (unsigned long long)((long long)wall_clock64() - wall0);  // 100 MHz ticks of the same span as sum(tk)
+            row[9] = (unsigned long long)wall0;  // absolute start (tools/cham_count_vs_plain.py: start-time spread)
+            row[15] = (unsigned long long)(RRL_NOW() - tk[0]);
+            for (int i = 2; i <= 6; ++i) row[8 + i] = (unsigned long long)(tk[i] - tk[i - 1]);
         }
     }
-    if (wave != 0) return;  // the minima of the patch are in wavefront 0
+#undef RRL_NOW
+    if (wv != 0) return;  // the minima of the patch are in wavefront 0
     // ---- mean: fixed-order sum of the patch (one wavefront: LDS operations execute in order); the
     //      partials are summed by a second, tiny launch (chamfer_partials_kernel)
     red[lane] = mine;
@@ -394,7 +469,7 @@ extern "C" int rrl_chamfer_tree_fwd(const float *x, const float *y, void *ws, si
     if (rc) return rc;
     const int nsgmax = (nmax + SGT - 1) / SGT;
 #define RRL_NN_LAUNCH(COUNT)                                                                                     \
-    hipLaunchKernelGGL(chamfer_tree_kernel<COUNT>, dim3((unsigned)(2 * B), (unsigned)nsgmax), dim3(64 * NNW), 0,      \
+    hipLaunchKernelGGL(chamfer_tree_kernel<COUNT>, dim3((unsigned)(2 * B), (unsigned)nsgmax), dim3(64 * NWV), 0,      \
                        s, (const float4 *)(w + L.p0s1), (const float4 *)(w + L.p0s2),                            \
                        (const float4 *)(w + L.grp1), (const float4 *)(w + L.grp2), (const float *)(w + L.apart),  \
                        L.nblk, (unsigned long long *)best_x, (unsigned long long *)best_y,                       \

@@ -428,9 +428,10 @@ def chamfer_counters(on):
     """Like scan_counters, for the tree Chamfer (include/rrl.h rrl_chamfer_counters)."""
     global _cham_counter_buf
     prev = _cham_counter_buf
-    _cham_counter_buf = torch.zeros(16, dtype=torch.int64, device=require_gpu()) if on else None
+    # one 16-slot row per wavefront of the walk (plain stores), summed here
+    _cham_counter_buf = torch.zeros(16 * 8 * 2 * 32768, dtype=torch.int64, device=require_gpu()) if on else None
     check(_lib.load().rrl_chamfer_counters(_p(_cham_counter_buf)), "rrl_chamfer_counters")
-    return prev
+    return prev.reshape(-1, 16).sum(0) if prev is not None else None
 
 
 # ---------------------------------------------------------------------------------------

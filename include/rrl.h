@@ -282,10 +282,11 @@ int rrl_chamfer_fwd(const float *x, const float *y, uint64_t *best_x, uint64_t *
 size_t rrl_chamfer_workspace_bytes(int B, int N, int M);
 int rrl_chamfer_tree_fwd(const float *x, const float *y, void *ws, size_t ws_bytes, uint64_t *best_x,
                          uint64_t *best_y, float *value, int B, int N, int M, void *stream);
-/* Profiling hook like rrl_scan_counters: while dev_counters != NULL (uint64[16], cleared by the caller;
- * [9..14] = summed shader-clock ticks of the kernel's phases)
- * rrl_chamfer_tree_fwd runs an instrumented instantiation that ADDS [0] patch-level supergroup tests,
- * [1] group sphere tests, [2] groups evaluated, [3] (query, target) pairs evaluated, [4] wavefronts. */
+/* Profiling hook like rrl_scan_counters: while dev_counters != NULL rrl_chamfer_tree_fwd runs an
+ * instrumented instantiation that WRITES one row of 16 uint64 per wavefront of the walk (row index =
+ * workgroup * wavefronts per workgroup + wavefront; the buffer must hold 16 * 8 * 2 B * ceil(max(N,M)/64)
+ * values, cleared by the caller): [0] patch-level leaf tests, [1] per-lane leaf tests, [2] (query, leaf)
+ * entries evaluated, [3] (query, target) pairs evaluated, [4] 1, [5..7] / [9..14] shader clocks of the phases. */
 int rrl_chamfer_counters(uint64_t *dev_counters);
 int rrl_chamfer_bwd(const float *x, const float *y, const uint64_t *best_x,
                     const uint64_t *best_y, const float *grad_value, float *gx, float *gy, int B,

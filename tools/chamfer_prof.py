@@ -26,10 +26,13 @@ if tree:
     Lm.chamfer_dist(x, y)
     torch.cuda.synchronize()
     c = ops.chamfer_counters(False).cpu().numpy()
+    print("  clocks per wave: seed search %.0f | seed eval %.0f | exchange %.0f | walk %.0f (staging %.0f, tests %.0f, passes %.0f) | final barrier %.0f"
+          % (c[10] / c[4], c[11] / c[4], c[12] / c[4], c[13] / c[4], c[5] / c[4], c[6] / c[4], c[7] / c[4], c[14] / c[4]))
+    print("  wavefront lifetime: %.0f shader clocks = %.2f us by the 100 MHz wall clock -> shader clock %.2f GHz" % (c[15] / c[4], c[8] / c[4] / 100.0, (c[15] / c[4]) / (c[8] / c[4] * 10.0)))
     print(f"  counters: patch-level tests/wave {c[0]/c[4]:.1f}, leaf tests/wave {c[1]/c[4]:.1f}, leaves evaluated/wave {c[2]/c[4]:.1f}, "
           f"pairs {c[3]:.3g} = {c[3]/(B*N*M*2):.4f} of dense, waves {c[4]}")
     # aligned clouds (target = source + small noise): what a converged registration looks like
-    y2 = x[:, :M] + 0.003 * torch.randn_like(x[:, :M]) if M <= N else None
+    y2 = x[:, :M] + 0.003 * torch.randn_like(x[:, :M]) if (M <= N and not os.environ.get('CHAM_NO_ALIGNED')) else None
     if y2 is not None:
         ops.chamfer_counters(True)
         Lm.chamfer_dist(x, y2)
