@@ -740,20 +740,57 @@ __device__ __forceinline__ void proc_a(WaveCtx &c, bool all) {
     }
 }
 
-// COUNT = true: the same kernel with executed-work counters (one u64 atomic per counter and
-// wavefront at exit) -- launched instead of the plain one while rrl_scan_counters() holds a buffer:
-//   counters[0] level-A sphere tests (line x supergroup)   [1] level-B (line x group)
+// The strict loop of a wavefront that cannot be culled (a line with |dir|^2 > 1 + 1e-6 or non-finite
+// data): ALL pairs of its 128 lines with the records at sorted positions [s0, s1), the reference's
+// semantics, NaN included.  The lane's two lines arrive packed (.x = line l0, .y = line l1).
+__device__ __attribute__((noinline)) void strict_slice(const float *ptri, const int32_t *idx, int s0, int s1, v2f ux,
+                                                       v2f uy, v2f uz, v2f ox, v2f oy, v2f oz, int l0, int l1, int L,
+                                                       int32_t *cnt, int32_t *hit, int32_t *status) {
+    kptr tp0 = (kptr)(uintptr_t)ptri;
+    kiptr ik = (kiptr)(uintptr_t)idx;
+    uint32_t nanacc = 0;
+    for (int sp = s0; sp < s1; ++sp) {
+        kptr tp = tp0 + (size_t)ik[sp] * PTRI_STRIDE;
+        const uint32_t thr2 = __float_as_uint(tp[9]);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float dx = h ? ux.y : ux.x, dy = h ? uy.y : uy.x, dz = h ? uz.y : uz.x;
+            const float px = h ? ox.y : ox.x, py = h ? oy.y : oy.x, pz = h ? oz.y : oz.x;
+            const int l = h ? l1 : l0;
+            const uint32_t x0 = __float_as_uint(dist_sq<float>(tp[0], tp[1], tp[2], dx, dy, dz, px, py, pz));
+            const uint32_t x1 = __float_as_uint(dist_sq<float>(tp[3], tp[4], tp[5], dx, dy, dz, px, py, pz));
+            const uint32_t x2 = __float_as_uint(dist_sq<float>(tp[6], tp[7], tp[8], dx, dy, dz, px, py, pz));
+            const uint32_t mm = max(max(x0, x1), x2);  // negative or NaN: sign bit set -> huge
+            if (l < L) {
+                nanacc = max(nanacc, mm);
+                if (mm < thr2) {
+                    const int pos = atomicAdd(&cnt[l], 1);
+                    if (pos < RRL_MAX_HITS) hit[(size_t)l * RRL_MAX_HITS + pos] = __float_as_int(tp[11]);
+                }
+            }
+        }
+    }
+    if (nanacc >= 0x80000000u) atomicOr(&status[0], 1);
+}
+
+// COUNT = true: the same kernel with executed-work counters -- launched instead of the plain one while
+// rrl_scan_counters() holds a buffer.  Every wavefront WRITES one row of 16 u64 (plain stores: thousands of
+// same-address atomics serialise at ~12 ns each and distort the kernel they measure), row index = linear
+// workgroup id x wavefronts per workgroup + wavefront; rows past the buffer's capacity are dropped:
+//   row[0] level-A sphere tests (line x supergroup)   [1] level-B (line x group)
 //           [2] level-C (line x half)                      [3] exact point-0 tests (line x record)
 //           [4] candidates resolved (points 1, 2)          [5] wavefronts that ran
 //           [6] wavefronts that took the strict fallback   [7] (line, triangle) pairs of the fallback
+//           [8] start, [9] end of the wavefront on the 100 MHz wall clock (the kernel lasts as long as its
+//           slowest wavefront: tools/scan_tail.py prints the spread)
 template <bool COUNT>
-__global__ __launch_bounds__(64 * WPB) void cull_scan_kernel(
+__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(6, 8))) void cull_scan_kernel(
     const float *__restrict__ ptri1, const float *__restrict__ ptri2, const float4 *__restrict__ p0s1,
     const float4 *__restrict__ p0s2, const int32_t *__restrict__ idx1, const int32_t *__restrict__ idx2,
     const float4 *__restrict__ tree1, const float4 *__restrict__ tree2, const float *__restrict__ line,
     int32_t *__restrict__ count1, int32_t *__restrict__ hit1, int32_t *__restrict__ count2,
     int32_t *__restrict__ hit2, int32_t *__restrict__ status, const uint32_t *__restrict__ pmax, int B,
-    int N, int M, int L, int spw, unsigned long long *__restrict__ counters) {
+    int N, int M, int L, int spw, int nrep, unsigned long long *__restrict__ counters, long long counter_rows) {
     __shared__ __attribute__((aligned(16))) float4 la_lds[WPB][LPW];          // 16 KiB
     __shared__ __attribute__((aligned(16))) float2 lb_lds[WPB][LPW];          //  8 KiB
     __shared__ __attribute__((aligned(16))) float4 rec_lds[SPW * SGG * ROWS]; //  8.5 KiB
@@ -762,23 +799,24 @@ __global__ __launch_bounds__(64 * WPB) void cull_scan_kernel(
     __shared__ unsigned cands_lds[WPB][WCCAP];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform for the compiler
+    const unsigned long long wall0 = COUNT ? wall_clock64() : 0ull;
+    unsigned long long *crow = nullptr;
+    if constexpr (COUNT) {
+        const long long wid = (((long long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + wave;
+        if (wid < counter_rows) crow = counters + 16 * wid;
+    }
     // XCD-aware mapping: workgroups go to the 8 XCDs round-robin by linear id, and x is the fast
     // index -- with (cloud, sample) on x, all workgroups of one cloud land on the same XCD (when
     // 2B is a multiple of 8), so each XCD's L2 holds 1/8 of the records instead of a copy of all
     const int z = blockIdx.x, cloud = z >= B ? 1 : 0, b = z - cloud * B;
     const int n = cloud ? M : N;
     const int nsg = (n + SGT - 1) / SGT;
-    const int sg0 = (int)blockIdx.z * spw;
-    if (sg0 >= nsg) return;  // uniform: the smaller cloud has fewer slices
-    const int nsl = min(spw, nsg - sg0);
+    if ((int)blockIdx.z * nrep * spw >= nsg) return;  // uniform: the smaller cloud has fewer slices
     const float4 *p0s = (cloud ? p0s2 : p0s1) + (size_t)b * nsg * SGT;
     const float4 *tree = (cloud ? tree2 : tree1) + (size_t)b * nsg * NODE;
 
-    // ---- stage the slice: records (padded rows) and tree nodes
-    for (int i = tid; i < nsl * SGT; i += blockDim.x) rec_lds[(i >> 4) * ROWS + (i & 15)] = p0s[(size_t)sg0 * SGT + i];
-    for (int i = tid; i < nsl * NODE; i += blockDim.x) node_lds[i] = tree[(size_t)sg0 * NODE + i];
-
-    // ---- this wave's lines
+    // ---- this wave's lines (staged once; the workgroup then walks `nrep` slices of the cloud one after
+    //      the other: fewer, longer-lived wavefronts -- see rrl_launch_cull_scan)
     const float *ln = line + (size_t)b * L * 6;
     const int lw0 = ((int)blockIdx.y * (int)(blockDim.x >> 6) + wave) * LPW;
     const int l0 = lw0 + lane, l1 = l0 + 64;
@@ -793,58 +831,21 @@ __global__ __launch_bounds__(64 * WPB) void cull_scan_kernel(
     lb_lds[wave][lane] = make_float2(v0[4], v0[5]);
     la_lds[wave][64 + lane] = make_float4(v1[0], v1[1], v1[2], v1[3]);
     lb_lds[wave][64 + lane] = make_float2(v1[4], v1[5]);
-    __syncthreads();
-    if (lw0 >= L) return;  // wave without lines (after the only barrier)
-#ifdef CULL_STOP_STAGE
-    return;
-#endif
+    // a wave without lines (the last tile of the line set) still stages its share of every slice
+    const bool has_lines = lw0 < L;
 
     const int32_t *idx = (cloud ? idx2 : idx1) + (size_t)b * nsg * SGT;
     const float *ptri = (cloud ? ptri2 : ptri1) + (size_t)b * n * PTRI_STRIDE;
     int32_t *cnt = (cloud ? count2 : count1) + (size_t)b * L;
     int32_t *hit = (cloud ? hit2 : hit1) + (size_t)b * L * RRL_MAX_HITS;
 
-    // Culling (and the lazy evaluation of points 1, 2) is only exact for lines that satisfy the
-    // NaN-impossibility bound.  A wavefront with an offending line evaluates ALL pairs of its
-    // lines with the slice's triangles strictly instead -- the reference's semantics, NaN included.
+    // Culling (and the lazy evaluation of points 1, 2) is only exact for lines with |dir|^2 <= 1 + 1e-6 and
+    // finite data (cull_line_slack).  A wavefront with an offending line evaluates ALL pairs of its
+    // lines with the slices' triangles strictly instead -- the reference's semantics, NaN included.
     const float pm = __uint_as_float(pmax[cloud * B + b]);
     const LineSlack ls0 = cull_line_slack(v0, pm), ls1 = cull_line_slack(v1, pm);
-    if (!__all(ls0.ok && ls1.ok)) {
-        kptr tp0 = (kptr)(uintptr_t)ptri;
-        kiptr ik = (kiptr)(uintptr_t)idx;
-        const int s0 = sg0 * SGT, s1 = min(n, s0 + nsl * SGT);  // real records sit at sorted positions [0, n)
-        uint32_t nanacc = 0;
-        for (int sp = s0; sp < s1; ++sp) {
-            kptr tp = tp0 + (size_t)ik[sp] * PTRI_STRIDE;
-            const uint32_t thr2 = __float_as_uint(tp[9]);
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const float *v = h ? v1 : v0;
-                const int l = h ? l1 : l0;
-                const uint32_t x0 = __float_as_uint(dist_sq<float>(tp[0], tp[1], tp[2], v[0], v[1], v[2], v[3], v[4], v[5]));
-                const uint32_t x1 = __float_as_uint(dist_sq<float>(tp[3], tp[4], tp[5], v[0], v[1], v[2], v[3], v[4], v[5]));
-                const uint32_t x2 = __float_as_uint(dist_sq<float>(tp[6], tp[7], tp[8], v[0], v[1], v[2], v[3], v[4], v[5]));
-                const uint32_t mm = max(max(x0, x1), x2);  // negative or NaN: sign bit set -> huge
-                if (l < L) {
-                    nanacc = max(nanacc, mm);
-                    if (mm < thr2) {
-                        const int pos = atomicAdd(&cnt[l], 1);
-                        if (pos < RRL_MAX_HITS) hit[(size_t)l * RRL_MAX_HITS + pos] = __float_as_int(tp[11]);
-                    }
-                }
-            }
-        }
-        if (nanacc >= 0x80000000u) atomicOr(&status[0], 1);
-        if (lane == 0) {
-            atomicAdd(&status[1], 1);  // always on: wavefronts that left the culled path
-            if constexpr (COUNT) {
-                atomicAdd(&counters[5], 1ull);
-                atomicAdd(&counters[6], 1ull);
-                atomicAdd(&counters[7], (unsigned long long)(s1 - s0) * (unsigned long long)min(LPW, L - lw0));
-            }
-        }
-        return;
-    }
+    const bool fallback = !__all(ls0.ok && ls1.ok);
+    unsigned long long fb_pairs = 0;
 
     WaveCtx ctx;
     ctx.la = la_lds[wave];
@@ -860,7 +861,6 @@ __global__ __launch_bounds__(64 * WPB) void cull_scan_kernel(
     ctx.cnt = cnt;
     ctx.hit = hit;
     ctx.lbase = lw0;
-    ctx.pos0 = sg0 * SGT;
     ctx.na = ctx.nb = ctx.nc = ctx.ncand = 0;
     ctx.lane = lane;
     ctx.tb = ctx.tc = ctx.td = ctx.tcand = 0;
@@ -868,11 +868,35 @@ __global__ __launch_bounds__(64 * WPB) void cull_scan_kernel(
     ctx.status = status;
     ctx.se = wave_max(fmaxf(ls0.se, ls1.se));
     ctx.track = !__all(ls0.nanfree && ls1.nanfree);
+    const v2f ux = {v0[0], v1[0]}, uy = {v0[1], v1[1]}, uz = {v0[2], v1[2]};
+    const v2f ox = {v0[3], v1[3]}, oy = {v0[4], v1[4]}, oz = {v0[5], v1[5]};
+    unsigned long long ta = 0;
+
+    for (int rep = 0; rep < nrep; ++rep) {
+    const int sg0 = ((int)blockIdx.z * nrep + rep) * spw;
+    if (sg0 >= nsg) break;  // uniform
+    const int nsl = min(spw, nsg - sg0);
+    // ---- stage the slice: records (padded rows) and tree nodes
+    if (rep > 0) __syncthreads();  // every wavefront is done with the previous slice
+    for (int i = tid; i < nsl * SGT; i += blockDim.x) rec_lds[(i >> 4) * ROWS + (i & 15)] = p0s[(size_t)sg0 * SGT + i];
+    for (int i = tid; i < nsl * NODE; i += blockDim.x) node_lds[i] = tree[(size_t)sg0 * NODE + i];
+    __syncthreads();
+#ifdef CULL_STOP_STAGE
+    continue;
+#endif
+    if (!has_lines) continue;  // uniform per wavefront
+    if (fallback) {  // rare: kept out of line so that its registers do not count against the culled walk
+        const int s0 = sg0 * SGT, s1 = min(n, s0 + nsl * SGT);  // real records sit at sorted positions [0, n)
+        strict_slice(ptri, idx, s0, s1, ux, uy, uz, ox, oy, oz, l0, l1, L, cnt, hit, status);
+        if (lane == 0 && rep == 0) atomicAdd(&status[1], 1);  // always on: wavefronts that left the culled path
+        fb_pairs += (unsigned long long)(s1 - s0) * (unsigned long long)min(LPW, L - lw0);
+        continue;
+    }
+    ctx.pos0 = sg0 * SGT;
+    ta += (unsigned long long)nsl * (unsigned long long)min(LPW, L - lw0);
 
     // ---- level A: conservative sphere test of every supergroup of the slice against the lane's
     //      two lines (packed fp32, wave-uniform sphere through the scalar cache)
-    const v2f ux = {v0[0], v1[0]}, uy = {v0[1], v1[1]}, uz = {v0[2], v1[2]};
-    const v2f ox = {v0[3], v1[3]}, oy = {v0[4], v1[4]}, oz = {v0[5], v1[5]};
     kptr gp = (kptr)(uintptr_t)(tree + (size_t)sg0 * NODE);
     // all SPW supergroup spheres are requested up front (one scalar-load latency instead of one per
     // iteration: the loop body is ~25 instructions); slots past the slice re-read its last node
@@ -907,14 +931,15 @@ __global__ __launch_bounds__(64 * WPB) void cull_scan_kernel(
     proc_b<COUNT>(ctx, true);
     proc_c<COUNT>(ctx, true);
     flush_cands<COUNT>(ctx);
+    }  // slices of this workgroup
     if constexpr (COUNT) {
-        if (lane == 0) {
-            atomicAdd(&counters[0], (unsigned long long)nsl * (unsigned long long)min(LPW, L - lw0));
-            atomicAdd(&counters[1], (unsigned long long)ctx.tb);
-            atomicAdd(&counters[2], (unsigned long long)ctx.tc);
-            atomicAdd(&counters[3], (unsigned long long)ctx.td);
-            atomicAdd(&counters[4], (unsigned long long)ctx.tcand);
-            atomicAdd(&counters[5], 1ull);
+        if (lane == 0 && crow && has_lines) {
+            crow[0] = ta;
+            crow[1] = ctx.tb; crow[2] = ctx.tc; crow[3] = ctx.td; crow[4] = ctx.tcand;
+            crow[5] = 1ull;
+            crow[6] = fallback ? 1ull : 0ull;
+            crow[7] = fb_pairs;
+            crow[8] = wall0; crow[9] = wall_clock64();
         }
     }
 }
@@ -922,8 +947,10 @@ __global__ __launch_bounds__(64 * WPB) void cull_scan_kernel(
 // Executed-work counters (profiling; include/rrl.h rrl_scan_counters): while a buffer is set,
 // culled scans launch the COUNT instantiation and add to it.
 static unsigned long long *g_cull_counters = nullptr;
-extern "C" int rrl_scan_counters(uint64_t *dev_counters) {
+static long long g_cull_counter_rows = 0;
+extern "C" int rrl_scan_counters(uint64_t *dev_counters, long long rows) {
     g_cull_counters = (unsigned long long *)dev_counters;
+    g_cull_counter_rows = dev_counters ? rows : 0;
     return 0;
 }
 
@@ -1030,15 +1057,25 @@ int rrl_launch_cull_scan(const float *line, void *ws, const WsLayout &w, int B, 
         if (sscanf(e, "%d,%d", &w_, &s_) == 2 && w_ >= 1 && w_ <= WPB && s_ >= 1 && s_ <= SPW) { waves = w_ < lw ? w_ : lw; spw = s_; }
     }
     const int tiles = (lw + waves - 1) / waves, slices = (nsgmax + spw - 1) / spw;
+    // A workgroup can walk `nrep` consecutive slices of its cloud (its lines staged once): fewer, longer-lived
+    // wavefronts, all resident at once.
+    // MEASURED AND NOT ADOPTED (nrep stays 1; RRL_CULL_NREP=n for experiments): at C2 the 10112 wavefronts
+    // run as one full round of 6144 + a second of 3968 (mean lifetime 15.3 us, last end 37.8 us); with
+    // nrep = 2 all 5056 wavefronts are resident from the start, but each lives 27.3 us and the kernel
+    // takes 40.2 us (nrep = 3: 43.9, 4: 58.8) -- the CU is throughput-bound on this instruction mix, not
+    // waiting for wavefronts to arrive (profiles/r02b_scan_tail.txt).
+    int nrep = 1;
+    if (const char *e = getenv("RRL_CULL_NREP")) { const int v = atoi(e); if (v >= 1 && v <= 64) nrep = v; }
+    const int zslices = (slices + nrep - 1) / nrep;
 #define RRL_CULL_LAUNCH(COUNT)                                                                              \
-    hipLaunchKernelGGL(cull_scan_kernel<COUNT>, dim3((unsigned)(clouds * B), (unsigned)tiles, (unsigned)slices),    \
+    hipLaunchKernelGGL(cull_scan_kernel<COUNT>, dim3((unsigned)(clouds * B), (unsigned)tiles, (unsigned)zslices),   \
                        dim3(64 * waves), 0, s, w.f32(ws, RRL_WS_PTRI1), w.f32(ws, RRL_WS_PTRI2),             \
                        (const float4 *)w.f32(ws, RRL_WS_P0S1), (const float4 *)w.f32(ws, RRL_WS_P0S2),       \
                        w.i32(ws, RRL_WS_IDX1), w.i32(ws, RRL_WS_IDX2), (const float4 *)w.f32(ws, RRL_WS_GRP1), \
                        (const float4 *)w.f32(ws, RRL_WS_GRP2), line, w.i32(ws, RRL_WS_COUNT1),               \
                        w.i32(ws, RRL_WS_HIT1), w.i32(ws, RRL_WS_COUNT2), w.i32(ws, RRL_WS_HIT2),             \
-                       w.i32(ws, RRL_WS_STATUS), (const uint32_t *)w.i32(ws, RRL_WS_PMAX), B, N, M, L, spw,  \
-                       g_cull_counters)
+                       w.i32(ws, RRL_WS_STATUS), (const uint32_t *)w.i32(ws, RRL_WS_PMAX), B, N, M, L, spw, nrep, \
+                       g_cull_counters, g_cull_counter_rows)
     if (g_cull_counters) RRL_CULL_LAUNCH(true);
     else RRL_CULL_LAUNCH(false);
 #undef RRL_CULL_LAUNCH

@@ -33,7 +33,7 @@ _SIGS = {
     "rrl_set_deterministic": [_I],
     "rrl_scan_timing_enable": [_I],
     "rrl_scan_timing_collect": [_P, _I],
-    "rrl_scan_counters": [_P],
+    "rrl_scan_counters": [_P, _c.c_longlong],
     "rrl_chamfer_counters": [_P],
     "rrl_rigid_apply_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "rrl_rigid_bwd_blocks": [_I],

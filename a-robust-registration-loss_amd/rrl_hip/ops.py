@@ -406,32 +406,22 @@ def scan_timing_collect(max_n=1024):
 _counter_buf = None
 
 
-def scan_counters(on):
-    """Profiling hook: on=True -> subsequent culled scans run the instrumented kernel and add to a
-    fresh device buffer; on=False -> back to the plain kernel.  Returns the buffer (uint64-as-int64
-    [8], see include/rrl.h rrl_scan_counters) of the period that just ended, or None."""
+def scan_counters(on, rows=1 << 17, raw=False):
+    """Profiling hook: on=True -> subsequent culled scans run the instrumented kernel, every wavefront writing
+    one row of 16 counters into a fresh device buffer of `rows` rows; on=False -> back to the plain kernel.
+    Returns the counters of the period that just ended, summed over the rows (int64 [16], see include/rrl.h
+    rrl_scan_counters; raw=True: the (rows, 16) table, e.g. for the start / end clocks), or None."""
     global _counter_buf
     prev = _counter_buf
     if on:
-        _counter_buf = torch.zeros(8, dtype=torch.int64, device=require_gpu())
-        check(_lib.load().rrl_scan_counters(_p(_counter_buf)), "rrl_scan_counters")
+        _counter_buf = torch.zeros(int(rows), 16, dtype=torch.int64, device=require_gpu())
+        check(_lib.load().rrl_scan_counters(_p(_counter_buf), int(rows)), "rrl_scan_counters")
     else:
         _counter_buf = None
-        check(_lib.load().rrl_scan_counters(None), "rrl_scan_counters")
-    return prev
-
-
-_cham_counter_buf = None
-
-
-def chamfer_counters(on):
-    """Like scan_counters, for the tree Chamfer (include/rrl.h rrl_chamfer_counters)."""
-    global _cham_counter_buf
-    prev = _cham_counter_buf
-    # one 16-slot row per wavefront of the walk (plain stores), summed here
-    _cham_counter_buf = torch.zeros(16 * 8 * 2 * 32768, dtype=torch.int64, device=require_gpu()) if on else None
-    check(_lib.load().rrl_chamfer_counters(_p(_cham_counter_buf)), "rrl_chamfer_counters")
-    return prev.reshape(-1, 16).sum(0) if prev is not None else None
+        check(_lib.load().rrl_scan_counters(None, 0), "rrl_scan_counters")
+    if prev is None:
+        return None
+    return prev if raw else prev.sum(0)
 
 
 # ---------------------------------------------------------------------------------------

@@ -318,10 +318,9 @@ def main():
     if do_extras and args.mode == "cull":
         # executed work of the culled kernel: the instrumented instantiation, same inputs
         ops.scan_counters(True)
-        for _ in range(3):
-            local_step("cull")
+        local_step("cull")  # one launch: every wavefront writes its row of counters
         torch.cuda.synchronize()
-        c = (ops.scan_counters(False).cpu().numpy().astype(np.float64) / 3.0)
+        c = ops.scan_counters(False).cpu().numpy().astype(np.float64)
         exe = OPS_SPHERE * (c[0] + c[1] + c[2]) + OPS_EXACT * c[3] + OPS_CAND * c[4] + OPS_FALLBACK * c[7]
         roof_default = {
             "kernel": "cull_scan_kernel (scan mode cull: the dominant kernel of the timed step)",
@@ -336,7 +335,7 @@ def main():
             "ops_per_test": {"sphere": OPS_SPHERE, "exact": OPS_EXACT, "candidate": OPS_CAND,
                              "fallback_pair": OPS_FALLBACK},
             "note": "executed = arithmetic of the tests the kernel really ran, from in-kernel counters of this run "
-                    "(rrl_scan_counters; queue/ballot/bookkeeping instructions not counted: SQ_INSTS_VALU x 64 in "
+                    "(rrl_scan_counters: one row per wavefront, plain stores; queue/ballot/bookkeeping instructions not counted: SQ_INSTS_VALU x 64 in "
                     "profiles/ is the issue-side figure).  work_ratio = dense flops / executed flops."}
     if do_extras:
         # the kernel that performs ALL counted flops: the strict scan of the same step

@@ -217,15 +217,16 @@ int rrl_scan_timing_enable(int on);
 int rrl_scan_timing_collect(float *ms, int max_n);
 
 /* Profiling hook: executed work of the culled scan.  While dev_counters != NULL every culled scan
- * launches an instrumented instantiation of the same kernel that ADDS to dev_counters (uint64[8],
- * device memory, cleared by the caller; one atomic per counter and wavefront at exit):
+ * launches an instrumented instantiation of the same kernel in which every wavefront WRITES one row of 16
+ * uint64 (plain stores; row = linear workgroup id x wavefronts per workgroup + wavefront; rows >= `rows`
+ * are dropped; the caller clears the buffer and adds the rows up):
  *   [0] level-A sphere tests (line x supergroup)   [1] level-B (line x group)   [2] level-C (line x half)
  *   [3] exact point-0 tests (line x record)        [4] point-0 passes resolved (points 1 and 2)
- *   [5] wavefronts                                 [6] wavefronts that took the strict fallback
- *   [7] (line, triangle) pairs evaluated by the fallback.
+ *   [5] 1 (the wavefront ran)                      [6] 1 if it took the strict fallback
+ *   [7] (line, triangle) pairs evaluated by the fallback   [8], [9] its start / end on the 100 MHz wall clock.
  * NULL switches back to the plain kernel.  bench.py derives the executed flops of a launch from
  * these (12 per sphere test, 16 per exact test, 32 per resolved candidate, 48 per fallback pair). */
-int rrl_scan_counters(uint64_t *dev_counters);
+int rrl_scan_counters(uint64_t *dev_counters, long long rows);
 
 /* Batch-shard payload: out[14] = { sum of valid losses, number of valid
  * samples, sum_b gR[b] (9), sum_b gt[b] (3) } in one launch, fixed summation order; this is

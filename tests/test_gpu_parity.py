@@ -958,6 +958,7 @@ def test_scan_counters(L):
     assert c[3] < nl * (n1 + n2)                 # fewer exact tests than the dense scan's pairs
     assert c[4] >= int(g["count1"].sum() + g["count2"].sum())  # every hit was a resolved candidate
     assert c[6] == 0 and c[7] == 0 and c[5] > 0
+    assert c[9] > c[8] > 0  # every wavefront's start / end on the wall clock (summed over the rows)
 
 
 @pytest.mark.parametrize("n_lines,spread", [(3000, 0.0), (3000, 1e-4), (600, 0.0), (9000, 1e-5)])

@@ -1,0 +1,30 @@
+"""Start-time / lifetime spread of the culled scan's wavefronts at the bench shape (the instrumented
+instantiation writes every wavefront's start and end on the 100 MHz wall clock): a kernel lasts as long as
+its slowest wavefront.  usage (GPU box): python tools/scan_tail.py [B N L]"""
+import os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "a-robust-registration-loss_amd")]
+import bench
+from rrl_hip import ops
+B, N, L = ([int(v) for v in sys.argv[1:4]] + [8, 4096, 10000][len(sys.argv) - 1:])[:3]
+dev = torch.device("cuda", 0)
+w = bench.make_workload(B, N, N, L, 0, dev)
+for _ in range(5):
+    st = ops.loss_forward_raw(w["tri1"], w["tri2"], w["lines"], mode="cull")
+torch.cuda.synchronize()
+ops.scan_counters(True)
+st = ops.loss_forward_raw(w["tri1"], w["tri2"], w["lines"], mode="cull")
+torch.cuda.synchronize()
+raw = ops.scan_counters(False, raw=True).cpu().numpy()
+rows = raw[raw[:, 5] == 1]
+start = (rows[:, 8] - rows[:, 8].min()) / 100.0
+life = (rows[:, 9] - rows[:, 8]) / 100.0
+end = start + life
+pc = lambda a, q: float(np.percentile(a, q))
+print(f"B={B} N=M={N} L={L}: {len(rows)} wavefronts; start (us after the first) 10/50/90/100 %: {pc(start,10):.1f} / {pc(start,50):.1f} / {pc(start,90):.1f} / {start.max():.1f}")
+print(f"  lifetime us mean {life.mean():.1f}, 10/50/90/99/100 %: {pc(life,10):.1f} / {pc(life,50):.1f} / {pc(life,90):.1f} / {pc(life,99):.1f} / {life.max():.1f}; last end {end.max():.1f} us")
+work = rows[:, 1] * 12 + rows[:, 2] * 12 + rows[:, 3] * 16 + rows[:, 4] * 32
+print(f"  per-wavefront work (lane-ops below level A): mean {work.mean():.0f}, 90 % {pc(work,90):.0f}, max {work.max():.0f}; corr(lifetime, work) = {np.corrcoef(life, work)[0,1]:.2f}")
+late = rows[end > pc(end, 99)]
+print(f"  the slowest 1 %: mean exact tests {late[:,3].mean():.0f} (all: {rows[:,3].mean():.0f}), candidates {late[:,4].mean():.0f} (all: {rows[:,4].mean():.0f})")
