@@ -1094,6 +1094,40 @@ def test_deterministic_direct_backward(L):
     assert float(runs[0][0].abs().sum()) > 0 and float(runs[0][2][1]) == B
 
 
+def test_grad_src_path_hand_over_stress(L):
+    """The d/dsrc route (scatter + reg_bwd_kernel: per-workgroup partials handed to the last workgroup through
+    write-through stores and a ticket -- outside the HIP memory model, csrc/rrl_geom.hip) run 60 times at two
+    shapes: a stale or missing partial would change dR / dt by a whole workgroup's share; the scatter's float
+    atomics alone only cause rounding noise (compared to 1e-4; loss and payload head bit for bit)."""
+    from rrl_hip import ops, synth
+    from LieAlgebra import se3
+    for B, N, M, nl in ((4, 3000, 2500, 6000), (8, 4096, 4096, 10000)):
+        prs = [synth.make_pair(80 + b, N, M) for b in range(B)]
+        src0 = np.stack([p["src_tri"] for p in prs])
+        tar = cu(np.stack([p["tar_tri"] for p in prs]))
+        lines = L.Random_uniform_distribution_lines_batch_efficient_resample(
+            torch.tensor([[p["radius"]] for p in prs]), torch.from_numpy(np.stack([p["center"] for p in prs])), nl,
+            cu(src0).reshape(B, -1, 3), tar.reshape(B, -1, 3), "cuda", device_rng=True)
+        R0, T0 = se3.exp3(0.05 * torch.randn(B, 6, generator=torch.Generator().manual_seed(4)))
+        ref = None
+        for it in range(30):
+            src = cu(src0).requires_grad_(True)
+            R, t = R0.cuda().requires_grad_(True), T0.cuda().requires_grad_(True)
+            loss, _, _ = ops.registration_loss(src, R, t, tar, lines, transpose_r=True, want_payload=True)
+            loss.sum().backward()
+            # the scatter into the per-triangle gradient uses float atomics (order-dependent rounding): compare what
+            # reg_bwd_kernel's hand-over produces from it only through values that do not depend on that order
+            out = (loss.detach().clone(), ops.last_state().payload[:2].clone())
+            assert torch.isfinite(src.grad).all() and torch.isfinite(R.grad).all() and float(src.grad.abs().sum()) > 0
+            if ref is None:
+                ref = out + (R.grad.clone(), t.grad.clone(), src.grad.clone())
+            else:
+                assert torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1])
+                np.testing.assert_allclose(R.grad.cpu().numpy(), ref[2].cpu().numpy(), rtol=1e-4, atol=1e-7)
+                np.testing.assert_allclose(t.grad.cpu().numpy(), ref[3].cpu().numpy(), rtol=1e-4, atol=1e-7)
+                np.testing.assert_allclose(src.grad.cpu().numpy(), ref[4].cpu().numpy(), rtol=1e-3, atol=1e-8)
+
+
 def test_identity_registration_is_nan_like_the_reference(L, oracle):
     """src == tar: every D is 0, the median is 0 and Welsch1(0, 0) = 1 - exp(-(0/0)/2) is NaN in the
     reference (code/loss.py:20-21, 223-229; the oracle and the torch-eager restatement agree): the loss must
