@@ -84,3 +84,47 @@ for name in ('src_tri','tar_tri'):
     o4=local_kd(P,np.arange(4096))
     full=count(P[o4],thr[o4],lines)
     print(name,'hilbert sg/grp/half per line:',[round(x,2) for x in base],'| local k-d in 64:',[round(x,2) for x in loc],'| in 256:',[round(x,2) for x in loc256],'| full k-d:',[round(x,2) for x in full])
+
+
+# ---- tighter spheres for the SAME (Hilbert) order: AABB centre (the kernel's) vs the better of AABB centre /
+#      centroid / one Ritter step, per node
+def spheres_best(P, thr, size):
+    n = len(P); k = n // size
+    Pg = P.reshape(k, size, 3); lo = Pg.min(1); hi = Pg.max(1)
+    c0 = 0.5 * lo + 0.5 * hi
+    r0 = np.linalg.norm(Pg - c0[:, None], axis=2).max(1)
+    c1 = Pg.mean(1)
+    r1 = np.linalg.norm(Pg - c1[:, None], axis=2).max(1)
+    # Ritter: start at AABB centre sphere, grow towards the farthest point a few times from a smaller start
+    c2 = c0.copy(); r2 = r0 * 0.85
+    for _ in range(8):
+        d = np.linalg.norm(Pg - c2[:, None], axis=2); j = d.argmax(1); dm = d.max(1)
+        far = Pg[np.arange(k), j]
+        grow = dm > r2
+        newr = np.where(grow, 0.5 * (r2 + dm), r2)
+        shift = np.where(grow, (dm - newr) / np.maximum(dm, 1e-30), 0.0)
+        c2 = c2 + (far - c2) * shift[:, None]; r2 = newr
+    r2 = np.linalg.norm(Pg - c2[:, None], axis=2).max(1)
+    best = np.argmin(np.stack([r0, r1, r2]), 0)
+    c = np.where((best == 0)[:, None], c0, np.where((best == 1)[:, None], c1, c2))
+    r = np.minimum(np.minimum(r0, r1), r2)
+    return c, r + thr.reshape(k, size).max(1), (r / r0).mean()
+
+def count_best(P, thr, lines):
+    d = lines[:, :3]; o = lines[:, 3:]
+    res = []; prev = None; ratios = []
+    for size in (64, 16, 8):
+        c, R, ratio = spheres_best(P, thr, size)
+        a = c[None] - o[:, None]
+        dot = (a * d[:, None]).sum(-1)
+        d2 = (a * a).sum(-1) - dot * dot
+        ok = d2 <= R[None] ** 2
+        if prev is not None:
+            ok &= np.repeat(prev, ok.shape[1] // prev.shape[1], axis=1)
+        res.append(round(float(ok.sum(1).mean()), 2)); prev = ok; ratios.append(round(float(ratio), 3))
+    return res, ratios
+
+for name in ('src_tri', 'tar_tri'):
+    tri = pr[name]; P = tri[:, :3].astype(np.float64); thr = thresholds(tri)
+    o = order_hilbert(P)
+    print(name, 'hilbert order, best-of-three spheres: sg/grp/half per line', *count_best(P[o], thr[o], lines), '(mean rho / rho_AABB-centre per level)')
