@@ -1,8 +1,9 @@
-"""CPU simulation (numpy) of how many supergroup / group / half spheres a line reaches per cloud under
-different orderings of the records: the kernel's Hilbert cell order, a local k-d reordering inside every
-supergroup of 64 (or block of 256), and a full k-d order.  The culled scan is VALU-issue bound, so these
-counts translate into its instruction count.  Needs no GPU.  (Uses the product's sampler inputs only
-through synth; lines are random chords drawn here.)"""
+"""CPU simulation (numpy) of the culled scan's executed work: sphere tests per tree level and exact point-0
+tests per (line, cloud) under different orderings of the records -- the kernel's Hilbert cell order, a local
+k-d reordering inside every supergroup of 64 / block of 256, a full k-d order -- and different level
+structures.  With lines accepted like the sampler's (chords of the sampling sphere that hit both clouds'
+boxes) the Hilbert row reproduces the kernel's own counters (rrl_scan_counters) at the bench shape:
+64 / 32.4 / 20.6 / 88.4.  Needs no GPU.  Results: profiles/r02c_kd_refine_and_stream_split_experiments.txt."""
 import os, sys, numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "a-robust-registration-loss_amd"))
@@ -71,60 +72,45 @@ def thresholds(tri):
     p=tri.reshape(-1,3,3).astype(np.float64)
     e=(np.linalg.norm(p[:,1]-p[:,0],axis=1)+np.linalg.norm(p[:,2]-p[:,0],axis=1)+np.linalg.norm(p[:,1]-p[:,2],axis=1))/3
     return e*1.731/2
-for name in ('src_tri','tar_tri'):
-    tri=pr[name]; P=tri[:,:3].astype(np.float64); thr=thresholds(tri)
-    o=order_hilbert(P)
-    base=count(P[o],thr[o],lines)
-    # local k-d inside each supergroup of 64
-    o2=np.concatenate([local_kd(P,o[i:i+64]) for i in range(0,4096,64)])
-    loc=count(P[o2],thr[o2],lines)
-    # local k-d inside blocks of 256 (4 supergroups)
-    o3=np.concatenate([local_kd(P,o[i:i+256]) for i in range(0,4096,256)])
-    loc256=count(P[o3],thr[o3],lines)
-    o4=local_kd(P,np.arange(4096))
-    full=count(P[o4],thr[o4],lines)
-    print(name,'hilbert sg/grp/half per line:',[round(x,2) for x in base],'| local k-d in 64:',[round(x,2) for x in loc],'| in 256:',[round(x,2) for x in loc256],'| full k-d:',[round(x,2) for x in full])
 
 
-# ---- tighter spheres for the SAME (Hilbert) order: AABB centre (the kernel's) vs the better of AABB centre /
-#      centroid / one Ritter step, per node
-def spheres_best(P, thr, size):
-    n = len(P); k = n // size
-    Pg = P.reshape(k, size, 3); lo = Pg.min(1); hi = Pg.max(1)
-    c0 = 0.5 * lo + 0.5 * hi
-    r0 = np.linalg.norm(Pg - c0[:, None], axis=2).max(1)
-    c1 = Pg.mean(1)
-    r1 = np.linalg.norm(Pg - c1[:, None], axis=2).max(1)
-    # Ritter: start at AABB centre sphere, grow towards the farthest point a few times from a smaller start
-    c2 = c0.copy(); r2 = r0 * 0.85
-    for _ in range(8):
-        d = np.linalg.norm(Pg - c2[:, None], axis=2); j = d.argmax(1); dm = d.max(1)
-        far = Pg[np.arange(k), j]
-        grow = dm > r2
-        newr = np.where(grow, 0.5 * (r2 + dm), r2)
-        shift = np.where(grow, (dm - newr) / np.maximum(dm, 1e-30), 0.0)
-        c2 = c2 + (far - c2) * shift[:, None]; r2 = newr
-    r2 = np.linalg.norm(Pg - c2[:, None], axis=2).max(1)
-    best = np.argmin(np.stack([r0, r1, r2]), 0)
-    c = np.where((best == 0)[:, None], c0, np.where((best == 1)[:, None], c1, c2))
-    r = np.minimum(np.minimum(r0, r1), r2)
-    return c, r + thr.reshape(k, size).max(1), (r / r0).mean()
-
-def count_best(P, thr, lines):
+def count_levels(P, thr, lines, sizes):
+    """tests per line at every level (top level: all nodes; below: fan-out x passing parents), last = exact tests"""
     d = lines[:, :3]; o = lines[:, 3:]
-    res = []; prev = None; ratios = []
-    for size in (64, 16, 8):
-        c, R, ratio = spheres_best(P, thr, size)
-        a = c[None] - o[:, None]
-        dot = (a * d[:, None]).sum(-1)
-        d2 = (a * a).sum(-1) - dot * dot
+    tests = []; prev = None
+    for size in sizes:
+        c, R = spheres(P, thr, size)
+        a = c[None] - o[:, None]; dot = (a * d[:, None]).sum(-1); d2 = (a * a).sum(-1) - dot * dot
         ok = d2 <= R[None] ** 2
-        if prev is not None:
-            ok &= np.repeat(prev, ok.shape[1] // prev.shape[1], axis=1)
-        res.append(round(float(ok.sum(1).mean()), 2)); prev = ok; ratios.append(round(float(ratio), 3))
-    return res, ratios
+        if prev is None:
+            tests.append(ok.shape[1])
+        else:
+            par = np.repeat(prev, ok.shape[1] // prev.shape[1], axis=1)
+            tests.append(par.sum(1).mean()); ok &= par
+        prev = ok
+    tests.append(prev.sum(1).mean() * sizes[-1])
+    return [round(float(t), 1) for t in tests]
 
+def kd_blocks(P, o, blk, leaf=8):
+    return np.concatenate([local_kd(P, o[i:i + blk], leaf) for i in range(0, len(o), blk)])
+
+def hits_box(lines, P):
+    lo = P.min(0); hi = P.max(0); d = lines[:, :3]; o = lines[:, 3:]
+    with np.errstate(divide='ignore', invalid='ignore'):
+        t1 = (lo - o) / d; t2 = (hi - o) / d
+    return np.minimum(t1, t2).max(1) <= np.maximum(t1, t2).min(1)
+
+P1 = pr['src_tri'][:, :3].astype(np.float64); P2 = pr['tar_tri'][:, :3].astype(np.float64)
+rng = np.random.default_rng(1)
+u = rng.standard_normal((2, 40000, 3)); u /= np.linalg.norm(u, axis=2, keepdims=True)
+q1, q2 = pr['radius'] * u[0] + pr['center'], pr['radius'] * u[1] + pr['center']
+dd = q2 - q1; Lacc = np.concatenate([dd / np.linalg.norm(dd, axis=1, keepdims=True), q1], 1)
+Lacc = Lacc[hits_box(Lacc, P1) & hits_box(Lacc, P2)][:3000]
+print('lines accepted like the sampler:', len(Lacc), '-- tests per (line, cloud): [level sizes] -> [top, ..., exact]')
 for name in ('src_tri', 'tar_tri'):
     tri = pr[name]; P = tri[:, :3].astype(np.float64); thr = thresholds(tri)
     o = order_hilbert(P)
-    print(name, 'hilbert order, best-of-three spheres: sg/grp/half per line', *count_best(P[o], thr[o], lines), '(mean rho / rho_AABB-centre per level)')
+    orders = {'hilbert': o, 'kd64': kd_blocks(P, o, 64), 'kd256': kd_blocks(P, o, 256), 'kdfull': local_kd(P, np.arange(len(P)))}
+    for on, oo in orders.items():
+        for sizes in ((64, 16, 8), (256, 64, 16, 8), (256, 64, 16, 8, 4)):
+            print(name, on, sizes, count_levels(P[oo], thr[oo], Lacc, sizes))
