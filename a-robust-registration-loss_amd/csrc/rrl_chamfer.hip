@@ -210,12 +210,17 @@ __device__ __forceinline__ void eval_entries(const NNShared &sh, int base, int t
 // COUNT: executed-work counters (rrl_chamfer_counters): [0] patch-level leaf tests (lane-parallel),
 // [1] per-lane leaf sphere tests (wave x leaf), [2] (query, leaf) entries evaluated, [3] (query, target)
 // pairs evaluated, [4] wavefronts.
-template <bool COUNT>
+// IDX = true (rrl_chamfer_from_loss): the records are the LOSS workspace's sorted (P0, thr2) records; the
+// original indices come from its IDX arrays and "a NaN coordinate in the cloud" from its PMAX entries
+// (pm1 = &PMAX[0] of the source's workspace, pm2 = &PMAX[B] of the target's).
+template <bool COUNT, bool IDX>
 __global__ __launch_bounds__(64 * NWV) void chamfer_tree_kernel(
     const float4 *__restrict__ p0s1, const float4 *__restrict__ p0s2, const float4 *__restrict__ grp1,
     const float4 *__restrict__ grp2, const float *__restrict__ apart, int nblk,
     unsigned long long *__restrict__ best_x, unsigned long long *__restrict__ best_y,
-    double *__restrict__ partial, int B, int N, int M, unsigned long long *__restrict__ counters) {
+    double *__restrict__ partial, int B, int N, int M, unsigned long long *__restrict__ counters,
+    const int32_t *__restrict__ idx1, const int32_t *__restrict__ idx2, const uint32_t *__restrict__ pm1,
+    const uint32_t *__restrict__ pm2) {
     __shared__ unsigned long long s_best[64];
     __shared__ __attribute__((aligned(16))) float4 s_q[64];
     __shared__ __attribute__((aligned(16))) float4 s_rec[NWV][CHK * LROW];
@@ -247,6 +252,14 @@ __global__ __launch_bounds__(64 * NWV) void chamfer_tree_kernel(
         const int qi = sgq * SGT + lane;
         w.valid = qi < nq;
         const float4 qr = Q[qi];  // pad records exist up to the supergroup boundary
+        const int32_t *idxT = IDX ? (dir ? idx1 : idx2) + (size_t)b * nsgt * SGT : nullptr;
+        const int qorig = IDX ? ((dir ? idx2 : idx1) + (size_t)b * nsgq * SGT)[qi] : __float_as_int(qr.w);
+        // a staged target record carries its original index in .w
+        auto target = [&](int pos) {
+            float4 r = w.T[pos];
+            if constexpr (IDX) r.w = __int_as_float(idxT[pos]);
+            return r;
+        };
         w.qx = qr.x; w.qy = qr.y; w.qz = qr.z;
         w.best = ~0ull;
         if (wv == 0) { s_q[lane] = qr; s_best[lane] = ~0ull; }
@@ -261,10 +274,14 @@ __global__ __launch_bounds__(64 * NWV) void chamfer_tree_kernel(
         // does the TARGET cloud hold a NaN coordinate (slot 7 of its AABB partial rows)?
         bool tnan = false;
         if (wv == 0) {
-            const int ct = dir ? 0 : 1, nb = (nt + 255) / 256;
-            const float *ap = apart + ((size_t)ct * B + b) * nblk * 8;
-            for (int j = lane; j < nb; j += 64) tnan |= ap[j * 8 + 7] != 0.0f;
-            tnan = __any(tnan);
+            if constexpr (IDX) {  // max |P|^2 of the target cloud: +inf when a coordinate is NaN (or overflows)
+                tnan = !(__uint_as_float((dir ? pm1 : pm2)[b]) <= 3.0e38f);
+            } else {
+                const int ct = dir ? 0 : 1, nb = (nt + 255) / 256;
+                const float *ap = apart + ((size_t)ct * B + b) * nblk * 8;
+                for (int j = lane; j < nb; j += 64) tnan |= ap[j * 8 + 7] != 0.0f;
+                tnan = __any(tnan);
+            }
         }
 
         tk[1] = RRL_NOW();
@@ -287,7 +304,7 @@ __global__ __launch_bounds__(64 * NWV) void chamfer_tree_kernel(
             const int cnt = min(LEAF, nt - seed * SGT - wave * LEAF);
             if (cnt > 0 && cls == 0) {
                 if (lane == 0) sh.pos[0] = seed * SGT + wave * LEAF;
-                if (lane < LEAF) sh.rec[lane] = w.T[seed * SGT + wave * LEAF + lane];
+                if (lane < LEAF) sh.rec[lane] = target(seed * SGT + wave * LEAF + lane);
                 sh.queue[lane] = (unsigned)lane << 8;
                 eval_entries(sh, 0, nq - sgq * SGT < 64 ? nq - sgq * SGT : 64, nt, lane);
                 if constexpr (COUNT) { c_ge += 64u; c_pairs += 64u * (unsigned)cnt; }
@@ -338,7 +355,7 @@ __global__ __launch_bounds__(64 * NWV) void chamfer_tree_kernel(
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 for (int i = lane; i < nc * LEAF; i += 64) {
                     const int slot = i / LEAF, t = i % LEAF;
-                    sh.rec[slot * LROW + t] = w.T[sh.pos[slot] + t];  // rows exist up to the supergroup boundary
+                    sh.rec[slot * LROW + t] = target(sh.pos[slot] + t);  // rows exist up to the supergroup boundary
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 if constexpr (COUNT) { (void)sh.rec[lane].x; }
@@ -394,7 +411,7 @@ __global__ __launch_bounds__(64 * NWV) void chamfer_tree_kernel(
             const bool qnan = (w.qx != w.qx) || (w.qy != w.qy) || (w.qz != w.qz);
             if (qnan || tnan)  // torch.min propagates NaN
                 w.best = ((unsigned long long)0x7fc00000u << 32) | (unsigned)(w.best & 0xffffffffu);
-            (dir ? best_y : best_x)[(size_t)b * nq + __float_as_int(qr.w)] = w.best;
+            (dir ? best_y : best_x)[(size_t)b * nq + qorig] = w.best;
             mine = (double)__uint_as_float((unsigned)(w.best >> 32));
         }
     }
@@ -469,15 +486,53 @@ extern "C" int rrl_chamfer_tree_fwd(const float *x, const float *y, void *ws, si
     if (rc) return rc;
     const int nsgmax = (nmax + SGT - 1) / SGT;
 #define RRL_NN_LAUNCH(COUNT)                                                                                     \
-    hipLaunchKernelGGL(chamfer_tree_kernel<COUNT>, dim3((unsigned)(2 * B), (unsigned)nsgmax), dim3(64 * NWV), 0,      \
+    hipLaunchKernelGGL((chamfer_tree_kernel<COUNT, false>), dim3((unsigned)(2 * B), (unsigned)nsgmax), dim3(64 * NWV), 0, \
                        s, (const float4 *)(w + L.p0s1), (const float4 *)(w + L.p0s2),                            \
                        (const float4 *)(w + L.grp1), (const float4 *)(w + L.grp2), (const float *)(w + L.apart),  \
                        L.nblk, (unsigned long long *)best_x, (unsigned long long *)best_y,                       \
-                       (double *)(w + L.partial), B, N, M, g_cham_counters)
+                       (double *)(w + L.partial), B, N, M, g_cham_counters, (const int32_t *)nullptr,            \
+                       (const int32_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr)
     if (g_cham_counters) RRL_NN_LAUNCH(true);
     else RRL_NN_LAUNCH(false);
 #undef RRL_NN_LAUNCH
     hipLaunchKernelGGL(chamfer_partials_kernel, dim3(1), dim3(256), 0, s, (const double *)(w + L.partial),
+                       2 * B * nsgmax, value, (double)B * (double)(N + M));
+    RRL_LAUNCH_CHECK();
+    return 0;
+}
+
+// Chamfer between the two clouds of a loss evaluation WITHOUT sorting them again (include/rrl.h): the loss
+// forward left the sorted P0 records, their original indices and the sphere trees of both clouds in its
+// workspace -- the first point of every pseudo-triangle IS the point of the cloud (loss.Sample_neighs:
+// row = [P, neighbour, neighbour]), and the fused op's source records are the MOVED source.
+//   ws_src: workspace of the evaluation (cloud 1);  ws_tar: the workspace that holds cloud 2's records --
+//   the same one, or the `target_ws` the evaluation was carried over from (rrl_loss_forward_cached).
+// The tree radii include the triangles' thresholds (looser bounds, same minima).  Keys and value are those of
+// rrl_chamfer_fwd on (P0 of cloud 1, P0 of cloud 2); a non-finite or overflowing coordinate gives NaN.
+extern "C" int rrl_chamfer_from_loss(const void *ws_src, const void *ws_tar, size_t loss_ws_bytes, int B, int N, int M,
+                                     int L, void *ws, size_t ws_bytes, uint64_t *best_x, uint64_t *best_y,
+                                     float *value, void *stream) {
+    if (!ws_src || !ws_tar || !ws || !best_x || !best_y || !value || B <= 0 || N <= 0 || M <= 0 || L < 0) return RRL_E_ARG;
+    if ((N > M ? N : M) > rrl_sort_capacity() || B > 32767) return RRL_E_ARG;  // larger clouds are not sorted by the loss
+    const WsLayout lw(B, N, M, L);
+    if (loss_ws_bytes < lw.total) return RRL_E_WS;
+    const ChamLayout C(B, N, M);
+    if (ws_bytes < C.total) return RRL_E_WS;
+    hipStream_t s = (hipStream_t)stream;
+    char *w = (char *)ws;
+    const int nmax = N > M ? N : M, nsgmax = (nmax + SGT - 1) / SGT;
+#define RRL_NN_LAUNCH(COUNT)                                                                                     \
+    hipLaunchKernelGGL((chamfer_tree_kernel<COUNT, true>), dim3((unsigned)(2 * B), (unsigned)nsgmax), dim3(64 * NWV), 0, \
+                       s, (const float4 *)lw.f32(ws_src, RRL_WS_P0S1), (const float4 *)lw.f32(ws_tar, RRL_WS_P0S2), \
+                       (const float4 *)lw.f32(ws_src, RRL_WS_GRP1), (const float4 *)lw.f32(ws_tar, RRL_WS_GRP2),  \
+                       (const float *)nullptr, 0, (unsigned long long *)best_x, (unsigned long long *)best_y,    \
+                       (double *)(w + C.partial), B, N, M, g_cham_counters, lw.i32(ws_src, RRL_WS_IDX1),        \
+                       lw.i32(ws_tar, RRL_WS_IDX2), (const uint32_t *)lw.i32(ws_src, RRL_WS_PMAX),              \
+                       (const uint32_t *)lw.i32(ws_tar, RRL_WS_PMAX) + B)
+    if (g_cham_counters) RRL_NN_LAUNCH(true);
+    else RRL_NN_LAUNCH(false);
+#undef RRL_NN_LAUNCH
+    hipLaunchKernelGGL(chamfer_partials_kernel, dim3(1), dim3(256), 0, s, (const double *)(w + C.partial),
                        2 * B * nsgmax, value, (double)B * (double)(N + M));
     RRL_LAUNCH_CHECK();
     return 0;

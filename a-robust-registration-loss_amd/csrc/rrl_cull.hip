@@ -20,9 +20,10 @@
 //              (wave-uniform sphere, scalar loads); passing (line, supergroup) pairs -> queue A;
 //     level B  the lanes pop one (line, supergroup) pair each and test its 4 group spheres
 //              -> queue B;   level C: (line, group) -> the 2 half spheres -> queue C;
-//     level D  the lanes pop one (line, half) pair each and run the scan's exact point-0 test
-//              (same dist_sq arithmetic, bit-identical) on the half's 8 records.  Point-0 passes
-//              are parked and their points 1, 2 (two dependent global loads) resolved densely.
+//     level D  the lanes pop one (line, half) pair each and run a conservative point-0 PREFILTER (FMA
+//              chain, below) on the half's 8 records.  Survivors (~3 % of the tested records) are
+//              parked and resolved densely with the reference's own unfused arithmetic on all three
+//              points (dist_sq, bit-identical to the strict scan; two dependent global loads).
 //   Below level A every lane works on a different tree node at the same time, and a level only
 //   runs when 64 pairs are waiting (or at the end), so the lanes stay full however unevenly the
 //   pairs are spread over the lines.  Per line and cloud at the bench shape: 64 + 8.1 x 4 + 10.2 x 2
@@ -55,14 +56,27 @@
 // that holds one evaluates all its (line, triangle) pairs of the slice with the strict loop
 // (status[1] counts such wavefronts).
 //
+// Point-0 prefilter (level D).  The kernel is VALU-issue bound and level D was 35 % of its instructions:
+// the reference's unfused evaluation of x_ref(P0) costs 16 operations + compare + mask per record.  The
+// prefilter evaluates e = fl(Q(P0)) + c with one FMA chain (3 subtractions, 3 + 3 + 1 FMAs; the staged
+// record carries c in place of thr2) and takes its SIGN BIT (one v_alignbit per record), 11 operations:
+//   |fl(Q) - Q| <= 14.2 u |a|^2 + 4 u |c|   (a rounded once; three-term FMA chains; |d| ~ 1)
+//   hit  =>  Q < thr2 - 2e-4 + 30 u |a|^2                                   (as above)
+//   c = -(T' + 1e-6 |T'| + s0),  T' = fl(thr2 - 2e-4),  s0 = 3e-6 A_wg^2 + 1e-9  (3e-6 = 50.3 u)
+// so a hit always gives e < 0: the 1e-6 |T'| covers the rounding of T' and 4 u |c|, 50.3 u A^2 covers
+// 44.2 u |a|^2 (|a| <= A), and the floor covers u 4e-4 when everything sits at the origin.  A_wg^2 and the
+// node slack se are the maxima over the lines of the workgroup's culled wavefronts (the staged records and
+// nodes are shared).  e < 0 only PARKS the triangle; whether it is a hit is decided by the exact arithmetic
+// in resolve_candidate, so a false candidate costs time, never a label.
+//
 // NaN (negative sqrt argument; the reference prints and exits, code/loss.py:88-91): provably
 // impossible when g <= 0 for every line of the wavefront (A^2 < 111; all unit-scale training data).
-// Otherwise (g > 0, e.g. the demo's full-diagonal radius) it is detected on every EVALUATED pair:
-// point 0 of every triangle whose half sphere the line reaches -- which includes every triangle
-// whose point 0 could produce one (x_ref(P0) < 0 needs Q(P0) < g, a "hit" with T = 0) -- and points
-// 1, 2 of the triangles whose point 0 passes.  A negative argument at point 1 or 2 of a triangle
-// whose point 0 does not pass is not evaluated, as in RRL_SCAN_LAZY; it needs rounding noise above
-// 2e-4 + Q, which at the demo's scale means > 11u |a|^2 of the 15u worst case (never observed).
+// Otherwise (g > 0, e.g. the demo's full-diagonal radius) it is detected on every pair that is evaluated
+// EXACTLY: all three points of every prefilter candidate -- which includes every triangle whose point 0
+// could produce one (x_ref(P0) < 0 needs Q(P0) < g: a "hit" with thr2 = 0, so its half sphere is reached
+// and its prefilter value is negative).  A negative argument at point 1 or 2 of a triangle that is not
+// a candidate is not evaluated, as in RRL_SCAN_LAZY; it needs rounding noise above 2e-4 + Q, which at
+// the demo's scale means > 11u |a|^2 of the 15u worst case (never observed).
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -518,29 +532,30 @@ struct WaveCtx {
     int32_t *cnt, *hit;           // per-line hit count / slots of the cloud
     int lbase;                    // first line of this wave
     int pos0;                     // sorted position of the slice's first record
-    int n;                        // real records of the cloud (sorted positions [0, n))
     int na, nb, nc, ncand;        // wave-uniform fill levels
     int lane;
     // executed-work counters of the COUNT instantiation (wave-uniform; see rrl_scan_counters)
     unsigned tb, tc, td, tcand;   // level-B / level-C sphere tests, exact point-0 tests, resolved candidates
-    float se;                     // wave-uniform slack added to every node radius (cull_line_slack)
     int32_t *status;              // NaN flag of the call
-    bool track;                   // wave-uniform: a NaN is not provably impossible for these lines
 };
 
-// cand = line_in_wave << 16 | sorted triangle position: evaluate points 1 and 2
+// cand = line_in_wave << 16 | sorted triangle position: a triangle whose point 0 passed the conservative
+// prefilter of level D.  The reference's own arithmetic (dist_sq, bit-identical to the strict scan) decides
+// on all three points here.
 __device__ __forceinline__ void resolve_candidate(const WaveCtx &c, unsigned cand) {
     const int ll = cand >> 16, spos = cand & 0xffff;
     const float4 la = c.la[ll];
     const float2 lb = c.lb[ll];
     const int f = c.idx[spos];  // (staging the slice's indices in LDS measured 0.8 us slower)
-    const float *q = c.ptri + PTRI_STRIDE * (size_t)f;
-    const uint32_t thr2 = __float_as_uint(q[9]);
-    const float x1 = dist_sq<float>(q[3], q[4], q[5], la.x, la.y, la.z, la.w, lb.x, lb.y);
-    const float x2 = dist_sq<float>(q[6], q[7], q[8], la.x, la.y, la.z, la.w, lb.x, lb.y);
+    const float4 *q = (const float4 *)(c.ptri + PTRI_STRIDE * (size_t)f);
+    const float4 r0 = q[0], r1 = q[1], r2 = q[2];  // P0 P1.x | P1.yz P2.xy | P2.z thr2 thr index
+    const uint32_t thr2 = __float_as_uint(r2.y);
+    const uint32_t x0 = __float_as_uint(dist_sq<float>(r0.x, r0.y, r0.z, la.x, la.y, la.z, la.w, lb.x, lb.y));
+    const uint32_t x1 = __float_as_uint(dist_sq<float>(r0.w, r1.x, r1.y, la.x, la.y, la.z, la.w, lb.x, lb.y));
+    const uint32_t x2 = __float_as_uint(dist_sq<float>(r1.z, r1.w, r2.x, la.x, la.y, la.z, la.w, lb.x, lb.y));
     // a negative sqrt argument is the reference's NaN (code/loss.py:88-91); candidates are rare
-    if ((__float_as_uint(x1) | __float_as_uint(x2)) >= 0x80000000u) atomicOr(&c.status[0], 1);
-    if (max(__float_as_uint(x1), __float_as_uint(x2)) < thr2) {
+    if ((x0 | x1 | x2) >= 0x80000000u) atomicOr(&c.status[0], 1);
+    if (max(max(x0, x1), x2) < thr2) {  // sign bit set (negative / NaN) -> huge: never a hit
         const int l = c.lbase + ll;
         int pos = atomicAdd(&c.cnt[l], 1);
         if (pos < RRL_MAX_HITS) c.hit[(size_t)l * RRL_MAX_HITS + pos] = f;
@@ -560,7 +575,8 @@ __device__ __forceinline__ int lane_rank(unsigned long long m) {  // set bits of
 // 1 + 1e-6, or non-finite data).  nanfree: a negative sqrt argument is provably impossible.
 struct LineSlack {
     bool ok, nanfree;
-    float se;
+    float se;  // slack of the node radii
+    float a2;  // (|x0| + max|P|)^2, rounded up: bounds |P - x0|^2 for every point of the cloud
 };
 __device__ __forceinline__ LineSlack cull_line_slack(const float *v, float pm) {
     const float s = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
@@ -574,18 +590,17 @@ __device__ __forceinline__ LineSlack cull_line_slack(const float *v, float pm) {
     r.nanfree = g <= 0.0f;
     const float se = g > 0.0f ? sqrtf(g + x) : fminf(sqrtf(x), x / (2.0f * sqrtf(-0.999f * g)));
     r.se = se * 1.0001f + 1e-12f;
+    r.a2 = A2;
     return r;
 }
 
-// conservative sphere test of one line against one tree node (see the culling bound above)
-__device__ __forceinline__ bool sphere_pass(const float4 nd, const float4 la, const float2 lb, float se) {
+// conservative sphere test of one line against one STAGED tree node (centre, w = (Rs + se)^2 rounded up;
+// see the culling bound above): d2 - 4e-6 q <= w, evaluated as the sign of one FMA chain
+__device__ __forceinline__ bool sphere_pass(const float4 nd, const float4 la, const float2 lb) {
     const float ax = nd.x - la.w, ay = nd.y - lb.x, az = nd.z - lb.y;
     const float dot = fmaf(az, la.z, fmaf(ay, la.y, ax * la.x));
     const float q = fmaf(az, az, fmaf(ay, ay, ax * ax));
-    float d2 = fmaf(-dot, dot, q);
-    d2 = fmaf(-4e-6f, q, d2);
-    const float t = nd.w + se;  // NaN (empty node) fails the comparison
-    return d2 <= t * t;
+    return fmaf(-dot, dot, fmaf(q, 0.999996f, -nd.w)) <= 0.0f;  // NaN (empty node) fails the comparison
 }
 
 template <bool COUNT>
@@ -606,8 +621,11 @@ __device__ __forceinline__ void flush_cands(WaveCtx &c) {
 // which doubles the instruction-level parallelism of these latency-bound passes.
 // all = false: only while at least 64 entries wait (full lanes); all = true: drain.
 
-// level D: pops (line, half) pairs, ONE per lane (8 records = 32 registers in flight), and runs
-// the exact point-0 test on the half's 8 records
+// level D: pops (line, half) pairs, ONE per lane (8 records = 32 registers in flight), and runs the point-0
+// PREFILTER on the half's 8 records: e = fl(Q(P0)) + c by FMAs, with the staged c = -(thr2 - 2e-4 + slack)
+// (see "Point-0 prefilter" above): 10 operations and one v_alignbit per record instead of the 16 + 3 of
+// the reference's unfused arithmetic.  e < 0 (sign bit) parks the triangle as a candidate; the exact test of
+// all three points happens there (resolve_candidate), on ~3 % of the records.
 template <bool COUNT>
 __device__ __forceinline__ void proc_c(WaveCtx &c, bool all) {
 #ifdef CULL_STOP_C  // timing experiments only (tools/knob_sweep.sh): the level is formed but not run
@@ -627,23 +645,14 @@ __device__ __forceinline__ void proc_c(WaveCtx &c, bool all) {
             const float4 la = c.la[ll];
             const float2 lb = c.lb[ll];
             const float4 *row = c.recs + (h >> 1) * ROWS + (h & 1) * 8;
-            if (!c.track) {  // uniform: the usual case, a NaN is provably impossible
 #pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    const float4 rec = row[t];
-                    const float x = dist_sq<float>(rec.x, rec.y, rec.z, la.x, la.y, la.z, la.w, lb.x, lb.y);
-                    passbits |= (__float_as_uint(x) < __float_as_uint(rec.w) ? 1u : 0u) << t;
-                }
-            } else {  // also watch for a negative sqrt argument (sign bit) among the evaluated pairs
-                uint32_t neg = 0;
-#pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    const float4 rec = row[t];
-                    const float x = dist_sq<float>(rec.x, rec.y, rec.z, la.x, la.y, la.z, la.w, lb.x, lb.y);
-                    passbits |= (__float_as_uint(x) < __float_as_uint(rec.w) ? 1u : 0u) << t;
-                    if (c.pos0 + h * 8 + t < c.n) neg |= __float_as_uint(x);  // pad records are not points
-                }
-                if (neg >= 0x80000000u) atomicOr(&c.status[0], 1);
+            for (int t = 7; t >= 0; --t) {  // record t ends up in bit t
+                const float4 rec = row[t];
+                const float ax = rec.x - la.w, ay = rec.y - lb.x, az = rec.z - lb.y;
+                const float dot = fmaf(az, la.z, fmaf(ay, la.y, ax * la.x));
+                const float q = fmaf(az, az, fmaf(ay, ay, fmaf(ax, ax, rec.w)));
+                const float ev = fmaf(-dot, dot, q);
+                passbits = __builtin_amdgcn_alignbit(passbits, __float_as_uint(ev), 31);  // passbits << 1 | sign(ev)
             }
             lh = ((unsigned)ll << 16) | (unsigned)(c.pos0 + h * 8);
         }
@@ -687,8 +696,8 @@ __device__ __forceinline__ void proc_b(WaveCtx &c, bool all) {
                 const float4 la = c.la[ll];
                 const float2 lb = c.lb[ll];
                 const float4 *nd = c.nodes + (g >> 2) * NODE + 5 + 2 * (g & 3);
-                p[u][0] = sphere_pass(nd[0], la, lb, c.se);
-                p[u][1] = sphere_pass(nd[1], la, lb, c.se);
+                p[u][0] = sphere_pass(nd[0], la, lb);
+                p[u][1] = sphere_pass(nd[1], la, lb);
                 e2[u] = ((unsigned)ll << 6) | (unsigned)(2 * g);
             }
         }
@@ -728,7 +737,7 @@ __device__ __forceinline__ void proc_a(WaveCtx &c, bool all) {
             const float2 lb = c.lb[ll];
             const float4 *nd = c.nodes + sg * NODE + 1;
 #pragma unroll
-            for (int k = 0; k < SGG; ++k) p[k] = sphere_pass(nd[k], la, lb, c.se);
+            for (int k = 0; k < SGG; ++k) p[k] = sphere_pass(nd[k], la, lb);
             e2 = ((unsigned)ll << 5) | (unsigned)(SGG * sg);
         }
 #pragma unroll
@@ -797,9 +806,11 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(6, 8))
     __shared__ __attribute__((aligned(16))) float4 node_lds[SPW * NODE];      //  1.6 KiB
     __shared__ unsigned short qa_lds[WPB][QA_CAP], qb_lds[WPB][QB_CAP], qc_lds[WPB][QC_CAP];
     __shared__ unsigned cands_lds[WPB][WCCAP];
+    __shared__ unsigned wg_slack[2];  // max over the workgroup's lines: bits of se, bits of A^2
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform for the compiler
     const unsigned long long wall0 = COUNT ? wall_clock64() : 0ull;
+    if (tid < 2) wg_slack[tid] = 0u;
     unsigned long long *crow = nullptr;
     if constexpr (COUNT) {
         const long long wid = (((long long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + wave;
@@ -846,6 +857,20 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(6, 8))
     const LineSlack ls0 = cull_line_slack(v0, pm), ls1 = cull_line_slack(v1, pm);
     const bool fallback = !__all(ls0.ok && ls1.ok);
     unsigned long long fb_pairs = 0;
+    // The slacks are taken over the whole WORKGROUP (the staged records and nodes are shared by its
+    // wavefronts and carry them folded in): max se and max A^2 of the lines of the culled wavefronts.
+    __syncthreads();  // wg_slack cleared
+    if (has_lines && !fallback) {
+        const float se_w = wave_max(fmaxf(ls0.se, ls1.se)), a2_w = wave_max(fmaxf(ls0.a2, ls1.a2));
+        if (lane == 0) {  // non-negative floats: unsigned order == float order
+            atomicMax(&wg_slack[0], __float_as_uint(se_w));
+            atomicMax(&wg_slack[1], __float_as_uint(a2_w));
+        }
+    }
+    __syncthreads();
+    const float se = __uint_as_float(wg_slack[0]);
+    // point-0 prefilter (header): 44.2 u A^2 of evaluation error on both sides, rounded up, + an absolute floor
+    const float s0 = 3.0e-6f * __uint_as_float(wg_slack[1]) + 1.0e-9f;
 
     WaveCtx ctx;
     ctx.la = la_lds[wave];
@@ -864,10 +889,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(6, 8))
     ctx.na = ctx.nb = ctx.nc = ctx.ncand = 0;
     ctx.lane = lane;
     ctx.tb = ctx.tc = ctx.td = ctx.tcand = 0;
-    ctx.n = n;
     ctx.status = status;
-    ctx.se = wave_max(fmaxf(ls0.se, ls1.se));
-    ctx.track = !__all(ls0.nanfree && ls1.nanfree);
     const v2f ux = {v0[0], v1[0]}, uy = {v0[1], v1[1]}, uz = {v0[2], v1[2]};
     const v2f ox = {v0[3], v1[3]}, oy = {v0[4], v1[4]}, oz = {v0[5], v1[5]};
     unsigned long long ta = 0;
@@ -878,8 +900,19 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(6, 8))
     const int nsl = min(spw, nsg - sg0);
     // ---- stage the slice: records (padded rows) and tree nodes
     if (rep > 0) __syncthreads();  // every wavefront is done with the previous slice
-    for (int i = tid; i < nsl * SGT; i += blockDim.x) rec_lds[(i >> 4) * ROWS + (i & 15)] = p0s[(size_t)sg0 * SGT + i];
-    for (int i = tid; i < nsl * NODE; i += blockDim.x) node_lds[i] = tree[(size_t)sg0 * NODE + i];
+    for (int i = tid; i < nsl * SGT; i += blockDim.x) {
+        float4 r = p0s[(size_t)sg0 * SGT + i];
+        // (P0, thr2) -> (P0, c): c = -(thr2 - 2e-4 + slack), slightly widened; pad records never pass
+        const float tp = r.w - RRL_EPS;
+        r.w = sg0 * SGT + i < n ? -(tp + 1.0e-6f * fabsf(tp) + s0) : INFINITY;
+        rec_lds[(i >> 4) * ROWS + (i & 15)] = r;
+    }
+    for (int i = tid; i < nsl * NODE; i += blockDim.x) {
+        float4 nd = tree[(size_t)sg0 * NODE + i];
+        const float rt = nd.w + se;  // (centre, Rs) -> (centre, (Rs + se)^2 rounded up); NaN (empty) stays NaN
+        nd.w = rt * rt * 1.0000003f;
+        node_lds[i] = nd;
+    }
     __syncthreads();
 #ifdef CULL_STOP_STAGE
     continue;
@@ -911,7 +944,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(6, 8))
     for (int s = 0; s < SPW; ++s) {
         if (s >= nsl) break;  // uniform
         const float cx = sgs[s][0], cy = sgs[s][1], cz = sgs[s][2];
-        const float Rt = sgs[s][3] + ctx.se, R2 = Rt * Rt;  // NaN (empty node) fails both comparisons
+        const float Rt = sgs[s][3] + se, R2 = Rt * Rt;  // NaN (empty node) fails both comparisons
         const v2f ax = cx - ox, ay = cy - oy, az = cz - oz;
         const v2f dot = __builtin_elementwise_fma(az, uz, __builtin_elementwise_fma(ay, uy, ax * ux));
         const v2f q = __builtin_elementwise_fma(az, az, __builtin_elementwise_fma(ay, ay, ax * ax));

@@ -41,6 +41,7 @@ _SIGS = {
     "rrl_chamfer_fwd": [_P] * 5 + [_I] * 3 + [_P],
     "rrl_chamfer_bwd": [_P] * 7 + [_I] * 3 + [_P],
     "rrl_chamfer_tree_fwd": [_P, _P, _P, _Z, _P, _P, _P, _I, _I, _I, _P],
+    "rrl_chamfer_from_loss": [_P, _P, _Z, _I, _I, _I, _I, _P, _Z, _P, _P, _P, _P],
     "rrl_aabb": [_P, _P, _I, _I, _P],
     "rrl_box_accept": [_P, _P, _P, _P, _P, _I, _I, _P],
     "rrl_log_row": [_P, _P, _P, _P, _P, _c.c_longlong, _P, _P],

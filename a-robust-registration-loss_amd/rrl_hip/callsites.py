@@ -33,6 +33,18 @@ def bounding_radius(tar_box, scale=1.0):
 
 
 DEVICE_RNG = False  # True: draw the candidate lines' uniforms on the GPU (opt-in, see draw_lines)
+CHAMFER_FROM_LOSS = False  # True: the Chamfer monitor walks the clouds the loss evaluation just sorted
+#   (ops.chamfer_from_state: no second sort, ~1/3 less device time).  Opt-in because it is the distance between
+#   the FIRST POINTS of the pseudo-triangles: identical to chamfer_dist(points_src_sample moved, points_tar_sample)
+#   only when those samples are exactly the rows 0, 3, 6, ... of points_based_neighs_* (what Sample_neighs emits,
+#   code/loss.py:473-485; a dataset that stores the samples separately may differ in the last bits).
+
+
+def _monitor(moved, tar):
+    """The trainers' Chamfer monitor next to a loss evaluation."""
+    if CHAMFER_FROM_LOSS and _ops.last_state() is not None:
+        return _ops.chamfer_from_state()
+    return _ops.chamfer(moved, tar)
 
 
 def draw_lines(radius, centers, n_lines, moved_src, tar, device=None, device_rng=None):
@@ -90,7 +102,7 @@ def rpm_intersection_loss(pred_transforms, data, n_lines=10000, lines=None, mode
         loss, ok = per_sample_loss(data['points_based_neighs_src'], R, t, tar_tri, lines, mode, first)
         first = first or _ops.last_state()
         per_iter.append(loss.sum().reshape(1) / num_iter)
-        chamfers.append(_ops.chamfer(tar, moved).detach())
+        chamfers.append((_ops.chamfer_from_state() if CHAMFER_FROM_LOSS else _ops.chamfer(tar, moved)).detach())
         valid.append(ok)
     disc = [0.5 ** (num_iter - ni - 1) for ni in range(num_iter)]
     return {'loss_intersection': sum(l * d for l, d in zip(per_iter, disc)),
@@ -109,12 +121,12 @@ def dcp_intersection_loss(data, rotation_ab_pred, translation_ab_pred, n_lines=1
     tar_tri = data['points_based_neighs_tar'].transpose(2, 1).reshape(B, -1, 9)
     moved = _ops.rigid_apply(data['points_src_sample'], rotation_ab_pred, translation_ab_pred,
                              transpose_r=True, channel_first=True).transpose(2, 1).contiguous()
-    chamfer = _ops.chamfer(moved, tar)
     if lines is None:
         lines = draw_lines(bounding_radius(data['tar_box'], 0.5), data['centers'], n_lines,
                            moved.detach(), tar)
     src_nb = data['points_based_neighs_src'].transpose(2, 1).contiguous()
     loss, ok = per_sample_loss(src_nb, rotation_ab_pred, translation_ab_pred, tar_tri, lines, mode)
+    chamfer = _monitor(moved, tar)  # the reference evaluates it before the loss; it depends on neither
     return (loss / 5.0).sum().reshape(1) / B, chamfer, lines, ok
 
 
@@ -139,4 +151,4 @@ def fmr_intersection_loss(g_series, data, n_lines=15000, lines=None, last=3, mod
         first = first or _ops.last_state()
         total = total + (loss / 5.0).sum().reshape(1) * 0.5 ** (maxiter - i - 1)
         valid.append(ok)
-    return total / B, _ops.chamfer(moved, tar), lines, torch.stack(valid)
+    return total / B, _monitor(moved, tar), lines, torch.stack(valid)  # the last estimate's evaluation is the latest

@@ -207,6 +207,7 @@ def loss_forward_raw(tri1, tri2, line, rng=(1, 1, 5, 5), pool=False, mode="cull"
     if tri2.device != dev or line.device != dev:
         raise ValueError("tri1, tri2 and line must live on the same GPU")
     st = LossState(B, N, M, L, G, dev)
+    st.target_state = getattr(target_from, "target_state", None) or target_from  # whose workspace holds cloud 2
     ws, nb = _p(st.ws), st.nbytes
     with _guard(dev):
         s = _stream(dev)
@@ -333,6 +334,7 @@ class _RegistrationLoss(torch.autograd.Function):
                 _p(src), _p(Rm), _p(tv), _p(tri2), _p(ln), _p(st.ws), st.nbytes, _p(st.loss), B, N, M, L,
                 int(transpose_r), s_m, s_n, e_m, e_n, _MODES[mode], int(chunk),
                 _target_ws(target_from, B, N, M, L), _stream(dev)), "rrl_registration_forward")
+        st.target_state = getattr(target_from, "target_state", None) or target_from  # whose workspace holds cloud 2
         ctx.st, ctx.src, ctx.Rm, ctx.tri2 = st, src, Rm, tri2
         ctx.meta = (int(transpose_r), bool(want_payload), R.shape, t.shape, src_tri.device, R.device, t.device)
         info, status = st.info, st.status
@@ -552,6 +554,34 @@ class _Chamfer(torch.autograd.Function):
 
 def chamfer(x, y):
     return _Chamfer.apply(x, y)
+
+
+def chamfer_from_state(state=None, keys=False):
+    """Chamfer distance between the two clouds of a loss evaluation (default: the latest one) from the
+    sorted records and sphere trees that evaluation left in its workspace -- no second sort
+    (include/rrl.h rrl_chamfer_from_loss; two launches instead of three).  The "points" are the first
+    points of the pseudo-triangles (code/loss.py:473-485: row = [P, neighbour, neighbour]); for the fused
+    op cloud 1 is the MOVED source.  Equals chamfer(P0 of cloud 1, P0 of cloud 2): use it for the trainers'
+    monitor next to the loss when their point sets are those first points.  Not differentiable.
+    keys=True also returns the (B, N) / (B, M) u64 keys (distance bits << 32 | argmin)."""
+    st = state or _IntersectionLoss.last_state
+    if st is None:
+        raise ValueError("no loss evaluation to take the clouds from")
+    B, N, M, L, _ = st.dims
+    dev = st.ws.device
+    tar = getattr(st, "target_state", None) or st
+    if tuple(tar.dims[:4]) != (B, N, M, L) or tar.ws.device != dev:
+        raise ValueError("the carried-over target state does not match")
+    nb = _chamfer_ws_bytes.get((B, N, M))
+    if nb is None:
+        nb = _chamfer_ws_bytes[(B, N, M)] = int(_lib.load().rrl_chamfer_workspace_bytes(B, N, M))
+    ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+    bx = torch.empty(B, N, dtype=torch.int64, device=dev)
+    by = torch.empty(B, M, dtype=torch.int64, device=dev)
+    val = torch.empty(1, device=dev)
+    _run(dev, "rrl_chamfer_from_loss", _p(st.ws), _p(tar.ws), st.nbytes, B, N, M, L, _p(ws), nb, _p(bx), _p(by),
+         _p(val))
+    return (val.reshape(()), bx, by) if keys else val.reshape(())
 
 
 # ---------------------------------------------------------------------------------------

@@ -400,6 +400,22 @@ def main():
                        "chamfer_brute_force_ms": bms, "chamfer_values_equal": cd == cdb,
                        "chamfer_note": "both directions, B x N x M dense-equivalent pairs; sorted clouds + sphere tree "
                                        "(rrl_chamfer.hip) vs the all-pairs kernel"})
+        # the monitor NEXT TO a loss evaluation: the loss workspace already holds both clouds sorted under
+        # their sphere trees (the triangles' first points are the points), so the walk needs no second sort
+        st0 = ops.loss_forward_raw(w["tri1"], w["tri2"], w["lines"], mode=args.mode)
+        fn = (lambda: ops.chamfer_from_state(st0))
+        gc = GraphedStep(fn) if not args.no_graph else fn
+        for _ in range(3):
+            gc()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(50):
+            cfs = gc()
+        torch.cuda.synchronize()
+        fms = (time.perf_counter() - t1) / 50 * 1e3
+        want = float(ops.chamfer(w["tri1"][..., :3].contiguous(), w["tri2"][..., :3].contiguous()))
+        extras.update({"chamfer_from_loss_state_ms": fms, "chamfer_from_loss_state": float(cfs),
+                       "chamfer_from_loss_state_equals_chamfer_of_first_points": float(cfs) == want})
 
     if rank == 0:
         value = sum_pairs(world, B, args, L, N, M) * args.steps / dt

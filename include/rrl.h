@@ -283,6 +283,20 @@ int rrl_chamfer_fwd(const float *x, const float *y, uint64_t *best_x, uint64_t *
 size_t rrl_chamfer_workspace_bytes(int B, int N, int M);
 int rrl_chamfer_tree_fwd(const float *x, const float *y, void *ws, size_t ws_bytes, uint64_t *best_x,
                          uint64_t *best_y, float *value, int B, int N, int M, void *stream);
+/* Chamfer between the two clouds of a LOSS EVALUATION without sorting them again: the loss forward
+ * (rrl_loss_forward*, rrl_registration_forward*, or rrl_tri_prepare) left the sorted P0 records, their
+ * original indices and the sphere trees of both clouds in its workspace, and the first point of every
+ * pseudo-triangle is the point of the cloud it was built from (code/loss.py:473-485: row = [P, neighbour,
+ * neighbour]); the fused op's source records are the MOVED source.  This replaces the trainers'
+ * chamfer_dist(moved source points, target points) next to the loss (rpm/Train_RPM.py:223-224) when the
+ * point sets ARE the triangles' first points: keys and value equal rrl_chamfer_fwd on (P0 of cloud 1,
+ * P0 of cloud 2).  ws_src: the evaluation's workspace; ws_tar: the workspace holding cloud 2's records
+ * (the same one, or the target_ws the evaluation was carried over from); both of layout (B, N, M, L).
+ * ws: scratch of rrl_chamfer_workspace_bytes(B, N, M).  N, M <= 65536 (larger clouds are not sorted).
+ * Two launches.  A non-finite (or overflowing) coordinate anywhere in a cloud gives NaN minima. */
+int rrl_chamfer_from_loss(const void *ws_src, const void *ws_tar, size_t loss_ws_bytes, int B, int N, int M,
+                          int L, void *ws, size_t ws_bytes, uint64_t *best_x, uint64_t *best_y, float *value,
+                          void *stream);
 /* Profiling hook like rrl_scan_counters: while dev_counters != NULL rrl_chamfer_tree_fwd runs an
  * instrumented instantiation that WRITES one row of 16 uint64 per wavefront of the walk (row index =
  * workgroup * wavefronts per workgroup + wavefront; the buffer must hold 16 * 8 * 2 B * ceil(max(N,M)/64)

@@ -105,6 +105,30 @@ def test_fmr_fragment(C, G):
     close_grad(t.grad, G["fmr_grad_t"])
 
 
+def test_fragments_monitor_from_the_loss_state(C, G):
+    """callsites.CHAMFER_FROM_LOSS: the trainers' Chamfer monitor walks the clouds the loss evaluation
+    just sorted (ops.chamfer_from_state) instead of sorting the point samples again.  The fixture's samples
+    are the first points of its pseudo-triangles, so the values equal the reference-generated ones."""
+    assert C.CHAMFER_FROM_LOSS is False  # opt-in
+    nb, src = np.asarray(G["nb_src"]), np.asarray(G["src"])
+    np.testing.assert_array_equal(nb.reshape(nb.shape[0], -1, 9)[..., :3], src[..., :3])  # the contract
+    C.CHAMFER_FROM_LOSS = True
+    try:
+        R, t = cu(G["R"]), cu(G["t"])
+        pred = [torch.cat([R[i], t[i][..., None]], dim=-1) for i in range(R.shape[0])]
+        out = C.rpm_intersection_loss(pred, data_dict(G), lines=cu(G["rpm_lines"]))
+        np.testing.assert_allclose(out['loss_chamfer'].item(), G["rpm_chamfer"], rtol=1e-5)
+        np.testing.assert_allclose(out['loss_intersection'].item(), G["rpm_loss"], rtol=2e-4)
+        _, chamfer, _, _ = C.dcp_intersection_loss(data_dict(G, channel_first=True), R[0], t[0], lines=cu(G["dcp_lines"]))
+        np.testing.assert_allclose(chamfer.item(), G["dcp_chamfer"], rtol=1e-5)
+        bottom = torch.tensor([0.0, 0, 0, 1], device='cuda').expand(R.shape[1], 1, 4)
+        gs = [torch.cat([torch.cat([R[i], t[i][..., None]], dim=-1), bottom], dim=1) for i in range(R.shape[0])]
+        _, chamfer, _, _ = C.fmr_intersection_loss(gs, data_dict(G), lines=cu(G["fmr_lines"]))
+        np.testing.assert_allclose(chamfer.item(), G["fmr_chamfer"], rtol=1e-5)
+    finally:
+        C.CHAMFER_FROM_LOSS = False
+
+
 def test_fragments_draw_their_own_lines(C, G):
     """lines=None: the sampler runs with the trainer's radius convention; rows are unit
     directions or unfilled zeros, and the loss is finite and reproducible under a seed."""

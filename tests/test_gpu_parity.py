@@ -634,6 +634,48 @@ def test_chamfer_nan_propagates(L):
     np.testing.assert_array_equal(np.isnan(np.concatenate([dx.reshape(-1), dy.reshape(-1)])), torch.isnan(want).numpy())
 
 
+@pytest.mark.parametrize("B,N,M,Ll", [(2, 1024, 700, 3000), (8, 4096, 4096, 2000), (1, 5000, 4100, 1500), (1, 65, 64, 300)])
+def test_chamfer_from_state_equals_chamfer_of_first_points(L, B, N, M, Ll):
+    """rrl_chamfer_from_loss (no second sort: the loss workspace's sorted records, index arrays and
+    sphere trees) against the brute-force kernel on (P0 of cloud 1, P0 of cloud 2): every u64 key
+    identical, for the plain loss, the fused op (cloud 1 = the MOVED source) and an evaluation whose
+    target was carried over from an earlier one (its records live in that workspace)."""
+    from rrl_hip import ops, synth
+    prs = [synth.make_pair(70 + b, N, M) for b in range(B)]
+    src = cu(np.stack([p["src_tri"] for p in prs]))
+    tar = cu(np.stack([p["tar_tri"] for p in prs]))
+    torch.manual_seed(5)
+    ln = torch.randn(B, Ll, 6, device="cuda")
+    ln[..., :3] = torch.nn.functional.normalize(ln[..., :3], dim=-1)
+    ln[..., 3:] *= 0.3
+
+    def check(st, p0_src, p0_tar):
+        val, bx, by = ops.chamfer_from_state(st, keys=True)
+        wx, wy, wv = _chamfer_keys(p0_src.cpu().numpy(), p0_tar.cpu().numpy(), False)
+        np.testing.assert_array_equal(bx.cpu().numpy().view(np.uint64), wx)
+        np.testing.assert_array_equal(by.cpu().numpy().view(np.uint64), wy)
+        assert abs(val.item() - wv) <= 2e-7 * abs(wv)
+
+    st = ops.loss_forward_raw(src, tar, ln)
+    check(st, src[..., :3].contiguous(), tar[..., :3].contiguous())
+    # fused op: a rotation about z and a shift per sample
+    ang = torch.linspace(0.1, 0.6, B, device="cuda")
+    R = torch.zeros(B, 3, 3, device="cuda")
+    R[:, 0, 0] = R[:, 1, 1] = torch.cos(ang); R[:, 0, 1] = -torch.sin(ang); R[:, 1, 0] = torch.sin(ang); R[:, 2, 2] = 1
+    t = torch.full((B, 3), 0.05, device="cuda")
+    _, _, _ = ops.registration_loss(src, R, t, tar, ln)
+    first = ops.last_state()
+    moved = first.tri1t[..., :3].contiguous()
+    np.testing.assert_array_equal(moved.cpu().numpy(),
+                                  ops.rigid_apply(src[..., :3].contiguous(), R, t, transpose_r=True).cpu().numpy())
+    check(first, moved, tar[..., :3].contiguous())
+    # a second pose against the same target and lines: the target's records stay in `first`'s workspace
+    _, _, _ = ops.registration_loss(src, R.transpose(1, 2).contiguous(), -t, tar, ln, target_from=first)
+    second = ops.last_state()
+    assert second is not first and second.target_state is first
+    check(second, second.tri1t[..., :3].contiguous(), tar[..., :3].contiguous())
+
+
 # ---------------------------------------------------------------------------------- K6 + R
 def test_reconstruction_point(L):
     g = load_golden("reconstruction_point.npz")
