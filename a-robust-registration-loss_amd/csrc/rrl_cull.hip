@@ -535,7 +535,7 @@ struct WaveCtx {
     int na, nb, nc, ncand;        // wave-uniform fill levels
     int lane;
     // executed-work counters of the COUNT instantiation (wave-uniform; see rrl_scan_counters)
-    unsigned tb, tc, td, tcand;   // level-B / level-C sphere tests, exact point-0 tests, resolved candidates
+    unsigned tb, tc, td, tcand;   // level-B / level-C sphere tests, point-0 prefilter tests, resolved candidates
     int32_t *status;              // NaN flag of the call
 };
 
@@ -787,7 +787,7 @@ __device__ __attribute__((noinline)) void strict_slice(const float *ptri, const 
 // same-address atomics serialise at ~12 ns each and distort the kernel they measure), row index = linear
 // workgroup id x wavefronts per workgroup + wavefront; rows past the buffer's capacity are dropped:
 //   row[0] level-A sphere tests (line x supergroup)   [1] level-B (line x group)
-//           [2] level-C (line x half)                      [3] exact point-0 tests (line x record)
+//           [2] level-C (line x half)                      [3] point-0 prefilter tests (line x record)
 //           [4] candidates resolved (points 1, 2)          [5] wavefronts that ran
 //           [6] wavefronts that took the strict fallback   [7] (line, triangle) pairs of the fallback
 //           [8] start, [9] end of the wavefront on the 100 MHz wall clock (the kernel lasts as long as its

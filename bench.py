@@ -49,7 +49,7 @@ HBM_PEAK_GBS = 8000.0
 # arithmetic of one test of the culled scan, in lane-ops (an FMA counted once, like every VALU op):
 # sphere test = 3 sub + 3 (dot) + 3 (|a|^2) + 2 fma + add + mul = 12 (compares excluded); exact test = dist_sq's 16;
 # a resolved candidate = points 1 and 2; a fallback pair = 3 points
-OPS_SPHERE, OPS_EXACT, OPS_CAND, OPS_FALLBACK = 12, 16, 32, 48
+OPS_SPHERE, OPS_EXACT, OPS_CAND, OPS_FALLBACK = 12, 11, 48, 48  # level-D prefilter: 10 FMA-chain ops + sign; candidate: 3 exact points
 
 
 def csrc_sha():
@@ -330,9 +330,9 @@ def main():
             "work_ratio": dense_flops / exe,
             "dense_equivalent_tflops": dense_flops / (cull_ms * 1e-3) / 1e12,
             "counters_per_launch": {"sphere_tests_A": c[0], "sphere_tests_B": c[1], "sphere_tests_C": c[2],
-                                    "exact_point0_tests": c[3], "candidates_resolved": c[4], "wavefronts": c[5],
+                                    "point0_prefilter_tests": c[3], "candidates_resolved": c[4], "wavefronts": c[5],
                                     "fallback_wavefronts": c[6], "fallback_pairs": c[7]},
-            "ops_per_test": {"sphere": OPS_SPHERE, "exact": OPS_EXACT, "candidate": OPS_CAND,
+            "ops_per_test": {"sphere": OPS_SPHERE, "point0_prefilter": OPS_EXACT, "candidate": OPS_CAND,
                              "fallback_pair": OPS_FALLBACK},
             "note": "executed = arithmetic of the tests the kernel really ran, from in-kernel counters of this run "
                     "(rrl_scan_counters: one row per wavefront, plain stores; queue/ballot/bookkeeping instructions not counted: SQ_INSTS_VALU x 64 in "

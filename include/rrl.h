@@ -48,18 +48,20 @@ extern "C" {
                              lines (|dir|^2 <= 1+1e-6 and (|x0| + max|P|)^2 <= 100), else strict.
                              Same results AND same NaN detection as strict. */
 #define RRL_SCAN_CULL 3   /* default.  Triangles are sorted by grid cell (Hilbert order) under a three-
-                             level sphere tree; a line evaluates (lazily, exactly) only the halves of 8
-                             whose sphere it can reach, found by a conservative test that is valid at
-                             any finite data scale (DESIGN.md "culling bound"): labels, hit lists and
-                             the loss equal strict's bit for bit.  NaN detection equals strict's
+                             level sphere tree; a line looks only at the halves of 8 whose sphere it can
+                             reach, found by a conservative test that is valid at any finite data scale
+                             (DESIGN.md "culling bound"); there a conservative FMA prefilter on point 0
+                             picks the candidates (~3 %) and the reference's own arithmetic decides on
+                             all three points of those: labels, hit lists and the loss equal strict's
+                             bit for bit.  NaN detection equals strict's
                              wherever a NaN is provably impossible ((|x0| + max|P|)^2 < 111 and
                              |dir|^2 <= 1 + 1e-6: none exists) and for lines with |dir|^2 > 1 + 1e-6
                              or non-finite data (their wavefront of 128 lines runs the strict loop;
                              STATUS[1] counts such wavefronts).  For unit directions at larger scale
                              (the demo's full-diagonal radius) a negative sqrt argument is reported
-                             when it occurs in an EVALUATED pair: point 0 of every triangle that
-                             could produce one, points 1, 2 of triangles whose point 0 passes (as
-                             RRL_SCAN_LAZY).  Needs N, M <= 65536, else behaves like AUTO. */
+                             when it occurs in an exactly EVALUATED pair: the three points of every
+                             prefilter candidate, which include point 0 of every triangle that could
+                             produce one.  Needs N, M <= 65536, else behaves like AUTO. */
 
 /* workspace fields (indices into rrl_workspace_layout's offset array) */
 enum {
@@ -221,11 +223,11 @@ int rrl_scan_timing_collect(float *ms, int max_n);
  * uint64 (plain stores; row = linear workgroup id x wavefronts per workgroup + wavefront; rows >= `rows`
  * are dropped; the caller clears the buffer and adds the rows up):
  *   [0] level-A sphere tests (line x supergroup)   [1] level-B (line x group)   [2] level-C (line x half)
- *   [3] exact point-0 tests (line x record)        [4] point-0 passes resolved (points 1 and 2)
+ *   [3] point-0 prefilter tests (line x record)    [4] candidates resolved exactly (all 3 points)
  *   [5] 1 (the wavefront ran)                      [6] 1 if it took the strict fallback
  *   [7] (line, triangle) pairs evaluated by the fallback   [8], [9] its start / end on the 100 MHz wall clock.
  * NULL switches back to the plain kernel.  bench.py derives the executed flops of a launch from
- * these (12 per sphere test, 16 per exact test, 32 per resolved candidate, 48 per fallback pair). */
+ * these (12 per sphere test, 11 per prefilter test, 48 per resolved candidate, 48 per fallback pair). */
 int rrl_scan_counters(uint64_t *dev_counters, long long rows);
 
 /* Batch-shard payload: out[14] = { sum of valid losses, number of valid
