@@ -504,8 +504,12 @@ typedef const float __attribute__((address_space(4))) * kptr;  // constant AS ->
 typedef const int __attribute__((address_space(4))) * kiptr;
 
 #ifndef SPW
-#define SPW 8      // supergroups per slice (<= 8: 3-bit slot in a queue-A entry); staged once per workgroup
+#define SPW 8      // supergroups per slice (<= 16: SG_BITS); staged once per workgroup
 #endif
+#define SG_BITS 4              // queue entries: line << SG_BITS | supergroup of the slice,
+#define GP_BITS (SG_BITS + 2)  //                line << GP_BITS | group of the slice,
+#define HF_BITS (SG_BITS + 3)  //                line << HF_BITS | half of the slice (7 + 7 bits: 16-bit entries)
+static_assert(SPW <= (1 << SG_BITS), "slot bits of the queue entries");
 #ifndef WPB
 #define WPB 8      // wavefronts per workgroup: same slice, LPW lines each
 #endif
@@ -521,11 +525,10 @@ typedef const int __attribute__((address_space(4))) * kiptr;
 #define QC_CAP 192
 
 struct WaveCtx {
-    const float4 *la;             // this wave's lines in LDS: (dir, x0.x) and (x0.y, x0.z)
-    const float2 *lb;
+    const float2 *lr;             // this wave's lines in LDS as they lie in memory: 3 float2 per line (dir.xy | dir.z x0.x | x0.yz)
     const float4 *recs;           // LDS: staged records of the slice, [group][ROWS]
     const float4 *nodes;          // LDS: staged tree nodes of the slice, [supergroup][NODE]
-    unsigned short *qa, *qb, *qc; // LDS queues: line << 3 | sg, line << 5 | group, line << 6 | half (slice-local)
+    unsigned short *qa, *qb, *qc; // LDS queues: line << SG_BITS | sg, << GP_BITS | group, << HF_BITS | half (slice-local)
     unsigned *cands;              // LDS [WCCAP]
     const int32_t *idx;           // sorted position -> original triangle index
     const float *ptri;            // prepared triangles (original order)
@@ -539,13 +542,25 @@ struct WaveCtx {
     int32_t *status;              // NaN flag of the call
 };
 
+// line ll of the wave from its raw 24-byte row: (dir, x0.x) and (x0.y, x0.z)
+struct LineRow {
+    float4 la;
+    float2 lb;
+};
+__device__ __forceinline__ LineRow line_row(const float2 *lr, int ll) {
+    const float2 *p = lr + 3 * ll;
+    const float2 a = p[0], b = p[1], c = p[2];
+    return {make_float4(a.x, a.y, b.x, b.y), c};
+}
+
 // cand = line_in_wave << 16 | sorted triangle position: a triangle whose point 0 passed the conservative
 // prefilter of level D.  The reference's own arithmetic (dist_sq, bit-identical to the strict scan) decides
 // on all three points here.
 __device__ __forceinline__ void resolve_candidate(const WaveCtx &c, unsigned cand) {
     const int ll = cand >> 16, spos = cand & 0xffff;
-    const float4 la = c.la[ll];
-    const float2 lb = c.lb[ll];
+    const LineRow lrw = line_row(c.lr, ll);
+    const float4 la = lrw.la;
+    const float2 lb = lrw.lb;
     const int f = c.idx[spos];  // (staging the slice's indices in LDS measured 0.8 us slower)
     const float4 *q = (const float4 *)(c.ptri + PTRI_STRIDE * (size_t)f);
     const float4 r0 = q[0], r1 = q[1], r2 = q[2];  // P0 P1.x | P1.yz P2.xy | P2.z thr2 thr index
@@ -641,9 +656,10 @@ __device__ __forceinline__ void proc_c(WaveCtx &c, bool all) {
         unsigned lh = 0;  // line << 16 | first sorted position of the half
         if (c.lane < take) {
             const unsigned e = c.qc[base + c.lane];
-            const int ll = e >> 6, h = e & 63;
-            const float4 la = c.la[ll];
-            const float2 lb = c.lb[ll];
+            const int ll = e >> HF_BITS, h = e & ((1 << HF_BITS) - 1);
+            const LineRow lrw = line_row(c.lr, ll);
+            const float4 la = lrw.la;
+            const float2 lb = lrw.lb;
             const float4 *row = c.recs + (h >> 1) * ROWS + (h & 1) * 8;
 #pragma unroll
             for (int t = 7; t >= 0; --t) {  // record t ends up in bit t
@@ -692,13 +708,14 @@ __device__ __forceinline__ void proc_b(WaveCtx &c, bool all) {
             if (u == 1 && take <= 64) break;  // uniform
             if (c.lane + 64 * u < take) {
                 const unsigned e = c.qb[base + 64 * u + c.lane];
-                const int ll = e >> 5, g = e & 31;
-                const float4 la = c.la[ll];
-                const float2 lb = c.lb[ll];
+                const int ll = e >> GP_BITS, g = e & ((1 << GP_BITS) - 1);
+                const LineRow lrw = line_row(c.lr, ll);
+                const float4 la = lrw.la;
+                const float2 lb = lrw.lb;
                 const float4 *nd = c.nodes + (g >> 2) * NODE + 5 + 2 * (g & 3);
                 p[u][0] = sphere_pass(nd[0], la, lb);
                 p[u][1] = sphere_pass(nd[1], la, lb);
-                e2[u] = ((unsigned)ll << 6) | (unsigned)(2 * g);
+                e2[u] = ((unsigned)ll << HF_BITS) | (unsigned)(2 * g);
             }
         }
 #pragma unroll
@@ -732,13 +749,14 @@ __device__ __forceinline__ void proc_a(WaveCtx &c, bool all) {
         unsigned e2 = 0;
         if (c.lane < take) {
             const unsigned e = c.qa[base + c.lane];
-            const int ll = e >> 3, sg = e & 7;
-            const float4 la = c.la[ll];
-            const float2 lb = c.lb[ll];
+            const int ll = e >> SG_BITS, sg = e & ((1 << SG_BITS) - 1);
+            const LineRow lrw = line_row(c.lr, ll);
+            const float4 la = lrw.la;
+            const float2 lb = lrw.lb;
             const float4 *nd = c.nodes + sg * NODE + 1;
 #pragma unroll
             for (int k = 0; k < SGG; ++k) p[k] = sphere_pass(nd[k], la, lb);
-            e2 = ((unsigned)ll << 5) | (unsigned)(SGG * sg);
+            e2 = ((unsigned)ll << GP_BITS) | (unsigned)(SGG * sg);
         }
 #pragma unroll
         for (int k = 0; k < SGG; ++k) {
@@ -799,9 +817,8 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(6, 8))
     const float4 *__restrict__ tree1, const float4 *__restrict__ tree2, const float *__restrict__ line,
     int32_t *__restrict__ count1, int32_t *__restrict__ hit1, int32_t *__restrict__ count2,
     int32_t *__restrict__ hit2, int32_t *__restrict__ status, const uint32_t *__restrict__ pmax, int B,
-    int N, int M, int L, int spw, int nrep, unsigned long long *__restrict__ counters, long long counter_rows) {
-    __shared__ __attribute__((aligned(16))) float4 la_lds[WPB][LPW];          // 16 KiB
-    __shared__ __attribute__((aligned(16))) float2 lb_lds[WPB][LPW];          //  8 KiB
+    int N, int M, int L, int spw, unsigned long long *__restrict__ counters, long long counter_rows) {
+    __shared__ __attribute__((aligned(16))) float2 line_lds[WPB][LPW * 3];    // 24 KiB: raw 24-byte line rows
     __shared__ __attribute__((aligned(16))) float4 rec_lds[SPW * SGG * ROWS]; //  8.5 KiB
     __shared__ __attribute__((aligned(16))) float4 node_lds[SPW * NODE];      //  1.6 KiB
     __shared__ unsigned short qa_lds[WPB][QA_CAP], qb_lds[WPB][QB_CAP], qc_lds[WPB][QC_CAP];
@@ -822,28 +839,54 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(6, 8))
     const int z = blockIdx.x, cloud = z >= B ? 1 : 0, b = z - cloud * B;
     const int n = cloud ? M : N;
     const int nsg = (n + SGT - 1) / SGT;
-    if ((int)blockIdx.z * nrep * spw >= nsg) return;  // uniform: the smaller cloud has fewer slices
+    const int sg0 = (int)blockIdx.z * spw;
+    if (sg0 >= nsg) return;  // uniform: the smaller cloud has fewer slices
+    const int nsl = min(spw, nsg - sg0);
     const float4 *p0s = (cloud ? p0s2 : p0s1) + (size_t)b * nsg * SGT;
     const float4 *tree = (cloud ? tree2 : tree1) + (size_t)b * nsg * NODE;
 
-    // ---- this wave's lines (staged once; the workgroup then walks `nrep` slices of the cloud one after
-    //      the other: fewer, longer-lived wavefronts -- see rrl_launch_cull_scan)
+    // ---- the slice's records and nodes: with one record per lane (the usual 8-wavefront workgroup) the
+    //      loads are issued FIRST and stay in flight while the lines arrive and their slack is reduced
+    constexpr int RPT = (SPW * SGT + 64 * WPB - 1) / (64 * WPB);  // records per lane of a full workgroup
+    static_assert(SPW * NODE <= 64 * WPB, "one node per lane");
+    const bool one_each = (int)blockDim.x == 64 * WPB;
+    float4 rec0[RPT], nd0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (one_each) {
+#pragma unroll
+        for (int k = 0; k < RPT; ++k)
+            if (tid + 64 * WPB * k < nsl * SGT) rec0[k] = p0s[(size_t)sg0 * SGT + tid + 64 * WPB * k];
+        if (tid < nsl * NODE) nd0 = tree[(size_t)sg0 * NODE + tid];
+    }
+
+    // ---- this wave's 128 lines: a full, 16-byte aligned tile arrives as three coalesced 16-byte loads per
+    //      lane straight into its LDS rows (12 strided 4-byte loads per lane before); the lanes then pick up
+    //      their own two lines from there
     const float *ln = line + (size_t)b * L * 6;
     const int lw0 = ((int)blockIdx.y * (int)(blockDim.x >> 6) + wave) * LPW;
     const int l0 = lw0 + lane, l1 = l0 + 64;
     const bool live0 = l0 < L, live1 = l1 < L;
-    float v0[6], v1[6];
-#pragma unroll
-    for (int c = 0; c < 6; ++c) {
-        v0[c] = live0 ? ln[6 * (size_t)l0 + c] : 0.0f;
-        v1[c] = live1 ? ln[6 * (size_t)l1 + c] : 0.0f;
+    const bool has_lines = lw0 < L;  // a wave without lines (the last tile of the line set) still stages records
+    float2 *lr = line_lds[wave];
+    if (has_lines) {
+        const float *lsrc = ln + (size_t)lw0 * 6;
+        if (lw0 + LPW <= L && (((uintptr_t)lsrc) & 15) == 0) {  // uniform
+            const float4 *s4 = (const float4 *)lsrc;
+            float4 *d4 = (float4 *)lr;
+            const float4 t0 = s4[lane], t1 = s4[64 + lane], t2 = s4[128 + lane];
+            d4[lane] = t0; d4[64 + lane] = t1; d4[128 + lane] = t2;
+        } else {  // ragged tail / odd alignment: 8-byte pieces (a row is 24 bytes), zeros past the end
+            const float2 *s2 = (const float2 *)lsrc;
+            const int nf2 = (L - lw0) * 3;
+            for (int i = lane; i < LPW * 3; i += 64) lr[i] = i < nf2 ? s2[i] : make_float2(0.0f, 0.0f);
+        }
     }
-    la_lds[wave][lane] = make_float4(v0[0], v0[1], v0[2], v0[3]);
-    lb_lds[wave][lane] = make_float2(v0[4], v0[5]);
-    la_lds[wave][64 + lane] = make_float4(v1[0], v1[1], v1[2], v1[3]);
-    lb_lds[wave][64 + lane] = make_float2(v1[4], v1[5]);
-    // a wave without lines (the last tile of the line set) still stages its share of every slice
-    const bool has_lines = lw0 < L;
+    wave_lds_fence();
+    float v0[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}, v1[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    if (has_lines) {
+        const LineRow r0 = line_row(lr, lane), r1 = line_row(lr, 64 + lane);
+        v0[0] = r0.la.x; v0[1] = r0.la.y; v0[2] = r0.la.z; v0[3] = r0.la.w; v0[4] = r0.lb.x; v0[5] = r0.lb.y;
+        v1[0] = r1.la.x; v1[1] = r1.la.y; v1[2] = r1.la.z; v1[3] = r1.la.w; v1[4] = r1.lb.x; v1[5] = r1.lb.y;
+    }
 
     const int32_t *idx = (cloud ? idx2 : idx1) + (size_t)b * nsg * SGT;
     const float *ptri = (cloud ? ptri2 : ptri1) + (size_t)b * n * PTRI_STRIDE;
@@ -852,7 +895,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(6, 8))
 
     // Culling (and the lazy evaluation of points 1, 2) is only exact for lines with |dir|^2 <= 1 + 1e-6 and
     // finite data (cull_line_slack).  A wavefront with an offending line evaluates ALL pairs of its
-    // lines with the slices' triangles strictly instead -- the reference's semantics, NaN included.
+    // lines with the slice's triangles strictly instead -- the reference's semantics, NaN included.
     const float pm = __uint_as_float(pmax[cloud * B + b]);
     const LineSlack ls0 = cull_line_slack(v0, pm), ls1 = cull_line_slack(v1, pm);
     const bool fallback = !__all(ls0.ok && ls1.ok);
@@ -872,9 +915,36 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(6, 8))
     // point-0 prefilter (header): 44.2 u A^2 of evaluation error on both sides, rounded up, + an absolute floor
     const float s0 = 3.0e-6f * __uint_as_float(wg_slack[1]) + 1.0e-9f;
 
+    // ---- stage the slice: records (padded rows) and tree nodes, slacks folded in
+    //   (P0, thr2) -> (P0, c): c = -(thr2 - 2e-4 + slack), slightly widened; pad records never pass
+    //   (centre, Rs) -> (centre, (Rs + se)^2 rounded up); NaN (empty node) stays NaN
+    auto stage_rec = [&](int i, float4 r) {
+        const float tp = r.w - RRL_EPS;
+        r.w = sg0 * SGT + i < n ? -(tp + 1.0e-6f * fabsf(tp) + s0) : INFINITY;
+        rec_lds[(i >> 4) * ROWS + (i & 15)] = r;
+    };
+    auto stage_node = [&](int i, float4 nd) {
+        const float rt = nd.w + se;
+        nd.w = rt * rt * 1.0000003f;
+        node_lds[i] = nd;
+    };
+    if (one_each) {
+#pragma unroll
+        for (int k = 0; k < RPT; ++k)
+            if (tid + 64 * WPB * k < nsl * SGT) stage_rec(tid + 64 * WPB * k, rec0[k]);
+        if (tid < nsl * NODE) stage_node(tid, nd0);
+    } else {
+        for (int i = tid; i < nsl * SGT; i += blockDim.x) stage_rec(i, p0s[(size_t)sg0 * SGT + i]);
+        for (int i = tid; i < nsl * NODE; i += blockDim.x) stage_node(i, tree[(size_t)sg0 * NODE + i]);
+    }
+    __syncthreads();
+#ifdef CULL_STOP_STAGE
+    return;
+#endif
+    if (!has_lines) return;  // uniform per wavefront
+
     WaveCtx ctx;
-    ctx.la = la_lds[wave];
-    ctx.lb = lb_lds[wave];
+    ctx.lr = lr;
     ctx.recs = rec_lds;
     ctx.nodes = node_lds;
     ctx.qa = qa_lds[wave];
@@ -890,61 +960,34 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(6, 8))
     ctx.lane = lane;
     ctx.tb = ctx.tc = ctx.td = ctx.tcand = 0;
     ctx.status = status;
+    ctx.pos0 = sg0 * SGT;
     const v2f ux = {v0[0], v1[0]}, uy = {v0[1], v1[1]}, uz = {v0[2], v1[2]};
     const v2f ox = {v0[3], v1[3]}, oy = {v0[4], v1[4]}, oz = {v0[5], v1[5]};
     unsigned long long ta = 0;
 
-    for (int rep = 0; rep < nrep; ++rep) {
-    const int sg0 = ((int)blockIdx.z * nrep + rep) * spw;
-    if (sg0 >= nsg) break;  // uniform
-    const int nsl = min(spw, nsg - sg0);
-    // ---- stage the slice: records (padded rows) and tree nodes
-    if (rep > 0) __syncthreads();  // every wavefront is done with the previous slice
-    for (int i = tid; i < nsl * SGT; i += blockDim.x) {
-        float4 r = p0s[(size_t)sg0 * SGT + i];
-        // (P0, thr2) -> (P0, c): c = -(thr2 - 2e-4 + slack), slightly widened; pad records never pass
-        const float tp = r.w - RRL_EPS;
-        r.w = sg0 * SGT + i < n ? -(tp + 1.0e-6f * fabsf(tp) + s0) : INFINITY;
-        rec_lds[(i >> 4) * ROWS + (i & 15)] = r;
-    }
-    for (int i = tid; i < nsl * NODE; i += blockDim.x) {
-        float4 nd = tree[(size_t)sg0 * NODE + i];
-        const float rt = nd.w + se;  // (centre, Rs) -> (centre, (Rs + se)^2 rounded up); NaN (empty) stays NaN
-        nd.w = rt * rt * 1.0000003f;
-        node_lds[i] = nd;
-    }
-    __syncthreads();
-#ifdef CULL_STOP_STAGE
-    continue;
-#endif
-    if (!has_lines) continue;  // uniform per wavefront
     if (fallback) {  // rare: kept out of line so that its registers do not count against the culled walk
-        const int s0 = sg0 * SGT, s1 = min(n, s0 + nsl * SGT);  // real records sit at sorted positions [0, n)
-        strict_slice(ptri, idx, s0, s1, ux, uy, uz, ox, oy, oz, l0, l1, L, cnt, hit, status);
-        if (lane == 0 && rep == 0) atomicAdd(&status[1], 1);  // always on: wavefronts that left the culled path
-        fb_pairs += (unsigned long long)(s1 - s0) * (unsigned long long)min(LPW, L - lw0);
-        continue;
-    }
-    ctx.pos0 = sg0 * SGT;
-    ta += (unsigned long long)nsl * (unsigned long long)min(LPW, L - lw0);
+        const int f0 = sg0 * SGT, f1 = min(n, f0 + nsl * SGT);  // real records sit at sorted positions [0, n)
+        strict_slice(ptri, idx, f0, f1, ux, uy, uz, ox, oy, oz, l0, l1, L, cnt, hit, status);
+        if (lane == 0) atomicAdd(&status[1], 1);  // always on: wavefronts that left the culled path
+        fb_pairs = (unsigned long long)(f1 - f0) * (unsigned long long)min(LPW, L - lw0);
+    } else {
+    ta = (unsigned long long)nsl * (unsigned long long)min(LPW, L - lw0);
 
     // ---- level A: conservative sphere test of every supergroup of the slice against the lane's
     //      two lines (packed fp32, wave-uniform sphere through the scalar cache)
     kptr gp = (kptr)(uintptr_t)(tree + (size_t)sg0 * NODE);
-    // all SPW supergroup spheres are requested up front (one scalar-load latency instead of one per
-    // iteration: the loop body is ~25 instructions); slots past the slice re-read its last node
-    float sgs[SPW][4];
+    // the next supergroup's sphere is requested (scalar loads) before the current one is processed: one
+    // scalar-load latency up front instead of one per iteration (the loop body is ~25 instructions)
+    float cur[4], nxt[4];
 #pragma unroll
-    for (int s = 0; s < SPW; ++s) {
-        const int sc = s < nsl ? s : nsl - 1;
+    for (int c = 0; c < 4; ++c) cur[c] = gp[c];
+#pragma unroll 1
+    for (int s = 0; s < nsl; ++s) {
+        const int sn = s + 1 < nsl ? s + 1 : s;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) sgs[s][c] = gp[4 * NODE * sc + c];
-    }
-#pragma unroll
-    for (int s = 0; s < SPW; ++s) {
-        if (s >= nsl) break;  // uniform
-        const float cx = sgs[s][0], cy = sgs[s][1], cz = sgs[s][2];
-        const float Rt = sgs[s][3] + se, R2 = Rt * Rt;  // NaN (empty node) fails both comparisons
+        for (int c = 0; c < 4; ++c) nxt[c] = gp[4 * NODE * sn + c];
+        const float cx = cur[0], cy = cur[1], cz = cur[2];
+        const float Rt = cur[3] + se, R2 = Rt * Rt;  // NaN (empty node) fails both comparisons
         const v2f ax = cx - ox, ay = cy - oy, az = cz - oz;
         const v2f dot = __builtin_elementwise_fma(az, uz, __builtin_elementwise_fma(ay, uy, ax * ux));
         const v2f q = __builtin_elementwise_fma(az, az, __builtin_elementwise_fma(ay, ay, ax * ax));
@@ -955,16 +998,18 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(6, 8))
         if (m0 | m1) {
             if (ctx.na > QA_CAP - 128) proc_a<COUNT>(ctx, false);
             const int c0 = __popcll(m0);
-            if (pass0) ctx.qa[ctx.na + lane_rank(m0)] = (unsigned short)((lane << 3) | s);
-            if (pass1) ctx.qa[ctx.na + c0 + lane_rank(m1)] = (unsigned short)(((64 + lane) << 3) | s);
+            if (pass0) ctx.qa[ctx.na + lane_rank(m0)] = (unsigned short)((lane << SG_BITS) | s);
+            if (pass1) ctx.qa[ctx.na + c0 + lane_rank(m1)] = (unsigned short)(((64 + lane) << SG_BITS) | s);
             ctx.na += c0 + __popcll(m1);
         }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) cur[c] = nxt[c];
     }
     proc_a<COUNT>(ctx, true);
     proc_b<COUNT>(ctx, true);
     proc_c<COUNT>(ctx, true);
     flush_cands<COUNT>(ctx);
-    }  // slices of this workgroup
+    }
     if constexpr (COUNT) {
         if (lane == 0 && crow && has_lines) {
             crow[0] = ta;
@@ -1090,16 +1135,10 @@ int rrl_launch_cull_scan(const float *line, void *ws, const WsLayout &w, int B, 
         if (sscanf(e, "%d,%d", &w_, &s_) == 2 && w_ >= 1 && w_ <= WPB && s_ >= 1 && s_ <= SPW) { waves = w_ < lw ? w_ : lw; spw = s_; }
     }
     const int tiles = (lw + waves - 1) / waves, slices = (nsgmax + spw - 1) / spw;
-    // A workgroup can walk `nrep` consecutive slices of its cloud (its lines staged once): fewer, longer-lived
-    // wavefronts, all resident at once.
-    // MEASURED AND NOT ADOPTED (nrep stays 1; RRL_CULL_NREP=n for experiments): at C2 the 10112 wavefronts
-    // run as one full round of 6144 + a second of 3968 (mean lifetime 15.3 us, last end 37.8 us); with
-    // nrep = 2 all 5056 wavefronts are resident from the start, but each lives 27.3 us and the kernel
-    // takes 40.2 us (nrep = 3: 43.9, 4: 58.8) -- the CU is throughput-bound on this instruction mix, not
-    // waiting for wavefronts to arrive (profiles/r02b_scan_tail.txt).
-    int nrep = 1;
-    if (const char *e = getenv("RRL_CULL_NREP")) { const int v = atoi(e); if (v >= 1 && v <= 64) nrep = v; }
-    const int zslices = (slices + nrep - 1) / nrep;
+    // (Letting a workgroup walk 2 / 3 / 4 consecutive slices with its lines staged once -- fewer, longer-lived
+    // wavefronts, all resident from the start -- was measured and dropped: 40.2 / 43.9 / 58.8 us against 37.8,
+    // profiles/r02b_scan_tail.txt.)
+    const int zslices = slices;
 #define RRL_CULL_LAUNCH(COUNT)                                                                              \
     hipLaunchKernelGGL(cull_scan_kernel<COUNT>, dim3((unsigned)(clouds * B), (unsigned)tiles, (unsigned)zslices),   \
                        dim3(64 * waves), 0, s, w.f32(ws, RRL_WS_PTRI1), w.f32(ws, RRL_WS_PTRI2),             \
@@ -1107,7 +1146,7 @@ int rrl_launch_cull_scan(const float *line, void *ws, const WsLayout &w, int B, 
                        w.i32(ws, RRL_WS_IDX1), w.i32(ws, RRL_WS_IDX2), (const float4 *)w.f32(ws, RRL_WS_GRP1), \
                        (const float4 *)w.f32(ws, RRL_WS_GRP2), line, w.i32(ws, RRL_WS_COUNT1),               \
                        w.i32(ws, RRL_WS_HIT1), w.i32(ws, RRL_WS_COUNT2), w.i32(ws, RRL_WS_HIT2),             \
-                       w.i32(ws, RRL_WS_STATUS), (const uint32_t *)w.i32(ws, RRL_WS_PMAX), B, N, M, L, spw, nrep, \
+                       w.i32(ws, RRL_WS_STATUS), (const uint32_t *)w.i32(ws, RRL_WS_PMAX), B, N, M, L, spw, \
                        g_cull_counters, g_cull_counter_rows)
     if (g_cull_counters) RRL_CULL_LAUNCH(true);
     else RRL_CULL_LAUNCH(false);
