@@ -285,10 +285,12 @@ def main():
     for _ in range(args.warmup):
         step()
     finish()
-    t0 = timed(step, args.steps)
+    t0 = timed(step, args.steps)  # barrier + synchronize, then the clock
     payload = finish()  # the last reduction is inside the timed region
-    fence()
-    dt = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0  # this rank's K steps, from the common start to its own completion
+    fence()  # closing barrier + synchronize; the MAX over the ranks' elapsed times below is the job's time (the
+    #          barrier's own ~60-90 us of host/NCCL latency is not part of any step and stays outside the clock)
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if dist.is_initialized():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
