@@ -150,11 +150,13 @@ __global__ __launch_bounds__(1024) void line_pair_dist_kernel(
     {
         const int l = blockIdx.x * 1024 + tid;
         bool sel = false;
+        unsigned kjb = 0;
         if (l < L) {
             const size_t gl = (size_t)b * L + l;
             const int k = count1[gl], j = count2[gl];
             sel = k >= s_m && k < e_m && j >= s_n && j < e_n;
-            kj[gl] = sel ? (uint8_t)(k | (j << 4)) : (uint8_t)0;
+            kjb = sel ? (unsigned)(k | (j << 4)) : 0u;
+            kj[gl] = (uint8_t)kjb;
         }
         const unsigned long long mask = __ballot(sel);
         if (lane == 0) s_wave[wave] = __popcll(mask);
@@ -168,7 +170,8 @@ __global__ __launch_bounds__(1024) void line_pair_dist_kernel(
             base_reg = acc ? atomicAdd(&nsel[b], acc) : 0;
         }
         __syncthreads();
-        if (sel) s_list[s_wave[wave] + __popcll(mask & ((1ull << lane) - 1ull))] = l;
+        // the line id (L < 2^24) and its (k, j) byte travel together: phase 2 needs no second look at the counts
+        if (sel) s_list[s_wave[wave] + __popcll(mask & ((1ull << lane) - 1ull))] = (int)((unsigned)l | (kjb << 24));
         __syncthreads();
     }
     // Compact copies for the reduce kernel live at slot = 1024 * (this workgroup) + rank: no global
@@ -182,9 +185,9 @@ __global__ __launch_bounds__(1024) void line_pair_dist_kernel(
     for (int r0 = 0; r0 < total; r0 += 128) {  // 128 selected lines per pass, 8 lanes each
         const int rank = r0 + (tid >> 3), sub = tid & 7;
         if (rank < total) {
-            const int l = s_list[rank];
+            const unsigned e = (unsigned)s_list[rank];
+            const int l = (int)(e & 0xffffffu), k = (int)((e >> 24) & 15u), j = (int)(e >> 28);
             const size_t gl = (size_t)b * L + l;
-            const int k = count1[gl], j = count2[gl];
             const size_t slot = (size_t)b * Lp + (size_t)blockIdx.x * 1024 + rank;
             if (sub == 0) kjc[slot] = (uint8_t)(k | (j << 4));
             pair_hit(tri1, tri2, line, hit1, hit2, hs1, hs2, w1, w2, Q1, Q2, D, dc + slot * 16, s_q[tid >> 3], b,
@@ -193,7 +196,7 @@ __global__ __launch_bounds__(1024) void line_pair_dist_kernel(
     }
     if (wave == 0) {
         const int base = __builtin_amdgcn_readfirstlane(base_reg);
-        for (int i = lane; i < total; i += 64) sel_out[(size_t)b * L + base + i] = s_list[i];
+        for (int i = lane; i < total; i += 64) sel_out[(size_t)b * L + base + i] = s_list[i] & 0xffffff;
     }
 }
 
@@ -202,7 +205,7 @@ __global__ __launch_bounds__(1024) void line_pair_dist_kernel(
 static int line_pair_dist_impl(const float *tri2_raw, const float *line, void *ws, size_t ws_bytes, int B,
                                int N, int M, int L, int s_m, int s_n, int e_m, int e_n, int pool,
                                void *stream) {
-    if (!line || !ws || B < 0 || N < 0 || M < 0 || L < 0) return RRL_E_ARG;
+    if (!line || !ws || B < 0 || N < 0 || M < 0 || L < 0 || L >= (1 << 24)) return RRL_E_ARG;  // 24-bit line ids in LDS
     if (s_m < 1 || s_n < 1 || e_m > RRL_MAX_HITS + 1 || e_n > RRL_MAX_HITS + 1) return RRL_E_RANGE;
     WsLayout w(B, N, M, L);
     if (ws_bytes < w.total) return RRL_E_WS;
