@@ -426,6 +426,21 @@ def scan_counters(on, rows=1 << 17, raw=False):
     return prev if raw else prev.sum(0)
 
 
+_cham_counter_buf = None
+
+
+def chamfer_counters(on, raw=False):
+    """Like scan_counters, for the tree Chamfer (include/rrl.h rrl_chamfer_counters): one 16-slot row per
+    wavefront of the walk (plain stores), summed here (raw=True: the table of rows)."""
+    global _cham_counter_buf
+    prev = _cham_counter_buf
+    _cham_counter_buf = torch.zeros(16 * 8 * 2 * 32768, dtype=torch.int64, device=require_gpu()) if on else None
+    check(_lib.load().rrl_chamfer_counters(_p(_cham_counter_buf)), "rrl_chamfer_counters")
+    if prev is None:
+        return None
+    return prev.reshape(-1, 16) if raw else prev.reshape(-1, 16).sum(0)
+
+
 # ---------------------------------------------------------------------------------------
 class _RigidApply(torch.autograd.Function):
     @staticmethod
