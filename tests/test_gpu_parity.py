@@ -615,6 +615,26 @@ def test_chamfer_tree_equals_brute_force(L, oracle, B, N, M, kind):
         assert np.all((tx & np.uint64(0xffffffff)) == 0)
 
 
+def test_chamfer_counters(L):
+    """rrl_chamfer_counters: the instrumented walk writes one row per wavefront; same value as the plain one."""
+    from rrl_hip import ops, synth
+    prs = [synth.make_pair(90 + b, 1000, 700) for b in range(2)]
+    x, y = cu(np.stack([p["src"] for p in prs])), cu(np.stack([p["tar"] for p in prs]))
+    plain = float(ops.chamfer(x, y))
+    ops.chamfer_counters(True)
+    try:
+        counted = float(ops.chamfer(x, y))
+        torch.cuda.synchronize()
+    finally:
+        c = ops.chamfer_counters(False)
+    assert counted == plain and ops.chamfer_counters(False) is None
+    c = c.cpu().numpy()
+    nsg = (1000 + 63) // 64 + (700 + 63) // 64        # query patches of both directions, per sample
+    assert c[4] == 2 * nsg * 8                           # 8 wavefronts per patch
+    assert 0 < c[3] <= 2 * 2 * 1000 * 700                # (query, target) pairs evaluated <= dense, both directions
+    assert float(ops.chamfer(x, y)) == plain
+
+
 def test_chamfer_nan_propagates(L):
     """torch.min propagates NaN: a NaN coordinate in a target cloud makes every minimum of that sample
     (and the batch mean) NaN, a NaN query only its own (code/loss.py:236-252 with torch semantics)."""
