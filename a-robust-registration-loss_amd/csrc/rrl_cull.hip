@@ -115,6 +115,7 @@ struct BuildArgs {
     uint4 *z2;                     // global cell histogram / cursors of the wide sort (may be NULL)
     size_t z2_vec4;
     int B, N, M, transpose_r, nblk;
+    int nchunk;                    // tri_sort_kernel: chunks of 4096 records per cloud (1: the whole cloud)
 };
 
 #define REC_BLK 256
@@ -207,14 +208,23 @@ __global__ __launch_bounds__(1024) void tri_sort_kernel(const BuildArgs a) {
     __shared__ unsigned wsum[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int B = a.B;
-    const int cloud = blockIdx.x >= (unsigned)B ? 1 : 0, b = blockIdx.x - cloud * B;
-    const int n = cloud ? a.M : a.N;
-    const int ng = (n + GRP - 1) / GRP;
+    // CHUNKED clouds (a.nchunk > 1, clouds of more than 4096 records): a workgroup sorts ONE chunk of 4096
+    // consecutive records (by original index) on its own grid and builds its 64 supergroups; the sorted cloud
+    // is the concatenation of its chunks (all but the last are full, so the real records still occupy the
+    // sorted positions [0, n)).  Any grouping of the records gives the same labels (rrl_launch_tri_build).
+    const int nch = RAW ? 1 : (a.nchunk > 1 ? a.nchunk : 1);
+    const int chunk = (int)blockIdx.x % nch, cb = (int)blockIdx.x / nch;
+    const int cloud = cb >= B ? 1 : 0, b = cb - cloud * B;
+    const int nfull = cloud ? a.M : a.N;                 // records of the whole cloud
+    const int base0 = chunk * (1024 * NPT);              // first record of the chunk (multiple of 64)
+    if (base0 >= nfull) return;                          // uniform: the smaller cloud has fewer chunks
+    const int n = min(1024 * NPT, nfull - base0);        // records of this chunk
+    const int ngf = (nfull + GRP - 1) / GRP, nsgf = (nfull + SGT - 1) / SGT;
     const int nsg = (n + SGT - 1) / SGT, ngp = nsg * SGG, npad = nsg * SGT;
-    const float4 *crec = (cloud ? a.crec2 : a.crec1) + (size_t)b * ng * GRP;
-    float4 *p0s = (cloud ? a.p0s2 : a.p0s1) + (size_t)b * npad;
-    int32_t *idx = (cloud ? a.idx2 : a.idx1) + (size_t)b * npad;
-    float4 *tree = (cloud ? a.grp2 : a.grp1) + (size_t)b * nsg * NODE;
+    const float4 *crec = (cloud ? a.crec2 : a.crec1) + (size_t)b * ngf * GRP + base0;
+    float4 *p0s = (cloud ? a.p0s2 : a.p0s1) + (size_t)b * nsgf * SGT + base0;
+    int32_t *idx = (cloud ? a.idx2 : a.idx1) + (size_t)b * nsgf * SGT + base0;
+    float4 *tree = (cloud ? a.grp2 : a.grp1) + ((size_t)b * nsgf + base0 / SGT) * NODE;
     int *sidx = (int *)(srec + (size_t)ngp * 17);
     auto pad = [](int s) { return s + (s >> 4); };
 
@@ -293,7 +303,7 @@ __global__ __launch_bounds__(1024) void tri_sort_kernel(const BuildArgs a) {
         // every row of 16 lanes reduces the <= 16 per-workgroup partials itself (DPP): no LDS round
         // trip and no barrier for the AABB
         const int nb = (n + REC_BLK - 1) / REC_BLK;  // <= 16 for n <= 4096
-        const float *ap = a.apart + ((size_t)cloud * B + b) * a.nblk * 8;
+        const float *ap = a.apart + (((size_t)cloud * B + b) * a.nblk + base0 / REC_BLK) * 8;
         // lanes 0..15 of each wavefront load one 32-byte partial row each (two 16-byte loads: the
         // kernel is bound by its single CU's memory pipe), reduce across the row, broadcast
         float4 p0 = make_float4(INFINITY, INFINITY, INFINITY, -INFINITY), p1 = make_float4(-INFINITY, -INFINITY, 0.0f, 0.0f);
@@ -310,7 +320,10 @@ __global__ __launch_bounds__(1024) void tri_sort_kernel(const BuildArgs a) {
 #if defined(SORT_STOP) && SORT_STOP == 1  // timing experiments only
     return;
 #endif
-    if (tid == 0) a.pmax[cloud * B + b] = __float_as_uint(bb[6]);
+    if (tid == 0) {
+        if (nch > 1) atomicMax(&a.pmax[cloud * B + b], __float_as_uint(bb[6]));  // non-negative floats; PMAX is cleared per call
+        else a.pmax[cloud * B + b] = __float_as_uint(bb[6]);
+    }
     float mn[3], scale[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -362,7 +375,7 @@ __global__ __launch_bounds__(1024) void tri_sort_kernel(const BuildArgs a) {
         if (f < n) {
             const int s = (int)atomicAdd(&hist[cell[k]], 1u);
             srec[pad(s)] = rec[k];
-            sidx[s] = f;
+            sidx[s] = base0 + f;
         }
     }
     for (int s = n + tid; s < npad; s += 1024) {  // pad: thr2 = 0 never passes
@@ -386,8 +399,10 @@ __global__ __launch_bounds__(1024) void tri_sort_kernel(const BuildArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------
-// Large clouds (n > 4096): the same sort in three WIDE launches -- one workgroup per cloud is
-// bound by a single CU (48 us for 16384 triangles), and a launch boundary costs ~3 us:
+// Large clouds (n > 4096), WHOLE-CLOUD order: the same sort in three WIDE launches -- one workgroup per
+// cloud is bound by a single CU (48 us for 16384 triangles), and a launch boundary costs ~3 us.  The loss
+// build uses the chunked single-launch sort instead (rrl_launch_tri_build); these kernels serve the Chamfer
+// path (nearest neighbours want whole-cloud groups) and RRL_SORT_WIDE=1:
 //   big_hist_kernel     cell of every triangle -> global histogram (atomics), max |P|^2
 //   big_scatter_kernel  every workgroup scans the 4096 bins itself (16 KiB), then places its
 //                       triangles at cell base + a global per-cell cursor (atomic)
@@ -1037,7 +1052,17 @@ int rrl_launch_tri_build(const float *tri1, const float *tri2, void *ws, const W
                          int N, int M, int clouds, const RrlXform *xf, hipStream_t s) {
     const int nmax = clouds == 2 && M > N ? M : N;
     const size_t ngpmax = (size_t)(nmax + SGT - 1) / SGT * SGG;  // groups, padded to whole supergroups
-    const size_t lds = nmax <= 4096 ? ngpmax * (17 * sizeof(float4) + GRP * sizeof(int)) : 16;
+    // Clouds of more than 4096 triangles: ONE launch of the single-workgroup sort per chunk of 4096 records
+    // (by original index) instead of the wide three-launch sort of the whole cloud (hist, scatter, spheres:
+    // ~19 us at N = 16384 against 9).  The chunks are interleaved subsets of the surface, each sorted on its
+    // own 16^3 grid; measured faster at every shape tried (C5 54.4 -> 44.1 us, C5 at B = 8 102 -> 62.5,
+    // B = 8 / N = 16384 / L = 10000 171 -> 140, N = 65536 / L = 512 77.5 -> 41.8: the whole-cloud grid holds
+    // ~27 triangles per cell at N = 16384, in arbitrary order, so its groups are no tighter).
+    // RRL_SORT_WIDE=1 keeps the wide sort (experiments / tests; it still serves the Chamfer path).
+    const char *wide_env = getenv("RRL_SORT_WIDE");
+    const bool chunked = nmax > 4096 && !(wide_env && atoi(wide_env) != 0);
+    const size_t ngps = nmax <= 4096 ? ngpmax : (size_t)(4096 / GRP);
+    const size_t lds = nmax <= 4096 || chunked ? ngps * (17 * sizeof(float4) + GRP * sizeof(int)) : 16;
     BuildArgs a;
     a.tri1 = xf ? xf->src : tri1;
     a.tri2 = tri2;
@@ -1066,10 +1091,11 @@ int rrl_launch_tri_build(const float *tri1, const float *tri2, void *ws, const W
     a.transpose_r = xf ? xf->transpose_r : 0;
     const int nall = N > M ? N : M;  // APART is laid out for the larger cloud
     a.nblk = (nall + REC_BLK - 1) / REC_BLK;
+    a.nchunk = chunked ? (nmax + 4095) / 4096 : 1;
     hipLaunchKernelGGL(tri_records_kernel, dim3((unsigned)((nmax + REC_BLK - 1) / REC_BLK), (unsigned)B, (unsigned)clouds),
                        dim3(REC_BLK), 0, s, a);
-    if (nmax <= 4096) {
-        hipLaunchKernelGGL((tri_sort_kernel<4, false>), dim3((unsigned)(clouds * B)), dim3(1024), lds, s, a);
+    if (nmax <= 4096 || chunked) {
+        hipLaunchKernelGGL((tri_sort_kernel<4, false>), dim3((unsigned)(clouds * B * a.nchunk)), dim3(1024), lds, s, a);
     } else {  // wide three-launch sort (HISTG was cleared by tri_records_kernel)
         unsigned *histg = (unsigned *)w.i32(ws, RRL_WS_HISTG);
         const dim3 gt((unsigned)((nmax + 255) / 256), (unsigned)B, (unsigned)clouds);
@@ -1102,6 +1128,8 @@ int rrl_launch_cloud_sort(const float *raw1, const float *raw2, float4 *crec1, f
     a.grp1 = grp1; a.grp2 = grp2;
     a.pmax = pmax;
     a.B = B; a.N = N; a.M = M;
+    // (the chunked sort of rrl_launch_tri_build was tried here too: a nearest-neighbour walk evaluates twice the
+    //  pairs on chunked clouds -- 63.0 -> 64.4 us at N = M = 16384, 188 -> 380 at 65536: whole-cloud order stays)
     if (nmax <= 4096) {
         const size_t lds = ngpmax * (17 * sizeof(float4) + GRP * sizeof(int));
         if (raw1 && raw2) hipLaunchKernelGGL((tri_sort_kernel<4, true>), dim3((unsigned)(2 * B)), dim3(1024), lds, s, a);

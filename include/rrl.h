@@ -76,7 +76,8 @@ enum {
     RRL_WS_HIT2,
     RRL_WS_PTRI1,      /* float[B][N][12] 9 coords, thr2, thr, original triangle index (int)  */
     RRL_WS_PTRI2,      /* float[B][M][12]                                                   */
-    RRL_WS_P0S1,       /* float[B][64*NSG1][4] P0 + thr2 in grid-cell (Hilbert curve) order; NSG = ceil(N/64) */
+    RRL_WS_P0S1,       /* float[B][64*NSG1][4] P0 + thr2 in grid-cell (Hilbert curve) order -- clouds of more than 4096
+                          triangles: each chunk of 4096 (by original index) in its own order; NSG = ceil(N/64)   */
     RRL_WS_P0S2,       /*   supergroups of 64 sorted triangles; pad records have thr2 = 0 (never hit)           */
     RRL_WS_IDX1,       /* int32[B][64*NSG1]  original triangle index of each sorted position     */
     RRL_WS_IDX2,

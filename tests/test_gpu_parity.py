@@ -79,6 +79,52 @@ def test_tri_prepare_exact(L, oracle):
         np.testing.assert_array_equal(p0s[slot], np.append(pt[idx[s_], :3], thr2[idx[s_]]))
 
 
+@pytest.mark.parametrize("wide", [0, 1])
+@pytest.mark.parametrize("N,M", [(5000, 4100), (16400, 9000), (65536, 4097)])
+def test_large_cloud_layouts(L, N, M, wide, monkeypatch):
+    """Clouds of more than 4096 triangles: the chunked single-launch sort (default: every chunk of 4096 records in
+    its own Hilbert order) and the wide whole-cloud sort (RRL_SORT_WIDE=1) both leave a permutation whose real
+    records occupy the sorted positions [0, n), tree nodes that bound their records, and the same labels,
+    loss and hit lists as the strict scan."""
+    from rrl_hip import ops, synth
+    monkeypatch.setenv("RRL_SORT_WIDE", str(wide))
+    pr = synth.make_pair(7, N, M)
+    src, tar = cu(pr["src_tri"])[None], cu(pr["tar_tri"])[None]
+    torch.manual_seed(2)
+    ln = L.Random_uniform_distribution_lines_batch_efficient_resample(
+        torch.tensor([[float(pr["radius"])]]), torch.from_numpy(pr["center"]).reshape(1, 3), 700,
+        cu(pr["src"])[None], cu(pr["tar"])[None], "cuda")
+    st = ops.loss_forward_raw(src, tar, ln, mode="cull")
+    ref = ops.loss_forward_raw(src, tar, ln, mode="strict")
+    torch.cuda.synchronize()
+    assert torch.equal(st.count1, ref.count1) and torch.equal(st.count2, ref.count2) and torch.equal(st.loss, ref.loss)
+    assert int(st.status[0]) == 0 and int(st.status[1]) == 0
+    for l in torch.nonzero((st.count1[0] > 0) & (st.count1[0] <= 4))[:50, 0].tolist():  # beyond 4 hits any 4 are kept
+        k = int(st.count1[0, l])
+        assert sorted(st.hit1[0, l, :k].tolist()) == sorted(ref.hit1[0, l, :k].tolist())
+    for n, idx_t, p0s_t, tree_t, ptri_t in ((N, st.idx1, st.p0s1, st.grp1, st.ptri1), (M, st.idx2, st.p0s2, st.grp2, st.ptri2)):
+        idx = idx_t[0].cpu().numpy()
+        assert sorted(idx[:n].tolist()) == list(range(n))          # real records at the positions [0, n)
+        pt = ptri_t[0].cpu().numpy()
+        p0s = p0s_t[0].cpu().numpy()
+        np.testing.assert_array_equal(p0s[:n, :3], pt[idx[:n], :3])
+        np.testing.assert_array_equal(p0s[:n, 3], pt[idx[:n], 9])
+        assert np.all(p0s[n:, 3] == 0)                              # pad records never pass
+        tree = tree_t[0].cpu().numpy()
+        P0, thr = pt[idx[:n], :3].astype(np.float64), pt[idx[:n], 10].astype(np.float64)
+        rng = np.random.default_rng(N + M)
+        for sg in set(rng.integers(0, len(tree), 40).tolist()) | {0, len(tree) - 1, (n - 1) // 64}:
+            nodes = [(0, 64 * sg, 64)] + [(1 + k, 64 * sg + 16 * k, 16) for k in range(4)] + \
+                    [(5 + k, 64 * sg + 8 * k, 8) for k in range(8)]
+            for slot, s0, cnt in nodes:
+                sl = slice(s0, min(s0 + cnt, n))
+                if sl.start >= n:
+                    assert np.isnan(tree[sg, slot, 3])
+                    continue
+                d = np.linalg.norm(P0[sl] - tree[sg, slot, :3].astype(np.float64), axis=1) + thr[sl]
+                assert np.all(d <= tree[sg, slot, 3])
+
+
 # ---------------------------------------------------------------------------------- K1
 @pytest.mark.parametrize("name", LOSS_FIXTURES)
 @pytest.mark.parametrize("mode", ["strict", "lazy", "auto", "cull"])
