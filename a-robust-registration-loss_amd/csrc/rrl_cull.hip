@@ -1085,7 +1085,7 @@ int rrl_launch_tri_build(const float *tri1, const float *tri2, void *ws, const W
     a.zero_vec4 = w.zero_bytes / 16;
     a.g1 = xf && xf->zero_g1 ? (uint4 *)((char *)ws + w.off[RRL_WS_GACC]) : nullptr;  // small: 12 B + 16 floats
     a.g1_vec4 = a.g1 ? (w.off[RRL_WS_KJC] - w.off[RRL_WS_GACC]) / 16 : 0;
-    a.z2 = nmax > 4096 ? (uint4 *)((char *)ws + w.off[RRL_WS_HISTG]) : nullptr;
+    a.z2 = nmax > 4096 && !chunked ? (uint4 *)((char *)ws + w.off[RRL_WS_HISTG]) : nullptr;
     a.z2_vec4 = a.z2 ? (size_t)2 * B * 2 * SORT_CELLS * sizeof(unsigned) / 16 : 0;
     a.B = B; a.N = N; a.M = M;
     a.transpose_r = xf ? xf->transpose_r : 0;
