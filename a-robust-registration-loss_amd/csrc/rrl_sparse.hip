@@ -128,35 +128,40 @@ __device__ __forceinline__ void pair_hit(const float *__restrict__ tri1, const f
     ((float2 *)dc_slot)[sub] = make_float2(t2[0], t2[1]);
 }
 
-// 1024 lines per workgroup.  Phase 1: every lane classifies its line and the selected ones
-// (~9 %) are compacted through LDS, so that phase 2 -- the gather-heavy part -- runs on dense
-// wavefronts, eight lanes per line; the compacted line ids also go to SEL[b] for the backward.
-__global__ __launch_bounds__(1024) void line_pair_dist_kernel(
-    const float *__restrict__ tri1, const float *__restrict__ tri2, const float *__restrict__ line,
-    const int32_t *__restrict__ count1, const int32_t *__restrict__ hit1,
-    const int32_t *__restrict__ count2, const int32_t *__restrict__ hit2,
-    uint8_t *__restrict__ kj, int32_t *__restrict__ sel_out, int32_t *__restrict__ nsel,
-    int32_t *__restrict__ hs1, int32_t *__restrict__ hs2, float *__restrict__ w1,
-    float *__restrict__ w2, float4 *__restrict__ Q1, float4 *__restrict__ Q2, float *__restrict__ D,
-    float *__restrict__ dc, uint8_t *__restrict__ kjc, int32_t *__restrict__ blkcnt, int B, int N, int M,
-    int L, int s_m, int s_n, int e_m, int e_n, int st1, int st2) {
+struct PairArgs {
+    const float *tri1, *tri2, *line;  // prepared records (or raw rows: stride 9) of both clouds, the lines
+    const int32_t *count1, *hit1, *count2, *hit2;
+    uint8_t *kj;
+    int32_t *sel_out, *nsel, *hs1, *hs2;
+    float *w1, *w2;
+    float4 *Q1, *Q2;
+    float *D, *dc;
+    uint8_t *kjc;
+    int32_t *blkcnt;
+    int B, N, M, L, s_m, s_n, e_m, e_n, st1, st2;
+};
+
+// One tile of 1024 lines of sample b by a 1024-lane workgroup.  Phase 1: every lane classifies its line
+// and the selected ones (~9 %) are compacted through LDS, so that phase 2 -- the gather-heavy part -- runs
+// on dense wavefronts, eight lanes per line; the compacted line ids also go to SEL[b] for the backward.
+__device__ __forceinline__ void pair_body(const PairArgs &a, int b, int tile, int ntile) {
     __shared__ int s_list[1024];
     __shared__ int s_wave[16];
     __shared__ int s_total;
     __shared__ float4 s_q[128][8];  // intersection points of the lines of one pass
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.y;
+    const int L = a.L;
     int base_reg = 0;
     {
-        const int l = blockIdx.x * 1024 + tid;
+        const int l = tile * 1024 + tid;
         bool sel = false;
         unsigned kjb = 0;
         if (l < L) {
             const size_t gl = (size_t)b * L + l;
-            const int k = count1[gl], j = count2[gl];
-            sel = k >= s_m && k < e_m && j >= s_n && j < e_n;
+            const int k = a.count1[gl], j = a.count2[gl];
+            sel = k >= a.s_m && k < a.e_m && j >= a.s_n && j < a.e_n;
             kjb = sel ? (unsigned)(k | (j << 4)) : 0u;
-            kj[gl] = (uint8_t)kjb;
+            a.kj[gl] = (uint8_t)kjb;
         }
         const unsigned long long mask = __ballot(sel);
         if (lane == 0) s_wave[wave] = __popcll(mask);
@@ -167,37 +172,62 @@ __global__ __launch_bounds__(1024) void line_pair_dist_kernel(
             s_total = acc;
             // the slot range in SEL[b] is only needed for the last store of the kernel: the
             // atomic's round trip overlaps the gathers below
-            base_reg = acc ? atomicAdd(&nsel[b], acc) : 0;
+            base_reg = acc ? atomicAdd(&a.nsel[b], acc) : 0;
         }
         __syncthreads();
         // the line id (L < 2^24) and its (k, j) byte travel together: phase 2 needs no second look at the counts
         if (sel) s_list[s_wave[wave] + __popcll(mask & ((1ull << lane) - 1ull))] = (int)((unsigned)l | (kjb << 24));
         __syncthreads();
     }
-    // Compact copies for the reduce kernel live at slot = 1024 * (this workgroup) + rank: no global
-    // counter is needed to place them (BLKCNT[b][x] tells the consumer how many each workgroup
+    // Compact copies for the reduce kernel live at slot = 1024 * tile + rank: no global
+    // counter is needed to place them (BLKCNT[b][tile] tells the consumer how many each workgroup
     // wrote), so nothing here waits for an atomic.  SEL[b] (dense list of the selected line ids,
     // for the backward kernels) is written at the end by wavefront 0 alone: lane 0 holds the base
     // returned by the nsel atomic, whose round trip has long been hidden by the gathers.
-    const size_t Lp = (size_t)gridDim.x * 1024;
+    const size_t Lp = (size_t)ntile * 1024;
     const int total = s_total;
-    if (tid == 0) blkcnt[(size_t)b * gridDim.x + blockIdx.x] = total;
+    if (tid == 0) a.blkcnt[(size_t)b * ntile + tile] = total;
     for (int r0 = 0; r0 < total; r0 += 128) {  // 128 selected lines per pass, 8 lanes each
         const int rank = r0 + (tid >> 3), sub = tid & 7;
         if (rank < total) {
             const unsigned e = (unsigned)s_list[rank];
             const int l = (int)(e & 0xffffffu), k = (int)((e >> 24) & 15u), j = (int)(e >> 28);
             const size_t gl = (size_t)b * L + l;
-            const size_t slot = (size_t)b * Lp + (size_t)blockIdx.x * 1024 + rank;
-            if (sub == 0) kjc[slot] = (uint8_t)(k | (j << 4));
-            pair_hit(tri1, tri2, line, hit1, hit2, hs1, hs2, w1, w2, Q1, Q2, D, dc + slot * 16, s_q[tid >> 3], b,
-                     N, M, gl, k, j, sub, st1, st2);
+            const size_t slot = (size_t)b * Lp + (size_t)tile * 1024 + rank;
+            if (sub == 0) a.kjc[slot] = (uint8_t)(k | (j << 4));
+            pair_hit(a.tri1, a.tri2, a.line, a.hit1, a.hit2, a.hs1, a.hs2, a.w1, a.w2, a.Q1, a.Q2, a.D, a.dc + slot * 16,
+                     s_q[tid >> 3], b, a.N, a.M, gl, k, j, sub, a.st1, a.st2);
         }
     }
     if (wave == 0) {
         const int base = __builtin_amdgcn_readfirstlane(base_reg);
-        for (int i = lane; i < total; i += 64) sel_out[(size_t)b * L + base + i] = s_list[i] & 0xffffff;
+        for (int i = lane; i < total; i += 64) a.sel_out[(size_t)b * L + base + i] = s_list[i] & 0xffffff;
     }
+}
+
+__global__ __launch_bounds__(1024) void line_pair_dist_kernel(const PairArgs a) {
+    pair_body(a, (int)blockIdx.y, (int)blockIdx.x, (int)gridDim.x);
+}
+
+static PairArgs pair_args(const float *tri2_raw, const float *line, void *ws, const WsLayout &w, int B, int N, int M,
+                          int L, int s_m, int s_n, int e_m, int e_n) {
+    PairArgs a;
+    a.tri1 = w.f32(ws, RRL_WS_PTRI1);
+    a.tri2 = tri2_raw ? tri2_raw : w.f32(ws, RRL_WS_PTRI2);
+    a.line = line;
+    a.count1 = w.i32(ws, RRL_WS_COUNT1); a.hit1 = w.i32(ws, RRL_WS_HIT1);
+    a.count2 = w.i32(ws, RRL_WS_COUNT2); a.hit2 = w.i32(ws, RRL_WS_HIT2);
+    a.kj = w.u8(ws, RRL_WS_KJ);
+    a.sel_out = w.i32(ws, RRL_WS_SEL); a.nsel = w.i32(ws, RRL_WS_NSEL);
+    a.hs1 = w.i32(ws, RRL_WS_HS1); a.hs2 = w.i32(ws, RRL_WS_HS2);
+    a.w1 = w.f32(ws, RRL_WS_W1); a.w2 = w.f32(ws, RRL_WS_W2);
+    a.Q1 = (float4 *)w.f32(ws, RRL_WS_Q1); a.Q2 = (float4 *)w.f32(ws, RRL_WS_Q2);
+    a.D = w.f32(ws, RRL_WS_D); a.dc = w.f32(ws, RRL_WS_VALS);
+    a.kjc = w.u8(ws, RRL_WS_KJC); a.blkcnt = w.i32(ws, RRL_WS_BLKCNT);
+    a.B = B; a.N = N; a.M = M; a.L = L;
+    a.s_m = s_m; a.s_n = s_n; a.e_m = e_m; a.e_n = e_n;
+    a.st1 = PTRI_STRIDE; a.st2 = tri2_raw ? 9 : PTRI_STRIDE;
+    return a;
 }
 
 // tri2_raw != NULL: the target's prepared records are not in this workspace (its scan was carried
@@ -210,16 +240,8 @@ static int line_pair_dist_impl(const float *tri2_raw, const float *line, void *w
     WsLayout w(B, N, M, L);
     if (ws_bytes < w.total) return RRL_E_WS;
     if (B == 0 || L == 0) return 0;
-    hipLaunchKernelGGL(line_pair_dist_kernel, dim3((unsigned)((L + 1023) / 1024), (unsigned)B),
-                       dim3(1024), 0, (hipStream_t)stream, w.f32(ws, RRL_WS_PTRI1),
-                       tri2_raw ? tri2_raw : w.f32(ws, RRL_WS_PTRI2), line,
-                       w.i32(ws, RRL_WS_COUNT1), w.i32(ws, RRL_WS_HIT1), w.i32(ws, RRL_WS_COUNT2),
-                       w.i32(ws, RRL_WS_HIT2), w.u8(ws, RRL_WS_KJ), w.i32(ws, RRL_WS_SEL),
-                       w.i32(ws, RRL_WS_NSEL), w.i32(ws, RRL_WS_HS1), w.i32(ws, RRL_WS_HS2),
-                       w.f32(ws, RRL_WS_W1), w.f32(ws, RRL_WS_W2), (float4 *)w.f32(ws, RRL_WS_Q1),
-                       (float4 *)w.f32(ws, RRL_WS_Q2), w.f32(ws, RRL_WS_D), w.f32(ws, RRL_WS_VALS),
-                       w.u8(ws, RRL_WS_KJC), w.i32(ws, RRL_WS_BLKCNT), B, N, M, L, s_m, s_n, e_m, e_n,
-                       PTRI_STRIDE, tri2_raw ? 9 : PTRI_STRIDE);
+    hipLaunchKernelGGL(line_pair_dist_kernel, dim3((unsigned)((L + 1023) / 1024), (unsigned)B), dim3(1024), 0,
+                       (hipStream_t)stream, pair_args(tri2_raw, line, ws, w, B, N, M, L, s_m, s_n, e_m, e_n));
     RRL_LAUNCH_CHECK();
     return 0;
 }
@@ -533,11 +555,31 @@ __device__ __forceinline__ void reduce_core(const uint8_t *__restrict__ kjc, con
     n_o = n;
 }
 
-__global__ __launch_bounds__(1024) void loss_reduce_kernel(
-    const uint8_t *__restrict__ kjc, const float *__restrict__ dc, const int32_t *__restrict__ blkcnt,
-    float *__restrict__ med_out, int32_t *__restrict__ bcnt_out, int64_t *__restrict__ bsum_out,
-    int32_t *__restrict__ info, float *__restrict__ loss, const int32_t *__restrict__ status, int B, int nblk,
-    int s_m, int s_n, int e_m, int e_n, int pool) {
+struct ReduceArgs {
+    const uint8_t *kjc;
+    const float *dc;
+    const int32_t *blkcnt;
+    float *med_out;
+    int32_t *bcnt_out;
+    int64_t *bsum_out;
+    int32_t *info;
+    float *loss;
+    const int32_t *status;
+    int B, nblk, s_m, s_n, e_m, e_n, pool;
+};
+
+// K3+K4 of one group g (a sample, or all samples with the last one's median when pool) by a 1024-lane workgroup
+__device__ __forceinline__ void reduce_body(const ReduceArgs &ra, int g) {
+    const uint8_t *__restrict__ kjc = ra.kjc;
+    const float *__restrict__ dc = ra.dc;
+    const int32_t *__restrict__ blkcnt = ra.blkcnt;
+    float *__restrict__ med_out = ra.med_out;
+    int32_t *__restrict__ bcnt_out = ra.bcnt_out;
+    int64_t *__restrict__ bsum_out = ra.bsum_out;
+    int32_t *__restrict__ info = ra.info;
+    float *__restrict__ loss = ra.loss;
+    const int32_t *__restrict__ status = ra.status;
+    const int B = ra.B, nblk = ra.nblk, s_m = ra.s_m, s_n = ra.s_n, e_m = ra.e_m, e_n = ra.e_n, pool = ra.pool;
     extern __shared__ int s_pref[];  // nblk + 1
     __shared__ unsigned s_hist[2048];
     __shared__ unsigned s_wtot[16];
@@ -548,7 +590,7 @@ __global__ __launch_bounds__(1024) void loss_reduce_kernel(
     __shared__ int s_cnt[16];
     __shared__ int s_bad;
     __shared__ float s_term[16];
-    const int g = blockIdx.x, tid = threadIdx.x;
+    const int tid = threadIdx.x;
     const int bm = pool ? B - 1 : g;  // whose values define the median
     const int b0 = pool ? 0 : g, b1 = pool ? B : g + 1;
     if (tid < 32) s_sum[tid] = 0ull;
@@ -601,6 +643,30 @@ __global__ __launch_bounds__(1024) void loss_reduce_kernel(
     }
 }
 
+__global__ __launch_bounds__(1024) void loss_reduce_kernel(const ReduceArgs ra) { reduce_body(ra, (int)blockIdx.x); }
+
+// K2 + K3 + K4 in ONE launch when a sample has a single tile of lines (L <= 1024) and the samples are not pooled:
+// the workgroup that ran the per-line stage of sample b owns everything the reduce of sample b reads, so it
+// simply carries on (a launch and the reduce's first load round less: small-L shapes such as C5 are nothing
+// but launch latency).  Same bodies, same results.
+__global__ __launch_bounds__(1024) void pair_reduce_kernel(const PairArgs pa, const ReduceArgs ra) {
+    pair_body(pa, (int)blockIdx.x, 0, 1);
+    __threadfence_block();  // this workgroup's KJC / VALS / BLKCNT stores are complete ...
+    __syncthreads();        // ... before any of its lanes reads them back
+    reduce_body(ra, (int)blockIdx.x);
+}
+
+static ReduceArgs reduce_args(void *ws, const WsLayout &w, float *loss, int B, int L, int s_m, int s_n, int e_m, int e_n,
+                              int pool) {
+    ReduceArgs r;
+    r.kjc = w.u8(ws, RRL_WS_KJC); r.dc = w.f32(ws, RRL_WS_VALS); r.blkcnt = w.i32(ws, RRL_WS_BLKCNT);
+    r.med_out = w.f32(ws, RRL_WS_MED); r.bcnt_out = w.i32(ws, RRL_WS_BCNT); r.bsum_out = w.i64(ws, RRL_WS_BSUM);
+    r.info = w.i32(ws, RRL_WS_INFO); r.loss = loss; r.status = w.i32(ws, RRL_WS_STATUS);
+    r.B = B; r.nblk = (L + 1023) / 1024;
+    r.s_m = s_m; r.s_n = s_n; r.e_m = e_m; r.e_n = e_n; r.pool = pool;
+    return r;
+}
+
 extern "C" int rrl_loss_reduce(void *ws, size_t ws_bytes, float *loss, int B, int N, int M, int L,
                                int s_m, int s_n, int e_m, int e_n, int pool, void *stream) {
     if (!ws || !loss || B < 0 || N < 0 || M < 0 || L < 0) return RRL_E_ARG;
@@ -609,11 +675,8 @@ extern "C" int rrl_loss_reduce(void *ws, size_t ws_bytes, float *loss, int B, in
     if (ws_bytes < w.total) return RRL_E_WS;
     if (B == 0) return 0;
     const int nblk = (L + 1023) / 1024;
-    hipLaunchKernelGGL(loss_reduce_kernel, dim3((unsigned)(pool ? 1 : B)), dim3(1024),
-                       sizeof(int) * (size_t)(nblk + 1), (hipStream_t)stream, w.u8(ws, RRL_WS_KJC),
-                       w.f32(ws, RRL_WS_VALS), w.i32(ws, RRL_WS_BLKCNT), w.f32(ws, RRL_WS_MED),
-                       w.i32(ws, RRL_WS_BCNT), w.i64(ws, RRL_WS_BSUM), w.i32(ws, RRL_WS_INFO), loss,
-                       w.i32(ws, RRL_WS_STATUS), B, nblk, s_m, s_n, e_m, e_n, pool);
+    hipLaunchKernelGGL(loss_reduce_kernel, dim3((unsigned)(pool ? 1 : B)), dim3(1024), sizeof(int) * (size_t)(nblk + 1),
+                       (hipStream_t)stream, reduce_args(ws, w, loss, B, L, s_m, s_n, e_m, e_n, pool));
     RRL_LAUNCH_CHECK();
     return 0;
 }
@@ -969,6 +1032,16 @@ static int loss_forward_impl(const float *tri1, const float *tri2, const float *
     {
         RrlRange r("K1 line<->triangle scan");
         if ((rc = rrl_line_tri_scan_clouds(line, ws, ws_bytes, B, N, M, L, mode, chunk, clouds, stream))) return rc;
+    }
+    if (L >= 1 && L <= 1024 && !pool && B > 0 && L < (1 << 24)) {  // one tile of lines per sample: K2 + K3 + K4 in one launch
+        RrlRange r("K2 + K3 + K4 (single tile)");
+        WsLayout w(B, N, M, L);
+        if (ws_bytes < w.total) return RRL_E_WS;
+        hipLaunchKernelGGL(pair_reduce_kernel, dim3((unsigned)B), dim3(1024), sizeof(int) * 2, (hipStream_t)stream,
+                           pair_args(target_ws ? tri2 : nullptr, line, ws, w, B, N, M, L, s_m, s_n, e_m, e_n),
+                           reduce_args(ws, w, loss, B, L, s_m, s_n, e_m, e_n, 0));
+        RRL_LAUNCH_CHECK();
+        return 0;
     }
     {
         RrlRange r("K2 per-line distances");
