@@ -383,6 +383,63 @@ def registration_loss(src_tri, R, t, tar_tri, line, rng=(1, 1, 5, 5), transpose_
                                    chunk, want_payload, target_from)
 
 
+class RegistrationStep:
+    """The fused training op WITHOUT autograd and without a graph: forward + backward to (dR, dt) as two C calls
+    on buffers allocated once -- what a training loop needs when (R, t) come out of a network:
+
+        step = ops.RegistrationStep(src_tri, tar_tri, L)            # once per shape
+        loss, gR, gt = step(R.detach(), t.detach(), lines)[:3]      # every iteration (gout = ones)
+        torch.autograd.backward([R, t], [gR, gt])                   # hand the gradient to the network
+
+    Issued this way the C2 step is GPU-bound at 74 us (about 30 us of host time per step); replaying the
+    same launches as a hipGraph costs 79 us (a replay has ~8 us of fixed cost + 1.5 us per node on this
+    stack, tools/graph_node_cost.py), and the autograd front end (registration_loss) is host-bound when
+    issued eagerly.  Same kernels, same numbers as registration_loss.  The outputs are views of buffers
+    that the next call overwrites.  want_payload: also the 14-float batch-shard payload (rrl_hip.dist)."""
+
+    def __init__(self, src_tri, tar_tri, n_lines, rng=(1, 1, 5, 5), transpose_r=True, mode="cull", chunk=0,
+                 want_payload=False):
+        dev = _home(src_tri, tar_tri)
+        self.dev = dev
+        self.src = _prep(src_tri, "src_tri", 9, dev)
+        self.tar = _prep(tar_tri, "tar_tri", 9, dev)
+        if self.src.dim() != 3 or self.tar.dim() != 3 or self.src.shape[0] != self.tar.shape[0]:
+            raise ValueError("src_tri/tar_tri must be (B, n, 9) with the same B")
+        B, N, _ = self.src.shape
+        M, L = self.tar.shape[1], int(n_lines)
+        if B == 0 or L <= 0:
+            raise ValueError("RegistrationStep needs a non-empty batch and line set")
+        self.dims = (B, N, M, L)
+        self.rng = _check_range(rng)
+        self.tr, self.mode, self.chunk = int(bool(transpose_r)), _MODES[mode], int(chunk)
+        self.st = LossState(B, N, M, L, B, dev)
+        self.ones = torch.ones(B, dtype=torch.float32, device=dev)
+        gacc = self.st.gacc
+        self.gR, self.gt = gacc[:B * 9].view(B, 3, 3), gacc[B * 9:B * 12].view(B, 3)
+        self.payload = gacc[B * 12:B * 12 + 14] if want_payload else None
+        self._lib = _lib.load()
+        self._fixed_f = (_p(self.st.ws), self.st.nbytes, _p(self.st.loss), B, N, M, L, self.tr, *self.rng, self.mode,
+                         self.chunk, None)
+        self._fixed_b = (_p(self.st.ws), self.st.nbytes, _p(self.st.loss))
+        self._tail_b = (None, _p(gacc[:B * 9]), _p(gacc[B * 9:B * 12]), _p(self.payload), B, N, M, L, self.tr)
+
+    def __call__(self, R, t, line, grad_loss=None):
+        B, N, M, L = self.dims
+        dev = self.dev
+        Rm, tv, ln = _prep(R, "R", None, dev), _prep(t, "t", None, dev), _prep(line, "line", 6, dev)
+        if Rm.numel() != B * 9 or tv.numel() != B * 3 or tuple(ln.shape) != (B, L, 6):
+            raise ValueError("R (B,3,3), t (B,3), line (B, L, 6) expected")
+        g = self.ones if grad_loss is None else _prep(grad_loss, "grad_loss", None, dev)
+        lib, s = self._lib, _stream(dev)
+        with _guard(dev):
+            check(lib.rrl_registration_forward_cached(_p(self.src), _p(Rm), _p(tv), _p(self.tar), _p(ln), *self._fixed_f, s),
+                  "rrl_registration_forward")
+            check(lib.rrl_registration_backward(_p(self.src), _p(Rm), _p(self.tar), *self._fixed_b, _p(g), *self._tail_b, s),
+                  "rrl_registration_backward")
+        _IntersectionLoss.last_state = self.st
+        return self.st.loss.view(-1), self.gR, self.gt, self.payload, self.st.info
+
+
 def set_deterministic(on):
     """Bit-reproducible direct backward of registration_loss (fixed-order partial sums, one more tiny
     launch) instead of float atomics; include/rrl.h rrl_set_deterministic.  Process-wide."""

@@ -163,6 +163,9 @@ def main():
                          "measures inline vs overlap during warm-up when there is more than one rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--issue", choices=["auto", "graph", "direct"], default="auto",
+                    help="how the step's launches are issued: one hipGraph replay, or the two C calls of "
+                         "ops.RegistrationStep on the stream (no autograd, no graph); auto measures both in warm-up")
     ap.add_argument("--no-extras", action="store_true", help="skip the strict / counter / drop-in passes")
     ap.add_argument("--no-dist", action="store_true",
                     help="single process without a process group (default: even a plain 1-GPU run creates a 1-rank "
@@ -219,9 +222,28 @@ def main():
 
     from rrl_hip.graph import GraphedStep
 
-    def build(inline):
+    rstep = [None]
+
+    def direct_step():
+        # the same launches as local_step, issued as two C calls on preallocated buffers (ops.RegistrationStep)
+        if rstep[0] is None:
+            rstep[0] = ops.RegistrationStep(w["tri1"], w["tri2"], L, transpose_r=True, mode=args.mode, want_payload=True)
+            rstep[0].Rd, rstep[0].Td = w["R"].detach(), w["T"].detach()
+        return rstep[0](rstep[0].Rd, rstep[0].Td, w["lines"])[3]
+
+    def build(inline, issue="graph"):
         """(callable step, finish) for one all-reduce placement; capture success is agreed on by
         all ranks, so nobody replays a graph with a collective the others do not have."""
+        if issue == "direct":
+            last = [None]
+            if inline:
+                def step():
+                    last[0] = reducer.allreduce_inline(direct_step())
+                return None, step, (lambda: last[0])
+
+            def step():
+                reducer.submit(direct_step())
+            return None, step, reducer.finish
         g, err = None, None
         if not args.no_graph:
             try:
@@ -260,12 +282,16 @@ def main():
     # ---- choose the all-reduce placement (identically on every rank)
     choice_note = None
     cands = []
-    if direct and args.reducer in ("auto", "inline"):
-        c = build(True)
-        if c is not None:
-            cands.append(("inline", c))
-    if args.reducer in ("overlap", "torch") or (args.reducer == "auto" and world > 1) or not cands:
-        cands.append(("overlap", build(False)))
+    issues = ["graph", "direct"] if args.issue == "auto" and not args.no_graph else [args.issue if args.issue != "auto" else "graph"]
+    for issue in issues:
+        have = False
+        if direct and args.reducer in ("auto", "inline"):
+            c = build(True, issue)
+            if c is not None:
+                cands.append(("inline/" + issue, c))
+                have = True
+        if args.reducer in ("overlap", "torch") or (args.reducer == "auto" and world > 1) or not have:
+            cands.append(("overlap/" + issue, build(False, issue)))
     if len(cands) > 1:  # measure both during warm-up; max over ranks -> the same decision everywhere
         probe = {}
         for name, (g, step, finish) in cands:
@@ -280,7 +306,7 @@ def main():
         best = min(probe, key=probe.get)
         choice_note = {k: round(v, 4) for k, v in probe.items()}
         cands = [(n, c) for n, c in cands if n == best]
-    placement, (graphed, step, finish) = cands[0]
+    (placement, issued), (graphed, step, finish) = cands[0][0].split("/"), cands[0][1]
 
     for _ in range(args.warmup):
         step()
@@ -467,8 +493,11 @@ def main():
                                    + f", N=M={N} pseudo-triangles, L={L} lines, fp32 loss fwd+bwd "
                                    f"(BASELINE.json configs[{2 if strong else 1}]); fused training op "
                                    f"(rigid apply + loss, backward to dR, dT); scan mode {args.mode}; "
-                                   + ("hipGraph replay" if graphed is not None else "eager launches")
+                                   + ("hipGraph replay" if graphed is not None else
+                                      ("two C calls per step on the stream (ops.RegistrationStep: no autograd node, no graph)"
+                                       if issued == "direct" else "eager launches"))
                                    + "; value counts dense-equivalent pairs",
+                       "issue": issued if (issued == "direct" or graphed is not None) else "eager",
                        "global_batch": args.global_batch if strong else B * world,
                        "parallelism": f"batch-shard dp{world}",
                        "allreduce": {"reducer": type(reducer).__name__, "placement": placement,

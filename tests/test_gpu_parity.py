@@ -79,6 +79,43 @@ def test_tri_prepare_exact(L, oracle):
         np.testing.assert_array_equal(p0s[slot], np.append(pt[idx[s_], :3], thr2[idx[s_]]))
 
 
+@pytest.mark.parametrize("tr", [True, False])
+def test_registration_step_equals_the_autograd_op(L, tr):
+    """ops.RegistrationStep (forward + backward as two C calls on preallocated buffers, no autograd node)
+    against ops.registration_loss + autograd: same loss bits, same info, dR / dt / payload to the rounding
+    noise of the float atomics; repeated calls on the same object and a non-unit grad_loss."""
+    from rrl_hip import ops, synth
+    B, N, M, Ll = 3, 1500, 1100, 2500
+    prs = [synth.make_pair(50 + b, N, M) for b in range(B)]
+    src, tar = cu(np.stack([p["src_tri"] for p in prs])), cu(np.stack([p["tar_tri"] for p in prs]))
+    ln = []
+    for b, p in enumerate(prs):
+        torch.manual_seed(b)
+        ln.append(L.Random_uniform_distribution_lines_batch_efficient_resample(
+            torch.tensor([[float(p["radius"])]]), torch.from_numpy(p["center"]).reshape(1, 3), Ll,
+            cu(p["src"])[None], cu(p["tar"])[None], "cuda")[0])
+    ln = torch.stack(ln)
+    ang = torch.tensor([0.05, -0.1, 0.2], device="cuda")
+    R0 = torch.zeros(B, 3, 3, device="cuda")
+    R0[:, 0, 0] = R0[:, 1, 1] = torch.cos(ang); R0[:, 0, 1] = -torch.sin(ang); R0[:, 1, 0] = torch.sin(ang); R0[:, 2, 2] = 1
+    t0 = torch.tensor([[0.01, 0.0, -0.02]] * B, device="cuda")
+    gout = torch.tensor([1.0, 0.5, 2.0], device="cuda")
+    R, t = R0.clone().requires_grad_(True), t0.clone().requires_grad_(True)
+    loss, info, _ = ops.registration_loss(src, R, t, tar, ln, transpose_r=tr, want_payload=True)
+    torch.autograd.backward([loss], [gout])
+    want_payload = ops.last_state().payload.clone()
+    step = ops.RegistrationStep(src, tar, Ll, transpose_r=tr, want_payload=True)
+    for rep in range(3):  # the buffers are reused: every call must stand on its own
+        l2, gR, gt, payload, info2 = step(R0, t0, ln, gout)
+        torch.cuda.synchronize()
+        assert torch.equal(l2, loss.detach()) and torch.equal(info2, info)
+        np.testing.assert_allclose(gR.cpu().numpy(), R.grad.cpu().numpy(), rtol=2e-5, atol=1e-7)
+        np.testing.assert_allclose(gt.cpu().numpy(), t.grad.cpu().numpy(), rtol=2e-5, atol=1e-7)
+        np.testing.assert_allclose(payload.cpu().numpy(), want_payload.cpu().numpy(), rtol=2e-5, atol=1e-7)
+    l1 = step(R0, t0, ln)[0]  # default grad_loss = ones
+    assert torch.equal(l1, loss.detach())
+
+
 @pytest.mark.parametrize("wide", [0, 1])
 @pytest.mark.parametrize("N,M", [(5000, 4100), (16400, 9000), (65536, 4097)])
 def test_large_cloud_layouts(L, N, M, wide, monkeypatch):
