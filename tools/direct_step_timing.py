@@ -9,7 +9,7 @@ import bench
 from rrl_hip import ops, _lib
 from rrl_hip.graph import GraphedStep
 dev = torch.device("cuda", 0)
-B, N, M, L = 8, 4096, 4096, 10000
+B, N, M, L = (int(v) for v in sys.argv[1:5]) if len(sys.argv) > 4 else (8, 4096, 4096, 10000)
 w = bench.make_workload(B, N, M, L, 0, dev)
 lib = _lib.load()
 st = ops.LossState(B, N, M, L, B, dev)
@@ -18,8 +18,8 @@ R, T = w["R"].detach().contiguous(), w["T"].detach().contiguous()
 g = torch.ones(B, device=dev)
 out = torch.zeros(B * 12 + 14, device=dev)
 gR, gt = out[:B * 9], out[B * 9:B * 12]
-s = ops._stream(dev)
 def step():
+    s = ops._stream(dev)
     rc = lib.rrl_registration_forward_cached(ops._p(src), ops._p(R), ops._p(T), ops._p(tar), ops._p(ln), ops._p(st.ws), st.nbytes,
                                              ops._p(st.loss), B, N, M, L, 1, 1, 1, 5, 5, 3, 0, None, s)
     assert rc == 0
