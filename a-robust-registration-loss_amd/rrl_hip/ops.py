@@ -423,9 +423,17 @@ class RegistrationStep:
         self._fixed_b = (_p(self.st.ws), self.st.nbytes, _p(self.st.loss))
         self._tail_b = (None, _p(gacc[:B * 9]), _p(gacc[B * 9:B * 12]), _p(self.payload), B, N, M, L, self.tr)
 
-    def __call__(self, R, t, line, grad_loss=None):
+    def __call__(self, R, t, line, grad_loss=None, src_tri=None, tar_tri=None):
+        """src_tri / tar_tri: this step's clouds (same shapes as at construction); default: the tensors given
+        to the constructor (update those in place, or pass the new batch here)."""
         B, N, M, L = self.dims
         dev = self.dev
+        if src_tri is not None:
+            self.src = _prep(src_tri, "src_tri", 9, dev)
+        if tar_tri is not None:
+            self.tar = _prep(tar_tri, "tar_tri", 9, dev)
+        if tuple(self.src.shape) != (B, N, 9) or tuple(self.tar.shape) != (B, M, 9):
+            raise ValueError(f"src_tri {(B, N, 9)} / tar_tri {(B, M, 9)} expected")
         Rm, tv, ln = _prep(R, "R", None, dev), _prep(t, "t", None, dev), _prep(line, "line", 6, dev)
         if Rm.numel() != B * 9 or tv.numel() != B * 3 or tuple(ln.shape) != (B, L, 6):
             raise ValueError("R (B,3,3), t (B,3), line (B, L, 6) expected")

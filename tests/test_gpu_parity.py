@@ -114,6 +114,10 @@ def test_registration_step_equals_the_autograd_op(L, tr):
         np.testing.assert_allclose(payload.cpu().numpy(), want_payload.cpu().numpy(), rtol=2e-5, atol=1e-7)
     l1 = step(R0, t0, ln)[0]  # default grad_loss = ones
     assert torch.equal(l1, loss.detach())
+    # a new batch of the same shape through the same object
+    l3 = step(R0, t0, ln, gout, src_tri=src.flip(0).contiguous(), tar_tri=tar.flip(0).contiguous())[0].clone()
+    want3, _, _ = ops.registration_loss(src.flip(0).contiguous(), R0, t0, tar.flip(0).contiguous(), ln, transpose_r=tr)
+    assert torch.equal(l3, want3)
 
 
 @pytest.mark.parametrize("wide", [0, 1])
