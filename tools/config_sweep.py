@@ -51,7 +51,15 @@ def run(name, B, N, M, L, crop=False, noise=0.01, diag=None):
     for _ in range(n): g()
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
     pairs = B * L * 3 * (N + M)
+    # the same step issued as two plain C calls (ops.RegistrationStep: no autograd node, no graph)
+    rs = ops.RegistrationStep(src, tar, L, transpose_r=True, mode=os.environ.get("RRL_SCAN_MODE", "cull"))
+    Rd, td = R.detach(), t.detach()
+    for _ in range(10): rs(Rd, td, ln)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n): rs(Rd, td, ln)
+    torch.cuda.synchronize(); dd = (time.perf_counter() - t0) / n
     print(json.dumps({"mode": os.environ.get("RRL_SCAN_MODE", "cull"), "config": name, "B": B, "N": N, "M": M, "L": L, "us_per_step": round(dt * 1e6, 1),
+                      "us_per_step_direct": round(dd * 1e6, 1),
                       "pairs_per_s": pairs / dt, "selected_lines": int(g.out[1][:, 1].sum()),
                       "loss0": float(g.out[0][0]), "filled_lines": int((ln.abs().sum(-1) > 0).sum()),
                       "fallback_wavefronts": int(ops.last_state().status[1])}))
