@@ -407,42 +407,44 @@ def main():
             "dR_max_rel_diff_vs_fused": float((w["R"].grad - fused_gR).abs().max() / fused_gR.abs().max())}
 
         # Chamfer monitor (every caller evaluates it next to the loss): device time per call, hipGraph replay
-        def chamfer_ms(tree):
-            ops.CHAMFER_TREE = tree
-            try:
-                fn = (lambda: Lmod.chamfer_dist(w["src"], w["tar"]))
-                gc = GraphedStep(fn) if not args.no_graph else fn
-                for _ in range(3):
+        def time_call(fn, n=50):
+            """ms per call of fn, issued eagerly and as a hipGraph replay (a replay has ~8 us of fixed cost on this
+            stack, tools/graph_node_cost.py): (best, how, last result)"""
+            out = {}
+            for how in (["eager"] if args.no_graph else ["eager", "graph"]):
+                gc = GraphedStep(fn) if how == "graph" else fn
+                for _ in range(5):
                     gc()
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
-                for _ in range(50):
-                    cd = gc()
+                for _ in range(n):
+                    res = gc()
                 torch.cuda.synchronize()
-                return (time.perf_counter() - t1) / 50 * 1e3, float(cd)
+                out[how] = ((time.perf_counter() - t1) / n * 1e3, res)
+            how = min(out, key=lambda k: out[k][0])
+            return out[how][0], how, out[how][1], {k: round(v[0], 5) for k, v in out.items()}
+
+        def chamfer_ms(tree):
+            ops.CHAMFER_TREE = tree
+            try:
+                ms, how, cd, both = time_call(lambda: Lmod.chamfer_dist(w["src"], w["tar"]))
+                return ms, float(cd), how, both
             finally:
                 ops.CHAMFER_TREE = True
-        cms, cd = chamfer_ms(True)
-        bms, cdb = chamfer_ms(False)
-        extras.update({"chamfer_ms": cms, "chamfer_pairs_per_s": B * N * M / (cms * 1e-3), "chamfer": cd,
+        cms, cd, chow, cboth = chamfer_ms(True)
+        bms, cdb, _, _ = chamfer_ms(False)
+        extras.update({"chamfer_ms": cms, "chamfer_issue": chow, "chamfer_ms_by_issue": cboth,
+                       "chamfer_pairs_per_s": B * N * M / (cms * 1e-3), "chamfer": cd,
                        "chamfer_brute_force_ms": bms, "chamfer_values_equal": cd == cdb,
                        "chamfer_note": "both directions, B x N x M dense-equivalent pairs; sorted clouds + sphere tree "
                                        "(rrl_chamfer.hip) vs the all-pairs kernel"})
         # the monitor NEXT TO a loss evaluation: the loss workspace already holds both clouds sorted under
         # their sphere trees (the triangles' first points are the points), so the walk needs no second sort
         st0 = ops.loss_forward_raw(w["tri1"], w["tri2"], w["lines"], mode=args.mode)
-        fn = (lambda: ops.chamfer_from_state(st0))
-        gc = GraphedStep(fn) if not args.no_graph else fn
-        for _ in range(3):
-            gc()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(50):
-            cfs = gc()
-        torch.cuda.synchronize()
-        fms = (time.perf_counter() - t1) / 50 * 1e3
+        fms, fhow, cfs, fboth = time_call(lambda: ops.chamfer_from_state(st0))
         want = float(ops.chamfer(w["tri1"][..., :3].contiguous(), w["tri2"][..., :3].contiguous()))
-        extras.update({"chamfer_from_loss_state_ms": fms, "chamfer_from_loss_state": float(cfs),
+        extras.update({"chamfer_from_loss_state_ms": fms, "chamfer_from_loss_state_issue": fhow,
+                       "chamfer_from_loss_state_ms_by_issue": fboth, "chamfer_from_loss_state": float(cfs),
                        "chamfer_from_loss_state_equals_chamfer_of_first_points": float(cfs) == want})
 
     if rank == 0:
