@@ -94,10 +94,13 @@ __device__ __forceinline__ uint32_t f2u(float x) { return __float_as_uint(x); }
 //   thr  = mean(|P1-P0|, |P2-P0|, |P1-P2|) * 1.731 / 2
 //   thr2 = min { x >= 0 : sqrtf(x) >= thr }  (sqrtf correctly rounded and monotone), so that
 //          sqrtf(x) < thr  <=>  x < thr2 exactly.  Start at fl(thr*thr) and walk a few ulps.
-__device__ __forceinline__ void tri_thresholds(const float *c, float *thr_out, float *thr2_out) {
+// e01_out (optional): max(|P1-P0|, |P2-P0|) as evaluated here -- how far points 1, 2 can sit from point 0
+// (the culled scan's NaN reach, rrl_cull.hip).
+__device__ __forceinline__ void tri_thresholds(const float *c, float *thr_out, float *thr2_out, float *e01_out = nullptr) {
     float e0 = norm3(c[3] - c[0], c[4] - c[1], c[5] - c[2]);
     float e1 = norm3(c[6] - c[0], c[7] - c[1], c[8] - c[2]);
     float e2 = norm3(c[3] - c[6], c[4] - c[7], c[5] - c[8]);
+    if (e01_out) *e01_out = fmaxf(e0, e1);
     float delta = ((e0 + e1) + e2) / 3.0f;
     float t = delta * RRL_CTHR;
     float thr = t / 2.0f;

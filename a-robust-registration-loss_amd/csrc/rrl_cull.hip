@@ -71,12 +71,19 @@
 //
 // NaN (negative sqrt argument; the reference prints and exits, code/loss.py:88-91): provably
 // impossible when g <= 0 for every line of the wavefront (A^2 < 111; all unit-scale training data).
-// Otherwise (g > 0, e.g. the demo's full-diagonal radius) it is detected on every pair that is evaluated
-// EXACTLY: all three points of every prefilter candidate -- which includes every triangle whose point 0
-// could produce one (x_ref(P0) < 0 needs Q(P0) < g: a "hit" with thr2 = 0, so its half sphere is reached
-// and its prefilter value is negative).  A negative argument at point 1 or 2 of a triangle that is not
-// a candidate is not evaluated, as in RRL_SCAN_LAZY; it needs rounding noise above 2e-4 + Q, which at
-// the demo's scale means > 11u |a|^2 of the 15u worst case (never observed).
+// Otherwise (g > 0, e.g. the demo's full-diagonal radius) the walk is WIDENED so that every pair that could
+// produce one is evaluated exactly (round 3; the detection equals the strict scan's):
+//   x_ref(P_k) < 0 for a point k of triangle f  =>  Q(P_k) < g  =>  sqrt(Q(P_k)) < se (|d| <= 1) resp.
+//   p(P_k) < se (|d| > 1) with the line's own se = sqrt(g + x)  =>  (1-Lipschitz, |P_k - P0| <= e01_f =
+//   max(|P1-P0|, |P2-P0|))  the same function of P0 is < se + e01_f, hence Q(P0) < (se + e01_f)^2, and of the
+//   centre of any sphere that bounds the triangle's P0: < rho + se + max e01.
+// The records kernel stores del_f >= e01_f - thr_f (clamped at 0, DEL1 / DEL2); a workgroup that holds a
+// wavefront with g > 0 ("nanwide") gathers del for its 512 staged records, widens every staged node radius
+// by the node's max del (rho + e01 <= rho + thr_max + max del <= Rs + max del) and the prefilter constant of
+// every record to max(thr2 - 2e-4, (se + sqrt(thr2) + del_f)^2) (+ the same evaluation slack): a triangle
+// whose point 0, 1 or 2 could see a negative argument is then a prefilter candidate, resolve_candidate
+// evaluates its three points with the reference's arithmetic and raises STATUS[0].  Unit-scale data never
+// takes this branch (one uniform test per workgroup); at the demo's scale it costs ~15 % more node passes.
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -114,6 +121,9 @@ struct BuildArgs {
     size_t g1_vec4;
     uint4 *z2;                     // global cell histogram / cursors of the wide sort (may be NULL)
     size_t z2_vec4;
+    uint4 *z3;                     // per-call state of the tiled reduce (MHIST, MCTL, MSUM; may be NULL)
+    size_t z3_vec4;
+    float *del1, *del2;            // NaN reach of every triangle (may be NULL: not stored)
     int B, N, M, transpose_r, nblk;
     int nchunk;                    // tri_sort_kernel: chunks of 4096 records per cloud (1: the whole cloud)
 };
@@ -131,13 +141,14 @@ __global__ __launch_bounds__(REC_BLK) void tri_records_kernel(const BuildArgs a)
         for (size_t i = me; i < a.zero_vec4; i += nthr) a.zero_base[i] = z;
         for (size_t i = me; i < a.g1_vec4; i += nthr) a.g1[i] = z;
         for (size_t i = me; i < a.z2_vec4; i += nthr) a.z2[i] = z;
+        for (size_t i = me; i < a.z3_vec4; i += nthr) a.z3[i] = z;
     }
     const int n = cloud ? a.M : a.N;
     const int f = blockIdx.x * REC_BLK + tid;
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY}, p2 = 0.0f;
     if (f < n) {
         const float *raw = (cloud ? a.tri2 : a.tri1) + ((size_t)b * n + f) * 9;
-        float c[9], thr, x;
+        float c[9], thr, x, e01;
 #pragma unroll
         for (int i = 0; i < 9; ++i) c[i] = raw[i];
         if (cloud == 0 && a.R != nullptr) {
@@ -160,7 +171,11 @@ __global__ __launch_bounds__(REC_BLK) void tri_records_kernel(const BuildArgs a)
 #pragma unroll
             for (int i = 0; i < 9; ++i) moved[i] = c[i];
         }
-        tri_thresholds(c, &thr, &x);  // code/loss.py:94-110
+        tri_thresholds(c, &thr, &x, &e01);  // code/loss.py:94-110
+        // NaN reach (culled scan, "NaN detection" in the header): points 1, 2 lie within e01 of point 0, and the
+        // tree nodes carry thr: del >= e01 - thr in exact arithmetic (e01, thr as rounded here: <= 3u off)
+        if (float *del = cloud ? a.del2 : a.del1)
+            del[(size_t)b * n + f] = fmaxf(e01 * 1.000002f - thr, 0.0f) * 1.000001f;
         float4 *row = (float4 *)((cloud ? a.ptri2 : a.ptri1) + ((size_t)b * n + f) * PTRI_STRIDE);
         row[0] = make_float4(c[0], c[1], c[2], c[3]);
         row[1] = make_float4(c[4], c[5], c[6], c[7]);
@@ -831,18 +846,23 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(6, 8))
     const float4 *__restrict__ p0s2, const int32_t *__restrict__ idx1, const int32_t *__restrict__ idx2,
     const float4 *__restrict__ tree1, const float4 *__restrict__ tree2, const float *__restrict__ line,
     int32_t *__restrict__ count1, int32_t *__restrict__ hit1, int32_t *__restrict__ count2,
-    int32_t *__restrict__ hit2, int32_t *__restrict__ status, const uint32_t *__restrict__ pmax, int B,
+    int32_t *__restrict__ hit2, int32_t *__restrict__ status, const uint32_t *__restrict__ pmax,
+    const float *__restrict__ del1, const float *__restrict__ del2, int B,
     int N, int M, int L, int spw, unsigned long long *__restrict__ counters, long long counter_rows) {
     __shared__ __attribute__((aligned(16))) float2 line_lds[WPB][LPW * 3];    // 24 KiB: raw 24-byte line rows
     __shared__ __attribute__((aligned(16))) float4 rec_lds[SPW * SGG * ROWS]; //  8.5 KiB
     __shared__ __attribute__((aligned(16))) float4 node_lds[SPW * NODE];      //  1.6 KiB
-    __shared__ unsigned short qa_lds[WPB][QA_CAP], qb_lds[WPB][QB_CAP], qc_lds[WPB][QC_CAP];
-    __shared__ unsigned cands_lds[WPB][WCCAP];
-    __shared__ unsigned wg_slack[2];  // max over the workgroup's lines: bits of se, bits of A^2
+    __shared__ __attribute__((aligned(16))) unsigned short qa_lds[WPB][QA_CAP];
+    __shared__ unsigned short qb_lds[WPB][QB_CAP], qc_lds[WPB][QC_CAP];
+    __shared__ __attribute__((aligned(16))) unsigned cands_lds[WPB][WCCAP];
+    __shared__ unsigned wg_slack[3];  // max over the workgroup's lines: bits of se, bits of A^2; [2] a NaN is not excluded
+    __shared__ float sg_dn[SPW];      // nanwide workgroups: NaN reach of the slice's supergroup nodes (level A)
+    static_assert(WPB * WCCAP >= SPW * SGT && WPB * QA_CAP * sizeof(unsigned short) >= SPW * NODE * sizeof(float),
+                  "the NaN-reach scratch aliases the (still unused) candidate and level-A queue buffers");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform for the compiler
     const unsigned long long wall0 = COUNT ? wall_clock64() : 0ull;
-    if (tid < 2) wg_slack[tid] = 0u;
+    if (tid < 3) wg_slack[tid] = 0u;
     unsigned long long *crow = nullptr;
     if constexpr (COUNT) {
         const long long wid = (((long long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + wave;
@@ -920,26 +940,55 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(6, 8))
     __syncthreads();  // wg_slack cleared
     if (has_lines && !fallback) {
         const float se_w = wave_max(fmaxf(ls0.se, ls1.se)), a2_w = wave_max(fmaxf(ls0.a2, ls1.a2));
+        const bool nanfree_w = __all(ls0.nanfree && ls1.nanfree);
         if (lane == 0) {  // non-negative floats: unsigned order == float order
             atomicMax(&wg_slack[0], __float_as_uint(se_w));
             atomicMax(&wg_slack[1], __float_as_uint(a2_w));
+            if (!nanfree_w) atomicOr(&wg_slack[2], 1u);
         }
     }
     __syncthreads();
     const float se = __uint_as_float(wg_slack[0]);
+    const bool nanwide = wg_slack[2] != 0u;  // uniform: some culled wavefront's lines could see a negative sqrt argument
     // point-0 prefilter (header): 44.2 u A^2 of evaluation error on both sides, rounded up, + an absolute floor
     const float s0 = 3.0e-6f * __uint_as_float(wg_slack[1]) + 1.0e-9f;
 
     // ---- stage the slice: records (padded rows) and tree nodes, slacks folded in
     //   (P0, thr2) -> (P0, c): c = -(thr2 - 2e-4 + slack), slightly widened; pad records never pass
     //   (centre, Rs) -> (centre, (Rs + se)^2 rounded up); NaN (empty node) stays NaN
+    // nanwide (header, "NaN"): the NaN reach del of the slice's records and its maxima over the nodes, through
+    // buffers the walk does not use yet
+    float *dl = (float *)&cands_lds[0][0];  // [SPW * SGT]
+    float *dn = (float *)&qa_lds[0][0];     // [SPW * NODE]
+    if (nanwide) {
+        const float *del = (cloud ? del2 : del1) + (size_t)b * n;
+        for (int i = tid; i < nsl * SGT; i += blockDim.x) {
+            const int sp = sg0 * SGT + i;
+            dl[i] = sp < n ? del[idx[sp]] : 0.0f;
+        }
+        __syncthreads();
+        for (int i = tid; i < nsl * NODE; i += blockDim.x) {  // node j of supergroup sg: [0] all 64, [1..4] 16 each, [5..12] 8 each
+            const int sg = i / NODE, j = i - sg * NODE;
+            const int o = j == 0 ? 0 : (j < 5 ? (j - 1) * GRP : (j - 5) * (GRP / 2)), cnt = j == 0 ? SGT : (j < 5 ? GRP : GRP / 2);
+            float m = 0.0f;
+            for (int t = 0; t < cnt; ++t) m = fmaxf(m, dl[sg * SGT + o + t]);
+            dn[i] = m;
+            if (j == 0) sg_dn[sg] = m;
+        }
+        __syncthreads();
+    }
     auto stage_rec = [&](int i, float4 r) {
-        const float tp = r.w - RRL_EPS;
+        float tp = r.w - RRL_EPS;
+        if (nanwide) {  // also a candidate when point 1 or 2 could see a negative argument: Q(P0) < (se + e01)^2
+            const float reach = se + sqrtf(r.w) * 1.000001f + dl[i];  // e01 <= thr + del <= sqrt(thr2) + del
+            tp = fmaxf(tp, reach * reach * 1.000002f);
+        }
         r.w = sg0 * SGT + i < n ? -(tp + 1.0e-6f * fabsf(tp) + s0) : INFINITY;
         rec_lds[(i >> 4) * ROWS + (i & 15)] = r;
     };
     auto stage_node = [&](int i, float4 nd) {
-        const float rt = nd.w + se;
+        float rt = nd.w + se;
+        if (nanwide) rt += dn[i];
         nd.w = rt * rt * 1.0000003f;
         node_lds[i] = nd;
     };
@@ -1002,7 +1051,9 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(6, 8))
 #pragma unroll
         for (int c = 0; c < 4; ++c) nxt[c] = gp[4 * NODE * sn + c];
         const float cx = cur[0], cy = cur[1], cz = cur[2];
-        const float Rt = cur[3] + se, R2 = Rt * Rt;  // NaN (empty node) fails both comparisons
+        float Rt = cur[3] + se;
+        if (nanwide) Rt += sg_dn[s];  // uniform
+        const float R2 = Rt * Rt;     // NaN (empty node) fails both comparisons
         const v2f ax = cx - ox, ay = cy - oy, az = cz - oz;
         const v2f dot = __builtin_elementwise_fma(az, uz, __builtin_elementwise_fma(ay, uy, ax * ux));
         const v2f q = __builtin_elementwise_fma(az, az, __builtin_elementwise_fma(ay, ay, ax * ax));
@@ -1087,6 +1138,10 @@ int rrl_launch_tri_build(const float *tri1, const float *tri2, void *ws, const W
     a.g1_vec4 = a.g1 ? (w.off[RRL_WS_KJC] - w.off[RRL_WS_GACC]) / 16 : 0;
     a.z2 = nmax > 4096 && !chunked ? (uint4 *)((char *)ws + w.off[RRL_WS_HISTG]) : nullptr;
     a.z2_vec4 = a.z2 ? (size_t)2 * B * 2 * SORT_CELLS * sizeof(unsigned) / 16 : 0;
+    a.z3 = (uint4 *)((char *)ws + w.state_off);
+    a.z3_vec4 = w.state_bytes / 16;
+    a.del1 = w.f32(ws, RRL_WS_DEL1);
+    a.del2 = w.f32(ws, RRL_WS_DEL2);
     a.B = B; a.N = N; a.M = M;
     a.transpose_r = xf ? xf->transpose_r : 0;
     const int nall = N > M ? N : M;  // APART is laid out for the larger cloud
@@ -1174,7 +1229,8 @@ int rrl_launch_cull_scan(const float *line, void *ws, const WsLayout &w, int B, 
                        w.i32(ws, RRL_WS_IDX1), w.i32(ws, RRL_WS_IDX2), (const float4 *)w.f32(ws, RRL_WS_GRP1), \
                        (const float4 *)w.f32(ws, RRL_WS_GRP2), line, w.i32(ws, RRL_WS_COUNT1),               \
                        w.i32(ws, RRL_WS_HIT1), w.i32(ws, RRL_WS_COUNT2), w.i32(ws, RRL_WS_HIT2),             \
-                       w.i32(ws, RRL_WS_STATUS), (const uint32_t *)w.i32(ws, RRL_WS_PMAX), B, N, M, L, spw, \
+                       w.i32(ws, RRL_WS_STATUS), (const uint32_t *)w.i32(ws, RRL_WS_PMAX),                   \
+                       w.f32(ws, RRL_WS_DEL1), w.f32(ws, RRL_WS_DEL2), B, N, M, L, spw,                      \
                        g_cull_counters, g_cull_counter_rows)
     if (g_cull_counters) RRL_CULL_LAUNCH(true);
     else RRL_CULL_LAUNCH(false);

@@ -150,6 +150,8 @@ int rrl_tri_prepare_clouds(const float *tri1, const float *tri2, void *ws, size_
         // one fill clears status, nvals, nsel, pmax, count1, count2 (contiguous by construction)
         int rc = rrl_fill(zb, 0u, w.zero_bytes, s);
         if (rc) return rc;
+        // ... and one more the tiled reduce's state (MHIST, MCTL, MSUM)
+        if ((rc = rrl_fill((char *)ws + w.state_off, 0u, w.state_bytes, s))) return rc;
     }
     if (B == 0 || nmax == 0) return 0;
     if (sorted) return rrl_launch_tri_build(tri1, tri2, ws, w, B, N, M, clouds, xf, s);

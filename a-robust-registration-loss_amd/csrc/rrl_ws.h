@@ -7,6 +7,7 @@
 struct WsLayout {
     size_t off[RRL_WS_FIELDS];
     size_t total, zero_bytes;
+    size_t state_off, state_bytes;  // MHIST .. MSUM: the tiled reduce's per-call state (cleared by the records kernel)
 
     __host__ WsLayout(int B, int N, int M, int L) {
         const size_t b = (size_t)(B > 0 ? B : 0), n = (size_t)(N > 0 ? N : 0),
@@ -52,12 +53,19 @@ struct WsLayout {
             b * ((l + 1023) / 1024) * 1024,              // KJC
             4 * b * ((l + 1023) / 1024 + 1),             // BLKCNT
             (n > 4096 || m > 4096) ? 4 * 2 * b * 2 * 4096 : 16,  // HISTG (wide sort of large clouds)
+            4 * b * n,           // DEL1
+            4 * b * m,           // DEL2
+            4 * b * 2048,        // MHIST  (MHIST .. MSUM: contiguous, cleared per call: state_bytes)
+            4 * b * 64,          // MCTL
+            8 * b * 32,          // MSUM
+            4 * b * 2048,        // MCAND
         };
         size_t o = 0;
         for (int i = 0; i < RRL_WS_FIELDS; ++i) {
             off[i] = o;
             o += (bytes[i] + 255) & ~(size_t)255;
             if (i == RRL_WS_COUNT2) zero_bytes = o;
+            if (i == RRL_WS_MSUM) { state_off = off[RRL_WS_MHIST]; state_bytes = o - state_off; }
         }
         total = o;
     }
@@ -65,6 +73,7 @@ struct WsLayout {
     __host__ int32_t *i32(void *ws, int f) const { return (int32_t *)((char *)ws + off[f]); }
     __host__ uint8_t *u8(void *ws, int f) const { return (uint8_t *)((char *)ws + off[f]); }
     __host__ int64_t *i64(void *ws, int f) const { return (int64_t *)((char *)ws + off[f]); }
+    __host__ uint32_t *u32(void *ws, int f) const { return (uint32_t *)((char *)ws + off[f]); }
     __host__ const float *f32(const void *ws, int f) const { return (const float *)((const char *)ws + off[f]); }
     __host__ const int32_t *i32(const void *ws, int f) const { return (const int32_t *)((const char *)ws + off[f]); }
     __host__ const uint8_t *u8(const void *ws, int f) const { return (const uint8_t *)((const char *)ws + off[f]); }

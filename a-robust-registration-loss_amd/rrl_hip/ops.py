@@ -54,6 +54,12 @@ _WS_FIELDS = [
     ("kjc", torch.uint8, lambda B, N, M, L, G: (B, (L + 1023) // 1024 * 1024)),
     ("blkcnt", torch.int32, lambda B, N, M, L, G: (B * ((L + 1023) // 1024 + 1),)),
     ("histg", torch.int32, lambda B, N, M, L, G: (2 * B * 2 * 4096 if max(N, M) > 4096 else 4,)),
+    ("del1", torch.float32, lambda B, N, M, L, G: (B, N)),
+    ("del2", torch.float32, lambda B, N, M, L, G: (B, M)),
+    ("mhist", torch.int32, lambda B, N, M, L, G: (B, 2048)),
+    ("mctl", torch.int32, lambda B, N, M, L, G: (B, 64)),
+    ("msum", torch.int64, lambda B, N, M, L, G: (B, 32)),
+    ("mcand", torch.int32, lambda B, N, M, L, G: (B, 2048)),
 ]
 _layout_cache = {}
 _FIELD_INDEX = {name: i for i, (name, _, _) in enumerate(_WS_FIELDS)}

@@ -53,15 +53,15 @@ extern "C" {
                              (DESIGN.md "culling bound"); there a conservative FMA prefilter on point 0
                              picks the candidates (~3 %) and the reference's own arithmetic decides on
                              all three points of those: labels, hit lists and the loss equal strict's
-                             bit for bit.  NaN detection equals strict's
-                             wherever a NaN is provably impossible ((|x0| + max|P|)^2 < 111 and
-                             |dir|^2 <= 1 + 1e-6: none exists) and for lines with |dir|^2 > 1 + 1e-6
-                             or non-finite data (their wavefront of 128 lines runs the strict loop;
-                             STATUS[1] counts such wavefronts).  For unit directions at larger scale
-                             (the demo's full-diagonal radius) a negative sqrt argument is reported
-                             when it occurs in an exactly EVALUATED pair: the three points of every
-                             prefilter candidate, which include point 0 of every triangle that could
-                             produce one.  Needs N, M <= 65536, else behaves like AUTO. */
+                             bit for bit.  NaN detection equals strict's at
+                             every scale (round 3): where (|x0| + max|P|)^2 < 111 and |dir|^2 <= 1 + 1e-6 a NaN
+                             is provably impossible; lines with |dir|^2 > 1 + 1e-6 or non-finite data send
+                             their wavefront of 128 lines through the strict loop (STATUS[1] counts such
+                             wavefronts); for unit directions at larger scale (the demo's full-diagonal
+                             radius) the walk is widened by every triangle's NaN reach (DEL1 / DEL2), so
+                             that each triangle one of whose three points could see a negative sqrt
+                             argument is evaluated exactly (csrc/rrl_cull.hip, "NaN").
+                             Needs N, M <= 65536, else behaves like AUTO. */
 
 /* workspace fields (indices into rrl_workspace_layout's offset array) */
 enum {
@@ -110,6 +110,14 @@ enum {
     RRL_WS_KJC,        /* uint8[B][Lp]  k | j<<4 at the compact slots                            */
     RRL_WS_BLKCNT,     /* int32[B][ceil(L/1024)] selected lines per 1024-line tile               */
     RRL_WS_HISTG,      /* uint32[2 B][2][4096] cell counts and cursors of the wide sort (clouds > 4096) */
+    RRL_WS_DEL1,       /* float[B][N]  NaN reach of a triangle: max(|P1-P0|, |P2-P0|) - thr, clamped at 0, rounded up: how   */
+    RRL_WS_DEL2,       /* float[B][M]  much farther than thr points 1, 2 can sit from point 0 (culled scan, NaN detection)   */
+    RRL_WS_MHIST,      /* uint32[B][2048] histogram of the D values' bits 30..20, accumulated by the per-line stage (the
+                          median's first radix pass); MHIST, MCTL, MSUM are contiguous and cleared per call                 */
+    RRL_WS_MCTL,       /* uint32[B][64]  [0..15] lines per (k,j) bucket (per-line stage); [16] candidate cursor, [17] / [18]
+                          arrival counters of the tiled reduce, [19] its error flag (spin time-out)                          */
+    RRL_WS_MSUM,       /* uint64[B][32]  bucket sums of the tiled reduce (2^-40 fixed point, device atomics)                */
+    RRL_WS_MCAND,      /* uint32[B][2048] D values (bit patterns) of the median's bin, gathered by the tiled reduce          */
     RRL_WS_FIELDS
 };
 

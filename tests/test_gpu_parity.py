@@ -1070,9 +1070,9 @@ def test_cull_is_exact_at_any_scale(L, scale, far):
     ln = lines[0].cpu().numpy()
     c = run_state(tri1, tri2, ln, mode="cull")
     s_ = run_state(tri1, tri2, ln, mode="strict")
-    # beyond the provably NaN-free scale the culled scan reports a negative sqrt argument on evaluated
-    # pairs only (include/rrl.h RRL_SCAN_CULL): never a flag that strict does not raise
-    assert int(c.status[1]) == 0 and int(c.status[0]) <= int(s_.status[0])
+    # the NaN flag (the reference's print-and-exit, code/loss.py:88-91) equals the strict scan's at every scale:
+    # beyond the provably NaN-free one the walk is widened by the triangles' NaN reach (rrl_cull.hip, "NaN")
+    assert int(c.status[1]) == 0 and int(c.status[0]) == int(s_.status[0])
     if scale == 1.0:
         assert int(s_.status[0]) == 0
     for a, b in ((c.count1, s_.count1), (c.count2, s_.count2)):
@@ -1084,6 +1084,54 @@ def test_cull_is_exact_at_any_scale(L, scale, far):
             assert sorted(hc[l, :k[l]].tolist()) == sorted(hs[l, :k[l]].tolist())
     assert c.loss[0].item() == s_.loss[0].item()
     assert int((c.count1 > 0).sum()) > 100  # not degenerate: lines do hit
+
+
+@pytest.mark.parametrize("scale", [12.0, 300.0, 5000.0])
+def test_cull_nan_detection_equals_strict(L, oracle, scale):
+    """A negative sqrt argument at point 1 of a triangle that is NO point-0 candidate (its P0 sits far from the
+    line, farther than thr and than the prefilter's slack): the reference flags a NaN on ANY pair
+    (code/loss.py:88-91), the strict scan does, and the culled scan must too -- its walk is widened by every
+    triangle's NaN reach max(|P1-P0|, |P2-P0|) - thr wherever a NaN is not provably impossible.  Constructed:
+    64 triangles with P1 exactly on "their" line, P0 at 0.04 * scale from it (thr = 0.58 of that), P2 next to P0;
+    beyond the provably NaN-free scale rounding decides the sign of |a|^2 - (a.d)^2 + 2e-4 for the on-line point."""
+    from rrl_hip import synth, ops
+    rng = np.random.default_rng(3)
+    pr = synth.make_pair(78, 1200, 900)
+    sc = np.float32(scale)
+    tri1, tri2 = pr["src_tri"] * sc, pr["tar_tri"] * sc
+    rands = synth.uniform_streams(5, 10, 3000)
+    lines, _ = ops.sample_lines(torch.from_numpy(rands)[:, :, None, :], torch.tensor([pr["radius"] * scale]),
+                                torch.from_numpy(np.asarray(pr["center"] * sc, np.float32))[None],
+                                ops.aabb(cu(tri1[None, :, :3])), ops.aabb(cu(tri2[None, :, :3])))
+    ln = lines[0].cpu().numpy()
+    ln = ln[np.abs(ln).sum(1) > 0]
+    ns = 64
+    d = rng.standard_normal((ns, 3))
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    d = (d.astype(np.float64) / np.linalg.norm(d.astype(np.float64), axis=1, keepdims=True)).astype(np.float32)
+    x0 = (rng.standard_normal((ns, 3)) * 0.7 * scale).astype(np.float32)
+    t = rng.uniform(0.3, 0.9, (ns, 1)) * scale
+    P1 = (x0.astype(np.float64) + t * d.astype(np.float64)).astype(np.float32)            # on the line, up to rounding
+    nrm = np.cross(d.astype(np.float64), rng.standard_normal((ns, 3)))
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    P0 = (P1.astype(np.float64) + 0.04 * scale * nrm).astype(np.float32)                  # far from the line: no hit
+    P2 = (P0.astype(np.float64) + 0.0002 * scale * rng.standard_normal((ns, 3))).astype(np.float32)
+    special = np.concatenate([P0, P1, P2], 1).astype(np.float32)
+    tri1s = np.concatenate([tri1, special]).astype(np.float32)
+    lns = np.concatenate([ln, np.concatenate([d, x0], 1)]).astype(np.float32)
+    c = run_state(tri1s, tri2, lns, mode="cull")
+    s_ = run_state(tri1s, tri2, lns, mode="strict")
+    assert int(c.status[1]) == 0  # unit directions: nobody left the culled walk
+    assert int(c.status[0]) == int(s_.status[0])
+    assert bool(int(s_.status[0])) == (oracle.scan(tri1s, lns, cap=4)["nan"] or oracle.scan(tri2, lns, cap=4)["nan"])
+    if scale >= 300.0:
+        assert int(s_.status[0]) == 1  # the construction does produce negative arguments there
+    np.testing.assert_array_equal(c.count1.cpu().numpy(), s_.count1.cpu().numpy())
+    np.testing.assert_array_equal(c.count2.cpu().numpy(), s_.count2.cpu().numpy())
+    # and the drop-in call raises like the reference exits
+    if int(s_.status[0]):
+        with pytest.raises(ValueError, match="NaN"):
+            L.cal_loss_intersection_batch_whole_median_pts_lines(1, 1, 5, 5, cu(tri1s)[None], cu(tri2)[None], cu(lns)[None], "cuda")
 
 
 def test_scan_counters(L):
