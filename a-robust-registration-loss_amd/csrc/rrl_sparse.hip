@@ -75,6 +75,7 @@ __device__ __forceinline__ void pair_hit(const float *__restrict__ tri1, const f
                                          float *__restrict__ w2, float4 *__restrict__ Q1,
                                          float4 *__restrict__ Q2, float *__restrict__ D,
                                          float *__restrict__ dc_slot, float4 *s_q /* LDS [8] of this line */,
+                                         unsigned *s_mh /* LDS [2048] or NULL */,
                                          int b, int N, int M, size_t gl, int k, int j, int sub, int st1,
                                          int st2) {
     const int cloud = sub >> 2, a = sub & 3;
@@ -123,6 +124,8 @@ __device__ __forceinline__ void pair_hit(const float *__restrict__ tri1, const f
             sq = sq + dz * dz;
             D[gl * 16 + ra * j + rb] = sq;
             t2[e] = sq;
+            // the median's first radix pass (bits 30..20 of the bit pattern; D >= 0), tallied where the value is born
+            if (s_mh) atomicAdd(&s_mh[(__float_as_uint(sq) >> 20) & 2047u], 1u);
         }
     }
     ((float2 *)dc_slot)[sub] = make_float2(t2[0], t2[1]);
@@ -138,6 +141,7 @@ struct PairArgs {
     float *D, *dc;
     uint8_t *kjc;
     int32_t *blkcnt;
+    uint32_t *mhist, *mctl;  // tiled reduce: per-sample histogram of the D values' top 11 bits, bucket counts (or NULL)
     int B, N, M, L, s_m, s_n, e_m, e_n, st1, st2;
 };
 
@@ -149,9 +153,17 @@ __device__ __forceinline__ void pair_body(const PairArgs &a, int b, int tile, in
     __shared__ int s_wave[16];
     __shared__ int s_total;
     __shared__ float4 s_q[128][8];  // intersection points of the lines of one pass
+    __shared__ unsigned s_mh[2048];  // this tile's share of MHIST
+    __shared__ unsigned s_bc[16];    // ... and of the bucket counts
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int L = a.L;
     int base_reg = 0;
+    const bool tally = a.mhist != nullptr;  // uniform
+    if (tally) {  // (the barriers of phase 1 publish the clearing)
+        s_mh[tid] = 0u;
+        s_mh[tid + 1024] = 0u;
+        if (tid < 16) s_bc[tid] = 0u;
+    }
     {
         const int l = tile * 1024 + tid;
         bool sel = false;
@@ -166,6 +178,7 @@ __device__ __forceinline__ void pair_body(const PairArgs &a, int b, int tile, in
         const unsigned long long mask = __ballot(sel);
         if (lane == 0) s_wave[wave] = __popcll(mask);
         __syncthreads();
+        if (sel && tally) atomicAdd(&s_bc[((kjb & 15u) - 1u) * 4u + ((kjb >> 4) - 1u)], 1u);
         if (tid == 0) {
             int acc = 0;
             for (int w = 0; w < 16; ++w) { int c = s_wave[w]; s_wave[w] = acc; acc += c; }
@@ -196,8 +209,18 @@ __device__ __forceinline__ void pair_body(const PairArgs &a, int b, int tile, in
             const size_t slot = (size_t)b * Lp + (size_t)tile * 1024 + rank;
             if (sub == 0) a.kjc[slot] = (uint8_t)(k | (j << 4));
             pair_hit(a.tri1, a.tri2, a.line, a.hit1, a.hit2, a.hs1, a.hs2, a.w1, a.w2, a.Q1, a.Q2, a.D, a.dc + slot * 16,
-                     s_q[tid >> 3], b, a.N, a.M, gl, k, j, sub, a.st1, a.st2);
+                     s_q[tid >> 3], tally ? s_mh : nullptr, b, a.N, a.M, gl, k, j, sub, a.st1, a.st2);
         }
+    }
+    if (tally) {  // flush the tile's tallies: <= one device atomic per populated bin and workgroup
+        __syncthreads();
+        uint32_t *mh = a.mhist + (size_t)b * 2048;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const unsigned v = s_mh[tid + 1024 * q];
+            if (v) atomicAdd(&mh[tid + 1024 * q], v);
+        }
+        if (tid < 16 && s_bc[tid]) atomicAdd(&a.mctl[(size_t)b * 64 + tid], s_bc[tid]);
     }
     if (wave == 0) {
         const int base = __builtin_amdgcn_readfirstlane(base_reg);
@@ -210,8 +233,10 @@ __global__ __launch_bounds__(1024) void line_pair_dist_kernel(const PairArgs a) 
 }
 
 static PairArgs pair_args(const float *tri2_raw, const float *line, void *ws, const WsLayout &w, int B, int N, int M,
-                          int L, int s_m, int s_n, int e_m, int e_n) {
+                          int L, int s_m, int s_n, int e_m, int e_n, bool tally = true) {
     PairArgs a;
+    a.mhist = tally ? w.u32(ws, RRL_WS_MHIST) : nullptr;
+    a.mctl = tally ? w.u32(ws, RRL_WS_MCTL) : nullptr;
     a.tri1 = w.f32(ws, RRL_WS_PTRI1);
     a.tri2 = tri2_raw ? tri2_raw : w.f32(ws, RRL_WS_PTRI2);
     a.line = line;
@@ -645,6 +670,360 @@ __device__ __forceinline__ void reduce_body(const ReduceArgs &ra, int g) {
 
 __global__ __launch_bounds__(1024) void loss_reduce_kernel(const ReduceArgs ra) { reduce_body(ra, (int)blockIdx.x); }
 
+// ---------------------------------------------------------------------------------------
+// K3+K4, TILED (round 3): one 256-lane workgroup per 1024-line tile of the per-line stage instead of one
+// 1024-lane workgroup per sample.  The single workgroup was bound by ONE compute unit: 11.3 us at C2 on 8 of
+// 256 CUs, 24.7 us at the demo's shape (2600 selected lines of one sample through one CU).  Here
+//   * the median's first radix pass (top 11 bits) arrives as a per-sample histogram that the per-line stage
+//     tallied where the D values were born (MHIST) -- complete at the kernel boundary, so EVERY workgroup of a
+//     sample finds the median's bin, the rank inside it and n by itself, without talking to anyone;
+//   * the values of that bin (~n / 20) are published to a per-sample list (MCAND; one returning cursor atomic
+//     per wavefront, write-through stores), the sample's workgroups meet at an arrival counter, and each then
+//     finishes the select on the whole list by itself (the wave-private passes of the single-workgroup
+//     kernel): one hop, no broadcast of the result;
+//   * every workgroup adds the Welsch terms of its own lines to the sample's fixed-point bucket sums (MSUM,
+//     64-bit device atomics: order-independent, so the loss keeps its bits) and the LAST one to arrive at a
+//     second counter turns them into the loss.
+// Cross-workgroup words follow the guide's hand-off rules: relaxed agent-scope atomic stores / loads (sc1:
+// write-through, L1-bypassing), every storing wavefront drains (s_waitcnt vmcnt(0)) before its workgroup
+// arrives, one lane polls.  The spin needs the sample's workgroups co-resident: the host takes this path only
+// while B x tiles <= 1024 workgroups of 256 lanes (4 per CU) and bounds every spin (MCTL[19] + a NaN loss
+// instead of a hang).  More than 2048 values in the bin (near-identical D values): tile 0 finishes the
+// select alone with two more streaming passes and publishes the median; the others wait for it.
+// Same arithmetic and summation rules as reduce_body: bit-identical median and loss.
+// ---------------------------------------------------------------------------------------
+#define MCTL_CURSOR 16
+#define MCTL_TICK1 17
+#define MCTL_TICK2 18
+#define MCTL_ERR 19
+#define MCTL_MEDBITS 20
+#define MCTL_MEDRDY 21
+#define MCTL_BAD 22
+#define MCAND_CAP 2048
+
+__device__ __forceinline__ unsigned ld_agent(const uint32_t *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent(uint32_t *p, unsigned v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// one lane polls one word until it reaches `want`; bounded (~1 s), so a lost workgroup becomes an error flag
+__device__ __forceinline__ bool spin_reach(const uint32_t *p, unsigned want) {
+    for (unsigned it = 0; it < (1u << 22); ++it) {
+        if (ld_agent(p) >= want) return true;
+        __builtin_amdgcn_s_sleep(2);
+    }
+    return false;
+}
+
+// The remaining 20 bits of the radix select by ONE wavefront over vals[0, ncand) in LDS (the values of the bin
+// `pre` chosen by the 11-bit pass; rk = rank inside it): three wave-private passes of 7 + 7 + 6 bits, 128-bin
+// histogram wh, no workgroup barrier.  Every lane returns the median's bit pattern.
+__device__ __forceinline__ unsigned wave_select20(const unsigned *vals, unsigned ncand, unsigned pre, unsigned rk,
+                                                  unsigned *wh, int lane) {
+#pragma unroll
+    for (int wp = 0; wp < 3; ++wp) {
+        const int sh = wp == 0 ? 13 : (wp == 1 ? 6 : 0);
+        const int width = wp == 2 ? 6 : 7;
+        const unsigned dmask = (1u << width) - 1u;
+        const int hi = sh + width;
+        wh[2 * lane] = 0;
+        wh[2 * lane + 1] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        for (unsigned i = lane; i < ncand; i += 64) {
+            const unsigned x = vals[i];
+            if (((x ^ pre) >> hi) == 0u) atomicAdd(&wh[(x >> sh) & dmask], 1u);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const unsigned h0 = wh[2 * lane], h1 = wh[2 * lane + 1];
+        const unsigned inc2 = (unsigned)wave_incl_scan((int)(h0 + h1));
+        const unsigned excl = inc2 - (h0 + h1);
+        const bool here = rk >= excl && rk < excl + h0 + h1;  // exactly one lane
+        const unsigned second = rk >= excl + h0 ? 1u : 0u;
+        const unsigned long long who = __ballot(here);
+        const int src = who ? __ffsll((long long)who) - 1 : 0;
+        pre |= (unsigned)__builtin_amdgcn_readlane((int)((2u * lane + second) << sh), src);
+        rk = (unsigned)__builtin_amdgcn_readlane((int)(rk - excl - (second ? h0 : 0u)), src);
+    }
+    return pre;
+}
+
+struct TiledArgs {
+    const uint8_t *kjc;
+    const float *dc;
+    const int32_t *blkcnt;
+    uint32_t *mhist, *mctl, *mcand;
+    unsigned long long *msum;
+    float *med_out;
+    int32_t *bcnt_out;
+    int64_t *bsum_out;
+    int32_t *info;
+    float *loss;
+    const int32_t *status;
+    int B, nblk, s_m, s_n, e_m, e_n;
+};
+
+__global__ __launch_bounds__(256) void loss_reduce_tiled_kernel(const TiledArgs a) {
+    __shared__ unsigned s_vals[MCAND_CAP];  // the bin's values (usual route) / histogram of the streaming passes
+    __shared__ unsigned s_wtot[4];
+    __shared__ unsigned s_pick[3];          // bin, rank inside it, its population
+    __shared__ unsigned s_whist[128];
+    __shared__ unsigned long long s_sum[32];
+    __shared__ unsigned s_flag[3];          // [0] spin ok, [1] this workgroup arrived last, [2] non-finite Welsch term
+    __shared__ unsigned s_med;
+    __shared__ float s_term[16];
+    __shared__ int s_cnt[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tile = blockIdx.x, b = blockIdx.y, nblk = a.nblk;
+    const size_t Lp = (size_t)nblk * 1024;
+    uint32_t *ctl = a.mctl + (size_t)b * 64;
+    uint32_t *cand = a.mcand + (size_t)b * MCAND_CAP;
+    const float *__restrict__ dc = a.dc;
+    const uint8_t *__restrict__ kjc = a.kjc;
+
+    // ---- one round of independent loads: the tile's count, its first 256 compact rows (speculative: the slots
+    //      exist whether or not they were written), the sample's histogram
+    const int cnt = a.blkcnt[(size_t)b * nblk + tile];
+    const size_t slot0 = (size_t)b * Lp + (size_t)tile * 1024;
+    float tl[16];
+    unsigned c0;
+    {
+        const float4 *row = (const float4 *)(dc + (slot0 + tid) * 16);
+        const float4 v0 = row[0], v1 = row[1], v2 = row[2], v3 = row[3];
+        c0 = kjc[slot0 + tid];
+        tl[0] = v0.x; tl[1] = v0.y; tl[2] = v0.z; tl[3] = v0.w; tl[4] = v1.x; tl[5] = v1.y; tl[6] = v1.z; tl[7] = v1.w;
+        tl[8] = v2.x; tl[9] = v2.y; tl[10] = v2.z; tl[11] = v2.w; tl[12] = v3.x; tl[13] = v3.y; tl[14] = v3.z; tl[15] = v3.w;
+    }
+    unsigned hb[8];
+    {
+        const uint4 *hp = (const uint4 *)(a.mhist + (size_t)b * 2048) + 2 * tid;
+        const uint4 h0 = hp[0], h1 = hp[1];
+        hb[0] = h0.x; hb[1] = h0.y; hb[2] = h0.z; hb[3] = h0.w; hb[4] = h1.x; hb[5] = h1.y; hb[6] = h1.z; hb[7] = h1.w;
+    }
+    if (tid < 32) s_sum[tid] = 0ull;
+    if (tid < 3) s_flag[tid] = tid == 0 ? 1u : 0u;
+    if (tid >= cnt) {  // not a selected line of this tile
+        c0 = 0u;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) tl[q] = INFINITY;
+    }
+
+    // ---- pick the bin of the rank among 2048 counts held 8 per lane (hb): exclusive scan over the workgroup,
+    //      the lane whose range holds the rank reports (bin, rank inside, population).  Returns the total.
+    auto pick_bin = [&](unsigned rank_or_none, bool have_rank) -> unsigned {
+        unsigned tsum = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) tsum += hb[k];
+        const unsigned incl = (unsigned)wave_incl_scan((int)tsum);
+        __syncthreads();  // s_wtot / s_pick free again
+        if (lane == 63) s_wtot[wave] = incl;
+        __syncthreads();
+        unsigned base = 0;
+        for (int w = 0; w < wave; ++w) base += s_wtot[w];
+        const unsigned total = s_wtot[0] + s_wtot[1] + s_wtot[2] + s_wtot[3];
+        const unsigned rank = have_rank ? rank_or_none : (total ? (total - 1) / 2 : 0u);  // lower median: sorted[(n - 1) / 2]
+        unsigned e = base + incl - tsum;
+        if (rank >= e && rank < e + tsum) {  // exactly one lane (none when total == 0)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (rank >= e && rank < e + hb[k]) { s_pick[0] = 8u * tid + k; s_pick[1] = rank - e; s_pick[2] = hb[k]; }
+                e += hb[k];
+            }
+        }
+        __syncthreads();
+        return total;
+    };
+    const unsigned n = pick_bin(0u, false);
+    if (n == 0) {  // nothing selected in this sample (the same for all its workgroups): loss 0, no bucket
+        if (tile == 0) {
+            if (tid < 16) a.bcnt_out[b * 16 + tid] = 0;
+            if (tid < 32) a.bsum_out[(size_t)b * 32 + tid] = 0;
+            if (tid == 0) {
+                a.med_out[b] = 0.0f;
+                a.loss[b] = 0.0f;
+                a.info[b * 4 + 0] = 0; a.info[b * 4 + 1] = 0; a.info[b * 4 + 2] = 0; a.info[b * 4 + 3] = a.status[0];
+            }
+        }
+        return;
+    }
+    const unsigned bin = s_pick[0], r1 = s_pick[1], pop = s_pick[2];
+    unsigned prefix = bin << 20;
+
+    // rows of this tile beyond the 256 held in registers (a tile has more than 256 selected lines only when more
+    // than a quarter of its lines are selected): re-read per phase
+    auto for_extra_rows = [&](auto &&fn) {
+        for (int i = tid + 256; i < cnt; i += 256) {
+            const float4 *row = (const float4 *)(dc + (slot0 + i) * 16);
+            float D_[16];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 v = row[q];
+                D_[4 * q] = v.x; D_[4 * q + 1] = v.y; D_[4 * q + 2] = v.z; D_[4 * q + 3] = v.w;
+            }
+            fn(D_, (unsigned)kjc[slot0 + i]);
+        }
+    };
+
+    if (pop <= MCAND_CAP) {
+        // ---- publish this tile's values of the bin, meet, read the whole list, finish the select
+        auto in_bin = [&](unsigned x) { return x != 0x7f800000u && (x >> 20) == bin; };
+        unsigned mine = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) mine += in_bin(__float_as_uint(tl[q])) ? 1u : 0u;
+        for_extra_rows([&](const float *D_, unsigned) {
+            for (int q = 0; q < 16; ++q) mine += in_bin(__float_as_uint(D_[q])) ? 1u : 0u;
+        });
+        const unsigned incl = (unsigned)wave_incl_scan((int)mine);
+        unsigned wbase = 0;
+        if (lane == 63 && incl) wbase = __hip_atomic_fetch_add(&ctl[MCTL_CURSOR], incl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        wbase = (unsigned)__builtin_amdgcn_readlane((int)wbase, 63);
+        unsigned at = wbase + incl - mine;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const unsigned x = __float_as_uint(tl[q]);
+            if (in_bin(x)) { if (at < MCAND_CAP) st_agent(&cand[at], x); ++at; }
+        }
+        for_extra_rows([&](const float *D_, unsigned) {
+            for (int q = 0; q < 16; ++q) {
+                const unsigned x = __float_as_uint(D_[q]);
+                if (in_bin(x)) { if (at < MCAND_CAP) st_agent(&cand[at], x); ++at; }
+            }
+        });
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wavefront drains before the workgroup arrives
+        __syncthreads();
+        if (tid == 0) {
+            __hip_atomic_fetch_add(&ctl[MCTL_TICK1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!spin_reach(&ctl[MCTL_TICK1], (unsigned)nblk)) s_flag[0] = 0u;
+        }
+        __syncthreads();
+        for (unsigned i = tid; i < pop; i += 256) s_vals[i] = ld_agent(&cand[i]);
+        __syncthreads();
+        if (tid < 64) {
+            const unsigned m = wave_select20(s_vals, pop, prefix, r1, s_whist, tid);
+            if (tid == 0) s_med = m;
+        }
+        __syncthreads();
+        prefix = s_med;
+    } else if (tile == 0) {
+        // ---- crowded bin: this workgroup alone streams over ALL the sample's values twice more (bits 19..9, 8..0)
+        unsigned rk = r1;
+        for (int pass = 1; pass <= 2; ++pass) {
+            const int sh = pass == 1 ? 9 : 0, width = pass == 1 ? 11 : 9, hi = sh + width;
+            const unsigned dmask = (1u << width) - 1u;
+            for (int i = tid; i < MCAND_CAP; i += 256) s_vals[i] = 0u;
+            __syncthreads();
+            for (int t = 0; t < nblk; ++t) {
+                const int ct = a.blkcnt[(size_t)b * nblk + t];
+                const float *base = dc + ((size_t)b * Lp + (size_t)t * 1024) * 16;
+                for (int i = tid; i < ct * 16; i += 256) {
+                    const unsigned x = __float_as_uint(base[i]);
+                    if (x != 0x7f800000u && ((x ^ prefix) >> hi) == 0u) atomicAdd(&s_vals[(x >> sh) & dmask], 1u);
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 8; ++k) hb[k] = s_vals[8 * tid + k];
+            pick_bin(rk, true);
+            prefix |= s_pick[0] << sh;
+            rk = s_pick[1];
+        }
+        if (tid == 0) {
+            st_agent(&ctl[MCTL_MEDBITS], prefix);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            st_agent(&ctl[MCTL_MEDRDY], 1u);
+        }
+    } else {
+        if (tid == 0) {
+            if (!spin_reach(&ctl[MCTL_MEDRDY], 1u)) s_flag[0] = 0u;
+            s_med = ld_agent(&ctl[MCTL_MEDBITS]);
+        }
+        __syncthreads();
+        prefix = s_med;
+    }
+    const float med = __uint_as_float(prefix);
+
+    // ---- Welsch terms of this tile's lines into the workgroup's fixed-point sums (as reduce_core::accumulate)
+    auto accumulate = [&](const float *Dl, int k, int j) {
+        float row = 0.0f, col = 0.0f;
+#pragma unroll
+        for (int q = 0; q < RRL_MAX_HITS; ++q)
+            if (q < k) row += welsch(fminf(fminf(Dl[q * 4], Dl[q * 4 + 1]), fminf(Dl[q * 4 + 2], Dl[q * 4 + 3])), med);
+#pragma unroll
+        for (int q = 0; q < RRL_MAX_HITS; ++q)
+            if (q < j) col += welsch(fminf(fminf(Dl[q], Dl[4 + q]), fminf(Dl[8 + q], Dl[12 + q])), med);
+        if (!(row <= 4.0f) || !(col <= 4.0f)) { atomicOr(&s_flag[2], 1u); row = col = 0.0f; }
+        const int bi = (k - 1) * 4 + (j - 1);
+        atomicAdd(&s_sum[bi * 2 + 0], (unsigned long long)((double)row * (double)(1ll << FIX_SHIFT) + 0.5));
+        atomicAdd(&s_sum[bi * 2 + 1], (unsigned long long)((double)col * (double)(1ll << FIX_SHIFT) + 0.5));
+    };
+    if (c0) accumulate(tl, (int)(c0 & 15u), (int)(c0 >> 4));
+    for_extra_rows([&](const float *D_, unsigned c) { if (c) accumulate(D_, (int)(c & 15u), (int)(c >> 4)); });
+    __syncthreads();
+    if (tid < 32) {
+        const unsigned long long v = s_sum[tid];
+        if (v) atomicAdd(&a.msum[(size_t)b * 32 + tid], v);
+    }
+    if (tid == 32 && (s_flag[2] || !s_flag[0])) {
+        if (s_flag[2]) atomicOr(&ctl[MCTL_BAD], 1u);
+        if (!s_flag[0]) atomicOr(&ctl[MCTL_ERR], 1u);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0)
+        s_flag[1] = __hip_atomic_fetch_add(&ctl[MCTL_TICK2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(nblk - 1) ? 1u : 0u;
+    __syncthreads();
+    if (!s_flag[1]) return;
+
+    // ---- the last workgroup of the sample: loss = ( sum_{non-empty (k,j), k-major} exp(-|k-j|/2) (mean_row + mean_col) ) / C
+    if (tid < 32) {
+        const unsigned long long v = __hip_atomic_load(&a.msum[(size_t)b * 32 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_sum[tid] = v;
+        a.bsum_out[(size_t)b * 32 + tid] = (int64_t)v;
+        __hip_atomic_store(&a.msum[(size_t)b * 32 + tid], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // a second reduce on this state starts clean
+    }
+    if (tid < 16) {
+        const int S = (int)ld_agent(&ctl[tid]);
+        s_cnt[tid] = S;
+        a.bcnt_out[b * 16 + tid] = S;
+    }
+    __syncthreads();
+    if (tid < 16) {  // one lane per bucket: the double-precision means (as reduce_body)
+        const int k = tid / 4 + 1, j = tid % 4 + 1, S = s_cnt[tid];
+        float term = 0.0f;
+        if (S > 0 && k >= a.s_m && k < a.e_m && j >= a.s_n && j < a.e_n) {
+            const double sc = 1.0 / (double)(1ll << FIX_SHIFT);
+            float mrow = (float)((double)s_sum[tid * 2 + 0] * sc / ((double)S * k));
+            float mcol = (float)((double)s_sum[tid * 2 + 1] * sc / ((double)S * j));
+            float wkj = expf(-0.5f * (float)abs(k - j));  // code/loss.py:215
+            term = wkj * (mrow + mcol);
+        }
+        s_term[tid] = term;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float acc = 0.0f;
+        int C = 0, nselected = 0, nvalues = 0;
+        for (int k = a.s_m; k < a.e_m; ++k)      // k-major, the reference's accumulation order
+            for (int j = a.s_n; j < a.e_n; ++j) {
+                const int bi = (k - 1) * 4 + (j - 1);
+                if (s_cnt[bi] == 0) continue;
+                acc = acc + s_term[bi];
+                ++C;
+                nselected += s_cnt[bi];
+            }
+        for (int bi = 0; bi < 16; ++bi) nvalues += s_cnt[bi] * (bi / 4 + 1) * (bi % 4 + 1);
+        const bool bad = ld_agent(&ctl[MCTL_BAD]) != 0u || ld_agent(&ctl[MCTL_ERR]) != 0u;
+        a.med_out[b] = med;
+        a.loss[b] = bad ? __builtin_nanf("") : (C ? acc / (float)C : 0.0f);  // code/loss.py:230
+        a.info[b * 4 + 0] = C;
+        a.info[b * 4 + 1] = nselected;
+        a.info[b * 4 + 2] = nvalues;
+        a.info[b * 4 + 3] = a.status[0];
+        st_agent(&ctl[MCTL_CURSOR], 0u); st_agent(&ctl[MCTL_TICK1], 0u); st_agent(&ctl[MCTL_TICK2], 0u);
+        st_agent(&ctl[MCTL_MEDRDY], 0u); st_agent(&ctl[MCTL_BAD], 0u);
+    }
+}
+
 // K2 + K3 + K4 in ONE launch when a sample has a single tile of lines (L <= 1024) and the samples are not pooled:
 // the workgroup that ran the per-line stage of sample b owns everything the reduce of sample b reads, so it
 // simply carries on (a launch and the reduce's first load round less: small-L shapes such as C5 are nothing
@@ -654,6 +1033,29 @@ __global__ __launch_bounds__(1024) void pair_reduce_kernel(const PairArgs pa, co
     __threadfence_block();  // this workgroup's KJC / VALS / BLKCNT stores are complete ...
     __syncthreads();        // ... before any of its lanes reads them back
     reduce_body(ra, (int)blockIdx.x);
+}
+
+// The tiled reduce (one workgroup per 1024-line tile; its workgroups spin on each other) is taken for independent
+// samples with at least two tiles while the whole grid is certainly co-resident: B x tiles <= 1024 workgroups of
+// 256 lanes = 4 per compute unit.  rrl_set_reduce_mode / RRL_REDUCE=single|tiled override (tiled still respects pool
+// and the bound; it then also serves a single tile).
+static int g_reduce_mode = -1;  // 0 auto, 1 single, 2 tiled; -1: read RRL_REDUCE once
+extern "C" int rrl_set_reduce_mode(int mode) {
+    if (mode < 0 || mode > 2) return RRL_E_ARG;
+    g_reduce_mode = mode;
+    return 0;
+}
+static int reduce_mode() {
+    if (g_reduce_mode < 0) {
+        const char *e = getenv("RRL_REDUCE");
+        g_reduce_mode = !e ? 0 : (e[0] == 's' ? 1 : (e[0] == 't' ? 2 : 0));
+    }
+    return g_reduce_mode;
+}
+static bool reduce_tiled(int B, int nblk, int pool) {
+    const int mode = reduce_mode();
+    if (pool || mode == 1 || (long)B * nblk > 1024) return false;
+    return mode == 2 ? nblk >= 1 : nblk >= 2;
 }
 
 static ReduceArgs reduce_args(void *ws, const WsLayout &w, float *loss, int B, int L, int s_m, int s_n, int e_m, int e_n,
@@ -675,6 +1077,18 @@ extern "C" int rrl_loss_reduce(void *ws, size_t ws_bytes, float *loss, int B, in
     if (ws_bytes < w.total) return RRL_E_WS;
     if (B == 0) return 0;
     const int nblk = (L + 1023) / 1024;
+    if (reduce_tiled(B, nblk, pool)) {
+        TiledArgs t;
+        t.kjc = w.u8(ws, RRL_WS_KJC); t.dc = w.f32(ws, RRL_WS_VALS); t.blkcnt = w.i32(ws, RRL_WS_BLKCNT);
+        t.mhist = w.u32(ws, RRL_WS_MHIST); t.mctl = w.u32(ws, RRL_WS_MCTL); t.mcand = w.u32(ws, RRL_WS_MCAND);
+        t.msum = (unsigned long long *)w.i64(ws, RRL_WS_MSUM);
+        t.med_out = w.f32(ws, RRL_WS_MED); t.bcnt_out = w.i32(ws, RRL_WS_BCNT); t.bsum_out = w.i64(ws, RRL_WS_BSUM);
+        t.info = w.i32(ws, RRL_WS_INFO); t.loss = loss; t.status = w.i32(ws, RRL_WS_STATUS);
+        t.B = B; t.nblk = nblk; t.s_m = s_m; t.s_n = s_n; t.e_m = e_m; t.e_n = e_n;
+        hipLaunchKernelGGL(loss_reduce_tiled_kernel, dim3((unsigned)nblk, (unsigned)B), dim3(256), 0, (hipStream_t)stream, t);
+        RRL_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(loss_reduce_kernel, dim3((unsigned)(pool ? 1 : B)), dim3(1024), sizeof(int) * (size_t)(nblk + 1),
                        (hipStream_t)stream, reduce_args(ws, w, loss, B, L, s_m, s_n, e_m, e_n, pool));
     RRL_LAUNCH_CHECK();
@@ -1033,12 +1447,12 @@ static int loss_forward_impl(const float *tri1, const float *tri2, const float *
         RrlRange r("K1 line<->triangle scan");
         if ((rc = rrl_line_tri_scan_clouds(line, ws, ws_bytes, B, N, M, L, mode, chunk, clouds, stream))) return rc;
     }
-    if (L >= 1 && L <= 1024 && !pool && B > 0 && L < (1 << 24)) {  // one tile of lines per sample: K2 + K3 + K4 in one launch
+    if (L >= 1 && L <= 1024 && !pool && B > 0 && reduce_mode() != 2) {  // one tile of lines per sample: K2 + K3 + K4 in one launch
         RrlRange r("K2 + K3 + K4 (single tile)");
         WsLayout w(B, N, M, L);
         if (ws_bytes < w.total) return RRL_E_WS;
         hipLaunchKernelGGL(pair_reduce_kernel, dim3((unsigned)B), dim3(1024), sizeof(int) * 2, (hipStream_t)stream,
-                           pair_args(target_ws ? tri2 : nullptr, line, ws, w, B, N, M, L, s_m, s_n, e_m, e_n),
+                           pair_args(target_ws ? tri2 : nullptr, line, ws, w, B, N, M, L, s_m, s_n, e_m, e_n, false),
                            reduce_args(ws, w, loss, B, L, s_m, s_n, e_m, e_n, 0));
         RRL_LAUNCH_CHECK();
         return 0;

@@ -31,6 +31,7 @@ _SIGS = {
     "rrl_shard_payload": [_P, _P, _Z, _P, _P, _P, _I, _I, _I, _I, _P],
     "rrl_set_scan_variant": [_I],
     "rrl_set_deterministic": [_I],
+    "rrl_set_reduce_mode": [_I],
     "rrl_scan_timing_enable": [_I],
     "rrl_scan_timing_collect": [_P, _I],
     "rrl_scan_counters": [_P, _c.c_longlong],

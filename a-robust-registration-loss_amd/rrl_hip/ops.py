@@ -460,6 +460,12 @@ def set_deterministic(on):
     check(_lib.load().rrl_set_deterministic(int(bool(on))), "rrl_set_deterministic")
 
 
+def set_reduce_mode(mode):
+    """Which reduce kernel the forwards launch: "auto" (tiled where legal and worthwhile), "single", "tiled"
+    (include/rrl.h rrl_set_reduce_mode).  Process-wide; same bits either way."""
+    check(_lib.load().rrl_set_reduce_mode({"auto": 0, "single": 1, "tiled": 2}[mode]), "rrl_set_reduce_mode")
+
+
 def last_state():
     """LossState of the most recent loss evaluation on this process (workspace views, payload)."""
     return _IntersectionLoss.last_state

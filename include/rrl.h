@@ -216,6 +216,15 @@ int rrl_line_pair_dist(const float *tri1, const float *tri2, const float *line, 
 int rrl_loss_reduce(void *ws, size_t ws_bytes, float *loss, int B, int N, int M, int L, int s_m,
                     int s_n, int e_m, int e_n, int pool, void *stream);
 
+/* Which reduce kernel rrl_loss_reduce (and the fused forwards) launch: 0 = automatic -- the TILED reduce (one
+ * 256-lane workgroup per 1024-line tile of a sample: the median's first radix pass comes as a histogram from the
+ * per-line stage, the bin's values are exchanged through the workspace, fixed-point bucket sums by device atomics,
+ * the last workgroup to arrive writes the loss) for independent samples with >= 2 tiles while B x tiles <= 1024,
+ * else the single 1024-lane workgroup per sample; 1 = always the single workgroup; 2 = tiled wherever it is legal
+ * (also for one tile).  Bit-identical median, loss and bucket sums either way.  Env RRL_REDUCE=single|tiled sets
+ * the initial state. */
+int rrl_set_reduce_mode(int mode);
+
 /* Tuning/testing knobs.  rrl_set_scan_variant: lines per lane of the scan (1 = scalar fp32,
  * 2 / 4 / 8 = one / two / four packed v_pk_*_f32 pairs); 0 = default.  All variants give
  * identical results.  Env RRL_SCAN_VARIANT / RRL_SCAN_CHUNK override the defaults. */

@@ -1177,6 +1177,67 @@ def test_median_with_crowded_bins(L, oracle, n_lines, spread):
     np.testing.assert_allclose(st.loss.cpu().numpy()[0], ref["loss"], rtol=1e-5)
 
 
+@pytest.mark.parametrize("case", ["golden", "batch", "crowded3000", "crowded9000", "one_tile", "sparse_tiles"])
+def test_tiled_reduce_equals_single_workgroup(L, case):
+    """The tiled reduce (one workgroup per 1024-line tile, bin values exchanged through the workspace, device-atomic
+    fixed-point bucket sums, last arriver writes the loss) against the single 1024-lane workgroup per sample:
+    median, loss, info, bucket counts and bucket sums bit for bit -- on the fixtures, a batch, crowded bins (more
+    than 2048 values in the median's bin: the streaming route; tiles with ~1000 selected lines: rows beyond the
+    256 held in registers), a single tile and tiles without any selected line -- and a repeated reduce on the
+    same prepared state."""
+    from rrl_hip import ops, synth, _lib
+    if case == "golden":
+        g = load_golden("loss_demo_scale.npz")
+        tri1, tri2, lines = g["tri1"][None], g["tri2"][None], g["lines"][None]
+    elif case == "batch":
+        prs = [synth.make_pair(300 + b, 1500, 1300) for b in range(5)]
+        tri1, tri2 = np.stack([p["src_tri"] for p in prs]), np.stack([p["tar_tri"] for p in prs])
+        ln = []
+        for b, p in enumerate(prs):
+            torch.manual_seed(b)
+            ln.append(L.Random_uniform_distribution_lines_batch_efficient_resample(
+                torch.tensor([[float(p["radius"])]]), torch.from_numpy(p["center"]).reshape(1, 3), 5000,
+                cu(p["src"])[None], cu(p["tar"])[None], "cuda")[0].cpu().numpy())
+        lines = np.stack(ln)
+        lines[4, 1024:] = 0  # sample 4: every tile but the first is empty (zero lines hit nothing here)
+    elif case in ("crowded3000", "crowded9000", "one_tile"):
+        n_lines = {"crowded3000": 3000, "crowded9000": 9000, "one_tile": 700}[case]
+        rng = np.random.default_rng(5)
+        base = np.array([[0.0, 0.0, 0.0, 0.05, 0.0, 0.0, 0.0, 0.05, 0.0]], np.float32)
+        tri1 = np.concatenate([base, base + np.float32(3.0)]).astype(np.float32)[None]
+        tri2 = (tri1 + np.array([0.004, -0.003, 0.002] * 3, np.float32)).astype(np.float32)
+        d = np.tile(np.array([[0.0, 0.0, 1.0]]), (n_lines, 1))
+        x0 = np.tile(np.array([[0.012, 0.011, -1.0]]), (n_lines, 1)) + (1e-5 if case == "crowded9000" else 0.0) * rng.standard_normal((n_lines, 3))
+        lines = np.concatenate([d, x0], 1).astype(np.float32)[None]
+    else:  # sparse_tiles: 6000 lines of which only a handful hit both clouds, spread over the tiles
+        pr = synth.make_pair(9, 400, 300)
+        tri1, tri2 = pr["src_tri"][None], pr["tar_tri"][None]
+        torch.manual_seed(1)
+        lines = L.Random_uniform_distribution_lines_batch_efficient_resample(
+            torch.tensor([[float(pr["radius"])]]), torch.from_numpy(pr["center"]).reshape(1, 3), 6000,
+            cu(pr["src"])[None], cu(pr["tar"])[None], "cuda").cpu().numpy()
+        lines[:, 40:5200] = 0
+    out = {}
+    try:
+        for mode in ("single", "tiled"):
+            ops.set_reduce_mode(mode)
+            st = run_state(tri1, tri2, lines, mode="cull")
+            out[mode] = [t.cpu().numpy().copy() for t in (st.loss, st.med, st.info, st.bcnt, st.bsum)]
+            if mode == "tiled":  # the reduce once more on the same prepared state (its control words reset themselves)
+                B, N, M, Ll, _ = st.dims
+                st.loss.fill_(-1.0)
+                ops._run(st.ws.device, "rrl_loss_reduce", ops._p(st.ws), st.nbytes, ops._p(st.loss), B, N, M, Ll, 1, 1, 5, 5, 0)
+                torch.cuda.synchronize()
+                out["again"] = [t.cpu().numpy().copy() for t in (st.loss, st.med, st.info, st.bcnt, st.bsum)]
+                assert int(st.mctl[:, 19].sum()) == 0  # no spin ran into its time-out
+    finally:
+        ops.set_reduce_mode("auto")
+    for other in ("tiled", "again"):
+        for a, b in zip(out["single"], out[other]):
+            np.testing.assert_array_equal(a.view(np.uint8), b.view(np.uint8))
+    assert out["single"][2][:, 1].sum() > 0  # lines were selected
+
+
 def test_fused_registration_op(L):
     """rrl_registration_forward/backward == rigid apply + loss + rigid backward, incl. payload."""
     from rrl_hip import ops
