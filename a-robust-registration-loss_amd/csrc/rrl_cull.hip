@@ -227,7 +227,15 @@ __global__ __launch_bounds__(1024) void tri_sort_kernel(const BuildArgs a) {
     // consecutive records (by original index) on its own grid and builds its 64 supergroups; the sorted cloud
     // is the concatenation of its chunks (all but the last are full, so the real records still occupy the
     // sorted positions [0, n)).  Any grouping of the records gives the same labels (rrl_launch_tri_build).
+    // PARTS (round 3): gridDim.y workgroups share one cloud (or chunk) WITHOUT talking to each other: every one
+    // reads all records, builds the whole cell histogram and its scan (that is the cheap half of the kernel: the
+    // loads and the LDS histogram), and then scatters, copies out and builds the tree nodes only for ITS range of
+    // supergroups [S0, S1) = sorted positions [64 S0, 64 S1) -- the expensive half, now 1 / parts of it per CU.
+    // The sorted position of a record must be the same in every workgroup that could own it: inside a cell the
+    // order is arbitrary (an LDS cursor), except in the (at most two) cells that straddle this part's first /
+    // last position, where the rank is the record's rank by original index (ballots + a 64-entry prefix).
     const int nch = RAW ? 1 : (a.nchunk > 1 ? a.nchunk : 1);
+    const int part = (int)blockIdx.y, nparts = (int)gridDim.y;
     const int chunk = (int)blockIdx.x % nch, cb = (int)blockIdx.x / nch;
     const int cloud = cb >= B ? 1 : 0, b = cb - cloud * B;
     const int nfull = cloud ? a.M : a.N;                 // records of the whole cloud
@@ -235,13 +243,19 @@ __global__ __launch_bounds__(1024) void tri_sort_kernel(const BuildArgs a) {
     if (base0 >= nfull) return;                          // uniform: the smaller cloud has fewer chunks
     const int n = min(1024 * NPT, nfull - base0);        // records of this chunk
     const int ngf = (nfull + GRP - 1) / GRP, nsgf = (nfull + SGT - 1) / SGT;
-    const int nsg = (n + SGT - 1) / SGT, ngp = nsg * SGG, npad = nsg * SGT;
+    const int nsg = (n + SGT - 1) / SGT;
     const float4 *crec = (cloud ? a.crec2 : a.crec1) + (size_t)b * ngf * GRP + base0;
     float4 *p0s = (cloud ? a.p0s2 : a.p0s1) + (size_t)b * nsgf * SGT + base0;
     int32_t *idx = (cloud ? a.idx2 : a.idx1) + (size_t)b * nsgf * SGT + base0;
     float4 *tree = (cloud ? a.grp2 : a.grp1) + ((size_t)b * nsgf + base0 / SGT) * NODE;
-    int *sidx = (int *)(srec + (size_t)ngp * 17);
+    const int S0 = (int)((long)part * nsg / nparts), S1 = (int)((long)(part + 1) * nsg / nparts);  // this part's supergroups
+    const int p0 = S0 * SGT, p1 = S1 * SGT;                                                        // ... and sorted positions
+    const int ngpm = (nsg + nparts - 1) / nparts * SGG;  // groups of the largest part: the LDS layout of every part
+    int *sidx = (int *)(srec + (size_t)ngpm * 17);
     auto pad = [](int s) { return s + (s >> 4); };
+    __shared__ int s_cb[2];          // the cells that straddle p0 / p1 (-1: the boundary falls between two cells)
+    __shared__ unsigned s_bw[2][64]; // their records per (pass k, wavefront): exclusive prefix in index order
+    if (tid < 2) s_cb[tid] = -1;
 
     // ---- AABB of the P0s and max |P|^2 from the per-workgroup partials of tri_records_kernel
     float4 rec[NPT];
@@ -309,7 +323,7 @@ __global__ __launch_bounds__(1024) void tri_sort_kernel(const BuildArgs a) {
         }
         // the NN kernel ORs slot 7 over the ceil(n / 256) partial rows of the cloud: row 0 carries the flag
         const int nb = (n + REC_BLK - 1) / REC_BLK;
-        if (tid < nb) a.apart[(((size_t)cloud * B + b) * a.nblk + tid) * 8 + 7] = tid == 0 ? any7 : 0.0f;
+        if (part == 0 && tid < nb) a.apart[(((size_t)cloud * B + b) * a.nblk + tid) * 8 + 7] = tid == 0 ? any7 : 0.0f;
     } else {
 #pragma unroll
         for (int k = 0; k < NPT; ++k)  // issue the record loads first: they overlap the reduction
@@ -335,7 +349,7 @@ __global__ __launch_bounds__(1024) void tri_sort_kernel(const BuildArgs a) {
 #if defined(SORT_STOP) && SORT_STOP == 1  // timing experiments only
     return;
 #endif
-    if (tid == 0) {
+    if (tid == 0 && part == 0) {
         if (nch > 1) atomicMax(&a.pmax[cloud * B + b], __float_as_uint(bb[6]));  // non-negative floats; PMAX is cleared per call
         else a.pmax[cloud * B + b] = __float_as_uint(bb[6]);
     }
@@ -377,40 +391,78 @@ __global__ __launch_bounds__(1024) void tri_sort_kernel(const BuildArgs a) {
         for (int w = 0; w < wave; ++w) base += wsum[w];
         unsigned run = base + inc - tsum;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { hist[4 * tid + k] = run; run += h[k]; }
+        for (int k = 0; k < 4; ++k) {
+            hist[4 * tid + k] = run;
+            // a cell with records on both sides of this part's first / last position
+            if ((int)run < p0 && p0 < (int)(run + h[k])) s_cb[0] = 4 * tid + k;
+            if ((int)run < p1 && p1 < (int)(run + h[k])) s_cb[1] = 4 * tid + k;
+            run += h[k];
+        }
     }
     __syncthreads();
 #if defined(SORT_STOP) && SORT_STOP == 3  // timing experiments only
     return;
 #endif
-    // scatter into LDS only; the global arrays are written afterwards, in order
+    // ---- ranks by original index (f = tid + 1024 k: pass-major, then wavefront, then lane) inside the straddling cells
+    const int cb0 = nparts > 1 ? s_cb[0] : -1, cb1 = nparts > 1 ? s_cb[1] : -1;
+    unsigned long long bm[2][NPT];
+    unsigned bbase[2] = {0u, 0u};
+    if (cb0 >= 0 || cb1 >= 0) {  // uniform
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int c = j ? cb1 : cb0;
+#pragma unroll
+            for (int k = 0; k < NPT; ++k) {
+                bm[j][k] = __ballot(c >= 0 && tid + 1024 * k < n && (int)cell[k] == c);
+                if (lane == 0 && 16 * k + wave < 64) s_bw[j][16 * k + wave] = (unsigned)__popcll(bm[j][k]);
+            }
+            if (c >= 0) bbase[j] = hist[c];  // no cursor runs in these cells: the value stays the cell's first position
+        }
+        __syncthreads();
+        if (tid < 64) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const unsigned v = tid < 16 * NPT ? s_bw[j][tid] : 0u;
+                s_bw[j][tid] = (unsigned)wave_incl_scan((int)v) - v;
+            }
+        }
+        __syncthreads();
+    }
+    static_assert(NPT <= 4, "s_bw holds 16 wavefronts x NPT passes");
+    // scatter into LDS only (this part's range); the global arrays are written afterwards, in order
 #pragma unroll
     for (int k = 0; k < NPT; ++k) {
         const int f = tid + 1024 * k;
         if (f < n) {
-            const int s = (int)atomicAdd(&hist[cell[k]], 1u);
-            srec[pad(s)] = rec[k];
-            sidx[s] = base0 + f;
+            const int c = (int)cell[k];
+            int s;
+            if (c == cb0) s = (int)(bbase[0] + s_bw[0][16 * k + wave]) + __popcll(bm[0][k] & ((1ull << lane) - 1ull));
+            else if (c == cb1) s = (int)(bbase[1] + s_bw[1][16 * k + wave]) + __popcll(bm[1][k] & ((1ull << lane) - 1ull));
+            else s = (int)atomicAdd(&hist[c], 1u);
+            if (s >= p0 && s < p1) {
+                srec[pad(s - p0)] = rec[k];
+                sidx[s - p0] = base0 + f;
+            }
         }
     }
-    for (int s = n + tid; s < npad; s += 1024) {  // pad: thr2 = 0 never passes
-        srec[pad(s)] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        sidx[s] = 0;
+    for (int s = max(n, p0) + tid; s < p1; s += 1024) {  // pad (the last part): thr2 = 0 never passes
+        srec[pad(s - p0)] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        sidx[s - p0] = 0;
     }
     __syncthreads();
 #if defined(SORT_STOP) && SORT_STOP == 4  // timing experiments only
     return;
 #endif
-    for (int s = tid; s < npad; s += 1024) {  // coalesced copy-out
-        p0s[s] = srec[pad(s)];
-        idx[s] = sidx[s];
+    for (int s = p0 + tid; s < p1; s += 1024) {  // coalesced copy-out
+        p0s[s] = srec[pad(s - p0)];
+        idx[s] = sidx[s - p0];
     }
 #if defined(SORT_STOP) && SORT_STOP == 5
     return;
 #endif
     // ---- sphere tree: one lane per half of 8 records
-    for (int hh = tid; hh < 2 * ngp; hh += 1024)
-        half_tree([&](int s_) { return srec[pad(s_)]; }, hh, n, tree);
+    for (int hh = 2 * SGG * S0 + tid; hh < 2 * SGG * S1; hh += 1024)
+        half_tree([&](int s_) { return srec[pad(s_ - p0)]; }, hh, n, tree);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1098,6 +1150,35 @@ extern "C" int rrl_scan_counters(uint64_t *dev_counters, long long rows) {
     return 0;
 }
 
+// Workgroups per cloud (or chunk) of tri_sort_kernel: 1 / parts of the scatter + copy-out + tree work per CU against
+// the loads and the histogram repeated in each -- 4 for >= 32 supergroups, fewer for small clouds whose sort is all
+// fixed cost.  rrl_set_sort_parts / RRL_SORT_PARTS override (1 = the single workgroup of rounds 1-2).
+static int g_sort_parts = -1;  // 0 automatic, k >= 1 forced; -1: read RRL_SORT_PARTS once
+extern "C" int rrl_set_sort_parts(int parts) {
+    if (parts < 0 || parts > 16) return RRL_E_ARG;
+    g_sort_parts = parts;
+    return 0;
+}
+static int sort_parts(int nsg) {
+    if (g_sort_parts < 0) {
+        const char *e = getenv("RRL_SORT_PARTS");
+        g_sort_parts = e ? atoi(e) : 0;
+        if (g_sort_parts < 0 || g_sort_parts > 16) g_sort_parts = 0;
+    }
+    int k = g_sort_parts ? g_sort_parts : nsg / 8;
+    if (!g_sort_parts && k > 4) k = 4;
+    if (k > nsg) k = nsg;
+    return k < 1 ? 1 : k;
+}
+// dynamic LDS of one sort workgroup: the padded records + indices of the largest part; the RAW variant first stages
+// its 3 n floats there
+static size_t sort_lds_bytes(int nsg, int parts, int raw_points) {
+    const size_t ngpm = (size_t)((nsg + parts - 1) / parts) * SGG;
+    size_t lds = ngpm * (17 * sizeof(float4) + GRP * sizeof(int));
+    const size_t rawb = (size_t)raw_points * 3 * sizeof(float);
+    return lds > rawb ? lds : rawb;
+}
+
 // Launchers used by rrl_tri_prepare / rrl_line_tri_scan (rrl_scan.hip)
 int rrl_launch_tri_build(const float *tri1, const float *tri2, void *ws, const WsLayout &w, int B,
                          int N, int M, int clouds, const RrlXform *xf, hipStream_t s) {
@@ -1113,7 +1194,8 @@ int rrl_launch_tri_build(const float *tri1, const float *tri2, void *ws, const W
     const char *wide_env = getenv("RRL_SORT_WIDE");
     const bool chunked = nmax > 4096 && !(wide_env && atoi(wide_env) != 0);
     const size_t ngps = nmax <= 4096 ? ngpmax : (size_t)(4096 / GRP);
-    const size_t lds = nmax <= 4096 || chunked ? ngps * (17 * sizeof(float4) + GRP * sizeof(int)) : 16;
+    const int parts = sort_parts((int)(ngps / SGG));
+    const size_t lds = nmax <= 4096 || chunked ? sort_lds_bytes((int)(ngps / SGG), parts, 0) : 16;
     BuildArgs a;
     a.tri1 = xf ? xf->src : tri1;
     a.tri2 = tri2;
@@ -1150,7 +1232,7 @@ int rrl_launch_tri_build(const float *tri1, const float *tri2, void *ws, const W
     hipLaunchKernelGGL(tri_records_kernel, dim3((unsigned)((nmax + REC_BLK - 1) / REC_BLK), (unsigned)B, (unsigned)clouds),
                        dim3(REC_BLK), 0, s, a);
     if (nmax <= 4096 || chunked) {
-        hipLaunchKernelGGL((tri_sort_kernel<4, false>), dim3((unsigned)(clouds * B * a.nchunk)), dim3(1024), lds, s, a);
+        hipLaunchKernelGGL((tri_sort_kernel<4, false>), dim3((unsigned)(clouds * B * a.nchunk), (unsigned)parts), dim3(1024), lds, s, a);
     } else {  // wide three-launch sort (HISTG was cleared by tri_records_kernel)
         unsigned *histg = (unsigned *)w.i32(ws, RRL_WS_HISTG);
         const dim3 gt((unsigned)((nmax + 255) / 256), (unsigned)B, (unsigned)clouds);
@@ -1186,9 +1268,11 @@ int rrl_launch_cloud_sort(const float *raw1, const float *raw2, float4 *crec1, f
     // (the chunked sort of rrl_launch_tri_build was tried here too: a nearest-neighbour walk evaluates twice the
     //  pairs on chunked clouds -- 63.0 -> 64.4 us at N = M = 16384, 188 -> 380 at 65536: whole-cloud order stays)
     if (nmax <= 4096) {
-        const size_t lds = ngpmax * (17 * sizeof(float4) + GRP * sizeof(int));
-        if (raw1 && raw2) hipLaunchKernelGGL((tri_sort_kernel<4, true>), dim3((unsigned)(2 * B)), dim3(1024), lds, s, a);
-        else hipLaunchKernelGGL((tri_sort_kernel<4, false>), dim3((unsigned)(2 * B)), dim3(1024), lds, s, a);
+        const int parts = sort_parts((int)(ngpmax / SGG));
+        if (raw1 && raw2) hipLaunchKernelGGL((tri_sort_kernel<4, true>), dim3((unsigned)(2 * B), (unsigned)parts), dim3(1024),
+                                             sort_lds_bytes((int)(ngpmax / SGG), parts, nmax), s, a);
+        else hipLaunchKernelGGL((tri_sort_kernel<4, false>), dim3((unsigned)(2 * B), (unsigned)parts), dim3(1024),
+                                sort_lds_bytes((int)(ngpmax / SGG), parts, 0), s, a);
     } else {
         const dim3 gt((unsigned)((nmax + 255) / 256), (unsigned)B, 2u);
         hipLaunchKernelGGL(big_hist_kernel, gt, dim3(256), 0, s, a, histg);

@@ -32,6 +32,7 @@ _SIGS = {
     "rrl_set_scan_variant": [_I],
     "rrl_set_deterministic": [_I],
     "rrl_set_reduce_mode": [_I],
+    "rrl_set_sort_parts": [_I],
     "rrl_scan_timing_enable": [_I],
     "rrl_scan_timing_collect": [_P, _I],
     "rrl_scan_counters": [_P, _c.c_longlong],

@@ -466,6 +466,11 @@ def set_reduce_mode(mode):
     check(_lib.load().rrl_set_reduce_mode({"auto": 0, "single": 1, "tiled": 2}[mode]), "rrl_set_reduce_mode")
 
 
+def set_sort_parts(parts):
+    """Workgroups per cloud of the sort + sphere-tree kernel (0 = automatic; include/rrl.h rrl_set_sort_parts)."""
+    check(_lib.load().rrl_set_sort_parts(int(parts)), "rrl_set_sort_parts")
+
+
 def last_state():
     """LossState of the most recent loss evaluation on this process (workspace views, payload)."""
     return _IntersectionLoss.last_state

@@ -225,6 +225,11 @@ int rrl_loss_reduce(void *ws, size_t ws_bytes, float *loss, int B, int N, int M,
  * the initial state. */
 int rrl_set_reduce_mode(int mode);
 
+/* Workgroups per cloud of the cell sort + sphere-tree kernel (they share nothing but their input: each owns a range
+ * of supergroups): 0 = automatic (up to 4), k = 1..16 forced.  Any value gives the same labels, loss and Chamfer
+ * keys; the order of records INSIDE a grid cell may differ.  Env RRL_SORT_PARTS sets the initial state. */
+int rrl_set_sort_parts(int parts);
+
 /* Tuning/testing knobs.  rrl_set_scan_variant: lines per lane of the scan (1 = scalar fp32,
  * 2 / 4 / 8 = one / two / four packed v_pk_*_f32 pairs); 0 = default.  All variants give
  * identical results.  Env RRL_SCAN_VARIANT / RRL_SCAN_CHUNK override the defaults. */

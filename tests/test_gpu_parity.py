@@ -79,6 +79,65 @@ def test_tri_prepare_exact(L, oracle):
         np.testing.assert_array_equal(p0s[slot], np.append(pt[idx[s_], :3], thr2[idx[s_]]))
 
 
+def _check_sorted_layout(st, tri, thr, cloud=1, b=0):
+    """Invariants of the build step for one cloud: IDX is a permutation, P0S holds (P0, thr2) of the indexed
+    triangle, every tree node contains its sorted records with the threshold margin, empty nodes are NaN."""
+    n = len(tri)
+    pt = (st.ptri1 if cloud == 1 else st.ptri2)[b].cpu().numpy()
+    idx = (st.idx1 if cloud == 1 else st.idx2)[b].cpu().numpy()
+    p0s = (st.p0s1 if cloud == 1 else st.p0s2)[b].cpu().numpy()
+    tree = (st.grp1 if cloud == 1 else st.grp2)[b].cpu().numpy()
+    assert sorted(idx[:n].tolist()) == list(range(n))
+    np.testing.assert_array_equal(p0s[:n, :3], pt[idx[:n], :3])
+    np.testing.assert_array_equal(p0s[:n, 3], pt[idx[:n], 9])
+    assert np.all(p0s[n:] == 0)
+    P0 = pt[idx[:n], :3].astype(np.float64)
+    for sg in range(len(tree)):
+        nodes = [(0, 64 * sg, 64)] + [(1 + k, 64 * sg + 16 * k, 16) for k in range(4)] + \
+                [(5 + k, 64 * sg + 8 * k, 8) for k in range(8)]
+        for slot, s0, cnt in nodes:
+            sl = slice(s0, min(s0 + cnt, n))
+            if sl.start >= n:
+                assert np.isnan(tree[sg, slot, 3])
+                continue
+            d = np.linalg.norm(P0[sl] - tree[sg, slot, :3].astype(np.float64), axis=1) + thr[idx[sl]]
+            assert np.all(d <= tree[sg, slot, 3])
+
+
+@pytest.mark.parametrize("parts", [1, 2, 3, 4, 7, 16])
+def test_sort_parts_layout_and_results(L, oracle, parts):
+    """The sort + tree kernel split over `parts` workgroups per cloud that share nothing but their input: same
+    invariants of the sorted layout, same scan counts, same loss, same Chamfer keys as one workgroup -- on a cloud
+    whose grid cells hold many records (600 of 3000 points are copies of three points: cells that straddle the
+    parts' boundaries take the deterministic-rank route), ragged sizes and a chunked large cloud."""
+    from rrl_hip import ops, synth
+    pr = synth.make_pair(21, 3000, 1111)
+    tri1, tri2 = pr["src_tri"].copy(), pr["tar_tri"].copy()
+    tri1[200:500] = tri1[7]; tri1[900:1100] = tri1[8]; tri1[2000:2100] = tri1[9]
+    rands = synth.uniform_streams(2, 10, 2500)
+    lines = oracle.resample_lines(rands, pr["radius"], pr["center"], pr["src"], pr["tar"], 2500)
+    big = synth.make_pair(22, 5000, 4100)
+    res = {}
+    try:
+        for k in (1, parts):
+            ops.set_sort_parts(k)
+            st = run_state(tri1, tri2, lines, mode="cull")
+            _check_sorted_layout(st, tri1, oracle.tri_threshold(tri1), 1)
+            _check_sorted_layout(st, tri2, oracle.tri_threshold(tri2), 2)
+            stb = run_state(big["src_tri"], big["tar_tri"], lines, mode="cull")  # chunks of 4096 + a ragged last chunk
+            cx = ops.chamfer_from_state(st, keys=True)
+            cy = ops.chamfer(cu(tri1[None, :, :3].copy()), cu(tri2[None, :, :3].copy()))
+            res[k] = [t.cpu().numpy().copy() for t in (st.count1, st.count2, st.loss, stb.count1, stb.count2, stb.loss,
+                                                         cx[0].reshape(1), cx[1], cx[2], cy.reshape(1))]
+    finally:
+        ops.set_sort_parts(0)
+    for a, b in zip(res[1], res[parts]):
+        np.testing.assert_array_equal(a, b)
+    s_ = run_state(tri1, tri2, lines, mode="strict")
+    np.testing.assert_array_equal(res[parts][0], s_.count1.cpu().numpy())
+    np.testing.assert_array_equal(res[parts][1], s_.count2.cpu().numpy())
+
+
 @pytest.mark.parametrize("tr", [True, False])
 def test_registration_step_equals_the_autograd_op(L, tr):
     """ops.RegistrationStep (forward + backward as two C calls on preallocated buffers, no autograd node)
