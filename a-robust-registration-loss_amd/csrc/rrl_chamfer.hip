@@ -218,7 +218,7 @@ __global__ __launch_bounds__(64 * NWV) void chamfer_tree_kernel(
     const float4 *__restrict__ p0s1, const float4 *__restrict__ p0s2, const float4 *__restrict__ grp1,
     const float4 *__restrict__ grp2, const float *__restrict__ apart, int nblk,
     unsigned long long *__restrict__ best_x, unsigned long long *__restrict__ best_y,
-    double *__restrict__ partial, int B, int N, int M, unsigned long long *__restrict__ counters,
+    double *__restrict__ partial, int B, int N, int M, unsigned long long *__restrict__ counters, long long counter_rows,
     const int32_t *__restrict__ idx1, const int32_t *__restrict__ idx2, const uint32_t *__restrict__ pm1,
     const uint32_t *__restrict__ pm2) {
     __shared__ unsigned long long s_best[64];
@@ -418,8 +418,9 @@ __global__ __launch_bounds__(64 * NWV) void chamfer_tree_kernel(
     if constexpr (COUNT) {
         // one 16-slot row per wavefront, plain stores (same-address atomics from 4096 wavefronts would
         // saturate the memory system and distort the very clocks recorded here); the host adds the rows
-        if (lane == 0 && sgq < nsgq) {
-            unsigned long long *row = counters + 16 * ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * NWV + wv);
+        const long long crow = (long long)(blockIdx.y * gridDim.x + blockIdx.x) * NWV + wv;  // rows past the buffer are dropped
+        if (lane == 0 && sgq < nsgq && crow < counter_rows) {
+            unsigned long long *row = counters + 16 * (size_t)crow;
             row[0] = c_sg; row[1] = c_gt; row[2] = c_ge; row[3] = c_pairs; row[4] = 1;
             row[5] = (unsigned long long)t_stage;
             row[6] = (unsigned long long)(t_test - t_pass);
@@ -459,8 +460,10 @@ __global__ __launch_bounds__(256) void chamfer_partials_kernel(const double *__r
 }
 
 static unsigned long long *g_cham_counters = nullptr;
-extern "C" int rrl_chamfer_counters(uint64_t *dev_counters) {
+static long long g_cham_counter_rows = 0;
+extern "C" int rrl_chamfer_counters(uint64_t *dev_counters, long long rows) {
     g_cham_counters = (unsigned long long *)dev_counters;
+    g_cham_counter_rows = dev_counters ? rows : 0;
     return 0;
 }
 
@@ -490,7 +493,7 @@ extern "C" int rrl_chamfer_tree_fwd(const float *x, const float *y, void *ws, si
                        s, (const float4 *)(w + L.p0s1), (const float4 *)(w + L.p0s2),                            \
                        (const float4 *)(w + L.grp1), (const float4 *)(w + L.grp2), (const float *)(w + L.apart),  \
                        L.nblk, (unsigned long long *)best_x, (unsigned long long *)best_y,                       \
-                       (double *)(w + L.partial), B, N, M, g_cham_counters, (const int32_t *)nullptr,            \
+                       (double *)(w + L.partial), B, N, M, g_cham_counters, g_cham_counter_rows, (const int32_t *)nullptr, \
                        (const int32_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr)
     if (g_cham_counters) RRL_NN_LAUNCH(true);
     else RRL_NN_LAUNCH(false);
@@ -526,7 +529,7 @@ extern "C" int rrl_chamfer_from_loss(const void *ws_src, const void *ws_tar, siz
                        s, (const float4 *)lw.f32(ws_src, RRL_WS_P0S1), (const float4 *)lw.f32(ws_tar, RRL_WS_P0S2), \
                        (const float4 *)lw.f32(ws_src, RRL_WS_GRP1), (const float4 *)lw.f32(ws_tar, RRL_WS_GRP2),  \
                        (const float *)nullptr, 0, (unsigned long long *)best_x, (unsigned long long *)best_y,    \
-                       (double *)(w + C.partial), B, N, M, g_cham_counters, lw.i32(ws_src, RRL_WS_IDX1),        \
+                       (double *)(w + C.partial), B, N, M, g_cham_counters, g_cham_counter_rows, lw.i32(ws_src, RRL_WS_IDX1), \
                        lw.i32(ws_tar, RRL_WS_IDX2), (const uint32_t *)lw.i32(ws_src, RRL_WS_PMAX),              \
                        (const uint32_t *)lw.i32(ws_tar, RRL_WS_PMAX) + B)
     if (g_cham_counters) RRL_NN_LAUNCH(true);

@@ -33,7 +33,8 @@ struct RrlRange {
     RrlRange &operator=(const RrlRange &) = delete;
 };
 
-// Fill / copy as KERNELS.  The library never issues hipMemsetAsync / hipMemcpyAsync: inside a
+// Fill / copy as KERNELS.  The library never issues hipMemsetAsync / hipMemcpyAsync on device buffers (the one
+// device-to-host read-back of rrl_loss_forward_info waits for the stream and cannot be captured anyway): inside a
 // captured hipGraph (the bench and the demo replay their step as one) memset nodes were observed
 // to race with the kernels that follow them on this stack -- the captured demo step
 // intermittently read half-initialised Chamfer keys until the memsets became a kernel.

@@ -1110,4 +1110,10 @@ extern "C" int rrl_shard_payload(const float *loss, const void *ws, size_t ws_by
     return 0;
 }
 
-extern "C" const char *rrl_version(void) { return "rrl_hip 0.1 (gfx950)"; }
+#ifndef RRL_BUILD_FLAGS
+#define RRL_BUILD_FLAGS ""
+#endif
+// experimental builds (RRL_HIPCC_FLAGS, rrl_hip/build.py) carry their flags in the version string
+extern "C" const char *rrl_version(void) {
+    return sizeof(RRL_BUILD_FLAGS) > 1 ? "rrl_hip 0.3 (gfx950) [" RRL_BUILD_FLAGS "]" : "rrl_hip 0.3 (gfx950)";
+}

@@ -1475,6 +1475,30 @@ extern "C" int rrl_loss_forward_cached(const float *tri1, const float *tri2, con
                              pool, mode, chunk, target_ws, nullptr, stream);
 }
 
+// The drop-in call (code/loss.py:170-232 as the reference's callers use it: one sample, a Python-level
+// decision on the result) in ONE entry: the forward, then INFO[0 .. 4 G) (nbuckets, nselected, nvalues, NaN
+// flag per group) copied to host_info, then a wait for the stream -- the only entry of the library that
+// synchronises, because the reference's return value (a tensor, or None when no bucket is populated, or an
+// exit on NaN) is a host-side decision by contract.  host_info: 4 G int32 in host memory (pinned memory makes
+// the copy asynchronous up to the wait).
+extern "C" int rrl_loss_forward_info(const float *tri1, const float *tri2, const float *line, void *ws,
+                                     size_t ws_bytes, float *loss, int B, int N, int M, int L, int s_m,
+                                     int s_n, int e_m, int e_n, int pool, int mode, int chunk,
+                                     const void *target_ws, int32_t *host_info, void *stream) {
+    if (!host_info) return RRL_E_ARG;
+    int rc = loss_forward_impl(tri1, tri2, line, ws, ws_bytes, loss, B, N, M, L, s_m, s_n, e_m, e_n,
+                               pool, mode, chunk, target_ws, nullptr, stream);
+    if (rc) return rc;
+    const int G = pool ? 1 : B;
+    if (G <= 0) return 0;
+    WsLayout w(B, N, M, L);
+    hipError_t e = hipMemcpyAsync(host_info, w.i32(ws, RRL_WS_INFO), sizeof(int32_t) * 4 * (size_t)G,
+                                  hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+    e = hipStreamSynchronize((hipStream_t)stream);
+    return e == hipSuccess ? 0 : (int)e;
+}
+
 extern "C" int rrl_loss_forward(const float *tri1, const float *tri2, const float *line, void *ws,
                                 size_t ws_bytes, float *loss, int B, int N, int M, int L, int s_m,
                                 int s_n, int e_m, int e_n, int pool, int mode, int chunk,

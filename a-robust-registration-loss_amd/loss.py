@@ -82,15 +82,18 @@ def cal_loss_intersection_batch_whole_median_pts_lines(s_m, s_n, e_m, e_n, point
     if points1.dim() != 3 or line.dim() != 3 or points2.dim() != 3:
         raise ValueError("Input is wrong")  # code/loss.py:69-71
     pool = points1.shape[0] > 1
-    loss, info, status = _ops.intersection_loss(points1, points2, line, (s_m, s_n, e_m, e_n),
+    # forward + the call's single host sync in one C call: (nbuckets, nselected, nvalues, NaN flag) arrive through a
+    # 16-byte pinned copy; the workspace is leased from a per-shape pool (rrl_hip.ops._DropinLoss)
+    loss, flags = _ops.intersection_loss_dropin(points1, points2, line, (s_m, s_n, e_m, e_n),
                                                 pool=pool, mode=_scan_mode(mode), chunk=chunk)
-    flags = info[0].tolist()  # the call's single host sync: (nbuckets, nselected, nvalues, NaN flag) in one 16-byte copy
     if flags[3]:
         raise ValueError("NaN point-to-line distance: line[..., :3] must be unit length or "
                          "all zero (reference: 'Exit the systerm', code/loss.py:88-91)")
     if flags[0] == 0:
         return None
-    return loss.reshape(1).to(device)
+    if loss.device.type != device and loss.device != device:  # (a 'cuda' / device-object argument: already there)
+        loss = loss.to(device)
+    return loss  # shape (1,): one group (B = 1, or the pooled B > 1 of SURVEY Q2)
 
 
 def batched_intersection_loss(points1, points2, line, rng=(1, 1, 5, 5), *, mode=None, chunk=0):

@@ -126,6 +126,7 @@ class Dataset_2021_8_29(Dataset):
         data['points_based_neighs_tar'] = nb_tar
         data['center'] = data['centers'] @ R + T
         data['tar_box'] = data['tar_box'] @ R + T
+        data.pop('p0_rows', None)  # samples and neighbours went through separate matrix products: let the consumer re-check
         return data
 
     def __getitem__(self, index):
@@ -166,6 +167,14 @@ class Dataset_2021_8_29(Dataset):
             'points_based_neighs_tar': nb_tar.astype(np.float32),
             'igt': igt.astype(np.float32),
         }
+        # beyond the reference's keys: do the point samples equal the first points of the pseudo-triangles (rows
+        # 0, 3, 6, ... of *_neigh.bin -- what Sample_neighs writes)?  rrl_hip.callsites then takes the Chamfer monitor
+        # from the loss evaluation's own sorted clouds instead of sorting the samples again.
+        data['p0_rows'] = np.bool_(
+            data['points_based_neighs_src'].shape[0] == 3 * data['points_src_sample'].shape[0]
+            and data['points_based_neighs_tar'].shape[0] == 3 * data['points_tar_sample'].shape[0]
+            and np.array_equal(data['points_based_neighs_src'].reshape(-1, 9)[:, :3], data['points_src_sample'])
+            and np.array_equal(data['points_based_neighs_tar'].reshape(-1, 9)[:, :3], data['points_tar_sample']))
         if self.DCP_True is True:  # channel-first clouds, transposed rotations
             for k in ('points_tar_sample', 'points_src_sample', 'points_based_neighs_src',
                       'points_based_neighs_tar', 'R', 'R_inv'):

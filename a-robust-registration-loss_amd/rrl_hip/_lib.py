@@ -23,6 +23,7 @@ _SIGS = {
     "rrl_registration_forward": [_P] * 6 + [_Z, _P] + [_I] * 11 + [_P],
     "rrl_registration_forward_cached": [_P] * 6 + [_Z, _P] + [_I] * 11 + [_P, _P],
     "rrl_loss_forward_cached": [_P, _P, _P, _P, _Z, _P] + [_I] * 11 + [_P, _P],
+    "rrl_loss_forward_info": [_P, _P, _P, _P, _Z, _P] + [_I] * 11 + [_P, _P, _P],
     "rrl_registration_backward": [_P] * 4 + [_Z] + [_P] * 6 + [_I] * 5 + [_P],
     "rrl_tri_prepare": [_P, _P, _P, _Z, _I, _I, _I, _I, _P],
     "rrl_line_tri_scan": [_P, _P, _Z] + [_I] * 6 + [_P],
@@ -36,7 +37,7 @@ _SIGS = {
     "rrl_scan_timing_enable": [_I],
     "rrl_scan_timing_collect": [_P, _I],
     "rrl_scan_counters": [_P, _c.c_longlong],
-    "rrl_chamfer_counters": [_P],
+    "rrl_chamfer_counters": [_P, _c.c_longlong],
     "rrl_rigid_apply_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "rrl_rigid_bwd_blocks": [_I],
     "rrl_rigid_apply_bwd": [_P] * 7 + [_I] * 4 + [_P],

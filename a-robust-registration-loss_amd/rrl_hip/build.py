@@ -11,7 +11,11 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 CSRC = os.path.join(PKG, "csrc")
-LIBDIR = os.path.join(PKG, "lib")
+# Experimental builds (RRL_HIPCC_FLAGS = extra -D knobs of the sweep scripts) go to their OWN directory and are loaded
+# only by processes that carry the same environment variable: an interrupted sweep can no longer leave a truncated
+# or re-tuned library where bench.py and the tests look; the flags are also part of rrl_version().
+EXP_FLAGS = os.environ.get("RRL_HIPCC_FLAGS", "").split()
+LIBDIR = os.path.join(PKG, "lib_exp" if EXP_FLAGS else "lib")
 LIB = os.path.join(LIBDIR, "librrl_hip.so")
 SOURCES = ["rrl_scan.hip", "rrl_cull.hip", "rrl_sparse.hip", "rrl_geom.hip", "rrl_neigh.hip", "rrl_chamfer.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
@@ -23,7 +27,7 @@ def _hipcc():
 
 
 def needs_build():
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or EXP_FLAGS:
         return True
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
@@ -39,7 +43,9 @@ def build_lib(force=False, verbose=False):
     for src in SOURCES:
         obj = os.path.join(LIBDIR, src.replace(".hip", ".o"))
         extra = ["-fno-slp-vectorize"] if src == "rrl_cull.hip" else []  # see the file header
-        extra += os.environ.get("RRL_HIPCC_FLAGS", "").split()  # experiments: -DNAME=value knobs
+        extra += EXP_FLAGS  # experiments: -DNAME=value knobs
+        if src == "rrl_geom.hip" and EXP_FLAGS:  # rrl_version() names them
+            extra.append('-DRRL_BUILD_FLAGS="' + " ".join(EXP_FLAGS).replace('"', "'") + '"')
         cmd = [_hipcc(), *FLAGS, *extra, "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))

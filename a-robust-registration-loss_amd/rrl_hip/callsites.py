@@ -33,18 +33,48 @@ def bounding_radius(tar_box, scale=1.0):
 
 
 DEVICE_RNG = False  # True: draw the candidate lines' uniforms on the GPU (opt-in, see draw_lines)
-CHAMFER_FROM_LOSS = False  # True: the Chamfer monitor walks the clouds the loss evaluation just sorted
-#   (ops.chamfer_from_state: no second sort, ~1/3 less device time).  Opt-in because it is the distance between
-#   the FIRST POINTS of the pseudo-triangles: identical to chamfer_dist(points_src_sample moved, points_tar_sample)
-#   only when those samples are exactly the rows 0, 3, 6, ... of points_based_neighs_* (what Sample_neighs emits,
-#   code/loss.py:473-485; a dataset that stores the samples separately may differ in the last bits).
+CHAMFER_FROM_LOSS = "auto"  # the Chamfer monitor walks the clouds the loss evaluation just sorted (ops.chamfer_from_state:
+#   no second sort, ~1/3 less device time).  That is the distance between the FIRST POINTS of the pseudo-triangles:
+#   identical to chamfer_dist(points_src_sample moved, points_tar_sample) when those samples are exactly the rows
+#   0, 3, 6, ... of points_based_neighs_* (what Sample_neighs emits, code/loss.py:473-485).  "auto" (round 3): used when
+#   that contract holds for the batch -- taken from the dataset's per-item flag `p0_rows` (pre_dataloader sets it when it
+#   builds an item: checked once per dataset item on the host), else checked once per data dict on the device and
+#   remembered in it.  True: always (the caller vouches), False: never.
+_SORT_CAP = 65536  # the loss sorts clouds up to this size (larger ones: dense scan, no sorted records to walk)
 
 
-def _monitor(moved, tar):
-    """The trainers' Chamfer monitor next to a loss evaluation."""
-    if CHAMFER_FROM_LOSS and _ops.last_state() is not None:
-        return _ops.chamfer_from_state()
-    return _ops.chamfer(moved, tar)
+def _first_points_contract(data, channel_first=False):
+    """Do the point samples of this batch equal the first points of its pseudo-triangles?  One answer per data
+    dict (stored under '_rrl_p0')."""
+    ok = data.get('_rrl_p0')
+    if ok is None:
+        flag = data.get('p0_rows')
+        if flag is not None:
+            ok = bool(torch.as_tensor(flag).all())
+        else:
+            ok = True
+            for pts, nb in (('points_src_sample', 'points_based_neighs_src'), ('points_tar_sample', 'points_based_neighs_tar')):
+                p, q = data[pts], data[nb]
+                if channel_first:
+                    p, q = p.transpose(2, 1), q.transpose(2, 1)
+                B = p.shape[0]
+                ok = ok and q.shape[1] == 3 * p.shape[1] and bool(torch.equal(p[..., :3], q.reshape(B, -1, 9)[..., :3]))
+        try:
+            data['_rrl_p0'] = ok
+        except TypeError:  # an immutable mapping: decide again next time
+            pass
+    return ok
+
+
+def _monitor(moved, tar, data=None, channel_first=False):
+    """The trainers' Chamfer monitor next to a loss evaluation: from the evaluation's own sorted clouds when that is
+    the same quantity (CHAMFER_FROM_LOSS), else the standalone kernel on (moved, tar)."""
+    st = _ops.last_state()
+    if CHAMFER_FROM_LOSS and st is not None and max(st.dims[1], st.dims[2]) <= _SORT_CAP and \
+            st.dims[1] == moved.shape[1] and st.dims[2] == tar.shape[1]:
+        if CHAMFER_FROM_LOSS is True or (data is not None and _first_points_contract(data, channel_first)):
+            return _ops.chamfer_from_state(st)
+    return _ops.chamfer(tar, moved)
 
 
 def draw_lines(radius, centers, n_lines, moved_src, tar, device=None, device_rng=None):
@@ -102,7 +132,7 @@ def rpm_intersection_loss(pred_transforms, data, n_lines=10000, lines=None, mode
         loss, ok = per_sample_loss(data['points_based_neighs_src'], R, t, tar_tri, lines, mode, first)
         first = first or _ops.last_state()
         per_iter.append(loss.sum().reshape(1) / num_iter)
-        chamfers.append((_ops.chamfer_from_state() if CHAMFER_FROM_LOSS else _ops.chamfer(tar, moved)).detach())
+        chamfers.append(_monitor(moved, tar, data).detach())
         valid.append(ok)
     disc = [0.5 ** (num_iter - ni - 1) for ni in range(num_iter)]
     return {'loss_intersection': sum(l * d for l, d in zip(per_iter, disc)),
@@ -126,7 +156,7 @@ def dcp_intersection_loss(data, rotation_ab_pred, translation_ab_pred, n_lines=1
                            moved.detach(), tar)
     src_nb = data['points_based_neighs_src'].transpose(2, 1).contiguous()
     loss, ok = per_sample_loss(src_nb, rotation_ab_pred, translation_ab_pred, tar_tri, lines, mode)
-    chamfer = _monitor(moved, tar)  # the reference evaluates it before the loss; it depends on neither
+    chamfer = _monitor(moved, tar, data, channel_first=True)  # the reference evaluates it before the loss; it depends on neither
     return (loss / 5.0).sum().reshape(1) / B, chamfer, lines, ok
 
 
@@ -151,4 +181,4 @@ def fmr_intersection_loss(g_series, data, n_lines=15000, lines=None, last=3, mod
         first = first or _ops.last_state()
         total = total + (loss / 5.0).sum().reshape(1) * 0.5 ** (maxiter - i - 1)
         valid.append(ok)
-    return total / B, _monitor(moved, tar), lines, torch.stack(valid)  # the last estimate's evaluation is the latest
+    return total / B, _monitor(moved, tar, data), lines, torch.stack(valid)  # the last estimate's evaluation is the latest

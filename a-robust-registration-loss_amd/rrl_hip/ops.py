@@ -3,6 +3,7 @@ all compute is librrl_hip.so).  No fallback path exists: CPU tensors are moved t
 current GPU, and a missing library / missing GPU raises RRLError.
 """
 import ctypes
+import sys
 
 import torch
 
@@ -282,6 +283,114 @@ class _IntersectionLoss(torch.autograd.Function):
         return g1, g2, None, None, None, None, None, None
 
 
+# ---- the reference-signature call (loss.cal_loss_intersection_batch_whole_median_pts_lines) ----------------------
+# Every reference trainer calls it once per SAMPLE inside a Python loop and tests / adds the result
+# (rpm/Train_RPM.py:226-231, dcp/Train_DCP.py:266-270, fmr/model.py:302-306), so its cost is host time: workspaces
+# are leased from a per-shape pool instead of allocated, the forward and its one read-back are a single C call
+# (rrl_loss_forward_info: launches + 16-byte copy into pinned memory + wait), and nothing but the loss tensor
+# escapes (a fresh tensor per call: a pooled buffer would alias the results of successive calls).
+_pool = {}          # (B, N, M, L, G, device index, raw stream) -> [LossState]
+_pool_bytes = [0]
+_POOL_CAP = 2 << 30
+
+
+def _lease_state(B, N, M, L, G, dev):
+    """A LossState nobody else refers to: from the pool of its shape / device / stream when one is free (no live
+    autograd node, not the `last_state`), else a new one (which joins the pool).  Reuse is stream-ordered like the
+    caching allocator's; never pooled while a graph is being captured (capture-time allocations belong to the
+    graph's private pool)."""
+    if torch.cuda.is_current_stream_capturing():
+        return LossState(B, N, M, L, G, dev)
+    key = (B, N, M, L, G, dev.index, torch._C._cuda_getCurrentRawStream(dev.index))
+    lst = _pool.get(key)
+    if lst is None:
+        lst = _pool[key] = []
+    for st in lst:
+        if sys.getrefcount(st) == 3:  # the pool's list, this loop variable, getrefcount's own argument
+            st.target_state = None
+            return st
+    st = LossState(B, N, M, L, G, dev)
+    st.wsp = _p(st.ws)
+    st.host_info = torch.empty(4 * G, dtype=torch.int32).pin_memory()
+    st.hostp = ctypes.c_void_p(st.host_info.data_ptr())
+    if _pool_bytes[0] + st.nbytes > _POOL_CAP:  # many distinct shapes (ragged data): start over
+        _pool.clear()
+        _pool_bytes[0] = 0
+        lst = _pool[key] = []
+    if len(lst) < 64:
+        lst.append(st)
+        _pool_bytes[0] += st.nbytes
+    return st
+
+
+class _DropinLoss(torch.autograd.Function):
+    """forward = rrl_loss_forward_info on a leased workspace; the host flags of the call are left in
+    _DropinLoss.flags ([nbuckets, nselected, nvalues, NaN flag] of group 0)."""
+    flags = None
+
+    @staticmethod
+    def forward(ctx, points1, points2, line, rng, pool, mode, chunk):
+        dev = _home(points1, points2, line)
+        tri1, tri2 = _prep(points1, "points1", 9, dev), _prep(points2, "points2", 9, dev)
+        ln = _prep(line, "line", 6, dev)
+        if tri1.dim() != 3 or tri2.dim() != 3 or ln.dim() != 3:
+            raise ValueError("Input is wrong: points1/points2/line must be 3-D (B, n, c)")
+        B, N, _ = tri1.shape
+        M, L = tri2.shape[1], ln.shape[1]
+        if not (tri2.shape[0] == ln.shape[0] == B):
+            raise ValueError("points1, points2 and line must share the batch dimension")
+        G = 1 if pool else B
+        ctx.set_materialize_grads(False)
+        if B == 0 or L == 0:  # empty batch / no lines: nothing to launch, no bucket
+            ctx.st = None
+            _DropinLoss.flags = [0, 0, 0, 0]
+            return torch.zeros(max(G, 1), device=dev)
+        s_m, s_n, e_m, e_n = _check_range(rng)
+        st = _lease_state(B, N, M, L, G, dev)
+        if not hasattr(st, "hostp"):  # created while capturing: no read-back possible there
+            raise RRLError("the reference-signature loss synchronises (it returns None / raises on the host): "
+                           "it cannot be captured into a graph; use batched_intersection_loss / ops.registration_loss")
+        st.loss = loss = torch.empty(G, dtype=torch.float32, device=dev)
+        with _guard(dev):
+            check(_lib.load().rrl_loss_forward_info(_p(tri1), _p(tri2), _p(ln), st.wsp, st.nbytes, _p(loss), B, N, M, L,
+                                                    s_m, s_n, e_m, e_n, int(pool), _MODES[mode], int(chunk), None,
+                                                    st.hostp, _stream(dev)), "rrl_loss_forward_info")
+        _DropinLoss.flags = st.host_info[:4].tolist()
+        ctx.st, ctx.tri1, ctx.tri2, ctx.pool = st, tri1, tri2, bool(pool)
+        ctx.in_devs = (points1.device, points2.device)
+        _IntersectionLoss.last_state = st
+        return loss
+
+    @staticmethod
+    def backward(ctx, g_loss):
+        if g_loss is None or ctx.st is None:
+            return (None,) * 7
+        st, tri1, tri2 = ctx.st, ctx.tri1, ctx.tri2
+        B, N, M, L, _ = st.dims
+        dev = tri1.device
+        g = g_loss if (g_loss.device == dev and g_loss.dtype == torch.float32 and g_loss.is_contiguous()) else \
+            g_loss.detach().to(device=dev, dtype=torch.float32).contiguous()
+        g1 = torch.empty_like(tri1)  # zeroed by rrl_loss_backward
+        g2 = torch.empty_like(tri2) if ctx.needs_input_grad[1] else None
+        with _guard(dev):
+            check(_lib.load().rrl_loss_backward(_p(tri1), _p(tri2), st.wsp, st.nbytes, _p(g), _p(g1), _p(g2),
+                                                B, N, M, L, int(ctx.pool), _stream(dev)), "rrl_loss_backward")
+        if not ctx.needs_input_grad[0]:
+            g1 = None
+        elif ctx.in_devs[0] != dev:
+            g1 = g1.to(ctx.in_devs[0])
+        if g2 is not None and ctx.in_devs[1] != dev:
+            g2 = g2.to(ctx.in_devs[1])
+        return g1, g2, None, None, None, None, None
+
+
+def intersection_loss_dropin(points1, points2, line, rng=(1, 1, 5, 5), pool=False, mode="cull", chunk=0):
+    """(loss (G,) with a grad_fn, [nbuckets, nselected, nvalues, NaN flag] as Python ints) -- the forward of the
+    reference-signature call with its single host read-back inside (one C call).  See _DropinLoss."""
+    loss = _DropinLoss.apply(points1, points2, line, tuple(rng), pool, mode, chunk)
+    return loss, _DropinLoss.flags
+
+
 def intersection_loss(points1, points2, line, rng=(1, 1, 5, 5), pool=False, mode="cull", chunk=0,
                       target_from=None):
     """Batched loss: returns (loss[G], info[G,4] = (nbuckets, nselected, nvalues, NaN flag), status[4])
@@ -511,13 +620,14 @@ def scan_counters(on, rows=1 << 17, raw=False):
 _cham_counter_buf = None
 
 
-def chamfer_counters(on, raw=False):
+def chamfer_counters(on, raw=False, rows=1 << 19):
     """Like scan_counters, for the tree Chamfer (include/rrl.h rrl_chamfer_counters): one 16-slot row per
-    wavefront of the walk (plain stores), summed here (raw=True: the table of rows)."""
+    wavefront of the walk (plain stores; rows beyond `rows` are dropped by the kernel), summed here (raw=True:
+    the table of rows).  A full table needs 8 * 2 B * ceil(max(N, M) / 64) rows."""
     global _cham_counter_buf
     prev = _cham_counter_buf
-    _cham_counter_buf = torch.zeros(16 * 8 * 2 * 32768, dtype=torch.int64, device=require_gpu()) if on else None
-    check(_lib.load().rrl_chamfer_counters(_p(_cham_counter_buf)), "rrl_chamfer_counters")
+    _cham_counter_buf = torch.zeros(16 * int(rows), dtype=torch.int64, device=require_gpu()) if on else None
+    check(_lib.load().rrl_chamfer_counters(_p(_cham_counter_buf), int(rows) if on else 0), "rrl_chamfer_counters")
     if prev is None:
         return None
     return prev.reshape(-1, 16) if raw else prev.reshape(-1, 16).sum(0)

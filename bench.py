@@ -12,12 +12,18 @@ resident in HBM before the timed region.  pairs per step = B * L * 3 * (N + M) p
 ~1 %; value = all ranks' pairs / max time over ranks.
 
 Measured in the same run, outside the timed region, and printed in the same JSON line:
-  * `variants.points1_grad`: SURVEY §8(d)'s definition through the DROP-IN callables chained by
-    autograd -- rigid apply -> loss -> backward to points1.grad (B, N, 9) and on to (dR, dT);
-  * `roofline`: the strict scan (every pair evaluated: the kernel that performs all 18 counted
-    flops per pair) against the non-FMA fp32 VALU peak, HIP-event timed on the launch stream; and
-    for the default culled kernel its launch time, the work it EXECUTED (in-kernel counters of an
-    instrumented instantiation, rrl_scan_counters) and the ratio to the dense work;
+  * `value_8d` / `ms_per_step_8d` (= `variants.points1_grad`): SURVEY §8(d)'s definition through the
+    DROP-IN callables chained by autograd -- rigid apply -> loss -> backward to points1.grad (B, N, 9)
+    and on to (dR, dT), as a hipGraph replay; `value` itself is the fused training op (config.workload);
+  * `variants.dropin_loop`: the reference trainers' LITERAL pattern (rpm/Train_RPM.py:226-231) --
+    `for j in range(B): loss += cal_loss_intersection_batch_whole_median_pts_lines(1, 1, 5, 5, p1[j:j+1], ...)`
+    then one `.backward()` -- issued eagerly, one host read-back per call as the reference's contract demands;
+  * `roofline`: the DOMINANT KERNEL OF THE TIMED STEP, cull_scan_kernel: its launch time (HIP events on
+    the launch stream), the arithmetic it EXECUTED (in-kernel counters of an instrumented instantiation,
+    rrl_scan_counters) against the non-FMA fp32 VALU peak (`frac`), the issue-side fraction from the
+    committed PMC pass of exactly this build (`issue_frac`), its HBM traffic, and `work_ratio` = dense
+    flops / executed; `roofline.dense_reference` = the strict scan (every pair evaluated: the kernel
+    that performs all 18 counted flops per pair), same run;
   * `cpu_baseline`: the C/OpenMP port and the reference-equivalent torch-eager formulation on the
     host cores, on bounded samples of the same workload.
 Weak scaling by default (B = 8 per GPU); --global-batch 64 fixes the total (BASELINE configs[2]).
@@ -59,6 +65,13 @@ def csrc_sha():
     d = os.path.join(PKG, "csrc")
     for f in sorted(x for x in os.listdir(d) if x.endswith((".hip", ".h"))) + ["../../include/rrl.h"]:
         h.update(open(os.path.join(d, f), "rb").read())
+    try:  # an experimental build (RRL_HIPCC_FLAGS) names its flags in the version string: another hash
+        from rrl_hip import _lib
+        ver = _lib.load().rrl_version()
+        if b"[" in ver:
+            h.update(ver)
+    except Exception:
+        pass
     return h.hexdigest()[:16]
 
 
@@ -219,6 +232,7 @@ def main():
     reducer = rrccl.make_reducer(dev)   # collective: the same class on every rank
     direct = hasattr(reducer, "allreduce_inline")
     evidence = reducer.evidence() if direct else None
+    print(f"[bench] rank {rank}/{world} local {local}: reducer {type(reducer).__name__} rccl {evidence}", file=sys.stderr)
 
     from rrl_hip.graph import GraphedStep
 
@@ -301,7 +315,8 @@ def main():
             finish()
             fence()
             tt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            if dist.is_initialized():
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             probe[name] = float(tt.item()) / 20 * 1e3
         best = min(probe, key=probe.get)
         choice_note = {k: round(v, 4) for k, v in probe.items()}
@@ -406,6 +421,38 @@ def main():
             "loss_sum": float(keep["loss"].sum()),
             "dR_max_rel_diff_vs_fused": float((w["R"].grad - fused_gR).abs().max() / fused_gR.abs().max())}
 
+        # the reference trainers' literal call pattern (rpm/Train_RPM.py:204-231, dcp/Train_DCP.py:266-270,
+        # fmr/model.py:302-306): transform once, then one reference-signature call per sample, summed in Python,
+        # one backward.  Eager by nature: every call reads its flags back (None / NaN are host-side decisions).
+        def loop_step():
+            w["R"].grad = w["T"].grad = None
+            tri1 = ops.rigid_apply(w["tri1"].reshape(B, 3 * N, 3), w["R"], w["T"], transpose_r=True).reshape(B, N, 9)
+            total = 0
+            for j in range(B):
+                one = Lmod.cal_loss_intersection_batch_whole_median_pts_lines(
+                    1, 1, 5, 5, tri1[j:j + 1], w["tri2"][j:j + 1], w["lines"][j:j + 1], dev)
+                if one is not None:
+                    total = total + one
+            total.backward()
+            return total
+        for _ in range(5):
+            tot = loop_step()
+        torch.cuda.synchronize()
+        nloop = max(10, min(args.steps, 50))
+        t1 = time.perf_counter()
+        for _ in range(nloop):
+            tot = loop_step()
+        torch.cuda.synchronize()
+        lms = (time.perf_counter() - t1) / nloop * 1e3
+        variants["dropin_loop"] = {
+            "ms_per_step": lms, "ms_per_call": lms / B, "value": pairs_step / (lms * 1e-3),
+            "unit": "point-pairs/s (this rank)",
+            "what": f"for j in range({B}): loss += loss.cal_loss_intersection_batch_whole_median_pts_lines(1, 1, 5, 5, "
+                    "p1[j:j+1], p2[j:j+1], line[j:j+1]) on the moved triangles, then loss.backward() to (dR, dT) -- the "
+                    "reference trainers' literal pattern, eager, one host read-back per call",
+            "loss_sum": float(tot.detach().sum()),
+            "dR_max_rel_diff_vs_fused": float((w["R"].grad - fused_gR).abs().max() / fused_gR.abs().max())}
+
         # Chamfer monitor (every caller evaluates it next to the loss): device time per call, hipGraph replay
         def time_call(fn, n=50):
             """ms per call of fn, issued eagerly and as a hipGraph replay (a replay has ~8 us of fixed cost on this
@@ -450,37 +497,57 @@ def main():
     if rank == 0:
         value = sum_pairs(world, B, args, L, N, M) * args.steps / dt
         alg_bytes = B * (N + M) * 48 + B * L * 24 + 2 * B * L * 4  # ptri + lines + counts
-        # HBM bytes per launch from PMC passes -- only when collected for exactly this build
-        traffic, traffic_detail = None, None
+        # PMC-derived figures (HBM bytes, VALU instructions per launch) -- only when collected for exactly this build
+        pmc = None
         pmc_file = os.path.join(ROOT, "profiles", "scan_hbm_traffic.json")
         if os.path.exists(pmc_file):
             rec = json.load(open(pmc_file))
             ent = rec.get(f"B{B}_N{N}_L{L}_{args.mode}")
             if ent and rec.get("csrc_sha") == csrc_sha():
-                traffic, traffic_detail = ent.get("bytes"), ent
+                pmc = ent
+        cull_s = cull_ms * 1e-3
         roofline = {
             "bound": "valu",
-            "note": "fp32 VALU-bound, not HBM- or MFMA-bound (no FMA allowed: label parity; O(L (N+M)) elementwise "
-                    "geometry).  peak = 157.3 / 2 TFLOP/s (one flop per lane-op).",
-            "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "traffic": traffic, "traffic_detail": traffic_detail,
+            "note": "fp32 VALU / latency-bound, not HBM- or MFMA-bound (no FMA allowed where labels are decided; O(L (N+M)) "
+                    "elementwise geometry).  peak = 157.3 / 2 TFLOP/s (one flop per lane-op: 256 CU x 4 SIMD-32 x 2.4 GHz).  "
+                    "achieved / frac = arithmetic the kernel EXECUTED (in-kernel counters, this run) / its launch time "
+                    "(HIP events on the launch stream, this run); issue_frac = SQ_INSTS_VALU x 64 of the committed PMC pass "
+                    "of exactly this build / the same launch time; the dense work this kernel decides (18 flops per pair) "
+                    "is work_ratio x executed.",
+            "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "kernel": "cull_scan_kernel<false> (scan mode cull: the dominant kernel of the timed step)" if args.mode == "cull"
+                      else f"scan_kernel (scan mode {args.mode})",
+            "launch_ms": cull_ms, "launches_timed": n_cull,
+            "traffic": pmc.get("bytes") if pmc else None, "traffic_detail": pmc,
             "csrc_sha": csrc_sha(),
         }
+        if roof_default is not None:
+            roofline.update({"achieved": roof_default["executed_tflops"], "frac": roof_default["executed_frac"],
+                             "executed_flops": roof_default["executed_flops"], "work_ratio": roof_default["work_ratio"],
+                             "dense_equivalent_tflops": roof_default["dense_equivalent_tflops"],
+                             "counters_per_launch": roof_default["counters_per_launch"],
+                             "ops_per_test": roof_default["ops_per_test"]})
+        elif args.mode != "cull":  # a dense mode was asked for: the timed kernel does evaluate every pair
+            roofline.update({"achieved": dense_flops / cull_s / 1e12, "frac": dense_flops / cull_s / 1e12 / VALU_PEAK_TFLOPS})
+        else:
+            roofline.update({"achieved": None, "frac": None})
+        if pmc and pmc.get("sq_insts_valu"):
+            roofline["issue_frac"] = pmc["sq_insts_valu"] * 64 / cull_s / 1e12 / VALU_PEAK_TFLOPS
+            roofline["pmc"] = {k: pmc[k] for k in pmc if k.startswith("sq_") or k == "rocprof_avg_us"}
+        else:
+            roofline["issue_frac"] = None
         if roof_dense is not None:
-            s = roof_dense["launch_ms"] * 1e-3
-            roofline.update({
-                "kernel": "scan_kernel<v2f,2> (scan mode strict: every (line, point) pair evaluated -- the kernel "
-                          "that performs all 18 counted flops per pair; HIP events on the launch stream, this run)",
-                "achieved": dense_flops / s / 1e12, "frac": dense_flops / s / 1e12 / VALU_PEAK_TFLOPS,
+            s_ = roof_dense["launch_ms"] * 1e-3
+            roofline["dense_reference"] = {
+                "kernel": "scan_kernel<v2f,2> (scan mode strict: every (line, point) pair evaluated -- the kernel that performs "
+                          "all 18 counted flops per pair; NOT part of the timed step; HIP events on the launch stream, this run)",
+                "achieved": dense_flops / s_ / 1e12, "frac": dense_flops / s_ / 1e12 / VALU_PEAK_TFLOPS,
                 "launch_ms": roof_dense["launch_ms"], "launches_timed": roof_dense["launches_timed"],
                 "algorithmic_flops_per_launch": dense_flops,
-                "loss_bit_identical_to_default_mode": roof_dense["loss_bit_identical_to_default_mode"]})
-        else:
-            roofline.update({"kernel": None, "achieved": None, "frac": None})
-        if roof_default is not None:
-            roofline["default_path"] = roof_default
+                "loss_bit_identical_to_default_mode": roof_dense["loss_bit_identical_to_default_mode"]}
         roofline["hbm"] = {"algorithmic_bytes": alg_bytes, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "achieved": alg_bytes / (cull_ms * 1e-3) / 1e9,
-                           "frac": alg_bytes / (cull_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                           "achieved": alg_bytes / cull_s / 1e9,
+                           "frac": alg_bytes / cull_s / 1e9 / HBM_PEAK_GBS,
                            "kernel": "scan launch of the timed step"}
         extras.update({"loss_sum": float(payload[0]), "valid": float(payload[1]),
                        "line_sampling_s": w["sample_s"], "scan_launch_ms": cull_ms,
@@ -507,6 +574,12 @@ def main():
                                      "rccl": evidence, "process_group": dist.is_initialized(),
                                      "backend": dist.get_backend() if dist.is_initialized() else None,
                                      "warmup_ms_per_step": choice_note}},
+            "value_8d": variants.get("points1_grad", {}).get("value"),
+            "ms_per_step_8d": variants.get("points1_grad", {}).get("ms_per_step"),
+            "value_is": "the fused training op (config.workload): rigid apply of the source + loss + backward to (dR, dT), "
+                        "dense-equivalent pairs; value_8d / ms_per_step_8d = SURVEY section 8(d) through the drop-in "
+                        "callables with points1.grad (B, N, 9) materialised (variants.points1_grad); variants.dropin_loop = "
+                        "the reference trainers' literal per-sample loop",
             "roofline": roofline,
             "variants": variants,
             "extras": extras,

@@ -12,7 +12,8 @@
  * Conventions
  *   - every pointer is a DEVICE pointer owned by the caller (PyTorch's
  *     allocator); the library allocates no device memory and never
- *     synchronises (the optional scan-timing hook owns a few hipEvents);
+ *     synchronises -- except rrl_loss_forward_info, whose purpose is the drop-in call's one read-back (the optional
+ *     scan-timing hook owns a few hipEvents);
  *   - `stream` is a hipStream_t (pass torch's current stream);
  *   - return value: 0 ok, <0 argument error (RRL_E_*), >0 a hipError_t;
  *   - all floating-point data is fp32, dense and contiguous;
@@ -176,6 +177,14 @@ int rrl_registration_forward_cached(const float *src, const float *R, const floa
                                     float *loss, int B, int N, int M, int L, int transpose_r,
                                     int s_m, int s_n, int e_m, int e_n, int mode, int chunk,
                                     const void *target_ws, void *stream);
+/* rrl_loss_forward_cached followed by the read-back the drop-in call needs: INFO (4 int32 per group: nbuckets,
+ * nselected, nvalues, NaN flag) is copied to host_info [4 G] (host memory, ideally pinned) and the call waits
+ * for the stream.  The reference's callable returns a tensor, None (no populated bucket, code/loss.py:231-232)
+ * or exits (NaN, :88-91): a host-side decision per call by contract, so this is the one entry that synchronises. */
+int rrl_loss_forward_info(const float *tri1, const float *tri2, const float *line, void *ws,
+                          size_t ws_bytes, float *loss, int B, int N, int M, int L, int s_m, int s_n,
+                          int e_m, int e_n, int pool, int mode, int chunk, const void *target_ws,
+                          int32_t *host_info, void *stream);
 /* Opt-in bit-reproducible direct backward (grad_src == NULL): on != 0 replaces the float atomics of
  * rrl_registration_backward by per-workgroup partial sums added in a fixed order by a second, tiny
  * launch (the reference's CPU autograd is deterministic).  Env RRL_DETERMINISTIC=1 sets the initial
@@ -324,10 +333,10 @@ int rrl_chamfer_from_loss(const void *ws_src, const void *ws_tar, size_t loss_ws
                           void *stream);
 /* Profiling hook like rrl_scan_counters: while dev_counters != NULL rrl_chamfer_tree_fwd runs an
  * instrumented instantiation that WRITES one row of 16 uint64 per wavefront of the walk (row index =
- * workgroup * wavefronts per workgroup + wavefront; the buffer must hold 16 * 8 * 2 B * ceil(max(N,M)/64)
- * values, cleared by the caller): [0] patch-level leaf tests, [1] per-lane leaf tests, [2] (query, leaf)
+ * workgroup * wavefronts per workgroup + wavefront; a full table has 8 * 2 B * ceil(max(N,M)/64) rows; rows >= `rows`
+ * are dropped; cleared by the caller): [0] patch-level leaf tests, [1] per-lane leaf tests, [2] (query, leaf)
  * entries evaluated, [3] (query, target) pairs evaluated, [4] 1, [5..7] / [9..14] shader clocks of the phases. */
-int rrl_chamfer_counters(uint64_t *dev_counters);
+int rrl_chamfer_counters(uint64_t *dev_counters, long long rows);
 int rrl_chamfer_bwd(const float *x, const float *y, const uint64_t *best_x,
                     const uint64_t *best_y, const float *grad_value, float *gx, float *gy, int B,
                     int N, int M, void *stream);

@@ -36,7 +36,7 @@ def test_items_match_the_reference(P, files, tag, kw):
     assert len(ds) == 2
     for i in range(2):
         item = ds[i]
-        assert set(item) == set(KEYS)
+        assert set(item) == set(KEYS) | {"p0_rows"}  # the reference's keys + the shim's first-points flag
         for k in KEYS:
             want = g[f"{tag}{i}_{k}"]
             assert item[k].shape == want.shape and item[k].dtype == want.dtype, (k, item[k].shape, want.shape)
@@ -87,3 +87,12 @@ def test_synthesize_and_list(P, tmp_path):
     train, test = P.make_loaders(str(tmp_path / "syn"), range(3), range(1), batch_size=2, n_test=1)
     b = next(iter(train))
     assert b["points_src_sample"].shape == (2, 64, 3) and len(test.dataset) == 1
+    # the first-points flag survives collation and says what it checks (the OBJ text round trip of the samples
+    # usually costs the last bits, the binary neighbour file does not: then the flag is False and rrl_hip.callsites
+    # keeps the standalone Chamfer kernel)
+    assert b["p0_rows"].dtype == __import__("torch").bool and b["p0_rows"].shape == (2,)
+    for i in range(3):
+        item = P.Dataset_2021_8_29(src[i:i + 1], tar[i:i + 1])[0]
+        same = np.array_equal(item["points_based_neighs_src"].reshape(-1, 9)[:, :3], item["points_src_sample"]) and \
+            np.array_equal(item["points_based_neighs_tar"].reshape(-1, 9)[:, :3], item["points_tar_sample"])
+        assert bool(item["p0_rows"]) == same

@@ -95,3 +95,51 @@ def test_world2_gloo(tmp_path, oracle):
     np.testing.assert_allclose(res["payload"].numpy(), np.arange(14.0) * 3)
     for step in range(3):  # ranks contribute (rank + 1) * (step + 1) * arange
         np.testing.assert_allclose(res["seen"][step].numpy(), np.arange(14.0) * 3 * (step + 1))
+
+
+def _worker8(rank, world, port, out):
+    """BASELINE configs[2] in miniature: a global batch of 64 samples sharded over 8 ranks (8 each), per-sample
+    "losses" that identify the sample (so a wrong or overlapping shard shows in the sum), and the overlapped
+    payload reducer over several steps."""
+    import sys
+    for p in (ROOT, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from rrl_hip import dist as rdist
+    r, w, _ = rdist.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+    lo, hi = rdist.shard_bounds(64, rank, world)
+    assert (lo, hi) == (8 * rank, 8 * rank + 8)
+    tag = torch.arange(64, dtype=torch.float32).reshape(64, 1, 1).expand(64, 2, 9).contiguous()  # sample b carries b
+
+    def fn(p1, p2, ln, rng):  # loss[b] = 2^-b-ish marker per sample; sample 13 and 40 are "invalid"
+        idx = p1[:, 0, 0]
+        return (idx + 1.0), ~((idx == 13) | (idx == 40))
+    total, nvalid = rdist.sharded_batch_loss(tag, tag, tag[:, :, :6].contiguous(), loss_fn=fn)
+    red = rdist.PayloadReducer(torch.device("cpu"))
+    buf = torch.zeros(14)
+    seen = []
+    for step in range(4):
+        buf.copy_(torch.arange(14.0) + 100.0 * rank + step)
+        red.submit(buf)
+        seen.append(red.finish().clone())
+    shared = torch.full((6,), float(rank))
+    rdist.reduce_loss(torch.zeros(1), torch.ones(1, dtype=torch.bool), (shared,))
+    if rank == 0:
+        torch.save(dict(total=total, nvalid=nvalid, seen=torch.stack(seen), shared=shared), out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world8_gloo_global_batch_64(tmp_path):
+    out = str(tmp_path / "r0.pt")
+    mp.spawn(_worker8, args=(8, _free_port(), out), nprocs=8, join=True)
+    res = torch.load(out)
+    want = sum(b + 1.0 for b in range(64) if b not in (13, 40))
+    assert float(res["nvalid"]) == 62.0 and float(res["total"]) == want
+    for step in range(4):  # sum over ranks of (arange + 100 rank + step)
+        np.testing.assert_allclose(res["seen"][step].numpy(), 8 * (np.arange(14.0) + step) + 100.0 * 28)
+    np.testing.assert_allclose(res["shared"].numpy(), np.full(6, 28.0))

@@ -108,25 +108,63 @@ def test_fmr_fragment(C, G):
 def test_fragments_monitor_from_the_loss_state(C, G):
     """callsites.CHAMFER_FROM_LOSS: the trainers' Chamfer monitor walks the clouds the loss evaluation
     just sorted (ops.chamfer_from_state) instead of sorting the point samples again.  The fixture's samples
-    are the first points of its pseudo-triangles, so the values equal the reference-generated ones."""
-    assert C.CHAMFER_FROM_LOSS is False  # opt-in
+    are the first points of its pseudo-triangles, so the values equal the reference-generated ones.  "auto" (the
+    default) finds that out itself -- from the dataset's `p0_rows` flag or one device comparison per data dict --
+    and falls back to the standalone kernel when the contract does not hold."""
+    from rrl_hip import ops
+    assert C.CHAMFER_FROM_LOSS == "auto"
     nb, src = np.asarray(G["nb_src"]), np.asarray(G["src"])
     np.testing.assert_array_equal(nb.reshape(nb.shape[0], -1, 9)[..., :3], src[..., :3])  # the contract
-    C.CHAMFER_FROM_LOSS = True
+    calls = {"state": 0, "plain": 0}
+    real_state, real_plain = ops.chamfer_from_state, ops.chamfer
+
+    def spy_state(*a, **k):
+        calls["state"] += 1
+        return real_state(*a, **k)
+
+    def spy_plain(*a, **k):
+        calls["plain"] += 1
+        return real_plain(*a, **k)
+    ops.chamfer_from_state, ops.chamfer = spy_state, spy_plain
     try:
-        R, t = cu(G["R"]), cu(G["t"])
-        pred = [torch.cat([R[i], t[i][..., None]], dim=-1) for i in range(R.shape[0])]
-        out = C.rpm_intersection_loss(pred, data_dict(G), lines=cu(G["rpm_lines"]))
+        for setting in ("auto", True):
+            C.CHAMFER_FROM_LOSS = setting
+            calls["state"] = calls["plain"] = 0
+            R, t = cu(G["R"]), cu(G["t"])
+            pred = [torch.cat([R[i], t[i][..., None]], dim=-1) for i in range(R.shape[0])]
+            d = data_dict(G)
+            out = C.rpm_intersection_loss(pred, d, lines=cu(G["rpm_lines"]))
+            np.testing.assert_allclose(out['loss_chamfer'].item(), G["rpm_chamfer"], rtol=1e-5)
+            np.testing.assert_allclose(out['loss_intersection'].item(), G["rpm_loss"], rtol=2e-4)
+            if setting == "auto":
+                assert d['_rrl_p0'] is True  # decided once for the dict, reused by the later iterations
+            _, chamfer, _, _ = C.dcp_intersection_loss(data_dict(G, channel_first=True), R[0], t[0], lines=cu(G["dcp_lines"]))
+            np.testing.assert_allclose(chamfer.item(), G["dcp_chamfer"], rtol=1e-5)
+            bottom = torch.tensor([0.0, 0, 0, 1], device='cuda').expand(R.shape[1], 1, 4)
+            gs = [torch.cat([torch.cat([R[i], t[i][..., None]], dim=-1), bottom], dim=1) for i in range(R.shape[0])]
+            _, chamfer, _, _ = C.fmr_intersection_loss(gs, data_dict(G), lines=cu(G["fmr_lines"]))
+            np.testing.assert_allclose(chamfer.item(), G["fmr_chamfer"], rtol=1e-5)
+            assert calls["plain"] == 0 and calls["state"] == len(pred) + 2
+        # a batch whose samples are NOT the triangles' first points: auto takes the standalone kernel, same value
+        C.CHAMFER_FROM_LOSS = "auto"
+        calls["state"] = calls["plain"] = 0
+        d = data_dict(G)
+        d['points_src_sample'] = d['points_src_sample'].flip(1).contiguous()  # the same cloud in another order
+        out = C.rpm_intersection_loss(pred, d, lines=cu(G["rpm_lines"]))
+        assert d['_rrl_p0'] is False and calls["state"] == 0 and calls["plain"] == len(pred)
         np.testing.assert_allclose(out['loss_chamfer'].item(), G["rpm_chamfer"], rtol=1e-5)
-        np.testing.assert_allclose(out['loss_intersection'].item(), G["rpm_loss"], rtol=2e-4)
-        _, chamfer, _, _ = C.dcp_intersection_loss(data_dict(G, channel_first=True), R[0], t[0], lines=cu(G["dcp_lines"]))
-        np.testing.assert_allclose(chamfer.item(), G["dcp_chamfer"], rtol=1e-5)
-        bottom = torch.tensor([0.0, 0, 0, 1], device='cuda').expand(R.shape[1], 1, 4)
-        gs = [torch.cat([torch.cat([R[i], t[i][..., None]], dim=-1), bottom], dim=1) for i in range(R.shape[0])]
-        _, chamfer, _, _ = C.fmr_intersection_loss(gs, data_dict(G), lines=cu(G["fmr_lines"]))
-        np.testing.assert_allclose(chamfer.item(), G["fmr_chamfer"], rtol=1e-5)
-    finally:
+        # the dataset's flag decides without looking at the data
+        d = data_dict(G)
+        d['p0_rows'] = torch.zeros(3, dtype=torch.bool)
+        C.rpm_intersection_loss(pred, d, lines=cu(G["rpm_lines"]))
+        assert d['_rrl_p0'] is False
         C.CHAMFER_FROM_LOSS = False
+        calls["state"] = 0
+        C.rpm_intersection_loss(pred, data_dict(G), lines=cu(G["rpm_lines"]))
+        assert calls["state"] == 0
+    finally:
+        C.CHAMFER_FROM_LOSS = "auto"
+        ops.chamfer_from_state, ops.chamfer = real_state, real_plain
 
 
 def test_fragments_draw_their_own_lines(C, G):
@@ -293,15 +331,14 @@ def test_dataset_to_fragments(C, tmp_path):
 
 
 # ------------------------------------------------------------------------ bench.py under torch.distributed.run
-def _bench_child(extra, launcher):
+def _bench_child(extra, launcher, base=("--steps", "200", "--warmup", "20", "--no-cpu-baseline", "--no-extras")):
     import json
     import subprocess
     import sys
     from conftest import ROOT
     cmd = ([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
             "127.0.0.1", "--master-port", "29731"] if launcher else [sys.executable])
-    cmd += [os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "200", "--warmup", "20", "--no-cpu-baseline",
-            "--no-extras"] + extra
+    cmd += [os.path.join(ROOT, "bench.py"), "--gpus", "1", *base] + extra
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -337,3 +374,25 @@ def test_bench_under_torchrun_uses_rccl_in_graph():
     # strong scaling flag: a fixed global batch sharded over the ranks (configs[2] with --global-batch 64)
     strong = _bench_child(["--global-batch", "16"], launcher=True)
     assert strong["scaling"] == "strong" and strong["config"]["global_batch"] == 16 and strong["extras"]["valid"] == 16.0
+
+
+def test_bench_line_describes_what_it_times():
+    """The JSON line's top-level roofline belongs to the dominant kernel of the TIMED step (the culled scan): its launch
+    is shorter than the step, its fraction is executed work / launch time; the strict scan sits under dense_reference;
+    the section-8(d) variant and the reference trainers' literal per-sample loop are in the same line; and a plain
+    `--no-dist` invocation with the default issue probe (two candidates) runs without a process group."""
+    run = _bench_child(["--no-dist"], launcher=False, base=("--steps", "60", "--warmup", "10", "--no-cpu-baseline"))
+    rf = run["roofline"]
+    assert rf["kernel"].startswith("cull_scan_kernel") and rf["bound"] == "valu" and rf["peak"] == 78.6
+    assert 0 < rf["launch_ms"] <= run["ms_per_step"]
+    assert abs(rf["frac"] - rf["executed_flops"] / (rf["launch_ms"] * 1e-3) / 1e12 / rf["peak"]) < 1e-9
+    assert 0.03 < rf["frac"] < 1.0 and rf["work_ratio"] > 10
+    dr = rf["dense_reference"]
+    assert dr["kernel"].startswith("scan_kernel") and dr["launch_ms"] > run["ms_per_step"] and 0.4 < dr["frac"] < 1.0
+    assert dr["loss_bit_identical_to_default_mode"] is True
+    v = run["variants"]
+    assert run["value_8d"] == v["points1_grad"]["value"] and run["ms_per_step_8d"] == v["points1_grad"]["ms_per_step"]
+    assert run["ms_per_step"] < run["ms_per_step_8d"] < v["dropin_loop"]["ms_per_step"]
+    assert v["dropin_loop"]["loss_sum"] == pytest.approx(v["points1_grad"]["loss_sum"], rel=1e-6)
+    assert v["dropin_loop"]["dR_max_rel_diff_vs_fused"] < 1e-5 and v["points1_grad"]["dR_max_rel_diff_vs_fused"] < 1e-5
+    assert run["config"]["allreduce"]["process_group"] is False

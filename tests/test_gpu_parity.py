@@ -434,6 +434,48 @@ def test_batched_equals_per_sample(L):
         assert one.item() == loss[b].item()
 
 
+def test_trainer_loop_over_samples(L):
+    """The reference trainers' literal pattern (rpm/Train_RPM.py:226-231): B reference-signature calls on [j:j+1]
+    slices summed in Python, ONE backward at the end.  The calls lease their workspaces from a per-shape pool
+    (ops._DropinLoss): every forward must keep its own state until the backward has used it, results held by the
+    caller must not alias, and a second round must reuse the pool instead of growing it."""
+    from rrl_hip import ops, synth
+    B, N, M, Ll = 4, 700, 600, 1500
+    prs = [synth.make_pair(400 + b, N, M) for b in range(B)]
+    tri1 = cu(np.stack([p["src_tri"] for p in prs]))
+    tri2 = cu(np.stack([p["tar_tri"] for p in prs]))
+    ln = []
+    for b, p in enumerate(prs):
+        torch.manual_seed(b)
+        ln.append(L.Random_uniform_distribution_lines_batch_efficient_resample(
+            torch.tensor([[float(p["radius"])]]), torch.from_numpy(p["center"]).reshape(1, 3), Ll,
+            cu(p["src"])[None], cu(p["tar"])[None], "cuda")[0])
+    ln = torch.stack(ln)
+    ref_in = tri1.clone().requires_grad_(True)
+    ref_loss, ref_info, _ = ops.intersection_loss(ref_in, tri2, ln)
+    ref_loss.sum().backward()
+    assert int((ref_info[:, 0] > 0).sum()) == B
+    for rnd in range(2):
+        p1 = tri1.clone().requires_grad_(True)
+        parts, total = [], 0
+        for j in range(B):
+            one = L.cal_loss_intersection_batch_whole_median_pts_lines(1, 1, 5, 5, p1[j:j + 1], tri2[j:j + 1], ln[j:j + 1], "cuda")
+            assert one is not None and one.shape == (1,)
+            parts.append(one)
+            total = total + one
+        for j in range(B):  # nothing was overwritten by the later calls
+            assert parts[j].item() == ref_loss[j].item()
+        total.backward()
+        np.testing.assert_allclose(p1.grad.cpu().numpy(), ref_in.grad.cpu().numpy(), rtol=2e-5, atol=1e-9)  # float atomics
+        if rnd == 0:
+            pooled = sum(len(v) for v in ops._pool.values())
+    assert sum(len(v) for v in ops._pool.values()) == pooled  # the second round reused the leased states
+    with torch.no_grad():  # no autograd node keeps the state: still no aliasing between successive results
+        a = L.cal_loss_intersection_batch_whole_median_pts_lines(1, 1, 5, 5, tri1[0:1], tri2[0:1], ln[0:1], "cuda")
+        b_ = L.cal_loss_intersection_batch_whole_median_pts_lines(1, 1, 5, 5, tri1[1:2], tri2[1:2], ln[1:2], "cuda")
+    assert a.item() == ref_loss[0].item() and b_.item() == ref_loss[1].item()
+
+
 def test_shard_payload(L):
     from rrl_hip import ops
     g = load_golden("loss_b2_quirk.npz")

@@ -2,7 +2,7 @@
 # usage (GPU box): tools/knob_prof.sh <kernel-substring> "<flags>" ...  rebuilds per flag set, prints that kernel's average
 K=$1; shift
 for flags in "$@"; do
-  RRL_HIPCC_FLAGS="$flags" python3 a-robust-registration-loss_amd/rrl_hip/build.py > /dev/null 2>&1 || { echo "$flags: BUILD FAILED"; continue; }
+  export RRL_HIPCC_FLAGS="$flags"; python3 a-robust-registration-loss_amd/rrl_hip/build.py > /dev/null 2>&1 || { echo "$flags: BUILD FAILED"; continue; }
   ( cd /tmp; export TMPDIR=/tmp; rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/gpurun_out/kp -o w -- python3 /root/repo/bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-graph > /dev/null 2>&1 )
   python3 - "$K" "$flags" <<'PY'
 import csv, sys

@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage (GPU box): tools/knob_sweep.sh "-DBGRP=16" "-DBGRP=8" ...   rebuilds the library per flag set, times the step
 for flags in "$@"; do
-  RRL_HIPCC_FLAGS="$flags" python3 a-robust-registration-loss_amd/rrl_hip/build.py > /dev/null 2>&1 || { echo "$flags: BUILD FAILED"; continue; }
+  export RRL_HIPCC_FLAGS="$flags"; python3 a-robust-registration-loss_amd/rrl_hip/build.py > /dev/null 2>&1 || { echo "$flags: BUILD FAILED"; continue; }
   echo "== $flags"
   python3 tools/reuse_timing.py 2>/dev/null | head -1
   python3 - <<'PY'

@@ -52,13 +52,22 @@ for d in ("sqa", "sqb"):
 out["sq_per_kernel"] = {k: v for k, v in sq.items() if "cull" in k or "tri_" in k or "loss_" in k or "line_pair" in k}
 json.dump(out, open(f"{O}/{tag}_pmc_summary.json", "w"), indent=1)
 c_ = out["hbm_per_kernel"].get("cull_scan_kernel", {})
-if "FETCH_SIZE" in c_ and "WRITE_SIZE" in c_:  # the object bench.py reports as roofline.traffic
-    json.dump({"csrc_sha": csrc_sha(), "B8_N4096_L10000_cull": {
-        "kernel": "cull_scan_kernel", "fetch_kb_raw": c_["FETCH_SIZE"], "write_kb_raw": c_["WRITE_SIZE"],
-        "bytes": int(c_["bytes_corrected"]),
-        "correction": "FETCH_SIZE x2 (gfx950 wide-read undercount), WRITE_SIZE as reported",
-        "source": f"profiles/{tag}_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, "
-                  "bench.py --no-graph --steps 6)"}}, open(f"{O}/{tag}_scan_hbm_traffic.json", "w"), indent=1)
+sq_ = out["sq_per_kernel"].get("cull_scan_kernel", {})
+step_rows = list(csv.DictReader(open(glob.glob(f"{O}/{tag}_stats_step/**/*kernel_stats.csv", recursive=True)[0])))
+cull_avg = [float(r["AverageNs"]) / 1e3 for r in step_rows if "cull_scan_kernel" in r["Name"]]
+if "FETCH_SIZE" in c_ and "WRITE_SIZE" in c_:  # the object bench.py reports under roofline (traffic, issue_frac, pmc)
+    ent = {"kernel": "cull_scan_kernel", "fetch_kb_raw": c_["FETCH_SIZE"], "write_kb_raw": c_["WRITE_SIZE"],
+           "bytes": int(c_["bytes_corrected"]),
+           "correction": "FETCH_SIZE x2 (gfx950 wide-read undercount), WRITE_SIZE as reported",
+           "source": f"profiles/{tag}_pmc_summary.json (rocprofv3 --pmc, separate passes per counter group, "
+                     "bench.py --no-graph --steps 6; per-launch means) and profiles/" + tag + "_step_kernel_stats.csv"}
+    for k in ("SQ_INSTS_VALU", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_VALU",
+              "SQ_ACTIVE_INST_ANY", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_ACTIVE_INST_LDS"):
+        if k in sq_:
+            ent[k.lower()] = sq_[k]
+    if cull_avg:
+        ent["rocprof_avg_us"] = cull_avg[0]
+    json.dump({"csrc_sha": csrc_sha(), "B8_N4096_L10000_cull": ent}, open(f"{O}/{tag}_scan_hbm_traffic.json", "w"), indent=1)
 rows = list(csv.DictReader(open(glob.glob(f"{O}/{tag}_stats_step/**/*kernel_stats.csv", recursive=True)[0])))
 for r in rows[:12]:
     print(f"{r['Name'][:44]:44s} {r['Calls']:>5s} {float(r['AverageNs'])/1e3:9.1f} us")

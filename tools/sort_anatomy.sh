@@ -20,9 +20,9 @@ PY
 export RRL_ROOT=$R
 for k in 1 2 3 4 5 0; do
   flags=""; [ $k != 0 ] && flags="-DSORT_STOP=$k"
-  RRL_HIPCC_FLAGS="$flags" python3 a-robust-registration-loss_amd/rrl_hip/build.py > /dev/null 2>&1 || { echo "$flags: BUILD FAILED"; continue; }
+  export RRL_HIPCC_FLAGS="$flags"; python3 a-robust-registration-loss_amd/rrl_hip/build.py > /dev/null 2>&1 || { echo "$flags: BUILD FAILED"; continue; }
   (cd /tmp; export TMPDIR=/tmp; rocprofv3 --kernel-trace --stats --output-format csv -d $O/sortan$k -o s -- python3 /tmp/sort_drv.py > /dev/null 2>&1)
   f=$(find $O/sortan$k -name '*kernel_stats.csv' | head -1)
   echo -n "SORT_STOP=$k  "; grep -E "tri_sort|tri_records" $f | awk -F, '{printf "%s avg %.2f us   ", substr($1,1,28), $4/1000}'; echo
 done
-python3 a-robust-registration-loss_amd/rrl_hip/build.py > /dev/null 2>&1
+unset RRL_HIPCC_FLAGS  # (experimental builds live in lib_exp/: the default library was never touched)

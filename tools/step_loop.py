@@ -1,0 +1,41 @@
+"""The fused step (ops.RegistrationStep: forward + direct backward) in a plain loop at one shape -- the
+workload tools/kt.sh runs under rocprofv3 to get per-kernel averages.  usage: step_loop.py B,N,M,L [steps] [diag]
+Environment knobs of the library apply (RRL_REDUCE, RRL_SORT_PARTS, RRL_CULL_GEOM, ...)."""
+import os, sys, time
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "a-robust-registration-loss_amd"))
+from rrl_hip import ops, synth
+import loss as Lmod
+
+B, N, M, L = (int(v) for v in sys.argv[1].split(","))
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+diag = float(sys.argv[3]) if len(sys.argv) > 3 and float(sys.argv[3]) > 0 else None
+prs = [synth.make_pair(b, N, M) for b in range(B)]
+scale = 1.0
+if diag is not None:
+    for p in prs:
+        sc = np.float32(diag / (2.0 * float(p["radius"])))
+        for k in ("src", "tar", "src_tri", "tar_tri", "center"):
+            p[k] = (p[k] * sc).astype(np.float32)
+        p["radius"] = float(p["radius"]) * float(sc)
+src = torch.from_numpy(np.stack([p["src_tri"] for p in prs])).cuda()
+tar = torch.from_numpy(np.stack([p["tar_tri"] for p in prs])).cuda()
+ln = []
+for b, p in enumerate(prs):
+    torch.manual_seed(b)
+    ln.append(Lmod.Random_uniform_distribution_lines_batch_efficient_resample(
+        torch.tensor([[float(p["radius"]) * (2.0 if diag is not None else 1.0)]]), torch.from_numpy(p["center"]).reshape(1, 3), L,
+        torch.from_numpy(p["src"])[None].cuda(), torch.from_numpy(p["tar"])[None].cuda(), "cuda")[0])
+ln = torch.stack(ln)
+R = torch.eye(3, device="cuda").repeat(B, 1, 1)
+t = torch.zeros(B, 3, device="cuda")
+rs = ops.RegistrationStep(src, tar, L, transpose_r=True, mode=os.environ.get("RRL_SCAN_MODE", "cull"))
+for _ in range(10):
+    rs(R, t, ln)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(steps):
+    rs(R, t, ln)
+torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
+print(f"shape {B},{N},{M},{L} diag {diag}: {dt * 1e6:.1f} us per step (direct issue), loss_sum {float(rs.st.loss.sum()):.10f} "
+      f"nsel {rs.st.info[:, 1].tolist()} status {rs.st.status.tolist()}")
