@@ -1058,6 +1058,8 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(6, 8))
     return;
 #endif
     if (!has_lines) return;  // uniform per wavefront
+    const unsigned long long wall_staged = COUNT ? wall_clock64() : 0ull;
+    unsigned long long wall_a = 0ull, wall_pa = 0ull, wall_pb = 0ull, wall_pc = 0ull;
 
     WaveCtx ctx;
     ctx.lr = lr;
@@ -1123,9 +1125,13 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(6, 8))
 #pragma unroll
         for (int c = 0; c < 4; ++c) cur[c] = nxt[c];
     }
+    if constexpr (COUNT) wall_a = wall_clock64();
     proc_a<COUNT>(ctx, true);
+    if constexpr (COUNT) wall_pa = wall_clock64();
     proc_b<COUNT>(ctx, true);
+    if constexpr (COUNT) wall_pb = wall_clock64();
     proc_c<COUNT>(ctx, true);
+    if constexpr (COUNT) wall_pc = wall_clock64();
     flush_cands<COUNT>(ctx);
     }
     if constexpr (COUNT) {
@@ -1136,6 +1142,9 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(6, 8))
             crow[6] = fallback ? 1ull : 0ull;
             crow[7] = fb_pairs;
             crow[8] = wall0; crow[9] = wall_clock64();
+            // phase stamps of the culled walk: staged (after the last staging barrier), level A done, the final drains
+            // of levels B, C, D done (the remainder up to [9] is the last candidate flush)
+            crow[10] = wall_staged; crow[11] = wall_a; crow[12] = wall_pa; crow[13] = wall_pb; crow[14] = wall_pc;
         }
     }
 }
@@ -1150,9 +1159,10 @@ extern "C" int rrl_scan_counters(uint64_t *dev_counters, long long rows) {
     return 0;
 }
 
-// Workgroups per cloud (or chunk) of tri_sort_kernel: 1 / parts of the scatter + copy-out + tree work per CU against
-// the loads and the histogram repeated in each -- 4 for >= 32 supergroups, fewer for small clouds whose sort is all
-// fixed cost.  rrl_set_sort_parts / RRL_SORT_PARTS override (1 = the single workgroup of rounds 1-2).
+// Workgroups per cloud (or chunk) of tri_sort_kernel.  Measured (round 3, profiles/r03_reduce_sort_parts.txt): 1 / 2 / 4
+// parts cost 10.4 / 10.3 / 10.2 us at C2 and 8.4 / 8.0 / 9.0-9.6 at the demo's shape -- the phases that split (scatter,
+// copy-out, tree) are one pass per lane either way, i.e. latency, not throughput, and the repeated loads cost what
+// the split saves.  So the default stays ONE workgroup; rrl_set_sort_parts / RRL_SORT_PARTS select more (tests, sweeps).
 static int g_sort_parts = -1;  // 0 automatic, k >= 1 forced; -1: read RRL_SORT_PARTS once
 extern "C" int rrl_set_sort_parts(int parts) {
     if (parts < 0 || parts > 16) return RRL_E_ARG;
@@ -1165,8 +1175,7 @@ static int sort_parts(int nsg) {
         g_sort_parts = e ? atoi(e) : 0;
         if (g_sort_parts < 0 || g_sort_parts > 16) g_sort_parts = 0;
     }
-    int k = g_sort_parts ? g_sort_parts : nsg / 8;
-    if (!g_sort_parts && k > 4) k = 4;
+    int k = g_sort_parts ? g_sort_parts : 1;
     if (k > nsg) k = nsg;
     return k < 1 ? 1 : k;
 }

@@ -359,7 +359,7 @@ class _DropinLoss(torch.autograd.Function):
         ctx.st, ctx.tri1, ctx.tri2, ctx.pool = st, tri1, tri2, bool(pool)
         ctx.in_devs = (points1.device, points2.device)
         _IntersectionLoss.last_state = st
-        return loss
+        return loss.view(-1)  # a view: st.loss itself must not become the autograd output (st -> loss -> node -> st)
 
     @staticmethod
     def backward(ctx, g_loss):

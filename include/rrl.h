@@ -235,7 +235,7 @@ int rrl_loss_reduce(void *ws, size_t ws_bytes, float *loss, int B, int N, int M,
 int rrl_set_reduce_mode(int mode);
 
 /* Workgroups per cloud of the cell sort + sphere-tree kernel (they share nothing but their input: each owns a range
- * of supergroups): 0 = automatic (up to 4), k = 1..16 forced.  Any value gives the same labels, loss and Chamfer
+ * of supergroups): 0 = default (one: more measured no faster, csrc/rrl_cull.hip sort_parts), k = 1..16 forced.  Any value gives the same labels, loss and Chamfer
  * keys; the order of records INSIDE a grid cell may differ.  Env RRL_SORT_PARTS sets the initial state. */
 int rrl_set_sort_parts(int parts);
 
@@ -257,7 +257,8 @@ int rrl_scan_timing_collect(float *ms, int max_n);
  *   [0] level-A sphere tests (line x supergroup)   [1] level-B (line x group)   [2] level-C (line x half)
  *   [3] point-0 prefilter tests (line x record)    [4] candidates resolved exactly (all 3 points)
  *   [5] 1 (the wavefront ran)                      [6] 1 if it took the strict fallback
- *   [7] (line, triangle) pairs evaluated by the fallback   [8], [9] its start / end on the 100 MHz wall clock.
+ *   [7] (line, triangle) pairs evaluated by the fallback   [8], [9] its start / end on the 100 MHz wall clock;
+ *   [10..14] phase stamps on the same clock: slice staged, level A done, final drains of levels B / C / D done.
  * NULL switches back to the plain kernel.  bench.py derives the executed flops of a launch from
  * these (12 per sphere test, 11 per prefilter test, 48 per resolved candidate, 48 per fallback pair). */
 int rrl_scan_counters(uint64_t *dev_counters, long long rows);

@@ -28,3 +28,12 @@ work = rows[:, 1] * 12 + rows[:, 2] * 12 + rows[:, 3] * 16 + rows[:, 4] * 32
 print(f"  per-wavefront work (lane-ops below level A): mean {work.mean():.0f}, 90 % {pc(work,90):.0f}, max {work.max():.0f}; corr(lifetime, work) = {np.corrcoef(life, work)[0,1]:.2f}")
 late = rows[end > pc(end, 99)]
 print(f"  the slowest 1 %: mean exact tests {late[:,3].mean():.0f} (all: {rows[:,3].mean():.0f}), candidates {late[:,4].mean():.0f} (all: {rows[:,4].mean():.0f})")
+
+if rows.shape[1] > 14 and rows[:, 10].max() > 0:
+    culled = rows[rows[:, 6] == 0]
+    ph = np.stack([culled[:, 10] - culled[:, 8], culled[:, 11] - culled[:, 10], culled[:, 12] - culled[:, 11],
+                   culled[:, 13] - culled[:, 12], culled[:, 14] - culled[:, 13], culled[:, 9] - culled[:, 14]], 1) / 100.0
+    names = ["prologue (loads, slack, staging)", "level A (+ interleaved drains)", "drain B", "drain C", "drain D", "candidate flush"]
+    first = culled[:, 8] - rows[:, 8].min() < 200  # started in the first 2 us: the full-occupancy generation
+    print("  phase means us (all / first generation / later): " + "; ".join(
+        f"{n} {ph[:, i].mean():.2f} / {ph[first, i].mean():.2f} / {ph[~first, i].mean() if (~first).any() else float('nan'):.2f}" for i, n in enumerate(names)))
