@@ -124,14 +124,66 @@ struct BuildArgs {
     uint4 *z3;                     // per-call state of the tiled reduce (MHIST, MCTL, MSUM; may be NULL)
     size_t z3_vec4;
     float *del1, *del2;            // NaN reach of every triangle (may be NULL: not stored)
+    const float *line;             // the samples' lines [B][L][6] and where their partial maxima go (may be NULL:
+    float2 *lmax;                  //   the scan entry computes them itself then)
+    int L;
+    int nblk_tri;                  // tri_records_kernel: workgroups [0, nblk_tri) of a (sample, cloud) hold triangles
     int B, N, M, transpose_r, nblk;
     int nchunk;                    // tri_sort_kernel: chunks of 4096 records per cloud (1: the whole cloud)
 };
 
 #define REC_BLK 256
+#define LMAX_CHUNKS 64  // per-sample partial maxima of the lines' |dir|^2 and |x0|^2 (-> the culled scan's slack)
+
+// |dir|^2 and |x0|^2 of a line as BOTH this pass (partial maxima) and the scan (per-line admission) evaluate them:
+// the same fp32 expressions, so a line the scan admits is covered by the maxima.
+__device__ __forceinline__ void line_norms(float dx, float dy, float dz, float ox, float oy, float oz, float &s, float &o2) {
+    s = dx * dx + dy * dy + dz * dz;
+    o2 = ox * ox + oy * oy + oz * oz;
+}
+// A line can be culled when its direction is (at most) unit length as evaluated and its offset is moderate; any
+// NaN fails both comparisons.  Lines that fail send their wavefront through the strict loop.
+__device__ __forceinline__ bool line_cullable(float s, float o2) { return s <= 1.000001f && o2 <= 1.0e11f; }
+
+// Chunks ch0, ch0 + stride, ... (< LMAX_CHUNKS) of sample b's lines by one 256-lane workgroup: lmax[b][ch] =
+// (max |dir|^2, max |x0|^2) over the chunk's cullable lines (0, 0 for none).  The culled scan derives its slacks
+// from the maxima over the 64 chunks, identically in every wavefront -- no exchange inside that kernel.
+__device__ __forceinline__ void line_max_chunks(const float *__restrict__ line, int L, float2 *__restrict__ lmax, int b,
+                                                int ch0, int stride, float (*red2)[2]) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int CL = (L + LMAX_CHUNKS - 1) / LMAX_CHUNKS;
+    for (int ch = ch0; ch < LMAX_CHUNKS; ch += stride) {  // uniform
+        float sm = 0.0f, om = 0.0f;
+        const int lend = min(L, (ch + 1) * CL);
+        for (int l = ch * CL + tid; l < lend; l += REC_BLK) {
+            const float2 *p = (const float2 *)(line + ((size_t)b * L + l) * 6);  // 24-byte rows: 8-byte aligned
+            const float2 q0 = p[0], q1 = p[1], q2 = p[2];                       // dir.xy | dir.z x0.x | x0.yz
+            float s, o2;
+            line_norms(q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, s, o2);
+            if (line_cullable(s, o2)) { sm = fmaxf(sm, s); om = fmaxf(om, o2); }
+        }
+        sm = wave_max(sm);
+        om = wave_max(om);
+        __syncthreads();  // red2 free again
+        if (lane == 0) { red2[wave][0] = sm; red2[wave][1] = om; }
+        __syncthreads();
+        if (tid == 0) {
+            float a0 = red2[0][0], a1 = red2[0][1];
+            for (int w = 1; w < REC_BLK / 64; ++w) { a0 = fmaxf(a0, red2[w][0]); a1 = fmaxf(a1, red2[w][1]); }
+            lmax[(size_t)b * LMAX_CHUNKS + ch] = make_float2(a0, a1);
+        }
+    }
+}
+
+// the same pass on its own, for callers that prepared the triangles without the lines (rrl_tri_prepare + rrl_line_tri_scan)
+__global__ __launch_bounds__(REC_BLK) void line_max_kernel(const float *__restrict__ line, int L, float2 *__restrict__ lmax) {
+    __shared__ float red2[REC_BLK / 64][2];
+    line_max_chunks(line, L, lmax, (int)blockIdx.y, (int)blockIdx.x, (int)gridDim.x, red2);
+}
 
 __global__ __launch_bounds__(REC_BLK) void tri_records_kernel(const BuildArgs a) {
     __shared__ float red[REC_BLK / 64][8];
+    __shared__ float red2[REC_BLK / 64][2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int cloud = blockIdx.z, b = blockIdx.y, B = a.B;
     {   // per-call state and gradient accumulator, spread over all workgroups of the launch
@@ -144,6 +196,11 @@ __global__ __launch_bounds__(REC_BLK) void tri_records_kernel(const BuildArgs a)
         for (size_t i = me; i < a.z3_vec4; i += nthr) a.z3[i] = z;
     }
     const int n = cloud ? a.M : a.N;
+    if ((int)blockIdx.x >= a.nblk_tri) {  // uniform: the launch's LMAX_CHUNKS extra workgroups per sample reduce its lines
+        if (cloud == 0 && a.lmax != nullptr)  // (one chunk each: they run beside the triangle workgroups)
+            line_max_chunks(a.line, a.L, a.lmax, b, (int)blockIdx.x - a.nblk_tri, LMAX_CHUNKS, red2);
+        return;
+    }
     const int f = blockIdx.x * REC_BLK + tid;
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY}, p2 = 0.0f;
     if (f < n) {
@@ -589,7 +646,6 @@ typedef const int __attribute__((address_space(4))) * kiptr;
 #define SPW 8      // supergroups per slice (<= 16: SG_BITS); staged once per workgroup
 #endif
 #define SG_BITS 4              // queue entries: line << SG_BITS | supergroup of the slice,
-#define GP_BITS (SG_BITS + 2)  //                line << GP_BITS | group of the slice,
 #define HF_BITS (SG_BITS + 3)  //                line << HF_BITS | half of the slice (7 + 7 bits: 16-bit entries)
 static_assert(SPW <= (1 << SG_BITS), "slot bits of the queue entries");
 #ifndef WPB
@@ -600,27 +656,27 @@ static_assert(SPW <= (1 << SG_BITS), "slot bits of the queue entries");
 #ifndef WCCAP
 #define WCCAP 128  // parked point-0 candidates per wave
 #endif
-// queue capacities: a level only runs while >= 64 entries wait (until the final drain), so a
-// queue holds at most 63 left-over entries plus one push round (128 / 256 / 128)
-#define QA_CAP 192
-#define QB_CAP 320
-#define QC_CAP 192
+// queue capacities.  Level A leaves ALL of a wavefront's (line, supergroup) pairs in queue A at once when they fit
+// (~128 of the 1024 possible; otherwise supergroup by supergroup with drains in between); level B pops 64 of them
+// and pushes their passing halves (~1.4 of 8 each, at most 512: split then) on top of < 64 left-overs of queue C.
+#define QA_CAP 256
+#define QC_CAP 256
 
 struct WaveCtx {
     const float2 *lr;             // this wave's lines in LDS as they lie in memory: 3 float2 per line (dir.xy | dir.z x0.x | x0.yz)
     const float4 *recs;           // LDS: staged records of the slice, [group][ROWS]
     const float4 *nodes;          // LDS: staged tree nodes of the slice, [supergroup][NODE]
-    unsigned short *qa, *qb, *qc; // LDS queues: line << SG_BITS | sg, << GP_BITS | group, << HF_BITS | half (slice-local)
+    unsigned short *qa, *qc;      // LDS queues: line << SG_BITS | sg, line << HF_BITS | half (slice-local)
     unsigned *cands;              // LDS [WCCAP]
     const int32_t *idx;           // sorted position -> original triangle index
     const float *ptri;            // prepared triangles (original order)
     int32_t *cnt, *hit;           // per-line hit count / slots of the cloud
     int lbase;                    // first line of this wave
     int pos0;                     // sorted position of the slice's first record
-    int na, nb, nc, ncand;        // wave-uniform fill levels
+    int na, nc, ncand;            // wave-uniform fill levels
     int lane;
     // executed-work counters of the COUNT instantiation (wave-uniform; see rrl_scan_counters)
-    unsigned tb, tc, td, tcand;   // level-B / level-C sphere tests, point-0 prefilter tests, resolved candidates
+    unsigned tb, tc, td, tcand;   // level-B half-sphere tests, halves that passed, point-0 prefilter tests, resolved candidates
     int32_t *status;              // NaN flag of the call
 };
 
@@ -668,36 +724,37 @@ __device__ __forceinline__ int lane_rank(unsigned long long m) {  // set bits of
     return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
 }
 
-// Per-line slack of the culling bound (header).  ok = false: the line cannot be culled (|d|^2 above
-// 1 + 1e-6, or non-finite data).  nanfree: a negative sqrt argument is provably impossible.
-struct LineSlack {
-    bool ok, nanfree;
-    float se;  // slack of the node radii
-    float a2;  // (|x0| + max|P|)^2, rounded up: bounds |P - x0|^2 for every point of the cloud
+// Slack of the culling bound (header) for one (cloud, sample) from the maxima over its cullable lines: s = max |dir|^2,
+// o2 = max |x0|^2, pm = max |P|^2.  Every term is monotone in s and o2, so the values cover each admitted line.
+struct CloudSlack {
+    bool ok;       // pm is finite and moderate (else: every wavefront of this cloud takes the strict loop)
+    bool nanwide;  // g > 0: a negative sqrt argument is not excluded at this scale
+    float se;      // slack of the node radii
+    float s0;      // slack of the point-0 prefilter
 };
-__device__ __forceinline__ LineSlack cull_line_slack(const float *v, float pm) {
-    const float s = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
-    const float o2 = v[3] * v[3] + v[4] * v[4] + v[5] * v[5];
+__device__ __forceinline__ CloudSlack cull_cloud_slack(float s, float o2, float pm) {
+    CloudSlack r;
+    r.ok = pm <= 1.0e11f;  // (false for NaN / inf: non-finite coordinates)
     const float A2 = (o2 + pm + 2.0f * sqrtf(o2 * pm)) * 1.00001f;  // (|x0| + max|P|)^2, rounded up
-    LineSlack r;
-    r.ok = (s <= 1.000001f) && (A2 <= 1.0e12f);  // a NaN anywhere fails both
     const float eta = fmaxf(s - 1.0f, 0.0f) + 2.5e-7f;  // |d|^2 - 1 incl. the rounding of s (<= 3u s)
     const float x = eta * A2;
     const float g = 1.8e-6f * A2 - 2e-4f;  // 30u = 1.788e-6
-    r.nanfree = g <= 0.0f;
+    r.nanwide = g > 0.0f;
     const float se = g > 0.0f ? sqrtf(g + x) : fminf(sqrtf(x), x / (2.0f * sqrtf(-0.999f * g)));
     r.se = se * 1.0001f + 1e-12f;
-    r.a2 = A2;
+    r.s0 = 3.0e-6f * A2 + 1.0e-9f;  // 44.2 u A^2 of evaluation error on both sides, rounded up, + an absolute floor
     return r;
 }
 
-// conservative sphere test of one line against one STAGED tree node (centre, w = (Rs + se)^2 rounded up;
-// see the culling bound above): d2 - 4e-6 q <= w, evaluated as the sign of one FMA chain
-__device__ __forceinline__ bool sphere_pass(const float4 nd, const float4 la, const float2 lb) {
+// conservative sphere test of one line against one STAGED tree node (centre, w = (Rs + se)^2 rounded up, or -inf for
+// an empty node; see the culling bound above): the node is kept when  d2 - 4e-6 q <= w,  evaluated as ONE FMA chain
+// whose SIGN BIT says "cannot be reached":  m = (a.d)^2 + (w - 0.999996 |a|^2)  (exactly the negation of the form
+// d2 - 4e-6 q - w; -0 cannot occur, -inf - ... stays negative)
+__device__ __forceinline__ float sphere_margin(const float4 nd, const float4 la, const float2 lb) {
     const float ax = nd.x - la.w, ay = nd.y - lb.x, az = nd.z - lb.y;
     const float dot = fmaf(az, la.z, fmaf(ay, la.y, ax * la.x));
     const float q = fmaf(az, az, fmaf(ay, ay, ax * ax));
-    return fmaf(-dot, dot, fmaf(q, 0.999996f, -nd.w)) <= 0.0f;  // NaN (empty node) fails the comparison
+    return fmaf(dot, dot, fmaf(-q, 0.999996f, nd.w));
 }
 
 template <bool COUNT>
@@ -713,9 +770,6 @@ __device__ __forceinline__ void flush_cands(WaveCtx &c) {
     c.ncand = 0;
 }
 
-// Level C below takes up to 128 queue entries at a time, TWO per lane: the two
-// dependent chains (entry -> line + node -> arithmetic -> ballot) are independent of each other,
-// which doubles the instruction-level parallelism of these latency-bound passes.
 // all = false: only while at least 64 entries wait (full lanes); all = true: drain.
 
 // level D: pops (line, half) pairs, ONE per lane (8 records = 32 registers in flight), and runs the point-0
@@ -771,50 +825,41 @@ __device__ __forceinline__ void proc_c(WaveCtx &c, bool all) {
     }
 }
 
-// level C: pops (line, group) pairs and tests the group's two half spheres
+// The passing halves of one level-B pass (bit k of `pass`: half 8 sg + k of the lane's entry; e2 = line << HF_BITS |
+// 8 sg) go to queue C.  Usual case: every lane writes its own run of entries behind an exclusive prefix of the
+// counts (one DPP scan instead of eight ballot / rank rounds).  Too many for the queue (dense hits): half by half
+// with drains in between.
 template <bool COUNT>
-__device__ __forceinline__ void proc_b(WaveCtx &c, bool all) {
-#ifdef CULL_STOP_B
-    c.nb = 0;
-    return;
-#endif
-    while (c.nb >= 64 || (all && c.nb > 0)) {
-        const int take = min(c.nb, 128), base = c.nb - take;
-        c.nb = base;
-        if constexpr (COUNT) c.tc += 2u * (unsigned)take;
-        wave_lds_fence();
-        bool p[2][2] = {{false, false}, {false, false}};
-        unsigned e2[2] = {0, 0};
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            if (u == 1 && take <= 64) break;  // uniform
-            if (c.lane + 64 * u < take) {
-                const unsigned e = c.qb[base + 64 * u + c.lane];
-                const int ll = e >> GP_BITS, g = e & ((1 << GP_BITS) - 1);
-                const LineRow lrw = line_row(c.lr, ll);
-                const float4 la = lrw.la;
-                const float2 lb = lrw.lb;
-                const float4 *nd = c.nodes + (g >> 2) * NODE + 5 + 2 * (g & 3);
-                p[u][0] = sphere_pass(nd[0], la, lb);
-                p[u][1] = sphere_pass(nd[1], la, lb);
-                e2[u] = ((unsigned)ll << HF_BITS) | (unsigned)(2 * g);
-            }
+__device__ __forceinline__ void push_halves(WaveCtx &c, unsigned pass, unsigned e2) {
+    const int cnt = __popc(pass);
+    const int incl = wave_incl_scan(cnt);
+    const int total = __builtin_amdgcn_readlane(incl, 63);
+    if (total == 0) return;  // uniform
+    if constexpr (COUNT) c.tc += (unsigned)total;
+    if (c.nc + total > QC_CAP) proc_c<COUNT>(c, false);  // leaves < 64
+    if (c.nc + total > QC_CAP) {
+        for (int k = 0; k < 8; ++k) {  // uniform
+            const bool p = (pass >> k) & 1u;
+            const unsigned long long m = __ballot(p);
+            if (m == 0ull) continue;
+            if (c.nc > QC_CAP - 64) proc_c<COUNT>(c, false);
+            if (p) c.qc[c.nc + lane_rank(m)] = (unsigned short)(e2 | (unsigned)k);
+            c.nc += __popcll(m);
         }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            if (u == 1 && take <= 64) break;
-            if (c.nc > QC_CAP - 128) proc_c<COUNT>(c, false);  // room for <= 128 entries on top of < 64 left-overs
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const unsigned long long m = __ballot(p[u][k]);
-                if (p[u][k]) c.qc[c.nc + lane_rank(m)] = (unsigned short)(e2[u] | (unsigned)k);
-                c.nc += __popcll(m);
-            }
-        }
+        return;
     }
+    int at = c.nc + incl - cnt;
+    while (pass) {
+        const int k = __ffs(pass) - 1;
+        pass &= pass - 1;
+        c.qc[at++] = (unsigned short)(e2 | (unsigned)k);
+    }
+    c.nc += total;
 }
 
-// level B: pops (line, supergroup) pairs, one per lane, and tests the supergroup's four group spheres
+// level B: pops (line, supergroup) pairs, one per lane, and tests the supergroup's EIGHT half spheres directly
+// (round 3: the group level in between -- 4 group tests, then 2 half tests per passing group, 9 tests on average
+// -- cost a whole round of queue passes per wavefront for one test less)
 template <bool COUNT>
 __device__ __forceinline__ void proc_a(WaveCtx &c, bool all) {
 #ifdef CULL_STOP_A
@@ -822,12 +867,11 @@ __device__ __forceinline__ void proc_a(WaveCtx &c, bool all) {
     return;
 #endif
     while (c.na >= 64 || (all && c.na > 0)) {
-        if (c.nb > QB_CAP - 256) proc_b<COUNT>(c, false);  // room for <= 256 entries on top of < 64 left-overs
         const int take = min(c.na, 64), base = c.na - take;
         c.na = base;
-        if constexpr (COUNT) c.tb += (unsigned)SGG * (unsigned)take;
+        if constexpr (COUNT) c.tb += 8u * (unsigned)take;
         wave_lds_fence();
-        bool p[SGG] = {false, false, false, false};
+        unsigned fail = 0xffu;  // bit k: half k cannot be reached (idle lanes: none can)
         unsigned e2 = 0;
         if (c.lane < take) {
             const unsigned e = c.qa[base + c.lane];
@@ -835,17 +879,14 @@ __device__ __forceinline__ void proc_a(WaveCtx &c, bool all) {
             const LineRow lrw = line_row(c.lr, ll);
             const float4 la = lrw.la;
             const float2 lb = lrw.lb;
-            const float4 *nd = c.nodes + sg * NODE + 1;
+            const float4 *nd = c.nodes + sg * NODE + 5;
+            fail = 0u;
 #pragma unroll
-            for (int k = 0; k < SGG; ++k) p[k] = sphere_pass(nd[k], la, lb);
-            e2 = ((unsigned)ll << GP_BITS) | (unsigned)(SGG * sg);
+            for (int k = 7; k >= 0; --k)  // half k ends up in bit k
+                fail = __builtin_amdgcn_alignbit(fail, __float_as_uint(sphere_margin(nd[k], la, lb)), 31);
+            e2 = ((unsigned)ll << HF_BITS) | (unsigned)(8 * sg);
         }
-#pragma unroll
-        for (int k = 0; k < SGG; ++k) {
-            const unsigned long long m = __ballot(p[k]);
-            if (p[k]) c.qb[c.nb + lane_rank(m)] = (unsigned short)(e2 | (unsigned)k);
-            c.nb += __popcll(m);
-        }
+        push_halves<COUNT>(c, ~fail & 0xffu, e2);
     }
 }
 
@@ -886,12 +927,12 @@ __device__ __attribute__((noinline)) void strict_slice(const float *ptri, const 
 // rrl_scan_counters() holds a buffer.  Every wavefront WRITES one row of 16 u64 (plain stores: thousands of
 // same-address atomics serialise at ~12 ns each and distort the kernel they measure), row index = linear
 // workgroup id x wavefronts per workgroup + wavefront; rows past the buffer's capacity are dropped:
-//   row[0] level-A sphere tests (line x supergroup)   [1] level-B (line x group)
-//           [2] level-C (line x half)                      [3] point-0 prefilter tests (line x record)
+//   row[0] level-A sphere tests (line x supergroup)   [1] level-B half-sphere tests (8 per (line, supergroup) pair)
+//           [2] halves that passed (line x half)           [3] point-0 prefilter tests (line x record)
 //           [4] candidates resolved (points 1, 2)          [5] wavefronts that ran
 //           [6] wavefronts that took the strict fallback   [7] (line, triangle) pairs of the fallback
 //           [8] start, [9] end of the wavefront on the 100 MHz wall clock (the kernel lasts as long as its
-//           slowest wavefront: tools/scan_tail.py prints the spread)
+//           slowest wavefront: tools/scan_tail.py prints the spread), [10..14] phase stamps
 template <bool COUNT>
 __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(6, 8))) void cull_scan_kernel(
     const float *__restrict__ ptri1, const float *__restrict__ ptri2, const float4 *__restrict__ p0s1,
@@ -899,22 +940,19 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(6, 8))
     const float4 *__restrict__ tree1, const float4 *__restrict__ tree2, const float *__restrict__ line,
     int32_t *__restrict__ count1, int32_t *__restrict__ hit1, int32_t *__restrict__ count2,
     int32_t *__restrict__ hit2, int32_t *__restrict__ status, const uint32_t *__restrict__ pmax,
-    const float *__restrict__ del1, const float *__restrict__ del2, int B,
+    const float *__restrict__ del1, const float *__restrict__ del2, const float2 *__restrict__ lmax, int B,
     int N, int M, int L, int spw, unsigned long long *__restrict__ counters, long long counter_rows) {
     __shared__ __attribute__((aligned(16))) float2 line_lds[WPB][LPW * 3];    // 24 KiB: raw 24-byte line rows
     __shared__ __attribute__((aligned(16))) float4 rec_lds[SPW * SGG * ROWS]; //  8.5 KiB
     __shared__ __attribute__((aligned(16))) float4 node_lds[SPW * NODE];      //  1.6 KiB
     __shared__ __attribute__((aligned(16))) unsigned short qa_lds[WPB][QA_CAP];
-    __shared__ unsigned short qb_lds[WPB][QB_CAP], qc_lds[WPB][QC_CAP];
+    __shared__ unsigned short qc_lds[WPB][QC_CAP];
     __shared__ __attribute__((aligned(16))) unsigned cands_lds[WPB][WCCAP];
-    __shared__ unsigned wg_slack[3];  // max over the workgroup's lines: bits of se, bits of A^2; [2] a NaN is not excluded
-    __shared__ float sg_dn[SPW];      // nanwide workgroups: NaN reach of the slice's supergroup nodes (level A)
     static_assert(WPB * WCCAP >= SPW * SGT && WPB * QA_CAP * sizeof(unsigned short) >= SPW * NODE * sizeof(float),
                   "the NaN-reach scratch aliases the (still unused) candidate and level-A queue buffers");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform for the compiler
     const unsigned long long wall0 = COUNT ? wall_clock64() : 0ull;
-    if (tid < 3) wg_slack[tid] = 0u;
     unsigned long long *crow = nullptr;
     if constexpr (COUNT) {
         const long long wid = (((long long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + wave;
@@ -932,8 +970,9 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(6, 8))
     const float4 *p0s = (cloud ? p0s2 : p0s1) + (size_t)b * nsg * SGT;
     const float4 *tree = (cloud ? tree2 : tree1) + (size_t)b * nsg * NODE;
 
-    // ---- the slice's records and nodes: with one record per lane (the usual 8-wavefront workgroup) the
-    //      loads are issued FIRST and stay in flight while the lines arrive and their slack is reduced
+    // ---- everything the prologue needs is requested up front, in one round of independent loads: the slice's
+    //      records and nodes (one per lane in the usual 8-wavefront workgroup), the sample's line maxima, this
+    //      wavefront's 128 lines
     constexpr int RPT = (SPW * SGT + 64 * WPB - 1) / (64 * WPB);  // records per lane of a full workgroup
     static_assert(SPW * NODE <= 64 * WPB, "one node per lane");
     const bool one_each = (int)blockDim.x == 64 * WPB;
@@ -944,10 +983,12 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(6, 8))
             if (tid + 64 * WPB * k < nsl * SGT) rec0[k] = p0s[(size_t)sg0 * SGT + tid + 64 * WPB * k];
         if (tid < nsl * NODE) nd0 = tree[(size_t)sg0 * NODE + tid];
     }
+    static_assert(LMAX_CHUNKS == 64, "one partial row per lane");
+    const float2 lm = lmax[(size_t)b * LMAX_CHUNKS + lane];  // (max |dir|^2, max |x0|^2) over 1/64 of the sample's cullable lines
+    const float pm = __uint_as_float(pmax[cloud * B + b]);
 
-    // ---- this wave's 128 lines: a full, 16-byte aligned tile arrives as three coalesced 16-byte loads per
-    //      lane straight into its LDS rows (12 strided 4-byte loads per lane before); the lanes then pick up
-    //      their own two lines from there
+    // this wave's 128 lines: a full, 16-byte aligned tile arrives as three coalesced 16-byte loads per lane straight
+    // into its LDS rows; the lanes then pick up their own two lines from there
     const float *ln = line + (size_t)b * L * 6;
     const int lw0 = ((int)blockIdx.y * (int)(blockDim.x >> 6) + wave) * LPW;
     const int l0 = lw0 + lane, l1 = l0 + 64;
@@ -967,6 +1008,13 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(6, 8))
             for (int i = lane; i < LPW * 3; i += 64) lr[i] = i < nf2 ? s2[i] : make_float2(0.0f, 0.0f);
         }
     }
+
+    // ---- slack of this (cloud, sample): the same values in every wavefront and workgroup (no exchange, no barrier)
+    const float smax = wave_max(lm.x), o2max = wave_max(lm.y);
+    const CloudSlack cs = cull_cloud_slack(smax, o2max, pm);
+    const float se = cs.se, s0 = cs.s0;
+    const bool nanwide = cs.nanwide;  // uniform over the launch's workgroups of this cloud and sample
+
     wave_lds_fence();
     float v0[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}, v1[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     if (has_lines) {
@@ -974,40 +1022,20 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(6, 8))
         v0[0] = r0.la.x; v0[1] = r0.la.y; v0[2] = r0.la.z; v0[3] = r0.la.w; v0[4] = r0.lb.x; v0[5] = r0.lb.y;
         v1[0] = r1.la.x; v1[1] = r1.la.y; v1[2] = r1.la.z; v1[3] = r1.la.w; v1[4] = r1.lb.x; v1[5] = r1.lb.y;
     }
+    // Culling (and the lazy evaluation of points 1, 2) is only exact for lines with |dir|^2 <= 1 + 1e-6 and finite,
+    // moderate data.  A wavefront with an offending line evaluates ALL pairs of its lines with the slice's
+    // triangles strictly instead -- the reference's semantics, NaN included.
+    float sa, oa, sb, ob;
+    line_norms(v0[0], v0[1], v0[2], v0[3], v0[4], v0[5], sa, oa);
+    line_norms(v1[0], v1[1], v1[2], v1[3], v1[4], v1[5], sb, ob);
+    const bool fallback = !cs.ok || !__all(line_cullable(sa, oa) && line_cullable(sb, ob));
+    unsigned long long fb_pairs = 0;
 
     const int32_t *idx = (cloud ? idx2 : idx1) + (size_t)b * nsg * SGT;
     const float *ptri = (cloud ? ptri2 : ptri1) + (size_t)b * n * PTRI_STRIDE;
     int32_t *cnt = (cloud ? count2 : count1) + (size_t)b * L;
     int32_t *hit = (cloud ? hit2 : hit1) + (size_t)b * L * RRL_MAX_HITS;
 
-    // Culling (and the lazy evaluation of points 1, 2) is only exact for lines with |dir|^2 <= 1 + 1e-6 and
-    // finite data (cull_line_slack).  A wavefront with an offending line evaluates ALL pairs of its
-    // lines with the slice's triangles strictly instead -- the reference's semantics, NaN included.
-    const float pm = __uint_as_float(pmax[cloud * B + b]);
-    const LineSlack ls0 = cull_line_slack(v0, pm), ls1 = cull_line_slack(v1, pm);
-    const bool fallback = !__all(ls0.ok && ls1.ok);
-    unsigned long long fb_pairs = 0;
-    // The slacks are taken over the whole WORKGROUP (the staged records and nodes are shared by its
-    // wavefronts and carry them folded in): max se and max A^2 of the lines of the culled wavefronts.
-    __syncthreads();  // wg_slack cleared
-    if (has_lines && !fallback) {
-        const float se_w = wave_max(fmaxf(ls0.se, ls1.se)), a2_w = wave_max(fmaxf(ls0.a2, ls1.a2));
-        const bool nanfree_w = __all(ls0.nanfree && ls1.nanfree);
-        if (lane == 0) {  // non-negative floats: unsigned order == float order
-            atomicMax(&wg_slack[0], __float_as_uint(se_w));
-            atomicMax(&wg_slack[1], __float_as_uint(a2_w));
-            if (!nanfree_w) atomicOr(&wg_slack[2], 1u);
-        }
-    }
-    __syncthreads();
-    const float se = __uint_as_float(wg_slack[0]);
-    const bool nanwide = wg_slack[2] != 0u;  // uniform: some culled wavefront's lines could see a negative sqrt argument
-    // point-0 prefilter (header): 44.2 u A^2 of evaluation error on both sides, rounded up, + an absolute floor
-    const float s0 = 3.0e-6f * __uint_as_float(wg_slack[1]) + 1.0e-9f;
-
-    // ---- stage the slice: records (padded rows) and tree nodes, slacks folded in
-    //   (P0, thr2) -> (P0, c): c = -(thr2 - 2e-4 + slack), slightly widened; pad records never pass
-    //   (centre, Rs) -> (centre, (Rs + se)^2 rounded up); NaN (empty node) stays NaN
     // nanwide (header, "NaN"): the NaN reach del of the slice's records and its maxima over the nodes, through
     // buffers the walk does not use yet
     float *dl = (float *)&cands_lds[0][0];  // [SPW * SGT]
@@ -1021,14 +1049,16 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(6, 8))
         __syncthreads();
         for (int i = tid; i < nsl * NODE; i += blockDim.x) {  // node j of supergroup sg: [0] all 64, [1..4] 16 each, [5..12] 8 each
             const int sg = i / NODE, j = i - sg * NODE;
-            const int o = j == 0 ? 0 : (j < 5 ? (j - 1) * GRP : (j - 5) * (GRP / 2)), cnt = j == 0 ? SGT : (j < 5 ? GRP : GRP / 2);
+            const int o = j == 0 ? 0 : (j < 5 ? (j - 1) * GRP : (j - 5) * (GRP / 2)), cnt_ = j == 0 ? SGT : (j < 5 ? GRP : GRP / 2);
             float m = 0.0f;
-            for (int t = 0; t < cnt; ++t) m = fmaxf(m, dl[sg * SGT + o + t]);
+            for (int t = 0; t < cnt_; ++t) m = fmaxf(m, dl[sg * SGT + o + t]);
             dn[i] = m;
-            if (j == 0) sg_dn[sg] = m;
         }
         __syncthreads();
     }
+    // ---- stage the slice: records (padded rows) and tree nodes, slacks folded in
+    //   (P0, thr2) -> (P0, c): c = -(thr2 - 2e-4 + slack), slightly widened; pad records never pass
+    //   (centre, Rs) -> (centre, (Rs + se)^2 rounded up); an empty node (NaN radius) -> -inf: fails by its sign
     auto stage_rec = [&](int i, float4 r) {
         float tp = r.w - RRL_EPS;
         if (nanwide) {  // also a candidate when point 1 or 2 could see a negative argument: Q(P0) < (se + e01)^2
@@ -1041,7 +1071,8 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(6, 8))
     auto stage_node = [&](int i, float4 nd) {
         float rt = nd.w + se;
         if (nanwide) rt += dn[i];
-        nd.w = rt * rt * 1.0000003f;
+        const float w = rt * rt * 1.0000003f;
+        nd.w = w == w ? w : -INFINITY;
         node_lds[i] = nd;
     };
     if (one_each) {
@@ -1053,20 +1084,19 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(6, 8))
         for (int i = tid; i < nsl * SGT; i += blockDim.x) stage_rec(i, p0s[(size_t)sg0 * SGT + i]);
         for (int i = tid; i < nsl * NODE; i += blockDim.x) stage_node(i, tree[(size_t)sg0 * NODE + i]);
     }
-    __syncthreads();
+    __syncthreads();  // the one barrier of the (usual) prologue
 #ifdef CULL_STOP_STAGE
     return;
 #endif
     if (!has_lines) return;  // uniform per wavefront
     const unsigned long long wall_staged = COUNT ? wall_clock64() : 0ull;
-    unsigned long long wall_a = 0ull, wall_pa = 0ull, wall_pb = 0ull, wall_pc = 0ull;
+    unsigned long long wall_a = 0ull, wall_pa = 0ull, wall_pc = 0ull;
 
     WaveCtx ctx;
     ctx.lr = lr;
     ctx.recs = rec_lds;
     ctx.nodes = node_lds;
     ctx.qa = qa_lds[wave];
-    ctx.qb = qb_lds[wave];
     ctx.qc = qc_lds[wave];
     ctx.cands = cands_lds[wave];
     ctx.idx = idx;
@@ -1074,7 +1104,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(6, 8))
     ctx.cnt = cnt;
     ctx.hit = hit;
     ctx.lbase = lw0;
-    ctx.na = ctx.nb = ctx.nc = ctx.ncand = 0;
+    ctx.na = ctx.nc = ctx.ncand = 0;
     ctx.lane = lane;
     ctx.tb = ctx.tc = ctx.td = ctx.tcand = 0;
     ctx.status = status;
@@ -1091,45 +1121,56 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(6, 8))
     } else {
     ta = (unsigned long long)nsl * (unsigned long long)min(LPW, L - lw0);
 
-    // ---- level A: conservative sphere test of every supergroup of the slice against the lane's
-    //      two lines (packed fp32, wave-uniform sphere through the scalar cache)
-    kptr gp = (kptr)(uintptr_t)(tree + (size_t)sg0 * NODE);
-    // the next supergroup's sphere is requested (scalar loads) before the current one is processed: one
-    // scalar-load latency up front instead of one per iteration (the loop body is ~25 instructions)
-    float cur[4], nxt[4];
+    // ---- level A: conservative sphere test of every supergroup of the slice against the lane's two lines
+    //      (packed fp32; the staged supergroup nodes come as wave-uniform LDS reads).  No queue traffic inside the
+    //      loop: the outcome is one bit per (line, supergroup) in two lane-private masks (sign bits, v_alignbit).
+    unsigned f0m = 0u, f1m = 0u;  // bit s: supergroup s cannot be reached by line 0 / line 1 of the lane
 #pragma unroll
-    for (int c = 0; c < 4; ++c) cur[c] = gp[c];
-#pragma unroll 1
-    for (int s = 0; s < nsl; ++s) {
-        const int sn = s + 1 < nsl ? s + 1 : s;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) nxt[c] = gp[4 * NODE * sn + c];
-        const float cx = cur[0], cy = cur[1], cz = cur[2];
-        float Rt = cur[3] + se;
-        if (nanwide) Rt += sg_dn[s];  // uniform
-        const float R2 = Rt * Rt;     // NaN (empty node) fails both comparisons
-        const v2f ax = cx - ox, ay = cy - oy, az = cz - oz;
+    for (int s = SPW - 1; s >= 0; --s) {  // supergroup s ends up in bit s
+        float4 nd = node_lds[(s < nsl ? s : 0) * NODE];
+        if (s >= nsl) nd.w = -INFINITY;  // uniform: not part of this slice
+        const v2f ax = nd.x - ox, ay = nd.y - oy, az = nd.z - oz;
         const v2f dot = __builtin_elementwise_fma(az, uz, __builtin_elementwise_fma(ay, uy, ax * ux));
         const v2f q = __builtin_elementwise_fma(az, az, __builtin_elementwise_fma(ay, ay, ax * ax));
-        v2f d2 = __builtin_elementwise_fma(-dot, dot, q);
-        d2 = __builtin_elementwise_fma((v2f){-4e-6f, -4e-6f}, q, d2);
-        const bool pass0 = live0 && d2.x <= R2, pass1 = live1 && d2.y <= R2;
-        const unsigned long long m0 = __ballot(pass0), m1 = __ballot(pass1);
-        if (m0 | m1) {
-            if (ctx.na > QA_CAP - 128) proc_a<COUNT>(ctx, false);
-            const int c0 = __popcll(m0);
-            if (pass0) ctx.qa[ctx.na + lane_rank(m0)] = (unsigned short)((lane << SG_BITS) | s);
-            if (pass1) ctx.qa[ctx.na + c0 + lane_rank(m1)] = (unsigned short)(((64 + lane) << SG_BITS) | s);
-            ctx.na += c0 + __popcll(m1);
+        const v2f w2 = {nd.w, nd.w};
+        const v2f mg = __builtin_elementwise_fma(dot, dot, __builtin_elementwise_fma(-q, (v2f){0.999996f, 0.999996f}, w2));
+        f0m = __builtin_amdgcn_alignbit(f0m, __float_as_uint(mg.x), 31);
+        f1m = __builtin_amdgcn_alignbit(f1m, __float_as_uint(mg.y), 31);
+    }
+    unsigned m0 = live0 ? (~f0m & ((1u << SPW) - 1u)) : 0u, m1 = live1 ? (~f1m & ((1u << SPW) - 1u)) : 0u;
+    {
+        const int cnt_ = __popc(m0) + __popc(m1);
+        const int incl = wave_incl_scan(cnt_);
+        const int total = __builtin_amdgcn_readlane(incl, 63);
+        if (total <= QA_CAP) {  // the usual case (~128): every lane writes its own run of entries
+            int at = incl - cnt_;
+            while (m0) {
+                const int s = __ffs(m0) - 1;
+                m0 &= m0 - 1;
+                ctx.qa[at++] = (unsigned short)((lane << SG_BITS) | s);
+            }
+            while (m1) {
+                const int s = __ffs(m1) - 1;
+                m1 &= m1 - 1;
+                ctx.qa[at++] = (unsigned short)(((64 + lane) << SG_BITS) | s);
+            }
+            ctx.na = total;
+        } else {  // dense hits: supergroup by supergroup, level B in between
+            for (int s = 0; s < nsl; ++s) {
+                const bool p0 = (m0 >> s) & 1u, p1 = (m1 >> s) & 1u;
+                const unsigned long long b0 = __ballot(p0), b1 = __ballot(p1);
+                if ((b0 | b1) == 0ull) continue;
+                if (ctx.na > QA_CAP - 128) proc_a<COUNT>(ctx, false);
+                const int c0 = __popcll(b0);
+                if (p0) ctx.qa[ctx.na + lane_rank(b0)] = (unsigned short)((lane << SG_BITS) | s);
+                if (p1) ctx.qa[ctx.na + c0 + lane_rank(b1)] = (unsigned short)(((64 + lane) << SG_BITS) | s);
+                ctx.na += c0 + __popcll(b1);
+            }
         }
-#pragma unroll
-        for (int c = 0; c < 4; ++c) cur[c] = nxt[c];
     }
     if constexpr (COUNT) wall_a = wall_clock64();
     proc_a<COUNT>(ctx, true);
     if constexpr (COUNT) wall_pa = wall_clock64();
-    proc_b<COUNT>(ctx, true);
-    if constexpr (COUNT) wall_pb = wall_clock64();
     proc_c<COUNT>(ctx, true);
     if constexpr (COUNT) wall_pc = wall_clock64();
     flush_cands<COUNT>(ctx);
@@ -1142,9 +1183,9 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(6, 8))
             crow[6] = fallback ? 1ull : 0ull;
             crow[7] = fb_pairs;
             crow[8] = wall0; crow[9] = wall_clock64();
-            // phase stamps of the culled walk: staged (after the last staging barrier), level A done, the final drains
-            // of levels B, C, D done (the remainder up to [9] is the last candidate flush)
-            crow[10] = wall_staged; crow[11] = wall_a; crow[12] = wall_pa; crow[13] = wall_pb; crow[14] = wall_pc;
+            // phase stamps of the culled walk: staged (after the staging barrier), level A done, the final drains
+            // of levels B and D done (the remainder up to [9] is the last candidate flush)
+            crow[10] = wall_staged; crow[11] = wall_a; crow[12] = wall_pa; crow[13] = wall_pa; crow[14] = wall_pc;
         }
     }
 }
@@ -1190,7 +1231,7 @@ static size_t sort_lds_bytes(int nsg, int parts, int raw_points) {
 
 // Launchers used by rrl_tri_prepare / rrl_line_tri_scan (rrl_scan.hip)
 int rrl_launch_tri_build(const float *tri1, const float *tri2, void *ws, const WsLayout &w, int B,
-                         int N, int M, int clouds, const RrlXform *xf, hipStream_t s) {
+                         int N, int M, int clouds, const RrlXform *xf, const float *line, int L, hipStream_t s) {
     const int nmax = clouds == 2 && M > N ? M : N;
     const size_t ngpmax = (size_t)(nmax + SGT - 1) / SGT * SGG;  // groups, padded to whole supergroups
     // Clouds of more than 4096 triangles: ONE launch of the single-workgroup sort per chunk of 4096 records
@@ -1233,12 +1274,16 @@ int rrl_launch_tri_build(const float *tri1, const float *tri2, void *ws, const W
     a.z3_vec4 = w.state_bytes / 16;
     a.del1 = w.f32(ws, RRL_WS_DEL1);
     a.del2 = w.f32(ws, RRL_WS_DEL2);
+    a.line = line;
+    a.lmax = line && L > 0 ? (float2 *)w.f32(ws, RRL_WS_LMAX) : nullptr;
+    a.L = L;
     a.B = B; a.N = N; a.M = M;
     a.transpose_r = xf ? xf->transpose_r : 0;
     const int nall = N > M ? N : M;  // APART is laid out for the larger cloud
     a.nblk = (nall + REC_BLK - 1) / REC_BLK;
     a.nchunk = chunked ? (nmax + 4095) / 4096 : 1;
-    hipLaunchKernelGGL(tri_records_kernel, dim3((unsigned)((nmax + REC_BLK - 1) / REC_BLK), (unsigned)B, (unsigned)clouds),
+    a.nblk_tri = (nmax + REC_BLK - 1) / REC_BLK;
+    hipLaunchKernelGGL(tri_records_kernel, dim3((unsigned)(a.nblk_tri + (a.lmax ? LMAX_CHUNKS : 0)), (unsigned)B, (unsigned)clouds),
                        dim3(REC_BLK), 0, s, a);
     if (nmax <= 4096 || chunked) {
         hipLaunchKernelGGL((tri_sort_kernel<4, false>), dim3((unsigned)(clouds * B * a.nchunk), (unsigned)parts), dim3(1024), lds, s, a);
@@ -1294,7 +1339,10 @@ int rrl_launch_cloud_sort(const float *raw1, const float *raw2, float4 *crec1, f
 }
 
 int rrl_launch_cull_scan(const float *line, void *ws, const WsLayout &w, int B, int N, int M, int L,
-                         int clouds, hipStream_t s) {
+                         int clouds, int lmax_ready, hipStream_t s) {
+    if (!lmax_ready)  // the triangles were prepared without the lines: their partial maxima first (a tiny launch)
+        hipLaunchKernelGGL(line_max_kernel, dim3(LMAX_CHUNKS, (unsigned)B), dim3(REC_BLK), 0, s, line, L,
+                           (float2 *)w.f32(ws, RRL_WS_LMAX));
     // a workgroup = (cloud and sample, tile of <= WPB x 128 lines, slice of spw supergroups).  With
     // few lines or small clouds the slices get thinner, so that the launch still has ~1000
     // workgroups for the 256 CUs (measured with tools/geom_sweep.sh: thinner slices cost little,
@@ -1323,7 +1371,8 @@ int rrl_launch_cull_scan(const float *line, void *ws, const WsLayout &w, int B, 
                        (const float4 *)w.f32(ws, RRL_WS_GRP2), line, w.i32(ws, RRL_WS_COUNT1),               \
                        w.i32(ws, RRL_WS_HIT1), w.i32(ws, RRL_WS_COUNT2), w.i32(ws, RRL_WS_HIT2),             \
                        w.i32(ws, RRL_WS_STATUS), (const uint32_t *)w.i32(ws, RRL_WS_PMAX),                   \
-                       w.f32(ws, RRL_WS_DEL1), w.f32(ws, RRL_WS_DEL2), B, N, M, L, spw,                      \
+                       w.f32(ws, RRL_WS_DEL1), w.f32(ws, RRL_WS_DEL2), (const float2 *)w.f32(ws, RRL_WS_LMAX),   \
+                       B, N, M, L, spw,                                                                      \
                        g_cull_counters, g_cull_counter_rows)
     if (g_cull_counters) RRL_CULL_LAUNCH(true);
     else RRL_CULL_LAUNCH(false);

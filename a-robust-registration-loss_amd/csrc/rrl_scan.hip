@@ -125,9 +125,9 @@ __global__ __launch_bounds__(64) void tri_prepare_kernel(const float *__restrict
 }
 
 int rrl_launch_tri_build(const float *tri1, const float *tri2, void *ws, const WsLayout &w, int B,
-                         int N, int M, int clouds, const RrlXform *xf, hipStream_t s);
+                         int N, int M, int clouds, const RrlXform *xf, const float *line, int L, hipStream_t s);
 int rrl_launch_cull_scan(const float *line, void *ws, const WsLayout &w, int B, int N, int M, int L,
-                         int clouds, hipStream_t s);
+                         int clouds, int lmax_ready, hipStream_t s);
 int rrl_sort_capacity(void);
 
 // clouds = 2: both clouds; clouds = 1: the source only (the target's scan results are carried
@@ -137,8 +137,10 @@ int rrl_sort_capacity(void);
 // (`tri1` is ignored).  Sorted path: ONE launch (tri_build_kernel) does transform + records +
 // state clearing + sort + spheres.  Legacy path (a cloud > 65536 triangles): rigid apply,
 // memset, tri_prepare_kernel<LEGACY>.
+// line != NULL: the records kernel also reduces the samples' lines to the partial maxima the culled scan derives its
+// slacks from (the fused forwards); NULL: the scan entry does that itself (rrl_tri_prepare + rrl_line_tri_scan).
 int rrl_tri_prepare_clouds(const float *tri1, const float *tri2, void *ws, size_t ws_bytes, int B,
-                           int N, int M, int L, int clouds, const RrlXform *xf, void *stream) {
+                           int N, int M, int L, int clouds, const RrlXform *xf, const float *line, void *stream) {
     if ((!tri1 && !xf) || !tri2 || !ws || B < 0 || N < 0 || M < 0 || L < 0) return RRL_E_ARG;
     WsLayout w(B, N, M, L);
     if (ws_bytes < w.total) return RRL_E_WS;
@@ -154,7 +156,7 @@ int rrl_tri_prepare_clouds(const float *tri1, const float *tri2, void *ws, size_
         if ((rc = rrl_fill((char *)ws + w.state_off, 0u, w.state_bytes, s))) return rc;
     }
     if (B == 0 || nmax == 0) return 0;
-    if (sorted) return rrl_launch_tri_build(tri1, tri2, ws, w, B, N, M, clouds, xf, s);
+    if (sorted) return rrl_launch_tri_build(tri1, tri2, ws, w, B, N, M, clouds, xf, line, L, s);
     if (xf) {
         if (xf->zero_g1) {
             int rc = rrl_fill(w.f32(ws, RRL_WS_GACC), 0u, w.off[RRL_WS_KJC] - w.off[RRL_WS_GACC], s);
@@ -175,7 +177,7 @@ int rrl_tri_prepare_clouds(const float *tri1, const float *tri2, void *ws, size_
 
 extern "C" int rrl_tri_prepare(const float *tri1, const float *tri2, void *ws, size_t ws_bytes,
                                int B, int N, int M, int L, void *stream) {
-    return rrl_tri_prepare_clouds(tri1, tri2, ws, ws_bytes, B, N, M, L, 2, nullptr, stream);
+    return rrl_tri_prepare_clouds(tri1, tri2, ws, ws_bytes, B, N, M, L, 2, nullptr, nullptr, stream);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -412,7 +414,7 @@ extern "C" int rrl_scan_timing_collect(float *ms, int max_n) {
 }
 
 int rrl_line_tri_scan_clouds(const float *line, void *ws, size_t ws_bytes, int B, int N, int M, int L,
-                             int mode, int chunk, int clouds, void *stream) {
+                             int mode, int chunk, int clouds, int lmax_ready, void *stream) {
     if (!line || !ws || B < 0 || N < 0 || M < 0 || L < 0 || chunk < 0) return RRL_E_ARG;
     if (mode != RRL_SCAN_STRICT && mode != RRL_SCAN_LAZY && mode != RRL_SCAN_AUTO &&
         mode != RRL_SCAN_CULL)
@@ -426,7 +428,7 @@ int rrl_line_tri_scan_clouds(const float *line, void *ws, size_t ws_bytes, int B
     const bool timed = g_timing_on && (g_timing_seen++ % g_timing_on) == 0 && g_timing_n < TIMING_RING;
     if (mode == RRL_SCAN_CULL) {  // one launch: sphere-culled scan with an inline strict fallback
         if (timed) (void)hipEventRecord(g_ev[g_timing_n][0], s);
-        int rc = rrl_launch_cull_scan(line, ws, w, B, N, M, L, clouds, s);
+        int rc = rrl_launch_cull_scan(line, ws, w, B, N, M, L, clouds, lmax_ready, s);
         if (rc) return rc;
         if (timed) (void)hipEventRecord(g_ev[g_timing_n++][1], s);
         return 0;
@@ -464,5 +466,5 @@ int rrl_line_tri_scan_clouds(const float *line, void *ws, size_t ws_bytes, int B
 
 extern "C" int rrl_line_tri_scan(const float *line, void *ws, size_t ws_bytes, int B, int N, int M,
                                  int L, int mode, int chunk, void *stream) {
-    return rrl_line_tri_scan_clouds(line, ws, ws_bytes, B, N, M, L, mode, chunk, 2, stream);
+    return rrl_line_tri_scan_clouds(line, ws, ws_bytes, B, N, M, L, mode, chunk, 2, 0, stream);
 }

@@ -1410,9 +1410,10 @@ extern "C" int rrl_workspace_layout(int B, int N, int M, int L, size_t *offsets)
 }
 
 int rrl_tri_prepare_clouds(const float *tri1, const float *tri2, void *ws, size_t ws_bytes, int B,
-                           int N, int M, int L, int clouds, const RrlXform *xf, void *stream);
+                           int N, int M, int L, int clouds, const RrlXform *xf, const float *line, void *stream);
 int rrl_line_tri_scan_clouds(const float *line, void *ws, size_t ws_bytes, int B, int N, int M, int L,
-                             int mode, int chunk, int clouds, void *stream);
+                             int mode, int chunk, int clouds, int lmax_ready, void *stream);
+int rrl_sort_capacity(void);
 
 // target_ws != NULL: a workspace of the same (B, N, M, L) that already went through a forward with
 // the SAME tri2 and line (RPM / FMR evaluate several source poses against one target and one
@@ -1431,7 +1432,7 @@ static int loss_forward_impl(const float *tri1, const float *tri2, const float *
     RrlRange step("rrl forward");
     {
         RrlRange r("K1' records + sort + tree");
-        if ((rc = rrl_tri_prepare_clouds(tri1, tri2, ws, ws_bytes, B, N, M, L, clouds, xf, stream))) return rc;
+        if ((rc = rrl_tri_prepare_clouds(tri1, tri2, ws, ws_bytes, B, N, M, L, clouds, xf, line, stream))) return rc;
     }
     if (target_ws && (size_t)B * L) {  // after the prepare step, which cleared COUNT2
         WsLayout w(B, N, M, L);
@@ -1445,7 +1446,9 @@ static int loss_forward_impl(const float *tri1, const float *tri2, const float *
     }
     {
         RrlRange r("K1 line<->triangle scan");
-        if ((rc = rrl_line_tri_scan_clouds(line, ws, ws_bytes, B, N, M, L, mode, chunk, clouds, stream))) return rc;
+        // (the records kernel reduced the lines' maxima whenever it ran: the sorted path)
+        const int lmax_ready = (N > M ? N : M) <= rrl_sort_capacity() && B > 0 && (clouds == 2 && M > N ? M : N) > 0 && L > 0;
+        if ((rc = rrl_line_tri_scan_clouds(line, ws, ws_bytes, B, N, M, L, mode, chunk, clouds, lmax_ready, stream))) return rc;
     }
     if (L >= 1 && L <= 1024 && !pool && B > 0 && reduce_mode() != 2) {  // one tile of lines per sample: K2 + K3 + K4 in one launch
         RrlRange r("K2 + K3 + K4 (single tile)");

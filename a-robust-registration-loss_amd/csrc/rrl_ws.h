@@ -59,6 +59,7 @@ struct WsLayout {
             4 * b * 64,          // MCTL
             8 * b * 32,          // MSUM
             4 * b * 2048,        // MCAND
+            4 * b * 64 * 2,      // LMAX
         };
         size_t o = 0;
         for (int i = 0; i < RRL_WS_FIELDS; ++i) {

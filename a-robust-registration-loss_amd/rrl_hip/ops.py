@@ -61,6 +61,7 @@ _WS_FIELDS = [
     ("mctl", torch.int32, lambda B, N, M, L, G: (B, 64)),
     ("msum", torch.int64, lambda B, N, M, L, G: (B, 32)),
     ("mcand", torch.int32, lambda B, N, M, L, G: (B, 2048)),
+    ("lmax", torch.float32, lambda B, N, M, L, G: (B, 64, 2)),
 ]
 _layout_cache = {}
 _FIELD_INDEX = {name: i for i, (name, _, _) in enumerate(_WS_FIELDS)}

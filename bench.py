@@ -364,7 +364,7 @@ def main():
         local_step("cull")  # one launch: every wavefront writes its row of counters
         torch.cuda.synchronize()
         c = ops.scan_counters(False).cpu().numpy().astype(np.float64)
-        exe = OPS_SPHERE * (c[0] + c[1] + c[2]) + OPS_EXACT * c[3] + OPS_CAND * c[4] + OPS_FALLBACK * c[7]
+        exe = OPS_SPHERE * (c[0] + c[1]) + OPS_EXACT * c[3] + OPS_CAND * c[4] + OPS_FALLBACK * c[7]  # c[2] counts survivors, not tests
         roof_default = {
             "kernel": "cull_scan_kernel (scan mode cull: the dominant kernel of the timed step)",
             "launch_ms": cull_ms, "launches_timed": n_cull,
@@ -372,7 +372,7 @@ def main():
             "executed_frac": exe / (cull_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS,
             "work_ratio": dense_flops / exe,
             "dense_equivalent_tflops": dense_flops / (cull_ms * 1e-3) / 1e12,
-            "counters_per_launch": {"sphere_tests_A": c[0], "sphere_tests_B": c[1], "sphere_tests_C": c[2],
+            "counters_per_launch": {"sphere_tests_A": c[0], "half_sphere_tests_B": c[1], "halves_passed": c[2],
                                     "point0_prefilter_tests": c[3], "candidates_resolved": c[4], "wavefronts": c[5],
                                     "fallback_wavefronts": c[6], "fallback_pairs": c[7]},
             "ops_per_test": {"sphere": OPS_SPHERE, "point0_prefilter": OPS_EXACT, "candidate": OPS_CAND,

@@ -119,6 +119,8 @@ enum {
                           arrival counters of the tiled reduce, [19] its error flag (spin time-out)                          */
     RRL_WS_MSUM,       /* uint64[B][32]  bucket sums of the tiled reduce (2^-40 fixed point, device atomics)                */
     RRL_WS_MCAND,      /* uint32[B][2048] D values (bit patterns) of the median's bin, gathered by the tiled reduce          */
+    RRL_WS_LMAX,       /* float[B][64][2] (max |dir|^2, max |x0|^2) over 1/64 of a sample's cullable lines: the culled scan's
+                          slacks come from their maxima (written by the records kernel, or by the scan entry itself)       */
     RRL_WS_FIELDS
 };
 

@@ -1252,7 +1252,8 @@ def test_scan_counters(L):
     nl, n1, n2 = g["lines"].shape[0], g["tri1"].shape[0], g["tri2"].shape[0]
     nsg = (n1 + 63) // 64 + (n2 + 63) // 64
     assert c[0] == nl * nsg                      # level A tests every (line, supergroup)
-    assert 0 < c[1] <= 4 * c[0] and 0 < c[2] <= 2 * c[1] and 0 < c[3] <= 8 * c[2]
+    # level B: 8 half spheres per surviving (line, supergroup) pair; level D: 8 records per surviving half
+    assert 0 < c[1] <= 8 * c[0] and c[1] % 8 == 0 and 0 < c[2] <= c[1] and c[3] == 8 * c[2]
     assert c[3] < nl * (n1 + n2)                 # fewer exact tests than the dense scan's pairs
     assert c[4] >= int(g["count1"].sum() + g["count2"].sum())  # every hit was a resolved candidate
     assert c[6] == 0 and c[7] == 0 and c[5] > 0

@@ -24,7 +24,7 @@ end = start + life
 pc = lambda a, q: float(np.percentile(a, q))
 print(f"B={B} N=M={N} L={L}: {len(rows)} wavefronts; start (us after the first) 10/50/90/100 %: {pc(start,10):.1f} / {pc(start,50):.1f} / {pc(start,90):.1f} / {start.max():.1f}")
 print(f"  lifetime us mean {life.mean():.1f}, 10/50/90/99/100 %: {pc(life,10):.1f} / {pc(life,50):.1f} / {pc(life,90):.1f} / {pc(life,99):.1f} / {life.max():.1f}; last end {end.max():.1f} us")
-work = rows[:, 1] * 12 + rows[:, 2] * 12 + rows[:, 3] * 16 + rows[:, 4] * 32
+work = rows[:, 1] * 12 + rows[:, 3] * 11 + rows[:, 4] * 48
 print(f"  per-wavefront work (lane-ops below level A): mean {work.mean():.0f}, 90 % {pc(work,90):.0f}, max {work.max():.0f}; corr(lifetime, work) = {np.corrcoef(life, work)[0,1]:.2f}")
 late = rows[end > pc(end, 99)]
 print(f"  the slowest 1 %: mean exact tests {late[:,3].mean():.0f} (all: {rows[:,3].mean():.0f}), candidates {late[:,4].mean():.0f} (all: {rows[:,4].mean():.0f})")
@@ -32,8 +32,8 @@ print(f"  the slowest 1 %: mean exact tests {late[:,3].mean():.0f} (all: {rows[:
 if rows.shape[1] > 14 and rows[:, 10].max() > 0:
     culled = rows[rows[:, 6] == 0]
     ph = np.stack([culled[:, 10] - culled[:, 8], culled[:, 11] - culled[:, 10], culled[:, 12] - culled[:, 11],
-                   culled[:, 13] - culled[:, 12], culled[:, 14] - culled[:, 13], culled[:, 9] - culled[:, 14]], 1) / 100.0
-    names = ["prologue (loads, slack, staging)", "level A (+ interleaved drains)", "drain B", "drain C", "drain D", "candidate flush"]
+                   culled[:, 14] - culled[:, 13], culled[:, 9] - culled[:, 14]], 1) / 100.0
+    names = ["prologue (loads, slack, staging)", "level A (masks + queue fill)", "level B (8 halves per pair, interleaved level D)", "drain D", "candidate flush"]
     first = culled[:, 8] - rows[:, 8].min() < 200  # started in the first 2 us: the full-occupancy generation
     print("  phase means us (all / first generation / later): " + "; ".join(
         f"{n} {ph[:, i].mean():.2f} / {ph[first, i].mean():.2f} / {ph[~first, i].mean() if (~first).any() else float('nan'):.2f}" for i, n in enumerate(names)))
