@@ -893,7 +893,7 @@ __device__ __forceinline__ void proc_a(WaveCtx &c, bool all) {
 // The strict loop of a wavefront that cannot be culled (a line with |dir|^2 > 1 + 1e-6 or non-finite
 // data): ALL pairs of its 128 lines with the records at sorted positions [s0, s1), the reference's
 // semantics, NaN included.  The lane's two lines arrive packed (.x = line l0, .y = line l1).
-__device__ __attribute__((noinline)) void strict_slice(const float *ptri, const int32_t *idx, int s0, int s1, v2f ux,
+__device__ __forceinline__ void strict_slice(const float *ptri, const int32_t *idx, int s0, int s1, v2f ux,
                                                        v2f uy, v2f uz, v2f ox, v2f oy, v2f oz, int l0, int l1, int L,
                                                        int32_t *cnt, int32_t *hit, int32_t *status) {
     kptr tp0 = (kptr)(uintptr_t)ptri;
@@ -921,6 +921,67 @@ __device__ __attribute__((noinline)) void strict_slice(const float *ptri, const 
         }
     }
     if (nanacc >= 0x80000000u) atomicOr(&status[0], 1);
+}
+
+// The culled walk of one wavefront over the STAGED slice (node_lds / ctx.recs): level A on the lane's two lines,
+// level B, level D, candidate resolution.  stamps (COUNT): wall clock after level A, after level B's drain, after
+// level D's drain.
+template <bool COUNT>
+__device__ __forceinline__ void cull_walk(WaveCtx &ctx, const float4 *node_lds, int nsl, int lane, bool live0, bool live1,
+                                          v2f ux, v2f uy, v2f uz, v2f ox, v2f oy, v2f oz, unsigned long long *stamps) {
+    // ---- level A: conservative sphere test of every supergroup of the slice against the lane's two lines
+    //      (packed fp32; the staged supergroup nodes come as wave-uniform LDS reads).  No queue traffic inside the
+    //      loop: the outcome is one bit per (line, supergroup) in two lane-private masks (sign bits, v_alignbit).
+    unsigned f0m = 0u, f1m = 0u;  // bit s: supergroup s cannot be reached by line 0 / line 1 of the lane
+#pragma unroll
+    for (int s = SPW - 1; s >= 0; --s) {  // supergroup s ends up in bit s
+        float4 nd = node_lds[(s < nsl ? s : 0) * NODE];
+        if (s >= nsl) nd.w = -INFINITY;  // uniform: not part of this slice
+        const v2f ax = nd.x - ox, ay = nd.y - oy, az = nd.z - oz;
+        const v2f dot = __builtin_elementwise_fma(az, uz, __builtin_elementwise_fma(ay, uy, ax * ux));
+        const v2f q = __builtin_elementwise_fma(az, az, __builtin_elementwise_fma(ay, ay, ax * ax));
+        const v2f w2 = {nd.w, nd.w};
+        const v2f mg = __builtin_elementwise_fma(dot, dot, __builtin_elementwise_fma(-q, (v2f){0.999996f, 0.999996f}, w2));
+        f0m = __builtin_amdgcn_alignbit(f0m, __float_as_uint(mg.x), 31);
+        f1m = __builtin_amdgcn_alignbit(f1m, __float_as_uint(mg.y), 31);
+    }
+    unsigned m0 = live0 ? (~f0m & ((1u << SPW) - 1u)) : 0u, m1 = live1 ? (~f1m & ((1u << SPW) - 1u)) : 0u;
+    {
+        const int cnt_ = __popc(m0) + __popc(m1);
+        const int incl = wave_incl_scan(cnt_);
+        const int total = __builtin_amdgcn_readlane(incl, 63);
+        if (total <= QA_CAP) {  // the usual case (~128): every lane writes its own run of entries
+            int at = incl - cnt_;
+            while (m0) {
+                const int s = __ffs(m0) - 1;
+                m0 &= m0 - 1;
+                ctx.qa[at++] = (unsigned short)((lane << SG_BITS) | s);
+            }
+            while (m1) {
+                const int s = __ffs(m1) - 1;
+                m1 &= m1 - 1;
+                ctx.qa[at++] = (unsigned short)(((64 + lane) << SG_BITS) | s);
+            }
+            ctx.na = total;
+        } else {  // dense hits: supergroup by supergroup, level B in between
+            for (int s = 0; s < nsl; ++s) {
+                const bool p0 = (m0 >> s) & 1u, p1 = (m1 >> s) & 1u;
+                const unsigned long long b0 = __ballot(p0), b1 = __ballot(p1);
+                if ((b0 | b1) == 0ull) continue;
+                if (ctx.na > QA_CAP - 128) proc_a<COUNT>(ctx, false);
+                const int c0 = __popcll(b0);
+                if (p0) ctx.qa[ctx.na + lane_rank(b0)] = (unsigned short)((lane << SG_BITS) | s);
+                if (p1) ctx.qa[ctx.na + c0 + lane_rank(b1)] = (unsigned short)(((64 + lane) << SG_BITS) | s);
+                ctx.na += c0 + __popcll(b1);
+            }
+        }
+    }
+    if constexpr (COUNT) stamps[0] = wall_clock64();
+    proc_a<COUNT>(ctx, true);
+    if constexpr (COUNT) stamps[1] = wall_clock64();
+    proc_c<COUNT>(ctx, true);
+    if constexpr (COUNT) stamps[2] = wall_clock64();
+    flush_cands<COUNT>(ctx);
 }
 
 // COUNT = true: the same kernel with executed-work counters -- launched instead of the plain one while
@@ -1121,59 +1182,9 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(6, 8))
     } else {
     ta = (unsigned long long)nsl * (unsigned long long)min(LPW, L - lw0);
 
-    // ---- level A: conservative sphere test of every supergroup of the slice against the lane's two lines
-    //      (packed fp32; the staged supergroup nodes come as wave-uniform LDS reads).  No queue traffic inside the
-    //      loop: the outcome is one bit per (line, supergroup) in two lane-private masks (sign bits, v_alignbit).
-    unsigned f0m = 0u, f1m = 0u;  // bit s: supergroup s cannot be reached by line 0 / line 1 of the lane
-#pragma unroll
-    for (int s = SPW - 1; s >= 0; --s) {  // supergroup s ends up in bit s
-        float4 nd = node_lds[(s < nsl ? s : 0) * NODE];
-        if (s >= nsl) nd.w = -INFINITY;  // uniform: not part of this slice
-        const v2f ax = nd.x - ox, ay = nd.y - oy, az = nd.z - oz;
-        const v2f dot = __builtin_elementwise_fma(az, uz, __builtin_elementwise_fma(ay, uy, ax * ux));
-        const v2f q = __builtin_elementwise_fma(az, az, __builtin_elementwise_fma(ay, ay, ax * ax));
-        const v2f w2 = {nd.w, nd.w};
-        const v2f mg = __builtin_elementwise_fma(dot, dot, __builtin_elementwise_fma(-q, (v2f){0.999996f, 0.999996f}, w2));
-        f0m = __builtin_amdgcn_alignbit(f0m, __float_as_uint(mg.x), 31);
-        f1m = __builtin_amdgcn_alignbit(f1m, __float_as_uint(mg.y), 31);
-    }
-    unsigned m0 = live0 ? (~f0m & ((1u << SPW) - 1u)) : 0u, m1 = live1 ? (~f1m & ((1u << SPW) - 1u)) : 0u;
-    {
-        const int cnt_ = __popc(m0) + __popc(m1);
-        const int incl = wave_incl_scan(cnt_);
-        const int total = __builtin_amdgcn_readlane(incl, 63);
-        if (total <= QA_CAP) {  // the usual case (~128): every lane writes its own run of entries
-            int at = incl - cnt_;
-            while (m0) {
-                const int s = __ffs(m0) - 1;
-                m0 &= m0 - 1;
-                ctx.qa[at++] = (unsigned short)((lane << SG_BITS) | s);
-            }
-            while (m1) {
-                const int s = __ffs(m1) - 1;
-                m1 &= m1 - 1;
-                ctx.qa[at++] = (unsigned short)(((64 + lane) << SG_BITS) | s);
-            }
-            ctx.na = total;
-        } else {  // dense hits: supergroup by supergroup, level B in between
-            for (int s = 0; s < nsl; ++s) {
-                const bool p0 = (m0 >> s) & 1u, p1 = (m1 >> s) & 1u;
-                const unsigned long long b0 = __ballot(p0), b1 = __ballot(p1);
-                if ((b0 | b1) == 0ull) continue;
-                if (ctx.na > QA_CAP - 128) proc_a<COUNT>(ctx, false);
-                const int c0 = __popcll(b0);
-                if (p0) ctx.qa[ctx.na + lane_rank(b0)] = (unsigned short)((lane << SG_BITS) | s);
-                if (p1) ctx.qa[ctx.na + c0 + lane_rank(b1)] = (unsigned short)(((64 + lane) << SG_BITS) | s);
-                ctx.na += c0 + __popcll(b1);
-            }
-        }
-    }
-    if constexpr (COUNT) wall_a = wall_clock64();
-    proc_a<COUNT>(ctx, true);
-    if constexpr (COUNT) wall_pa = wall_clock64();
-    proc_c<COUNT>(ctx, true);
-    if constexpr (COUNT) wall_pc = wall_clock64();
-    flush_cands<COUNT>(ctx);
+    unsigned long long stamps[3] = {0ull, 0ull, 0ull};
+    cull_walk<COUNT>(ctx, node_lds, nsl, lane, live0, live1, ux, uy, uz, ox, oy, oz, stamps);
+    wall_a = stamps[0]; wall_pa = stamps[1]; wall_pc = stamps[2];
     }
     if constexpr (COUNT) {
         if (lane == 0 && crow && has_lines) {
@@ -1340,9 +1351,6 @@ int rrl_launch_cloud_sort(const float *raw1, const float *raw2, float4 *crec1, f
 
 int rrl_launch_cull_scan(const float *line, void *ws, const WsLayout &w, int B, int N, int M, int L,
                          int clouds, int lmax_ready, hipStream_t s) {
-    if (!lmax_ready)  // the triangles were prepared without the lines: their partial maxima first (a tiny launch)
-        hipLaunchKernelGGL(line_max_kernel, dim3(LMAX_CHUNKS, (unsigned)B), dim3(REC_BLK), 0, s, line, L,
-                           (float2 *)w.f32(ws, RRL_WS_LMAX));
     // a workgroup = (cloud and sample, tile of <= WPB x 128 lines, slice of spw supergroups).  With
     // few lines or small clouds the slices get thinner, so that the launch still has ~1000
     // workgroups for the 256 CUs (measured with tools/geom_sweep.sh: thinner slices cost little,
@@ -1359,9 +1367,15 @@ int rrl_launch_cull_scan(const float *line, void *ws, const WsLayout &w, int B, 
         if (sscanf(e, "%d,%d", &w_, &s_) == 2 && w_ >= 1 && w_ <= WPB && s_ >= 1 && s_ <= SPW) { waves = w_ < lw ? w_ : lw; spw = s_; }
     }
     const int tiles = (lw + waves - 1) / waves, slices = (nsgmax + spw - 1) / spw;
-    // (Letting a workgroup walk 2 / 3 / 4 consecutive slices with its lines staged once -- fewer, longer-lived
-    // wavefronts, all resident from the start -- was measured and dropped: 40.2 / 43.9 / 58.8 us against 37.8,
-    // profiles/r02b_scan_tail.txt.)
+    if (!lmax_ready)  // the triangles were prepared without the lines: their partial maxima first (a tiny launch)
+        hipLaunchKernelGGL(line_max_kernel, dim3(LMAX_CHUNKS, (unsigned)B), dim3(REC_BLK), 0, s, line, L,
+                           (float2 *)w.f32(ws, RRL_WS_LMAX));
+    // (A PERSISTENT variant -- as many workgroups as fit on the chip, each keeping one line tile staged and pulling
+    // (cloud, slice) items from per-tile work queues, the next slice's records prefetched during the walk -- was built
+    // and measured in round 3: exact, but 40.7 us against 30.4 at C2 and 29.0 against 13.8 at the demo's shape.  A slot
+    // is held for the SLOWEST of a workgroup's eight wavefronts either way (16.5 us per item against a mean wavefront
+    // lifetime of 12.4), so queueing the items removed no waiting, and the item barriers added some;
+    // profiles/r03_scan_experiments.txt.)
     const int zslices = slices;
 #define RRL_CULL_LAUNCH(COUNT)                                                                              \
     hipLaunchKernelGGL(cull_scan_kernel<COUNT>, dim3((unsigned)(clouds * B), (unsigned)tiles, (unsigned)zslices),   \

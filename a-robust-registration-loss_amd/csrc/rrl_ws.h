@@ -7,7 +7,7 @@
 struct WsLayout {
     size_t off[RRL_WS_FIELDS];
     size_t total, zero_bytes;
-    size_t state_off, state_bytes;  // MHIST .. MSUM: the tiled reduce's per-call state (cleared by the records kernel)
+    size_t state_off, state_bytes;  // MHIST .. MSUM: per-call state of the tiled reduce (cleared by the records kernel)
 
     __host__ WsLayout(int B, int N, int M, int L) {
         const size_t b = (size_t)(B > 0 ? B : 0), n = (size_t)(N > 0 ? N : 0),
