@@ -891,9 +891,9 @@ __global__ __launch_bounds__(256) void loss_reduce_tiled_kernel(const TiledArgs 
         });
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wavefront drains before the workgroup arrives
         __syncthreads();
-        if (tid == 0) {
-            __hip_atomic_fetch_add(&ctl[MCTL_TICK1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (!spin_reach(&ctl[MCTL_TICK1], (unsigned)nblk)) s_flag[0] = 0u;
+        if (tid == 0) {  // the last to arrive learns it from its own ticket and does not poll at all
+            const unsigned prev = __hip_atomic_fetch_add(&ctl[MCTL_TICK1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (prev + 1u < (unsigned)nblk && !spin_reach(&ctl[MCTL_TICK1], (unsigned)nblk)) s_flag[0] = 0u;
         }
         __syncthreads();
         for (unsigned i = tid; i < pop; i += 256) s_vals[i] = ld_agent(&cand[i]);
@@ -981,10 +981,14 @@ __global__ __launch_bounds__(256) void loss_reduce_tiled_kernel(const TiledArgs 
         a.bsum_out[(size_t)b * 32 + tid] = (int64_t)v;
         __hip_atomic_store(&a.msum[(size_t)b * 32 + tid], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // a second reduce on this state starts clean
     }
-    if (tid < 16) {
-        const int S = (int)ld_agent(&ctl[tid]);
-        s_cnt[tid] = S;
-        a.bcnt_out[b * 16 + tid] = S;
+    if (tid >= 32 && tid < 64) {  // the sample's control words in the same round of loads: bucket counts, error / bad flags
+        const unsigned v = ld_agent(&ctl[tid - 32]);
+        if (tid < 48) {
+            s_cnt[tid - 32] = (int)v;
+            a.bcnt_out[b * 16 + tid - 32] = (int)v;
+        } else if (tid - 32 == MCTL_BAD || tid - 32 == MCTL_ERR) {
+            if (v) atomicOr(&s_flag[2], 2u);  // (s_flag[2] bit 0 was this workgroup's own; bit 1: anyone's)
+        }
     }
     __syncthreads();
     if (tid < 16) {  // one lane per bucket: the double-precision means (as reduce_body)
@@ -1012,7 +1016,7 @@ __global__ __launch_bounds__(256) void loss_reduce_tiled_kernel(const TiledArgs 
                 nselected += s_cnt[bi];
             }
         for (int bi = 0; bi < 16; ++bi) nvalues += s_cnt[bi] * (bi / 4 + 1) * (bi % 4 + 1);
-        const bool bad = ld_agent(&ctl[MCTL_BAD]) != 0u || ld_agent(&ctl[MCTL_ERR]) != 0u;
+        const bool bad = (s_flag[2] & 2u) != 0u;
         a.med_out[b] = med;
         a.loss[b] = bad ? __builtin_nanf("") : (C ? acc / (float)C : 0.0f);  // code/loss.py:230
         a.info[b * 4 + 0] = C;
