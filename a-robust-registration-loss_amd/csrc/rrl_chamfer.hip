@@ -46,11 +46,11 @@ typedef const float __attribute__((address_space(4))) * kptr;  // constant AS ->
 
 int rrl_launch_cloud_sort(const float *raw1, const float *raw2, float4 *crec1, float4 *crec2, float *apart, int nblk,
                           float4 *p0s1, float4 *p0s2, int32_t *idx1, int32_t *idx2, float4 *grp1, float4 *grp2,
-                          uint32_t *pmax, unsigned *histg, int B, int N, int M, hipStream_t s);
+                          uint32_t *pmax, unsigned *histg, uint32_t *zwords, int nzwords, int B, int N, int M, hipStream_t s);
 int rrl_sort_capacity(void);
 
 struct ChamLayout {
-    size_t crec1, crec2, p0s1, p0s2, idx1, idx2, grp1, grp2, apart, pmax, histg, partial, total;
+    size_t crec1, crec2, p0s1, p0s2, idx1, idx2, grp1, grp2, apart, pmax, histg, partial, gpart, ctrl, ctrl_bytes, total;
     int nblk;
     __host__ ChamLayout(int B, int N, int M) {
         const size_t b = (size_t)B, n = (size_t)N, m = (size_t)M;
@@ -69,7 +69,10 @@ struct ChamLayout {
         apart = take(4 * 2 * b * 8 * (size_t)nblk);
         pmax = take(4 * 2 * b);
         partial = take(8 * (2 * b * ((nmax + 63) / 64) + 1));  // one per workgroup of the NN launch
+        gpart = take(8 * 2 * b);  // per (sample, direction) sum of its patches' partials
         histg = take(nmax > 4096 ? 4 * 2 * b * 2 * SORT_CELLS : 16);  // cleared by pts_records_kernel
+        ctrl_bytes = 4 * (32 + 64 * b);  // arrival counters of the mean (ChamTick): zero before the walk -- inside the
+        ctrl = take(ctrl_bytes);         //   range pts_records_kernel clears; the small-cloud sort kernel clears them itself
         total = o;
     }
 };
@@ -207,6 +210,13 @@ __device__ __forceinline__ void eval_entries(const NNShared &sh, int base, int t
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
 
+// Arrival counters of the in-launch mean (chamfer_tree_kernel's ending): one per (sample, direction) group at
+// group + b * stride_b + dir * stride_d, one for the groups.  All zero before the launch; they rewind themselves.
+struct ChamTick {
+    uint32_t *top, *group;
+    int stride_b, stride_d;
+};
+
 // COUNT: executed-work counters (rrl_chamfer_counters): [0] patch-level leaf tests (lane-parallel),
 // [1] per-lane leaf sphere tests (wave x leaf), [2] (query, leaf) entries evaluated, [3] (query, target)
 // pairs evaluated, [4] wavefronts.
@@ -220,7 +230,7 @@ __global__ __launch_bounds__(64 * NWV) void chamfer_tree_kernel(
     unsigned long long *__restrict__ best_x, unsigned long long *__restrict__ best_y,
     double *__restrict__ partial, int B, int N, int M, unsigned long long *__restrict__ counters, long long counter_rows,
     const int32_t *__restrict__ idx1, const int32_t *__restrict__ idx2, const uint32_t *__restrict__ pm1,
-    const uint32_t *__restrict__ pm2) {
+    const uint32_t *__restrict__ pm2, const ChamTick tk_, double *__restrict__ gpart, float *__restrict__ value, double denom) {
     __shared__ unsigned long long s_best[64];
     __shared__ __attribute__((aligned(16))) float4 s_q[64];
     __shared__ __attribute__((aligned(16))) float4 s_rec[NWV][CHK * LROW];
@@ -433,30 +443,59 @@ __global__ __launch_bounds__(64 * NWV) void chamfer_tree_kernel(
     }
 #undef RRL_NOW
     if (wv != 0) return;  // the minima of the patch are in wavefront 0
-    // ---- mean: fixed-order sum of the patch (one wavefront: LDS operations execute in order); the
-    //      partials are summed by a second, tiny launch (chamfer_partials_kernel)
-    red[lane] = mine;
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    for (int o = 32; o > 0; o >>= 1) {
-        if (lane < o) red[lane] += red[lane + o];
+    // ---- mean: fixed-order sums, finished INSIDE this launch (round 3; a second, tiny launch added 4.2 us + a launch
+    //      boundary to a 22 us walk).  The patch's 64 minima in one wavefront (LDS operations execute in order) ->
+    //      partial[workgroup]; the LAST patch of a (sample, direction) to arrive adds that group's partials in index
+    //      order -> gpart[group]; the last GROUP adds the 2 B group sums in index order and writes the value.  Two
+    //      levels because a thousand arrivals on one word serialise (~12 ns each); the counters live 128 bytes apart.
+    //      Stores / loads of what crosses workgroups are agent-scope (sc1), every counter rewinds itself.
+    auto wave_total = [&](double v) {  // all lanes must call; lane 0 holds the sum
+        red[lane] = v;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        for (int o = 32; o > 0; o >>= 1) {
+            if (lane < o) red[lane] += red[lane + o];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+        return red[0];
+    };
+    auto ld64 = [](const double *p) {
+        return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    };
+    auto st64 = [](double *p, double v) {
+        __hip_atomic_store((unsigned long long *)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    const double psum = wave_total(mine);
+    const int wg = (int)(blockIdx.y * gridDim.x + blockIdx.x), grp = (int)blockIdx.x, ngrp = (int)gridDim.x, npatch = (int)gridDim.y;
+    if (tk_.top == nullptr) {  // (no counters: leave the partials to the caller)
+        if (lane == 0) partial[wg] = psum;
+        return;
     }
-    if (lane == 0) partial[blockIdx.y * gridDim.x + blockIdx.x] = red[0];
-}
-
-// value = (sum of the per-patch partial sums, fixed order) / (B (N + M)): deterministic
-__global__ __launch_bounds__(256) void chamfer_partials_kernel(const double *__restrict__ partial, int n,
-                                                               float *__restrict__ value, double denom) {
-    __shared__ double red[256];
+    uint32_t *gtick = tk_.group + (size_t)b * tk_.stride_b + (size_t)dir * tk_.stride_d;
+    int last = 0;
+    if (lane == 0) {
+        st64(&partial[wg], psum);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        last = __hip_atomic_fetch_add(gtick, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(npatch - 1) ? 1 : 0;
+    }
+    if (!__builtin_amdgcn_readfirstlane(last)) return;
     double acc = 0.0;
-    for (int i = threadIdx.x; i < n; i += 256) acc += partial[i];
-    red[threadIdx.x] = acc;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
-        __syncthreads();
+    for (int i = lane; i < npatch; i += 64) acc += ld64(&partial[(size_t)i * ngrp + grp]);  // patches of this group, index order per lane
+    const double gsum = wave_total(acc);
+    last = 0;
+    if (lane == 0) {
+        __hip_atomic_store(gtick, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        st64(&gpart[grp], gsum);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        last = __hip_atomic_fetch_add(tk_.top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(ngrp - 1) ? 1 : 0;
     }
-    if (threadIdx.x == 0) value[0] = (float)(red[0] / denom);
+    if (!__builtin_amdgcn_readfirstlane(last)) return;
+    acc = 0.0;
+    for (int i = lane; i < ngrp; i += 64) acc += ld64(&gpart[i]);
+    const double tot = wave_total(acc);
+    if (lane == 0) {
+        value[0] = (float)(tot / denom);
+        __hip_atomic_store(tk_.top, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 static unsigned long long *g_cham_counters = nullptr;
@@ -485,21 +524,23 @@ extern "C" int rrl_chamfer_tree_fwd(const float *x, const float *y, void *ws, si
     int rc = rrl_launch_cloud_sort(small ? x : nullptr, small ? y : nullptr, (float4 *)(w + L.crec1), (float4 *)(w + L.crec2), (float *)(w + L.apart), L.nblk,
                                    (float4 *)(w + L.p0s1), (float4 *)(w + L.p0s2), (int32_t *)(w + L.idx1),
                                    (int32_t *)(w + L.idx2), (float4 *)(w + L.grp1), (float4 *)(w + L.grp2),
-                                   (uint32_t *)(w + L.pmax), (unsigned *)(w + L.histg), B, N, M, s);
+                                   (uint32_t *)(w + L.pmax), (unsigned *)(w + L.histg),
+                                   small ? (uint32_t *)(w + L.ctrl) : nullptr, (int)(L.ctrl_bytes / 4),  // (large clouds: cleared by pts_records_kernel)
+                                   B, N, M, s);
     if (rc) return rc;
     const int nsgmax = (nmax + SGT - 1) / SGT;
+    const ChamTick tick = {(uint32_t *)(w + L.ctrl), (uint32_t *)(w + L.ctrl) + 32, 64, 32};
 #define RRL_NN_LAUNCH(COUNT)                                                                                     \
     hipLaunchKernelGGL((chamfer_tree_kernel<COUNT, false>), dim3((unsigned)(2 * B), (unsigned)nsgmax), dim3(64 * NWV), 0, \
                        s, (const float4 *)(w + L.p0s1), (const float4 *)(w + L.p0s2),                            \
                        (const float4 *)(w + L.grp1), (const float4 *)(w + L.grp2), (const float *)(w + L.apart),  \
                        L.nblk, (unsigned long long *)best_x, (unsigned long long *)best_y,                       \
                        (double *)(w + L.partial), B, N, M, g_cham_counters, g_cham_counter_rows, (const int32_t *)nullptr, \
-                       (const int32_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr)
+                       (const int32_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr, tick,      \
+                       (double *)(w + L.gpart), value, (double)B * (double)(N + M))
     if (g_cham_counters) RRL_NN_LAUNCH(true);
     else RRL_NN_LAUNCH(false);
 #undef RRL_NN_LAUNCH
-    hipLaunchKernelGGL(chamfer_partials_kernel, dim3(1), dim3(256), 0, s, (const double *)(w + L.partial),
-                       2 * B * nsgmax, value, (double)B * (double)(N + M));
     RRL_LAUNCH_CHECK();
     return 0;
 }
@@ -512,7 +553,7 @@ extern "C" int rrl_chamfer_tree_fwd(const float *x, const float *y, void *ws, si
 //   the same one, or the `target_ws` the evaluation was carried over from (rrl_loss_forward_cached).
 // The tree radii include the triangles' thresholds (looser bounds, same minima).  Keys and value are those of
 // rrl_chamfer_fwd on (P0 of cloud 1, P0 of cloud 2); a non-finite or overflowing coordinate gives NaN.
-extern "C" int rrl_chamfer_from_loss(const void *ws_src, const void *ws_tar, size_t loss_ws_bytes, int B, int N, int M,
+extern "C" int rrl_chamfer_from_loss(void *ws_src, const void *ws_tar, size_t loss_ws_bytes, int B, int N, int M,
                                      int L, void *ws, size_t ws_bytes, uint64_t *best_x, uint64_t *best_y,
                                      float *value, void *stream) {
     if (!ws_src || !ws_tar || !ws || !best_x || !best_y || !value || B <= 0 || N <= 0 || M <= 0 || L < 0) return RRL_E_ARG;
@@ -524,6 +565,10 @@ extern "C" int rrl_chamfer_from_loss(const void *ws_src, const void *ws_tar, siz
     hipStream_t s = (hipStream_t)stream;
     char *w = (char *)ws;
     const int nmax = N > M ? N : M, nsgmax = (nmax + SGT - 1) / SGT;
+    // arrival counters of the mean: words of the evaluation's own workspace that every forward leaves zero and that
+    // rewind themselves (MCTL[b][30 + direction] per group, MCTL[0][32] for the groups): any number of calls per forward
+    uint32_t *mctl = (uint32_t *)((char *)ws_src + lw.off[RRL_WS_MCTL]);
+    const ChamTick tick = {mctl + 32, mctl + 30, 64, 1};
 #define RRL_NN_LAUNCH(COUNT)                                                                                     \
     hipLaunchKernelGGL((chamfer_tree_kernel<COUNT, true>), dim3((unsigned)(2 * B), (unsigned)nsgmax), dim3(64 * NWV), 0, \
                        s, (const float4 *)lw.f32(ws_src, RRL_WS_P0S1), (const float4 *)lw.f32(ws_tar, RRL_WS_P0S2), \
@@ -531,12 +576,11 @@ extern "C" int rrl_chamfer_from_loss(const void *ws_src, const void *ws_tar, siz
                        (const float *)nullptr, 0, (unsigned long long *)best_x, (unsigned long long *)best_y,    \
                        (double *)(w + C.partial), B, N, M, g_cham_counters, g_cham_counter_rows, lw.i32(ws_src, RRL_WS_IDX1), \
                        lw.i32(ws_tar, RRL_WS_IDX2), (const uint32_t *)lw.i32(ws_src, RRL_WS_PMAX),              \
-                       (const uint32_t *)lw.i32(ws_tar, RRL_WS_PMAX) + B)
+                       (const uint32_t *)lw.i32(ws_tar, RRL_WS_PMAX) + B, tick, (double *)(w + C.gpart), value,  \
+                       (double)B * (double)(N + M))
     if (g_cham_counters) RRL_NN_LAUNCH(true);
     else RRL_NN_LAUNCH(false);
 #undef RRL_NN_LAUNCH
-    hipLaunchKernelGGL(chamfer_partials_kernel, dim3(1), dim3(256), 0, s, (const double *)(w + C.partial),
-                       2 * B * nsgmax, value, (double)B * (double)(N + M));
     RRL_LAUNCH_CHECK();
     return 0;
 }

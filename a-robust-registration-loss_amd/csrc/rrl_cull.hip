@@ -128,6 +128,8 @@ struct BuildArgs {
     float2 *lmax;                  //   the scan entry computes them itself then)
     int L;
     int nblk_tri;                  // tri_records_kernel: workgroups [0, nblk_tri) of a (sample, cloud) hold triangles
+    uint32_t *zwords;              // tri_sort_kernel (Chamfer path): words its first workgroup clears (may be NULL)
+    int nzwords;
     int B, N, M, transpose_r, nblk;
     int nchunk;                    // tri_sort_kernel: chunks of 4096 records per cloud (1: the whole cloud)
 };
@@ -313,6 +315,8 @@ __global__ __launch_bounds__(1024) void tri_sort_kernel(const BuildArgs a) {
     __shared__ int s_cb[2];          // the cells that straddle p0 / p1 (-1: the boundary falls between two cells)
     __shared__ unsigned s_bw[2][64]; // their records per (pass k, wavefront): exclusive prefix in index order
     if (tid < 2) s_cb[tid] = -1;
+    if (a.zwords != nullptr && blockIdx.x == 0 && blockIdx.y == 0)  // the Chamfer walk's arrival counters (next launch)
+        for (int i = tid; i < a.nzwords; i += 1024) a.zwords[i] = 0u;
 
     // ---- AABB of the P0s and max |P|^2 from the per-workgroup partials of tri_records_kernel
     float4 rec[NPT];
@@ -652,15 +656,21 @@ static_assert(SPW <= (1 << SG_BITS), "slot bits of the queue entries");
 #define WPB 8      // wavefronts per workgroup: same slice, LPW lines each
 #endif
 #define LPW 128    // lines per wavefront (two per lane in level A)
+#ifndef ROWS
 #define ROWS 17    // float4 per staged group row: 16 records + 16 bytes of padding (bank spread)
+#endif
 #ifndef WCCAP
 #define WCCAP 128  // parked point-0 candidates per wave
 #endif
 // queue capacities.  Level A leaves ALL of a wavefront's (line, supergroup) pairs in queue A at once when they fit
 // (~128 of the 1024 possible; otherwise supergroup by supergroup with drains in between); level B pops 64 of them
 // and pushes their passing halves (~1.4 of 8 each, at most 512: split then) on top of < 64 left-overs of queue C.
+#ifndef QA_CAP
 #define QA_CAP 256
+#endif
+#ifndef QC_CAP
 #define QC_CAP 256
+#endif
 
 struct WaveCtx {
     const float2 *lr;             // this wave's lines in LDS as they lie in memory: 3 float2 per line (dir.xy | dir.z x0.x | x0.yz)
@@ -1285,6 +1295,7 @@ int rrl_launch_tri_build(const float *tri1, const float *tri2, void *ws, const W
     a.z3_vec4 = w.state_bytes / 16;
     a.del1 = w.f32(ws, RRL_WS_DEL1);
     a.del2 = w.f32(ws, RRL_WS_DEL2);
+    a.zwords = nullptr; a.nzwords = 0;
     a.line = line;
     a.lmax = line && L > 0 ? (float2 *)w.f32(ws, RRL_WS_LMAX) : nullptr;
     a.L = L;
@@ -1317,7 +1328,7 @@ int rrl_launch_tri_build(const float *tri1, const float *tri2, void *ws, const W
 // and sample) must already exist and histg (cleared by the caller) is used beyond 4096 records.
 int rrl_launch_cloud_sort(const float *raw1, const float *raw2, float4 *crec1, float4 *crec2, float *apart, int nblk,
                           float4 *p0s1, float4 *p0s2, int32_t *idx1, int32_t *idx2, float4 *grp1, float4 *grp2,
-                          uint32_t *pmax, unsigned *histg, int B, int N, int M, hipStream_t s) {
+                          uint32_t *pmax, unsigned *histg, uint32_t *zwords, int nzwords, int B, int N, int M, hipStream_t s) {
     const int nmax = M > N ? M : N;
     if (nmax > SORT_CAP || B <= 0 || nmax <= 0) return RRL_E_ARG;
     const size_t ngpmax = (size_t)(nmax + SGT - 1) / SGT * SGG;
@@ -1329,6 +1340,7 @@ int rrl_launch_cloud_sort(const float *raw1, const float *raw2, float4 *crec1, f
     a.idx1 = idx1; a.idx2 = idx2;
     a.grp1 = grp1; a.grp2 = grp2;
     a.pmax = pmax;
+    a.zwords = zwords; a.nzwords = nzwords;
     a.B = B; a.N = N; a.M = M;
     // (the chunked sort of rrl_launch_tri_build was tried here too: a nearest-neighbour walk evaluates twice the
     //  pairs on chunked clouds -- 63.0 -> 64.4 us at N = M = 16384, 188 -> 380 at 65536: whole-cloud order stays)

@@ -892,14 +892,44 @@ __device__ __forceinline__ SampleGeom sample_geom(const float *r, const float *c
     return g;
 }
 
-// candidate i of round rd: code/loss.py:394-411
-__device__ __forceinline__ void sample_line(const SampleGeom &g, const float *__restrict__ rands, int B, int n,
+// The library's own generator for the sampler's uniforms (round 3; opt-in like every GPU-drawn stream: the reference
+// draws from torch's CPU generator).  Philox4x32-10, counter-based: the four uniforms of candidate i of round rd of
+// sample b in call number `call` are one block keyed by the seed -- no state to advance per draw, the count and the
+// write pass regenerate identical candidates, and a captured step needs no host-side generator bookkeeping (torch's
+// GPU generator costs two fill kernels per graph replay to move its offset: ~9 us of the demo's 131 us epoch).
+// state[0] = seed, state[1] = call counter (advanced by the LAST workgroup of the write pass), state[2] = its ticket.
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1,
+                                              unsigned *out) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// candidate i of round rd: code/loss.py:394-411.  rands != NULL: the caller's uniforms [rd][4][b][i]; else rng_state.
+__device__ __forceinline__ void sample_line(const SampleGeom &g, const float *__restrict__ rands,
+                                            const unsigned long long *__restrict__ rng_state, int B, int n,
                                             int b, int rd, int i, float *ln) {
     const float pi32 = 3.14159274101257324f;  // torch.pi of code/loss.py:9
-    const float *rr = rands + ((size_t)rd * 4 * B + b) * n;  // [rd][s][b][i]
-    const size_t sstride = (size_t)B * n;
-    float al1 = (rr[i] * 2.0f) * pi32, v1 = rr[sstride + i] * 2.0f - 1.0f;
-    float al2 = (rr[2 * sstride + i] * 2.0f) * pi32, v2 = rr[3 * sstride + i] * 2.0f - 1.0f;
+    float u[4];
+    if (rands) {
+        const float *rr = rands + ((size_t)rd * 4 * B + b) * n;  // [rd][s][b][i]
+        const size_t sstride = (size_t)B * n;
+        u[0] = rr[i]; u[1] = rr[sstride + i]; u[2] = rr[2 * sstride + i]; u[3] = rr[3 * sstride + i];
+    } else {
+        const unsigned long long seed = rng_state[0], call = rng_state[1];
+        unsigned x[4];
+        philox4x32_10((unsigned)i, (unsigned)rd | ((unsigned)b << 16), (unsigned)call, (unsigned)(call >> 32), (unsigned)seed,
+                      (unsigned)(seed >> 32), x);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) u[q] = (float)(x[q] >> 8) * (1.0f / 16777216.0f);  // 24 bits: [0, 1) like torch.rand
+    }
+    float al1 = (u[0] * 2.0f) * pi32, v1 = u[1] * 2.0f - 1.0f;
+    float al2 = (u[2] * 2.0f) * pi32, v2 = u[3] * 2.0f - 1.0f;
     float s1 = sqrtf(1.0f - v1 * v1), s2 = sqrtf(1.0f - v2 * v2);
     float q1[3] = {(g.rad * s1) * cosf(al1), (g.rad * sinf(al1)) * s1, g.rad * v1};
     float q2[3] = {(g.rad * s2) * cosf(al2), (g.rad * sinf(al2)) * s2, g.rad * v2};
@@ -919,7 +949,8 @@ __device__ __forceinline__ void sample_line(const SampleGeom &g, const float *__
 //      ballot per wavefront is stored for the write pass.
 // prefilter = 0 sends every candidate through step 2 (tests: identical ballots).
 __global__ __launch_bounds__(1024) void sample_count_kernel(
-    const float *__restrict__ rands, const float *__restrict__ r, const float *__restrict__ centers,
+    const float *__restrict__ rands, const unsigned long long *__restrict__ rng_state, const float *__restrict__ r,
+    const float *__restrict__ centers,
     const float *__restrict__ aabb1, const float *__restrict__ aabb2,
     unsigned long long *__restrict__ accept, int B, int n, int rounds, int prefilter, int rd0) {
     __shared__ __attribute__((aligned(16))) float faces[24][FACE_FLOATS];
@@ -957,7 +988,7 @@ __global__ __launch_bounds__(1024) void sample_count_kernel(
         float ln[6];
         bool pre = false;
         if (ok) {
-            sample_line(g, rands, B, n, b, rd, i, ln);
+            sample_line(g, rands, rng_state, B, n, b, rd, i, ln);
             pre = !prefilter || (slab_maybe(g.bb1, ln) && slab_maybe(g.bb2, ln));
         }
         const unsigned long long m = __ballot(pre);
@@ -989,7 +1020,8 @@ __global__ __launch_bounds__(1024) void sample_count_kernel(
 }
 
 __global__ __launch_bounds__(1024) void sample_write_kernel(
-    const float *__restrict__ rands, const float *__restrict__ r, const float *__restrict__ centers,
+    const float *__restrict__ rands, unsigned long long *__restrict__ rng_state, const float *__restrict__ r,
+    const float *__restrict__ centers,
     const float *__restrict__ aabb1, const float *__restrict__ aabb2,
     const unsigned long long *__restrict__ accept, float *__restrict__ lines, int32_t *__restrict__ filled,
     int B, int n, int rounds) {
@@ -1030,7 +1062,7 @@ __global__ __launch_bounds__(1024) void sample_write_kernel(
         if (slot < n) {
             const SampleGeom g = sample_geom(r, centers, aabb1, aabb2, b);
             float ln[6];
-            sample_line(g, rands, B, n, b, rd, i, ln);
+            sample_line(g, rands, rng_state, B, n, b, rd, i, ln);
             float *dst = lines + ((size_t)b * n + slot) * 6;
 #pragma unroll
             for (int c = 0; c < 6; ++c) dst[c] = ln[c];
@@ -1043,13 +1075,23 @@ __global__ __launch_bounds__(1024) void sample_write_kernel(
         for (int c = 0; c < 6; ++c) dst[c] = 0.0f;
     }
     if (rd == 0 && tile == 0 && tid == 0) filled[b] = s_total;
+    if (rng_state != nullptr) {  // the next call draws the next block of the stream: advanced by whoever finishes last
+        __syncthreads();         // (every lane of this workgroup has drawn its candidate)
+        if (tid == 0) {
+            unsigned *ticket = (unsigned *)(rng_state + 2);
+            const unsigned nwg = gridDim.x * gridDim.y * gridDim.z;
+            if (atomicAdd(ticket, 1u) == nwg - 1u) {
+                rng_state[1] += 1ull;
+                __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
 }
 
-extern "C" int rrl_sample_lines(const float *rands, const float *r, const float *centers,
-                                const float *aabb1, const float *aabb2, float *lines,
-                                int32_t *filled, int32_t *tile_counts, int B, int n, int rounds,
-                                void *stream) {
-    if (!rands || !r || !centers || !lines || !filled || !tile_counts) return RRL_E_ARG;
+static int sample_lines_impl(const float *rands, unsigned long long *rng_state, const float *r, const float *centers,
+                             const float *aabb1, const float *aabb2, float *lines, int32_t *filled,
+                             int32_t *tile_counts, int B, int n, int rounds, void *stream) {
+    if ((!rands && !rng_state) || !r || !centers || !lines || !filled || !tile_counts) return RRL_E_ARG;
     if (B < 0 || n < 0 || rounds < 0 || rounds > 65535 || B > 65535) return RRL_E_ARG;
     if (B == 0 || n == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
@@ -1067,17 +1109,34 @@ extern "C" int rrl_sample_lines(const float *rands, const float *r, const float 
     // 10 x 10000 candidates, radius = half the box diagonal).  Small calls (the demo: 200 workgroups,
     // never full) stay one launch: two latency-bound launches cost it 10 us of 15.
     const int first = (rounds < 3 || (size_t)grid.x * rounds * B < 512) ? rounds : 3;
-    hipLaunchKernelGGL(sample_count_kernel, dim3(grid.x, (unsigned)first, grid.z), dim3(1024), 0, s, rands, r, centers,
-                       aabb1, aabb2, accept, B, n, rounds, prefilter, 0);
+    hipLaunchKernelGGL(sample_count_kernel, dim3(grid.x, (unsigned)first, grid.z), dim3(1024), 0, s, rands, rng_state, r,
+                       centers, aabb1, aabb2, accept, B, n, rounds, prefilter, 0);
     if (rounds > first)
         hipLaunchKernelGGL(sample_count_kernel, dim3(grid.x, (unsigned)(rounds - first), grid.z), dim3(1024), 0, s, rands,
-                           r, centers, aabb1, aabb2, accept, B, n, rounds, prefilter, first);
+                           rng_state, r, centers, aabb1, aabb2, accept, B, n, rounds, prefilter, first);
     const size_t lds = sizeof(int32_t) * (size_t)rounds * grid.x;
     if (lds > 96 * 1024) return RRL_E_ARG;  // > 24576 tiles x rounds: far beyond any caller
-    hipLaunchKernelGGL(sample_write_kernel, grid, dim3(1024), lds, s, rands, r, centers, aabb1, aabb2,
+    hipLaunchKernelGGL(sample_write_kernel, grid, dim3(1024), lds, s, rands, rng_state, r, centers, aabb1, aabb2,
                        accept, lines, filled, B, n, rounds);
     RRL_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int rrl_sample_lines(const float *rands, const float *r, const float *centers,
+                                const float *aabb1, const float *aabb2, float *lines,
+                                int32_t *filled, int32_t *tile_counts, int B, int n, int rounds,
+                                void *stream) {
+    if (!rands) return RRL_E_ARG;
+    return sample_lines_impl(rands, nullptr, r, centers, aabb1, aabb2, lines, filled, tile_counts, B, n, rounds, stream);
+}
+
+extern "C" int rrl_sample_lines_rng(uint64_t *rng_state, const float *r, const float *centers,
+                                    const float *aabb1, const float *aabb2, float *lines,
+                                    int32_t *filled, int32_t *tile_counts, int B, int n, int rounds,
+                                    void *stream) {
+    if (!rng_state) return RRL_E_ARG;
+    return sample_lines_impl(nullptr, (unsigned long long *)rng_state, r, centers, aabb1, aabb2, lines, filled, tile_counts,
+                             B, n, rounds, stream);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -141,11 +141,12 @@ def _uniform_rounds(B, n, rounds, device_rng=None, dev=None):
     `torch.manual_seed(s)` before the call selects the same candidates as in the reference.
     One `torch.rand` of the stacked shape consumes the generator exactly like the 4 * rounds
     separate calls (checked in tests/test_host.py) and lands in a reused pinned buffer, so the
-    upload is one asynchronous copy; the result is on the GPU.  device_rng: a torch.device -> draw on the GPU instead (same
-    distribution, different stream: for training loops, where 4 * rounds * B * n host-generated
+    upload is one asynchronous copy; the result is on the GPU.  device_rng: a torch.device -> None is returned and the
+    sampler kernels draw the uniforms themselves (the library's counter-based generator, rrl_hip.ops.sampler_rng: same
+    distribution, a different stream -- for training loops and captured steps, where 4 * rounds * B * n host-generated
     floats per step would cost more than the loss itself)."""
     if device_rng is not None:
-        return torch.rand(rounds, 4, B, n, device=device_rng)
+        return None  # drawn inside the sampler kernels by the library's own generator (rrl_hip.ops.sampler_rng)
     dev = dev if dev is not None else _ops.require_gpu()
     if B * n < 16:  # torch's scalar path for tiny tensors: keep the reference's call pattern
         return torch.stack([torch.stack([torch.rand(B, n) for _ in range(4)]) for _ in range(rounds)]).to(dev)
@@ -170,7 +171,7 @@ def Random_uniform_distribution_lines_batch_efficient(r, centers, N, device='cpu
     around `centers` (code/loss.py:384-412).  (B, N, 6) = [unit direction, x0]."""
     B = r.shape[0]
     rands = _uniform_rounds(B, N, 1, _ops.require_gpu() if device_rng else None)
-    lines, _ = _sample(rands, r, centers, None, None)
+    lines, _ = _sample(rands, r, centers, None, None, shape=(1, B, N))
     return lines.to(device)
 
 
@@ -188,14 +189,14 @@ def Random_uniform_distribution_lines_batch_efficient_resample(r, centers, N, ve
     dev = _ops._home(out, vertices1, vertices2)  # the lines are built where the clouds live
     rands = _uniform_rounds(B, N, rounds, dev if device_rng else None, dev)
     bb2 = box2 if box2 is not None else _ops.aabb(vertices2)
-    lines, _ = _sample(rands, r, centers, _ops.aabb(vertices1), bb2, out)
+    lines, _ = _sample(rands, r, centers, _ops.aabb(vertices1), bb2, out, shape=(rounds, B, N))
     return lines if out is not None else lines.to(device)
 
 
-def _sample(rands, r, centers, bb1, bb2, out=None):
-    B = rands.shape[2]
+def _sample(rands, r, centers, bb1, bb2, out=None, shape=None):
+    B = shape[1]
     rr = r.reshape(B, -1)[:, 0]
-    return _ops.sample_lines(rands, rr, centers.reshape(B, 3), bb1, bb2, out)
+    return _ops.sample_lines(rands, rr, centers.reshape(B, 3), bb1, bb2, out, rng_shape=shape)
 
 
 # ----------------------------------------------------------------- rigid transform module

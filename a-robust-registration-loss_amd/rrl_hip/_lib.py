@@ -55,6 +55,7 @@ _SIGS = {
     "rrl_fps": [_P, _P, _P, _P, _I, _I, _I, _P],
     "rrl_knn3": [_P, _P, _P, _I, _I, _I, _P],
     "rrl_sample_lines": [_P] * 8 + [_I] * 3 + [_P],
+    "rrl_sample_lines_rng": [_P] * 8 + [_I] * 3 + [_P],
 }
 EXPORTS = sorted(list(_SIGS) + ["rrl_version", "rrl_workspace_bytes", "rrl_chamfer_workspace_bytes"])
 

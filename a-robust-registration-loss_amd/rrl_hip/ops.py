@@ -831,28 +831,57 @@ def box_accept(lines, aabb1, aabb2):
     return mask, hits
 
 
-def sample_lines(rands, r, centers, aabb1, aabb2, out=None):
+_sampler_rng = {}  # device index -> int64[4] state of the library's generator (include/rrl.h rrl_sample_lines_rng)
+
+
+def sampler_rng(dev=None, seed=None):
+    """State of the library's own uniform generator for the line sampler on `dev` (Philox4x32-10 inside the sampler
+    kernels: [seed, call counter, ticket, 0]).  Created on first use from torch's default seed (torch.initial_seed(), i.e.
+    the last torch.manual_seed); seed=<int> re-seeds and rewinds it.  The counter lives on the device and is advanced by
+    every call, so a captured step replays a fresh stream each time with no host-side bookkeeping."""
+    dev = dev if dev is not None else require_gpu()
+    st = _sampler_rng.get(dev.index)
+    if st is None or seed is not None:
+        sd = torch.initial_seed() if seed is None else int(seed)
+        new = torch.tensor([sd & 0x7FFFFFFFFFFFFFFF, 0, 0, 0], dtype=torch.int64, device=dev)
+        if st is None:
+            st = _sampler_rng[dev.index] = new
+        else:
+            st.copy_(new)  # in place: a captured step keeps pointing at the same memory
+    return st
+
+
+def sample_lines(rands, r, centers, aabb1, aabb2, out=None, rng_shape=None):
     """rands (rounds, 4, B, n) uniform draws -> lines (B, n, 6), filled (B,) int32.
+    rands=None with rng_shape=(rounds, B, n): the uniforms are drawn inside the kernels by the library's generator
+    (sampler_rng) -- no (rounds, 4, B, n) tensor exists at all.
     out: a contiguous fp32 (B, n, 6) GPU tensor to write the lines into (no extra copy)."""
-    dev = _home(out, rands, aabb1, aabb2)
-    rd = _prep(rands, "rands", None, dev)
-    rounds, four, B, n = rd.shape
-    assert four == 4
+    dev = _home(out, rands, aabb1, aabb2, r)
+    if rands is not None:
+        rd = _prep(rands, "rands", None, dev)
+        rounds, four, B, n = rd.shape
+        assert four == 4
+    else:
+        rounds, B, n = (int(v) for v in rng_shape)
     rr = _prep(r, "r", None, dev).reshape(B)
     cc = _prep(centers, "centers", None, dev).reshape(B, 3)
     aabb1 = _prep(aabb1, "aabb1", 6, dev) if aabb1 is not None else None
     aabb2 = _prep(aabb2, "aabb2", 6, dev) if aabb2 is not None else None
     if out is None:
-        lines = torch.empty(B, n, 6, device=rd.device)
+        lines = torch.empty(B, n, 6, device=dev)
     else:
         if not (out.is_cuda and out.device == dev and out.dtype == torch.float32 and out.is_contiguous()
                 and out.numel() == B * n * 6):
             raise ValueError("out must be a contiguous fp32 GPU tensor of B * n * 6 elements")
         lines = out
-    filled = torch.empty(B, dtype=torch.int32, device=rd.device)
-    scratch = torch.empty(B * max(rounds, 1) * ((n + 1023) // 1024) * 32, dtype=torch.int32, device=rd.device)
-    _run(dev, "rrl_sample_lines", _p(rd), _p(rr), _p(cc), _p(aabb1), _p(aabb2), _p(lines), _p(filled), _p(scratch),
-         B, n, rounds)
+    filled = torch.empty(B, dtype=torch.int32, device=dev)
+    scratch = torch.empty(B * max(rounds, 1) * ((n + 1023) // 1024) * 32, dtype=torch.int32, device=dev)
+    if rands is not None:
+        _run(dev, "rrl_sample_lines", _p(rd), _p(rr), _p(cc), _p(aabb1), _p(aabb2), _p(lines), _p(filled), _p(scratch),
+             B, n, rounds)
+    else:
+        _run(dev, "rrl_sample_lines_rng", _p(sampler_rng(dev)), _p(rr), _p(cc), _p(aabb1), _p(aabb2), _p(lines), _p(filled),
+             _p(scratch), B, n, rounds)
     return lines, filled
 
 

@@ -122,6 +122,16 @@ class _GatedAdam:
         _ops.adam_gated(self.p.data, grad, self.m, self.v, self.step, self.lr, gate)
 
 
+def _same_point_set(points, tri):
+    """Are the first points of the pseudo-triangles `tri` (.., 9) exactly the points `points` (.., 3), in any order?
+    (Then the Chamfer distance of the loss evaluation's sorted P0 records is the monitor's value.)"""
+    p = points.detach().reshape(-1, 3).cpu().numpy()
+    q = tri.detach().reshape(-1, 9)[:, :3].cpu().numpy()
+    if p.shape != q.shape:
+        return False
+    return bool(np.array_equal(p[np.lexsort(p.T[::-1])], q[np.lexsort(q.T[::-1])]))
+
+
 def _default_lines(radius, centers, n_sample_line, target, device, device_rng=False):
     box2 = []  # the target does not move: its AABB is computed once
 
@@ -207,21 +217,32 @@ def _run_graphed(model, draw, src, src_nb, tar, tar_tri, Save_path, writer, n_ep
     src_pts = src.reshape(1, -1, 3).contiguous()
     tar_pts = tar.reshape(1, -1, 3).contiguous()
 
+    # No autograd inside the captured step (round 3): the pose kernels and the fused op are called directly on
+    # preallocated buffers (autograd's AccumulateGrad / view bookkeeping added two copy kernels per epoch, ~9 us of the
+    # 131), and the Chamfer monitor walks the clouds the loss evaluation just sorted when the point sets ARE the
+    # triangles' first points (Sample_neighs keeps every point when the cloud has <= 5000: checked once, on the host).
+    Rb = torch.empty(1, 3, 3, device=dev)
+    Tb = torch.empty(1, 3, device=dev)
+    gxi = torch.empty(1, 6, device=dev)
+    n_lines = lines.shape[1]
+    reg = _ops.RegistrationStep(src_tri, tar_tri, n_lines, transpose_r=False)
+    monitor_from_state = _same_point_set(src, src_tri) and _same_point_set(tar, tar_tri) and \
+        max(src_tri.shape[1], tar_tri.shape[1]) <= 65536
+    P = _ops._p
+
     def step():
-        # the whole epoch in ~21 launches: sampler (rand, AABB, 2 sample kernels), exp map, the
-        # loss's 5 + 1, exp-map backward, Adam, rigid apply, Chamfer (4), log row
+        # the whole epoch in ~17 launches: sampler (rand, AABB, 2 sample kernels), exp map, the loss's 5 + 1,
+        # exp-map backward, Adam, rigid apply, Chamfer (1 or 2), log row
         if draw_in_graph:  # lines from the previous epoch's moved source, like the reference loop
             draw(0, moved.reshape(-1, 3), out=lines)
-        xi.grad = None
-        R, T = _ops.se3_exp(xi)  # == model.Transform() (LieAlgebra.se3.exp3), one launch each way
-        loss, info, _ = _ops.registration_loss(src_tri, R, T, tar_tri, lines, transpose_r=False)
-        torch.autograd.backward([loss], [ones])
-        opt.update(xi.grad, info)  # skipped on the device when no bucket is populated
-        with torch.no_grad():
-            _ops.rigid_apply_into(src_pts, R, T, moved)
-            cf = _ops.chamfer(moved, tar_pts)
-            # loss, Chamfer, valid -> row (and, with the sampler in the graph, the trace table)
-            _ops.log_row(loss, cf.reshape(1), info, trace if draw_in_graph else scratch_row, slot, row)
+        _ops._run(dev, "rrl_se3_exp", P(xi.data), P(Rb), P(Tb), 1)  # == model.Transform() (LieAlgebra.se3.exp3)
+        loss, gR, gt, _, info = reg(Rb, Tb, lines)                  # forward + backward to (dL/dR, dL/dT)
+        _ops._run(dev, "rrl_se3_exp_bwd", P(xi.data), P(gR), P(gt), P(gxi), 1)
+        opt.update(gxi.view(-1), info)  # skipped on the device when no bucket is populated
+        _ops.rigid_apply_into(src_pts, Rb, Tb, moved)
+        cf = _ops.chamfer_from_state(reg.st) if monitor_from_state else _ops.chamfer(moved, tar_pts)
+        # loss, Chamfer, valid -> row (and, with the sampler in the graph, the trace table)
+        _ops.log_row(loss, cf.reshape(1), info, trace if draw_in_graph else scratch_row, slot, row)
         return row
 
     lr = 2e-2

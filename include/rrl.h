@@ -313,7 +313,7 @@ int rrl_chamfer_fwd(const float *x, const float *y, uint64_t *best_x, uint64_t *
                     float *value, int B, int N, int M, void *stream);
 /* The same result (keys bit-identical, value from a fixed-order sum) through the scan's spatial
  * structures: both clouds in grid-cell (Hilbert) order under the sphere tree, nearest neighbours by a
- * pruned tree walk, the mean folded into the same launch (3 launches for N, M <= 4096).  ws: scratch of
+ * pruned tree walk, the mean folded into the same launch (2 launches for N, M <= 4096).  ws: scratch of
  * rrl_chamfer_workspace_bytes(B, N, M) bytes.  N, M in [1, 65536].  best_x / best_y need no
  * initialisation.  A NaN coordinate in a target cloud makes every minimum of that sample NaN and a
  * NaN query its own minimum, as torch.min does. */
@@ -330,8 +330,9 @@ int rrl_chamfer_tree_fwd(const float *x, const float *y, void *ws, size_t ws_byt
  * P0 of cloud 2).  ws_src: the evaluation's workspace; ws_tar: the workspace holding cloud 2's records
  * (the same one, or the target_ws the evaluation was carried over from); both of layout (B, N, M, L).
  * ws: scratch of rrl_chamfer_workspace_bytes(B, N, M).  N, M <= 65536 (larger clouds are not sorted).
- * Two launches.  A non-finite (or overflowing) coordinate anywhere in a cloud gives NaN minima. */
-int rrl_chamfer_from_loss(const void *ws_src, const void *ws_tar, size_t loss_ws_bytes, int B, int N, int M,
+ * ONE launch (round 3: the mean is finished by the last workgroups to arrive; their counters are words of ws_src's MCTL
+ * field, which is why ws_src is not const).  A non-finite (or overflowing) coordinate anywhere in a cloud gives NaN minima. */
+int rrl_chamfer_from_loss(void *ws_src, const void *ws_tar, size_t loss_ws_bytes, int B, int N, int M,
                           int L, void *ws, size_t ws_bytes, uint64_t *best_x, uint64_t *best_y, float *value,
                           void *stream);
 /* Profiling hook like rrl_scan_counters: while dev_counters != NULL rrl_chamfer_tree_fwd runs an
@@ -372,6 +373,14 @@ int rrl_box_accept(const float *lines, const float *aabb1, const float *aabb2, u
 int rrl_sample_lines(const float *rands, const float *r, const float *centers, const float *aabb1,
                      const float *aabb2, float *lines, int32_t *filled, int32_t *tile_counts, int B,
                      int n, int rounds, void *stream);
+/* The same with the uniforms drawn INSIDE the kernels by the library's counter-based generator (Philox4x32-10) instead
+ * of read from `rands` -- the GPU-side stream for training loops and captured steps (same distribution as torch.rand:
+ * 24-bit uniforms in [0, 1); a different stream from both torch generators).  rng_state: 4 uint64 on the device,
+ * [0] seed, [1] call counter (every call draws a fresh block and advances it), [2] internal ticket (zero), [3] unused.
+ * A captured graph replays correctly: the counter lives on the device. */
+int rrl_sample_lines_rng(uint64_t *rng_state, const float *r, const float *centers, const float *aabb1,
+                         const float *aabb2, float *lines, int32_t *filled, int32_t *tile_counts, int B,
+                         int n, int rounds, void *stream);
 
 /* ---- pseudo-triangle builder (code/loss.py:473-485 + code/utils.py:275-296) --------------- */
 /* Farthest-point sampling of S <= n points per cloud, starting at start[b] (the reference draws it

@@ -1028,6 +1028,50 @@ def test_sampler(L, oracle):
     assert abs(nb - int((np.abs(g["final_big"]).sum(1) > 0).sum())) <= 15
 
 
+def test_sampler_library_generator(L):
+    """device_rng=True: the uniforms come from the library's counter-based generator INSIDE the sampler kernels
+    (rrl_sample_lines_rng): unit directions on chords of the sphere, the accept test still applied (every filled row
+    passes rrl_box_accept), a fresh stream per call, the same stream after re-seeding, and -- captured in a graph --
+    a fresh stream per REPLAY (the call counter lives on the device)."""
+    from rrl_hip import ops, synth
+    from rrl_hip.graph import GraphedStep
+    pr = synth.make_pair(3, 800, 700)
+    src, tar = cu(pr["src"])[None], cu(pr["tar"])[None]
+    r = torch.tensor([[float(pr["radius"])]])
+    c = torch.from_numpy(pr["center"]).reshape(1, 3)
+    n = 5000
+
+    def draw(out=None):
+        return L.Random_uniform_distribution_lines_batch_efficient_resample(r, c, n, src, tar, "cuda", device_rng=True, out=out)
+    ops.sampler_rng(seed=1234)
+    a, b_ = draw().clone(), draw().clone()
+    ops.sampler_rng(seed=1234)
+    a2 = draw().clone()
+    assert torch.equal(a, a2) and not torch.equal(a, b_)
+    for ln in (a, b_):
+        filled = ln[0].abs().sum(1) > 0
+        assert int(filled.sum()) > 0.5 * n
+        d = ln[0][filled, :3]
+        np.testing.assert_allclose(d.norm(dim=1).cpu().numpy(), 1.0, atol=2e-6)
+        x0 = ln[0][filled, 3:] - c.cuda()
+        np.testing.assert_allclose(x0.norm(dim=1).cpu().numpy(), float(pr["radius"]), rtol=1e-5)
+        mask, _ = ops.box_accept(ln, ops.aabb(src), ops.aabb(tar))
+        assert bool(((mask[0][filled] & 3) == 3).all())
+    # all candidates of one round, no boxes: uniform on the sphere (mean offset ~ 0, second moments ~ r^2 / 3)
+    allc = L.Random_uniform_distribution_lines_batch_efficient(r, c, 200000, "cuda", device_rng=True)
+    x0 = (allc[0, :, 3:] - c.cuda()) / float(pr["radius"])
+    assert float(x0.mean(0).abs().max()) < 0.01 and float(((x0 ** 2).mean(0) - 1 / 3).abs().max()) < 0.01
+    # captured: every replay draws the next block
+    buf = torch.empty(1, n, 6, device="cuda")
+    rg, cg, box2 = r.cuda(), c.cuda(), ops.aabb(tar)  # (a captured step works on GPU-resident arguments)
+    g = GraphedStep(lambda: L.Random_uniform_distribution_lines_batch_efficient_resample(
+        rg, cg, n, src, tar, "cuda", device_rng=True, out=buf, box2=box2))
+    g(); first = buf.clone()
+    g(); second = buf.clone()
+    assert not torch.equal(first, second)
+    ops.sampler_rng(seed=None)  # back to torch's seed for whoever comes next
+
+
 def test_box_accept_bit_exact(L, oracle):
     """Row F pinned: on IDENTICAL candidate lines the HIP accept test (rrl_box_accept: the sampler's own
     face table / face_hit / slab pre-test) gives the reference's per-box hit counts bit for bit --
