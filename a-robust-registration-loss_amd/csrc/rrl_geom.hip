@@ -561,6 +561,80 @@ extern "C" int rrl_adam_gated(float *p, const float *g, float *m, float *v, floa
     return 0;
 }
 
+// The pose side of one demo epoch in ONE launch (a single pose, one wave): d loss / d xi from (dL/dR, dL/dT) by the
+// dual-number exponential (== se3_exp_bwd_kernel), the gated Adam update of xi (== adam_gated_kernel, same
+// expressions in the same order), the exponential of the UPDATED xi into (R, T) for the next epoch (== se3_exp_kernel)
+// and the epoch's log row (== log_row_kernel).  As four launches these cost ~18 us of pure launch latency per epoch
+// on 6 floats; results are bit-identical to the four (tests/test_gpu_harness.py).
+__global__ __launch_bounds__(64) void se3_adam_step_kernel(float *__restrict__ xi, const float *__restrict__ gR,
+                                                           const float *__restrict__ gT, float *__restrict__ m,
+                                                           float *__restrict__ v, float *__restrict__ state,
+                                                           const float *__restrict__ lr,
+                                                           const int32_t *__restrict__ gate, float b1, float b2,
+                                                           float eps, float *__restrict__ R, float *__restrict__ T,
+                                                           float *__restrict__ gxi, const float *__restrict__ loss,
+                                                           const float *__restrict__ value, float *__restrict__ table,
+                                                           long long *__restrict__ cursor, long long nrows,
+                                                           float *__restrict__ row) {
+    const int k = threadIdx.x;
+    const bool ok = gate == nullptr || gate[0] > 0;
+    const float step = state[0] + (ok ? 1.0f : 0.0f);
+    float pk = k < 6 ? xi[k] : 0.0f;
+    if (k < 6) {
+        Dual x[6], r[9], t[3];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) x[i] = {xi[i], i == k ? 1.0f : 0.0f};
+        se3_exp3<Dual>(x, r, t);
+        float g = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) g += (gR ? gR[i] : 0.0f) * r[i].d;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) g += (gT ? gT[i] : 0.0f) * t[i].d;
+        if (gxi) gxi[k] = g;
+        if (ok) {
+            const float mi = m[k] * b1 + g * (1.0f - b1);
+            const float vi = v[k] * b2 + g * g * (1.0f - b2);
+            m[k] = mi;
+            v[k] = vi;
+            const float bias1 = 1.0f - powf(b1, step), bias2 = 1.0f - powf(b2, step);
+            const float denom = sqrtf(vi) / sqrtf(bias2) + eps;
+            pk = pk - (lr[0] / bias1) * mi / denom;
+            xi[k] = pk;
+        }
+    }
+    float xn[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) xn[i] = __shfl(pk, i);
+    if (k != 0) return;
+    state[0] = step;
+    float r[9], t[3];
+    se3_exp3<float>(xn, r, t);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R[i] = r[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) T[i] = t[i];
+    if (table && cursor) {
+        const long long at = cursor[0];
+        const float q[3] = {loss ? loss[0] : 0.0f, value ? value[0] : 0.0f, ok ? 1.0f : 0.0f};
+        for (int c = 0; c < 3; ++c) {
+            if (row) row[c] = q[c];
+            if (at >= 0 && at < nrows) table[at * 3 + c] = q[c];
+        }
+        cursor[0] = at + 1;
+    }
+}
+
+extern "C" int rrl_se3_adam_step(float *xi, const float *gR, const float *gT, float *m, float *v, float *state,
+                                 const float *lr, const int32_t *gate, float b1, float b2, float eps, float *R,
+                                 float *T, float *gxi, const float *loss, const float *value, float *table,
+                                 long long *cursor, long long nrows, float *row, void *stream) {
+    if (!xi || !m || !v || !state || !lr || !R || !T) return RRL_E_ARG;
+    hipLaunchKernelGGL(se3_adam_step_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, xi, gR, gT, m, v, state, lr,
+                       gate, b1, b2, eps, R, T, gxi, loss, value, table, cursor, nrows, row);
+    RRL_LAUNCH_CHECK();
+    return 0;
+}
+
 // One row of the demo's scalar log inside a captured step: table[cursor[0]] = (loss[0], value[0],
 // info[0] > 0), then cursor[0] += 1 -- as torch ops (cast, cat, index_copy_, add_) four launches.
 __global__ void log_row_kernel(const float *__restrict__ loss, const float *__restrict__ value,
@@ -662,6 +736,60 @@ extern "C" int rrl_aabb(const float *v, float *aabb, int B, int n, void *stream)
     if (!v || !aabb || B < 0 || n <= 0) return RRL_E_ARG;
     if (B == 0) return 0;
     hipLaunchKernelGGL(aabb_kernel, dim3((unsigned)B), dim3(1024), 0, (hipStream_t)stream, v, aabb, n);
+    RRL_LAUNCH_CHECK();
+    return 0;
+}
+
+// y = x R + t AND the AABB of y, one 1024-lane workgroup per sample: the demo's epoch needs both (the moved
+// cloud and, for the next epoch's line sampler, its box) and at its sizes (<= a few thousand points) each is
+// launch latency; rrl_rigid_apply_fwd's arithmetic, aabb_kernel's reduction.
+__global__ __launch_bounds__(1024) void rigid_aabb_kernel(const float *__restrict__ x, const float *__restrict__ R,
+                                                          const float *__restrict__ t, float *__restrict__ y,
+                                                          float *__restrict__ aabb, int n, int transpose_r) {
+    __shared__ float red[16][6];
+    const int b = blockIdx.x;
+    const Mat m = load_mat(R, t, b, transpose_r);
+    const size_t base = (size_t)b * n * 3;
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        float p[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) p[c] = x[base + 3 * (size_t)i + c];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const float s = fmaf(p[2], m.r[6 + j], fmaf(p[1], m.r[3 + j], p[0] * m.r[j])) + m.t[j];
+            y[base + 3 * (size_t)i + j] = s;
+            mn[j] = fminf(mn[j], s);
+            mx[j] = fmaxf(mx[j], s);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+        for (int o = 32; o > 0; o >>= 1) {
+            mn[c] = fminf(mn[c], __shfl_down(mn[c], o));
+            mx[c] = fmaxf(mx[c], __shfl_down(mx[c], o));
+        }
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            red[threadIdx.x >> 6][c] = mn[c];
+            red[threadIdx.x >> 6][3 + c] = mx[c];
+        }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        float r = red[0][threadIdx.x];
+        for (int w = 1; w < 16; ++w)
+            r = threadIdx.x < 3 ? fminf(r, red[w][threadIdx.x]) : fmaxf(r, red[w][threadIdx.x]);
+        aabb[b * 6 + threadIdx.x] = r;
+    }
+}
+
+extern "C" int rrl_rigid_apply_aabb(const float *x, const float *R, const float *t, float *y, float *aabb, int B,
+                                    int n, int transpose_r, void *stream) {
+    if (!x || !R || !t || !y || !aabb || B < 0 || n <= 0) return RRL_E_ARG;
+    if (B == 0) return 0;
+    hipLaunchKernelGGL(rigid_aabb_kernel, dim3((unsigned)B), dim3(1024), 0, (hipStream_t)stream, x, R, t, y, aabb, n,
+                       transpose_r);
     RRL_LAUNCH_CHECK();
     return 0;
 }

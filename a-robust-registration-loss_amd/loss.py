@@ -177,19 +177,20 @@ def Random_uniform_distribution_lines_batch_efficient(r, centers, N, device='cpu
 
 def Random_uniform_distribution_lines_batch_efficient_resample(r, centers, N, vertices1, vertices2,
                                                                device='cpu', *, rounds=10, device_rng=False,
-                                                               out=None, box2=None):
+                                                               out=None, box2=None, box1=None):
     """`rounds` (reference: 10) rejection rounds: a candidate is kept when it crosses the AABB
     of BOTH clouds by the reference's 12-triangle sub-area test; kept candidates fill an
     (B, N, 6) buffer front to back, overflow is dropped, unfilled rows stay all-zero
     (code/loss.py:415-432, 365-381).
     Keyword-only extras for loops that call this every step: out = a (B, N, 6) fp32 GPU tensor to
     fill in place, box2 = the (B, 6) AABB of `vertices2` from rrl_hip.ops.aabb when that cloud does
-    not move."""
+    not move (box1: the same for `vertices1`, e.g. from rrl_hip.ops.rigid_apply_aabb_into)."""
     B = r.shape[0]
     dev = _ops._home(out, vertices1, vertices2)  # the lines are built where the clouds live
     rands = _uniform_rounds(B, N, rounds, dev if device_rng else None, dev)
     bb2 = box2 if box2 is not None else _ops.aabb(vertices2)
-    lines, _ = _sample(rands, r, centers, _ops.aabb(vertices1), bb2, out, shape=(rounds, B, N))
+    bb1 = box1 if box1 is not None else _ops.aabb(vertices1)
+    lines, _ = _sample(rands, r, centers, bb1, bb2, out, shape=(rounds, B, N))
     return lines if out is not None else lines.to(device)
 
 

@@ -832,18 +832,31 @@ def box_accept(lines, aabb1, aabb2):
 
 
 _sampler_rng = {}  # device index -> int64[4] state of the library's generator (include/rrl.h rrl_sample_lines_rng)
+_sampler_key = {}  # device index -> (seed, offset) of torch's CUDA generator as this module left it
 
 
 def sampler_rng(dev=None, seed=None):
     """State of the library's own uniform generator for the line sampler on `dev` (Philox4x32-10 inside the sampler
-    kernels: [seed, call counter, ticket, 0]).  Created on first use from torch's default seed (torch.initial_seed(), i.e.
-    the last torch.manual_seed); seed=<int> re-seeds and rewinds it.  The counter lives on the device and is advanced by
-    every call, so a captured step replays a fresh stream each time with no host-side bookkeeping."""
+    kernels: [seed, call counter, ticket, 0]).  The counter lives on the device and is advanced by every call, so a
+    captured step replays a fresh stream each time with no host-side bookkeeping.
+    Seeding follows torch: the state is (re)created from torch's CUDA generator of `dev` -- its seed and offset --
+    whenever that generator is not where this module left it, i.e. after torch.manual_seed / torch.cuda.manual_seed
+    (the offset returns to 0) or after other GPU draws; each (re)seed moves the torch offset by 4 as its mark.  So
+    `torch.manual_seed(s)` followed by the same calls gives the same lines.  seed=<int> re-seeds explicitly.
+    (No check while the stream is capturing: a captured step keeps the state it was captured with.)"""
     dev = dev if dev is not None else require_gpu()
     st = _sampler_rng.get(dev.index)
+    if not (st is not None and torch.cuda.is_current_stream_capturing()):
+        g = torch.cuda.default_generators[dev.index]
+        key = (g.initial_seed(), g.get_offset())
+        if seed is not None or st is None or key != _sampler_key.get(dev.index):
+            if seed is None:
+                seed = (key[0] ^ (key[1] * 0x9E3779B97F4A7C15)) & 0xFFFFFFFFFFFFFFFF
+            g.set_offset(key[1] + 4)
+            _sampler_key[dev.index] = (key[0], key[1] + 4)
     if st is None or seed is not None:
-        sd = torch.initial_seed() if seed is None else int(seed)
-        new = torch.tensor([sd & 0x7FFFFFFFFFFFFFFF, 0, 0, 0], dtype=torch.int64, device=dev)
+        sd = int(seed) & 0x7FFFFFFFFFFFFFFF
+        new = torch.tensor([sd, 0, 0, 0], dtype=torch.int64, device=dev)
         if st is None:
             st = _sampler_rng[dev.index] = new
         else:
@@ -893,6 +906,27 @@ def rigid_apply_into(x, R, t, out, transpose_r=False):
     n = x.numel() // (3 * B)
     _run(x.device, "rrl_rigid_apply_fwd", _p(x), _p(Rm), _p(tv), _p(out), B, n, int(transpose_r), 0)
     return out
+
+
+def rigid_apply_aabb_into(x, R, t, out, box, transpose_r=False):
+    """out[...] = x R + t and box (B, 6) = the AABB of out, one launch (rrl_rigid_apply_aabb): x, out contiguous fp32
+    (B, n, 3) on the GPU."""
+    Rm, tv = _prep(R, "R", None, x.device).reshape(-1, 3, 3), _prep(t, "t", None, x.device).reshape(-1, 3)
+    B = Rm.shape[0]
+    n = x.numel() // (3 * B)
+    _run(x.device, "rrl_rigid_apply_aabb", _p(x), _p(Rm), _p(tv), _p(out), _p(box), B, n, int(transpose_r))
+    return out
+
+
+def se3_adam_step(xi, gR, gT, m, v, state, lr, gate, R, T, *, gxi=None, loss=None, value=None, table=None,
+                  cursor=None, row=None, betas=(0.9, 0.999), eps=1e-8):
+    """One pose's backward through the exponential, gated Adam step, exponential of the updated xi into (R, T) and
+    the log row, in one launch (rrl_se3_adam_step): all tensors contiguous fp32 on the GPU (cursor int64, gate int32),
+    xi (6,), R (.., 3, 3), T (.., 3)."""
+    nrows = 0 if table is None else table.shape[0]
+    _run(xi.device, "rrl_se3_adam_step", _p(xi), _p(gR), _p(gT), _p(m), _p(v), _p(state), _p(lr), _p(gate),
+         float(betas[0]), float(betas[1]), float(eps), _p(R), _p(T), _p(gxi), _p(loss), _p(value), _p(table),
+         _p(cursor), nrows, _p(row))
 
 
 def log_row(loss, value, info, table, cursor, row=None):

@@ -135,12 +135,12 @@ def _same_point_set(points, tri):
 def _default_lines(radius, centers, n_sample_line, target, device, device_rng=False):
     box2 = []  # the target does not move: its AABB is computed once
 
-    def draw(epoch, moved, out=None):
+    def draw(epoch, moved, out=None, box1=None):
         if not box2:
             box2.append(_ops.aabb(target.view(1, -1, 3)))
         lines = Random_uniform_distribution_lines_batch_efficient_resample(
             radius.reshape(1, 1), centers.reshape(1, -1), n_sample_line, moved.view(1, -1, 3),
-            target.view(1, -1, 3), device, device_rng=device_rng, out=out, box2=box2[0])
+            target.view(1, -1, 3), device, device_rng=device_rng, out=out, box2=box2[0], box1=box1)
         return lines.detach().view(-1, 6)
     return draw
 
@@ -223,26 +223,27 @@ def _run_graphed(model, draw, src, src_nb, tar, tar_tri, Save_path, writer, n_ep
     # triangles' first points (Sample_neighs keeps every point when the cloud has <= 5000: checked once, on the host).
     Rb = torch.empty(1, 3, 3, device=dev)
     Tb = torch.empty(1, 3, device=dev)
-    gxi = torch.empty(1, 6, device=dev)
+    box1 = _ops.aabb(moved)  # the moved cloud's AABB, kept current by the rigid-apply launch
     n_lines = lines.shape[1]
     reg = _ops.RegistrationStep(src_tri, tar_tri, n_lines, transpose_r=False)
     monitor_from_state = _same_point_set(src, src_tri) and _same_point_set(tar, tar_tri) and \
         max(src_tri.shape[1], tar_tri.shape[1]) <= 65536
     P = _ops._p
+    _ops._run(dev, "rrl_se3_exp", P(xi.data), P(Rb), P(Tb), 1)  # == model.Transform() for the first epoch
 
     def step():
-        # the whole epoch in ~17 launches: sampler (rand, AABB, 2 sample kernels), exp map, the loss's 5 + 1,
-        # exp-map backward, Adam, rigid apply, Chamfer (1 or 2), log row
+        # the whole epoch in 11 launches: sampler (2), the loss's 5 + 1, rigid apply + AABB, Chamfer, and the pose step
+        # (exp-map backward, Adam, the NEXT epoch's exp map == model.Transform(), the log row).  (Rb, Tb) always hold
+        # exp(xi): the pose launch refreshes them right after it moves xi.
         if draw_in_graph:  # lines from the previous epoch's moved source, like the reference loop
-            draw(0, moved.reshape(-1, 3), out=lines)
-        _ops._run(dev, "rrl_se3_exp", P(xi.data), P(Rb), P(Tb), 1)  # == model.Transform() (LieAlgebra.se3.exp3)
+            draw(0, moved.reshape(-1, 3), out=lines, box1=box1)
         loss, gR, gt, _, info = reg(Rb, Tb, lines)                  # forward + backward to (dL/dR, dL/dT)
-        _ops._run(dev, "rrl_se3_exp_bwd", P(xi.data), P(gR), P(gt), P(gxi), 1)
-        opt.update(gxi.view(-1), info)  # skipped on the device when no bucket is populated
-        _ops.rigid_apply_into(src_pts, Rb, Tb, moved)
+        _ops.rigid_apply_aabb_into(src_pts, Rb, Tb, moved, box1)
         cf = _ops.chamfer_from_state(reg.st) if monitor_from_state else _ops.chamfer(moved, tar_pts)
-        # loss, Chamfer, valid -> row (and, with the sampler in the graph, the trace table)
-        _ops.log_row(loss, cf.reshape(1), info, trace if draw_in_graph else scratch_row, slot, row)
+        # skipped on the device when no bucket is populated; loss, Chamfer, valid -> row (and, with the sampler in
+        # the graph, the trace table)
+        _ops.se3_adam_step(xi.data, gR, gt, opt.m, opt.v, opt.step, opt.lr, info, Rb, Tb, loss=loss,
+                           value=cf.reshape(1), table=trace if draw_in_graph else scratch_row, cursor=slot, row=row)
         return row
 
     lr = 2e-2
@@ -256,7 +257,7 @@ def _run_graphed(model, draw, src, src_nb, tar, tar_tri, Save_path, writer, n_ep
         lr = new_lr
         if stepper is None:
             # the warm-up runs inside GraphedStep must not move the state: snapshot, restore
-            state = (xi.data, opt.m, opt.v, opt.step, moved, slot)
+            state = (xi.data, opt.m, opt.v, opt.step, moved, slot, Rb, Tb, box1)
             keep = [t.clone() for t in state]
             slot.fill_(n_epoch)  # warm-up rows land in the scratch rows
             stepper = GraphedStep(step, warmup=WARM)

@@ -306,6 +306,16 @@ int rrl_adam_gated(float *p, const float *g, float *m, float *v, float *state, c
 int rrl_log_row(const float *loss, const float *value, const int32_t *info, float *table,
                 long long *cursor, long long nrows, float *row, void *stream);
 
+/* The pose side of one epoch of the demo loop (code/test_demo_optimized_Lie_Algebra.py:55-82: backward through
+ * model.Transform(), optimizer.step(), the next epoch's Transform(), the printed/logged scalars) for ONE pose in one
+ * launch: gxi = d/dxi <gR, R(xi)> + <gT, T(xi)> (rrl_se3_exp_bwd), the gated Adam step on xi (rrl_adam_gated),
+ * (R, T) = exp(updated xi) (rrl_se3_exp) and, when table and cursor are given, the log row (rrl_log_row with
+ * info = gate).  Bit-identical to the four calls.  gxi, loss, value, table, cursor, row may be NULL. */
+int rrl_se3_adam_step(float *xi, const float *gR, const float *gT, float *m, float *v, float *state,
+                      const float *lr, const int32_t *gate, float b1, float b2, float eps, float *R, float *T,
+                      float *gxi, const float *loss, const float *value, float *table, long long *cursor,
+                      long long nrows, float *row, void *stream);
+
 /* ---- Chamfer monitor (code/loss.py:38-52, 236-252) -------------------------------------- */
 /* best_x [B][N], best_y [B][M] are u64 keys (dist bits << 32 | argmin), set to all-ones by
  * the call itself.  value[0] = mean of all B*(N+M) minima. */
@@ -363,6 +373,10 @@ int rrl_dense_scan(const float *tri, const float *line, float *norm_d, uint8_t *
  *   tile_counts: scratch, 8-byte aligned, int32 [B * rounds * ceil(n/1024) * 32] (one 64-bit accept
  *     ballot per wavefront of every tile of 1024 candidates) */
 int rrl_aabb(const float *v, float *aabb, int B, int n, void *stream);
+/* y = x R + t (rrl_rigid_apply_fwd, row layout) and aabb [B][6] of y (rrl_aabb) in one launch, one workgroup per
+ * sample: for loops whose clouds are small enough that either is launch latency (the demo's epoch). */
+int rrl_rigid_apply_aabb(const float *x, const float *R, const float *t, float *y, float *aabb, int B, int n,
+                         int transpose_r, void *stream);
 /* The resampler's accept test on caller-supplied lines (code/loss.py:265-322, 415-432: label1 * label2):
  * lines [B][n][6], aabb1/aabb2 [B][6] -> mask [B][n] (bit 0: the line crosses >= 1 of the 12 triangles
  * of box 1 by the reference's sub-area test; bit 1: same for box 2 -- accepted == both; bit 2: the
