@@ -62,11 +62,11 @@
 // record carries c in place of thr2) and takes its SIGN BIT (one v_alignbit per record), 11 operations:
 //   |fl(Q) - Q| <= 14.2 u |a|^2 + 4 u |c|   (a rounded once; three-term FMA chains; |d| ~ 1)
 //   hit  =>  Q < thr2 - 2e-4 + 30 u |a|^2                                   (as above)
-//   c = -(T' + 1e-6 |T'| + s0),  T' = fl(thr2 - 2e-4),  s0 = 3e-6 A_wg^2 + 1e-9  (3e-6 = 50.3 u)
+//   c = -(T' + 1e-6 |T'| + s0),  T' = fl(thr2 - 2e-4),  s0 = 3e-6 A^2 + 1e-9  (3e-6 = 50.3 u)
 // so a hit always gives e < 0: the 1e-6 |T'| covers the rounding of T' and 4 u |c|, 50.3 u A^2 covers
-// 44.2 u |a|^2 (|a| <= A), and the floor covers u 4e-4 when everything sits at the origin.  A_wg^2 and the
-// node slack se are the maxima over the lines of the workgroup's culled wavefronts (the staged records and
-// nodes are shared).  e < 0 only PARKS the triangle; whether it is a hit is decided by the exact arithmetic
+// 44.2 u |a|^2 (|a| <= A), and the floor covers u 4e-4 when everything sits at the origin.  A^2 and the
+// node slack se are evaluated at the SAMPLE's line maxima (LMAX, from the records kernel: cull_cloud_slack),
+// identically in every wavefront of the launch.  e < 0 only PARKS the triangle; whether it is a hit is decided by the exact arithmetic
 // in resolve_candidate, so a false candidate costs time, never a label.
 //
 // NaN (negative sqrt argument; the reference prints and exits, code/loss.py:88-91): provably
@@ -77,13 +77,15 @@
 //   p(P_k) < se (|d| > 1) with the line's own se = sqrt(g + x)  =>  (1-Lipschitz, |P_k - P0| <= e01_f =
 //   max(|P1-P0|, |P2-P0|))  the same function of P0 is < se + e01_f, hence Q(P0) < (se + e01_f)^2, and of the
 //   centre of any sphere that bounds the triangle's P0: < rho + se + max e01.
-// The records kernel stores del_f >= e01_f - thr_f (clamped at 0, DEL1 / DEL2); a workgroup that holds a
-// wavefront with g > 0 ("nanwide") gathers del for its 512 staged records, widens every staged node radius
-// by the node's max del (rho + e01 <= rho + thr_max + max del <= Rs + max del) and the prefilter constant of
-// every record to max(thr2 - 2e-4, (se + sqrt(thr2) + del_f)^2) (+ the same evaluation slack): a triangle
-// whose point 0, 1 or 2 could see a negative argument is then a prefilter candidate, resolve_candidate
-// evaluates its three points with the reference's arithmetic and raises STATUS[0].  Unit-scale data never
-// takes this branch (one uniform test per workgroup); at the demo's scale it costs ~15 % more node passes.
+// The records kernel stores del_f >= e01_f - thr_f (clamped at 0, DEL1 / DEL2); a workgroup of a (cloud, sample)
+// with g > 0 ("nanwide") gathers del for its 512 staged records (requested while the lines are still in flight),
+// widens every staged node radius by the node's max del (rho + e01 <= rho + thr_max + max del <= Rs + max del;
+// the values meet in LDS, one more barrier) and the prefilter constant of every record to
+// max(thr2 - 2e-4, (se + sqrt(thr2) + del_f)^2) (+ the same evaluation slack): a triangle whose point 0, 1 or 2
+// could see a negative argument is then a prefilter candidate, resolve_candidate evaluates its three points with
+// the reference's arithmetic and raises STATUS[0].  Unit-scale data never takes this branch (one uniform test
+// per workgroup).  At the demo's scale (diagonal 11.7) it costs 13.0 -> 16.4 us at C1 and 32.7 -> 42.2 at C2,
+// in three similar parts: the ring thr -> thr + se, the reach del, and the dependent gather + barrier.
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -1019,8 +1021,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(6, 8))
     __shared__ __attribute__((aligned(16))) unsigned short qa_lds[WPB][QA_CAP];
     __shared__ unsigned short qc_lds[WPB][QC_CAP];
     __shared__ __attribute__((aligned(16))) unsigned cands_lds[WPB][WCCAP];
-    static_assert(WPB * WCCAP >= SPW * SGT && WPB * QA_CAP * sizeof(unsigned short) >= SPW * NODE * sizeof(float),
-                  "the NaN-reach scratch aliases the (still unused) candidate and level-A queue buffers");
+    static_assert(WPB * WCCAP >= SPW * SGT, "the NaN-reach scratch aliases the (still unused) candidate buffers");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform for the compiler
     const unsigned long long wall0 = COUNT ? wall_clock64() : 0ull;
@@ -1047,14 +1048,15 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(6, 8))
     constexpr int RPT = (SPW * SGT + 64 * WPB - 1) / (64 * WPB);  // records per lane of a full workgroup
     static_assert(SPW * NODE <= 64 * WPB, "one node per lane");
     const bool one_each = (int)blockDim.x == 64 * WPB;
+    const int32_t *idx = (cloud ? idx2 : idx1) + (size_t)b * nsg * SGT;
     float4 rec0[RPT], nd0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    static_assert(LMAX_CHUNKS == 64, "one partial row per lane");
     if (one_each) {
 #pragma unroll
         for (int k = 0; k < RPT; ++k)
             if (tid + 64 * WPB * k < nsl * SGT) rec0[k] = p0s[(size_t)sg0 * SGT + tid + 64 * WPB * k];
         if (tid < nsl * NODE) nd0 = tree[(size_t)sg0 * NODE + tid];
     }
-    static_assert(LMAX_CHUNKS == 64, "one partial row per lane");
     const float2 lm = lmax[(size_t)b * LMAX_CHUNKS + lane];  // (max |dir|^2, max |x0|^2) over 1/64 of the sample's cullable lines
     const float pm = __uint_as_float(pmax[cloud * B + b]);
 
@@ -1066,18 +1068,12 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(6, 8))
     const bool live0 = l0 < L, live1 = l1 < L;
     const bool has_lines = lw0 < L;  // a wave without lines (the last tile of the line set) still stages records
     float2 *lr = line_lds[wave];
-    if (has_lines) {
-        const float *lsrc = ln + (size_t)lw0 * 6;
-        if (lw0 + LPW <= L && (((uintptr_t)lsrc) & 15) == 0) {  // uniform
-            const float4 *s4 = (const float4 *)lsrc;
-            float4 *d4 = (float4 *)lr;
-            const float4 t0 = s4[lane], t1 = s4[64 + lane], t2 = s4[128 + lane];
-            d4[lane] = t0; d4[64 + lane] = t1; d4[128 + lane] = t2;
-        } else {  // ragged tail / odd alignment: 8-byte pieces (a row is 24 bytes), zeros past the end
-            const float2 *s2 = (const float2 *)lsrc;
-            const int nf2 = (L - lw0) * 3;
-            for (int i = lane; i < LPW * 3; i += 64) lr[i] = i < nf2 ? s2[i] : make_float2(0.0f, 0.0f);
-        }
+    const float *lsrc = ln + (size_t)lw0 * 6;
+    const bool full_tile = has_lines && lw0 + LPW <= L && (((uintptr_t)lsrc) & 15) == 0;  // uniform
+    float4 t0, t1, t2;
+    if (full_tile) {
+        const float4 *s4 = (const float4 *)lsrc;
+        t0 = s4[lane]; t1 = s4[64 + lane]; t2 = s4[128 + lane];
     }
 
     // ---- slack of this (cloud, sample): the same values in every wavefront and workgroup (no exchange, no barrier)
@@ -1085,6 +1081,24 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(6, 8))
     const CloudSlack cs = cull_cloud_slack(smax, o2max, pm);
     const float se = cs.se, s0 = cs.s0;
     const bool nanwide = cs.nanwide;  // uniform over the launch's workgroups of this cloud and sample
+    // nanwide (header, "NaN"): the NaN reach del of this lane's records, requested while the lines are still in flight
+    float dv[RPT];
+    if (nanwide && one_each) {
+        const float *del = (cloud ? del2 : del1) + (size_t)b * n;
+        int idx0[RPT];
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) idx0[k] = tid + 64 * WPB * k < nsl * SGT ? idx[sg0 * SGT + tid + 64 * WPB * k] : 0;
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) dv[k] = sg0 * SGT + tid + 64 * WPB * k < n ? del[idx0[k]] : 0.0f;
+    }
+    if (full_tile) {
+        float4 *d4 = (float4 *)lr;
+        d4[lane] = t0; d4[64 + lane] = t1; d4[128 + lane] = t2;
+    } else if (has_lines) {  // ragged tail / odd alignment: 8-byte pieces (a row is 24 bytes), zeros past the end
+        const float2 *s2 = (const float2 *)lsrc;
+        const int nf2 = (L - lw0) * 3;
+        for (int i = lane; i < LPW * 3; i += 64) lr[i] = i < nf2 ? s2[i] : make_float2(0.0f, 0.0f);
+    }
 
     wave_lds_fence();
     float v0[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}, v1[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
@@ -1102,38 +1116,34 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(6, 8))
     const bool fallback = !cs.ok || !__all(line_cullable(sa, oa) && line_cullable(sb, ob));
     unsigned long long fb_pairs = 0;
 
-    const int32_t *idx = (cloud ? idx2 : idx1) + (size_t)b * nsg * SGT;
     const float *ptri = (cloud ? ptri2 : ptri1) + (size_t)b * n * PTRI_STRIDE;
     int32_t *cnt = (cloud ? count2 : count1) + (size_t)b * L;
     int32_t *hit = (cloud ? hit2 : hit1) + (size_t)b * L * RRL_MAX_HITS;
 
-    // nanwide (header, "NaN"): the NaN reach del of the slice's records and its maxima over the nodes, through
-    // buffers the walk does not use yet
+    // nanwide: the slice's del values meet in LDS (a buffer the walk does not use yet) so that every node lane can
+    // take the maximum over ITS records -- one more barrier, only on this path
     float *dl = (float *)&cands_lds[0][0];  // [SPW * SGT]
-    float *dn = (float *)&qa_lds[0][0];     // [SPW * NODE]
     if (nanwide) {
-        const float *del = (cloud ? del2 : del1) + (size_t)b * n;
-        for (int i = tid; i < nsl * SGT; i += blockDim.x) {
-            const int sp = sg0 * SGT + i;
-            dl[i] = sp < n ? del[idx[sp]] : 0.0f;
-        }
-        __syncthreads();
-        for (int i = tid; i < nsl * NODE; i += blockDim.x) {  // node j of supergroup sg: [0] all 64, [1..4] 16 each, [5..12] 8 each
-            const int sg = i / NODE, j = i - sg * NODE;
-            const int o = j == 0 ? 0 : (j < 5 ? (j - 1) * GRP : (j - 5) * (GRP / 2)), cnt_ = j == 0 ? SGT : (j < 5 ? GRP : GRP / 2);
-            float m = 0.0f;
-            for (int t = 0; t < cnt_; ++t) m = fmaxf(m, dl[sg * SGT + o + t]);
-            dn[i] = m;
+        if (one_each) {
+#pragma unroll
+            for (int k = 0; k < RPT; ++k)
+                if (tid + 64 * WPB * k < nsl * SGT) dl[tid + 64 * WPB * k] = dv[k];
+        } else {
+            const float *del = (cloud ? del2 : del1) + (size_t)b * n;
+            for (int i = tid; i < nsl * SGT; i += blockDim.x) {
+                const int sp = sg0 * SGT + i;
+                dl[i] = sp < n ? del[idx[sp]] : 0.0f;
+            }
         }
         __syncthreads();
     }
     // ---- stage the slice: records (padded rows) and tree nodes, slacks folded in
     //   (P0, thr2) -> (P0, c): c = -(thr2 - 2e-4 + slack), slightly widened; pad records never pass
     //   (centre, Rs) -> (centre, (Rs + se)^2 rounded up); an empty node (NaN radius) -> -inf: fails by its sign
-    auto stage_rec = [&](int i, float4 r) {
+    auto stage_rec = [&](int i, float4 r, float d) {
         float tp = r.w - RRL_EPS;
         if (nanwide) {  // also a candidate when point 1 or 2 could see a negative argument: Q(P0) < (se + e01)^2
-            const float reach = se + sqrtf(r.w) * 1.000001f + dl[i];  // e01 <= thr + del <= sqrt(thr2) + del
+            const float reach = se + sqrtf(r.w) * 1.000001f + d;  // e01 <= thr + del <= sqrt(thr2) + del
             tp = fmaxf(tp, reach * reach * 1.000002f);
         }
         r.w = sg0 * SGT + i < n ? -(tp + 1.0e-6f * fabsf(tp) + s0) : INFINITY;
@@ -1141,7 +1151,17 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(6, 8))
     };
     auto stage_node = [&](int i, float4 nd) {
         float rt = nd.w + se;
-        if (nanwide) rt += dn[i];
+        if (nanwide) {  // node j of supergroup sg covers the records [0] all 64, [1..4] 16 each, [5..12] 8 each
+            const int sg = i / NODE, j = i - sg * NODE;
+            const int o = j == 0 ? 0 : (j < 5 ? (j - 1) * GRP : (j - 5) * (GRP / 2)), c4 = j == 0 ? SGT / 4 : (j < 5 ? GRP / 4 : GRP / 8);
+            const float4 *q = (const float4 *)(dl + sg * SGT + o);  // 32-byte aligned
+            float m = 0.0f;
+            for (int t = 0; t < c4; ++t) {
+                const float4 v = q[t];
+                m = fmaxf(m, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
+            }
+            rt += m;
+        }
         const float w = rt * rt * 1.0000003f;
         nd.w = w == w ? w : -INFINITY;
         node_lds[i] = nd;
@@ -1149,10 +1169,10 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(6, 8))
     if (one_each) {
 #pragma unroll
         for (int k = 0; k < RPT; ++k)
-            if (tid + 64 * WPB * k < nsl * SGT) stage_rec(tid + 64 * WPB * k, rec0[k]);
+            if (tid + 64 * WPB * k < nsl * SGT) stage_rec(tid + 64 * WPB * k, rec0[k], nanwide ? dv[k] : 0.0f);
         if (tid < nsl * NODE) stage_node(tid, nd0);
     } else {
-        for (int i = tid; i < nsl * SGT; i += blockDim.x) stage_rec(i, p0s[(size_t)sg0 * SGT + i]);
+        for (int i = tid; i < nsl * SGT; i += blockDim.x) stage_rec(i, p0s[(size_t)sg0 * SGT + i], nanwide ? dl[i] : 0.0f);
         for (int i = tid; i < nsl * NODE; i += blockDim.x) stage_node(i, tree[(size_t)sg0 * NODE + i]);
     }
     __syncthreads();  // the one barrier of the (usual) prologue
