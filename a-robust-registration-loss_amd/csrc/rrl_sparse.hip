@@ -77,7 +77,7 @@ __device__ __forceinline__ void pair_hit(const float *__restrict__ tri1, const f
                                          float *__restrict__ dc_slot, float4 *s_q /* LDS [8] of this line */,
                                          unsigned *s_mh /* LDS [2048] or NULL */,
                                          int b, int N, int M, size_t gl, int k, int j, int sub, int st1,
-                                         int st2) {
+                                         int st2, float *t2 /* out: this lane's two tile entries (+inf: outside the block) */) {
     const int cloud = sub >> 2, a = sub & 3;
     const int cnt = cloud ? j : k;
     float q[3] = {0.0f, 0.0f, 0.0f};
@@ -111,7 +111,6 @@ __device__ __forceinline__ void pair_hit(const float *__restrict__ tri1, const f
     s_q[sub] = make_float4(q[0], q[1], q[2], 0.0f);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the 8 lanes share a wavefront: LDS is in order
     // D[a][b] = sum_c (q1 - q2)^2, code/loss.py:38-52: entries 2 sub and 2 sub + 1 of the 4 x 4 tile
-    float t2[2];
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
         const int ee = 2 * sub + e, ra = ee >> 2, rb = ee & 3;
@@ -140,6 +139,9 @@ struct PairArgs {
     float4 *Q1, *Q2;
     float *D, *dc;
     uint8_t *kjc;
+    uint32_t *lidc;          // line | kj << 24 at the compact slot (or NULL)
+    float *vlist;            // [B][ntile][16384] dense list of the tile's valid D values (with mhist; or NULL)
+    int32_t *vlcnt;
     int32_t *blkcnt;
     uint32_t *mhist, *mctl;  // tiled reduce: per-sample histogram of the D values' top 11 bits, bucket counts (or NULL)
     int B, N, M, L, s_m, s_n, e_m, e_n, st1, st2;
@@ -155,6 +157,7 @@ __device__ __forceinline__ void pair_body(const PairArgs &a, int b, int tile, in
     __shared__ float4 s_q[128][8];  // intersection points of the lines of one pass
     __shared__ unsigned s_mh[2048];  // this tile's share of MHIST
     __shared__ unsigned s_bc[16];    // ... and of the bucket counts
+    __shared__ unsigned s_nv;        // ... and the length of its value list
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int L = a.L;
     int base_reg = 0;
@@ -163,6 +166,7 @@ __device__ __forceinline__ void pair_body(const PairArgs &a, int b, int tile, in
         s_mh[tid] = 0u;
         s_mh[tid + 1024] = 0u;
         if (tid < 16) s_bc[tid] = 0u;
+        if (tid == 0) s_nv = 0u;
     }
     {
         const int l = tile * 1024 + tid;
@@ -200,16 +204,33 @@ __device__ __forceinline__ void pair_body(const PairArgs &a, int b, int tile, in
     const size_t Lp = (size_t)ntile * 1024;
     const int total = s_total;
     if (tid == 0) a.blkcnt[(size_t)b * ntile + tile] = total;
+    float *vl = tally && a.vlist ? a.vlist + ((size_t)b * ntile + tile) * 16384 : nullptr;
     for (int r0 = 0; r0 < total; r0 += 128) {  // 128 selected lines per pass, 8 lanes each
         const int rank = r0 + (tid >> 3), sub = tid & 7;
+        float t2[2] = {INFINITY, INFINITY};
+        unsigned nvl = 0;  // this lane's entries inside the line's k x j block
         if (rank < total) {
             const unsigned e = (unsigned)s_list[rank];
             const int l = (int)(e & 0xffffffu), k = (int)((e >> 24) & 15u), j = (int)(e >> 28);
             const size_t gl = (size_t)b * L + l;
             const size_t slot = (size_t)b * Lp + (size_t)tile * 1024 + rank;
-            if (sub == 0) a.kjc[slot] = (uint8_t)(k | (j << 4));
+            if (sub == 0) {
+                a.kjc[slot] = (uint8_t)(k | (j << 4));
+                if (a.lidc) a.lidc[slot] = e;
+            }
             pair_hit(a.tri1, a.tri2, a.line, a.hit1, a.hit2, a.hs1, a.hs2, a.w1, a.w2, a.Q1, a.Q2, a.D, a.dc + slot * 16,
-                     s_q[tid >> 3], tally ? s_mh : nullptr, b, a.N, a.M, gl, k, j, sub, a.st1, a.st2);
+                     s_q[tid >> 3], tally ? s_mh : nullptr, b, a.N, a.M, gl, k, j, sub, a.st1, a.st2, t2);
+            nvl = (((2 * sub) >> 2) < k && ((2 * sub) & 3) < j ? 1u : 0u) | (((2 * sub + 1) >> 2) < k && ((2 * sub + 1) & 3) < j ? 2u : 0u);
+        }
+        if (vl) {  // (all lanes: uniform) the valid entries join the tile's dense value list: one LDS cursor atomic per wavefront
+            const unsigned mine = (nvl & 1u) + (nvl >> 1);
+            const unsigned incl = (unsigned)wave_incl_scan((int)mine);
+            unsigned wbase = 0;
+            if (lane == 63 && incl) wbase = atomicAdd(&s_nv, incl);
+            wbase = (unsigned)__builtin_amdgcn_readlane((int)wbase, 63);
+            unsigned at = wbase + incl - mine;
+            if (nvl & 1u) vl[at++] = t2[0];
+            if (nvl & 2u) vl[at] = t2[1];
         }
     }
     if (tally) {  // flush the tile's tallies: <= one device atomic per populated bin and workgroup
@@ -221,6 +242,11 @@ __device__ __forceinline__ void pair_body(const PairArgs &a, int b, int tile, in
             if (v) atomicAdd(&mh[tid + 1024 * q], v);
         }
         if (tid < 16 && s_bc[tid]) atomicAdd(&a.mctl[(size_t)b * 64 + tid], s_bc[tid]);
+        if (vl) {  // the list's length; padded with -1 (no D value is negative) to whole 16-byte groups
+            const unsigned nv = s_nv;
+            if (tid == 0) a.vlcnt[(size_t)b * ntile + tile] = (int)nv;
+            if (tid < ((4u - (nv & 3u)) & 3u)) vl[nv + tid] = -1.0f;
+        }
     }
     if (wave == 0) {
         const int base = __builtin_amdgcn_readfirstlane(base_reg);
@@ -249,24 +275,31 @@ static PairArgs pair_args(const float *tri2_raw, const float *line, void *ws, co
     a.Q1 = (float4 *)w.f32(ws, RRL_WS_Q1); a.Q2 = (float4 *)w.f32(ws, RRL_WS_Q2);
     a.D = w.f32(ws, RRL_WS_D); a.dc = w.f32(ws, RRL_WS_VALS);
     a.kjc = w.u8(ws, RRL_WS_KJC); a.blkcnt = w.i32(ws, RRL_WS_BLKCNT);
+    a.lidc = w.u32(ws, RRL_WS_LIDC);
+    a.vlist = w.f32(ws, RRL_WS_VLIST); a.vlcnt = w.i32(ws, RRL_WS_VLCNT);
     a.B = B; a.N = N; a.M = M; a.L = L;
     a.s_m = s_m; a.s_n = s_n; a.e_m = e_m; a.e_n = e_n;
     a.st1 = PTRI_STRIDE; a.st2 = tri2_raw ? 9 : PTRI_STRIDE;
     return a;
 }
 
+static int reduce_kind(int B, int nblk, int pool, bool with_bwd);
+
 // tri2_raw != NULL: the target's prepared records are not in this workspace (its scan was carried
-// over from another one): read its raw rows instead
+// over from another one): read its raw rows instead.  with_bwd: the reduce that follows will carry the direct backward
+// (rrl_registration_step) -- it decides, with the shape, whether the tail kernel runs and wants the dense value lists
 static int line_pair_dist_impl(const float *tri2_raw, const float *line, void *ws, size_t ws_bytes, int B,
                                int N, int M, int L, int s_m, int s_n, int e_m, int e_n, int pool,
-                               void *stream) {
+                               void *stream, bool with_bwd = false) {
     if (!line || !ws || B < 0 || N < 0 || M < 0 || L < 0 || L >= (1 << 24)) return RRL_E_ARG;  // 24-bit line ids in LDS
     if (s_m < 1 || s_n < 1 || e_m > RRL_MAX_HITS + 1 || e_n > RRL_MAX_HITS + 1) return RRL_E_RANGE;
     WsLayout w(B, N, M, L);
     if (ws_bytes < w.total) return RRL_E_WS;
     if (B == 0 || L == 0) return 0;
+    PairArgs pa = pair_args(tri2_raw, line, ws, w, B, N, M, L, s_m, s_n, e_m, e_n);
+    if (reduce_kind(B, (L + 1023) / 1024, pool, with_bwd) != 2) pa.vlist = nullptr;  // only the tail kernel reads VLIST
     hipLaunchKernelGGL(line_pair_dist_kernel, dim3((unsigned)((L + 1023) / 1024), (unsigned)B), dim3(1024), 0,
-                       (hipStream_t)stream, pair_args(tri2_raw, line, ws, w, B, N, M, L, s_m, s_n, e_m, e_n));
+                       (hipStream_t)stream, pa);
     RRL_LAUNCH_CHECK();
     return 0;
 }
@@ -1028,6 +1061,460 @@ __global__ __launch_bounds__(256) void loss_reduce_tiled_kernel(const TiledArgs 
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// K3 + K4 (+ K5') "tail" kernel (round 3): the tiled reduce WITHOUT the exchange, and optionally the direct
+// backward of the fused training op in the same launch.
+// loss_reduce_tiled_kernel lets the workgroups of a sample exchange the median bin's values (cursor atomic,
+// write-through stores, arrival counter, poll, read-back: four to five dependent cross-workgroup round trips).
+// Here every live workgroup reads ALL compact D tiles of its sample itself -- they sit in the L2 (57 KB per
+// sample at C2, 168 KB at the demo's shape) -- filters the bin's values into its own LDS and selects the median
+// alone: the same bits in every workgroup, nobody waits for anybody.  What remains shared is order-independent:
+// the fixed-point bucket sums (MSUM) and ONE arrival counter whose last arriver turns them into the loss.
+// Geometry: a workgroup = 512 lanes = up to TAIL_LINES (64) selected lines of one 1024-line tile (16 workgroups
+// per tile in the grid; those beyond the tile's count return at once, like loss_bwd_rt_kernel's): the per-line
+// arithmetic is exp-heavy (~1200 instructions per lane), and more lines per compute unit would queue on its SIMDs
+// (1024-lane workgroups with a whole tile each: 5.6 us in this phase instead of ~2).  Lanes 256 .. 511 only help
+// to stream and to pick the bin.
+// do_bwd: the gradient of the workgroup's lines to (dL/dR, dL/dt) needs the median, the bucket counts (known
+// since the per-line stage: MCTL) and dL/dloss (an input) -- not the loss -- so it runs in the same workgroup:
+// its chain of dependent loads (compact slot -> line -> Q1 / Q2 / hit / weights -> source triangle) is requested
+// at the START of the kernel and is in flight while the median is found (the LDS-only barriers below do not
+// drain vector memory).  As separate launches the reduce and the backward cost 11.2 + 8.3 us at C2.
+// payload[0 .. 1] (sum of the valid losses, their number) without a last-of-all hand-over: every sample's
+// finaliser adds its loss to a 2^-40 fixed-point sum (returning atomic) and offers float(sum so far) to
+// payload[0] by an unsigned atomicMax on the bit pattern -- the partial sums are monotone (losses >= 0), so the
+// maximum is the complete sum, independent of the order; a NaN loss offers the (larger) NaN pattern.
+// Same arithmetic and summation rules as reduce_body / loss_bwd_rt_kernel: bit-identical median and loss;
+// (dR, dt) up to the order of the float atomics, as before; payload[0] may differ from the two-call path's
+// double-precision sum in its last bit.
+// ---------------------------------------------------------------------------------------
+#define TAIL_MAX_TILES 32
+#define TAIL_LANES 512
+#define TAIL_LINES 64  // selected lines per workgroup (four lanes each)
+#define TAIL_SUBS 4    // workgroups per tile (grid z): workgroup s takes the tile's chunks s, s + 4, ... of TAIL_LINES lines
+#define TAIL_RPL 4     // compact rows per lane and streaming round
+#define MCTL_LSUM 34   // (row of sample 0, 8-byte aligned) uint64: fixed-point sum of the valid samples' losses
+
+struct TailArgs {
+    const uint32_t *lidc;
+    const float *dc;
+    const float *vlist;
+    const int32_t *vlcnt;
+    const int32_t *blkcnt;
+    const uint32_t *mhist;
+    uint32_t *mctl;
+    unsigned long long *msum;
+    float *med_out;
+    int32_t *bcnt_out;
+    int64_t *bsum_out;
+    int32_t *info;
+    float *loss;
+    const int32_t *status;
+    int B, nblk, s_m, s_n, e_m, e_n;
+    int do_bwd, N, L, transpose_r;
+    const int32_t *hs1;
+    const float *w1;
+    const float4 *Q1, *Q2;
+    const float *grad_loss, *src;
+    float *gR, *gt, *payload;
+};
+
+// LDS-only workgroup barrier: this wavefront's LDS traffic is complete, its vector-memory loads stay in flight
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// one sample's final loss into payload[0 .. 1] (header); one lane
+__device__ __forceinline__ void tail_payload(const TailArgs &a, float lv) {
+    atomicAdd(&a.payload[1], 1.0f);
+    if (lv != lv) { atomicMax((unsigned *)&a.payload[0], 0x7fc00000u); return; }
+    const unsigned long long mine = (unsigned long long)((double)lv * (double)(1ll << FIX_SHIFT) + 0.5);
+    const unsigned long long old = __hip_atomic_fetch_add((unsigned long long *)(a.mctl + MCTL_LSUM), mine, __ATOMIC_RELAXED,
+                                                          __HIP_MEMORY_SCOPE_AGENT);
+    const float tot = (float)((double)(old + mine) * (1.0 / (double)(1ll << FIX_SHIFT)));
+    atomicMax((unsigned *)&a.payload[0], __float_as_uint(tot));
+}
+
+__global__ __launch_bounds__(TAIL_LANES) void loss_tail_kernel(const TailArgs a) {
+    __shared__ unsigned s_vals[MCAND_CAP];  // the bin's values (usual route) / histogram of the streaming passes
+    __shared__ unsigned s_wtot[TAIL_LANES / 64];
+    __shared__ unsigned s_pick[3];          // bin, rank inside it, its population
+    __shared__ unsigned s_whist[128];
+    __shared__ unsigned long long s_sum[32];
+    __shared__ unsigned s_flag[2];          // [0] this workgroup arrived last, [1] non-finite Welsch term (bit 0 own, bit 1 anyone's)
+    __shared__ unsigned s_med, s_ncand;
+    __shared__ float s_term[16];
+    __shared__ int s_cnt[16];
+    __shared__ int s_pref[TAIL_MAX_TILES + 1];
+    __shared__ int s_vpref[TAIL_MAX_TILES + 1];  // prefix of the tiles' value lists, in 16-byte groups
+    __shared__ float s_red[4][12];
+    constexpr int NW = TAIL_LANES / 64, BPL = 2048 / TAIL_LANES;  // wavefronts; histogram bins per lane
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // (sub is the SLOW grid index: the workgroups that certainly have lines are dispatched first)
+    const int tile = blockIdx.x, sub = blockIdx.z, b = blockIdx.y, nblk = a.nblk;
+    const size_t Lp = (size_t)nblk * 1024;
+    uint32_t *ctl = a.mctl + (size_t)b * 64;
+    const float *__restrict__ dc = a.dc;
+    const uint32_t *__restrict__ lidc = a.lidc;
+    const size_t slot0 = (size_t)b * Lp + (size_t)tile * 1024;
+    const bool do_bwd = a.do_bwd != 0;  // uniform
+
+    // ---- round 1: the sample's tile counts, histogram and bucket counts; the compact tile of "this lane's" line
+    //      (lanes 0 .. 255, four per line: lane h of line r adds hit slot h's gradient, lane 0 the line's Welsch terms)
+    const int mycnt = a.blkcnt[(size_t)b * nblk + tile];
+    if (sub * TAIL_LINES >= mycnt && !(tile == 0 && sub == 0)) return;  // uniform: no line for this workgroup
+    const int bc = tid < nblk ? a.blkcnt[(size_t)b * nblk + tid] : 0;
+    const int vc = tid < nblk ? (a.vlcnt[(size_t)b * nblk + tid] + 3) >> 2 : 0;
+    unsigned hb[BPL];
+    {
+        const uint4 hq = ((const uint4 *)(a.mhist + (size_t)b * 2048))[tid];
+        hb[0] = hq.x; hb[1] = hq.y; hb[2] = hq.z; hb[3] = hq.w;
+        static_assert(BPL == 4, "one 16-byte load of the histogram per lane");
+    }
+    const unsigned bkt = tid < 16 ? ctl[tid] : 0u;
+    const int h = tid & 3;
+    int r = sub * TAIL_LINES + (tid >> 2);  // compact rank within the tile of this lane's line (lanes < 256); first chunk
+    bool mine_on = tid < 4 * TAIL_LINES && r < mycnt;
+    unsigned kl = 0u;
+    float Dm[16];
+    auto load_line = [&]() {
+        kl = 0u;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) Dm[q] = INFINITY;
+        if (mine_on) {
+            kl = lidc[slot0 + r];
+            const float4 *row = (const float4 *)(dc + (slot0 + r) * 16);
+            const float4 v0 = row[0], v1 = row[1], v2 = row[2], v3 = row[3];
+            Dm[0] = v0.x; Dm[1] = v0.y; Dm[2] = v0.z; Dm[3] = v0.w; Dm[4] = v1.x; Dm[5] = v1.y; Dm[6] = v1.z; Dm[7] = v1.w;
+            Dm[8] = v2.x; Dm[9] = v2.y; Dm[10] = v2.z; Dm[11] = v2.w; Dm[12] = v3.x; Dm[13] = v3.y; Dm[14] = v3.z; Dm[15] = v3.w;
+        }
+    };
+    load_line();
+    const float gl_in = do_bwd ? a.grad_loss[b] : 0.0f;
+    if (tid < 32) s_sum[tid] = 0ull;
+    if (tid < 2) s_flag[tid] = 0u;
+    if (tid == 0) s_ncand = 0u;
+    if (tid < 16) s_cnt[tid] = (int)bkt;
+    if (wave == 0) {  // exclusive prefix of the tile counts (nblk <= 32)
+        const int incl = wave_incl_scan(bc), vincl = wave_incl_scan(vc);
+        if (lane < nblk) { s_pref[lane + 1] = incl; s_vpref[lane + 1] = vincl; }
+        if (lane == 0) { s_pref[0] = 0; s_vpref[0] = 0; }
+    }
+    int k, j;  // 0, 0 for a lane without a line
+
+    // ---- the gradient chain of this lane's line, requested now: hit / Q1 / weights of hit slot h and the line's Q2
+    //      points hang off the line index; the source triangle off the hit index (one round later, below) -- none of it
+    //      depends on the median
+    bool bwd_live;
+    float4 q1;
+    float qx[4], qy[4], qz[4], wq[3], xs[9];
+    int fhit;
+    auto request_line = [&]() {
+        k = (int)((kl >> 24) & 15u); j = (int)(kl >> 28);
+        bwd_live = do_bwd && mine_on && h < k;
+        q1 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        fhit = 0;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) wq[q] = 0.0f;
+#pragma unroll
+        for (int o = 0; o < RRL_MAX_HITS; ++o) { qx[o] = qy[o] = qz[o] = 0.0f; }
+        if (bwd_live) {
+            const size_t gl = (size_t)b * a.L + (kl & 0xffffffu);
+            fhit = a.hs1[gl * 4 + h];
+            q1 = a.Q1[gl * 4 + h];
+            const float *w = a.w1 + (gl * 4 + h) * 3;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) wq[q] = w[q];
+#pragma unroll
+            for (int o = 0; o < RRL_MAX_HITS; ++o)
+                if (o < j) { const float4 t = a.Q2[gl * 4 + o]; qx[o] = t.x; qy[o] = t.y; qz[o] = t.z; }
+        }
+    };
+    auto request_source = [&]() {
+#pragma unroll
+        for (int q = 0; q < 9; ++q) xs[q] = 0.0f;
+        if (bwd_live) {
+            const float *x = a.src + ((size_t)b * a.N + fhit) * 9;
+#pragma unroll
+            for (int q = 0; q < 9; ++q) xs[q] = x[q];
+        }
+    };
+    request_line();
+    lds_barrier();  // s_pref, s_cnt
+    const int ngrp = s_vpref[nblk];  // 16-byte groups of D values in the sample's lists
+    int nlive = 0;  // workgroups of this sample that get past the test above: they all arrive at TICK2
+    for (int t = 0; t < nblk; ++t) {
+        const int c = s_pref[t + 1] - s_pref[t], w = min((c + TAIL_LINES - 1) / TAIL_LINES, TAIL_SUBS);
+        nlive += t == 0 && w == 0 ? 1 : w;
+    }
+
+    // ---- pick the bin of a rank among 2048 counts held BPL per lane: exclusive scan over the workgroup, the lane whose
+    //      range holds the rank reports (bin, rank inside, population).  Returns the total.
+    auto pick_bin = [&](unsigned rank_in, bool have_rank) -> unsigned {
+        unsigned tsum = 0;
+#pragma unroll
+        for (int q = 0; q < BPL; ++q) tsum += hb[q];
+        const unsigned incl = (unsigned)wave_incl_scan((int)tsum);
+        lds_barrier();  // s_wtot / s_pick free again
+        if (lane == 63) s_wtot[wave] = incl;
+        lds_barrier();
+        unsigned base = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            const unsigned v = s_wtot[w];
+            if (w < wave) base += v;
+            total += v;
+        }
+        const unsigned rank = have_rank ? rank_in : (total ? (total - 1) / 2 : 0u);  // lower median: sorted[(n - 1) / 2]
+        unsigned e = base + incl - tsum;
+        if (rank >= e && rank < e + tsum) {  // exactly one lane (none when total == 0)
+#pragma unroll
+            for (int q = 0; q < BPL; ++q) {
+                if (rank >= e && rank < e + hb[q]) { s_pick[0] = (unsigned)(BPL * tid + q); s_pick[1] = rank - e; s_pick[2] = hb[q]; }
+                e += hb[q];
+            }
+        }
+        lds_barrier();
+        return total;
+    };
+    const unsigned n = pick_bin(0u, false);
+    if (n == 0) {  // nothing selected in this sample: its only live workgroup is (tile 0, sub 0): loss 0, no bucket
+        if (tid < 16) a.bcnt_out[b * 16 + tid] = 0;
+        if (tid < 32) a.bsum_out[(size_t)b * 32 + tid] = 0;
+        if (tid == 0) {
+            a.med_out[b] = 0.0f;
+            a.loss[b] = 0.0f;
+            a.info[b * 4 + 0] = 0; a.info[b * 4 + 1] = 0; a.info[b * 4 + 2] = 0; a.info[b * 4 + 3] = a.status[0];
+        }
+        return;
+    }
+    const unsigned bin = s_pick[0], r1 = s_pick[1], pop = s_pick[2];
+    unsigned prefix = bin << 20;
+
+    // ---- every D value of the sample from the tiles' dense lists (VLIST: only the valid entries, ~2 per line instead of the
+    //      16 slots of a canonical tile; -1 pads), TAIL_RPL 16-byte groups per lane and round: fn(groups) for each round;
+    //      after_issue() runs once, when the first round of loads is in flight
+    auto stream_rows = [&](auto &&after_issue, auto &&fn) {
+        bool first = true;
+        for (int i0 = 0; i0 < ngrp; i0 += TAIL_LANES * TAIL_RPL) {  // uniform trip count
+            float4 v[TAIL_RPL];
+#pragma unroll
+            for (int u = 0; u < TAIL_RPL; ++u) {
+                const int i = i0 + tid + TAIL_LANES * u;
+                int t = 0;
+                for (int q = 1; q < nblk; ++q) t += i >= s_vpref[q] ? 1 : 0;  // the tile of group i
+                v[u] = make_float4(-1.0f, -1.0f, -1.0f, -1.0f);
+                if (i < ngrp) v[u] = ((const float4 *)(a.vlist + ((size_t)b * nblk + t) * 16384))[i - s_vpref[t]];
+            }
+            if (first) { after_issue(); first = false; }
+            fn(v);
+        }
+        if (first) after_issue();
+    };
+    auto each16 = [](const float4 *v, auto &&g) {
+#pragma unroll
+        for (int u = 0; u < TAIL_RPL; ++u) {
+            g(__float_as_uint(v[u].x)); g(__float_as_uint(v[u].y));
+            g(__float_as_uint(v[u].z)); g(__float_as_uint(v[u].w));
+        }
+    };
+
+    if (pop <= MCAND_CAP) {
+        // the bin's values into this workgroup's own list: count, ONE cursor atomic per wavefront and round, plain stores
+        stream_rows([&]() { request_source(); }, [&](const float4 *v) {
+            unsigned mine = 0;
+            each16(v, [&](unsigned x) { mine += (x >> 20) == bin ? 1u : 0u; });
+            const unsigned incl = (unsigned)wave_incl_scan((int)mine);
+            unsigned wbase = 0;
+            if (lane == 63 && incl) wbase = atomicAdd(&s_ncand, incl);
+            wbase = (unsigned)__builtin_amdgcn_readlane((int)wbase, 63);
+            unsigned at = wbase + incl - mine;
+            each16(v, [&](unsigned x) {
+                if ((x >> 20) == bin) { if (at < MCAND_CAP) s_vals[at] = x; ++at; }
+            });
+        });
+        lds_barrier();
+        if (tid < 64) {
+            const unsigned m = wave_select20(s_vals, pop, prefix, r1, s_whist, tid);
+            if (tid == 0) s_med = m;
+        }
+        lds_barrier();
+        prefix = s_med;
+    } else {
+        // ---- crowded bin (near-identical D values): two more streaming passes (bits 19..9, 8..0), by every workgroup itself
+        request_source();
+        unsigned rk = r1;
+        for (int pass = 1; pass <= 2; ++pass) {
+            const int sh = pass == 1 ? 9 : 0, width = pass == 1 ? 11 : 9, hi = sh + width;
+            const unsigned dmask = (1u << width) - 1u;
+            lds_barrier();
+#pragma unroll
+            for (int q = 0; q < BPL; ++q) s_vals[tid + TAIL_LANES * q] = 0u;
+            lds_barrier();
+            const unsigned pre = prefix;
+            stream_rows([&]() {}, [&](const float4 *v) {
+                each16(v, [&](unsigned x) {
+                    if (((x ^ pre) >> hi) == 0u) atomicAdd(&s_vals[(x >> sh) & dmask], 1u);
+                });
+            });
+            lds_barrier();
+#pragma unroll
+            for (int q = 0; q < BPL; ++q) hb[q] = s_vals[BPL * tid + q];
+            pick_bin(rk, true);
+            prefix |= s_pick[0] << sh;
+            rk = s_pick[1];
+        }
+    }
+    const float med = __uint_as_float(prefix);
+
+    // ---- the workgroup's lines: Welsch terms into the fixed-point sums (lane 0 of a line; as reduce_core::accumulate) and
+    //      hit slot h's gradient terms (as loss_bwd_rt_kernel)
+    int C = 0;
+    for (int kk = a.s_m; kk < a.e_m; ++kk)
+        for (int jj = a.s_n; jj < a.e_n; ++jj) C += s_cnt[(kk - 1) * 4 + (jj - 1)] > 0 ? 1 : 0;
+    float acc[12];
+#pragma unroll
+    for (int q = 0; q < 12; ++q) acc[q] = 0.0f;
+    for (int chunk = sub;; chunk += TAIL_SUBS) {  // (a second trip only when the tile has more than 256 selected lines)
+    if (chunk != sub) {
+        r = chunk * TAIL_LINES + (tid >> 2);
+        mine_on = tid < 4 * TAIL_LINES && r < mycnt;
+        load_line();
+        request_line();
+        request_source();
+    }
+    if (mine_on && h == 0) {
+        float row = 0.0f, col = 0.0f;
+#pragma unroll
+        for (int q = 0; q < RRL_MAX_HITS; ++q)
+            if (q < k) row += welsch(fminf(fminf(Dm[q * 4], Dm[q * 4 + 1]), fminf(Dm[q * 4 + 2], Dm[q * 4 + 3])), med);
+#pragma unroll
+        for (int q = 0; q < RRL_MAX_HITS; ++q)
+            if (q < j) col += welsch(fminf(fminf(Dm[q], Dm[4 + q]), fminf(Dm[8 + q], Dm[12 + q])), med);
+        if (!(row <= 4.0f) || !(col <= 4.0f)) { atomicOr(&s_flag[1], 1u); row = col = 0.0f; }
+        const int bi = (k - 1) * 4 + (j - 1);
+        atomicAdd(&s_sum[bi * 2 + 0], (unsigned long long)((double)row * (double)(1ll << FIX_SHIFT) + 0.5));
+        atomicAdd(&s_sum[bi * 2 + 1], (unsigned long long)((double)col * (double)(1ll << FIX_SHIFT) + 0.5));
+    }
+    if (bwd_live && C > 0) {
+        float rowmin[4], colmin[4];
+        int arg_b[4], arg_a[4];
+        welsch_block(Dm, med, rowmin, colmin, arg_b, arg_a);
+        const int S = s_cnt[(k - 1) * 4 + (j - 1)];
+        const float wkj = expf(-0.5f * (float)abs(k - j));
+        const float scale = gl_in * wkj / (float)C;
+        const float inv_row = 1.0f / ((float)S * (float)k), inv_col = 1.0f / ((float)S * (float)j);
+        float gq[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int o = 0; o < RRL_MAX_HITS; ++o) {
+            if (o >= j) continue;
+            float sw = 0.0f;
+#pragma unroll
+            for (int x = 0; x < RRL_MAX_HITS; ++x) {  // static indexing of arg_b / arg_a
+                if (x == h && arg_b[x] == o) sw += inv_row;
+                if (x == o && arg_a[x] == h) sw += inv_col;
+            }
+            if (sw == 0.0f) continue;
+            float dho = 0.0f;  // D[h][o] with static indices
+#pragma unroll
+            for (int x = 0; x < RRL_MAX_HITS; ++x)
+                if (x == h) dho = Dm[x * 4 + o];
+            const float gD = scale * sw * expf(-(dho / med) / 2.0f) / (2.0f * med);
+            gq[0] += 2.0f * (q1.x - qx[o]) * gD;
+            gq[1] += 2.0f * (q1.y - qy[o]) * gD;
+            gq[2] += 2.0f * (q1.z - qz[o]) * gD;
+        }
+#pragma unroll
+        for (int kk = 0; kk < 3; ++kk) {
+            const float wk = wq[kk] / 3.0f;  // q = mean_k(w_k P_k)
+            float gv[3];
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc) gv[cc] = wk * gq[cc];
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc) {
+                const float xc = xs[3 * kk + cc];
+#pragma unroll
+                for (int jj = 0; jj < 3; ++jj) acc[cc * 3 + jj] = fmaf(xc, gv[jj], acc[cc * 3 + jj]);
+                acc[9 + cc] += gv[cc];
+            }
+        }
+    }
+    if ((chunk + TAIL_SUBS) * TAIL_LINES >= mycnt) break;  // uniform
+    }
+    if (do_bwd && wave < 4) {  // (the lines sit in the first four wavefronts)
+#pragma unroll
+        for (int q = 0; q < 12; ++q) acc[q] = wave_sum(acc[q]);
+        if (lane == 0)
+#pragma unroll
+            for (int q = 0; q < 12; ++q) s_red[wave][q] = acc[q];
+    }
+    __syncthreads();
+    if (tid < 32) {
+        const unsigned long long v = s_sum[tid];
+        if (v) atomicAdd(&a.msum[(size_t)b * 32 + tid], v);
+    }
+    if (tid == 32 && s_flag[1]) atomicOr(&ctl[MCTL_BAD], 1u);
+    if (do_bwd && mycnt > 0 && tid >= 64 && tid < 76) {
+        const int q = tid - 64;
+        const float v = (s_red[0][q] + s_red[1][q]) + (s_red[2][q] + s_red[3][q]);
+        int o = q;  // m-index (i, j) -> memory order of R
+        if (q < 9 && a.transpose_r) o = (q % 3) * 3 + q / 3;
+        if (q < 9) atomicAdd(&a.gR[b * 9 + o], v); else atomicAdd(&a.gt[b * 3 + (q - 9)], v);
+        if (a.payload) atomicAdd(&a.payload[2 + o], v);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0)
+        s_flag[0] = __hip_atomic_fetch_add(&ctl[MCTL_TICK2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(nlive - 1) ? 1u : 0u;
+    __syncthreads();
+    if (!s_flag[0]) return;
+
+    // ---- the last workgroup of the sample: loss = ( sum_{non-empty (k,j), k-major} exp(-|k-j|/2) (mean_row + mean_col) ) / C
+    if (tid < 32) {
+        const unsigned long long v = __hip_atomic_load(&a.msum[(size_t)b * 32 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_sum[tid] = v;
+        a.bsum_out[(size_t)b * 32 + tid] = (int64_t)v;
+        __hip_atomic_store(&a.msum[(size_t)b * 32 + tid], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // a second reduce on this state starts clean
+    }
+    if (tid >= 32 && tid < 48) a.bcnt_out[b * 16 + tid - 32] = s_cnt[tid - 32];
+    if (tid == 48 && ld_agent(&ctl[MCTL_BAD])) atomicOr(&s_flag[1], 2u);
+    __syncthreads();
+    if (tid < 16) {  // one lane per bucket: the double-precision means (as reduce_body)
+        const int kk = tid / 4 + 1, jj = tid % 4 + 1, S = s_cnt[tid];
+        float term = 0.0f;
+        if (S > 0 && kk >= a.s_m && kk < a.e_m && jj >= a.s_n && jj < a.e_n) {
+            const double sc = 1.0 / (double)(1ll << FIX_SHIFT);
+            float mrow = (float)((double)s_sum[tid * 2 + 0] * sc / ((double)S * kk));
+            float mcol = (float)((double)s_sum[tid * 2 + 1] * sc / ((double)S * jj));
+            float wkj = expf(-0.5f * (float)abs(kk - jj));  // code/loss.py:215
+            term = wkj * (mrow + mcol);
+        }
+        s_term[tid] = term;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float accl = 0.0f;
+        int Cn = 0, nselected = 0, nvalues = 0;
+        for (int kk = a.s_m; kk < a.e_m; ++kk)      // k-major, the reference's accumulation order
+            for (int jj = a.s_n; jj < a.e_n; ++jj) {
+                const int bi = (kk - 1) * 4 + (jj - 1);
+                if (s_cnt[bi] == 0) continue;
+                accl = accl + s_term[bi];
+                ++Cn;
+                nselected += s_cnt[bi];
+            }
+        for (int bi = 0; bi < 16; ++bi) nvalues += s_cnt[bi] * (bi / 4 + 1) * (bi % 4 + 1);
+        const bool bad = (s_flag[1] & 2u) != 0u;
+        const float lv = bad ? __builtin_nanf("") : (Cn ? accl / (float)Cn : 0.0f);  // code/loss.py:230
+        a.med_out[b] = med;
+        a.loss[b] = lv;
+        a.info[b * 4 + 0] = Cn;
+        a.info[b * 4 + 1] = nselected;
+        a.info[b * 4 + 2] = nvalues;
+        a.info[b * 4 + 3] = a.status[0];
+        st_agent(&ctl[MCTL_TICK2], 0u); st_agent(&ctl[MCTL_BAD], 0u);
+        if (do_bwd && a.payload && Cn > 0) tail_payload(a, lv);
+    }
+}
+
 // K2 + K3 + K4 in ONE launch when a sample has a single tile of lines (L <= 1024) and the samples are not pooled:
 // the workgroup that ran the per-line stage of sample b owns everything the reduce of sample b reads, so it
 // simply carries on (a launch and the reduce's first load round less: small-L shapes such as C5 are nothing
@@ -1045,22 +1532,41 @@ __global__ __launch_bounds__(1024) void pair_reduce_kernel(const PairArgs pa, co
 // and the bound; it then also serves a single tile).
 static int g_reduce_mode = -1;  // 0 auto, 1 single, 2 tiled; -1: read RRL_REDUCE once
 extern "C" int rrl_set_reduce_mode(int mode) {
-    if (mode < 0 || mode > 2) return RRL_E_ARG;
+    if (mode < 0 || mode > 3) return RRL_E_ARG;
     g_reduce_mode = mode;
     return 0;
 }
 static int reduce_mode() {
     if (g_reduce_mode < 0) {
         const char *e = getenv("RRL_REDUCE");
-        g_reduce_mode = !e ? 0 : (e[0] == 's' ? 1 : (e[0] == 't' ? 2 : 0));
+        g_reduce_mode = !e ? 0 : (e[0] == 's' ? 1 : (e[0] == 't' ? 2 : (e[0] == 'x' ? 3 : 0)));
     }
     return g_reduce_mode;
 }
-static bool reduce_tiled(int B, int nblk, int pool) {
+// Which reduce kernel: 0 one workgroup per sample, 1 tiled with the candidate exchange (loss_reduce_tiled_kernel), 2 the
+// tail kernel (no exchange: every workgroup streams its sample's dense value lists; one 512-lane workgroup or two
+// per compute unit, so it serves the small, latency-bound grids: B x tiles <= 128, <= 16 tiles per sample).
+// mode 0 (auto): the tail kernel where the direct backward rides along (with_bwd: rrl_registration_step -- measured
+// -1.9 .. -3.4 us per step at C2 / L = 4096 / C4; as a reduce alone it is 1.7 us SLOWER than the exchange kernel, and at
+// the demo's shape, one sample of 20 tiles, the two are even), else the exchange kernel for >= 2 tiles while the grid
+// is co-resident, else the single workgroup; 1: single; 2 ("tiled"): the tail kernel wherever it is legal (also forward
+// only, also one tile: tests), exchange beyond; 3 ("xchg"): the exchange kernel wherever it is legal.
+static int reduce_kind(int B, int nblk, int pool, bool with_bwd) {
     const int mode = reduce_mode();
-    if (pool || mode == 1 || (long)B * nblk > 1024) return false;
-    return mode == 2 ? nblk >= 1 : nblk >= 2;
+    if (pool || mode == 1) return 0;
+    const bool xchg_ok = (long)B * nblk <= 1024;
+    if (mode == 3) return xchg_ok && nblk >= 1 ? 1 : 0;
+    const bool tail_ok = nblk <= TAIL_MAX_TILES && (long)B * nblk <= 128;
+    if (mode == 2 && tail_ok && nblk >= 1) return 2;
+    if (mode == 0 && tail_ok && with_bwd && nblk >= 2 && nblk <= 16) return 2;
+    return xchg_ok && nblk >= 2 ? 1 : 0;
 }
+// the direct backward that may ride in the tail kernel's launch (rrl_registration_step)
+struct TailBwd {
+    const float *grad_loss, *src;
+    float *gR, *gt, *payload;
+    int transpose_r;
+};
 
 static ReduceArgs reduce_args(void *ws, const WsLayout &w, float *loss, int B, int L, int s_m, int s_n, int e_m, int e_n,
                               int pool) {
@@ -1073,15 +1579,38 @@ static ReduceArgs reduce_args(void *ws, const WsLayout &w, float *loss, int B, i
     return r;
 }
 
-extern "C" int rrl_loss_reduce(void *ws, size_t ws_bytes, float *loss, int B, int N, int M, int L,
-                               int s_m, int s_n, int e_m, int e_n, int pool, void *stream) {
+// tb != NULL: the caller wants the direct backward too; *bwd_done tells whether this launch carried it
+static int loss_reduce_impl(void *ws, size_t ws_bytes, float *loss, int B, int N, int M, int L, int s_m, int s_n, int e_m,
+                            int e_n, int pool, const TailBwd *tb, bool *bwd_done, void *stream) {
+    if (bwd_done) *bwd_done = false;
     if (!ws || !loss || B < 0 || N < 0 || M < 0 || L < 0) return RRL_E_ARG;
     if (s_m < 1 || s_n < 1 || e_m > RRL_MAX_HITS + 1 || e_n > RRL_MAX_HITS + 1) return RRL_E_RANGE;
     WsLayout w(B, N, M, L);
     if (ws_bytes < w.total) return RRL_E_WS;
     if (B == 0) return 0;
     const int nblk = (L + 1023) / 1024;
-    if (reduce_tiled(B, nblk, pool)) {
+    const int kind = reduce_kind(B, nblk, pool, tb != nullptr);
+    if (kind == 2) {
+        TailArgs t;
+        t.lidc = w.u32(ws, RRL_WS_LIDC); t.dc = w.f32(ws, RRL_WS_VALS); t.blkcnt = w.i32(ws, RRL_WS_BLKCNT);
+        t.vlist = w.f32(ws, RRL_WS_VLIST); t.vlcnt = w.i32(ws, RRL_WS_VLCNT);
+        t.mhist = w.u32(ws, RRL_WS_MHIST); t.mctl = w.u32(ws, RRL_WS_MCTL);
+        t.msum = (unsigned long long *)w.i64(ws, RRL_WS_MSUM);
+        t.med_out = w.f32(ws, RRL_WS_MED); t.bcnt_out = w.i32(ws, RRL_WS_BCNT); t.bsum_out = w.i64(ws, RRL_WS_BSUM);
+        t.info = w.i32(ws, RRL_WS_INFO); t.loss = loss; t.status = w.i32(ws, RRL_WS_STATUS);
+        t.B = B; t.nblk = nblk; t.s_m = s_m; t.s_n = s_n; t.e_m = e_m; t.e_n = e_n;
+        t.do_bwd = tb ? 1 : 0; t.N = N; t.L = L; t.transpose_r = tb ? tb->transpose_r : 0;
+        t.hs1 = w.i32(ws, RRL_WS_HS1); t.w1 = w.f32(ws, RRL_WS_W1);
+        t.Q1 = (const float4 *)w.f32(ws, RRL_WS_Q1); t.Q2 = (const float4 *)w.f32(ws, RRL_WS_Q2);
+        t.grad_loss = tb ? tb->grad_loss : nullptr; t.src = tb ? tb->src : nullptr;
+        t.gR = tb ? tb->gR : nullptr; t.gt = tb ? tb->gt : nullptr; t.payload = tb ? tb->payload : nullptr;
+        hipLaunchKernelGGL(loss_tail_kernel, dim3((unsigned)nblk, (unsigned)B, TAIL_SUBS), dim3(TAIL_LANES), 0,
+                           (hipStream_t)stream, t);
+        RRL_LAUNCH_CHECK();
+        if (bwd_done) *bwd_done = tb != nullptr;
+        return 0;
+    }
+    if (kind == 1) {
         TiledArgs t;
         t.kjc = w.u8(ws, RRL_WS_KJC); t.dc = w.f32(ws, RRL_WS_VALS); t.blkcnt = w.i32(ws, RRL_WS_BLKCNT);
         t.mhist = w.u32(ws, RRL_WS_MHIST); t.mctl = w.u32(ws, RRL_WS_MCTL); t.mcand = w.u32(ws, RRL_WS_MCAND);
@@ -1097,6 +1626,11 @@ extern "C" int rrl_loss_reduce(void *ws, size_t ws_bytes, float *loss, int B, in
                        (hipStream_t)stream, reduce_args(ws, w, loss, B, L, s_m, s_n, e_m, e_n, pool));
     RRL_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int rrl_loss_reduce(void *ws, size_t ws_bytes, float *loss, int B, int N, int M, int L,
+                               int s_m, int s_n, int e_m, int e_n, int pool, void *stream) {
+    return loss_reduce_impl(ws, ws_bytes, loss, B, N, M, L, s_m, s_n, e_m, e_n, pool, nullptr, nullptr, stream);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1427,7 +1961,9 @@ int rrl_sort_capacity(void);
 static int loss_forward_impl(const float *tri1, const float *tri2, const float *line, void *ws,
                              size_t ws_bytes, float *loss, int B, int N, int M, int L, int s_m,
                              int s_n, int e_m, int e_n, int pool, int mode, int chunk,
-                             const void *target_ws, const RrlXform *xf, void *stream) {
+                             const void *target_ws, const RrlXform *xf, void *stream,
+                             const TailBwd *tb = nullptr, bool *bwd_done = nullptr) {
+    if (bwd_done) *bwd_done = false;
     if (!tri1 || !tri2 || !line || !ws || !loss) return RRL_E_ARG;
     if (s_m < 1 || s_n < 1 || e_m > RRL_MAX_HITS + 1 || e_n > RRL_MAX_HITS + 1) return RRL_E_RANGE;
     if (target_ws == ws) return RRL_E_ARG;
@@ -1454,7 +1990,7 @@ static int loss_forward_impl(const float *tri1, const float *tri2, const float *
         const int lmax_ready = (N > M ? N : M) <= rrl_sort_capacity() && B > 0 && (clouds == 2 && M > N ? M : N) > 0 && L > 0;
         if ((rc = rrl_line_tri_scan_clouds(line, ws, ws_bytes, B, N, M, L, mode, chunk, clouds, lmax_ready, stream))) return rc;
     }
-    if (L >= 1 && L <= 1024 && !pool && B > 0 && reduce_mode() != 2) {  // one tile of lines per sample: K2 + K3 + K4 in one launch
+    if (L >= 1 && L <= 1024 && !pool && B > 0 && reduce_mode() < 2) {  // one tile of lines per sample: K2 + K3 + K4 in one launch
         RrlRange r("K2 + K3 + K4 (single tile)");
         WsLayout w(B, N, M, L);
         if (ws_bytes < w.total) return RRL_E_WS;
@@ -1467,11 +2003,11 @@ static int loss_forward_impl(const float *tri1, const float *tri2, const float *
     {
         RrlRange r("K2 per-line distances");
         if ((rc = line_pair_dist_impl(target_ws ? tri2 : nullptr, line, ws, ws_bytes, B, N, M, L, s_m, s_n, e_m,
-                                      e_n, pool, stream)))
+                                      e_n, pool, stream, tb != nullptr)))
             return rc;
     }
     RrlRange r("K3+K4 median + Welsch reduce");
-    return rrl_loss_reduce(ws, ws_bytes, loss, B, N, M, L, s_m, s_n, e_m, e_n, pool, stream);
+    return loss_reduce_impl(ws, ws_bytes, loss, B, N, M, L, s_m, s_n, e_m, e_n, pool, tb, bwd_done, stream);
 }
 
 extern "C" int rrl_loss_forward_cached(const float *tri1, const float *tri2, const float *line,
@@ -1541,6 +2077,51 @@ extern "C" int rrl_registration_forward(const float *src, const float *R, const 
     return rrl_registration_forward_cached(src, R, t, tri2, line, ws, ws_bytes, loss, B, N, M, L,
                                            transpose_r, s_m, s_n, e_m, e_n, mode, chunk, nullptr,
                                            stream);
+}
+
+extern "C" int rrl_registration_backward(const float *src, const float *R, const float *tri2,
+                                         void *ws, size_t ws_bytes, const float *loss,
+                                         const float *grad_loss, float *grad_src, float *gR, float *gt,
+                                         float *payload, int B, int N, int M, int L, int transpose_r,
+                                         void *stream);
+
+// Forward + direct backward of the fused training op in ONE call (dL/dloss is an input, so nothing has to come back
+// to the host in between): when the tail kernel serves the shape, the backward rides in its launch (5 launches per
+// step instead of 6, and the reduce's and the backward's chains of dependent loads overlap); otherwise exactly
+// rrl_registration_forward_cached followed by rrl_registration_backward.  gR, gt (and payload) should be the
+// workspace's GACC field, which the forward's first launch clears; other buffers are cleared here first.
+extern "C" int rrl_registration_step(const float *src, const float *R, const float *t, const float *tri2,
+                                     const float *line, void *ws, size_t ws_bytes, float *loss,
+                                     const float *grad_loss, float *gR, float *gt, float *payload, int B, int N,
+                                     int M, int L, int transpose_r, int s_m, int s_n, int e_m, int e_n, int mode,
+                                     int chunk, const void *target_ws, void *stream) {
+    if (!src || !R || !t || !tri2 || !line || !ws || !loss || !grad_loss || !gR || !gt) return RRL_E_ARG;
+    if (B < 0 || N < 0 || M < 0 || L < 0) return RRL_E_ARG;
+    WsLayout w(B, N, M, L);
+    if (ws_bytes < w.total) return RRL_E_WS;
+    const int nblk = (L + 1023) / 1024;
+    bool done = false;
+    int rc;
+    if (B > 0 && L > 0 && !rrl_deterministic() && reduce_kind(B, nblk, 0, true) == 2 && !(L <= 1024 && reduce_mode() < 2)) {
+        float *gacc = w.f32(ws, RRL_WS_GACC);
+        hipStream_t s = (hipStream_t)stream;
+        if (gR != gacc || gt != gacc + 9 * (size_t)B || (payload && payload != gacc + 12 * (size_t)B)) {
+            if ((rc = rrl_fill(gR, 0u, sizeof(float) * 9 * (size_t)B, s))) return rc;
+            if ((rc = rrl_fill(gt, 0u, sizeof(float) * 3 * (size_t)B, s))) return rc;
+            if (payload && (rc = rrl_fill(payload, 0u, sizeof(float) * 14, s))) return rc;
+        }
+        const RrlXform xf = {src, R, t, transpose_r, 1};
+        const TailBwd tb = {grad_loss, src, gR, gt, payload, transpose_r};
+        rc = loss_forward_impl(w.f32(ws, RRL_WS_TRI1), tri2, line, ws, ws_bytes, loss, B, N, M, L, s_m, s_n, e_m, e_n, 0,
+                               mode, chunk, target_ws, &xf, stream, &tb, &done);
+        if (rc || done) return rc;
+    } else {
+        rc = rrl_registration_forward_cached(src, R, t, tri2, line, ws, ws_bytes, loss, B, N, M, L, transpose_r, s_m,
+                                             s_n, e_m, e_n, mode, chunk, target_ws, stream);
+        if (rc) return rc;
+    }
+    return rrl_registration_backward(src, R, tri2, ws, ws_bytes, loss, grad_loss, nullptr, gR, gt, payload, B, N, M, L,
+                                     transpose_r, stream);
 }
 
 extern "C" int rrl_registration_backward(const float *src, const float *R, const float *tri2,

@@ -60,6 +60,9 @@ struct WsLayout {
             8 * b * 32,          // MSUM
             4 * b * 2048,        // MCAND
             4 * b * 64 * 2,      // LMAX
+            4 * b * ((l + 1023) / 1024) * 1024,  // LIDC
+            4 * b * ((l + 1023) / 1024) * 16384, // VLIST
+            4 * b * ((l + 1023) / 1024 + 1),     // VLCNT
         };
         size_t o = 0;
         for (int i = 0; i < RRL_WS_FIELDS; ++i) {

@@ -25,6 +25,7 @@ _SIGS = {
     "rrl_loss_forward_cached": [_P, _P, _P, _P, _Z, _P] + [_I] * 11 + [_P, _P],
     "rrl_loss_forward_info": [_P, _P, _P, _P, _Z, _P] + [_I] * 11 + [_P, _P, _P],
     "rrl_registration_backward": [_P] * 4 + [_Z] + [_P] * 6 + [_I] * 5 + [_P],
+    "rrl_registration_step": [_P] * 6 + [_Z] + [_P] * 5 + [_I] * 11 + [_P, _P],
     "rrl_tri_prepare": [_P, _P, _P, _Z, _I, _I, _I, _I, _P],
     "rrl_line_tri_scan": [_P, _P, _Z] + [_I] * 6 + [_P],
     "rrl_line_pair_dist": [_P, _P, _P, _P, _Z] + [_I] * 9 + [_P],

@@ -3,6 +3,7 @@ all compute is librrl_hip.so).  No fallback path exists: CPU tensors are moved t
 current GPU, and a missing library / missing GPU raises RRLError.
 """
 import ctypes
+import os
 import sys
 
 import torch
@@ -62,6 +63,9 @@ _WS_FIELDS = [
     ("msum", torch.int64, lambda B, N, M, L, G: (B, 32)),
     ("mcand", torch.int32, lambda B, N, M, L, G: (B, 2048)),
     ("lmax", torch.float32, lambda B, N, M, L, G: (B, 64, 2)),
+    ("lidc", torch.int32, lambda B, N, M, L, G: (B, (L + 1023) // 1024 * 1024)),
+    ("vlist", torch.float32, lambda B, N, M, L, G: (B, (L + 1023) // 1024, 16384)),
+    ("vlcnt", torch.int32, lambda B, N, M, L, G: (B * ((L + 1023) // 1024 + 1),)),
 ]
 _layout_cache = {}
 _FIELD_INDEX = {name: i for i, (name, _, _) in enumerate(_WS_FIELDS)}
@@ -513,6 +517,9 @@ class RegistrationStep:
     issued eagerly.  Same kernels, same numbers as registration_loss.  The outputs are views of buffers
     that the next call overwrites.  want_payload: also the 14-float batch-shard payload (rrl_hip.dist)."""
 
+    # rrl_registration_step; False (or RRL_ONE_CALL=0): rrl_registration_forward_cached + rrl_registration_backward
+    ONE_CALL = os.environ.get("RRL_ONE_CALL", "1") != "0"
+
     def __init__(self, src_tri, tar_tri, n_lines, rng=(1, 1, 5, 5), transpose_r=True, mode="cull", chunk=0,
                  want_payload=False):
         dev = _home(src_tri, tar_tri)
@@ -538,6 +545,9 @@ class RegistrationStep:
                          self.chunk, None)
         self._fixed_b = (_p(self.st.ws), self.st.nbytes, _p(self.st.loss))
         self._tail_b = (None, _p(gacc[:B * 9]), _p(gacc[B * 9:B * 12]), _p(self.payload), B, N, M, L, self.tr)
+        self._head_s = (_p(self.st.ws), self.st.nbytes, _p(self.st.loss))
+        self._tail_s = (_p(gacc[:B * 9]), _p(gacc[B * 9:B * 12]), _p(self.payload), B, N, M, L, self.tr, *self.rng,
+                        self.mode, self.chunk, None)
 
     def __call__(self, R, t, line, grad_loss=None, src_tri=None, tar_tri=None):
         """src_tri / tar_tri: this step's clouds (same shapes as at construction); default: the tensors given
@@ -556,10 +566,14 @@ class RegistrationStep:
         g = self.ones if grad_loss is None else _prep(grad_loss, "grad_loss", None, dev)
         lib, s = self._lib, _stream(dev)
         with _guard(dev):
-            check(lib.rrl_registration_forward_cached(_p(self.src), _p(Rm), _p(tv), _p(self.tar), _p(ln), *self._fixed_f, s),
-                  "rrl_registration_forward")
-            check(lib.rrl_registration_backward(_p(self.src), _p(Rm), _p(self.tar), *self._fixed_b, _p(g), *self._tail_b, s),
-                  "rrl_registration_backward")
+            if RegistrationStep.ONE_CALL:  # forward + backward as one C entry: the backward may ride in the reduce's launch
+                check(lib.rrl_registration_step(_p(self.src), _p(Rm), _p(tv), _p(self.tar), _p(ln), *self._head_s, _p(g),
+                                                *self._tail_s, s), "rrl_registration_step")
+            else:
+                check(lib.rrl_registration_forward_cached(_p(self.src), _p(Rm), _p(tv), _p(self.tar), _p(ln), *self._fixed_f, s),
+                      "rrl_registration_forward")
+                check(lib.rrl_registration_backward(_p(self.src), _p(Rm), _p(self.tar), *self._fixed_b, _p(g), *self._tail_b, s),
+                      "rrl_registration_backward")
         _IntersectionLoss.last_state = self.st
         return self.st.loss.view(-1), self.gR, self.gt, self.payload, self.st.info
 
@@ -573,7 +587,7 @@ def set_deterministic(on):
 def set_reduce_mode(mode):
     """Which reduce kernel the forwards launch: "auto" (tiled where legal and worthwhile), "single", "tiled"
     (include/rrl.h rrl_set_reduce_mode).  Process-wide; same bits either way."""
-    check(_lib.load().rrl_set_reduce_mode({"auto": 0, "single": 1, "tiled": 2}[mode]), "rrl_set_reduce_mode")
+    check(_lib.load().rrl_set_reduce_mode({"auto": 0, "single": 1, "tiled": 2, "xchg": 3}[mode]), "rrl_set_reduce_mode")
 
 
 def set_sort_parts(parts):

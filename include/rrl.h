@@ -121,6 +121,11 @@ enum {
     RRL_WS_MCAND,      /* uint32[B][2048] D values (bit patterns) of the median's bin, gathered by the tiled reduce          */
     RRL_WS_LMAX,       /* float[B][64][2] (max |dir|^2, max |x0|^2) over 1/64 of a sample's cullable lines: the culled scan's
                           slacks come from their maxima (written by the records kernel, or by the scan entry itself)       */
+    RRL_WS_LIDC,       /* uint32[B][Lp]  line index | (k | j<<4) << 24 at the compact slots (the tail kernel's way from a
+                          compact slot back to the per-line arrays)                                                        */
+    RRL_WS_VLIST,      /* float[B][ceil(L/1024)][16384]  the valid D values of each 1024-line tile as a dense list (arbitrary order,
+                          padded with -1 to a multiple of 4): what the tail kernel streams to find the median                */
+    RRL_WS_VLCNT,      /* int32[B][ceil(L/1024)]  their number per tile                                                     */
     RRL_WS_FIELDS
 };
 
@@ -197,6 +202,18 @@ int rrl_registration_backward(const float *src, const float *R, const float *tri
                               float *grad_src, float *gR, float *gt, float *payload, int B, int N,
                               int M, int L, int transpose_r, void *stream);
 
+/* Forward + direct backward of the fused training op in ONE call -- what a training step does when dL/dloss is
+ * known up front (grad_loss [B], usually ones): rpm/Train_RPM.py:226-259, dcp/Train_DCP.py:246-270 compute the loss
+ * and call backward() right away.  Same arguments and results as rrl_registration_forward_cached followed by
+ * rrl_registration_backward(grad_src = NULL); where the tail kernel serves the shape (2 .. 32 line tiles per sample,
+ * not deterministic mode) the backward rides in the reduce's launch: 5 launches per step, the two kernels' chains of
+ * dependent loads overlap.  gR [B][9], gt [B][3], payload [14] or NULL: ideally the workspace's GACC field. */
+int rrl_registration_step(const float *src, const float *R, const float *t, const float *tri2,
+                          const float *line, void *ws, size_t ws_bytes, float *loss, const float *grad_loss,
+                          float *gR, float *gt, float *payload, int B, int N, int M, int L, int transpose_r,
+                          int s_m, int s_n, int e_m, int e_n, int mode, int chunk, const void *target_ws,
+                          void *stream);
+
 /* ---- the four forward stages, individually (tests, profiling) ------------------------- */
 
 /* K1': prepared triangles for both clouds + zeroing of the per-call state.
@@ -227,13 +244,14 @@ int rrl_line_pair_dist(const float *tri1, const float *tri2, const float *line, 
 int rrl_loss_reduce(void *ws, size_t ws_bytes, float *loss, int B, int N, int M, int L, int s_m,
                     int s_n, int e_m, int e_n, int pool, void *stream);
 
-/* Which reduce kernel rrl_loss_reduce (and the fused forwards) launch: 0 = automatic -- the TILED reduce (one
- * 256-lane workgroup per 1024-line tile of a sample: the median's first radix pass comes as a histogram from the
- * per-line stage, the bin's values are exchanged through the workspace, fixed-point bucket sums by device atomics,
- * the last workgroup to arrive writes the loss) for independent samples with >= 2 tiles while B x tiles <= 1024,
- * else the single 1024-lane workgroup per sample; 1 = always the single workgroup; 2 = tiled wherever it is legal
- * (also for one tile).  Bit-identical median, loss and bucket sums either way.  Env RRL_REDUCE=single|tiled sets
- * the initial state. */
+/* Which reduce kernel rrl_loss_reduce (and the fused forwards) launch.  0 = automatic: for independent samples with
+ * 2 .. 32 line tiles the TAIL kernel (one 1024-lane workgroup per 1024-line tile of a sample; the median's first radix
+ * pass comes as a histogram from the per-line stage, every workgroup re-reads its sample's compact D tiles from the L2
+ * and selects the median itself -- no exchange --, fixed-point bucket sums by device atomics, the last workgroup to
+ * arrive writes the loss); beyond 32 tiles, while B x tiles <= 1024, the tiled kernel WITH the candidate exchange
+ * through the workspace (round 3a); else the single 1024-lane workgroup per sample.  1 = always the single workgroup;
+ * 2 = tiled wherever legal (the tail kernel also for one tile); 3 = the exchange kernel wherever legal.  Bit-identical
+ * median, loss and bucket sums in every case.  Env RRL_REDUCE=single|tiled|xchg sets the initial state. */
 int rrl_set_reduce_mode(int mode);
 
 /* Workgroups per cloud of the cell sort + sphere-tree kernel (they share nothing but their input: each owns a range

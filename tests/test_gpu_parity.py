@@ -1411,23 +1411,87 @@ def test_tiled_reduce_equals_single_workgroup(L, case):
         lines[:, 40:5200] = 0
     out = {}
     try:
-        for mode in ("single", "tiled"):
+        for mode in ("single", "tiled", "xchg"):  # tiled: the tail kernel (no exchange); xchg: the exchange kernel
             ops.set_reduce_mode(mode)
             st = run_state(tri1, tri2, lines, mode="cull")
             out[mode] = [t.cpu().numpy().copy() for t in (st.loss, st.med, st.info, st.bcnt, st.bsum)]
-            if mode == "tiled":  # the reduce once more on the same prepared state (its control words reset themselves)
+            if mode != "single":  # the reduce once more on the same prepared state (its control words reset themselves)
                 B, N, M, Ll, _ = st.dims
                 st.loss.fill_(-1.0)
                 ops._run(st.ws.device, "rrl_loss_reduce", ops._p(st.ws), st.nbytes, ops._p(st.loss), B, N, M, Ll, 1, 1, 5, 5, 0)
                 torch.cuda.synchronize()
-                out["again"] = [t.cpu().numpy().copy() for t in (st.loss, st.med, st.info, st.bcnt, st.bsum)]
+                out["again_" + mode] = [t.cpu().numpy().copy() for t in (st.loss, st.med, st.info, st.bcnt, st.bsum)]
                 assert int(st.mctl[:, 19].sum()) == 0  # no spin ran into its time-out
     finally:
         ops.set_reduce_mode("auto")
-    for other in ("tiled", "again"):
+    for other in ("tiled", "xchg", "again_tiled", "again_xchg"):
         for a, b in zip(out["single"], out[other]):
             np.testing.assert_array_equal(a.view(np.uint8), b.view(np.uint8))
     assert out["single"][2][:, 1].sum() > 0  # lines were selected
+
+
+@pytest.mark.parametrize("case", ["batch", "dense_tiles", "one_tile_forced", "empty_sample"])
+def test_step_in_one_call_equals_forward_then_backward(L, case):
+    """rrl_registration_step (the direct backward inside the tail kernel's launch) against rrl_registration_forward +
+    rrl_registration_backward: loss, median, info, bucket sums bit for bit; dR, dt, payload to the rounding of their float
+    atomics -- a batch with 3-5 line tiles per sample, tiles with more than 256 selected lines (the kernel's second
+    pass over a tile, and the crowded-bin route of the median), a single tile (tail kernel forced), a sample whose lines hit nothing; with and without payload,
+    both R layouts, non-unit dL/dloss."""
+    from rrl_hip import ops, synth
+    from LieAlgebra import se3
+    B = 3
+    nl = {"batch": 4500, "dense_tiles": 2600, "one_tile_forced": 900, "empty_sample": 3000}[case]
+    gen = torch.Generator().manual_seed(2)
+    R, T = se3.exp3(0.03 * torch.randn(B, 6, generator=gen))
+    if case == "dense_tiles":  # two tiny triangles per cloud, every line through the first: ~1000 selected lines per tile,
+        rng = np.random.default_rng(5)  # near-identical D values (the crowded-bin route of the median) -- no motion
+        base = np.array([[0.0, 0.0, 0.0, 0.05, 0.0, 0.0, 0.0, 0.05, 0.0]], np.float32)
+        t1 = np.concatenate([base, base + np.float32(3.0)]).astype(np.float32)
+        src = cu(np.stack([t1] * B))
+        tar = cu(np.stack([(t1 + np.array([0.004, -0.003, 0.002] * 3, np.float32) * (1 + 0.1 * b)).astype(np.float32) for b in range(B)]))
+        d = np.tile(np.array([[0.0, 0.0, 1.0]]), (nl, 1))
+        ln = cu(np.stack([np.concatenate([d, np.tile(np.array([[0.012, 0.011, -1.0]]), (nl, 1)) + 1e-5 * b * rng.standard_normal((nl, 3))], 1)
+                          for b in range(B)]).astype(np.float32))
+        R, T = torch.eye(3).repeat(B, 1, 1), torch.zeros(B, 3)
+    else:
+        prs = [synth.make_pair(40 + b, 900, 800) for b in range(B)]
+        src, tar = cu(np.stack([p["src_tri"] for p in prs])), cu(np.stack([p["tar_tri"] for p in prs]))
+        ln = []
+        for b, p in enumerate(prs):
+            torch.manual_seed(b)
+            ln.append(L.Random_uniform_distribution_lines_batch_efficient_resample(
+                torch.tensor([[float(p["radius"])]]), torch.from_numpy(p["center"]).reshape(1, 3), nl, cu(p["src"])[None],
+                cu(p["tar"])[None], "cuda")[0])
+        ln = torch.stack(ln)
+    if case == "empty_sample":
+        ln[1] = torch.tensor([1.0, 0, 0, 0, 50, 50], device="cuda")
+    R, T = R.cuda().contiguous(), T.cuda().contiguous()
+    gl = torch.tensor([1.0, 0.5, 2.0], device="cuda")
+    try:
+        if case == "one_tile_forced":
+            ops.set_reduce_mode("tiled")
+        for tr in (True, False):
+            res = {}
+            for one in (False, True):
+                ops.RegistrationStep.ONE_CALL = one
+                rs = ops.RegistrationStep(src, tar, nl, transpose_r=tr, want_payload=True)
+                for _ in range(2):  # twice: the control words reset themselves
+                    loss, gR, gt, pay, info = rs(R, T, ln, grad_loss=gl)
+                torch.cuda.synchronize()
+                res[one] = [t.cpu().numpy().copy() for t in (loss, rs.st.med, info, rs.st.bcnt, rs.st.bsum, gR, gt, pay)]
+            for a, b_ in zip(res[False][:5], res[True][:5]):
+                np.testing.assert_array_equal(a.view(np.uint8), b_.view(np.uint8))
+            for a, b_ in zip(res[False][5:], res[True][5:]):
+                np.testing.assert_allclose(b_, a, rtol=2e-5, atol=2e-6 * float(np.abs(a).max()) + 1e-12)
+            nsel = res[True][2][:, 1]
+            assert nsel[0] > 0 and (case != "empty_sample" or nsel[1] == 0)
+            if case == "dense_tiles":
+                assert int(rs.st.blkcnt[:B * 3].max()) > 256
+            assert res[True][7][1] == float((res[True][2][:, 0] > 0).sum())  # payload[1] = number of valid samples
+            assert res[True][7][1] == (2.0 if case == "empty_sample" else 3.0)
+    finally:
+        ops.RegistrationStep.ONE_CALL = True
+        ops.set_reduce_mode("auto")
 
 
 def test_fused_registration_op(L):

@@ -30,6 +30,7 @@ for b, p in enumerate(prs):
 ln = torch.stack(ln)
 R = torch.eye(3, device="cuda").repeat(B, 1, 1)
 t = torch.zeros(B, 3, device="cuda")
+ops.RegistrationStep.ONE_CALL = os.environ.get("RRL_ONE_CALL", "1") != "0"
 rs = ops.RegistrationStep(src, tar, L, transpose_r=True, mode=os.environ.get("RRL_SCAN_MODE", "cull"))
 for _ in range(10):
     rs(R, t, ln)
