@@ -1394,10 +1394,38 @@ __global__ __launch_bounds__(TAIL_LANES) void loss_tail_kernel(const TailArgs a)
         atomicAdd(&s_sum[bi * 2 + 0], (unsigned long long)((double)row * (double)(1ll << FIX_SHIFT) + 0.5));
         atomicAdd(&s_sum[bi * 2 + 1], (unsigned long long)((double)col * (double)(1ll << FIX_SHIFT) + 0.5));
     }
+    // (the block sizes of the wavefront's lines bound the exponentials of the Welsch tile: uniform, taken with all lanes on)
+    const int kmax = (int)wave_max((float)k), jmax = (int)wave_max((float)j);
     if (bwd_live && C > 0) {
-        float rowmin[4], colmin[4];
         int arg_b[4], arg_a[4];
-        welsch_block(Dm, med, rowmin, colmin, arg_b, arg_a);
+        {   // welsch_block on the entries a < kmax, b < jmax (the others are +inf padding in every lane)
+            float Wl[16];
+#pragma unroll
+            for (int aa = 0; aa < RRL_MAX_HITS; ++aa)
+#pragma unroll
+                for (int bb = 0; bb < RRL_MAX_HITS; ++bb) {
+                    Wl[aa * 4 + bb] = INFINITY;
+                    if (aa < kmax && bb < jmax) Wl[aa * 4 + bb] = Dm[aa * 4 + bb] < INFINITY ? welsch(Dm[aa * 4 + bb], med) : INFINITY;
+                }
+#pragma unroll
+            for (int aa = 0; aa < RRL_MAX_HITS; ++aa) {
+                float best = Wl[aa * 4];
+                int m = 0;
+#pragma unroll
+                for (int bb = 1; bb < RRL_MAX_HITS; ++bb)
+                    if (Wl[aa * 4 + bb] < best) { best = Wl[aa * 4 + bb]; m = bb; }
+                arg_b[aa] = m;
+            }
+#pragma unroll
+            for (int bb = 0; bb < RRL_MAX_HITS; ++bb) {
+                float best = Wl[bb];
+                int m = 0;
+#pragma unroll
+                for (int aa = 1; aa < RRL_MAX_HITS; ++aa)
+                    if (Wl[aa * 4 + bb] < best) { best = Wl[aa * 4 + bb]; m = aa; }
+                arg_a[bb] = m;
+            }
+        }
         const int S = s_cnt[(k - 1) * 4 + (j - 1)];
         const float wkj = expf(-0.5f * (float)abs(k - j));
         const float scale = gl_in * wkj / (float)C;
@@ -1447,50 +1475,58 @@ __global__ __launch_bounds__(TAIL_LANES) void loss_tail_kernel(const TailArgs a)
             for (int q = 0; q < 12; ++q) s_red[wave][q] = acc[q];
     }
     __syncthreads();
-    if (tid < 32) {
-        const unsigned long long v = s_sum[tid];
-        if (v) atomicAdd(&a.msum[(size_t)b * 32 + tid], v);
-    }
-    if (tid == 32 && s_flag[1]) atomicOr(&ctl[MCTL_BAD], 1u);
-    if (do_bwd && mycnt > 0 && tid >= 64 && tid < 76) {
-        const int q = tid - 64;
+    // ---- from here on wavefront 1 adds the workgroup's gradient sums and wavefront 0 does everything else by itself (its
+    //      lanes see each other's LDS writes in program order: no workgroup barrier any more); the rest is done
+    if (wave == 1 && do_bwd && mycnt > 0 && lane < 12) {
+        const int q = lane;
         const float v = (s_red[0][q] + s_red[1][q]) + (s_red[2][q] + s_red[3][q]);
         int o = q;  // m-index (i, j) -> memory order of R
         if (q < 9 && a.transpose_r) o = (q % 3) * 3 + q / 3;
         if (q < 9) atomicAdd(&a.gR[b * 9 + o], v); else atomicAdd(&a.gt[b * 3 + (q - 9)], v);
         if (a.payload) atomicAdd(&a.payload[2 + o], v);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0)
-        s_flag[0] = __hip_atomic_fetch_add(&ctl[MCTL_TICK2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(nlive - 1) ? 1u : 0u;
-    __syncthreads();
-    if (!s_flag[0]) return;
+    if (wave != 0) return;
+    if (lane < 32) {
+        const unsigned long long v = s_sum[lane];
+        if (v) atomicAdd(&a.msum[(size_t)b * 32 + lane], v);
+    }
+    if (lane == 32 && s_flag[1]) atomicOr(&ctl[MCTL_BAD], 1u);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wavefront's sums have arrived before it takes its ticket
+    unsigned last = 0;
+    if (lane == 0)
+        last = __hip_atomic_fetch_add(&ctl[MCTL_TICK2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(nlive - 1) ? 1u : 0u;
+    if (!__builtin_amdgcn_readfirstlane((int)last)) return;
 
     // ---- the last workgroup of the sample: loss = ( sum_{non-empty (k,j), k-major} exp(-|k-j|/2) (mean_row + mean_col) ) / C
-    if (tid < 32) {
-        const unsigned long long v = __hip_atomic_load(&a.msum[(size_t)b * 32 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_sum[tid] = v;
-        a.bsum_out[(size_t)b * 32 + tid] = (int64_t)v;
-        __hip_atomic_store(&a.msum[(size_t)b * 32 + tid], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // a second reduce on this state starts clean
+    unsigned long long tot = 0ull;
+    unsigned anybad = 0u;
+    if (lane < 32) {
+        tot = __hip_atomic_load(&a.msum[(size_t)b * 32 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        a.bsum_out[(size_t)b * 32 + lane] = (int64_t)tot;
+        __hip_atomic_store(&a.msum[(size_t)b * 32 + lane], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // a second reduce on this state starts clean
+    } else if (lane < 48) {
+        a.bcnt_out[b * 16 + lane - 32] = s_cnt[lane - 32];
+    } else if (lane == 48) {
+        anybad = ld_agent(&ctl[MCTL_BAD]);
     }
-    if (tid >= 32 && tid < 48) a.bcnt_out[b * 16 + tid - 32] = s_cnt[tid - 32];
-    if (tid == 48 && ld_agent(&ctl[MCTL_BAD])) atomicOr(&s_flag[1], 2u);
-    __syncthreads();
-    if (tid < 16) {  // one lane per bucket: the double-precision means (as reduce_body)
-        const int kk = tid / 4 + 1, jj = tid % 4 + 1, S = s_cnt[tid];
-        float term = 0.0f;
+    const bool bad = __builtin_amdgcn_readlane((int)anybad, 48) != 0;
+    // lane 2 q + c holds sum c (row / column) of bucket q: one lane per bucket takes both (the double-precision means, as
+    // reduce_body)
+    const unsigned long long trow = __shfl(tot, (2 * lane) & 63), tcol = __shfl(tot, (2 * lane + 1) & 63);
+    float term = 0.0f;
+    if (lane < 16) {
+        const int kk = lane / 4 + 1, jj = lane % 4 + 1, S = s_cnt[lane];
         if (S > 0 && kk >= a.s_m && kk < a.e_m && jj >= a.s_n && jj < a.e_n) {
             const double sc = 1.0 / (double)(1ll << FIX_SHIFT);
-            float mrow = (float)((double)s_sum[tid * 2 + 0] * sc / ((double)S * kk));
-            float mcol = (float)((double)s_sum[tid * 2 + 1] * sc / ((double)S * jj));
+            float mrow = (float)((double)trow * sc / ((double)S * kk));
+            float mcol = (float)((double)tcol * sc / ((double)S * jj));
             float wkj = expf(-0.5f * (float)abs(kk - jj));  // code/loss.py:215
             term = wkj * (mrow + mcol);
         }
-        s_term[tid] = term;
+        s_term[lane] = term;
     }
-    __syncthreads();
-    if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (lane == 0) {
         float accl = 0.0f;
         int Cn = 0, nselected = 0, nvalues = 0;
         for (int kk = a.s_m; kk < a.e_m; ++kk)      // k-major, the reference's accumulation order
@@ -1502,7 +1538,6 @@ __global__ __launch_bounds__(TAIL_LANES) void loss_tail_kernel(const TailArgs a)
                 nselected += s_cnt[bi];
             }
         for (int bi = 0; bi < 16; ++bi) nvalues += s_cnt[bi] * (bi / 4 + 1) * (bi % 4 + 1);
-        const bool bad = (s_flag[1] & 2u) != 0u;
         const float lv = bad ? __builtin_nanf("") : (Cn ? accl / (float)Cn : 0.0f);  // code/loss.py:230
         a.med_out[b] = med;
         a.loss[b] = lv;
