@@ -1430,17 +1430,18 @@ def test_tiled_reduce_equals_single_workgroup(L, case):
     assert out["single"][2][:, 1].sum() > 0  # lines were selected
 
 
-@pytest.mark.parametrize("case", ["batch", "dense_tiles", "one_tile_forced", "empty_sample"])
+@pytest.mark.parametrize("case", ["batch", "dense_tiles", "long_lists", "one_tile_forced", "empty_sample"])
 def test_step_in_one_call_equals_forward_then_backward(L, case):
     """rrl_registration_step (the direct backward inside the tail kernel's launch) against rrl_registration_forward +
     rrl_registration_backward: loss, median, info, bucket sums bit for bit; dR, dt, payload to the rounding of their float
     atomics -- a batch with 3-5 line tiles per sample, tiles with more than 256 selected lines (the kernel's second
-    pass over a tile, and the crowded-bin route of the median), a single tile (tail kernel forced), a sample whose lines hit nothing; with and without payload,
+    pass over a tile, and the crowded-bin route of the median), value lists longer than one streaming round
+    of the kernel (32 tiles per sample), a single tile (tail kernel forced), a sample whose lines hit nothing; with and without payload,
     both R layouts, non-unit dL/dloss."""
     from rrl_hip import ops, synth
     from LieAlgebra import se3
     B = 3
-    nl = {"batch": 4500, "dense_tiles": 2600, "one_tile_forced": 900, "empty_sample": 3000}[case]
+    nl = {"batch": 4500, "dense_tiles": 2600, "long_lists": 32000, "one_tile_forced": 900, "empty_sample": 3000}[case]
     gen = torch.Generator().manual_seed(2)
     R, T = se3.exp3(0.03 * torch.randn(B, 6, generator=gen))
     if case == "dense_tiles":  # two tiny triangles per cloud, every line through the first: ~1000 selected lines per tile,
@@ -1459,8 +1460,9 @@ def test_step_in_one_call_equals_forward_then_backward(L, case):
         ln = []
         for b, p in enumerate(prs):
             torch.manual_seed(b)
+            rad = float(p["radius"]) * (0.75 if case == "long_lists" else 1.0)  # a tighter sphere: more lines through both clouds
             ln.append(L.Random_uniform_distribution_lines_batch_efficient_resample(
-                torch.tensor([[float(p["radius"])]]), torch.from_numpy(p["center"]).reshape(1, 3), nl, cu(p["src"])[None],
+                torch.tensor([[rad]]), torch.from_numpy(p["center"]).reshape(1, 3), nl, cu(p["src"])[None],
                 cu(p["tar"])[None], "cuda")[0])
         ln = torch.stack(ln)
     if case == "empty_sample":
@@ -1468,7 +1470,7 @@ def test_step_in_one_call_equals_forward_then_backward(L, case):
     R, T = R.cuda().contiguous(), T.cuda().contiguous()
     gl = torch.tensor([1.0, 0.5, 2.0], device="cuda")
     try:
-        if case == "one_tile_forced":
+        if case in ("one_tile_forced", "long_lists"):  # (long_lists: 32 tiles per sample, beyond the automatic choice's 16)
             ops.set_reduce_mode("tiled")
         for tr in (True, False):
             res = {}
@@ -1487,6 +1489,9 @@ def test_step_in_one_call_equals_forward_then_backward(L, case):
             assert nsel[0] > 0 and (case != "empty_sample" or nsel[1] == 0)
             if case == "dense_tiles":
                 assert int(rs.st.blkcnt[:B * 3].max()) > 256
+            if case == "long_lists":  # more than the 8192 values one streaming round of the tail kernel covers, and a median
+                assert int(rs.st.vlcnt[:B * 32].reshape(B, 32).sum(1).max()) > 8192  # bin that is NOT crowded (the usual route)
+                assert int(rs.st.mhist.max()) <= 2048
             assert res[True][7][1] == float((res[True][2][:, 0] > 0).sum())  # payload[1] = number of valid samples
             assert res[True][7][1] == (2.0 if case == "empty_sample" else 3.0)
     finally:
