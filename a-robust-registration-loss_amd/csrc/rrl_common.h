@@ -154,6 +154,12 @@ __device__ __forceinline__ int wave_sum_i(int v) {
     return __builtin_amdgcn_readlane(wave_incl_scan(v), 63);
 }
 
+// the value of lane A of every quad of four lanes (DPP quad_perm [A, A, A, A]; the source lanes must be active)
+template <int A>
+__device__ __forceinline__ float quad_bcast(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), A * 0x55, 0xf, 0xf, true));
+}
+
 // all-reduce inside each row of 16 lanes (butterfly on DPP: quad_perm [1,0,3,2], [2,3,0,1],
 // row_half_mirror, row_mirror); every lane of the row receives the result
 #define RRL_DPP_F(v, ctrl) \

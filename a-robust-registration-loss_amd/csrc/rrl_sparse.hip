@@ -1174,17 +1174,15 @@ __global__ __launch_bounds__(TAIL_LANES) void loss_tail_kernel(const TailArgs a)
     int r = sub * TAIL_LINES + (tid >> 2);  // compact rank within the tile of this lane's line (lanes < 256); first chunk
     bool mine_on = tid < 4 * TAIL_LINES && r < mycnt;
     unsigned kl = 0u;
-    float Dm[16];
+    float dr[4];  // row h of the line's canonical D tile (the four lanes of a line hold one row each)
     auto load_line = [&]() {
         kl = 0u;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) Dm[q] = INFINITY;
+        for (int q = 0; q < 4; ++q) dr[q] = INFINITY;
         if (mine_on) {
             kl = lidc[slot0 + r];
-            const float4 *row = (const float4 *)(dc + (slot0 + r) * 16);
-            const float4 v0 = row[0], v1 = row[1], v2 = row[2], v3 = row[3];
-            Dm[0] = v0.x; Dm[1] = v0.y; Dm[2] = v0.z; Dm[3] = v0.w; Dm[4] = v1.x; Dm[5] = v1.y; Dm[6] = v1.z; Dm[7] = v1.w;
-            Dm[8] = v2.x; Dm[9] = v2.y; Dm[10] = v2.z; Dm[11] = v2.w; Dm[12] = v3.x; Dm[13] = v3.y; Dm[14] = v3.z; Dm[15] = v3.w;
+            const float4 v = ((const float4 *)(dc + (slot0 + r) * 16))[h];
+            dr[0] = v.x; dr[1] = v.y; dr[2] = v.z; dr[3] = v.w;
         }
     };
     load_line();
@@ -1381,51 +1379,73 @@ __global__ __launch_bounds__(TAIL_LANES) void loss_tail_kernel(const TailArgs a)
         request_line();
         request_source();
     }
-    if (mine_on && h == 0) {
-        float row = 0.0f, col = 0.0f;
+    int arg_b_own = 0, arg_a[4] = {0, 0, 0, 0};
+    float er[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // exp(-(D[h][b] / med) / 2): row h of the tile
+    if (wave < 4) {  // uniform: the wavefronts that hold lines.  Every lane of them takes part (the four lanes of a line
+        // exchange by quad DPP, which reads active lanes only): lanes without a line carry +inf tiles and k = j = 0.
+        // The Welsch tile of a line is SHARED by its four lanes: lane h evaluates row h -- <= 4 exponentials and
+        // divisions instead of the 16 + 8 every lane of loss_bwd_rt_kernel / reduce_core::accumulate spends -- and
+        //   * the line's Welsch terms are those of the row / column minima of D (Welsch1 is evaluated by the same
+        //     instructions on the same input: the entry that holds the minimum of D holds Welsch1(min D), bit for bit),
+        //   * the gradient's exp(-(D/med)/2) is the very value 1 - Welsch1 was formed from.
+        const int jmax = (int)wave_max((float)j);  // bounds the columns worth evaluating (uniform)
+        float wr[4];
 #pragma unroll
-        for (int q = 0; q < RRL_MAX_HITS; ++q)
-            if (q < k) row += welsch(fminf(fminf(Dm[q * 4], Dm[q * 4 + 1]), fminf(Dm[q * 4 + 2], Dm[q * 4 + 3])), med);
-#pragma unroll
-        for (int q = 0; q < RRL_MAX_HITS; ++q)
-            if (q < j) col += welsch(fminf(fminf(Dm[q], Dm[4 + q]), fminf(Dm[8 + q], Dm[12 + q])), med);
-        if (!(row <= 4.0f) || !(col <= 4.0f)) { atomicOr(&s_flag[1], 1u); row = col = 0.0f; }
-        const int bi = (k - 1) * 4 + (j - 1);
-        atomicAdd(&s_sum[bi * 2 + 0], (unsigned long long)((double)row * (double)(1ll << FIX_SHIFT) + 0.5));
-        atomicAdd(&s_sum[bi * 2 + 1], (unsigned long long)((double)col * (double)(1ll << FIX_SHIFT) + 0.5));
-    }
-    // (the block sizes of the wavefront's lines bound the exponentials of the Welsch tile: uniform, taken with all lanes on)
-    const int kmax = (int)wave_max((float)k), jmax = (int)wave_max((float)j);
-    if (bwd_live && C > 0) {
-        int arg_b[4], arg_a[4];
-        {   // welsch_block on the entries a < kmax, b < jmax (the others are +inf padding in every lane)
-            float Wl[16];
-#pragma unroll
-            for (int aa = 0; aa < RRL_MAX_HITS; ++aa)
-#pragma unroll
-                for (int bb = 0; bb < RRL_MAX_HITS; ++bb) {
-                    Wl[aa * 4 + bb] = INFINITY;
-                    if (aa < kmax && bb < jmax) Wl[aa * 4 + bb] = Dm[aa * 4 + bb] < INFINITY ? welsch(Dm[aa * 4 + bb], med) : INFINITY;
-                }
-#pragma unroll
-            for (int aa = 0; aa < RRL_MAX_HITS; ++aa) {
-                float best = Wl[aa * 4];
-                int m = 0;
-#pragma unroll
-                for (int bb = 1; bb < RRL_MAX_HITS; ++bb)
-                    if (Wl[aa * 4 + bb] < best) { best = Wl[aa * 4 + bb]; m = bb; }
-                arg_b[aa] = m;
-            }
-#pragma unroll
-            for (int bb = 0; bb < RRL_MAX_HITS; ++bb) {
-                float best = Wl[bb];
-                int m = 0;
-#pragma unroll
-                for (int aa = 1; aa < RRL_MAX_HITS; ++aa)
-                    if (Wl[aa * 4 + bb] < best) { best = Wl[aa * 4 + bb]; m = aa; }
-                arg_a[bb] = m;
+        for (int bb = 0; bb < RRL_MAX_HITS; ++bb) {
+            const float d = dr[bb];
+            wr[bb] = INFINITY;
+            if (bb < jmax) {
+                const float e = expf(-(d / med) / 2.0f);  // == welsch(): 1 - e
+                er[bb] = e;
+                if (d < INFINITY) wr[bb] = 1.0f - e;
             }
         }
+        // row h: first-occurrence argmin of the Welsch values (the gradient's routing, welsch_block), and the Welsch value
+        // of the row's smallest D (the line's row term)
+        float bestw = wr[0];
+#pragma unroll
+        for (int bb = 1; bb < RRL_MAX_HITS; ++bb)
+            if (wr[bb] < bestw) { bestw = wr[bb]; arg_b_own = bb; }
+        const float dmin = fminf(fminf(dr[0], dr[1]), fminf(dr[2], dr[3]));
+        const float rowterm = dr[0] == dmin ? wr[0] : (dr[1] == dmin ? wr[1] : (dr[2] == dmin ? wr[2] : wr[3]));
+        // the whole Welsch tile and the whole D tile, from the other three lanes of the line
+        float W[16], Dm[16];
+#pragma unroll
+        for (int bb = 0; bb < RRL_MAX_HITS; ++bb) {
+            W[0 + bb] = quad_bcast<0>(wr[bb]); W[4 + bb] = quad_bcast<1>(wr[bb]);
+            W[8 + bb] = quad_bcast<2>(wr[bb]); W[12 + bb] = quad_bcast<3>(wr[bb]);
+            Dm[0 + bb] = quad_bcast<0>(dr[bb]); Dm[4 + bb] = quad_bcast<1>(dr[bb]);
+            Dm[8 + bb] = quad_bcast<2>(dr[bb]); Dm[12 + bb] = quad_bcast<3>(dr[bb]);
+        }
+        float colterm[4];
+#pragma unroll
+        for (int bb = 0; bb < RRL_MAX_HITS; ++bb) {
+            float best = W[bb];
+            int m = 0;
+#pragma unroll
+            for (int aa = 1; aa < RRL_MAX_HITS; ++aa)
+                if (W[aa * 4 + bb] < best) { best = W[aa * 4 + bb]; m = aa; }
+            arg_a[bb] = m;
+            const float cmin = fminf(fminf(Dm[bb], Dm[4 + bb]), fminf(Dm[8 + bb], Dm[12 + bb]));
+            colterm[bb] = Dm[bb] == cmin ? W[bb] : (Dm[4 + bb] == cmin ? W[4 + bb] : (Dm[8 + bb] == cmin ? W[8 + bb] : W[12 + bb]));
+        }
+        const float rt0 = quad_bcast<0>(rowterm), rt1 = quad_bcast<1>(rowterm), rt2 = quad_bcast<2>(rowterm), rt3 = quad_bcast<3>(rowterm);
+        if (mine_on && h == 0) {  // the line's Welsch terms, summed in reduce_core::accumulate's order
+            float row = 0.0f, col = 0.0f;
+            if (0 < k) row += rt0;
+            if (1 < k) row += rt1;
+            if (2 < k) row += rt2;
+            if (3 < k) row += rt3;
+#pragma unroll
+            for (int q = 0; q < RRL_MAX_HITS; ++q)
+                if (q < j) col += colterm[q];
+            if (!(row <= 4.0f) || !(col <= 4.0f)) { atomicOr(&s_flag[1], 1u); row = col = 0.0f; }
+            const int bi = (k - 1) * 4 + (j - 1);
+            atomicAdd(&s_sum[bi * 2 + 0], (unsigned long long)((double)row * (double)(1ll << FIX_SHIFT) + 0.5));
+            atomicAdd(&s_sum[bi * 2 + 1], (unsigned long long)((double)col * (double)(1ll << FIX_SHIFT) + 0.5));
+        }
+    }
+    if (bwd_live && C > 0) {
         const int S = s_cnt[(k - 1) * 4 + (j - 1)];
         const float wkj = expf(-0.5f * (float)abs(k - j));
         const float scale = gl_in * wkj / (float)C;
@@ -1435,17 +1455,10 @@ __global__ __launch_bounds__(TAIL_LANES) void loss_tail_kernel(const TailArgs a)
         for (int o = 0; o < RRL_MAX_HITS; ++o) {
             if (o >= j) continue;
             float sw = 0.0f;
-#pragma unroll
-            for (int x = 0; x < RRL_MAX_HITS; ++x) {  // static indexing of arg_b / arg_a
-                if (x == h && arg_b[x] == o) sw += inv_row;
-                if (x == o && arg_a[x] == h) sw += inv_col;
-            }
+            if (arg_b_own == o) sw += inv_row;
+            if (arg_a[o] == h) sw += inv_col;
             if (sw == 0.0f) continue;
-            float dho = 0.0f;  // D[h][o] with static indices
-#pragma unroll
-            for (int x = 0; x < RRL_MAX_HITS; ++x)
-                if (x == h) dho = Dm[x * 4 + o];
-            const float gD = scale * sw * expf(-(dho / med) / 2.0f) / (2.0f * med);
+            const float gD = scale * sw * er[o] / (2.0f * med);  // er[o] = exp(-(D[h][o] / med) / 2)
             gq[0] += 2.0f * (q1.x - qx[o]) * gD;
             gq[1] += 2.0f * (q1.y - qy[o]) * gD;
             gq[2] += 2.0f * (q1.z - qz[o]) * gD;
