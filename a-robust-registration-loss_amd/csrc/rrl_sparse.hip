@@ -1828,55 +1828,97 @@ __global__ __launch_bounds__(256) void loss_bwd_rt_kernel(
 #pragma unroll
     for (int q = 0; q < 12; ++q) acc[q] = 0.0f;
     const int C = info[b * 4];
-    if (li >= 0 && C > 0) {
-        const size_t gl = (size_t)b * L + li;
-        const unsigned c = kj[gl];
-        const int k = c & 15, j = c >> 4;
-        if (h < k) {
-            const float m = med[b];
-            float Dm[16], rowmin[4], colmin[4];
-            int arg_b[4], arg_a[4];
-            load_block(D + gl * 16, k, j, Dm);
-            welsch_block(Dm, m, rowmin, colmin, arg_b, arg_a);
-            const int S = bcnt[b * 16 + (k - 1) * 4 + (j - 1)];
-            const float wkj = expf(-0.5f * (float)abs(k - j));
-            const float scale = grad_loss[b] * wkj / (float)C;
-            const float inv_row = 1.0f / ((float)S * (float)k), inv_col = 1.0f / ((float)S * (float)j);
-            const float4 mine = Q1[gl * 4 + h];
-            float gq[3] = {0.0f, 0.0f, 0.0f};
+    // The four lanes of a line SHARE its Welsch tile (round 3): lane h evaluates row h -- <= 4 exponentials and divisions
+    // where every lane used to evaluate all 16 entries -- and the rows travel by quad DPP; all lanes take part (DPP
+    // reads active lanes only), lanes without a line or hit slot carry +inf rows and k = j = 0.  Same expressions, same
+    // first-occurrence minima, same results as welsch_block on the whole tile.
+    const bool valid = li >= 0 && C > 0;
+    const size_t gl = (size_t)b * L + (valid ? li : 0);
+    const unsigned c = valid ? kj[gl] : 0u;
+    const int k = c & 15, j = c >> 4;
+    const bool live = valid && h < k;
+    const float m = med[b];
+    float dr[4] = {INFINITY, INFINITY, INFINITY, INFINITY};
+    float4 mine = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    float qx[4] = {0.0f, 0.0f, 0.0f, 0.0f}, qy[4] = {0.0f, 0.0f, 0.0f, 0.0f}, qz[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    float wq[3] = {0.0f, 0.0f, 0.0f}, xs[9] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    int S = 1;
+    if (live) {
 #pragma unroll
-            for (int o = 0; o < RRL_MAX_HITS; ++o) {
-                if (o >= j) continue;
-                float sw = 0.0f;
-#pragma unroll
-                for (int x = 0; x < RRL_MAX_HITS; ++x) {  // static indexing of arg_b / arg_a
-                    if (x == h && arg_b[x] == o) sw += inv_row;
-                    if (x == o && arg_a[x] == h) sw += inv_col;
-                }
-                if (sw == 0.0f) continue;
-                // same expressions as loss_bwd_kernel
-                const float gD = scale * sw * expf(-(D[gl * 16 + h * j + o] / m) / 2.0f) / (2.0f * m);
-                const float4 other = Q2[gl * 4 + o];
-                gq[0] += 2.0f * (mine.x - other.x) * gD;
-                gq[1] += 2.0f * (mine.y - other.y) * gD;
-                gq[2] += 2.0f * (mine.z - other.z) * gD;
+        for (int o = 0; o < RRL_MAX_HITS; ++o)
+            if (o < j) {
+                dr[o] = D[gl * 16 + h * j + o];
+                const float4 t = Q2[gl * 4 + o];
+                qx[o] = t.x; qy[o] = t.y; qz[o] = t.z;
             }
-            const int f = hs1[gl * 4 + h];
-            const float *w = w1 + (gl * 4 + h) * 3;
-            const float *x = src + ((size_t)b * N + f) * 9;
+        S = bcnt[b * 16 + (k - 1) * 4 + (j - 1)];
+        mine = Q1[gl * 4 + h];
+        const int f = hs1[gl * 4 + h];
+        const float *w = w1 + (gl * 4 + h) * 3;
 #pragma unroll
-            for (int kk = 0; kk < 3; ++kk) {
-                const float wk = w[kk] / 3.0f;  // q = mean_k(w_k P_k)
-                float gv[3];
+        for (int q = 0; q < 3; ++q) wq[q] = w[q];
+        const float *x = src + ((size_t)b * N + f) * 9;
 #pragma unroll
-                for (int cc = 0; cc < 3; ++cc) gv[cc] = wk * gq[cc];
+        for (int q = 0; q < 9; ++q) xs[q] = x[q];
+    }
+    const int jmax = (int)wave_max((float)j);  // uniform
+    float er[4] = {0.0f, 0.0f, 0.0f, 0.0f}, wr[4];
 #pragma unroll
-                for (int cc = 0; cc < 3; ++cc) {
-                    const float xc = x[3 * kk + cc];
+    for (int o = 0; o < RRL_MAX_HITS; ++o) {
+        wr[o] = INFINITY;
+        if (o < jmax) {
+            const float e = expf(-(dr[o] / m) / 2.0f);  // == welsch(): 1 - e
+            er[o] = e;
+            if (dr[o] < INFINITY) wr[o] = 1.0f - e;
+        }
+    }
+    int arg_b_own = 0, arg_a[4];
+    {
+        float bestw = wr[0];
 #pragma unroll
-                    for (int jj = 0; jj < 3; ++jj) acc[cc * 3 + jj] = fmaf(xc, gv[jj], acc[cc * 3 + jj]);
-                    acc[9 + cc] += gv[cc];
-                }
+        for (int o = 1; o < RRL_MAX_HITS; ++o)
+            if (wr[o] < bestw) { bestw = wr[o]; arg_b_own = o; }
+#pragma unroll
+        for (int o = 0; o < RRL_MAX_HITS; ++o) {
+            const float w0 = quad_bcast<0>(wr[o]), w1_ = quad_bcast<1>(wr[o]), w2_ = quad_bcast<2>(wr[o]), w3 = quad_bcast<3>(wr[o]);
+            float best = w0;
+            int mm = 0;
+            if (w1_ < best) { best = w1_; mm = 1; }
+            if (w2_ < best) { best = w2_; mm = 2; }
+            if (w3 < best) { best = w3; mm = 3; }
+            arg_a[o] = mm;
+        }
+    }
+    if (live) {
+        const float wkj = expf(-0.5f * (float)abs(k - j));
+        const float scale = grad_loss[b] * wkj / (float)C;
+        const float inv_row = 1.0f / ((float)S * (float)k), inv_col = 1.0f / ((float)S * (float)j);
+        float gq[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int o = 0; o < RRL_MAX_HITS; ++o) {
+            if (o >= j) continue;
+            float sw = 0.0f;
+            if (arg_b_own == o) sw += inv_row;
+            if (arg_a[o] == h) sw += inv_col;
+            if (sw == 0.0f) continue;
+            // same expressions as loss_bwd_kernel
+            const float gD = scale * sw * er[o] / (2.0f * m);
+            gq[0] += 2.0f * (mine.x - qx[o]) * gD;
+            gq[1] += 2.0f * (mine.y - qy[o]) * gD;
+            gq[2] += 2.0f * (mine.z - qz[o]) * gD;
+        }
+#pragma unroll
+        for (int kk = 0; kk < 3; ++kk) {
+            const float wk = wq[kk] / 3.0f;  // q = mean_k(w_k P_k)
+            float gv[3];
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc) gv[cc] = wk * gq[cc];
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc) {
+                const float xc = xs[3 * kk + cc];
+#pragma unroll
+                for (int jj = 0; jj < 3; ++jj) acc[cc * 3 + jj] = fmaf(xc, gv[jj], acc[cc * 3 + jj]);
+                acc[9 + cc] += gv[cc];
             }
         }
     }
