@@ -1694,28 +1694,59 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(
     const float *__restrict__ D, const float *__restrict__ med, const int32_t *__restrict__ bcnt,
     const int32_t *__restrict__ info, const float *__restrict__ grad_loss, float *__restrict__ g1,
     float *__restrict__ g2, int B, int N, int M, int L, int pool) {
-    // one lane per (selected line, side, hit slot): 8 lanes share a line, each owns <= 9 atomics
+    // one lane per (selected line, side, hit slot): 8 lanes share a line, each owns <= 9 atomics.  They also SHARE the
+    // line's Welsch tile (round 3): the lane of (cloud 1, hit a) evaluates row a, the lane of (cloud 2, hit b) column b --
+    // <= 4 exponentials and divisions where every lane used to evaluate all 16 entries (welsch_block) -- and the two
+    // quads swap their first-occurrence minima by DPP.  All lanes take part (DPP reads active lanes only); lanes
+    // without a line or hit carry +inf.  Same expressions and tie-breaks as welsch_block on the whole tile.
     const int t = blockIdx.x * 256 + threadIdx.x;
     const int b = blockIdx.y;
     const int i = t >> 3, side = (t >> 2) & 1, h = t & 3, g = pool ? 0 : b;
-    if (i >= L || (side && !g2)) return;
     // independent loads first (the grid covers every possible slot, ~9 % are live): SEL[i] is
     // read before nsel is known and clamped, so that kj -- the next link of the chain -- can be
     // requested one round trip earlier
     const int ns = nsel[b];
-    int li = sel[(size_t)b * L + i];
+    int li = i < L ? sel[(size_t)b * L + i] : 0;
     const int C = info[g * 4];
     const float m = med[g], gl_in = grad_loss[g];
     li = li < 0 ? 0 : (li >= L ? L - 1 : li);
     const size_t gl = (size_t)b * L + li;
-    const unsigned c = kj[gl];
-    if (i >= ns || C == 0) return;
+    const bool valid = i < L && i < ns && C > 0;
+    const unsigned c = valid ? kj[gl] : 0u;
     const int k = c & 15, j = c >> 4;
-    if (h >= (side ? j : k)) return;
-    float Dm[16], rowmin[4], colmin[4];
-    int arg_b[4], arg_a[4];
-    load_block(D + gl * 16, k, j, Dm);
-    welsch_block(Dm, m, rowmin, colmin, arg_b, arg_a);
+    const int mycnt = side ? j : k, ocnt = side ? k : j;  // this lane's hit slots, the other cloud's
+    const bool live = valid && h < mycnt && !(side && !g2);
+    float d[4] = {INFINITY, INFINITY, INFINITY, INFINITY};
+    if (valid && h < mycnt) {
+#pragma unroll
+        for (int o = 0; o < RRL_MAX_HITS; ++o)
+            if (o < ocnt) d[o] = D[gl * 16 + (side ? o * j + h : h * j + o)];  // row h (cloud 1) / column h (cloud 2)
+    }
+    const int omax = (int)wave_max((float)(k > j ? k : j));  // uniform
+    float er[4] = {0.0f, 0.0f, 0.0f, 0.0f}, wr[4];
+#pragma unroll
+    for (int o = 0; o < RRL_MAX_HITS; ++o) {
+        wr[o] = INFINITY;
+        if (o < omax) {
+            const float e = expf(-(d[o] / m) / 2.0f);  // == welsch(): 1 - e
+            er[o] = e;
+            if (d[o] < INFINITY) wr[o] = 1.0f - e;
+        }
+    }
+    int own = 0;  // first-occurrence argmin of this row / column
+    {
+        float bestw = wr[0];
+#pragma unroll
+        for (int o = 1; o < RRL_MAX_HITS; ++o)
+            if (wr[o] < bestw) { bestw = wr[o]; own = o; }
+    }
+    // the other quad's minima: lane (side, .) reads lane (1 - side, .) of its line, then slot o of that quad
+    const int up = __builtin_amdgcn_update_dpp(0, own, 0x104, 0xf, 0xf, true);  // row_shl:4: from lane + 4
+    const int dn = __builtin_amdgcn_update_dpp(0, own, 0x114, 0xf, 0xf, true);  // row_shr:4: from lane - 4
+    const float oth = __int_as_float(side ? dn : up);
+    const int oarg[4] = {__float_as_int(quad_bcast<0>(oth)), __float_as_int(quad_bcast<1>(oth)),
+                         __float_as_int(quad_bcast<2>(oth)), __float_as_int(quad_bcast<3>(oth))};
+    if (!live) return;
     const int S = bcnt[g * 16 + (k - 1) * 4 + (j - 1)];
     const float wkj = expf(-0.5f * (float)abs(k - j));
     const float scale = gl_in * wkj / (float)C;
@@ -1724,17 +1755,20 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(
     float gq[3] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
     for (int o = 0; o < RRL_MAX_HITS; ++o) {
-        if (o >= (side ? k : j)) continue;
-        const int a = side ? o : h, bb = side ? h : o;
+        if (o >= ocnt) continue;
+        // entry (a, bb) = (h, o) for cloud 1, (o, h) for cloud 2: it is the row minimum when arg_b[a] == bb and the column
+        // minimum when arg_a[bb] == a
         float sw = 0.0f;
-#pragma unroll
-        for (int x = 0; x < RRL_MAX_HITS; ++x) {  // static indexing of arg_b / arg_a
-            if (x == a && arg_b[x] == bb) sw += inv_row;
-            if (x == bb && arg_a[x] == a) sw += inv_col;
+        if (side) {
+            if (oarg[o] == h) sw += inv_row;  // arg_b[o] == h
+            if (own == o) sw += inv_col;      // arg_a[h] == o
+        } else {
+            if (own == o) sw += inv_row;      // arg_b[h] == o
+            if (oarg[o] == h) sw += inv_col;  // arg_a[o] == h
         }
         if (sw == 0.0f) continue;
         // dWl/dD = exp(-D/(2 med)) / (2 med);  dD/dq1 = 2 (q1 - q2) = -dD/dq2
-        const float gD = scale * sw * expf(-(D[gl * 16 + a * j + bb] / m) / 2.0f) / (2.0f * m);
+        const float gD = scale * sw * er[o] / (2.0f * m);
         const float4 other = (side ? Q1 : Q2)[gl * 4 + o];
         gq[0] += 2.0f * (mine.x - other.x) * gD;
         gq[1] += 2.0f * (mine.y - other.y) * gD;
