@@ -504,15 +504,16 @@ def registration_loss(src_tri, R, t, tar_tri, line, rng=(1, 1, 5, 5), transpose_
 
 
 class RegistrationStep:
-    """The fused training op WITHOUT autograd and without a graph: forward + backward to (dR, dt) as two C calls
-    on buffers allocated once -- what a training loop needs when (R, t) come out of a network:
+    """The fused training op WITHOUT autograd and without a graph: forward + backward to (dR, dt) as ONE C call
+    (rrl_registration_step: where the tail kernel serves the shape the backward rides in the reduce's launch, 5 launches
+    per step) on buffers allocated once -- what a training loop needs when (R, t) come out of a network:
 
         step = ops.RegistrationStep(src_tri, tar_tri, L)            # once per shape
         loss, gR, gt = step(R.detach(), t.detach(), lines)[:3]      # every iteration (gout = ones)
         torch.autograd.backward([R, t], [gR, gt])                   # hand the gradient to the network
 
-    Issued this way the C2 step is GPU-bound at 74 us (about 30 us of host time per step); replaying the
-    same launches as a hipGraph costs 79 us (a replay has ~8 us of fixed cost + 1.5 us per node on this
+    Issued this way the C2 step is GPU-bound at 70 us (about 30 us of host time per step); replaying the
+    launches as a hipGraph costs 76 us (a replay has ~8 us of fixed cost + 1.5 us per node on this
     stack, tools/graph_node_cost.py), and the autograd front end (registration_loss) is host-bound when
     issued eagerly.  Same kernels, same numbers as registration_loss.  The outputs are views of buffers
     that the next call overwrites.  want_payload: also the 14-float batch-shard payload (rrl_hip.dist)."""

@@ -177,7 +177,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--issue", choices=["auto", "graph", "direct"], default="auto",
-                    help="how the step's launches are issued: one hipGraph replay, or the two C calls of "
+                    help="how the step's launches are issued: one hipGraph replay, or the C call of "
                          "ops.RegistrationStep on the stream (no autograd, no graph); auto measures both in warm-up")
     ap.add_argument("--no-extras", action="store_true", help="skip the strict / counter / drop-in passes")
     ap.add_argument("--no-dist", action="store_true",
@@ -239,7 +239,7 @@ def main():
     rstep = [None]
 
     def direct_step():
-        # the same launches as local_step, issued as two C calls on preallocated buffers (ops.RegistrationStep)
+        # the same launches as local_step, issued by one C call on preallocated buffers (ops.RegistrationStep -> rrl_registration_step)
         if rstep[0] is None:
             rstep[0] = ops.RegistrationStep(w["tri1"], w["tri2"], L, transpose_r=True, mode=args.mode, want_payload=True)
             rstep[0].Rd, rstep[0].Td = w["R"].detach(), w["T"].detach()
@@ -563,7 +563,7 @@ def main():
                                    f"(BASELINE.json configs[{2 if strong else 1}]); fused training op "
                                    f"(rigid apply + loss, backward to dR, dT); scan mode {args.mode}; "
                                    + ("hipGraph replay" if graphed is not None else
-                                      ("two C calls per step on the stream (ops.RegistrationStep: no autograd node, no graph)"
+                                      ("one C call per step on the stream (ops.RegistrationStep -> rrl_registration_step: 5 launches, no autograd node, no graph)"
                                        if issued == "direct" else "eager launches"))
                                    + "; value counts dense-equivalent pairs",
                        "issue": issued if (issued == "direct" or graphed is not None) else "eager",
