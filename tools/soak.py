@@ -1,6 +1,7 @@
 """Randomised soak: many random (B, N, M, L, scale) shapes through the fused op and the drop-in
 loss, culled vs strict scan bit-identical (counts, loss), finite gradients, cached-target path
-bit-identical.  Product-only (no oracle): consistency between independent code paths."""
+bit-identical, the step in one C call (tail kernel) against forward + backward.  Product-only (no oracle): consistency
+between independent code paths."""
 import os, sys, time
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -16,7 +17,7 @@ for case in range(n_cases):
     B = int(rng.integers(1, 5))
     N = int(rng.choice([1, 7, 16, 17, 100, 513, 1024, 3000, 4097, 9000]))
     M = int(rng.choice([1, 5, 16, 31, 200, 777, 2048, 5000]))
-    Ln = int(rng.choice([1, 2, 63, 64, 65, 127, 128, 129, 500, 1023, 1024, 1025, 2500, 7000]))
+    Ln = int(rng.choice([1, 2, 63, 64, 65, 127, 128, 129, 500, 1023, 1024, 1025, 2500, 7000, 12000, 20000]))
     scale = float(rng.choice([0.3, 1.0, 1.0, 3.0, 9.0, 30.0, 200.0]))
     prs = [synth.make_pair(int(rng.integers(0, 10**6)), max(N, 8), max(M, 8)) for _ in range(B)]
     src = torch.from_numpy(np.stack([p["src_tri"][:N] for p in prs]) * np.float32(scale)).cuda()
@@ -41,8 +42,32 @@ for case in range(n_cases):
     same = torch.equal(loss.detach(), st_c.loss) or int(status[0]) != 0
     loss2, _, _ = ops.registration_loss(src, R, t, tar, lines, target_from=st_c)
     cached = torch.equal(loss2.detach(), loss.detach())
-    if not (ok and fin and same and cached):
+    # the step in one C call (the tail kernel where it serves the shape; forced for every second case) against forward +
+    # backward: loss / median / info / bucket sums bit for bit, (dR, dt, payload) to the rounding of their atomics
+    step = True
+    if N >= 1 and M >= 1:
+        forced = case % 2 == 1
+        res = {}
+        try:
+            if forced:
+                ops.set_reduce_mode("tiled")
+            for one in (False, True):
+                ops.RegistrationStep.ONE_CALL = one
+                rs = ops.RegistrationStep(src, tar, Ln, transpose_r=bool(case & 2), want_payload=True)
+                for _ in range(3):
+                    out = rs(R.detach(), t.detach(), lines)
+                torch.cuda.synchronize()
+                res[one] = [x.clone() for x in (out[0], rs.st.med, out[4], rs.st.bsum, out[1], out[2], out[3])]
+        finally:
+            ops.RegistrationStep.ONE_CALL = True
+            ops.set_reduce_mode("auto")
+        nanok = lambda a, b: torch.equal(a, b) or (a.dtype.is_floating_point and torch.equal(torch.nan_to_num(a, nan=-7.0), torch.nan_to_num(b, nan=-7.0)))
+        step = all(nanok(a, b) for a, b in zip(res[False][:4], res[True][:4]))
+        for a, b in zip(res[False][4:], res[True][4:]):
+            a, b = torch.nan_to_num(a, nan=-7.0), torch.nan_to_num(b, nan=-7.0)
+            step = step and bool(((a - b).abs() <= 2e-5 * a.abs() + 2e-6 * float(a.abs().max()) + 1e-12).all())
+    if not (ok and fin and same and cached and step):
         bad += 1
-        print("MISMATCH", dict(case=case, B=B, N=N, M=M, L=Ln, scale=scale, ok=ok, fin=fin, same=same, cached=cached))
+        print("MISMATCH", dict(case=case, B=B, N=N, M=M, L=Ln, scale=scale, ok=ok, fin=fin, same=same, cached=cached, step=step))
 print(f"{n_cases} cases, {bad} mismatches, {time.time() - t0:.1f} s")
 sys.exit(1 if bad else 0)
