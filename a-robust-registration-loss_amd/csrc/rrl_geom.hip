@@ -1153,12 +1153,13 @@ __global__ __launch_bounds__(1024) void sample_write_kernel(
     const float *__restrict__ aabb1, const float *__restrict__ aabb2,
     const unsigned long long *__restrict__ accept, float *__restrict__ lines, int32_t *__restrict__ filled,
     int B, int n, int rounds) {
-    __shared__ int s_base, s_total, s_skip;
+    __shared__ int s_total, s_w[16];
     const int tile = blockIdx.x, rd = blockIdx.y, b = blockIdx.z, ntiles = gridDim.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    extern __shared__ int s_tc[];  // this sample's tile counts [rounds][ntiles], from the ballots
-    for (int q = tid; q < rounds * ntiles; q += 1024) {
-        const unsigned long long *aq = accept + ((size_t)b * rounds * ntiles + q) * 16;
+    extern __shared__ int s_tc[];  // this sample's tile counts [rounds][ntiles] from the ballots, then their exclusive prefix
+    const int E = rounds * ntiles;
+    for (int q = tid; q < E; q += 1024) {
+        const unsigned long long *aq = accept + ((size_t)b * E + q) * 16;
         int c = 0;
 #pragma unroll
         for (int w = 0; w < 16; ++w) c += __popcll(aq[w]);
@@ -1169,20 +1170,32 @@ __global__ __launch_bounds__(1024) void sample_write_kernel(
     int woff = 0;
     for (int w = 0; w < wave; ++w) woff += __popcll(am[w]);
     __syncthreads();
-    if (tid == 0) {  // the skip rule and this workgroup's base slot from the tile counts
-        int count = 0, base = 0, skip = 0;
-        for (int q = 0; q < rounds; ++q) {
-            const bool skipped = count > n;  // code/loss.py:368-369
-            if (q == rd) { base = count; skip = skipped; }
-            if (skipped) continue;
-            for (int t = 0; t < ntiles; ++t) {
-                if (q == rd && t == tile) base = count;
-                count += s_tc[q * ntiles + t];
-            }
-        }
-        s_base = base; s_total = count; s_skip = skip;
+    // Exclusive prefix of the tile counts in (round, tile) order by the whole workgroup (one lane walking the 200 entries
+    // of the demo's call through LDS took 5 of this kernel's 12.6 us).  The reference skips a round once more than n
+    // candidates were accepted BEFORE it (code/loss.py:368-369); the counts only grow, so every later round is skipped
+    // too, and the slots of the rounds that are not skipped are the plain prefix: base = prefix at (rd, tile), skipped =
+    // prefix at the round's first tile > n, total = prefix at the first skipped round (else the grand total).
+    int carry = 0;
+    for (int base0 = 0; base0 < E; base0 += 1024) {  // uniform
+        const int q = base0 + tid;
+        const int v = q < E ? s_tc[q] : 0;
+        const int incl = wave_incl_scan(v);
+        if (lane == 63) s_w[wave] = incl;
+        __syncthreads();
+        int off = carry, all = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) { off += w < wave ? s_w[w] : 0; all += s_w[w]; }
+        if (q < E) s_tc[q] = off + incl - v;
+        carry += all;
+        __syncthreads();
     }
+    if (tid == 0) s_total = carry;
     __syncthreads();
+    for (int q = tid; q < rounds; q += 1024)
+        if (s_tc[q * ntiles] > n) atomicMin(&s_total, s_tc[q * ntiles]);
+    __syncthreads();
+    const int s_base = s_tc[rd * ntiles + tile];
+    const bool s_skip = s_tc[rd * ntiles] > n;
     const int i = tile * 1024 + tid;
     const bool ok = (mask >> lane) & 1ull;
     if (ok && !s_skip) {
