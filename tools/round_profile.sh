@@ -79,4 +79,9 @@ if s:
         4 * s.get("SQ_ACTIVE_INST_VALU", 0) / max(s.get("SQ_BUSY_CYCLES", 1), 1) , 4 * s.get("SQ_ACTIVE_INST_LDS", 0) / max(s.get("SQ_BUSY_CYCLES", 1), 1),
         s.get("SQ_WAIT_ANY", 0) / max(s.get("SQ_WAVE_CYCLES", 1), 1), s.get("SQ_WAIT_INST_ANY", 0) / max(s.get("SQ_WAVE_CYCLES", 1), 1), s.get("SQ_INSTS_VALU", 0)))
 PY
+# the bench line once more, now that the traffic / PMC object of exactly this build exists: the committed line carries it
+if [ -f $O/${TAG}_scan_hbm_traffic.json ]; then
+  cp $O/${TAG}_scan_hbm_traffic.json $R/profiles/scan_hbm_traffic.json
+  (cd /tmp; python3 $R/bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err)
+fi
 tail -c 1500 $O/${TAG}_bench.json
