@@ -1170,7 +1170,9 @@ def test_resample_is_accept_of_own_candidates(L):
     fill rule (code/loss.py:365-381: candidate order, `counter > N` skips the round, truncation,
     zero tail) produces from the SAME kernel's unfiltered candidates and the pinned accept test."""
     from rrl_hip import ops, synth
-    for seed, n, scale in ((5, 3000, 1.0), (6, 1200, 0.5), (7, 700, 4.0)):
+    # (the last two: 108 tiles x 10 rounds -- more tile counts than the write pass's workgroup scans at once --, once with
+    # the usual fill and once with a small sphere that fills the buffer early, so that rounds are skipped)
+    for seed, n, scale in ((5, 3000, 1.0), (6, 1200, 0.5), (7, 700, 4.0), (8, 110000, 1.0), (9, 110000, 0.45)):
         pr = synth.make_pair(seed, 400, 350)
         rands = torch.from_numpy(synth.uniform_streams(seed, 10, n))[:, :, None, :]
         r, c = torch.tensor([pr["radius"] * scale]), torch.from_numpy(pr["center"])[None]
@@ -1497,6 +1499,42 @@ def test_step_in_one_call_equals_forward_then_backward(L, case):
     finally:
         ops.RegistrationStep.ONE_CALL = True
         ops.set_reduce_mode("auto")
+
+
+def test_step_in_one_call_at_the_bench_shape(L):
+    """BASELINE configs[1] at full size (B=8, N=M=4096, L=10000; bench.py's workload): the one-call step equals forward +
+    backward (loss / median / info / bucket sums bit for bit, gradients to the rounding of their atomics) and reproduces
+    itself over 50 calls."""
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, ROOT)
+    import bench
+    from rrl_hip import ops
+    dev = torch.device("cuda:0")
+    B, N, nl = 8, 4096, 10000
+    w = bench.make_workload(B, N, N, nl, 0, dev)
+    R, t = torch.eye(3, device=dev).repeat(B, 1, 1), torch.zeros(B, 3, device=dev)
+    try:
+        res = {}
+        for one in (False, True):
+            ops.RegistrationStep.ONE_CALL = one
+            rs = ops.RegistrationStep(w["tri1"], w["tri2"], nl, want_payload=True)
+            out = rs(R, t, w["lines"])
+            torch.cuda.synchronize()
+            res[one] = [x.clone() for x in (out[0], rs.st.med, out[4], rs.st.bsum, out[3][:2], out[1], out[2])]
+            if one:
+                for _ in range(50):
+                    out = rs(R, t, w["lines"])
+                    again = [out[0], rs.st.med, out[4], rs.st.bsum, out[3][:2]]
+                    assert all(torch.equal(a, b_) for a, b_ in zip(again, res[True][:5]))
+    finally:
+        ops.RegistrationStep.ONE_CALL = True
+    for a, b_ in zip(res[False][:4], res[True][:4]):
+        assert torch.equal(a, b_)
+    np.testing.assert_allclose(res[True][4].cpu().numpy(), res[False][4].cpu().numpy(), rtol=1e-6)
+    for a, b_ in zip(res[False][5:], res[True][5:]):
+        np.testing.assert_allclose(b_.cpu().numpy(), a.cpu().numpy(), rtol=2e-5, atol=2e-6 * float(a.abs().max()))
+    assert float(res[True][4][1]) == 8.0 and int(res[True][2][:, 1].min()) > 500
 
 
 def test_fused_registration_op(L):
