@@ -550,9 +550,12 @@ class RegistrationStep:
         self._tail_s = (_p(gacc[:B * 9]), _p(gacc[B * 9:B * 12]), _p(self.payload), B, N, M, L, self.tr, *self.rng,
                         self.mode, self.chunk, None)
 
-    def __call__(self, R, t, line, grad_loss=None, src_tri=None, tar_tri=None):
+    def __call__(self, R, t, line, grad_loss=None, src_tri=None, tar_tri=None, target_from=None):
         """src_tri / tar_tri: this step's clouds (same shapes as at construction); default: the tensors given
-        to the constructor (update those in place, or pass the new batch here)."""
+        to the constructor (update those in place, or pass the new batch here).
+        target_from: the LossState (another step's .st, or ops.last_state()) of an evaluation with the SAME tar_tri and
+        line -- RPM / FMR evaluate several poses against one target and one line set --: only the source is prepared,
+        sorted and scanned here, the target's hit lists are taken from that state (bit-identical results)."""
         B, N, M, L = self.dims
         dev = self.dev
         if src_tri is not None:
@@ -566,12 +569,19 @@ class RegistrationStep:
             raise ValueError("R (B,3,3), t (B,3), line (B, L, 6) expected")
         g = self.ones if grad_loss is None else _prep(grad_loss, "grad_loss", None, dev)
         lib, s = self._lib, _stream(dev)
+        tail_s, fixed_f = self._tail_s, self._fixed_f
+        if target_from is not None:
+            if target_from is self.st:
+                raise ValueError("target_from must be another evaluation's state")
+            tws = _target_ws(target_from, B, N, M, L)
+            tail_s, fixed_f = tail_s[:-1] + (tws,), fixed_f[:-1] + (tws,)
+        self.st.target_state = getattr(target_from, "target_state", None) or target_from  # whose workspace holds cloud 2
         with _guard(dev):
             if RegistrationStep.ONE_CALL:  # forward + backward as one C entry: the backward may ride in the reduce's launch
                 check(lib.rrl_registration_step(_p(self.src), _p(Rm), _p(tv), _p(self.tar), _p(ln), *self._head_s, _p(g),
-                                                *self._tail_s, s), "rrl_registration_step")
+                                                *tail_s, s), "rrl_registration_step")
             else:
-                check(lib.rrl_registration_forward_cached(_p(self.src), _p(Rm), _p(tv), _p(self.tar), _p(ln), *self._fixed_f, s),
+                check(lib.rrl_registration_forward_cached(_p(self.src), _p(Rm), _p(tv), _p(self.tar), _p(ln), *fixed_f, s),
                       "rrl_registration_forward")
                 check(lib.rrl_registration_backward(_p(self.src), _p(Rm), _p(self.tar), *self._fixed_b, _p(g), *self._tail_b, s),
                       "rrl_registration_backward")

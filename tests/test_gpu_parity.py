@@ -1501,6 +1501,45 @@ def test_step_in_one_call_equals_forward_then_backward(L, case):
         ops.set_reduce_mode("auto")
 
 
+def test_step_with_a_carried_target(L):
+    """RPM / FMR: several poses against ONE target and ONE line set.  The second pose's step takes the target's scan from
+    the first pose's state (target_from): loss, median, info, bucket sums and hit counts bit for bit what a full step of
+    that pose gives, gradients to the rounding of their atomics -- for the one-call step and for forward + backward.
+    (Hit lists are committed in atomic order: the counts are compared, the lists through everything derived from them.)"""
+    from rrl_hip import ops, synth
+    from LieAlgebra import se3
+    B, nl = 4, 6000
+    prs = [synth.make_pair(60 + b, 1200, 1000) for b in range(B)]
+    src, tar = cu(np.stack([p["src_tri"] for p in prs])), cu(np.stack([p["tar_tri"] for p in prs]))
+    ln = []
+    for b, p in enumerate(prs):
+        torch.manual_seed(b)
+        ln.append(L.Random_uniform_distribution_lines_batch_efficient_resample(
+            torch.tensor([[float(p["radius"])]]), torch.from_numpy(p["center"]).reshape(1, 3), nl, cu(p["src"])[None],
+            cu(p["tar"])[None], "cuda")[0])
+    ln = torch.stack(ln)
+    gen = torch.Generator().manual_seed(9)
+    poses = [tuple(x.cuda().contiguous() for x in se3.exp3(0.02 * torch.randn(B, 6, generator=gen))) for _ in range(2)]
+    try:
+        for one in (True, False):
+            ops.RegistrationStep.ONE_CALL = one
+            first, full, carried = (ops.RegistrationStep(src, tar, nl, want_payload=True) for _ in range(3))
+            first(*poses[0], ln)
+            a = full(*poses[1], ln)
+            b_ = carried(*poses[1], ln, target_from=first.st)
+            torch.cuda.synchronize()
+            for x, y in ((a[0], b_[0]), (full.st.med, carried.st.med), (a[4], b_[4]), (full.st.bsum, carried.st.bsum),
+                         (full.st.count2, carried.st.count2), (full.st.count1, carried.st.count1)):
+                assert torch.equal(x, y)
+            for x, y in ((a[1], b_[1]), (a[2], b_[2]), (a[3], b_[3])):
+                np.testing.assert_allclose(y.cpu().numpy(), x.cpu().numpy(), rtol=2e-5, atol=2e-6 * float(x.abs().max()))
+            assert int(a[4][:, 1].min()) > 0
+            with pytest.raises(ValueError):
+                carried(*poses[1], ln, target_from=carried.st)
+    finally:
+        ops.RegistrationStep.ONE_CALL = True
+
+
 def test_step_in_one_call_at_the_bench_shape(L):
     """BASELINE configs[1] at full size (B=8, N=M=4096, L=10000; bench.py's workload): the one-call step equals forward +
     backward (loss / median / info / bucket sums bit for bit, gradients to the rounding of their atomics) and reproduces
