@@ -246,6 +246,8 @@ __device__ __forceinline__ void pair_body(const PairArgs &a, int b, int tile, in
             const unsigned nv = s_nv;
             if (tid == 0) a.vlcnt[(size_t)b * ntile + tile] = (int)nv;
             if (tid < ((4u - (nv & 3u)) & 3u)) vl[nv + tid] = -1.0f;
+        } else if (tid == 0 && a.vlcnt) {
+            a.vlcnt[(size_t)b * ntile + tile] = -1;  // no list this time: a tail kernel run on this state reports it (NaN loss)
         }
     }
     if (wave == 0) {
@@ -1162,7 +1164,8 @@ __global__ __launch_bounds__(TAIL_LANES) void loss_tail_kernel(const TailArgs a)
     const int mycnt = a.blkcnt[(size_t)b * nblk + tile];
     if (sub * TAIL_LINES >= mycnt && !(tile == 0 && sub == 0)) return;  // uniform: no line for this workgroup
     const int bc = tid < nblk ? a.blkcnt[(size_t)b * nblk + tid] : 0;
-    const int vc = tid < nblk ? (a.vlcnt[(size_t)b * nblk + tid] + 3) >> 2 : 0;
+    const int vraw = tid < nblk ? a.vlcnt[(size_t)b * nblk + tid] : 0;  // (-1: the per-line stage built no list -- a knob
+    const int vc = vraw > 0 ? (vraw + 3) >> 2 : 0;                      // changed between the stages: flagged below)
     unsigned hb[BPL];
     {
         const uint4 hq = ((const uint4 *)(a.mhist + (size_t)b * 2048))[tid];
@@ -1191,6 +1194,8 @@ __global__ __launch_bounds__(TAIL_LANES) void loss_tail_kernel(const TailArgs a)
     if (tid < 2) s_flag[tid] = 0u;
     if (tid == 0) s_ncand = 0u;
     if (tid < 16) s_cnt[tid] = (int)bkt;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (vraw < 0) atomicOr(&s_flag[1], 1u);  // (after the clearing above: same wavefront 0, LDS in order)
     if (wave == 0) {  // exclusive prefix of the tile counts (nblk <= 32)
         const int incl = wave_incl_scan(bc), vincl = wave_incl_scan(vc);
         if (lane < nblk) { s_pref[lane + 1] = incl; s_vpref[lane + 1] = vincl; }

@@ -1432,6 +1432,27 @@ def test_tiled_reduce_equals_single_workgroup(L, case):
     assert out["single"][2][:, 1].sum() > 0  # lines were selected
 
 
+def test_tail_kernel_reports_a_missing_value_list(L):
+    """The tail kernel streams the dense D-value lists that the per-line stage builds WHEN it knows the tail kernel
+    follows.  A reduce-mode switch between the two stages (a misuse of the knob) must not give a silently wrong median:
+    the kernel finds the lists marked absent and returns NaN."""
+    from rrl_hip import ops
+    g = load_golden("loss_demo_scale.npz")
+    try:
+        ops.set_reduce_mode("xchg")
+        st = run_state(g["tri1"][None], g["tri2"][None], g["lines"][None], mode="cull")
+        good = float(st.loss[0])
+        B, N, M, Ll, _ = st.dims
+        ops.set_reduce_mode("tiled")  # the per-line stage above ran for the exchange kernel: no lists
+        ops._run(st.ws.device, "rrl_loss_reduce", ops._p(st.ws), st.nbytes, ops._p(st.loss), B, N, M, Ll, 1, 1, 5, 5, 0)
+        torch.cuda.synchronize()
+        assert np.isfinite(good) and good > 0 and np.isnan(float(st.loss[0]))
+        st2 = run_state(g["tri1"][None], g["tri2"][None], g["lines"][None], mode="cull")  # both stages under "tiled"
+        assert float(st2.loss[0]) == good
+    finally:
+        ops.set_reduce_mode("auto")
+
+
 @pytest.mark.parametrize("case", ["batch", "dense_tiles", "long_lists", "one_tile_forced", "empty_sample"])
 def test_step_in_one_call_equals_forward_then_backward(L, case):
     """rrl_registration_step (the direct backward inside the tail kernel's launch) against rrl_registration_forward +
