@@ -1686,6 +1686,34 @@ extern "C" int rrl_loss_reduce(void *ws, size_t ws_bytes, float *loss, int B, in
     return loss_reduce_impl(ws, ws_bytes, loss, B, N, M, L, s_m, s_n, e_m, e_n, pool, nullptr, nullptr, stream);
 }
 
+// K3 + K4 over CALLER-SUPPLIED rows (the merge step of the line-sharded single-sample mode, rrl_hip/dist.py): every rank
+// ran the scan and the per-line stage on ITS share of one sample's lines; the selected lines' canonical D tiles and
+// (k | j << 4) bytes of all ranks, gathered into one dense list, are reduced here by the single-workgroup kernel exactly
+// as if one per-line stage had produced them (full tiles of 1024 rows: blkcnt is filled by a tiny launch).  The median
+// is over the same multiset and the bucket sums are order-independent fixed point, so loss, median, bucket counts and
+// sums are bit-identical to the unsharded evaluation.
+__global__ void rows_blkcnt_kernel(int32_t *__restrict__ blkcnt, int nblk, int nrows) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < nblk) blkcnt[t] = min(1024, nrows - 1024 * t);
+}
+
+extern "C" int rrl_loss_reduce_rows(const float *rows16, const uint8_t *kj, int nrows, int32_t *blkcnt_scratch, float *loss,
+                                    float *med, int32_t *bcnt, int64_t *bsum, int32_t *info, const int32_t *status,
+                                    int s_m, int s_n, int e_m, int e_n, void *stream) {
+    if (!rows16 || !kj || !blkcnt_scratch || !loss || !med || !bcnt || !bsum || !info || !status || nrows < 0) return RRL_E_ARG;
+    if (s_m < 1 || s_n < 1 || e_m > RRL_MAX_HITS + 1 || e_n > RRL_MAX_HITS + 1) return RRL_E_RANGE;
+    const int nblk = nrows > 0 ? (nrows + 1023) / 1024 : 1;
+    hipLaunchKernelGGL(rows_blkcnt_kernel, dim3((unsigned)((nblk + 255) / 256)), dim3(256), 0, (hipStream_t)stream, blkcnt_scratch,
+                       nblk, nrows);
+    ReduceArgs r;
+    r.kjc = kj; r.dc = rows16; r.blkcnt = blkcnt_scratch;
+    r.med_out = med; r.bcnt_out = bcnt; r.bsum_out = bsum; r.info = info; r.loss = loss; r.status = status;
+    r.B = 1; r.nblk = nblk; r.s_m = s_m; r.s_n = s_n; r.e_m = e_m; r.e_n = e_n; r.pool = 0;
+    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(1024), sizeof(int) * (size_t)(nblk + 1), (hipStream_t)stream, r);
+    RRL_LAUNCH_CHECK();
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------
 // K5 backward.  dL/dD[a][b] = gout * w_kj / C * exp(-D/(2 med)) / (2 med)
 //                              * ( [b = argmin_b(a)] / (S k) + [a = argmin_a(b)] / (S j) )

@@ -30,6 +30,7 @@ _SIGS = {
     "rrl_line_tri_scan": [_P, _P, _Z] + [_I] * 6 + [_P],
     "rrl_line_pair_dist": [_P, _P, _P, _P, _Z] + [_I] * 9 + [_P],
     "rrl_loss_reduce": [_P, _Z, _P] + [_I] * 9 + [_P],
+    "rrl_loss_reduce_rows": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "rrl_shard_payload": [_P, _P, _Z, _P, _P, _P, _I, _I, _I, _I, _P],
     "rrl_set_scan_variant": [_I],
     "rrl_set_deterministic": [_I],

@@ -244,6 +244,17 @@ int rrl_line_pair_dist(const float *tri1, const float *tri2, const float *line, 
 int rrl_loss_reduce(void *ws, size_t ws_bytes, float *loss, int B, int N, int M, int L, int s_m,
                     int s_n, int e_m, int e_n, int pool, void *stream);
 
+/* K3 + K4 over caller-supplied rows: rows16 [nrows][16] = canonical 4 x 4 D tiles (+inf outside the k x j block) and
+ * kj [nrows] = k | j << 4, i.e. what rrl_line_pair_dist leaves at its compact slots (fields VALS, KJC, BLKCNT) -- the merge
+ * step of the line-sharded single-sample mode ("within one sample, lines could also be sharded ... one all-gather
+ * of <= 16 S D values"; rrl_hip/dist.py line_sharded_loss): every rank evaluates its share of the lines up to the per-line
+ * stage, the rows of all ranks are gathered and reduced here.  Outputs as the fields MED [1], BCNT [16], BSUM [32], INFO [4]
+ * (INFO[3] = status[0]) and loss [1]: point them at a rank's own workspace fields and its backward entries use the merged
+ * statistics.  blkcnt_scratch: int32 [ceil(nrows / 1024) + 1] device scratch.  Bit-identical to the unsharded loss. */
+int rrl_loss_reduce_rows(const float *rows16, const uint8_t *kj, int nrows, int32_t *blkcnt_scratch, float *loss,
+                         float *med, int32_t *bcnt, int64_t *bsum, int32_t *info, const int32_t *status, int s_m,
+                         int s_n, int e_m, int e_n, void *stream);
+
 /* Which reduce kernel rrl_loss_reduce (and the fused forwards) launch.  0 = automatic: for independent samples with
  * 2 .. 32 line tiles the TAIL kernel (one 1024-lane workgroup per 1024-line tile of a sample; the median's first radix
  * pass comes as a histogram from the per-line stage, every workgroup re-reads its sample's compact D tiles from the L2

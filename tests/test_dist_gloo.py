@@ -143,3 +143,41 @@ def test_world8_gloo_global_batch_64(tmp_path):
     for step in range(4):  # sum over ranks of (arange + 100 rank + step)
         np.testing.assert_allclose(res["seen"][step].numpy(), 8 * (np.arange(14.0) + step) + 100.0 * 28)
     np.testing.assert_allclose(res["shared"].numpy(), np.full(6, 28.0))
+
+
+def _worker_rows(rank, world, port, out):
+    import sys
+    for p in (ROOT, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from rrl_hip import dist as rdist
+    rdist.init_from_env(backend="gloo")
+    # rank r brings (3 r) % 5 rows (rank 0 and the ranks 5 k none at all) whose entries identify (rank, row, column)
+    n = (3 * rank) % 5
+    rows = (1000.0 * rank + 16.0 * torch.arange(n, dtype=torch.float32)[:, None] + torch.arange(16, dtype=torch.float32)[None, :])
+    kj = ((rank + torch.arange(n)) % 4 + 1 + 16 * ((rank + 2 * torch.arange(n)) % 4 + 1)).to(torch.uint8)
+    allr, allk = rdist.gather_rows(rows, kj)
+    lo, hi = rdist.shard_bounds(7001, rank, world)
+    if rank == world - 1:
+        torch.save(dict(rows=allr, kj=allk, last=(lo, hi)), out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_line_shard_gather_rows_gloo(tmp_path):
+    """The all-gather of the line-sharded single-sample mode (rrl_hip.dist.gather_rows): ragged shares incl. empty ones
+    arrive concatenated in rank order, k | j << 4 bytes intact, on every rank (checked on the last)."""
+    world = 4
+    out = str(tmp_path / "rows.pt")
+    mp.spawn(_worker_rows, args=(world, _free_port(), out), nprocs=world, join=True)
+    res = torch.load(out)
+    want_rows, want_kj = [], []
+    for rank in range(world):
+        n = (3 * rank) % 5
+        want_rows.append(1000.0 * rank + 16.0 * torch.arange(n, dtype=torch.float32)[:, None] + torch.arange(16, dtype=torch.float32)[None, :])
+        want_kj.append(((rank + torch.arange(n)) % 4 + 1 + 16 * ((rank + 2 * torch.arange(n)) % 4 + 1)).to(torch.uint8))
+    assert torch.equal(res["rows"], torch.cat(want_rows)) and torch.equal(res["kj"], torch.cat(want_kj))
+    assert res["rows"].shape[0] == 0 + 3 + 1 + 4 and res["last"][1] == 7001

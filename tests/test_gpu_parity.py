@@ -7,6 +7,8 @@ Tolerances (stated per BASELINE.json north_star: loss within 1e-5 rel):
   loss                                               1e-5 rel vs reference and oracle
   gradient (per-point sums, see merge_by_point)      1e-4 rel, 1e-5 of max abs
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -1520,6 +1522,108 @@ def test_step_in_one_call_equals_forward_then_backward(L, case):
     finally:
         ops.RegistrationStep.ONE_CALL = True
         ops.set_reduce_mode("auto")
+
+
+@pytest.mark.parametrize("world", [1, 3, 4])
+def test_line_sharded_single_sample(L, world):
+    """SURVEY 8(e), last sentence: ONE sample with its lines partitioned over `world` ranks (simulated here in one process:
+    every share goes through rrl_hip.dist.line_shard_local, the rows are concatenated in rank order as the all-gather
+    would, every share's state is reduced with line_shard_merge).  Loss, median, bucket counts and sums of every rank are
+    bit-identical to the unsharded evaluation, and the sum of the ranks' point gradients equals its gradient."""
+    from rrl_hip import ops, synth, dist as rdist
+    pr = synth.make_pair(77, 2500, 2200)
+    tri1, tri2 = cu(pr["src_tri"])[None], cu(pr["tar_tri"])[None]
+    nl = 7001  # ragged shares, a last tile that is not full
+    torch.manual_seed(4)
+    ln = L.Random_uniform_distribution_lines_batch_efficient_resample(
+        torch.tensor([[float(pr["radius"])]]), torch.from_numpy(pr["center"]).reshape(1, 3), nl, cu(pr["src"])[None],
+        cu(pr["tar"])[None], "cuda")
+    p1 = tri1.clone().requires_grad_(True)
+    p2 = tri2.clone().requires_grad_(True)
+    ref_loss, ref_info, _ = ops.intersection_loss(p1, p2, ln)
+    ref_state = ops.last_state()
+    ref = [t.clone() for t in (ref_loss.detach(), ref_state.med, ref_state.bcnt, ref_state.bsum, ref_info)]
+    (2.0 * ref_loss.sum()).backward()
+    if world == 1:  # the public entry without a process group
+        q1, q2 = tri1.clone().requires_grad_(True), tri2.clone().requires_grad_(True)
+        loss, info, _ = rdist.line_sharded_loss(q1, q2, ln)
+        assert torch.equal(loss.detach(), ref[0]) and torch.equal(info, ref[4])
+        (2.0 * loss.sum()).backward()
+        np.testing.assert_allclose(q1.grad.cpu().numpy(), p1.grad.cpu().numpy(), rtol=1e-5, atol=1e-9)
+        np.testing.assert_allclose(q2.grad.cpu().numpy(), p2.grad.cpu().numpy(), rtol=1e-5, atol=1e-9)
+        return
+    shares = [rdist.line_shard_local(tri1, tri2, ln[:, lo:hi].contiguous())
+              for lo, hi in (rdist.shard_bounds(nl, r, world) for r in range(world))]
+    rows = torch.cat([s[1] for s in shares])
+    kj = torch.cat([s[2] for s in shares])
+    assert rows.shape[0] == int(ref[4][0, 1]) > 300  # every selected line arrives exactly once
+    g1 = torch.zeros_like(tri1)
+    g2 = torch.zeros_like(tri2)
+    gl = torch.full((1,), 2.0, device="cuda")
+    for r, (st, _, _) in enumerate(shares):
+        rdist.line_shard_merge(st, rows, kj)
+        for a, b_ in zip((st.loss, st.med, st.bcnt, st.bsum, st.info), ref):
+            assert torch.equal(a.reshape(-1), b_.reshape(-1)), r
+        lo, hi = rdist.shard_bounds(nl, r, world)
+        a1, a2 = torch.empty_like(tri1), torch.empty_like(tri2)
+        ops._run(tri1.device, "rrl_loss_backward", ops._p(tri1), ops._p(tri2), ops._p(st.ws), st.nbytes, ops._p(gl),
+                 ops._p(a1), ops._p(a2), 1, tri1.shape[1], tri2.shape[1], hi - lo, 0)
+        g1 += a1
+        g2 += a2
+    np.testing.assert_allclose(g1.cpu().numpy(), p1.grad.cpu().numpy(), rtol=1e-5, atol=1e-9)
+    np.testing.assert_allclose(g2.cpu().numpy(), p2.grad.cpu().numpy(), rtol=1e-5, atol=1e-9)
+    assert float(p1.grad.abs().sum()) > 0
+
+
+def _line_shard_worker(rank, world, port, out):
+    import sys
+    from conftest import ROOT, PKG
+    for p in (ROOT, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0")
+    import torch.distributed as tdist
+    from rrl_hip import dist as rdist
+    tdist.init_process_group(backend="gloo", rank=rank, world_size=world)  # (one GPU here: RCCL wants a GPU per rank)
+    d = np.load(out + ".in.npz")
+    t1 = torch.from_numpy(d["tri1"]).cuda().requires_grad_(True)
+    t2 = torch.from_numpy(d["tri2"]).cuda().requires_grad_(True)
+    ln = torch.from_numpy(d["lines"]).cuda()
+    loss, info, status = rdist.line_sharded_loss(t1, t2, ln)
+    (3.0 * loss.sum()).backward()
+    torch.cuda.synchronize()
+    torch.save(dict(loss=loss.detach().cpu(), info=info.cpu(), g1=t1.grad.cpu(), g2=t2.grad.cpu()), f"{out}.{rank}.pt")
+    tdist.barrier()
+    tdist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_line_sharded_two_processes(L, tmp_path):
+    """rrl_hip.dist.line_sharded_loss end to end with real collectives: two processes (both on this GPU, gloo moving the
+    device tensors) share the lines of one sample; each returns the unsharded loss bit for bit and the full gradient."""
+    import socket
+    import torch.multiprocessing as mp
+    from rrl_hip import ops, synth
+    pr = synth.make_pair(78, 1800, 1600)
+    tri1, tri2 = pr["src_tri"][None], pr["tar_tri"][None]
+    torch.manual_seed(2)
+    ln = L.Random_uniform_distribution_lines_batch_efficient_resample(
+        torch.tensor([[float(pr["radius"])]]), torch.from_numpy(pr["center"]).reshape(1, 3), 5003, cu(pr["src"])[None],
+        cu(pr["tar"])[None], "cuda")
+    p1, p2 = cu(tri1).requires_grad_(True), cu(tri2).requires_grad_(True)
+    ref_loss, ref_info, _ = ops.intersection_loss(p1, p2, ln)
+    (3.0 * ref_loss.sum()).backward()
+    out = str(tmp_path / "ls")
+    np.savez(out + ".in.npz", tri1=tri1, tri2=tri2, lines=ln.cpu().numpy())
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_line_shard_worker, args=(2, port, out), nprocs=2, join=True)
+    for rank in range(2):
+        r = torch.load(f"{out}.{rank}.pt")
+        assert torch.equal(r["loss"], ref_loss.detach().cpu()) and torch.equal(r["info"], ref_info.cpu())
+        np.testing.assert_allclose(r["g1"].numpy(), p1.grad.cpu().numpy(), rtol=1e-5, atol=1e-9)
+        np.testing.assert_allclose(r["g2"].numpy(), p2.grad.cpu().numpy(), rtol=1e-5, atol=1e-9)
+    assert int(ref_info[0, 1]) > 200
 
 
 def test_step_with_a_carried_target(L):
