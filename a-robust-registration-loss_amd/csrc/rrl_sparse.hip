@@ -1835,65 +1835,15 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(
 
 __device__ __forceinline__ int bwd_live_blocks(int ns) { return ns > 0 ? (ns + BWD_LINES - 1) / BWD_LINES : 1; }
 
-// DET = true (rrl_set_deterministic): instead of the atomics every workgroup stores its 12 sums to
-// part[b][workgroup][12] and loss_bwd_rt_finalize_kernel adds them in index order; the assignment of
-// lines to workgroups is fixed too (see below) -- bit-reproducible from run to run, one more (tiny) launch.
-template <bool DET>
-__global__ __launch_bounds__(256) void loss_bwd_rt_kernel(
-    const uint8_t *__restrict__ kj, const int32_t *__restrict__ sel, const int32_t *__restrict__ nsel,
-    const int32_t *__restrict__ hs1, const float *__restrict__ w1, const float4 *__restrict__ Q1,
-    const float4 *__restrict__ Q2, const float *__restrict__ D, const float *__restrict__ med,
-    const int32_t *__restrict__ bcnt, const int32_t *__restrict__ info,
-    const float *__restrict__ grad_loss, const float *__restrict__ src, float *__restrict__ gR,
-    float *__restrict__ gt, float *__restrict__ payload, const float *__restrict__ loss, int B, int N,
-    int L, int transpose_r, float *__restrict__ part) {
-    __shared__ float red[4][12];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.y;
-    const int h = tid & 3;
-    int li = -1;  // this lane's selected line (index within the sample), or none
-    if constexpr (DET) {
-        // SEL lists the selected lines in the order the pair kernel's workgroups happened to reserve their
-        // slots (an atomic): grouping lines into workgroups by SEL position would change the rounding of
-        // the partial sums from run to run.  Here workgroup (tile, sub) takes the selected lines of its
-        // 1024-line tile with rank 64 sub .. 64 sub + 63 in a FIXED order (round r, then thread), found
-        // from the KJ bytes of the tile.
-        __shared__ int s_line[BWD_LINES];
-        __shared__ int s_wc[4][4];
-        const int tile = blockIdx.x >> 4, sub = blockIdx.x & 15;
-        bool sl[4];
-        unsigned long long bm[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int l = tile * 1024 + r * 256 + tid;
-            sl[r] = l < L && kj[(size_t)b * L + l] != 0;
-            bm[r] = __ballot(sl[r]);
-            if (lane == 0) s_wc[r][wave] = __popcll(bm[r]);
-        }
-        if (tid < BWD_LINES) s_line[tid] = -1;
-        __syncthreads();
-        int before = 0;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            int mine = before;
-            for (int w = 0; w < 4; ++w) {
-                if (w < wave) mine += s_wc[r][w];
-                before += s_wc[r][w];
-            }
-            const int rel = mine + __popcll(bm[r] & ((1ull << lane) - 1ull)) - BWD_LINES * sub;
-            if (sl[r] && rel >= 0 && rel < BWD_LINES) s_line[rel] = tile * 1024 + r * 256 + tid;
-        }
-        __syncthreads();
-        li = s_line[tid >> 2];
-    } else {
-        const int ns = nsel[b];
-        if ((int)blockIdx.x >= bwd_live_blocks(ns)) return;  // uniform: nothing selected in this slice
-        const int i = blockIdx.x * BWD_LINES + (tid >> 2);
-        if (i < ns) li = sel[(size_t)b * L + i];
-    }
-    float acc[12];
-#pragma unroll
-    for (int q = 0; q < 12; ++q) acc[q] = 0.0f;
+// The (dL/dR, dL/dt) terms of ONE selected line's hit slot h (li: its index within sample b, or -1) added to acc[12]
+// (9 sums of x (x) g in m-index order, 3 of g).  ALL lanes of the wavefront must call it: the four lanes of a line share
+// its Welsch tile by quad DPP.
+__device__ __forceinline__ void bwd_rt_line(int li, int h, int b, int L, int N, const uint8_t *__restrict__ kj,
+                                            const int32_t *__restrict__ hs1, const float *__restrict__ w1,
+                                            const float4 *__restrict__ Q1, const float4 *__restrict__ Q2,
+                                            const float *__restrict__ D, const float *__restrict__ med,
+                                            const int32_t *__restrict__ bcnt, const int32_t *__restrict__ info,
+                                            const float *__restrict__ grad_loss, const float *__restrict__ src, float *acc) {
     const int C = info[b * 4];
     // The four lanes of a line SHARE its Welsch tile (round 3): lane h evaluates row h -- <= 4 exponentials and divisions
     // where every lane used to evaluate all 16 entries -- and the rows travel by quad DPP; all lanes take part (DPP
@@ -1989,6 +1939,68 @@ __global__ __launch_bounds__(256) void loss_bwd_rt_kernel(
             }
         }
     }
+}
+
+// DET = true (rrl_set_deterministic): instead of the atomics every workgroup stores its 12 sums to
+// part[b][workgroup][12] and loss_bwd_rt_finalize_kernel adds them in index order; the assignment of
+// lines to workgroups is fixed too (see below) -- bit-reproducible from run to run, one more (tiny) launch.
+template <bool DET>
+__global__ __launch_bounds__(256) void loss_bwd_rt_kernel(
+    const uint8_t *__restrict__ kj, const int32_t *__restrict__ sel, const int32_t *__restrict__ nsel,
+    const int32_t *__restrict__ hs1, const float *__restrict__ w1, const float4 *__restrict__ Q1,
+    const float4 *__restrict__ Q2, const float *__restrict__ D, const float *__restrict__ med,
+    const int32_t *__restrict__ bcnt, const int32_t *__restrict__ info,
+    const float *__restrict__ grad_loss, const float *__restrict__ src, float *__restrict__ gR,
+    float *__restrict__ gt, float *__restrict__ payload, const float *__restrict__ loss, int B, int N,
+    int L, int transpose_r, float *__restrict__ part) {
+    __shared__ float red[4][12];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y;
+    const int h = tid & 3;
+    int li = -1;  // this lane's selected line (index within the sample), or none
+    if constexpr (DET) {
+        // SEL lists the selected lines in the order the pair kernel's workgroups happened to reserve their
+        // slots (an atomic): grouping lines into workgroups by SEL position would change the rounding of
+        // the partial sums from run to run.  Here workgroup (tile, sub) takes the selected lines of its
+        // 1024-line tile with rank 64 sub .. 64 sub + 63 in a FIXED order (round r, then thread), found
+        // from the KJ bytes of the tile.
+        __shared__ int s_line[BWD_LINES];
+        __shared__ int s_wc[4][4];
+        const int tile = blockIdx.x >> 4, sub = blockIdx.x & 15;
+        bool sl[4];
+        unsigned long long bm[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int l = tile * 1024 + r * 256 + tid;
+            sl[r] = l < L && kj[(size_t)b * L + l] != 0;
+            bm[r] = __ballot(sl[r]);
+            if (lane == 0) s_wc[r][wave] = __popcll(bm[r]);
+        }
+        if (tid < BWD_LINES) s_line[tid] = -1;
+        __syncthreads();
+        int before = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            int mine = before;
+            for (int w = 0; w < 4; ++w) {
+                if (w < wave) mine += s_wc[r][w];
+                before += s_wc[r][w];
+            }
+            const int rel = mine + __popcll(bm[r] & ((1ull << lane) - 1ull)) - BWD_LINES * sub;
+            if (sl[r] && rel >= 0 && rel < BWD_LINES) s_line[rel] = tile * 1024 + r * 256 + tid;
+        }
+        __syncthreads();
+        li = s_line[tid >> 2];
+    } else {
+        const int ns = nsel[b];
+        if ((int)blockIdx.x >= bwd_live_blocks(ns)) return;  // uniform: nothing selected in this slice
+        const int i = blockIdx.x * BWD_LINES + (tid >> 2);
+        if (i < ns) li = sel[(size_t)b * L + i];
+    }
+    float acc[12];
+#pragma unroll
+    for (int q = 0; q < 12; ++q) acc[q] = 0.0f;
+    bwd_rt_line(li, h, b, L, N, kj, hs1, w1, Q1, Q2, D, med, bcnt, info, grad_loss, src, acc);
 #pragma unroll
     for (int q = 0; q < 12; ++q) acc[q] = wave_sum(acc[q]);
     if (lane == 0)
@@ -2039,6 +2051,59 @@ __global__ __launch_bounds__(256) void loss_bwd_rt_finalize_kernel(const float *
             else s += (double)gt[b * 3 + (q - 11)];
         }
         payload[q] = (float)s;
+    }
+}
+
+// K2 + K3 + K4 + K5' in ONE launch for a single tile of lines (L <= 1024; C5: N = M = 16384, L = 512): the workgroup of
+// sample b ran the per-line stage and the reduce of sample b, so it holds everything the direct backward of sample b
+// reads -- no other workgroup is involved at all.  Same bodies (pair_body, reduce_body, bwd_rt_line), same results;
+// (dR, dt) of a sample by ONE workgroup in a fixed order (deterministic here), payload[0 .. 1] as in the tail kernel.
+struct SoloBwd {
+    const uint8_t *kj;
+    const int32_t *sel, *nsel, *hs1, *bcnt, *info;
+    const float *w1, *D, *med, *grad_loss, *src, *loss;
+    const float4 *Q1, *Q2;
+    float *gR, *gt, *payload;
+    uint32_t *mctl;
+    int B, N, L, transpose_r;
+};
+
+__global__ __launch_bounds__(1024) void pair_reduce_bwd_kernel(const PairArgs pa, const ReduceArgs ra, const SoloBwd a) {
+    __shared__ float s_red[16][12];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    pair_body(pa, b, 0, 1);
+    __threadfence_block();  // this workgroup's KJC / VALS / BLKCNT stores are complete ...
+    __syncthreads();        // ... before any of its lanes reads them back
+    reduce_body(ra, b);
+    __threadfence_block();  // ... and so are MED / BCNT / INFO / loss, SEL / NSEL and the per-line arrays
+    __syncthreads();
+    const int ns = a.nsel[b], h = tid & 3;
+    float acc[12];
+#pragma unroll
+    for (int q = 0; q < 12; ++q) acc[q] = 0.0f;
+    for (int i0 = 0; i0 < ns; i0 += 256) {  // uniform: 256 selected lines per pass, four lanes each
+        const int i = i0 + (tid >> 2);
+        const int li = i < ns ? a.sel[(size_t)b * a.L + i] : -1;
+        bwd_rt_line(li, h, b, a.L, a.N, a.kj, a.hs1, a.w1, a.Q1, a.Q2, a.D, a.med, a.bcnt, a.info, a.grad_loss, a.src, acc);
+    }
+#pragma unroll
+    for (int q = 0; q < 12; ++q) acc[q] = wave_sum(acc[q]);
+    if (lane == 0)
+#pragma unroll
+        for (int q = 0; q < 12; ++q) s_red[wave][q] = acc[q];
+    __syncthreads();
+    if (tid < 12) {
+        float v = 0.0f;
+        for (int w = 0; w < 16; ++w) v += s_red[w][tid];
+        int o = tid;  // m-index (i, j) -> memory order of R
+        if (tid < 9 && a.transpose_r) o = (tid % 3) * 3 + tid / 3;
+        if (tid < 9) atomicAdd(&a.gR[b * 9 + o], v); else atomicAdd(&a.gt[b * 3 + (tid - 9)], v);  // (zero on entry)
+        if (a.payload) atomicAdd(&a.payload[2 + o], v);
+    }
+    if (tid == 64 && a.payload && a.info[b * 4] > 0) {  // payload[0 .. 1] as in the tail kernel (order-independent)
+        TailArgs t;
+        t.payload = a.payload; t.mctl = a.mctl;
+        tail_payload(t, a.loss[b]);
     }
 }
 
@@ -2151,6 +2216,22 @@ static int loss_forward_impl(const float *tri1, const float *tri2, const float *
         RrlRange r("K2 + K3 + K4 (single tile)");
         WsLayout w(B, N, M, L);
         if (ws_bytes < w.total) return RRL_E_WS;
+        if (tb) {  // ... and the direct backward too (rrl_registration_step)
+            SoloBwd sb;
+            sb.kj = w.u8(ws, RRL_WS_KJ); sb.sel = w.i32(ws, RRL_WS_SEL); sb.nsel = w.i32(ws, RRL_WS_NSEL);
+            sb.hs1 = w.i32(ws, RRL_WS_HS1); sb.bcnt = w.i32(ws, RRL_WS_BCNT); sb.info = w.i32(ws, RRL_WS_INFO);
+            sb.w1 = w.f32(ws, RRL_WS_W1); sb.D = w.f32(ws, RRL_WS_D); sb.med = w.f32(ws, RRL_WS_MED);
+            sb.grad_loss = tb->grad_loss; sb.src = tb->src; sb.loss = loss;
+            sb.Q1 = (const float4 *)w.f32(ws, RRL_WS_Q1); sb.Q2 = (const float4 *)w.f32(ws, RRL_WS_Q2);
+            sb.gR = tb->gR; sb.gt = tb->gt; sb.payload = tb->payload; sb.mctl = w.u32(ws, RRL_WS_MCTL);
+            sb.B = B; sb.N = N; sb.L = L; sb.transpose_r = tb->transpose_r;
+            hipLaunchKernelGGL(pair_reduce_bwd_kernel, dim3((unsigned)B), dim3(1024), sizeof(int) * 2, (hipStream_t)stream,
+                               pair_args(target_ws ? tri2 : nullptr, line, ws, w, B, N, M, L, s_m, s_n, e_m, e_n, false),
+                               reduce_args(ws, w, loss, B, L, s_m, s_n, e_m, e_n, 0), sb);
+            RRL_LAUNCH_CHECK();
+            if (bwd_done) *bwd_done = true;
+            return 0;
+        }
         hipLaunchKernelGGL(pair_reduce_kernel, dim3((unsigned)B), dim3(1024), sizeof(int) * 2, (hipStream_t)stream,
                            pair_args(target_ws ? tri2 : nullptr, line, ws, w, B, N, M, L, s_m, s_n, e_m, e_n, false),
                            reduce_args(ws, w, loss, B, L, s_m, s_n, e_m, e_n, 0));
@@ -2259,7 +2340,8 @@ extern "C" int rrl_registration_step(const float *src, const float *R, const flo
     const int nblk = (L + 1023) / 1024;
     bool done = false;
     int rc;
-    if (B > 0 && L > 0 && !rrl_deterministic() && reduce_kind(B, nblk, 0, true) == 2 && !(L <= 1024 && reduce_mode() < 2)) {
+    const bool solo = L <= 1024 && reduce_mode() < 2;  // one tile of lines: per-line stage + reduce + backward by one workgroup per sample
+    if (B > 0 && L > 0 && !rrl_deterministic() && (solo || reduce_kind(B, nblk, 0, true) == 2)) {
         float *gacc = w.f32(ws, RRL_WS_GACC);
         hipStream_t s = (hipStream_t)stream;
         if (gR != gacc || gt != gacc + 9 * (size_t)B || (payload && payload != gacc + 12 * (size_t)B)) {

@@ -1455,18 +1455,20 @@ def test_tail_kernel_reports_a_missing_value_list(L):
         ops.set_reduce_mode("auto")
 
 
-@pytest.mark.parametrize("case", ["batch", "dense_tiles", "long_lists", "one_tile_forced", "empty_sample"])
+@pytest.mark.parametrize("case", ["batch", "dense_tiles", "long_lists", "one_tile", "one_tile_forced", "empty_sample"])
 def test_step_in_one_call_equals_forward_then_backward(L, case):
     """rrl_registration_step (the direct backward inside the tail kernel's launch) against rrl_registration_forward +
     rrl_registration_backward: loss, median, info, bucket sums bit for bit; dR, dt, payload to the rounding of their float
     atomics -- a batch with 3-5 line tiles per sample, tiles with more than 256 selected lines (the kernel's second
     pass over a tile, and the crowded-bin route of the median), value lists longer than one streaming round
-    of the kernel (32 tiles per sample), a single tile (tail kernel forced), a sample whose lines hit nothing; with and without payload,
+    of the kernel (32 tiles per sample), a single tile (per-line stage + reduce + backward by one workgroup per sample: the
+    C5 route; and with the tail kernel forced), a sample whose lines hit nothing; with and without payload,
     both R layouts, non-unit dL/dloss."""
     from rrl_hip import ops, synth
     from LieAlgebra import se3
     B = 3
-    nl = {"batch": 4500, "dense_tiles": 2600, "long_lists": 32000, "one_tile_forced": 900, "empty_sample": 3000}[case]
+    nl = {"batch": 4500, "dense_tiles": 2600, "long_lists": 32000, "one_tile": 1000, "one_tile_forced": 900,
+          "empty_sample": 3000}[case]
     gen = torch.Generator().manual_seed(2)
     R, T = se3.exp3(0.03 * torch.randn(B, 6, generator=gen))
     if case == "dense_tiles":  # two tiny triangles per cloud, every line through the first: ~1000 selected lines per tile,
