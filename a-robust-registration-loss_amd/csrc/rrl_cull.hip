@@ -185,20 +185,69 @@ __global__ __launch_bounds__(REC_BLK) void line_max_kernel(const float *__restri
     line_max_chunks(line, L, lmax, (int)blockIdx.y, (int)blockIdx.x, (int)gridDim.x, red2);
 }
 
+// One triangle of the build step (both records kernels): the raw row, moved by the sample's rigid transform when it
+// belongs to the source of the fused op (-> TRI1), its thresholds (code/loss.py:94-110), NaN reach (DEL) and 48-byte
+// prepared record (PTRI, original order).  c: the (moved) coordinates, x: thr2, p2: max |P|^2 of its three points
+// (+inf for non-finite coordinates).
+__device__ __forceinline__ void tri_record_row(const BuildArgs &a, int cloud, int b, int n, int f, float (&c)[9], float &x,
+                                               float &p2) {
+    const float *raw = (cloud ? a.tri2 : a.tri1) + ((size_t)b * n + f) * 9;
+    float thr, e01;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) c[i] = raw[i];
+    if (cloud == 0 && a.R != nullptr) {
+        float m[9], tv[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)  // m[i*3+j] multiplies x_i into y_j (rigid_fwd_kernel)
+                m[i * 3 + j] = a.transpose_r ? a.R[b * 9 + j * 3 + i] : a.R[b * 9 + i * 3 + j];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) tv[j] = a.t[b * 3 + j];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const float v0 = c[3 * q], v1 = c[3 * q + 1], v2 = c[3 * q + 2];
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                c[3 * q + j] = fmaf(v2, m[6 + j], fmaf(v1, m[3 + j], v0 * m[j])) + tv[j];
+        }
+        float *moved = a.tri1_out + ((size_t)b * n + f) * 9;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) moved[i] = c[i];
+    }
+    tri_thresholds(c, &thr, &x, &e01);  // code/loss.py:94-110
+    // NaN reach (culled scan, "NaN detection" in the header): points 1, 2 lie within e01 of point 0, and the
+    // tree nodes carry thr: del >= e01 - thr in exact arithmetic (e01, thr as rounded here: <= 3u off)
+    if (float *del = cloud ? a.del2 : a.del1)
+        del[(size_t)b * n + f] = fmaxf(e01 * 1.000002f - thr, 0.0f) * 1.000001f;
+    float4 *row = (float4 *)((cloud ? a.ptri2 : a.ptri1) + ((size_t)b * n + f) * PTRI_STRIDE);
+    row[0] = make_float4(c[0], c[1], c[2], c[3]);
+    row[1] = make_float4(c[4], c[5], c[6], c[7]);
+    row[2] = make_float4(c[8], x, thr, __int_as_float(f));
+    p2 = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+        p2 = fmaxf(p2, c[3 * q] * c[3 * q] + c[3 * q + 1] * c[3 * q + 1] + c[3 * q + 2] * c[3 * q + 2]);
+    if (!(p2 <= 3.0e38f)) p2 = INFINITY;  // NaN/inf coordinates: never "provably safe"
+}
+
+// the clearing of the per-call state (and of the small accumulators), spread over all workgroups of a records launch
+__device__ __forceinline__ void build_clear_state(const BuildArgs &a) {
+    const size_t nthr = (size_t)gridDim.x * gridDim.y * gridDim.z * REC_BLK;
+    const size_t me = (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * REC_BLK + threadIdx.x;
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    for (size_t i = me; i < a.zero_vec4; i += nthr) a.zero_base[i] = z;
+    for (size_t i = me; i < a.g1_vec4; i += nthr) a.g1[i] = z;
+    for (size_t i = me; i < a.z2_vec4; i += nthr) a.z2[i] = z;
+    for (size_t i = me; i < a.z3_vec4; i += nthr) a.z3[i] = z;
+}
+
 __global__ __launch_bounds__(REC_BLK) void tri_records_kernel(const BuildArgs a) {
     __shared__ float red[REC_BLK / 64][8];
     __shared__ float red2[REC_BLK / 64][2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int cloud = blockIdx.z, b = blockIdx.y, B = a.B;
-    {   // per-call state and gradient accumulator, spread over all workgroups of the launch
-        const size_t nthr = (size_t)gridDim.x * gridDim.y * gridDim.z * REC_BLK;
-        const size_t me = (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * REC_BLK + tid;
-        const uint4 z = make_uint4(0, 0, 0, 0);
-        for (size_t i = me; i < a.zero_vec4; i += nthr) a.zero_base[i] = z;
-        for (size_t i = me; i < a.g1_vec4; i += nthr) a.g1[i] = z;
-        for (size_t i = me; i < a.z2_vec4; i += nthr) a.z2[i] = z;
-        for (size_t i = me; i < a.z3_vec4; i += nthr) a.z3[i] = z;
-    }
+    build_clear_state(a);  // per-call state and gradient accumulator
     const int n = cloud ? a.M : a.N;
     if ((int)blockIdx.x >= a.nblk_tri) {  // uniform: the launch's LMAX_CHUNKS extra workgroups per sample reduce its lines
         if (cloud == 0 && a.lmax != nullptr)  // (one chunk each: they run beside the triangle workgroups)
@@ -208,47 +257,12 @@ __global__ __launch_bounds__(REC_BLK) void tri_records_kernel(const BuildArgs a)
     const int f = blockIdx.x * REC_BLK + tid;
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY}, p2 = 0.0f;
     if (f < n) {
-        const float *raw = (cloud ? a.tri2 : a.tri1) + ((size_t)b * n + f) * 9;
-        float c[9], thr, x, e01;
-#pragma unroll
-        for (int i = 0; i < 9; ++i) c[i] = raw[i];
-        if (cloud == 0 && a.R != nullptr) {
-            float m[9], tv[3];
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-#pragma unroll
-                for (int j = 0; j < 3; ++j)  // m[i*3+j] multiplies x_i into y_j (rigid_fwd_kernel)
-                    m[i * 3 + j] = a.transpose_r ? a.R[b * 9 + j * 3 + i] : a.R[b * 9 + i * 3 + j];
-#pragma unroll
-            for (int j = 0; j < 3; ++j) tv[j] = a.t[b * 3 + j];
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                const float v0 = c[3 * q], v1 = c[3 * q + 1], v2 = c[3 * q + 2];
-#pragma unroll
-                for (int j = 0; j < 3; ++j)
-                    c[3 * q + j] = fmaf(v2, m[6 + j], fmaf(v1, m[3 + j], v0 * m[j])) + tv[j];
-            }
-            float *moved = a.tri1_out + ((size_t)b * n + f) * 9;
-#pragma unroll
-            for (int i = 0; i < 9; ++i) moved[i] = c[i];
-        }
-        tri_thresholds(c, &thr, &x, &e01);  // code/loss.py:94-110
-        // NaN reach (culled scan, "NaN detection" in the header): points 1, 2 lie within e01 of point 0, and the
-        // tree nodes carry thr: del >= e01 - thr in exact arithmetic (e01, thr as rounded here: <= 3u off)
-        if (float *del = cloud ? a.del2 : a.del1)
-            del[(size_t)b * n + f] = fmaxf(e01 * 1.000002f - thr, 0.0f) * 1.000001f;
-        float4 *row = (float4 *)((cloud ? a.ptri2 : a.ptri1) + ((size_t)b * n + f) * PTRI_STRIDE);
-        row[0] = make_float4(c[0], c[1], c[2], c[3]);
-        row[1] = make_float4(c[4], c[5], c[6], c[7]);
-        row[2] = make_float4(c[8], x, thr, __int_as_float(f));
+        float c[9], x;
+        tri_record_row(a, cloud, b, n, f, c, x, p2);
         const int ngp = (n + GRP - 1) / GRP * GRP;
         ((cloud ? a.crec2 : a.crec1) + (size_t)b * ngp)[f] = make_float4(c[0], c[1], c[2], x);
 #pragma unroll
         for (int d = 0; d < 3; ++d) { mn[d] = c[d]; mx[d] = c[d]; }
-#pragma unroll
-        for (int q = 0; q < 3; ++q)
-            p2 = fmaxf(p2, c[3 * q] * c[3 * q] + c[3 * q + 1] * c[3 * q + 1] + c[3 * q + 2] * c[3 * q + 2]);
-        if (!(p2 <= 3.0e38f)) p2 = INFINITY;  // NaN/inf coordinates: never "provably safe"
     }
     if (blockIdx.x * REC_BLK >= n) return;  // uniform: this workgroup has no triangle of the cloud
 #pragma unroll
@@ -265,6 +279,136 @@ __global__ __launch_bounds__(REC_BLK) void tri_records_kernel(const BuildArgs a)
         for (int w = 1; w < REC_BLK / 64; ++w) r = tid < 3 ? fminf(r, red[w][tid]) : fmaxf(r, red[w][tid]);
         a.apart[(((size_t)cloud * B + b) * a.nblk + blockIdx.x) * 8 + tid] = r;
     }
+}
+
+// ---------------------------------------------------------------------------------------
+// Prepared clouds (round 4): the records launch of a cloud whose spatial ORDER is already known.
+// A rigid motion preserves the spatial order of a cloud, and every caller of the reference moves the same source,
+// step after step, against a target that never moves (code/test_demo_optimized_Lie_Algebra.py:57-62,
+// rpm/Train_RPM.py:207-231; the reference itself suggests a tree, code/loss.py:260-262).  So the cell sort runs once
+// per cloud (rrl_cloud_order) and this kernel replaces tri_records_kernel + tri_sort_kernel in every later step:
+//   lane = one SORTED position s of the cloud; f = order[s]; the triangle's raw row is gathered, moved by the sample's
+//   pose (source of the fused op), thresholds / NaN reach / 48-byte record go to their ORIGINAL-order rows (PTRI,
+//   TRI1, DEL: the later stages index them by triangle), the 16-byte (P0, thr2) record and f to position s (P0S,
+//   IDX), and the wavefront -- which holds exactly one supergroup of 64 sorted records -- REFITS the supergroup's 13
+//   sphere-tree nodes to the moved points with DPP reductions over 8 / 16 / 64 lanes (wave_tree): the same nodes,
+//   bit for bit, that tri_sort_kernel derives from the same sorted records.
+// Any permutation gives identical labels, hit lists and loss (the tree is a conservative filter; the reference's
+// arithmetic decides in resolve_candidate): an order taken in another pose, or a stale one, only shapes the nodes.
+// PMAX (max |P|^2 per cloud and sample) is not reduced here -- that would take a hand-over between workgroups of
+// this launch --: the scan reduces the <= n / 256 partial rows (APART) in its prologue, next to the line maxima.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float xrow_min(float v) {  // rows of 16 already reduced: combine lanes 0, 16, 32, 48
+    const int b = __float_as_int(v);
+    return fminf(fminf(__int_as_float(__builtin_amdgcn_readlane(b, 0)), __int_as_float(__builtin_amdgcn_readlane(b, 16))),
+                 fminf(__int_as_float(__builtin_amdgcn_readlane(b, 32)), __int_as_float(__builtin_amdgcn_readlane(b, 48))));
+}
+__device__ __forceinline__ float xrow_max(float v) {
+    const int b = __float_as_int(v);
+    return fmaxf(fmaxf(__int_as_float(__builtin_amdgcn_readlane(b, 0)), __int_as_float(__builtin_amdgcn_readlane(b, 16))),
+                 fmaxf(__int_as_float(__builtin_amdgcn_readlane(b, 32)), __int_as_float(__builtin_amdgcn_readlane(b, 48))));
+}
+
+// The 13 tree nodes of ONE supergroup by the wavefront whose lanes hold its 64 sorted records (valid: a real record).
+// Expressions and association as in half_tree (rrl_tree.h): centre = mid-point of the node's AABB, rho^2 = max squared
+// distance of its records, thr_max = sqrt(max thr2) (1 + 1e-6): min / max are exact, so the nodes are bit-identical.
+__device__ __forceinline__ void wave_tree(float px, float py, float pz, float thr2, bool valid, int lane, float4 *__restrict__ node) {
+    float lo[3] = {valid ? px : INFINITY, valid ? py : INFINITY, valid ? pz : INFINITY};
+    float hi[3] = {valid ? px : -INFINITY, valid ? py : -INFINITY, valid ? pz : -INFINITY};
+    float tm2 = valid ? thr2 : 0.0f, any = valid ? 1.0f : 0.0f;
+    auto dist2 = [&](float cx, float cy, float cz) {
+        const float ex = px - cx, ey = py - cy, ez = pz - cz;
+        const float e2 = ex * ex + ey * ey + ez * ez;
+        return valid ? e2 : 0.0f;
+    };
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { OCT_MIN(lo[c]); OCT_MAX(hi[c]); }
+    OCT_MAX(tm2);
+    OCT_MAX(any);
+    float tm = sqrtf(tm2) * 1.000001f;
+    {   // the half of 8
+        const float cx = 0.5f * lo[0] + 0.5f * hi[0], cy = 0.5f * lo[1] + 0.5f * hi[1], cz = 0.5f * lo[2] + 0.5f * hi[2];
+        float d2 = dist2(cx, cy, cz);
+        OCT_MAX(d2);
+        if ((lane & 7) == 0) node[5 + (lane >> 3)] = finish_sphere(cx, cy, cz, d2, tm, any > 0.0f);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { lo[c] = fminf(lo[c], RRL_DPP_F(lo[c], 0x140)); hi[c] = fmaxf(hi[c], RRL_DPP_F(hi[c], 0x140)); }
+    tm = fmaxf(tm, RRL_DPP_F(tm, 0x140));
+    any = fmaxf(any, RRL_DPP_F(any, 0x140));
+    {   // the group of 16 (one DPP row)
+        const float cx = 0.5f * lo[0] + 0.5f * hi[0], cy = 0.5f * lo[1] + 0.5f * hi[1], cz = 0.5f * lo[2] + 0.5f * hi[2];
+        const float d2 = row16_max(dist2(cx, cy, cz));
+        if ((lane & 15) == 0) node[1 + (lane >> 4)] = finish_sphere(cx, cy, cz, d2, tm, any > 0.0f);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { lo[c] = xrow_min(lo[c]); hi[c] = xrow_max(hi[c]); }
+    tm = xrow_max(tm);
+    any = xrow_max(any);
+    {   // the supergroup
+        const float cx = 0.5f * lo[0] + 0.5f * hi[0], cy = 0.5f * lo[1] + 0.5f * hi[1], cz = 0.5f * lo[2] + 0.5f * hi[2];
+        const float d2 = wave_max(dist2(cx, cy, cz));
+        if (lane == 0) node[0] = finish_sphere(cx, cy, cz, d2, tm, any > 0.0f);
+    }
+}
+
+__global__ __launch_bounds__(REC_BLK) void tri_records_sorted_kernel(const BuildArgs a, const int32_t *__restrict__ order1,
+                                                                      const int32_t *__restrict__ order2) {
+    __shared__ float red[REC_BLK / 64][8];
+    __shared__ float red2[REC_BLK / 64][2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cloud = blockIdx.z, b = blockIdx.y, B = a.B;
+    build_clear_state(a);
+    const int n = cloud ? a.M : a.N;
+    if ((int)blockIdx.x >= a.nblk_tri) {  // uniform: the line maxima, beside the triangle workgroups (tri_records_kernel)
+        if (cloud == 0 && a.lmax != nullptr)
+            line_max_chunks(a.line, a.L, a.lmax, b, (int)blockIdx.x - a.nblk_tri, LMAX_CHUNKS, red2);
+        return;
+    }
+    const int npad = (n + SGT - 1) / SGT * SGT;
+    if ((int)blockIdx.x * REC_BLK >= npad) return;  // uniform: the smaller cloud has fewer workgroups
+    const int s = blockIdx.x * REC_BLK + tid;
+    const bool valid = s < n;  // real records occupy the sorted positions [0, n)
+    float c[9] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}, x = 0.0f, p2 = 0.0f;
+    int f = 0;
+    if (valid) {
+        f = (cloud ? order2 : order1)[(size_t)b * npad + s];
+        f = min(max(f, 0), n - 1);  // memory safety only: the order must be a permutation of [0, n)
+        tri_record_row(a, cloud, b, n, f, c, x, p2);
+    }
+    if (s - lane < npad) {  // wave-uniform: this wavefront holds a supergroup
+        (cloud ? a.p0s2 : a.p0s1)[(size_t)b * npad + s] = valid ? make_float4(c[0], c[1], c[2], x) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        (cloud ? a.idx2 : a.idx1)[(size_t)b * npad + s] = f;
+        wave_tree(c[0], c[1], c[2], x, valid, lane, (cloud ? a.grp2 : a.grp1) + ((size_t)b * (npad / SGT) + (s - lane) / SGT) * NODE);
+    }
+    // per-workgroup partial AABB of the P0s and max |P|^2, as tri_records_kernel leaves them
+    float mn[3], mx[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { mn[d] = wave_min(valid ? c[d] : INFINITY); mx[d] = wave_max(valid ? c[d] : -INFINITY); }
+    p2 = wave_max(p2);
+    if (lane == 0) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { red[wave][d] = mn[d]; red[wave][3 + d] = mx[d]; }
+        red[wave][6] = p2;
+    }
+    __syncthreads();
+    if (tid < 7) {
+        float r = red[0][tid];
+        for (int w = 1; w < REC_BLK / 64; ++w) r = tid < 3 ? fminf(r, red[w][tid]) : fmaxf(r, red[w][tid]);
+        a.apart[(((size_t)cloud * B + b) * a.nblk + blockIdx.x) * 8 + tid] = r;
+    }
+}
+
+// PMAX from the partial rows, for callers of the prepared build that do not run the culled scan next (rrl_tri_prepare_ex
+// on its own; the scan does this reduction in its prologue): one wavefront per (cloud, sample).
+__global__ __launch_bounds__(64) void pmax_from_partials_kernel(const float *__restrict__ apart, uint32_t *__restrict__ pmax,
+                                                                int B, int N, int M, int nblk) {
+    const int cb = blockIdx.x, cloud = cb >= B ? 1 : 0;
+    const int nb = ((cloud ? M : N) + REC_BLK - 1) / REC_BLK;
+    float v = 0.0f;
+    for (int j = threadIdx.x; j < nb; j += 64) v = fmaxf(v, apart[((size_t)cb * nblk + j) * 8 + 6]);
+    v = wave_max(v);
+    if (threadIdx.x == 0) pmax[cb] = __float_as_uint(v);
 }
 
 // Every lane keeps its <= NPT records in registers between the passes (n <= 1024 NPT).
@@ -1012,8 +1156,9 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(6, 8))
     const float4 *__restrict__ p0s2, const int32_t *__restrict__ idx1, const int32_t *__restrict__ idx2,
     const float4 *__restrict__ tree1, const float4 *__restrict__ tree2, const float *__restrict__ line,
     int32_t *__restrict__ count1, int32_t *__restrict__ hit1, int32_t *__restrict__ count2,
-    int32_t *__restrict__ hit2, int32_t *__restrict__ status, const uint32_t *__restrict__ pmax,
-    const float *__restrict__ del1, const float *__restrict__ del2, const float2 *__restrict__ lmax, int B,
+    int32_t *__restrict__ hit2, int32_t *__restrict__ status, uint32_t *pmax,
+    const float *__restrict__ del1, const float *__restrict__ del2, const float2 *__restrict__ lmax,
+    const float *__restrict__ apart, int nblk_apart, int B,
     int N, int M, int L, int spw, unsigned long long *__restrict__ counters, long long counter_rows) {
     __shared__ __attribute__((aligned(16))) float2 line_lds[WPB][LPW * 3];    // 24 KiB: raw 24-byte line rows
     __shared__ __attribute__((aligned(16))) float4 rec_lds[SPW * SGG * ROWS]; //  8.5 KiB
@@ -1058,7 +1203,20 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(6, 8))
         if (tid < nsl * NODE) nd0 = tree[(size_t)sg0 * NODE + tid];
     }
     const float2 lm = lmax[(size_t)b * LMAX_CHUNKS + lane];  // (max |dir|^2, max |x0|^2) over 1/64 of the sample's cullable lines
-    const float pm = __uint_as_float(pmax[cloud * B + b]);
+    // max |P|^2 of the cloud: from the sort kernel (PMAX), or -- prepared clouds, whose build has no single-workgroup stage
+    // -- from the records kernel's per-workgroup partial rows, reduced here next to the line maxima (one more independent
+    // load of the prologue; one workgroup per cloud and sample leaves PMAX for the later consumers)
+    float pm;
+    if (apart != nullptr) {  // uniform
+        const int nb = (n + REC_BLK - 1) / REC_BLK;
+        const float *ap = apart + (size_t)(cloud * B + b) * nblk_apart * 8 + 6;
+        float v = 0.0f;
+        for (int j = lane; j < nb; j += 64) v = fmaxf(v, ap[(size_t)j * 8]);
+        pm = wave_max(v);
+        if (blockIdx.y == 0 && blockIdx.z == 0 && tid == 0) pmax[cloud * B + b] = __float_as_uint(pm);
+    } else {
+        pm = __uint_as_float(pmax[cloud * B + b]);
+    }
 
     // this wave's 128 lines: a full, 16-byte aligned tile arrives as three coalesced 16-byte loads per lane straight
     // into its LDS rows; the lanes then pick up their own two lines from there
@@ -1251,13 +1409,21 @@ extern "C" int rrl_set_sort_parts(int parts) {
     g_sort_parts = parts;
     return 0;
 }
-static int sort_parts(int nsg) {
+int rrl_default_sort_parts(void) {
     if (g_sort_parts < 0) {
         const char *e = getenv("RRL_SORT_PARTS");
-        g_sort_parts = e ? atoi(e) : 0;
-        if (g_sort_parts < 0 || g_sort_parts > 16) g_sort_parts = 0;
+        int v = e ? atoi(e) : 0;
+        if (v < 0 || v > 16) v = 0;
+        g_sort_parts = v;
     }
-    int k = g_sort_parts ? g_sort_parts : 1;
+    return g_sort_parts;
+}
+void rrl_default_scan_counters(unsigned long long **buf, long long *rows) {
+    *buf = g_cull_counters;
+    *rows = g_cull_counter_rows;
+}
+static int sort_parts(int nsg, int requested) {  // requested: RrlCall::sort_parts (0 = automatic = one workgroup)
+    int k = requested ? requested : 1;
     if (k > nsg) k = nsg;
     return k < 1 ? 1 : k;
 }
@@ -1272,7 +1438,8 @@ static size_t sort_lds_bytes(int nsg, int parts, int raw_points) {
 
 // Launchers used by rrl_tri_prepare / rrl_line_tri_scan (rrl_scan.hip)
 int rrl_launch_tri_build(const float *tri1, const float *tri2, void *ws, const WsLayout &w, int B,
-                         int N, int M, int clouds, const RrlXform *xf, const float *line, int L, hipStream_t s) {
+                         int N, int M, int clouds, const RrlXform *xf, const float *line, int L, const RrlCall &o,
+                         hipStream_t s) {
     const int nmax = clouds == 2 && M > N ? M : N;
     const size_t ngpmax = (size_t)(nmax + SGT - 1) / SGT * SGG;  // groups, padded to whole supergroups
     // Clouds of more than 4096 triangles: ONE launch of the single-workgroup sort per chunk of 4096 records
@@ -1285,7 +1452,7 @@ int rrl_launch_tri_build(const float *tri1, const float *tri2, void *ws, const W
     const char *wide_env = getenv("RRL_SORT_WIDE");
     const bool chunked = nmax > 4096 && !(wide_env && atoi(wide_env) != 0);
     const size_t ngps = nmax <= 4096 ? ngpmax : (size_t)(4096 / GRP);
-    const int parts = sort_parts((int)(ngps / SGG));
+    const int parts = sort_parts((int)(ngps / SGG), o.sort_parts);
     const size_t lds = nmax <= 4096 || chunked ? sort_lds_bytes((int)(ngps / SGG), parts, 0) : 16;
     BuildArgs a;
     a.tri1 = xf ? xf->src : tri1;
@@ -1325,6 +1492,14 @@ int rrl_launch_tri_build(const float *tri1, const float *tri2, void *ws, const W
     a.nblk = (nall + REC_BLK - 1) / REC_BLK;
     a.nchunk = chunked ? (nmax + 4095) / 4096 : 1;
     a.nblk_tri = (nmax + REC_BLK - 1) / REC_BLK;
+    if (o.prepared()) {  // the order is known: ONE launch (records at their sorted positions + tree refit), no sort
+        a.z2 = nullptr; a.z2_vec4 = 0;
+        a.nblk_tri = (int)(((size_t)(nmax + SGT - 1) / SGT * SGT + REC_BLK - 1) / REC_BLK);
+        hipLaunchKernelGGL(tri_records_sorted_kernel, dim3((unsigned)(a.nblk_tri + (a.lmax ? LMAX_CHUNKS : 0)), (unsigned)B, (unsigned)clouds),
+                           dim3(REC_BLK), 0, s, a, o.order1, o.order2);
+        hipError_t e = hipGetLastError();
+        return e == hipSuccess ? 0 : (int)e;
+    }
     hipLaunchKernelGGL(tri_records_kernel, dim3((unsigned)(a.nblk_tri + (a.lmax ? LMAX_CHUNKS : 0)), (unsigned)B, (unsigned)clouds),
                        dim3(REC_BLK), 0, s, a);
     if (nmax <= 4096 || chunked) {
@@ -1337,6 +1512,15 @@ int rrl_launch_tri_build(const float *tri1, const float *tri2, void *ws, const W
         const dim3 gs((unsigned)((2 * ngpmax + 255) / 256), (unsigned)B, (unsigned)clouds);
         hipLaunchKernelGGL(big_sphere_kernel, gs, dim3(256), 0, s, a);
     }
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+// PMAX of a prepared build for consumers other than the culled scan (include/rrl.h rrl_tri_prepare_ex)
+int rrl_launch_pmax_from_partials(void *ws, const WsLayout &w, int B, int N, int M, int clouds, hipStream_t s) {
+    const int nall = N > M ? N : M;
+    hipLaunchKernelGGL(pmax_from_partials_kernel, dim3((unsigned)(clouds * B)), dim3(64), 0, s, w.f32(ws, RRL_WS_APART),
+                       (uint32_t *)w.i32(ws, RRL_WS_PMAX), B, N, M, (nall + REC_BLK - 1) / REC_BLK);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }
@@ -1365,7 +1549,7 @@ int rrl_launch_cloud_sort(const float *raw1, const float *raw2, float4 *crec1, f
     // (the chunked sort of rrl_launch_tri_build was tried here too: a nearest-neighbour walk evaluates twice the
     //  pairs on chunked clouds -- 63.0 -> 64.4 us at N = M = 16384, 188 -> 380 at 65536: whole-cloud order stays)
     if (nmax <= 4096) {
-        const int parts = sort_parts((int)(ngpmax / SGG));
+        const int parts = sort_parts((int)(ngpmax / SGG), rrl_default_sort_parts());
         if (raw1 && raw2) hipLaunchKernelGGL((tri_sort_kernel<4, true>), dim3((unsigned)(2 * B), (unsigned)parts), dim3(1024),
                                              sort_lds_bytes((int)(ngpmax / SGG), parts, nmax), s, a);
         else hipLaunchKernelGGL((tri_sort_kernel<4, false>), dim3((unsigned)(2 * B), (unsigned)parts), dim3(1024),
@@ -1382,7 +1566,7 @@ int rrl_launch_cloud_sort(const float *raw1, const float *raw2, float4 *crec1, f
 }
 
 int rrl_launch_cull_scan(const float *line, void *ws, const WsLayout &w, int B, int N, int M, int L,
-                         int clouds, int lmax_ready, hipStream_t s) {
+                         int clouds, int lmax_ready, const RrlCall &o, hipStream_t s) {
     // a workgroup = (cloud and sample, tile of <= WPB x 128 lines, slice of spw supergroups).  With
     // few lines or small clouds the slices get thinner, so that the launch still has ~1000
     // workgroups for the 256 CUs (measured with tools/geom_sweep.sh: thinner slices cost little,
@@ -1416,11 +1600,13 @@ int rrl_launch_cull_scan(const float *line, void *ws, const WsLayout &w, int B, 
                        w.i32(ws, RRL_WS_IDX1), w.i32(ws, RRL_WS_IDX2), (const float4 *)w.f32(ws, RRL_WS_GRP1), \
                        (const float4 *)w.f32(ws, RRL_WS_GRP2), line, w.i32(ws, RRL_WS_COUNT1),               \
                        w.i32(ws, RRL_WS_HIT1), w.i32(ws, RRL_WS_COUNT2), w.i32(ws, RRL_WS_HIT2),             \
-                       w.i32(ws, RRL_WS_STATUS), (const uint32_t *)w.i32(ws, RRL_WS_PMAX),                   \
+                       w.i32(ws, RRL_WS_STATUS), (uint32_t *)w.i32(ws, RRL_WS_PMAX),                         \
                        w.f32(ws, RRL_WS_DEL1), w.f32(ws, RRL_WS_DEL2), (const float2 *)w.f32(ws, RRL_WS_LMAX),   \
-                       B, N, M, L, spw,                                                                      \
-                       g_cull_counters, g_cull_counter_rows)
-    if (g_cull_counters) RRL_CULL_LAUNCH(true);
+                       apart, nblk_apart, B, N, M, L, spw,                                                   \
+                       o.counters, o.counter_rows)
+    const float *apart = o.prepared() ? w.f32(ws, RRL_WS_APART) : nullptr;  // prepared build: PMAX comes from the partial rows
+    const int nblk_apart = ((N > M ? N : M) + REC_BLK - 1) / REC_BLK;
+    if (o.counters) RRL_CULL_LAUNCH(true);
     else RRL_CULL_LAUNCH(false);
 #undef RRL_CULL_LAUNCH
     hipError_t e = hipGetLastError();
@@ -1428,3 +1614,24 @@ int rrl_launch_cull_scan(const float *line, void *ws, const WsLayout &w, int B, 
 }
 
 int rrl_sort_capacity(void) { return SORT_CAP; }
+
+// ---------------------------------------------------------------------------------------
+// rrl_cloud_order (include/rrl.h): the spatial order of a cloud, computed once.
+// ---------------------------------------------------------------------------------------
+extern "C" size_t rrl_cloud_order_workspace_bytes(int B, int n) {
+    return WsLayout(B > 0 ? B : 0, n > 0 ? n : 0, 0, 0).total + 256;
+}
+
+extern "C" int rrl_cloud_order(const float *tri, int32_t *order, void *ws, size_t ws_bytes, int B, int n, void *stream) {
+    if (!tri || !order || !ws || B < 0 || n < 0 || n > SORT_CAP) return RRL_E_ARG;
+    if (B == 0 || n == 0) return 0;
+    WsLayout w(B, n, 0, 0);
+    if (ws_bytes < w.total) return RRL_E_WS;
+    hipStream_t s = (hipStream_t)stream;
+    RrlCall o = {};
+    o.sort_parts = rrl_default_sort_parts();
+    int rc = rrl_launch_tri_build(tri, tri, ws, w, B, n, 0, 1, nullptr, nullptr, 0, o, s);  // records + cell sort of cloud 0
+    if (rc) return rc;
+    const size_t npad = (size_t)(n + SGT - 1) / SGT * SGT;
+    return rrl_copy(order, w.i32(ws, RRL_WS_IDX1), sizeof(int32_t) * (size_t)B * npad, s);
+}

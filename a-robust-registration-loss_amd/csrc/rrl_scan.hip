@@ -124,10 +124,12 @@ __global__ __launch_bounds__(64) void tri_prepare_kernel(const float *__restrict
     }
 }
 
+int rrl_launch_pmax_from_partials(void *ws, const WsLayout &w, int B, int N, int M, int clouds, hipStream_t s);
 int rrl_launch_tri_build(const float *tri1, const float *tri2, void *ws, const WsLayout &w, int B,
-                         int N, int M, int clouds, const RrlXform *xf, const float *line, int L, hipStream_t s);
+                         int N, int M, int clouds, const RrlXform *xf, const float *line, int L, const RrlCall &o,
+                         hipStream_t s);
 int rrl_launch_cull_scan(const float *line, void *ws, const WsLayout &w, int B, int N, int M, int L,
-                         int clouds, int lmax_ready, hipStream_t s);
+                         int clouds, int lmax_ready, const RrlCall &o, hipStream_t s);
 int rrl_sort_capacity(void);
 
 // clouds = 2: both clouds; clouds = 1: the source only (the target's scan results are carried
@@ -140,7 +142,8 @@ int rrl_sort_capacity(void);
 // line != NULL: the records kernel also reduces the samples' lines to the partial maxima the culled scan derives its
 // slacks from (the fused forwards); NULL: the scan entry does that itself (rrl_tri_prepare + rrl_line_tri_scan).
 int rrl_tri_prepare_clouds(const float *tri1, const float *tri2, void *ws, size_t ws_bytes, int B,
-                           int N, int M, int L, int clouds, const RrlXform *xf, const float *line, void *stream) {
+                           int N, int M, int L, int clouds, const RrlXform *xf, const float *line, const RrlCall &o,
+                           void *stream) {
     if ((!tri1 && !xf) || !tri2 || !ws || B < 0 || N < 0 || M < 0 || L < 0) return RRL_E_ARG;
     WsLayout w(B, N, M, L);
     if (ws_bytes < w.total) return RRL_E_WS;
@@ -156,7 +159,7 @@ int rrl_tri_prepare_clouds(const float *tri1, const float *tri2, void *ws, size_
         if ((rc = rrl_fill((char *)ws + w.state_off, 0u, w.state_bytes, s))) return rc;
     }
     if (B == 0 || nmax == 0) return 0;
-    if (sorted) return rrl_launch_tri_build(tri1, tri2, ws, w, B, N, M, clouds, xf, line, L, s);
+    if (sorted) return rrl_launch_tri_build(tri1, tri2, ws, w, B, N, M, clouds, xf, line, L, o, s);
     if (xf) {
         if (xf->zero_g1) {
             int rc = rrl_fill(w.f32(ws, RRL_WS_GACC), 0u, w.off[RRL_WS_KJC] - w.off[RRL_WS_GACC], s);
@@ -175,9 +178,19 @@ int rrl_tri_prepare_clouds(const float *tri1, const float *tri2, void *ws, size_
     return 0;
 }
 
+extern "C" int rrl_tri_prepare_ex(const float *tri1, const float *tri2, void *ws, size_t ws_bytes,
+                                  int B, int N, int M, int L, const rrl_opts *opts, void *stream) {
+    RrlCall o = rrl_resolve_opts(opts);
+    if (o.prepared() && (!o.order2 || (N > M ? N : M) > rrl_sort_capacity())) o.order1 = o.order2 = nullptr;  // both orders, sorted layout
+    o.flags &= ~RRL_F_TARGET_KEPT;  // a stage call builds both clouds
+    int rc = rrl_tri_prepare_clouds(tri1, tri2, ws, ws_bytes, B, N, M, L, 2, nullptr, nullptr, o, stream);
+    if (rc || !o.prepared() || B <= 0 || (N <= 0 && M <= 0)) return rc;
+    // prepared build: PMAX is normally reduced by the culled scan's prologue; a stage call leaves it complete itself
+    return rrl_launch_pmax_from_partials(ws, WsLayout(B, N, M, L), B, N, M, 2, (hipStream_t)stream);
+}
 extern "C" int rrl_tri_prepare(const float *tri1, const float *tri2, void *ws, size_t ws_bytes,
                                int B, int N, int M, int L, void *stream) {
-    return rrl_tri_prepare_clouds(tri1, tri2, ws, ws_bytes, B, N, M, L, 2, nullptr, nullptr, stream);
+    return rrl_tri_prepare_ex(tri1, tri2, ws, ws_bytes, B, N, M, L, nullptr, stream);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -373,6 +386,7 @@ __global__ __launch_bounds__(256) void scan_kernel(
 }
 
 static int g_scan_variant = 0;  // 0 = default; else lines per lane (1, 2, 4, 8)
+int rrl_default_scan_variant(void) { return g_scan_variant; }
 
 extern "C" int rrl_set_scan_variant(int lines_per_lane) {
     if (lines_per_lane != 0 && lines_per_lane != 1 && lines_per_lane != 2 && lines_per_lane != 4 &&
@@ -414,7 +428,7 @@ extern "C" int rrl_scan_timing_collect(float *ms, int max_n) {
 }
 
 int rrl_line_tri_scan_clouds(const float *line, void *ws, size_t ws_bytes, int B, int N, int M, int L,
-                             int mode, int chunk, int clouds, int lmax_ready, void *stream) {
+                             int mode, int chunk, int clouds, int lmax_ready, const RrlCall &o, void *stream) {
     if (!line || !ws || B < 0 || N < 0 || M < 0 || L < 0 || chunk < 0) return RRL_E_ARG;
     if (mode != RRL_SCAN_STRICT && mode != RRL_SCAN_LAZY && mode != RRL_SCAN_AUTO &&
         mode != RRL_SCAN_CULL)
@@ -428,12 +442,12 @@ int rrl_line_tri_scan_clouds(const float *line, void *ws, size_t ws_bytes, int B
     const bool timed = g_timing_on && (g_timing_seen++ % g_timing_on) == 0 && g_timing_n < TIMING_RING;
     if (mode == RRL_SCAN_CULL) {  // one launch: sphere-culled scan with an inline strict fallback
         if (timed) (void)hipEventRecord(g_ev[g_timing_n][0], s);
-        int rc = rrl_launch_cull_scan(line, ws, w, B, N, M, L, clouds, lmax_ready, s);
+        int rc = rrl_launch_cull_scan(line, ws, w, B, N, M, L, clouds, lmax_ready, o, s);
         if (rc) return rc;
         if (timed) (void)hipEventRecord(g_ev[g_timing_n++][1], s);
         return 0;
     }
-    int R = g_scan_variant;
+    int R = o.scan_variant;
     if (R == 0) {
         const char *v = getenv("RRL_SCAN_VARIANT");
         R = v ? atoi(v) : 0;
@@ -464,7 +478,13 @@ int rrl_line_tri_scan_clouds(const float *line, void *ws, size_t ws_bytes, int B
     return 0;
 }
 
+extern "C" int rrl_line_tri_scan_ex(const float *line, void *ws, size_t ws_bytes, int B, int N, int M,
+                                    int L, int mode, int chunk, const rrl_opts *opts, void *stream) {
+    RrlCall o = rrl_resolve_opts(opts);
+    if (o.prepared() && (!o.order2 || (N > M ? N : M) > rrl_sort_capacity())) o.order1 = o.order2 = nullptr;
+    return rrl_line_tri_scan_clouds(line, ws, ws_bytes, B, N, M, L, mode, chunk, 2, 0, o, stream);
+}
 extern "C" int rrl_line_tri_scan(const float *line, void *ws, size_t ws_bytes, int B, int N, int M,
                                  int L, int mode, int chunk, void *stream) {
-    return rrl_line_tri_scan_clouds(line, ws, ws_bytes, B, N, M, L, mode, chunk, 2, 0, stream);
+    return rrl_line_tri_scan_ex(line, ws, ws_bytes, B, N, M, L, mode, chunk, nullptr, stream);
 }

@@ -6,6 +6,7 @@
 // About 9 % of the lines are selected; these kernels touch O(L) data and are latency bound
 // (a few microseconds each) next to the O(L*(N+M)) scan.
 #include <stdlib.h>
+#include <string.h>
 
 #include "rrl_ws.h"
 
@@ -285,32 +286,37 @@ static PairArgs pair_args(const float *tri2_raw, const float *line, void *ws, co
     return a;
 }
 
-static int reduce_kind(int B, int nblk, int pool, bool with_bwd);
+static int reduce_kind(int mode, int B, int nblk, int pool, bool with_bwd);
 
 // tri2_raw != NULL: the target's prepared records are not in this workspace (its scan was carried
 // over from another one): read its raw rows instead.  with_bwd: the reduce that follows will carry the direct backward
 // (rrl_registration_step) -- it decides, with the shape, whether the tail kernel runs and wants the dense value lists
 static int line_pair_dist_impl(const float *tri2_raw, const float *line, void *ws, size_t ws_bytes, int B,
                                int N, int M, int L, int s_m, int s_n, int e_m, int e_n, int pool,
-                               void *stream, bool with_bwd = false) {
+                               const RrlCall &o, void *stream, bool with_bwd = false) {
     if (!line || !ws || B < 0 || N < 0 || M < 0 || L < 0 || L >= (1 << 24)) return RRL_E_ARG;  // 24-bit line ids in LDS
     if (s_m < 1 || s_n < 1 || e_m > RRL_MAX_HITS + 1 || e_n > RRL_MAX_HITS + 1) return RRL_E_RANGE;
     WsLayout w(B, N, M, L);
     if (ws_bytes < w.total) return RRL_E_WS;
     if (B == 0 || L == 0) return 0;
     PairArgs pa = pair_args(tri2_raw, line, ws, w, B, N, M, L, s_m, s_n, e_m, e_n);
-    if (reduce_kind(B, (L + 1023) / 1024, pool, with_bwd) != 2) pa.vlist = nullptr;  // only the tail kernel reads VLIST
+    if (reduce_kind(o.reduce_mode, B, (L + 1023) / 1024, pool, with_bwd) != 2) pa.vlist = nullptr;  // only the tail kernel reads VLIST
     hipLaunchKernelGGL(line_pair_dist_kernel, dim3((unsigned)((L + 1023) / 1024), (unsigned)B), dim3(1024), 0,
                        (hipStream_t)stream, pa);
     RRL_LAUNCH_CHECK();
     return 0;
 }
 
+extern "C" int rrl_line_pair_dist_ex(const float *tri1, const float *tri2, const float *line,
+                                     void *ws, size_t ws_bytes, int B, int N, int M, int L, int s_m,
+                                     int s_n, int e_m, int e_n, int pool, const rrl_opts *opts, void *stream) {
+    if (!tri1 || !tri2) return RRL_E_ARG;  // the prepared records of both (rrl_tri_prepare) are read
+    return line_pair_dist_impl(nullptr, line, ws, ws_bytes, B, N, M, L, s_m, s_n, e_m, e_n, pool, rrl_resolve_opts(opts), stream);
+}
 extern "C" int rrl_line_pair_dist(const float *tri1, const float *tri2, const float *line,
                                   void *ws, size_t ws_bytes, int B, int N, int M, int L, int s_m,
                                   int s_n, int e_m, int e_n, int pool, void *stream) {
-    if (!tri1 || !tri2) return RRL_E_ARG;  // the prepared records of both (rrl_tri_prepare) are read
-    return line_pair_dist_impl(nullptr, line, ws, ws_bytes, B, N, M, L, s_m, s_n, e_m, e_n, pool, stream);
+    return rrl_line_pair_dist_ex(tri1, tri2, line, ws, ws_bytes, B, N, M, L, s_m, s_n, e_m, e_n, pool, nullptr, stream);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1589,12 +1595,33 @@ extern "C" int rrl_set_reduce_mode(int mode) {
     g_reduce_mode = mode;
     return 0;
 }
-static int reduce_mode() {
+static int default_reduce_mode() {
     if (g_reduce_mode < 0) {
         const char *e = getenv("RRL_REDUCE");
         g_reduce_mode = !e ? 0 : (e[0] == 's' ? 1 : (e[0] == 't' ? 2 : (e[0] == 'x' ? 3 : 0)));
     }
     return g_reduce_mode;
+}
+static bool default_deterministic();
+// include/rrl.h rrl_opts -> the options of one call (csrc/rrl_ws.h RrlCall).  Fields the caller's struct does not
+// reach (struct_bytes), -1 and NULL mean the process-wide default.
+RrlCall rrl_resolve_opts(const rrl_opts *p) {
+    RrlCall o;
+    rrl_opts v;
+    memset(&v, 0, sizeof v);
+    v.reduce_mode = v.deterministic = v.sort_parts = v.scan_variant = -1;
+    if (p && p->struct_bytes >= 8) memcpy(&v, p, (size_t)p->struct_bytes < sizeof v ? (size_t)p->struct_bytes : sizeof v);
+    o.flags = v.flags;
+    o.reduce_mode = v.reduce_mode >= 0 && v.reduce_mode <= 3 ? v.reduce_mode : default_reduce_mode();
+    o.deterministic = v.deterministic >= 0 ? (v.deterministic ? 1 : 0) : (default_deterministic() ? 1 : 0);
+    o.sort_parts = v.sort_parts >= 0 && v.sort_parts <= 16 ? v.sort_parts : rrl_default_sort_parts();
+    const int sv = v.scan_variant;
+    o.scan_variant = (sv == 0 || sv == 1 || sv == 2 || sv == 4 || sv == 8) ? sv : rrl_default_scan_variant();
+    o.order1 = v.order1;
+    o.order2 = v.order2;
+    if (v.scan_counters) { o.counters = (unsigned long long *)v.scan_counters; o.counter_rows = v.scan_counter_rows; }
+    else rrl_default_scan_counters(&o.counters, &o.counter_rows);
+    return o;
 }
 // Which reduce kernel: 0 one workgroup per sample, 1 tiled with the candidate exchange (loss_reduce_tiled_kernel), 2 the
 // tail kernel (no exchange: every workgroup streams its sample's dense value lists; one 512-lane workgroup or two
@@ -1604,8 +1631,7 @@ static int reduce_mode() {
 // the demo's shape, one sample of 20 tiles, the two are even), else the exchange kernel for >= 2 tiles while the grid
 // is co-resident, else the single workgroup; 1: single; 2 ("tiled"): the tail kernel wherever it is legal (also forward
 // only, also one tile: tests), exchange beyond; 3 ("xchg"): the exchange kernel wherever it is legal.
-static int reduce_kind(int B, int nblk, int pool, bool with_bwd) {
-    const int mode = reduce_mode();
+static int reduce_kind(int mode, int B, int nblk, int pool, bool with_bwd) {
     if (pool || mode == 1) return 0;
     const bool xchg_ok = (long)B * nblk <= 1024;
     if (mode == 3) return xchg_ok && nblk >= 1 ? 1 : 0;
@@ -1634,7 +1660,7 @@ static ReduceArgs reduce_args(void *ws, const WsLayout &w, float *loss, int B, i
 
 // tb != NULL: the caller wants the direct backward too; *bwd_done tells whether this launch carried it
 static int loss_reduce_impl(void *ws, size_t ws_bytes, float *loss, int B, int N, int M, int L, int s_m, int s_n, int e_m,
-                            int e_n, int pool, const TailBwd *tb, bool *bwd_done, void *stream) {
+                            int e_n, int pool, const TailBwd *tb, bool *bwd_done, const RrlCall &o, void *stream) {
     if (bwd_done) *bwd_done = false;
     if (!ws || !loss || B < 0 || N < 0 || M < 0 || L < 0) return RRL_E_ARG;
     if (s_m < 1 || s_n < 1 || e_m > RRL_MAX_HITS + 1 || e_n > RRL_MAX_HITS + 1) return RRL_E_RANGE;
@@ -1642,7 +1668,7 @@ static int loss_reduce_impl(void *ws, size_t ws_bytes, float *loss, int B, int N
     if (ws_bytes < w.total) return RRL_E_WS;
     if (B == 0) return 0;
     const int nblk = (L + 1023) / 1024;
-    const int kind = reduce_kind(B, nblk, pool, tb != nullptr);
+    const int kind = reduce_kind(o.reduce_mode, B, nblk, pool, tb != nullptr);
     if (kind == 2) {
         TailArgs t;
         t.lidc = w.u32(ws, RRL_WS_LIDC); t.dc = w.f32(ws, RRL_WS_VALS); t.blkcnt = w.i32(ws, RRL_WS_BLKCNT);
@@ -1681,9 +1707,13 @@ static int loss_reduce_impl(void *ws, size_t ws_bytes, float *loss, int B, int N
     return 0;
 }
 
+extern "C" int rrl_loss_reduce_ex(void *ws, size_t ws_bytes, float *loss, int B, int N, int M, int L,
+                                  int s_m, int s_n, int e_m, int e_n, int pool, const rrl_opts *opts, void *stream) {
+    return loss_reduce_impl(ws, ws_bytes, loss, B, N, M, L, s_m, s_n, e_m, e_n, pool, nullptr, nullptr, rrl_resolve_opts(opts), stream);
+}
 extern "C" int rrl_loss_reduce(void *ws, size_t ws_bytes, float *loss, int B, int N, int M, int L,
                                int s_m, int s_n, int e_m, int e_n, int pool, void *stream) {
-    return loss_reduce_impl(ws, ws_bytes, loss, B, N, M, L, s_m, s_n, e_m, e_n, pool, nullptr, nullptr, stream);
+    return rrl_loss_reduce_ex(ws, ws_bytes, loss, B, N, M, L, s_m, s_n, e_m, e_n, pool, nullptr, stream);
 }
 
 // K3 + K4 over CALLER-SUPPLIED rows (the merge step of the line-sharded single-sample mode, rrl_hip/dist.py): every rank
@@ -2112,7 +2142,7 @@ extern "C" int rrl_set_deterministic(int on) {
     g_deterministic = on ? 1 : 0;
     return 0;
 }
-static bool rrl_deterministic() {
+static bool default_deterministic() {
     if (g_deterministic < 0) {
         const char *e = getenv("RRL_DETERMINISTIC");
         g_deterministic = (e && e[0] == '1') ? 1 : 0;
@@ -2170,9 +2200,10 @@ extern "C" int rrl_workspace_layout(int B, int N, int M, int L, size_t *offsets)
 }
 
 int rrl_tri_prepare_clouds(const float *tri1, const float *tri2, void *ws, size_t ws_bytes, int B,
-                           int N, int M, int L, int clouds, const RrlXform *xf, const float *line, void *stream);
+                           int N, int M, int L, int clouds, const RrlXform *xf, const float *line, const RrlCall &o,
+                           void *stream);
 int rrl_line_tri_scan_clouds(const float *line, void *ws, size_t ws_bytes, int B, int N, int M, int L,
-                             int mode, int chunk, int clouds, int lmax_ready, void *stream);
+                             int mode, int chunk, int clouds, int lmax_ready, const RrlCall &o, void *stream);
 int rrl_sort_capacity(void);
 
 // target_ws != NULL: a workspace of the same (B, N, M, L) that already went through a forward with
@@ -2183,18 +2214,25 @@ int rrl_sort_capacity(void);
 static int loss_forward_impl(const float *tri1, const float *tri2, const float *line, void *ws,
                              size_t ws_bytes, float *loss, int B, int N, int M, int L, int s_m,
                              int s_n, int e_m, int e_n, int pool, int mode, int chunk,
-                             const void *target_ws, const RrlXform *xf, void *stream,
+                             const void *target_ws, const RrlXform *xf, RrlCall o, void *stream,
                              const TailBwd *tb = nullptr, bool *bwd_done = nullptr) {
     if (bwd_done) *bwd_done = false;
     if (!tri1 || !tri2 || !line || !ws || !loss) return RRL_E_ARG;
     if (s_m < 1 || s_n < 1 || e_m > RRL_MAX_HITS + 1 || e_n > RRL_MAX_HITS + 1) return RRL_E_RANGE;
     if (target_ws == ws) return RRL_E_ARG;
     const int clouds = target_ws ? 1 : 2;
+    // prepared clouds (include/rrl.h rrl_opts): honoured by the sorted layout of scan mode cull, with the orders of every
+    // cloud this call builds; anything else takes the plain path (same results)
+    if (o.prepared() && (mode != RRL_SCAN_CULL || (N > M ? N : M) > rrl_sort_capacity() ||
+                         (clouds == 2 && !o.order2 && !(o.flags & RRL_F_TARGET_KEPT))))
+        o.order1 = o.order2 = nullptr;
+    // a kept target: cloud 2's records / tree / partials stay as the previous call on this workspace left them
+    const int build_clouds = o.target_kept() ? 1 : clouds;
     int rc;
     RrlRange step("rrl forward");
     {
         RrlRange r("K1' records + sort + tree");
-        if ((rc = rrl_tri_prepare_clouds(tri1, tri2, ws, ws_bytes, B, N, M, L, clouds, xf, line, stream))) return rc;
+        if ((rc = rrl_tri_prepare_clouds(tri1, tri2, ws, ws_bytes, B, N, M, L, build_clouds, xf, line, o, stream))) return rc;
     }
     if (target_ws && (size_t)B * L) {  // after the prepare step, which cleared COUNT2
         WsLayout w(B, N, M, L);
@@ -2210,9 +2248,9 @@ static int loss_forward_impl(const float *tri1, const float *tri2, const float *
         RrlRange r("K1 line<->triangle scan");
         // (the records kernel reduced the lines' maxima whenever it ran: the sorted path)
         const int lmax_ready = (N > M ? N : M) <= rrl_sort_capacity() && B > 0 && (clouds == 2 && M > N ? M : N) > 0 && L > 0;
-        if ((rc = rrl_line_tri_scan_clouds(line, ws, ws_bytes, B, N, M, L, mode, chunk, clouds, lmax_ready, stream))) return rc;
+        if ((rc = rrl_line_tri_scan_clouds(line, ws, ws_bytes, B, N, M, L, mode, chunk, clouds, lmax_ready, o, stream))) return rc;
     }
-    if (L >= 1 && L <= 1024 && !pool && B > 0 && reduce_mode() < 2) {  // one tile of lines per sample: K2 + K3 + K4 in one launch
+    if (L >= 1 && L <= 1024 && !pool && B > 0 && o.reduce_mode < 2) {  // one tile of lines per sample: K2 + K3 + K4 in one launch
         RrlRange r("K2 + K3 + K4 (single tile)");
         WsLayout w(B, N, M, L);
         if (ws_bytes < w.total) return RRL_E_WS;
@@ -2241,19 +2279,26 @@ static int loss_forward_impl(const float *tri1, const float *tri2, const float *
     {
         RrlRange r("K2 per-line distances");
         if ((rc = line_pair_dist_impl(target_ws ? tri2 : nullptr, line, ws, ws_bytes, B, N, M, L, s_m, s_n, e_m,
-                                      e_n, pool, stream, tb != nullptr)))
+                                      e_n, pool, o, stream, tb != nullptr)))
             return rc;
     }
     RrlRange r("K3+K4 median + Welsch reduce");
-    return loss_reduce_impl(ws, ws_bytes, loss, B, N, M, L, s_m, s_n, e_m, e_n, pool, tb, bwd_done, stream);
+    return loss_reduce_impl(ws, ws_bytes, loss, B, N, M, L, s_m, s_n, e_m, e_n, pool, tb, bwd_done, o, stream);
 }
 
+extern "C" int rrl_loss_forward_ex(const float *tri1, const float *tri2, const float *line,
+                                   void *ws, size_t ws_bytes, float *loss, int B, int N, int M,
+                                   int L, int s_m, int s_n, int e_m, int e_n, int pool, int mode,
+                                   int chunk, const void *target_ws, const rrl_opts *opts, void *stream) {
+    return loss_forward_impl(tri1, tri2, line, ws, ws_bytes, loss, B, N, M, L, s_m, s_n, e_m, e_n,
+                             pool, mode, chunk, target_ws, nullptr, rrl_resolve_opts(opts), stream);
+}
 extern "C" int rrl_loss_forward_cached(const float *tri1, const float *tri2, const float *line,
                                        void *ws, size_t ws_bytes, float *loss, int B, int N, int M,
                                        int L, int s_m, int s_n, int e_m, int e_n, int pool, int mode,
                                        int chunk, const void *target_ws, void *stream) {
-    return loss_forward_impl(tri1, tri2, line, ws, ws_bytes, loss, B, N, M, L, s_m, s_n, e_m, e_n,
-                             pool, mode, chunk, target_ws, nullptr, stream);
+    return rrl_loss_forward_ex(tri1, tri2, line, ws, ws_bytes, loss, B, N, M, L, s_m, s_n, e_m, e_n,
+                               pool, mode, chunk, target_ws, nullptr, stream);
 }
 
 // The drop-in call (code/loss.py:170-232 as the reference's callers use it: one sample, a Python-level
@@ -2268,7 +2313,7 @@ extern "C" int rrl_loss_forward_info(const float *tri1, const float *tri2, const
                                      const void *target_ws, int32_t *host_info, void *stream) {
     if (!host_info) return RRL_E_ARG;
     int rc = loss_forward_impl(tri1, tri2, line, ws, ws_bytes, loss, B, N, M, L, s_m, s_n, e_m, e_n,
-                               pool, mode, chunk, target_ws, nullptr, stream);
+                               pool, mode, chunk, target_ws, nullptr, rrl_resolve_opts(nullptr), stream);
     if (rc) return rc;
     const int G = pool ? 1 : B;
     if (G <= 0) return 0;
@@ -2291,12 +2336,12 @@ extern "C" int rrl_loss_forward(const float *tri1, const float *tri2, const floa
 // ---------------------------------------------------------------------------------------
 // fused training op: rigid transform of the source + loss, and its backward to (dR, dt)
 // ---------------------------------------------------------------------------------------
-extern "C" int rrl_registration_forward_cached(const float *src, const float *R, const float *t,
-                                               const float *tri2, const float *line, void *ws,
-                                               size_t ws_bytes, float *loss, int B, int N, int M,
-                                               int L, int transpose_r, int s_m, int s_n, int e_m,
-                                               int e_n, int mode, int chunk, const void *target_ws,
-                                               void *stream) {
+extern "C" int rrl_registration_forward_ex(const float *src, const float *R, const float *t,
+                                           const float *tri2, const float *line, void *ws,
+                                           size_t ws_bytes, float *loss, int B, int N, int M,
+                                           int L, int transpose_r, int s_m, int s_n, int e_m,
+                                           int e_n, int mode, int chunk, const void *target_ws,
+                                           const rrl_opts *opts, void *stream) {
     if (!src || !R || !t || !tri2 || !line || !ws || !loss) return RRL_E_ARG;
     if (B < 0 || N < 0 || M < 0 || L < 0) return RRL_E_ARG;
     WsLayout w(B, N, M, L);
@@ -2304,7 +2349,16 @@ extern "C" int rrl_registration_forward_cached(const float *src, const float *R,
     // the transform runs inside the prepare step
     const RrlXform xf = {src, R, t, transpose_r, 1};  // 1: clear GACC for the backward's atomics
     return loss_forward_impl(w.f32(ws, RRL_WS_TRI1), tri2, line, ws, ws_bytes, loss, B, N, M, L, s_m,
-                             s_n, e_m, e_n, 0, mode, chunk, target_ws, &xf, stream);
+                             s_n, e_m, e_n, 0, mode, chunk, target_ws, &xf, rrl_resolve_opts(opts), stream);
+}
+extern "C" int rrl_registration_forward_cached(const float *src, const float *R, const float *t,
+                                               const float *tri2, const float *line, void *ws,
+                                               size_t ws_bytes, float *loss, int B, int N, int M,
+                                               int L, int transpose_r, int s_m, int s_n, int e_m,
+                                               int e_n, int mode, int chunk, const void *target_ws,
+                                               void *stream) {
+    return rrl_registration_forward_ex(src, R, t, tri2, line, ws, ws_bytes, loss, B, N, M, L, transpose_r, s_m, s_n,
+                                       e_m, e_n, mode, chunk, target_ws, nullptr, stream);
 }
 
 extern "C" int rrl_registration_forward(const float *src, const float *R, const float *t,
@@ -2317,31 +2371,32 @@ extern "C" int rrl_registration_forward(const float *src, const float *R, const 
                                            stream);
 }
 
-extern "C" int rrl_registration_backward(const float *src, const float *R, const float *tri2,
-                                         void *ws, size_t ws_bytes, const float *loss,
-                                         const float *grad_loss, float *grad_src, float *gR, float *gt,
-                                         float *payload, int B, int N, int M, int L, int transpose_r,
-                                         void *stream);
+static int registration_backward_impl(const float *src, const float *R, const float *tri2,
+                                      void *ws, size_t ws_bytes, const float *loss,
+                                      const float *grad_loss, float *grad_src, float *gR, float *gt,
+                                      float *payload, int B, int N, int M, int L, int transpose_r,
+                                      const RrlCall &o, void *stream);
 
 // Forward + direct backward of the fused training op in ONE call (dL/dloss is an input, so nothing has to come back
 // to the host in between): when the tail kernel serves the shape, the backward rides in its launch (5 launches per
 // step instead of 6, and the reduce's and the backward's chains of dependent loads overlap); otherwise exactly
 // rrl_registration_forward_cached followed by rrl_registration_backward.  gR, gt (and payload) should be the
 // workspace's GACC field, which the forward's first launch clears; other buffers are cleared here first.
-extern "C" int rrl_registration_step(const float *src, const float *R, const float *t, const float *tri2,
-                                     const float *line, void *ws, size_t ws_bytes, float *loss,
-                                     const float *grad_loss, float *gR, float *gt, float *payload, int B, int N,
-                                     int M, int L, int transpose_r, int s_m, int s_n, int e_m, int e_n, int mode,
-                                     int chunk, const void *target_ws, void *stream) {
+extern "C" int rrl_registration_step_ex(const float *src, const float *R, const float *t, const float *tri2,
+                                        const float *line, void *ws, size_t ws_bytes, float *loss,
+                                        const float *grad_loss, float *gR, float *gt, float *payload, int B, int N,
+                                        int M, int L, int transpose_r, int s_m, int s_n, int e_m, int e_n, int mode,
+                                        int chunk, const void *target_ws, const rrl_opts *opts, void *stream) {
     if (!src || !R || !t || !tri2 || !line || !ws || !loss || !grad_loss || !gR || !gt) return RRL_E_ARG;
     if (B < 0 || N < 0 || M < 0 || L < 0) return RRL_E_ARG;
     WsLayout w(B, N, M, L);
     if (ws_bytes < w.total) return RRL_E_WS;
+    const RrlCall o = rrl_resolve_opts(opts);
     const int nblk = (L + 1023) / 1024;
     bool done = false;
     int rc;
-    const bool solo = L <= 1024 && reduce_mode() < 2;  // one tile of lines: per-line stage + reduce + backward by one workgroup per sample
-    if (B > 0 && L > 0 && !rrl_deterministic() && (solo || reduce_kind(B, nblk, 0, true) == 2)) {
+    const bool solo = L <= 1024 && o.reduce_mode < 2;  // one tile of lines: per-line stage + reduce + backward by one workgroup per sample
+    if (B > 0 && L > 0 && !o.deterministic && (solo || reduce_kind(o.reduce_mode, B, nblk, 0, true) == 2)) {
         float *gacc = w.f32(ws, RRL_WS_GACC);
         hipStream_t s = (hipStream_t)stream;
         if (gR != gacc || gt != gacc + 9 * (size_t)B || (payload && payload != gacc + 12 * (size_t)B)) {
@@ -2352,22 +2407,48 @@ extern "C" int rrl_registration_step(const float *src, const float *R, const flo
         const RrlXform xf = {src, R, t, transpose_r, 1};
         const TailBwd tb = {grad_loss, src, gR, gt, payload, transpose_r};
         rc = loss_forward_impl(w.f32(ws, RRL_WS_TRI1), tri2, line, ws, ws_bytes, loss, B, N, M, L, s_m, s_n, e_m, e_n, 0,
-                               mode, chunk, target_ws, &xf, stream, &tb, &done);
+                               mode, chunk, target_ws, &xf, o, stream, &tb, &done);
         if (rc || done) return rc;
     } else {
-        rc = rrl_registration_forward_cached(src, R, t, tri2, line, ws, ws_bytes, loss, B, N, M, L, transpose_r, s_m,
-                                             s_n, e_m, e_n, mode, chunk, target_ws, stream);
+        const RrlXform xf = {src, R, t, transpose_r, 1};
+        rc = loss_forward_impl(w.f32(ws, RRL_WS_TRI1), tri2, line, ws, ws_bytes, loss, B, N, M, L, s_m, s_n, e_m, e_n, 0,
+                               mode, chunk, target_ws, &xf, o, stream);
         if (rc) return rc;
     }
-    return rrl_registration_backward(src, R, tri2, ws, ws_bytes, loss, grad_loss, nullptr, gR, gt, payload, B, N, M, L,
-                                     transpose_r, stream);
+    return registration_backward_impl(src, R, tri2, ws, ws_bytes, loss, grad_loss, nullptr, gR, gt, payload, B, N, M, L,
+                                      transpose_r, o, stream);
+}
+extern "C" int rrl_registration_step(const float *src, const float *R, const float *t, const float *tri2,
+                                     const float *line, void *ws, size_t ws_bytes, float *loss,
+                                     const float *grad_loss, float *gR, float *gt, float *payload, int B, int N,
+                                     int M, int L, int transpose_r, int s_m, int s_n, int e_m, int e_n, int mode,
+                                     int chunk, const void *target_ws, void *stream) {
+    return rrl_registration_step_ex(src, R, t, tri2, line, ws, ws_bytes, loss, grad_loss, gR, gt, payload, B, N, M, L,
+                                    transpose_r, s_m, s_n, e_m, e_n, mode, chunk, target_ws, nullptr, stream);
 }
 
+extern "C" int rrl_registration_backward_ex(const float *src, const float *R, const float *tri2,
+                                            void *ws, size_t ws_bytes, const float *loss,
+                                            const float *grad_loss, float *grad_src, float *gR, float *gt,
+                                            float *payload, int B, int N, int M, int L, int transpose_r,
+                                            const rrl_opts *opts, void *stream) {
+    return registration_backward_impl(src, R, tri2, ws, ws_bytes, loss, grad_loss, grad_src, gR, gt, payload, B, N, M, L,
+                                      transpose_r, rrl_resolve_opts(opts), stream);
+}
 extern "C" int rrl_registration_backward(const float *src, const float *R, const float *tri2,
                                          void *ws, size_t ws_bytes, const float *loss,
                                          const float *grad_loss, float *grad_src, float *gR, float *gt,
                                          float *payload, int B, int N, int M, int L, int transpose_r,
                                          void *stream) {
+    return rrl_registration_backward_ex(src, R, tri2, ws, ws_bytes, loss, grad_loss, grad_src, gR, gt, payload, B, N, M, L,
+                                        transpose_r, nullptr, stream);
+}
+
+static int registration_backward_impl(const float *src, const float *R, const float *tri2,
+                                      void *ws, size_t ws_bytes, const float *loss,
+                                      const float *grad_loss, float *grad_src, float *gR, float *gt,
+                                      float *payload, int B, int N, int M, int L, int transpose_r,
+                                      const RrlCall &o, void *stream) {
     if (!src || !R || !tri2 || !ws || !grad_loss || !gR || !gt) return RRL_E_ARG;
     if (payload && !loss) return RRL_E_ARG;
     WsLayout w(B, N, M, L);
@@ -2380,7 +2461,7 @@ extern "C" int rrl_registration_backward(const float *src, const float *R, const
         // are accumulated with atomics -- clear them unless they are the workspace's GACC field,
         // which the forward left zeroed
         float *gacc = w.f32(ws, RRL_WS_GACC);
-        const int nblk = rrl_deterministic() ? 16 * ((L + 1023) / 1024) : (L + BWD_LINES - 1) / BWD_LINES;
+        const int nblk = o.deterministic ? 16 * ((L + 1023) / 1024) : (L + BWD_LINES - 1) / BWD_LINES;
 #define RRL_BWD_RT(DET, PART)                                                                                  \
         hipLaunchKernelGGL(loss_bwd_rt_kernel<DET>, dim3((unsigned)nblk, (unsigned)B), dim3(256), 0, s,            \
                            w.u8(ws, RRL_WS_KJ), w.i32(ws, RRL_WS_SEL), w.i32(ws, RRL_WS_NSEL), w.i32(ws, RRL_WS_HS1), \
@@ -2388,7 +2469,7 @@ extern "C" int rrl_registration_backward(const float *src, const float *R, const
                            (const float4 *)w.f32(ws, RRL_WS_Q2), w.f32(ws, RRL_WS_D), w.f32(ws, RRL_WS_MED),       \
                            w.i32(ws, RRL_WS_BCNT), w.i32(ws, RRL_WS_INFO), grad_loss, src, gR, gt, payload, loss,  \
                            B, N, L, transpose_r, PART)
-        if (rrl_deterministic()) {
+        if (o.deterministic) {
             // partials in VALS (the reduce kernel's input tiles: dead after the forward; B * Lp * 16 floats
             // >= B * 16 ceil(L / 1024) * 12), fixed-order sums by a second launch: nothing to clear
             float *part = w.f32(ws, RRL_WS_VALS);

@@ -83,6 +83,26 @@ struct WsLayout {
     __host__ const uint8_t *u8(const void *ws, int f) const { return (const uint8_t *)((const char *)ws + off[f]); }
 };
 
+// The options of ONE call, resolved once at its top (include/rrl.h rrl_opts; defaults = what the rrl_set_* setters /
+// RRL_* environment variables selected) and handed through its stages by value: no stage reads a process-wide knob.
+struct RrlCall {
+    int flags;
+    int reduce_mode;    // 0 auto, 1 single, 2 tiled, 3 xchg
+    int deterministic;  // 0 / 1
+    int sort_parts;     // 0 automatic, k forced
+    int scan_variant;   // 0 default, else lines per lane
+    const int32_t *order1, *order2;
+    unsigned long long *counters;
+    long long counter_rows;
+    __host__ bool prepared() const { return order1 != nullptr; }
+    __host__ bool target_kept() const { return order1 != nullptr && (flags & RRL_F_TARGET_KEPT); }
+};
+RrlCall rrl_resolve_opts(const rrl_opts *o);  // rrl_sparse.hip
+// the process-wide defaults, one accessor per translation unit that owns one
+int rrl_default_sort_parts(void);                                           // rrl_cull.hip
+void rrl_default_scan_counters(unsigned long long **buf, long long *rows);  // rrl_cull.hip
+int rrl_default_scan_variant(void);                                         // rrl_scan.hip
+
 // Rigid transform of the source cloud folded into the prepare step (the fused training op):
 // tri1 = src moved by (R, t) per sample, stored into the workspace field TRI1.
 struct RrlXform {

@@ -26,6 +26,15 @@ _SIGS = {
     "rrl_loss_forward_info": [_P, _P, _P, _P, _Z, _P] + [_I] * 11 + [_P, _P, _P],
     "rrl_registration_backward": [_P] * 4 + [_Z] + [_P] * 6 + [_I] * 5 + [_P],
     "rrl_registration_step": [_P] * 6 + [_Z] + [_P] * 5 + [_I] * 11 + [_P, _P],
+    "rrl_loss_forward_ex": [_P, _P, _P, _P, _Z, _P] + [_I] * 11 + [_P, _P, _P],
+    "rrl_registration_forward_ex": [_P] * 6 + [_Z, _P] + [_I] * 11 + [_P, _P, _P],
+    "rrl_registration_backward_ex": [_P] * 4 + [_Z] + [_P] * 6 + [_I] * 5 + [_P, _P],
+    "rrl_registration_step_ex": [_P] * 6 + [_Z] + [_P] * 5 + [_I] * 11 + [_P, _P, _P],
+    "rrl_cloud_order": [_P, _P, _P, _Z, _I, _I, _P],
+    "rrl_tri_prepare_ex": [_P, _P, _P, _Z, _I, _I, _I, _I, _P, _P],
+    "rrl_line_tri_scan_ex": [_P, _P, _Z] + [_I] * 6 + [_P, _P],
+    "rrl_loss_reduce_ex": [_P, _Z, _P] + [_I] * 9 + [_P, _P],
+    "rrl_line_pair_dist_ex": [_P, _P, _P, _P, _Z] + [_I] * 9 + [_P, _P],
     "rrl_tri_prepare": [_P, _P, _P, _Z, _I, _I, _I, _I, _P],
     "rrl_line_tri_scan": [_P, _P, _Z] + [_I] * 6 + [_P],
     "rrl_line_pair_dist": [_P, _P, _P, _P, _Z] + [_I] * 9 + [_P],
@@ -61,7 +70,22 @@ _SIGS = {
     "rrl_sample_lines": [_P] * 8 + [_I] * 3 + [_P],
     "rrl_sample_lines_rng": [_P] * 8 + [_I] * 3 + [_P],
 }
-EXPORTS = sorted(list(_SIGS) + ["rrl_version", "rrl_workspace_bytes", "rrl_chamfer_workspace_bytes"])
+EXPORTS = sorted(list(_SIGS) + ["rrl_version", "rrl_workspace_bytes", "rrl_chamfer_workspace_bytes",
+                                 "rrl_cloud_order_workspace_bytes"])
+
+F_TARGET_KEPT = 1  # include/rrl.h RRL_F_TARGET_KEPT
+
+
+class Opts(ctypes.Structure):
+    """include/rrl.h rrl_opts: the per-call options of the *_ex entry points (-1 / NULL = the library default)."""
+    _fields_ = [("struct_bytes", _c.c_int32), ("flags", _c.c_int32), ("reduce_mode", _c.c_int32),
+                ("deterministic", _c.c_int32), ("sort_parts", _c.c_int32), ("scan_variant", _c.c_int32),
+                ("order1", _P), ("order2", _P), ("scan_counters", _P), ("scan_counter_rows", _c.c_longlong)]
+
+    def __init__(self, flags=0, reduce_mode=-1, deterministic=-1, sort_parts=-1, scan_variant=-1, order1=None,
+                 order2=None, scan_counters=None, scan_counter_rows=0):
+        super().__init__(ctypes.sizeof(Opts), int(flags), int(reduce_mode), int(deterministic), int(sort_parts),
+                         int(scan_variant), order1, order2, scan_counters, int(scan_counter_rows))
 
 _lib = None
 
@@ -89,6 +113,8 @@ def load():
     lib.rrl_workspace_bytes.restype = _Z
     lib.rrl_chamfer_workspace_bytes.argtypes = [_I, _I, _I]
     lib.rrl_chamfer_workspace_bytes.restype = _Z
+    lib.rrl_cloud_order_workspace_bytes.argtypes = [_I, _I]
+    lib.rrl_cloud_order_workspace_bytes.restype = _Z
     _lib = lib
     return lib
 

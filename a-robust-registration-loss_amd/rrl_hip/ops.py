@@ -204,12 +204,80 @@ def _target_ws(target_from, B, N, M, L):
     return _p(target_from.ws)
 
 
+_order_ws = {}  # (B, n, device index) -> scratch of rrl_cloud_order
+
+
+def cloud_order(tri):
+    """Spatial order of the clouds tri (B, n, 9) -- pseudo-triangles; only the first point of a row places it -- computed
+    ONCE per cloud (include/rrl.h rrl_cloud_order): int32 (B, 64 ceil(n / 64)), sorted position -> triangle index.
+    A rigid motion preserves the order, so the same tensor serves every pose of the cloud: hand it to
+    RegistrationStep / intersection_loss / registration_loss (order1= / order2=) and the per-step cell sort
+    disappears.  Any permutation gives identical labels and loss; this one makes the culled scan fast."""
+    dev = _home(tri)
+    t = _prep(tri, "tri", 9, dev)
+    if t.dim() != 3:
+        raise ValueError("tri must be (B, n, 9)")
+    B, n, _ = t.shape
+    if n > 65536:
+        raise ValueError("clouds beyond 65536 triangles are not sorted (the dense scan serves them)")
+    order = torch.zeros(B, (n + 63) // 64 * 64, dtype=torch.int32, device=dev)
+    if B == 0 or n == 0:
+        return order
+    key = (B, n, dev.index)
+    ws = _order_ws.get(key)
+    if ws is None:
+        if len(_order_ws) > 16:
+            _order_ws.clear()
+        nb = int(_lib.load().rrl_cloud_order_workspace_bytes(B, n))
+        ws = _order_ws[key] = torch.empty(nb, dtype=torch.uint8, device=dev)
+    _run(dev, "rrl_cloud_order", _p(t), _p(order), _p(ws), ws.numel(), B, n)
+    return order
+
+
+def _check_order(order, B, n, dev, name):
+    if order is None:
+        return None
+    if not (isinstance(order, torch.Tensor) and order.dtype == torch.int32 and order.is_cuda and order.device == dev
+            and order.is_contiguous() and tuple(order.shape) == (B, (n + 63) // 64 * 64)):
+        raise ValueError(f"{name} must be the int32 (B, 64 ceil(n / 64)) tensor of ops.cloud_order on the op's GPU")
+    return order
+
+
+_REDUCE = {"auto": 0, "single": 1, "tiled": 2, "xchg": 3}
+
+
+def make_opts(order1=None, order2=None, target_kept=False, reduce_mode=None, deterministic=None, sort_parts=None,
+              scan_variant=None, counters=None):
+    """include/rrl.h rrl_opts for one call (None = the library default everywhere); the returned object keeps the
+    tensors it points at alive (.keep)."""
+    if order1 is None and order2 is None and not target_kept and reduce_mode is None and deterministic is None \
+            and sort_parts is None and scan_variant is None and counters is None:
+        return None
+    o = _lib.Opts(flags=_lib.F_TARGET_KEPT if target_kept else 0,
+                  reduce_mode=-1 if reduce_mode is None else _REDUCE.get(reduce_mode, reduce_mode),
+                  deterministic=-1 if deterministic is None else int(bool(deterministic)),
+                  sort_parts=-1 if sort_parts is None else int(sort_parts),
+                  scan_variant=-1 if scan_variant is None else int(scan_variant),
+                  order1=order1.data_ptr() if order1 is not None else None,
+                  order2=order2.data_ptr() if order2 is not None else None,
+                  scan_counters=counters.data_ptr() if counters is not None else None,
+                  scan_counter_rows=counters.shape[0] if counters is not None else 0)
+    o.keep = (order1, order2, counters)
+    return o
+
+
+def _optr(opts):
+    return ctypes.byref(opts) if opts is not None else None
+
+
 def loss_forward_raw(tri1, tri2, line, rng=(1, 1, 5, 5), pool=False, mode="cull", chunk=0,
-                     staged=False, target_from=None):
+                     staged=False, target_from=None, opts=None, state=None):
     """Forward on already-prepared GPU tensors; returns the LossState.  staged=True issues the
     four stages through their individual C entry points instead of the fused one.
     target_from: LossState of an earlier call with the SAME tri2 and line -- its target scan is
-    reused (rrl_loss_forward_cached)."""
+    reused (rrl_loss_forward_cached).
+    opts: make_opts(...) -- per-call options (prepared orders, reduce mode, ...); state: evaluate into this LossState
+    (same shape) instead of a new one (needed for target_kept: the target's records live in the workspace)."""
     lib = _lib.load()
     B, N, _ = tri1.shape
     M, L = tri2.shape[1], line.shape[1]
@@ -218,30 +286,36 @@ def loss_forward_raw(tri1, tri2, line, rng=(1, 1, 5, 5), pool=False, mode="cull"
     dev = tri1.device
     if tri2.device != dev or line.device != dev:
         raise ValueError("tri1, tri2 and line must live on the same GPU")
-    st = LossState(B, N, M, L, G, dev)
+    if state is not None:
+        if tuple(state.dims) != (B, N, M, L, G) or state.ws.device != dev:
+            raise ValueError("state was made for another shape / device")
+        st = state
+    else:
+        st = LossState(B, N, M, L, G, dev)
     st.target_state = getattr(target_from, "target_state", None) or target_from  # whose workspace holds cloud 2
     ws, nb = _p(st.ws), st.nbytes
+    op = _optr(opts)
     with _guard(dev):
         s = _stream(dev)
         if not staged:
-            check(lib.rrl_loss_forward_cached(_p(tri1), _p(tri2), _p(line), ws, nb, _p(st.loss), B, N, M,
-                                              L, s_m, s_n, e_m, e_n, int(pool), _MODES[mode], int(chunk),
-                                              _target_ws(target_from, B, N, M, L), s),
+            check(lib.rrl_loss_forward_ex(_p(tri1), _p(tri2), _p(line), ws, nb, _p(st.loss), B, N, M,
+                                          L, s_m, s_n, e_m, e_n, int(pool), _MODES[mode], int(chunk),
+                                          _target_ws(target_from, B, N, M, L), op, s),
                   "rrl_loss_forward")
             return st
-        check(lib.rrl_tri_prepare(_p(tri1), _p(tri2), ws, nb, B, N, M, L, s), "rrl_tri_prepare")
-        check(lib.rrl_line_tri_scan(_p(line), ws, nb, B, N, M, L, _MODES[mode], int(chunk), s),
+        check(lib.rrl_tri_prepare_ex(_p(tri1), _p(tri2), ws, nb, B, N, M, L, op, s), "rrl_tri_prepare")
+        check(lib.rrl_line_tri_scan_ex(_p(line), ws, nb, B, N, M, L, _MODES[mode], int(chunk), op, s),
               "rrl_line_tri_scan")
-        check(lib.rrl_line_pair_dist(_p(tri1), _p(tri2), _p(line), ws, nb, B, N, M, L, s_m, s_n, e_m,
-                                     e_n, int(pool), s), "rrl_line_pair_dist")
-        check(lib.rrl_loss_reduce(ws, nb, _p(st.loss), B, N, M, L, s_m, s_n, e_m, e_n, int(pool), s),
+        check(lib.rrl_line_pair_dist_ex(_p(tri1), _p(tri2), _p(line), ws, nb, B, N, M, L, s_m, s_n, e_m,
+                                        e_n, int(pool), op, s), "rrl_line_pair_dist")
+        check(lib.rrl_loss_reduce_ex(ws, nb, _p(st.loss), B, N, M, L, s_m, s_n, e_m, e_n, int(pool), op, s),
               "rrl_loss_reduce")
     return st
 
 
 class _IntersectionLoss(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, points1, points2, line, rng, pool, mode, chunk, target_from=None):
+    def forward(ctx, points1, points2, line, rng, pool, mode, chunk, target_from=None, opts=None):
         dev = _home(points1, points2, line)
         tri1, tri2 = _prep(points1, "points1", 9, dev), _prep(points2, "points2", 9, dev)
         ln = _prep(line, "line", 6, dev)
@@ -257,7 +331,7 @@ class _IntersectionLoss(torch.autograd.Function):
                    torch.zeros(4, dtype=torch.int32, device=dev))
             ctx.mark_non_differentiable(out[1], out[2])
             return out
-        st = loss_forward_raw(tri1, tri2, ln, rng, pool, mode, chunk, target_from=target_from)
+        st = loss_forward_raw(tri1, tri2, ln, rng, pool, mode, chunk, target_from=target_from, opts=opts)
         ctx.st, ctx.tri1, ctx.tri2, ctx.pool = st, tri1, tri2, bool(pool)
         ctx.in_devs = (points1.device, points2.device)
         info, status = st.info, st.status
@@ -271,7 +345,7 @@ class _IntersectionLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_loss, _g1, _g2):
         if g_loss is None or ctx.st is None:
-            return (None,) * 8
+            return (None,) * 9
         lib = _lib.load()
         st, tri1, tri2 = ctx.st, ctx.tri1, ctx.tri2
         B, N, _ = tri1.shape
@@ -285,7 +359,7 @@ class _IntersectionLoss(torch.autograd.Function):
         g1 = g1.to(ctx.in_devs[0]) if ctx.needs_input_grad[0] else None
         if g2 is not None:
             g2 = g2.to(ctx.in_devs[1])
-        return g1, g2, None, None, None, None, None, None
+        return g1, g2, None, None, None, None, None, None, None
 
 
 # ---- the reference-signature call (loss.cal_loss_intersection_batch_whole_median_pts_lines) ----------------------
@@ -397,12 +471,16 @@ def intersection_loss_dropin(points1, points2, line, rng=(1, 1, 5, 5), pool=Fals
 
 
 def intersection_loss(points1, points2, line, rng=(1, 1, 5, 5), pool=False, mode="cull", chunk=0,
-                      target_from=None):
+                      target_from=None, order1=None, order2=None, opts=None):
     """Batched loss: returns (loss[G], info[G,4] = (nbuckets, nselected, nvalues, NaN flag), status[4])
     on the GPU, G = 1 if pool else B.  Each sample is an independent loss (what every reference
     caller obtains by looping B=1 calls); pool=True reproduces the reference's own B>1 behaviour
-    (SURVEY Q2).  No host synchronisation happens here."""
-    return _IntersectionLoss.apply(points1, points2, line, tuple(rng), pool, mode, chunk, target_from)
+    (SURVEY Q2).  No host synchronisation happens here.
+    order1 / order2: ops.cloud_order of the two clouds (in any rigid pose of them) -- the per-call cell sort is skipped,
+    same results; opts: make_opts(...) for anything else per call."""
+    if opts is None and (order1 is not None or order2 is not None):
+        opts = make_opts(order1=order1, order2=order2)
+    return _IntersectionLoss.apply(points1, points2, line, tuple(rng), pool, mode, chunk, target_from, opts)
 
 
 def shard_payload(loss, gR=None, gt=None, state=None):
@@ -427,7 +505,7 @@ class _RegistrationLoss(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, src_tri, R, t, tar_tri, line, rng, transpose_r, mode, chunk, want_payload,
-                target_from=None):
+                target_from=None, opts=None):
         dev = _home(src_tri, tar_tri, line, R, t)
         src = _prep(src_tri, "src_tri", 9, dev)
         tri2, ln = _prep(tar_tri, "tar_tri", 9, dev), _prep(line, "line", 6, dev)
@@ -450,13 +528,14 @@ class _RegistrationLoss(torch.autograd.Function):
         s_m, s_n, e_m, e_n = _check_range(rng)
         st = LossState(B, N, M, L, B, src.device)
         with _guard(dev):
-            check(_lib.load().rrl_registration_forward_cached(
+            check(_lib.load().rrl_registration_forward_ex(
                 _p(src), _p(Rm), _p(tv), _p(tri2), _p(ln), _p(st.ws), st.nbytes, _p(st.loss), B, N, M, L,
                 int(transpose_r), s_m, s_n, e_m, e_n, _MODES[mode], int(chunk),
-                _target_ws(target_from, B, N, M, L), _stream(dev)), "rrl_registration_forward")
+                _target_ws(target_from, B, N, M, L), _optr(opts), _stream(dev)), "rrl_registration_forward")
         st.target_state = getattr(target_from, "target_state", None) or target_from  # whose workspace holds cloud 2
         ctx.st, ctx.src, ctx.Rm, ctx.tri2 = st, src, Rm, tri2
         ctx.meta = (int(transpose_r), bool(want_payload), R.shape, t.shape, src_tri.device, R.device, t.device)
+        ctx.opts = opts
         info, status = st.info, st.status
         ctx.mark_non_differentiable(info, status)
         ctx.set_materialize_grads(False)
@@ -466,7 +545,7 @@ class _RegistrationLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_loss, _g1, _g2):
         if g_loss is None or ctx.st is None:
-            return (None,) * 11
+            return (None,) * 12
         st, src, Rm, tri2 = ctx.st, ctx.src, ctx.Rm, ctx.tri2
         tr, want_payload, Rshape, tshape, sdev, Rdev, tdev = ctx.meta
         B, N, M, L, _ = st.dims
@@ -480,17 +559,17 @@ class _RegistrationLoss(torch.autograd.Function):
         gR, gt, payload = out[:B * 9], out[B * 9:B * 12], out[B * 12:B * 12 + 14]
         gsrc = torch.empty_like(src) if ctx.needs_input_grad[0] else None
         with _guard(src.device):
-            check(_lib.load().rrl_registration_backward(
+            check(_lib.load().rrl_registration_backward_ex(
                 _p(src), _p(Rm), _p(tri2), _p(st.ws), st.nbytes, _p(st.loss), _p(g), _p(gsrc), _p(gR),
-                _p(gt), _p(payload) if want_payload else None, B, N, M, L, tr, _stream(src.device)),
+                _p(gt), _p(payload) if want_payload else None, B, N, M, L, tr, _optr(ctx.opts), _stream(src.device)),
                 "rrl_registration_backward")
         st.payload = payload if want_payload else None
         return (gsrc.to(sdev) if gsrc is not None else None, gR.reshape(Rshape).to(Rdev),
-                gt.reshape(tshape).to(tdev), None, None, None, None, None, None, None, None)
+                gt.reshape(tshape).to(tdev), None, None, None, None, None, None, None, None, None)
 
 
 def registration_loss(src_tri, R, t, tar_tri, line, rng=(1, 1, 5, 5), transpose_r=True,
-                      mode="cull", chunk=0, want_payload=False, target_from=None):
+                      mode="cull", chunk=0, want_payload=False, target_from=None, order1=None, order2=None, opts=None):
     """loss[b] of `src_tri[b]` moved by (R[b], t[b]) against `tar_tri[b]` along `line[b]` -- the
     rigid transform of the training call sites fused with the loss.  transpose_r=True is
     x R^T + t (R x + t per point: RPM / DCP / FMR), False is x R + t (Reconstruction_point).
@@ -498,9 +577,13 @@ def registration_loss(src_tri, R, t, tar_tri, line, rng=(1, 1, 5, 5), transpose_
     want_payload=True also builds the 14-float batch-shard payload during backward
     (LossState.payload of the call, see rrl_hip.dist).
     target_from: LossState (ops.last_state()) of an earlier call with the SAME tar_tri and line:
-    the target cloud is not scanned again (RPM / FMR: several poses, one target, one line set)."""
+    the target cloud is not scanned again (RPM / FMR: several poses, one target, one line set).
+    order1 / order2: ops.cloud_order of src_tri (in its own frame: a rigid motion keeps the order) and tar_tri -- the
+    per-call cell sort is skipped, same results."""
+    if opts is None and (order1 is not None or order2 is not None):
+        opts = make_opts(order1=order1, order2=order2)
     return _RegistrationLoss.apply(src_tri, R, t, tar_tri, line, tuple(rng), transpose_r, mode,
-                                   chunk, want_payload, target_from)
+                                   chunk, want_payload, target_from, opts)
 
 
 class RegistrationStep:
@@ -512,17 +595,25 @@ class RegistrationStep:
         loss, gR, gt = step(R.detach(), t.detach(), lines)[:3]      # every iteration (gout = ones)
         torch.autograd.backward([R, t], [gR, gt])                   # hand the gradient to the network
 
-    Issued this way the C2 step is GPU-bound at 70 us (about 30 us of host time per step); replaying the
-    launches as a hipGraph costs 76 us (a replay has ~8 us of fixed cost + 1.5 us per node on this
+    Issued this way the C2 step is GPU-bound (about 30 us of host time per step); replaying the
+    launches as a hipGraph costs ~6 us more (a replay has ~8 us of fixed cost + 1.5 us per node on this
     stack, tools/graph_node_cost.py), and the autograd front end (registration_loss) is host-bound when
     issued eagerly.  Same kernels, same numbers as registration_loss.  The outputs are views of buffers
-    that the next call overwrites.  want_payload: also the 14-float batch-shard payload (rrl_hip.dist)."""
+    that the next call overwrites.  want_payload: also the 14-float batch-shard payload (rrl_hip.dist).
+
+    prepared=True (default; round 4): the spatial ORDER of both clouds is computed once (ops.cloud_order, at
+    construction and whenever a new cloud arrives through src_tri= / tar_tri= without its src_order= / tar_order=) and
+    every step runs the prepared build -- one wide launch moves the source, writes the records at their sorted
+    positions and refits the sphere tree; the cell sort (10 us of a 70 us step) is gone -- and a target that has not
+    changed since the previous call (same tensor, same torch version counter) is not rebuilt at all
+    (RRL_F_TARGET_KEPT).  Bit-identical loss either way; prepared=False is the cold path (records + sort each step), the
+    right choice when every step brings new clouds that are evaluated once."""
 
     # rrl_registration_step; False (or RRL_ONE_CALL=0): rrl_registration_forward_cached + rrl_registration_backward
     ONE_CALL = os.environ.get("RRL_ONE_CALL", "1") != "0"
 
     def __init__(self, src_tri, tar_tri, n_lines, rng=(1, 1, 5, 5), transpose_r=True, mode="cull", chunk=0,
-                 want_payload=False):
+                 want_payload=False, prepared=True, src_order=None, tar_order=None):
         dev = _home(src_tri, tar_tri)
         self.dev = dev
         self.src = _prep(src_tri, "src_tri", 9, dev)
@@ -549,8 +640,21 @@ class RegistrationStep:
         self._head_s = (_p(self.st.ws), self.st.nbytes, _p(self.st.loss))
         self._tail_s = (_p(gacc[:B * 9]), _p(gacc[B * 9:B * 12]), _p(self.payload), B, N, M, L, self.tr, *self.rng,
                         self.mode, self.chunk, None)
+        self.prepared = bool(prepared) and mode == "cull" and max(N, M) <= 65536
+        self._kept_key = None  # (data_ptr, version) of the target whose records the workspace holds
+        self.order1 = self.order2 = None
+        if self.prepared:
+            self.order1 = _check_order(src_order, B, N, dev, "src_order") if src_order is not None else cloud_order(self.src)
+            self.order2 = _check_order(tar_order, B, M, dev, "tar_order") if tar_order is not None else cloud_order(self.tar)
+            self._set_opts()
 
-    def __call__(self, R, t, line, grad_loss=None, src_tri=None, tar_tri=None, target_from=None):
+    def _set_opts(self):
+        self._opts = make_opts(order1=self.order1, order2=self.order2)
+        self._opts_kept = make_opts(order1=self.order1, order2=self.order2, target_kept=True)
+        self._optr, self._optr_kept = ctypes.byref(self._opts), ctypes.byref(self._opts_kept)
+
+    def __call__(self, R, t, line, grad_loss=None, src_tri=None, tar_tri=None, target_from=None, src_order=None,
+                 tar_order=None):
         """src_tri / tar_tri: this step's clouds (same shapes as at construction); default: the tensors given
         to the constructor (update those in place, or pass the new batch here).
         target_from: the LossState (another step's .st, or ops.last_state()) of an evaluation with the SAME tar_tri and
@@ -564,6 +668,18 @@ class RegistrationStep:
             self.tar = _prep(tar_tri, "tar_tri", 9, dev)
         if tuple(self.src.shape) != (B, N, 9) or tuple(self.tar.shape) != (B, M, 9):
             raise ValueError(f"src_tri {(B, N, 9)} / tar_tri {(B, M, 9)} expected")
+        op = None
+        if self.prepared:
+            if src_tri is not None or src_order is not None or tar_tri is not None or tar_order is not None:
+                if src_tri is not None or src_order is not None:  # a new source: its order comes along, or is taken now
+                    self.order1 = _check_order(src_order, B, N, dev, "src_order") if src_order is not None else cloud_order(self.src)
+                if tar_tri is not None or tar_order is not None:
+                    self.order2 = _check_order(tar_order, B, M, dev, "tar_order") if tar_order is not None else cloud_order(self.tar)
+                    self._kept_key = None
+                self._set_opts()
+            key = (self.tar.data_ptr(), self.tar._version)
+            op = self._optr_kept if (key == self._kept_key and target_from is None) else self._optr
+            self._kept_key = key if target_from is None else None  # (a carried-over target is not built here)
         Rm, tv, ln = _prep(R, "R", None, dev), _prep(t, "t", None, dev), _prep(line, "line", 6, dev)
         if Rm.numel() != B * 9 or tv.numel() != B * 3 or tuple(ln.shape) != (B, L, 6):
             raise ValueError("R (B,3,3), t (B,3), line (B, L, 6) expected")
@@ -578,10 +694,10 @@ class RegistrationStep:
         self.st.target_state = getattr(target_from, "target_state", None) or target_from  # whose workspace holds cloud 2
         with _guard(dev):
             if RegistrationStep.ONE_CALL:  # forward + backward as one C entry: the backward may ride in the reduce's launch
-                check(lib.rrl_registration_step(_p(self.src), _p(Rm), _p(tv), _p(self.tar), _p(ln), *self._head_s, _p(g),
-                                                *tail_s, s), "rrl_registration_step")
+                check(lib.rrl_registration_step_ex(_p(self.src), _p(Rm), _p(tv), _p(self.tar), _p(ln), *self._head_s, _p(g),
+                                                   *tail_s, op, s), "rrl_registration_step")
             else:
-                check(lib.rrl_registration_forward_cached(_p(self.src), _p(Rm), _p(tv), _p(self.tar), _p(ln), *fixed_f, s),
+                check(lib.rrl_registration_forward_ex(_p(self.src), _p(Rm), _p(tv), _p(self.tar), _p(ln), *fixed_f, op, s),
                       "rrl_registration_forward")
                 check(lib.rrl_registration_backward(_p(self.src), _p(Rm), _p(self.tar), *self._fixed_b, _p(g), *self._tail_b, s),
                       "rrl_registration_backward")

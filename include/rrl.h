@@ -131,6 +131,36 @@ enum {
 
 const char *rrl_version(void);
 
+/* ---- per-call options ------------------------------------------------------------------------
+ * Every entry point that has an `_ex` twin takes `const rrl_opts *opts` in front of the stream; NULL (and the
+ * plain entry) means "the library defaults", i.e. what rrl_set_* / the RRL_* environment variables selected.
+ * A field left at -1 / NULL also means "default".  The options are resolved ONCE at the top of a call and travel
+ * through all of its stages by value, so a call never observes a setter running in another thread half way
+ * through, and two host threads may drive different streams with different options at the same time (the only
+ * process-wide state left are the defaults themselves and the rrl_scan_timing ring, a profiling hook).
+ * Thread-safety contract: re-entrant; thread-safe per stream and per workspace -- two calls that
+ * share a workspace or output buffers must be ordered by the caller (same stream, or events). */
+#define RRL_F_TARGET_KEPT 1  /* with order1: cloud 2's prepared records, sphere tree and partials in `ws` are those
+                                the PREVIOUS call on this workspace built from the same tri2 -- the target has not moved
+                                (code/test_demo_optimized_Lie_Algebra.py:57-62, rpm/Train_RPM.py:207-231 move only the
+                                source) -- so nothing of cloud 2 is rebuilt; order2 is not read.  Same results bit for bit. */
+typedef struct rrl_opts {
+    int32_t struct_bytes;    /* sizeof(rrl_opts) of the caller's header (fields beyond it are defaults) */
+    int32_t flags;           /* RRL_F_* */
+    int32_t reduce_mode;     /* -1 default; 0 auto, 1 single, 2 tiled, 3 xchg (rrl_set_reduce_mode) */
+    int32_t deterministic;   /* -1 default; 0 / 1 (rrl_set_deterministic) */
+    int32_t sort_parts;      /* -1 default; 0 automatic, 1..16 (rrl_set_sort_parts) */
+    int32_t scan_variant;    /* -1 default; 0, 1, 2, 4, 8 (rrl_set_scan_variant) */
+    /* Prepared clouds: order [B][64 ceil(n / 64)] from rrl_cloud_order -- sorted position -> triangle, computed ONCE
+     * per cloud in any rigid frame of it.  Both given (or order1 + RRL_F_TARGET_KEPT), scan mode cull: the cell sort
+     * leaves the step; one wide launch moves the source, writes the records at their sorted positions and refits
+     * the sphere tree.  Any permutation gives the same labels, hit lists and loss (the tree is a conservative
+     * filter, the reference's arithmetic decides); a stale or arbitrary order only costs time. */
+    const int32_t *order1, *order2;
+    uint64_t *scan_counters;       /* per-call counter table of the culled scan (see rrl_scan_counters) */
+    long long scan_counter_rows;
+} rrl_opts;
+
 size_t rrl_workspace_bytes(int B, int N, int M, int L);
 /* offsets[RRL_WS_FIELDS] in bytes from the workspace base */
 int rrl_workspace_layout(int B, int N, int M, int L, size_t *offsets);
@@ -214,6 +244,37 @@ int rrl_registration_step(const float *src, const float *R, const float *t, cons
                           int s_m, int s_n, int e_m, int e_n, int mode, int chunk, const void *target_ws,
                           void *stream);
 
+/* ---- prepared clouds (round 4) ----------------------------------------------------------------
+ * The reference itself points at a spatial structure (code/loss.py:260-262), and every caller moves the SAME source
+ * rigidly, step after step, against a target that never moves (test_demo_optimized_Lie_Algebra.py:57-62,
+ * rpm/Train_RPM.py:207-231).  A rigid motion preserves the spatial order of a cloud, so the order is computed once
+ * per cloud (dataset item / demo start) and handed to every later call through rrl_opts.order1 / order2.
+ * rrl_cloud_order: order [B][64 ceil(n/64)] int32 = sorted position -> triangle index (positions >= n hold 0) for
+ * the clouds tri [B][n][9] in the frame they are given in: the cell sort of the plain path (16^3 grid, Hilbert curve;
+ * clouds beyond 4096 triangles in chunks of 4096) followed by a k-d refinement of every supergroup of 64 sorted
+ * records (median splits along the longest axis down to halves of 8: tighter tree nodes, fewer tests per line --
+ * affordable because it runs once).  ws: scratch of rrl_cloud_order_workspace_bytes(B, n) bytes.  n <= 65536. */
+size_t rrl_cloud_order_workspace_bytes(int B, int n);
+int rrl_cloud_order(const float *tri, int32_t *order, void *ws, size_t ws_bytes, int B, int n, void *stream);
+
+/* The fused entries with per-call options (rrl_opts above; NULL = defaults = the plain entries). */
+int rrl_loss_forward_ex(const float *tri1, const float *tri2, const float *line, void *ws, size_t ws_bytes,
+                        float *loss, int B, int N, int M, int L, int s_m, int s_n, int e_m, int e_n, int pool,
+                        int mode, int chunk, const void *target_ws, const rrl_opts *opts, void *stream);
+int rrl_registration_forward_ex(const float *src, const float *R, const float *t, const float *tri2,
+                                const float *line, void *ws, size_t ws_bytes, float *loss, int B, int N, int M,
+                                int L, int transpose_r, int s_m, int s_n, int e_m, int e_n, int mode, int chunk,
+                                const void *target_ws, const rrl_opts *opts, void *stream);
+int rrl_registration_backward_ex(const float *src, const float *R, const float *tri2, void *ws, size_t ws_bytes,
+                                 const float *loss, const float *grad_loss, float *grad_src, float *gR, float *gt,
+                                 float *payload, int B, int N, int M, int L, int transpose_r, const rrl_opts *opts,
+                                 void *stream);
+int rrl_registration_step_ex(const float *src, const float *R, const float *t, const float *tri2,
+                             const float *line, void *ws, size_t ws_bytes, float *loss, const float *grad_loss,
+                             float *gR, float *gt, float *payload, int B, int N, int M, int L, int transpose_r,
+                             int s_m, int s_n, int e_m, int e_n, int mode, int chunk, const void *target_ws,
+                             const rrl_opts *opts, void *stream);
+
 /* ---- the four forward stages, individually (tests, profiling) ------------------------- */
 
 /* K1': prepared triangles for both clouds + zeroing of the per-call state.
@@ -222,11 +283,25 @@ int rrl_registration_step(const float *src, const float *R, const float *t, cons
 int rrl_tri_prepare(const float *tri1, const float *tri2, void *ws, size_t ws_bytes, int B, int N,
                     int M, int L, void *stream);
 
+/* With options: sort parts; orders (both): the prepared build -- records at their sorted positions + tree refit in one
+ * launch, and PMAX completed by a tiny second launch (inside a fused forward the culled scan's prologue does that).
+ * rrl_line_tri_scan_ex must then be given the same opts. */
+int rrl_tri_prepare_ex(const float *tri1, const float *tri2, void *ws, size_t ws_bytes, int B, int N,
+                       int M, int L, const rrl_opts *opts, void *stream);
+
 /* K1: dense line <-> pseudo-triangle scan of both clouds in one launch
  * (code/loss.py:68-112 for points1 and points2, :181-186).  Emits per line the hit count and
  * the (unordered) indices of the first RRL_MAX_HITS hits; nothing of size L*N is written. */
 int rrl_line_tri_scan(const float *line, void *ws, size_t ws_bytes, int B, int N, int M, int L,
                       int mode, int chunk, void *stream);
+
+int rrl_line_tri_scan_ex(const float *line, void *ws, size_t ws_bytes, int B, int N, int M, int L,
+                         int mode, int chunk, const rrl_opts *opts, void *stream);
+/* (K2 below with options: the reduce mode decides whether the dense value lists of the tail kernel are written, so the
+ * stage calls of ONE evaluation must be given the same opts) */
+int rrl_line_pair_dist_ex(const float *tri1, const float *tri2, const float *line, void *ws,
+                          size_t ws_bytes, int B, int N, int M, int L, int s_m, int s_n, int e_m,
+                          int e_n, int pool, const rrl_opts *opts, void *stream);
 
 /* K2: per-line sparse stage (code/loss.py:115-167): for lines whose two hit counts fall in
  * [s_m,e_m) x [s_n,e_n): hits sorted ascending (nonzero() order), weights w = d / sum d
@@ -243,6 +318,9 @@ int rrl_line_pair_dist(const float *tri1, const float *tri2, const float *line, 
  * the result does not depend on summation order. */
 int rrl_loss_reduce(void *ws, size_t ws_bytes, float *loss, int B, int N, int M, int L, int s_m,
                     int s_n, int e_m, int e_n, int pool, void *stream);
+
+int rrl_loss_reduce_ex(void *ws, size_t ws_bytes, float *loss, int B, int N, int M, int L, int s_m,
+                       int s_n, int e_m, int e_n, int pool, const rrl_opts *opts, void *stream);
 
 /* K3 + K4 over caller-supplied rows: rows16 [nrows][16] = canonical 4 x 4 D tiles (+inf outside the k x j block) and
  * kj [nrows] = k | j << 4, i.e. what rrl_line_pair_dist leaves at its compact slots (fields VALS, KJC, BLKCNT) -- the merge

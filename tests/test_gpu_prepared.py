@@ -1,0 +1,255 @@
+"""Prepared clouds (round 4; include/rrl.h rrl_cloud_order, rrl_opts.order1 / order2, RRL_F_TARGET_KEPT).
+
+The reference's callers move the same source rigidly, step after step, against a target that never moves
+(code/test_demo_optimized_Lie_Algebra.py:57-62, rpm/Train_RPM.py:207-231), and the reference points at a spatial
+structure itself (code/loss.py:260-262).  The spatial order of a cloud is therefore computed once and every later
+step runs the prepared build (records at their sorted positions + tree refit, one launch, no cell sort).  The bar:
+labels, hit lists, median, bucket sums and loss BIT-IDENTICAL to the plain (sorting) path and to the strict scan --
+for an order taken in the cloud's own frame, in another pose, for a stale order and for an arbitrary permutation.
+"""
+import numpy as np
+import pytest
+import torch
+
+from test_gpu_parity import _check_sorted_layout, cu
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def L():
+    import loss
+    from rrl_hip import _lib
+    _lib.load()
+    assert torch.cuda.is_available()
+    return loss
+
+
+def _lines(L, prs, nl):
+    out = []
+    for b, p in enumerate(prs):
+        torch.manual_seed(100 + b)
+        out.append(L.Random_uniform_distribution_lines_batch_efficient_resample(
+            torch.tensor([[float(p["radius"])]]), torch.from_numpy(p["center"]).reshape(1, 3), nl, cu(p["src"])[None],
+            cu(p["tar"])[None], "cuda")[0])
+    return torch.stack(out)
+
+
+def _pairs(seed, B, n, m):
+    from rrl_hip import synth
+    prs = [synth.make_pair(seed + b, n, m) for b in range(B)]
+    return prs, cu(np.stack([p["src_tri"] for p in prs])), cu(np.stack([p["tar_tri"] for p in prs]))
+
+
+def _hits_sorted(st, which):
+    cnt = (st.count1 if which == 1 else st.count2).clone()
+    hit = (st.hit1 if which == 1 else st.hit2).clone()
+    k = torch.where(cnt <= 4, cnt, torch.zeros_like(cnt))  # beyond 4 hits only the first four ARRIVALS are kept (no bucket takes the line)
+    mask = torch.arange(4, device=hit.device)[None, None, :] < k[..., None]
+    hit = torch.where(mask, hit, torch.full_like(hit, 1 << 30))
+    return cnt, hit.sort(-1).values
+
+
+def _same_evaluation(a, b):
+    for w in (1, 2):
+        ca, ha = _hits_sorted(a, w)
+        cb, hb = _hits_sorted(b, w)
+        assert torch.equal(ca, cb) and torch.equal(ha, hb)
+    for x, y in ((a.loss, b.loss), (a.med, b.med), (a.info, b.info), (a.bsum, b.bsum), (a.bcnt, b.bcnt), (a.status[:1], b.status[:1])):
+        assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("B,n,m,nl", [(2, 1200, 1000, 6000), (1, 300, 200, 2500), (1, 5000, 4100, 1500), (2, 65, 64, 300),
+                                      (1, 16390, 500, 700), (3, 3, 70, 200)])
+def test_cloud_order_and_prepared_forward(L, oracle, B, n, m, nl):
+    """rrl_cloud_order gives a permutation per sample; a forward that is handed the orders equals the plain forward and the
+    strict scan bit for bit, and its sorted layout (IDX / P0S / sphere tree) satisfies the build step's invariants."""
+    from rrl_hip import ops
+    prs, t1, t2 = _pairs(300, B, n, m)
+    ln = _lines(L, prs, nl)
+    o1, o2 = ops.cloud_order(t1), ops.cloud_order(t2)
+    assert o1.shape == (B, (n + 63) // 64 * 64) and o1.dtype == torch.int32
+    for o, k in ((o1, n), (o2, m)):
+        oc = o.cpu().numpy()
+        for b in range(B):
+            assert sorted(oc[b, :k].tolist()) == list(range(k))
+            assert not oc[b, k:].any()
+    plain = ops.loss_forward_raw(t1, t2, ln, mode="cull")
+    strict = ops.loss_forward_raw(t1, t2, ln, mode="strict")
+    prep = ops.loss_forward_raw(t1, t2, ln, mode="cull", opts=ops.make_opts(order1=o1, order2=o2))
+    staged = ops.loss_forward_raw(t1, t2, ln, mode="cull", staged=True, opts=ops.make_opts(order1=o1, order2=o2))
+    torch.cuda.synchronize()
+    for st in (strict, prep, staged):
+        _same_evaluation(plain, st)
+    assert torch.equal(prep.idx1, o1) and torch.equal(prep.idx2, o2)
+    assert torch.equal(plain.pmax, prep.pmax) and torch.equal(plain.pmax, staged.pmax)
+    assert int(prep.status[1]) == 0  # no wavefront left the culled path
+    for b in range(min(B, 2)):
+        _check_sorted_layout(prep, prs[b]["src_tri"], oracle.tri_threshold(prs[b]["src_tri"]), 1, b)
+        _check_sorted_layout(prep, prs[b]["tar_tri"], oracle.tri_threshold(prs[b]["tar_tri"]), 2, b)
+
+
+@pytest.mark.parametrize("n,m", [(1200, 1000), (5000, 4100), (70, 130)])
+def test_refit_tree_equals_the_sort_kernels_tree(L, n, m):
+    """Handed the plain path's own order (its IDX arrays), the prepared build leaves the SAME workspace: sorted records,
+    indices, every node of the sphere tree, prepared triangles, NaN reach, max |P|^2 -- the DPP refit over 8 / 16 / 64
+    lanes reproduces tri_sort_kernel's one-lane-per-half tree bit for bit."""
+    from rrl_hip import ops
+    prs, t1, t2 = _pairs(320, 2, n, m)
+    ln = _lines(L, prs, 1500)
+    plain = ops.loss_forward_raw(t1, t2, ln, mode="cull")
+    prep = ops.loss_forward_raw(t1, t2, ln, mode="cull",
+                                opts=ops.make_opts(order1=plain.idx1.clone(), order2=plain.idx2.clone()))
+    torch.cuda.synchronize()
+    for f in ("idx1", "idx2", "p0s1", "p0s2", "ptri1", "ptri2", "del1", "del2", "pmax"):
+        assert torch.equal(getattr(plain, f), getattr(prep, f)), f
+    for f in ("grp1", "grp2"):  # NaN radii mark empty nodes: compare the bit patterns
+        assert torch.equal(getattr(plain, f).view(torch.int32), getattr(prep, f).view(torch.int32)), f
+    _same_evaluation(plain, prep)
+
+
+def _rot(axis, deg):
+    a = np.deg2rad(deg)
+    x, y, z = axis
+    K = np.array([[0, -z, y], [z, 0, -x], [-y, x, 0]], np.float64)
+    return (np.eye(3) + np.sin(a) * K + (1 - np.cos(a)) * (K @ K)).astype(np.float32)
+
+
+@pytest.mark.parametrize("one_call", [True, False])
+def test_prepared_step_over_poses(L, one_call):
+    """The order is taken ONCE in the source's own frame; steps at the identity, after 90 and 180 degree turns, a general
+    pose and a large translation equal the cold (sorting) step: loss / median / info / bucket sums / counts bit for bit,
+    (dR, dt, payload) to the rounding of their atomics.  A stale order (taken in ANOTHER pose of another cloud of the same
+    size) and a random permutation give the same bits too."""
+    from rrl_hip import ops
+    B, n, m, nl = 3, 1500, 1300, 5000
+    prs, src, tar = _pairs(340, B, n, m)
+    ln = _lines(L, prs, nl)
+    poses = [(np.eye(3, dtype=np.float32), np.zeros(3, np.float32)),
+             (_rot((0, 0, 1), 90), np.zeros(3, np.float32)),
+             (_rot((1, 0, 0), 180), np.array([0.1, 0.0, -0.05], np.float32)),
+             (_rot((0.6, 0.0, 0.8), 33), np.array([0.02, -0.03, 0.01], np.float32)),
+             (_rot((0, 1, 0), 7), np.array([3.0, -2.0, 1.0], np.float32))]
+    try:
+        ops.RegistrationStep.ONE_CALL = one_call
+        cold = ops.RegistrationStep(src, tar, nl, want_payload=True, prepared=False)
+        prep = ops.RegistrationStep(src, tar, nl, want_payload=True)
+        assert prep.prepared and not cold.prepared
+        gen = torch.Generator().manual_seed(3)
+        perm1 = torch.stack([torch.cat([torch.randperm(n, generator=gen), torch.zeros((n + 63) // 64 * 64 - n, dtype=torch.int64)])
+                             for _ in range(B)]).to(torch.int32).cuda()
+        _, other, _ = _pairs(999, B, n, m)
+        stale = ops.cloud_order(ops.rigid_apply(other.reshape(B, -1, 3), cu(np.stack([_rot((0, 0, 1), 45)] * B)),
+                                                cu(np.zeros((B, 3), np.float32))).reshape(B, n, 9))
+        odd = {"perm": ops.RegistrationStep(src, tar, nl, want_payload=True, src_order=perm1),
+               "stale": ops.RegistrationStep(src, tar, nl, want_payload=True, src_order=stale)}
+        for i, (Rm, tv) in enumerate(poses):
+            R, t = cu(np.stack([Rm] * B)), cu(np.stack([tv] * B))
+            a = [x.clone() for x in cold(R, t, ln)]
+            steps = [prep] + (list(odd.values()) if i in (0, 3) else [])
+            for stp in steps:
+                b_ = stp(R, t, ln)
+                torch.cuda.synchronize()
+                for x, y in ((a[0], b_[0]), (cold.st.med, stp.st.med), (a[4], b_[4]), (cold.st.bsum, stp.st.bsum),
+                             (cold.st.count1, stp.st.count1), (cold.st.count2, stp.st.count2), (cold.st.tri1t, stp.st.tri1t)):
+                    assert torch.equal(x, y)
+                for x, y in ((a[1], b_[1]), (a[2], b_[2]), (a[3], b_[3])):
+                    np.testing.assert_allclose(y.cpu().numpy(), x.cpu().numpy(), rtol=2e-5, atol=2e-6 * float(x.abs().max()))
+            if i < 4:
+                assert int(a[4][:, 1].min()) > 0  # lines are selected (the far translation may leave none)
+    finally:
+        ops.RegistrationStep.ONE_CALL = True
+
+
+def test_kept_target_is_rebuilt_when_it_changes(L):
+    """A target that has not changed since the previous call on the step's workspace is not rebuilt (RRL_F_TARGET_KEPT:
+    same tensor, same version counter); an in-place edit, a new tensor (tar_tri=) or a carried-over scan in between
+    make the next call build it again.  Every call equals the cold step of the same inputs bit for bit."""
+    from rrl_hip import ops
+    B, n, m, nl = 2, 900, 1100, 4000
+    prs, src, tar = _pairs(360, B, n, m)
+    ln = _lines(L, prs, nl)
+    R, t = cu(np.stack([_rot((0, 0, 1), 5)] * B)), cu(np.zeros((B, 3), np.float32))
+    cold = ops.RegistrationStep(src, tar, nl, prepared=False)
+    prep = ops.RegistrationStep(src, tar, nl)
+
+    def same():
+        a = cold(R, t, ln)
+        b_ = prep(R, t, ln)
+        torch.cuda.synchronize()
+        assert torch.equal(a[0], b_[0]) and torch.equal(cold.st.bsum, prep.st.bsum) and torch.equal(a[4], b_[4])
+        assert torch.equal(cold.st.count2, prep.st.count2)
+        assert torch.equal(cold.st.ptri2, prep.st.ptri2)
+
+    same()
+    assert prep._kept_key is not None
+    kept_opts = prep._optr_kept
+    same()  # second call: kept
+    same()
+    with torch.no_grad():
+        tar[:, : m // 2] += 0.01  # in place: the version counter moves, the records are rebuilt
+    same()
+    assert not torch.equal(prep.st.ptri2[:, 0, :3], torch.zeros_like(prep.st.ptri2[:, 0, :3]))
+    tar2 = tar.clone()
+    with torch.no_grad():
+        tar2[:, m // 2:] -= 0.02
+    a = cold(R, t, ln, tar_tri=tar2)
+    b_ = prep(R, t, ln, tar_tri=tar2)
+    torch.cuda.synchronize()
+    assert torch.equal(a[0], b_[0]) and torch.equal(cold.st.ptri2, prep.st.ptri2)
+    a = cold(R, t, ln)
+    b_ = prep(R, t, ln)  # kept again, now tar2's records
+    torch.cuda.synchronize()
+    assert torch.equal(a[0], b_[0]) and torch.equal(cold.st.bsum, prep.st.bsum)
+    assert kept_opts is not None
+
+
+@pytest.mark.parametrize("scale", [12.0, 300.0])
+def test_prepared_build_at_the_demo_scale(L, scale):
+    """Clouds scaled to the reference demo's data scale and beyond (the culled scan's NaN reach DEL is gathered through
+    IDX there): prepared == plain == strict, NaN flag included."""
+    from rrl_hip import ops
+    prs, t1, t2 = _pairs(380, 1, 1024, 1024)
+    t1, t2 = t1 * scale, t2 * scale
+    p = prs[0]
+    torch.manual_seed(5)
+    ln = L.Random_uniform_distribution_lines_batch_efficient_resample(
+        torch.tensor([[float(p["radius"]) * scale * 2.0]]), torch.from_numpy(p["center"] * scale).reshape(1, 3), 4000,
+        t1[:, :, :3].contiguous(), t2[:, :, :3].contiguous(), "cuda")
+    o1, o2 = ops.cloud_order(t1), ops.cloud_order(t2)
+    plain = ops.loss_forward_raw(t1, t2, ln, mode="cull")
+    strict = ops.loss_forward_raw(t1, t2, ln, mode="strict")
+    prep = ops.loss_forward_raw(t1, t2, ln, mode="cull", opts=ops.make_opts(order1=o1, order2=o2))
+    torch.cuda.synchronize()
+    _same_evaluation(plain, prep)
+    _same_evaluation(strict, prep)
+    assert int(prep.status[1]) == 0
+
+
+def test_prepared_autograd_ops(L):
+    """ops.intersection_loss / ops.registration_loss take the orders too (order1= / order2=): same loss bits, gradients
+    to the rounding of the scatter's atomics."""
+    from rrl_hip import ops
+    B, n, m, nl = 2, 700, 800, 3000
+    prs, src, tar = _pairs(400, B, n, m)
+    ln = _lines(L, prs, nl)
+    o1, o2 = ops.cloud_order(src), ops.cloud_order(tar)
+    res = []
+    for kw in ({}, {"order1": o1, "order2": o2}):
+        p1 = src.clone().requires_grad_(True)
+        loss, info, _ = ops.intersection_loss(p1, tar, ln, **kw)
+        loss.sum().backward()
+        res.append((loss.detach().clone(), p1.grad.clone()))
+    assert torch.equal(res[0][0], res[1][0])
+    np.testing.assert_allclose(res[1][1].cpu().numpy(), res[0][1].cpu().numpy(), rtol=2e-5, atol=1e-7)
+    R = cu(np.stack([_rot((0, 1, 0), 10)] * B)).requires_grad_(True)
+    t = cu(np.zeros((B, 3), np.float32)).requires_grad_(True)
+    out = []
+    for kw in ({}, {"order1": o1, "order2": o2}):
+        R.grad = t.grad = None
+        loss, info, _ = ops.registration_loss(src, R, t, tar, ln, **kw)
+        loss.sum().backward()
+        out.append((loss.detach().clone(), R.grad.clone(), t.grad.clone()))
+    assert torch.equal(out[0][0], out[1][0])
+    for x, y in zip(out[0][1:], out[1][1:]):
+        np.testing.assert_allclose(y.cpu().numpy(), x.cpu().numpy(), rtol=2e-5, atol=2e-6 * float(x.abs().max()))

@@ -1,6 +1,7 @@
 """The fused step (ops.RegistrationStep: forward + direct backward) in a plain loop at one shape -- the
 workload tools/kt.sh runs under rocprofv3 to get per-kernel averages.  usage: step_loop.py B,N,M,L [steps] [diag]
-Environment knobs of the library apply (RRL_REDUCE, RRL_SORT_PARTS, RRL_CULL_GEOM, ...)."""
+Environment knobs of the library apply (RRL_REDUCE, RRL_SORT_PARTS, RRL_CULL_GEOM, ...); RRL_PREPARED=0: the cold
+(sorting) step instead of the prepared build."""
 import os, sys, time
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -31,7 +32,8 @@ ln = torch.stack(ln)
 R = torch.eye(3, device="cuda").repeat(B, 1, 1)
 t = torch.zeros(B, 3, device="cuda")
 ops.RegistrationStep.ONE_CALL = os.environ.get("RRL_ONE_CALL", "1") != "0"
-rs = ops.RegistrationStep(src, tar, L, transpose_r=True, mode=os.environ.get("RRL_SCAN_MODE", "cull"))
+rs = ops.RegistrationStep(src, tar, L, transpose_r=True, mode=os.environ.get("RRL_SCAN_MODE", "cull"),
+                          prepared=os.environ.get("RRL_PREPARED", "1") != "0")
 for _ in range(10):
     rs(R, t, ln)
 torch.cuda.synchronize(); t0 = time.perf_counter()
