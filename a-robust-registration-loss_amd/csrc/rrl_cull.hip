@@ -1614,24 +1614,3 @@ int rrl_launch_cull_scan(const float *line, void *ws, const WsLayout &w, int B, 
 }
 
 int rrl_sort_capacity(void) { return SORT_CAP; }
-
-// ---------------------------------------------------------------------------------------
-// rrl_cloud_order (include/rrl.h): the spatial order of a cloud, computed once.
-// ---------------------------------------------------------------------------------------
-extern "C" size_t rrl_cloud_order_workspace_bytes(int B, int n) {
-    return WsLayout(B > 0 ? B : 0, n > 0 ? n : 0, 0, 0).total + 256;
-}
-
-extern "C" int rrl_cloud_order(const float *tri, int32_t *order, void *ws, size_t ws_bytes, int B, int n, void *stream) {
-    if (!tri || !order || !ws || B < 0 || n < 0 || n > SORT_CAP) return RRL_E_ARG;
-    if (B == 0 || n == 0) return 0;
-    WsLayout w(B, n, 0, 0);
-    if (ws_bytes < w.total) return RRL_E_WS;
-    hipStream_t s = (hipStream_t)stream;
-    RrlCall o = {};
-    o.sort_parts = rrl_default_sort_parts();
-    int rc = rrl_launch_tri_build(tri, tri, ws, w, B, n, 0, 1, nullptr, nullptr, 0, o, s);  // records + cell sort of cloud 0
-    if (rc) return rc;
-    const size_t npad = (size_t)(n + SGT - 1) / SGT * SGT;
-    return rrl_copy(order, w.i32(ws, RRL_WS_IDX1), sizeof(int32_t) * (size_t)B * npad, s);
-}

