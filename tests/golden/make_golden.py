@@ -505,7 +505,93 @@ def dataset():
     save("dataset.npz", **out)
 
 
+def _ref_pair(group, label, seed):
+    """One pair of the reference's own sample data, prepared exactly like its demo does
+    (code/test_demo_optimized_Lie_Algebra.py:103-143): vertices of the two OBJ files, pseudo-triangles by the
+    reference's Sample_neighs, both centred, sampling sphere = the target's AABB diagonal around its mean.
+    Only DERIVED arrays leave this function (centred points / pseudo-triangles); never the OBJ text."""
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    v1 = read_obj_vertices(os.path.join(REF, f"sample_data/{group}/{label}_src_sample.obj"))
+    v2 = read_obj_vertices(os.path.join(REF, f"sample_data/{group}/{label}_tar_sample.obj"))
+    n1 = RL.Sample_neighs(v1).reshape(-1, 9)
+    n2 = RL.Sample_neighs(v2).reshape(-1, 9)
+    c1, c2 = v1.mean(0, keepdims=True), v2.mean(0, keepdims=True)
+    v1, v2 = (v1 - c1).astype(np.float32), (v2 - c2).astype(np.float32)
+    n1 = (n1.reshape(-1, 3) - c1).reshape(-1, 9).astype(np.float32)
+    n2 = (n2.reshape(-1, 3) - c2).reshape(-1, 9).astype(np.float32)
+    bb = RL.generate_bbox(t(v2)[None])[0].numpy()
+    return v1, v2, n1, n2, bb, float(np.linalg.norm(bb[0] - bb[-1]))
+
+
+def refdata():
+    """Loss fixtures on the REFERENCE'S OWN sample pairs (code/sample_data/*; its demo iterates such pairs,
+    test_demo_optimized_Lie_Algebra.py:158-162): two airplane pairs (1024 / 1024), a human pair (N = 1024, M = 2048: the
+    first N != M fixture on reference data) and a real-scan fragment pair (2048 / 2048, BASELINE configs[4]'s kind of
+    data) -- counts, hit lists, weights, D, median, loss and points1.grad from the reference.  The line seed of each
+    fixture is the first one whose label decisions are provably non-borderline (margin > 2e-6 >> 1 ulp)."""
+    for group, label, tag, nl in (("airplane_data", "0", "airplane0", 3000), ("airplane_data", "3", "airplane3", 3000),
+                                  ("human_data", "0", "human0", 3000), ("real_data", "0", "real0", 2500)):
+        v1, v2, n1, n2, bb, rad = _ref_pair(group, label, 123)
+        for seed in range(7, 40):
+            lines = ref_lines(seed, rad, v2.mean(0), v1, v2, nl)
+            mg = min(margin(n1, lines), margin(n2, lines))
+            if mg > 2e-6:
+                break
+        print(f"{tag}: N={n1.shape[0]} M={n2.shape[0]} radius={rad:.3f} filled "
+              f"{(np.abs(lines).sum(1) > 0).sum()}/{nl} line seed {seed} margin {mg:.2e}")
+        loss_fixture(f"loss_ref_{tag}.npz", n1, n2, lines, [(1, 1, 5, 5)])
+
+
+def demo_trajectory_airplane():
+    """The demo loop (test_demo_optimized_Lie_Algebra.py:27-75) on a pair of the reference's own data
+    (airplane_data/1, N = M = 1024), 8 epochs with recorded lines: like demo_trajectory() on reference data."""
+    nl, epochs = 3000, 8
+    v1n, v2n, n1, n2, bbn, _ = _ref_pair("airplane_data", "1", 123)
+    v1, v2 = t(v1n), t(v2n)
+    f1 = t(n1).reshape(1, -1, 3)
+    f2 = t(n2)
+    bbox = RL.generate_bbox(v2[None])[0]
+    centers = v2.mean(0)
+    np.random.seed(19)
+    torch.manual_seed(19)
+    rec = RL.Reconstruction_point()
+    xi0 = rec.parameters_.detach().numpy().copy()
+    opt = torch.optim.Adam(rec.parameters(), lr=2e-2)
+    R = (bbox[0] - bbox[-1]).norm(p=2)
+    cur = v1
+    lines_all, losses, chamfers, xis, lrs = [], [], [], [], []
+    for epoch in range(epochs):
+        lines = RL.Random_uniform_distribution_lines_batch_efficient_resample(
+            torch.FloatTensor([R]).reshape(1, 1), centers.reshape(1, -1), nl,
+            cur.view(1, -1, 3), v2.view(1, -1, 3), "cpu").detach().view(-1, 6)
+        lr = opt.param_groups[0]["lr"]
+        if epoch % 1000 == 0:
+            lr *= 0.5
+        for gparam in opt.param_groups:
+            gparam["lr"] = lr
+        cur, tri = rec(v1, f1)
+        loss = RL.cal_loss_intersection_batch_whole_median_pts_lines(
+            1, 1, 5, 5, tri.reshape(1, -1, 9), f2.reshape(1, -1, 9), lines.reshape(1, -1, 6), "cpu")
+        assert not isinstance(loss, tuple)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        cf = RL.chamfer_dist(cur.reshape(-1, cur.shape[0], 3), v2.reshape(-1, v2.shape[0], 3))
+        lines_all.append(lines.numpy().copy())
+        losses.append(loss.item())
+        chamfers.append(cf.item())
+        xis.append(rec.parameters_.detach().numpy().copy())
+        lrs.append(lr)
+        cur = cur.detach()
+    print("airplane demo trajectory: loss", losses, "chamfer", chamfers)
+    save("demo_trajectory_airplane.npz", src=v1n, tar=v2n, src_tri=n1, tar_tri=n2, bbox=bbox.numpy(),
+         centers=centers.numpy(), xi0=xi0, lines=np.array(lines_all, np.float32), loss=np.array(losses, np.float32),
+         chamfer=np.array(chamfers, np.float32), xi=np.array(xis, np.float32), lr=np.array(lrs, np.float64))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["main", "neighs", "callsites", "demo_trajectory", "dataset", "accept"]
+    which = sys.argv[1:] or ["main", "neighs", "callsites", "demo_trajectory", "dataset", "accept", "refdata",
+                             "demo_trajectory_airplane"]
     for name in which:
         globals()[name]()

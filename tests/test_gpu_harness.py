@@ -224,8 +224,11 @@ def demo_inputs(g):
 
 
 @pytest.mark.parametrize("graph", [False, True])
-def test_demo_trajectory(demo, tmp_path, graph):
-    g = load_golden("demo_trajectory.npz")
+@pytest.mark.parametrize("fixture", ["demo_trajectory.npz", "demo_trajectory_airplane.npz"])
+def test_demo_trajectory(demo, tmp_path, graph, fixture):
+    """8 reference epochs with the reference's recorded lines: a synthetic pair, and (round 4) a pair of the reference's
+    OWN sample data (code/sample_data/airplane_data/1, N = M = 1024, prepared like its demo does)."""
+    g = load_golden(fixture)
     data, model, lines_fn = demo_inputs(g)
     n = len(g["loss"])
     log = demo.ScalarLog(str(tmp_path / "log"))

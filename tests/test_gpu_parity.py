@@ -18,7 +18,10 @@ from conftest import load_golden, merge_by_point
 pytestmark = pytest.mark.gpu
 
 LOSS_FIXTURES = ["loss_synth_s0.npz", "loss_synth_s1.npz", "loss_demo_scale.npz",
-                 "loss_edge_zero_dup.npz"]
+                 "loss_edge_zero_dup.npz",
+                 # the reference's OWN sample pairs (code/sample_data/: airplane 1024 / 1024, human 1024 / 2048,
+                 # real-scan fragments 2048 / 2048), prepared like its demo does -- make_golden.py refdata
+                 "loss_ref_airplane0.npz", "loss_ref_airplane3.npz", "loss_ref_human0.npz", "loss_ref_real0.npz"]
 
 
 @pytest.fixture(scope="module")
