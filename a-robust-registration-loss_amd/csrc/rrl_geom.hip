@@ -523,6 +523,25 @@ extern "C" int rrl_se3_exp_bwd(const float *xi, const float *gR, const float *gT
     return 0;
 }
 
+// One parameter's torch.optim.Adam update (no weight decay, no amsgrad) as PyTorch's CPU path evaluates it
+// (torch/optim/adam.py _single_tensor_adam of the PyTorch that generated the fixtures, 2.10: exp_avg.lerp_; 1.7.1, which
+// the reference pins, wrote exp_avg.mul_(beta1).add_(grad, alpha=1 - beta1) -- the same value to an ulp): the betas, 1 - beta and eps are Python doubles cast to fp32 where they
+// meet the fp32 tensors (exp_avg.lerp_ / mul_ / addcmul_), the bias corrections and step_size = lr / (1 - beta1^t) are
+// DOUBLE arithmetic on the host, denom = sqrt(v) / float(sqrt(1 - beta2^t)) + eps, p += float(-step_size) * m / denom.
+// (Round 4: in fp32, 1 - 0.999^t carries a relative error of 3e-5 at small t and 1.0f - 0.999f differs from
+// float(0.001) by 1.3e-5 -- enough to move the demo's xi by 3e-8 per epoch and, at the reference's data scale, to
+// flip labels within three epochs; tests/golden/demo_trajectory_airplane.npz.)
+__device__ __forceinline__ float adam_update(float p, float g, float &m, float &v, float step, float lr, double b1, double b2,
+                                             double eps) {
+    const float w1 = (float)(1.0 - b1), b2f = (float)b2, w2 = (float)(1.0 - b2);
+    m = m + w1 * (g - m);                  // exp_avg.lerp_(grad, 1 - beta1)
+    v = v * b2f + (g * g) * w2;            // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
+    const double bias1 = 1.0 - pow(b1, (double)step), bias2 = 1.0 - pow(b2, (double)step);
+    const float step_size = (float)((double)lr / bias1), bc2 = (float)sqrt(bias2);
+    const float denom = sqrtf(v) / bc2 + (float)eps;
+    return p + (-step_size * m) / denom;   // param.addcdiv_(exp_avg, denom, value=-step_size)
+}
+
 // torch.optim.Adam's update (no weight decay, no amsgrad) with every scalar on the device, so a
 // captured graph takes a new learning rate per replay and skips the update when gate[0] <= 0 (the
 // demo's `if loss_di is not None`, gate = the loss's bucket count).  state = [step]; one lane per
@@ -530,29 +549,25 @@ extern "C" int rrl_se3_exp_bwd(const float *xi, const float *gR, const float *gT
 __global__ __launch_bounds__(256) void adam_gated_kernel(float *__restrict__ p, const float *__restrict__ g,
                                                          float *__restrict__ m, float *__restrict__ v,
                                                          float *__restrict__ state, const float *__restrict__ lr,
-                                                         const int32_t *__restrict__ gate, int n, float b1, float b2,
-                                                         float eps) {
+                                                         const int32_t *__restrict__ gate, int n, double b1, double b2,
+                                                         double eps) {
     const int i = threadIdx.x;
     const bool ok = gate == nullptr || gate[0] > 0;
     const float step = state[0] + (ok ? 1.0f : 0.0f);
     __syncthreads();
     if (ok) {
         for (int q = i; q < n; q += 256) {
-            const float gi = g[q];
-            const float mi = m[q] * b1 + gi * (1.0f - b1);
-            const float vi = v[q] * b2 + gi * gi * (1.0f - b2);
+            float mi = m[q], vi = v[q];
+            p[q] = adam_update(p[q], g[q], mi, vi, step, lr[0], b1, b2, eps);
             m[q] = mi;
             v[q] = vi;
-            const float bias1 = 1.0f - powf(b1, step), bias2 = 1.0f - powf(b2, step);
-            const float denom = sqrtf(vi) / sqrtf(bias2) + eps;
-            p[q] = p[q] - (lr[0] / bias1) * mi / denom;
         }
     }
     if (i == 0) state[0] = step;
 }
 
 extern "C" int rrl_adam_gated(float *p, const float *g, float *m, float *v, float *state, const float *lr,
-                              const int32_t *gate, int n, float b1, float b2, float eps, void *stream) {
+                              const int32_t *gate, int n, double b1, double b2, double eps, void *stream) {
     if (!p || !g || !m || !v || !state || !lr || n < 0) return RRL_E_ARG;
     if (n == 0) return 0;
     hipLaunchKernelGGL(adam_gated_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, p, g, m, v, state, lr, gate, n,
@@ -570,8 +585,8 @@ __global__ __launch_bounds__(64) void se3_adam_step_kernel(float *__restrict__ x
                                                            const float *__restrict__ gT, float *__restrict__ m,
                                                            float *__restrict__ v, float *__restrict__ state,
                                                            const float *__restrict__ lr,
-                                                           const int32_t *__restrict__ gate, float b1, float b2,
-                                                           float eps, float *__restrict__ R, float *__restrict__ T,
+                                                           const int32_t *__restrict__ gate, double b1, double b2,
+                                                           double eps, float *__restrict__ R, float *__restrict__ T,
                                                            float *__restrict__ gxi, const float *__restrict__ loss,
                                                            const float *__restrict__ value, float *__restrict__ table,
                                                            long long *__restrict__ cursor, long long nrows,
@@ -592,13 +607,10 @@ __global__ __launch_bounds__(64) void se3_adam_step_kernel(float *__restrict__ x
         for (int i = 0; i < 3; ++i) g += (gT ? gT[i] : 0.0f) * t[i].d;
         if (gxi) gxi[k] = g;
         if (ok) {
-            const float mi = m[k] * b1 + g * (1.0f - b1);
-            const float vi = v[k] * b2 + g * g * (1.0f - b2);
+            float mi = m[k], vi = v[k];
+            pk = adam_update(pk, g, mi, vi, step, lr[0], b1, b2, eps);
             m[k] = mi;
             v[k] = vi;
-            const float bias1 = 1.0f - powf(b1, step), bias2 = 1.0f - powf(b2, step);
-            const float denom = sqrtf(vi) / sqrtf(bias2) + eps;
-            pk = pk - (lr[0] / bias1) * mi / denom;
             xi[k] = pk;
         }
     }
@@ -625,7 +637,7 @@ __global__ __launch_bounds__(64) void se3_adam_step_kernel(float *__restrict__ x
 }
 
 extern "C" int rrl_se3_adam_step(float *xi, const float *gR, const float *gT, float *m, float *v, float *state,
-                                 const float *lr, const int32_t *gate, float b1, float b2, float eps, float *R,
+                                 const float *lr, const int32_t *gate, double b1, double b2, double eps, float *R,
                                  float *T, float *gxi, const float *loss, const float *value, float *table,
                                  long long *cursor, long long nrows, float *row, void *stream) {
     if (!xi || !m || !v || !state || !lr || !R || !T) return RRL_E_ARG;

@@ -613,7 +613,7 @@ class RegistrationStep:
     ONE_CALL = os.environ.get("RRL_ONE_CALL", "1") != "0"
 
     def __init__(self, src_tri, tar_tri, n_lines, rng=(1, 1, 5, 5), transpose_r=True, mode="cull", chunk=0,
-                 want_payload=False, prepared=True, src_order=None, tar_order=None):
+                 want_payload=False, prepared=None, src_order=None, tar_order=None):
         dev = _home(src_tri, tar_tri)
         self.dev = dev
         self.src = _prep(src_tri, "src_tri", 9, dev)
@@ -640,6 +640,8 @@ class RegistrationStep:
         self._head_s = (_p(self.st.ws), self.st.nbytes, _p(self.st.loss))
         self._tail_s = (_p(gacc[:B * 9]), _p(gacc[B * 9:B * 12]), _p(self.payload), B, N, M, L, self.tr, *self.rng,
                         self.mode, self.chunk, None)
+        if prepared is None:  # default: on (RRL_PREPARED=0 turns the default off: A/B runs of unmodified callers)
+            prepared = os.environ.get("RRL_PREPARED", "1") != "0"
         self.prepared = bool(prepared) and mode == "cull" and max(N, M) <= 65536
         self._kept_key = None  # (data_ptr, version) of the target whose records the workspace holds
         self.order1 = self.order2 = None

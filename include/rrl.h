@@ -403,10 +403,11 @@ int rrl_rigid_apply_bwd(const float *x, const float *R, const float *gy, float *
 int rrl_se3_exp(const float *xi, float *R, float *T, int B, void *stream);
 int rrl_se3_exp_bwd(const float *xi, const float *gR, const float *gT, float *gxi, int B, void *stream);
 /* torch.optim.Adam's step (test_demo_optimized_Lie_Algebra.py:42, 64-66) on p [n] with device-side
- * scalars: state[0] = step count (float), lr[0]; the update is skipped when gate != NULL and
- * gate[0] <= 0 (the demo's `if loss_di is not None`; gate = INFO[0] of the loss). */
+ * scalars: state[0] = step count (float), lr[0]; b1, b2, eps are DOUBLES like the Python floats torch.optim.Adam
+ * holds (its bias corrections are double arithmetic; in fp32 1 - 0.999^t is 3e-5 off at small t); the update is
+ * skipped when gate != NULL and gate[0] <= 0 (the demo's `if loss_di is not None`; gate = INFO[0] of the loss). */
 int rrl_adam_gated(float *p, const float *g, float *m, float *v, float *state, const float *lr,
-                   const int32_t *gate, int n, float b1, float b2, float eps, void *stream);
+                   const int32_t *gate, int n, double b1, double b2, double eps, void *stream);
 
 /* One row of the demo's per-epoch log (code/test_demo_optimized_Lie_Algebra.py:72-82 prints / logs
  * loss and Chamfer) written on the device, so a captured step needs no host read-back:
@@ -421,7 +422,7 @@ int rrl_log_row(const float *loss, const float *value, const int32_t *info, floa
  * (R, T) = exp(updated xi) (rrl_se3_exp) and, when table and cursor are given, the log row (rrl_log_row with
  * info = gate).  Bit-identical to the four calls.  gxi, loss, value, table, cursor, row may be NULL. */
 int rrl_se3_adam_step(float *xi, const float *gR, const float *gT, float *m, float *v, float *state,
-                      const float *lr, const int32_t *gate, float b1, float b2, float eps, float *R, float *T,
+                      const float *lr, const int32_t *gate, double b1, double b2, double eps, float *R, float *T,
                       float *gxi, const float *loss, const float *value, float *table, long long *cursor,
                       long long nrows, float *row, void *stream);
 

@@ -238,9 +238,13 @@ def test_demo_trajectory(demo, tmp_path, graph, fixture):
     assert [h[0] for h in hist] == list(range(n))
     # measured (gpurun_out/r02v_demo.txt): loss within 8.6e-4 (eager, last step) / 3.3e-5 (graph), Chamfer
     # within 1.3e-6, xi within 1.7e-5 of the reference's trajectory; see test_demo_moved_source_flips_no_label
-    np.testing.assert_allclose([h[1] for h in hist], g["loss"], rtol=2e-3)
+    # Round 4 (the airplane pair; Adam's scalars now follow torch's double arithmetic): xi within 2.3e-6 (eager) / 1.3e-6
+    # (captured) of the reference's after 8 epochs, loss within 1.5e-4 / 3.4e-3: at the reference's data scale (AABB
+    # diagonal 13) one line changes its bucket when xi moves by 1e-6 (the labels are that noisy there, DESIGN section 3
+    # "culling bound"), which moves one epoch's loss by a few 1e-3 and nothing else.
+    np.testing.assert_allclose([h[1] for h in hist], g["loss"], rtol=2e-3 if fixture == "demo_trajectory.npz" else 6e-3)
     np.testing.assert_allclose([h[2] for h in hist], g["chamfer"], rtol=1e-5)
-    np.testing.assert_allclose(model.parameters_.detach().cpu().numpy(), g["xi"][-1], atol=1e-4)
+    np.testing.assert_allclose(model.parameters_.detach().cpu().numpy(), g["xi"][-1], atol=1e-4 if fixture == "demo_trajectory.npz" else 2e-5)
     # first step: lr already halved to 1e-2 at epoch 0 -> Adam moves every coordinate by ~lr
     np.testing.assert_allclose(np.abs(g["xi"][0] - g["xi0"]), 1e-2, rtol=1e-3)
     for name in ("0.obj", "target.obj", "model.pkl", "0_transform.txt", os.path.join("log", "scalars.csv")):

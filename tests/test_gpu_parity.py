@@ -957,7 +957,9 @@ def test_adam_gated_kernel_vs_torch_adam(L):
             ref.grad = g.clone()
             opt.step()
         ops.adam_gated(p, g.cuda(), m, v, state, lr, torch.tensor([gate, 0, 0, 0], dtype=torch.int32, device="cuda"))
-        np.testing.assert_allclose(p.cpu().numpy(), ref.detach().numpy(), rtol=2e-5, atol=2e-7)
+        # round 4: the kernel follows torch's evaluation (double bias corrections, float(1 - beta) weights): a few ulps
+        # (round 3 allowed 2e-5: 1 - 0.999^t in fp32 is 3e-5 off at small t)
+        np.testing.assert_allclose(p.cpu().numpy(), ref.detach().numpy(), rtol=1e-6, atol=2e-8)
     assert float(state[0]) == 27.0
 
 
