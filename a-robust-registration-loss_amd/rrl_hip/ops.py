@@ -402,71 +402,203 @@ def _lease_state(B, N, M, L, G, dev):
     return st
 
 
+def _dropin_forward(ctx, points1, points2, line, rng, pool, mode, chunk):
+    """Forward of the reference-signature call: rrl_loss_forward_info on a leased workspace (one C call incl. the read-back
+    of the flags).  Returns loss (G,) -- a fresh tensor -- and leaves the flags of all groups in _DropinLoss.flags_all."""
+    dev = _home(points1, points2, line)
+    tri1, tri2 = _prep(points1, "points1", 9, dev), _prep(points2, "points2", 9, dev)
+    ln = _prep(line, "line", 6, dev)
+    if tri1.dim() != 3 or tri2.dim() != 3 or ln.dim() != 3:
+        raise ValueError("Input is wrong: points1/points2/line must be 3-D (B, n, c)")
+    B, N, _ = tri1.shape
+    M, L = tri2.shape[1], ln.shape[1]
+    if not (tri2.shape[0] == ln.shape[0] == B):
+        raise ValueError("points1, points2 and line must share the batch dimension")
+    G = 1 if pool else B
+    ctx.set_materialize_grads(False)
+    if B == 0 or L == 0:  # empty batch / no lines: nothing to launch, no bucket
+        ctx.st = None
+        _DropinLoss.flags_all = [0, 0, 0, 0] * max(G, 1)
+        _DropinLoss.flags = [0, 0, 0, 0]
+        return torch.zeros(max(G, 1), device=dev)
+    s_m, s_n, e_m, e_n = _check_range(rng)
+    st = _lease_state(B, N, M, L, G, dev)
+    if not hasattr(st, "hostp"):  # created while capturing: no read-back possible there
+        raise RRLError("the reference-signature loss synchronises (it returns None / raises on the host): "
+                       "it cannot be captured into a graph; use batched_intersection_loss / ops.registration_loss")
+    st.loss = loss = torch.empty(G, dtype=torch.float32, device=dev)
+    with _guard(dev):
+        check(_lib.load().rrl_loss_forward_info(_p(tri1), _p(tri2), _p(ln), st.wsp, st.nbytes, _p(loss), B, N, M, L,
+                                                s_m, s_n, e_m, e_n, int(pool), _MODES[mode], int(chunk), None,
+                                                st.hostp, _stream(dev)), "rrl_loss_forward_info")
+    _DropinLoss.flags_all = fl = st.host_info.tolist()  # 4 per group
+    _DropinLoss.flags = fl[:4]
+    ctx.st, ctx.tri1, ctx.tri2, ctx.pool = st, tri1, tri2, bool(pool)
+    ctx.in_devs = (points1.device, points2.device)
+    _IntersectionLoss.last_state = st
+    return loss
+
+
+def _dropin_backward(ctx, g_loss):
+    """(grad points1, grad points2) of a _dropin_forward evaluation for dL/dloss = g_loss (G,)."""
+    st, tri1, tri2 = ctx.st, ctx.tri1, ctx.tri2
+    B, N, M, L, _ = st.dims
+    dev = tri1.device
+    g = g_loss if (g_loss.device == dev and g_loss.dtype == torch.float32 and g_loss.is_contiguous()) else \
+        g_loss.detach().to(device=dev, dtype=torch.float32).contiguous()
+    g1 = torch.empty_like(tri1)  # zeroed by rrl_loss_backward
+    g2 = torch.empty_like(tri2) if ctx.needs_input_grad[1] else None
+    with _guard(dev):
+        check(_lib.load().rrl_loss_backward(_p(tri1), _p(tri2), st.wsp, st.nbytes, _p(g), _p(g1), _p(g2),
+                                            B, N, M, L, int(ctx.pool), _stream(dev)), "rrl_loss_backward")
+    if not ctx.needs_input_grad[0]:
+        g1 = None
+    elif ctx.in_devs[0] != dev:
+        g1 = g1.to(ctx.in_devs[0])
+    if g2 is not None and ctx.in_devs[1] != dev:
+        g2 = g2.to(ctx.in_devs[1])
+    return g1, g2
+
+
 class _DropinLoss(torch.autograd.Function):
     """forward = rrl_loss_forward_info on a leased workspace; the host flags of the call are left in
-    _DropinLoss.flags ([nbuckets, nselected, nvalues, NaN flag] of group 0)."""
+    _DropinLoss.flags ([nbuckets, nselected, nvalues, NaN flag] of group 0; flags_all: of every group)."""
     flags = None
+    flags_all = None
 
     @staticmethod
     def forward(ctx, points1, points2, line, rng, pool, mode, chunk):
-        dev = _home(points1, points2, line)
-        tri1, tri2 = _prep(points1, "points1", 9, dev), _prep(points2, "points2", 9, dev)
-        ln = _prep(line, "line", 6, dev)
-        if tri1.dim() != 3 or tri2.dim() != 3 or ln.dim() != 3:
-            raise ValueError("Input is wrong: points1/points2/line must be 3-D (B, n, c)")
-        B, N, _ = tri1.shape
-        M, L = tri2.shape[1], ln.shape[1]
-        if not (tri2.shape[0] == ln.shape[0] == B):
-            raise ValueError("points1, points2 and line must share the batch dimension")
-        G = 1 if pool else B
-        ctx.set_materialize_grads(False)
-        if B == 0 or L == 0:  # empty batch / no lines: nothing to launch, no bucket
-            ctx.st = None
-            _DropinLoss.flags = [0, 0, 0, 0]
-            return torch.zeros(max(G, 1), device=dev)
-        s_m, s_n, e_m, e_n = _check_range(rng)
-        st = _lease_state(B, N, M, L, G, dev)
-        if not hasattr(st, "hostp"):  # created while capturing: no read-back possible there
-            raise RRLError("the reference-signature loss synchronises (it returns None / raises on the host): "
-                           "it cannot be captured into a graph; use batched_intersection_loss / ops.registration_loss")
-        st.loss = loss = torch.empty(G, dtype=torch.float32, device=dev)
-        with _guard(dev):
-            check(_lib.load().rrl_loss_forward_info(_p(tri1), _p(tri2), _p(ln), st.wsp, st.nbytes, _p(loss), B, N, M, L,
-                                                    s_m, s_n, e_m, e_n, int(pool), _MODES[mode], int(chunk), None,
-                                                    st.hostp, _stream(dev)), "rrl_loss_forward_info")
-        _DropinLoss.flags = st.host_info[:4].tolist()
-        ctx.st, ctx.tri1, ctx.tri2, ctx.pool = st, tri1, tri2, bool(pool)
-        ctx.in_devs = (points1.device, points2.device)
-        _IntersectionLoss.last_state = st
-        return loss.view(-1)  # a view: st.loss itself must not become the autograd output (st -> loss -> node -> st)
+        return _dropin_forward(ctx, points1, points2, line, rng, pool, mode, chunk).view(-1)  # a view: st.loss itself
+        #                                      must not become the autograd output (st -> loss -> node -> st)
 
     @staticmethod
     def backward(ctx, g_loss):
         if g_loss is None or ctx.st is None:
             return (None,) * 7
-        st, tri1, tri2 = ctx.st, ctx.tri1, ctx.tri2
-        B, N, M, L, _ = st.dims
-        dev = tri1.device
-        g = g_loss if (g_loss.device == dev and g_loss.dtype == torch.float32 and g_loss.is_contiguous()) else \
-            g_loss.detach().to(device=dev, dtype=torch.float32).contiguous()
-        g1 = torch.empty_like(tri1)  # zeroed by rrl_loss_backward
-        g2 = torch.empty_like(tri2) if ctx.needs_input_grad[1] else None
-        with _guard(dev):
-            check(_lib.load().rrl_loss_backward(_p(tri1), _p(tri2), st.wsp, st.nbytes, _p(g), _p(g1), _p(g2),
-                                                B, N, M, L, int(ctx.pool), _stream(dev)), "rrl_loss_backward")
-        if not ctx.needs_input_grad[0]:
-            g1 = None
-        elif ctx.in_devs[0] != dev:
-            g1 = g1.to(ctx.in_devs[0])
-        if g2 is not None and ctx.in_devs[1] != dev:
-            g2 = g2.to(ctx.in_devs[1])
-        return g1, g2, None, None, None, None, None
+        return (*_dropin_backward(ctx, g_loss), None, None, None, None, None)
+
+
+class _DropinBatch(torch.autograd.Function):
+    """The whole batch of a trainer's per-sample loop as ONE node with B outputs of shape (1,): the caller's
+    `total = total + one_j ... ; total.backward()` hands this node B gradients at once -- no slice / scatter kernels of
+    autograd's own, one rrl_loss_backward for the batch."""
+
+    @staticmethod
+    def forward(ctx, points1, points2, line, rng, mode, chunk):
+        loss = _dropin_forward(ctx, points1, points2, line, rng, False, mode, chunk)
+        return tuple(loss.view(-1, 1).unbind(0))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        if ctx.st is None or all(g is None for g in grads):
+            return (None,) * 6
+        zero = None
+        parts = []
+        for g in grads:
+            if g is None:
+                if zero is None:
+                    zero = ctx.tri1.new_zeros(1)
+                g = zero
+            parts.append(g.reshape(1))
+        return (*_dropin_backward(ctx, torch.cat(parts)), None, None, None, None)
+
+
+# ---- the trainers' literal loop, served by ONE evaluation of the whole batch (round 4) ----------------------------
+# `for j in range(B): loss += cal_loss...(1, 1, 5, 5, p1[j:j+1], p2[j:j+1], line[j:j+1])` (rpm/Train_RPM.py:226-231,
+# dcp/Train_DCP.py:266-270, fmr/model.py:302-306) hands this module B slices of three batch tensors.  A slice knows its
+# base (Tensor._base) and its offset in it, so the FIRST call of such a loop evaluates all B samples at once with the
+# independent-sample op (bit-identical per sample to B single calls, test_batched_equals_per_sample), reads all B flag
+# rows back in its one host sync, and the calls for the other j are served from that evaluation: each returned loss is a
+# slice of ONE autograd node, so the caller's `total.backward()` runs one batched backward.  A hit needs the same base
+# OBJECTS (held weakly), unchanged version counters of all three, equal shapes / bucket range / mode and the same grad
+# mode; anything else -- and a batch whose scan saw a NaN, which the per-call path attributes to its sample -- takes the
+# per-call path.  RRL_DROPIN_BATCH=0 (or ops.DROPIN_BATCH = False) turns it off; RRL_DROPIN_BATCH_MAX bounds B (64).
+DROPIN_BATCH = os.environ.get("RRL_DROPIN_BATCH", "1") != "0"
+DROPIN_BATCH_MAX = int(os.environ.get("RRL_DROPIN_BATCH_MAX", "64"))
+_batch_cache = [None]
+dropin_batch_stats = {"evaluations": 0, "served": 0, "nan_fallbacks": 0}
+
+
+class _BatchEval:
+    __slots__ = ("bases", "key", "loss", "flags", "nan", "geo")
+
+
+def _slice_of_batch(t, last):
+    """(base, B, j, n) when t == base.view(B, n, last)[j:j+1] for a contiguous base with B >= 2, else None."""
+    b = t._base
+    if b is None or t.dim() != 3 or t.shape[0] != 1 or t.shape[2] != last or not t.is_cuda or t.dtype != torch.float32:
+        return None
+    if not (t.is_contiguous() and b.is_contiguous()):
+        return None
+    per = t.shape[1] * last
+    tot = b.numel()
+    if per == 0 or tot % per or tot // per < 2:
+        return None
+    off = t.storage_offset() - b.storage_offset()
+    if off < 0 or off % per or off // per >= tot // per:
+        return None
+    return b, tot // per, off // per, t.shape[1]
+
+
+def dropin_batch_clear():
+    """Drop the cached whole-batch evaluation (it keeps one workspace and the batch's autograd node alive)."""
+    _batch_cache[0] = None
+
+
+def _serve_from_batch(points1, points2, line, rng, mode, chunk):
+    c = _batch_cache[0]
+    b1, b2, bl = points1._base, points2._base, line._base
+    if b1 is None or b2 is None or bl is None:
+        return None
+    grad = torch.is_grad_enabled() and (b1.requires_grad or b2.requires_grad)
+    if c is not None and c.bases[0]() is b1 and c.bases[1]() is b2 and c.bases[2]() is bl:
+        # the usual call of a loop: same bases as the cached evaluation -- is it still valid, and which sample is this?
+        B, N, M, L, o1, o2, ol = c.geo
+        if c.key == (b1._version, b2._version, bl._version, rng, mode, chunk, grad) and points1.shape == (1, N, 9) \
+                and points2.shape == (1, M, 9) and line.shape == (1, L, 6) and points1.is_contiguous() \
+                and points2.is_contiguous() and line.is_contiguous():
+            j, r = divmod(points1.storage_offset() - o1, N * 9)
+            if r == 0 and 0 <= j < B and points2.storage_offset() - o2 == j * M * 9 and line.storage_offset() - ol == j * L * 6:
+                if c.nan:
+                    return None
+                dropin_batch_stats["served"] += 1
+                return c.loss[j], c.flags[4 * j:4 * j + 4]
+    import weakref
+    s1, s2, sl = _slice_of_batch(points1, 9), _slice_of_batch(points2, 9), _slice_of_batch(line, 6)
+    if s1 is None or s2 is None or sl is None:
+        return None
+    (b1, B, j, N), (b2, B2, j2, M), (bl, BL, jl, L) = s1, s2, sl
+    if not (B == B2 == BL and j == j2 == jl) or B > DROPIN_BATCH_MAX or not (b1.device == b2.device == bl.device):
+        return None
+    c = _BatchEval()
+    c.bases = (weakref.ref(b1), weakref.ref(b2), weakref.ref(bl))
+    c.key = (b1._version, b2._version, bl._version, rng, mode, chunk, grad)
+    c.geo = (B, N, M, L, b1.storage_offset(), b2.storage_offset(), bl.storage_offset())
+    c.loss = _DropinBatch.apply(b1.view(B, N, 9), b2.view(B, M, 9), bl.view(B, L, 6), rng, mode, chunk)  # B outputs
+    c.flags = _DropinLoss.flags_all
+    c.nan = bool(c.flags[3])  # one flag per launch: which sample it was is the per-call path's to say
+    if c.nan:
+        c.loss = None
+        dropin_batch_stats["nan_fallbacks"] += 1
+    dropin_batch_stats["evaluations"] += 1
+    _batch_cache[0] = c
+    if c.nan:
+        return None
+    dropin_batch_stats["served"] += 1
+    return c.loss[j], c.flags[4 * j:4 * j + 4]
 
 
 def intersection_loss_dropin(points1, points2, line, rng=(1, 1, 5, 5), pool=False, mode="cull", chunk=0):
     """(loss (G,) with a grad_fn, [nbuckets, nselected, nvalues, NaN flag] as Python ints) -- the forward of the
-    reference-signature call with its single host read-back inside (one C call).  See _DropinLoss."""
-    loss = _DropinLoss.apply(points1, points2, line, tuple(rng), pool, mode, chunk)
+    reference-signature call with its single host read-back inside (one C call).  See _DropinLoss; a call whose three
+    arguments are the [j:j+1] slices of batch tensors is served from one evaluation of the whole batch (above)."""
+    rng = tuple(rng)
+    if DROPIN_BATCH and isinstance(points1, torch.Tensor) and points1.dim() == 3 and points1.shape[0] == 1 \
+            and isinstance(points2, torch.Tensor) and isinstance(line, torch.Tensor):
+        hit = _serve_from_batch(points1, points2, line, rng, mode, chunk)
+        if hit is not None:
+            return hit
+    loss = _DropinLoss.apply(points1, points2, line, rng, pool, mode, chunk)
     return loss, _DropinLoss.flags
 
 

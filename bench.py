@@ -361,11 +361,13 @@ def main():
 
     # ---- everything below is outside the timed region -----------------------------------------
     def scan_launch_ms(mode, n):
-        """HIP events around the scan launch of an eager pass of the same step (events cannot be
-        read back from inside a replayed graph), on the launch stream."""
+        """HIP events around the scan launch, on the launch stream: of the TIMED step itself when it is issued directly
+        (ops.RegistrationStep: the events bracket the same launch the clock sees), else of an eager pass of the same
+        step (events cannot be read back from inside a replayed graph)."""
         ops.scan_timing(1)
+        own = issued == "direct" and mode == args.mode
         for _ in range(n):
-            local_step(mode)
+            direct_step() if own else local_step(mode)
         torch.cuda.synchronize()
         t = ops.scan_timing_collect()
         ops.scan_timing(0)
@@ -378,11 +380,13 @@ def main():
     if rank == 0:
         cull_ms, n_cull = scan_launch_ms(args.mode, min(args.steps, 20))
         loss_default = ops.last_state().loss.clone()
+    if do_extras:
+        local_step(args.mode)  # the autograd front end of the same op: its dR is what the variants below compare with
         fused_gR = w["R"].grad.clone()
     if do_extras and args.mode == "cull":
-        # executed work of the culled kernel: the instrumented instantiation, same inputs
+        # executed work of the culled kernel: the instrumented instantiation, same inputs, same (prepared) build
         ops.scan_counters(True)
-        local_step("cull")  # one launch: every wavefront writes its row of counters
+        (direct_step if issued == "direct" else local_step)()  # one launch: every wavefront writes its row of counters
         torch.cuda.synchronize()
         c = ops.scan_counters(False).cpu().numpy().astype(np.float64)
         exe = OPS_SPHERE * (c[0] + c[1]) + OPS_EXACT * c[3] + OPS_CAND * c[4] + OPS_FALLBACK * c[7]  # c[2] counts survivors, not tests

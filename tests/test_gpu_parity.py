@@ -439,11 +439,22 @@ def test_batched_equals_per_sample(L):
         assert one.item() == loss[b].item()
 
 
-def test_trainer_loop_over_samples(L):
+@pytest.fixture
+def per_call_dropin():
+    """the reference-signature call evaluated per call (round 3's path), not served from a whole-batch evaluation"""
+    from rrl_hip import ops
+    old, ops.DROPIN_BATCH = ops.DROPIN_BATCH, False
+    yield
+    ops.DROPIN_BATCH = old
+    ops.dropin_batch_clear()
+
+
+def test_trainer_loop_over_samples(L, per_call_dropin):
     """The reference trainers' literal pattern (rpm/Train_RPM.py:226-231): B reference-signature calls on [j:j+1]
     slices summed in Python, ONE backward at the end.  The calls lease their workspaces from a per-shape pool
     (ops._DropinLoss): every forward must keep its own state until the backward has used it, results held by the
-    caller must not alias, and a second round must reuse the pool instead of growing it."""
+    caller must not alias, and a second round must reuse the pool instead of growing it.  (Per-call evaluation:
+    ops.DROPIN_BATCH off; the batched serving of the same loop is the next test.)"""
     from rrl_hip import ops, synth
     B, N, M, Ll = 4, 700, 600, 1500
     prs = [synth.make_pair(400 + b, N, M) for b in range(B)]
@@ -479,6 +490,114 @@ def test_trainer_loop_over_samples(L):
         a = L.cal_loss_intersection_batch_whole_median_pts_lines(1, 1, 5, 5, tri1[0:1], tri2[0:1], ln[0:1], "cuda")
         b_ = L.cal_loss_intersection_batch_whole_median_pts_lines(1, 1, 5, 5, tri1[1:2], tri2[1:2], ln[1:2], "cuda")
     assert a.item() == ref_loss[0].item() and b_.item() == ref_loss[1].item()
+
+
+def test_trainer_loop_served_by_one_batch_evaluation(L):
+    """Round 4: the same literal loop, but the first call of a loop over [j:j+1] slices evaluates the WHOLE batch once
+    (ops._serve_from_batch) and the other calls are slices of that one autograd node.  Against the per-call path
+    (ops.DROPIN_BATCH off) on the same inputs: every returned loss bit for bit, None for the sample without a
+    populated bucket, gradients to the rounding of the scatter's atomics, exactly one evaluation per batch -- also for
+    out-of-order j, under no_grad, after an in-place edit between two calls (re-evaluated), with bases that do not
+    belong together (per-call path) and with a NaN sample in the batch (raises at that sample's call only)."""
+    from rrl_hip import ops, synth
+    B, N, M, Ll = 5, 600, 500, 1500
+    prs = [synth.make_pair(430 + b, N, M) for b in range(B)]
+    tri1 = cu(np.stack([p["src_tri"] for p in prs]))
+    tri2 = cu(np.stack([p["tar_tri"] for p in prs]))
+    ln = []
+    for b, p in enumerate(prs):
+        torch.manual_seed(b)
+        ln.append(L.Random_uniform_distribution_lines_batch_efficient_resample(
+            torch.tensor([[float(p["radius"])]]), torch.from_numpy(p["center"]).reshape(1, 3), Ll,
+            cu(p["src"])[None], cu(p["tar"])[None], "cuda")[0])
+    ln = torch.stack(ln)
+    ln[2] = torch.tensor([1.0, 0, 0, 0, 50, 50], device="cuda")  # sample 2: every line misses both clouds -> None
+
+    def loop(p1, t2, lines, order, batch):
+        old, ops.DROPIN_BATCH = ops.DROPIN_BATCH, batch
+        try:
+            out = {}
+            for j in order:
+                out[j] = L.cal_loss_intersection_batch_whole_median_pts_lines(1, 1, 5, 5, p1[j:j + 1], t2[j:j + 1], lines[j:j + 1], "cuda")
+            return out
+        finally:
+            ops.DROPIN_BATCH = old
+
+    def run(order, batch, lines=ln):
+        p1 = tri1.clone().requires_grad_(True)
+        out = loop(p1, tri2, lines, order, batch)
+        total = 0
+        for j in order:
+            if out[j] is not None:
+                total = total + out[j]
+        total.backward()
+        return out, p1.grad.clone(), float(total)
+
+    ops.dropin_batch_clear()
+    for order in (list(range(B)), [3, 1, 0, 4, 2], [1, 1, 3]):
+        ref, gref, tref = run(order, False)
+        ev0, sv0 = ops.dropin_batch_stats["evaluations"], ops.dropin_batch_stats["served"]
+        got, ggot, tgot = run(order, True)
+        assert ops.dropin_batch_stats["evaluations"] == ev0 + 1 and ops.dropin_batch_stats["served"] == sv0 + len(order)
+        assert tref == tgot
+        for j in set(order):
+            if ref[j] is None:
+                assert got[j] is None and j == 2
+            else:
+                assert got[j].shape == (1,) and got[j].item() == ref[j].item() and got[j].grad_fn is not None
+        np.testing.assert_allclose(ggot.cpu().numpy(), gref.cpu().numpy(), rtol=2e-5, atol=1e-9)
+        assert float(ggot[2].abs().sum()) == 0.0
+    # under no_grad: plain tensors, the same values, one evaluation
+    with torch.no_grad():
+        ev0 = ops.dropin_batch_stats["evaluations"]
+        got = loop(tri1, tri2, ln, range(B), True)
+        assert ops.dropin_batch_stats["evaluations"] == ev0 + 1
+    ref, _, _ = run(list(range(B)), False)
+    assert all((got[j] is None) == (ref[j] is None) and (got[j] is None or (got[j].item() == ref[j].item() and got[j].grad_fn is None))
+               for j in range(B))
+    # an in-place edit of a base between two calls: the cached evaluation is stale, the next call evaluates again
+    ln2 = ln.clone()
+    p1 = tri1.clone().requires_grad_(True)
+    ev0 = ops.dropin_batch_stats["evaluations"]
+    a0 = loop(p1, tri2, ln2, [0, 1], True)
+    with torch.no_grad():
+        ln2[3] = ln[4]  # (lines of another sample: still unit directions)
+    a1 = loop(p1, tri2, ln2, [3, 4], True)
+    assert ops.dropin_batch_stats["evaluations"] == ev0 + 2
+    want = loop(tri1.clone().requires_grad_(True), tri2, ln2, [0, 1, 3, 4], False)
+    for j, got_j in ((0, a0[0]), (1, a0[1]), (3, a1[3]), (4, a1[4])):
+        assert (got_j is None) == (want[j] is None) and (got_j is None or got_j.item() == want[j].item())
+    # bases that do not belong together (another batch size / another j): the per-call path, same values
+    tri2_big = torch.cat([tri2, tri2[:1]])  # B + 1 samples
+    ev0 = ops.dropin_batch_stats["evaluations"]
+    mixed = loop(tri1, tri2_big, ln, [0, 1], True)
+    assert ops.dropin_batch_stats["evaluations"] == ev0
+    old, ops.DROPIN_BATCH = ops.DROPIN_BATCH, True
+    try:
+        crossed = L.cal_loss_intersection_batch_whole_median_pts_lines(1, 1, 5, 5, tri1[0:1], tri2[1:2], ln[0:1], "cuda")
+    finally:
+        ops.DROPIN_BATCH = old
+    assert ops.dropin_batch_stats["evaluations"] == ev0
+    assert mixed[0].item() == ref[0].item() and mixed[1].item() == ref[1].item() and crossed is not None
+    # a NaN sample (non-unit direction): raises at ITS call, the others return their values
+    ln3 = ln.clone()
+    ln3[1, :, :3] *= 1.5
+    for batch in (False, True):
+        p1 = tri1.clone().requires_grad_(True)
+        old, ops.DROPIN_BATCH = ops.DROPIN_BATCH, batch
+        try:
+            vals = {}
+            for j in range(B):
+                if j == 1:
+                    with pytest.raises(ValueError):
+                        L.cal_loss_intersection_batch_whole_median_pts_lines(1, 1, 5, 5, p1[j:j + 1], tri2[j:j + 1], ln3[j:j + 1], "cuda")
+                else:
+                    vals[j] = L.cal_loss_intersection_batch_whole_median_pts_lines(1, 1, 5, 5, p1[j:j + 1], tri2[j:j + 1], ln3[j:j + 1], "cuda")
+        finally:
+            ops.DROPIN_BATCH = old
+        assert vals[0].item() == ref[0].item() and vals[3].item() == ref[3].item() and vals[2] is None
+    assert ops.dropin_batch_stats["nan_fallbacks"] >= 1
+    ops.dropin_batch_clear()
 
 
 def test_shard_payload(L):
