@@ -125,6 +125,8 @@ struct BuildArgs {
     size_t z2_vec4;
     uint4 *z3;                     // per-call state of the tiled reduce (MHIST, MCTL, MSUM; may be NULL)
     size_t z3_vec4;
+    uint32_t *z4;                  // a caller-owned buffer to clear (RrlCall::clear_ptr: the scatter target of rrl_loss_step)
+    size_t z4_words;
     float *del1, *del2;            // NaN reach of every triangle (may be NULL: not stored)
     const float *line;             // the samples' lines [B][L][6] and where their partial maxima go (may be NULL:
     float2 *lmax;                  //   the scan entry computes them itself then)
@@ -240,6 +242,7 @@ __device__ __forceinline__ void build_clear_state(const BuildArgs &a) {
     for (size_t i = me; i < a.g1_vec4; i += nthr) a.g1[i] = z;
     for (size_t i = me; i < a.z2_vec4; i += nthr) a.z2[i] = z;
     for (size_t i = me; i < a.z3_vec4; i += nthr) a.z3[i] = z;
+    for (size_t i = me; i < a.z4_words; i += nthr) a.z4[i] = 0u;  // (4-byte stores: any alignment)
 }
 
 __global__ __launch_bounds__(REC_BLK) void tri_records_kernel(const BuildArgs a) {
@@ -1480,6 +1483,8 @@ int rrl_launch_tri_build(const float *tri1, const float *tri2, void *ws, const W
     a.z2_vec4 = a.z2 ? (size_t)2 * B * 2 * SORT_CELLS * sizeof(unsigned) / 16 : 0;
     a.z3 = (uint4 *)((char *)ws + w.state_off);
     a.z3_vec4 = w.state_bytes / 16;
+    a.z4 = (uint32_t *)o.clear_ptr;
+    a.z4_words = o.clear_ptr ? o.clear_bytes / 4 : 0;
     a.del1 = w.f32(ws, RRL_WS_DEL1);
     a.del2 = w.f32(ws, RRL_WS_DEL2);
     a.zwords = nullptr; a.nzwords = 0;

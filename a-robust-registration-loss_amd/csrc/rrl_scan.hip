@@ -157,6 +157,7 @@ int rrl_tri_prepare_clouds(const float *tri1, const float *tri2, void *ws, size_
         if (rc) return rc;
         // ... and one more the tiled reduce's state (MHIST, MCTL, MSUM)
         if ((rc = rrl_fill((char *)ws + w.state_off, 0u, w.state_bytes, s))) return rc;
+        if (o.clear_ptr && (rc = rrl_fill(o.clear_ptr, 0u, o.clear_bytes, s))) return rc;
     }
     if (B == 0 || nmax == 0) return 0;
     if (sorted) return rrl_launch_tri_build(tri1, tri2, ws, w, B, N, M, clouds, xf, line, L, o, s);

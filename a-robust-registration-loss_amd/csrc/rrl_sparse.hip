@@ -1125,6 +1125,7 @@ struct TailArgs {
     const float4 *Q1, *Q2;
     const float *grad_loss, *src;
     float *gR, *gt, *payload;
+    float *grad_tri1;  // != NULL: the backward SCATTERS dL/dpoints1 [B][N][9] (rrl_loss_step) instead of summing (dR, dt)
 };
 
 // LDS-only workgroup barrier: this wavefront's LDS traffic is complete, its vector-memory loads stay in flight
@@ -1164,6 +1165,7 @@ __global__ __launch_bounds__(TAIL_LANES) void loss_tail_kernel(const TailArgs a)
     const uint32_t *__restrict__ lidc = a.lidc;
     const size_t slot0 = (size_t)b * Lp + (size_t)tile * 1024;
     const bool do_bwd = a.do_bwd != 0;  // uniform
+    const bool scatter = a.grad_tri1 != nullptr;  // uniform: gradient to the points (rrl_loss_step), not to (R, t)
 
     // ---- round 1: the sample's tile counts, histogram and bucket counts; the compact tile of "this lane's" line
     //      (lanes 0 .. 255, four per line: lane h of line r adds hit slot h's gradient, lane 0 the line's Welsch terms)
@@ -1240,7 +1242,7 @@ __global__ __launch_bounds__(TAIL_LANES) void loss_tail_kernel(const TailArgs a)
     auto request_source = [&]() {
 #pragma unroll
         for (int q = 0; q < 9; ++q) xs[q] = 0.0f;
-        if (bwd_live) {
+        if (bwd_live && !scatter) {  // (the scatter needs no source coordinates)
             const float *x = a.src + ((size_t)b * a.N + fhit) * 9;
 #pragma unroll
             for (int q = 0; q < 9; ++q) xs[q] = x[q];
@@ -1474,6 +1476,15 @@ __global__ __launch_bounds__(TAIL_LANES) void loss_tail_kernel(const TailArgs a)
             gq[1] += 2.0f * (q1.y - qy[o]) * gD;
             gq[2] += 2.0f * (q1.z - qz[o]) * gD;
         }
+        if (scatter) {  // dL/dP1[f][kk] += w_kk / 3 * dL/dq1 (loss_bwd_kernel's expression; the records launch cleared the target)
+            float *gp = a.grad_tri1 + ((size_t)b * a.N + fhit) * 9;
+#pragma unroll
+            for (int kk = 0; kk < 3; ++kk) {
+                const float wk = wq[kk] / 3.0f;
+#pragma unroll
+                for (int cc = 0; cc < 3; ++cc) atomicAdd(gp + 3 * kk + cc, wk * gq[cc]);
+            }
+        } else {
 #pragma unroll
         for (int kk = 0; kk < 3; ++kk) {
             const float wk = wq[kk] / 3.0f;  // q = mean_k(w_k P_k)
@@ -1488,10 +1499,11 @@ __global__ __launch_bounds__(TAIL_LANES) void loss_tail_kernel(const TailArgs a)
                 acc[9 + cc] += gv[cc];
             }
         }
+        }
     }
     if ((chunk + TAIL_SUBS) * TAIL_LINES >= mycnt) break;  // uniform
     }
-    if (do_bwd && wave < 4) {  // (the lines sit in the first four wavefronts)
+    if (do_bwd && !scatter && wave < 4) {  // (the lines sit in the first four wavefronts)
 #pragma unroll
         for (int q = 0; q < 12; ++q) acc[q] = wave_sum(acc[q]);
         if (lane == 0)
@@ -1501,7 +1513,7 @@ __global__ __launch_bounds__(TAIL_LANES) void loss_tail_kernel(const TailArgs a)
     __syncthreads();
     // ---- from here on wavefront 1 adds the workgroup's gradient sums and wavefront 0 does everything else by itself (its
     //      lanes see each other's LDS writes in program order: no workgroup barrier any more); the rest is done
-    if (wave == 1 && do_bwd && mycnt > 0 && lane < 12) {
+    if (wave == 1 && do_bwd && !scatter && mycnt > 0 && lane < 12) {
         const int q = lane;
         const float v = (s_red[0][q] + s_red[1][q]) + (s_red[2][q] + s_red[3][q]);
         int o = q;  // m-index (i, j) -> memory order of R
@@ -1607,6 +1619,8 @@ static bool default_deterministic();
 // reach (struct_bytes), -1 and NULL mean the process-wide default.
 RrlCall rrl_resolve_opts(const rrl_opts *p) {
     RrlCall o;
+    o.clear_ptr = nullptr;
+    o.clear_bytes = 0;
     rrl_opts v;
     memset(&v, 0, sizeof v);
     v.reduce_mode = v.deterministic = v.sort_parts = v.scan_variant = -1;
@@ -1645,6 +1659,7 @@ struct TailBwd {
     const float *grad_loss, *src;
     float *gR, *gt, *payload;
     int transpose_r;
+    float *grad_tri1;  // scatter target (rrl_loss_step) instead of (gR, gt)
 };
 
 static ReduceArgs reduce_args(void *ws, const WsLayout &w, float *loss, int B, int L, int s_m, int s_n, int e_m, int e_n,
@@ -1683,6 +1698,7 @@ static int loss_reduce_impl(void *ws, size_t ws_bytes, float *loss, int B, int N
         t.Q1 = (const float4 *)w.f32(ws, RRL_WS_Q1); t.Q2 = (const float4 *)w.f32(ws, RRL_WS_Q2);
         t.grad_loss = tb ? tb->grad_loss : nullptr; t.src = tb ? tb->src : nullptr;
         t.gR = tb ? tb->gR : nullptr; t.gt = tb ? tb->gt : nullptr; t.payload = tb ? tb->payload : nullptr;
+        t.grad_tri1 = tb ? tb->grad_tri1 : nullptr;
         hipLaunchKernelGGL(loss_tail_kernel, dim3((unsigned)nblk, (unsigned)B, TAIL_SUBS), dim3(TAIL_LANES), 0,
                            (hipStream_t)stream, t);
         RRL_LAUNCH_CHECK();
@@ -2254,7 +2270,7 @@ static int loss_forward_impl(const float *tri1, const float *tri2, const float *
         RrlRange r("K2 + K3 + K4 (single tile)");
         WsLayout w(B, N, M, L);
         if (ws_bytes < w.total) return RRL_E_WS;
-        if (tb) {  // ... and the direct backward too (rrl_registration_step)
+        if (tb && !tb->grad_tri1) {  // ... and the direct backward too (rrl_registration_step)
             SoloBwd sb;
             sb.kj = w.u8(ws, RRL_WS_KJ); sb.sel = w.i32(ws, RRL_WS_SEL); sb.nsel = w.i32(ws, RRL_WS_NSEL);
             sb.hs1 = w.i32(ws, RRL_WS_HS1); sb.bcnt = w.i32(ws, RRL_WS_BCNT); sb.info = w.i32(ws, RRL_WS_INFO);
@@ -2405,7 +2421,7 @@ extern "C" int rrl_registration_step_ex(const float *src, const float *R, const 
             if (payload && (rc = rrl_fill(payload, 0u, sizeof(float) * 14, s))) return rc;
         }
         const RrlXform xf = {src, R, t, transpose_r, 1};
-        const TailBwd tb = {grad_loss, src, gR, gt, payload, transpose_r};
+        const TailBwd tb = {grad_loss, src, gR, gt, payload, transpose_r, nullptr};
         rc = loss_forward_impl(w.f32(ws, RRL_WS_TRI1), tri2, line, ws, ws_bytes, loss, B, N, M, L, s_m, s_n, e_m, e_n, 0,
                                mode, chunk, target_ws, &xf, o, stream, &tb, &done);
         if (rc || done) return rc;
@@ -2425,6 +2441,37 @@ extern "C" int rrl_registration_step(const float *src, const float *R, const flo
                                      int chunk, const void *target_ws, void *stream) {
     return rrl_registration_step_ex(src, R, t, tri2, line, ws, ws_bytes, loss, grad_loss, gR, gt, payload, B, N, M, L,
                                     transpose_r, s_m, s_n, e_m, e_n, mode, chunk, target_ws, nullptr, stream);
+}
+
+// SURVEY 8(d)'s own definition -- T-apply + S + P + median + Welsch reduce + backward to points1.grad -- in ONE call
+// (include/rrl.h rrl_loss_step_ex): the forward of rrl_loss_forward_ex / rrl_registration_forward_ex with the scatter
+// backward of rrl_loss_backward riding in the reduce's launch where the tail kernel serves the shape (the records launch
+// clears grad_tri1 with the per-call state: 4 launches with prepared orders); elsewhere, and when grad_tri2 is wanted,
+// forward + loss_bwd_kernel.  Bit-identical loss; gradients to the rounding of the float atomics.
+extern "C" int rrl_loss_step_ex(const float *tri1, const float *R, const float *t, const float *tri2, const float *line,
+                                void *ws, size_t ws_bytes, float *loss, const float *grad_loss, float *grad_tri1,
+                                float *grad_tri2, int B, int N, int M, int L, int transpose_r, int s_m, int s_n, int e_m,
+                                int e_n, int mode, int chunk, const void *target_ws, const rrl_opts *opts, void *stream) {
+    if (!tri1 || !tri2 || !line || !ws || !loss || !grad_loss || !grad_tri1 || ((R == nullptr) != (t == nullptr))) return RRL_E_ARG;
+    if (B < 0 || N < 0 || M < 0 || L < 0) return RRL_E_ARG;
+    WsLayout w(B, N, M, L);
+    if (ws_bytes < w.total) return RRL_E_WS;
+    RrlCall o = rrl_resolve_opts(opts);
+    o.clear_ptr = grad_tri1;
+    o.clear_bytes = sizeof(float) * 9 * (size_t)B * N;
+    const int nblk = (L + 1023) / 1024;
+    const RrlXform xf = {tri1, R, t, transpose_r, 0};
+    const float *p1 = R ? w.f32(ws, RRL_WS_TRI1) : tri1;  // points1: the moved source, or the caller's triangles as given
+    const bool ride = B > 0 && L > 0 && !grad_tri2 && L > 1024 && reduce_kind(o.reduce_mode, B, nblk, 0, true) == 2;
+    const TailBwd tb = {grad_loss, nullptr, nullptr, nullptr, nullptr, 0, grad_tri1};
+    bool done = false;
+    int rc = loss_forward_impl(p1, tri2, line, ws, ws_bytes, loss, B, N, M, L, s_m, s_n, e_m, e_n, 0, mode, chunk, target_ws,
+                               R ? &xf : nullptr, o, stream, ride ? &tb : nullptr, &done);
+    if (rc || done) return rc;
+    // (grad_tri1 was cleared by the build step's first launch -- or by its fill on the unsorted path; an empty batch /
+    //  cloud launches nothing: clear here)
+    if (B == 0 || (N == 0 && M == 0)) return rrl_fill(grad_tri1, 0u, o.clear_bytes, (hipStream_t)stream);
+    return loss_backward_impl(p1, tri2, ws, ws_bytes, grad_loss, grad_tri1, grad_tri2, B, N, M, L, 0, false, stream);
 }
 
 extern "C" int rrl_registration_backward_ex(const float *src, const float *R, const float *tri2,

@@ -94,6 +94,10 @@ struct RrlCall {
     const int32_t *order1, *order2;
     unsigned long long *counters;
     long long counter_rows;
+    // (internal, not part of rrl_opts) a caller-owned buffer the build step's first launch clears along with the per-call
+    // state: the scatter target of rrl_loss_step (grad_tri1), so that no fill launch precedes the step
+    void *clear_ptr;
+    size_t clear_bytes;  // multiple of 4
     __host__ bool prepared() const { return order1 != nullptr; }
     __host__ bool target_kept() const { return order1 != nullptr && (flags & RRL_F_TARGET_KEPT); }
 };

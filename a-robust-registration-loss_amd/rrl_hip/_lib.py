@@ -30,6 +30,7 @@ _SIGS = {
     "rrl_registration_forward_ex": [_P] * 6 + [_Z, _P] + [_I] * 11 + [_P, _P, _P],
     "rrl_registration_backward_ex": [_P] * 4 + [_Z] + [_P] * 6 + [_I] * 5 + [_P, _P],
     "rrl_registration_step_ex": [_P] * 6 + [_Z] + [_P] * 5 + [_I] * 11 + [_P, _P, _P],
+    "rrl_loss_step_ex": [_P] * 6 + [_Z] + [_P] * 4 + [_I] * 11 + [_P, _P, _P],
     "rrl_cloud_order": [_P, _P, _P, _Z, _I, _I, _P],
     "rrl_tri_prepare_ex": [_P, _P, _P, _Z, _I, _I, _I, _I, _P, _P],
     "rrl_line_tri_scan_ex": [_P, _P, _Z] + [_I] * 6 + [_P, _P],

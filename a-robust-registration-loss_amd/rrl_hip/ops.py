@@ -839,6 +839,73 @@ class RegistrationStep:
         return self.st.loss.view(-1), self.gR, self.gt, self.payload, self.st.info
 
 
+class LossStep:
+    """SURVEY 8(d)'s definition by direct issue (round 4): rigid apply of the source + loss + backward to points1.grad
+    (B, N, 9) as ONE C call (rrl_loss_step_ex) on buffers allocated once, no autograd node, no graph -- the drop-in
+    chain `tri = rigid_apply(src, R, t); loss = intersection_loss(tri, tar, line); loss.backward()` without its host cost:
+
+        step = ops.LossStep(src_tri, tar_tri, L)                   # once per shape (orders computed here)
+        loss, g_points1, info = step(R, t, lines)                  # every iteration; g_points1 = dL/d(moved triangles)
+        moved_tri.backward(g_points1)                              # hand it to whatever produced the pose
+
+    R = t = None evaluates the triangles as given (no transform).  Same numbers as the autograd chain: loss bit for bit,
+    gradient to the rounding of the scatter's float atomics.  prepared / src_order / tar_order as RegistrationStep."""
+
+    def __init__(self, src_tri, tar_tri, n_lines, rng=(1, 1, 5, 5), transpose_r=True, mode="cull", chunk=0,
+                 prepared=None, src_order=None, tar_order=None):
+        dev = _home(src_tri, tar_tri)
+        self.dev = dev
+        self.src = _prep(src_tri, "src_tri", 9, dev)
+        self.tar = _prep(tar_tri, "tar_tri", 9, dev)
+        if self.src.dim() != 3 or self.tar.dim() != 3 or self.src.shape[0] != self.tar.shape[0]:
+            raise ValueError("src_tri/tar_tri must be (B, n, 9) with the same B")
+        B, N, _ = self.src.shape
+        M, L = self.tar.shape[1], int(n_lines)
+        if B == 0 or L <= 0:
+            raise ValueError("LossStep needs a non-empty batch and line set")
+        self.dims = (B, N, M, L)
+        self.rng = _check_range(rng)
+        self.tr, self.mode, self.chunk = int(bool(transpose_r)), _MODES[mode], int(chunk)
+        self.st = LossState(B, N, M, L, B, dev)
+        self.ones = torch.ones(B, dtype=torch.float32, device=dev)
+        self.grad = torch.empty(B, N, 9, dtype=torch.float32, device=dev)
+        if prepared is None:
+            prepared = os.environ.get("RRL_PREPARED", "1") != "0"
+        self.prepared = bool(prepared) and mode == "cull" and max(N, M) <= 65536
+        self._kept_key = None
+        self._optr = self._optr_kept = None
+        if self.prepared:
+            self.order1 = _check_order(src_order, B, N, dev, "src_order") if src_order is not None else cloud_order(self.src)
+            self.order2 = _check_order(tar_order, B, M, dev, "tar_order") if tar_order is not None else cloud_order(self.tar)
+            self._opts = make_opts(order1=self.order1, order2=self.order2)
+            self._opts_kept = make_opts(order1=self.order1, order2=self.order2, target_kept=True)
+            self._optr, self._optr_kept = ctypes.byref(self._opts), ctypes.byref(self._opts_kept)
+        self._lib = _lib.load()
+
+    def __call__(self, R, t, line, grad_loss=None):
+        B, N, M, L = self.dims
+        dev = self.dev
+        Rm = _prep(R, "R", None, dev) if R is not None else None
+        tv = _prep(t, "t", None, dev) if t is not None else None
+        ln = _prep(line, "line", 6, dev)
+        if (Rm is None) != (tv is None) or (Rm is not None and (Rm.numel() != B * 9 or tv.numel() != B * 3)) \
+                or tuple(ln.shape) != (B, L, 6):
+            raise ValueError("R (B,3,3) and t (B,3) (or both None), line (B, L, 6) expected")
+        g = self.ones if grad_loss is None else _prep(grad_loss, "grad_loss", None, dev)
+        op = None
+        if self.prepared:
+            key = (self.tar.data_ptr(), self.tar._version)
+            op = self._optr_kept if key == self._kept_key else self._optr
+            self._kept_key = key
+        with _guard(dev):
+            check(self._lib.rrl_loss_step_ex(_p(self.src), _p(Rm), _p(tv), _p(self.tar), _p(ln), _p(self.st.ws),
+                                             self.st.nbytes, _p(self.st.loss), _p(g), _p(self.grad), None, B, N, M, L,
+                                             self.tr, *self.rng, self.mode, self.chunk, None, op, _stream(dev)),
+                  "rrl_loss_step")
+        _IntersectionLoss.last_state = self.st
+        return self.st.loss.view(-1), self.grad, self.st.info
+
+
 def set_deterministic(on):
     """Bit-reproducible direct backward of registration_loss (fixed-order partial sums, one more tiny
     launch) instead of float atomics; include/rrl.h rrl_set_deterministic.  Process-wide."""

@@ -15,9 +15,11 @@ resident in HBM before the timed region.  pairs per step = B * L * 3 * (N + M) p
 ~1 %; value = all ranks' pairs / max time over ranks.
 
 Measured in the same run, outside the timed region, and printed in the same JSON line:
-  * `value_8d` / `ms_per_step_8d` (= `variants.points1_grad`): SURVEY §8(d)'s definition through the
-    DROP-IN callables chained by autograd -- rigid apply -> loss -> backward to points1.grad (B, N, 9)
-    and on to (dR, dT), as a hipGraph replay; `value` itself is the fused training op (config.workload);
+  * `value_8d` / `ms_per_step_8d` (= `variants.points1_grad_direct`): SURVEY §8(d)'s definition -- rigid apply +
+    loss + backward to points1.grad (B, N, 9) -- by direct issue, one C call per step (ops.LossStep ->
+    rrl_loss_step_ex); `variants.points1_grad`: the same through the DROP-IN callables chained by autograd (rigid
+    apply -> loss -> backward to points1.grad and on to (dR, dT)) as a hipGraph replay; `value` itself is the fused
+    training op (config.workload);
   * `variants.dropin_loop`: the reference trainers' LITERAL pattern (rpm/Train_RPM.py:226-231) --
     `for j in range(B): loss += cal_loss_intersection_batch_whole_median_pts_lines(1, 1, 5, 5, p1[j:j+1], ...)`
     then one `.backward()` -- issued eagerly, one host read-back per call as the reference's contract demands;
@@ -447,6 +449,27 @@ def main():
             "loss_sum": float(keep["loss"].sum()),
             "dR_max_rel_diff_vs_fused": float((w["R"].grad - fused_gR).abs().max() / fused_gR.abs().max())}
 
+        # SURVEY 8(d) by DIRECT ISSUE: rigid apply + S + P + median + Welsch + backward to points1.grad (B, N, 9) as one C
+        # call per step (ops.LossStep -> rrl_loss_step_ex: the scatter rides in the reduce's launch), no autograd, no graph
+        ls = ops.LossStep(w["tri1"], w["tri2"], L, transpose_r=True, mode=args.mode, prepared=prepared,
+                          src_order=order1, tar_order=order2)
+        Rd, Td = w["R"].detach(), w["T"].detach()
+        for _ in range(10):
+            lout = ls(Rd, Td, w["lines"])
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            lout = ls(Rd, Td, w["lines"])
+        torch.cuda.synchronize()
+        lms = (time.perf_counter() - t1) / args.steps * 1e3
+        variants["points1_grad_direct"] = {
+            "ms_per_step": lms, "value": pairs_step / (lms * 1e-3), "unit": "point-pairs/s (this rank)",
+            "what": "SURVEY 8(d) as defined: rigid apply of the source + loss forward + backward to points1.grad (B,N,9), "
+                    "ONE C call per step (ops.LossStep -> rrl_loss_step_ex; 4 launches with prepared orders), direct issue",
+            "loss_bit_identical_to_fused_op": bool(torch.equal(lout[0], loss_default)),
+            "points1_grad_nonzero_rows": int((lout[1].abs().sum(-1) > 0).sum()),
+            "points1_grad_max_rel_diff_vs_autograd_chain": float((lout[1] - g1).abs().max() / g1.abs().max())}
+
         # the reference trainers' literal call pattern (rpm/Train_RPM.py:204-231, dcp/Train_DCP.py:266-270,
         # fmr/model.py:302-306): transform once, then one reference-signature call per sample, summed in Python,
         # one backward.  Eager by nature: every call reads its flags back (None / NaN are host-side decisions).
@@ -623,12 +646,14 @@ def main():
                                      "rccl": evidence, "process_group": dist.is_initialized(),
                                      "backend": dist.get_backend() if dist.is_initialized() else None,
                                      "warmup_ms_per_step": choice_note}},
-            "value_8d": variants.get("points1_grad", {}).get("value"),
-            "ms_per_step_8d": variants.get("points1_grad", {}).get("ms_per_step"),
+            "value_8d": variants.get("points1_grad_direct", variants.get("points1_grad", {})).get("value"),
+            "ms_per_step_8d": variants.get("points1_grad_direct", variants.get("points1_grad", {})).get("ms_per_step"),
             "value_is": "the fused training op (config.workload): rigid apply of the source + loss + backward to (dR, dT), "
-                        "dense-equivalent pairs; value_8d / ms_per_step_8d = SURVEY section 8(d) through the drop-in "
-                        "callables with points1.grad (B, N, 9) materialised (variants.points1_grad); variants.dropin_loop = "
-                        "the reference trainers' literal per-sample loop",
+                        "dense-equivalent pairs; value_8d / ms_per_step_8d = SURVEY section 8(d) as defined (rigid apply + loss "
+                        "+ backward to points1.grad (B, N, 9)) by direct issue, one C call per step "
+                        "(variants.points1_grad_direct); variants.points1_grad = the same through the drop-in callables "
+                        "chained by autograd, on to (dR, dT), as a hipGraph replay; variants.dropin_loop = the reference "
+                        "trainers' literal per-sample loop",
             "roofline": roofline,
             "variants": variants,
             "extras": extras,

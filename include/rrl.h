@@ -277,6 +277,22 @@ int rrl_registration_step_ex(const float *src, const float *R, const float *t, c
                              int s_m, int s_n, int e_m, int e_n, int mode, int chunk, const void *target_ws,
                              const rrl_opts *opts, void *stream);
 
+/* SURVEY 8(d) by direct issue: forward + backward to points1.grad in ONE call -- what
+ * `loss = cal_loss_intersection_batch_whole_median_pts_lines(...); loss.backward()` delivers through autograd
+ * (code/loss.py:170-232: points1.grad (B, N, 9)), with the rigid apply of the call sites in front when R, t are given
+ * (code/loss.py:458-463, rpm/Train_RPM.py:205-212): points1 = tri1 R + t (x R^T + t when transpose_r), kept in the
+ * workspace field TRI1; R == t == NULL: points1 = tri1 as given.  grad_loss [B] = dL/dloss (usually ones),
+ * grad_tri1 [B][N][9] = dL/dpoints1 -- cleared by the call's first launch, accumulated by float atomics like
+ * rrl_loss_backward --, grad_tri2 [B][M][9] or NULL.  Where the tail kernel serves the shape (2 .. 16 line tiles,
+ * B x tiles <= 128) and grad_tri2 == NULL the scatter rides in the reduce's launch: 4 launches per step with prepared
+ * orders (opts), 5 without; otherwise forward + the scatter kernel of rrl_loss_backward.  Loss, median, bucket sums
+ * bit-identical to rrl_loss_forward / rrl_registration_forward; gradients equal rrl_loss_backward's to the rounding of
+ * the atomics.  pool semantics: independent samples (pool = 0). */
+int rrl_loss_step_ex(const float *tri1, const float *R, const float *t, const float *tri2, const float *line,
+                     void *ws, size_t ws_bytes, float *loss, const float *grad_loss, float *grad_tri1,
+                     float *grad_tri2, int B, int N, int M, int L, int transpose_r, int s_m, int s_n, int e_m,
+                     int e_n, int mode, int chunk, const void *target_ws, const rrl_opts *opts, void *stream);
+
 /* ---- the four forward stages, individually (tests, profiling) ------------------------- */
 
 /* K1': prepared triangles for both clouds + zeroing of the per-call state.

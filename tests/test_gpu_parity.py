@@ -1827,6 +1827,48 @@ def test_step_in_one_call_at_the_bench_shape(L):
     assert float(res[True][4][1]) == 8.0 and int(res[True][2][:, 1].min()) > 500
 
 
+@pytest.mark.parametrize("B,n,m,nl,with_pose,prepared", [
+    (2, 1200, 1000, 6000, True, True), (2, 1200, 1000, 6000, True, False), (3, 700, 900, 3000, False, True),
+    (1, 900, 800, 800, True, True), (20, 300, 260, 8000, True, True), (1, 5000, 4100, 2500, True, True)])
+def test_loss_step_equals_the_autograd_chain(L, B, n, m, nl, with_pose, prepared):
+    """rrl_loss_step_ex (ops.LossStep): SURVEY 8(d)'s definition -- rigid apply + loss + backward to points1.grad -- in one
+    C call.  Against the drop-in autograd chain rigid_apply -> intersection_loss -> backward: loss / median / info /
+    bucket sums bit for bit, points1.grad to the rounding of the scatter's float atomics (1e-6 of the largest entry),
+    the same rows non-zero.  Shapes: the tail kernel carrying the scatter (2 .. 16 tiles), a single tile of lines, a
+    grid beyond the tail kernel's (B x tiles > 128), a chunked large cloud; without a pose (R = t = None); cold and
+    prepared builds; a non-unit dL/dloss; repeated calls (the records launch clears the gradient each time)."""
+    from rrl_hip import ops, synth
+    from LieAlgebra import se3
+    prs = [synth.make_pair(500 + b, n, m) for b in range(B)]
+    src, tar = cu(np.stack([p["src_tri"] for p in prs])), cu(np.stack([p["tar_tri"] for p in prs]))
+    ln = []
+    for b, p in enumerate(prs):
+        torch.manual_seed(b)
+        ln.append(L.Random_uniform_distribution_lines_batch_efficient_resample(
+            torch.tensor([[float(p["radius"])]]), torch.from_numpy(p["center"]).reshape(1, 3), nl, cu(p["src"])[None],
+            cu(p["tar"])[None], "cuda")[0])
+    ln = torch.stack(ln)
+    gen = torch.Generator().manual_seed(11)
+    R, t = (x.cuda().contiguous() for x in se3.exp3(0.03 * torch.randn(B, 6, generator=gen)))
+    gl = (0.5 + torch.rand(B, generator=gen)).cuda()
+    step = ops.LossStep(src, tar, nl, prepared=prepared)
+    for rnd, g in enumerate((None, gl, gl)):
+        tri = (ops.rigid_apply(src.reshape(B, -1, 3), R, t, transpose_r=True).reshape(B, n, 9) if with_pose else src.clone()).detach().requires_grad_(True)
+        loss, info, _ = ops.intersection_loss(tri, tar, ln)
+        ref_st = ops.last_state()
+        torch.autograd.backward([loss], [g if g is not None else torch.ones_like(loss)])
+        out = step(R if with_pose else None, t if with_pose else None, ln, grad_loss=g)
+        torch.cuda.synchronize()
+        assert torch.equal(out[0], loss.detach()) and torch.equal(out[2], info)
+        assert torch.equal(step.st.med, ref_st.med) and torch.equal(step.st.bsum, ref_st.bsum)
+        a, b_ = tri.grad, out[1]
+        assert torch.equal(a.abs().sum(-1) > 0, b_.abs().sum(-1) > 0)
+        np.testing.assert_allclose(b_.cpu().numpy(), a.cpu().numpy(), rtol=2e-5, atol=1e-6 * float(a.abs().max()))
+        if with_pose:
+            assert torch.equal(step.st.tri1t, tri.detach())
+    assert int(out[2][:, 1].min()) > 0
+
+
 def test_fused_registration_op(L):
     """rrl_registration_forward/backward == rigid apply + loss + rigid backward, incl. payload."""
     from rrl_hip import ops
