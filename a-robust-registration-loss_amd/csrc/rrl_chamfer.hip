@@ -130,6 +130,49 @@ __global__ __launch_bounds__(256) void pts_records_kernel(const float *__restric
     }
 }
 
+// Prepared point clouds (round 4; include/rrl.h rrl_chamfer_tree_fwd_ex, order_x / order_y from rrl_cloud_order on the
+// same clouds in any rigid pose): the sort leaves the call.  One lane per SORTED position gathers its point, writes the
+// (x, y, z, original index) record there and the wavefront -- one supergroup -- refits its 13 tree nodes (wave_tree,
+// rrl_tree.h: the nodes tri_sort_kernel<4, true> derives from the same sorted records); slot 7 of the workgroup's
+// partial row = "saw a NaN coordinate" as pts_records_kernel leaves it; the walk's arrival counters are cleared here.
+__global__ __launch_bounds__(256) void pts_records_sorted_kernel(const float *__restrict__ x, const float *__restrict__ y,
+                                                                 const int32_t *__restrict__ order1, const int32_t *__restrict__ order2,
+                                                                 float4 *__restrict__ p0s1, float4 *__restrict__ p0s2,
+                                                                 int32_t *__restrict__ idx1, int32_t *__restrict__ idx2,
+                                                                 float4 *__restrict__ grp1, float4 *__restrict__ grp2,
+                                                                 float *__restrict__ apart, uint32_t *__restrict__ zwords, int nzwords,
+                                                                 int B, int N, int M, int nblk) {
+    __shared__ float red[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cloud = blockIdx.z, b = blockIdx.y;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)
+        for (int i = tid; i < nzwords; i += 256) zwords[i] = 0u;
+    const int n = cloud ? M : N;
+    const int npad = (n + SGT - 1) / SGT * SGT;
+    if ((int)blockIdx.x * 256 >= npad) return;  // uniform
+    const int s_ = blockIdx.x * 256 + tid;
+    const bool valid = s_ < n;
+    float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
+    int f = 0;
+    if (valid) {
+        f = (cloud ? order2 : order1)[(size_t)b * npad + s_];
+        f = min(max(f, 0), n - 1);  // memory safety only: the order must be a permutation of [0, n)
+        const float *p = (cloud ? y : x) + ((size_t)b * n + f) * 3;
+        c0 = p[0]; c1 = p[1]; c2 = p[2];
+    }
+    if (s_ - lane < npad) {  // wave-uniform: this wavefront holds a supergroup
+        (cloud ? p0s2 : p0s1)[(size_t)b * npad + s_] = valid ? make_float4(c0, c1, c2, __int_as_float(f)) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        (cloud ? idx2 : idx1)[(size_t)b * npad + s_] = f;
+        wave_tree(c0, c1, c2, __int_as_float(f), valid, lane, (cloud ? grp2 : grp1) + ((size_t)b * (npad / SGT) + (s_ - lane) / SGT) * NODE);
+    }
+    const bool bad = valid && ((c0 != c0) || (c1 != c1) || (c2 != c2));
+    const float anybad = __any(bad) ? 1.0f : 0.0f;
+    if (lane == 0) red[wave] = anybad;
+    __syncthreads();
+    if (tid == 0 && (int)blockIdx.x < nblk)
+        apart[(((size_t)cloud * B + b) * nblk + blockIdx.x) * 8 + 7] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
 #define LB_SCALE 0.9999f  // squared distances to node centres are shrunk: evaluation error of the bound (~1e-6)
 
 struct NNWave {
@@ -507,8 +550,11 @@ extern "C" int rrl_chamfer_counters(uint64_t *dev_counters, long long rows) {
 }
 
 // best_x [B][N], best_y [B][M]: u64 keys, every entry written exactly once (no initialisation needed).
-extern "C" int rrl_chamfer_tree_fwd(const float *x, const float *y, void *ws, size_t ws_bytes, uint64_t *best_x,
-                                    uint64_t *best_y, float *value, int B, int N, int M, void *stream) {
+extern "C" int rrl_chamfer_tree_fwd_ex(const float *x, const float *y, void *ws, size_t ws_bytes, uint64_t *best_x,
+                                       uint64_t *best_y, float *value, int B, int N, int M, const int32_t *order_x,
+                                       const int32_t *order_y, uint64_t *counters, long long counter_rows, void *stream) {
+    unsigned long long *const cnt_buf = (unsigned long long *)counters;  // per-call counter table (NULL: the plain kernel)
+    const long long cnt_rows = counters ? counter_rows : 0;
     if (!x || !y || !ws || !best_x || !best_y || !value || B <= 0 || N <= 0 || M <= 0) return RRL_E_ARG;
     if ((N > M ? N : M) > rrl_sort_capacity() || B > 32767) return RRL_E_ARG;
     const ChamLayout L(B, N, M);
@@ -517,16 +563,25 @@ extern "C" int rrl_chamfer_tree_fwd(const float *x, const float *y, void *ws, si
     char *w = (char *)ws;
     const int nmax = N > M ? N : M;
     const bool small = nmax <= 4096;  // the sort kernel reads the points itself: no records launch
+    int rc = 0;
+    if (order_x && order_y) {  // prepared clouds: records at their sorted positions + tree refit, no sort
+        const int npadmax = (nmax + SGT - 1) / SGT * SGT;
+        hipLaunchKernelGGL(pts_records_sorted_kernel, dim3((unsigned)((npadmax + 255) / 256), (unsigned)B, 2u), dim3(256), 0, s, x, y,
+                           order_x, order_y, (float4 *)(w + L.p0s1), (float4 *)(w + L.p0s2), (int32_t *)(w + L.idx1),
+                           (int32_t *)(w + L.idx2), (float4 *)(w + L.grp1), (float4 *)(w + L.grp2), (float *)(w + L.apart),
+                           (uint32_t *)(w + L.ctrl), (int)(L.ctrl_bytes / 4), B, N, M, L.nblk);
+    } else {
     if (!small)
         hipLaunchKernelGGL(pts_records_kernel, dim3((unsigned)((nmax + 255) / 256), (unsigned)B, 2u), dim3(256), 0, s, x,
                            y, (float4 *)(w + L.crec1), (float4 *)(w + L.crec2), (float *)(w + L.apart),
                            (uint4 *)(w + L.histg), (L.total - L.histg) / 16, B, N, M, L.nblk);
-    int rc = rrl_launch_cloud_sort(small ? x : nullptr, small ? y : nullptr, (float4 *)(w + L.crec1), (float4 *)(w + L.crec2), (float *)(w + L.apart), L.nblk,
+    rc = rrl_launch_cloud_sort(small ? x : nullptr, small ? y : nullptr, (float4 *)(w + L.crec1), (float4 *)(w + L.crec2), (float *)(w + L.apart), L.nblk,
                                    (float4 *)(w + L.p0s1), (float4 *)(w + L.p0s2), (int32_t *)(w + L.idx1),
                                    (int32_t *)(w + L.idx2), (float4 *)(w + L.grp1), (float4 *)(w + L.grp2),
                                    (uint32_t *)(w + L.pmax), (unsigned *)(w + L.histg),
                                    small ? (uint32_t *)(w + L.ctrl) : nullptr, (int)(L.ctrl_bytes / 4),  // (large clouds: cleared by pts_records_kernel)
                                    B, N, M, s);
+    }
     if (rc) return rc;
     const int nsgmax = (nmax + SGT - 1) / SGT;
     const ChamTick tick = {(uint32_t *)(w + L.ctrl), (uint32_t *)(w + L.ctrl) + 32, 64, 32};
@@ -535,14 +590,19 @@ extern "C" int rrl_chamfer_tree_fwd(const float *x, const float *y, void *ws, si
                        s, (const float4 *)(w + L.p0s1), (const float4 *)(w + L.p0s2),                            \
                        (const float4 *)(w + L.grp1), (const float4 *)(w + L.grp2), (const float *)(w + L.apart),  \
                        L.nblk, (unsigned long long *)best_x, (unsigned long long *)best_y,                       \
-                       (double *)(w + L.partial), B, N, M, g_cham_counters, g_cham_counter_rows, (const int32_t *)nullptr, \
+                       (double *)(w + L.partial), B, N, M, cnt_buf, cnt_rows, (const int32_t *)nullptr, \
                        (const int32_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr, tick,      \
                        (double *)(w + L.gpart), value, (double)B * (double)(N + M))
-    if (g_cham_counters) RRL_NN_LAUNCH(true);
+    if (cnt_buf) RRL_NN_LAUNCH(true);
     else RRL_NN_LAUNCH(false);
 #undef RRL_NN_LAUNCH
     RRL_LAUNCH_CHECK();
     return 0;
+}
+extern "C" int rrl_chamfer_tree_fwd(const float *x, const float *y, void *ws, size_t ws_bytes, uint64_t *best_x,
+                                    uint64_t *best_y, float *value, int B, int N, int M, void *stream) {
+    return rrl_chamfer_tree_fwd_ex(x, y, ws, ws_bytes, best_x, best_y, value, B, N, M, nullptr, nullptr,
+                                   (uint64_t *)g_cham_counters, g_cham_counter_rows, stream);
 }
 
 // Chamfer between the two clouds of a loss evaluation WITHOUT sorting them again (include/rrl.h): the loss
@@ -553,9 +613,11 @@ extern "C" int rrl_chamfer_tree_fwd(const float *x, const float *y, void *ws, si
 //   the same one, or the `target_ws` the evaluation was carried over from (rrl_loss_forward_cached).
 // The tree radii include the triangles' thresholds (looser bounds, same minima).  Keys and value are those of
 // rrl_chamfer_fwd on (P0 of cloud 1, P0 of cloud 2); a non-finite or overflowing coordinate gives NaN.
-extern "C" int rrl_chamfer_from_loss(void *ws_src, const void *ws_tar, size_t loss_ws_bytes, int B, int N, int M,
-                                     int L, void *ws, size_t ws_bytes, uint64_t *best_x, uint64_t *best_y,
-                                     float *value, void *stream) {
+extern "C" int rrl_chamfer_from_loss_ex(void *ws_src, const void *ws_tar, size_t loss_ws_bytes, int B, int N, int M,
+                                        int L, void *ws, size_t ws_bytes, uint64_t *best_x, uint64_t *best_y,
+                                        float *value, uint64_t *counters, long long counter_rows, void *stream) {
+    unsigned long long *const cnt_buf = (unsigned long long *)counters;
+    const long long cnt_rows = counters ? counter_rows : 0;
     if (!ws_src || !ws_tar || !ws || !best_x || !best_y || !value || B <= 0 || N <= 0 || M <= 0 || L < 0) return RRL_E_ARG;
     if ((N > M ? N : M) > rrl_sort_capacity() || B > 32767) return RRL_E_ARG;  // larger clouds are not sorted by the loss
     const WsLayout lw(B, N, M, L);
@@ -574,13 +636,19 @@ extern "C" int rrl_chamfer_from_loss(void *ws_src, const void *ws_tar, size_t lo
                        s, (const float4 *)lw.f32(ws_src, RRL_WS_P0S1), (const float4 *)lw.f32(ws_tar, RRL_WS_P0S2), \
                        (const float4 *)lw.f32(ws_src, RRL_WS_GRP1), (const float4 *)lw.f32(ws_tar, RRL_WS_GRP2),  \
                        (const float *)nullptr, 0, (unsigned long long *)best_x, (unsigned long long *)best_y,    \
-                       (double *)(w + C.partial), B, N, M, g_cham_counters, g_cham_counter_rows, lw.i32(ws_src, RRL_WS_IDX1), \
+                       (double *)(w + C.partial), B, N, M, cnt_buf, cnt_rows, lw.i32(ws_src, RRL_WS_IDX1), \
                        lw.i32(ws_tar, RRL_WS_IDX2), (const uint32_t *)lw.i32(ws_src, RRL_WS_PMAX),              \
                        (const uint32_t *)lw.i32(ws_tar, RRL_WS_PMAX) + B, tick, (double *)(w + C.gpart), value,  \
                        (double)B * (double)(N + M))
-    if (g_cham_counters) RRL_NN_LAUNCH(true);
+    if (cnt_buf) RRL_NN_LAUNCH(true);
     else RRL_NN_LAUNCH(false);
 #undef RRL_NN_LAUNCH
     RRL_LAUNCH_CHECK();
     return 0;
+}
+extern "C" int rrl_chamfer_from_loss(void *ws_src, const void *ws_tar, size_t loss_ws_bytes, int B, int N, int M,
+                                     int L, void *ws, size_t ws_bytes, uint64_t *best_x, uint64_t *best_y,
+                                     float *value, void *stream) {
+    return rrl_chamfer_from_loss_ex(ws_src, ws_tar, loss_ws_bytes, B, N, M, L, ws, ws_bytes, best_x, best_y, value,
+                                    (uint64_t *)g_cham_counters, g_cham_counter_rows, stream);
 }

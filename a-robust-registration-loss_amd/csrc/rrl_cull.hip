@@ -301,60 +301,6 @@ __global__ __launch_bounds__(REC_BLK) void tri_records_kernel(const BuildArgs a)
 // PMAX (max |P|^2 per cloud and sample) is not reduced here -- that would take a hand-over between workgroups of
 // this launch --: the scan reduces the <= n / 256 partial rows (APART) in its prologue, next to the line maxima.
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ float xrow_min(float v) {  // rows of 16 already reduced: combine lanes 0, 16, 32, 48
-    const int b = __float_as_int(v);
-    return fminf(fminf(__int_as_float(__builtin_amdgcn_readlane(b, 0)), __int_as_float(__builtin_amdgcn_readlane(b, 16))),
-                 fminf(__int_as_float(__builtin_amdgcn_readlane(b, 32)), __int_as_float(__builtin_amdgcn_readlane(b, 48))));
-}
-__device__ __forceinline__ float xrow_max(float v) {
-    const int b = __float_as_int(v);
-    return fmaxf(fmaxf(__int_as_float(__builtin_amdgcn_readlane(b, 0)), __int_as_float(__builtin_amdgcn_readlane(b, 16))),
-                 fmaxf(__int_as_float(__builtin_amdgcn_readlane(b, 32)), __int_as_float(__builtin_amdgcn_readlane(b, 48))));
-}
-
-// The 13 tree nodes of ONE supergroup by the wavefront whose lanes hold its 64 sorted records (valid: a real record).
-// Expressions and association as in half_tree (rrl_tree.h): centre = mid-point of the node's AABB, rho^2 = max squared
-// distance of its records, thr_max = sqrt(max thr2) (1 + 1e-6): min / max are exact, so the nodes are bit-identical.
-__device__ __forceinline__ void wave_tree(float px, float py, float pz, float thr2, bool valid, int lane, float4 *__restrict__ node) {
-    float lo[3] = {valid ? px : INFINITY, valid ? py : INFINITY, valid ? pz : INFINITY};
-    float hi[3] = {valid ? px : -INFINITY, valid ? py : -INFINITY, valid ? pz : -INFINITY};
-    float tm2 = valid ? thr2 : 0.0f, any = valid ? 1.0f : 0.0f;
-    auto dist2 = [&](float cx, float cy, float cz) {
-        const float ex = px - cx, ey = py - cy, ez = pz - cz;
-        const float e2 = ex * ex + ey * ey + ez * ez;
-        return valid ? e2 : 0.0f;
-    };
-#pragma unroll
-    for (int c = 0; c < 3; ++c) { OCT_MIN(lo[c]); OCT_MAX(hi[c]); }
-    OCT_MAX(tm2);
-    OCT_MAX(any);
-    float tm = sqrtf(tm2) * 1.000001f;
-    {   // the half of 8
-        const float cx = 0.5f * lo[0] + 0.5f * hi[0], cy = 0.5f * lo[1] + 0.5f * hi[1], cz = 0.5f * lo[2] + 0.5f * hi[2];
-        float d2 = dist2(cx, cy, cz);
-        OCT_MAX(d2);
-        if ((lane & 7) == 0) node[5 + (lane >> 3)] = finish_sphere(cx, cy, cz, d2, tm, any > 0.0f);
-    }
-#pragma unroll
-    for (int c = 0; c < 3; ++c) { lo[c] = fminf(lo[c], RRL_DPP_F(lo[c], 0x140)); hi[c] = fmaxf(hi[c], RRL_DPP_F(hi[c], 0x140)); }
-    tm = fmaxf(tm, RRL_DPP_F(tm, 0x140));
-    any = fmaxf(any, RRL_DPP_F(any, 0x140));
-    {   // the group of 16 (one DPP row)
-        const float cx = 0.5f * lo[0] + 0.5f * hi[0], cy = 0.5f * lo[1] + 0.5f * hi[1], cz = 0.5f * lo[2] + 0.5f * hi[2];
-        const float d2 = row16_max(dist2(cx, cy, cz));
-        if ((lane & 15) == 0) node[1 + (lane >> 4)] = finish_sphere(cx, cy, cz, d2, tm, any > 0.0f);
-    }
-#pragma unroll
-    for (int c = 0; c < 3; ++c) { lo[c] = xrow_min(lo[c]); hi[c] = xrow_max(hi[c]); }
-    tm = xrow_max(tm);
-    any = xrow_max(any);
-    {   // the supergroup
-        const float cx = 0.5f * lo[0] + 0.5f * hi[0], cy = 0.5f * lo[1] + 0.5f * hi[1], cz = 0.5f * lo[2] + 0.5f * hi[2];
-        const float d2 = wave_max(dist2(cx, cy, cz));
-        if (lane == 0) node[0] = finish_sphere(cx, cy, cz, d2, tm, any > 0.0f);
-    }
-}
-
 __global__ __launch_bounds__(REC_BLK) void tri_records_sorted_kernel(const BuildArgs a, const int32_t *__restrict__ order1,
                                                                       const int32_t *__restrict__ order2) {
     __shared__ float red[REC_BLK / 64][8];

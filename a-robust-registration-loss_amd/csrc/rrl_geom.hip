@@ -1329,3 +1329,25 @@ extern "C" int rrl_shard_payload(const float *loss, const void *ws, size_t ws_by
 extern "C" const char *rrl_version(void) {
     return sizeof(RRL_BUILD_FLAGS) > 1 ? "rrl_hip 0.3 (gfx950) [" RRL_BUILD_FLAGS "]" : "rrl_hip 0.3 (gfx950)";
 }
+
+// ---------------------------------------------------------------------------------------
+// Test hook (include/rrl.h rrl_debug_occupy): a filler launch that HOLDS compute-unit slots -- `workgroups` x `lanes`
+// threads spin until the 100 MHz wall clock has advanced by `ticks` -- so that tests can run the library's in-launch
+// hand-offs (the exchange reduce's bounded spins) while another stream or process occupies most of the device.
+// ---------------------------------------------------------------------------------------
+__global__ void occupy_kernel(long long ticks, unsigned *sink) {
+    const long long t0 = (long long)wall_clock64();
+    unsigned spins = 0;
+    while ((long long)wall_clock64() - t0 < ticks) {
+        __builtin_amdgcn_s_sleep(8);
+        ++spins;
+    }
+    if (sink && spins == 0xffffffffu) sink[0] = spins;  // (keeps the loop observable)
+}
+extern "C" int rrl_debug_occupy(int workgroups, int lanes, long long ticks, void *stream) {
+    if (workgroups <= 0 || lanes <= 0 || lanes > 1024 || ticks < 0 || ticks > 100000000ll * 10) return RRL_E_ARG;  // <= 10 s
+    hipLaunchKernelGGL(occupy_kernel, dim3((unsigned)workgroups), dim3((unsigned)lanes), 0, (hipStream_t)stream, ticks, (unsigned *)nullptr);
+    RRL_LAUNCH_CHECK();
+    return 0;
+}
+

@@ -66,12 +66,13 @@ __device__ __forceinline__ void lds_bitonic(uint32_t *key, int32_t *idx, int W, 
 // Window of W <= 4096 positions of sample blockIdx.y: levels S = S0, S0 / 2, ..., 16 (S0 <= W).  idx_g [B][P] holds the
 // current order (-1 = pad).  At the end the window's part of `order` ([B][npad], pads -> 0) is written.
 __global__ __launch_bounds__(KD_THREADS) void kd_window_kernel(const float *__restrict__ tri, int32_t *__restrict__ idx_g,
-                                                               int32_t *__restrict__ order, int n, int npad, int P, int W, int S0) {
+                                                               int32_t *__restrict__ order, int n, int npad, int P, int W, int S0,
+                                                               int stride) {
     __shared__ uint32_t key[KD_WIN];
     __shared__ int32_t idx[KD_WIN];
     __shared__ uint32_t bb[KD_WIN / 16 * 6];  // per node: min xyz, max xyz (order-preserving bits)
     const int b = blockIdx.y, w0 = blockIdx.x * W, tid = threadIdx.x;
-    const float *t0 = tri + (size_t)b * n * 9;
+    const float *t0 = tri + (size_t)b * n * stride;  // rows of `stride` floats whose first three are the point
     for (int p = tid; p < W; p += KD_THREADS) idx[p] = idx_g[(size_t)b * P + w0 + p];
     __syncthreads();
     for (int S = S0; S >= 16; S >>= 1) {
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(KD_THREADS) void kd_window_kernel(const float *__re
         for (int p = tid; p < W; p += KD_THREADS) {
             const int f = idx[p];
             if (f >= 0) {
-                const float *r = t0 + (size_t)f * 9;
+                const float *r = t0 + (size_t)f * stride;
                 const int nd = p / S;
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(KD_THREADS) void kd_window_kernel(const float *__re
                 const uint32_t *q = bb + (p / S) * 6;
                 const float e0 = ord2f(q[3]) - ord2f(q[0]), e1 = ord2f(q[4]) - ord2f(q[1]), e2 = ord2f(q[5]) - ord2f(q[2]);
                 const int ax = (e1 > e0 && e1 >= e2) ? 1 : ((e2 > e0 && e2 > e1) ? 2 : 0);
-                k = f2ord(t0[(size_t)f * 9 + ax]);
+                k = f2ord(t0[(size_t)f * stride + ax]);
                 if (k == 0xffffffffu) k = 0xfffffffeu;  // (a negative NaN pattern) keep real records in front of the pads
             }
             key[p] = k;
@@ -118,12 +119,12 @@ __global__ void kd_init_kernel(int32_t *__restrict__ idx_g, uint32_t *__restrict
     if (p < nbb) nodebb[(size_t)b * nbb + p] = (p % 6) < 3 ? 0xffffffffu : 0u;
 }
 __global__ void kd_aabb_kernel(const float *__restrict__ tri, const int32_t *__restrict__ idx_g, uint32_t *__restrict__ nodebb,
-                               int n, int P, int S, int nbb) {
+                               int n, int P, int S, int nbb, int stride) {
     const int b = blockIdx.y, p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= P) return;
     const int f = idx_g[(size_t)b * P + p];
     if (f < 0) return;
-    const float *r = tri + ((size_t)b * n + f) * 9;
+    const float *r = tri + ((size_t)b * n + f) * stride;
     uint32_t *q = nodebb + (size_t)b * nbb + (size_t)(p / S) * 6;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -135,7 +136,7 @@ __global__ void kd_aabb_kernel(const float *__restrict__ tri, const int32_t *__r
 // keys of one level; the node boxes are reset for the next level by the last use (each thread clears nothing: the host
 // re-initialises the table with kd_clear_kernel)
 __global__ void kd_keys_kernel(const float *__restrict__ tri, const int32_t *__restrict__ idx_g, const uint32_t *__restrict__ nodebb,
-                               uint32_t *__restrict__ key_g, int n, int P, int S, int nbb) {
+                               uint32_t *__restrict__ key_g, int n, int P, int S, int nbb, int stride) {
     const int b = blockIdx.y, p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= P) return;
     const int f = idx_g[(size_t)b * P + p];
@@ -144,7 +145,7 @@ __global__ void kd_keys_kernel(const float *__restrict__ tri, const int32_t *__r
         const uint32_t *q = nodebb + (size_t)b * nbb + (size_t)(p / S) * 6;
         const float e0 = ord2f(q[3]) - ord2f(q[0]), e1 = ord2f(q[4]) - ord2f(q[1]), e2 = ord2f(q[5]) - ord2f(q[2]);
         const int ax = (e1 > e0 && e1 >= e2) ? 1 : ((e2 > e0 && e2 > e1) ? 2 : 0);
-        k = f2ord(tri[((size_t)b * n + f) * 9 + ax]);
+        k = f2ord(tri[((size_t)b * n + f) * stride + ax]);
         if (k == 0xffffffffu) k = 0xfffffffeu;
     }
     key_g[(size_t)b * P + p] = k;
@@ -207,7 +208,7 @@ extern "C" size_t rrl_cloud_order_workspace_bytes(int B, int n) {
     return KdScratch(B > 0 ? B : 0, n > 0 ? n : 0).total + 256;
 }
 
-extern "C" int rrl_cloud_order(const float *tri, int32_t *order, void *ws, size_t ws_bytes, int B, int n, void *stream) {
+static int cloud_order_impl(const float *tri, int stride, int32_t *order, void *ws, size_t ws_bytes, int B, int n, void *stream) {
     if (!tri || !order || !ws || B < 0 || n < 0 || n > SORT_CAP || B > 65535) return RRL_E_ARG;
     if (B == 0 || n == 0) return 0;
     const KdScratch L(B, n);
@@ -219,8 +220,8 @@ extern "C" int rrl_cloud_order(const float *tri, int32_t *order, void *ws, size_
     const dim3 gp((unsigned)((P + 255) / 256), (unsigned)B);
     hipLaunchKernelGGL(kd_init_kernel, gp, dim3(256), 0, s, idx_g, bb, n, P, L.nbb);
     for (int S = P; S > KD_WIN; S >>= 1) {  // levels whose windows exceed one workgroup's LDS
-        hipLaunchKernelGGL(kd_aabb_kernel, gp, dim3(256), 0, s, tri, idx_g, bb, n, P, S, L.nbb);
-        hipLaunchKernelGGL(kd_keys_kernel, gp, dim3(256), 0, s, tri, idx_g, bb, key_g, n, P, S, L.nbb);
+        hipLaunchKernelGGL(kd_aabb_kernel, gp, dim3(256), 0, s, tri, idx_g, bb, n, P, S, L.nbb, stride);
+        hipLaunchKernelGGL(kd_keys_kernel, gp, dim3(256), 0, s, tri, idx_g, bb, key_g, n, P, S, L.nbb, stride);
         hipLaunchKernelGGL(kd_clear_kernel, dim3((unsigned)((B * L.nbb + 255) / 256)), dim3(256), 0, s, bb, B * L.nbb);
         const dim3 gw((unsigned)(P / KD_WIN), (unsigned)B), gh((unsigned)((P / 2 + 255) / 256), (unsigned)B);
         hipLaunchKernelGGL(kd_local_stages_kernel, gw, dim3(KD_THREADS), 0, s, key_g, idx_g, P, 2, KD_WIN, S);
@@ -231,7 +232,14 @@ extern "C" int rrl_cloud_order(const float *tri, int32_t *order, void *ws, size_
         }
     }
     const int W = P < KD_WIN ? P : KD_WIN;
-    hipLaunchKernelGGL(kd_window_kernel, dim3((unsigned)(P / W), (unsigned)B), dim3(KD_THREADS), 0, s, tri, idx_g, order, n, npad, P, W, W);
+    hipLaunchKernelGGL(kd_window_kernel, dim3((unsigned)(P / W), (unsigned)B), dim3(KD_THREADS), 0, s, tri, idx_g, order, n, npad, P, W, W, stride);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
+}
+extern "C" int rrl_cloud_order(const float *tri, int32_t *order, void *ws, size_t ws_bytes, int B, int n, void *stream) {
+    return cloud_order_impl(tri, 9, order, ws, ws_bytes, B, n, stream);
+}
+// the same for point clouds pts [B][n][3] (the Chamfer monitor's inputs, rrl_chamfer_tree_fwd_ex)
+extern "C" int rrl_cloud_order_points(const float *pts, int32_t *order, void *ws, size_t ws_bytes, int B, int n, void *stream) {
+    return cloud_order_impl(pts, 3, order, ws, ws_bytes, B, n, stream);
 }

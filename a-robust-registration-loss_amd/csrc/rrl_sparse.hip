@@ -748,9 +748,11 @@ __device__ __forceinline__ unsigned ld_agent(const uint32_t *p) {
 __device__ __forceinline__ void st_agent(uint32_t *p, unsigned v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// one lane polls one word until it reaches `want`; bounded (~1 s), so a lost workgroup becomes an error flag
-__device__ __forceinline__ bool spin_reach(const uint32_t *p, unsigned want) {
-    for (unsigned it = 0; it < (1u << 22); ++it) {
+// one lane polls one word until it reaches `want`; bounded (limit polls of ~1-2 us each: a fraction of a second by
+// default), so workgroups that are not co-resident -- a partitioned device, a CU mask, another process or stream holding
+// the slots -- become a flag, and the sample is then REPAIRED by its last workgroup (loss_reduce_tiled_kernel), not lost
+__device__ __forceinline__ bool spin_reach(const uint32_t *p, unsigned want, unsigned limit) {
+    for (unsigned it = 0; it < limit; ++it) {
         if (ld_agent(p) >= want) return true;
         __builtin_amdgcn_s_sleep(2);
     }
@@ -800,10 +802,17 @@ struct TiledArgs {
     int64_t *bsum_out;
     int32_t *info;
     float *loss;
-    const int32_t *status;
+    int32_t *status;      // [0] the scan's NaN flag (read); [2] += samples repaired after a hand-off time-out
     int B, nblk, s_m, s_n, e_m, e_n;
+    unsigned spin_limit;  // polls before a waiting workgroup gives up (rrl_set_spin_limit: tests set 0)
 };
 
+// Hand-offs between the workgroups of this launch (candidate list + TICK1, MEDRDY) are bounded spins.  A workgroup whose
+// spin times out (the others were not resident in time) adds NOTHING to the sample's sums, raises MCTL_ERR and still
+// draws its TICK2 ticket; the sample's LAST workgroup then sees the flag and recomputes the whole sample by itself --
+// median from all tiles' values, Welsch sums over all its lines, the single-workgroup kernel's arithmetic on the same
+// multiset -- so the result is bit-identical to the undisturbed one instead of NaN (round 3), at the cost of one
+// workgroup's serial pass over ~1000 lines.  STATUS[2] counts such samples.
 __global__ __launch_bounds__(256) void loss_reduce_tiled_kernel(const TiledArgs a) {
     __shared__ unsigned s_vals[MCAND_CAP];  // the bin's values (usual route) / histogram of the streaming passes
     __shared__ unsigned s_wtot[4];
@@ -905,6 +914,34 @@ __global__ __launch_bounds__(256) void loss_reduce_tiled_kernel(const TiledArgs 
         }
     };
 
+    // the remaining 20 bits when the bin is crowded (near-identical D values): this workgroup alone streams over ALL the
+    // sample's values twice more (bits 19..9, 8..0); returns the median's bit pattern in every lane
+    auto crowded_select = [&]() -> unsigned {
+        unsigned pre = bin << 20, rk = r1;
+        for (int pass = 1; pass <= 2; ++pass) {
+            const int sh = pass == 1 ? 9 : 0, width = pass == 1 ? 11 : 9, hi = sh + width;
+            const unsigned dmask = (1u << width) - 1u;
+            __syncthreads();
+            for (int i = tid; i < MCAND_CAP; i += 256) s_vals[i] = 0u;
+            __syncthreads();
+            for (int t = 0; t < nblk; ++t) {
+                const int ct = a.blkcnt[(size_t)b * nblk + t];
+                const float *base = dc + ((size_t)b * Lp + (size_t)t * 1024) * 16;
+                for (int i = tid; i < ct * 16; i += 256) {
+                    const unsigned x = __float_as_uint(base[i]);
+                    if (x != 0x7f800000u && ((x ^ pre) >> hi) == 0u) atomicAdd(&s_vals[(x >> sh) & dmask], 1u);
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 8; ++k) hb[k] = s_vals[8 * tid + k];
+            pick_bin(rk, true);
+            pre |= s_pick[0] << sh;
+            rk = s_pick[1];
+        }
+        return pre;
+    };
+
     if (pop <= MCAND_CAP) {
         // ---- publish this tile's values of the bin, meet, read the whole list, finish the select
         auto in_bin = [&](unsigned x) { return x != 0x7f800000u && (x >> 20) == bin; };
@@ -934,7 +971,7 @@ __global__ __launch_bounds__(256) void loss_reduce_tiled_kernel(const TiledArgs 
         __syncthreads();
         if (tid == 0) {  // the last to arrive learns it from its own ticket and does not poll at all
             const unsigned prev = __hip_atomic_fetch_add(&ctl[MCTL_TICK1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (prev + 1u < (unsigned)nblk && !spin_reach(&ctl[MCTL_TICK1], (unsigned)nblk)) s_flag[0] = 0u;
+            if (prev + 1u < (unsigned)nblk && !spin_reach(&ctl[MCTL_TICK1], (unsigned)nblk, a.spin_limit)) s_flag[0] = 0u;
         }
         __syncthreads();
         for (unsigned i = tid; i < pop; i += 256) s_vals[i] = ld_agent(&cand[i]);
@@ -947,27 +984,7 @@ __global__ __launch_bounds__(256) void loss_reduce_tiled_kernel(const TiledArgs 
         prefix = s_med;
     } else if (tile == 0) {
         // ---- crowded bin: this workgroup alone streams over ALL the sample's values twice more (bits 19..9, 8..0)
-        unsigned rk = r1;
-        for (int pass = 1; pass <= 2; ++pass) {
-            const int sh = pass == 1 ? 9 : 0, width = pass == 1 ? 11 : 9, hi = sh + width;
-            const unsigned dmask = (1u << width) - 1u;
-            for (int i = tid; i < MCAND_CAP; i += 256) s_vals[i] = 0u;
-            __syncthreads();
-            for (int t = 0; t < nblk; ++t) {
-                const int ct = a.blkcnt[(size_t)b * nblk + t];
-                const float *base = dc + ((size_t)b * Lp + (size_t)t * 1024) * 16;
-                for (int i = tid; i < ct * 16; i += 256) {
-                    const unsigned x = __float_as_uint(base[i]);
-                    if (x != 0x7f800000u && ((x ^ prefix) >> hi) == 0u) atomicAdd(&s_vals[(x >> sh) & dmask], 1u);
-                }
-            }
-            __syncthreads();
-#pragma unroll
-            for (int k = 0; k < 8; ++k) hb[k] = s_vals[8 * tid + k];
-            pick_bin(rk, true);
-            prefix |= s_pick[0] << sh;
-            rk = s_pick[1];
-        }
+        prefix = crowded_select();
         if (tid == 0) {
             st_agent(&ctl[MCTL_MEDBITS], prefix);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -975,13 +992,13 @@ __global__ __launch_bounds__(256) void loss_reduce_tiled_kernel(const TiledArgs 
         }
     } else {
         if (tid == 0) {
-            if (!spin_reach(&ctl[MCTL_MEDRDY], 1u)) s_flag[0] = 0u;
+            if (!spin_reach(&ctl[MCTL_MEDRDY], 1u, a.spin_limit)) s_flag[0] = 0u;
             s_med = ld_agent(&ctl[MCTL_MEDBITS]);
         }
         __syncthreads();
         prefix = s_med;
     }
-    const float med = __uint_as_float(prefix);
+    float med = __uint_as_float(prefix);
 
     // ---- Welsch terms of this tile's lines into the workgroup's fixed-point sums (as reduce_core::accumulate)
     auto accumulate = [&](const float *Dl, int k, int j) {
@@ -997,8 +1014,11 @@ __global__ __launch_bounds__(256) void loss_reduce_tiled_kernel(const TiledArgs 
         atomicAdd(&s_sum[bi * 2 + 0], (unsigned long long)((double)row * (double)(1ll << FIX_SHIFT) + 0.5));
         atomicAdd(&s_sum[bi * 2 + 1], (unsigned long long)((double)col * (double)(1ll << FIX_SHIFT) + 0.5));
     };
-    if (c0) accumulate(tl, (int)(c0 & 15u), (int)(c0 >> 4));
-    for_extra_rows([&](const float *D_, unsigned c) { if (c) accumulate(D_, (int)(c & 15u), (int)(c >> 4)); });
+    const bool handoff_ok = s_flag[0] != 0u;  // uniform (written before the last barrier): false = a spin timed out: this
+    if (handoff_ok) {                         // workgroup's median may be wrong -- it adds nothing; the last one repairs
+        if (c0) accumulate(tl, (int)(c0 & 15u), (int)(c0 >> 4));
+        for_extra_rows([&](const float *D_, unsigned c) { if (c) accumulate(D_, (int)(c & 15u), (int)(c >> 4)); });
+    }
     __syncthreads();
     if (tid < 32) {
         const unsigned long long v = s_sum[tid];
@@ -1015,9 +1035,59 @@ __global__ __launch_bounds__(256) void loss_reduce_tiled_kernel(const TiledArgs 
     __syncthreads();
     if (!s_flag[1]) return;
 
-    // ---- the last workgroup of the sample: loss = ( sum_{non-empty (k,j), k-major} exp(-|k-j|/2) (mean_row + mean_col) ) / C
+    // ---- the last workgroup of the sample.  A hand-off timed out somewhere (MCTL_ERR): recompute the sample alone.
+    const bool repair = ld_agent(&ctl[MCTL_ERR]) != 0u;  // uniform: every producer's flag precedes its ticket
+    if (repair) {
+        __syncthreads();
+        if (tid < 32) s_sum[tid] = 0ull;
+        if (tid == 0) { s_flag[2] = 0u; s_flag[0] = 0u; }  // s_flag[0]: cursor of the gathered values
+        __syncthreads();
+        unsigned pre = bin << 20;
+        if (pop <= MCAND_CAP) {  // the bin's values of ALL tiles into LDS (any order), then the wave-private passes
+            for (int t = 0; t < nblk; ++t) {
+                const int ct = a.blkcnt[(size_t)b * nblk + t];
+                const float *base = dc + ((size_t)b * Lp + (size_t)t * 1024) * 16;
+                for (int i = tid; i < ct * 16; i += 256) {
+                    const unsigned x = __float_as_uint(base[i]);
+                    if (x != 0x7f800000u && (x >> 20) == bin) {
+                        const unsigned at = atomicAdd(&s_flag[0], 1u);
+                        if (at < MCAND_CAP) s_vals[at] = x;
+                    }
+                }
+            }
+            __syncthreads();
+            if (tid < 64) {
+                const unsigned m = wave_select20(s_vals, pop, pre, r1, s_whist, tid);
+                if (tid == 0) s_med = m;
+            }
+            __syncthreads();
+            pre = s_med;
+        } else {
+            pre = crowded_select();
+        }
+        med = __uint_as_float(pre);
+        for (int t = 0; t < nblk; ++t) {  // every selected line of the sample, the same per-line arithmetic
+            const int ct = a.blkcnt[(size_t)b * nblk + t];
+            const size_t s0 = (size_t)b * Lp + (size_t)t * 1024;
+            for (int i = tid; i < ct; i += 256) {
+                const float4 *row = (const float4 *)(dc + (s0 + i) * 16);
+                float D_[16];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 v = row[q];
+                    D_[4 * q] = v.x; D_[4 * q + 1] = v.y; D_[4 * q + 2] = v.z; D_[4 * q + 3] = v.w;
+                }
+                const unsigned c = kjc[s0 + i];
+                if (c) accumulate(D_, (int)(c & 15u), (int)(c >> 4));
+            }
+        }
+        __syncthreads();
+        if (tid == 0) atomicAdd(&a.status[2], 1);
+    }
+    // loss = ( sum_{non-empty (k,j), k-major} exp(-|k-j|/2) (mean_row + mean_col) ) / C
     if (tid < 32) {
-        const unsigned long long v = __hip_atomic_load(&a.msum[(size_t)b * 32 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long v = repair ? s_sum[tid]
+                                            : __hip_atomic_load(&a.msum[(size_t)b * 32 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_sum[tid] = v;
         a.bsum_out[(size_t)b * 32 + tid] = (int64_t)v;
         __hip_atomic_store(&a.msum[(size_t)b * 32 + tid], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // a second reduce on this state starts clean
@@ -1027,7 +1097,7 @@ __global__ __launch_bounds__(256) void loss_reduce_tiled_kernel(const TiledArgs 
         if (tid < 48) {
             s_cnt[tid - 32] = (int)v;
             a.bcnt_out[b * 16 + tid - 32] = (int)v;
-        } else if (tid - 32 == MCTL_BAD || tid - 32 == MCTL_ERR) {
+        } else if (tid - 32 == MCTL_BAD && !repair) {
             if (v) atomicOr(&s_flag[2], 2u);  // (s_flag[2] bit 0 was this workgroup's own; bit 1: anyone's)
         }
     }
@@ -1057,7 +1127,7 @@ __global__ __launch_bounds__(256) void loss_reduce_tiled_kernel(const TiledArgs 
                 nselected += s_cnt[bi];
             }
         for (int bi = 0; bi < 16; ++bi) nvalues += s_cnt[bi] * (bi / 4 + 1) * (bi % 4 + 1);
-        const bool bad = (s_flag[2] & 2u) != 0u;
+        const bool bad = repair ? (s_flag[2] & 1u) != 0u : (s_flag[2] & 2u) != 0u;  // a non-finite Welsch term (median 0)
         a.med_out[b] = med;
         a.loss[b] = bad ? __builtin_nanf("") : (C ? acc / (float)C : 0.0f);  // code/loss.py:230
         a.info[b * 4 + 0] = C;
@@ -1065,7 +1135,7 @@ __global__ __launch_bounds__(256) void loss_reduce_tiled_kernel(const TiledArgs 
         a.info[b * 4 + 2] = nvalues;
         a.info[b * 4 + 3] = a.status[0];
         st_agent(&ctl[MCTL_CURSOR], 0u); st_agent(&ctl[MCTL_TICK1], 0u); st_agent(&ctl[MCTL_TICK2], 0u);
-        st_agent(&ctl[MCTL_MEDRDY], 0u); st_agent(&ctl[MCTL_BAD], 0u);
+        st_agent(&ctl[MCTL_MEDRDY], 0u); st_agent(&ctl[MCTL_BAD], 0u); st_agent(&ctl[MCTL_ERR], 0u);
     }
 }
 
@@ -1597,11 +1667,10 @@ __global__ __launch_bounds__(1024) void pair_reduce_kernel(const PairArgs pa, co
     reduce_body(ra, (int)blockIdx.x);
 }
 
-// The tiled reduce (one workgroup per 1024-line tile; its workgroups spin on each other) is taken for independent
-// samples with at least two tiles while the whole grid is certainly co-resident: B x tiles <= 1024 workgroups of
-// 256 lanes = 4 per compute unit.  rrl_set_reduce_mode / RRL_REDUCE=single|tiled override (tiled still respects pool
-// and the bound; it then also serves a single tile).
-static int g_reduce_mode = -1;  // 0 auto, 1 single, 2 tiled; -1: read RRL_REDUCE once
+// The DEFAULT reduce mode (include/rrl.h rrl_set_reduce_mode; a call's rrl_opts.reduce_mode overrides it): 0 auto, 1 single,
+// 2 tiled (the tail kernel wherever legal), 3 xchg (the exchange kernel wherever legal); reduce_kind() below turns a mode
+// and a shape into the kernel.  Env RRL_REDUCE=single|tiled|xchg.
+static int g_reduce_mode = -1;  // -1: read RRL_REDUCE once
 extern "C" int rrl_set_reduce_mode(int mode) {
     if (mode < 0 || mode > 3) return RRL_E_ARG;
     g_reduce_mode = mode;
@@ -1645,9 +1714,46 @@ RrlCall rrl_resolve_opts(const rrl_opts *p) {
 // the demo's shape, one sample of 20 tiles, the two are even), else the exchange kernel for >= 2 tiles while the grid
 // is co-resident, else the single workgroup; 1: single; 2 ("tiled"): the tail kernel wherever it is legal (also forward
 // only, also one tile: tests), exchange beyond; 3 ("xchg"): the exchange kernel wherever it is legal.
+// Test hook: polls a waiting workgroup of the exchange reduce makes before it gives up (default 2^18, ~0.3 s); 0 makes
+// every hand-off "time out", so the repair path runs on every sample (tests/test_gpu_stress.py).  Env RRL_SPIN_LIMIT.
+static long g_spin_limit = -1;
+extern "C" int rrl_set_spin_limit(long long polls) {
+    if (polls < 0 || polls > 0xffffffffll) return RRL_E_ARG;
+    g_spin_limit = (long)polls;
+    return 0;
+}
+static unsigned spin_limit() {
+    if (g_spin_limit < 0) {
+        const char *e = getenv("RRL_SPIN_LIMIT");
+        g_spin_limit = e ? atol(e) : (1l << 18);
+        if (g_spin_limit < 0) g_spin_limit = 1l << 18;
+    }
+    return (unsigned)g_spin_limit;
+}
+// Workgroups of loss_reduce_tiled_kernel that are co-resident on the CURRENT device when it has the device to itself:
+// compute units (as the runtime reports them: a CPX partition or a CU mask reports fewer) x the occupancy the
+// runtime computes for this kernel.  (Round 3 hard-coded 1024 = 256 CUs x 4.)  Co-residency is a matter of speed only
+// since round 4 -- a workgroup that waits in vain is repaired by its sample's last workgroup -- but a grid beyond the
+// capacity would make that slow path the usual one, so the exchange kernel is only chosen within it.
+static long xchg_capacity() {
+    static long cap[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cap[dev] == 0) {
+        hipDeviceProp_t p;
+        int per_cu = 0;
+        long c = 256;
+        if (hipGetDeviceProperties(&p, dev) == hipSuccess &&
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, loss_reduce_tiled_kernel, 256, 0) == hipSuccess && per_cu > 0)
+            c = (long)p.multiProcessorCount * per_cu;
+        if (const char *e = getenv("RRL_XCHG_CAPACITY")) c = atol(e);  // experiments / tests
+        cap[dev] = c < 1 ? 1 : (c > 4096 ? 4096 : c);
+    }
+    return cap[dev];
+}
 static int reduce_kind(int mode, int B, int nblk, int pool, bool with_bwd) {
     if (pool || mode == 1) return 0;
-    const bool xchg_ok = (long)B * nblk <= 1024;
+    const bool xchg_ok = (long)B * nblk <= xchg_capacity();
     if (mode == 3) return xchg_ok && nblk >= 1 ? 1 : 0;
     const bool tail_ok = nblk <= TAIL_MAX_TILES && (long)B * nblk <= 128;
     if (mode == 2 && tail_ok && nblk >= 1) return 2;
@@ -1713,6 +1819,7 @@ static int loss_reduce_impl(void *ws, size_t ws_bytes, float *loss, int B, int N
         t.med_out = w.f32(ws, RRL_WS_MED); t.bcnt_out = w.i32(ws, RRL_WS_BCNT); t.bsum_out = w.i64(ws, RRL_WS_BSUM);
         t.info = w.i32(ws, RRL_WS_INFO); t.loss = loss; t.status = w.i32(ws, RRL_WS_STATUS);
         t.B = B; t.nblk = nblk; t.s_m = s_m; t.s_n = s_n; t.e_m = e_m; t.e_n = e_n;
+        t.spin_limit = spin_limit();
         hipLaunchKernelGGL(loss_reduce_tiled_kernel, dim3((unsigned)nblk, (unsigned)B), dim3(256), 0, (hipStream_t)stream, t);
         RRL_LAUNCH_CHECK();
         return 0;

@@ -32,6 +32,7 @@ _SIGS = {
     "rrl_registration_step_ex": [_P] * 6 + [_Z] + [_P] * 5 + [_I] * 11 + [_P, _P, _P],
     "rrl_loss_step_ex": [_P] * 6 + [_Z] + [_P] * 4 + [_I] * 11 + [_P, _P, _P],
     "rrl_cloud_order": [_P, _P, _P, _Z, _I, _I, _P],
+    "rrl_cloud_order_points": [_P, _P, _P, _Z, _I, _I, _P],
     "rrl_tri_prepare_ex": [_P, _P, _P, _Z, _I, _I, _I, _I, _P, _P],
     "rrl_line_tri_scan_ex": [_P, _P, _Z] + [_I] * 6 + [_P, _P],
     "rrl_loss_reduce_ex": [_P, _Z, _P] + [_I] * 9 + [_P, _P],
@@ -43,6 +44,8 @@ _SIGS = {
     "rrl_loss_reduce_rows": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "rrl_shard_payload": [_P, _P, _Z, _P, _P, _P, _I, _I, _I, _I, _P],
     "rrl_set_scan_variant": [_I],
+    "rrl_set_spin_limit": [_c.c_longlong],
+    "rrl_debug_occupy": [_I, _I, _c.c_longlong, _P],
     "rrl_set_deterministic": [_I],
     "rrl_set_reduce_mode": [_I],
     "rrl_set_sort_parts": [_I],
@@ -57,6 +60,8 @@ _SIGS = {
     "rrl_chamfer_bwd": [_P] * 7 + [_I] * 3 + [_P],
     "rrl_chamfer_tree_fwd": [_P, _P, _P, _Z, _P, _P, _P, _I, _I, _I, _P],
     "rrl_chamfer_from_loss": [_P, _P, _Z, _I, _I, _I, _I, _P, _Z, _P, _P, _P, _P],
+    "rrl_chamfer_tree_fwd_ex": [_P, _P, _P, _Z, _P, _P, _P, _I, _I, _I, _P, _P, _P, _c.c_longlong, _P],
+    "rrl_chamfer_from_loss_ex": [_P, _P, _Z, _I, _I, _I, _I, _P, _Z, _P, _P, _P, _P, _c.c_longlong, _P],
     "rrl_aabb": [_P, _P, _I, _I, _P],
     "rrl_box_accept": [_P, _P, _P, _P, _P, _I, _I, _P],
     "rrl_log_row": [_P, _P, _P, _P, _P, _c.c_longlong, _P, _P],

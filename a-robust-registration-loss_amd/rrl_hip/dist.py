@@ -129,17 +129,23 @@ def sharded_batch_loss(points1, points2, line, rng=(1, 1, 5, 5), loss_fn=None, g
 # unsharded one and identical on all ranks) and the backward of a rank's own lines uses the merged statistics; the
 # point gradients are summed by one all-reduce.
 # ---------------------------------------------------------------------------------------
-def gather_rows(rows, kj, group=None):
+def gather_rows(rows, kj, group=None, flag=None):
     """All ranks' (rows (S_r, 16) fp32, kj (S_r,) uint8) concatenated in rank order on every rank: one all-gather of the
-    sizes, one of the rows padded to the largest share (kj travels in a 17th column)."""
+    sizes, one of the rows padded to the largest share (kj travels in a 17th column).  flag (int tensor (1,), optional):
+    a per-rank flag that rides in the sizes' all-gather (round 4: the scan's NaN flag -- one collective less per call);
+    then (rows, kj, max over the ranks' flags) is returned."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world == 1:
-        return rows, kj
+        return (rows, kj) if flag is None else (rows, kj, flag.reshape(1).clone())
     dev = rows.device
-    n = torch.tensor([rows.shape[0]], dtype=torch.int64, device=dev)
+    n = torch.zeros(2, dtype=torch.int64, device=dev)
+    n[0] = rows.shape[0]
+    if flag is not None:
+        n[1] = flag.reshape(-1)[0].to(torch.int64)
     sizes = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(sizes, n, group=group)
-    sizes = [int(s) for s in sizes]
+    fmax = torch.stack(sizes)[:, 1].max().reshape(1)
+    sizes = [int(s[0]) for s in sizes]
     cap = max(max(sizes), 1)
     mine = torch.zeros(cap, 17, dtype=torch.float32, device=dev)
     mine[:rows.shape[0], :16] = rows
@@ -147,7 +153,8 @@ def gather_rows(rows, kj, group=None):
     parts = [torch.empty_like(mine) for _ in range(world)]
     dist.all_gather(parts, mine, group=group)
     allr = torch.cat([p[:s] for p, s in zip(parts, sizes)])
-    return allr[:, :16].contiguous(), allr[:, 16].to(torch.uint8).contiguous()
+    out = (allr[:, :16].contiguous(), allr[:, 16].to(torch.uint8).contiguous())
+    return out if flag is None else out + (fmax.to(flag.dtype),)
 
 
 def line_shard_local(tri1, tri2, line, rng=(1, 1, 5, 5), mode="cull", chunk=0):
@@ -213,10 +220,7 @@ class _LineShardedLoss(torch.autograd.Function):
         lo, hi = shard_bounds(ln.shape[1], rank, world)
         mine = ln[:, lo:hi].contiguous()
         st, rows, kj = line_shard_local(tri1, tri2, mine, rng, mode)
-        flag = st.status[:1].clone()
-        if world > 1:
-            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
-        rows, kj = gather_rows(rows, kj, group)
+        rows, kj, flag = gather_rows(rows, kj, group, flag=st.status[:1])  # (the NaN flag rides with the shares' sizes)
         line_shard_merge(st, rows, kj, rng, flag[0])
         ctx.st, ctx.tri1, ctx.tri2, ctx.group, ctx.world = st, tri1, tri2, group, world
         ctx.nlines = hi - lo
@@ -228,15 +232,18 @@ class _LineShardedLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_loss, _g1, _g2):
         from . import ops
-        if g_loss is None:
-            return (None,) * 6
         st, tri1, tri2 = ctx.st, ctx.tri1, ctx.tri2
         N, M = tri1.shape[1], tri2.shape[1]
         dev = tri1.device
-        g = g_loss.detach().to(device=dev, dtype=torch.float32).contiguous()
+        if g_loss is None and ctx.world == 1:
+            return (None,) * 6
+        # A rank whose loss is unused in ITS graph (g_loss None) still takes part in the collectives below with zero
+        # gradients (round 4, ADVICE r3: returning early here left the other ranks hanging in their all-reduce).  Whether
+        # points2 wants a gradient is a property of the call, the same on every rank.
         g1 = torch.zeros_like(tri1)
         g2 = torch.zeros_like(tri2) if ctx.needs_input_grad[1] else None
-        if ctx.nlines > 0:
+        if g_loss is not None and ctx.nlines > 0:
+            g = g_loss.detach().to(device=dev, dtype=torch.float32).contiguous()
             with ops._guard(dev):
                 ops.check(ops._lib.load().rrl_loss_backward(ops._p(tri1), ops._p(tri2), ops._p(st.ws), st.nbytes, ops._p(g),
                                                             ops._p(g1), ops._p(g2), 1, N, M, ctx.nlines, 0, ops._stream(dev)),
@@ -256,6 +263,6 @@ def line_sharded_loss(points1, points2, line, rng=(1, 1, 5, 5), mode="cull", gro
     lines partitioned over the ranks of `group` (contiguous shares, shard_bounds).  Returns (loss (1,), info (1, 4),
     status (4,)) like ops.intersection_loss; the loss is bit-identical to the unsharded one and the same on all ranks,
     its gradient w.r.t. points1 / points2 is the full gradient (summed over the ranks) on every rank.  Collectives per
-    call: the NaN flag (4 bytes), the shares' sizes (8 bytes), the selected lines' rows (68 bytes each); per backward:
-    the point gradients."""
+    call: the shares' sizes with the NaN flag (16 bytes), the selected lines' rows (68 bytes each); per backward: the
+    point gradients (every rank takes part, with zeros when its own loss is not used)."""
     return _LineShardedLoss.apply(points1, points2, line, tuple(rng), mode, group)

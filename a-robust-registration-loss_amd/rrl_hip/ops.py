@@ -208,15 +208,16 @@ _order_ws = {}  # (B, n, device index) -> scratch of rrl_cloud_order
 
 
 def cloud_order(tri):
-    """Spatial order of the clouds tri (B, n, 9) -- pseudo-triangles; only the first point of a row places it -- computed
+    """Spatial order of the clouds tri (B, n, 9) -- pseudo-triangles; only the first point of a row places it -- or of
+    point clouds (B, n, 3) (the Chamfer monitor's inputs: ops.chamfer(x, y, order_x=, order_y=)), computed
     ONCE per cloud (include/rrl.h rrl_cloud_order): int32 (B, 64 ceil(n / 64)), sorted position -> triangle index.
     A rigid motion preserves the order, so the same tensor serves every pose of the cloud: hand it to
     RegistrationStep / intersection_loss / registration_loss (order1= / order2=) and the per-step cell sort
     disappears.  Any permutation gives identical labels and loss; this one makes the culled scan fast."""
     dev = _home(tri)
-    t = _prep(tri, "tri", 9, dev)
-    if t.dim() != 3:
-        raise ValueError("tri must be (B, n, 9)")
+    if not isinstance(tri, torch.Tensor) or tri.dim() != 3 or tri.shape[-1] not in (3, 9):
+        raise ValueError("cloud_order takes pseudo-triangles (B, n, 9) or points (B, n, 3)")
+    t = _prep(tri, "tri", None, dev)
     B, n, _ = t.shape
     if n > 65536:
         raise ValueError("clouds beyond 65536 triangles are not sorted (the dense scan serves them)")
@@ -230,7 +231,7 @@ def cloud_order(tri):
             _order_ws.clear()
         nb = int(_lib.load().rrl_cloud_order_workspace_bytes(B, n))
         ws = _order_ws[key] = torch.empty(nb, dtype=torch.uint8, device=dev)
-    _run(dev, "rrl_cloud_order", _p(t), _p(order), _p(ws), ws.numel(), B, n)
+    _run(dev, "rrl_cloud_order" if t.shape[-1] == 9 else "rrl_cloud_order_points", _p(t), _p(order), _p(ws), ws.numel(), B, n)
     return order
 
 
@@ -745,9 +746,14 @@ class RegistrationStep:
     ONE_CALL = os.environ.get("RRL_ONE_CALL", "1") != "0"
 
     def __init__(self, src_tri, tar_tri, n_lines, rng=(1, 1, 5, 5), transpose_r=True, mode="cull", chunk=0,
-                 want_payload=False, prepared=None, src_order=None, tar_order=None):
+                 want_payload=False, prepared=None, src_order=None, tar_order=None, reduce_mode=None, deterministic=None,
+                 sort_parts=None):
+        """reduce_mode / deterministic / sort_parts: per-call options of THIS step object (include/rrl.h rrl_opts; None =
+        the library default) -- they travel with every call, so two steps with different options can run from two
+        threads on two streams at the same time (tests/test_gpu_threads.py)."""
         dev = _home(src_tri, tar_tri)
         self.dev = dev
+        self._extra = dict(reduce_mode=reduce_mode, deterministic=deterministic, sort_parts=sort_parts)
         self.src = _prep(src_tri, "src_tri", 9, dev)
         self.tar = _prep(tar_tri, "tar_tri", 9, dev)
         if self.src.dim() != 3 or self.tar.dim() != 3 or self.src.shape[0] != self.tar.shape[0]:
@@ -780,12 +786,13 @@ class RegistrationStep:
         if self.prepared:
             self.order1 = _check_order(src_order, B, N, dev, "src_order") if src_order is not None else cloud_order(self.src)
             self.order2 = _check_order(tar_order, B, M, dev, "tar_order") if tar_order is not None else cloud_order(self.tar)
-            self._set_opts()
+        self._set_opts()
 
     def _set_opts(self):
-        self._opts = make_opts(order1=self.order1, order2=self.order2)
-        self._opts_kept = make_opts(order1=self.order1, order2=self.order2, target_kept=True)
-        self._optr, self._optr_kept = ctypes.byref(self._opts), ctypes.byref(self._opts_kept)
+        self._opts = make_opts(order1=self.order1, order2=self.order2, **self._extra)
+        self._opts_kept = make_opts(order1=self.order1, order2=self.order2, target_kept=True, **self._extra) if self.prepared else self._opts
+        self._optr = ctypes.byref(self._opts) if self._opts is not None else None
+        self._optr_kept = ctypes.byref(self._opts_kept) if self._opts_kept is not None else None
 
     def __call__(self, R, t, line, grad_loss=None, src_tri=None, tar_tri=None, target_from=None, src_order=None,
                  tar_order=None):
@@ -802,7 +809,7 @@ class RegistrationStep:
             self.tar = _prep(tar_tri, "tar_tri", 9, dev)
         if tuple(self.src.shape) != (B, N, 9) or tuple(self.tar.shape) != (B, M, 9):
             raise ValueError(f"src_tri {(B, N, 9)} / tar_tri {(B, M, 9)} expected")
-        op = None
+        op = self._optr
         if self.prepared:
             if src_tri is not None or src_order is not None or tar_tri is not None or tar_order is not None:
                 if src_tri is not None or src_order is not None:  # a new source: its order comes along, or is taken now
@@ -833,7 +840,7 @@ class RegistrationStep:
             else:
                 check(lib.rrl_registration_forward_ex(_p(self.src), _p(Rm), _p(tv), _p(self.tar), _p(ln), *fixed_f, op, s),
                       "rrl_registration_forward")
-                check(lib.rrl_registration_backward(_p(self.src), _p(Rm), _p(self.tar), *self._fixed_b, _p(g), *self._tail_b, s),
+                check(lib.rrl_registration_backward_ex(_p(self.src), _p(Rm), _p(self.tar), *self._fixed_b, _p(g), *self._tail_b, op, s),
                       "rrl_registration_backward")
         _IntersectionLoss.last_state = self.st
         return self.st.loss.view(-1), self.gR, self.gt, self.payload, self.st.info
@@ -916,6 +923,20 @@ def set_reduce_mode(mode):
     """Which reduce kernel the forwards launch: "auto" (tiled where legal and worthwhile), "single", "tiled"
     (include/rrl.h rrl_set_reduce_mode).  Process-wide; same bits either way."""
     check(_lib.load().rrl_set_reduce_mode({"auto": 0, "single": 1, "tiled": 2, "xchg": 3}[mode]), "rrl_set_reduce_mode")
+
+
+def set_spin_limit(polls):
+    """Test hook (include/rrl.h rrl_set_spin_limit): polls before a waiting workgroup of the exchange reduce gives up and
+    leaves the sample to its last workgroup's repair; None = the default (2^18)."""
+    check(_lib.load().rrl_set_spin_limit(int(1 << 18 if polls is None else polls)), "rrl_set_spin_limit")
+
+
+def debug_occupy(workgroups, lanes, seconds, stream=None):
+    """Test hook (rrl_debug_occupy): a filler launch that holds `workgroups` x `lanes` threads' slots for `seconds` on
+    `stream` (a torch.cuda.Stream; default: the current one)."""
+    dev = require_gpu()
+    raw = ctypes.c_void_p(stream.cuda_stream) if stream is not None else _stream(dev)
+    check(_lib.load().rrl_debug_occupy(int(workgroups), int(lanes), int(seconds * 1e8), raw), "rrl_debug_occupy")
 
 
 def set_sort_parts(parts):
@@ -1066,7 +1087,7 @@ _chamfer_ws_bytes = {}
 
 class _Chamfer(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, y):
+    def forward(ctx, x, y, order_x=None, order_y=None):
         dev = _home(x, y)
         xs, ys = _prep(x, "points_x", 3, dev), _prep(y, "points_y", 3, dev)
         if xs.dim() != 3 or ys.dim() != 3 or xs.shape[0] != ys.shape[0]:
@@ -1082,7 +1103,12 @@ class _Chamfer(torch.autograd.Function):
             if nb is None:
                 nb = _chamfer_ws_bytes[(B, N, M)] = int(_lib.load().rrl_chamfer_workspace_bytes(B, N, M))
             ws = torch.empty(nb, dtype=torch.uint8, device=dev)
-            _run(dev, "rrl_chamfer_tree_fwd", _p(xs), _p(ys), _p(ws), nb, _p(bx), _p(by), _p(val), B, N, M)
+            if order_x is not None and order_y is not None:  # prepared clouds: no sort in this call
+                ox, oy = _check_order(order_x, B, N, dev, "order_x"), _check_order(order_y, B, M, dev, "order_y")
+                _run(dev, "rrl_chamfer_tree_fwd_ex", _p(xs), _p(ys), _p(ws), nb, _p(bx), _p(by), _p(val), B, N, M, _p(ox), _p(oy),
+                     None, 0)
+            else:
+                _run(dev, "rrl_chamfer_tree_fwd", _p(xs), _p(ys), _p(ws), nb, _p(bx), _p(by), _p(val), B, N, M)
         else:
             _run(dev, "rrl_chamfer_fwd", _p(xs), _p(ys), _p(bx), _p(by), _p(val), B, N, M)
         ctx.save_for_backward(xs, ys, bx, by)
@@ -1099,11 +1125,14 @@ class _Chamfer(torch.autograd.Function):
         gy = torch.zeros_like(ys) if ctx.needs_input_grad[1] else None
         _run(xs.device, "rrl_chamfer_bwd", _p(xs), _p(ys), _p(bx), _p(by), _p(g), _p(gx), _p(gy), B, N, M)
         return (gx.to(ctx.devs[0]) if gx is not None else None,
-                gy.to(ctx.devs[1]) if gy is not None else None)
+                gy.to(ctx.devs[1]) if gy is not None else None, None, None)
 
 
-def chamfer(x, y):
-    return _Chamfer.apply(x, y)
+def chamfer(x, y, order_x=None, order_y=None):
+    """chamfer_dist (code/loss.py:236-252) of x (B, N, 3), y (B, M, 3): scalar, differentiable.  order_x / order_y:
+    ops.cloud_order of the two point clouds (or of the pseudo-triangles they are the first points of) in any rigid pose
+    -- both given, the per-call sort is skipped (same keys, same value)."""
+    return _Chamfer.apply(x, y, order_x, order_y)
 
 
 def chamfer_from_state(state=None, keys=False):
@@ -1174,35 +1203,45 @@ def box_accept(lines, aabb1, aabb2):
 
 
 _sampler_rng = {}  # device index -> int64[4] state of the library's generator (include/rrl.h rrl_sample_lines_rng)
-_sampler_key = {}  # device index -> (seed, offset) of torch's CUDA generator as this module left it
+_sampler_key = {}  # device index -> (seed, offset) of torch's CUDA generator at the last look (never written back)
+_sampler_pin = {}  # device index -> pinned int64[4] staging buffer of a (re)seed
 
 
 def sampler_rng(dev=None, seed=None):
     """State of the library's own uniform generator for the line sampler on `dev` (Philox4x32-10 inside the sampler
     kernels: [seed, call counter, ticket, 0]).  The counter lives on the device and is advanced by every call, so a
     captured step replays a fresh stream each time with no host-side bookkeeping.
-    Seeding follows torch: the state is (re)created from torch's CUDA generator of `dev` -- its seed and offset --
-    whenever that generator is not where this module left it, i.e. after torch.manual_seed / torch.cuda.manual_seed
-    (the offset returns to 0) or after other GPU draws; each (re)seed moves the torch offset by 4 as its mark.  So
-    `torch.manual_seed(s)` followed by the same calls gives the same lines.  seed=<int> re-seeds explicitly.
+    Seeding follows torch WITHOUT touching it (round 4): the state is (re)created from the SEED of torch's CUDA generator
+    of `dev` whenever torch was re-seeded since the last look -- its seed changed, or its offset went BACKWARDS (only
+    torch.manual_seed / torch.cuda.manual_seed / set_state do that) -- torch's offset is read, never moved, so other
+    GPU draws (dropout, rand) neither re-seed the sampler nor are shifted by it.  `torch.manual_seed(s)` followed by the
+    same calls gives the same lines.  One blind spot: re-seeding torch with the SAME seed while nothing else has drawn
+    from its CUDA generator is invisible (seed and offset unchanged) -- use seed=<int> to re-seed explicitly then.
+    The new state is uploaded from pinned memory without blocking the host.
     (No check while the stream is capturing: a captured step keeps the state it was captured with.)"""
     dev = dev if dev is not None else require_gpu()
     st = _sampler_rng.get(dev.index)
-    if not (st is not None and torch.cuda.is_current_stream_capturing()):
+    if seed is None and not (st is not None and torch.cuda.is_current_stream_capturing()):
         g = torch.cuda.default_generators[dev.index]
-        key = (g.initial_seed(), g.get_offset())
-        if seed is not None or st is None or key != _sampler_key.get(dev.index):
-            if seed is None:
-                seed = (key[0] ^ (key[1] * 0x9E3779B97F4A7C15)) & 0xFFFFFFFFFFFFFFFF
-            g.set_offset(key[1] + 4)
-            _sampler_key[dev.index] = (key[0], key[1] + 4)
+        tseed, toff = g.initial_seed(), g.get_offset()
+        known = _sampler_key.get(dev.index)
+        if st is None or known is None or tseed != known[0] or toff < known[1]:
+            seed = (tseed ^ 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+        _sampler_key[dev.index] = (tseed, toff)
+    elif seed is not None and not torch.cuda.is_current_stream_capturing():
+        g = torch.cuda.default_generators[dev.index]  # an explicit seed stands until torch is re-seeded AFTER it
+        _sampler_key[dev.index] = (g.initial_seed(), g.get_offset())
     if st is None or seed is not None:
         sd = int(seed) & 0x7FFFFFFFFFFFFFFF
-        new = torch.tensor([sd, 0, 0, 0], dtype=torch.int64, device=dev)
+        host = _sampler_pin.get(dev.index)
+        if host is None:
+            host = _sampler_pin[dev.index] = torch.zeros(4, dtype=torch.int64).pin_memory()
+        elif st is not None:
+            torch.cuda.current_stream(dev).synchronize()  # (re-seeding only: the previous upload must have left the pinned buffer)
+        host[0], host[1], host[2], host[3] = sd, 0, 0, 0
         if st is None:
-            st = _sampler_rng[dev.index] = new
-        else:
-            st.copy_(new)  # in place: a captured step keeps pointing at the same memory
+            st = _sampler_rng[dev.index] = torch.empty(4, dtype=torch.int64, device=dev)
+        st.copy_(host, non_blocking=True)  # in place: a captured step keeps pointing at the same memory
     return st
 
 

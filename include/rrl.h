@@ -17,7 +17,13 @@
  *   - `stream` is a hipStream_t (pass torch's current stream);
  *   - return value: 0 ok, <0 argument error (RRL_E_*), >0 a hipError_t;
  *   - all floating-point data is fp32, dense and contiguous;
- *   - re-entrant and thread-safe per stream.
+ *   - re-entrant and thread-safe per stream AND per workspace: no entry keeps state between calls except what the
+ *     caller's buffers hold, the options of a call are resolved once at its top (rrl_opts below), and two host threads
+ *     may drive different streams with different options concurrently (tests/test_gpu_threads.py).  Calls that share
+ *     a workspace or an output buffer must be ordered by the caller.  Process-wide state: only the DEFAULTS that the
+ *     rrl_set_* setters / RRL_* environment variables choose (read once per call), the rrl_scan_counters /
+ *     rrl_chamfer_counters hooks (profiling; use the per-call counter fields / *_ex entries from threads) and the
+ *     rrl_scan_timing ring (a profiling hook, not thread-safe);
  *
  * Layouts
  *   tri   [B][N][9]   pseudo-triangles, row = P0 P1 P2 (xyz interleaved)
@@ -67,7 +73,8 @@ extern "C" {
 /* workspace fields (indices into rrl_workspace_layout's offset array) */
 enum {
     RRL_WS_STATUS = 0, /* int32[4]   [0] = NaN seen (reference exit(0), loss.py:89-91); [1] = wavefronts of the
-                          culled scan that fell back to the strict loop; [3] = internal ticket */
+                          culled scan that fell back to the strict loop; [2] = samples whose exchange reduce was repaired
+                          by their last workgroup after a hand-off time-out (rrl_set_spin_limit); [3] = internal ticket */
     RRL_WS_NVALS,      /* int32[B]   (unused since the compact-slot layout; kept for ABI stability) */
     RRL_WS_NSEL,       /* int32[B]   selected lines per sample (length of SEL[b])           */
     RRL_WS_PMAX,       /* uint32[2][B] bits of max |P|^2 per cloud and sample                */
@@ -235,9 +242,12 @@ int rrl_registration_backward(const float *src, const float *R, const float *tri
 /* Forward + direct backward of the fused training op in ONE call -- what a training step does when dL/dloss is
  * known up front (grad_loss [B], usually ones): rpm/Train_RPM.py:226-259, dcp/Train_DCP.py:246-270 compute the loss
  * and call backward() right away.  Same arguments and results as rrl_registration_forward_cached followed by
- * rrl_registration_backward(grad_src = NULL); where the tail kernel serves the shape (2 .. 32 line tiles per sample,
- * not deterministic mode) the backward rides in the reduce's launch: 5 launches per step, the two kernels' chains of
- * dependent loads overlap.  gR [B][9], gt [B][3], payload [14] or NULL: ideally the workspace's GACC field. */
+ * rrl_registration_backward(grad_src = NULL); where the tail kernel serves the shape (auto mode: 2 .. 16 line tiles per
+ * sample and B x tiles <= 128; not in deterministic mode) the backward rides in the reduce's launch -- 4 launches per
+ * step with prepared orders (rrl_opts), 5 without -- and the two kernels' chains of dependent loads overlap; a single
+ * tile of lines (L <= 1024) is finished by one workgroup per sample (per-line stage + reduce + backward); every other
+ * shape runs the forward and then the backward launch.  gR [B][9], gt [B][3], payload [14] or NULL: ideally the
+ * workspace's GACC field. */
 int rrl_registration_step(const float *src, const float *R, const float *t, const float *tri2,
                           const float *line, void *ws, size_t ws_bytes, float *loss, const float *grad_loss,
                           float *gR, float *gt, float *payload, int B, int N, int M, int L, int transpose_r,
@@ -258,6 +268,9 @@ int rrl_registration_step(const float *src, const float *R, const float *t, cons
  * of a row places it.  ws: scratch of rrl_cloud_order_workspace_bytes(B, n) bytes.  n <= 65536. */
 size_t rrl_cloud_order_workspace_bytes(int B, int n);
 int rrl_cloud_order(const float *tri, int32_t *order, void *ws, size_t ws_bytes, int B, int n, void *stream);
+/* the same for point clouds pts [B][n][3] (the Chamfer monitor's inputs: rrl_chamfer_tree_fwd_ex); a cloud of
+ * pseudo-triangles and the cloud of their first points have the same order */
+int rrl_cloud_order_points(const float *pts, int32_t *order, void *ws, size_t ws_bytes, int B, int n, void *stream);
 
 /* The fused entries with per-call options (rrl_opts above; NULL = defaults = the plain entries). */
 int rrl_loss_forward_ex(const float *tri1, const float *tri2, const float *line, void *ws, size_t ws_bytes,
@@ -351,20 +364,40 @@ int rrl_loss_reduce_rows(const float *rows16, const uint8_t *kj, int nrows, int3
                          float *med, int32_t *bcnt, int64_t *bsum, int32_t *info, const int32_t *status, int s_m,
                          int s_n, int e_m, int e_n, void *stream);
 
-/* Which reduce kernel rrl_loss_reduce (and the fused forwards) launch.  0 = automatic: for independent samples with
- * 2 .. 32 line tiles the TAIL kernel (one 1024-lane workgroup per 1024-line tile of a sample; the median's first radix
- * pass comes as a histogram from the per-line stage, every workgroup re-reads its sample's compact D tiles from the L2
- * and selects the median itself -- no exchange --, fixed-point bucket sums by device atomics, the last workgroup to
- * arrive writes the loss); beyond 32 tiles, while B x tiles <= 1024, the tiled kernel WITH the candidate exchange
- * through the workspace (round 3a); else the single 1024-lane workgroup per sample.  1 = always the single workgroup;
- * 2 = tiled wherever legal (the tail kernel also for one tile); 3 = the exchange kernel wherever legal.  Bit-identical
- * median, loss and bucket sums in every case.  Env RRL_REDUCE=single|tiled|xchg sets the initial state. */
+/* Which reduce kernel rrl_loss_reduce (and the fused forwards) launch -- the DEFAULT; a call's rrl_opts.reduce_mode
+ * overrides it.  Three kernels, bit-identical median, loss and bucket sums (csrc/rrl_sparse.hip reduce_kind):
+ *   single   one 1024-lane workgroup per sample (always legal; the only one for pool != 0);
+ *   xchg     loss_reduce_tiled_kernel: one 256-lane workgroup per 1024-line tile; the median's first radix pass comes as a
+ *            histogram from the per-line stage, the tiles exchange the values of the median's bin through the workspace
+ *            (two tickets, bounded spins; a hand-off that times out is repaired by the sample's last workgroup, see
+ *            rrl_set_spin_limit).  Legal while B x tiles <= the number of its workgroups that are co-resident on the
+ *            device (compute units x occupancy, queried once per device; 1280 on a whole MI355X);
+ *   tail     loss_tail_kernel: no exchange (every workgroup streams its sample's dense D-value lists and selects the
+ *            median itself, one ticket, no spin), and the direct / scatter backward can ride in the same launch.
+ *            Legal for <= 32 tiles per sample and B x tiles <= 128.
+ * mode 0 (auto): tail where a backward rides along (rrl_registration_step, rrl_loss_step), the sample has 2 .. 16 tiles
+ *   and B x tiles <= 128; else xchg for >= 2 tiles within its capacity; else single.  A forward alone never takes the
+ *   tail kernel in auto mode (as a reduce alone it is 1.7 us slower than xchg).  A single tile of lines (L <= 1024) is
+ *   finished by one workgroup per sample together with the per-line stage (and the direct backward).
+ * mode 1: single everywhere.  mode 2 ("tiled"): tail wherever it is legal (also forward only, also one tile), xchg
+ * beyond, else single.  mode 3 ("xchg"): xchg wherever it is legal (also one tile), else single.
+ * Env RRL_REDUCE=single|tiled|xchg sets the initial default. */
 int rrl_set_reduce_mode(int mode);
 
 /* Workgroups per cloud of the cell sort + sphere-tree kernel (they share nothing but their input: each owns a range
  * of supergroups): 0 = default (one: more measured no faster, csrc/rrl_cull.hip sort_parts), k = 1..16 forced.  Any value gives the same labels, loss and Chamfer
  * keys; the order of records INSIDE a grid cell may differ.  Env RRL_SORT_PARTS sets the initial state. */
 int rrl_set_sort_parts(int parts);
+
+/* Test hooks of the in-launch hand-offs.  rrl_set_spin_limit: polls a waiting workgroup of the exchange reduce makes
+ * before it gives up (default 2^18, a fraction of a second; env RRL_SPIN_LIMIT).  A hand-off that times out -- its
+ * partners were not co-resident in time: a partitioned device, a CU mask, another process holding the slots -- is
+ * REPAIRED inside the same launch by the sample's last workgroup (bit-identical result; STATUS[2] counts the repaired
+ * samples); 0 makes every hand-off time out, which is how the tests drive that path.  rrl_debug_occupy: a filler launch
+ * of `workgroups` x `lanes` threads that hold their compute-unit slots until the 100 MHz wall clock has advanced by
+ * `ticks` (contention tests: a second stream / process that leaves the library only part of the device). */
+int rrl_set_spin_limit(long long polls);
+int rrl_debug_occupy(int workgroups, int lanes, long long ticks, void *stream);
 
 /* Tuning/testing knobs.  rrl_set_scan_variant: lines per lane of the scan (1 = scalar fp32,
  * 2 / 4 / 8 = one / two / four packed v_pk_*_f32 pairs); 0 = default.  All variants give
@@ -477,6 +510,19 @@ int rrl_chamfer_from_loss(void *ws_src, const void *ws_tar, size_t loss_ws_bytes
  * are dropped; cleared by the caller): [0] patch-level leaf tests, [1] per-lane leaf tests, [2] (query, leaf)
  * entries evaluated, [3] (query, target) pairs evaluated, [4] 1, [5..7] / [9..14] shader clocks of the phases. */
 int rrl_chamfer_counters(uint64_t *dev_counters, long long rows);
+/* The two tree-walk entries with the counter table given PER CALL (NULL: the plain kernel) instead of through the
+ * process-wide hook above: two threads / streams can profile independently.  rrl_chamfer_tree_fwd_ex also takes
+ * PREPARED clouds: order_x [B][64 ceil(N/64)], order_y [B][64 ceil(M/64)] from rrl_cloud_order on the same clouds in any
+ * rigid pose (point clouds: call it on (B, n, 9) rows whose first three floats are the points, or on the pseudo-
+ * triangles they are the first points of) -- both given, the per-call sort is replaced by one wide launch that writes
+ * the records at their sorted positions and refits the sphere tree; keys and value are the same bits (any permutation
+ * gives the same minima and first-occurrence argmins). */
+int rrl_chamfer_tree_fwd_ex(const float *x, const float *y, void *ws, size_t ws_bytes, uint64_t *best_x,
+                            uint64_t *best_y, float *value, int B, int N, int M, const int32_t *order_x,
+                            const int32_t *order_y, uint64_t *counters, long long counter_rows, void *stream);
+int rrl_chamfer_from_loss_ex(void *ws_src, const void *ws_tar, size_t loss_ws_bytes, int B, int N, int M,
+                             int L, void *ws, size_t ws_bytes, uint64_t *best_x, uint64_t *best_y, float *value,
+                             uint64_t *counters, long long counter_rows, void *stream);
 int rrl_chamfer_bwd(const float *x, const float *y, const uint64_t *best_x,
                     const uint64_t *best_y, const float *grad_value, float *gx, float *gy, int B,
                     int N, int M, void *stream);

@@ -160,6 +160,10 @@ def _worker_rows(rank, world, port, out):
     rows = (1000.0 * rank + 16.0 * torch.arange(n, dtype=torch.float32)[:, None] + torch.arange(16, dtype=torch.float32)[None, :])
     kj = ((rank + torch.arange(n)) % 4 + 1 + 16 * ((rank + 2 * torch.arange(n)) % 4 + 1)).to(torch.uint8)
     allr, allk = rdist.gather_rows(rows, kj)
+    # round 4: a per-rank flag (the scan's NaN flag) rides in the sizes' all-gather: the maximum comes back on every rank
+    r2, k2, fl = rdist.gather_rows(rows, kj, flag=torch.tensor([1 if rank == 2 else 0], dtype=torch.int32))
+    r3, k3, f0 = rdist.gather_rows(rows, kj, flag=torch.tensor([0], dtype=torch.int32))
+    assert torch.equal(r2, allr) and torch.equal(k2, allk) and int(fl) == 1 and fl.dtype == torch.int32 and int(f0) == 0
     lo, hi = rdist.shard_bounds(7001, rank, world)
     if rank == world - 1:
         torch.save(dict(rows=allr, kj=allk, last=(lo, hi)), out)

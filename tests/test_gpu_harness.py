@@ -180,9 +180,10 @@ def test_fragments_draw_their_own_lines(C, G):
     assert torch.equal(c0[2], c0b[2]) and torch.equal(c0[0], c0b[0])  # reproducible under the CPU seed
     C.DEVICE_RNG = True           # opt-in: the GPU generator draws the candidates
     try:
-        torch.manual_seed(3)
-        a = C.dcp_intersection_loss(d, R, t, n_lines=2000)
-        torch.manual_seed(3)
+        from rrl_hip import ops
+        ops.sampler_rng(seed=3)   # (explicit: re-seeding torch with the SAME seed while nothing else drew from its CUDA
+        a = C.dcp_intersection_loss(d, R, t, n_lines=2000)  # generator is invisible to the sampler, ops.sampler_rng)
+        ops.sampler_rng(seed=3)
         b = C.dcp_intersection_loss(d, R, t, n_lines=2000)
     finally:
         C.DEVICE_RNG = False
@@ -398,8 +399,16 @@ def test_bench_line_describes_what_it_times():
     assert dr["kernel"].startswith("scan_kernel") and dr["launch_ms"] > run["ms_per_step"] and 0.4 < dr["frac"] < 1.0
     assert dr["loss_bit_identical_to_default_mode"] is True
     v = run["variants"]
-    assert run["value_8d"] == v["points1_grad"]["value"] and run["ms_per_step_8d"] == v["points1_grad"]["ms_per_step"]
-    assert run["ms_per_step"] < run["ms_per_step_8d"] < v["dropin_loop"]["ms_per_step"]
+    # round 4: value_8d = SURVEY 8(d) by direct issue (ops.LossStep); the autograd chain of the drop-in callables stays
+    # beside it; the timed step runs the prepared build (orders computed once, outside the timed region) and the cold
+    # step (records + cell sort every step) is reported as a variant with the same loss bits
+    d8 = v["points1_grad_direct"]
+    assert run["value_8d"] == d8["value"] and run["ms_per_step_8d"] == d8["ms_per_step"]
+    assert d8["loss_bit_identical_to_fused_op"] is True and d8["points1_grad_max_rel_diff_vs_autograd_chain"] < 1e-5
+    assert d8["points1_grad_nonzero_rows"] == v["points1_grad"]["points1_grad_nonzero_rows"]
+    assert run["ms_per_step"] < run["ms_per_step_8d"] < v["points1_grad"]["ms_per_step"] < v["dropin_loop"]["ms_per_step"]
     assert v["dropin_loop"]["loss_sum"] == pytest.approx(v["points1_grad"]["loss_sum"], rel=1e-6)
     assert v["dropin_loop"]["dR_max_rel_diff_vs_fused"] < 1e-5 and v["points1_grad"]["dR_max_rel_diff_vs_fused"] < 1e-5
+    assert run["config"]["prepared_order"] is True and run["config"]["prepare_us"] > 0 and "prepared order" in run["config"]["workload"]
+    assert v["cold_step"]["loss_bit_identical_to_prepared"] is True and v["cold_step"]["ms_per_step"] > run["ms_per_step"]
     assert run["config"]["allreduce"]["process_group"] is False

@@ -1236,12 +1236,30 @@ def test_sampler_library_generator(L):
     g(); first = buf.clone()
     g(); second = buf.clone()
     assert not torch.equal(first, second)
-    # seeding follows torch: the same torch seed, the same lines; successive calls differ
+    # seeding follows torch's SEED without touching torch's generator (round 4): a new torch seed starts a new
+    # stream, the same seed after a re-seed reproduces it, other GPU draws in between neither re-seed the sampler nor are
+    # they shifted by it (torch's offset is never moved), and successive calls differ
+    gen = torch.cuda.default_generators[torch.cuda.current_device()]
     torch.manual_seed(7)
-    m1, m1b = draw().clone(), draw().clone()
-    torch.manual_seed(7)
+    off0 = gen.get_offset()
+    m1 = draw().clone()
+    assert gen.get_offset() == off0  # the sampler left torch's generator where it was
+    torch.rand(1000, device="cuda")  # somebody else draws on the GPU (dropout, rand ...): no re-seed, the stream goes on
+    m1b = draw().clone()
+    torch.manual_seed(8)
+    m3 = draw().clone()
+    torch.manual_seed(7)             # seen: the seed changed
     m2 = draw().clone()
-    assert torch.equal(m1, m2) and not torch.equal(m1, m1b) and not torch.equal(m1, a)
+    torch.rand(1000, device="cuda")
+    m2b = draw().clone()
+    torch.manual_seed(7)             # seen: same seed, but torch's offset went backwards
+    m4 = draw().clone()
+    assert torch.equal(m1, m2) and torch.equal(m1b, m2b) and torch.equal(m1, m4)
+    assert not torch.equal(m1, m1b) and not torch.equal(m1, a) and not torch.equal(m1, m3)
+    ops.sampler_rng(seed=99)         # explicit
+    e1 = draw().clone()
+    ops.sampler_rng(seed=99)
+    assert torch.equal(e1, draw())
 
 
 def test_box_accept_bit_exact(L, oracle):

@@ -253,3 +253,44 @@ def test_prepared_autograd_ops(L):
     assert torch.equal(out[0][0], out[1][0])
     for x, y in zip(out[0][1:], out[1][1:]):
         np.testing.assert_allclose(y.cpu().numpy(), x.cpu().numpy(), rtol=2e-5, atol=2e-6 * float(x.abs().max()))
+
+
+@pytest.mark.parametrize("B,N,M", [(2, 1024, 700), (8, 4096, 4096), (1, 5000, 4100), (3, 65, 64), (1, 16400, 300)])
+def test_chamfer_with_prepared_orders(L, B, N, M):
+    """ops.chamfer(x, y, order_x, order_y): the per-call sort replaced by the prepared build (records at their sorted
+    positions + tree refit).  The u64 keys (distance bits << 32 | first-occurrence argmin) of both directions and the
+    value equal the sorting path's and the all-pairs kernel's bit for bit -- with orders taken from the point clouds, from
+    the pseudo-triangles they are the first points of (the same order), and from ANOTHER pose of the clouds."""
+    from rrl_hip import ops
+    from test_gpu_parity import _chamfer_keys
+    prs, t1, t2 = _pairs(600, B, N, M)
+    x, y = t1[..., :3].contiguous(), t2[..., :3].contiguous()
+    ox, oy = ops.cloud_order(x), ops.cloud_order(y)
+    assert torch.equal(ox, ops.cloud_order(t1)) and torch.equal(oy, ops.cloud_order(t2))
+    Rm = cu(np.stack([_rot((0.3, 0.5, 0.8), 77)] * B))
+    moved = ops.rigid_apply(x, Rm, cu(np.full((B, 3), 0.4, np.float32)))
+    o_other = ops.cloud_order(moved)
+
+    def keys(order_x, order_y):
+        ops._Chamfer.apply(x, y, order_x, order_y)  # warm
+        dev = x.device
+        bx = torch.empty(B, N, dtype=torch.int64, device=dev)
+        by = torch.empty(B, M, dtype=torch.int64, device=dev)
+        val = torch.empty(1, device=dev)
+        nb = int(ops._lib.load().rrl_chamfer_workspace_bytes(B, N, M))
+        ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+        ops._run(dev, "rrl_chamfer_tree_fwd_ex", ops._p(x), ops._p(y), ops._p(ws), nb, ops._p(bx), ops._p(by), ops._p(val), B, N, M,
+                 ops._p(order_x), ops._p(order_y), None, 0)
+        torch.cuda.synchronize()
+        return bx, by, val
+
+    plain = keys(None, None)
+    for oxx, oyy in ((ox, oy), (o_other, oy)):
+        got = keys(oxx, oyy)
+        for a, b_ in zip(plain, got):
+            assert torch.equal(a, b_)
+    brute = _chamfer_keys(x.cpu().numpy(), y.cpu().numpy(), False)
+    np.testing.assert_array_equal(plain[0].cpu().numpy().view(np.uint64), brute[0])
+    np.testing.assert_array_equal(plain[1].cpu().numpy().view(np.uint64), brute[1])
+    v = ops.chamfer(x, y, order_x=ox, order_y=oy)
+    assert float(v) == float(ops.chamfer(x, y))
