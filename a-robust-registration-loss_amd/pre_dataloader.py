@@ -44,6 +44,39 @@ def M(axis, theta):
     return np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * (K @ K)
 
 
+def kd_order(points):
+    """Spatial order of a cloud for the prepared build of the loss (include/rrl.h rrl_opts.order1 / order2; the
+    host-side twin of rrl_cloud_order): int32 (64 ceil(n / 64),) sorted position -> point index, positions >= n hold 0.
+    Positions [0, P), P = the power of two >= n, form an implicit binary tree of aligned windows; every window sorts
+    its points along the longest axis of their bounding box (stable, ties by index), so its lower half of positions
+    receives the points below the median plane -- aligned runs of 64 / 16 / 8 positions are compact k-d cells.  ANY
+    permutation gives the same loss bits; this one only makes the culled scan's tree nodes tight.  points (n, 3)."""
+    pts = np.asarray(points, np.float64).reshape(-1, 3)
+    n = len(pts)
+    npad = (n + 63) // 64 * 64
+    out = np.zeros(npad, np.int32)
+    if n == 0:
+        return out
+    P = 64
+    while P < n:
+        P *= 2
+
+    def split(idx, S):  # idx: the points of an aligned window of S positions (len(idx) <= S, filled from the left)
+        if S <= 8 or len(idx) <= 1:
+            return idx
+        p = pts[idx]
+        ax = int(np.argmax(p.max(0) - p.min(0)))
+        idx = idx[np.lexsort((idx, p[:, ax]))]
+        h = S // 2
+        if len(idx) <= h:
+            return split(idx, h)
+        return np.concatenate([split(idx[:h], h), split(idx[h:], h)])
+
+    order = split(np.arange(n), P)
+    out[:n] = order
+    return out
+
+
 def read_obj_vertices(path):
     """(V, 3) float64 rows of the "v" records, what igl.read_triangle_mesh returns as V."""
     rows = []
@@ -93,12 +126,13 @@ def write_pair(directory, mesh_idx, view_idx, src, tar, src_neigh, tar_neigh, tr
 class Dataset_2021_8_29(Dataset):
     """pre_dataloader.py:28-181; see the module docstring for the item dict."""
 
-    def __init__(self, points_files_src_sample, points_files_tar_sample, DCP_True=False, FMR_True=False):
+    def __init__(self, points_files_src_sample, points_files_tar_sample, DCP_True=False, FMR_True=False, with_orders=True):
         self.points_files_src_sample = points_files_src_sample
         self.points_files_tar_sample = points_files_tar_sample
         self.randg = np.random.RandomState(0)
         self.DCP_True = DCP_True
         self.FMR_True = FMR_True
+        self.with_orders = with_orders  # add 'order_src' / 'order_tar' (kd_order) to every item
 
     @staticmethod
     def transform_R_T(points, R, T):
@@ -175,6 +209,13 @@ class Dataset_2021_8_29(Dataset):
             and data['points_based_neighs_tar'].shape[0] == 3 * data['points_tar_sample'].shape[0]
             and np.array_equal(data['points_based_neighs_src'].reshape(-1, 9)[:, :3], data['points_src_sample'])
             and np.array_equal(data['points_based_neighs_tar'].reshape(-1, 9)[:, :3], data['points_tar_sample']))
+        # beyond the reference's keys (round 4): the spatial ORDER of both clouds of pseudo-triangles, computed once per item
+        # here on the host (kd_order below: any permutation gives the same loss, this one makes the culled scan fast; a
+        # rigid motion -- the predicted pose, the augmentation -- preserves it).  rrl_hip.callsites hands them to the
+        # fused op (rrl_opts.order1 / order2): the per-step cell sort disappears for every pose of the batch.
+        if self.with_orders:
+            data['order_src'] = kd_order(data['points_based_neighs_src'].reshape(-1, 9)[:, :3])
+            data['order_tar'] = kd_order(data['points_based_neighs_tar'].reshape(-1, 9)[:, :3])
         if self.DCP_True is True:  # channel-first clouds, transposed rotations
             for k in ('points_tar_sample', 'points_src_sample', 'points_based_neighs_src',
                       'points_based_neighs_tar', 'R', 'R_inv'):

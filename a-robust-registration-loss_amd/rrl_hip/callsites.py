@@ -100,15 +100,33 @@ def draw_lines(radius, centers, n_lines, moved_src, tar, device=None, device_rng
         radius, centers, n_lines, moved_src, tar, device, device_rng=device_rng)
 
 
-def per_sample_loss(src_nb, R, t, tar_tri, lines, mode=None, target_from=None):
+USE_ORDERS = True  # hand the dataset's 'order_src' / 'order_tar' (pre_dataloader.kd_order, or ops.cloud_order) to the fused
+#   op: the prepared build -- no cell sort in any pose's step; same loss bits.  False: ignore them.
+
+
+def _orders(data, n_src, n_tar):
+    """(order1, order2) from the trainer's dict when it carries usable ones -- int32 (B, 64 ceil(n / 64)) tensors on the
+    GPU, as the DataLoader collates pre_dataloader's per-item arrays -- else (None, None): the fused op then sorts."""
+    if not USE_ORDERS or data is None:
+        return None, None
+    o1, o2 = data.get('order_src'), data.get('order_tar')
+    ok = all(isinstance(o, torch.Tensor) and o.is_cuda and o.dtype == torch.int32 and o.dim() == 2 and o.is_contiguous()
+             and o.shape[1] == (n + 63) // 64 * 64 for o, n in ((o1, n_src), (o2, n_tar)))
+    return (o1, o2) if ok else (None, None)
+
+
+def per_sample_loss(src_nb, R, t, tar_tri, lines, mode=None, target_from=None, data=None):
     """loss[b] of the pseudo-triangles `src_nb` (B, 3N, 3) or (B, N, 9) moved by x -> R x + t,
     against tar_tri (B, M, 9) along lines (B, L, 6).  (loss (B,), valid (B,) bool).
     target_from: ops.last_state() of an earlier call with the same tar_tri and lines, whose
-    target scan is reused (the iterative trainers keep target and lines fixed across poses)."""
+    target scan is reused (the iterative trainers keep target and lines fixed across poses).
+    data: the trainer's dict; when it carries the clouds' spatial orders ('order_src', 'order_tar') the prepared build
+    is used (the source's order holds for every pose: a rigid motion preserves it)."""
     B = src_nb.shape[0]
-    loss, info, _ = _ops.registration_loss(src_nb.reshape(B, -1, 9), R, t, tar_tri.reshape(B, -1, 9),
-                                           lines, RNG, transpose_r=True, mode=_mode(mode),
-                                           target_from=target_from)
+    src_tri, tar_tri = src_nb.reshape(B, -1, 9), tar_tri.reshape(B, -1, 9)
+    o1, o2 = _orders(data, src_tri.shape[1], tar_tri.shape[1])
+    loss, info, _ = _ops.registration_loss(src_tri, R, t, tar_tri, lines, RNG, transpose_r=True, mode=_mode(mode),
+                                           target_from=target_from, order1=o1, order2=o2)
     return loss, info[:, 0] > 0
 
 
@@ -136,7 +154,7 @@ def rpm_intersection_loss(pred_transforms, data, n_lines=10000, lines=None, mode
         if lines is None:
             lines = draw_lines(bounding_radius(data['tar_box']), data['centers'], n_lines,
                                moved.detach(), tar)
-        loss, ok = per_sample_loss(data['points_based_neighs_src'], R, t, tar_tri, lines, mode, first)
+        loss, ok = per_sample_loss(data['points_based_neighs_src'], R, t, tar_tri, lines, mode, first, data=data)
         first = first or _ops.last_state()
         per_iter.append(loss.sum().reshape(1) / num_iter)
         chamfers.append(_monitor(moved, tar, data).detach())
@@ -162,7 +180,7 @@ def dcp_intersection_loss(data, rotation_ab_pred, translation_ab_pred, n_lines=1
         lines = draw_lines(bounding_radius(data['tar_box'], 0.5), data['centers'], n_lines,
                            moved.detach(), tar)
     src_nb = data['points_based_neighs_src'].transpose(2, 1).contiguous()
-    loss, ok = per_sample_loss(src_nb, rotation_ab_pred, translation_ab_pred, tar_tri, lines, mode)
+    loss, ok = per_sample_loss(src_nb, rotation_ab_pred, translation_ab_pred, tar_tri, lines, mode, data=data)
     chamfer = _monitor(moved, tar, data, channel_first=True)  # the reference evaluates it before the loss; it depends on neither
     return (loss / 5.0).sum().reshape(1) / B, chamfer, lines, ok
 
@@ -184,7 +202,7 @@ def fmr_intersection_loss(g_series, data, n_lines=15000, lines=None, last=3, mod
     total, valid, first = 0.0, [], None
     for i in range(maxiter - last, maxiter):
         R, t = _split(g_series[i])
-        loss, ok = per_sample_loss(data['points_based_neighs_src'], R, t, tar_tri, lines, mode, first)
+        loss, ok = per_sample_loss(data['points_based_neighs_src'], R, t, tar_tri, lines, mode, first, data=data)
         first = first or _ops.last_state()
         total = total + (loss / 5.0).sum().reshape(1) * 0.5 ** (maxiter - i - 1)
         valid.append(ok)

@@ -36,7 +36,7 @@ def test_items_match_the_reference(P, files, tag, kw):
     assert len(ds) == 2
     for i in range(2):
         item = ds[i]
-        assert set(item) == set(KEYS) | {"p0_rows"}  # the reference's keys + the shim's first-points flag
+        assert set(item) == set(KEYS) | {"p0_rows", "order_src", "order_tar"}  # the reference's keys + the shim's own
         for k in KEYS:
             want = g[f"{tag}{i}_{k}"]
             assert item[k].shape == want.shape and item[k].dtype == want.dtype, (k, item[k].shape, want.shape)
@@ -66,7 +66,11 @@ def test_random_data_matches_the_reference(P, files):
     item["normals_ref"] = item["normals_tar"]
     np.random.seed(33)
     aug = ds.random_data(item)
+    before = {k: item[k].copy() for k in ("order_src", "order_tar")}
     for k in aug:
+        if k in ("order_src", "order_tar"):  # the shim's own keys: a rigid motion keeps the spatial order valid
+            np.testing.assert_array_equal(aug[k], before[k])
+            continue
         np.testing.assert_allclose(aug[k], g[f"aug0_{k}"], rtol=1e-5, atol=1e-6, err_msg=k)
     np.testing.assert_allclose(P.M(g["M_axis"], g["M_theta"]), g["M_out"], atol=1e-14)
 

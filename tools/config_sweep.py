@@ -1,4 +1,5 @@
-"""Step time (fused forward + backward, hipGraph replay) at the BASELINE.json configs that are not
+"""Step time (fused forward + backward: hipGraph replay and direct issue, prepared k-d orders; direct issue of the cold
+-- sorting -- step beside it) at the BASELINE.json configs that are not
 the bench line: C1 demo (B=1, N=M=1024, L=20000), C4 (N=2048, M=1024 cropped), C5 (N=M=16384,
 L=512), plus L=4096 / L=20000 at the C2 shape.  With arguments "B,N,M,L" ...
 it times those shapes instead."""
@@ -39,9 +40,10 @@ def run(name, B, N, M, L, crop=False, noise=0.01, diag=None):
     R = torch.eye(3, device="cuda").repeat(B, 1, 1).requires_grad_(True)
     t = torch.zeros(B, 3, device="cuda").requires_grad_(True)
     ones = torch.ones(B, device="cuda")
+    o1, o2 = (ops.cloud_order(src), ops.cloud_order(tar)) if max(N, M) <= 65536 else (None, None)
     def f():
         R.grad = t.grad = None
-        loss, info, _ = ops.registration_loss(src, R, t, tar, ln, mode=os.environ.get("RRL_SCAN_MODE", "cull"))
+        loss, info, _ = ops.registration_loss(src, R, t, tar, ln, mode=os.environ.get("RRL_SCAN_MODE", "cull"), order1=o1, order2=o2)
         torch.autograd.backward([loss], [ones])
         return loss, info
     g = GraphedStep(f)
@@ -52,14 +54,18 @@ def run(name, B, N, M, L, crop=False, noise=0.01, diag=None):
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
     pairs = B * L * 3 * (N + M)
     # the same step issued as two plain C calls (ops.RegistrationStep: no autograd node, no graph)
-    rs = ops.RegistrationStep(src, tar, L, transpose_r=True, mode=os.environ.get("RRL_SCAN_MODE", "cull"))
     Rd, td = R.detach(), t.detach()
-    for _ in range(10): rs(Rd, td, ln)
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(n): rs(Rd, td, ln)
-    torch.cuda.synchronize(); dd = (time.perf_counter() - t0) / n
+    times = {}
+    for prepared in (True, False):
+        rs = ops.RegistrationStep(src, tar, L, transpose_r=True, mode=os.environ.get("RRL_SCAN_MODE", "cull"), prepared=prepared,
+                                  src_order=o1 if prepared else None, tar_order=o2 if prepared else None)
+        for _ in range(10): rs(Rd, td, ln)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(n): rs(Rd, td, ln)
+        torch.cuda.synchronize(); times[prepared] = (time.perf_counter() - t0) / n
+    dd = times[True]
     print(json.dumps({"mode": os.environ.get("RRL_SCAN_MODE", "cull"), "config": name, "B": B, "N": N, "M": M, "L": L, "us_per_step": round(dt * 1e6, 1),
-                      "us_per_step_direct": round(dd * 1e6, 1),
+                      "us_per_step_direct": round(dd * 1e6, 1), "us_per_step_direct_cold": round(times[False] * 1e6, 1),
                       "pairs_per_s": pairs / dt, "selected_lines": int(g.out[1][:, 1].sum()),
                       "loss0": float(g.out[0][0]), "filled_lines": int((ln.abs().sum(-1) > 0).sum()),
                       "fallback_wavefronts": int(ops.last_state().status[1])}))
