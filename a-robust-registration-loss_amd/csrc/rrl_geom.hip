@@ -590,9 +590,22 @@ __global__ __launch_bounds__(64) void se3_adam_step_kernel(float *__restrict__ x
                                                            float *__restrict__ gxi, const float *__restrict__ loss,
                                                            const float *__restrict__ value, float *__restrict__ table,
                                                            long long *__restrict__ cursor, long long nrows,
-                                                           float *__restrict__ row) {
+                                                           float *__restrict__ row, const float *__restrict__ aabb_rows,
+                                                           int n_aabb_rows, float *__restrict__ box) {
     const int k = threadIdx.x;
     const bool ok = gate == nullptr || gate[0] > 0;
+    // the moved source's AABB for the NEXT epoch's sampler (code/test_demo_optimized_Lie_Algebra.py:46-51 samples against
+    // the previous epoch's moved source) from the per-workgroup partial rows the loss step's records launch just left
+    // (APART: min xyz, max xyz of the moved first points) -- one launch (rigid apply + AABB) less per epoch
+    if (box != nullptr && k >= 8 && k < 14) {
+        const int c = k - 8;
+        float v = c < 3 ? INFINITY : -INFINITY;
+        for (int r = 0; r < n_aabb_rows; ++r) {
+            const float q = aabb_rows[(size_t)r * 8 + c];
+            v = c < 3 ? fminf(v, q) : fmaxf(v, q);
+        }
+        box[c] = v;
+    }
     const float step = state[0] + (ok ? 1.0f : 0.0f);
     float pk = k < 6 ? xi[k] : 0.0f;
     if (k < 6) {
@@ -639,10 +652,11 @@ __global__ __launch_bounds__(64) void se3_adam_step_kernel(float *__restrict__ x
 extern "C" int rrl_se3_adam_step(float *xi, const float *gR, const float *gT, float *m, float *v, float *state,
                                  const float *lr, const int32_t *gate, double b1, double b2, double eps, float *R,
                                  float *T, float *gxi, const float *loss, const float *value, float *table,
-                                 long long *cursor, long long nrows, float *row, void *stream) {
-    if (!xi || !m || !v || !state || !lr || !R || !T) return RRL_E_ARG;
+                                 long long *cursor, long long nrows, float *row, const float *aabb_rows, int n_aabb_rows,
+                                 float *box, void *stream) {
+    if (!xi || !m || !v || !state || !lr || !R || !T || (box && (!aabb_rows || n_aabb_rows <= 0))) return RRL_E_ARG;
     hipLaunchKernelGGL(se3_adam_step_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, xi, gR, gT, m, v, state, lr,
-                       gate, b1, b2, eps, R, T, gxi, loss, value, table, cursor, nrows, row);
+                       gate, b1, b2, eps, R, T, gxi, loss, value, table, cursor, nrows, row, aabb_rows, n_aabb_rows, box);
     RRL_LAUNCH_CHECK();
     return 0;
 }

@@ -65,7 +65,7 @@ _SIGS = {
     "rrl_aabb": [_P, _P, _I, _I, _P],
     "rrl_box_accept": [_P, _P, _P, _P, _P, _I, _I, _P],
     "rrl_log_row": [_P, _P, _P, _P, _P, _c.c_longlong, _P, _P],
-    "rrl_se3_adam_step": [_P] * 8 + [_c.c_double] * 3 + [_P] * 7 + [_c.c_longlong, _P, _P],
+    "rrl_se3_adam_step": [_P] * 8 + [_c.c_double] * 3 + [_P] * 7 + [_c.c_longlong, _P, _P, _I, _P, _P],
     "rrl_rigid_apply_aabb": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
     "rrl_se3_exp": [_P, _P, _P, _I, _P],
     "rrl_se3_exp_bwd": [_P, _P, _P, _P, _I, _P],

@@ -1300,14 +1300,15 @@ def rigid_apply_aabb_into(x, R, t, out, box, transpose_r=False):
 
 
 def se3_adam_step(xi, gR, gT, m, v, state, lr, gate, R, T, *, gxi=None, loss=None, value=None, table=None,
-                  cursor=None, row=None, betas=(0.9, 0.999), eps=1e-8):
+                  cursor=None, row=None, betas=(0.9, 0.999), eps=1e-8, aabb_rows=None, box=None):
     """One pose's backward through the exponential, gated Adam step, exponential of the updated xi into (R, T) and
     the log row, in one launch (rrl_se3_adam_step): all tensors contiguous fp32 on the GPU (cursor int64, gate int32),
-    xi (6,), R (.., 3, 3), T (.., 3)."""
+    xi (6,), R (.., 3, 3), T (.., 3).  aabb_rows (rows, 8) + box (6,): also the AABB over the rows' (min xyz, max xyz)
+    -- the loss state's `apart[0, 0, :ceil(N / 256)]` gives the moved source's box for the next epoch's sampler."""
     nrows = 0 if table is None else table.shape[0]
     _run(xi.device, "rrl_se3_adam_step", _p(xi), _p(gR), _p(gT), _p(m), _p(v), _p(state), _p(lr), _p(gate),
          float(betas[0]), float(betas[1]), float(eps), _p(R), _p(T), _p(gxi), _p(loss), _p(value), _p(table),
-         _p(cursor), nrows, _p(row))
+         _p(cursor), nrows, _p(row), _p(aabb_rows), 0 if aabb_rows is None else int(aabb_rows.shape[0]), _p(box))
 
 
 def log_row(loss, value, info, table, cursor, row=None):

@@ -231,19 +231,32 @@ def _run_graphed(model, draw, src, src_nb, tar, tar_tri, Save_path, writer, n_ep
     P = _ops._p
     _ops._run(dev, "rrl_se3_exp", P(xi.data), P(Rb), P(Tb), 1)  # == model.Transform() for the first epoch
 
+    # With the sampler in the graph and the point sets == the triangles' first points (round 4) nothing needs the moved
+    # POINTS inside the epoch: the sampler wants only their AABB -- the pose launch takes it from the partial rows the
+    # loss step's records launch just wrote (APART: the moved first points) -- and checkpoints read the moved first
+    # points from the step's TRI1 field.  One launch (rigid apply + AABB) less per epoch.
+    box_from_step = draw_in_graph and monitor_from_state
+    arows = None
+    if box_from_step:
+        arows = reg.st.apart[0, 0, :(src_tri.shape[1] + 255) // 256]  # a view of the workspace: rows of cloud 1, sample 0
+        assert arows.is_contiguous()
+
     def step():
-        # the whole epoch in 11 launches: sampler (2), the loss's 5 + 1, rigid apply + AABB, Chamfer, and the pose step
-        # (exp-map backward, Adam, the NEXT epoch's exp map == model.Transform(), the log row).  (Rb, Tb) always hold
-        # exp(xi): the pose launch refreshes them right after it moves xi.
+        # the whole epoch in 9 launches (10 without box_from_step): sampler (2), the loss's 4 (prepared build, kept target)
+        # + 1, [rigid apply + AABB], Chamfer, and the pose step (exp-map backward, Adam, the NEXT epoch's exp map ==
+        # model.Transform(), the log row, the next sampler box).  (Rb, Tb) always hold exp(xi): the pose launch refreshes
+        # them right after it moves xi.
         if draw_in_graph:  # lines from the previous epoch's moved source, like the reference loop
             draw(0, moved.reshape(-1, 3), out=lines, box1=box1)
         loss, gR, gt, _, info = reg(Rb, Tb, lines)                  # forward + backward to (dL/dR, dL/dT)
-        _ops.rigid_apply_aabb_into(src_pts, Rb, Tb, moved, box1)
+        if not box_from_step:
+            _ops.rigid_apply_aabb_into(src_pts, Rb, Tb, moved, box1)
         cf = _ops.chamfer_from_state(reg.st) if monitor_from_state else _ops.chamfer(moved, tar_pts)
         # skipped on the device when no bucket is populated; loss, Chamfer, valid -> row (and, with the sampler in
         # the graph, the trace table)
         _ops.se3_adam_step(xi.data, gR, gt, opt.m, opt.v, opt.step, opt.lr, info, Rb, Tb, loss=loss,
-                           value=cf.reshape(1), table=trace if draw_in_graph else scratch_row, cursor=slot, row=row)
+                           value=cf.reshape(1), table=trace if draw_in_graph else scratch_row, cursor=slot, row=row,
+                           aabb_rows=arows, box=box1.reshape(-1) if box_from_step else None)
         return row
 
     lr = 2e-2
@@ -271,7 +284,8 @@ def _run_graphed(model, draw, src, src_nb, tar, tar_tri, Save_path, writer, n_ep
             if ok:
                 print("\033[34mthis is the chamfer loss:{:4f}, loss_intersection{:4f}\033[0m".format(cf, di))
         if save_every and epoch % save_every == 0:
-            save_checkpoint(Save_path, epoch, moved.reshape(-1, 3), tar, model)
+            pts = reg.st.tri1t[0, :, :3] if box_from_step else moved.reshape(-1, 3)  # the moved first points ARE the points
+            save_checkpoint(Save_path, epoch, pts, tar, model)
     history = []
     for epoch, (di, cf, ok) in enumerate(trace[:n_epoch].tolist()):
         history.append((epoch, di, cf) if ok else (epoch, None, None))

@@ -469,11 +469,15 @@ int rrl_log_row(const float *loss, const float *value, const int32_t *info, floa
  * model.Transform(), optimizer.step(), the next epoch's Transform(), the printed/logged scalars) for ONE pose in one
  * launch: gxi = d/dxi <gR, R(xi)> + <gT, T(xi)> (rrl_se3_exp_bwd), the gated Adam step on xi (rrl_adam_gated),
  * (R, T) = exp(updated xi) (rrl_se3_exp) and, when table and cursor are given, the log row (rrl_log_row with
- * info = gate).  Bit-identical to the four calls.  gxi, loss, value, table, cursor, row may be NULL. */
+ * info = gate).  Bit-identical to the four calls.  gxi, loss, value, table, cursor, row may be NULL.
+ * box (6 floats, optional): min xyz, max xyz over aabb_rows [n_aabb_rows][8] -- the per-workgroup partial rows (APART
+ * field, cloud 1 of sample 0: rows of (min xyz, max xyz, ..)) that the loss step's records launch just wrote for the
+ * MOVED source's first points: the next epoch's sampler box (test_demo…:46-51 samples against the previous epoch's moved
+ * source) without a rigid-apply + AABB launch of its own. */
 int rrl_se3_adam_step(float *xi, const float *gR, const float *gT, float *m, float *v, float *state,
                       const float *lr, const int32_t *gate, double b1, double b2, double eps, float *R, float *T,
                       float *gxi, const float *loss, const float *value, float *table, long long *cursor,
-                      long long nrows, float *row, void *stream);
+                      long long nrows, float *row, const float *aabb_rows, int n_aabb_rows, float *box, void *stream);
 
 /* ---- Chamfer monitor (code/loss.py:38-52, 236-252) -------------------------------------- */
 /* best_x [B][N], best_y [B][M] are u64 keys (dist bits << 32 | argmin), set to all-ones by

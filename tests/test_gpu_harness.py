@@ -275,6 +275,27 @@ def test_demo_trajectory(demo, tmp_path, graph, fixture):
     assert len(rows) == 1 + 2 * n
 
 
+def test_graphed_demo_with_the_sampler_in_the_graph_saves_the_moved_source(demo, tmp_path):
+    """Round 4: with the sampler inside the captured epoch nothing computes the moved POINTS any more (the sampler's box
+    comes from the loss step's partial rows via the pose launch); a checkpoint reads the moved first points from the
+    step's TRI1 field.  `0.obj` must hold the source moved by the epoch's own pose, bit for bit what ops.rigid_apply gives,
+    and the optimisation must run as before (the sampler box of epoch 1 is the AABB of exactly those points)."""
+    from rrl_hip import ops
+    from LieAlgebra import se3
+    g = load_golden("demo_trajectory.npz")
+    data, model, _ = demo_inputs(g)
+    xi0 = model.parameters_.detach().cpu().clone()
+    hist, model = demo.test_one_case(data, str(tmp_path), n_epoch=4, n_sample_line=3000, device='cuda:0', graph=True,
+                                     device_rng=True, save_every=1, print_every=0, model=model)
+    assert all(h[1] is not None for h in hist)
+    R, T = se3.exp3(xi0)
+    want = ops.rigid_apply(data['vertics1_tensor'].reshape(1, -1, 3), R.cuda(), T.cuda()).reshape(-1, 3).cpu().numpy()
+    got = demo.read_obj_vertices(str(tmp_path / "0.obj"))
+    np.testing.assert_array_equal(got, want)
+    later = demo.read_obj_vertices(str(tmp_path / "3.obj"))
+    assert later.shape == want.shape and np.abs(later - want).max() > 1e-3  # three Adam steps moved it
+
+
 def test_demo_moved_source_flips_no_label(oracle):
     """Why the trajectory is not bit-equal: the source is moved on the GPU (FMA rigid apply) where the
     reference uses torch's CPU matmul -- the moved vertices differ by <= 2 ulp.  With the REFERENCE's own
