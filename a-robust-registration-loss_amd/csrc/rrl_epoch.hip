@@ -1,0 +1,33 @@
+// rrl_epoch.hip -- one epoch of the single-pair demo as ONE C call (include/rrl.h rrl_demo_epoch).
+//
+// code/test_demo_optimized_Lie_Algebra.py:46-82 does, per epoch: sample lines through both clouds' boxes (against the
+// PREVIOUS epoch's moved source), move the source by the current pose, evaluate the loss, backward, Adam step, Chamfer
+// monitor, log.  Every piece has its entry in this library already; this file only issues them back to back on the
+// caller's stream -- sampler (2 launches) -> fused registration step on prepared clouds (4) -> Chamfer from the loss state
+// (1) -> pose step (1: exp-map backward, gated Adam, next exp map, log row, next sampler box) -- so that a loop pays one
+// host call (~5 us) per epoch instead of a hipGraph replay (~8 us fixed + ~1.5 us per node on this stack,
+// tools/graph_node_cost.py) or eight Python-level calls.  No new arithmetic: the results are those of the four entries.
+#include "rrl_ws.h"
+
+extern "C" int rrl_demo_epoch(const rrl_demo_epoch_args *a, void *stream) {
+    if (!a || a->struct_bytes < (int32_t)sizeof(rrl_demo_epoch_args)) return RRL_E_ARG;
+    const int N = a->N, M = a->M, L = a->L;
+    if (N <= 0 || M <= 0 || L <= 0 || a->rounds <= 0) return RRL_E_ARG;
+    int rc = rrl_sample_lines_rng(a->rng_state, a->radius, a->centers, a->box1, a->box2, a->lines, a->filled, a->tile_counts,
+                                  1, L, a->rounds, stream);
+    if (rc) return rc;
+    rc = rrl_registration_step_ex(a->src_tri, a->R, a->T, a->tar_tri, a->lines, a->ws, a->ws_bytes, a->loss, a->grad_loss,
+                                  a->gR, a->gt, nullptr, 1, N, M, L, a->transpose_r, 1, 1, 5, 5, RRL_SCAN_CULL, 0, nullptr,
+                                  a->opts, stream);
+    if (rc) return rc;
+    rc = rrl_chamfer_from_loss(a->ws, a->ws, a->ws_bytes, 1, N, M, L, a->cham_ws, a->cham_ws_bytes, a->best_x, a->best_y,
+                               a->cham_value, stream);
+    if (rc) return rc;
+    const WsLayout w(1, N, M, L);
+    if (a->ws_bytes < w.total) return RRL_E_WS;
+    const int32_t *info = w.i32(a->ws, RRL_WS_INFO);        // gate: the loss's bucket count (`if loss_di is not None`)
+    const float *rows = w.f32(a->ws, RRL_WS_APART);         // cloud 1, sample 0: the moved first points' partial boxes
+    return rrl_se3_adam_step(a->xi, a->gR, a->gt, a->m, a->v, a->adam_state, a->lr, info, a->b1, a->b2, a->eps, a->R, a->T,
+                             nullptr, a->loss, a->cham_value, a->table, a->cursor, a->table_rows, a->row, rows,
+                             (N + 255) / 256, a->box1, stream);
+}

@@ -44,6 +44,7 @@ _SIGS = {
     "rrl_loss_reduce_rows": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "rrl_shard_payload": [_P, _P, _Z, _P, _P, _P, _I, _I, _I, _I, _P],
     "rrl_set_scan_variant": [_I],
+    "rrl_demo_epoch": [_P, _P],
     "rrl_set_spin_limit": [_c.c_longlong],
     "rrl_debug_occupy": [_I, _I, _c.c_longlong, _P],
     "rrl_set_deterministic": [_I],
@@ -92,6 +93,19 @@ class Opts(ctypes.Structure):
                  order2=None, scan_counters=None, scan_counter_rows=0):
         super().__init__(ctypes.sizeof(Opts), int(flags), int(reduce_mode), int(deterministic), int(sort_parts),
                          int(scan_variant), order1, order2, scan_counters, int(scan_counter_rows))
+
+class DemoEpochArgs(ctypes.Structure):
+    """include/rrl.h rrl_demo_epoch_args (same field order)."""
+    _fields_ = [("struct_bytes", _c.c_int32), ("N", _c.c_int32), ("M", _c.c_int32), ("L", _c.c_int32),
+                ("rounds", _c.c_int32), ("transpose_r", _c.c_int32),
+                ("rng_state", _P), ("radius", _P), ("centers", _P), ("box1", _P), ("box2", _P), ("lines", _P),
+                ("filled", _P), ("tile_counts", _P),
+                ("src_tri", _P), ("tar_tri", _P), ("R", _P), ("T", _P), ("ws", _P), ("ws_bytes", _Z), ("loss", _P),
+                ("grad_loss", _P), ("gR", _P), ("gt", _P), ("opts", _P),
+                ("cham_ws", _P), ("cham_ws_bytes", _Z), ("best_x", _P), ("best_y", _P), ("cham_value", _P),
+                ("xi", _P), ("m", _P), ("v", _P), ("adam_state", _P), ("lr", _P), ("b1", _c.c_double), ("b2", _c.c_double),
+                ("eps", _c.c_double), ("table", _P), ("cursor", _P), ("table_rows", _c.c_longlong), ("row", _P)]
+
 
 _lib = None
 

@@ -17,7 +17,7 @@ CSRC = os.path.join(PKG, "csrc")
 EXP_FLAGS = os.environ.get("RRL_HIPCC_FLAGS", "").split()
 LIBDIR = os.path.join(PKG, "lib_exp" if EXP_FLAGS else "lib")
 LIB = os.path.join(LIBDIR, "librrl_hip.so")
-SOURCES = ["rrl_scan.hip", "rrl_cull.hip", "rrl_sparse.hip", "rrl_geom.hip", "rrl_neigh.hip", "rrl_chamfer.hip", "rrl_order.hip"]
+SOURCES = ["rrl_scan.hip", "rrl_cull.hip", "rrl_sparse.hip", "rrl_geom.hip", "rrl_neigh.hip", "rrl_chamfer.hip", "rrl_order.hip", "rrl_epoch.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
          "-Wall", "-Wno-unused-function"]
 

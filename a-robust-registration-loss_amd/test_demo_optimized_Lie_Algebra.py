@@ -142,6 +142,7 @@ def _default_lines(radius, centers, n_sample_line, target, device, device_rng=Fa
             radius.reshape(1, 1), centers.reshape(1, -1), n_sample_line, moved.view(1, -1, 3),
             target.view(1, -1, 3), device, device_rng=device_rng, out=out, box2=box2[0], box1=box1)
         return lines.detach().view(-1, 6)
+    draw.sampler = (radius, centers, n_sample_line, target, box2)  # for the one-call epoch (rrl_demo_epoch)
     return draw
 
 
@@ -259,6 +260,15 @@ def _run_graphed(model, draw, src, src_nb, tar, tar_tri, Save_path, writer, n_ep
                            aabb_rows=arows, box=box1.reshape(-1) if box_from_step else None)
         return row
 
+    # ONE C call per epoch (round 4, include/rrl.h rrl_demo_epoch: sampler -> fused step -> Chamfer from the step's state ->
+    # pose step, issued back to back) instead of a hipGraph replay of the same launches: a replay costs ~8 us + ~1.5 us per
+    # node on this stack (tools/graph_node_cost.py), the call ~5 us of host time.  Same launches, same results.
+    # RRL_DEMO_ISSUE=graph keeps the replay.
+    epoch_call = None
+    if box_from_step and hasattr(draw, "sampler") and reg.prepared and os.environ.get("RRL_DEMO_ISSUE", "call") != "graph":
+        epoch_call = _one_call_epoch(draw, reg, lines, box1, xi, opt, Rb, Tb, trace, slot, row, n_epoch + WARM)
+        slot.zero_()
+
     lr = 2e-2
     stepper = None
     for epoch in range(n_epoch):
@@ -268,7 +278,9 @@ def _run_graphed(model, draw, src, src_nb, tar, tar_tri, Save_path, writer, n_ep
         if new_lr != lr or epoch == 0:
             opt.set_lr()
         lr = new_lr
-        if stepper is None:
+        if epoch_call is not None:
+            epoch_call(epoch)
+        elif stepper is None:
             # the warm-up runs inside GraphedStep must not move the state: snapshot, restore
             state = (xi.data, opt.m, opt.v, opt.step, moved, slot, Rb, Tb, box1)
             keep = [t.clone() for t in state]
@@ -276,9 +288,10 @@ def _run_graphed(model, draw, src, src_nb, tar, tar_tri, Save_path, writer, n_ep
             stepper = GraphedStep(step, warmup=WARM)
             for t, k in zip(state, keep):
                 t.copy_(k)
-        out = stepper()
-        if not draw_in_graph:
-            trace[epoch].copy_(out)
+        if epoch_call is None:
+            out = stepper()
+            if not draw_in_graph:
+                trace[epoch].copy_(out)
         if print_every and epoch % print_every == 0:
             di, cf, ok = trace[epoch].tolist()
             if ok:
@@ -293,6 +306,46 @@ def _run_graphed(model, draw, src, src_nb, tar, tar_tri, Save_path, writer, n_ep
             writer.add_scalar('./loss/chamfer_loss', cf, epoch)
             writer.add_scalar('./loss/intersection_loss', di, epoch)
     return history
+
+
+def _one_call_epoch(draw, reg, lines, box1, xi, opt, Rb, Tb, trace, slot, row, table_rows):
+    """The epoch as ONE C call (rrl_demo_epoch).  Returns epoch_call(epoch); all buffers are the captured path's own."""
+    import ctypes
+    from rrl_hip import _lib
+    radius, centers, n_lines, target, box2 = draw.sampler
+    dev = lines.device
+    if not box2:
+        box2.append(_ops.aabb(target.view(1, -1, 3)))
+    B, N, M, L = reg.dims
+    rounds = 10
+    keep = dict(
+        radius=radius.reshape(1).to(dev, torch.float32).contiguous(), centers=centers.reshape(1, 3).to(dev, torch.float32).contiguous(),
+        filled=torch.empty(1, dtype=torch.int32, device=dev),
+        tiles=torch.empty(rounds * ((L + 1023) // 1024) * 32, dtype=torch.int32, device=dev),
+        rng=_ops.sampler_rng(dev), cham_ws=torch.empty(int(_lib.load().rrl_chamfer_workspace_bytes(1, N, M)), dtype=torch.uint8, device=dev),
+        bx=torch.empty(1, N, dtype=torch.int64, device=dev), by=torch.empty(1, M, dtype=torch.int64, device=dev),
+        cf=torch.empty(1, device=dev), gacc=reg.st.gacc, box2=box2[0].contiguous())
+    P = _ops._p
+    a = _lib.DemoEpochArgs()
+    a.struct_bytes, a.N, a.M, a.L, a.rounds, a.transpose_r = ctypes.sizeof(_lib.DemoEpochArgs), N, M, L, rounds, reg.tr
+    a.rng_state, a.radius, a.centers, a.box1, a.box2 = P(keep["rng"]), P(keep["radius"]), P(keep["centers"]), P(box1), P(keep["box2"])
+    a.lines, a.filled, a.tile_counts = P(lines), P(keep["filled"]), P(keep["tiles"])
+    a.src_tri, a.tar_tri, a.R, a.T = P(reg.src), P(reg.tar), P(Rb), P(Tb)
+    a.ws, a.ws_bytes, a.loss, a.grad_loss = P(reg.st.ws), reg.st.nbytes, P(reg.st.loss), P(reg.ones)
+    a.gR, a.gt = P(reg.gR), P(reg.gt)
+    a.cham_ws, a.cham_ws_bytes, a.best_x, a.best_y, a.cham_value = P(keep["cham_ws"]), keep["cham_ws"].numel(), P(keep["bx"]), P(keep["by"]), P(keep["cf"])
+    a.xi, a.m, a.v, a.adam_state, a.lr = P(xi.data), P(opt.m), P(opt.v), P(opt.step), P(opt.lr)
+    a.b1, a.b2, a.eps = 0.9, 0.999, 1e-8
+    a.table, a.cursor, a.table_rows, a.row = P(trace), P(slot), table_rows, P(row)
+    lib = _lib.load()
+    aref = ctypes.byref(a)
+    opts_first, opts_kept = ctypes.addressof(reg._opts), ctypes.addressof(reg._opts_kept)
+
+    def epoch_call(epoch):
+        a.opts = opts_first if epoch == 0 else opts_kept  # the target's records are built once, then kept
+        _lib.check(lib.rrl_demo_epoch(aref, _ops._stream(dev)), "rrl_demo_epoch")
+    epoch_call.keep = (keep, a)
+    return epoch_call
 
 
 # -------------------------------------------------------------------------------- driver

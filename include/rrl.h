@@ -479,6 +479,27 @@ int rrl_se3_adam_step(float *xi, const float *gR, const float *gT, float *m, flo
                       float *gxi, const float *loss, const float *value, float *table, long long *cursor,
                       long long nrows, float *row, const float *aabb_rows, int n_aabb_rows, float *box, void *stream);
 
+/* One epoch of the single-pair demo (code/test_demo_optimized_Lie_Algebra.py:46-82) as ONE call: line sampler with the
+ * library's generator (rrl_sample_lines_rng, against box1 = the previous epoch's moved source) -> fused registration step
+ * (rrl_registration_step_ex; pass prepared orders in opts) -> Chamfer between the step's own sorted clouds
+ * (rrl_chamfer_from_loss: requires the point sets to be the triangles' first points) -> pose step (rrl_se3_adam_step:
+ * exp-map backward, gated Adam on xi, (R, T) = exp(updated xi), log row, box1 = the moved source's AABB for the next
+ * epoch).  Nothing but the four entries' own launches, issued back to back: a loop pays one host call per epoch.  One pair
+ * (B = 1); every pointer a device pointer as in the four entries; struct_bytes = sizeof(rrl_demo_epoch_args). */
+typedef struct rrl_demo_epoch_args {
+    int32_t struct_bytes, N, M, L, rounds, transpose_r;
+    /* sampler */
+    uint64_t *rng_state; const float *radius, *centers; float *box1; const float *box2; float *lines; int32_t *filled, *tile_counts;
+    /* loss step: src_tri [N][9], tar_tri [M][9], pose (R [9], T [3]: in / out), workspace of rrl_workspace_bytes(1, N, M, L) */
+    const float *src_tri, *tar_tri; float *R, *T; void *ws; size_t ws_bytes; float *loss; const float *grad_loss; float *gR, *gt;
+    const rrl_opts *opts;
+    /* Chamfer monitor from the loss state: scratch of rrl_chamfer_workspace_bytes(1, N, M) */
+    void *cham_ws; size_t cham_ws_bytes; uint64_t *best_x, *best_y; float *cham_value;
+    /* pose: xi [6], Adam moments / state / lr on the device, log table [table_rows][3] + cursor, row [3] */
+    float *xi, *m, *v, *adam_state; const float *lr; double b1, b2, eps; float *table; long long *cursor; long long table_rows; float *row;
+} rrl_demo_epoch_args;
+int rrl_demo_epoch(const rrl_demo_epoch_args *args, void *stream);
+
 /* ---- Chamfer monitor (code/loss.py:38-52, 236-252) -------------------------------------- */
 /* best_x [B][N], best_y [B][M] are u64 keys (dist bits << 32 | argmin), set to all-ones by
  * the call itself.  value[0] = mean of all B*(N+M) minima. */
