@@ -20,7 +20,7 @@
 //   windows of <= 4096 positions: ONE workgroup runs all remaining levels in LDS (kd_window_kernel);
 //   larger windows (clouds beyond 4096): per level a node-AABB pass, a key pass and the network with its strides
 //   >= 4096 as global passes and everything below inside 4096-position LDS windows.
-// One-off cost: ~0.1 ms for n <= 4096, ~1 ms at 65536.
+// One-off cost: ~0.33 ms per call of 8 clouds of 4096, ~2.8 ms at 16384.
 #include "rrl_tree.h"
 
 #define KD_WIN 4096   // positions per LDS window
@@ -62,54 +62,133 @@ __device__ __forceinline__ void lds_bitonic(uint32_t *key, int32_t *idx, int W, 
     }
 }
 
-// ---- levels inside one LDS window ------------------------------------------------------------------------------
+// ---- levels inside one window of <= 4096 positions ---------------------------------------------------------------
 // Window of W <= 4096 positions of sample blockIdx.y: levels S = S0, S0 / 2, ..., 16 (S0 <= W).  idx_g [B][P] holds the
 // current order (-1 = pad).  At the end the window's part of `order` ([B][npad], pads -> 0) is written.
+// Every lane keeps its E = W / T elements (T = min(W, 1024) lanes; element i <-> lane i % T, slot i / T) in REGISTERS
+// between the stages, so that a compare-exchange at stride j costs
+//   j >= T        nothing but the lane's own registers (slots r and r ^ (j / T)),
+//   j <  64       two cross-lane reads inside the wavefront (ds_bpermute via __shfl_xor),
+//   64 <= j < T   one trip through LDS (write, barrier, read the partner, barrier).
+// A full sort of 4096 keys then has 18 barrier stages instead of the 78 of the all-LDS network, all nine levels 52
+// instead of 354 (measured: 0.41 -> 0.33 ms per call of 8 clouds of 4096 -- the chain of ~300 dependent in-wavefront
+// exchanges and the per-level gathers remain; one workgroup per cloud).
 __global__ __launch_bounds__(KD_THREADS) void kd_window_kernel(const float *__restrict__ tri, int32_t *__restrict__ idx_g,
                                                                int32_t *__restrict__ order, int n, int npad, int P, int W, int S0,
                                                                int stride) {
-    __shared__ uint32_t key[KD_WIN];
-    __shared__ int32_t idx[KD_WIN];
+    __shared__ uint32_t xkey[KD_WIN];
+    __shared__ int32_t xidx[KD_WIN];
     __shared__ uint32_t bb[KD_WIN / 16 * 6];  // per node: min xyz, max xyz (order-preserving bits)
     const int b = blockIdx.y, w0 = blockIdx.x * W, tid = threadIdx.x;
+    const int T = W < KD_THREADS ? W : KD_THREADS, E = W / T;  // E in {1, 2, 4}
+    const bool live = tid < T;
     const float *t0 = tri + (size_t)b * n * stride;  // rows of `stride` floats whose first three are the point
-    for (int p = tid; p < W; p += KD_THREADS) idx[p] = idx_g[(size_t)b * P + w0 + p];
-    __syncthreads();
+    uint32_t key[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+    int32_t idx[4] = {-1, -1, -1, -1};
+    if (live)
+        for (int r = 0; r < E; ++r) idx[r] = idx_g[(size_t)b * P + w0 + tid + T * r];
+    // the smaller (keep_min) or larger of the lane's pair (ka, ia) and a partner's pair
+    auto take = [](uint32_t &ka, int32_t &ia, uint32_t kb, int32_t ib, bool keep_min) {
+        const bool b_less = kb < ka || (kb == ka && (uint32_t)ib < (uint32_t)ia);
+        if (b_less == keep_min) { ka = kb; ia = ib; }
+    };
     for (int S = S0; S >= 16; S >>= 1) {
         const int nodes = W / S;
         for (int q = tid; q < nodes * 6; q += KD_THREADS) bb[q] = (q % 6) < 3 ? 0xffffffffu : 0u;
         __syncthreads();
-        for (int p = tid; p < W; p += KD_THREADS) {
-            const int f = idx[p];
+        // ---- bounding box of every node's records
+        for (int r = 0; r < E; ++r) {
+            const int i = tid + T * r, f = live ? idx[r] : -1;
+            uint32_t u[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, v[3] = {0u, 0u, 0u};  // (pads: neutral for min / max)
             if (f >= 0) {
-                const float *r = t0 + (size_t)f * stride;
-                const int nd = p / S;
+                const float *p = t0 + (size_t)f * stride;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) u[c] = v[c] = f2ord(p[c]);
+            }
+            if (S >= 64) {  // a wavefront's 64 consecutive positions lie in one node: reduce first, one atomic per value
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
-                    const uint32_t u = f2ord(r[c]);
-                    atomicMin(&bb[nd * 6 + c], u);
-                    atomicMax(&bb[nd * 6 + 3 + c], u);
+                    for (int o = 32; o > 0; o >>= 1) {
+                        u[c] = min(u[c], (uint32_t)__shfl_xor((int)u[c], o));
+                        v[c] = max(v[c], (uint32_t)__shfl_xor((int)v[c], o));
+                    }
                 }
+                if (live && (tid & 63) == 0) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) { atomicMin(&bb[(i / S) * 6 + c], u[c]); atomicMax(&bb[(i / S) * 6 + 3 + c], v[c]); }
+                }
+            } else if (f >= 0) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { atomicMin(&bb[(i / S) * 6 + c], u[c]); atomicMax(&bb[(i / S) * 6 + 3 + c], v[c]); }
             }
         }
         __syncthreads();
-        for (int p = tid; p < W; p += KD_THREADS) {
-            const int f = idx[p];
+        // ---- keys: the coordinate along the node's longest axis (pads last)
+        for (int r = 0; r < E; ++r) {
+            const int i = tid + T * r, f = live ? idx[r] : -1;
             uint32_t k = 0xffffffffu;
             if (f >= 0) {
-                const uint32_t *q = bb + (p / S) * 6;
+                const uint32_t *q = bb + (i / S) * 6;
                 const float e0 = ord2f(q[3]) - ord2f(q[0]), e1 = ord2f(q[4]) - ord2f(q[1]), e2 = ord2f(q[5]) - ord2f(q[2]);
                 const int ax = (e1 > e0 && e1 >= e2) ? 1 : ((e2 > e0 && e2 > e1) ? 2 : 0);
                 k = f2ord(t0[(size_t)f * stride + ax]);
                 if (k == 0xffffffffu) k = 0xfffffffeu;  // (a negative NaN pattern) keep real records in front of the pads
             }
-            key[p] = k;
+            key[r] = k;
         }
-        __syncthreads();
-        lds_bitonic(key, idx, W, w0, 2, S, S);
+        // ---- the network: every node of S positions ascending
+        for (int k = 2; k <= S; k <<= 1) {
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                if (j >= T) {  // both elements in this lane's registers (static register indices: no scratch)
+                    auto cswap = [&](uint32_t &ka, int32_t &ia, uint32_t &kb, int32_t &ib, int r) {
+                        const int i = tid + T * r;
+                        const bool asc = ((i & k) == 0) || k == S;
+                        const bool gt = ka > kb || (ka == kb && (uint32_t)ia > (uint32_t)ib);
+                        if (gt == asc) {
+                            const uint32_t tk = ka; ka = kb; kb = tk;
+                            const int32_t ti = ia; ia = ib; ib = ti;
+                        }
+                    };
+                    if (j == T) {  // slots (0, 1) and (2, 3)
+                        cswap(key[0], idx[0], key[1], idx[1], 0);
+                        if (E == 4) cswap(key[2], idx[2], key[3], idx[3], 2);
+                    } else {       // j == 2 T: slots (0, 2) and (1, 3)
+                        cswap(key[0], idx[0], key[2], idx[2], 0);
+                        cswap(key[1], idx[1], key[3], idx[3], 1);
+                    }
+                } else if (j < 64) {  // partner in the same wavefront
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (r < E) {
+                            const int i = tid + T * r;
+                            const uint32_t kb = (uint32_t)__shfl_xor((int)key[r], j);
+                            const int32_t ib = __shfl_xor(idx[r], j);
+                            const bool asc = ((i & k) == 0) || k == S;
+                            take(key[r], idx[r], kb, ib, ((i & j) == 0) == asc);
+                        }
+                    }
+                } else {  // partner in another wavefront: through LDS
+                    if (live)
+                        for (int r = 0; r < E; ++r) { xkey[tid + T * r] = key[r]; xidx[tid + T * r] = idx[r]; }
+                    __syncthreads();
+                    if (live) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            if (r < E) {
+                                const int i = tid + T * r;
+                                const bool asc = ((i & k) == 0) || k == S;
+                                take(key[r], idx[r], xkey[i ^ j], xidx[i ^ j], ((i & j) == 0) == asc);
+                            }
+                        }
+                    }
+                    __syncthreads();
+                }
+            }
+        }
     }
-    for (int p = tid; p < W; p += KD_THREADS)
-        if (w0 + p < npad) order[(size_t)b * npad + w0 + p] = max(idx[p], 0);
+    if (live)
+        for (int r = 0; r < E; ++r)
+            if (w0 + tid + T * r < npad) order[(size_t)b * npad + w0 + tid + T * r] = max(idx[r], 0);
 }
 
 // ---- levels above one LDS window (clouds beyond 4096 positions) --------------------------------------------------

@@ -294,3 +294,24 @@ def test_chamfer_with_prepared_orders(L, B, N, M):
     np.testing.assert_array_equal(plain[1].cpu().numpy().view(np.uint64), brute[1])
     v = ops.chamfer(x, y, order_x=ox, order_y=oy)
     assert float(v) == float(ops.chamfer(x, y))
+
+
+@pytest.mark.parametrize("n", [1, 7, 64, 65, 300, 1024, 3000, 4096, 4097, 9000, 20000])
+def test_cloud_order_equals_its_host_twin(L, n):
+    """rrl_cloud_order (GPU: registers / in-wavefront exchanges / LDS / global passes, by stride) and
+    pre_dataloader.kd_order (numpy, recursive) build the SAME order: median splits of aligned power-of-two windows along
+    the longest axis of their records' box, ties by index, pads last -- on random clouds, a cloud with many duplicate
+    points and a flat one; for pseudo-triangles (B, n, 9) and for their first points (B, n, 3)."""
+    from rrl_hip import ops
+    import pre_dataloader as P
+    rng = np.random.default_rng(n)
+    clouds = [rng.standard_normal((n, 3)).astype(np.float32) * np.array([1.0, 0.6, 0.3], np.float32),
+              np.repeat(rng.standard_normal(((n + 3) // 4, 3)).astype(np.float32), 4, 0)[:n],      # duplicates: ties by index
+              np.concatenate([rng.standard_normal((n, 2)), np.zeros((n, 1))], 1).astype(np.float32)]  # flat: a zero extent
+    pts = np.stack(clouds)
+    tri = np.concatenate([pts, rng.standard_normal((3, n, 6)).astype(np.float32)], -1)
+    got3 = ops.cloud_order(cu(pts)).cpu().numpy()
+    got9 = ops.cloud_order(cu(tri)).cpu().numpy()
+    np.testing.assert_array_equal(got3, got9)
+    for b in range(3):
+        np.testing.assert_array_equal(got3[b], P.kd_order(pts[b]))
