@@ -767,8 +767,19 @@ static_assert(SPW <= (1 << SG_BITS), "slot bits of the queue entries");
 #define QC_CAP 256
 #endif
 
+#ifndef CULL_REGLINES
+#define CULL_REGLINES 0  // 1 (experiment, round 4; exact on the whole suite, NOT shipped): the wavefront's 128 lines stay in
+#endif                   // REGISTERS (two per lane) and travel between lanes by ds_bpermute instead of 24 KB of LDS per
+//                          workgroup -> 22.6 KB, 62 VGPRs, 4 workgroups = 32 wavefronts per compute unit instead of 3 / 24.
+//                          Measured slower: 28.3 us against 26.8-27.4 at C2, 13.9 against 12.9 at C1, even at B = 64 --
+//                          twelve cross-lane reads per pass cost more than the extra residency returns; the launch is
+//                          paced by each wavefront's own chain of dependent steps, not by the number of resident ones.
 struct WaveCtx {
+#if CULL_REGLINES
+    float v0[6], v1[6];           // this lane's two lines (dir, x0): line `lane` and line `64 + lane` of the wavefront
+#else
     const float2 *lr;             // this wave's lines in LDS as they lie in memory: 3 float2 per line (dir.xy | dir.z x0.x | x0.yz)
+#endif
     const float4 *recs;           // LDS: staged records of the slice, [group][ROWS]
     const float4 *nodes;          // LDS: staged tree nodes of the slice, [supergroup][NODE]
     unsigned short *qa, *qc;      // LDS queues: line << SG_BITS | sg, line << HF_BITS | half (slice-local)
@@ -795,13 +806,30 @@ __device__ __forceinline__ LineRow line_row(const float2 *lr, int ll) {
     const float2 a = p[0], b = p[1], c = p[2];
     return {make_float4(a.x, a.y, b.x, b.y), c};
 }
+#if CULL_REGLINES
+// Line ll (0 .. 127) of the wavefront from the registers of the lane that holds it: EVERY lane of the wavefront must
+// call (a ds_bpermute reads the registers of active lanes only); lanes without work pass any ll.  Twelve cross-lane
+// reads + six selects instead of three 8-byte LDS reads -- and 24 KB of LDS per workgroup less: 22.3 KB instead of 47.2,
+// so the wavefront limit (8 per SIMD), not LDS, bounds the residency: 4 workgroups per compute unit instead of 3.
+__device__ __forceinline__ LineRow line_get(const WaveCtx &c, int ll) {
+    const int src = (ll & 63) << 2;
+    const bool hi = ll >= 64;
+    float r[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        const int a = __builtin_amdgcn_ds_bpermute(src, __float_as_int(c.v0[q]));
+        const int b = __builtin_amdgcn_ds_bpermute(src, __float_as_int(c.v1[q]));
+        r[q] = __int_as_float(hi ? b : a);
+    }
+    return {make_float4(r[0], r[1], r[2], r[3]), make_float2(r[4], r[5])};
+}
+#endif
 
 // cand = line_in_wave << 16 | sorted triangle position: a triangle whose point 0 passed the conservative
 // prefilter of level D.  The reference's own arithmetic (dist_sq, bit-identical to the strict scan) decides
 // on all three points here.
-__device__ __forceinline__ void resolve_candidate(const WaveCtx &c, unsigned cand) {
+__device__ __forceinline__ void resolve_candidate(const WaveCtx &c, unsigned cand, const LineRow &lrw) {
     const int ll = cand >> 16, spos = cand & 0xffff;
-    const LineRow lrw = line_row(c.lr, ll);
     const float4 la = lrw.la;
     const float2 lb = lrw.lb;
     const int f = c.idx[spos];  // (staging the slice's indices in LDS measured 0.8 us slower)
@@ -871,7 +899,16 @@ __device__ __forceinline__ void flush_cands(WaveCtx &c) {
     wave_lds_fence();
     const int nc = min(c.ncand, WCCAP);
     if constexpr (COUNT) c.tcand += (unsigned)c.ncand;  // entries past WCCAP were resolved inline: counted here too
-    for (int i = c.lane; i < nc; i += 64) resolve_candidate(c, c.cands[i]);
+#if CULL_REGLINES
+    for (int i0 = 0; i0 < nc; i0 += 64) {  // uniform trip count: every lane fetches (line_get), the live ones resolve
+        const int i = i0 + c.lane;
+        const unsigned cand = i < nc ? c.cands[i] : 0u;
+        const LineRow lrw = line_get(c, (int)(cand >> 16));
+        if (i < nc) resolve_candidate(c, cand, lrw);
+    }
+#else
+    for (int i = c.lane; i < nc; i += 64) { const unsigned cand = c.cands[i]; resolve_candidate(c, cand, line_row(c.lr, (int)(cand >> 16))); }
+#endif
     c.ncand = 0;
 }
 
@@ -895,10 +932,17 @@ __device__ __forceinline__ void proc_c(WaveCtx &c, bool all) {
         wave_lds_fence();
         uint32_t passbits = 0;
         unsigned lh = 0;  // line << 16 | first sorted position of the half
+#if CULL_REGLINES
+        const unsigned e = c.lane < take ? c.qc[base + c.lane] : 0u;
+        const int ll = e >> HF_BITS, h = e & ((1 << HF_BITS) - 1);
+        const LineRow lrw = line_get(c, ll);  // (every lane)
+        if (c.lane < take) {
+#else
         if (c.lane < take) {
             const unsigned e = c.qc[base + c.lane];
             const int ll = e >> HF_BITS, h = e & ((1 << HF_BITS) - 1);
             const LineRow lrw = line_row(c.lr, ll);
+#endif
             const float4 la = lrw.la;
             const float2 lb = lrw.lb;
             const float4 *row = c.recs + (h >> 1) * ROWS + (h & 1) * 8;
@@ -914,6 +958,9 @@ __device__ __forceinline__ void proc_c(WaveCtx &c, bool all) {
             lh = ((unsigned)ll << 16) | (unsigned)(c.pos0 + h * 8);
         }
         while (__any(passbits != 0)) {
+#if CULL_REGLINES
+            if (c.ncand > WCCAP - 64) flush_cands<COUNT>(c);  // uniform: room for this round's <= 64 candidates (no inline resolve)
+#endif
             const bool has = passbits != 0;
             const unsigned long long m = __ballot(has);
             const int t = has ? __ffs(passbits) - 1 : 0;
@@ -921,8 +968,12 @@ __device__ __forceinline__ void proc_c(WaveCtx &c, bool all) {
             const int pos = c.ncand + lane_rank(m);
             const unsigned cand = lh + (unsigned)t;
             if (has) {
+#if CULL_REGLINES
+                c.cands[pos] = cand;
+#else
                 if (pos < WCCAP) c.cands[pos] = cand;
-                else resolve_candidate(c, cand);
+                else resolve_candidate(c, cand, line_row(c.lr, (int)(cand >> 16)));
+#endif
             }
             c.ncand += __popcll(m);
         }
@@ -978,10 +1029,17 @@ __device__ __forceinline__ void proc_a(WaveCtx &c, bool all) {
         wave_lds_fence();
         unsigned fail = 0xffu;  // bit k: half k cannot be reached (idle lanes: none can)
         unsigned e2 = 0;
+#if CULL_REGLINES
+        const unsigned e = c.lane < take ? c.qa[base + c.lane] : 0u;
+        const int ll = e >> SG_BITS, sg = e & ((1 << SG_BITS) - 1);
+        const LineRow lrw = line_get(c, ll);  // (every lane)
+        if (c.lane < take) {
+#else
         if (c.lane < take) {
             const unsigned e = c.qa[base + c.lane];
             const int ll = e >> SG_BITS, sg = e & ((1 << SG_BITS) - 1);
             const LineRow lrw = line_row(c.lr, ll);
+#endif
             const float4 la = lrw.la;
             const float2 lb = lrw.lb;
             const float4 *nd = c.nodes + sg * NODE + 5;
@@ -1109,7 +1167,9 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(6, 8))
     const float *__restrict__ del1, const float *__restrict__ del2, const float2 *__restrict__ lmax,
     const float *__restrict__ apart, int nblk_apart, int B,
     int N, int M, int L, int spw, unsigned long long *__restrict__ counters, long long counter_rows) {
+#if !CULL_REGLINES
     __shared__ __attribute__((aligned(16))) float2 line_lds[WPB][LPW * 3];    // 24 KiB: raw 24-byte line rows
+#endif
     __shared__ __attribute__((aligned(16))) float4 rec_lds[SPW * SGG * ROWS]; //  8.5 KiB
     __shared__ __attribute__((aligned(16))) float4 node_lds[SPW * NODE];      //  1.6 KiB
     __shared__ __attribute__((aligned(16))) unsigned short qa_lds[WPB][QA_CAP];
@@ -1174,6 +1234,16 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(6, 8))
     const int l0 = lw0 + lane, l1 = l0 + 64;
     const bool live0 = l0 < L, live1 = l1 < L;
     const bool has_lines = lw0 < L;  // a wave without lines (the last tile of the line set) still stages records
+#if CULL_REGLINES
+    // each lane's own two lines straight into registers: three 8-byte loads per line (rows are 24 bytes, 8-byte aligned;
+    // the three instructions of a line cover the wavefront's 1536 contiguous bytes completely); rows past L: zero lines
+    float2 g0[3] = {make_float2(0.0f, 0.0f), make_float2(0.0f, 0.0f), make_float2(0.0f, 0.0f)}, g1[3] = {g0[0], g0[0], g0[0]};
+    {
+        const float2 *s2 = (const float2 *)ln;
+        if (live0) { g0[0] = s2[3 * (size_t)l0]; g0[1] = s2[3 * (size_t)l0 + 1]; g0[2] = s2[3 * (size_t)l0 + 2]; }
+        if (live1) { g1[0] = s2[3 * (size_t)l1]; g1[1] = s2[3 * (size_t)l1 + 1]; g1[2] = s2[3 * (size_t)l1 + 2]; }
+    }
+#else
     float2 *lr = line_lds[wave];
     const float *lsrc = ln + (size_t)lw0 * 6;
     const bool full_tile = has_lines && lw0 + LPW <= L && (((uintptr_t)lsrc) & 15) == 0;  // uniform
@@ -1182,6 +1252,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(6, 8))
         const float4 *s4 = (const float4 *)lsrc;
         t0 = s4[lane]; t1 = s4[64 + lane]; t2 = s4[128 + lane];
     }
+#endif
 
     // ---- slack of this (cloud, sample): the same values in every wavefront and workgroup (no exchange, no barrier)
     const float smax = wave_max(lm.x), o2max = wave_max(lm.y);
@@ -1198,6 +1269,10 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(6, 8))
 #pragma unroll
         for (int k = 0; k < RPT; ++k) dv[k] = sg0 * SGT + tid + 64 * WPB * k < n ? del[idx0[k]] : 0.0f;
     }
+#if CULL_REGLINES
+    const float v0[6] = {g0[0].x, g0[0].y, g0[1].x, g0[1].y, g0[2].x, g0[2].y};
+    const float v1[6] = {g1[0].x, g1[0].y, g1[1].x, g1[1].y, g1[2].x, g1[2].y};
+#else
     if (full_tile) {
         float4 *d4 = (float4 *)lr;
         d4[lane] = t0; d4[64 + lane] = t1; d4[128 + lane] = t2;
@@ -1214,6 +1289,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(6, 8))
         v0[0] = r0.la.x; v0[1] = r0.la.y; v0[2] = r0.la.z; v0[3] = r0.la.w; v0[4] = r0.lb.x; v0[5] = r0.lb.y;
         v1[0] = r1.la.x; v1[1] = r1.la.y; v1[2] = r1.la.z; v1[3] = r1.la.w; v1[4] = r1.lb.x; v1[5] = r1.lb.y;
     }
+#endif
     // Culling (and the lazy evaluation of points 1, 2) is only exact for lines with |dir|^2 <= 1 + 1e-6 and finite,
     // moderate data.  A wavefront with an offending line evaluates ALL pairs of its lines with the slice's
     // triangles strictly instead -- the reference's semantics, NaN included.
@@ -1291,7 +1367,12 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(6, 8))
     unsigned long long wall_a = 0ull, wall_pa = 0ull, wall_pc = 0ull;
 
     WaveCtx ctx;
+#if CULL_REGLINES
+#pragma unroll
+    for (int q = 0; q < 6; ++q) { ctx.v0[q] = v0[q]; ctx.v1[q] = v1[q]; }
+#else
     ctx.lr = lr;
+#endif
     ctx.recs = rec_lds;
     ctx.nodes = node_lds;
     ctx.qa = qa_lds[wave];
