@@ -487,7 +487,11 @@ class _DropinBatch(torch.autograd.Function):
     @staticmethod
     def forward(ctx, points1, points2, line, rng, mode, chunk):
         loss = _dropin_forward(ctx, points1, points2, line, rng, False, mode, chunk)
-        return tuple(loss.view(-1, 1).unbind(0))
+        # B one-element tensors on the batch's loss buffer that autograd does NOT know as views of each other (set_ on the
+        # shared storage): a caller may modify a returned loss in place (`total = first; total += second`), which outputs
+        # that are views of one tensor would refuse ("function that returns multiple views")
+        st_, off = loss.untyped_storage(), loss.storage_offset()
+        return tuple(torch.empty(0, dtype=loss.dtype, device=loss.device).set_(st_, off + j, (1,), (1,)) for j in range(loss.numel()))
 
     @staticmethod
     def backward(ctx, *grads):

@@ -597,6 +597,17 @@ def test_trainer_loop_served_by_one_batch_evaluation(L):
             ops.DROPIN_BATCH = old
         assert vals[0].item() == ref[0].item() and vals[3].item() == ref[3].item() and vals[2] is None
     assert ops.dropin_batch_stats["nan_fallbacks"] >= 1
+    # a caller that accumulates IN PLACE into the first returned loss (`total = first; total += second`): allowed (the B
+    # outputs are not views of one tensor as far as autograd is concerned), same sum, same gradient
+    p1 = tri1.clone().requires_grad_(True)
+    out = loop(p1, tri2, ln, [0, 1, 3], True)
+    total = out[0]
+    total += out[1]
+    total += out[3]
+    total.backward()
+    want, gwant, _ = run([0, 1, 3], False)
+    assert float(total) == float(want[0] + want[1] + want[3])
+    np.testing.assert_allclose(p1.grad.cpu().numpy(), gwant.cpu().numpy(), rtol=2e-5, atol=1e-9)
     ops.dropin_batch_clear()
 
 
