@@ -122,6 +122,18 @@ def _run(dev, name, *args):
         check(getattr(_lib.load(), name)(*args, _stream(dev)), name)
 
 
+def _touched(*tensors):
+    """The library wrote these caller-owned tensors through raw pointers: advance their autograd version counters like
+    an in-place torch op would, so that everything keyed on (data_ptr, _version) -- RegistrationStep's kept target, the
+    drop-in batch cache, autograd's own saved-tensor checks -- sees the change."""
+    ts = [t for t in tensors if isinstance(t, torch.Tensor)]
+    if ts:
+        try:
+            torch._C._autograd._unsafe_set_version_counter(ts, [t._version + 1 for t in ts])
+        except (AttributeError, TypeError, RuntimeError):
+            pass  # (older PyTorch: no such hook; the callers' contract then is not to reuse such outputs as kept targets)
+
+
 def _home(*tensors):
     """The device an op runs on: that of its first GPU argument, else the current GPU."""
     for t in tensors:
@@ -1280,6 +1292,8 @@ def sample_lines(rands, r, centers, aabb1, aabb2, out=None, rng_shape=None):
     else:
         _run(dev, "rrl_sample_lines_rng", _p(sampler_rng(dev)), _p(rr), _p(cc), _p(aabb1), _p(aabb2), _p(lines), _p(filled),
              _p(scratch), B, n, rounds)
+    if out is not None:
+        _touched(out)
     return lines, filled
 
 
@@ -1290,6 +1304,7 @@ def rigid_apply_into(x, R, t, out, transpose_r=False):
     B = Rm.shape[0]
     n = x.numel() // (3 * B)
     _run(x.device, "rrl_rigid_apply_fwd", _p(x), _p(Rm), _p(tv), _p(out), B, n, int(transpose_r), 0)
+    _touched(out)
     return out
 
 
@@ -1300,6 +1315,7 @@ def rigid_apply_aabb_into(x, R, t, out, box, transpose_r=False):
     B = Rm.shape[0]
     n = x.numel() // (3 * B)
     _run(x.device, "rrl_rigid_apply_aabb", _p(x), _p(Rm), _p(tv), _p(out), _p(box), B, n, int(transpose_r))
+    _touched(out, box)
     return out
 
 

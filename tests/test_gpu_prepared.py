@@ -190,6 +190,13 @@ def test_kept_target_is_rebuilt_when_it_changes(L):
         tar[:, : m // 2] += 0.01  # in place: the version counter moves, the records are rebuilt
     same()
     assert not torch.equal(prep.st.ptri2[:, 0, :3], torch.zeros_like(prep.st.ptri2[:, 0, :3]))
+    # the library itself writes the target through a raw pointer (ops.rigid_apply_into, in place): the version counter is
+    # advanced by hand (ops._touched), so this is seen too
+    v0 = tar._version
+    ops.rigid_apply_into(tar.view(B, -1, 3), cu(np.stack([_rot((0, 1, 0), 3)] * B)), cu(np.full((B, 3), 0.01, np.float32)),
+                         tar.view(B, -1, 3))
+    assert tar._version > v0
+    same()
     tar2 = tar.clone()
     with torch.no_grad():
         tar2[:, m // 2:] -= 0.02
