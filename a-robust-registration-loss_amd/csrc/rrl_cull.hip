@@ -1205,26 +1205,25 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(6, 8))
     const int32_t *idx = (cloud ? idx2 : idx1) + (size_t)b * nsg * SGT;
     float4 rec0[RPT], nd0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     static_assert(LMAX_CHUNKS == 64, "one partial row per lane");
+    // (the line maxima and max |P|^2 are requested FIRST: vector loads return in order, so the slack arithmetic below can
+    //  start while the records, nodes and lines requested after them are still in flight)
+    const float2 lm = lmax[(size_t)b * LMAX_CHUNKS + lane];  // (max |dir|^2, max |x0|^2) over 1/64 of the sample's cullable lines
+    // max |P|^2 of the cloud: from the sort kernel (PMAX), or -- prepared clouds, whose build has no single-workgroup stage
+    // -- from the records kernel's per-workgroup partial rows, reduced here next to the line maxima (one more independent
+    // load of the prologue; one workgroup per cloud and sample leaves PMAX for the later consumers)
+    float pmv = 0.0f;
+    if (apart != nullptr) {  // uniform
+        const int nb = (n + REC_BLK - 1) / REC_BLK;
+        const float *ap = apart + (size_t)(cloud * B + b) * nblk_apart * 8 + 6;
+        for (int j = lane; j < nb; j += 64) pmv = fmaxf(pmv, ap[(size_t)j * 8]);
+    } else {
+        pmv = __uint_as_float(pmax[cloud * B + b]);
+    }
     if (one_each) {
 #pragma unroll
         for (int k = 0; k < RPT; ++k)
             if (tid + 64 * WPB * k < nsl * SGT) rec0[k] = p0s[(size_t)sg0 * SGT + tid + 64 * WPB * k];
         if (tid < nsl * NODE) nd0 = tree[(size_t)sg0 * NODE + tid];
-    }
-    const float2 lm = lmax[(size_t)b * LMAX_CHUNKS + lane];  // (max |dir|^2, max |x0|^2) over 1/64 of the sample's cullable lines
-    // max |P|^2 of the cloud: from the sort kernel (PMAX), or -- prepared clouds, whose build has no single-workgroup stage
-    // -- from the records kernel's per-workgroup partial rows, reduced here next to the line maxima (one more independent
-    // load of the prologue; one workgroup per cloud and sample leaves PMAX for the later consumers)
-    float pm;
-    if (apart != nullptr) {  // uniform
-        const int nb = (n + REC_BLK - 1) / REC_BLK;
-        const float *ap = apart + (size_t)(cloud * B + b) * nblk_apart * 8 + 6;
-        float v = 0.0f;
-        for (int j = lane; j < nb; j += 64) v = fmaxf(v, ap[(size_t)j * 8]);
-        pm = wave_max(v);
-        if (blockIdx.y == 0 && blockIdx.z == 0 && tid == 0) pmax[cloud * B + b] = __float_as_uint(pm);
-    } else {
-        pm = __uint_as_float(pmax[cloud * B + b]);
     }
 
     // this wave's 128 lines: a full, 16-byte aligned tile arrives as three coalesced 16-byte loads per lane straight
@@ -1255,6 +1254,11 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(6, 8))
 #endif
 
     // ---- slack of this (cloud, sample): the same values in every wavefront and workgroup (no exchange, no barrier)
+    float pm = pmv;
+    if (apart != nullptr) {  // uniform
+        pm = wave_max(pmv);
+        if (blockIdx.y == 0 && blockIdx.z == 0 && tid == 0) pmax[cloud * B + b] = __float_as_uint(pm);
+    }
     const float smax = wave_max(lm.x), o2max = wave_max(lm.y);
     const CloudSlack cs = cull_cloud_slack(smax, o2max, pm);
     const float se = cs.se, s0 = cs.s0;
