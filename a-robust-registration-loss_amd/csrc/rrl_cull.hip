@@ -865,15 +865,35 @@ struct CloudSlack {
     float se;      // slack of the node radii
     float s0;      // slack of the point-0 prefilter
 };
+// max over the wavefront of NON-NEGATIVE floats (or NaN, which then wins: its bit pattern is the largest) on their bit
+// patterns: v_max_u32 takes the DPP operand directly (the float version needs a canonicalising v_max per step), and
+// the four row results meet in scalar registers.  Every lane receives the result.
+__device__ __forceinline__ float wave_max_nonneg(float v) {
+    unsigned u = __float_as_uint(v);
+#define RRL_DPP_U(x, ctrl) (unsigned)__builtin_amdgcn_update_dpp((int)(x), (int)(x), ctrl, 0xf, 0xf, false)
+    u = max(u, RRL_DPP_U(u, 0xB1)); u = max(u, RRL_DPP_U(u, 0x4E));
+    u = max(u, RRL_DPP_U(u, 0x141)); u = max(u, RRL_DPP_U(u, 0x140));
+#undef RRL_DPP_U
+    const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)u, 0), b = (unsigned)__builtin_amdgcn_readlane((int)u, 16);
+    const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)u, 32), d = (unsigned)__builtin_amdgcn_readlane((int)u, 48);
+    return __uint_as_float(max(max(a, b), max(c, d)));
+}
+// square root / reciprocal for the SLACKS only (never for a label): the hardware approximations (1 ulp), nudged upwards
+// so that the result is >= the exact one -- a slack may be too large by 1e-6 of itself, never too small.  (The IEEE
+// sqrtf / division sequences were ~55 of the ~250 VALU instructions of every wavefront's prologue.)
+__device__ __forceinline__ float sqrt_up(float x) { return __builtin_amdgcn_sqrtf(x) * 1.0000005f; }
+__device__ __forceinline__ float rcp_up(float x) { return __builtin_amdgcn_rcpf(x) * 1.0000005f; }
+
 __device__ __forceinline__ CloudSlack cull_cloud_slack(float s, float o2, float pm) {
     CloudSlack r;
     r.ok = pm <= 1.0e11f;  // (false for NaN / inf: non-finite coordinates)
-    const float A2 = (o2 + pm + 2.0f * sqrtf(o2 * pm)) * 1.00001f;  // (|x0| + max|P|)^2, rounded up
+    const float A2 = (o2 + pm + 2.0f * sqrt_up(o2 * pm)) * 1.00001f;  // (|x0| + max|P|)^2, rounded up
     const float eta = fmaxf(s - 1.0f, 0.0f) + 2.5e-7f;  // |d|^2 - 1 incl. the rounding of s (<= 3u s)
     const float x = eta * A2;
     const float g = 1.8e-6f * A2 - 2e-4f;  // 30u = 1.788e-6
     r.nanwide = g > 0.0f;
-    const float se = g > 0.0f ? sqrtf(g + x) : fminf(sqrtf(x), x / (2.0f * sqrtf(-0.999f * g)));
+    // (-0.999 g under the root: a smaller divisor, i.e. a larger quotient; the approximations only add to that)
+    const float se = g > 0.0f ? sqrt_up(g + x) : fminf(sqrt_up(x), x * 0.5f * rcp_up(__builtin_amdgcn_sqrtf(-0.998f * g)));
     r.se = se * 1.0001f + 1e-12f;
     r.s0 = 3.0e-6f * A2 + 1.0e-9f;  // 44.2 u A^2 of evaluation error on both sides, rounded up, + an absolute floor
     return r;
@@ -1256,10 +1276,10 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(6, 8))
     // ---- slack of this (cloud, sample): the same values in every wavefront and workgroup (no exchange, no barrier)
     float pm = pmv;
     if (apart != nullptr) {  // uniform
-        pm = wave_max(pmv);
+        pm = wave_max_nonneg(pmv);
         if (blockIdx.y == 0 && blockIdx.z == 0 && tid == 0) pmax[cloud * B + b] = __float_as_uint(pm);
     }
-    const float smax = wave_max(lm.x), o2max = wave_max(lm.y);
+    const float smax = wave_max_nonneg(lm.x), o2max = wave_max_nonneg(lm.y);
     const CloudSlack cs = cull_cloud_slack(smax, o2max, pm);
     const float se = cs.se, s0 = cs.s0;
     const bool nanwide = cs.nanwide;  // uniform over the launch's workgroups of this cloud and sample
