@@ -191,8 +191,10 @@ __global__ __launch_bounds__(REC_BLK) void line_max_kernel(const float *__restri
 // belongs to the source of the fused op (-> TRI1), its thresholds (code/loss.py:94-110), NaN reach (DEL) and 48-byte
 // prepared record (PTRI, original order).  c: the (moved) coordinates, x: thr2, p2: max |P|^2 of its three points
 // (+inf for non-finite coordinates).
-__device__ __forceinline__ void tri_record_row(const BuildArgs &a, int cloud, int b, int n, int f, float (&c)[9], float &x,
-                                               float &p2) {
+// prow: the row of PTRI the record goes to -- f (original order: the cold build) or the triangle's SORTED position (prepared
+// build: the culled scan then resolves a candidate from its position alone, without the IDX hop; the record carries f).
+__device__ __forceinline__ void tri_record_row(const BuildArgs &a, int cloud, int b, int n, int f, int prow, float (&c)[9],
+                                               float &x, float &p2) {
     const float *raw = (cloud ? a.tri2 : a.tri1) + ((size_t)b * n + f) * 9;
     float thr, e01;
 #pragma unroll
@@ -222,7 +224,7 @@ __device__ __forceinline__ void tri_record_row(const BuildArgs &a, int cloud, in
     // tree nodes carry thr: del >= e01 - thr in exact arithmetic (e01, thr as rounded here: <= 3u off)
     if (float *del = cloud ? a.del2 : a.del1)
         del[(size_t)b * n + f] = fmaxf(e01 * 1.000002f - thr, 0.0f) * 1.000001f;
-    float4 *row = (float4 *)((cloud ? a.ptri2 : a.ptri1) + ((size_t)b * n + f) * PTRI_STRIDE);
+    float4 *row = (float4 *)((cloud ? a.ptri2 : a.ptri1) + ((size_t)b * n + prow) * PTRI_STRIDE);
     row[0] = make_float4(c[0], c[1], c[2], c[3]);
     row[1] = make_float4(c[4], c[5], c[6], c[7]);
     row[2] = make_float4(c[8], x, thr, __int_as_float(f));
@@ -261,7 +263,7 @@ __global__ __launch_bounds__(REC_BLK) void tri_records_kernel(const BuildArgs a)
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY}, p2 = 0.0f;
     if (f < n) {
         float c[9], x;
-        tri_record_row(a, cloud, b, n, f, c, x, p2);
+        tri_record_row(a, cloud, b, n, f, f, c, x, p2);
         const int ngp = (n + GRP - 1) / GRP * GRP;
         ((cloud ? a.crec2 : a.crec1) + (size_t)b * ngp)[f] = make_float4(c[0], c[1], c[2], x);
 #pragma unroll
@@ -281,6 +283,8 @@ __global__ __launch_bounds__(REC_BLK) void tri_records_kernel(const BuildArgs a)
         float r = red[0][tid];
         for (int w = 1; w < REC_BLK / 64; ++w) r = tid < 3 ? fminf(r, red[w][tid]) : fmaxf(r, red[w][tid]);
         a.apart[(((size_t)cloud * B + b) * a.nblk + blockIdx.x) * 8 + tid] = r;
+    } else if (tid == 7) {
+        a.apart[(((size_t)cloud * B + b) * a.nblk + blockIdx.x) * 8 + 7] = 0.0f;  // PTRI layout of this cloud: original order
     }
 }
 
@@ -291,9 +295,11 @@ __global__ __launch_bounds__(REC_BLK) void tri_records_kernel(const BuildArgs a)
 // rpm/Train_RPM.py:207-231; the reference itself suggests a tree, code/loss.py:260-262).  So the cell sort runs once
 // per cloud (rrl_cloud_order) and this kernel replaces tri_records_kernel + tri_sort_kernel in every later step:
 //   lane = one SORTED position s of the cloud; f = order[s]; the triangle's raw row is gathered, moved by the sample's
-//   pose (source of the fused op), thresholds / NaN reach / 48-byte record go to their ORIGINAL-order rows (PTRI,
-//   TRI1, DEL: the later stages index them by triangle), the 16-byte (P0, thr2) record and f to position s (P0S,
-//   IDX), and the wavefront -- which holds exactly one supergroup of 64 sorted records -- REFITS the supergroup's 13
+//   pose (source of the fused op), the moved row and the NaN reach go to their ORIGINAL-order rows (TRI1, DEL: the later
+//   stages index them by triangle), the 48-byte record (PTRI: it carries f), the 16-byte (P0, thr2) record and f to
+//   position s (PTRI, P0S, IDX -- coalesced stores; the scan resolves a candidate from its position alone, one dependent
+//   load less than through IDX; slot 7 of the cloud's first APART row tells the scan which layout PTRI has), and the
+//   wavefront -- which holds exactly one supergroup of 64 sorted records -- REFITS the supergroup's 13
 //   sphere-tree nodes to the moved points with DPP reductions over 8 / 16 / 64 lanes (wave_tree): the same nodes,
 //   bit for bit, that tri_sort_kernel derives from the same sorted records.
 // Any permutation gives identical labels, hit lists and loss (the tree is a conservative filter; the reference's
@@ -323,7 +329,7 @@ __global__ __launch_bounds__(REC_BLK) void tri_records_sorted_kernel(const Build
     if (valid) {
         f = (cloud ? order2 : order1)[(size_t)b * npad + s];
         f = min(max(f, 0), n - 1);  // memory safety only: the order must be a permutation of [0, n)
-        tri_record_row(a, cloud, b, n, f, c, x, p2);
+        tri_record_row(a, cloud, b, n, f, s, c, x, p2);
     }
     if (s - lane < npad) {  // wave-uniform: this wavefront holds a supergroup
         (cloud ? a.p0s2 : a.p0s1)[(size_t)b * npad + s] = valid ? make_float4(c[0], c[1], c[2], x) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -345,6 +351,8 @@ __global__ __launch_bounds__(REC_BLK) void tri_records_sorted_kernel(const Build
         float r = red[0][tid];
         for (int w = 1; w < REC_BLK / 64; ++w) r = tid < 3 ? fminf(r, red[w][tid]) : fmaxf(r, red[w][tid]);
         a.apart[(((size_t)cloud * B + b) * a.nblk + blockIdx.x) * 8 + tid] = r;
+    } else if (tid == 7) {
+        a.apart[(((size_t)cloud * B + b) * a.nblk + blockIdx.x) * 8 + 7] = 1.0f;  // PTRI layout of this cloud: sorted positions
     }
 }
 
@@ -785,7 +793,8 @@ struct WaveCtx {
     unsigned short *qa, *qc;      // LDS queues: line << SG_BITS | sg, line << HF_BITS | half (slice-local)
     unsigned *cands;              // LDS [WCCAP]
     const int32_t *idx;           // sorted position -> original triangle index
-    const float *ptri;            // prepared triangles (original order)
+    const float *ptri;            // prepared triangles: rows in original order, or -- psorted -- at their sorted positions
+    bool psorted;                 // uniform: the layout of ptri (the prepared build leaves sorted rows)
     int32_t *cnt, *hit;           // per-line hit count / slots of the cloud
     int lbase;                    // first line of this wave
     int pos0;                     // sorted position of the slice's first record
@@ -832,9 +841,12 @@ __device__ __forceinline__ void resolve_candidate(const WaveCtx &c, unsigned can
     const int ll = cand >> 16, spos = cand & 0xffff;
     const float4 la = lrw.la;
     const float2 lb = lrw.lb;
-    const int f = c.idx[spos];  // (staging the slice's indices in LDS measured 0.8 us slower)
-    const float4 *q = (const float4 *)(c.ptri + PTRI_STRIDE * (size_t)f);
+    // original-order rows: one more dependent load for the row index (staging the slice's indices in LDS measured 0.8 us
+    // slower); sorted rows (prepared build): the row sits at the candidate's position and carries its triangle index
+    const int prow = c.psorted ? spos : c.idx[spos];
+    const float4 *q = (const float4 *)(c.ptri + PTRI_STRIDE * (size_t)prow);
     const float4 r0 = q[0], r1 = q[1], r2 = q[2];  // P0 P1.x | P1.yz P2.xy | P2.z thr2 thr index
+    const int f = __float_as_int(r2.w);
     const uint32_t thr2 = __float_as_uint(r2.y);
     const uint32_t x0 = __float_as_uint(dist_sq<float>(r0.x, r0.y, r0.z, la.x, la.y, la.z, la.w, lb.x, lb.y));
     const uint32_t x1 = __float_as_uint(dist_sq<float>(r0.w, r1.x, r1.y, la.x, la.y, la.z, la.w, lb.x, lb.y));
@@ -1076,14 +1088,14 @@ __device__ __forceinline__ void proc_a(WaveCtx &c, bool all) {
 // The strict loop of a wavefront that cannot be culled (a line with |dir|^2 > 1 + 1e-6 or non-finite
 // data): ALL pairs of its 128 lines with the records at sorted positions [s0, s1), the reference's
 // semantics, NaN included.  The lane's two lines arrive packed (.x = line l0, .y = line l1).
-__device__ __forceinline__ void strict_slice(const float *ptri, const int32_t *idx, int s0, int s1, v2f ux,
+__device__ __forceinline__ void strict_slice(const float *ptri, const int32_t *idx, bool psorted, int s0, int s1, v2f ux,
                                                        v2f uy, v2f uz, v2f ox, v2f oy, v2f oz, int l0, int l1, int L,
                                                        int32_t *cnt, int32_t *hit, int32_t *status) {
     kptr tp0 = (kptr)(uintptr_t)ptri;
     kiptr ik = (kiptr)(uintptr_t)idx;
     uint32_t nanacc = 0;
     for (int sp = s0; sp < s1; ++sp) {
-        kptr tp = tp0 + (size_t)ik[sp] * PTRI_STRIDE;
+        kptr tp = tp0 + (size_t)(psorted ? sp : ik[sp]) * PTRI_STRIDE;
         const uint32_t thr2 = __float_as_uint(tp[9]);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -1185,7 +1197,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(6, 8))
     int32_t *__restrict__ count1, int32_t *__restrict__ hit1, int32_t *__restrict__ count2,
     int32_t *__restrict__ hit2, int32_t *__restrict__ status, uint32_t *pmax,
     const float *__restrict__ del1, const float *__restrict__ del2, const float2 *__restrict__ lmax,
-    const float *__restrict__ apart, int nblk_apart, int B,
+    const float *__restrict__ apart, const float *__restrict__ aflag, int nblk_apart, int B,
     int N, int M, int L, int spw, unsigned long long *__restrict__ counters, long long counter_rows) {
 #if !CULL_REGLINES
     __shared__ __attribute__((aligned(16))) float2 line_lds[WPB][LPW * 3];    // 24 KiB: raw 24-byte line rows
@@ -1228,6 +1240,9 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(6, 8))
     // (the line maxima and max |P|^2 are requested FIRST: vector loads return in order, so the slack arithmetic below can
     //  start while the records, nodes and lines requested after them are still in flight)
     const float2 lm = lmax[(size_t)b * LMAX_CHUNKS + lane];  // (max |dir|^2, max |x0|^2) over 1/64 of the sample's cullable lines
+    // layout of this cloud's PTRI rows, left by the records launch that built it (slot 7 of its first partial row; not
+    // needed before the first candidate is resolved)
+    const float play = aflag[(size_t)(cloud * B + b) * nblk_apart * 8 + 7];
     // max |P|^2 of the cloud: from the sort kernel (PMAX), or -- prepared clouds, whose build has no single-workgroup stage
     // -- from the records kernel's per-workgroup partial rows, reduced here next to the line maxima (one more independent
     // load of the prologue; one workgroup per cloud and sample leaves PMAX for the later consumers)
@@ -1404,6 +1419,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(6, 8))
     ctx.cands = cands_lds[wave];
     ctx.idx = idx;
     ctx.ptri = ptri;
+    ctx.psorted = __builtin_amdgcn_readfirstlane(__float_as_int(play)) != 0;  // (1.0f: sorted rows)
     ctx.cnt = cnt;
     ctx.hit = hit;
     ctx.lbase = lw0;
@@ -1418,7 +1434,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(6, 8))
 
     if (fallback) {  // rare: kept out of line so that its registers do not count against the culled walk
         const int f0 = sg0 * SGT, f1 = min(n, f0 + nsl * SGT);  // real records sit at sorted positions [0, n)
-        strict_slice(ptri, idx, f0, f1, ux, uy, uz, ox, oy, oz, l0, l1, L, cnt, hit, status);
+        strict_slice(ptri, idx, ctx.psorted, f0, f1, ux, uy, uz, ox, oy, oz, l0, l1, L, cnt, hit, status);
         if (lane == 0) atomicAdd(&status[1], 1);  // always on: wavefronts that left the culled path
         fb_pairs = (unsigned long long)(f1 - f0) * (unsigned long long)min(LPW, L - lw0);
     } else {
@@ -1658,7 +1674,7 @@ int rrl_launch_cull_scan(const float *line, void *ws, const WsLayout &w, int B, 
                        w.i32(ws, RRL_WS_HIT1), w.i32(ws, RRL_WS_COUNT2), w.i32(ws, RRL_WS_HIT2),             \
                        w.i32(ws, RRL_WS_STATUS), (uint32_t *)w.i32(ws, RRL_WS_PMAX),                         \
                        w.f32(ws, RRL_WS_DEL1), w.f32(ws, RRL_WS_DEL2), (const float2 *)w.f32(ws, RRL_WS_LMAX),   \
-                       apart, nblk_apart, B, N, M, L, spw,                                                   \
+                       apart, w.f32(ws, RRL_WS_APART), nblk_apart, B, N, M, L, spw,                          \
                        o.counters, o.counter_rows)
     const float *apart = o.prepared() ? w.f32(ws, RRL_WS_APART) : nullptr;  // prepared build: PMAX comes from the partial rows
     const int nblk_apart = ((N > M ? N : M) + REC_BLK - 1) / REC_BLK;

@@ -41,7 +41,7 @@ __device__ __forceinline__ void inter_point(const float *p, const float *w, floa
 // of nine 4-byte gathers from the 36-byte input rows (a wavefront-level gather costs ~64 cycles
 // of the CU's address path per instruction, whatever its width)
 __device__ __forceinline__ void tri_coords(const float *__restrict__ ptri, int stride, int f, float *c) {
-    if (stride != PTRI_STRIDE) {  // raw 36-byte rows (a target whose records live in another workspace)
+    if (stride != PTRI_STRIDE) {  // raw 36-byte rows (what the per-line stage reads since round 4)
 #pragma unroll
         for (int i = 0; i < 9; ++i) c[i] = ptri[9 * (size_t)f + i];
         return;
@@ -132,7 +132,7 @@ __device__ __forceinline__ void pair_hit(const float *__restrict__ tri1, const f
 }
 
 struct PairArgs {
-    const float *tri1, *tri2, *line;  // prepared records (or raw rows: stride 9) of both clouds, the lines
+    const float *tri1, *tri2, *line;  // the triangles of both clouds (raw 36-byte rows: st1 = st2 = 9), the lines
     const int32_t *count1, *hit1, *count2, *hit2;
     uint8_t *kj;
     int32_t *sel_out, *nsel, *hs1, *hs2;
@@ -261,13 +261,16 @@ __global__ __launch_bounds__(1024) void line_pair_dist_kernel(const PairArgs a) 
     pair_body(a, (int)blockIdx.y, (int)blockIdx.x, (int)gridDim.x);
 }
 
-static PairArgs pair_args(const float *tri2_raw, const float *line, void *ws, const WsLayout &w, int B, int N, int M,
-                          int L, int s_m, int s_n, int e_m, int e_n, bool tally = true) {
+// tri1 / tri2: the triangles as the loss sees them -- the caller's rows, or TRI1 (the moved source of the fused op) --, raw
+// 36-byte rows indexed by triangle.  (The prepared 48-byte records, PTRI, belong to the scans alone since round 4: the
+// prepared build keeps them at their SORTED positions, and a target's records may live in another workspace.)
+static PairArgs pair_args(const float *tri1, const float *tri2, const float *line, void *ws, const WsLayout &w, int B, int N,
+                          int M, int L, int s_m, int s_n, int e_m, int e_n, bool tally = true) {
     PairArgs a;
     a.mhist = tally ? w.u32(ws, RRL_WS_MHIST) : nullptr;
     a.mctl = tally ? w.u32(ws, RRL_WS_MCTL) : nullptr;
-    a.tri1 = w.f32(ws, RRL_WS_PTRI1);
-    a.tri2 = tri2_raw ? tri2_raw : w.f32(ws, RRL_WS_PTRI2);
+    a.tri1 = tri1;
+    a.tri2 = tri2;
     a.line = line;
     a.count1 = w.i32(ws, RRL_WS_COUNT1); a.hit1 = w.i32(ws, RRL_WS_HIT1);
     a.count2 = w.i32(ws, RRL_WS_COUNT2); a.hit2 = w.i32(ws, RRL_WS_HIT2);
@@ -282,24 +285,23 @@ static PairArgs pair_args(const float *tri2_raw, const float *line, void *ws, co
     a.vlist = w.f32(ws, RRL_WS_VLIST); a.vlcnt = w.i32(ws, RRL_WS_VLCNT);
     a.B = B; a.N = N; a.M = M; a.L = L;
     a.s_m = s_m; a.s_n = s_n; a.e_m = e_m; a.e_n = e_n;
-    a.st1 = PTRI_STRIDE; a.st2 = tri2_raw ? 9 : PTRI_STRIDE;
+    a.st1 = 9; a.st2 = 9;
     return a;
 }
 
 static int reduce_kind(int mode, int B, int nblk, int pool, bool with_bwd);
 
-// tri2_raw != NULL: the target's prepared records are not in this workspace (its scan was carried
-// over from another one): read its raw rows instead.  with_bwd: the reduce that follows will carry the direct backward
-// (rrl_registration_step) -- it decides, with the shape, whether the tail kernel runs and wants the dense value lists
-static int line_pair_dist_impl(const float *tri2_raw, const float *line, void *ws, size_t ws_bytes, int B,
+// with_bwd: the reduce that follows will carry the direct backward (rrl_registration_step) -- it decides, with the shape,
+// whether the tail kernel runs and wants the dense value lists
+static int line_pair_dist_impl(const float *tri1, const float *tri2, const float *line, void *ws, size_t ws_bytes, int B,
                                int N, int M, int L, int s_m, int s_n, int e_m, int e_n, int pool,
                                const RrlCall &o, void *stream, bool with_bwd = false) {
-    if (!line || !ws || B < 0 || N < 0 || M < 0 || L < 0 || L >= (1 << 24)) return RRL_E_ARG;  // 24-bit line ids in LDS
+    if (!tri1 || !tri2 || !line || !ws || B < 0 || N < 0 || M < 0 || L < 0 || L >= (1 << 24)) return RRL_E_ARG;  // 24-bit line ids in LDS
     if (s_m < 1 || s_n < 1 || e_m > RRL_MAX_HITS + 1 || e_n > RRL_MAX_HITS + 1) return RRL_E_RANGE;
     WsLayout w(B, N, M, L);
     if (ws_bytes < w.total) return RRL_E_WS;
     if (B == 0 || L == 0) return 0;
-    PairArgs pa = pair_args(tri2_raw, line, ws, w, B, N, M, L, s_m, s_n, e_m, e_n);
+    PairArgs pa = pair_args(tri1, tri2, line, ws, w, B, N, M, L, s_m, s_n, e_m, e_n);
     if (reduce_kind(o.reduce_mode, B, (L + 1023) / 1024, pool, with_bwd) != 2) pa.vlist = nullptr;  // only the tail kernel reads VLIST
     hipLaunchKernelGGL(line_pair_dist_kernel, dim3((unsigned)((L + 1023) / 1024), (unsigned)B), dim3(1024), 0,
                        (hipStream_t)stream, pa);
@@ -310,8 +312,7 @@ static int line_pair_dist_impl(const float *tri2_raw, const float *line, void *w
 extern "C" int rrl_line_pair_dist_ex(const float *tri1, const float *tri2, const float *line,
                                      void *ws, size_t ws_bytes, int B, int N, int M, int L, int s_m,
                                      int s_n, int e_m, int e_n, int pool, const rrl_opts *opts, void *stream) {
-    if (!tri1 || !tri2) return RRL_E_ARG;  // the prepared records of both (rrl_tri_prepare) are read
-    return line_pair_dist_impl(nullptr, line, ws, ws_bytes, B, N, M, L, s_m, s_n, e_m, e_n, pool, rrl_resolve_opts(opts), stream);
+    return line_pair_dist_impl(tri1, tri2, line, ws, ws_bytes, B, N, M, L, s_m, s_n, e_m, e_n, pool, rrl_resolve_opts(opts), stream);
 }
 extern "C" int rrl_line_pair_dist(const float *tri1, const float *tri2, const float *line,
                                   void *ws, size_t ws_bytes, int B, int N, int M, int L, int s_m,
@@ -2387,21 +2388,21 @@ static int loss_forward_impl(const float *tri1, const float *tri2, const float *
             sb.gR = tb->gR; sb.gt = tb->gt; sb.payload = tb->payload; sb.mctl = w.u32(ws, RRL_WS_MCTL);
             sb.B = B; sb.N = N; sb.L = L; sb.transpose_r = tb->transpose_r;
             hipLaunchKernelGGL(pair_reduce_bwd_kernel, dim3((unsigned)B), dim3(1024), sizeof(int) * 2, (hipStream_t)stream,
-                               pair_args(target_ws ? tri2 : nullptr, line, ws, w, B, N, M, L, s_m, s_n, e_m, e_n, false),
+                               pair_args(tri1, tri2, line, ws, w, B, N, M, L, s_m, s_n, e_m, e_n, false),
                                reduce_args(ws, w, loss, B, L, s_m, s_n, e_m, e_n, 0), sb);
             RRL_LAUNCH_CHECK();
             if (bwd_done) *bwd_done = true;
             return 0;
         }
         hipLaunchKernelGGL(pair_reduce_kernel, dim3((unsigned)B), dim3(1024), sizeof(int) * 2, (hipStream_t)stream,
-                           pair_args(target_ws ? tri2 : nullptr, line, ws, w, B, N, M, L, s_m, s_n, e_m, e_n, false),
+                           pair_args(tri1, tri2, line, ws, w, B, N, M, L, s_m, s_n, e_m, e_n, false),
                            reduce_args(ws, w, loss, B, L, s_m, s_n, e_m, e_n, 0));
         RRL_LAUNCH_CHECK();
         return 0;
     }
     {
         RrlRange r("K2 per-line distances");
-        if ((rc = line_pair_dist_impl(target_ws ? tri2 : nullptr, line, ws, ws_bytes, B, N, M, L, s_m, s_n, e_m,
+        if ((rc = line_pair_dist_impl(tri1, tri2, line, ws, ws_bytes, B, N, M, L, s_m, s_n, e_m,
                                       e_n, pool, o, stream, tb != nullptr)))
             return rc;
     }

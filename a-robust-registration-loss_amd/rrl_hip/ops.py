@@ -317,6 +317,8 @@ def loss_forward_raw(tri1, tri2, line, rng=(1, 1, 5, 5), pool=False, mode="cull"
                   "rrl_loss_forward")
             return st
         check(lib.rrl_tri_prepare_ex(_p(tri1), _p(tri2), ws, nb, B, N, M, L, op, s), "rrl_tri_prepare")
+        if staged == "mixed":  # (tests) the later stages WITHOUT the build's options: the workspace describes itself
+            op = None
         check(lib.rrl_line_tri_scan_ex(_p(line), ws, nb, B, N, M, L, _MODES[mode], int(chunk), op, s),
               "rrl_line_tri_scan")
         check(lib.rrl_line_pair_dist_ex(_p(tri1), _p(tri2), _p(line), ws, nb, B, N, M, L, s_m, s_n, e_m,

@@ -82,7 +82,9 @@ enum {
     RRL_WS_COUNT2,     /* int32[B][L]                                                      */
     RRL_WS_HIT1,       /* int32[B][L][4] unordered hit indices                              */
     RRL_WS_HIT2,
-    RRL_WS_PTRI1,      /* float[B][N][12] 9 coords, thr2, thr, original triangle index (int)  */
+    RRL_WS_PTRI1,      /* float[B][N][12] 9 coords, thr2, thr, original triangle index (int): the scans' records.  Rows in
+                          original order after a cold build, at the triangles' SORTED positions after a prepared build
+                          (rrl_opts.order1 / order2) -- slot 7 of the cloud's first APART row says which (0 / 1)  */
     RRL_WS_PTRI2,      /* float[B][M][12]                                                   */
     RRL_WS_P0S1,       /* float[B][64*NSG1][4] P0 + thr2 in grid-cell (Hilbert curve) order -- clouds of more than 4096
                           triangles: each chunk of 4096 (by original index) in its own order; NSG = ceil(N/64)   */
@@ -93,7 +95,7 @@ enum {
     RRL_WS_GRP2,       /*   supergroup [0] its own sphere, [1..4] its groups of 16, [5..12] their halves of 8   */
     RRL_WS_CREC1,      /* float[B][16*NG1][4] P0 + thr2 in original order (input of the sort)   */
     RRL_WS_CREC2,
-    RRL_WS_APART,      /* float[2][B][ceil(max(N,M)/256)][8] per-workgroup AABB / max |P|^2 partials */
+    RRL_WS_APART,      /* float[2][B][ceil(max(N,M)/256)][8] per-workgroup AABB / max |P|^2 partials (slot 7: PTRI layout) */
     RRL_WS_KJ,         /* uint8[B][L]  k | j<<4, 0 = line not selected                      */
     RRL_WS_SEL,        /* int32[B][L]  indices of the selected lines, compacted (any order)  */
     RRL_WS_HS1,        /* int32[B][L][4] ascending hit indices (nonzero() order)            */

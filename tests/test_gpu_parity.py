@@ -93,6 +93,11 @@ def _check_sorted_layout(st, tri, thr, cloud=1, b=0):
     p0s = (st.p0s1 if cloud == 1 else st.p0s2)[b].cpu().numpy()
     tree = (st.grp1 if cloud == 1 else st.grp2)[b].cpu().numpy()
     assert sorted(idx[:n].tolist()) == list(range(n))
+    # the 48-byte records carry their triangle index: in original order (cold build) or at the sorted positions (prepared
+    # build) -- by triangle from here on
+    own = pt[:, 11].copy().view(np.int32)
+    assert np.array_equal(own, np.arange(n)) or np.array_equal(own, idx[:n])
+    pt = pt[np.argsort(own, kind="stable")]
     np.testing.assert_array_equal(p0s[:n, :3], pt[idx[:n], :3])
     np.testing.assert_array_equal(p0s[:n, 3], pt[idx[:n], 9])
     assert np.all(p0s[n:] == 0)

@@ -78,8 +78,11 @@ def test_cloud_order_and_prepared_forward(L, oracle, B, n, m, nl):
     strict = ops.loss_forward_raw(t1, t2, ln, mode="strict")
     prep = ops.loss_forward_raw(t1, t2, ln, mode="cull", opts=ops.make_opts(order1=o1, order2=o2))
     staged = ops.loss_forward_raw(t1, t2, ln, mode="cull", staged=True, opts=ops.make_opts(order1=o1, order2=o2))
+    # a prepared build followed by stage calls that are NOT handed the build's options: the workspace itself says where the
+    # 48-byte records lie (slot 7 of the cloud's first partial row), PMAX is complete after rrl_tri_prepare_ex
+    mixed = ops.loss_forward_raw(t1, t2, ln, mode="cull", staged="mixed", opts=ops.make_opts(order1=o1, order2=o2))
     torch.cuda.synchronize()
-    for st in (strict, prep, staged):
+    for st in (strict, prep, staged, mixed):
         _same_evaluation(plain, st)
     assert torch.equal(prep.idx1, o1) and torch.equal(prep.idx2, o2)
     assert torch.equal(plain.pmax, prep.pmax) and torch.equal(plain.pmax, staged.pmax)
@@ -101,11 +104,24 @@ def test_refit_tree_equals_the_sort_kernels_tree(L, n, m):
     prep = ops.loss_forward_raw(t1, t2, ln, mode="cull",
                                 opts=ops.make_opts(order1=plain.idx1.clone(), order2=plain.idx2.clone()))
     torch.cuda.synchronize()
-    for f in ("idx1", "idx2", "p0s1", "p0s2", "ptri1", "ptri2", "del1", "del2", "pmax"):
+    for f in ("idx1", "idx2", "p0s1", "p0s2", "del1", "del2", "pmax"):
         assert torch.equal(getattr(plain, f), getattr(prep, f)), f
+    for f in ("ptri1", "ptri2"):  # the prepared build keeps the 48-byte records at their SORTED positions
+        assert not torch.equal(getattr(plain, f), getattr(prep, f)), f
+        assert torch.equal(_ptri_by_triangle(getattr(plain, f)), _ptri_by_triangle(getattr(prep, f))), f
+        assert torch.equal(getattr(prep, f)[..., 11].view(torch.int32), getattr(plain, "idx" + f[-1])[:, :getattr(prep, f).shape[1]]), f
     for f in ("grp1", "grp2"):  # NaN radii mark empty nodes: compare the bit patterns
         assert torch.equal(getattr(plain, f).view(torch.int32), getattr(prep, f).view(torch.int32)), f
     _same_evaluation(plain, prep)
+
+
+def _ptri_by_triangle(rows):
+    """PTRI [B][n][12] re-indexed by the triangle index every record carries (slot 11): the cold build keeps the records in
+    original order, the prepared build at their sorted positions -- the same records either way."""
+    f = rows[..., 11].contiguous().view(torch.int32).long()
+    out = torch.full_like(rows, float("nan"))
+    out.scatter_(1, f.unsqueeze(-1).expand_as(rows), rows)
+    return out
 
 
 def _rot(axis, deg):
@@ -179,7 +195,7 @@ def test_kept_target_is_rebuilt_when_it_changes(L):
         torch.cuda.synchronize()
         assert torch.equal(a[0], b_[0]) and torch.equal(cold.st.bsum, prep.st.bsum) and torch.equal(a[4], b_[4])
         assert torch.equal(cold.st.count2, prep.st.count2)
-        assert torch.equal(cold.st.ptri2, prep.st.ptri2)
+        assert torch.equal(_ptri_by_triangle(cold.st.ptri2), _ptri_by_triangle(prep.st.ptri2))
 
     same()
     assert prep._kept_key is not None
@@ -203,7 +219,7 @@ def test_kept_target_is_rebuilt_when_it_changes(L):
     a = cold(R, t, ln, tar_tri=tar2)
     b_ = prep(R, t, ln, tar_tri=tar2)
     torch.cuda.synchronize()
-    assert torch.equal(a[0], b_[0]) and torch.equal(cold.st.ptri2, prep.st.ptri2)
+    assert torch.equal(a[0], b_[0]) and torch.equal(_ptri_by_triangle(cold.st.ptri2), _ptri_by_triangle(prep.st.ptri2))
     a = cold(R, t, ln)
     b_ = prep(R, t, ln)  # kept again, now tar2's records
     torch.cuda.synchronize()
