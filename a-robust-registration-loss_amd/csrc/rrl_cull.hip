@@ -222,8 +222,8 @@ __device__ __forceinline__ void tri_record_row(const BuildArgs &a, int cloud, in
     tri_thresholds(c, &thr, &x, &e01);  // code/loss.py:94-110
     // NaN reach (culled scan, "NaN detection" in the header): points 1, 2 lie within e01 of point 0, and the
     // tree nodes carry thr: del >= e01 - thr in exact arithmetic (e01, thr as rounded here: <= 3u off)
-    if (float *del = cloud ? a.del2 : a.del1)
-        del[(size_t)b * n + f] = fmaxf(e01 * 1.000002f - thr, 0.0f) * 1.000001f;
+    if (float *del = cloud ? a.del2 : a.del1)  // (at the record's row, like PTRI)
+        del[(size_t)b * n + prow] = fmaxf(e01 * 1.000002f - thr, 0.0f) * 1.000001f;
     float4 *row = (float4 *)((cloud ? a.ptri2 : a.ptri1) + ((size_t)b * n + prow) * PTRI_STRIDE);
     row[0] = make_float4(c[0], c[1], c[2], c[3]);
     row[1] = make_float4(c[4], c[5], c[6], c[7]);
@@ -295,9 +295,9 @@ __global__ __launch_bounds__(REC_BLK) void tri_records_kernel(const BuildArgs a)
 // rpm/Train_RPM.py:207-231; the reference itself suggests a tree, code/loss.py:260-262).  So the cell sort runs once
 // per cloud (rrl_cloud_order) and this kernel replaces tri_records_kernel + tri_sort_kernel in every later step:
 //   lane = one SORTED position s of the cloud; f = order[s]; the triangle's raw row is gathered, moved by the sample's
-//   pose (source of the fused op), the moved row and the NaN reach go to their ORIGINAL-order rows (TRI1, DEL: the later
-//   stages index them by triangle), the 48-byte record (PTRI: it carries f), the 16-byte (P0, thr2) record and f to
-//   position s (PTRI, P0S, IDX -- coalesced stores; the scan resolves a candidate from its position alone, one dependent
+//   pose (source of the fused op), the moved row goes to its ORIGINAL-order row (TRI1: the later stages index it by
+//   triangle), the 48-byte record (PTRI: it carries f), the NaN reach, the 16-byte (P0, thr2) record and f to position
+//   s (PTRI, DEL, P0S, IDX -- coalesced stores; the scan resolves a candidate from its position alone, one dependent
 //   load less than through IDX; slot 7 of the cloud's first APART row tells the scan which layout PTRI has), and the
 //   wavefront -- which holds exactly one supergroup of 64 sorted records -- REFITS the supergroup's 13
 //   sphere-tree nodes to the moved points with DPP reductions over 8 / 16 / 64 lanes (wave_tree): the same nodes,
@@ -1300,13 +1300,19 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(6, 8))
     const bool nanwide = cs.nanwide;  // uniform over the launch's workgroups of this cloud and sample
     // nanwide (header, "NaN"): the NaN reach del of this lane's records, requested while the lines are still in flight
     float dv[RPT];
+    const bool psorted = __builtin_amdgcn_readfirstlane(__float_as_int(play)) != 0;  // (1.0f: PTRI / DEL rows at sorted positions)
     if (nanwide && one_each) {
         const float *del = (cloud ? del2 : del1) + (size_t)b * n;
-        int idx0[RPT];
+        if (psorted) {  // uniform: the prepared build left DEL at the sorted positions -- no dependent gather through IDX
 #pragma unroll
-        for (int k = 0; k < RPT; ++k) idx0[k] = tid + 64 * WPB * k < nsl * SGT ? idx[sg0 * SGT + tid + 64 * WPB * k] : 0;
+            for (int k = 0; k < RPT; ++k) dv[k] = sg0 * SGT + tid + 64 * WPB * k < n ? del[sg0 * SGT + tid + 64 * WPB * k] : 0.0f;
+        } else {
+            int idx0[RPT];
 #pragma unroll
-        for (int k = 0; k < RPT; ++k) dv[k] = sg0 * SGT + tid + 64 * WPB * k < n ? del[idx0[k]] : 0.0f;
+            for (int k = 0; k < RPT; ++k) idx0[k] = tid + 64 * WPB * k < nsl * SGT ? idx[sg0 * SGT + tid + 64 * WPB * k] : 0;
+#pragma unroll
+            for (int k = 0; k < RPT; ++k) dv[k] = sg0 * SGT + tid + 64 * WPB * k < n ? del[idx0[k]] : 0.0f;
+        }
     }
 #if CULL_REGLINES
     const float v0[6] = {g0[0].x, g0[0].y, g0[1].x, g0[1].y, g0[2].x, g0[2].y};
@@ -1354,7 +1360,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(6, 8))
             const float *del = (cloud ? del2 : del1) + (size_t)b * n;
             for (int i = tid; i < nsl * SGT; i += blockDim.x) {
                 const int sp = sg0 * SGT + i;
-                dl[i] = sp < n ? del[idx[sp]] : 0.0f;
+                dl[i] = sp < n ? del[psorted ? sp : idx[sp]] : 0.0f;
             }
         }
         __syncthreads();
@@ -1419,7 +1425,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(6, 8))
     ctx.cands = cands_lds[wave];
     ctx.idx = idx;
     ctx.ptri = ptri;
-    ctx.psorted = __builtin_amdgcn_readfirstlane(__float_as_int(play)) != 0;  // (1.0f: sorted rows)
+    ctx.psorted = psorted;
     ctx.cnt = cnt;
     ctx.hit = hit;
     ctx.lbase = lw0;

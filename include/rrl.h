@@ -121,7 +121,8 @@ enum {
     RRL_WS_BLKCNT,     /* int32[B][ceil(L/1024)] selected lines per 1024-line tile               */
     RRL_WS_HISTG,      /* uint32[2 B][2][4096] cell counts and cursors of the wide sort (clouds > 4096) */
     RRL_WS_DEL1,       /* float[B][N]  NaN reach of a triangle: max(|P1-P0|, |P2-P0|) - thr, clamped at 0, rounded up: how   */
-    RRL_WS_DEL2,       /* float[B][M]  much farther than thr points 1, 2 can sit from point 0 (culled scan, NaN detection)   */
+    RRL_WS_DEL2,       /* float[B][M]  much farther than thr points 1, 2 can sit from point 0 (culled scan, NaN detection);
+                          rows laid out like PTRI's (original order / sorted positions)                                  */
     RRL_WS_MHIST,      /* uint32[B][2048] histogram of the D values' bits 30..20, accumulated by the per-line stage (the
                           median's first radix pass); MHIST, MCTL, MSUM are contiguous and cleared per call                 */
     RRL_WS_MCTL,       /* uint32[B][64]  [0..15] lines per (k,j) bucket (per-line stage); [16] candidate cursor, [17] / [18]
