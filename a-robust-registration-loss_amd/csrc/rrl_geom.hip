@@ -531,12 +531,16 @@ extern "C" int rrl_se3_exp_bwd(const float *xi, const float *gR, const float *gT
 // (Round 4: in fp32, 1 - 0.999^t carries a relative error of 3e-5 at small t and 1.0f - 0.999f differs from
 // float(0.001) by 1.3e-5 -- enough to move the demo's xi by 3e-8 per epoch and, at the reference's data scale, to
 // flip labels within three epochs; tests/golden/demo_trajectory_airplane.npz.)
+// lb1 / lb2 = log2(b1), log2(b2), taken on the HOST in double: beta ** step = exp2(step * log2(beta)) -- a product and one
+// double exp2 instead of two double pow calls (1.2 us of the single wavefront's 6.2 us in se3_adam_step_kernel); the
+// result is within ~1e-15 of pow's (|step * log2 beta| <= 15 for beta = 0.999 over 10^4 steps), far inside the float
+// rounding of step_size and sqrt(bias2) that follows.
 __device__ __forceinline__ float adam_update(float p, float g, float &m, float &v, float step, float lr, double b1, double b2,
-                                             double eps) {
+                                             double eps, double lb1, double lb2) {
     const float w1 = (float)(1.0 - b1), b2f = (float)b2, w2 = (float)(1.0 - b2);
     m = m + w1 * (g - m);                  // exp_avg.lerp_(grad, 1 - beta1)
     v = v * b2f + (g * g) * w2;            // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
-    const double bias1 = 1.0 - pow(b1, (double)step), bias2 = 1.0 - pow(b2, (double)step);
+    const double bias1 = 1.0 - exp2((double)step * lb1), bias2 = 1.0 - exp2((double)step * lb2);
     const float step_size = (float)((double)lr / bias1), bc2 = (float)sqrt(bias2);
     const float denom = sqrtf(v) / bc2 + (float)eps;
     return p + (-step_size * m) / denom;   // param.addcdiv_(exp_avg, denom, value=-step_size)
@@ -550,7 +554,7 @@ __global__ __launch_bounds__(256) void adam_gated_kernel(float *__restrict__ p, 
                                                          float *__restrict__ m, float *__restrict__ v,
                                                          float *__restrict__ state, const float *__restrict__ lr,
                                                          const int32_t *__restrict__ gate, int n, double b1, double b2,
-                                                         double eps) {
+                                                         double eps, double lb1, double lb2) {
     const int i = threadIdx.x;
     const bool ok = gate == nullptr || gate[0] > 0;
     const float step = state[0] + (ok ? 1.0f : 0.0f);
@@ -558,7 +562,7 @@ __global__ __launch_bounds__(256) void adam_gated_kernel(float *__restrict__ p, 
     if (ok) {
         for (int q = i; q < n; q += 256) {
             float mi = m[q], vi = v[q];
-            p[q] = adam_update(p[q], g[q], mi, vi, step, lr[0], b1, b2, eps);
+            p[q] = adam_update(p[q], g[q], mi, vi, step, lr[0], b1, b2, eps, lb1, lb2);
             m[q] = mi;
             v[q] = vi;
         }
@@ -571,7 +575,7 @@ extern "C" int rrl_adam_gated(float *p, const float *g, float *m, float *v, floa
     if (!p || !g || !m || !v || !state || !lr || n < 0) return RRL_E_ARG;
     if (n == 0) return 0;
     hipLaunchKernelGGL(adam_gated_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, p, g, m, v, state, lr, gate, n,
-                       b1, b2, eps);
+                       b1, b2, eps, log2(b1), log2(b2));
     RRL_LAUNCH_CHECK();
     return 0;
 }
@@ -586,7 +590,8 @@ __global__ __launch_bounds__(64) void se3_adam_step_kernel(float *__restrict__ x
                                                            float *__restrict__ v, float *__restrict__ state,
                                                            const float *__restrict__ lr,
                                                            const int32_t *__restrict__ gate, double b1, double b2,
-                                                           double eps, float *__restrict__ R, float *__restrict__ T,
+                                                           double eps, double lb1, double lb2, float *__restrict__ R,
+                                                           float *__restrict__ T,
                                                            float *__restrict__ gxi, const float *__restrict__ loss,
                                                            const float *__restrict__ value, float *__restrict__ table,
                                                            long long *__restrict__ cursor, long long nrows,
@@ -594,6 +599,14 @@ __global__ __launch_bounds__(64) void se3_adam_step_kernel(float *__restrict__ x
                                                            int n_aabb_rows, float *__restrict__ box) {
     const int k = threadIdx.x;
     const bool ok = gate == nullptr || gate[0] > 0;
+    // (the log row's inputs are requested with the first loads, not after the arithmetic)
+    long long at = -1;
+    float q0 = 0.0f, q1 = 0.0f;
+    if (k == 0 && table && cursor) {
+        at = cursor[0];
+        q0 = loss ? loss[0] : 0.0f;
+        q1 = value ? value[0] : 0.0f;
+    }
     // the moved source's AABB for the NEXT epoch's sampler (code/test_demo_optimized_Lie_Algebra.py:46-51 samples against
     // the previous epoch's moved source) from the per-workgroup partial rows the loss step's records launch just left
     // (APART: min xyz, max xyz of the moved first points) -- one launch (rigid apply + AABB) less per epoch
@@ -621,7 +634,7 @@ __global__ __launch_bounds__(64) void se3_adam_step_kernel(float *__restrict__ x
         if (gxi) gxi[k] = g;
         if (ok) {
             float mi = m[k], vi = v[k];
-            pk = adam_update(pk, g, mi, vi, step, lr[0], b1, b2, eps);
+            pk = adam_update(pk, g, mi, vi, step, lr[0], b1, b2, eps, lb1, lb2);
             m[k] = mi;
             v[k] = vi;
             xi[k] = pk;
@@ -639,8 +652,7 @@ __global__ __launch_bounds__(64) void se3_adam_step_kernel(float *__restrict__ x
 #pragma unroll
     for (int i = 0; i < 3; ++i) T[i] = t[i];
     if (table && cursor) {
-        const long long at = cursor[0];
-        const float q[3] = {loss ? loss[0] : 0.0f, value ? value[0] : 0.0f, ok ? 1.0f : 0.0f};
+        const float q[3] = {q0, q1, ok ? 1.0f : 0.0f};
         for (int c = 0; c < 3; ++c) {
             if (row) row[c] = q[c];
             if (at >= 0 && at < nrows) table[at * 3 + c] = q[c];
@@ -656,7 +668,8 @@ extern "C" int rrl_se3_adam_step(float *xi, const float *gR, const float *gT, fl
                                  float *box, void *stream) {
     if (!xi || !m || !v || !state || !lr || !R || !T || (box && (!aabb_rows || n_aabb_rows <= 0))) return RRL_E_ARG;
     hipLaunchKernelGGL(se3_adam_step_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, xi, gR, gT, m, v, state, lr,
-                       gate, b1, b2, eps, R, T, gxi, loss, value, table, cursor, nrows, row, aabb_rows, n_aabb_rows, box);
+                       gate, b1, b2, eps, log2(b1), log2(b2), R, T, gxi, loss, value, table, cursor, nrows, row, aabb_rows,
+                       n_aabb_rows, box);
     RRL_LAUNCH_CHECK();
     return 0;
 }
@@ -949,7 +962,13 @@ __device__ __forceinline__ bool face_hit(const float *tab, const float *ln) {
 // error of ~1e-7 size^2 in the cross products (far-away I: the sub-areas dwarf S outright; I from a
 // near-zero denominator is inf/NaN and fails every comparison).  With the demo's radius (the full
 // box diagonal) ~85 % of the candidates end here, for ~40 instructions instead of ~4000.
-__device__ __forceinline__ bool slab_maybe(const float *bb, const float *ln) {
+// inv[a] = 1 / ln[a] (slab_inv: one division per axis, shared by the two boxes of a candidate): the slab parameters are
+// products with it -- 2 ulp from the quotients, against pads of 1e-3 of the extent and a 1e-5 relative tolerance below.
+__device__ __forceinline__ void slab_inv(const float *ln, float *inv) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) inv[a] = 1.0f / ln[a];  // (inf for a zero component: that axis takes the parallel branch)
+}
+__device__ __forceinline__ bool slab_maybe(const float *bb, const float *ln, const float *inv) {
     const float ext[3] = {bb[3] - bb[0], bb[4] - bb[1], bb[5] - bb[2]};
     const float big = fmaxf(fmaxf(ext[0], ext[1]), ext[2]);
     if (!(big < 3.0e38f)) return true;  // non-finite box: decide by the full test
@@ -961,7 +980,7 @@ __device__ __forceinline__ bool slab_maybe(const float *bb, const float *ln) {
         if (fabsf(u) < 1e-12f) {
             if (o < lo || o > hi) return false;
         } else {
-            float t1 = (lo - o) / u, t2 = (hi - o) / u;
+            float t1 = (lo - o) * inv[a], t2 = (hi - o) * inv[a];
             if (t1 > t2) { const float t = t1; t1 = t2; t2 = t; }
             tlo = fmaxf(tlo, t1);
             thi = fminf(thi, t2);
@@ -997,7 +1016,9 @@ __global__ __launch_bounds__(256) void box_accept_kernel(const float *__restrict
         h1 += face_hit(faces[f], ln) ? 1 : 0;
         h2 += face_hit(faces[12 + f], ln) ? 1 : 0;
     }
-    const bool slab = slab_maybe(bb1, ln) && slab_maybe(bb2, ln);
+    float inv[3];
+    slab_inv(ln, inv);
+    const bool slab = slab_maybe(bb1, ln, inv) && slab_maybe(bb2, ln, inv);
     mask[(size_t)b * n + i] = (uint8_t)((h1 > 0 ? 1 : 0) | (h2 > 0 ? 2 : 0) | (slab ? 4 : 0));
     if (hits) {
         hits[((size_t)b * n + i) * 2] = h1;
@@ -1085,8 +1106,11 @@ __device__ __forceinline__ void sample_line(const SampleGeom &g, const float *__
     float al1 = (u[0] * 2.0f) * pi32, v1 = u[1] * 2.0f - 1.0f;
     float al2 = (u[2] * 2.0f) * pi32, v2 = u[3] * 2.0f - 1.0f;
     float s1 = sqrtf(1.0f - v1 * v1), s2 = sqrtf(1.0f - v2 * v2);
-    float q1[3] = {(g.rad * s1) * cosf(al1), (g.rad * sinf(al1)) * s1, g.rad * v1};
-    float q2[3] = {(g.rad * s2) * cosf(al2), (g.rad * sinf(al2)) * s2, g.rad * v2};
+    float sn1, cs1, sn2, cs2;  // (sincosf: ONE argument reduction for the pair -- the same bits as sinf / cosf, which each
+    sincosf(al1, &sn1, &cs1);  //  evaluate both polynomials after their own reduction and pick one)
+    sincosf(al2, &sn2, &cs2);
+    float q1[3] = {(g.rad * s1) * cs1, (g.rad * sn1) * s1, g.rad * v1};
+    float q2[3] = {(g.rad * s2) * cs2, (g.rad * sn2) * s2, g.rad * v2};
     float d[3] = {q2[0] - q1[0], q2[1] - q1[1], q2[2] - q1[2]};
     float den = fmaxf(norm3f(d[0], d[1], d[2]), 1e-12f);  // F.normalize
 #pragma unroll
@@ -1143,7 +1167,9 @@ __global__ __launch_bounds__(1024) void sample_count_kernel(
         bool pre = false;
         if (ok) {
             sample_line(g, rands, rng_state, B, n, b, rd, i, ln);
-            pre = !prefilter || (slab_maybe(g.bb1, ln) && slab_maybe(g.bb2, ln));
+            float inv[3];
+            slab_inv(ln, inv);
+            pre = !prefilter || (slab_maybe(g.bb1, ln, inv) && slab_maybe(g.bb2, ln, inv));
         }
         const unsigned long long m = __ballot(pre);
         if (lane == 0) wave_cnt[wave] = __popcll(m);
