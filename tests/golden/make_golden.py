@@ -524,20 +524,32 @@ def _ref_pair(group, label, seed):
     return v1, v2, n1, n2, bb, float(np.linalg.norm(bb[0] - bb[-1]))
 
 
-def refdata():
+REF_PAIRS_A = (("airplane_data", "0", "airplane0", 3000), ("airplane_data", "3", "airplane3", 3000),
+               ("human_data", "0", "human0", 3000), ("real_data", "0", "real0", 2500))
+# ... and every other pair the reference ships (challenge_data/0 is loss_demo_scale.npz): all 12 are fixtures
+REF_PAIRS_B = (("airplane_data", "1", "airplane1", 2000), ("airplane_data", "2", "airplane2", 2000),
+               ("airplane_data", "4", "airplane4", 2000), ("human_data", "1", "human1", 2000),
+               ("human_data", "2", "human2", 2000), ("real_data", "1", "real1", 2000), ("real_data", "2", "real2", 2000))
+
+
+def refdata_rest():
+    """The remaining seven pairs of code/sample_data/ (2000 lines each), same recipe as refdata()."""
+    refdata(REF_PAIRS_B)
+
+
+def refdata(pairs=REF_PAIRS_A):
     """Loss fixtures on the REFERENCE'S OWN sample pairs (code/sample_data/*; its demo iterates such pairs,
     test_demo_optimized_Lie_Algebra.py:158-162): two airplane pairs (1024 / 1024), a human pair (N = 1024, M = 2048: the
     first N != M fixture on reference data) and a real-scan fragment pair (2048 / 2048, BASELINE configs[4]'s kind of
     data) -- counts, hit lists, weights, D, median, loss and points1.grad from the reference.  The line seed of each
     fixture is the first one whose label decisions are provably non-borderline (margin > 2e-6 >> 1 ulp)."""
-    for group, label, tag, nl in (("airplane_data", "0", "airplane0", 3000), ("airplane_data", "3", "airplane3", 3000),
-                                  ("human_data", "0", "human0", 3000), ("real_data", "0", "real0", 2500)):
+    for group, label, tag, nl in pairs:
         v1, v2, n1, n2, bb, rad = _ref_pair(group, label, 123)
         for seed in range(7, 40):
             lines = ref_lines(seed, rad, v2.mean(0), v1, v2, nl)
             mg = min(margin(n1, lines), margin(n2, lines))
-            if mg > 2e-6:
-                break
+            if mg > (2e-6 if pairs is REF_PAIRS_A else 1.2e-5):  # (the tests ask for > 1e-5; the first four were taken at > 2e-6
+                break                                             #  and happen to clear it)
         print(f"{tag}: N={n1.shape[0]} M={n2.shape[0]} radius={rad:.3f} filled "
               f"{(np.abs(lines).sum(1) > 0).sum()}/{nl} line seed {seed} margin {mg:.2e}")
         loss_fixture(f"loss_ref_{tag}.npz", n1, n2, lines, [(1, 1, 5, 5)])
@@ -592,6 +604,6 @@ def demo_trajectory_airplane():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["main", "neighs", "callsites", "demo_trajectory", "dataset", "accept", "refdata",
-                             "demo_trajectory_airplane"]
+                             "demo_trajectory_airplane", "refdata_rest"]
     for name in which:
         globals()[name]()

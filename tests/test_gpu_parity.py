@@ -21,7 +21,10 @@ LOSS_FIXTURES = ["loss_synth_s0.npz", "loss_synth_s1.npz", "loss_demo_scale.npz"
                  "loss_edge_zero_dup.npz",
                  # the reference's OWN sample pairs (code/sample_data/: airplane 1024 / 1024, human 1024 / 2048,
                  # real-scan fragments 2048 / 2048), prepared like its demo does -- make_golden.py refdata
-                 "loss_ref_airplane0.npz", "loss_ref_airplane3.npz", "loss_ref_human0.npz", "loss_ref_real0.npz"]
+                 "loss_ref_airplane0.npz", "loss_ref_airplane3.npz", "loss_ref_human0.npz", "loss_ref_real0.npz",
+                 # ... and the other seven pairs it ships (refdata_rest; challenge_data/0 is loss_demo_scale): all twelve
+                 "loss_ref_airplane1.npz", "loss_ref_airplane2.npz", "loss_ref_airplane4.npz", "loss_ref_human1.npz",
+                 "loss_ref_human2.npz", "loss_ref_real1.npz", "loss_ref_real2.npz"]
 
 
 @pytest.fixture(scope="module")
