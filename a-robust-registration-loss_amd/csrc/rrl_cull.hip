@@ -92,6 +92,7 @@
 #include "rrl_ws.h"
 
 #include "rrl_tree.h"
+#include "rrl_chamfer_walk.h"  // the Chamfer walk as a device function: cull_scan_chamfer_kernel carries it
 
 
 // The build step: everything the scans need from the raw triangles, in two launches.
@@ -1189,40 +1190,56 @@ __device__ __forceinline__ void cull_walk(WaveCtx &ctx, const float4 *node_lds, 
 //           [6] wavefronts that took the strict fallback   [7] (line, triangle) pairs of the fallback
 //           [8] start, [9] end of the wavefront on the 100 MHz wall clock (the kernel lasts as long as its
 //           slowest wavefront: tools/scan_tail.py prints the spread), [10..14] phase stamps
+// The scan's LDS (47 KiB per 8-wavefront workgroup) as ONE object: cull_scan_chamfer_kernel overlays it with the Chamfer
+// walk's (rrl_chamfer_walk.h ChamLds).
+struct CullLds {
+#if !CULL_REGLINES
+    __attribute__((aligned(16))) float2 line_lds[WPB][LPW * 3];    // 24 KiB: raw 24-byte line rows
+#endif
+    __attribute__((aligned(16))) float4 rec_lds[SPW * SGG * ROWS]; //  8.5 KiB
+    __attribute__((aligned(16))) float4 node_lds[SPW * NODE];      //  1.6 KiB
+    __attribute__((aligned(16))) unsigned short qa_lds[WPB][QA_CAP];
+    unsigned short qc_lds[WPB][QC_CAP];
+    __attribute__((aligned(16))) unsigned cands_lds[WPB][WCCAP];
+};
+
+// One workgroup of the culled scan: (bx, by, bz) = its place in the scan's grid (gx, gy: the grid's first two extents)
+// -- blockIdx / gridDim in cull_scan_kernel, decoded from a linear index in cull_scan_chamfer_kernel.
 template <bool COUNT>
-__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(6, 8))) void cull_scan_kernel(
-    const float *__restrict__ ptri1, const float *__restrict__ ptri2, const float4 *__restrict__ p0s1,
+__device__ __forceinline__ void cull_scan_body(
+    CullLds &lds_, const float *__restrict__ ptri1, const float *__restrict__ ptri2, const float4 *__restrict__ p0s1,
     const float4 *__restrict__ p0s2, const int32_t *__restrict__ idx1, const int32_t *__restrict__ idx2,
     const float4 *__restrict__ tree1, const float4 *__restrict__ tree2, const float *__restrict__ line,
     int32_t *__restrict__ count1, int32_t *__restrict__ hit1, int32_t *__restrict__ count2,
     int32_t *__restrict__ hit2, int32_t *__restrict__ status, uint32_t *pmax,
     const float *__restrict__ del1, const float *__restrict__ del2, const float2 *__restrict__ lmax,
     const float *__restrict__ apart, const float *__restrict__ aflag, int nblk_apart, int B,
-    int N, int M, int L, int spw, unsigned long long *__restrict__ counters, long long counter_rows) {
+    int N, int M, int L, int spw, unsigned long long *__restrict__ counters, long long counter_rows,
+    const int bx, const int by, const int bz, const int gx, const int gy) {
 #if !CULL_REGLINES
-    __shared__ __attribute__((aligned(16))) float2 line_lds[WPB][LPW * 3];    // 24 KiB: raw 24-byte line rows
+    float2 (&line_lds)[WPB][LPW * 3] = lds_.line_lds;
 #endif
-    __shared__ __attribute__((aligned(16))) float4 rec_lds[SPW * SGG * ROWS]; //  8.5 KiB
-    __shared__ __attribute__((aligned(16))) float4 node_lds[SPW * NODE];      //  1.6 KiB
-    __shared__ __attribute__((aligned(16))) unsigned short qa_lds[WPB][QA_CAP];
-    __shared__ unsigned short qc_lds[WPB][QC_CAP];
-    __shared__ __attribute__((aligned(16))) unsigned cands_lds[WPB][WCCAP];
+    float4 (&rec_lds)[SPW * SGG * ROWS] = lds_.rec_lds;
+    float4 (&node_lds)[SPW * NODE] = lds_.node_lds;
+    unsigned short (&qa_lds)[WPB][QA_CAP] = lds_.qa_lds;
+    unsigned short (&qc_lds)[WPB][QC_CAP] = lds_.qc_lds;
+    unsigned (&cands_lds)[WPB][WCCAP] = lds_.cands_lds;
     static_assert(WPB * WCCAP >= SPW * SGT, "the NaN-reach scratch aliases the (still unused) candidate buffers");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform for the compiler
     const unsigned long long wall0 = COUNT ? wall_clock64() : 0ull;
     unsigned long long *crow = nullptr;
     if constexpr (COUNT) {
-        const long long wid = (((long long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + wave;
+        const long long wid = (((long long)bz * gy + by) * gx + bx) * (blockDim.x >> 6) + wave;
         if (wid < counter_rows) crow = counters + 16 * wid;
     }
     // XCD-aware mapping: workgroups go to the 8 XCDs round-robin by linear id, and x is the fast
     // index -- with (cloud, sample) on x, all workgroups of one cloud land on the same XCD (when
     // 2B is a multiple of 8), so each XCD's L2 holds 1/8 of the records instead of a copy of all
-    const int z = blockIdx.x, cloud = z >= B ? 1 : 0, b = z - cloud * B;
+    const int z = bx, cloud = z >= B ? 1 : 0, b = z - cloud * B;
     const int n = cloud ? M : N;
     const int nsg = (n + SGT - 1) / SGT;
-    const int sg0 = (int)blockIdx.z * spw;
+    const int sg0 = bz * spw;
     if (sg0 >= nsg) return;  // uniform: the smaller cloud has fewer slices
     const int nsl = min(spw, nsg - sg0);
     const float4 *p0s = (cloud ? p0s2 : p0s1) + (size_t)b * nsg * SGT;
@@ -1264,7 +1281,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(6, 8))
     // this wave's 128 lines: a full, 16-byte aligned tile arrives as three coalesced 16-byte loads per lane straight
     // into its LDS rows; the lanes then pick up their own two lines from there
     const float *ln = line + (size_t)b * L * 6;
-    const int lw0 = ((int)blockIdx.y * (int)(blockDim.x >> 6) + wave) * LPW;
+    const int lw0 = (by * (int)(blockDim.x >> 6) + wave) * LPW;
     const int l0 = lw0 + lane, l1 = l0 + 64;
     const bool live0 = l0 < L, live1 = l1 < L;
     const bool has_lines = lw0 < L;  // a wave without lines (the last tile of the line set) still stages records
@@ -1292,7 +1309,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(6, 8))
     float pm = pmv;
     if (apart != nullptr) {  // uniform
         pm = wave_max_nonneg(pmv);
-        if (blockIdx.y == 0 && blockIdx.z == 0 && tid == 0) pmax[cloud * B + b] = __float_as_uint(pm);
+        if (by == 0 && bz == 0 && tid == 0) pmax[cloud * B + b] = __float_as_uint(pm);
     }
     const float smax = wave_max_nonneg(lm.x), o2max = wave_max_nonneg(lm.y);
     const CloudSlack cs = cull_cloud_slack(smax, o2max, pm);
@@ -1463,6 +1480,74 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(6, 8))
             crow[10] = wall_staged; crow[11] = wall_a; crow[12] = wall_pa; crow[13] = wall_pa; crow[14] = wall_pc;
         }
     }
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(6, 8))) void cull_scan_kernel(
+    const float *__restrict__ ptri1, const float *__restrict__ ptri2, const float4 *__restrict__ p0s1,
+    const float4 *__restrict__ p0s2, const int32_t *__restrict__ idx1, const int32_t *__restrict__ idx2,
+    const float4 *__restrict__ tree1, const float4 *__restrict__ tree2, const float *__restrict__ line,
+    int32_t *__restrict__ count1, int32_t *__restrict__ hit1, int32_t *__restrict__ count2,
+    int32_t *__restrict__ hit2, int32_t *__restrict__ status, uint32_t *pmax,
+    const float *__restrict__ del1, const float *__restrict__ del2, const float2 *__restrict__ lmax,
+    const float *__restrict__ apart, const float *__restrict__ aflag, int nblk_apart, int B,
+    int N, int M, int L, int spw, unsigned long long *__restrict__ counters, long long counter_rows) {
+    __shared__ CullLds lds_;
+    cull_scan_body<COUNT>(lds_, ptri1, ptri2, p0s1, p0s2, idx1, idx2, tree1, tree2, line, count1, hit1, count2, hit2, status,
+                          pmax, del1, del2, lmax, apart, aflag, nblk_apart, B, N, M, L, spw, counters, counter_rows,
+                          (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, (int)gridDim.y);
+}
+
+// ---------------------------------------------------------------------------------------
+// The culled scan AND the Chamfer walk of the same evaluation in ONE launch (round 4b; rrl_ws.h RrlChamRider, rrl_demo_epoch).
+// The walk (rrl_chamfer_from_loss: nearest neighbours between the moved source's and the target's first points through
+// the sorted records and sphere trees the records launch just left) depends on that launch only -- not on the scan -- but
+// consecutive launches of a stream never overlap on this stack (hipExtAnyOrderLaunch is ignored on gfx9, event edges
+// between streams cost tens of microseconds: profiles/r04_experiments.txt 4, 12), so the only way to run two independent
+// 512-lane kernels side by side is to issue them as one grid: workgroups [0, ncham) walk (the long ones start first),
+// the others scan.  Same bodies, same results as the two launches; the LDS of the two is overlaid.  The walk takes
+// max |P|^2 of its target from the partial rows (pm1 == NULL): PMAX is being rebuilt by this launch's scan.
+// ---------------------------------------------------------------------------------------
+struct CullKArgs {
+    const float *ptri1, *ptri2;
+    const float4 *p0s1, *p0s2;
+    const int32_t *idx1, *idx2;
+    const float4 *tree1, *tree2;
+    const float *line;
+    int32_t *count1, *hit1, *count2, *hit2, *status;
+    uint32_t *pmax;
+    const float *del1, *del2;
+    const float2 *lmax;
+    const float *apart, *aflag;
+    int nblk_apart, B, N, M, L, spw, gx, gy;
+};
+struct ChamKArgs {
+    unsigned long long *best_x, *best_y;
+    double *partial, *gpart;
+    float *value;
+    double denom;
+    ChamTick tick;
+    int gx, gy;
+};
+static_assert(NWV == WPB, "the walk and the scan share one launch: the same 512-lane workgroups");
+
+__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4, 8))) void cull_scan_chamfer_kernel(
+    const CullKArgs a, const ChamKArgs c) {
+    __shared__ union {
+        CullLds scan;
+        ChamLds walk;
+    } lds_;
+    const int ncham = c.gx * c.gy, lin = (int)blockIdx.x;
+    if (lin < ncham) {  // uniform per workgroup
+        chamfer_tree_body<false, true>(lds_.walk, a.p0s1, a.p0s2, a.tree1, a.tree2, a.aflag, a.nblk_apart, c.best_x, c.best_y,
+                                       c.partial, a.B, a.N, a.M, nullptr, 0, a.idx1, a.idx2, nullptr, nullptr, c.tick, c.gpart,
+                                       c.value, c.denom, lin % c.gx, lin / c.gx, c.gx, c.gy);
+        return;
+    }
+    const int l2 = lin - ncham, bx = l2 % a.gx, r = l2 / a.gx;
+    cull_scan_body<false>(lds_.scan, a.ptri1, a.ptri2, a.p0s1, a.p0s2, a.idx1, a.idx2, a.tree1, a.tree2, a.line, a.count1,
+                          a.hit1, a.count2, a.hit2, a.status, a.pmax, a.del1, a.del2, a.lmax, a.apart, a.aflag, a.nblk_apart,
+                          a.B, a.N, a.M, a.L, a.spw, nullptr, 0, bx, r % a.gy, r / a.gy, a.gx, a.gy);
 }
 
 // Executed-work counters (profiling; include/rrl.h rrl_scan_counters): while a buffer is set,
@@ -1684,6 +1769,40 @@ int rrl_launch_cull_scan(const float *line, void *ws, const WsLayout &w, int B, 
                        o.counters, o.counter_rows)
     const float *apart = o.prepared() ? w.f32(ws, RRL_WS_APART) : nullptr;  // prepared build: PMAX comes from the partial rows
     const int nblk_apart = ((N > M ? N : M) + REC_BLK - 1) / REC_BLK;
+    if (o.rider && !o.counters && clouds == 2 && waves == WPB && B <= 32767 && N > 0 && M > 0) {
+        // the evaluation's Chamfer walk rides along (cull_scan_chamfer_kernel): ONE launch for both
+        const ChamLayout C(B, N, M);
+        if (o.rider->ws && o.rider->ws_bytes >= C.total && o.rider->best_x && o.rider->best_y && o.rider->value) {
+            CullKArgs a;
+            a.ptri1 = w.f32(ws, RRL_WS_PTRI1); a.ptri2 = w.f32(ws, RRL_WS_PTRI2);
+            a.p0s1 = (const float4 *)w.f32(ws, RRL_WS_P0S1); a.p0s2 = (const float4 *)w.f32(ws, RRL_WS_P0S2);
+            a.idx1 = w.i32(ws, RRL_WS_IDX1); a.idx2 = w.i32(ws, RRL_WS_IDX2);
+            a.tree1 = (const float4 *)w.f32(ws, RRL_WS_GRP1); a.tree2 = (const float4 *)w.f32(ws, RRL_WS_GRP2);
+            a.line = line;
+            a.count1 = w.i32(ws, RRL_WS_COUNT1); a.hit1 = w.i32(ws, RRL_WS_HIT1);
+            a.count2 = w.i32(ws, RRL_WS_COUNT2); a.hit2 = w.i32(ws, RRL_WS_HIT2);
+            a.status = w.i32(ws, RRL_WS_STATUS); a.pmax = (uint32_t *)w.i32(ws, RRL_WS_PMAX);
+            a.del1 = w.f32(ws, RRL_WS_DEL1); a.del2 = w.f32(ws, RRL_WS_DEL2);
+            a.lmax = (const float2 *)w.f32(ws, RRL_WS_LMAX);
+            a.apart = apart; a.aflag = w.f32(ws, RRL_WS_APART);
+            a.nblk_apart = nblk_apart; a.B = B; a.N = N; a.M = M; a.L = L; a.spw = spw;
+            a.gx = clouds * B; a.gy = tiles;
+            ChamKArgs c;
+            char *cw = (char *)o.rider->ws;
+            c.best_x = o.rider->best_x; c.best_y = o.rider->best_y;
+            c.partial = (double *)(cw + C.partial); c.gpart = (double *)(cw + C.gpart);
+            c.value = o.rider->value;
+            c.denom = (double)B * (double)(N + M);
+            uint32_t *mctl = w.u32(ws, RRL_WS_MCTL);  // arrival counters of the walk's mean (rrl_chamfer_from_loss_ex)
+            c.tick = ChamTick{mctl + 32, mctl + 30, 64, 1};
+            c.gx = 2 * B; c.gy = nsgmax;
+            const unsigned nwg = (unsigned)(c.gx * c.gy) + (unsigned)(a.gx * a.gy * zslices);
+            hipLaunchKernelGGL(cull_scan_chamfer_kernel, dim3(nwg), dim3(64 * WPB), 0, s, a, c);
+            hipError_t e = hipGetLastError();
+            if (e == hipSuccess) o.rider->done = 1;
+            return e == hipSuccess ? 0 : (int)e;
+        }
+    }
     if (o.counters) RRL_CULL_LAUNCH(true);
     else RRL_CULL_LAUNCH(false);
 #undef RRL_CULL_LAUNCH

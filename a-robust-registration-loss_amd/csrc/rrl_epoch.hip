@@ -7,6 +7,7 @@
 // (1) -> pose step (1: exp-map backward, gated Adam, next exp map, log row, next sampler box) -- so that a loop pays one
 // host call (~5 us) per epoch instead of a hipGraph replay (~8 us fixed + ~1.5 us per node on this stack,
 // tools/graph_node_cost.py) or eight Python-level calls.  No new arithmetic: the results are those of the four entries.
+#include <cstdlib>
 #include "rrl_ws.h"
 
 extern "C" int rrl_demo_epoch(const rrl_demo_epoch_args *a, void *stream) {
@@ -16,13 +17,23 @@ extern "C" int rrl_demo_epoch(const rrl_demo_epoch_args *a, void *stream) {
     int rc = rrl_sample_lines_rng(a->rng_state, a->radius, a->centers, a->box1, a->box2, a->lines, a->filled, a->tile_counts,
                                   1, L, a->rounds, stream);
     if (rc) return rc;
-    rc = rrl_registration_step_ex(a->src_tri, a->R, a->T, a->tar_tri, a->lines, a->ws, a->ws_bytes, a->loss, a->grad_loss,
-                                  a->gR, a->gt, nullptr, 1, N, M, L, a->transpose_r, 1, 1, 5, 5, RRL_SCAN_CULL, 0, nullptr,
-                                  a->opts, stream);
+    // The Chamfer monitor needs the step's records launch only (the sorted moved source + the kept target), and launches of
+    // one stream never overlap on this stack: its walk RIDES in the culled scan's launch (rrl_ws.h RrlChamRider; same
+    // arithmetic, same value) -- one launch and ~12 us per epoch less.  RRL_DEMO_RIDE=0: the separate launch, as before.
+    RrlCall o = rrl_resolve_opts(a->opts);
+    RrlChamRider rider = {a->cham_ws, a->cham_ws_bytes, (unsigned long long *)a->best_x, (unsigned long long *)a->best_y,
+                          a->cham_value, 0};
+    const char *env = getenv("RRL_DEMO_RIDE");  // (read per call: tests switch it between epochs)
+    if (!(env && env[0] == '0')) o.rider = &rider;
+    rc = rrl_registration_step_call(a->src_tri, a->R, a->T, a->tar_tri, a->lines, a->ws, a->ws_bytes, a->loss, a->grad_loss,
+                                    a->gR, a->gt, nullptr, 1, N, M, L, a->transpose_r, 1, 1, 5, 5, RRL_SCAN_CULL, 0, nullptr, o,
+                                    stream);
     if (rc) return rc;
-    rc = rrl_chamfer_from_loss(a->ws, a->ws, a->ws_bytes, 1, N, M, L, a->cham_ws, a->cham_ws_bytes, a->best_x, a->best_y,
-                               a->cham_value, stream);
-    if (rc) return rc;
+    if (!rider.done) {
+        rc = rrl_chamfer_from_loss(a->ws, a->ws, a->ws_bytes, 1, N, M, L, a->cham_ws, a->cham_ws_bytes, a->best_x, a->best_y,
+                                   a->cham_value, stream);
+        if (rc) return rc;
+    }
     const WsLayout w(1, N, M, L);
     if (a->ws_bytes < w.total) return RRL_E_WS;
     const int32_t *info = w.i32(a->ws, RRL_WS_INFO);        // gate: the loss's bucket count (`if loss_di is not None`)

@@ -1691,6 +1691,7 @@ RrlCall rrl_resolve_opts(const rrl_opts *p) {
     RrlCall o;
     o.clear_ptr = nullptr;
     o.clear_bytes = 0;
+    o.rider = nullptr;
     rrl_opts v;
     memset(&v, 0, sizeof v);
     v.reduce_mode = v.deterministic = v.sort_parts = v.scan_variant = -1;
@@ -2511,11 +2512,17 @@ extern "C" int rrl_registration_step_ex(const float *src, const float *R, const 
                                         const float *grad_loss, float *gR, float *gt, float *payload, int B, int N,
                                         int M, int L, int transpose_r, int s_m, int s_n, int e_m, int e_n, int mode,
                                         int chunk, const void *target_ws, const rrl_opts *opts, void *stream) {
+    return rrl_registration_step_call(src, R, t, tri2, line, ws, ws_bytes, loss, grad_loss, gR, gt, payload, B, N, M, L,
+                                      transpose_r, s_m, s_n, e_m, e_n, mode, chunk, target_ws, rrl_resolve_opts(opts), stream);
+}
+int rrl_registration_step_call(const float *src, const float *R, const float *t, const float *tri2, const float *line,
+                               void *ws, size_t ws_bytes, float *loss, const float *grad_loss, float *gR, float *gt,
+                               float *payload, int B, int N, int M, int L, int transpose_r, int s_m, int s_n, int e_m, int e_n,
+                               int mode, int chunk, const void *target_ws, const RrlCall &o, void *stream) {
     if (!src || !R || !t || !tri2 || !line || !ws || !loss || !grad_loss || !gR || !gt) return RRL_E_ARG;
     if (B < 0 || N < 0 || M < 0 || L < 0) return RRL_E_ARG;
     WsLayout w(B, N, M, L);
     if (ws_bytes < w.total) return RRL_E_WS;
-    const RrlCall o = rrl_resolve_opts(opts);
     const int nblk = (L + 1023) / 1024;
     bool done = false;
     int rc;

@@ -85,6 +85,17 @@ struct WsLayout {
 
 // The options of ONE call, resolved once at its top (include/rrl.h rrl_opts; defaults = what the rrl_set_* setters /
 // RRL_* environment variables selected) and handed through its stages by value: no stage reads a process-wide knob.
+// A Chamfer walk between the two clouds of THIS evaluation (what rrl_chamfer_from_loss computes after it) that the culled
+// scan's launch may carry beside its own workgroups: the walk needs the records launch only, and launches of one stream
+// never overlap on this stack.  done = 1 when it rode along (else the caller launches rrl_chamfer_from_loss as before).
+struct RrlChamRider {
+    void *ws;              // Chamfer workspace (rrl_chamfer_workspace_bytes)
+    size_t ws_bytes;
+    unsigned long long *best_x, *best_y;
+    float *value;
+    int done;
+};
+
 struct RrlCall {
     int flags;
     int reduce_mode;    // 0 auto, 1 single, 2 tiled, 3 xchg
@@ -98,10 +109,16 @@ struct RrlCall {
     // state: the scatter target of rrl_loss_step (grad_tri1), so that no fill launch precedes the step
     void *clear_ptr;
     size_t clear_bytes;  // multiple of 4
+    RrlChamRider *rider;  // (internal) rrl_demo_epoch: see RrlChamRider
     __host__ bool prepared() const { return order1 != nullptr; }
     __host__ bool target_kept() const { return order1 != nullptr && (flags & RRL_F_TARGET_KEPT); }
 };
 RrlCall rrl_resolve_opts(const rrl_opts *o);  // rrl_sparse.hip
+// rrl_registration_step_ex with the call's options already resolved (rrl_sparse.hip; rrl_epoch.hip adds a rider)
+int rrl_registration_step_call(const float *src, const float *R, const float *t, const float *tri2, const float *line,
+                               void *ws, size_t ws_bytes, float *loss, const float *grad_loss, float *gR, float *gt,
+                               float *payload, int B, int N, int M, int L, int transpose_r, int s_m, int s_n, int e_m, int e_n,
+                               int mode, int chunk, const void *target_ws, const RrlCall &o, void *stream);
 // the process-wide defaults, one accessor per translation unit that owns one
 int rrl_default_sort_parts(void);                                           // rrl_cull.hip
 void rrl_default_scan_counters(unsigned long long **buf, long long *rows);  // rrl_cull.hip

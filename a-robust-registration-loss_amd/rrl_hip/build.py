@@ -10,7 +10,7 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
-CSRC = os.path.join(PKG, "csrc")
+CSRC = os.environ.get("RRL_CSRC") or os.path.join(PKG, "csrc")  # (RRL_CSRC: A/B builds of another source tree, with RRL_HIPCC_FLAGS)
 # Experimental builds (RRL_HIPCC_FLAGS = extra -D knobs of the sweep scripts) go to their OWN directory and are loaded
 # only by processes that carry the same environment variable: an interrupted sweep can no longer leave a truncated
 # or re-tuned library where bench.py and the tests look; the flags are also part of rrl_version().

@@ -347,6 +347,38 @@ def test_demo_end_to_end_reduces_chamfer(demo, tmp_path, device_rng):
     assert done[-1][2] < 0.8 * done[0][2], (done[0], done[-1])
 
 
+def test_demo_epoch_chamfer_rides_in_the_scans_launch(demo, tmp_path, monkeypatch):
+    """Round 4b: in the one-call epoch (rrl_demo_epoch) the Chamfer walk of the step's clouds is carried by the culled
+    scan's launch (cull_scan_chamfer_kernel: workgroups [0, 2 B x supergroups) walk, the others scan) instead of being a
+    launch of its own behind the step.  Same bodies, same inputs: the whole run -- per-epoch loss, Chamfer value, validity,
+    the final pose -- is bit-identical to the run with RRL_DEMO_RIDE=0 (the separate rrl_chamfer_from_loss launch), at two
+    sizes (one and several line tiles per wavefront row, ragged clouds)."""
+    import argparse
+    from rrl_hip import ops
+    out = {}
+    ops.set_deterministic(True)  # (the backward's float atomics would make two runs differ by themselves)
+    try:
+        _rides(demo, tmp_path, monkeypatch, ops, out, argparse)
+    finally:
+        ops.set_deterministic(False)
+
+
+def _rides(demo, tmp_path, monkeypatch, ops, out, argparse):
+    for n_pts, n_lines in ((400, 4000), (1000, 9000)):
+        for ride in ("1", "0"):
+            monkeypatch.setenv("RRL_DEMO_RIDE", ride)
+            ops._sampler_key.clear()  # (both runs re-seed the device generator from torch's seed: the same lines)
+            args = argparse.Namespace(data_path=None, device='cuda:0', seed=11, label1='s', Save_path=str(tmp_path),
+                                      n_epoch=25, n_sample_line=n_lines, synthetic=n_pts, graph=True, print_every=0,
+                                      device_rng=True, save_every=0)
+            hist, model = demo.main(args)
+            out[ride] = (np.array([[np.nan if v is None else v for v in h[1:4]] for h in hist], np.float64),
+                         model.parameters_.detach().cpu().numpy().copy())
+        assert np.isfinite(out["1"][0][:, 1]).all() and (out["1"][0][:, 1] > 0).all()   # the monitor ran in every epoch
+        np.testing.assert_array_equal(out["1"][0], out["0"][0])
+        np.testing.assert_array_equal(out["1"][1], out["0"][1])
+
+
 # ------------------------------------------------------- dataset files -> trainer fragment
 def test_dataset_to_fragments(C, tmp_path):
     """Pairs on disk (pre_dataloader layout) -> DataLoader batch -> RPM and DCP fragments."""
