@@ -1789,7 +1789,7 @@ int rrl_launch_cull_scan(const float *line, void *ws, const WsLayout &w, int B, 
             a.gx = clouds * B; a.gy = tiles;
             ChamKArgs c;
             char *cw = (char *)o.rider->ws;
-            c.best_x = o.rider->best_x; c.best_y = o.rider->best_y;
+            c.best_x = (unsigned long long *)o.rider->best_x; c.best_y = (unsigned long long *)o.rider->best_y;
             c.partial = (double *)(cw + C.partial); c.gpart = (double *)(cw + C.gpart);
             c.value = o.rider->value;
             c.denom = (double)B * (double)(N + M);

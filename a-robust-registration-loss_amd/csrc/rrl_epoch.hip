@@ -21,10 +21,9 @@ extern "C" int rrl_demo_epoch(const rrl_demo_epoch_args *a, void *stream) {
     // one stream never overlap on this stack: its walk RIDES in the culled scan's launch (rrl_ws.h RrlChamRider; same
     // arithmetic, same value) -- one launch and ~12 us per epoch less.  RRL_DEMO_RIDE=0: the separate launch, as before.
     RrlCall o = rrl_resolve_opts(a->opts);
-    RrlChamRider rider = {a->cham_ws, a->cham_ws_bytes, (unsigned long long *)a->best_x, (unsigned long long *)a->best_y,
-                          a->cham_value, 0};
+    RrlChamRider rider = {a->cham_ws, a->cham_ws_bytes, a->best_x, a->best_y, a->cham_value, 0};
     const char *env = getenv("RRL_DEMO_RIDE");  // (read per call: tests switch it between epochs)
-    if (!(env && env[0] == '0')) o.rider = &rider;
+    o.rider = env && env[0] == '0' ? nullptr : &rider;
     rc = rrl_registration_step_call(a->src_tri, a->R, a->T, a->tar_tri, a->lines, a->ws, a->ws_bytes, a->loss, a->grad_loss,
                                     a->gR, a->gt, nullptr, 1, N, M, L, a->transpose_r, 1, 1, 5, 5, RRL_SCAN_CULL, 0, nullptr, o,
                                     stream);

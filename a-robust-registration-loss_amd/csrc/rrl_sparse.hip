@@ -1691,7 +1691,7 @@ RrlCall rrl_resolve_opts(const rrl_opts *p) {
     RrlCall o;
     o.clear_ptr = nullptr;
     o.clear_bytes = 0;
-    o.rider = nullptr;
+    o.rider = nullptr;  // (set below from rrl_opts.chamfer)
     rrl_opts v;
     memset(&v, 0, sizeof v);
     v.reduce_mode = v.deterministic = v.sort_parts = v.scan_variant = -1;
@@ -1706,6 +1706,7 @@ RrlCall rrl_resolve_opts(const rrl_opts *p) {
     o.order2 = v.order2;
     if (v.scan_counters) { o.counters = (unsigned long long *)v.scan_counters; o.counter_rows = v.scan_counter_rows; }
     else rrl_default_scan_counters(&o.counters, &o.counter_rows);
+    o.rider = v.chamfer;  // (done is the caller's to clear; the scan's launcher sets it when the walk rides along)
     return o;
 }
 // Which reduce kernel: 0 one workgroup per sample, 1 tiled with the candidate exchange (loss_reduce_tiled_kernel), 2 the

@@ -85,16 +85,7 @@ struct WsLayout {
 
 // The options of ONE call, resolved once at its top (include/rrl.h rrl_opts; defaults = what the rrl_set_* setters /
 // RRL_* environment variables selected) and handed through its stages by value: no stage reads a process-wide knob.
-// A Chamfer walk between the two clouds of THIS evaluation (what rrl_chamfer_from_loss computes after it) that the culled
-// scan's launch may carry beside its own workgroups: the walk needs the records launch only, and launches of one stream
-// never overlap on this stack.  done = 1 when it rode along (else the caller launches rrl_chamfer_from_loss as before).
-struct RrlChamRider {
-    void *ws;              // Chamfer workspace (rrl_chamfer_workspace_bytes)
-    size_t ws_bytes;
-    unsigned long long *best_x, *best_y;
-    float *value;
-    int done;
-};
+typedef rrl_chamfer_rider RrlChamRider;  // include/rrl.h: the evaluation's Chamfer walk, carried by the culled scan's launch
 
 struct RrlCall {
     int flags;
@@ -109,7 +100,7 @@ struct RrlCall {
     // state: the scatter target of rrl_loss_step (grad_tri1), so that no fill launch precedes the step
     void *clear_ptr;
     size_t clear_bytes;  // multiple of 4
-    RrlChamRider *rider;  // (internal) rrl_demo_epoch: see RrlChamRider
+    RrlChamRider *rider;  // rrl_opts.chamfer
     __host__ bool prepared() const { return order1 != nullptr; }
     __host__ bool target_kept() const { return order1 != nullptr && (flags & RRL_F_TARGET_KEPT); }
 };

@@ -83,16 +83,22 @@ EXPORTS = sorted(list(_SIGS) + ["rrl_version", "rrl_workspace_bytes", "rrl_chamf
 F_TARGET_KEPT = 1  # include/rrl.h RRL_F_TARGET_KEPT
 
 
+class ChamferRider(ctypes.Structure):
+    """include/rrl.h rrl_chamfer_rider: the evaluation's Chamfer walk, carried by its culled scan's launch."""
+    _fields_ = [("ws", _P), ("ws_bytes", _Z), ("best_x", _P), ("best_y", _P), ("value", _P), ("done", _c.c_int32)]
+
+
 class Opts(ctypes.Structure):
     """include/rrl.h rrl_opts: the per-call options of the *_ex entry points (-1 / NULL = the library default)."""
     _fields_ = [("struct_bytes", _c.c_int32), ("flags", _c.c_int32), ("reduce_mode", _c.c_int32),
                 ("deterministic", _c.c_int32), ("sort_parts", _c.c_int32), ("scan_variant", _c.c_int32),
-                ("order1", _P), ("order2", _P), ("scan_counters", _P), ("scan_counter_rows", _c.c_longlong)]
+                ("order1", _P), ("order2", _P), ("scan_counters", _P), ("scan_counter_rows", _c.c_longlong),
+                ("chamfer", _P)]
 
     def __init__(self, flags=0, reduce_mode=-1, deterministic=-1, sort_parts=-1, scan_variant=-1, order1=None,
-                 order2=None, scan_counters=None, scan_counter_rows=0):
+                 order2=None, scan_counters=None, scan_counter_rows=0, chamfer=None):
         super().__init__(ctypes.sizeof(Opts), int(flags), int(reduce_mode), int(deterministic), int(sort_parts),
-                         int(scan_variant), order1, order2, scan_counters, int(scan_counter_rows))
+                         int(scan_variant), order1, order2, scan_counters, int(scan_counter_rows), chamfer)
 
 class DemoEpochArgs(ctypes.Structure):
     """include/rrl.h rrl_demo_epoch_args (same field order)."""

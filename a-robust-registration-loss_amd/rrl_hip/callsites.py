@@ -73,6 +73,13 @@ def _first_points_contract(data, channel_first=False):
     return ok
 
 
+def _ride_monitor(data, channel_first=False):
+    """Will _monitor take the value from the loss evaluation's own clouds?  Then that evaluation carries the walk inside
+    its scan launch (ops.ChamferRide: round 4b) and the monitor costs no launch of its own."""
+    return bool(CHAMFER_FROM_LOSS) and (CHAMFER_FROM_LOSS is True or
+                                        (data is not None and _first_points_contract(data, channel_first)))
+
+
 def _monitor(moved, tar, data=None, channel_first=False):
     """The trainers' Chamfer monitor next to a loss evaluation: from the evaluation's own sorted clouds when that is
     the same quantity (CHAMFER_FROM_LOSS), else the standalone kernel on (moved, tar)."""
@@ -115,18 +122,21 @@ def _orders(data, n_src, n_tar):
     return (o1, o2) if ok else (None, None)
 
 
-def per_sample_loss(src_nb, R, t, tar_tri, lines, mode=None, target_from=None, data=None):
+def per_sample_loss(src_nb, R, t, tar_tri, lines, mode=None, target_from=None, data=None, chamfer=False):
     """loss[b] of the pseudo-triangles `src_nb` (B, 3N, 3) or (B, N, 9) moved by x -> R x + t,
     against tar_tri (B, M, 9) along lines (B, L, 6).  (loss (B,), valid (B,) bool).
     target_from: ops.last_state() of an earlier call with the same tar_tri and lines, whose
     target scan is reused (the iterative trainers keep target and lines fixed across poses).
     data: the trainer's dict; when it carries the clouds' spatial orders ('order_src', 'order_tar') the prepared build
-    is used (the source's order holds for every pose: a rigid motion preserves it)."""
+    is used (the source's order holds for every pose: a rigid motion preserves it).
+    chamfer: the caller will monitor the Chamfer distance of this evaluation's clouds (_monitor): its walk then rides in
+    the evaluation's scan launch (a full evaluation only: a carried-over target scans one cloud)."""
     B = src_nb.shape[0]
     src_tri, tar_tri = src_nb.reshape(B, -1, 9), tar_tri.reshape(B, -1, 9)
     o1, o2 = _orders(data, src_tri.shape[1], tar_tri.shape[1])
+    ride = bool(chamfer) and target_from is None and max(src_tri.shape[1], tar_tri.shape[1]) <= _SORT_CAP
     loss, info, _ = _ops.registration_loss(src_tri, R, t, tar_tri, lines, RNG, transpose_r=True, mode=_mode(mode),
-                                           target_from=target_from, order1=o1, order2=o2)
+                                           target_from=target_from, order1=o1, order2=o2, chamfer=ride)
     return loss, info[:, 0] > 0
 
 
@@ -154,7 +164,8 @@ def rpm_intersection_loss(pred_transforms, data, n_lines=10000, lines=None, mode
         if lines is None:
             lines = draw_lines(bounding_radius(data['tar_box']), data['centers'], n_lines,
                                moved.detach(), tar)
-        loss, ok = per_sample_loss(data['points_based_neighs_src'], R, t, tar_tri, lines, mode, first, data=data)
+        loss, ok = per_sample_loss(data['points_based_neighs_src'], R, t, tar_tri, lines, mode, first, data=data,
+                                   chamfer=first is None and _ride_monitor(data))
         first = first or _ops.last_state()
         per_iter.append(loss.sum().reshape(1) / num_iter)
         chamfers.append(_monitor(moved, tar, data).detach())
@@ -180,7 +191,8 @@ def dcp_intersection_loss(data, rotation_ab_pred, translation_ab_pred, n_lines=1
         lines = draw_lines(bounding_radius(data['tar_box'], 0.5), data['centers'], n_lines,
                            moved.detach(), tar)
     src_nb = data['points_based_neighs_src'].transpose(2, 1).contiguous()
-    loss, ok = per_sample_loss(src_nb, rotation_ab_pred, translation_ab_pred, tar_tri, lines, mode, data=data)
+    loss, ok = per_sample_loss(src_nb, rotation_ab_pred, translation_ab_pred, tar_tri, lines, mode, data=data,
+                               chamfer=_ride_monitor(data, channel_first=True))
     chamfer = _monitor(moved, tar, data, channel_first=True)  # the reference evaluates it before the loss; it depends on neither
     return (loss / 5.0).sum().reshape(1) / B, chamfer, lines, ok
 

@@ -259,12 +259,39 @@ def _check_order(order, B, n, dev, name):
 _REDUCE = {"auto": 0, "single": 1, "tiled": 2, "xchg": 3}
 
 
+class ChamferRide:
+    """include/rrl.h rrl_chamfer_rider: the Chamfer monitor of a loss evaluation (what chamfer_from_state computes after
+    it), issued INSIDE the evaluation's culled-scan launch -- the walk needs the records launch only, and launches of one
+    stream never overlap on this stack, so riding along hides its time beside the scan's.  Hand it to make_opts(chamfer=)
+    (registration_loss / intersection_loss / RegistrationStep take chamfer=True and do that themselves); after the call
+    `.done` says whether it rode (else: chamfer_from_state, which looks here first).  Buffers are this object's own."""
+
+    def __init__(self, B, N, M, dev):
+        nb = _chamfer_ws_bytes.get((B, N, M))
+        if nb is None:
+            nb = _chamfer_ws_bytes[(B, N, M)] = int(_lib.load().rrl_chamfer_workspace_bytes(B, N, M))
+        self.dims = (B, N, M)
+        self.ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+        self.bx = torch.empty(B, N, dtype=torch.int64, device=dev)
+        self.by = torch.empty(B, M, dtype=torch.int64, device=dev)
+        self.val = torch.empty(1, device=dev)
+        self.c = _lib.ChamferRider(_p(self.ws), nb, _p(self.bx), _p(self.by), _p(self.val), 0)
+
+    @property
+    def done(self):
+        return bool(self.c.done)
+
+    def arm(self):
+        self.c.done = 0
+        return self
+
+
 def make_opts(order1=None, order2=None, target_kept=False, reduce_mode=None, deterministic=None, sort_parts=None,
-              scan_variant=None, counters=None):
+              scan_variant=None, counters=None, chamfer=None):
     """include/rrl.h rrl_opts for one call (None = the library default everywhere); the returned object keeps the
     tensors it points at alive (.keep)."""
     if order1 is None and order2 is None and not target_kept and reduce_mode is None and deterministic is None \
-            and sort_parts is None and scan_variant is None and counters is None:
+            and sort_parts is None and scan_variant is None and counters is None and chamfer is None:
         return None
     o = _lib.Opts(flags=_lib.F_TARGET_KEPT if target_kept else 0,
                   reduce_mode=-1 if reduce_mode is None else _REDUCE.get(reduce_mode, reduce_mode),
@@ -274,13 +301,27 @@ def make_opts(order1=None, order2=None, target_kept=False, reduce_mode=None, det
                   order1=order1.data_ptr() if order1 is not None else None,
                   order2=order2.data_ptr() if order2 is not None else None,
                   scan_counters=counters.data_ptr() if counters is not None else None,
-                  scan_counter_rows=counters.shape[0] if counters is not None else 0)
-    o.keep = (order1, order2, counters)
+                  scan_counter_rows=counters.shape[0] if counters is not None else 0,
+                  chamfer=ctypes.addressof(chamfer.c) if chamfer is not None else None)
+    o.keep = (order1, order2, counters, chamfer)
+    o.ride = chamfer  # a ChamferRide (or None): the forwards arm it before the call and leave it on the LossState when it rode
     return o
 
 
 def _optr(opts):
     return ctypes.byref(opts) if opts is not None else None
+
+
+def _arm_ride(opts):
+    ride = getattr(opts, "ride", None)
+    if ride is not None:
+        ride.arm()
+    return ride
+
+
+def _keep_ride(st, ride):
+    """After a forward into `st`: the Chamfer walk that rode in its scan launch (chamfer_from_state looks here first)."""
+    st.cham_ride = ride if (ride is not None and ride.done) else None
 
 
 def loss_forward_raw(tri1, tri2, line, rng=(1, 1, 5, 5), pool=False, mode="cull", chunk=0,
@@ -308,6 +349,7 @@ def loss_forward_raw(tri1, tri2, line, rng=(1, 1, 5, 5), pool=False, mode="cull"
     st.target_state = getattr(target_from, "target_state", None) or target_from  # whose workspace holds cloud 2
     ws, nb = _p(st.ws), st.nbytes
     op = _optr(opts)
+    ride = _arm_ride(opts)
     with _guard(dev):
         s = _stream(dev)
         if not staged:
@@ -315,6 +357,7 @@ def loss_forward_raw(tri1, tri2, line, rng=(1, 1, 5, 5), pool=False, mode="cull"
                                           L, s_m, s_n, e_m, e_n, int(pool), _MODES[mode], int(chunk),
                                           _target_ws(target_from, B, N, M, L), op, s),
                   "rrl_loss_forward")
+            _keep_ride(st, ride)
             return st
         check(lib.rrl_tri_prepare_ex(_p(tri1), _p(tri2), ws, nb, B, N, M, L, op, s), "rrl_tri_prepare")
         if staged == "mixed":  # (tests) the later stages WITHOUT the build's options: the workspace describes itself
@@ -325,6 +368,7 @@ def loss_forward_raw(tri1, tri2, line, rng=(1, 1, 5, 5), pool=False, mode="cull"
                                         e_n, int(pool), op, s), "rrl_line_pair_dist")
         check(lib.rrl_loss_reduce_ex(ws, nb, _p(st.loss), B, N, M, L, s_m, s_n, e_m, e_n, int(pool), op, s),
               "rrl_loss_reduce")
+    _keep_ride(st, ride)
     return st
 
 
@@ -621,16 +665,31 @@ def intersection_loss_dropin(points1, points2, line, rng=(1, 1, 5, 5), pool=Fals
     return loss, _DropinLoss.flags
 
 
+def _with_ride(opts, order1, order2, chamfer, B, N, M, dev):
+    """opts for a call that takes order1= / order2= / chamfer=True as keywords (or a ready make_opts object)."""
+    if opts is not None:
+        if chamfer and getattr(opts, "ride", None) is None:
+            raise ValueError("chamfer=True with ready-made opts: build them with make_opts(chamfer=ChamferRide(...))")
+        return opts
+    ride = ChamferRide(B, N, M, dev) if chamfer else None
+    if ride is None and order1 is None and order2 is None:
+        return None
+    return make_opts(order1=order1, order2=order2, chamfer=ride)
+
+
 def intersection_loss(points1, points2, line, rng=(1, 1, 5, 5), pool=False, mode="cull", chunk=0,
-                      target_from=None, order1=None, order2=None, opts=None):
+                      target_from=None, order1=None, order2=None, opts=None, chamfer=False):
     """Batched loss: returns (loss[G], info[G,4] = (nbuckets, nselected, nvalues, NaN flag), status[4])
     on the GPU, G = 1 if pool else B.  Each sample is an independent loss (what every reference
     caller obtains by looping B=1 calls); pool=True reproduces the reference's own B>1 behaviour
     (SURVEY Q2).  No host synchronisation happens here.
     order1 / order2: ops.cloud_order of the two clouds (in any rigid pose of them) -- the per-call cell sort is skipped,
-    same results; opts: make_opts(...) for anything else per call."""
-    if opts is None and (order1 is not None or order2 is not None):
-        opts = make_opts(order1=order1, order2=order2)
+    same results; opts: make_opts(...) for anything else per call.
+    chamfer=True: the Chamfer monitor between the clouds' first points (chamfer_from_state) is issued inside this
+    evaluation's scan launch (ChamferRide); chamfer_from_state(last_state()) then returns it without a launch."""
+    if opts is None and (chamfer or order1 is not None or order2 is not None):
+        opts = _with_ride(None, order1, order2, chamfer and not pool, points1.shape[0], points1.shape[1], points2.shape[1],
+                          _home(points1, points2, line))
     return _IntersectionLoss.apply(points1, points2, line, tuple(rng), pool, mode, chunk, target_from, opts)
 
 
@@ -678,12 +737,14 @@ class _RegistrationLoss(torch.autograd.Function):
             return out
         s_m, s_n, e_m, e_n = _check_range(rng)
         st = LossState(B, N, M, L, B, src.device)
+        ride = _arm_ride(opts)
         with _guard(dev):
             check(_lib.load().rrl_registration_forward_ex(
                 _p(src), _p(Rm), _p(tv), _p(tri2), _p(ln), _p(st.ws), st.nbytes, _p(st.loss), B, N, M, L,
                 int(transpose_r), s_m, s_n, e_m, e_n, _MODES[mode], int(chunk),
                 _target_ws(target_from, B, N, M, L), _optr(opts), _stream(dev)), "rrl_registration_forward")
         st.target_state = getattr(target_from, "target_state", None) or target_from  # whose workspace holds cloud 2
+        _keep_ride(st, ride)
         ctx.st, ctx.src, ctx.Rm, ctx.tri2 = st, src, Rm, tri2
         ctx.meta = (int(transpose_r), bool(want_payload), R.shape, t.shape, src_tri.device, R.device, t.device)
         ctx.opts = opts
@@ -720,7 +781,8 @@ class _RegistrationLoss(torch.autograd.Function):
 
 
 def registration_loss(src_tri, R, t, tar_tri, line, rng=(1, 1, 5, 5), transpose_r=True,
-                      mode="cull", chunk=0, want_payload=False, target_from=None, order1=None, order2=None, opts=None):
+                      mode="cull", chunk=0, want_payload=False, target_from=None, order1=None, order2=None, opts=None,
+                      chamfer=False):
     """loss[b] of `src_tri[b]` moved by (R[b], t[b]) against `tar_tri[b]` along `line[b]` -- the
     rigid transform of the training call sites fused with the loss.  transpose_r=True is
     x R^T + t (R x + t per point: RPM / DCP / FMR), False is x R + t (Reconstruction_point).
@@ -730,9 +792,12 @@ def registration_loss(src_tri, R, t, tar_tri, line, rng=(1, 1, 5, 5), transpose_
     target_from: LossState (ops.last_state()) of an earlier call with the SAME tar_tri and line:
     the target cloud is not scanned again (RPM / FMR: several poses, one target, one line set).
     order1 / order2: ops.cloud_order of src_tri (in its own frame: a rigid motion keeps the order) and tar_tri -- the
-    per-call cell sort is skipped, same results."""
-    if opts is None and (order1 is not None or order2 is not None):
-        opts = make_opts(order1=order1, order2=order2)
+    per-call cell sort is skipped, same results.
+    chamfer=True: the trainers' Chamfer monitor (moved source's first points vs the target's; chamfer_from_state) is issued
+    inside this evaluation's scan launch (ChamferRide) -- chamfer_from_state(last_state()) then costs no launch."""
+    if opts is None and (chamfer or order1 is not None or order2 is not None):
+        opts = _with_ride(None, order1, order2, chamfer, src_tri.shape[0], src_tri.reshape(src_tri.shape[0], -1, 9).shape[1],
+                          tar_tri.reshape(tar_tri.shape[0], -1, 9).shape[1], _home(src_tri, tar_tri, line, R, t))
     return _RegistrationLoss.apply(src_tri, R, t, tar_tri, line, tuple(rng), transpose_r, mode,
                                    chunk, want_payload, target_from, opts)
 
@@ -765,13 +830,15 @@ class RegistrationStep:
 
     def __init__(self, src_tri, tar_tri, n_lines, rng=(1, 1, 5, 5), transpose_r=True, mode="cull", chunk=0,
                  want_payload=False, prepared=None, src_order=None, tar_order=None, reduce_mode=None, deterministic=None,
-                 sort_parts=None):
+                 sort_parts=None, chamfer=False):
         """reduce_mode / deterministic / sort_parts: per-call options of THIS step object (include/rrl.h rrl_opts; None =
         the library default) -- they travel with every call, so two steps with different options can run from two
         threads on two streams at the same time (tests/test_gpu_threads.py)."""
         dev = _home(src_tri, tar_tri)
         self.dev = dev
         self._extra = dict(reduce_mode=reduce_mode, deterministic=deterministic, sort_parts=sort_parts)
+        self._want_chamfer = bool(chamfer)  # the Chamfer monitor of every step, issued inside its scan launch (ChamferRide)
+        self.ride = self.chamfer_value = None
         self.src = _prep(src_tri, "src_tri", 9, dev)
         self.tar = _prep(tar_tri, "tar_tri", 9, dev)
         if self.src.dim() != 3 or self.tar.dim() != 3 or self.src.shape[0] != self.tar.shape[0]:
@@ -784,6 +851,9 @@ class RegistrationStep:
         self.rng = _check_range(rng)
         self.tr, self.mode, self.chunk = int(bool(transpose_r)), _MODES[mode], int(chunk)
         self.st = LossState(B, N, M, L, B, dev)
+        if self._want_chamfer:
+            self.ride = ChamferRide(B, N, M, dev)
+            self._extra["chamfer"] = self.ride
         self.ones = torch.ones(B, dtype=torch.float32, device=dev)
         gacc = self.st.gacc
         self.gR, self.gt = gacc[:B * 9].view(B, 3, 3), gacc[B * 9:B * 12].view(B, 3)
@@ -851,6 +921,8 @@ class RegistrationStep:
             tws = _target_ws(target_from, B, N, M, L)
             tail_s, fixed_f = tail_s[:-1] + (tws,), fixed_f[:-1] + (tws,)
         self.st.target_state = getattr(target_from, "target_state", None) or target_from  # whose workspace holds cloud 2
+        if self.ride is not None:
+            self.ride.arm()
         with _guard(dev):
             if RegistrationStep.ONE_CALL:  # forward + backward as one C entry: the backward may ride in the reduce's launch
                 check(lib.rrl_registration_step_ex(_p(self.src), _p(Rm), _p(tv), _p(self.tar), _p(ln), *self._head_s, _p(g),
@@ -861,6 +933,9 @@ class RegistrationStep:
                 check(lib.rrl_registration_backward_ex(_p(self.src), _p(Rm), _p(self.tar), *self._fixed_b, _p(g), *self._tail_b, op, s),
                       "rrl_registration_backward")
         _IntersectionLoss.last_state = self.st
+        if self.ride is not None:  # .chamfer_value: this step's monitor (it rode in the scan's launch, or one launch now)
+            _keep_ride(self.st, self.ride)
+            self.chamfer_value = chamfer_from_state(self.st)
         return self.st.loss.view(-1), self.gR, self.gt, self.payload, self.st.info
 
 
@@ -1164,6 +1239,9 @@ def chamfer_from_state(state=None, keys=False):
     st = state or _IntersectionLoss.last_state
     if st is None:
         raise ValueError("no loss evaluation to take the clouds from")
+    ride = getattr(st, "cham_ride", None)
+    if ride is not None:  # the walk rode in this evaluation's own scan launch (ChamferRide): nothing left to launch
+        return (ride.val.reshape(()), ride.bx, ride.by) if keys else ride.val.reshape(())
     B, N, M, L, _ = st.dims
     dev = st.ws.device
     tar = getattr(st, "target_state", None) or st

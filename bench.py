@@ -567,6 +567,29 @@ def main():
         extras.update({"chamfer_from_loss_state_ms": fms, "chamfer_from_loss_state_issue": fhow,
                        "chamfer_from_loss_state_ms_by_issue": fboth, "chamfer_from_loss_state": float(cfs),
                        "chamfer_from_loss_state_equals_chamfer_of_first_points": float(cfs) == want})
+        # ... and INSIDE the step (round 4b): the walk needs the step's records launch only, and launches of one stream never
+        # overlap on this stack, so ops.ChamferRide issues its workgroups in the culled scan's grid -- the timed step with the
+        # trainers' monitor, per step: a launch of its own behind the step against riding in the scan's launch
+        if prepared and args.mode == "cull":
+            Rd, Td = w["R"].detach(), w["T"].detach()
+            ride_ms = {}
+            for name, kw in (("step_then_chamfer_from_state", {}), ("step_with_the_walk_riding", {"chamfer": True})):
+                rs = ops.RegistrationStep(w["tri1"], w["tri2"], L, transpose_r=True, mode=args.mode, src_order=order1,
+                                          tar_order=order2, **kw)
+
+                def monitored():
+                    rs(Rd, Td, w["lines"])
+                    return rs.chamfer_value if kw else ops.chamfer_from_state(rs.st)
+                for _ in range(10):
+                    cv = monitored()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    cv = monitored()
+                torch.cuda.synchronize()
+                ride_ms[name] = (time.perf_counter() - t1) / args.steps * 1e3
+                ride_ms[name + "_value"] = float(cv)
+            extras["step_with_chamfer_monitor_ms"] = ride_ms
 
     if rank == 0:
         value = sum_pairs(world, B, args, L, N, M) * args.steps / dt

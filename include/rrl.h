@@ -154,6 +154,23 @@ const char *rrl_version(void);
                                 the PREVIOUS call on this workspace built from the same tri2 -- the target has not moved
                                 (code/test_demo_optimized_Lie_Algebra.py:57-62, rpm/Train_RPM.py:207-231 move only the
                                 source) -- so nothing of cloud 2 is rebuilt; order2 is not read.  Same results bit for bit. */
+/* A Chamfer walk carried by the evaluation's own scan launch (round 4b).  rrl_chamfer_from_loss -- the monitor every caller
+ * of the reference computes next to the loss (rpm/Train_RPM.py:223-224, dcp/Train_DCP.py:246, fmr/model.py:293,
+ * test_demo_optimized_Lie_Algebra.py:68) -- needs the evaluation's records launch only, not its scan, but launches of one
+ * stream never overlap on this stack; handed to an `_ex` forward / step through rrl_opts.chamfer, the walk's workgroups
+ * are issued in the culled scan's grid (one launch for both, the walk's time hidden beside the scan's).  Same arithmetic,
+ * same keys and value as rrl_chamfer_from_loss after the call.  done: clear it before the call; the call sets it to 1
+ * (host side, before it returns) when the walk rode along.  Still 0: it did not (scan mode other than cull, a carried-over
+ * target, counters, a short line set, clouds beyond the sort capacity, an entry that runs no scan) -- call
+ * rrl_chamfer_from_loss as before. */
+typedef struct rrl_chamfer_rider {
+    void *ws;                  /* Chamfer workspace, rrl_chamfer_workspace_bytes(B, N, M) */
+    size_t ws_bytes;
+    uint64_t *best_x, *best_y; /* [B][N], [B][M] keys (distance bits << 32 | argmin), as rrl_chamfer_from_loss */
+    float *value;              /* [1] the mean */
+    int32_t done;              /* out */
+} rrl_chamfer_rider;
+
 typedef struct rrl_opts {
     int32_t struct_bytes;    /* sizeof(rrl_opts) of the caller's header (fields beyond it are defaults) */
     int32_t flags;           /* RRL_F_* */
@@ -169,6 +186,7 @@ typedef struct rrl_opts {
     const int32_t *order1, *order2;
     uint64_t *scan_counters;       /* per-call counter table of the culled scan (see rrl_scan_counters) */
     long long scan_counter_rows;
+    rrl_chamfer_rider *chamfer;    /* NULL, or the evaluation's Chamfer walk to be carried by its scan launch (above) */
 } rrl_opts;
 
 size_t rrl_workspace_bytes(int B, int N, int M, int L);

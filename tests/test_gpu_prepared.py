@@ -230,6 +230,50 @@ def test_kept_target_is_rebuilt_when_it_changes(L):
     assert kept_opts is not None
 
 
+@pytest.mark.parametrize("B,n,m,nl,prepared", [(2, 1200, 1000, 6000, True), (1, 1024, 1024, 20000, True), (3, 700, 900, 4000, False),
+                                                (1, 5000, 4100, 3000, True)])
+def test_chamfer_walk_rides_in_the_scan_launch(L, B, n, m, nl, prepared):
+    """rrl_opts.chamfer (ops.ChamferRide; round 4b): the Chamfer walk between the moved source's and the target's first
+    points is issued INSIDE the evaluation's culled-scan launch (cull_scan_chamfer_kernel) -- keys and value bit-identical
+    to rrl_chamfer_from_loss after a plain evaluation, the loss evaluation itself unchanged; where the walk cannot ride (a
+    carried-over target, a short line set, a dense scan mode) `done` stays 0 and chamfer_from_state launches it as before."""
+    from rrl_hip import ops
+    prs, src, tar = _pairs(400, B, n, m)
+    ln = _lines(L, prs, nl)
+    R = cu(np.stack([_rot((0.3, 0.5, 0.8), 9)] * B))
+    t = cu(np.full((B, 3), 0.01, np.float32))
+    o1, o2 = (ops.cloud_order(src), ops.cloud_order(tar)) if prepared else (None, None)
+    ops.registration_loss(src, R, t, tar, ln, order1=o1, order2=o2)
+    plain = ops.last_state()
+    want = ops.chamfer_from_state(plain, keys=True)
+    loss = ops.registration_loss(src, R, t, tar, ln, order1=o1, order2=o2, chamfer=True)[0]
+    st = ops.last_state()
+    assert st.cham_ride is not None and st.cham_ride.done
+    got = ops.chamfer_from_state(st, keys=True)  # (no launch: the ride's own buffers)
+    torch.cuda.synchronize()
+    assert got[0].data_ptr() == st.cham_ride.val.data_ptr()
+    for a, b_ in zip(want, got):
+        assert torch.equal(a, b_)
+    _same_evaluation(plain, st)
+    assert torch.equal(loss, plain.loss.view(-1))
+    # the one-call step object
+    step = ops.RegistrationStep(src, tar, nl, chamfer=True, prepared=prepared, src_order=o1, tar_order=o2)
+    for _ in range(3):  # (kept target from the second call on)
+        out = step(R, t, ln)
+        assert step.ride.done and torch.equal(step.chamfer_value, want[0]) and torch.equal(out[0], plain.loss.view(-1))
+    # refused: a carried-over target scans one cloud only; a short line set runs thinner workgroups; a dense scan mode
+    ops.registration_loss(src, R, t, tar, ln, order1=o1, order2=o2, target_from=plain, chamfer=True)
+    st2 = ops.last_state()
+    assert st2.cham_ride is None and torch.equal(ops.chamfer_from_state(st2), want[0])
+    ops.registration_loss(src, R, t, tar, ln[:, :300].contiguous(), chamfer=True)
+    st3 = ops.last_state()
+    assert st3.cham_ride is None and torch.equal(ops.chamfer_from_state(st3), want[0])
+    if n <= 4096:
+        ops.registration_loss(src, R, t, tar, ln, mode="strict", chamfer=True)
+        st4 = ops.last_state()
+        assert st4.cham_ride is None and torch.equal(ops.chamfer_from_state(st4), want[0])
+
+
 @pytest.mark.parametrize("scale", [12.0, 300.0])
 def test_prepared_build_at_the_demo_scale(L, scale):
     """Clouds scaled to the reference demo's data scale and beyond (the culled scan's NaN reach DEL is gathered through

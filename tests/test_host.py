@@ -166,13 +166,14 @@ def test_stacked_rand_consumes_the_generator_like_separate_calls():
 
 
 def test_ctypes_structs_match_the_header(tmp_path):
-    """rrl_opts / rrl_demo_epoch_args as the Python binding declares them (rrl_hip/_lib.py) against the C header compiled
+    """rrl_opts / rrl_demo_epoch_args / rrl_chamfer_rider as the Python binding declares them (rrl_hip/_lib.py) against the C header compiled
     by gcc: same size, same offset of every field -- an ABI drift between include/rrl.h and the ctypes mirror would
     silently shift pointers."""
     import ctypes
     import subprocess
     from rrl_hip import _lib
-    fields = {"rrl_opts": [f for f, _ in _lib.Opts._fields_], "rrl_demo_epoch_args": [f for f, _ in _lib.DemoEpochArgs._fields_]}
+    fields = {"rrl_opts": [f for f, _ in _lib.Opts._fields_], "rrl_demo_epoch_args": [f for f, _ in _lib.DemoEpochArgs._fields_],
+              "rrl_chamfer_rider": [f for f, _ in _lib.ChamferRider._fields_]}
     src = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{os.path.join(ROOT, "include", "rrl.h")}"', 'int main(void) {']
     for name, fs in fields.items():
         src.append(f'  printf("{name} %zu\\n", sizeof({name}));')
@@ -184,7 +185,7 @@ def test_ctypes_structs_match_the_header(tmp_path):
     exe = tmp_path / "abi"
     subprocess.check_call(["gcc", "-std=c99", "-o", str(exe), str(c)])
     got = dict(line.split() for line in subprocess.check_output([str(exe)], text=True).splitlines())
-    for name, cls in (("rrl_opts", _lib.Opts), ("rrl_demo_epoch_args", _lib.DemoEpochArgs)):
+    for name, cls in (("rrl_opts", _lib.Opts), ("rrl_demo_epoch_args", _lib.DemoEpochArgs), ("rrl_chamfer_rider", _lib.ChamferRider)):
         assert int(got[name]) == ctypes.sizeof(cls), name
         for f, _ in cls._fields_:
             assert int(got[f"{name}.{f}"]) == getattr(cls, f).offset, (name, f)
