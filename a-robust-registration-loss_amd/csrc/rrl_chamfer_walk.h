@@ -152,7 +152,7 @@ __device__ __forceinline__ void chamfer_tree_body(
     double *__restrict__ partial, int B, int N, int M, unsigned long long *__restrict__ counters, long long counter_rows,
     const int32_t *__restrict__ idx1, const int32_t *__restrict__ idx2, const uint32_t *__restrict__ pm1,
     const uint32_t *__restrict__ pm2, const ChamTick tk_, double *__restrict__ gpart, float *__restrict__ value, double denom,
-    const int bx, const int by, const int gx, const int gy) {
+    const int bx, const int by, const int gx, const int gy, const float *__restrict__ apart_tar = nullptr) {
     unsigned long long (&s_best)[64] = lds_.s_best;
     float4 (&s_q)[64] = lds_.s_q;
     float4 (&s_rec)[NWV][CHK * LROW] = lds_.s_rec;
@@ -210,8 +210,8 @@ __device__ __forceinline__ void chamfer_tree_body(
                 if (pm1 != nullptr) {  // uniform
                     tnan = !(__uint_as_float((dir ? pm1 : pm2)[b]) <= 3.0e38f);
                 } else {  // (riding in the scan's launch) ... from the records launch's per-workgroup partial rows, slot 6
-                    const int ct = dir ? 0 : 1, nb = (nt + 255) / 256;
-                    const float *ap = apart + ((size_t)ct * B + b) * nblk * 8 + 6;
+                    const int ct = dir ? 0 : 1, nb = (nt + 255) / 256;  // (cloud 2's rows may live in another workspace)
+                    const float *ap = (ct && apart_tar ? apart_tar : apart) + ((size_t)ct * B + b) * nblk * 8 + 6;
                     float pmv = 0.0f;
                     for (int j = lane; j < nb; j += 64) pmv = fmaxf(pmv, ap[j * 8]);
                     tnan = __any(!(pmv <= 3.0e38f));

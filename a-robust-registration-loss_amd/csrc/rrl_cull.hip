@@ -1519,6 +1519,7 @@ struct CullKArgs {
     const float *del1, *del2;
     const float2 *lmax;
     const float *apart, *aflag;
+    const float *aflag_tar;  // the partial rows of the workspace that holds cloud 2 (== aflag unless the target is carried over)
     int nblk_apart, B, N, M, L, spw, gx, gy;
 };
 struct ChamKArgs {
@@ -1541,7 +1542,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4, 8))
     if (lin < ncham) {  // uniform per workgroup
         chamfer_tree_body<false, true>(lds_.walk, a.p0s1, a.p0s2, a.tree1, a.tree2, a.aflag, a.nblk_apart, c.best_x, c.best_y,
                                        c.partial, a.B, a.N, a.M, nullptr, 0, a.idx1, a.idx2, nullptr, nullptr, c.tick, c.gpart,
-                                       c.value, c.denom, lin % c.gx, lin / c.gx, c.gx, c.gy);
+                                       c.value, c.denom, lin % c.gx, lin / c.gx, c.gx, c.gy, a.aflag_tar);
         return;
     }
     const int l2 = lin - ncham, bx = l2 % a.gx, r = l2 / a.gx;
@@ -1740,7 +1741,9 @@ int rrl_launch_cull_scan(const float *line, void *ws, const WsLayout &w, int B, 
     int waves = lw < WPB ? lw : WPB, spw = SPW;
     auto wgs = [&]() { return (long)clouds * B * ((lw + waves - 1) / waves) * ((nsgmax + spw - 1) / spw); };
     while (wgs() < 768 && spw > 1) spw >>= 1;
-    while (wgs() < 256 && waves > 2) waves >>= 1;
+    // (a riding Chamfer walk needs the scan's full 512-lane workgroups -- and brings workgroups of its own: no thinning then)
+    const bool may_ride = o.rider && !o.counters && (clouds == 2 || o.tar_ws) && lw >= WPB && B <= 32767 && N > 0 && M > 0;
+    while (!may_ride && wgs() < 256 && waves > 2) waves >>= 1;
     if (const char *e = getenv("RRL_CULL_GEOM")) {  // experiments: "waves,spw"
         int w_ = 0, s_ = 0;
         if (sscanf(e, "%d,%d", &w_, &s_) == 2 && w_ >= 1 && w_ <= WPB && s_ >= 1 && s_ <= SPW) { waves = w_ < lw ? w_ : lw; spw = s_; }
@@ -1769,22 +1772,24 @@ int rrl_launch_cull_scan(const float *line, void *ws, const WsLayout &w, int B, 
                        o.counters, o.counter_rows)
     const float *apart = o.prepared() ? w.f32(ws, RRL_WS_APART) : nullptr;  // prepared build: PMAX comes from the partial rows
     const int nblk_apart = ((N > M ? N : M) + REC_BLK - 1) / REC_BLK;
-    if (o.rider && !o.counters && clouds == 2 && waves == WPB && B <= 32767 && N > 0 && M > 0) {
-        // the evaluation's Chamfer walk rides along (cull_scan_chamfer_kernel): ONE launch for both
+    if (may_ride && waves == WPB) {
+        // the evaluation's Chamfer walk rides along (cull_scan_chamfer_kernel): ONE launch for both.  A carried-over target
+        // (clouds == 1: only the source is scanned here) is walked in the workspace that holds its records.
+        const void *tws = clouds == 2 ? ws : o.tar_ws;
         const ChamLayout C(B, N, M);
         if (o.rider->ws && o.rider->ws_bytes >= C.total && o.rider->best_x && o.rider->best_y && o.rider->value) {
             CullKArgs a;
-            a.ptri1 = w.f32(ws, RRL_WS_PTRI1); a.ptri2 = w.f32(ws, RRL_WS_PTRI2);
-            a.p0s1 = (const float4 *)w.f32(ws, RRL_WS_P0S1); a.p0s2 = (const float4 *)w.f32(ws, RRL_WS_P0S2);
-            a.idx1 = w.i32(ws, RRL_WS_IDX1); a.idx2 = w.i32(ws, RRL_WS_IDX2);
-            a.tree1 = (const float4 *)w.f32(ws, RRL_WS_GRP1); a.tree2 = (const float4 *)w.f32(ws, RRL_WS_GRP2);
+            a.ptri1 = w.f32(ws, RRL_WS_PTRI1); a.ptri2 = w.f32(tws, RRL_WS_PTRI2);
+            a.p0s1 = (const float4 *)w.f32(ws, RRL_WS_P0S1); a.p0s2 = (const float4 *)w.f32(tws, RRL_WS_P0S2);
+            a.idx1 = w.i32(ws, RRL_WS_IDX1); a.idx2 = w.i32(tws, RRL_WS_IDX2);
+            a.tree1 = (const float4 *)w.f32(ws, RRL_WS_GRP1); a.tree2 = (const float4 *)w.f32(tws, RRL_WS_GRP2);
             a.line = line;
             a.count1 = w.i32(ws, RRL_WS_COUNT1); a.hit1 = w.i32(ws, RRL_WS_HIT1);
             a.count2 = w.i32(ws, RRL_WS_COUNT2); a.hit2 = w.i32(ws, RRL_WS_HIT2);
             a.status = w.i32(ws, RRL_WS_STATUS); a.pmax = (uint32_t *)w.i32(ws, RRL_WS_PMAX);
             a.del1 = w.f32(ws, RRL_WS_DEL1); a.del2 = w.f32(ws, RRL_WS_DEL2);
             a.lmax = (const float2 *)w.f32(ws, RRL_WS_LMAX);
-            a.apart = apart; a.aflag = w.f32(ws, RRL_WS_APART);
+            a.apart = apart; a.aflag = w.f32(ws, RRL_WS_APART); a.aflag_tar = w.f32(tws, RRL_WS_APART);
             a.nblk_apart = nblk_apart; a.B = B; a.N = N; a.M = M; a.L = L; a.spw = spw;
             a.gx = clouds * B; a.gy = tiles;
             ChamKArgs c;
@@ -1795,7 +1800,7 @@ int rrl_launch_cull_scan(const float *line, void *ws, const WsLayout &w, int B, 
             c.denom = (double)B * (double)(N + M);
             uint32_t *mctl = w.u32(ws, RRL_WS_MCTL);  // arrival counters of the walk's mean (rrl_chamfer_from_loss_ex)
             c.tick = ChamTick{mctl + 32, mctl + 30, 64, 1};
-            c.gx = 2 * B; c.gy = nsgmax;
+            c.gx = 2 * B; c.gy = ((N > M ? N : M) + SGT - 1) / SGT;  // patches of the larger cloud (either direction)
             const unsigned nwg = (unsigned)(c.gx * c.gy) + (unsigned)(a.gx * a.gy * zslices);
             hipLaunchKernelGGL(cull_scan_chamfer_kernel, dim3(nwg), dim3(64 * WPB), 0, s, a, c);
             hipError_t e = hipGetLastError();

@@ -1692,6 +1692,7 @@ RrlCall rrl_resolve_opts(const rrl_opts *p) {
     o.clear_ptr = nullptr;
     o.clear_bytes = 0;
     o.rider = nullptr;  // (set below from rrl_opts.chamfer)
+    o.tar_ws = nullptr;
     rrl_opts v;
     memset(&v, 0, sizeof v);
     v.reduce_mode = v.deterministic = v.sort_parts = v.scan_variant = -1;
@@ -2347,6 +2348,7 @@ static int loss_forward_impl(const float *tri1, const float *tri2, const float *
     if (s_m < 1 || s_n < 1 || e_m > RRL_MAX_HITS + 1 || e_n > RRL_MAX_HITS + 1) return RRL_E_RANGE;
     if (target_ws == ws) return RRL_E_ARG;
     const int clouds = target_ws ? 1 : 2;
+    o.tar_ws = target_ws;
     // prepared clouds (include/rrl.h rrl_opts): honoured by the sorted layout of scan mode cull, with the orders of every
     // cloud this call builds; anything else takes the plain path (same results)
     if (o.prepared() && (mode != RRL_SCAN_CULL || (N > M ? N : M) > rrl_sort_capacity() ||

@@ -101,6 +101,8 @@ struct RrlCall {
     void *clear_ptr;
     size_t clear_bytes;  // multiple of 4
     RrlChamRider *rider;  // rrl_opts.chamfer
+    const void *tar_ws;   // (internal) the workspace that holds cloud 2's records when the target's scan is carried over
+                          // (rrl_*_forward_cached: `target_ws`): the riding walk takes the target from there
     __host__ bool prepared() const { return order1 != nullptr; }
     __host__ bool target_kept() const { return order1 != nullptr && (flags & RRL_F_TARGET_KEPT); }
 };

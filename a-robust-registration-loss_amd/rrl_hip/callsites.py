@@ -130,11 +130,11 @@ def per_sample_loss(src_nb, R, t, tar_tri, lines, mode=None, target_from=None, d
     data: the trainer's dict; when it carries the clouds' spatial orders ('order_src', 'order_tar') the prepared build
     is used (the source's order holds for every pose: a rigid motion preserves it).
     chamfer: the caller will monitor the Chamfer distance of this evaluation's clouds (_monitor): its walk then rides in
-    the evaluation's scan launch (a full evaluation only: a carried-over target scans one cloud)."""
+    the evaluation's scan launch (with a carried-over target too: the walk then reads the target in the state that holds it)."""
     B = src_nb.shape[0]
     src_tri, tar_tri = src_nb.reshape(B, -1, 9), tar_tri.reshape(B, -1, 9)
     o1, o2 = _orders(data, src_tri.shape[1], tar_tri.shape[1])
-    ride = bool(chamfer) and target_from is None and max(src_tri.shape[1], tar_tri.shape[1]) <= _SORT_CAP
+    ride = bool(chamfer) and max(src_tri.shape[1], tar_tri.shape[1]) <= _SORT_CAP
     loss, info, _ = _ops.registration_loss(src_tri, R, t, tar_tri, lines, RNG, transpose_r=True, mode=_mode(mode),
                                            target_from=target_from, order1=o1, order2=o2, chamfer=ride)
     return loss, info[:, 0] > 0
@@ -165,7 +165,7 @@ def rpm_intersection_loss(pred_transforms, data, n_lines=10000, lines=None, mode
             lines = draw_lines(bounding_radius(data['tar_box']), data['centers'], n_lines,
                                moved.detach(), tar)
         loss, ok = per_sample_loss(data['points_based_neighs_src'], R, t, tar_tri, lines, mode, first, data=data,
-                                   chamfer=first is None and _ride_monitor(data))
+                                   chamfer=_ride_monitor(data))
         first = first or _ops.last_state()
         per_iter.append(loss.sum().reshape(1) / num_iter)
         chamfers.append(_monitor(moved, tar, data).detach())
@@ -214,7 +214,8 @@ def fmr_intersection_loss(g_series, data, n_lines=15000, lines=None, last=3, mod
     total, valid, first = 0.0, [], None
     for i in range(maxiter - last, maxiter):
         R, t = _split(g_series[i])
-        loss, ok = per_sample_loss(data['points_based_neighs_src'], R, t, tar_tri, lines, mode, first, data=data)
+        loss, ok = per_sample_loss(data['points_based_neighs_src'], R, t, tar_tri, lines, mode, first, data=data,
+                                   chamfer=i == maxiter - 1 and _ride_monitor(data))  # (the last estimate's monitor)
         first = first or _ops.last_state()
         total = total + (loss / 5.0).sum().reshape(1) * 0.5 ** (maxiter - i - 1)
         valid.append(ok)

@@ -160,8 +160,9 @@ const char *rrl_version(void);
  * stream never overlap on this stack; handed to an `_ex` forward / step through rrl_opts.chamfer, the walk's workgroups
  * are issued in the culled scan's grid (one launch for both, the walk's time hidden beside the scan's).  Same arithmetic,
  * same keys and value as rrl_chamfer_from_loss after the call.  done: clear it before the call; the call sets it to 1
- * (host side, before it returns) when the walk rode along.  Still 0: it did not (scan mode other than cull, a carried-over
- * target, counters, a short line set, clouds beyond the sort capacity, an entry that runs no scan) -- call
+ * (host side, before it returns) when the walk rode along -- also with a carried-over target (`target_ws`: only the source is
+ * scanned, the walk reads the target in the workspace that holds it).  Still 0: it did not (scan mode other than cull,
+ * counters, fewer than 1024 lines, clouds beyond the sort capacity, an entry that runs no scan) -- call
  * rrl_chamfer_from_loss as before. */
 typedef struct rrl_chamfer_rider {
     void *ws;                  /* Chamfer workspace, rrl_chamfer_workspace_bytes(B, N, M) */

@@ -261,10 +261,18 @@ def test_chamfer_walk_rides_in_the_scan_launch(L, B, n, m, nl, prepared):
     for _ in range(3):  # (kept target from the second call on)
         out = step(R, t, ln)
         assert step.ride.done and torch.equal(step.chamfer_value, want[0]) and torch.equal(out[0], plain.loss.view(-1))
-    # refused: a carried-over target scans one cloud only; a short line set runs thinner workgroups; a dense scan mode
-    ops.registration_loss(src, R, t, tar, ln, order1=o1, order2=o2, target_from=plain, chamfer=True)
+    # a carried-over target (the iterative trainers: same target and lines, another pose): only the source is scanned, the
+    # walk reads the target in the state that holds it
+    R2 = cu(np.stack([_rot((0.1, 0.9, 0.2), 4)] * B))
+    ops.registration_loss(src, R2, t, tar, ln, order1=o1, order2=o2, target_from=plain)
+    want2 = ops.chamfer_from_state(ops.last_state(), keys=True)
+    ops.registration_loss(src, R2, t, tar, ln, order1=o1, order2=o2, target_from=plain, chamfer=True)
     st2 = ops.last_state()
-    assert st2.cham_ride is None and torch.equal(ops.chamfer_from_state(st2), want[0])
+    assert st2.cham_ride is not None and st2.cham_ride.done
+    for a, b_ in zip(want2, ops.chamfer_from_state(st2, keys=True)):
+        assert torch.equal(a, b_)
+    assert not torch.equal(want2[0], want[0])
+    # refused: a short line set runs thinner workgroups; a dense scan mode has no culled scan
     ops.registration_loss(src, R, t, tar, ln[:, :300].contiguous(), chamfer=True)
     st3 = ops.last_state()
     assert st3.cham_ride is None and torch.equal(ops.chamfer_from_state(st3), want[0])
