@@ -20,12 +20,15 @@ def data_for(B, n):
     d["centers"] = d["points_tar_sample"].mean(1)
     return d
 
-def timeit(f, n=30):
-    for _ in range(3): f()
+def timeit(f, n=100):
+    for _ in range(10): f()  # (the caching allocator needs a few rounds to settle: every evaluation leases a 48 MB state)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(n): f()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
 
+if os.environ.get("RRL_FRAGMENT_NO_RIDE"):  # A/B: the monitor as a launch of its own after every evaluation (round 3 / 4a)
+    C._ride_monitor = lambda *a, **k: False
+    print("(the Chamfer monitor does NOT ride in the scan launches)")
 for B, n in ((8, 1024), (8, 4096)):
     d = data_for(B, n)
     gen = torch.Generator().manual_seed(0)
