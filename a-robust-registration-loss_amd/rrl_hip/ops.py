@@ -952,7 +952,9 @@ class LossStep:
     gradient to the rounding of the scatter's float atomics.  prepared / src_order / tar_order as RegistrationStep."""
 
     def __init__(self, src_tri, tar_tri, n_lines, rng=(1, 1, 5, 5), transpose_r=True, mode="cull", chunk=0,
-                 prepared=None, src_order=None, tar_order=None):
+                 prepared=None, src_order=None, tar_order=None, chamfer=False):
+        """chamfer=True: every step also leaves the Chamfer monitor of its clouds in .chamfer_value -- its walk rides in the
+        step's scan launch (ChamferRide), as in RegistrationStep."""
         dev = _home(src_tri, tar_tri)
         self.dev = dev
         self.src = _prep(src_tri, "src_tri", 9, dev)
@@ -963,6 +965,8 @@ class LossStep:
         M, L = self.tar.shape[1], int(n_lines)
         if B == 0 or L <= 0:
             raise ValueError("LossStep needs a non-empty batch and line set")
+        self.ride = ChamferRide(B, N, M, dev) if chamfer else None
+        self.chamfer_value = None
         self.dims = (B, N, M, L)
         self.rng = _check_range(rng)
         self.tr, self.mode, self.chunk = int(bool(transpose_r)), _MODES[mode], int(chunk)
@@ -973,13 +977,13 @@ class LossStep:
             prepared = os.environ.get("RRL_PREPARED", "1") != "0"
         self.prepared = bool(prepared) and mode == "cull" and max(N, M) <= 65536
         self._kept_key = None
-        self._optr = self._optr_kept = None
+        self._opts = self._opts_kept = make_opts(chamfer=self.ride)  # (None without a ride)
         if self.prepared:
             self.order1 = _check_order(src_order, B, N, dev, "src_order") if src_order is not None else cloud_order(self.src)
             self.order2 = _check_order(tar_order, B, M, dev, "tar_order") if tar_order is not None else cloud_order(self.tar)
-            self._opts = make_opts(order1=self.order1, order2=self.order2)
-            self._opts_kept = make_opts(order1=self.order1, order2=self.order2, target_kept=True)
-            self._optr, self._optr_kept = ctypes.byref(self._opts), ctypes.byref(self._opts_kept)
+            self._opts = make_opts(order1=self.order1, order2=self.order2, chamfer=self.ride)
+            self._opts_kept = make_opts(order1=self.order1, order2=self.order2, target_kept=True, chamfer=self.ride)
+        self._optr, self._optr_kept = _optr(self._opts), _optr(self._opts_kept)
         self._lib = _lib.load()
 
     def __call__(self, R, t, line, grad_loss=None):
@@ -992,17 +996,22 @@ class LossStep:
                 or tuple(ln.shape) != (B, L, 6):
             raise ValueError("R (B,3,3) and t (B,3) (or both None), line (B, L, 6) expected")
         g = self.ones if grad_loss is None else _prep(grad_loss, "grad_loss", None, dev)
-        op = None
+        op = self._optr
         if self.prepared:
             key = (self.tar.data_ptr(), self.tar._version)
             op = self._optr_kept if key == self._kept_key else self._optr
             self._kept_key = key
+        if self.ride is not None:
+            self.ride.arm()
         with _guard(dev):
             check(self._lib.rrl_loss_step_ex(_p(self.src), _p(Rm), _p(tv), _p(self.tar), _p(ln), _p(self.st.ws),
                                              self.st.nbytes, _p(self.st.loss), _p(g), _p(self.grad), None, B, N, M, L,
                                              self.tr, *self.rng, self.mode, self.chunk, None, op, _stream(dev)),
                   "rrl_loss_step")
         _IntersectionLoss.last_state = self.st
+        if self.ride is not None:
+            _keep_ride(self.st, self.ride)
+            self.chamfer_value = chamfer_from_state(self.st)
         return self.st.loss.view(-1), self.grad, self.st.info
 
 

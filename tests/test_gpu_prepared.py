@@ -261,6 +261,10 @@ def test_chamfer_walk_rides_in_the_scan_launch(L, B, n, m, nl, prepared):
     for _ in range(3):  # (kept target from the second call on)
         out = step(R, t, ln)
         assert step.ride.done and torch.equal(step.chamfer_value, want[0]) and torch.equal(out[0], plain.loss.view(-1))
+    ls = ops.LossStep(src, tar, nl, chamfer=True, prepared=prepared, src_order=o1, tar_order=o2)  # SURVEY 8(d)'s step, monitored
+    for _ in range(2):
+        lo = ls(R, t, ln)
+        assert ls.ride.done and torch.equal(ls.chamfer_value, want[0]) and torch.equal(lo[0], plain.loss.view(-1))
     # a carried-over target (the iterative trainers: same target and lines, another pose): only the source is scanned, the
     # walk reads the target in the state that holds it
     R2 = cu(np.stack([_rot((0.1, 0.9, 0.2), 4)] * B))
