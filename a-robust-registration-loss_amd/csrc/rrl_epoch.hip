@@ -3,8 +3,9 @@
 // code/test_demo_optimized_Lie_Algebra.py:46-82 does, per epoch: sample lines through both clouds' boxes (against the
 // PREVIOUS epoch's moved source), move the source by the current pose, evaluate the loss, backward, Adam step, Chamfer
 // monitor, log.  Every piece has its entry in this library already; this file only issues them back to back on the
-// caller's stream -- sampler (2 launches) -> fused registration step on prepared clouds (4) -> Chamfer from the loss state
-// (1) -> pose step (1: exp-map backward, gated Adam, next exp map, log row, next sampler box) -- so that a loop pays one
+// caller's stream -- sampler (2 launches) -> fused registration step on prepared clouds (4; 5 at the demo's 20 line tiles),
+// the Chamfer walk of the step's clouds riding in its scan launch (round 4b; a launch of its own before) -> pose step (1:
+// exp-map backward, gated Adam, next exp map, log row, next sampler box) -- so that a loop pays one
 // host call (~5 us) per epoch instead of a hipGraph replay (~8 us fixed + ~1.5 us per node on this stack,
 // tools/graph_node_cost.py) or eight Python-level calls.  No new arithmetic: the results are those of the four entries.
 #include <cstdlib>

@@ -503,10 +503,11 @@ int rrl_se3_adam_step(float *xi, const float *gR, const float *gT, float *m, flo
 
 /* One epoch of the single-pair demo (code/test_demo_optimized_Lie_Algebra.py:46-82) as ONE call: line sampler with the
  * library's generator (rrl_sample_lines_rng, against box1 = the previous epoch's moved source) -> fused registration step
- * (rrl_registration_step_ex; pass prepared orders in opts) -> Chamfer between the step's own sorted clouds
- * (rrl_chamfer_from_loss: requires the point sets to be the triangles' first points) -> pose step (rrl_se3_adam_step:
- * exp-map backward, gated Adam on xi, (R, T) = exp(updated xi), log row, box1 = the moved source's AABB for the next
- * epoch).  Nothing but the four entries' own launches, issued back to back: a loop pays one host call per epoch.  One pair
+ * (rrl_registration_step_ex; pass prepared orders in opts) with the Chamfer walk between the step's own sorted clouds
+ * riding in its scan launch (rrl_chamfer_rider; = rrl_chamfer_from_loss: requires the point sets to be the triangles' first
+ * points; RRL_DEMO_RIDE=0 in the environment: the separate launch) -> pose step (rrl_se3_adam_step: exp-map backward,
+ * gated Adam on xi, (R, T) = exp(updated xi), log row, box1 = the moved source's AABB for the next epoch).  Nothing but
+ * the entries' own kernels, 8 launches issued back to back: a loop pays one host call per epoch.  One pair
  * (B = 1); every pointer a device pointer as in the four entries; struct_bytes = sizeof(rrl_demo_epoch_args). */
 typedef struct rrl_demo_epoch_args {
     int32_t struct_bytes, N, M, L, rounds, transpose_r;
