@@ -8,27 +8,46 @@
 // exp-map backward, gated Adam, next exp map, log row, next sampler box) -- so that a loop pays one
 // host call (~5 us) per epoch instead of a hipGraph replay (~8 us fixed + ~1.5 us per node on this stack,
 // tools/graph_node_cost.py) or eight Python-level calls.  No new arithmetic: the results are those of the four entries.
+#include <cstddef>
+#include <cstdint>
 #include <cstdlib>
 #include "rrl_ws.h"
 
 extern "C" int rrl_demo_epoch(const rrl_demo_epoch_args *a, void *stream) {
-    if (!a || a->struct_bytes < (int32_t)sizeof(rrl_demo_epoch_args)) return RRL_E_ARG;
+    if (!a || a->struct_bytes < (int32_t)offsetof(rrl_demo_epoch_args, pipeline)) return RRL_E_ARG;  // (pipeline: appended in round 4b)
     const int N = a->N, M = a->M, L = a->L;
     if (N <= 0 || M <= 0 || L <= 0 || a->rounds <= 0) return RRL_E_ARG;
-    int rc = rrl_sample_lines_rng(a->rng_state, a->radius, a->centers, a->box1, a->box2, a->lines, a->filled, a->tile_counts,
+    const char *env = getenv("RRL_DEMO_RIDE");  // (read per call: tests switch it between epochs) 0: no launch carries another's work
+    const bool rides = !(env && env[0] == '0');
+    int32_t *pipe = a->struct_bytes >= (int32_t)sizeof(rrl_demo_epoch_args) && rides ? a->pipeline : nullptr;
+    if (pipe && ((long)((L + 1023) / 1024) * a->rounds >= 512 || L <= 1024)) pipe = nullptr;  // (the rider's limits: line_pair_dist_impl)
+    int rc;
+    if (pipe && *pipe == 1) {  // the previous epoch's per-line launch carried this epoch's count pass: the write pass remains
+        rc = rrl_sample_write_pass(a->rng_state, a->radius, a->centers, a->lines, a->filled, a->tile_counts, 1, L, a->rounds, stream);
+    } else {
+        rc = rrl_sample_lines_rng(a->rng_state, a->radius, a->centers, a->box1, a->box2, a->lines, a->filled, a->tile_counts,
                                   1, L, a->rounds, stream);
+    }
+    if (a->pipeline && a->struct_bytes >= (int32_t)sizeof(rrl_demo_epoch_args)) *a->pipeline = 0;
     if (rc) return rc;
     // The Chamfer monitor needs the step's records launch only (the sorted moved source + the kept target), and launches of
     // one stream never overlap on this stack: its walk RIDES in the culled scan's launch (rrl_ws.h RrlChamRider; same
     // arithmetic, same value) -- one launch and ~12 us per epoch less.  RRL_DEMO_RIDE=0: the separate launch, as before.
     RrlCall o = rrl_resolve_opts(a->opts);
     RrlChamRider rider = {a->cham_ws, a->cham_ws_bytes, a->best_x, a->best_y, a->cham_value, 0};
-    const char *env = getenv("RRL_DEMO_RIDE");  // (read per call: tests switch it between epochs)
-    o.rider = env && env[0] == '0' ? nullptr : &rider;
+    o.rider = rides ? &rider : nullptr;
+    // ... and so does the NEXT epoch's count pass, in the per-line launch (RrlCountRider): it samples against the moved source
+    // of THIS epoch (code/test_demo_optimized_Lie_Algebra.py:46-51), whose box is in the records launch's partial rows
+    const WsLayout wl(1, N, M, L);
+    if (a->ws_bytes < wl.total) return RRL_E_WS;
+    RrlCountRider counter = {(const unsigned long long *)a->rng_state, a->radius, a->centers, a->box2, wl.f32(a->ws, RRL_WS_APART),
+                             (N + 255) / 256, (unsigned long long *)a->tile_counts, L, a->rounds, 0};
+    if (pipe && (((uintptr_t)a->tile_counts) & 7) == 0) o.count_rider = &counter;
     rc = rrl_registration_step_call(a->src_tri, a->R, a->T, a->tar_tri, a->lines, a->ws, a->ws_bytes, a->loss, a->grad_loss,
                                     a->gR, a->gt, nullptr, 1, N, M, L, a->transpose_r, 1, 1, 5, 5, RRL_SCAN_CULL, 0, nullptr, o,
                                     stream);
     if (rc) return rc;
+    if (pipe) *pipe = counter.done;
     if (!rider.done) {
         rc = rrl_chamfer_from_loss(a->ws, a->ws, a->ws_bytes, 1, N, M, L, a->cham_ws, a->cham_ws_bytes, a->best_x, a->best_y,
                                    a->cham_value, stream);

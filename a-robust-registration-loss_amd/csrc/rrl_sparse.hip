@@ -9,6 +9,7 @@
 #include <string.h>
 
 #include "rrl_ws.h"
+#include "rrl_sampler.h"  // the sampler's count pass as a device function: pair_count_kernel carries it
 
 #define FIX_SHIFT 40  // bucket sums in 2^-40 fixed point: order-independent, bit-deterministic
 
@@ -264,6 +265,28 @@ __global__ __launch_bounds__(1024) void line_pair_dist_kernel(const PairArgs a) 
 // tri1 / tri2: the triangles as the loss sees them -- the caller's rows, or TRI1 (the moved source of the fused op) --, raw
 // 36-byte rows indexed by triangle.  (The prepared 48-byte records, PTRI, belong to the scans alone since round 4: the
 // prepared build keeps them at their SORTED positions, and a target's records may live in another workspace.)
+// The per-line stage AND the count pass of the next epoch's line sampler in ONE launch (round 4b; rrl_ws.h RrlCountRider,
+// rrl_demo_epoch): both run 1024-lane workgroups, the count pass needs nothing the scan produced, and launches of one
+// stream never overlap on this stack.  Workgroups [0, tiles x rounds) count (the long ones start first), the others run
+// the per-line stage.  Same bodies, same results as the two launches.
+struct CountKArgs {
+    const unsigned long long *rng_state;
+    const float *r, *centers, *aabb2, *rows;
+    unsigned long long *accept;
+    int n_rows, n, rounds, prefilter, gx, gy;
+};
+__global__ __launch_bounds__(1024) void pair_count_kernel(const PairArgs a, const CountKArgs c, int pair_gx) {
+    __shared__ SampleCountLds clds;
+    const int ncount = c.gx * c.gy, lin = (int)blockIdx.x;
+    if (lin < ncount) {  // uniform per workgroup
+        sample_count_body(clds, nullptr, c.rng_state, c.r, c.centers, nullptr, c.aabb2, c.accept, 1, c.n, c.rounds, c.prefilter, 0,
+                          lin % c.gx, lin / c.gx, 0, c.gx, c.rows, c.n_rows);
+        return;
+    }
+    const int l2 = lin - ncount;
+    pair_body(a, l2 / pair_gx, l2 % pair_gx, pair_gx);
+}
+
 static PairArgs pair_args(const float *tri1, const float *tri2, const float *line, void *ws, const WsLayout &w, int B, int N,
                           int M, int L, int s_m, int s_n, int e_m, int e_n, bool tally = true) {
     PairArgs a;
@@ -303,6 +326,19 @@ static int line_pair_dist_impl(const float *tri1, const float *tri2, const float
     if (B == 0 || L == 0) return 0;
     PairArgs pa = pair_args(tri1, tri2, line, ws, w, B, N, M, L, s_m, s_n, e_m, e_n);
     if (reduce_kind(o.reduce_mode, B, (L + 1023) / 1024, pool, with_bwd) != 2) pa.vlist = nullptr;  // only the tail kernel reads VLIST
+    if (RrlCountRider *cr = o.count_rider) {  // the next epoch's count pass rides along (pair_count_kernel)
+        const int ctiles = (cr->n + 1023) / 1024;
+        if (B == 1 && cr->rounds > 0 && cr->n > 0 && (long)ctiles * cr->rounds < 512 && cr->rows && cr->n_rows > 0) {
+            const CountKArgs c = {cr->rng_state, cr->r, cr->centers, cr->aabb2, cr->rows, cr->accept, cr->n_rows, cr->n,
+                                  cr->rounds, rrl_sample_prefilter(), ctiles, cr->rounds};
+            const int pgx = (L + 1023) / 1024;
+            hipLaunchKernelGGL(pair_count_kernel, dim3((unsigned)(ctiles * cr->rounds + pgx * B)), dim3(1024), 0,
+                               (hipStream_t)stream, pa, c, pgx);
+            RRL_LAUNCH_CHECK();
+            cr->done = 1;
+            return 0;
+        }
+    }
     hipLaunchKernelGGL(line_pair_dist_kernel, dim3((unsigned)((L + 1023) / 1024), (unsigned)B), dim3(1024), 0,
                        (hipStream_t)stream, pa);
     RRL_LAUNCH_CHECK();
@@ -1692,6 +1728,7 @@ RrlCall rrl_resolve_opts(const rrl_opts *p) {
     o.clear_ptr = nullptr;
     o.clear_bytes = 0;
     o.rider = nullptr;  // (set below from rrl_opts.chamfer)
+    o.count_rider = nullptr;
     o.tar_ws = nullptr;
     rrl_opts v;
     memset(&v, 0, sizeof v);

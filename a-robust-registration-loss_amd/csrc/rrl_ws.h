@@ -87,6 +87,19 @@ struct WsLayout {
 // RRL_* environment variables selected) and handed through its stages by value: no stage reads a process-wide knob.
 typedef rrl_chamfer_rider RrlChamRider;  // include/rrl.h: the evaluation's Chamfer walk, carried by the culled scan's launch
 
+// (internal, rrl_demo_epoch) The COUNT pass of the NEXT epoch's line sampler, carried by this evaluation's per-line launch
+// (pair_count_kernel): it needs the moved source's box -- the records launch's partial rows -- and the sampler's static
+// geometry, not the scan; the per-line stage and the count pass both run 1024-lane workgroups.
+struct RrlCountRider {
+    const unsigned long long *rng_state;
+    const float *r, *centers, *aabb2;
+    const float *rows;  // APART rows of cloud 1 (the moved source's partial boxes)
+    int n_rows;
+    unsigned long long *accept;  // the sampler's ballots (tile_counts)
+    int n, rounds;
+    int done;
+};
+
 struct RrlCall {
     int flags;
     int reduce_mode;    // 0 auto, 1 single, 2 tiled, 3 xchg
@@ -101,12 +114,19 @@ struct RrlCall {
     void *clear_ptr;
     size_t clear_bytes;  // multiple of 4
     RrlChamRider *rider;  // rrl_opts.chamfer
+    RrlCountRider *count_rider;  // (internal) see RrlCountRider
     const void *tar_ws;   // (internal) the workspace that holds cloud 2's records when the target's scan is carried over
                           // (rrl_*_forward_cached: `target_ws`): the riding walk takes the target from there
     __host__ bool prepared() const { return order1 != nullptr; }
     __host__ bool target_kept() const { return order1 != nullptr && (flags & RRL_F_TARGET_KEPT); }
 };
 RrlCall rrl_resolve_opts(const rrl_opts *o);  // rrl_sparse.hip
+// the sampler's two passes on their own (rrl_geom.hip; rrl_sample_lines_rng = both): rrl_demo_epoch pipelines them
+int rrl_sample_count_pass(const uint64_t *rng_state, const float *r, const float *centers, const float *aabb1, const float *aabb2,
+                          int32_t *tile_counts, int B, int n, int rounds, void *stream);
+int rrl_sample_write_pass(uint64_t *rng_state, const float *r, const float *centers, float *lines, int32_t *filled,
+                          int32_t *tile_counts, int B, int n, int rounds, void *stream);
+int rrl_sample_prefilter(void);
 // rrl_registration_step_ex with the call's options already resolved (rrl_sparse.hip; rrl_epoch.hip adds a rider)
 int rrl_registration_step_call(const float *src, const float *R, const float *t, const float *tri2, const float *line,
                                void *ws, size_t ws_bytes, float *loss, const float *grad_loss, float *gR, float *gt,

@@ -110,7 +110,8 @@ class DemoEpochArgs(ctypes.Structure):
                 ("grad_loss", _P), ("gR", _P), ("gt", _P), ("opts", _P),
                 ("cham_ws", _P), ("cham_ws_bytes", _Z), ("best_x", _P), ("best_y", _P), ("cham_value", _P),
                 ("xi", _P), ("m", _P), ("v", _P), ("adam_state", _P), ("lr", _P), ("b1", _c.c_double), ("b2", _c.c_double),
-                ("eps", _c.c_double), ("table", _P), ("cursor", _P), ("table_rows", _c.c_longlong), ("row", _P)]
+                ("eps", _c.c_double), ("table", _P), ("cursor", _P), ("table_rows", _c.c_longlong), ("row", _P),
+                ("pipeline", _P)]
 
 
 _lib = None

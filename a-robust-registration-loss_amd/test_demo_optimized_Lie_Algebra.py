@@ -337,6 +337,9 @@ def _one_call_epoch(draw, reg, lines, box1, xi, opt, Rb, Tb, trace, slot, row, t
     a.xi, a.m, a.v, a.adam_state, a.lr = P(xi.data), P(opt.m), P(opt.v), P(opt.step), P(opt.lr)
     a.b1, a.b2, a.eps = 0.9, 0.999, 1e-8
     a.table, a.cursor, a.table_rows, a.row = P(trace), P(slot), table_rows, P(row)
+    pipe = ctypes.c_int32(0)  # (host word: the next epoch's count pass rides in this epoch's per-line launch; rrl.h)
+    a.pipeline = ctypes.addressof(pipe)
+    keep["pipe"] = pipe
     lib = _lib.load()
     aref = ctypes.byref(a)
     opts_first, opts_kept = ctypes.addressof(reg._opts), ctypes.addressof(reg._opts_kept)

@@ -350,9 +350,11 @@ def test_demo_end_to_end_reduces_chamfer(demo, tmp_path, device_rng):
 def test_demo_epoch_chamfer_rides_in_the_scans_launch(demo, tmp_path, monkeypatch):
     """Round 4b: in the one-call epoch (rrl_demo_epoch) the Chamfer walk of the step's clouds is carried by the culled
     scan's launch (cull_scan_chamfer_kernel: workgroups [0, 2 B x supergroups) walk, the others scan) instead of being a
-    launch of its own behind the step.  Same bodies, same inputs: the whole run -- per-epoch loss, Chamfer value, validity,
-    the final pose -- is bit-identical to the run with RRL_DEMO_RIDE=0 (the separate rrl_chamfer_from_loss launch), at two
-    sizes (one and several line tiles per wavefront row, ragged clouds)."""
+    launch of its own behind the step, and the COUNT pass of the next epoch's line sampler by the per-line launch
+    (pair_count_kernel; it takes the moved source's box from the records launch's partial rows -- the sampler is software-
+    pipelined across epochs through rrl_demo_epoch_args.pipeline).  Same bodies, same inputs: the whole run -- per-epoch
+    loss, Chamfer value, validity, the final pose -- is bit-identical to the run with RRL_DEMO_RIDE=0 (every kernel in a
+    launch of its own, the sampler at the start of its epoch), at two sizes (ragged clouds, 4 and 9 line tiles)."""
     import argparse
     from rrl_hip import ops
     out = {}
