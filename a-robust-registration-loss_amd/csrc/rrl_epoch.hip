@@ -22,7 +22,9 @@ extern "C" int rrl_demo_epoch(const rrl_demo_epoch_args *a, void *stream) {
     int32_t *pipe = a->struct_bytes >= (int32_t)sizeof(rrl_demo_epoch_args) && rides ? a->pipeline : nullptr;
     if (pipe && ((long)((L + 1023) / 1024) * a->rounds >= 512 || L <= 1024)) pipe = nullptr;  // (the rider's limits: line_pair_dist_impl)
     int rc;
-    if (pipe && *pipe == 1) {  // the previous epoch's per-line launch carried this epoch's count pass: the write pass remains
+    if (pipe && *pipe == 3) {  // ... and its backward launch the write pass too: this epoch's lines are in place
+        rc = 0;
+    } else if (pipe && (*pipe & 1)) {  // the previous epoch's per-line launch carried this epoch's count pass: the write pass remains
         rc = rrl_sample_write_pass(a->rng_state, a->radius, a->centers, a->lines, a->filled, a->tile_counts, 1, L, a->rounds, stream);
     } else {
         rc = rrl_sample_lines_rng(a->rng_state, a->radius, a->centers, a->box1, a->box2, a->lines, a->filled, a->tile_counts,
@@ -42,12 +44,19 @@ extern "C" int rrl_demo_epoch(const rrl_demo_epoch_args *a, void *stream) {
     if (a->ws_bytes < wl.total) return RRL_E_WS;
     RrlCountRider counter = {(const unsigned long long *)a->rng_state, a->radius, a->centers, a->box2, wl.f32(a->ws, RRL_WS_APART),
                              (N + 255) / 256, (unsigned long long *)a->tile_counts, L, a->rounds, 0};
-    if (pipe && (((uintptr_t)a->tile_counts) & 7) == 0) o.count_rider = &counter;
+    // ... and its WRITE pass in the direct backward's launch (RrlWriteRider): the ballots are there by then (the per-line
+    // launch precedes it), and nothing after the per-line stage reads the line buffer it overwrites
+    RrlWriteRider writer = {(unsigned long long *)a->rng_state, a->radius, a->centers, (const unsigned long long *)a->tile_counts,
+                            a->lines, a->filled, L, a->rounds, 0};
+    if (pipe && (((uintptr_t)a->tile_counts) & 7) == 0) {
+        o.count_rider = &counter;
+        o.write_rider = &writer;
+    }
     rc = rrl_registration_step_call(a->src_tri, a->R, a->T, a->tar_tri, a->lines, a->ws, a->ws_bytes, a->loss, a->grad_loss,
                                     a->gR, a->gt, nullptr, 1, N, M, L, a->transpose_r, 1, 1, 5, 5, RRL_SCAN_CULL, 0, nullptr, o,
                                     stream);
     if (rc) return rc;
-    if (pipe) *pipe = counter.done;
+    if (pipe) *pipe = counter.done ? (writer.done ? 3 : 1) : 0;  // (a write pass without its count pass cannot have ridden)
     if (!rider.done) {
         rc = rrl_chamfer_from_loss(a->ws, a->ws, a->ws_bytes, 1, N, M, L, a->cham_ws, a->cham_ws_bytes, a->best_x, a->best_y,
                                    a->cham_value, stream);

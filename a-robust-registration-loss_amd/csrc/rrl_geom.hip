@@ -958,80 +958,9 @@ __global__ __launch_bounds__(1024) void sample_write_kernel(
     const float *__restrict__ aabb1, const float *__restrict__ aabb2,
     const unsigned long long *__restrict__ accept, float *__restrict__ lines, int32_t *__restrict__ filled,
     int B, int n, int rounds) {
-    __shared__ int s_total, s_w[16];
-    const int tile = blockIdx.x, rd = blockIdx.y, b = blockIdx.z, ntiles = gridDim.x;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     extern __shared__ int s_tc[];  // this sample's tile counts [rounds][ntiles] from the ballots, then their exclusive prefix
-    const int E = rounds * ntiles;
-    for (int q = tid; q < E; q += 1024) {
-        const unsigned long long *aq = accept + ((size_t)b * E + q) * 16;
-        int c = 0;
-#pragma unroll
-        for (int w = 0; w < 16; ++w) c += __popcll(aq[w]);
-        s_tc[q] = c;
-    }
-    const unsigned long long *am = accept + (((size_t)b * rounds + rd) * ntiles + tile) * 16;
-    const unsigned long long mask = am[wave];
-    int woff = 0;
-    for (int w = 0; w < wave; ++w) woff += __popcll(am[w]);
-    __syncthreads();
-    // Exclusive prefix of the tile counts in (round, tile) order by the whole workgroup (one lane walking the 200 entries
-    // of the demo's call through LDS took 5 of this kernel's 12.6 us).  The reference skips a round once more than n
-    // candidates were accepted BEFORE it (code/loss.py:368-369); the counts only grow, so every later round is skipped
-    // too, and the slots of the rounds that are not skipped are the plain prefix: base = prefix at (rd, tile), skipped =
-    // prefix at the round's first tile > n, total = prefix at the first skipped round (else the grand total).
-    int carry = 0;
-    for (int base0 = 0; base0 < E; base0 += 1024) {  // uniform
-        const int q = base0 + tid;
-        const int v = q < E ? s_tc[q] : 0;
-        const int incl = wave_incl_scan(v);
-        if (lane == 63) s_w[wave] = incl;
-        __syncthreads();
-        int off = carry, all = 0;
-#pragma unroll
-        for (int w = 0; w < 16; ++w) { off += w < wave ? s_w[w] : 0; all += s_w[w]; }
-        if (q < E) s_tc[q] = off + incl - v;
-        carry += all;
-        __syncthreads();
-    }
-    if (tid == 0) s_total = carry;
-    __syncthreads();
-    for (int q = tid; q < rounds; q += 1024)
-        if (s_tc[q * ntiles] > n) atomicMin(&s_total, s_tc[q * ntiles]);
-    __syncthreads();
-    const int s_base = s_tc[rd * ntiles + tile];
-    const bool s_skip = s_tc[rd * ntiles] > n;
-    const int i = tile * 1024 + tid;
-    const bool ok = (mask >> lane) & 1ull;
-    if (ok && !s_skip) {
-        const int slot = s_base + woff + __popcll(mask & ((1ull << lane) - 1ull));
-        if (slot < n) {
-            const SampleGeom g = sample_geom(r, centers, aabb1, aabb2, b);
-            float ln[6];
-            sample_line(g, rands, rng_state, B, n, b, rd, i, ln);
-            float *dst = lines + ((size_t)b * n + slot) * 6;
-#pragma unroll
-            for (int c = 0; c < 6; ++c) dst[c] = ln[c];
-        }
-    }
-    // unfilled rows stay zero: the workgroups of round 0 clear the part of their tile beyond the total
-    if (rd == 0 && i < n && i >= s_total) {
-        float *dst = lines + ((size_t)b * n + i) * 6;
-#pragma unroll
-        for (int c = 0; c < 6; ++c) dst[c] = 0.0f;
-    }
-    if (rd == 0 && tile == 0 && tid == 0) filled[b] = s_total;
-    if (rng_state != nullptr) {  // the next call draws the next block of the stream: advanced by whoever finishes last
-        __syncthreads();         // (every lane of this workgroup has drawn its candidate)
-        if (tid == 0) {
-            unsigned *ticket = (unsigned *)(rng_state + 2);
-            const unsigned nwg = gridDim.x * gridDim.y * gridDim.z;
-            if (atomicAdd(ticket, 1u) == nwg - 1u) {
-                rng_state[1] += 1ull;
-                __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-    }
+    sample_write_body<1024>(s_tc, rands, rng_state, r, centers, aabb1, aabb2, accept, lines, filled, B, n, rounds, (int)blockIdx.x,
+                            (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, gridDim.x * gridDim.y * gridDim.z);
 }
 
 int rrl_sample_prefilter(void) {

@@ -287,3 +287,91 @@ __device__ __forceinline__ void sample_count_body(
     if (lane == 0) accept[(((size_t)b * rounds + rd) * gx + tile) * 16 + wave] = mask;
 }
 
+// The WRITE pass of one (tile of 1024 candidates, round, sample) by a workgroup of LANES lanes (1024: sample_write_kernel;
+// 256: the rider of the direct backward's launch, bwd_write_kernel in rrl_sparse.hip, four passes over the tile's sixteen
+// ballots).  s_tc: LDS, rounds x ntiles ints.  nwg: the write pass's workgroups in this launch (the generator's ticket).
+template <int LANES>
+__device__ __forceinline__ void sample_write_body(
+    int *s_tc, const float *__restrict__ rands, unsigned long long *__restrict__ rng_state, const float *__restrict__ r,
+    const float *__restrict__ centers, const float *__restrict__ aabb1, const float *__restrict__ aabb2,
+    const unsigned long long *__restrict__ accept, float *__restrict__ lines, int32_t *__restrict__ filled,
+    int B, int n, int rounds, const int bx, const int by, const int bz, const int ntiles, const unsigned nwg) {
+    constexpr int NW = LANES / 64, PASSES = 1024 / LANES;
+    __shared__ int s_total, s_w[NW];
+    const int tile = bx, rd = by, b = bz;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int E = rounds * ntiles;
+    for (int q = tid; q < E; q += LANES) {
+        const unsigned long long *aq = accept + ((size_t)b * E + q) * 16;
+        int c = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) c += __popcll(aq[w]);
+        s_tc[q] = c;
+    }
+    const unsigned long long *am = accept + (((size_t)b * rounds + rd) * ntiles + tile) * 16;
+    __syncthreads();
+    // Exclusive prefix of the tile counts in (round, tile) order by the whole workgroup (one lane walking the 200 entries
+    // of the demo's call through LDS took 5 of this kernel's 12.6 us).  The reference skips a round once more than n
+    // candidates were accepted BEFORE it (code/loss.py:368-369); the counts only grow, so every later round is skipped
+    // too, and the slots of the rounds that are not skipped are the plain prefix: base = prefix at (rd, tile), skipped =
+    // prefix at the round's first tile > n, total = prefix at the first skipped round (else the grand total).
+    int carry = 0;
+    for (int base0 = 0; base0 < E; base0 += LANES) {  // uniform
+        const int q = base0 + tid;
+        const int v = q < E ? s_tc[q] : 0;
+        const int incl = wave_incl_scan(v);
+        if (lane == 63) s_w[wave] = incl;
+        __syncthreads();
+        int off = carry, all = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) { off += w < wave ? s_w[w] : 0; all += s_w[w]; }
+        if (q < E) s_tc[q] = off + incl - v;
+        carry += all;
+        __syncthreads();
+    }
+    if (tid == 0) s_total = carry;
+    __syncthreads();
+    for (int q = tid; q < rounds; q += LANES)
+        if (s_tc[q * ntiles] > n) atomicMin(&s_total, s_tc[q * ntiles]);
+    __syncthreads();
+    const int s_base = s_tc[rd * ntiles + tile];
+    const bool s_skip = s_tc[rd * ntiles] > n;
+    const int total = s_total;
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+        const int w16 = p * NW + wave;  // this wavefront's ballot of the tile
+        const unsigned long long mask = am[w16];
+        int woff = 0;
+        for (int w = 0; w < w16; ++w) woff += __popcll(am[w]);
+        const int i = tile * 1024 + 64 * w16 + lane;
+        const bool ok = (mask >> lane) & 1ull;
+        if (ok && !s_skip) {
+            const int slot = s_base + woff + __popcll(mask & ((1ull << lane) - 1ull));
+            if (slot < n) {
+                const SampleGeom g = sample_geom(r, centers, aabb1, aabb2, b);
+                float ln[6];
+                sample_line(g, rands, rng_state, B, n, b, rd, i, ln);
+                float *dst = lines + ((size_t)b * n + slot) * 6;
+#pragma unroll
+                for (int c = 0; c < 6; ++c) dst[c] = ln[c];
+            }
+        }
+        // unfilled rows stay zero: the workgroups of round 0 clear the part of their tile beyond the total
+        if (rd == 0 && i < n && i >= total) {
+            float *dst = lines + ((size_t)b * n + i) * 6;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) dst[c] = 0.0f;
+        }
+    }
+    if (rd == 0 && tile == 0 && tid == 0) filled[b] = total;
+    if (rng_state != nullptr) {  // the next call draws the next block of the stream: advanced by whoever finishes last
+        __syncthreads();         // (every lane of this workgroup has drawn its candidate)
+        if (tid == 0) {
+            unsigned *ticket = (unsigned *)(rng_state + 2);
+            if (atomicAdd(ticket, 1u) == nwg - 1u) {
+                rng_state[1] += 1ull;
+                __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+}

@@ -1729,6 +1729,7 @@ RrlCall rrl_resolve_opts(const rrl_opts *p) {
     o.clear_bytes = 0;
     o.rider = nullptr;  // (set below from rrl_opts.chamfer)
     o.count_rider = nullptr;
+    o.write_rider = nullptr;
     o.tar_ws = nullptr;
     rrl_opts v;
     memset(&v, 0, sizeof v);
@@ -2138,18 +2139,20 @@ __device__ __forceinline__ void bwd_rt_line(int li, int h, int b, int L, int N, 
 // DET = true (rrl_set_deterministic): instead of the atomics every workgroup stores its 12 sums to
 // part[b][workgroup][12] and loss_bwd_rt_finalize_kernel adds them in index order; the assignment of
 // lines to workgroups is fixed too (see below) -- bit-reproducible from run to run, one more (tiny) launch.
+// (bx, by: the workgroup's place in the backward's grid, gx its first extent -- blockIdx / gridDim in loss_bwd_rt_kernel,
+//  decoded from a linear index in bwd_write_kernel)
 template <bool DET>
-__global__ __launch_bounds__(256) void loss_bwd_rt_kernel(
+__device__ __forceinline__ void loss_bwd_rt_body(
     const uint8_t *__restrict__ kj, const int32_t *__restrict__ sel, const int32_t *__restrict__ nsel,
     const int32_t *__restrict__ hs1, const float *__restrict__ w1, const float4 *__restrict__ Q1,
     const float4 *__restrict__ Q2, const float *__restrict__ D, const float *__restrict__ med,
     const int32_t *__restrict__ bcnt, const int32_t *__restrict__ info,
     const float *__restrict__ grad_loss, const float *__restrict__ src, float *__restrict__ gR,
     float *__restrict__ gt, float *__restrict__ payload, const float *__restrict__ loss, int B, int N,
-    int L, int transpose_r, float *__restrict__ part) {
+    int L, int transpose_r, float *__restrict__ part, const int bx, const int by, const int gx) {
     __shared__ float red[4][12];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.y;
+    const int b = by;
     const int h = tid & 3;
     int li = -1;  // this lane's selected line (index within the sample), or none
     if constexpr (DET) {
@@ -2160,7 +2163,7 @@ __global__ __launch_bounds__(256) void loss_bwd_rt_kernel(
         // from the KJ bytes of the tile.
         __shared__ int s_line[BWD_LINES];
         __shared__ int s_wc[4][4];
-        const int tile = blockIdx.x >> 4, sub = blockIdx.x & 15;
+        const int tile = bx >> 4, sub = bx & 15;
         bool sl[4];
         unsigned long long bm[4];
 #pragma unroll
@@ -2187,8 +2190,8 @@ __global__ __launch_bounds__(256) void loss_bwd_rt_kernel(
         li = s_line[tid >> 2];
     } else {
         const int ns = nsel[b];
-        if ((int)blockIdx.x >= bwd_live_blocks(ns)) return;  // uniform: nothing selected in this slice
-        const int i = blockIdx.x * BWD_LINES + (tid >> 2);
+        if (bx >= bwd_live_blocks(ns)) return;  // uniform: nothing selected in this slice
+        const int i = bx * BWD_LINES + (tid >> 2);
         if (i < ns) li = sel[(size_t)b * L + i];
     }
     float acc[12];
@@ -2206,17 +2209,68 @@ __global__ __launch_bounds__(256) void loss_bwd_rt_kernel(
         int o = tid;  // m-index (i, j) -> memory order of R
         if (tid < 9 && transpose_r) o = (tid % 3) * 3 + tid / 3;
         if constexpr (DET) {
-            part[((size_t)b * gridDim.x + blockIdx.x) * 12 + o] = v;
+            part[((size_t)b * gx + bx) * 12 + o] = v;
         } else {
             if (tid < 9) atomicAdd(&gR[b * 9 + o], v); else atomicAdd(&gt[b * 3 + (tid - 9)], v);
             if (payload) atomicAdd(&payload[2 + o], v);
         }
     }
-    if (!DET && payload && blockIdx.x == 0 && b == 0 && tid >= 64 && tid < 66) {  // [sum of valid losses, #valid]
+    if (!DET && payload && bx == 0 && b == 0 && tid >= 64 && tid < 66) {  // [sum of valid losses, #valid]
         double sp = 0.0;
         for (int k = 0; k < B; ++k) sp += info[k * 4] > 0 ? (tid == 64 ? (double)loss[k] : 1.0) : 0.0;
         payload[tid - 64] = (float)sp;
     }
+}
+
+template <bool DET>
+__global__ __launch_bounds__(256) void loss_bwd_rt_kernel(
+    const uint8_t *__restrict__ kj, const int32_t *__restrict__ sel, const int32_t *__restrict__ nsel,
+    const int32_t *__restrict__ hs1, const float *__restrict__ w1, const float4 *__restrict__ Q1,
+    const float4 *__restrict__ Q2, const float *__restrict__ D, const float *__restrict__ med,
+    const int32_t *__restrict__ bcnt, const int32_t *__restrict__ info,
+    const float *__restrict__ grad_loss, const float *__restrict__ src, float *__restrict__ gR,
+    float *__restrict__ gt, float *__restrict__ payload, const float *__restrict__ loss, int B, int N,
+    int L, int transpose_r, float *__restrict__ part) {
+    loss_bwd_rt_body<DET>(kj, sel, nsel, hs1, w1, Q1, Q2, D, med, bcnt, info, grad_loss, src, gR, gt, payload, loss, B, N, L,
+                          transpose_r, part, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x);
+}
+
+// The direct backward AND the write pass of the next epoch's line sampler in ONE launch (round 4b; rrl_ws.h RrlWriteRider,
+// rrl_demo_epoch): 256-lane workgroups both; workgroups [0, tiles x rounds) write, the others run the backward.
+struct BwdKArgs {
+    const uint8_t *kj;
+    const int32_t *sel, *nsel, *hs1;
+    const float *w1;
+    const float4 *Q1, *Q2;
+    const float *D, *med;
+    const int32_t *bcnt, *info;
+    const float *grad_loss, *src;
+    float *gR, *gt, *payload;
+    const float *loss;
+    int B, N, L, transpose_r;
+    float *part;
+    int gx;
+};
+struct WriteKArgs {
+    unsigned long long *rng_state;
+    const float *r, *centers;
+    const unsigned long long *accept;
+    float *lines;
+    int32_t *filled;
+    int n, rounds, gx, gy;
+};
+template <bool DET>
+__global__ __launch_bounds__(256) void bwd_write_kernel(const BwdKArgs a, const WriteKArgs c) {
+    extern __shared__ int s_tc_dyn[];  // the write pass's tile counts [rounds][tiles]
+    const int nwrite = c.gx * c.gy, lin = (int)blockIdx.x;
+    if (lin < nwrite) {  // uniform per workgroup
+        sample_write_body<256>(s_tc_dyn, nullptr, c.rng_state, c.r, c.centers, nullptr, nullptr, c.accept, c.lines, c.filled, 1, c.n,
+                               c.rounds, lin % c.gx, lin / c.gx, 0, c.gx, (unsigned)nwrite);
+        return;
+    }
+    const int l2 = lin - nwrite;
+    loss_bwd_rt_body<DET>(a.kj, a.sel, a.nsel, a.hs1, a.w1, a.Q1, a.Q2, a.D, a.med, a.bcnt, a.info, a.grad_loss, a.src, a.gR, a.gt,
+                          a.payload, a.loss, a.B, a.N, a.L, a.transpose_r, a.part, l2 % a.gx, l2 / a.gx, a.gx);
 }
 
 // Fixed-order tail of the deterministic direct backward: one lane per (sample, entry) adds the live
@@ -2671,11 +2725,32 @@ static int registration_backward_impl(const float *src, const float *R, const fl
                            (const float4 *)w.f32(ws, RRL_WS_Q2), w.f32(ws, RRL_WS_D), w.f32(ws, RRL_WS_MED),       \
                            w.i32(ws, RRL_WS_BCNT), w.i32(ws, RRL_WS_INFO), grad_loss, src, gR, gt, payload, loss,  \
                            B, N, L, transpose_r, PART)
+        // the next epoch's sampler write pass rides along (bwd_write_kernel; rrl_demo_epoch)
+        RrlWriteRider *wr = o.write_rider;
+        const int wtiles = wr ? (wr->n + 1023) / 1024 : 0;
+        const bool ride = wr && (!o.count_rider || o.count_rider->done) &&  // (the ballots of THAT count pass: it must have ridden)
+                          B == 1 && wr->n > 0 && wr->rounds > 0 && (long)wtiles * wr->rounds < 512 &&
+                          sizeof(int32_t) * (size_t)wr->rounds * wtiles <= 48 * 1024;
+        const WriteKArgs wk = ride ? WriteKArgs{wr->rng_state, wr->r, wr->centers, wr->accept, wr->lines, wr->filled, wr->n,
+                                                wr->rounds, wtiles, wr->rounds}
+                                   : WriteKArgs{};
+#define RRL_BWD_WRITE(DET, PART)                                                                               \
+        do {                                                                                                   \
+            const BwdKArgs ba = {w.u8(ws, RRL_WS_KJ), w.i32(ws, RRL_WS_SEL), w.i32(ws, RRL_WS_NSEL), w.i32(ws, RRL_WS_HS1), \
+                                 w.f32(ws, RRL_WS_W1), (const float4 *)w.f32(ws, RRL_WS_Q1),                    \
+                                 (const float4 *)w.f32(ws, RRL_WS_Q2), w.f32(ws, RRL_WS_D), w.f32(ws, RRL_WS_MED), \
+                                 w.i32(ws, RRL_WS_BCNT), w.i32(ws, RRL_WS_INFO), grad_loss, src, gR, gt, payload, loss, \
+                                 B, N, L, transpose_r, PART, nblk};                                             \
+            hipLaunchKernelGGL(bwd_write_kernel<DET>, dim3((unsigned)(wk.gx * wk.gy + nblk * B)), dim3(256),     \
+                               sizeof(int32_t) * (size_t)wk.rounds * wk.gx, s, ba, wk);                         \
+            wr->done = 1;                                                                                      \
+        } while (0)
         if (o.deterministic) {
             // partials in VALS (the reduce kernel's input tiles: dead after the forward; B * Lp * 16 floats
             // >= B * 16 ceil(L / 1024) * 12), fixed-order sums by a second launch: nothing to clear
             float *part = w.f32(ws, RRL_WS_VALS);
-            RRL_BWD_RT(true, part);
+            if (ride) RRL_BWD_WRITE(true, part);
+            else RRL_BWD_RT(true, part);
             hipLaunchKernelGGL(loss_bwd_rt_finalize_kernel, dim3(1), dim3(256), 0, s, part, w.i32(ws, RRL_WS_INFO), loss,
                                gR, gt, payload, B, nblk);
             RRL_LAUNCH_CHECK();
@@ -2687,8 +2762,10 @@ static int registration_backward_impl(const float *src, const float *R, const fl
             if ((rc = rrl_fill(gt, 0u, sizeof(float) * 3 * (size_t)B, s))) return rc;
             if (payload && (rc = rrl_fill(payload, 0u, sizeof(float) * 14, s))) return rc;
         }
-        RRL_BWD_RT(false, nullptr);
+        if (ride) RRL_BWD_WRITE(false, nullptr);
+        else RRL_BWD_RT(false, nullptr);
 #undef RRL_BWD_RT
+#undef RRL_BWD_WRITE
         RRL_LAUNCH_CHECK();
         return 0;
     }

@@ -100,6 +100,19 @@ struct RrlCountRider {
     int done;
 };
 
+// (internal, rrl_demo_epoch) ... and the WRITE pass of the next epoch's sampler, carried by this evaluation's direct-backward
+// launch (bwd_write_kernel; 256-lane workgroups): it needs the count pass's ballots (which rode in the per-line launch) and
+// overwrites the line buffer, which nothing after the per-line stage reads.
+struct RrlWriteRider {
+    unsigned long long *rng_state;
+    const float *r, *centers;
+    const unsigned long long *accept;
+    float *lines;
+    int32_t *filled;
+    int n, rounds;
+    int done;
+};
+
 struct RrlCall {
     int flags;
     int reduce_mode;    // 0 auto, 1 single, 2 tiled, 3 xchg
@@ -115,6 +128,7 @@ struct RrlCall {
     size_t clear_bytes;  // multiple of 4
     RrlChamRider *rider;  // rrl_opts.chamfer
     RrlCountRider *count_rider;  // (internal) see RrlCountRider
+    RrlWriteRider *write_rider;  // (internal) see RrlWriteRider
     const void *tar_ws;   // (internal) the workspace that holds cloud 2's records when the target's scan is carried over
                           // (rrl_*_forward_cached: `target_ws`): the riding walk takes the target from there
     __host__ bool prepared() const { return order1 != nullptr; }

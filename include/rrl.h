@@ -507,8 +507,8 @@ int rrl_se3_adam_step(float *xi, const float *gR, const float *gT, float *m, flo
  * riding in its scan launch (rrl_chamfer_rider; = rrl_chamfer_from_loss: requires the point sets to be the triangles' first
  * points; RRL_DEMO_RIDE=0 in the environment: the separate launch) -> pose step (rrl_se3_adam_step: exp-map backward,
  * gated Adam on xi, (R, T) = exp(updated xi), log row, box1 = the moved source's AABB for the next epoch).  Nothing but
- * the entries' own kernels, 8 launches issued back to back (7 with `pipeline`: the next epoch's count pass rides in this
- * epoch's per-line launch): a loop pays one host call per epoch.  One pair
+ * the entries' own kernels, 8 launches issued back to back (6 with `pipeline`: the next epoch's sampler passes ride in this
+ * epoch's per-line and backward launches): a loop pays one host call per epoch.  One pair
  * (B = 1); every pointer a device pointer as in the four entries; struct_bytes = sizeof(rrl_demo_epoch_args). */
 typedef struct rrl_demo_epoch_args {
     int32_t struct_bytes, N, M, L, rounds, transpose_r;
@@ -523,8 +523,10 @@ typedef struct rrl_demo_epoch_args {
     float *xi, *m, *v, *adam_state; const float *lr; double b1, b2, eps; float *table; long long *cursor; long long table_rows; float *row;
     /* NULL, or one HOST int32 the caller zeroes before the first epoch and then leaves alone: with it the sampler is software-
      * pipelined across epochs -- the COUNT pass of epoch k + 1 (it needs the moved source's box = the partial rows of epoch
-     * k's records launch, not box1 from the pose launch) rides in the per-line launch of epoch k; the word remembers that
-     * the next call starts with the write pass only.  radius / centers / box2 / L / rounds must not change while it is 1. */
+     * k's records launch, not box1 from the pose launch) rides in the per-line launch of epoch k, its WRITE pass in the
+     * direct-backward launch of epoch k (nothing after the per-line stage reads `lines`); the word remembers what the next
+     * call may skip (bit 0: the count pass, bit 1: the write pass too).  radius / centers / box2 / L / rounds must not
+     * change while it is non-zero, and `lines` belongs to the library between two calls. */
     int32_t *pipeline;
 } rrl_demo_epoch_args;
 int rrl_demo_epoch(const rrl_demo_epoch_args *args, void *stream);
