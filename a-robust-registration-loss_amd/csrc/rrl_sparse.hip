@@ -287,8 +287,10 @@ __global__ __launch_bounds__(1024) void pair_count_kernel(const PairArgs a, cons
     pair_body(a, l2 / pair_gx, l2 % pair_gx, pair_gx);
 }
 
+// tar_ws != NULL: cloud 2's hit counts / hit lists are read where its scan left them -- the workspace of the evaluation the
+// target was carried over from (round 4b: they used to be copied into this workspace first, two launches per evaluation).
 static PairArgs pair_args(const float *tri1, const float *tri2, const float *line, void *ws, const WsLayout &w, int B, int N,
-                          int M, int L, int s_m, int s_n, int e_m, int e_n, bool tally = true) {
+                          int M, int L, int s_m, int s_n, int e_m, int e_n, bool tally = true, const void *tar_ws = nullptr) {
     PairArgs a;
     a.mhist = tally ? w.u32(ws, RRL_WS_MHIST) : nullptr;
     a.mctl = tally ? w.u32(ws, RRL_WS_MCTL) : nullptr;
@@ -296,7 +298,8 @@ static PairArgs pair_args(const float *tri1, const float *tri2, const float *lin
     a.tri2 = tri2;
     a.line = line;
     a.count1 = w.i32(ws, RRL_WS_COUNT1); a.hit1 = w.i32(ws, RRL_WS_HIT1);
-    a.count2 = w.i32(ws, RRL_WS_COUNT2); a.hit2 = w.i32(ws, RRL_WS_HIT2);
+    a.count2 = tar_ws ? w.i32(tar_ws, RRL_WS_COUNT2) : w.i32(ws, RRL_WS_COUNT2);
+    a.hit2 = tar_ws ? w.i32(tar_ws, RRL_WS_HIT2) : w.i32(ws, RRL_WS_HIT2);
     a.kj = w.u8(ws, RRL_WS_KJ);
     a.sel_out = w.i32(ws, RRL_WS_SEL); a.nsel = w.i32(ws, RRL_WS_NSEL);
     a.hs1 = w.i32(ws, RRL_WS_HS1); a.hs2 = w.i32(ws, RRL_WS_HS2);
@@ -324,7 +327,7 @@ static int line_pair_dist_impl(const float *tri1, const float *tri2, const float
     WsLayout w(B, N, M, L);
     if (ws_bytes < w.total) return RRL_E_WS;
     if (B == 0 || L == 0) return 0;
-    PairArgs pa = pair_args(tri1, tri2, line, ws, w, B, N, M, L, s_m, s_n, e_m, e_n);
+    PairArgs pa = pair_args(tri1, tri2, line, ws, w, B, N, M, L, s_m, s_n, e_m, e_n, true, o.tar_ws);
     if (reduce_kind(o.reduce_mode, B, (L + 1023) / 1024, pool, with_bwd) != 2) pa.vlist = nullptr;  // only the tail kernel reads VLIST
     if (RrlCountRider *cr = o.count_rider) {  // the next epoch's count pass rides along (pair_count_kernel)
         const int ctiles = (cr->n + 1023) / 1024;
@@ -2453,16 +2456,7 @@ static int loss_forward_impl(const float *tri1, const float *tri2, const float *
         RrlRange r("K1' records + sort + tree");
         if ((rc = rrl_tri_prepare_clouds(tri1, tri2, ws, ws_bytes, B, N, M, L, build_clouds, xf, line, o, stream))) return rc;
     }
-    if (target_ws && (size_t)B * L) {  // after the prepare step, which cleared COUNT2
-        WsLayout w(B, N, M, L);
-        hipStream_t s = (hipStream_t)stream;
-        if ((rc = rrl_copy(w.i32(ws, RRL_WS_COUNT2), (const char *)target_ws + w.off[RRL_WS_COUNT2],
-                           sizeof(int32_t) * (size_t)B * L, s)))
-            return rc;
-        if ((rc = rrl_copy(w.i32(ws, RRL_WS_HIT2), (const char *)target_ws + w.off[RRL_WS_HIT2],
-                           sizeof(int32_t) * RRL_MAX_HITS * (size_t)B * L, s)))
-            return rc;
-    }
+    // (a carried-over target: the per-line stage reads cloud 2's hit counts and lists in `target_ws` itself -- pair_args)
     {
         RrlRange r("K1 line<->triangle scan");
         // (the records kernel reduced the lines' maxima whenever it ran: the sorted path)
@@ -2483,14 +2477,14 @@ static int loss_forward_impl(const float *tri1, const float *tri2, const float *
             sb.gR = tb->gR; sb.gt = tb->gt; sb.payload = tb->payload; sb.mctl = w.u32(ws, RRL_WS_MCTL);
             sb.B = B; sb.N = N; sb.L = L; sb.transpose_r = tb->transpose_r;
             hipLaunchKernelGGL(pair_reduce_bwd_kernel, dim3((unsigned)B), dim3(1024), sizeof(int) * 2, (hipStream_t)stream,
-                               pair_args(tri1, tri2, line, ws, w, B, N, M, L, s_m, s_n, e_m, e_n, false),
+                               pair_args(tri1, tri2, line, ws, w, B, N, M, L, s_m, s_n, e_m, e_n, false, target_ws),
                                reduce_args(ws, w, loss, B, L, s_m, s_n, e_m, e_n, 0), sb);
             RRL_LAUNCH_CHECK();
             if (bwd_done) *bwd_done = true;
             return 0;
         }
         hipLaunchKernelGGL(pair_reduce_kernel, dim3((unsigned)B), dim3(1024), sizeof(int) * 2, (hipStream_t)stream,
-                           pair_args(tri1, tri2, line, ws, w, B, N, M, L, s_m, s_n, e_m, e_n, false),
+                           pair_args(tri1, tri2, line, ws, w, B, N, M, L, s_m, s_n, e_m, e_n, false, target_ws),
                            reduce_args(ws, w, loss, B, L, s_m, s_n, e_m, e_n, 0));
         RRL_LAUNCH_CHECK();
         return 0;

@@ -180,6 +180,10 @@ class LossState:
         i = _FIELD_INDEX.get(name)
         if i is None:
             raise AttributeError(name)
+        if name in ("count2", "hit2"):  # a carried-over target: its hit counts / lists live where its scan left them
+            tgt = self.__dict__.get("target_state")
+            if tgt is not None and tgt is not self:
+                return getattr(tgt, name)
         specs = _spec_cache.get(self.dims)
         if specs is None:
             specs = _spec_cache[self.dims] = {}
@@ -213,7 +217,10 @@ def _target_ws(target_from, B, N, M, L):
         return None
     if tuple(target_from.dims[:4]) != (B, N, M, L):
         raise ValueError(f"target_from was evaluated at {tuple(target_from.dims[:4])}, not {(B, N, M, L)}")
-    return _p(target_from.ws)
+    # the workspace that HOLDS the target's scan (records, hit counts and lists): of the full evaluation at the end of a chain
+    # of carried-over ones
+    tgt = getattr(target_from, "target_state", None) or target_from
+    return _p(tgt.ws)
 
 
 _order_ws = {}  # (B, n, device index) -> scratch of rrl_cloud_order

@@ -232,8 +232,10 @@ int rrl_registration_forward(const float *src, const float *R, const float *t, c
  * (B, N, M, L) that already ran a forward with the same tri2 and line (RPM and FMR evaluate
  * num_iter source poses against one target and one line set, rpm/Train_RPM.py:204-231,
  * fmr/model.py:295-310).  Only the source cloud is prepared/sorted/scanned; the target's hit
- * counts and lists are copied (20 bytes per line).  target_ws == NULL: identical to the plain
- * call.  The result is bit-identical to the plain call either way. */
+ * counts and lists are READ in target_ws by the per-line stage (round 4b; they used to be copied: two launches) -- so
+ * target_ws must be the workspace of the FULL evaluation that scanned the target (not of another carried-over one), and
+ * it must stay untouched until this call's kernels have run (same stream, or an event).  COUNT2 / HIT2 of `ws` are not
+ * written.  target_ws == NULL: identical to the plain call.  The result is bit-identical to the plain call either way. */
 int rrl_loss_forward_cached(const float *tri1, const float *tri2, const float *line, void *ws,
                             size_t ws_bytes, float *loss, int B, int N, int M, int L, int s_m,
                             int s_n, int e_m, int e_n, int pool, int mode, int chunk,

@@ -701,6 +701,15 @@ def test_target_scan_reuse_is_bit_identical(L, mode, n, m):
     hf = np.where(live, full.hit2.cpu().numpy().reshape(live.shape), 1 << 30)
     hc = np.where(live, cached.hit2.cpu().numpy().reshape(live.shape), 1 << 30)
     np.testing.assert_array_equal(np.sort(hf, -1), np.sort(hc, -1))
+    # a chain: the target carried over from an evaluation that itself carried it over -- resolved to the workspace that holds the
+    # target's scan (round 4b: the per-line stage reads cloud 2's counts and hit lists THERE, nothing is copied any more)
+    moved2 = src - 0.02
+    full2 = ops.loss_forward_raw(moved2, tar, lines, mode=mode)
+    chained = ops.loss_forward_raw(moved2, tar, lines, mode=mode, target_from=cached)
+    torch.cuda.synchronize()
+    assert chained.target_state is first
+    for f in ("loss", "count1", "count2", "med", "info"):
+        assert torch.equal(getattr(full2, f), getattr(chained, f)), f
     # through autograd, fused with the rigid transform
     R = torch.eye(3, device="cuda").repeat(B, 1, 1).requires_grad_(True)
     t = torch.full((B, 3), 0.01, device="cuda").requires_grad_(True)
