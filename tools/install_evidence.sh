@@ -43,4 +43,9 @@ if os.path.exists(ride):
     out["bytes_corrected"] = (2 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024
     json.dump(out, open(f"profiles/{T}_pmc_ride.json", "w"), indent=1)
 PY
+if [ -f gpurun_out/${T}_demo_ride_soak.txt ]; then
+  (echo "# round 4, final tree (csrc_sha $SHA): tools/demo_ride_soak.py 10000 on MI355X (gpurun) -- rrl_demo_epoch with all three riding launches against"
+   echo "# RRL_DEMO_RIDE=0 (every kernel in a launch of its own), deterministic backward: per-epoch loss / Chamfer / validity and final pose bit-identical"
+   cat gpurun_out/${T}_demo_ride_soak.txt) > profiles/r04_demo_ride_soak.txt
+fi
 echo "installed profiles/${T}_* (csrc_sha $SHA)"
