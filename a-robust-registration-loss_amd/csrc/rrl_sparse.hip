@@ -1749,6 +1749,7 @@ RrlCall rrl_resolve_opts(const rrl_opts *p) {
     if (v.scan_counters) { o.counters = (unsigned long long *)v.scan_counters; o.counter_rows = v.scan_counter_rows; }
     else rrl_default_scan_counters(&o.counters, &o.counter_rows);
     o.rider = v.chamfer;  // (done is the caller's to clear; the scan's launcher sets it when the walk rides along)
+    o.payload = v.payload;
     return o;
 }
 // Which reduce kernel: 0 one workgroup per sample, 1 tiled with the candidate exchange (loss_reduce_tiled_kernel), 2 the
@@ -2663,10 +2664,18 @@ extern "C" int rrl_loss_step_ex(const float *tri1, const float *R, const float *
     o.clear_ptr = grad_tri1;
     o.clear_bytes = sizeof(float) * 9 * (size_t)B * N;
     const int nblk = (L + 1023) / 1024;
-    const RrlXform xf = {tri1, R, t, transpose_r, 0};
+    // the shard payload of the step (rrl_opts.payload): in the workspace's GACC field the records launch clears it with the
+    // rest of the accumulator (the fused op's convention); any other buffer is cleared here first
+    float *payload = o.payload;
+    const bool pay_in_ws = payload && R && payload == w.f32(ws, RRL_WS_GACC) + 12 * (size_t)B;
+    if (payload && !pay_in_ws) {
+        int rcf = rrl_fill(payload, 0u, sizeof(float) * 14, (hipStream_t)stream);
+        if (rcf) return rcf;
+    }
+    const RrlXform xf = {tri1, R, t, transpose_r, pay_in_ws ? 1 : 0};
     const float *p1 = R ? w.f32(ws, RRL_WS_TRI1) : tri1;  // points1: the moved source, or the caller's triangles as given
     const bool ride = B > 0 && L > 0 && !grad_tri2 && L > 1024 && reduce_kind(o.reduce_mode, B, nblk, 0, true) == 2;
-    const TailBwd tb = {grad_loss, nullptr, nullptr, nullptr, nullptr, 0, grad_tri1};
+    const TailBwd tb = {grad_loss, nullptr, nullptr, nullptr, payload, 0, grad_tri1};
     bool done = false;
     int rc = loss_forward_impl(p1, tri2, line, ws, ws_bytes, loss, B, N, M, L, s_m, s_n, e_m, e_n, 0, mode, chunk, target_ws,
                                R ? &xf : nullptr, o, stream, ride ? &tb : nullptr, &done);
@@ -2674,7 +2683,9 @@ extern "C" int rrl_loss_step_ex(const float *tri1, const float *R, const float *
     // (grad_tri1 was cleared by the build step's first launch -- or by its fill on the unsorted path; an empty batch /
     //  cloud launches nothing: clear here)
     if (B == 0 || (N == 0 && M == 0)) return rrl_fill(grad_tri1, 0u, o.clear_bytes, (hipStream_t)stream);
-    return loss_backward_impl(p1, tri2, ws, ws_bytes, grad_loss, grad_tri1, grad_tri2, B, N, M, L, 0, false, stream);
+    rc = loss_backward_impl(p1, tri2, ws, ws_bytes, grad_loss, grad_tri1, grad_tri2, B, N, M, L, 0, false, stream);
+    if (rc || !payload || L <= 0) return rc;
+    return rrl_shard_payload(loss, ws, ws_bytes, nullptr, nullptr, payload, B, N, M, L, stream);
 }
 
 extern "C" int rrl_registration_backward_ex(const float *src, const float *R, const float *tri2,

@@ -129,6 +129,7 @@ struct RrlCall {
     RrlChamRider *rider;  // rrl_opts.chamfer
     RrlCountRider *count_rider;  // (internal) see RrlCountRider
     RrlWriteRider *write_rider;  // (internal) see RrlWriteRider
+    float *payload;       // rrl_opts.payload (rrl_loss_step_ex): [sum of valid losses, #valid, 0 x 12], or NULL
     const void *tar_ws;   // (internal) the workspace that holds cloud 2's records when the target's scan is carried over
                           // (rrl_*_forward_cached: `target_ws`): the riding walk takes the target from there
     __host__ bool prepared() const { return order1 != nullptr; }

@@ -39,7 +39,7 @@ def build_lib(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
-    objs = []
+    objs, cmds = [], []
     for src in SOURCES:
         obj = os.path.join(LIBDIR, src.replace(".hip", ".o"))
         extra = ["-fno-slp-vectorize"] if src == "rrl_cull.hip" else []  # see the file header
@@ -49,8 +49,12 @@ def build_lib(force=False, verbose=False):
         cmd = [_hipcc(), *FLAGS, *extra, "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
-        subprocess.check_call(cmd)
+        cmds.append(cmd)
         objs.append(obj)
+    # the translation units are independent: compile them side by side (a few host cores; hipcc is single-threaded)
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=min(len(cmds), max(1, (os.cpu_count() or 2) // 2))) as pool:
+        list(pool.map(subprocess.check_call, cmds))
     cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, "-ldl"]
     if verbose:
         print(" ".join(cmd))

@@ -50,7 +50,7 @@ def _first_points_contract(data, channel_first=False):
     a fresh check instead of a stale True).  The value ops.chamfer_from_state returns carries no grad_fn: the
     reference's callers only log the monitor (FMR multiplies it by 0.0)."""
     keys = ('points_src_sample', 'points_based_neighs_src', 'points_tar_sample', 'points_based_neighs_tar')
-    stamp = tuple((data[k].data_ptr(), data[k]._version) for k in keys if isinstance(data.get(k), torch.Tensor))
+    stamp = tuple(ops._write_key(data[k]) for k in keys if isinstance(data.get(k), torch.Tensor))
     cached = data.get('_rrl_p0_key')
     ok = data.get('_rrl_p0') if cached == stamp else None
     if ok is None:
@@ -87,7 +87,7 @@ def _ride_monitor(data, channel_first=False):
     if data is None:
         return False
     keys = ('points_src_sample', 'points_based_neighs_src', 'points_tar_sample', 'points_based_neighs_tar')
-    stamp = tuple((data[k].data_ptr(), data[k]._version) for k in keys if isinstance(data.get(k), torch.Tensor))
+    stamp = tuple(ops._write_key(data[k]) for k in keys if isinstance(data.get(k), torch.Tensor))
     if data.get('_rrl_p0_key') == stamp and data.get('_rrl_p0') is not None:
         return bool(data['_rrl_p0'])
     flag = data.get('p0_rows')
@@ -127,14 +127,17 @@ USE_ORDERS = True  # hand the dataset's 'order_src' / 'order_tar' (pre_dataloade
 #   op: the prepared build -- no cell sort in any pose's step; same loss bits.  False: ignore them.
 
 
-def _orders(data, n_src, n_tar):
-    """(order1, order2) from the trainer's dict when it carries usable ones -- int32 (B, 64 ceil(n / 64)) tensors on the
-    GPU, as the DataLoader collates pre_dataloader's per-item arrays -- else (None, None): the fused op then sorts."""
+def _orders(data, n_src, n_tar, B=None, dev=None):
+    """(order1, order2) from the trainer's dict when it carries usable ones -- contiguous int32 (B, 64 ceil(n / 64))
+    tensors on the op's GPU, as the DataLoader collates pre_dataloader's per-item arrays -- else (None, None): the fused
+    op then sorts.  (Batch dimension and device are part of "usable": the kernels read the tensor as [B][npad] on the
+    GPU that owns the clouds.)"""
     if not USE_ORDERS or data is None:
         return None, None
     o1, o2 = data.get('order_src'), data.get('order_tar')
     ok = all(isinstance(o, torch.Tensor) and o.is_cuda and o.dtype == torch.int32 and o.dim() == 2 and o.is_contiguous()
-             and o.shape[1] == (n + 63) // 64 * 64 for o, n in ((o1, n_src), (o2, n_tar)))
+             and o.shape[1] == (n + 63) // 64 * 64 and (B is None or o.shape[0] == B) and (dev is None or o.device == dev)
+             for o, n in ((o1, n_src), (o2, n_tar)))
     return (o1, o2) if ok else (None, None)
 
 
@@ -149,7 +152,7 @@ def per_sample_loss(src_nb, R, t, tar_tri, lines, mode=None, target_from=None, d
     the evaluation's scan launch (with a carried-over target too: the walk then reads the target in the state that holds it)."""
     B = src_nb.shape[0]
     src_tri, tar_tri = src_nb.reshape(B, -1, 9), tar_tri.reshape(B, -1, 9)
-    o1, o2 = _orders(data, src_tri.shape[1], tar_tri.shape[1])
+    o1, o2 = _orders(data, src_tri.shape[1], tar_tri.shape[1], B, src_tri.device if src_tri.is_cuda else None)
     ride = bool(chamfer) and max(src_tri.shape[1], tar_tri.shape[1]) <= _SORT_CAP
     loss, info, _ = _ops.registration_loss(src_tri, R, t, tar_tri, lines, RNG, transpose_r=True, mode=_mode(mode),
                                            target_from=target_from, order1=o1, order2=o2, chamfer=ride)

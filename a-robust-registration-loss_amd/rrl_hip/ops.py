@@ -90,11 +90,38 @@ def _p(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
+# ---- torch internals this module uses for SPEED, each with a public-API fallback (round 5) ---------
+#   torch._C._cuda_getCurrentRawStream        raw hipStream_t without the ~15 us Stream wrapper -> torch.cuda.current_stream
+#   torch._C._autograd._unsafe_set_version_counter   bump a tensor's version after a raw-pointer write -> the module's OWN
+#                                             write map (_raw_writes), which every cache key of this module includes anyway
+#   Tensor._base                              recognising the trainers' [j:j+1] loop -> without it the per-call path runs
+# INTERNALS says which fast paths are live; a missing symbol degrades with ONE warning, never an AttributeError.
+_raw_stream_fn = getattr(getattr(torch, "_C", None), "_cuda_getCurrentRawStream", None)
+_set_version_fn = getattr(getattr(getattr(torch, "_C", None), "_autograd", None), "_unsafe_set_version_counter", None)
+INTERNALS = {"raw_stream": _raw_stream_fn is not None, "version_bump": _set_version_fn is not None,
+             "tensor_base": hasattr(torch.Tensor, "_base"), "torch": torch.__version__}
+_warned = set()
+
+
+def _warn_once(what):
+    if what not in _warned:
+        _warned.add(what)
+        import warnings
+        warnings.warn(f"rrl_hip: torch {torch.__version__} lacks {what}; using the public-API fallback (slower, same results)")
+
+
+def _raw_stream(index):
+    """hipStream_t (int) of torch's current stream on device `index`."""
+    if _raw_stream_fn is not None:
+        return _raw_stream_fn(index)
+    _warn_once("torch._C._cuda_getCurrentRawStream")
+    return torch.cuda.current_stream(index).cuda_stream
+
+
 def _stream(dev=None):
     # raw hipStream_t of torch's current stream ON THE DEVICE THE DATA LIVES ON (the Stream object
     # wrapper costs ~15 us per call)
-    return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(
-        dev.index if dev is not None else torch.cuda.current_device()))
+    return ctypes.c_void_p(_raw_stream(dev.index if dev is not None else torch.cuda.current_device()))
 
 
 class _NoGuard:
@@ -122,16 +149,37 @@ def _run(dev, name, *args):
         check(getattr(_lib.load(), name)(*args, _stream(dev)), name)
 
 
+_raw_writes = {}     # data_ptr -> serial of the library's latest raw-pointer write into that buffer
+_raw_serial = [0]    # monotone: a pruned map never repeats a key
+
+
+def _write_key(t):
+    """What this module's caches key a tensor's CONTENT on: (data_ptr, torch's version counter, the library's own
+    raw-write serial of that buffer).  The third part makes the caches independent of the private version-bump hook."""
+    p = t.data_ptr()
+    return (p, t._version, _raw_writes.get(p, 0))
+
+
 def _touched(*tensors):
-    """The library wrote these caller-owned tensors through raw pointers: advance their autograd version counters like
-    an in-place torch op would, so that everything keyed on (data_ptr, _version) -- RegistrationStep's kept target, the
-    drop-in batch cache, autograd's own saved-tensor checks -- sees the change."""
+    """The library wrote these caller-owned tensors through raw pointers: record the write in the module's own map (every
+    cache key of this module -- the steps' kept target, the drop-in batch cache -- includes it, _write_key) and, where
+    torch offers the hook, advance their autograd version counters like an in-place torch op would (autograd's own
+    saved-tensor checks then see the change too)."""
     ts = [t for t in tensors if isinstance(t, torch.Tensor)]
-    if ts:
+    if not ts:
+        return
+    if len(_raw_writes) > 4096:  # bounded; the serial keeps growing, so old keys never come back
+        _raw_writes.clear()
+    for t in ts:
+        _raw_serial[0] += 1
+        _raw_writes[t.data_ptr()] = _raw_serial[0]
+    if _set_version_fn is not None:
         try:
-            torch._C._autograd._unsafe_set_version_counter(ts, [t._version + 1 for t in ts])
-        except (AttributeError, TypeError, RuntimeError):
-            pass  # (older PyTorch: no such hook; the callers' contract then is not to reuse such outputs as kept targets)
+            _set_version_fn(ts, [t._version + 1 for t in ts])
+        except (TypeError, RuntimeError):
+            pass
+    else:
+        _warn_once("torch._C._autograd._unsafe_set_version_counter")
 
 
 def _home(*tensors):
@@ -223,7 +271,7 @@ def _target_ws(target_from, B, N, M, L):
     return _p(tgt.ws)
 
 
-_order_ws = {}  # (B, n, device index) -> scratch of rrl_cloud_order
+_order_ws_bytes = {}  # (B, n) -> scratch bytes of rrl_cloud_order
 
 
 def cloud_order(tri):
@@ -243,13 +291,13 @@ def cloud_order(tri):
     order = torch.zeros(B, (n + 63) // 64 * 64, dtype=torch.int32, device=dev)
     if B == 0 or n == 0:
         return order
-    key = (B, n, dev.index)
-    ws = _order_ws.get(key)
-    if ws is None:
-        if len(_order_ws) > 16:
-            _order_ws.clear()
-        nb = int(_lib.load().rrl_cloud_order_workspace_bytes(B, n))
-        ws = _order_ws[key] = torch.empty(nb, dtype=torch.uint8, device=dev)
+    # scratch per CALL from torch's caching allocator, which is stream-aware: two calls of one shape on two streams /
+    # from two threads never sort in the same memory (a per-shape global buffer did); the call runs once per
+    # cloud, so the allocation is not on any step's path
+    nb = _order_ws_bytes.get((B, n))
+    if nb is None:
+        nb = _order_ws_bytes[(B, n)] = int(_lib.load().rrl_cloud_order_workspace_bytes(B, n))
+    ws = torch.empty(nb, dtype=torch.uint8, device=dev)
     _run(dev, "rrl_cloud_order" if t.shape[-1] == 9 else "rrl_cloud_order_points", _p(t), _p(order), _p(ws), ws.numel(), B, n)
     return order
 
@@ -259,8 +307,17 @@ def _check_order(order, B, n, dev, name):
         return None
     if not (isinstance(order, torch.Tensor) and order.dtype == torch.int32 and order.is_cuda and order.device == dev
             and order.is_contiguous() and tuple(order.shape) == (B, (n + 63) // 64 * 64)):
-        raise ValueError(f"{name} must be the int32 (B, 64 ceil(n / 64)) tensor of ops.cloud_order on the op's GPU")
+        raise ValueError(f"{name} must be the contiguous int32 (B, 64 ceil(n / 64)) = {(B, (n + 63) // 64 * 64)} tensor of "
+                         f"ops.cloud_order on the op's GPU ({dev}); got "
+                         + (f"{order.dtype} {tuple(order.shape)} on {order.device}" if isinstance(order, torch.Tensor) else repr(type(order))))
+    if ORDER_DEBUG and n > 0:  # RRL_ORDER_DEBUG=1: a host-side permutation check (synchronises; debugging only)
+        srt = torch.sort(order[:, :n].to(torch.int64), dim=1).values
+        if not bool((srt == torch.arange(n, device=dev)).all()):
+            raise ValueError(f"{name}: every row's first n entries must be a permutation of [0, n)")
     return order
+
+
+ORDER_DEBUG = os.environ.get("RRL_ORDER_DEBUG", "0") == "1"
 
 
 _REDUCE = {"auto": 0, "single": 1, "tiled": 2, "xchg": 3}
@@ -294,11 +351,11 @@ class ChamferRide:
 
 
 def make_opts(order1=None, order2=None, target_kept=False, reduce_mode=None, deterministic=None, sort_parts=None,
-              scan_variant=None, counters=None, chamfer=None):
+              scan_variant=None, counters=None, chamfer=None, payload=None):
     """include/rrl.h rrl_opts for one call (None = the library default everywhere); the returned object keeps the
     tensors it points at alive (.keep)."""
     if order1 is None and order2 is None and not target_kept and reduce_mode is None and deterministic is None \
-            and sort_parts is None and scan_variant is None and counters is None and chamfer is None:
+            and sort_parts is None and scan_variant is None and counters is None and chamfer is None and payload is None:
         return None
     o = _lib.Opts(flags=_lib.F_TARGET_KEPT if target_kept else 0,
                   reduce_mode=-1 if reduce_mode is None else _REDUCE.get(reduce_mode, reduce_mode),
@@ -309,8 +366,9 @@ def make_opts(order1=None, order2=None, target_kept=False, reduce_mode=None, det
                   order2=order2.data_ptr() if order2 is not None else None,
                   scan_counters=counters.data_ptr() if counters is not None else None,
                   scan_counter_rows=counters.shape[0] if counters is not None else 0,
-                  chamfer=ctypes.addressof(chamfer.c) if chamfer is not None else None)
-    o.keep = (order1, order2, counters, chamfer)
+                  chamfer=ctypes.addressof(chamfer.c) if chamfer is not None else None,
+                  payload=payload.data_ptr() if payload is not None else None)
+    o.keep = (order1, order2, counters, chamfer, payload)
     o.ride = chamfer  # a ChamferRide (or None): the forwards arm it before the call and leave it on the LossState when it rode
     return o
 
@@ -446,7 +504,7 @@ def _lease_state(B, N, M, L, G, dev):
     graph's private pool)."""
     if torch.cuda.is_current_stream_capturing():
         return LossState(B, N, M, L, G, dev)
-    key = (B, N, M, L, G, dev.index, torch._C._cuda_getCurrentRawStream(dev.index))
+    key = (B, N, M, L, G, dev.index, _raw_stream(dev.index))
     lst = _pool.get(key)
     if lst is None:
         lst = _pool[key] = []
@@ -617,6 +675,9 @@ def dropin_batch_clear():
 
 def _serve_from_batch(points1, points2, line, rng, mode, chunk):
     c = _batch_cache[0]
+    if not INTERNALS["tensor_base"]:  # (a torch without Tensor._base: the per-call path serves the loop)
+        _warn_once("Tensor._base")
+        return None
     b1, b2, bl = points1._base, points2._base, line._base
     if b1 is None or b2 is None or bl is None:
         return None
@@ -624,7 +685,7 @@ def _serve_from_batch(points1, points2, line, rng, mode, chunk):
     if c is not None and c.bases[0]() is b1 and c.bases[1]() is b2 and c.bases[2]() is bl:
         # the usual call of a loop: same bases as the cached evaluation -- is it still valid, and which sample is this?
         B, N, M, L, o1, o2, ol = c.geo
-        if c.key == (b1._version, b2._version, bl._version, rng, mode, chunk, grad) and points1.shape == (1, N, 9) \
+        if c.key == (_write_key(b1), _write_key(b2), _write_key(bl), rng, mode, chunk, grad) and points1.shape == (1, N, 9) \
                 and points2.shape == (1, M, 9) and line.shape == (1, L, 6) and points1.is_contiguous() \
                 and points2.is_contiguous() and line.is_contiguous():
             j, r = divmod(points1.storage_offset() - o1, N * 9)
@@ -642,7 +703,7 @@ def _serve_from_batch(points1, points2, line, rng, mode, chunk):
         return None
     c = _BatchEval()
     c.bases = (weakref.ref(b1), weakref.ref(b2), weakref.ref(bl))
-    c.key = (b1._version, b2._version, bl._version, rng, mode, chunk, grad)
+    c.key = (_write_key(b1), _write_key(b2), _write_key(bl), rng, mode, chunk, grad)
     c.geo = (B, N, M, L, b1.storage_offset(), b2.storage_offset(), bl.storage_offset())
     c.loss = _DropinBatch.apply(b1.view(B, N, 9), b2.view(B, M, 9), bl.view(B, L, 6), rng, mode, chunk)  # B outputs
     c.flags = _DropinLoss.flags_all
@@ -681,7 +742,9 @@ def _with_ride(opts, order1, order2, chamfer, B, N, M, dev):
     ride = ChamferRide(B, N, M, dev) if chamfer else None
     if ride is None and order1 is None and order2 is None:
         return None
-    return make_opts(order1=order1, order2=order2, chamfer=ride)
+    # the kernels read an order as int32 [B][64 ceil(n / 64)] on the op's GPU: anything else would be read out of bounds
+    return make_opts(order1=_check_order(order1, B, N, dev, "order1"), order2=_check_order(order2, B, M, dev, "order2"),
+                     chamfer=ride)
 
 
 def intersection_loss(points1, points2, line, rng=(1, 1, 5, 5), pool=False, mode="cull", chunk=0,
@@ -876,12 +939,22 @@ class RegistrationStep:
         if prepared is None:  # default: on (RRL_PREPARED=0 turns the default off: A/B runs of unmodified callers)
             prepared = os.environ.get("RRL_PREPARED", "1") != "0"
         self.prepared = bool(prepared) and mode == "cull" and max(N, M) <= 65536
-        self._kept_key = None  # (data_ptr, version) of the target whose records the workspace holds
+        self._kept_key = None  # _write_key of the target whose records the workspace holds
+        self.keep_target = True  # False: rebuild the target's records in every call (see invalidate_target)
         self.order1 = self.order2 = None
         if self.prepared:
             self.order1 = _check_order(src_order, B, N, dev, "src_order") if src_order is not None else cloud_order(self.src)
             self.order2 = _check_order(tar_order, B, M, dev, "tar_order") if tar_order is not None else cloud_order(self.tar)
         self._set_opts()
+
+    def invalidate_target(self):
+        """Forget the kept target: the next call rebuilds cloud 2's records and tree.  The step notices a changed target by
+        itself through (data_ptr, torch's version counter, the library's own raw-write serial); what it cannot see is a
+        write that bypasses both -- `tar.data.copy_()`, a custom kernel or another raw-pointer library writing into the
+        same buffer -- : call this after such a write, or set `.keep_target = False` to rebuild in every call.  (A hipGraph
+        capture bakes in whichever variant is active at capture time: capture with keep_target = False when the target's
+        CONTENT changes between replays.)"""
+        self._kept_key = None
 
     def _set_opts(self):
         self._opts = make_opts(order1=self.order1, order2=self.order2, **self._extra)
@@ -913,9 +986,9 @@ class RegistrationStep:
                     self.order2 = _check_order(tar_order, B, M, dev, "tar_order") if tar_order is not None else cloud_order(self.tar)
                     self._kept_key = None
                 self._set_opts()
-            key = (self.tar.data_ptr(), self.tar._version)
-            op = self._optr_kept if (key == self._kept_key and target_from is None) else self._optr
-            self._kept_key = key if target_from is None else None  # (a carried-over target is not built here)
+            key = _write_key(self.tar) if (self.keep_target and target_from is None) else None
+            op = self._optr_kept if (key is not None and key == self._kept_key) else self._optr
+            self._kept_key = None  # (set again below, once the call has been issued: a call that raises keeps nothing)
         Rm, tv, ln = _prep(R, "R", None, dev), _prep(t, "t", None, dev), _prep(line, "line", 6, dev)
         if Rm.numel() != B * 9 or tv.numel() != B * 3 or tuple(ln.shape) != (B, L, 6):
             raise ValueError("R (B,3,3), t (B,3), line (B, L, 6) expected")
@@ -939,6 +1012,8 @@ class RegistrationStep:
                       "rrl_registration_forward")
                 check(lib.rrl_registration_backward_ex(_p(self.src), _p(Rm), _p(self.tar), *self._fixed_b, _p(g), *self._tail_b, op, s),
                       "rrl_registration_backward")
+        if self.prepared:
+            self._kept_key = key  # (None for a carried-over target -- it is not built here -- and with keep_target off)
         _IntersectionLoss.last_state = self.st
         if self.ride is not None:  # .chamfer_value: this step's monitor (it rode in the scan's launch, or one launch now)
             _keep_ride(self.st, self.ride)
@@ -959,9 +1034,11 @@ class LossStep:
     gradient to the rounding of the scatter's float atomics.  prepared / src_order / tar_order as RegistrationStep."""
 
     def __init__(self, src_tri, tar_tri, n_lines, rng=(1, 1, 5, 5), transpose_r=True, mode="cull", chunk=0,
-                 prepared=None, src_order=None, tar_order=None, chamfer=False):
+                 prepared=None, src_order=None, tar_order=None, chamfer=False, want_payload=False):
         """chamfer=True: every step also leaves the Chamfer monitor of its clouds in .chamfer_value -- its walk rides in the
-        step's scan launch (ChamferRide), as in RegistrationStep."""
+        step's scan launch (ChamferRide), as in RegistrationStep.
+        want_payload=True: .payload (14,) = [sum of the valid losses, #valid, 0 x 12] after every step -- what a rank
+        contributes to the all-reduce of the scalar loss (rrl_hip.dist; points1.grad stays local)."""
         dev = _home(src_tri, tar_tri)
         self.dev = dev
         self.src = _prep(src_tri, "src_tri", 9, dev)
@@ -984,14 +1061,22 @@ class LossStep:
             prepared = os.environ.get("RRL_PREPARED", "1") != "0"
         self.prepared = bool(prepared) and mode == "cull" and max(N, M) <= 65536
         self._kept_key = None
-        self._opts = self._opts_kept = make_opts(chamfer=self.ride)  # (None without a ride)
+        self.keep_target = True  # see RegistrationStep.invalidate_target
+        # (in the workspace's accumulator field: the step's first launch clears it, as for RegistrationStep)
+        self.payload = self.st.gacc[B * 12:B * 12 + 14] if want_payload else None
+        self._opts = self._opts_kept = make_opts(chamfer=self.ride, payload=self.payload)  # (None without either)
         if self.prepared:
             self.order1 = _check_order(src_order, B, N, dev, "src_order") if src_order is not None else cloud_order(self.src)
             self.order2 = _check_order(tar_order, B, M, dev, "tar_order") if tar_order is not None else cloud_order(self.tar)
-            self._opts = make_opts(order1=self.order1, order2=self.order2, chamfer=self.ride)
-            self._opts_kept = make_opts(order1=self.order1, order2=self.order2, target_kept=True, chamfer=self.ride)
+            self._opts = make_opts(order1=self.order1, order2=self.order2, chamfer=self.ride, payload=self.payload)
+            self._opts_kept = make_opts(order1=self.order1, order2=self.order2, target_kept=True, chamfer=self.ride,
+                                        payload=self.payload)
         self._optr, self._optr_kept = _optr(self._opts), _optr(self._opts_kept)
         self._lib = _lib.load()
+
+    def invalidate_target(self):
+        """As RegistrationStep.invalidate_target: the next call rebuilds the target's records."""
+        self._kept_key = None
 
     def __call__(self, R, t, line, grad_loss=None):
         B, N, M, L = self.dims
@@ -1003,11 +1088,11 @@ class LossStep:
                 or tuple(ln.shape) != (B, L, 6):
             raise ValueError("R (B,3,3) and t (B,3) (or both None), line (B, L, 6) expected")
         g = self.ones if grad_loss is None else _prep(grad_loss, "grad_loss", None, dev)
-        op = self._optr
+        op, key = self._optr, None
         if self.prepared:
-            key = (self.tar.data_ptr(), self.tar._version)
-            op = self._optr_kept if key == self._kept_key else self._optr
-            self._kept_key = key
+            key = _write_key(self.tar) if self.keep_target else None
+            op = self._optr_kept if (key is not None and key == self._kept_key) else self._optr
+            self._kept_key = None  # (set below, once the call has been issued)
         if self.ride is not None:
             self.ride.arm()
         with _guard(dev):
@@ -1015,6 +1100,7 @@ class LossStep:
                                              self.st.nbytes, _p(self.st.loss), _p(g), _p(self.grad), None, B, N, M, L,
                                              self.tr, *self.rng, self.mode, self.chunk, None, op, _stream(dev)),
                   "rrl_loss_step")
+        self._kept_key = key
         _IntersectionLoss.last_state = self.st
         if self.ride is not None:
             _keep_ride(self.st, self.ride)

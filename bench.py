@@ -2,35 +2,35 @@
 """bench.py -- BASELINE.json's metric on MI355X: point-pairs/sec for the intersected-line loss
 fwd+bwd at B=8, N=M=4096 (L=10000 lines, the RPM call-site default), per GPU.
 
-One "step" (the timed one) = the fused training op forward + backward in four launches: triangle
-records at their SORTED positions (rigid apply of the source, thresholds, sphere-tree refit, state
-clearing; the spatial order of each cloud was computed once, outside the timed region: rrl_cloud_order,
-reported as config.prepare_us; the target's records are kept while it does not move) -> tree-culled
-line<->triangle scan of both clouds (K1) -> per-line distances (K2) -> median + Welsch reduce with the
-backward to (dR, dT) and the 14-float shard payload riding in the same launch (K3+K4+K5') -> one
-all-reduce of [loss sum, valid count, sum dR, sum dT] over the ranks.  --cold (and variants.cold_step)
-= round 3's step: records + cell sort + tree of both clouds in every step, five launches.  Inputs are
-resident in HBM before the timed region.  pairs per step = B * L * 3 * (N + M) per GPU (SURVEY.md
-§8d) -- DENSE-EQUIVALENT pairs: the culled scan decides every one of them exactly but evaluates
-~1 %; value = all ranks' pairs / max time over ranks.
+One "step" (the timed one) = SURVEY.md section 8(d)'s definition, exactly: rigid apply of the source
+pseudo-triangles -> S (line<->triangle scan of both clouds) -> P (per-line distances) -> median +
+Welsch reduce -> backward to points1.grad (B, N, 9) -- what code/loss.py:170-232 + autograd delivers --
+issued as ONE C call per step (ops.LossStep -> rrl_loss_step_ex; four launches with prepared orders,
+five cold), followed by one all-reduce of the 14-float shard payload [loss sum, valid count, 0 x 12]
+over the ranks (points1.grad stays local).  Inputs are resident in HBM before the timed
+region.  pairs per step = B * L * 3 * (N + M) per GPU -- DENSE-EQUIVALENT pairs: the culled scan
+decides every one of them exactly but evaluates ~1 %; value = all ranks' pairs / max time over ranks.
 
-Measured in the same run, outside the timed region, and printed in the same JSON line:
-  * `value_8d` / `ms_per_step_8d` (= `variants.points1_grad_direct`): SURVEY §8(d)'s definition -- rigid apply +
-    loss + backward to points1.grad (B, N, 9) -- by direct issue, one C call per step (ops.LossStep ->
-    rrl_loss_step_ex); `variants.points1_grad`: the same through the DROP-IN callables chained by autograd (rigid
-    apply -> loss -> backward to points1.grad and on to (dR, dT)) as a hipGraph replay; `value` itself is the fused
-    training op (config.workload);
-  * `variants.dropin_loop`: the reference trainers' LITERAL pattern (rpm/Train_RPM.py:226-231) --
-    `for j in range(B): loss += cal_loss_intersection_batch_whole_median_pts_lines(1, 1, 5, 5, p1[j:j+1], ...)`
-    then one `.backward()` -- issued eagerly, one host read-back per call as the reference's contract demands;
-  * `roofline`: the DOMINANT KERNEL OF THE TIMED STEP, cull_scan_kernel: its launch time (HIP events on
-    the launch stream), the arithmetic it EXECUTED (in-kernel counters of an instrumented instantiation,
-    rrl_scan_counters) against the non-FMA fp32 VALU peak (`frac`), the issue-side fraction from the
-    committed PMC pass of exactly this build (`issue_frac`), its HBM traffic, and `work_ratio` = dense
-    flops / executed; `roofline.dense_reference` = the strict scan (every pair evaluated: the kernel
-    that performs all 18 counted flops per pair), same run;
-  * `cpu_baseline`: the C/OpenMP port and the reference-equivalent torch-eager formulation on the
-    host cores, on bounded samples of the same workload.
+`config.workload` says whether the step is PREPARED (default: the k-d order of each cloud was computed
+once, outside the timed region -- rrl_cloud_order, config.prepare_us -- as a training loop does per
+dataset item; a target that has not moved keeps its records) or COLD (--cold: records + cell sort +
+tree of both clouds in every step).  Whichever one is timed, the other is measured right after on the
+same inputs and printed at top level (`value_cold` / `ms_per_step_cold`, or `value_prepared` / ...):
+round-over-round comparisons of rounds 1-3 must use the cold number.
+
+Measured in the same run, outside the timed region, in the same JSON line:
+  * `variants.fused_dRdT`: the fused TRAINING op (ops.RegistrationStep: backward straight to (dR, dT),
+    the headline of rounds 3-4); `variants.points1_grad_autograd`: section 8(d) through the drop-in
+    callables chained by autograd (hipGraph replay); `variants.dropin_loop`: the reference trainers'
+    LITERAL per-sample loop (rpm/Train_RPM.py:226-231), eager, one host read-back per call;
+  * `roofline`: the DOMINANT KERNEL OF THE TIMED STEP, cull_scan_kernel: launch time by HIP events on
+    the launch stream (this run) AND rocprof's average of the committed profile of this build
+    (`launch_ms_rocprof`, `frac_rocprof`), the arithmetic it EXECUTED (in-kernel counters) against the
+    non-FMA fp32 VALU peak, issue-side fraction and HBM traffic from the committed PMC pass;
+    `roofline.at_B64` = the same figures at a CHIP-FILLING shape (BASELINE configs[2] as one batch on
+    one GPU); `roofline.dense_reference` = the strict scan (all 18 counted flops per pair);
+  * `cpu_baseline`: the reference-equivalent torch-eager formulation on the host cores (SURVEY 8(d)'s
+    stated baseline), the C/OpenMP port nested as `c_port`; bounded samples of the same workload.
 Weak scaling by default (B = 8 per GPU); --global-batch 64 fixes the total (BASELINE configs[2]).
 
     python bench.py [--gpus N --steps K --warmup W]
@@ -107,11 +107,11 @@ def make_workload(B, N, M, L, rank, dev):
 
 def cpu_baseline(N, M, L, budget_s=12.0, eager_budget_s=8.0):
     """Two CPU legs on bounded samples of the same workload, host cores of this box:
-    (a) oracle/rrl_oracle.c (C, OpenMP over lines): whole samples of N=M, L lines, fwd+bwd, until
-        ~budget_s seconds are spent -- the headline `cpu_baseline` (kind "port");
-    (b) oracle/torch_eager.py: the reference's own op sequence (materialised (L, N, 3, 3)
-        temporaries, per-bucket gathers, autograd backward) in torch CPU ops on a line subset of one
-        sample sized to ~eager_budget_s -- reported inside as `torch_eager`."""
+    (top level) oracle/torch_eager.py: the reference's own op sequence (materialised (L, N, 3, 3)
+        temporaries, per-bucket gathers, autograd backward; code/loss.py:68-232) in torch CPU ops on a line
+        subset of one sample sized to ~eager_budget_s -- SURVEY 8(d)'s stated baseline;
+    (`c_port`) oracle/rrl_oracle.c (C, OpenMP over lines): whole samples of N=M, L lines, fwd+bwd, until
+        ~budget_s seconds are spent."""
     from oracle import rrl_oracle, torch_eager
     from rrl_hip import synth
     rrl_oracle.build()
@@ -126,12 +126,12 @@ def cpu_baseline(N, M, L, budget_s=12.0, eager_budget_s=8.0):
         spent += time.perf_counter() - t0
         done += 1
     pairs = done * L * 3 * (N + M)
-    out = {"value": pairs / spent, "unit": "point-pairs/s", "cores": cores, "kind": "port",
-           "sample": f"{done} evaluation(s) of one N=M={N}, L={L} sample, loss fwd+bwd, oracle/rrl_oracle.c "
-                     f"with OpenMP on {cores} threads, {spent:.1f} s"}
+    c_port = {"value": pairs / spent, "unit": "point-pairs/s", "cores": cores, "kind": "port",
+              "sample": f"{done} evaluation(s) of one N=M={N}, L={L} sample, loss fwd+bwd, oracle/rrl_oracle.c "
+                        f"(fused C restatement) with OpenMP on {cores} threads, {spent:.1f} s"}
     try:
         # torch's intra-op pool degrades badly beyond a few dozen threads on these small per-chunk ops
-        # (gpurun_out/r02b_threads.txt: 256 lines take 0.02 s on 32 threads, 0.2 s on 128, 29 s on 256)
+        # (profiles/r02_torch_eager_threads.txt: 256 lines take 0.02 s on 32 threads, 0.2 s on 128, 29 s on 256)
         eth = min(cores, 32)
         torch.set_num_threads(eth)
         t2 = torch.from_numpy(pr["tar_tri"])
@@ -148,15 +148,78 @@ def cpu_baseline(N, M, L, budget_s=12.0, eager_budget_s=8.0):
         tp, _ = run(probe)
         nl = int(max(probe, min(L, probe * eager_budget_s / max(tp, 1e-3))))
         te, val = run(nl)
-        out["torch_eager"] = {
-            "value": nl * 3 * (N + M) / te, "unit": "point-pairs/s", "cores": eth, "kind": "port",
-            "sample": f"one N=M={N} sample, first {nl} of its {L} lines, loss fwd+bwd by autograd, "
-                      f"oracle/torch_eager.py (the reference's materialising op sequence, code/loss.py:68-232) "
-                      f"with torch.set_num_threads({eth}) (of {cores} host threads), {te:.1f} s",
-            "loss_full_sample_c_port": float(ref["loss"]) if ref["loss"] is not None else None}
+        return {"value": nl * 3 * (N + M) / te, "unit": "point-pairs/s", "cores": eth, "kind": "port",
+                "sample": f"one N=M={N} sample, first {nl} of its {L} lines, loss fwd+bwd by autograd, "
+                          f"oracle/torch_eager.py (the reference's materialising op sequence, code/loss.py:68-232) "
+                          f"with torch.set_num_threads({eth}) (of {cores} host threads), {te:.1f} s",
+                "loss_full_sample_c_port": float(ref["loss"]) if ref["loss"] is not None else None,
+                "c_port": c_port}
     except Exception as exc:  # the C leg stands on its own
-        out["torch_eager"] = {"error": f"{type(exc).__name__}: {exc}"}
+        out = dict(c_port)
+        out["torch_eager_error"] = f"{type(exc).__name__}: {exc}"
+        out["c_port"] = c_port
+        return out
+
+
+def scan_roofline(ops, run_step, B, N, M, L, launches=20, counters=True):
+    """Figures of the culled scan's launch inside `run_step()` (a callable that issues one step directly on the current
+    stream): HIP-event launch time on the launch stream (mean over `launches`, first two dropped), and -- from the
+    instrumented instantiation of the kernel, one extra launch -- the arithmetic it executed."""
+    ops.scan_timing(1)
+    for _ in range(launches):
+        run_step()
+    torch.cuda.synchronize()
+    t = ops.scan_timing_collect()
+    ops.scan_timing(0)
+    ms = float(np.mean(t[2:] if len(t) > 4 else t))
+    out = {"launch_ms": ms, "launches_timed": len(t)}
+    dense_flops = FLOPS_PER_PAIR * B * L * 3 * (N + M)
+    if counters:
+        ops.scan_counters(True)
+        run_step()  # one launch: every wavefront writes its row of counters
+        torch.cuda.synchronize()
+        c = ops.scan_counters(False).cpu().numpy().astype(np.float64)
+        exe = OPS_SPHERE * (c[0] + c[1]) + OPS_EXACT * c[3] + OPS_CAND * c[4] + OPS_FALLBACK * c[7]  # c[2] counts survivors, not tests
+        out.update({
+            "executed_flops": exe, "achieved": exe / (ms * 1e-3) / 1e12,
+            "frac": exe / (ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS,
+            "work_ratio": dense_flops / exe,
+            "dense_equivalent_tflops": dense_flops / (ms * 1e-3) / 1e12,
+            "counters_per_launch": {"sphere_tests_A": c[0], "half_sphere_tests_B": c[1], "halves_passed": c[2],
+                                    "point0_prefilter_tests": c[3], "candidates_resolved": c[4], "wavefronts": c[5],
+                                    "fallback_wavefronts": c[6], "fallback_pairs": c[7]}})
     return out
+
+
+def attach_pmc(roof, B, N, L, mode):
+    """PMC-derived figures (HBM bytes, VALU instructions, rocprof's average duration per launch) -- only when the committed
+    pass (profiles/scan_hbm_traffic.json) was collected for exactly this build."""
+    pmc = None
+    pmc_file = os.path.join(ROOT, "profiles", "scan_hbm_traffic.json")
+    if os.path.exists(pmc_file):
+        rec = json.load(open(pmc_file))
+        ent = rec.get(f"B{B}_N{N}_L{L}_{mode}")
+        if ent and rec.get("csrc_sha") == csrc_sha():
+            pmc = ent
+    roof["traffic"] = pmc.get("bytes") if pmc else None
+    roof["traffic_detail"] = pmc
+    s_ = roof["launch_ms"] * 1e-3
+    if pmc and pmc.get("sq_insts_valu"):
+        roof["issue_frac"] = pmc["sq_insts_valu"] * 64 / s_ / 1e12 / VALU_PEAK_TFLOPS
+        roof["pmc"] = {k: pmc[k] for k in pmc if k.startswith("sq_") or k == "rocprof_avg_us"}
+    else:
+        roof["issue_frac"] = None
+    # the same fraction against rocprof's own average duration of the kernel (the HIP-event figure brackets the launch on
+    # the stream: it includes the launch's start-up; rocprof times the kernel's execution)
+    avg_us = pmc.get("rocprof_avg_us") if pmc else None
+    roof["launch_ms_rocprof"] = avg_us * 1e-3 if avg_us else None
+    if avg_us and roof.get("executed_flops"):
+        roof["frac_rocprof"] = roof["executed_flops"] / (avg_us * 1e-6) / 1e12 / VALU_PEAK_TFLOPS
+        if pmc.get("sq_insts_valu"):
+            roof["issue_frac_rocprof"] = pmc["sq_insts_valu"] * 64 / (avg_us * 1e-6) / 1e12 / VALU_PEAK_TFLOPS
+    else:
+        roof["frac_rocprof"] = None
+    return roof
 
 
 def main():
@@ -166,7 +229,7 @@ def main():
     os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300)  # 80 us each: the closing fence costs ~3 us/step at 30
+    ap.add_argument("--steps", type=int, default=300)  # ~65 us each: the closing fence costs ~3 us/step at 30
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=8, help="samples per GPU (weak scaling)")
     ap.add_argument("--global-batch", type=int, default=0,
@@ -176,20 +239,21 @@ def main():
     ap.add_argument("--mode", default=os.environ.get("RRL_SCAN_MODE", "cull"))
     ap.add_argument("--reducer", default=os.environ.get("RRL_REDUCER", "auto"),
                     choices=["auto", "inline", "overlap", "torch"],
-                    help="all-reduce of the shard payload: a node of the captured step (inline), overlapped "
+                    help="all-reduce of the shard payload: a node of the step's stream (inline), overlapped "
                          "with the next step on a second stream (overlap), torch.distributed (torch); auto "
                          "measures inline vs overlap during warm-up when there is more than one rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--no-graph", action="store_true", help="never replay a hipGraph")
     ap.add_argument("--issue", choices=["auto", "graph", "direct"], default="auto",
-                    help="how the step's launches are issued: one hipGraph replay, or the C call of "
-                         "ops.RegistrationStep on the stream (no autograd, no graph); auto measures both in warm-up")
-    ap.add_argument("--no-extras", action="store_true", help="skip the strict / counter / drop-in passes")
+                    help="how the step's launches are issued: the C call of ops.LossStep on the stream (direct), or one "
+                         "hipGraph replay of it; auto measures both in warm-up")
+    ap.add_argument("--no-extras", action="store_true", help="skip the variant / strict / counter / B=64 passes")
+    ap.add_argument("--no-b64", action="store_true", help="skip roofline.at_B64 (64 synthetic pairs take ~20 s to make)")
     ap.add_argument("--cold", action="store_true",
-                    help="no prepared orders: every step sorts both clouds (records + cell sort + tree), the round-3 step")
+                    help="time the COLD step: no prepared orders, every step sorts both clouds (records + cell sort + tree)")
     ap.add_argument("--no-dist", action="store_true",
                     help="single process without a process group (default: even a plain 1-GPU run creates a 1-rank "
-                         "RCCL group, so that the timed step carries the same in-graph all-reduce as N > 1)")
+                         "RCCL group, so that the timed step carries the same all-reduce as N > 1)")
     args = ap.parse_args()
     if "RANK" not in os.environ and not args.no_dist and args.gpus == 1:
         # not under torchrun: a standalone 1-rank group on a free local port
@@ -222,15 +286,16 @@ def main():
         B = args.batch
     N, M, L = args.points, args.points, args.lines
     w = make_workload(B, N, M, L, rank, dev)
+    Rd, Td = w["R"].detach(), w["T"].detach()
     ones = torch.ones(B, device=dev)
     # Prepared clouds (include/rrl.h rrl_cloud_order): the spatial order of each cloud is computed ONCE, outside the
     # timed region -- as a training loop does per dataset item and the demo at its start (the reference's callers move
     # the same source against a fixed target, rpm/Train_RPM.py:207-231) -- and every step runs the prepared build.
-    # --cold: no orders, records + cell sort in every step (reported beside it as variants.cold_step).
-    prepared = args.mode == "cull" and not args.cold
+    can_prepare = args.mode == "cull"
+    prepared = can_prepare and not args.cold
     order1 = order2 = None
     prepare_us = None
-    if prepared:
+    if can_prepare:
         ops.cloud_order(w["tri1"])  # (first call: scratch allocation, code load)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -239,14 +304,17 @@ def main():
         torch.cuda.synchronize()
         prepare_us = (time.perf_counter() - t0) / 5 / 2 * 1e6  # per call = per B clouds of N triangles
 
-    def local_step(mode=args.mode):
-        # transform + loss forward, backward to (dR, dt), and the 14-float shard payload
-        w["R"].grad = w["T"].grad = None
-        loss, info, _ = ops.registration_loss(w["tri1"], w["R"], w["T"], w["tri2"], w["lines"],
-                                              (1, 1, 5, 5), transpose_r=True, mode=mode,
-                                              want_payload=True, order1=order1, order2=order2)
-        torch.autograd.backward([loss], [ones])  # d(sum of losses): no reduction kernel needed
-        return ops.last_state().payload
+    def loss_step(prep):
+        """SURVEY 8(d) by direct issue: ops.LossStep (rigid apply + loss + backward to points1.grad, one C call) with the
+        shard payload [loss sum, valid count, 0 x 12] in its workspace."""
+        return ops.LossStep(w["tri1"], w["tri2"], L, transpose_r=True, mode=args.mode, prepared=prep,
+                            src_order=order1 if prep else None, tar_order=order2 if prep else None, want_payload=True)
+
+    ls = loss_step(prepared)
+
+    def direct_step():
+        ls(Rd, Td, w["lines"])
+        return ls.payload
 
     from rrl_hip import rccl as rrccl
     if args.reducer == "torch":
@@ -258,21 +326,11 @@ def main():
 
     from rrl_hip.graph import GraphedStep
 
-    rstep = [None]
-
-    def direct_step():
-        # the same launches as local_step, issued by one C call on preallocated buffers (ops.RegistrationStep -> rrl_registration_step)
-        if rstep[0] is None:
-            rstep[0] = ops.RegistrationStep(w["tri1"], w["tri2"], L, transpose_r=True, mode=args.mode, want_payload=True,
-                                            prepared=prepared, src_order=order1, tar_order=order2)
-            rstep[0].Rd, rstep[0].Td = w["R"].detach(), w["T"].detach()
-        return rstep[0](rstep[0].Rd, rstep[0].Td, w["lines"])[3]
-
-    def build(inline, issue="graph"):
-        """(callable step, finish) for one all-reduce placement; capture success is agreed on by
-        all ranks, so nobody replays a graph with a collective the others do not have."""
+    def build(inline, issue):
+        """(graph or None, callable step, finish) for one all-reduce placement and one way of issuing; capture success is
+        agreed on by all ranks, so nobody replays a graph with a collective the others do not have."""
+        last = [None]
         if issue == "direct":
-            last = [None]
             if inline:
                 def step():
                     last[0] = reducer.allreduce_inline(direct_step())
@@ -282,25 +340,21 @@ def main():
                 reducer.submit(direct_step())
             return None, step, reducer.finish
         g, err = None, None
-        if not args.no_graph:
-            try:
-                g = GraphedStep((lambda: reducer.allreduce_inline(local_step())) if inline else local_step)
-            except Exception as exc:
-                err = exc
-            if not rrccl.agree(g is not None, dev):
-                if rank == 0:
-                    print(f"[bench] graph capture failed on some rank ({err}); eager launches", file=sys.stderr)
-                g = None
-                if inline:
-                    return None
-        last = [None]
+        try:
+            g = GraphedStep((lambda: reducer.allreduce_inline(direct_step())) if inline else direct_step)
+        except Exception as exc:
+            err = exc
+        if not rrccl.agree(g is not None, dev):
+            if rank == 0:
+                print(f"[bench] graph capture failed on some rank ({err}); direct issue only", file=sys.stderr)
+            return None
         if inline:
             def step():
-                last[0] = g() if g is not None else reducer.allreduce_inline(local_step())
+                last[0] = g()
             return g, step, (lambda: last[0])
 
         def step():
-            reducer.submit(g() if g is not None else local_step())
+            reducer.submit(g())
         return g, step, reducer.finish
 
     def fence():
@@ -316,10 +370,11 @@ def main():
             step()
         return t0
 
-    # ---- choose the all-reduce placement (identically on every rank)
+    # ---- choose how the step is issued and where the all-reduce sits (identically on every rank)
     choice_note = None
     cands = []
-    issues = ["graph", "direct"] if args.issue == "auto" and not args.no_graph else [args.issue if args.issue != "auto" else "graph"]
+    issues = ["direct", "graph"] if args.issue == "auto" and not args.no_graph else \
+        [args.issue if args.issue != "auto" else "direct"]
     for issue in issues:
         have = False
         if direct and args.reducer in ("auto", "inline"):
@@ -328,8 +383,12 @@ def main():
                 cands.append(("inline/" + issue, c))
                 have = True
         if args.reducer in ("overlap", "torch") or (args.reducer == "auto" and world > 1) or not have:
-            cands.append(("overlap/" + issue, build(False, issue)))
-    if len(cands) > 1:  # measure both during warm-up; max over ranks -> the same decision everywhere
+            c = build(False, issue)
+            if c is not None:
+                cands.append(("overlap/" + issue, c))
+    if not cands:
+        raise SystemExit("no way to issue the step (graph capture failed and --issue graph was forced)")
+    if len(cands) > 1:  # measure all during warm-up; max over ranks -> the same decision everywhere
         probe = {}
         for trial in range(3):  # the smallest of three short trials per candidate: one host hiccup during a 1 ms probe
             for name, (g, step, finish) in cands:  # must not decide how the timed region is issued
@@ -362,60 +421,69 @@ def main():
     dt = float(tmax.item())
     payload = payload.clone()
 
-    # ---- everything below is outside the timed region -----------------------------------------
-    def scan_launch_ms(mode, n):
-        """HIP events around the scan launch, on the launch stream: of the TIMED step itself when it is issued directly
-        (ops.RegistrationStep: the events bracket the same launch the clock sees), else of an eager pass of the same
-        step (events cannot be read back from inside a replayed graph)."""
-        ops.scan_timing(1)
-        own = issued == "direct" and mode == args.mode
-        for _ in range(n):
-            direct_step() if own else local_step(mode)
+    # ---- everything below is outside the timed region (rank 0 only, no collectives: the other ranks wait at the end)
+    def time_loop(fn, n, warm=10):
+        for _ in range(warm):
+            out = fn()
         torch.cuda.synchronize()
-        t = ops.scan_timing_collect()
-        ops.scan_timing(0)
-        return float(np.mean(t[2:] if len(t) > 4 else t)), len(t)
+        t1 = time.perf_counter()
+        for _ in range(n):
+            out = fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t1) / n * 1e3, out
 
-    extras, variants, roof_default, roof_dense = {}, {}, None, None
+    extras, variants, roofline = {}, {}, None
     pairs_step = B * L * 3 * (N + M)
     dense_flops = FLOPS_PER_PAIR * pairs_step
-    do_extras = rank == 0 and not args.no_extras  # no collectives below: the other ranks wait at the end
+    do_extras = rank == 0 and not args.no_extras
+    other = None
     if rank == 0:
-        cull_ms, n_cull = scan_launch_ms(args.mode, min(args.steps, 20))
-        loss_default = ops.last_state().loss.clone()
+        loss_default = ls.st.loss.clone()
+        grad_default = ls.grad.clone()
+        # the OTHER build of the same step, always measured (round-over-round comparisons use the cold number): this rank's
+        # step without the all-reduce
+        if can_prepare:
+            lo_ = loss_step(not prepared)
+            oms, oout = time_loop(lambda: lo_(Rd, Td, w["lines"]), args.steps)
+            other = {"ms_per_step": oms, "value": pairs_step / (oms * 1e-3), "unit": "point-pairs/s (this rank, no all-reduce)",
+                     "loss_bit_identical_to_timed_step": bool(torch.equal(oout[0], loss_default)),
+                     "what": ("the section-8(d) step with NO prepared order: records + cell sort + sphere tree of both clouds in "
+                              "every step (ops.LossStep(prepared=False), one C call, 5 launches) -- what a loop pays whose clouds "
+                              "are new in every step; rounds 1-3 timed this build") if prepared else
+                             "the section-8(d) step with prepared orders (ops.LossStep, 4 launches)"}
+            variants["loss_step_cold" if prepared else "loss_step_prepared"] = other
+            del lo_
+        roofline = scan_roofline(ops, lambda: ls(Rd, Td, w["lines"]), B, N, M, L, launches=min(args.steps, 20),
+                                 counters=do_extras and args.mode == "cull")
     if do_extras:
-        local_step(args.mode)  # the autograd front end of the same op: its dR is what the variants below compare with
-        fused_gR = w["R"].grad.clone()
-    if do_extras and args.mode == "cull":
-        # executed work of the culled kernel: the instrumented instantiation, same inputs, same (prepared) build
-        ops.scan_counters(True)
-        (direct_step if issued == "direct" else local_step)()  # one launch: every wavefront writes its row of counters
-        torch.cuda.synchronize()
-        c = ops.scan_counters(False).cpu().numpy().astype(np.float64)
-        exe = OPS_SPHERE * (c[0] + c[1]) + OPS_EXACT * c[3] + OPS_CAND * c[4] + OPS_FALLBACK * c[7]  # c[2] counts survivors, not tests
-        roof_default = {
-            "kernel": "cull_scan_kernel (scan mode cull: the dominant kernel of the timed step)",
-            "launch_ms": cull_ms, "launches_timed": n_cull,
-            "executed_flops": exe, "executed_tflops": exe / (cull_ms * 1e-3) / 1e12,
-            "executed_frac": exe / (cull_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS,
-            "work_ratio": dense_flops / exe,
-            "dense_equivalent_tflops": dense_flops / (cull_ms * 1e-3) / 1e12,
-            "counters_per_launch": {"sphere_tests_A": c[0], "half_sphere_tests_B": c[1], "halves_passed": c[2],
-                                    "point0_prefilter_tests": c[3], "candidates_resolved": c[4], "wavefronts": c[5],
-                                    "fallback_wavefronts": c[6], "fallback_pairs": c[7]},
-            "ops_per_test": {"sphere": OPS_SPHERE, "point0_prefilter": OPS_EXACT, "candidate": OPS_CAND,
-                             "fallback_pair": OPS_FALLBACK},
-            "note": "executed = arithmetic of the tests the kernel really ran, from in-kernel counters of this run "
-                    "(rrl_scan_counters: one row per wavefront, plain stores; queue/ballot/bookkeeping instructions not counted: SQ_INSTS_VALU x 64 in "
-                    "profiles/ is the issue-side figure).  work_ratio = dense flops / executed flops."}
-    if do_extras:
-        # the kernel that performs ALL counted flops: the strict scan of the same step
-        strict_ms, n_strict = scan_launch_ms("strict", 20)
-        same = bool(torch.equal(ops.last_state().loss, loss_default))
-        roof_dense = {"launch_ms": strict_ms, "launches_timed": n_strict, "loss_bit_identical_to_default_mode": same}
+        # ---- the fused TRAINING op (rounds 3-4's headline): backward straight to (dR, dT), 14-float payload with the sums
+        rs = ops.RegistrationStep(w["tri1"], w["tri2"], L, transpose_r=True, mode=args.mode, want_payload=True,
+                                  prepared=prepared, src_order=order1 if prepared else None,
+                                  tar_order=order2 if prepared else None)
+        fms, fout = time_loop(lambda: rs(Rd, Td, w["lines"]), args.steps)
+        fused_gR = fout[1].clone()
+        variants["fused_dRdT"] = {
+            "ms_per_step": fms, "value": pairs_step / (fms * 1e-3), "unit": "point-pairs/s (this rank, no all-reduce)",
+            "what": "ops.RegistrationStep -> rrl_registration_step: rigid apply + loss + backward straight to (dR, dT) "
+                    "(no points1.grad), one C call per step -- what a trainer whose pose comes out of a network needs",
+            "loss_bit_identical_to_timed_step": bool(torch.equal(fout[0], loss_default))}
+        del rs
 
-        # SURVEY §8(d) through the drop-in callables: T-apply -> loss -> backward to points1.grad
-        # (and on through the rigid apply to dR, dT), chained by autograd
+        # ---- the kernel that performs ALL counted flops: the strict scan of the same step
+        lstrict = ops.LossStep(w["tri1"], w["tri2"], L, transpose_r=True, mode="strict")
+        sroof = scan_roofline(ops, lambda: lstrict(Rd, Td, w["lines"]), B, N, M, L, launches=20, counters=False)
+        same = bool(torch.equal(lstrict.st.loss, loss_default))
+        s_ = sroof["launch_ms"] * 1e-3
+        roofline["dense_reference"] = {
+            "kernel": "scan_kernel<v2f,2> (scan mode strict: every (line, point) pair evaluated -- the kernel that performs "
+                      "all 18 counted flops per pair; NOT part of the timed step; HIP events on the launch stream, this run)",
+            "achieved": dense_flops / s_ / 1e12, "frac": dense_flops / s_ / 1e12 / VALU_PEAK_TFLOPS,
+            "launch_ms": sroof["launch_ms"], "launches_timed": sroof["launches_timed"],
+            "algorithmic_flops_per_launch": dense_flops, "loss_bit_identical_to_default_mode": same}
+        del lstrict
+
+        # ---- SURVEY 8(d) through the drop-in callables: T-apply -> loss -> backward to points1.grad (and on through the
+        # rigid apply to dR, dT), chained by autograd
         keep = {}
 
         def dropin_step():
@@ -423,7 +491,7 @@ def main():
             tri1 = ops.rigid_apply(w["tri1"].reshape(B, 3 * N, 3), w["R"], w["T"], transpose_r=True).reshape(B, N, 9)
             tri1.retain_grad()
             loss, info, _ = ops.intersection_loss(tri1, w["tri2"], w["lines"], (1, 1, 5, 5), mode=args.mode,
-                                                  order1=order1, order2=order2)
+                                                  order1=order1 if prepared else None, order2=order2 if prepared else None)
             torch.autograd.backward([loss], [ones])
             keep["g"], keep["loss"] = tri1.grad, loss
             return tri1.grad
@@ -432,46 +500,21 @@ def main():
         except Exception as exc:
             print(f"[bench] drop-in capture failed ({type(exc).__name__}: {exc}); eager", file=sys.stderr)
             gd = dropin_step
-        for _ in range(min(args.warmup, 10)):
-            gd()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            gd()
-        torch.cuda.synchronize()
-        dms = (time.perf_counter() - t1) / args.steps * 1e3
+        dms, _ = time_loop(gd, args.steps)
         g1 = keep["g"]
-        variants["points1_grad"] = {
+        variants["points1_grad_autograd"] = {
             "ms_per_step": dms, "value": pairs_step / (dms * 1e-3), "unit": "point-pairs/s (this rank)",
             "what": "ops.rigid_apply -> ops.intersection_loss (what loss.cal_loss_intersection_batch_whole_median_"
                     "pts_lines calls) -> backward to points1.grad (B,N,9), then rigid-apply backward to dR, dT; "
                     + ("hipGraph replay" if gd is not dropin_step else "eager launches"),
             "points1_grad_nonzero_rows": int((g1.abs().sum(-1) > 0).sum()),
             "loss_sum": float(keep["loss"].sum()),
+            "loss_bit_identical_to_timed_step": bool(torch.equal(keep["loss"].detach(), loss_default)),
+            "points1_grad_max_rel_diff_vs_timed_step": float((grad_default - g1).abs().max() / g1.abs().max()),
             "dR_max_rel_diff_vs_fused": float((w["R"].grad - fused_gR).abs().max() / fused_gR.abs().max())}
+        extras["points1_grad_nonzero_rows"] = int((grad_default.abs().sum(-1) > 0).sum())
 
-        # SURVEY 8(d) by DIRECT ISSUE: rigid apply + S + P + median + Welsch + backward to points1.grad (B, N, 9) as one C
-        # call per step (ops.LossStep -> rrl_loss_step_ex: the scatter rides in the reduce's launch), no autograd, no graph
-        ls = ops.LossStep(w["tri1"], w["tri2"], L, transpose_r=True, mode=args.mode, prepared=prepared,
-                          src_order=order1, tar_order=order2)
-        Rd, Td = w["R"].detach(), w["T"].detach()
-        for _ in range(10):
-            lout = ls(Rd, Td, w["lines"])
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            lout = ls(Rd, Td, w["lines"])
-        torch.cuda.synchronize()
-        lms = (time.perf_counter() - t1) / args.steps * 1e3
-        variants["points1_grad_direct"] = {
-            "ms_per_step": lms, "value": pairs_step / (lms * 1e-3), "unit": "point-pairs/s (this rank)",
-            "what": "SURVEY 8(d) as defined: rigid apply of the source + loss forward + backward to points1.grad (B,N,9), "
-                    "ONE C call per step (ops.LossStep -> rrl_loss_step_ex; 4 launches with prepared orders), direct issue",
-            "loss_bit_identical_to_fused_op": bool(torch.equal(lout[0], loss_default)),
-            "points1_grad_nonzero_rows": int((lout[1].abs().sum(-1) > 0).sum()),
-            "points1_grad_max_rel_diff_vs_autograd_chain": float((lout[1] - g1).abs().max() / g1.abs().max())}
-
-        # the reference trainers' literal call pattern (rpm/Train_RPM.py:204-231, dcp/Train_DCP.py:266-270,
+        # ---- the reference trainers' literal call pattern (rpm/Train_RPM.py:204-231, dcp/Train_DCP.py:266-270,
         # fmr/model.py:302-306): transform once, then one reference-signature call per sample, summed in Python,
         # one backward.  Eager by nature: every call reads its flags back (None / NaN are host-side decisions).
         def loop_step():
@@ -485,15 +528,7 @@ def main():
                     total = total + one
             total.backward()
             return total
-        for _ in range(5):
-            tot = loop_step()
-        torch.cuda.synchronize()
-        nloop = max(10, min(args.steps, 50))
-        t1 = time.perf_counter()
-        for _ in range(nloop):
-            tot = loop_step()
-        torch.cuda.synchronize()
-        lms = (time.perf_counter() - t1) / nloop * 1e3
+        lms, tot = time_loop(loop_step, max(10, min(args.steps, 50)), warm=5)
         variants["dropin_loop"] = {
             "ms_per_step": lms, "ms_per_call": lms / B, "value": pairs_step / (lms * 1e-3),
             "unit": "point-pairs/s (this rank)",
@@ -503,40 +538,14 @@ def main():
             "loss_sum": float(tot.detach().sum()),
             "dR_max_rel_diff_vs_fused": float((w["R"].grad - fused_gR).abs().max() / fused_gR.abs().max())}
 
-        # the same step WITHOUT prepared orders (round 3's step: records + cell sort + tree in every step), direct issue
-        if prepared:
-            cs = ops.RegistrationStep(w["tri1"], w["tri2"], L, transpose_r=True, mode=args.mode, want_payload=True, prepared=False)
-            Rd, Td = w["R"].detach(), w["T"].detach()
-            for _ in range(10):
-                cs(Rd, Td, w["lines"])
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(args.steps):
-                cout = cs(Rd, Td, w["lines"])
-            torch.cuda.synchronize()
-            cms = (time.perf_counter() - t1) / args.steps * 1e3
-            variants["cold_step"] = {
-                "ms_per_step": cms, "value": pairs_step / (cms * 1e-3), "unit": "point-pairs/s (this rank)",
-                "what": "the fused step with NO prepared order: records + cell sort + sphere tree of both clouds in every step "
-                        "(ops.RegistrationStep(prepared=False), one C call per step, no all-reduce); what a loop pays whose "
-                        "clouds are new in every step",
-                "loss_bit_identical_to_prepared": bool(torch.equal(cout[0], loss_default))}
-
-        # Chamfer monitor (every caller evaluates it next to the loss): device time per call, hipGraph replay
+        # ---- Chamfer monitor (every caller evaluates it next to the loss): device time per call
         def time_call(fn, n=50):
-            """ms per call of fn, issued eagerly and as a hipGraph replay (a replay has ~8 us of fixed cost on this
-            stack, tools/graph_node_cost.py): (best, how, last result)"""
+            """ms per call of fn, issued eagerly and as a hipGraph replay: (best, how, last result, both)"""
             out = {}
             for how in (["eager"] if args.no_graph else ["eager", "graph"]):
                 gc = GraphedStep(fn) if how == "graph" else fn
-                for _ in range(5):
-                    gc()
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                for _ in range(n):
-                    res = gc()
-                torch.cuda.synchronize()
-                out[how] = ((time.perf_counter() - t1) / n * 1e3, res)
+                ms, res = time_loop(gc, n, warm=5)
+                out[how] = (ms, res)
             how = min(out, key=lambda k: out[k][0])
             return out[how][0], how, out[how][1], {k: round(v[0], 5) for k, v in out.items()}
 
@@ -549,8 +558,7 @@ def main():
                 ops.CHAMFER_TREE = True
         cms, cd, chow, cboth = chamfer_ms(True)
         bms, cdb, _, _ = chamfer_ms(False)
-        # with PREPARED point clouds (the orders of the loss's clouds serve their first points): no sort in the call
-        if prepared:
+        if prepared:  # with PREPARED point clouds (the orders of the loss's clouds serve their first points): no sort in the call
             pms, phow, pcd, pboth = time_call(lambda: ops.chamfer(w["src"], w["tar"], order_x=order1, order_y=order2))
             extras.update({"chamfer_prepared_ms": pms, "chamfer_prepared_issue": phow, "chamfer_prepared_ms_by_issue": pboth,
                            "chamfer_prepared_equals_chamfer": float(pcd) == cd})
@@ -559,115 +567,95 @@ def main():
                        "chamfer_brute_force_ms": bms, "chamfer_values_equal": cd == cdb,
                        "chamfer_note": "both directions, B x N x M dense-equivalent pairs; sorted clouds + sphere tree "
                                        "(rrl_chamfer.hip) vs the all-pairs kernel"})
-        # the monitor NEXT TO a loss evaluation: the loss workspace already holds both clouds sorted under
-        # their sphere trees (the triangles' first points are the points), so the walk needs no second sort
-        st0 = ops.loss_forward_raw(w["tri1"], w["tri2"], w["lines"], mode=args.mode)
-        fms, fhow, cfs, fboth = time_call(lambda: ops.chamfer_from_state(st0))
-        want = float(ops.chamfer(w["tri1"][..., :3].contiguous(), w["tri2"][..., :3].contiguous()))
-        extras.update({"chamfer_from_loss_state_ms": fms, "chamfer_from_loss_state_issue": fhow,
-                       "chamfer_from_loss_state_ms_by_issue": fboth, "chamfer_from_loss_state": float(cfs),
-                       "chamfer_from_loss_state_equals_chamfer_of_first_points": float(cfs) == want})
-        # ... and INSIDE the step (round 4b): the walk needs the step's records launch only, and launches of one stream never
-        # overlap on this stack, so ops.ChamferRide issues its workgroups in the culled scan's grid -- the timed step with the
-        # trainers' monitor, per step: a launch of its own behind the step against riding in the scan's launch
+        # the monitor INSIDE the step: the walk needs the step's records launch only, and launches of one stream never
+        # overlap on this stack, so ops.ChamferRide issues its workgroups in the culled scan's grid
         if prepared and args.mode == "cull":
-            Rd, Td = w["R"].detach(), w["T"].detach()
             ride_ms = {}
             for name, kw in (("step_then_chamfer_from_state", {}), ("step_with_the_walk_riding", {"chamfer": True})):
-                rs = ops.RegistrationStep(w["tri1"], w["tri2"], L, transpose_r=True, mode=args.mode, src_order=order1,
-                                          tar_order=order2, **kw)
+                rs = ops.LossStep(w["tri1"], w["tri2"], L, transpose_r=True, mode=args.mode, src_order=order1,
+                                  tar_order=order2, **kw)
 
                 def monitored():
                     rs(Rd, Td, w["lines"])
                     return rs.chamfer_value if kw else ops.chamfer_from_state(rs.st)
-                for _ in range(10):
-                    cv = monitored()
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                for _ in range(args.steps):
-                    cv = monitored()
-                torch.cuda.synchronize()
-                ride_ms[name] = (time.perf_counter() - t1) / args.steps * 1e3
+                ride_ms[name], cv = time_loop(monitored, args.steps)
                 ride_ms[name + "_value"] = float(cv)
             extras["step_with_chamfer_monitor_ms"] = ride_ms
+
+        # ---- a CHIP-FILLING shape: BASELINE configs[2] (B = 64) as one batch on this GPU -- separates the kernel's quality
+        # from "B = 8 fills under half of the 256 CUs"
+        if not args.no_b64 and args.mode == "cull" and B < 64:
+            B64 = 64
+            w64 = make_workload(B64, N, M, L, 7 + rank, dev)
+            o1, o2 = ops.cloud_order(w64["tri1"]), ops.cloud_order(w64["tri2"])
+            l64 = ops.LossStep(w64["tri1"], w64["tri2"], L, transpose_r=True, mode=args.mode, src_order=o1, tar_order=o2)
+            R64, T64 = w64["R"].detach(), w64["T"].detach()
+            ms64, out64 = time_loop(lambda: l64(R64, T64, w64["lines"]), max(20, args.steps // 4))
+            r64 = scan_roofline(ops, lambda: l64(R64, T64, w64["lines"]), B64, N, M, L, launches=20)
+            r64 = attach_pmc(r64, B64, N, L, args.mode)
+            r64.update({"workload": f"B={B64} on ONE GPU, N=M={N}, L={L} (BASELINE configs[2] as one batch), the same section-8(d) "
+                                    "step, prepared orders, direct issue, no all-reduce",
+                        "ms_per_step": ms64, "value": B64 * L * 3 * (N + M) / (ms64 * 1e-3), "unit_value": "point-pairs/s",
+                        "ms_per_8_samples": ms64 / (B64 / 8), "valid_samples": int((out64[2][:, 0] > 0).sum()),
+                        "scan_share_of_step": r64["launch_ms"] / ms64})
+            roofline["at_B64"] = r64
+            del l64, w64
 
     if rank == 0:
         value = sum_pairs(world, B, args, L, N, M) * args.steps / dt
         alg_bytes = B * (N + M) * 48 + B * L * 24 + 2 * B * L * 4  # ptri + lines + counts
-        # PMC-derived figures (HBM bytes, VALU instructions per launch) -- only when collected for exactly this build
-        pmc = None
-        pmc_file = os.path.join(ROOT, "profiles", "scan_hbm_traffic.json")
-        if os.path.exists(pmc_file):
-            rec = json.load(open(pmc_file))
-            ent = rec.get(f"B{B}_N{N}_L{L}_{args.mode}")
-            if ent and rec.get("csrc_sha") == csrc_sha():
-                pmc = ent
+        cull_ms = roofline["launch_ms"]
         cull_s = cull_ms * 1e-3
-        roofline = {
+        if "frac" not in roofline:
+            if args.mode != "cull":  # a dense mode was asked for: the timed kernel does evaluate every pair
+                roofline.update({"achieved": dense_flops / cull_s / 1e12, "frac": dense_flops / cull_s / 1e12 / VALU_PEAK_TFLOPS})
+            else:
+                roofline.update({"achieved": None, "frac": None})
+        attach_pmc(roofline, B, N, L, args.mode)
+        roofline.update({
             "bound": "valu",
             "note": "fp32 VALU / latency-bound, not HBM- or MFMA-bound (no FMA allowed where labels are decided; O(L (N+M)) "
                     "elementwise geometry).  peak = 157.3 / 2 TFLOP/s (one flop per lane-op: 256 CU x 4 SIMD-32 x 2.4 GHz).  "
-                    "achieved / frac = arithmetic the kernel EXECUTED (in-kernel counters, this run) / its launch time "
-                    "(HIP events on the launch stream, this run); issue_frac = SQ_INSTS_VALU x 64 of the committed PMC pass "
-                    "of exactly this build / the same launch time; the dense work this kernel decides (18 flops per pair) "
-                    "is work_ratio x executed.",
+                    "achieved / frac = arithmetic the kernel EXECUTED (in-kernel counters, this run: sphere tests x 12 + "
+                    "point-0 prefilter x 11 + resolved candidates x 48 lane-ops; queue / ballot / bookkeeping instructions not "
+                    "counted) / its launch time by HIP events on the launch stream (this run); frac_rocprof = the same / "
+                    "rocprof's average kernel duration of the committed profile of exactly this build; issue_frac = "
+                    "SQ_INSTS_VALU x 64 of the committed PMC pass / launch time; the dense work this kernel decides "
+                    "(18 flops per pair) is work_ratio x executed.",
             "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
             "kernel": "cull_scan_kernel<false> (scan mode cull: the dominant kernel of the timed step)" if args.mode == "cull"
                       else f"scan_kernel (scan mode {args.mode})",
-            "launch_ms": cull_ms, "launches_timed": n_cull,
-            "traffic": pmc.get("bytes") if pmc else None, "traffic_detail": pmc,
+            "ops_per_test": {"sphere": OPS_SPHERE, "point0_prefilter": OPS_EXACT, "candidate": OPS_CAND,
+                             "fallback_pair": OPS_FALLBACK},
             "csrc_sha": csrc_sha(),
-        }
-        if roof_default is not None:
-            roofline.update({"achieved": roof_default["executed_tflops"], "frac": roof_default["executed_frac"],
-                             "executed_flops": roof_default["executed_flops"], "work_ratio": roof_default["work_ratio"],
-                             "dense_equivalent_tflops": roof_default["dense_equivalent_tflops"],
-                             "counters_per_launch": roof_default["counters_per_launch"],
-                             "ops_per_test": roof_default["ops_per_test"]})
-        elif args.mode != "cull":  # a dense mode was asked for: the timed kernel does evaluate every pair
-            roofline.update({"achieved": dense_flops / cull_s / 1e12, "frac": dense_flops / cull_s / 1e12 / VALU_PEAK_TFLOPS})
-        else:
-            roofline.update({"achieved": None, "frac": None})
-        if pmc and pmc.get("sq_insts_valu"):
-            roofline["issue_frac"] = pmc["sq_insts_valu"] * 64 / cull_s / 1e12 / VALU_PEAK_TFLOPS
-            roofline["pmc"] = {k: pmc[k] for k in pmc if k.startswith("sq_") or k == "rocprof_avg_us"}
-        else:
-            roofline["issue_frac"] = None
-        if roof_dense is not None:
-            s_ = roof_dense["launch_ms"] * 1e-3
-            roofline["dense_reference"] = {
-                "kernel": "scan_kernel<v2f,2> (scan mode strict: every (line, point) pair evaluated -- the kernel that performs "
-                          "all 18 counted flops per pair; NOT part of the timed step; HIP events on the launch stream, this run)",
-                "achieved": dense_flops / s_ / 1e12, "frac": dense_flops / s_ / 1e12 / VALU_PEAK_TFLOPS,
-                "launch_ms": roof_dense["launch_ms"], "launches_timed": roof_dense["launches_timed"],
-                "algorithmic_flops_per_launch": dense_flops,
-                "loss_bit_identical_to_default_mode": roof_dense["loss_bit_identical_to_default_mode"]}
-        roofline["hbm"] = {"algorithmic_bytes": alg_bytes, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "achieved": alg_bytes / cull_s / 1e9,
-                           "frac": alg_bytes / cull_s / 1e9 / HBM_PEAK_GBS,
-                           "kernel": "scan launch of the timed step"}
+            "hbm": {"algorithmic_bytes": alg_bytes, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "achieved": alg_bytes / cull_s / 1e9, "frac": alg_bytes / cull_s / 1e9 / HBM_PEAK_GBS,
+                    "kernel": "scan launch of the timed step"}})
+        ms_step = dt / args.steps * 1e3
         extras.update({"loss_sum": float(payload[0]), "valid": float(payload[1]),
                        "line_sampling_s": w["sample_s"], "scan_launch_ms": cull_ms,
-                       "scan_share_of_step": cull_ms / (dt / args.steps * 1e3)})
+                       "scan_share_of_step": cull_ms / ms_step})
         out = {
             "metric": "point-pairs/sec for loss fwd+bwd at B=8, N=M=4096",
             "value": value, "unit": "point-pairs/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "warmup": args.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": (f"B={B}/GPU" if not strong else f"global B={args.global_batch} sharded over {world}")
                                    + f", N=M={N} pseudo-triangles, L={L} lines, fp32 loss fwd+bwd "
-                                   f"(BASELINE.json configs[{2 if strong else 1}]); fused training op "
-                                   f"(rigid apply + loss, backward to dR, dT); scan mode {args.mode}; "
-                                   + ("prepared order (k-d order of each cloud computed once outside the timed region, "
-                                      "rrl_cloud_order: prepare_us; target records kept while it does not move); "
-                                      if prepared else "cold (records + cell sort every step); ")
-                                   + ("hipGraph replay" if graphed is not None else
-                                      ("one C call per step on the stream (ops.RegistrationStep -> rrl_registration_step: 4 launches prepared / 5 cold, no autograd node, no graph)"
-                                       if issued == "direct" else "eager launches"))
+                                   f"(BASELINE.json configs[{2 if strong else 1}]); SURVEY 8(d) step: rigid apply of the source + "
+                                   f"S + P + median + Welsch + backward to points1.grad (B,N,9) (code/loss.py:170-232 + autograd), "
+                                   f"one C call per step (ops.LossStep -> rrl_loss_step_ex), then the all-reduce of "
+                                   f"[loss sum, valid count]; scan mode {args.mode}; "
+                                   + ("PREPARED: k-d order of each cloud computed once outside the timed region "
+                                      "(rrl_cloud_order: prepare_us), target records kept while it does not move; 4 launches; "
+                                      if prepared else "COLD: records + cell sort + sphere tree of both clouds every step; 5 launches; ")
+                                   + ("hipGraph replay" if graphed is not None else "direct issue on the stream")
                                    + "; value counts dense-equivalent pairs",
-                       "issue": issued if (issued == "direct" or graphed is not None) else "eager",
-                       "prepared_order": prepared, "prepare_us": prepare_us,
+                       "step": "loss_step (SURVEY 8(d): points1.grad)",
+                       "issue": issued, "prepared_order": prepared, "prepare_us": prepare_us,
+                       "prepare_note": "rrl_cloud_order of B clouds of N triangles, once per cloud (dataset item / demo start); a "
+                                       "rigid motion keeps the order, so it serves every pose of the cloud",
                        "global_batch": args.global_batch if strong else B * world,
                        "parallelism": f"batch-shard dp{world}",
                        "allreduce": {"reducer": type(reducer).__name__, "placement": placement,
@@ -675,18 +663,18 @@ def main():
                                      "rccl": evidence, "process_group": dist.is_initialized(),
                                      "backend": dist.get_backend() if dist.is_initialized() else None,
                                      "warmup_ms_per_step": choice_note}},
-            "value_8d": variants.get("points1_grad_direct", variants.get("points1_grad", {})).get("value"),
-            "ms_per_step_8d": variants.get("points1_grad_direct", variants.get("points1_grad", {})).get("ms_per_step"),
-            "value_is": "the fused training op (config.workload): rigid apply of the source + loss + backward to (dR, dT), "
-                        "dense-equivalent pairs; value_8d / ms_per_step_8d = SURVEY section 8(d) as defined (rigid apply + loss "
-                        "+ backward to points1.grad (B, N, 9)) by direct issue, one C call per step "
-                        "(variants.points1_grad_direct); variants.points1_grad = the same through the drop-in callables "
-                        "chained by autograd, on to (dR, dT), as a hipGraph replay; variants.dropin_loop = the reference "
-                        "trainers' literal per-sample loop",
+            "value_is": "SURVEY section 8(d) as defined: rigid apply + loss forward + backward to points1.grad (B, N, 9), "
+                        "dense-equivalent pairs, " + ("prepared orders" if prepared else "cold build")
+                        + "; the other build of the same step is value_" + ("cold" if prepared else "prepared")
+                        + " (this rank, no all-reduce); round-over-round comparisons with rounds 1-3 must use the cold number; "
+                          "variants.fused_dRdT = the fused training op (rounds 3-4's headline)",
             "roofline": roofline,
             "variants": variants,
             "extras": extras,
         }
+        if other is not None:
+            out["value_" + ("cold" if prepared else "prepared")] = other["value"]
+            out["ms_per_step_" + ("cold" if prepared else "prepared")] = other["ms_per_step"]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(N, M, L)
         sys.stdout.flush()

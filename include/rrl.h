@@ -182,12 +182,21 @@ typedef struct rrl_opts {
     /* Prepared clouds: order [B][64 ceil(n / 64)] from rrl_cloud_order -- sorted position -> triangle, computed ONCE
      * per cloud in any rigid frame of it.  Both given (or order1 + RRL_F_TARGET_KEPT), scan mode cull: the cell sort
      * leaves the step; one wide launch moves the source, writes the records at their sorted positions and refits
-     * the sphere tree.  Any permutation gives the same labels, hit lists and loss (the tree is a conservative
-     * filter, the reference's arithmetic decides); a stale or arbitrary order only costs time. */
+     * the sphere tree.  The first n entries of every row MUST be a permutation of [0, n) (the kernels only clamp the
+     * index range: a duplicated or missing triangle silently changes labels and loss).  ANY permutation gives the same
+     * labels, hit lists and loss (the tree is a conservative filter, the reference's arithmetic decides): an order taken
+     * in another pose of the cloud, or a stale one, only costs time. */
     const int32_t *order1, *order2;
     uint64_t *scan_counters;       /* per-call counter table of the culled scan (see rrl_scan_counters) */
     long long scan_counter_rows;
     rrl_chamfer_rider *chamfer;    /* NULL, or the evaluation's Chamfer walk to be carried by its scan launch (above) */
+    /* rrl_loss_step_ex only (round 5): NULL, or float[14] that receives the batch-shard payload of the section-8(d) step
+     * { sum of the valid losses, #valid, 0 x 12 } -- the buffer a rank contributes to the all-reduce of the scalar loss
+     * (points1.grad stays local, so the (dR, dt) slots of rrl_registration_step's payload stay zero).
+     * Ideally the workspace's GACC + 12 B floats (cleared by the step's first launch when R, t are given); any other
+     * buffer is cleared by a fill launch first.  Written in the reduce's launch where the scatter rides in it, else by
+     * one small launch behind the backward. */
+    float *payload;
 } rrl_opts;
 
 size_t rrl_workspace_bytes(int B, int N, int M, int L);

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (build container, repo root; CPU only): tools/oracle_sanitize.sh -- the CPU oracle (oracle/rrl_oracle.c) built with
+# usage (build container, repo root; CPU only): oracle/sanitize.sh -- the CPU oracle (oracle/rrl_oracle.c) built with
 # AddressSanitizer + UndefinedBehaviorSanitizer, run against the reference's golden vectors (tests/test_oracle_golden.py);
 # the regular build is restored afterwards.  (GPU sanitizers are not available on this pool.)
 set -e

@@ -16,6 +16,21 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# Collection order of the -m gpu suite: the KERNEL parity tests first, then the prepared-build parity, then the harness
+# (fragments, demo, bench.py children), then threads / stress / soak -- with `-x` a failure late in the list must never
+# hide the kernels (round 4 lost 321 parity tests to one assertion in the harness file, which sorts first by name).
+_ORDER = ["test_oracle_golden", "test_host", "test_dataset", "test_dist_gloo",
+          "test_gpu_parity", "test_gpu_prepared", "test_gpu_callsites", "test_gpu_harness", "test_gpu_threads",
+          "test_gpu_stress", "test_gpu_soak"]
+
+
+def pytest_collection_modifyitems(session, config, items):
+    def rank(item):
+        mod = os.path.splitext(os.path.basename(str(item.fspath)))[0]
+        return _ORDER.index(mod) if mod in _ORDER else len(_ORDER)
+    items.sort(key=rank)  # stable: the order inside a file is kept
+
+
 def load_golden(name):
     return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
 

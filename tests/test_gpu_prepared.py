@@ -397,3 +397,173 @@ def test_cloud_order_equals_its_host_twin(L, n):
     np.testing.assert_array_equal(got3, got9)
     for b in range(3):
         np.testing.assert_array_equal(got3[b], P.kd_order(pts[b]))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# round 5: the section-8(d) step's shard payload, order validation, explicit target invalidation, torch-internals fallbacks
+@pytest.mark.parametrize("B,n,m,nl,prepared,pose", [(3, 900, 1100, 4000, True, True), (2, 700, 600, 3000, False, True),
+                                                     (2, 500, 400, 800, True, True), (2, 600, 500, 2500, True, False),
+                                                     (8, 4096, 4096, 10000, True, True)])
+def test_loss_step_payload(L, B, n, m, nl, prepared, pose):
+    """ops.LossStep(want_payload=True) (include/rrl.h rrl_opts.payload): after every step .payload ==
+    [sum of the valid losses, #valid, 0 x 12] -- riding in the reduce's launch (2 .. 16 line tiles), by the small launch
+    behind the backward (one tile of lines), with and without the rigid apply in front, on the first (building) and on later
+    (kept-target) calls -- and the step's loss / gradient are those of the step without a payload, bit for bit / to the
+    rounding of the scatter's atomics."""
+    from rrl_hip import ops
+    prs, src, tar = _pairs(520, B, n, m)
+    ln = _lines(L, prs, nl)
+    R = cu(np.stack([_rot((0, 0, 1), 4 + b) for b in range(B)])) if pose else None
+    t = cu(np.full((B, 3), 0.01, np.float32)) if pose else None
+    plain = ops.LossStep(src, tar, nl, prepared=prepared)
+    pay = ops.LossStep(src, tar, nl, prepared=prepared, want_payload=True)
+    for it in range(3):
+        a = plain(R, t, ln)
+        b_ = pay(R, t, ln)
+        torch.cuda.synchronize()
+        assert torch.equal(a[0], b_[0]) and torch.equal(a[2], b_[2])
+        ga, gb = a[1], b_[1]
+        assert bool(((ga - gb).abs() <= 2e-5 * ga.abs() + 2e-6 * float(ga.abs().max())).all())
+        valid = b_[2][:, 0] > 0
+        want_sum = float(b_[0][valid].double().sum())
+        p = pay.payload.cpu().numpy()
+        assert p[1] == float(valid.sum()) and np.all(p[2:] == 0.0), p
+        assert abs(p[0] - want_sum) <= 2e-6 * max(1.0, abs(want_sum)), (p[0], want_sum)
+    assert int(valid.sum()) == B
+
+
+def test_orders_are_validated_where_they_enter(L):
+    """An order reaches the kernels as a raw int32 [B][64 ceil(n / 64)] pointer on the op's GPU: every Python entry that
+    takes one refuses anything else -- dtype, batch dimension, padding, contiguity."""
+    from rrl_hip import ops, callsites
+    B, n, m, nl = 2, 300, 280, 1500
+    prs, src, tar = _pairs(530, B, n, m)
+    ln = _lines(L, prs, nl)
+    R, t = cu(np.stack([np.eye(3, dtype=np.float32)] * B)), cu(np.zeros((B, 3), np.float32))
+    o1, o2 = ops.cloud_order(src), ops.cloud_order(tar)
+    good = ops.registration_loss(src, R, t, tar, ln, order1=o1, order2=o2)[0].clone()
+    bad = [o1.to(torch.int64), o1[:1].contiguous(), o1[:, :256].contiguous(), o1.t().contiguous().t(), o1.cpu()]
+    for b_ in bad:
+        with pytest.raises(ValueError, match="order1"):
+            ops.registration_loss(src, R, t, tar, ln, order1=b_, order2=o2)
+        with pytest.raises(ValueError, match="order1"):
+            ops.intersection_loss(src, tar, ln, order1=b_, order2=o2)
+        with pytest.raises(ValueError):
+            ops.RegistrationStep(src, tar, nl, src_order=b_, tar_order=o2)
+        with pytest.raises(ValueError):
+            ops.LossStep(src, tar, nl, src_order=b_, tar_order=o2)
+        # the trainers' dict: an unusable order is ignored (the fused op sorts), never handed on
+        assert callsites._orders({'order_src': b_, 'order_tar': o2}, n, m, B, src.device) == (None, None)
+    assert callsites._orders({'order_src': o1, 'order_tar': o2}, n, m, B, src.device)[0] is o1
+    assert torch.equal(ops.registration_loss(src, R, t, tar, ln, order1=o1, order2=o2)[0], good)
+    try:  # the debugging aid: a host-side permutation check
+        ops.ORDER_DEBUG = True
+        dup = o1.clone()
+        dup[0, 1] = dup[0, 0]
+        with pytest.raises(ValueError, match="permutation"):
+            ops.intersection_loss(src, tar, ln, order1=dup, order2=o2)
+        ops.intersection_loss(src, tar, ln, order1=o1, order2=o2)
+    finally:
+        ops.ORDER_DEBUG = False
+
+
+def test_invalidate_target_and_failed_calls_keep_nothing(L):
+    """A write that bypasses torch's version counter AND the library (tar.data.copy_ bumps it; a raw alias does not) is the
+    one thing a step cannot see: invalidate_target() / keep_target = False are the switches.  A call that raises before it
+    is issued keeps nothing."""
+    from rrl_hip import ops
+    B, n, m, nl = 2, 800, 900, 3500
+    prs, src, tar = _pairs(540, B, n, m)
+    ln = _lines(L, prs, nl)
+    R, t = cu(np.stack([_rot((0, 0, 1), 5)] * B)), cu(np.zeros((B, 3), np.float32))
+    for cls in (ops.RegistrationStep, ops.LossStep):
+        cold, prep = cls(src, tar, nl, prepared=False), cls(src, tar, nl)
+        prep(R, t, ln); prep(R, t, ln)
+        assert prep._kept_key is not None
+        with pytest.raises(ValueError):  # wrong line shape: raises before the C call -> nothing is "kept"
+            prep(R, t, ln[:, :100].contiguous())
+        assert prep._kept_key is None
+        prep(R, t, ln)
+        # a write NOBODY's bookkeeping sees: through a second tensor on the same storage (its own version counter; what a custom
+        # kernel or another raw-pointer library does).  The kept records are stale -- the documented blind spot -- until
+        # invalidate_target()
+        alias = torch.empty(0, device="cuda").set_(tar.untyped_storage(), 0, tar.shape, tar.stride())
+        v0 = tar._version
+        alias.mul_(1.01)
+        assert tar._version == v0
+        a, b_ = cold(R, t, ln), prep(R, t, ln)
+        torch.cuda.synchronize()
+        assert not torch.equal(a[0], b_[0])  # (stale target)
+        prep.invalidate_target()
+        b_ = prep(R, t, ln)
+        torch.cuda.synchronize()
+        assert torch.equal(a[0], b_[0])
+        # the explicit switches
+        prep.invalidate_target()
+        assert prep._kept_key is None
+        prep.keep_target = False
+        for _ in range(2):
+            a, b_ = cold(R, t, ln), prep(R, t, ln)
+            torch.cuda.synchronize()
+            assert torch.equal(a[0], b_[0]) and prep._kept_key is None
+        with torch.no_grad():
+            tar.div_(1.01)  # (the next class starts from the same target, up to rounding)
+
+
+def test_torch_internals_fallbacks(L, monkeypatch):
+    """rrl_hip.ops uses three torch internals for speed (INTERNALS); without them it degrades to public API with one
+    warning, never an AttributeError: same loss bits, same gradients, the trainers' loop served per call."""
+    import warnings
+    from rrl_hip import ops
+    B, n, m, nl = 3, 600, 500, 2500
+    prs, src, tar = _pairs(550, B, n, m)
+    ln = _lines(L, prs, nl)
+    assert ops.INTERNALS["raw_stream"] and ops.INTERNALS["version_bump"] and ops.INTERNALS["tensor_base"]
+
+    def trainer_loop():
+        p1 = src.clone().requires_grad_(True)
+        total = 0
+        for j in range(B):
+            one = L.cal_loss_intersection_batch_whole_median_pts_lines(1, 1, 5, 5, p1[j:j + 1], tar[j:j + 1], ln[j:j + 1], "cuda")
+            total = total + one
+        total.backward()
+        return total.detach().clone(), p1.grad.clone()
+
+    def kept_step():
+        step = ops.RegistrationStep(src, tar, nl)
+        R, t = cu(np.stack([_rot((0, 1, 0), 3)] * B)), cu(np.zeros((B, 3), np.float32))
+        step(R, t, ln)
+        out = step(R, t, ln)
+        ops.rigid_apply_into(tar.view(B, -1, 3), R, t, tar.view(B, -1, 3))  # raw-pointer write into the kept target
+        new = step(R, t, ln)[0].clone()
+        ref = ops.RegistrationStep(src, tar, nl, prepared=False)(R, t, ln)[0].clone()
+        ops.rigid_apply_into(tar.view(B, -1, 3), R.transpose(1, 2).contiguous(), -torch.einsum("bij,bj->bi", R.transpose(1, 2), t), tar.view(B, -1, 3))
+        return out[0].clone(), new, ref
+
+    ops.dropin_batch_clear()
+    base_loss, base_grad = trainer_loop()
+    s0 = dict(ops.dropin_batch_stats)
+    assert s0["evaluations"] >= 1
+    monkeypatch.setattr(ops, "DROPIN_BATCH", False)  # RRL_DROPIN_BATCH=0: the literal per-call path
+    off_loss, off_grad = trainer_loop()
+    assert torch.equal(off_loss, base_loss)
+    assert bool(((off_grad - base_grad).abs() <= 2e-5 * base_grad.abs() + 2e-6 * float(base_grad.abs().max())).all())
+    monkeypatch.setattr(ops, "DROPIN_BATCH", True)
+    _, new, ref = kept_step()
+    assert torch.equal(new, ref)
+    # now without the internals
+    monkeypatch.setattr(ops, "_raw_stream_fn", None)
+    monkeypatch.setattr(ops, "_set_version_fn", None)
+    monkeypatch.setitem(ops.INTERNALS, "tensor_base", False)
+    ops._warned.clear()
+    ops.dropin_batch_clear()
+    with warnings.catch_warnings(record=True) as wlist:
+        warnings.simplefilter("always")
+        f_loss, f_grad = trainer_loop()
+        _, new, ref = kept_step()  # the kept target is still invalidated by the library's own write map
+        torch.cuda.synchronize()
+    assert torch.equal(f_loss, base_loss) and torch.equal(new, ref)
+    assert bool(((f_grad - base_grad).abs() <= 2e-5 * base_grad.abs() + 2e-6 * float(base_grad.abs().max())).all())
+    msgs = " ".join(str(w.message) for w in wlist)
+    assert "_cuda_getCurrentRawStream" in msgs and "_unsafe_set_version_counter" in msgs and "Tensor._base" in msgs
+    assert sum("_cuda_getCurrentRawStream" in str(w.message) for w in wlist) == 1  # one warning per missing symbol

@@ -102,3 +102,40 @@ def test_two_threads_two_streams_different_options(L):
     assert not errors, errors
     # the process-wide defaults were never touched: a plain call still takes them
     assert ops.loss_forward_raw(*wa[:3]).loss.shape == (4,)
+
+
+@pytest.mark.timeout(600)
+def test_cloud_order_from_two_threads_on_two_streams(L):
+    """ops.cloud_order of the SAME shape from two threads on two streams at once (a data-preparation side stream next to a
+    step's construction): every returned order is a permutation and equals the single-threaded one (the scratch
+    used to be one global buffer per shape)."""
+    from rrl_hip import ops, synth
+    B, n = 4, 3000
+    clouds = [cu(np.stack([synth.make_pair(900 + 10 * k + b, n, 64)["src_tri"] for b in range(B)])) for k in range(2)]
+    want = [ops.cloud_order(c).clone() for c in clouds]
+    torch.cuda.synchronize()
+    ar = torch.arange(n, device="cuda")
+    for w_ in want:
+        assert bool((torch.sort(w_[:, :n].long(), dim=1).values == ar).all())
+    errors = []
+
+    def worker(k, stream):
+        with torch.cuda.stream(stream):
+            for it in range(200):
+                o = ops.cloud_order(clouds[k])
+                if it % 20 == 19:
+                    stream.synchronize()
+                    if not torch.equal(o, want[k]):
+                        errors.append((k, it))
+                        return
+            stream.synchronize()
+            if not torch.equal(o, want[k]):
+                errors.append((k, "last"))
+
+    ths = [threading.Thread(target=worker, args=(k, torch.cuda.Stream())) for k in range(2)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    torch.cuda.synchronize()
+    assert not errors, errors
