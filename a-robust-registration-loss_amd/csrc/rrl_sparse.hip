@@ -62,6 +62,38 @@ __device__ __forceinline__ void sort4(int *h, int n) {  // ascending, n <= 4
             if (j < n && h[j] < h[j - 1]) { int t = h[j]; h[j] = h[j - 1]; h[j - 1] = t; }
 }
 
+// Scatter of a wavefront's gradient rows (round 5).  Every LIVE lane owns nine products that go to nine CONSECUTIVE floats
+// of its triangle's gradient row [9].  One lane per row meant nine instructions of 64 scattered 4-byte atomics -- 64 cache
+// lines per instruction through the CU's address path: +4.5 us on the C2 tail kernel against the (dR, dt) variant, 53 us for
+// loss_bwd_kernel at B = 64.  Here the rows meet in the wavefront's LDS strip, compacted by rank among the live lanes, and
+// lane p of a round adds element (p % 9) of row (p / 9): one instruction covers seven whole rows (8 .. 14 cache lines),
+// ceil(9 nlive / 64) instructions per wavefront instead of nine.  The products are computed by the owning lane exactly as
+// before; only WHICH lane issues an atomic changes (float atomics: the sums agree to their rounding order, as before).
+// rowkey = triangle index | (cloud 2 ? 1u << 31 : 0); g1b / g2b: the sample's gradient rows [n][9]; strip: 64 x 10 words.
+#define SCAT_STRIDE 10
+__device__ __forceinline__ void wave_scatter_rows(bool live, const float (&v)[9], unsigned rowkey, float *__restrict__ g1b,
+                                                  float *__restrict__ g2b, unsigned *strip, int lane) {
+    const unsigned long long mask = __ballot(live);
+    const int nlive = __popcll(mask);
+    if (nlive == 0) return;  // uniform
+    if (live) {
+        unsigned *row = strip + __popcll(mask & ((1ull << lane) - 1ull)) * SCAT_STRIDE;
+        row[0] = rowkey;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) row[1 + q] = __float_as_uint(v[q]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // one wavefront: its LDS traffic is in order
+    const int total = nlive * 9;
+    for (int p = lane; p < total; p += 64) {
+        const int rk = p / 9, e = p - rk * 9;
+        const unsigned key = strip[rk * SCAT_STRIDE];
+        const float val = __uint_as_float(strip[rk * SCAT_STRIDE + 1 + e]);
+        float *dst = ((key >> 31) ? g2b : g1b) + (size_t)(key & 0x7fffffffu) * 9 + e;
+        atomicAdd(dst, val);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the strip is free for the wavefront's next pass
+}
+
 // Phase 2 of line_pair_dist_kernel: EIGHT lanes per selected line, one per (cloud, hit slot) --
 // a selected line has up to 4 + 4 hits and one lane doing them in turn was the kernel's long pole
 // (8 us of 13).  Each lane gathers its triangle (three 16-byte loads of the prepared record, or
@@ -1265,6 +1297,7 @@ __global__ __launch_bounds__(TAIL_LANES) void loss_tail_kernel(const TailArgs a)
     __shared__ int s_pref[TAIL_MAX_TILES + 1];
     __shared__ int s_vpref[TAIL_MAX_TILES + 1];  // prefix of the tiles' value lists, in 16-byte groups
     __shared__ float s_red[4][12];
+    __shared__ unsigned s_scat[4][64 * SCAT_STRIDE];  // wave_scatter_rows strips of the four wavefronts that hold lines
     constexpr int NW = TAIL_LANES / 64, BPL = 2048 / TAIL_LANES;  // wavefronts; histogram bins per lane
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // (sub is the SLOW grid index: the workgroups that certainly have lines are dispatched first)
@@ -1568,6 +1601,8 @@ __global__ __launch_bounds__(TAIL_LANES) void loss_tail_kernel(const TailArgs a)
             atomicAdd(&s_sum[bi * 2 + 1], (unsigned long long)((double)col * (double)(1ll << FIX_SHIFT) + 0.5));
         }
     }
+    float sv[9] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};  // this lane's gradient row (scatter)
+    bool sc_live = false;
     if (bwd_live && C > 0) {
         const int S = s_cnt[(k - 1) * 4 + (j - 1)];
         const float wkj = expf(-0.5f * (float)abs(k - j));
@@ -1587,13 +1622,13 @@ __global__ __launch_bounds__(TAIL_LANES) void loss_tail_kernel(const TailArgs a)
             gq[2] += 2.0f * (q1.z - qz[o]) * gD;
         }
         if (scatter) {  // dL/dP1[f][kk] += w_kk / 3 * dL/dq1 (loss_bwd_kernel's expression; the records launch cleared the target)
-            float *gp = a.grad_tri1 + ((size_t)b * a.N + fhit) * 9;
 #pragma unroll
             for (int kk = 0; kk < 3; ++kk) {
                 const float wk = wq[kk] / 3.0f;
 #pragma unroll
-                for (int cc = 0; cc < 3; ++cc) atomicAdd(gp + 3 * kk + cc, wk * gq[cc]);
+                for (int cc = 0; cc < 3; ++cc) sv[3 * kk + cc] = wk * gq[cc];
             }
+            sc_live = true;
         } else {
 #pragma unroll
         for (int kk = 0; kk < 3; ++kk) {
@@ -1611,6 +1646,8 @@ __global__ __launch_bounds__(TAIL_LANES) void loss_tail_kernel(const TailArgs a)
         }
         }
     }
+    if (scatter && wave < 4)  // (wave-uniform) the rows of this wavefront's lines, transposed through its LDS strip
+        wave_scatter_rows(sc_live, sv, (unsigned)fhit, a.grad_tri1 + (size_t)b * a.N * 9, nullptr, s_scat[wave], lane);
     if ((chunk + TAIL_SUBS) * TAIL_LINES >= mycnt) break;  // uniform
     }
     if (do_bwd && !scatter && wave < 4) {  // (the lines sit in the first four wavefronts)
@@ -1919,33 +1956,42 @@ extern "C" int rrl_loss_reduce_rows(const float *rows16, const uint8_t *kj, int 
 // dL/dq1[a] = sum_b 2 (q1_a - q2_b) dL/dD;  dL/dP1[f_a][kk] += w_kk / 3 * dL/dq1[a];
 // weights, median and labels carry no gradient (code/loss.py:112, 224).
 // ---------------------------------------------------------------------------------------
+// Grid (round 5): (line tiles, samples, BWDS_SUBS) over the COMPACT slots the per-line stage left per 1024-line tile
+// (BLKCNT[b][tile] selected lines at slots 1024 tile + rank, LIDC = line | kj << 24): a workgroup takes the tile's lines
+// rank 32 (sub + BWDS_SUBS i) ..., eight lanes per line; workgroups beyond the tile's count return after one load.  The
+// round-1 grid covered every POSSIBLE slot of the sample's dense list (8 L lanes per sample, ~9 % live, every dead lane
+// walking the same chain of loads up to the DPP exchange): 11 us at C2, 53 us at B = 64; and every live lane issued its
+// nine atomics itself (wave_scatter_rows above).
+#define BWDS_LINES 32  // selected lines per pass of a 256-lane workgroup
+#define BWDS_SUBS 4
 __global__ __launch_bounds__(256) void loss_bwd_kernel(
-    const uint8_t *__restrict__ kj, const int32_t *__restrict__ sel, const int32_t *__restrict__ nsel,
+    const uint32_t *__restrict__ lidc, const int32_t *__restrict__ blkcnt,
     const int32_t *__restrict__ hs1, const int32_t *__restrict__ hs2, const float *__restrict__ w1,
     const float *__restrict__ w2, const float4 *__restrict__ Q1, const float4 *__restrict__ Q2,
     const float *__restrict__ D, const float *__restrict__ med, const int32_t *__restrict__ bcnt,
     const int32_t *__restrict__ info, const float *__restrict__ grad_loss, float *__restrict__ g1,
     float *__restrict__ g2, int B, int N, int M, int L, int pool) {
-    // one lane per (selected line, side, hit slot): 8 lanes share a line, each owns <= 9 atomics.  They also SHARE the
-    // line's Welsch tile (round 3): the lane of (cloud 1, hit a) evaluates row a, the lane of (cloud 2, hit b) column b --
-    // <= 4 exponentials and divisions where every lane used to evaluate all 16 entries (welsch_block) -- and the two
-    // quads swap their first-occurrence minima by DPP.  All lanes take part (DPP reads active lanes only); lanes
+    // one lane per (selected line, side, hit slot): 8 lanes share a line, each owns one gradient row of <= 9 floats.  They
+    // also SHARE the line's Welsch tile (round 3): the lane of (cloud 1, hit a) evaluates row a, the lane of (cloud 2, hit b)
+    // column b -- <= 4 exponentials and divisions where every lane used to evaluate all 16 entries (welsch_block) -- and the
+    // two quads swap their first-occurrence minima by DPP.  All lanes take part (DPP reads active lanes only); lanes
     // without a line or hit carry +inf.  Same expressions and tie-breaks as welsch_block on the whole tile.
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    const int b = blockIdx.y;
-    const int i = t >> 3, side = (t >> 2) & 1, h = t & 3, g = pool ? 0 : b;
-    // independent loads first (the grid covers every possible slot, ~9 % are live): SEL[i] is
-    // read before nsel is known and clamped, so that kj -- the next link of the chain -- can be
-    // requested one round trip earlier
-    const int ns = nsel[b];
-    int li = i < L ? sel[(size_t)b * L + i] : 0;
+    __shared__ unsigned s_scat[4][64 * SCAT_STRIDE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tile = blockIdx.x, b = blockIdx.y, sub = blockIdx.z, ntile = gridDim.x;
+    const int g = pool ? 0 : b;
+    const int cnt = blkcnt[(size_t)b * ntile + tile];
+    if (sub * BWDS_LINES >= cnt) return;  // uniform: no line for this workgroup
+    const int side = (tid >> 2) & 1, h = tid & 3;
     const int C = info[g * 4];
     const float m = med[g], gl_in = grad_loss[g];
-    li = li < 0 ? 0 : (li >= L ? L - 1 : li);
-    const size_t gl = (size_t)b * L + li;
-    const bool valid = i < L && i < ns && C > 0;
-    const unsigned c = valid ? kj[gl] : 0u;
-    const int k = c & 15, j = c >> 4;
+    const size_t slot0 = ((size_t)b * ntile + tile) * 1024;
+    for (int r0 = sub * BWDS_LINES; r0 < cnt; r0 += BWDS_LINES * BWDS_SUBS) {  // uniform; a second trip only beyond 128 lines
+    const int r = r0 + (tid >> 3);
+    const bool valid = r < cnt && C > 0;
+    const unsigned e = valid ? lidc[slot0 + r] : 0u;  // line | k << 24 | j << 28: no second look at the counts
+    const int k = (int)((e >> 24) & 15u), j = (int)(e >> 28);
+    const size_t gl = (size_t)b * L + (e & 0xffffffu);
     const int mycnt = side ? j : k, ocnt = side ? k : j;  // this lane's hit slots, the other cloud's
     const bool live = valid && h < mycnt && !(side && !g2);
     float d[4] = {INFINITY, INFINITY, INFINITY, INFINITY};
@@ -1954,15 +2000,27 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(
         for (int o = 0; o < RRL_MAX_HITS; ++o)
             if (o < ocnt) d[o] = D[gl * 16 + (side ? o * j + h : h * j + o)];  // row h (cloud 1) / column h (cloud 2)
     }
+    // (requested now, used after the exchange: the loads of the gradient's own chain overlap the Welsch arithmetic)
+    int f = 0, S = 1;
+    float4 mine = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    float wq[3] = {0.0f, 0.0f, 0.0f};
+    if (live) {
+        S = bcnt[g * 16 + (k - 1) * 4 + (j - 1)];
+        mine = (side ? Q2 : Q1)[gl * 4 + h];
+        f = (side ? hs2 : hs1)[gl * 4 + h];
+        const float *w = (side ? w2 : w1) + (gl * 4 + h) * 3;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) wq[q] = w[q];
+    }
     const int omax = (int)wave_max((float)(k > j ? k : j));  // uniform
     float er[4] = {0.0f, 0.0f, 0.0f, 0.0f}, wr[4];
 #pragma unroll
     for (int o = 0; o < RRL_MAX_HITS; ++o) {
         wr[o] = INFINITY;
         if (o < omax) {
-            const float e = expf(-(d[o] / m) / 2.0f);  // == welsch(): 1 - e
-            er[o] = e;
-            if (d[o] < INFINITY) wr[o] = 1.0f - e;
+            const float ex = expf(-(d[o] / m) / 2.0f);  // == welsch(): 1 - e
+            er[o] = ex;
+            if (d[o] < INFINITY) wr[o] = 1.0f - ex;
         }
     }
     int own = 0;  // first-occurrence argmin of this row / column
@@ -1978,42 +2036,42 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(
     const float oth = __int_as_float(side ? dn : up);
     const int oarg[4] = {__float_as_int(quad_bcast<0>(oth)), __float_as_int(quad_bcast<1>(oth)),
                          __float_as_int(quad_bcast<2>(oth)), __float_as_int(quad_bcast<3>(oth))};
-    if (!live) return;
-    const int S = bcnt[g * 16 + (k - 1) * 4 + (j - 1)];
-    const float wkj = expf(-0.5f * (float)abs(k - j));
-    const float scale = gl_in * wkj / (float)C;
-    const float inv_row = 1.0f / ((float)S * (float)k), inv_col = 1.0f / ((float)S * (float)j);
-    const float4 mine = (side ? Q2 : Q1)[gl * 4 + h];
-    float gq[3] = {0.0f, 0.0f, 0.0f};
+    float sv[9] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    if (live) {
+        const float wkj = expf(-0.5f * (float)abs(k - j));
+        const float scale = gl_in * wkj / (float)C;
+        const float inv_row = 1.0f / ((float)S * (float)k), inv_col = 1.0f / ((float)S * (float)j);
+        float gq[3] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
-    for (int o = 0; o < RRL_MAX_HITS; ++o) {
-        if (o >= ocnt) continue;
-        // entry (a, bb) = (h, o) for cloud 1, (o, h) for cloud 2: it is the row minimum when arg_b[a] == bb and the column
-        // minimum when arg_a[bb] == a
-        float sw = 0.0f;
-        if (side) {
-            if (oarg[o] == h) sw += inv_row;  // arg_b[o] == h
-            if (own == o) sw += inv_col;      // arg_a[h] == o
-        } else {
-            if (own == o) sw += inv_row;      // arg_b[h] == o
-            if (oarg[o] == h) sw += inv_col;  // arg_a[o] == h
+        for (int o = 0; o < RRL_MAX_HITS; ++o) {
+            if (o >= ocnt) continue;
+            // entry (a, bb) = (h, o) for cloud 1, (o, h) for cloud 2: it is the row minimum when arg_b[a] == bb and the column
+            // minimum when arg_a[bb] == a
+            float sw = 0.0f;
+            if (side) {
+                if (oarg[o] == h) sw += inv_row;  // arg_b[o] == h
+                if (own == o) sw += inv_col;      // arg_a[h] == o
+            } else {
+                if (own == o) sw += inv_row;      // arg_b[h] == o
+                if (oarg[o] == h) sw += inv_col;  // arg_a[o] == h
+            }
+            if (sw == 0.0f) continue;
+            // dWl/dD = exp(-D/(2 med)) / (2 med);  dD/dq1 = 2 (q1 - q2) = -dD/dq2
+            const float gD = scale * sw * er[o] / (2.0f * m);
+            const float4 other = (side ? Q1 : Q2)[gl * 4 + o];
+            gq[0] += 2.0f * (mine.x - other.x) * gD;
+            gq[1] += 2.0f * (mine.y - other.y) * gD;
+            gq[2] += 2.0f * (mine.z - other.z) * gD;
         }
-        if (sw == 0.0f) continue;
-        // dWl/dD = exp(-D/(2 med)) / (2 med);  dD/dq1 = 2 (q1 - q2) = -dD/dq2
-        const float gD = scale * sw * er[o] / (2.0f * m);
-        const float4 other = (side ? Q1 : Q2)[gl * 4 + o];
-        gq[0] += 2.0f * (mine.x - other.x) * gD;
-        gq[1] += 2.0f * (mine.y - other.y) * gD;
-        gq[2] += 2.0f * (mine.z - other.z) * gD;
+#pragma unroll
+        for (int kk = 0; kk < 3; ++kk) {
+            const float wk = wq[kk] / 3.0f;  // q = mean_k(w_k P_k)
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc) sv[3 * kk + cc] = wk * gq[cc];
+        }
     }
-    const int f = (side ? hs2 : hs1)[gl * 4 + h];
-    const float *w = (side ? w2 : w1) + (gl * 4 + h) * 3;
-    float *dst = (side ? g2 + ((size_t)b * M + f) * 9 : g1 + ((size_t)b * N + f) * 9);
-#pragma unroll
-    for (int kk = 0; kk < 3; ++kk) {
-        const float wk = w[kk] / 3.0f;  // q = mean_k(w_k P_k)
-#pragma unroll
-        for (int cc = 0; cc < 3; ++cc) atomicAdd(dst + 3 * kk + cc, wk * gq[cc]);
+    wave_scatter_rows(live, sv, (unsigned)f | (side ? 0x80000000u : 0u), g1 + (size_t)b * N * 9,
+                      g2 ? g2 + (size_t)b * M * 9 : nullptr, s_scat[wave], lane);
     }
 }
 
@@ -2385,9 +2443,9 @@ static int loss_backward_impl(const float *tri1, const float *tri2, const void *
     if (zero1 && (rc = rrl_fill(grad_tri1, 0u, sizeof(float) * 9 * (size_t)B * N, s))) return rc;
     if (grad_tri2 && (rc = rrl_fill(grad_tri2, 0u, sizeof(float) * 9 * (size_t)B * M, s))) return rc;
     if (B == 0 || L == 0) return 0;
-    hipLaunchKernelGGL(loss_bwd_kernel, dim3((unsigned)((8 * (size_t)L + 255) / 256), (unsigned)B),
-                       dim3(256), 0, s, w.u8(ws, RRL_WS_KJ), w.i32(ws, RRL_WS_SEL),
-                       w.i32(ws, RRL_WS_NSEL), w.i32(ws, RRL_WS_HS1), w.i32(ws, RRL_WS_HS2),
+    hipLaunchKernelGGL(loss_bwd_kernel, dim3((unsigned)((L + 1023) / 1024), (unsigned)B, BWDS_SUBS),
+                       dim3(256), 0, s, w.u32(ws, RRL_WS_LIDC), w.i32(ws, RRL_WS_BLKCNT),
+                       w.i32(ws, RRL_WS_HS1), w.i32(ws, RRL_WS_HS2),
                        w.f32(ws, RRL_WS_W1), w.f32(ws, RRL_WS_W2), (const float4 *)w.f32(ws, RRL_WS_Q1),
                        (const float4 *)w.f32(ws, RRL_WS_Q2),
                        w.f32(ws, RRL_WS_D), w.f32(ws, RRL_WS_MED), w.i32(ws, RRL_WS_BCNT),

@@ -81,6 +81,7 @@ struct WsLayout {
     __host__ const float *f32(const void *ws, int f) const { return (const float *)((const char *)ws + off[f]); }
     __host__ const int32_t *i32(const void *ws, int f) const { return (const int32_t *)((const char *)ws + off[f]); }
     __host__ const uint8_t *u8(const void *ws, int f) const { return (const uint8_t *)((const char *)ws + off[f]); }
+    __host__ const uint32_t *u32(const void *ws, int f) const { return (const uint32_t *)((const char *)ws + off[f]); }
 };
 
 // The options of ONE call, resolved once at its top (include/rrl.h rrl_opts; defaults = what the rrl_set_* setters /

@@ -469,8 +469,8 @@ def test_orders_are_validated_where_they_enter(L):
 
 def test_invalidate_target_and_failed_calls_keep_nothing(L):
     """A write that bypasses torch's version counter AND the library (tar.data.copy_ bumps it; a raw alias does not) is the
-    one thing a step cannot see: invalidate_target() / keep_target = False are the switches.  A call that raises before it
-    is issued keeps nothing."""
+    one thing a step cannot see: invalidate_target() / keep_target = False are the switches.  The kept key is set only after
+    a call has been issued: a refused call changes nothing."""
     from rrl_hip import ops
     B, n, m, nl = 2, 800, 900, 3500
     prs, src, tar = _pairs(540, B, n, m)
@@ -480,10 +480,11 @@ def test_invalidate_target_and_failed_calls_keep_nothing(L):
         cold, prep = cls(src, tar, nl, prepared=False), cls(src, tar, nl)
         prep(R, t, ln); prep(R, t, ln)
         assert prep._kept_key is not None
-        with pytest.raises(ValueError):  # wrong line shape: raises before the C call -> nothing is "kept"
-            prep(R, t, ln[:, :100].contiguous())
-        assert prep._kept_key is None
-        prep(R, t, ln)
+        with pytest.raises(ValueError):  # wrong line shape: refused before anything is issued (the workspace is untouched;
+            prep(R, t, ln[:, :100].contiguous())  # a key is only ever SET after the C call has been issued)
+        a, b_ = cold(R, t, ln), prep(R, t, ln)
+        torch.cuda.synchronize()
+        assert torch.equal(a[0], b_[0])
         # a write NOBODY's bookkeeping sees: through a second tensor on the same storage (its own version counter; what a custom
         # kernel or another raw-pointer library does).  The kept records are stale -- the documented blind spot -- until
         # invalidate_target()

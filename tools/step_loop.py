@@ -32,8 +32,10 @@ ln = torch.stack(ln)
 R = torch.eye(3, device="cuda").repeat(B, 1, 1)
 t = torch.zeros(B, 3, device="cuda")
 ops.RegistrationStep.ONE_CALL = os.environ.get("RRL_ONE_CALL", "1") != "0"
-rs = ops.RegistrationStep(src, tar, L, transpose_r=True, mode=os.environ.get("RRL_SCAN_MODE", "cull"),
-                          prepared=os.environ.get("RRL_PREPARED", "1") != "0")
+# RRL_STEP=loss: SURVEY 8(d)'s step (ops.LossStep: backward to points1.grad) -- bench.py's timed step since round 5
+Step = ops.LossStep if os.environ.get("RRL_STEP", "reg") == "loss" else ops.RegistrationStep
+rs = Step(src, tar, L, transpose_r=True, mode=os.environ.get("RRL_SCAN_MODE", "cull"),
+          prepared=os.environ.get("RRL_PREPARED", "1") != "0")
 for _ in range(10):
     rs(R, t, ln)
 torch.cuda.synchronize(); t0 = time.perf_counter()
