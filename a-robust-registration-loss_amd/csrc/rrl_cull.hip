@@ -137,7 +137,11 @@ struct BuildArgs {
     int nzwords;
     int B, N, M, transpose_r, nblk;
     int nchunk;                    // tri_sort_kernel: chunks of 4096 records per cloud (1: the whole cloud)
+    int Bt;                        // multi-pose evaluation (rrl_opts.problems): the INPUT clouds, orders and lines have Bt
+                                   // entries and instance b uses entry b % Bt; 0 / B: every instance has its own
 };
+// the input entry of instance b (multi-pose: rrl_opts.problems)
+__device__ __forceinline__ int input_of(int b, int Bt) { return (Bt > 0 && b >= Bt) ? b % Bt : b; }
 
 #define REC_BLK 256
 #define LMAX_CHUNKS 64  // per-sample partial maxima of the lines' |dir|^2 and |x0|^2 (-> the culled scan's slack)
@@ -156,14 +160,14 @@ __device__ __forceinline__ bool line_cullable(float s, float o2) { return s <= 1
 // (max |dir|^2, max |x0|^2) over the chunk's cullable lines (0, 0 for none).  The culled scan derives its slacks
 // from the maxima over the 64 chunks, identically in every wavefront -- no exchange inside that kernel.
 __device__ __forceinline__ void line_max_chunks(const float *__restrict__ line, int L, float2 *__restrict__ lmax, int b,
-                                                int ch0, int stride, float (*red2)[2]) {
+                                                int ch0, int stride, float (*red2)[2], int bl /* the lines' entry */) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int CL = (L + LMAX_CHUNKS - 1) / LMAX_CHUNKS;
     for (int ch = ch0; ch < LMAX_CHUNKS; ch += stride) {  // uniform
         float sm = 0.0f, om = 0.0f;
         const int lend = min(L, (ch + 1) * CL);
         for (int l = ch * CL + tid; l < lend; l += REC_BLK) {
-            const float2 *p = (const float2 *)(line + ((size_t)b * L + l) * 6);  // 24-byte rows: 8-byte aligned
+            const float2 *p = (const float2 *)(line + ((size_t)bl * L + l) * 6);  // 24-byte rows: 8-byte aligned
             const float2 q0 = p[0], q1 = p[1], q2 = p[2];                       // dir.xy | dir.z x0.x | x0.yz
             float s, o2;
             line_norms(q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, s, o2);
@@ -183,9 +187,9 @@ __device__ __forceinline__ void line_max_chunks(const float *__restrict__ line, 
 }
 
 // the same pass on its own, for callers that prepared the triangles without the lines (rrl_tri_prepare + rrl_line_tri_scan)
-__global__ __launch_bounds__(REC_BLK) void line_max_kernel(const float *__restrict__ line, int L, float2 *__restrict__ lmax) {
+__global__ __launch_bounds__(REC_BLK) void line_max_kernel(const float *__restrict__ line, int L, float2 *__restrict__ lmax, int Bt) {
     __shared__ float red2[REC_BLK / 64][2];
-    line_max_chunks(line, L, lmax, (int)blockIdx.y, (int)blockIdx.x, (int)gridDim.x, red2);
+    line_max_chunks(line, L, lmax, (int)blockIdx.y, (int)blockIdx.x, (int)gridDim.x, red2, input_of((int)blockIdx.y, Bt));
 }
 
 // One triangle of the build step (both records kernels): the raw row, moved by the sample's rigid transform when it
@@ -196,7 +200,7 @@ __global__ __launch_bounds__(REC_BLK) void line_max_kernel(const float *__restri
 // build: the culled scan then resolves a candidate from its position alone, without the IDX hop; the record carries f).
 __device__ __forceinline__ void tri_record_row(const BuildArgs &a, int cloud, int b, int n, int f, int prow, float (&c)[9],
                                                float &x, float &p2) {
-    const float *raw = (cloud ? a.tri2 : a.tri1) + ((size_t)b * n + f) * 9;
+    const float *raw = (cloud ? a.tri2 : a.tri1) + ((size_t)input_of(b, a.Bt) * n + f) * 9;
     float thr, e01;
 #pragma unroll
     for (int i = 0; i < 9; ++i) c[i] = raw[i];
@@ -257,7 +261,7 @@ __global__ __launch_bounds__(REC_BLK) void tri_records_kernel(const BuildArgs a)
     const int n = cloud ? a.M : a.N;
     if ((int)blockIdx.x >= a.nblk_tri) {  // uniform: the launch's LMAX_CHUNKS extra workgroups per sample reduce its lines
         if (cloud == 0 && a.lmax != nullptr)  // (one chunk each: they run beside the triangle workgroups)
-            line_max_chunks(a.line, a.L, a.lmax, b, (int)blockIdx.x - a.nblk_tri, LMAX_CHUNKS, red2);
+            line_max_chunks(a.line, a.L, a.lmax, b, (int)blockIdx.x - a.nblk_tri, LMAX_CHUNKS, red2, input_of(b, a.Bt));
         return;
     }
     const int f = blockIdx.x * REC_BLK + tid;
@@ -318,7 +322,7 @@ __global__ __launch_bounds__(REC_BLK) void tri_records_sorted_kernel(const Build
     const int n = cloud ? a.M : a.N;
     if ((int)blockIdx.x >= a.nblk_tri) {  // uniform: the line maxima, beside the triangle workgroups (tri_records_kernel)
         if (cloud == 0 && a.lmax != nullptr)
-            line_max_chunks(a.line, a.L, a.lmax, b, (int)blockIdx.x - a.nblk_tri, LMAX_CHUNKS, red2);
+            line_max_chunks(a.line, a.L, a.lmax, b, (int)blockIdx.x - a.nblk_tri, LMAX_CHUNKS, red2, input_of(b, a.Bt));
         return;
     }
     const int npad = (n + SGT - 1) / SGT * SGT;
@@ -328,7 +332,7 @@ __global__ __launch_bounds__(REC_BLK) void tri_records_sorted_kernel(const Build
     float c[9] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}, x = 0.0f, p2 = 0.0f;
     int f = 0;
     if (valid) {
-        f = (cloud ? order2 : order1)[(size_t)b * npad + s];
+        f = (cloud ? order2 : order1)[(size_t)input_of(b, a.Bt) * npad + s];
         f = min(max(f, 0), n - 1);  // memory safety only: the order must be a permutation of [0, n)
         tri_record_row(a, cloud, b, n, f, s, c, x, p2);
     }
@@ -1215,7 +1219,7 @@ __device__ __forceinline__ void cull_scan_body(
     const float *__restrict__ del1, const float *__restrict__ del2, const float2 *__restrict__ lmax,
     const float *__restrict__ apart, const float *__restrict__ aflag, int nblk_apart, int B,
     int N, int M, int L, int spw, unsigned long long *__restrict__ counters, long long counter_rows,
-    const int bx, const int by, const int bz, const int gx, const int gy) {
+    const int bx, const int by, const int bz, const int gx, const int gy, const int Bt) {
 #if !CULL_REGLINES
     float2 (&line_lds)[WPB][LPW * 3] = lds_.line_lds;
 #endif
@@ -1241,6 +1245,9 @@ __device__ __forceinline__ void cull_scan_body(
     const int nsg = (n + SGT - 1) / SGT;
     const int sg0 = bz * spw;
     if (sg0 >= nsg) return;  // uniform: the smaller cloud has fewer slices
+    // multi-pose evaluation (rrl_opts.problems): instance b has the target and lines of problem b % Bt -- the target's scan
+    // is the same for every pose, so only the first Bt instances scan cloud 2 (the per-line stage reads it there)
+    if (cloud && Bt > 0 && b >= Bt) return;  // uniform
     const int nsl = min(spw, nsg - sg0);
     const float4 *p0s = (cloud ? p0s2 : p0s1) + (size_t)b * nsg * SGT;
     const float4 *tree = (cloud ? tree2 : tree1) + (size_t)b * nsg * NODE;
@@ -1280,7 +1287,7 @@ __device__ __forceinline__ void cull_scan_body(
 
     // this wave's 128 lines: a full, 16-byte aligned tile arrives as three coalesced 16-byte loads per lane straight
     // into its LDS rows; the lanes then pick up their own two lines from there
-    const float *ln = line + (size_t)b * L * 6;
+    const float *ln = line + (size_t)input_of(b, Bt) * L * 6;
     const int lw0 = (by * (int)(blockDim.x >> 6) + wave) * LPW;
     const int l0 = lw0 + lane, l1 = l0 + 64;
     const bool live0 = l0 < L, live1 = l1 < L;
@@ -1491,11 +1498,11 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(6, 8))
     int32_t *__restrict__ hit2, int32_t *__restrict__ status, uint32_t *pmax,
     const float *__restrict__ del1, const float *__restrict__ del2, const float2 *__restrict__ lmax,
     const float *__restrict__ apart, const float *__restrict__ aflag, int nblk_apart, int B,
-    int N, int M, int L, int spw, unsigned long long *__restrict__ counters, long long counter_rows) {
+    int N, int M, int L, int spw, unsigned long long *__restrict__ counters, long long counter_rows, int Bt) {
     __shared__ CullLds lds_;
     cull_scan_body<COUNT>(lds_, ptri1, ptri2, p0s1, p0s2, idx1, idx2, tree1, tree2, line, count1, hit1, count2, hit2, status,
                           pmax, del1, del2, lmax, apart, aflag, nblk_apart, B, N, M, L, spw, counters, counter_rows,
-                          (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, (int)gridDim.y);
+                          (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, (int)gridDim.y, Bt);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1520,7 +1527,7 @@ struct CullKArgs {
     const float2 *lmax;
     const float *apart, *aflag;
     const float *aflag_tar;  // the partial rows of the workspace that holds cloud 2 (== aflag unless the target is carried over)
-    int nblk_apart, B, N, M, L, spw, gx, gy;
+    int nblk_apart, B, N, M, L, spw, gx, gy, Bt;
 };
 struct ChamKArgs {
     unsigned long long *best_x, *best_y;
@@ -1548,7 +1555,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4, 8))
     const int l2 = lin - ncham, bx = l2 % a.gx, r = l2 / a.gx;
     cull_scan_body<false>(lds_.scan, a.ptri1, a.ptri2, a.p0s1, a.p0s2, a.idx1, a.idx2, a.tree1, a.tree2, a.line, a.count1,
                           a.hit1, a.count2, a.hit2, a.status, a.pmax, a.del1, a.del2, a.lmax, a.apart, a.aflag, a.nblk_apart,
-                          a.B, a.N, a.M, a.L, a.spw, nullptr, 0, bx, r % a.gy, r / a.gy, a.gx, a.gy);
+                          a.B, a.N, a.M, a.L, a.spw, nullptr, 0, bx, r % a.gy, r / a.gy, a.gx, a.gy, a.Bt);
 }
 
 // Executed-work counters (profiling; include/rrl.h rrl_scan_counters): while a buffer is set,
@@ -1652,6 +1659,7 @@ int rrl_launch_tri_build(const float *tri1, const float *tri2, void *ws, const W
     a.L = L;
     a.B = B; a.N = N; a.M = M;
     a.transpose_r = xf ? xf->transpose_r : 0;
+    a.Bt = o.problems;
     const int nall = N > M ? N : M;  // APART is laid out for the larger cloud
     a.nblk = (nall + REC_BLK - 1) / REC_BLK;
     a.nchunk = chunked ? (nmax + 4095) / 4096 : 1;
@@ -1709,7 +1717,7 @@ int rrl_launch_cloud_sort(const float *raw1, const float *raw2, float4 *crec1, f
     a.grp1 = grp1; a.grp2 = grp2;
     a.pmax = pmax;
     a.zwords = zwords; a.nzwords = nzwords;
-    a.B = B; a.N = N; a.M = M;
+    a.B = B; a.N = N; a.M = M; a.Bt = 0;
     // (the chunked sort of rrl_launch_tri_build was tried here too: a nearest-neighbour walk evaluates twice the
     //  pairs on chunked clouds -- 63.0 -> 64.4 us at N = M = 16384, 188 -> 380 at 65536: whole-cloud order stays)
     if (nmax <= 4096) {
@@ -1751,7 +1759,7 @@ int rrl_launch_cull_scan(const float *line, void *ws, const WsLayout &w, int B, 
     const int tiles = (lw + waves - 1) / waves, slices = (nsgmax + spw - 1) / spw;
     if (!lmax_ready)  // the triangles were prepared without the lines: their partial maxima first (a tiny launch)
         hipLaunchKernelGGL(line_max_kernel, dim3(LMAX_CHUNKS, (unsigned)B), dim3(REC_BLK), 0, s, line, L,
-                           (float2 *)w.f32(ws, RRL_WS_LMAX));
+                           (float2 *)w.f32(ws, RRL_WS_LMAX), o.problems);
     // (A PERSISTENT variant -- as many workgroups as fit on the chip, each keeping one line tile staged and pulling
     // (cloud, slice) items from per-tile work queues, the next slice's records prefetched during the walk -- was built
     // and measured in round 3: exact, but 40.7 us against 30.4 at C2 and 29.0 against 13.8 at the demo's shape.  A slot
@@ -1769,7 +1777,7 @@ int rrl_launch_cull_scan(const float *line, void *ws, const WsLayout &w, int B, 
                        w.i32(ws, RRL_WS_STATUS), (uint32_t *)w.i32(ws, RRL_WS_PMAX),                         \
                        w.f32(ws, RRL_WS_DEL1), w.f32(ws, RRL_WS_DEL2), (const float2 *)w.f32(ws, RRL_WS_LMAX),   \
                        apart, w.f32(ws, RRL_WS_APART), nblk_apart, B, N, M, L, spw,                          \
-                       o.counters, o.counter_rows)
+                       o.counters, o.counter_rows, o.problems)
     const float *apart = o.prepared() ? w.f32(ws, RRL_WS_APART) : nullptr;  // prepared build: PMAX comes from the partial rows
     const int nblk_apart = ((N > M ? N : M) + REC_BLK - 1) / REC_BLK;
     if (may_ride && waves == WPB) {
@@ -1791,7 +1799,7 @@ int rrl_launch_cull_scan(const float *line, void *ws, const WsLayout &w, int B, 
             a.lmax = (const float2 *)w.f32(ws, RRL_WS_LMAX);
             a.apart = apart; a.aflag = w.f32(ws, RRL_WS_APART); a.aflag_tar = w.f32(tws, RRL_WS_APART);
             a.nblk_apart = nblk_apart; a.B = B; a.N = N; a.M = M; a.L = L; a.spw = spw;
-            a.gx = clouds * B; a.gy = tiles;
+            a.gx = clouds * B; a.gy = tiles; a.Bt = o.problems;
             ChamKArgs c;
             char *cw = (char *)o.rider->ws;
             c.best_x = (unsigned long long *)o.rider->best_x; c.best_y = (unsigned long long *)o.rider->best_y;

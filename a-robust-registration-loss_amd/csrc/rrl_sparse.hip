@@ -111,27 +111,28 @@ __device__ __forceinline__ void pair_hit(const float *__restrict__ tri1, const f
                                          float *__restrict__ dc_slot, float4 *s_q /* LDS [8] of this line */,
                                          unsigned *s_mh /* LDS [2048] or NULL */,
                                          int b, int N, int M, size_t gl, int k, int j, int sub, int st1,
-                                         int st2, float *t2 /* out: this lane's two tile entries (+inf: outside the block) */) {
+                                         int st2, float *t2 /* out: this lane's two tile entries (+inf: outside the block) */,
+                                         int bi, size_t gli /* multi-pose: the instance's problem, its line's row there */) {
     const int cloud = sub >> 2, a = sub & 3;
     const int cnt = cloud ? j : k;
     float q[3] = {0.0f, 0.0f, 0.0f};
     if (a < cnt) {
         float ln[6];
         {
-            const float2 *lp = (const float2 *)(line + gl * 6);  // 24-byte rows: 8-byte aligned
+            const float2 *lp = (const float2 *)(line + gli * 6);  // 24-byte rows: 8-byte aligned
             const float2 a0 = lp[0], a1 = lp[1], a2 = lp[2];
             ln[0] = a0.x; ln[1] = a0.y; ln[2] = a1.x; ln[3] = a1.y; ln[4] = a2.x; ln[5] = a2.y;
         }
         int h[RRL_MAX_HITS];
         {
-            const int4 r = ((const int4 *)(cloud ? hit2 : hit1))[gl];
+            const int4 r = cloud ? ((const int4 *)hit2)[gli] : ((const int4 *)hit1)[gl];  // (cloud 2 was scanned by its problem's first instance)
             const int rr[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
             for (int t = 0; t < RRL_MAX_HITS; ++t) h[t] = t < cnt ? rr[t] : 0x7fffffff;
         }
         sort4(h, cnt);  // ascending triangle index == nonzero() order (code/loss.py:125-131)
         const int f = a == 0 ? h[0] : (a == 1 ? h[1] : (a == 2 ? h[2] : h[3]));
-        const float *tb = cloud ? tri2 + (size_t)b * M * st2 : tri1 + (size_t)b * N * st1;
+        const float *tb = cloud ? tri2 + (size_t)bi * M * st2 : tri1 + (size_t)b * N * st1;
         float w[3], c[9];
         tri_coords(tb, cloud ? st2 : st1, f, c);
         hit_weights(c, ln, w);
@@ -179,6 +180,8 @@ struct PairArgs {
     int32_t *blkcnt;
     uint32_t *mhist, *mctl;  // tiled reduce: per-sample histogram of the D values' top 11 bits, bucket counts (or NULL)
     int B, N, M, L, s_m, s_n, e_m, e_n, st1, st2;
+    int Bt;  // multi-pose evaluation (rrl_opts.problems): tri2, line and cloud 2's scan (count2, hit2) of instance b are those
+             // of problem b % Bt; 0: every instance has its own
 };
 
 // One tile of 1024 lines of sample b by a 1024-lane workgroup.  Phase 1: every lane classifies its line
@@ -194,6 +197,7 @@ __device__ __forceinline__ void pair_body(const PairArgs &a, int b, int tile, in
     __shared__ unsigned s_nv;        // ... and the length of its value list
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int L = a.L;
+    const int bi = (a.Bt > 0 && b >= a.Bt) ? b % a.Bt : b;  // the instance's problem (multi-pose)
     int base_reg = 0;
     const bool tally = a.mhist != nullptr;  // uniform
     if (tally) {  // (the barriers of phase 1 publish the clearing)
@@ -208,7 +212,7 @@ __device__ __forceinline__ void pair_body(const PairArgs &a, int b, int tile, in
         unsigned kjb = 0;
         if (l < L) {
             const size_t gl = (size_t)b * L + l;
-            const int k = a.count1[gl], j = a.count2[gl];
+            const int k = a.count1[gl], j = a.count2[(size_t)bi * L + l];
             sel = k >= a.s_m && k < a.e_m && j >= a.s_n && j < a.e_n;
             kjb = sel ? (unsigned)(k | (j << 4)) : 0u;
             a.kj[gl] = (uint8_t)kjb;
@@ -253,7 +257,7 @@ __device__ __forceinline__ void pair_body(const PairArgs &a, int b, int tile, in
                 if (a.lidc) a.lidc[slot] = e;
             }
             pair_hit(a.tri1, a.tri2, a.line, a.hit1, a.hit2, a.hs1, a.hs2, a.w1, a.w2, a.Q1, a.Q2, a.D, a.dc + slot * 16,
-                     s_q[tid >> 3], tally ? s_mh : nullptr, b, a.N, a.M, gl, k, j, sub, a.st1, a.st2, t2);
+                     s_q[tid >> 3], tally ? s_mh : nullptr, b, a.N, a.M, gl, k, j, sub, a.st1, a.st2, t2, bi, (size_t)bi * L + l);
             nvl = (((2 * sub) >> 2) < k && ((2 * sub) & 3) < j ? 1u : 0u) | (((2 * sub + 1) >> 2) < k && ((2 * sub + 1) & 3) < j ? 2u : 0u);
         }
         if (vl) {  // (all lanes: uniform) the valid entries join the tile's dense value list: one LDS cursor atomic per wavefront
@@ -322,7 +326,8 @@ __global__ __launch_bounds__(1024) void pair_count_kernel(const PairArgs a, cons
 // tar_ws != NULL: cloud 2's hit counts / hit lists are read where its scan left them -- the workspace of the evaluation the
 // target was carried over from (round 4b: they used to be copied into this workspace first, two launches per evaluation).
 static PairArgs pair_args(const float *tri1, const float *tri2, const float *line, void *ws, const WsLayout &w, int B, int N,
-                          int M, int L, int s_m, int s_n, int e_m, int e_n, bool tally = true, const void *tar_ws = nullptr) {
+                          int M, int L, int s_m, int s_n, int e_m, int e_n, bool tally = true, const void *tar_ws = nullptr,
+                          int Bt = 0) {
     PairArgs a;
     a.mhist = tally ? w.u32(ws, RRL_WS_MHIST) : nullptr;
     a.mctl = tally ? w.u32(ws, RRL_WS_MCTL) : nullptr;
@@ -344,6 +349,7 @@ static PairArgs pair_args(const float *tri1, const float *tri2, const float *lin
     a.B = B; a.N = N; a.M = M; a.L = L;
     a.s_m = s_m; a.s_n = s_n; a.e_m = e_m; a.e_n = e_n;
     a.st1 = 9; a.st2 = 9;
+    a.Bt = Bt;  // multi-pose (RrlCall::problems)
     return a;
 }
 
@@ -360,6 +366,7 @@ static int line_pair_dist_impl(const float *tri1, const float *tri2, const float
     if (ws_bytes < w.total) return RRL_E_WS;
     if (B == 0 || L == 0) return 0;
     PairArgs pa = pair_args(tri1, tri2, line, ws, w, B, N, M, L, s_m, s_n, e_m, e_n, true, o.tar_ws);
+    pa.Bt = o.problems;
     if (reduce_kind(o.reduce_mode, B, (L + 1023) / 1024, pool, with_bwd) != 2) pa.vlist = nullptr;  // only the tail kernel reads VLIST
     if (RrlCountRider *cr = o.count_rider) {  // the next epoch's count pass rides along (pair_count_kernel)
         const int ctiles = (cr->n + 1023) / 1024;
@@ -1268,6 +1275,7 @@ struct TailArgs {
     const float *grad_loss, *src;
     float *gR, *gt, *payload;
     float *grad_tri1;  // != NULL: the backward SCATTERS dL/dpoints1 [B][N][9] (rrl_loss_step) instead of summing (dR, dt)
+    int Bt;            // multi-pose (rrl_opts.problems): src has Bt entries, instance b is a pose of entry b % Bt; 0: its own
 };
 
 // LDS-only workgroup barrier: this wavefront's LDS traffic is complete, its vector-memory loads stay in flight
@@ -1386,7 +1394,7 @@ __global__ __launch_bounds__(TAIL_LANES) void loss_tail_kernel(const TailArgs a)
 #pragma unroll
         for (int q = 0; q < 9; ++q) xs[q] = 0.0f;
         if (bwd_live && !scatter) {  // (the scatter needs no source coordinates)
-            const float *x = a.src + ((size_t)b * a.N + fhit) * 9;
+            const float *x = a.src + ((size_t)((a.Bt > 0 && b >= a.Bt) ? b % a.Bt : b) * a.N + fhit) * 9;
 #pragma unroll
             for (int q = 0; q < 9; ++q) xs[q] = x[q];
         }
@@ -1787,6 +1795,7 @@ RrlCall rrl_resolve_opts(const rrl_opts *p) {
     else rrl_default_scan_counters(&o.counters, &o.counter_rows);
     o.rider = v.chamfer;  // (done is the caller's to clear; the scan's launcher sets it when the walk rides along)
     o.payload = v.payload;
+    o.problems = v.problems > 0 ? v.problems : 0;
     return o;
 }
 // Which reduce kernel: 0 one workgroup per sample, 1 tiled with the candidate exchange (loss_reduce_tiled_kernel), 2 the
@@ -1888,6 +1897,7 @@ static int loss_reduce_impl(void *ws, size_t ws_bytes, float *loss, int B, int N
         t.grad_loss = tb ? tb->grad_loss : nullptr; t.src = tb ? tb->src : nullptr;
         t.gR = tb ? tb->gR : nullptr; t.gt = tb ? tb->gt : nullptr; t.payload = tb ? tb->payload : nullptr;
         t.grad_tri1 = tb ? tb->grad_tri1 : nullptr;
+        t.Bt = o.problems;
         hipLaunchKernelGGL(loss_tail_kernel, dim3((unsigned)nblk, (unsigned)B, TAIL_SUBS), dim3(TAIL_LANES), 0,
                            (hipStream_t)stream, t);
         RRL_LAUNCH_CHECK();
@@ -2100,7 +2110,8 @@ __device__ __forceinline__ void bwd_rt_line(int li, int h, int b, int L, int N, 
                                             const float4 *__restrict__ Q1, const float4 *__restrict__ Q2,
                                             const float *__restrict__ D, const float *__restrict__ med,
                                             const int32_t *__restrict__ bcnt, const int32_t *__restrict__ info,
-                                            const float *__restrict__ grad_loss, const float *__restrict__ src, float *acc) {
+                                            const float *__restrict__ grad_loss, const float *__restrict__ src, float *acc,
+                                            int bs /* the source entry of sample b (multi-pose: b % Bt) */) {
     const int C = info[b * 4];
     // The four lanes of a line SHARE its Welsch tile (round 3): lane h evaluates row h -- <= 4 exponentials and divisions
     // where every lane used to evaluate all 16 entries -- and the rows travel by quad DPP; all lanes take part (DPP
@@ -2131,7 +2142,7 @@ __device__ __forceinline__ void bwd_rt_line(int li, int h, int b, int L, int N, 
         const float *w = w1 + (gl * 4 + h) * 3;
 #pragma unroll
         for (int q = 0; q < 3; ++q) wq[q] = w[q];
-        const float *x = src + ((size_t)b * N + f) * 9;
+        const float *x = src + ((size_t)bs * N + f) * 9;
 #pragma unroll
         for (int q = 0; q < 9; ++q) xs[q] = x[q];
     }
@@ -2211,7 +2222,7 @@ __device__ __forceinline__ void loss_bwd_rt_body(
     const int32_t *__restrict__ bcnt, const int32_t *__restrict__ info,
     const float *__restrict__ grad_loss, const float *__restrict__ src, float *__restrict__ gR,
     float *__restrict__ gt, float *__restrict__ payload, const float *__restrict__ loss, int B, int N,
-    int L, int transpose_r, float *__restrict__ part, const int bx, const int by, const int gx) {
+    int L, int transpose_r, float *__restrict__ part, const int bx, const int by, const int gx, const int Bt = 0) {
     __shared__ float red[4][12];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = by;
@@ -2259,7 +2270,7 @@ __device__ __forceinline__ void loss_bwd_rt_body(
     float acc[12];
 #pragma unroll
     for (int q = 0; q < 12; ++q) acc[q] = 0.0f;
-    bwd_rt_line(li, h, b, L, N, kj, hs1, w1, Q1, Q2, D, med, bcnt, info, grad_loss, src, acc);
+    bwd_rt_line(li, h, b, L, N, kj, hs1, w1, Q1, Q2, D, med, bcnt, info, grad_loss, src, acc, (Bt > 0 && b >= Bt) ? b % Bt : b);
 #pragma unroll
     for (int q = 0; q < 12; ++q) acc[q] = wave_sum(acc[q]);
     if (lane == 0)
@@ -2292,9 +2303,9 @@ __global__ __launch_bounds__(256) void loss_bwd_rt_kernel(
     const int32_t *__restrict__ bcnt, const int32_t *__restrict__ info,
     const float *__restrict__ grad_loss, const float *__restrict__ src, float *__restrict__ gR,
     float *__restrict__ gt, float *__restrict__ payload, const float *__restrict__ loss, int B, int N,
-    int L, int transpose_r, float *__restrict__ part) {
+    int L, int transpose_r, float *__restrict__ part, int Bt) {
     loss_bwd_rt_body<DET>(kj, sel, nsel, hs1, w1, Q1, Q2, D, med, bcnt, info, grad_loss, src, gR, gt, payload, loss, B, N, L,
-                          transpose_r, part, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x);
+                          transpose_r, part, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x, Bt);
 }
 
 // The direct backward AND the write pass of the next epoch's line sampler in ONE launch (round 4b; rrl_ws.h RrlWriteRider,
@@ -2376,6 +2387,7 @@ struct SoloBwd {
     float *gR, *gt, *payload;
     uint32_t *mctl;
     int B, N, L, transpose_r;
+    int Bt;  // multi-pose (rrl_opts.problems)
 };
 
 __global__ __launch_bounds__(1024) void pair_reduce_bwd_kernel(const PairArgs pa, const ReduceArgs ra, const SoloBwd a) {
@@ -2394,7 +2406,8 @@ __global__ __launch_bounds__(1024) void pair_reduce_bwd_kernel(const PairArgs pa
     for (int i0 = 0; i0 < ns; i0 += 256) {  // uniform: 256 selected lines per pass, four lanes each
         const int i = i0 + (tid >> 2);
         const int li = i < ns ? a.sel[(size_t)b * a.L + i] : -1;
-        bwd_rt_line(li, h, b, a.L, a.N, a.kj, a.hs1, a.w1, a.Q1, a.Q2, a.D, a.med, a.bcnt, a.info, a.grad_loss, a.src, acc);
+        bwd_rt_line(li, h, b, a.L, a.N, a.kj, a.hs1, a.w1, a.Q1, a.Q2, a.D, a.med, a.bcnt, a.info, a.grad_loss, a.src, acc,
+                    (a.Bt > 0 && b >= a.Bt) ? b % a.Bt : b);
     }
 #pragma unroll
     for (int q = 0; q < 12; ++q) acc[q] = wave_sum(acc[q]);
@@ -2502,6 +2515,13 @@ static int loss_forward_impl(const float *tri1, const float *tri2, const float *
     if (target_ws == ws) return RRL_E_ARG;
     const int clouds = target_ws ? 1 : 2;
     o.tar_ws = target_ws;
+    // multi-pose evaluation (rrl_opts.problems = Bt): the B instances are B / Bt poses of Bt problems; the inputs have Bt
+    // entries.  Served by the sorted layout of scan mode cull through the fused entries that move the source (xf); anything
+    // else is an argument error (the caller evaluates pose after pose then)
+    if (o.problems >= B) o.problems = 0;
+    if (o.problems > 0 && (B % o.problems != 0 || !xf || pool || target_ws || mode != RRL_SCAN_CULL ||
+                           (N > M ? N : M) > rrl_sort_capacity() || N <= 0 || M <= 0))
+        return RRL_E_ARG;
     // prepared clouds (include/rrl.h rrl_opts): honoured by the sorted layout of scan mode cull, with the orders of every
     // cloud this call builds; anything else takes the plain path (same results)
     if (o.prepared() && (mode != RRL_SCAN_CULL || (N > M ? N : M) > rrl_sort_capacity() ||
@@ -2534,16 +2554,16 @@ static int loss_forward_impl(const float *tri1, const float *tri2, const float *
             sb.grad_loss = tb->grad_loss; sb.src = tb->src; sb.loss = loss;
             sb.Q1 = (const float4 *)w.f32(ws, RRL_WS_Q1); sb.Q2 = (const float4 *)w.f32(ws, RRL_WS_Q2);
             sb.gR = tb->gR; sb.gt = tb->gt; sb.payload = tb->payload; sb.mctl = w.u32(ws, RRL_WS_MCTL);
-            sb.B = B; sb.N = N; sb.L = L; sb.transpose_r = tb->transpose_r;
+            sb.B = B; sb.N = N; sb.L = L; sb.transpose_r = tb->transpose_r; sb.Bt = o.problems;
             hipLaunchKernelGGL(pair_reduce_bwd_kernel, dim3((unsigned)B), dim3(1024), sizeof(int) * 2, (hipStream_t)stream,
-                               pair_args(tri1, tri2, line, ws, w, B, N, M, L, s_m, s_n, e_m, e_n, false, target_ws),
+                               pair_args(tri1, tri2, line, ws, w, B, N, M, L, s_m, s_n, e_m, e_n, false, target_ws, o.problems),
                                reduce_args(ws, w, loss, B, L, s_m, s_n, e_m, e_n, 0), sb);
             RRL_LAUNCH_CHECK();
             if (bwd_done) *bwd_done = true;
             return 0;
         }
         hipLaunchKernelGGL(pair_reduce_kernel, dim3((unsigned)B), dim3(1024), sizeof(int) * 2, (hipStream_t)stream,
-                           pair_args(tri1, tri2, line, ws, w, B, N, M, L, s_m, s_n, e_m, e_n, false, target_ws),
+                           pair_args(tri1, tri2, line, ws, w, B, N, M, L, s_m, s_n, e_m, e_n, false, target_ws, o.problems),
                            reduce_args(ws, w, loss, B, L, s_m, s_n, e_m, e_n, 0));
         RRL_LAUNCH_CHECK();
         return 0;
@@ -2770,6 +2790,7 @@ static int registration_backward_impl(const float *src, const float *R, const fl
                                       const RrlCall &o, void *stream) {
     if (!src || !R || !tri2 || !ws || !grad_loss || !gR || !gt) return RRL_E_ARG;
     if (payload && !loss) return RRL_E_ARG;
+    if (o.problems > 0 && o.problems < B && grad_src) return RRL_E_ARG;  // multi-pose: the direct backward only (dL/dsrc would sum over the poses)
     WsLayout w(B, N, M, L);
     if (ws_bytes < w.total) return RRL_E_WS;
     float *g1 = w.f32(ws, RRL_WS_G1);
@@ -2787,7 +2808,7 @@ static int registration_backward_impl(const float *src, const float *R, const fl
                            w.f32(ws, RRL_WS_W1), (const float4 *)w.f32(ws, RRL_WS_Q1),                             \
                            (const float4 *)w.f32(ws, RRL_WS_Q2), w.f32(ws, RRL_WS_D), w.f32(ws, RRL_WS_MED),       \
                            w.i32(ws, RRL_WS_BCNT), w.i32(ws, RRL_WS_INFO), grad_loss, src, gR, gt, payload, loss,  \
-                           B, N, L, transpose_r, PART)
+                           B, N, L, transpose_r, PART, o.problems)
         // the next epoch's sampler write pass rides along (bwd_write_kernel; rrl_demo_epoch)
         RrlWriteRider *wr = o.write_rider;
         const int wtiles = wr ? (wr->n + 1023) / 1024 : 0;

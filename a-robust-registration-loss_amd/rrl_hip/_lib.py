@@ -54,6 +54,7 @@ _SIGS = {
     "rrl_scan_timing_collect": [_P, _I],
     "rrl_scan_counters": [_P, _c.c_longlong],
     "rrl_chamfer_counters": [_P, _c.c_longlong],
+    "rrl_chamfer_group_means": [_P, _P, _P, _I, _c.c_longlong, _c.c_longlong, _P],
     "rrl_rigid_apply_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "rrl_rigid_bwd_blocks": [_I],
     "rrl_rigid_apply_bwd": [_P] * 7 + [_I] * 4 + [_P],
@@ -93,12 +94,13 @@ class Opts(ctypes.Structure):
     _fields_ = [("struct_bytes", _c.c_int32), ("flags", _c.c_int32), ("reduce_mode", _c.c_int32),
                 ("deterministic", _c.c_int32), ("sort_parts", _c.c_int32), ("scan_variant", _c.c_int32),
                 ("order1", _P), ("order2", _P), ("scan_counters", _P), ("scan_counter_rows", _c.c_longlong),
-                ("chamfer", _P), ("payload", _P)]
+                ("chamfer", _P), ("payload", _P), ("problems", _c.c_int32)]
 
     def __init__(self, flags=0, reduce_mode=-1, deterministic=-1, sort_parts=-1, scan_variant=-1, order1=None,
-                 order2=None, scan_counters=None, scan_counter_rows=0, chamfer=None, payload=None):
+                 order2=None, scan_counters=None, scan_counter_rows=0, chamfer=None, payload=None, problems=0):
         super().__init__(ctypes.sizeof(Opts), int(flags), int(reduce_mode), int(deterministic), int(sort_parts),
-                         int(scan_variant), order1, order2, scan_counters, int(scan_counter_rows), chamfer, payload)
+                         int(scan_variant), order1, order2, scan_counters, int(scan_counter_rows), chamfer, payload,
+                         int(problems))
 
 class DemoEpochArgs(ctypes.Structure):
     """include/rrl.h rrl_demo_epoch_args (same field order)."""

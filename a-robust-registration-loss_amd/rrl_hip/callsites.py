@@ -15,6 +15,8 @@ transform (ops.registration_loss: rigid apply + loss, backward straight to dR / 
 host synchronisation; a sample whose line set populates no (k, j) bucket contributes 0 (the
 reference would fail on `tensor += (None, None)`).  All functions take and return GPU tensors.
 """
+import os
+
 import torch
 
 from . import ops as _ops
@@ -50,7 +52,7 @@ def _first_points_contract(data, channel_first=False):
     a fresh check instead of a stale True).  The value ops.chamfer_from_state returns carries no grad_fn: the
     reference's callers only log the monitor (FMR multiplies it by 0.0)."""
     keys = ('points_src_sample', 'points_based_neighs_src', 'points_tar_sample', 'points_based_neighs_tar')
-    stamp = tuple(ops._write_key(data[k]) for k in keys if isinstance(data.get(k), torch.Tensor))
+    stamp = tuple(_ops._write_key(data[k]) for k in keys if isinstance(data.get(k), torch.Tensor))
     cached = data.get('_rrl_p0_key')
     ok = data.get('_rrl_p0') if cached == stamp else None
     if ok is None:
@@ -87,7 +89,7 @@ def _ride_monitor(data, channel_first=False):
     if data is None:
         return False
     keys = ('points_src_sample', 'points_based_neighs_src', 'points_tar_sample', 'points_based_neighs_tar')
-    stamp = tuple(ops._write_key(data[k]) for k in keys if isinstance(data.get(k), torch.Tensor))
+    stamp = tuple(_ops._write_key(data[k]) for k in keys if isinstance(data.get(k), torch.Tensor))
     if data.get('_rrl_p0_key') == stamp and data.get('_rrl_p0') is not None:
         return bool(data['_rrl_p0'])
     flag = data.get('p0_rows')
@@ -159,6 +161,30 @@ def per_sample_loss(src_nb, R, t, tar_tri, lines, mode=None, target_from=None, d
     return loss, info[:, 0] > 0
 
 
+MULTI_POSE = os.environ.get("RRL_MULTI_POSE", "1") != "0"  # the iterative trainers' poses in ONE evaluation (round 5)
+
+
+def multi_pose_loss(src_nb, Rs, ts, tar_tri, lines, mode=None, data=None, chamfer=False):
+    """The iterative trainers' loop over poses as ONE evaluation (include/rrl.h rrl_opts.problems): Rs / ts are the k
+    per-iteration (B, 3, 3) / (B, 3) estimates -- all known before the first loss call (rpm/Train_RPM.py:207-231,
+    fmr/model.py:292-308) --, target and lines are shared.  Returns ([loss_i (B,)], [valid_i (B,) bool]) per iteration,
+    bit-identical to per_sample_loss pose after pose (target scanned once, the k source scans side by side, one per-line
+    stage, one reduce + backward), or None where the multi-pose path does not serve the call (clouds beyond the sort
+    capacity, a scan mode other than cull, RRL_MULTI_POSE=0): the caller then loops.
+    chamfer: the walk of the evaluation's monitor rides in its scan launch over all k * B instances (_monitor_groups)."""
+    k = len(Rs)
+    B = src_nb.shape[0]
+    src_tri, tar_tri = src_nb.reshape(B, -1, 9), tar_tri.reshape(B, -1, 9)
+    if not MULTI_POSE or k < 2 or _mode(mode) != "cull" or max(src_tri.shape[1], tar_tri.shape[1]) > _SORT_CAP:
+        return None
+    o1, o2 = _orders(data, src_tri.shape[1], tar_tri.shape[1], B, src_tri.device if src_tri.is_cuda else None)
+    R, t = torch.cat([r.reshape(B, 3, 3) for r in Rs]), torch.cat([x.reshape(B, 3) for x in ts])
+    loss, info, _ = _ops.registration_loss(src_tri, R, t, tar_tri, lines, RNG, transpose_r=True, mode="cull",
+                                           order1=o1, order2=o2, chamfer=bool(chamfer))
+    ok = info[:, 0] > 0
+    return [loss[i * B:(i + 1) * B] for i in range(k)], [ok[i * B:(i + 1) * B] for i in range(k)]
+
+
 def _split(transform):
     """(B, 3, 4) [R | t] (RPM's se3 matrices) -> R (B, 3, 3), t (B, 3)."""
     return transform[..., :3, :3], transform[..., :3, 3]
@@ -177,6 +203,31 @@ def rpm_intersection_loss(pred_transforms, data, n_lines=10000, lines=None, mode
     src = data['points_src_sample'][..., :3]
     per_iter, chamfers, valid = [], [], []
     first = None  # LossState of iteration 0: target + lines are the same in every iteration
+    if num_iter > 1:  # all poses are known up front: ONE evaluation of num_iter * B instances (round 5, multi_pose_loss)
+        Rs, ts = zip(*(_split(p) for p in pred_transforms))
+        moved0 = None
+        if lines is None:
+            moved0 = _ops.rigid_apply(src, Rs[0], ts[0], transpose_r=True)
+            lines = draw_lines(bounding_radius(data['tar_box']), data['centers'], n_lines, moved0.detach(), tar)
+        ride = _ride_monitor(data)
+        got = multi_pose_loss(data['points_based_neighs_src'], Rs, ts, tar_tri, lines, mode, data=data, chamfer=ride)
+        if got is not None:
+            losses, oks = got
+            st = _ops.last_state()
+            own = CHAMFER_FROM_LOSS and max(st.dims[1], st.dims[2]) <= _SORT_CAP and st.dims[1] == src.shape[1] and \
+                st.dims[2] == tar.shape[1] and (CHAMFER_FROM_LOSS is True or _first_points_contract(data))
+            if own:  # the monitor of every iteration from the evaluation's own clouds (the walk rode in its scan launch)
+                cms = _ops.chamfer_group_means(st, num_iter)
+                chamfers = [cms[ni] for ni in range(num_iter)]
+            else:
+                chamfers = [_ops.chamfer(tar, (moved0 if (ni == 0 and moved0 is not None) else
+                                               _ops.rigid_apply(src, Rs[ni], ts[ni], transpose_r=True))).detach()
+                            for ni in range(num_iter)]
+            per_iter = [l.sum().reshape(1) / num_iter for l in losses]
+            disc = [0.5 ** (num_iter - ni - 1) for ni in range(num_iter)]
+            return {'loss_intersection': sum(l * d for l, d in zip(per_iter, disc)),
+                    'loss_chamfer': sum(c * d for c, d in zip(chamfers, disc)),
+                    'per_iter': per_iter, 'lines': lines, 'valid': torch.stack(oks)}
     for ni in range(num_iter):
         R, t = _split(pred_transforms[ni])
         moved = _ops.rigid_apply(src, R, t, transpose_r=True)
@@ -231,6 +282,20 @@ def fmr_intersection_loss(g_series, data, n_lines=15000, lines=None, last=3, mod
         lines = draw_lines(bounding_radius(data['tar_box'], 0.5), data['centers'], n_lines,
                            moved.detach(), tar)
     total, valid, first = 0.0, [], None
+    idx = list(range(max(maxiter - last, 0), maxiter))
+    if len(idx) > 1:  # the last estimates as ONE evaluation (round 5, multi_pose_loss)
+        Rs, ts = zip(*(_split(g_series[i]) for i in idx))
+        ride = _ride_monitor(data)
+        got = multi_pose_loss(data['points_based_neighs_src'], Rs, ts, tar_tri, lines, mode, data=data, chamfer=ride)
+        if got is not None:
+            losses, oks = got
+            st = _ops.last_state()
+            for i, l in zip(idx, losses):
+                total = total + (l / 5.0).sum().reshape(1) * 0.5 ** (maxiter - i - 1)
+            own = CHAMFER_FROM_LOSS and max(st.dims[1], st.dims[2]) <= _SORT_CAP and st.dims[1] == moved.shape[1] and \
+                st.dims[2] == tar.shape[1] and (CHAMFER_FROM_LOSS is True or _first_points_contract(data))
+            cham = _ops.chamfer_group_means(st, len(idx))[-1] if own else _ops.chamfer(tar, moved)  # the LAST estimate's monitor
+            return total / B, cham, lines, torch.stack(oks)
     for i in range(maxiter - last, maxiter):
         R, t = _split(g_series[i])
         loss, ok = per_sample_loss(data['points_based_neighs_src'], R, t, tar_tri, lines, mode, first, data=data,

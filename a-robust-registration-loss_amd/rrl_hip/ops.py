@@ -351,11 +351,12 @@ class ChamferRide:
 
 
 def make_opts(order1=None, order2=None, target_kept=False, reduce_mode=None, deterministic=None, sort_parts=None,
-              scan_variant=None, counters=None, chamfer=None, payload=None):
+              scan_variant=None, counters=None, chamfer=None, payload=None, problems=None):
     """include/rrl.h rrl_opts for one call (None = the library default everywhere); the returned object keeps the
     tensors it points at alive (.keep)."""
     if order1 is None and order2 is None and not target_kept and reduce_mode is None and deterministic is None \
-            and sort_parts is None and scan_variant is None and counters is None and chamfer is None and payload is None:
+            and sort_parts is None and scan_variant is None and counters is None and chamfer is None and payload is None \
+            and not problems:
         return None
     o = _lib.Opts(flags=_lib.F_TARGET_KEPT if target_kept else 0,
                   reduce_mode=-1 if reduce_mode is None else _REDUCE.get(reduce_mode, reduce_mode),
@@ -367,8 +368,8 @@ def make_opts(order1=None, order2=None, target_kept=False, reduce_mode=None, det
                   scan_counters=counters.data_ptr() if counters is not None else None,
                   scan_counter_rows=counters.shape[0] if counters is not None else 0,
                   chamfer=ctypes.addressof(chamfer.c) if chamfer is not None else None,
-                  payload=payload.data_ptr() if payload is not None else None)
-    o.keep = (order1, order2, counters, chamfer, payload)
+                  payload=payload.data_ptr() if payload is not None else None, problems=int(problems or 0))
+    o.keep = (order1, order2, counters, chamfer, payload)  # (o.problems: the ctypes field itself)
     o.ride = chamfer  # a ChamferRide (or None): the forwards arm it before the call and leave it on the LossState when it rode
     return o
 
@@ -733,18 +734,20 @@ def intersection_loss_dropin(points1, points2, line, rng=(1, 1, 5, 5), pool=Fals
     return loss, _DropinLoss.flags
 
 
-def _with_ride(opts, order1, order2, chamfer, B, N, M, dev):
-    """opts for a call that takes order1= / order2= / chamfer=True as keywords (or a ready make_opts object)."""
+def _with_ride(opts, order1, order2, chamfer, B, N, M, dev, problems=0):
+    """opts for a call that takes order1= / order2= / chamfer=True as keywords (or a ready make_opts object).
+    problems = Bt > 0: a multi-pose evaluation of B instances (include/rrl.h rrl_opts.problems); the orders then have Bt rows."""
     if opts is not None:
         if chamfer and getattr(opts, "ride", None) is None:
             raise ValueError("chamfer=True with ready-made opts: build them with make_opts(chamfer=ChamferRide(...))")
         return opts
     ride = ChamferRide(B, N, M, dev) if chamfer else None
-    if ride is None and order1 is None and order2 is None:
+    if ride is None and order1 is None and order2 is None and not problems:
         return None
     # the kernels read an order as int32 [B][64 ceil(n / 64)] on the op's GPU: anything else would be read out of bounds
-    return make_opts(order1=_check_order(order1, B, N, dev, "order1"), order2=_check_order(order2, B, M, dev, "order2"),
-                     chamfer=ride)
+    Bo = problems or B
+    return make_opts(order1=_check_order(order1, Bo, N, dev, "order1"), order2=_check_order(order2, Bo, M, dev, "order2"),
+                     chamfer=ride, problems=problems)
 
 
 def intersection_loss(points1, points2, line, rng=(1, 1, 5, 5), pool=False, mode="cull", chunk=0,
@@ -792,10 +795,14 @@ class _RegistrationLoss(torch.autograd.Function):
         Rm, tv = _prep(R, "R", None, dev).reshape(-1, 3, 3), _prep(t, "t", None, dev).reshape(-1, 3)
         if src.dim() != 3 or tri2.dim() != 3 or ln.dim() != 3:
             raise ValueError("src_tri/tar_tri/line must be 3-D (B, n, c)")
-        B, N, _ = src.shape
+        Bt, N, _ = src.shape
         M, L = tri2.shape[1], ln.shape[1]
-        if not (tri2.shape[0] == ln.shape[0] == Rm.shape[0] == tv.shape[0] == B):
-            raise ValueError("batch dimensions differ")
+        B = Rm.shape[0]  # instances: B == Bt, or k poses of each of the Bt problems (multi-pose, rrl_opts.problems)
+        if not (tri2.shape[0] == ln.shape[0] == Bt and tv.shape[0] == B) or (B != Bt and (Bt == 0 or B % Bt)):
+            raise ValueError("batch dimensions differ (src_tri / tar_tri / line share B_t; R, t hold B_t or k * B_t poses)")
+        multi = B != Bt
+        if multi and (opts is None or getattr(opts, "problems", 0) != Bt):
+            raise ValueError("multi-pose call without rrl_opts.problems (use ops.registration_loss, which sets it)")
         if B == 0 or L == 0:  # empty batch / no lines: nothing to launch, zero loss, zero gradient
             ctx.st = None
             ctx.set_materialize_grads(False)
@@ -818,6 +825,7 @@ class _RegistrationLoss(torch.autograd.Function):
         ctx.st, ctx.src, ctx.Rm, ctx.tri2 = st, src, Rm, tri2
         ctx.meta = (int(transpose_r), bool(want_payload), R.shape, t.shape, src_tri.device, R.device, t.device)
         ctx.opts = opts
+        ctx.multi = multi
         info, status = st.info, st.status
         ctx.mark_non_differentiable(info, status)
         ctx.set_materialize_grads(False)
@@ -831,6 +839,8 @@ class _RegistrationLoss(torch.autograd.Function):
         st, src, Rm, tri2 = ctx.st, ctx.src, ctx.Rm, ctx.tri2
         tr, want_payload, Rshape, tshape, sdev, Rdev, tdev = ctx.meta
         B, N, M, L, _ = st.dims
+        if ctx.multi and ctx.needs_input_grad[0]:
+            raise RRLError("a multi-pose evaluation returns dL/dR, dL/dt only (src_tri must not require grad)")
         g = g_loss if (g_loss.device == src.device and g_loss.is_contiguous()) else \
             g_loss.to(device=src.device, dtype=torch.float32).contiguous()
         if not ctx.needs_input_grad[0] and not getattr(st, "gacc_used", False):
@@ -865,9 +875,18 @@ def registration_loss(src_tri, R, t, tar_tri, line, rng=(1, 1, 5, 5), transpose_
     per-call cell sort is skipped, same results.
     chamfer=True: the trainers' Chamfer monitor (moved source's first points vs the target's; chamfer_from_state) is issued
     inside this evaluation's scan launch (ChamferRide) -- chamfer_from_state(last_state()) then costs no launch."""
-    if opts is None and (chamfer or order1 is not None or order2 is not None):
-        opts = _with_ride(None, order1, order2, chamfer, src_tri.shape[0], src_tri.reshape(src_tri.shape[0], -1, 9).shape[1],
-                          tar_tri.reshape(tar_tri.shape[0], -1, 9).shape[1], _home(src_tri, tar_tri, line, R, t))
+    # MULTI-POSE (round 5; include/rrl.h rrl_opts.problems): R / t may hold k poses for each of the B_t problems
+    # (instance s = pose s // B_t of problem s % B_t -- torch.cat of the per-iteration (B_t, 3, 3) estimates): all k * B_t
+    # losses come out of ONE evaluation, the target scanned once per problem; loss (k * B_t,), bit-identical per instance to
+    # k separate calls.  (What RPM's num_iter and FMR's last three estimates evaluate: callsites.)
+    Bt = src_tri.shape[0]
+    Binst = R.reshape(-1, 3, 3).shape[0]
+    problems = Bt if (Binst != Bt and Bt > 0 and Binst % Bt == 0) else 0
+    if problems and (target_from is not None or mode != "cull"):
+        raise ValueError("a multi-pose evaluation scans its target itself, in scan mode cull")
+    if opts is None and (chamfer or order1 is not None or order2 is not None or problems):
+        opts = _with_ride(None, order1, order2, chamfer, Binst, src_tri.reshape(Bt, -1, 9).shape[1],
+                          tar_tri.reshape(tar_tri.shape[0], -1, 9).shape[1], _home(src_tri, tar_tri, line, R, t), problems)
     return _RegistrationLoss.apply(src_tri, R, t, tar_tri, line, tuple(rng), transpose_r, mode,
                                    chunk, want_payload, target_from, opts)
 
@@ -1359,6 +1378,22 @@ def chamfer_from_state(state=None, keys=False):
     _run(dev, "rrl_chamfer_from_loss", _p(st.ws), _p(tar.ws), st.nbytes, B, N, M, L, _p(ws), nb, _p(bx), _p(by),
          _p(val))
     return (val.reshape(()), bx, by) if keys else val.reshape(())
+
+
+def chamfer_group_means(state=None, groups=1):
+    """The Chamfer monitor of a MULTI-POSE evaluation per pose: (groups,) means over the evaluation's instances
+    [g * B_t, (g + 1) * B_t) -- what chamfer_from_state would return for each pose evaluated on its own.  From the keys of
+    the walk that rode in the evaluation's scan launch (one small launch), or of chamfer_from_state otherwise."""
+    st = state or _IntersectionLoss.last_state
+    if st is None:
+        raise ValueError("no loss evaluation to take the clouds from")
+    _, bx, by = chamfer_from_state(st, keys=True)
+    B, N, M = st.dims[:3]
+    if B % groups:
+        raise ValueError("groups must divide the evaluation's instances")
+    out = torch.empty(groups, device=bx.device)
+    _run(bx.device, "rrl_chamfer_group_means", _p(bx), _p(by), _p(out), int(groups), (B // groups) * N, (B // groups) * M)
+    return out
 
 
 # ---------------------------------------------------------------------------------------

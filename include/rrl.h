@@ -197,6 +197,16 @@ typedef struct rrl_opts {
      * buffer is cleared by a fill launch first.  Written in the reduce's launch where the scatter rides in it, else by
      * one small launch behind the backward. */
     float *payload;
+    /* MULTI-POSE evaluation (round 5): 0, or Bt with B % Bt == 0 and Bt < B.  The iterative trainers evaluate several
+     * poses of the SAME source against the SAME target along the SAME lines (rpm/Train_RPM.py:207-231 num_iter,
+     * fmr/model.py:292-308 the last three estimates), and all poses are known before the first loss call.  With
+     * problems = Bt the fused entries that move the source (rrl_registration_forward_ex / _backward_ex / _step_ex,
+     * rrl_loss_step_ex with R, t) take src [Bt][N][9], tri2 [Bt][M][9], line [Bt][L][6] and the orders [Bt][..] with
+     * R [B][3][3], t [B][3]: instance s = pose (s / Bt) of problem (s % Bt).  Every output (loss [B], gR [B][9], gt [B][3],
+     * grad_tri1 [B][N][9], the workspace of B instances) is per instance and bit-identical to evaluating the B / Bt poses one
+     * after the other; the target's scan runs ONCE per problem (instances < Bt), the sources' scans side by side in the same
+     * launch.  Scan mode cull, clouds within the sort capacity, no target_ws, pool = 0; RRL_E_ARG otherwise. */
+    int32_t problems;
 } rrl_opts;
 
 size_t rrl_workspace_bytes(int B, int N, int M, int L);
@@ -577,6 +587,11 @@ int rrl_chamfer_from_loss(void *ws_src, const void *ws_tar, size_t loss_ws_bytes
  * are dropped; cleared by the caller): [0] patch-level leaf tests, [1] per-lane leaf tests, [2] (query, leaf)
  * entries evaluated, [3] (query, target) pairs evaluated, [4] 1, [5..7] / [9..14] shader clocks of the phases. */
 int rrl_chamfer_counters(uint64_t *dev_counters, long long rows);
+/* values[g] = the Chamfer mean (code/loss.py:249-252) over group g of the keys of ONE evaluation: best_x [G][nx], best_y [G][ny]
+ * (nx = samples per group x N, ny = ... x M) -- the monitor per ITERATION of a multi-pose evaluation (rrl_opts.problems:
+ * group g = pose g of every problem; rpm/Train_RPM.py:223-224 logs the distance of every iteration's moved source). */
+int rrl_chamfer_group_means(const uint64_t *best_x, const uint64_t *best_y, float *values, int G, long long nx, long long ny,
+                            void *stream);
 /* The two tree-walk entries with the counter table given PER CALL (NULL: the plain kernel) instead of through the
  * process-wide hook above: two threads / streams can profile independently.  rrl_chamfer_tree_fwd_ex also takes
  * PREPARED clouds: order_x [B][64 ceil(N/64)], order_y [B][64 ceil(M/64)] from rrl_cloud_order on the same clouds in any

@@ -144,7 +144,8 @@ def test_fragments_monitor_from_the_loss_state(C, G):
             gs = [torch.cat([torch.cat([R[i], t[i][..., None]], dim=-1), bottom], dim=1) for i in range(R.shape[0])]
             _, chamfer, _, _ = C.fmr_intersection_loss(gs, data_dict(G), lines=cu(G["fmr_lines"]))
             np.testing.assert_allclose(chamfer.item(), G["fmr_chamfer"], rtol=1e-5)
-            assert calls["plain"] == 0 and calls["state"] == len(pred) + 2
+            # (round 5: RPM's iterations are one multi-pose evaluation -- one look at its state serves all of them)
+            assert calls["plain"] == 0 and calls["state"] == (1 if C.MULTI_POSE and len(pred) > 1 else len(pred)) + 2
         # a batch whose samples are NOT the triangles' first points: auto takes the standalone kernel, same value
         C.CHAMFER_FROM_LOSS = "auto"
         calls["state"] = calls["plain"] = 0
@@ -416,7 +417,9 @@ def test_dataset_to_fragments(C, tmp_path):
     again = C.rpm_intersection_loss([eye, eye], data, lines=out['lines'])
     assert torch.equal(plain['loss_intersection'], again['loss_intersection']) and torch.equal(plain['per_iter'][0], out['per_iter'][0])
     from rrl_hip import ops
-    assert torch.equal(ops.last_state().idx1[:, :256], data['order_src'])  # the prepared build ran with the dataset's order
+    # the prepared build ran with the dataset's order -- for both poses of the (round 5) multi-pose evaluation
+    assert ops.last_state().dims[0] == 6
+    assert torch.equal(ops.last_state().idx1[:3, :256], data['order_src']) and torch.equal(ops.last_state().idx1[3:, :256], data['order_src'])
     batch = next(iter(torch.utils.data.DataLoader(P.Dataset_2021_8_29(src, tar, DCP_True=True), batch_size=3)))
     data = {k: v.cuda() for k, v in batch.items()}
     assert data['points_src_sample'].shape == (3, 3, 256)
@@ -512,3 +515,36 @@ def test_bench_line_describes_what_it_times():
     assert run["extras"]["loss_sum"] == pytest.approx(ag["loss_sum"], rel=1e-6) and run["extras"]["valid"] == 8.0
     print("ms_per_step:", {"timed": run["ms_per_step"], "cold": run["ms_per_step_cold"], "B64": b64["ms_per_step"],
                            **{k: x["ms_per_step"] for k, x in v.items()}})
+
+
+def test_fragments_multi_pose_equals_the_loop(C, G):
+    """round 5: RPM's num_iter poses and FMR's last three estimates go through ONE multi-pose evaluation
+    (callsites.multi_pose_loss); RRL_MULTI_POSE=0 / callsites.MULTI_POSE = False is round 4's loop, pose after pose with the
+    target's scan carried over.  Per-iteration losses BIT-identical, the discounted sums and the monitors equal, gradients
+    equal to the rounding of the backward's float atomics."""
+    R, t = cu(G["R"], True), cu(G["t"], True)
+    outs = {}
+    for multi in (True, False):
+        C.MULTI_POSE = multi
+        try:
+            R.grad = t.grad = None
+            pred = [torch.cat([R[i], t[i][..., None]], dim=-1) for i in range(R.shape[0])]
+            out = C.rpm_intersection_loss(pred, data_dict(G), lines=cu(G["rpm_lines"]))
+            out['loss_intersection'].backward()
+            bottom = torch.tensor([0.0, 0, 0, 1], device='cuda').expand(R.shape[1], 1, 4)
+            g4 = torch.stack([torch.cat([torch.cat([R[i], t[i][..., None]], dim=-1), bottom], dim=1)
+                              for i in range(R.shape[0])]).detach().requires_grad_(True)
+            fl, fc, _, fok = C.fmr_intersection_loss([g4[i] for i in range(g4.shape[0])], data_dict(G), lines=cu(G["fmr_lines"]))
+            fl.backward()
+            outs[multi] = ([x.detach().clone() for x in out['per_iter']], out['loss_intersection'].detach().clone(),
+                           out['loss_chamfer'].clone(), out['valid'].clone(), R.grad.clone(), t.grad.clone(),
+                           fl.detach().clone(), fc.clone(), fok.clone(), g4.grad.clone())
+        finally:
+            C.MULTI_POSE = True
+    a, b = outs[True], outs[False]
+    for x, y in zip(a[0], b[0]):
+        assert torch.equal(x, y)
+    assert torch.equal(a[1], b[1]) and torch.equal(a[3], b[3]) and torch.equal(a[6], b[6]) and torch.equal(a[8], b[8])
+    assert abs(float(a[2]) - float(b[2])) <= 1e-6 * abs(float(b[2])) and abs(float(a[7]) - float(b[7])) <= 1e-6 * abs(float(b[7]))
+    for i in (4, 5, 9):
+        assert bool(((a[i] - b[i]).abs() <= 2e-5 * b[i].abs() + 2e-6 * float(b[i].abs().max())).all())

@@ -531,15 +531,16 @@ def test_torch_internals_fallbacks(L, monkeypatch):
         return total.detach().clone(), p1.grad.clone()
 
     def kept_step():
-        step = ops.RegistrationStep(src, tar, nl)
+        tk = tar.clone()  # (its own target: the trainer loops above and below must see the same one)
+        step = ops.RegistrationStep(src, tk, nl)
         R, t = cu(np.stack([_rot((0, 1, 0), 3)] * B)), cu(np.zeros((B, 3), np.float32))
         step(R, t, ln)
-        out = step(R, t, ln)
-        ops.rigid_apply_into(tar.view(B, -1, 3), R, t, tar.view(B, -1, 3))  # raw-pointer write into the kept target
+        out = step(R, t, ln)[0].clone()
+        ops.rigid_apply_into(tk.view(B, -1, 3), R, t, tk.view(B, -1, 3))  # raw-pointer write into the kept target
         new = step(R, t, ln)[0].clone()
-        ref = ops.RegistrationStep(src, tar, nl, prepared=False)(R, t, ln)[0].clone()
-        ops.rigid_apply_into(tar.view(B, -1, 3), R.transpose(1, 2).contiguous(), -torch.einsum("bij,bj->bi", R.transpose(1, 2), t), tar.view(B, -1, 3))
-        return out[0].clone(), new, ref
+        ref = ops.RegistrationStep(src, tk, nl, prepared=False)(R, t, ln)[0].clone()
+        assert not torch.equal(out, new)
+        return out, new, ref
 
     ops.dropin_batch_clear()
     base_loss, base_grad = trainer_loop()
@@ -568,3 +569,71 @@ def test_torch_internals_fallbacks(L, monkeypatch):
     msgs = " ".join(str(w.message) for w in wlist)
     assert "_cuda_getCurrentRawStream" in msgs and "_unsafe_set_version_counter" in msgs and "Tensor._base" in msgs
     assert sum("_cuda_getCurrentRawStream" in str(w.message) for w in wlist) == 1  # one warning per missing symbol
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# round 5: multi-pose evaluation (include/rrl.h rrl_opts.problems) -- the iterative trainers' poses in ONE set of launches
+@pytest.mark.parametrize("Bt,k,n,m,nl,prepared", [(3, 2, 900, 1100, 4000, True), (2, 3, 700, 600, 3000, False),
+                                                  (8, 2, 4096, 4096, 10000, True), (1, 3, 1024, 1024, 20000, True),
+                                                  (2, 2, 500, 400, 800, True), (1, 2, 5000, 4100, 1500, False)])
+def test_multi_pose_equals_pose_after_pose(L, Bt, k, n, m, nl, prepared):
+    """k poses of each of Bt problems as ONE evaluation of k * Bt instances (R, t hold k * Bt poses; source, target, lines
+    and orders have Bt entries; the target is scanned once per problem) against the k evaluations pose after pose (the second
+    and later ones with the target's scan carried over, as the trainers' fragments did until round 4): loss, info, median,
+    bucket sums, hit lists of the sources BIT-identical per instance; (dR, dt) to the rounding of the float atomics; the
+    Chamfer monitor per pose (ops.chamfer_group_means, its walk riding in the scan launch) equals each single evaluation's."""
+    from rrl_hip import ops
+    prs, src, tar = _pairs(600, Bt, n, m)
+    ln = _lines(L, prs, nl)
+    gen = torch.Generator().manual_seed(5)
+    from LieAlgebra import se3
+    Rs, ts = [], []
+    for i in range(k):
+        R, t = se3.exp3(0.04 * torch.randn(Bt, 6, generator=gen))
+        Rs.append(R.cuda().contiguous().requires_grad_(True)); ts.append(t.cuda().contiguous().requires_grad_(True))
+    o1, o2 = (ops.cloud_order(src), ops.cloud_order(tar)) if prepared else (None, None)
+    singles, first = [], None
+    for i in range(k):
+        loss, info, _ = ops.registration_loss(src, Rs[i], ts[i], tar, ln, order1=o1, order2=o2, target_from=first, chamfer=True)
+        st = ops.last_state()
+        first = first or st
+        cham = ops.chamfer_from_state(st).clone()
+        loss.sum().backward()
+        singles.append((loss.detach().clone(), info.clone(), st.med.clone(), st.bsum.clone(), st.count1.clone(),
+                        _hits_sorted(st, 1)[1].clone(), Rs[i].grad.clone(), ts[i].grad.clone(), cham))
+        Rs[i].grad = ts[i].grad = None
+    Rm = torch.cat([r.detach() for r in Rs]).requires_grad_(True)
+    tm = torch.cat([t.detach() for t in ts]).requires_grad_(True)
+    loss, info, _ = ops.registration_loss(src, Rm, tm, tar, ln, order1=o1, order2=o2, chamfer=True)
+    st = ops.last_state()
+    assert loss.shape == (k * Bt,) and st.dims[0] == k * Bt
+    cms = ops.chamfer_group_means(st, k)
+    loss.sum().backward()
+    torch.cuda.synchronize()
+    assert int(st.count2[Bt:].abs().sum()) == 0  # the target was scanned for the first Bt instances only
+    hits1 = _hits_sorted(st, 1)[1]
+    for i in range(k):
+        sl = slice(i * Bt, (i + 1) * Bt)
+        l1, i1, med, bsum, c1, h1, gR, gt, cham = singles[i]
+        assert torch.equal(loss.detach()[sl], l1) and torch.equal(info[sl], i1) and torch.equal(st.med[sl], med)
+        assert torch.equal(st.bsum[sl], bsum) and torch.equal(st.count1[sl], c1) and torch.equal(hits1[sl], h1)
+        for got, want in ((Rm.grad[sl], gR), (tm.grad[sl], gt)):
+            assert bool(((got - want).abs() <= 2e-5 * want.abs() + 2e-6 * float(want.abs().max())).all())
+        assert abs(float(cms[i]) - float(cham)) <= 1e-6 * max(1e-6, abs(float(cham)))
+    assert int((info[:, 0] > 0).sum()) == k * Bt
+
+
+def test_multi_pose_argument_errors(L):
+    from rrl_hip import ops, RRLError
+    prs, src, tar = _pairs(610, 2, 300, 280)
+    ln = _lines(L, prs, 1500)
+    R = cu(np.stack([np.eye(3, dtype=np.float32)] * 4)); t = cu(np.zeros((4, 3), np.float32))
+    assert ops.registration_loss(src, R, t, tar, ln)[0].shape == (4,)
+    with pytest.raises(ValueError):  # 3 poses for 2 problems
+        ops.registration_loss(src, R[:3], t[:3], tar, ln)
+    with pytest.raises(ValueError):  # a dense scan mode
+        ops.registration_loss(src, R, t, tar, ln, mode="strict")
+    s2 = src.clone().requires_grad_(True)
+    out = ops.registration_loss(s2, R.clone().requires_grad_(True), t, tar, ln)[0]
+    with pytest.raises(RRLError, match="multi-pose"):
+        out.sum().backward()
