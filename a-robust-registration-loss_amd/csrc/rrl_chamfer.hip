@@ -257,3 +257,31 @@ extern "C" int rrl_chamfer_from_loss(void *ws_src, const void *ws_tar, size_t lo
     return rrl_chamfer_from_loss_ex(ws_src, ws_tar, loss_ws_bytes, B, N, M, L, ws, ws_bytes, best_x, best_y, value,
                                     (uint64_t *)g_cham_counters, g_cham_counter_rows, stream);
 }
+
+// G group means of ONE walk (include/rrl.h rrl_chamfer_group_means): the walk leaves the sum of every (sample, direction)
+// in its workspace (GPART [2 B] doubles, index 2 b + direction: chamfer_tree_body's second-level partials); group g =
+// samples [g B / G, (g + 1) B / G).  One wavefront per group, fixed-order double sums.
+__global__ __launch_bounds__(64) void chamfer_group_mean_kernel(const double *__restrict__ gpart, float *__restrict__ values,
+                                                                int per, double denom) {
+    __shared__ double red[64];
+    const int g = blockIdx.x, lane = threadIdx.x;
+    double acc = 0.0;
+    for (int i = lane; i < 2 * per; i += 64) acc += gpart[(size_t)2 * per * g + i];
+    red[lane] = acc;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    for (int o = 32; o > 0; o >>= 1) {
+        if (lane < o) red[lane] += red[lane + o];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+    if (lane == 0) values[g] = (float)(red[0] / denom);
+}
+extern "C" int rrl_chamfer_group_means(const void *cham_ws, size_t cham_ws_bytes, float *values, int G, int B, int N, int M,
+                                       void *stream) {
+    if (!cham_ws || !values || G <= 0 || B <= 0 || B % G || N < 0 || M < 0 || N + M == 0) return RRL_E_ARG;
+    const ChamLayout C(B, N, M);
+    if (cham_ws_bytes < C.total) return RRL_E_WS;
+    hipLaunchKernelGGL(chamfer_group_mean_kernel, dim3((unsigned)G), dim3(64), 0, (hipStream_t)stream,
+                       (const double *)((const char *)cham_ws + C.gpart), values, B / G, (double)(B / G) * (double)(N + M));
+    RRL_LAUNCH_CHECK();
+    return 0;
+}

@@ -376,34 +376,6 @@ __global__ __launch_bounds__(1024) void chamfer_mean_kernel(const unsigned long 
     if (threadIdx.x == 0) value[0] = (float)(red[0] / (double)(nx + ny));
 }
 
-// G group means from the keys of one evaluation over G x Bg samples (include/rrl.h rrl_chamfer_group_means): the multi-pose
-// evaluation's monitor per ITERATION (rpm/Train_RPM.py:223-224 logs chamfer_dist of every iteration's moved source)
-__global__ __launch_bounds__(1024) void chamfer_group_mean_kernel(const unsigned long long *__restrict__ bx,
-                                                                  const unsigned long long *__restrict__ by,
-                                                                  float *__restrict__ values, long nx, long ny) {
-    __shared__ double red[1024];
-    const long g = blockIdx.x;
-    bx += g * nx; by += g * ny;
-    double s = 0.0;
-    for (long i = threadIdx.x; i < nx; i += 1024) s += (double)__uint_as_float((unsigned)(bx[i] >> 32));
-    for (long i = threadIdx.x; i < ny; i += 1024) s += (double)__uint_as_float((unsigned)(by[i] >> 32));
-    red[threadIdx.x] = s;
-    __syncthreads();
-    for (int o = 512; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) values[g] = (float)(red[0] / (double)(nx + ny));
-}
-extern "C" int rrl_chamfer_group_means(const uint64_t *best_x, const uint64_t *best_y, float *values, int G, long long nx,
-                                       long long ny, void *stream) {
-    if (!best_x || !best_y || !values || G <= 0 || nx < 0 || ny < 0 || nx + ny == 0) return RRL_E_ARG;
-    hipLaunchKernelGGL(chamfer_group_mean_kernel, dim3((unsigned)G), dim3(1024), 0, (hipStream_t)stream,
-                       (const unsigned long long *)best_x, (const unsigned long long *)best_y, values, (long)nx, (long)ny);
-    RRL_LAUNCH_CHECK();
-    return 0;
-}
-
 extern "C" int rrl_chamfer_fwd(const float *x, const float *y, uint64_t *best_x, uint64_t *best_y,
                                float *value, int B, int N, int M, void *stream) {
     if (!x || !y || !best_x || !best_y || !value || B < 0 || N < 0 || M < 0) return RRL_E_ARG;

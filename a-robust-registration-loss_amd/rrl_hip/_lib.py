@@ -54,7 +54,7 @@ _SIGS = {
     "rrl_scan_timing_collect": [_P, _I],
     "rrl_scan_counters": [_P, _c.c_longlong],
     "rrl_chamfer_counters": [_P, _c.c_longlong],
-    "rrl_chamfer_group_means": [_P, _P, _P, _I, _c.c_longlong, _c.c_longlong, _P],
+    "rrl_chamfer_group_means": [_P, _Z, _P, _I, _I, _I, _I, _P],
     "rrl_rigid_apply_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "rrl_rigid_bwd_blocks": [_I],
     "rrl_rigid_apply_bwd": [_P] * 7 + [_I] * 4 + [_P],

@@ -164,25 +164,66 @@ def per_sample_loss(src_nb, R, t, tar_tri, lines, mode=None, target_from=None, d
 MULTI_POSE = os.environ.get("RRL_MULTI_POSE", "1") != "0"  # the iterative trainers' poses in ONE evaluation (round 5)
 
 
-def multi_pose_loss(src_nb, Rs, ts, tar_tri, lines, mode=None, data=None, chamfer=False):
-    """The iterative trainers' loop over poses as ONE evaluation (include/rrl.h rrl_opts.problems): Rs / ts are the k
-    per-iteration (B, 3, 3) / (B, 3) estimates -- all known before the first loss call (rpm/Train_RPM.py:207-231,
-    fmr/model.py:292-308) --, target and lines are shared.  Returns ([loss_i (B,)], [valid_i (B,) bool]) per iteration,
-    bit-identical to per_sample_loss pose after pose (target scanned once, the k source scans side by side, one per-line
-    stage, one reduce + backward), or None where the multi-pose path does not serve the call (clouds beyond the sort
-    capacity, a scan mode other than cull, RRL_MULTI_POSE=0): the caller then loops.
-    chamfer: the walk of the evaluation's monitor rides in its scan launch over all k * B instances (_monitor_groups)."""
-    k = len(Rs)
+class _PackedPoses(torch.autograd.Function):
+    """k x B poses given as ONE (k, B, 3, 4) tensor [R | t] -> loss (k * B,), info (k * B, 4): the multi-pose evaluation
+    (ops.registration_loss with k * B poses for B problems) behind a node that takes and returns the PACKED transforms --
+    the fragment's own torch ops shrink to a stack in front and one product + sum behind (the fragments' device time was
+    half tiny torch kernels: 40 launches of ~2 us around 6 of ours; eager, their host time dominates)."""
+
+    @staticmethod
+    def forward(ctx, P, src_tri, tar_tri, lines, o1, o2, ride):
+        k, B = P.shape[:2]
+        Pd = P.detach().reshape(k * B, 3, 4)
+        R = Pd[:, :, :3].contiguous().requires_grad_(True)
+        t = Pd[:, :, 3].contiguous().requires_grad_(True)
+        with torch.enable_grad():
+            loss, info, _ = _ops.registration_loss(src_tri, R, t, tar_tri, lines, RNG, transpose_r=True, mode="cull",
+                                                   order1=o1, order2=o2, chamfer=ride)
+        ctx.inner, ctx.shape = (loss, R, t), P.shape
+        ctx.mark_non_differentiable(info)
+        ctx.set_materialize_grads(False)
+        return loss.detach(), info
+
+    @staticmethod
+    def backward(ctx, g, _gi):
+        if g is None:
+            return (None,) * 7
+        loss, R, t = ctx.inner
+        gR, gt = torch.autograd.grad([loss], [R, t], [g])
+        return torch.cat([gR, gt.unsqueeze(-1)], -1).reshape(ctx.shape), None, None, None, None, None, None
+
+
+_weights = {}  # (values, B, device) -> (k * B,) per-instance weights of a fragment's discounted sum
+
+
+def _instance_weights(per_pose, B, dev):
+    key = (tuple(per_pose), B, str(dev))
+    w = _weights.get(key)
+    if w is None:
+        if len(_weights) > 64:
+            _weights.clear()
+        w = _weights[key] = torch.tensor(per_pose, dtype=torch.float32).repeat_interleave(B).to(dev)
+    return w
+
+
+def multi_pose_loss(src_nb, transforms, tar_tri, lines, mode=None, data=None, chamfer=False):
+    """The iterative trainers' loop over poses as ONE evaluation (include/rrl.h rrl_opts.problems): `transforms` are the k
+    per-iteration (B, 3, 4) / (B, 4, 4) estimates [R | t] -- all known before the first loss call (rpm/Train_RPM.py:207-231,
+    fmr/model.py:292-308) --, target and lines are shared.  Returns (loss (k * B,) -- instance i * B + b = pose i of sample
+    b, differentiable back into every transform --, valid (k, B) bool), bit-identical per instance to per_sample_loss pose
+    after pose (target scanned once, the k source scans side by side, one per-line stage, one reduce + backward); or None
+    where the multi-pose path does not serve the call (clouds beyond the sort capacity, a scan mode other than cull,
+    RRL_MULTI_POSE=0): the caller then loops.
+    chamfer: the walk of the evaluation's monitor rides in its scan launch over all k * B instances (ops.chamfer_group_means)."""
+    k = len(transforms)
     B = src_nb.shape[0]
     src_tri, tar_tri = src_nb.reshape(B, -1, 9), tar_tri.reshape(B, -1, 9)
     if not MULTI_POSE or k < 2 or _mode(mode) != "cull" or max(src_tri.shape[1], tar_tri.shape[1]) > _SORT_CAP:
         return None
     o1, o2 = _orders(data, src_tri.shape[1], tar_tri.shape[1], B, src_tri.device if src_tri.is_cuda else None)
-    R, t = torch.cat([r.reshape(B, 3, 3) for r in Rs]), torch.cat([x.reshape(B, 3) for x in ts])
-    loss, info, _ = _ops.registration_loss(src_tri, R, t, tar_tri, lines, RNG, transpose_r=True, mode="cull",
-                                           order1=o1, order2=o2, chamfer=bool(chamfer))
-    ok = info[:, 0] > 0
-    return [loss[i * B:(i + 1) * B] for i in range(k)], [ok[i * B:(i + 1) * B] for i in range(k)]
+    P = torch.stack([x[..., :3, :] for x in transforms])  # (k, B, 3, 4)
+    loss, info = _PackedPoses.apply(P, src_tri, tar_tri, lines, o1, o2, bool(chamfer))
+    return loss, (info[:, 0] > 0).view(k, B)
 
 
 def _split(transform):
@@ -204,30 +245,29 @@ def rpm_intersection_loss(pred_transforms, data, n_lines=10000, lines=None, mode
     per_iter, chamfers, valid = [], [], []
     first = None  # LossState of iteration 0: target + lines are the same in every iteration
     if num_iter > 1:  # all poses are known up front: ONE evaluation of num_iter * B instances (round 5, multi_pose_loss)
-        Rs, ts = zip(*(_split(p) for p in pred_transforms))
         moved0 = None
         if lines is None:
-            moved0 = _ops.rigid_apply(src, Rs[0], ts[0], transpose_r=True)
+            moved0 = _ops.rigid_apply(src, *_split(pred_transforms[0]), transpose_r=True)
             lines = draw_lines(bounding_radius(data['tar_box']), data['centers'], n_lines, moved0.detach(), tar)
-        ride = _ride_monitor(data)
-        got = multi_pose_loss(data['points_based_neighs_src'], Rs, ts, tar_tri, lines, mode, data=data, chamfer=ride)
+        got = multi_pose_loss(data['points_based_neighs_src'], pred_transforms, tar_tri, lines, mode, data=data,
+                              chamfer=_ride_monitor(data))
         if got is not None:
-            losses, oks = got
+            loss, ok = got
             st = _ops.last_state()
+            disc = [0.5 ** (num_iter - ni - 1) for ni in range(num_iter)]
             own = CHAMFER_FROM_LOSS and max(st.dims[1], st.dims[2]) <= _SORT_CAP and st.dims[1] == src.shape[1] and \
                 st.dims[2] == tar.shape[1] and (CHAMFER_FROM_LOSS is True or _first_points_contract(data))
             if own:  # the monitor of every iteration from the evaluation's own clouds (the walk rode in its scan launch)
-                cms = _ops.chamfer_group_means(st, num_iter)
-                chamfers = [cms[ni] for ni in range(num_iter)]
+                cham = (_ops.chamfer_group_means(st, num_iter) * _instance_weights(disc, 1, loss.device)).sum()
             else:
-                chamfers = [_ops.chamfer(tar, (moved0 if (ni == 0 and moved0 is not None) else
-                                               _ops.rigid_apply(src, Rs[ni], ts[ni], transpose_r=True))).detach()
-                            for ni in range(num_iter)]
-            per_iter = [l.sum().reshape(1) / num_iter for l in losses]
-            disc = [0.5 ** (num_iter - ni - 1) for ni in range(num_iter)]
-            return {'loss_intersection': sum(l * d for l, d in zip(per_iter, disc)),
-                    'loss_chamfer': sum(c * d for c, d in zip(chamfers, disc)),
-                    'per_iter': per_iter, 'lines': lines, 'valid': torch.stack(oks)}
+                cham = sum(_ops.chamfer(tar, (moved0 if (ni == 0 and moved0 is not None) else
+                                              _ops.rigid_apply(src, *_split(pred_transforms[ni]), transpose_r=True))).detach() * disc[ni]
+                           for ni in range(num_iter))
+            # sum_i disc_i (sum_b loss[i, b]) / num_iter as ONE weighted sum; the per-iteration values (reporting) detached
+            total = (loss * _instance_weights([d / num_iter for d in disc], B, loss.device)).sum().reshape(1)
+            per = loss.detach().view(num_iter, B).sum(1) / num_iter
+            return {'loss_intersection': total, 'loss_chamfer': cham,
+                    'per_iter': [per[ni:ni + 1] for ni in range(num_iter)], 'lines': lines, 'valid': ok}
     for ni in range(num_iter):
         R, t = _split(pred_transforms[ni])
         moved = _ops.rigid_apply(src, R, t, transpose_r=True)
@@ -284,18 +324,16 @@ def fmr_intersection_loss(g_series, data, n_lines=15000, lines=None, last=3, mod
     total, valid, first = 0.0, [], None
     idx = list(range(max(maxiter - last, 0), maxiter))
     if len(idx) > 1:  # the last estimates as ONE evaluation (round 5, multi_pose_loss)
-        Rs, ts = zip(*(_split(g_series[i]) for i in idx))
-        ride = _ride_monitor(data)
-        got = multi_pose_loss(data['points_based_neighs_src'], Rs, ts, tar_tri, lines, mode, data=data, chamfer=ride)
+        got = multi_pose_loss(data['points_based_neighs_src'], [g_series[i] for i in idx], tar_tri, lines, mode, data=data,
+                              chamfer=_ride_monitor(data))
         if got is not None:
-            losses, oks = got
+            loss, ok = got
             st = _ops.last_state()
-            for i, l in zip(idx, losses):
-                total = total + (l / 5.0).sum().reshape(1) * 0.5 ** (maxiter - i - 1)
+            w = _instance_weights([0.5 ** (maxiter - i - 1) / 5.0 / B for i in idx], B, loss.device)
             own = CHAMFER_FROM_LOSS and max(st.dims[1], st.dims[2]) <= _SORT_CAP and st.dims[1] == moved.shape[1] and \
                 st.dims[2] == tar.shape[1] and (CHAMFER_FROM_LOSS is True or _first_points_contract(data))
             cham = _ops.chamfer_group_means(st, len(idx))[-1] if own else _ops.chamfer(tar, moved)  # the LAST estimate's monitor
-            return total / B, cham, lines, torch.stack(oks)
+            return (loss * w).sum().reshape(1), cham, lines, ok
     for i in range(maxiter - last, maxiter):
         R, t = _split(g_series[i])
         loss, ok = per_sample_loss(data['points_based_neighs_src'], R, t, tar_tri, lines, mode, first, data=data,

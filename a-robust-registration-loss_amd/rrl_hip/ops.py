@@ -1382,17 +1382,31 @@ def chamfer_from_state(state=None, keys=False):
 
 def chamfer_group_means(state=None, groups=1):
     """The Chamfer monitor of a MULTI-POSE evaluation per pose: (groups,) means over the evaluation's instances
-    [g * B_t, (g + 1) * B_t) -- what chamfer_from_state would return for each pose evaluated on its own.  From the keys of
-    the walk that rode in the evaluation's scan launch (one small launch), or of chamfer_from_state otherwise."""
+    [g * B_t, (g + 1) * B_t) -- what chamfer_from_state returns for each pose evaluated on its own.  From the
+    per-(sample, direction) sums the walk left in its workspace (include/rrl.h rrl_chamfer_group_means: one tiny launch) --
+    the walk that rode in the evaluation's scan launch, else one run now."""
     st = state or _IntersectionLoss.last_state
     if st is None:
         raise ValueError("no loss evaluation to take the clouds from")
-    _, bx, by = chamfer_from_state(st, keys=True)
-    B, N, M = st.dims[:3]
+    B, N, M, L, _ = st.dims
     if B % groups:
         raise ValueError("groups must divide the evaluation's instances")
-    out = torch.empty(groups, device=bx.device)
-    _run(bx.device, "rrl_chamfer_group_means", _p(bx), _p(by), _p(out), int(groups), (B // groups) * N, (B // groups) * M)
+    dev = st.ws.device
+    ride = getattr(st, "cham_ride", None)
+    if ride is not None:
+        ws = ride.ws
+    else:
+        tar = getattr(st, "target_state", None) or st
+        nb = _chamfer_ws_bytes.get((B, N, M))
+        if nb is None:
+            nb = _chamfer_ws_bytes[(B, N, M)] = int(_lib.load().rrl_chamfer_workspace_bytes(B, N, M))
+        ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+        bx = torch.empty(B, N, dtype=torch.int64, device=dev)
+        by = torch.empty(B, M, dtype=torch.int64, device=dev)
+        val = torch.empty(1, device=dev)
+        _run(dev, "rrl_chamfer_from_loss", _p(st.ws), _p(tar.ws), st.nbytes, B, N, M, L, _p(ws), nb, _p(bx), _p(by), _p(val))
+    out = torch.empty(groups, device=dev)
+    _run(dev, "rrl_chamfer_group_means", _p(ws), ws.numel(), _p(out), int(groups), B, N, M)
     return out
 
 

@@ -587,10 +587,11 @@ int rrl_chamfer_from_loss(void *ws_src, const void *ws_tar, size_t loss_ws_bytes
  * are dropped; cleared by the caller): [0] patch-level leaf tests, [1] per-lane leaf tests, [2] (query, leaf)
  * entries evaluated, [3] (query, target) pairs evaluated, [4] 1, [5..7] / [9..14] shader clocks of the phases. */
 int rrl_chamfer_counters(uint64_t *dev_counters, long long rows);
-/* values[g] = the Chamfer mean (code/loss.py:249-252) over group g of the keys of ONE evaluation: best_x [G][nx], best_y [G][ny]
- * (nx = samples per group x N, ny = ... x M) -- the monitor per ITERATION of a multi-pose evaluation (rrl_opts.problems:
- * group g = pose g of every problem; rpm/Train_RPM.py:223-224 logs the distance of every iteration's moved source). */
-int rrl_chamfer_group_means(const uint64_t *best_x, const uint64_t *best_y, float *values, int G, long long nx, long long ny,
+/* values[g] = the Chamfer mean (code/loss.py:249-252) over samples [g B / G, (g + 1) B / G) of the evaluation whose walk
+ * (rrl_chamfer_from_loss / _ex, or the rider of an `_ex` forward) ran on the Chamfer workspace cham_ws -- the monitor per
+ * ITERATION of a multi-pose evaluation (rrl_opts.problems: group g = pose g of every problem; rpm/Train_RPM.py:223-224 logs
+ * the distance of every iteration's moved source).  From the per-(sample, direction) sums the walk left in cham_ws. */
+int rrl_chamfer_group_means(const void *cham_ws, size_t cham_ws_bytes, float *values, int G, int B, int N, int M,
                             void *stream);
 /* The two tree-walk entries with the counter table given PER CALL (NULL: the plain kernel) instead of through the
  * process-wide hook above: two threads / streams can profile independently.  rrl_chamfer_tree_fwd_ex also takes

@@ -145,7 +145,8 @@ def test_fragments_monitor_from_the_loss_state(C, G):
             _, chamfer, _, _ = C.fmr_intersection_loss(gs, data_dict(G), lines=cu(G["fmr_lines"]))
             np.testing.assert_allclose(chamfer.item(), G["fmr_chamfer"], rtol=1e-5)
             # (round 5: RPM's iterations are one multi-pose evaluation -- one look at its state serves all of them)
-            assert calls["plain"] == 0 and calls["state"] == (1 if C.MULTI_POSE and len(pred) > 1 else len(pred)) + 2
+            assert calls["plain"] == 0 and calls["state"] == (0 if C.MULTI_POSE and len(pred) > 1 else len(pred)) + \
+                (1 if C.MULTI_POSE else 2)  # (DCP: one look at its state; FMR's estimates: group means of the walk's own sums)
         # a batch whose samples are NOT the triangles' first points: auto takes the standalone kernel, same value
         C.CHAMFER_FROM_LOSS = "auto"
         calls["state"] = calls["plain"] = 0
@@ -542,9 +543,10 @@ def test_fragments_multi_pose_equals_the_loop(C, G):
         finally:
             C.MULTI_POSE = True
     a, b = outs[True], outs[False]
-    for x, y in zip(a[0], b[0]):
-        assert torch.equal(x, y)
-    assert torch.equal(a[1], b[1]) and torch.equal(a[3], b[3]) and torch.equal(a[6], b[6]) and torch.equal(a[8], b[8])
+    rel = lambda x, y: float((x - y).abs().max()) <= 1e-6 * float(y.abs().max())  # noqa: E731 (sums of bit-identical instance
+    for x, y in zip(a[0], b[0]):                                                   #  losses, associated differently)
+        assert rel(x, y)
+    assert rel(a[1], b[1]) and torch.equal(a[3].reshape(-1), b[3].reshape(-1)) and rel(a[6], b[6]) and torch.equal(a[8].reshape(-1), b[8].reshape(-1))
     assert abs(float(a[2]) - float(b[2])) <= 1e-6 * abs(float(b[2])) and abs(float(a[7]) - float(b[7])) <= 1e-6 * abs(float(b[7]))
     for i in (4, 5, 9):
         assert bool(((a[i] - b[i]).abs() <= 2e-5 * b[i].abs() + 2e-6 * float(b[i].abs().max())).all())
