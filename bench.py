@@ -248,6 +248,9 @@ def main():
                     help="how the step's launches are issued: the C call of ops.LossStep on the stream (direct), or one "
                          "hipGraph replay of it; auto measures both in warm-up")
     ap.add_argument("--no-extras", action="store_true", help="skip the variant / strict / counter / B=64 passes")
+    ap.add_argument("--no-other", action="store_true",
+                    help="skip the other build of the step (value_cold / value_prepared): profiling passes want the timed "
+                         "step's kernels only")
     ap.add_argument("--no-b64", action="store_true", help="skip roofline.at_B64 (64 synthetic pairs take ~20 s to make)")
     ap.add_argument("--cold", action="store_true",
                     help="time the COLD step: no prepared orders, every step sorts both clouds (records + cell sort + tree)")
@@ -442,7 +445,7 @@ def main():
         grad_default = ls.grad.clone()
         # the OTHER build of the same step, always measured (round-over-round comparisons use the cold number): this rank's
         # step without the all-reduce
-        if can_prepare:
+        if can_prepare and not args.no_other:
             lo_ = loss_step(not prepared)
             oms, oout = time_loop(lambda: lo_(Rd, Td, w["lines"]), args.steps)
             other = {"ms_per_step": oms, "value": pairs_step / (oms * 1e-3), "unit": "point-pairs/s (this rank, no all-reduce)",

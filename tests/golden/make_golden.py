@@ -390,6 +390,53 @@ def callsites():
     save("callsites.npz", **out)
 
 
+def callsites_moved():
+    """The TIGHT W check inside the fragment fixtures (round 5): callsites.npz stores the trainers'
+    inputs and the reference's results, but not the reference's MOVED pseudo-triangles -- the build moves the source on
+    the GPU (x R^T + t with FMAs) while the reference's BLAS matmul rounds differently, an ulp in a vertex can flip a
+    borderline label, and the end-to-end fragment tests therefore compare at 2e-4.  SURVEY 8a-R defines W's parity "on
+    identical transformed inputs": this fixture adds, for the RPM fragment of callsites.npz (same seeds: the poses, lines and
+    per-sample values are re-derived and checked against that file), the reference's moved triangles of every iteration, its
+    per-line hit counts on them (labels), its per-sample loss and the gradient dL/dpoints1 -- so the HIP loss can be checked
+    at 1e-5 / label-exact on exactly the reference's inputs, separating "FMA in the rigid apply" from anything else."""
+    old = np.load(os.path.join(HERE, "callsites.npz"))
+    B, n, nl, num_iter = 3, 256, 3000, 3
+    src_nb, tar_nb = t(old["nb_src"]), t(old["nb_tar"])
+    Rs, ps = t(old["R"]), t(old["t"])
+    lines = t(old["rpm_lines"])
+    tar_tri = tar_nb.reshape(B, -1, 9)
+
+    def move(x, R, p):
+        return x @ R.transpose(-1, -2) + p[:, None, :]
+
+    moved, per_sample, grads, c1s, c2s = [], [], [], [], None
+    for ni in range(num_iter):
+        tri = move(src_nb, Rs[ni], ps[ni]).reshape(B, -1, 9).detach().clone().requires_grad_(True)
+        row = []
+        acc = torch.zeros(1)
+        for j in range(B):
+            lj = RL.cal_loss_intersection_batch_whole_median_pts_lines(
+                1, 1, 5, 5, tri[j:j + 1], tar_tri[j:j + 1], lines[j:j + 1], "cpu")
+            row.append(lj.item())
+            acc = acc + lj
+        acc.backward()
+        moved.append(tri.detach().numpy().copy())
+        grads.append(tri.grad.numpy().copy())
+        per_sample.append(row)
+        c1s.append(np.stack([ref_scan(tri[j].detach().numpy(), lines[j].numpy())["count"] for j in range(B)]))
+    c2s = np.stack([ref_scan(tar_tri[j].numpy(), lines[j].numpy())["count"] for j in range(B)])
+    per_sample = np.array(per_sample, np.float32)
+    assert np.array_equal(per_sample, old["rpm_per_sample"]), (per_sample, old["rpm_per_sample"])  # the same fragment
+    mg = min(margin(moved[ni][j], lines[j].numpy()) for ni in range(num_iter) for j in range(B))
+    np.savez_compressed(os.path.join(HERE, "callsites_moved.npz"), moved_tri=np.stack(moved).astype(np.float32),
+                        grad_tri=np.stack(grads).astype(np.float32), per_sample=per_sample,
+                        count1=np.stack(c1s).astype(np.int16), count2=c2s.astype(np.int16), margin=np.float64(mg),
+                        **{k: np.array(str(v)) for k, v in META.items()})
+    print("callsites_moved: per-sample", per_sample.tolist(), "margin %.3g" % mg,
+          "selected lines / sample", [[int(((c1s[ni][j] >= 1) & (c1s[ni][j] <= 4) & (c2s[j] >= 1) & (c2s[j] <= 4)).sum())
+                                       for j in range(B)] for ni in range(num_iter)])
+
+
 def demo_trajectory():
     """test_demo_optimized_Lie_Algebra.py:27-75 (test_one_case) replayed with the reference's
     modules for a few epochs on a small synthetic pair; the sampled lines of every epoch are
@@ -604,6 +651,6 @@ def demo_trajectory_airplane():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["main", "neighs", "callsites", "demo_trajectory", "dataset", "accept", "refdata",
-                             "demo_trajectory_airplane", "refdata_rest"]
+                             "demo_trajectory_airplane", "refdata_rest", "callsites_moved"]
     for name in which:
         globals()[name]()

@@ -93,6 +93,41 @@ def test_dcp_fragment(C, G):
     close_grad(t.grad, G["dcp_grad_t"])
 
 
+def test_fragment_loss_on_the_references_moved_triangles(C, G):
+    """The TIGHT W check of the fragments (round 5): tests/golden/callsites_moved.npz holds the reference's MOVED
+    pseudo-triangles of every RPM iteration, its labels (per-line hit counts), per-sample losses and dL/dpoints1.  On those
+    identical inputs -- SURVEY 8a-R's definition of W's parity -- the HIP loss is label-exact and within 1e-5 per sample (the
+    end-to-end fragment checks above stay at 2e-4: there the source is moved on the GPU with FMAs, an ulp in a vertex may
+    flip a borderline label).  All three entries that evaluate given triangles: the batched op, the section-8(d) step with
+    R = t = None, and the reference-signature per-sample call."""
+    import loss as L
+    from conftest import merge_by_point
+    from rrl_hip import ops
+    M_ = load_golden("callsites_moved.npz")
+    assert M_["margin"] > 1e-5
+    B = G["nb_tar"].shape[0]
+    tar_tri, lines = cu(G["nb_tar"]).reshape(B, -1, 9), cu(G["rpm_lines"])
+    for ni in range(M_["moved_tri"].shape[0]):
+        tri = cu(M_["moved_tri"][ni], True)
+        loss, info, _ = ops.intersection_loss(tri, tar_tri, lines)
+        st = ops.last_state()
+        np.testing.assert_array_equal(st.count1.cpu().numpy(), M_["count1"][ni])   # labels: exact
+        np.testing.assert_array_equal(st.count2.cpu().numpy(), M_["count2"])
+        np.testing.assert_allclose(loss.detach().cpu().numpy(), M_["per_sample"][ni], rtol=1e-5)
+        loss.sum().backward()
+        step = ops.LossStep(tri.detach(), tar_tri, lines.shape[1])
+        sl, sg, _ = step(None, None, lines)
+        assert torch.equal(sl, loss.detach())
+        for j in range(B):
+            ref = merge_by_point(M_["moved_tri"][ni, j], M_["grad_tri"][ni, j])
+            for got in (tri.grad[j], sg[j]):
+                mine = merge_by_point(M_["moved_tri"][ni, j], got.cpu().numpy())
+                np.testing.assert_allclose(mine, ref, rtol=1e-4, atol=1e-5 * np.abs(ref).max())
+            one = L.cal_loss_intersection_batch_whole_median_pts_lines(1, 1, 5, 5, tri.detach()[j:j + 1], tar_tri[j:j + 1],
+                                                                       lines[j:j + 1], "cuda")
+            np.testing.assert_allclose(one.item(), M_["per_sample"][ni, j], rtol=1e-5)
+
+
 def test_fmr_fragment(C, G):
     R, t = cu(G["R"], True), cu(G["t"], True)
     bottom = torch.tensor([0.0, 0, 0, 1], device='cuda').expand(R.shape[1], 1, 4)

@@ -64,8 +64,18 @@ def run(name, B, N, M, L, crop=False, noise=0.01, diag=None):
         for _ in range(n): rs(Rd, td, ln)
         torch.cuda.synchronize(); times[prepared] = (time.perf_counter() - t0) / n
     dd = times[True]
+    # SURVEY 8(d)'s step (bench.py's timed step since round 5): ops.LossStep -> rrl_loss_step_ex, backward to points1.grad
+    ltimes = {}
+    for prepared in (True, False):
+        ls = ops.LossStep(src, tar, L, transpose_r=True, mode=os.environ.get("RRL_SCAN_MODE", "cull"), prepared=prepared,
+                          src_order=o1 if prepared else None, tar_order=o2 if prepared else None)
+        for _ in range(10): ls(Rd, td, ln)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(n): ls(Rd, td, ln)
+        torch.cuda.synchronize(); ltimes[prepared] = (time.perf_counter() - t0) / n
     print(json.dumps({"mode": os.environ.get("RRL_SCAN_MODE", "cull"), "config": name, "B": B, "N": N, "M": M, "L": L, "us_per_step": round(dt * 1e6, 1),
                       "us_per_step_direct": round(dd * 1e6, 1), "us_per_step_direct_cold": round(times[False] * 1e6, 1),
+                      "us_per_loss_step_8d": round(ltimes[True] * 1e6, 1), "us_per_loss_step_8d_cold": round(ltimes[False] * 1e6, 1),
                       "pairs_per_s": pairs / dt, "selected_lines": int(g.out[1][:, 1].sum()),
                       "loss0": float(g.out[0][0]), "filled_lines": int((ln.abs().sum(-1) > 0).sum()),
                       "fallback_wavefronts": int(ops.last_state().status[1])}))
