@@ -754,810 +754,70 @@ __global__ __launch_bounds__(256) void big_sphere_kernel(const BuildArgs a) {
 typedef const float __attribute__((address_space(4))) * kptr;  // constant AS -> s_load
 typedef const int __attribute__((address_space(4))) * kiptr;
 
-#ifndef SPW
-#define SPW 8      // supergroups per slice (<= 16: SG_BITS); staged once per workgroup
-#endif
-#define SG_BITS 4              // queue entries: line << SG_BITS | supergroup of the slice,
-#define HF_BITS (SG_BITS + 3)  //                line << HF_BITS | half of the slice (7 + 7 bits: 16-bit entries)
-static_assert(SPW <= (1 << SG_BITS), "slot bits of the queue entries");
-#ifndef WPB
-#define WPB 8      // wavefronts per workgroup: same slice, LPW lines each
-#endif
-#define LPW 128    // lines per wavefront (two per lane in level A)
-#ifndef ROWS
-#define ROWS 17    // float4 per staged group row: 16 records + 16 bytes of padding (bank spread)
-#endif
-#ifndef WCCAP
-#define WCCAP 128  // parked point-0 candidates per wave
-#endif
-// queue capacities.  Level A leaves ALL of a wavefront's (line, supergroup) pairs in queue A at once when they fit
-// (~128 of the 1024 possible; otherwise supergroup by supergroup with drains in between); level B pops 64 of them
-// and pushes their passing halves (~1.4 of 8 each, at most 512: split then) on top of < 64 left-overs of queue C.
-#ifndef QA_CAP
-#define QA_CAP 256
-#endif
-#ifndef QC_CAP
+// The two geometry variants of the culled scan (rrl_cull_scan.inc): same source, two sets of compile-time knobs.
+namespace scan8 {
+#include "rrl_cull_scan.inc"
+}
+#undef SPW
+#undef SG_BITS
+#undef HF_BITS
+#undef WPB
+#undef LPW
+#undef ROWS
+#undef WCCAP
+#undef QA_CAP
+#undef QC_CAP
+#undef CULL_REGLINES
+namespace scan16 {
+#define SPW 16
+#define CULL_REGLINES 1
+#define QA_CAP 384
 #define QC_CAP 256
-#endif
-
-#ifndef CULL_REGLINES
-#define CULL_REGLINES 0  // 1 (experiment, round 4; exact on the whole suite, NOT shipped): the wavefront's 128 lines stay in
-#endif                   // REGISTERS (two per lane) and travel between lanes by ds_bpermute instead of 24 KB of LDS per
-//                          workgroup -> 22.6 KB, 62 VGPRs, 4 workgroups = 32 wavefronts per compute unit instead of 3 / 24.
-//                          Measured slower: 28.3 us against 26.8-27.4 at C2, 13.9 against 12.9 at C1, even at B = 64 --
-//                          twelve cross-lane reads per pass cost more than the extra residency returns; the launch is
-//                          paced by each wavefront's own chain of dependent steps, not by the number of resident ones.
-struct WaveCtx {
-#if CULL_REGLINES
-    float v0[6], v1[6];           // this lane's two lines (dir, x0): line `lane` and line `64 + lane` of the wavefront
-#else
-    const float2 *lr;             // this wave's lines in LDS as they lie in memory: 3 float2 per line (dir.xy | dir.z x0.x | x0.yz)
-#endif
-    const float4 *recs;           // LDS: staged records of the slice, [group][ROWS]
-    const float4 *nodes;          // LDS: staged tree nodes of the slice, [supergroup][NODE]
-    unsigned short *qa, *qc;      // LDS queues: line << SG_BITS | sg, line << HF_BITS | half (slice-local)
-    unsigned *cands;              // LDS [WCCAP]
-    const int32_t *idx;           // sorted position -> original triangle index
-    const float *ptri;            // prepared triangles: rows in original order, or -- psorted -- at their sorted positions
-    bool psorted;                 // uniform: the layout of ptri (the prepared build leaves sorted rows)
-    int32_t *cnt, *hit;           // per-line hit count / slots of the cloud
-    int lbase;                    // first line of this wave
-    int pos0;                     // sorted position of the slice's first record
-    int na, nc, ncand;            // wave-uniform fill levels
-    int lane;
-    // executed-work counters of the COUNT instantiation (wave-uniform; see rrl_scan_counters)
-    unsigned tb, tc, td, tcand;   // level-B half-sphere tests, halves that passed, point-0 prefilter tests, resolved candidates
-    int32_t *status;              // NaN flag of the call
-};
-
-// line ll of the wave from its raw 24-byte row: (dir, x0.x) and (x0.y, x0.z)
-struct LineRow {
-    float4 la;
-    float2 lb;
-};
-__device__ __forceinline__ LineRow line_row(const float2 *lr, int ll) {
-    const float2 *p = lr + 3 * ll;
-    const float2 a = p[0], b = p[1], c = p[2];
-    return {make_float4(a.x, a.y, b.x, b.y), c};
+#include "rrl_cull_scan.inc"
 }
-#if CULL_REGLINES
-// Line ll (0 .. 127) of the wavefront from the registers of the lane that holds it: EVERY lane of the wavefront must
-// call (a ds_bpermute reads the registers of active lanes only); lanes without work pass any ll.  Twelve cross-lane
-// reads + six selects instead of three 8-byte LDS reads -- and 24 KB of LDS per workgroup less: 22.3 KB instead of 47.2,
-// so the wavefront limit (8 per SIMD), not LDS, bounds the residency: 4 workgroups per compute unit instead of 3.
-__device__ __forceinline__ LineRow line_get(const WaveCtx &c, int ll) {
-    const int src = (ll & 63) << 2;
-    const bool hi = ll >= 64;
-    float r[6];
-#pragma unroll
-    for (int q = 0; q < 6; ++q) {
-        const int a = __builtin_amdgcn_ds_bpermute(src, __float_as_int(c.v0[q]));
-        const int b = __builtin_amdgcn_ds_bpermute(src, __float_as_int(c.v1[q]));
-        r[q] = __int_as_float(hi ? b : a);
-    }
-    return {make_float4(r[0], r[1], r[2], r[3]), make_float2(r[4], r[5])};
-}
-#endif
+static_assert(scan8::kWPB == scan16::kWPB && scan8::kLPW == scan16::kLPW, "one line tiling for both variants");
 
-// cand = line_in_wave << 16 | sorted triangle position: a triangle whose point 0 passed the conservative
-// prefilter of level D.  The reference's own arithmetic (dist_sq, bit-identical to the strict scan) decides
-// on all three points here.
-__device__ __forceinline__ void resolve_candidate(const WaveCtx &c, unsigned cand, const LineRow &lrw) {
-    const int ll = cand >> 16, spos = cand & 0xffff;
-    const float4 la = lrw.la;
-    const float2 lb = lrw.lb;
-    // original-order rows: one more dependent load for the row index (staging the slice's indices in LDS measured 0.8 us
-    // slower); sorted rows (prepared build): the row sits at the candidate's position and carries its triangle index
-    const int prow = c.psorted ? spos : c.idx[spos];
-    const float4 *q = (const float4 *)(c.ptri + PTRI_STRIDE * (size_t)prow);
-    const float4 r0 = q[0], r1 = q[1], r2 = q[2];  // P0 P1.x | P1.yz P2.xy | P2.z thr2 thr index
-    const int f = __float_as_int(r2.w);
-    const uint32_t thr2 = __float_as_uint(r2.y);
-    const uint32_t x0 = __float_as_uint(dist_sq<float>(r0.x, r0.y, r0.z, la.x, la.y, la.z, la.w, lb.x, lb.y));
-    const uint32_t x1 = __float_as_uint(dist_sq<float>(r0.w, r1.x, r1.y, la.x, la.y, la.z, la.w, lb.x, lb.y));
-    const uint32_t x2 = __float_as_uint(dist_sq<float>(r1.z, r1.w, r2.x, la.x, la.y, la.z, la.w, lb.x, lb.y));
-    // a negative sqrt argument is the reference's NaN (code/loss.py:88-91); candidates are rare
-    if ((x0 | x1 | x2) >= 0x80000000u) atomicOr(&c.status[0], 1);
-    if (max(max(x0, x1), x2) < thr2) {  // sign bit set (negative / NaN) -> huge: never a hit
-        const int l = c.lbase + ll;
-        int pos = atomicAdd(&c.cnt[l], 1);
-        if (pos < RRL_MAX_HITS) c.hit[(size_t)l * RRL_MAX_HITS + pos] = f;
-    }
-}
-
-__device__ __forceinline__ void wave_lds_fence() {
-    // LDS is processed in order per wave; this only stops the compiler from reordering across it
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-}
-
-__device__ __forceinline__ int lane_rank(unsigned long long m) {  // set bits of m below this lane
-    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-}
-
-// Slack of the culling bound (header) for one (cloud, sample) from the maxima over its cullable lines: s = max |dir|^2,
-// o2 = max |x0|^2, pm = max |P|^2.  Every term is monotone in s and o2, so the values cover each admitted line.
-struct CloudSlack {
-    bool ok;       // pm is finite and moderate (else: every wavefront of this cloud takes the strict loop)
-    bool nanwide;  // g > 0: a negative sqrt argument is not excluded at this scale
-    float se;      // slack of the node radii
-    float s0;      // slack of the point-0 prefilter
-};
-// max over the wavefront of NON-NEGATIVE floats (or NaN, which then wins: its bit pattern is the largest) on their bit
-// patterns: v_max_u32 takes the DPP operand directly (the float version needs a canonicalising v_max per step), and
-// the four row results meet in scalar registers.  Every lane receives the result.
-__device__ __forceinline__ float wave_max_nonneg(float v) {
-    unsigned u = __float_as_uint(v);
-#define RRL_DPP_U(x, ctrl) (unsigned)__builtin_amdgcn_update_dpp((int)(x), (int)(x), ctrl, 0xf, 0xf, false)
-    u = max(u, RRL_DPP_U(u, 0xB1)); u = max(u, RRL_DPP_U(u, 0x4E));
-    u = max(u, RRL_DPP_U(u, 0x141)); u = max(u, RRL_DPP_U(u, 0x140));
-#undef RRL_DPP_U
-    const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)u, 0), b = (unsigned)__builtin_amdgcn_readlane((int)u, 16);
-    const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)u, 32), d = (unsigned)__builtin_amdgcn_readlane((int)u, 48);
-    return __uint_as_float(max(max(a, b), max(c, d)));
-}
-// square root / reciprocal for the SLACKS only (never for a label): the hardware approximations (1 ulp), nudged upwards
-// so that the result is >= the exact one -- a slack may be too large by 1e-6 of itself, never too small.  (The IEEE
-// sqrtf / division sequences were ~55 of the ~250 VALU instructions of every wavefront's prologue.)
-__device__ __forceinline__ float sqrt_up(float x) { return __builtin_amdgcn_sqrtf(x) * 1.0000005f; }
-__device__ __forceinline__ float rcp_up(float x) { return __builtin_amdgcn_rcpf(x) * 1.0000005f; }
-
-__device__ __forceinline__ CloudSlack cull_cloud_slack(float s, float o2, float pm) {
-    CloudSlack r;
-    r.ok = pm <= 1.0e11f;  // (false for NaN / inf: non-finite coordinates)
-    const float A2 = (o2 + pm + 2.0f * sqrt_up(o2 * pm)) * 1.00001f;  // (|x0| + max|P|)^2, rounded up
-    const float eta = fmaxf(s - 1.0f, 0.0f) + 2.5e-7f;  // |d|^2 - 1 incl. the rounding of s (<= 3u s)
-    const float x = eta * A2;
-    const float g = 1.8e-6f * A2 - 2e-4f;  // 30u = 1.788e-6
-    r.nanwide = g > 0.0f;
-    // (-0.999 g under the root: a smaller divisor, i.e. a larger quotient; the approximations only add to that)
-    const float se = g > 0.0f ? sqrt_up(g + x) : fminf(sqrt_up(x), x * 0.5f * rcp_up(__builtin_amdgcn_sqrtf(-0.998f * g)));
-    r.se = se * 1.0001f + 1e-12f;
-    r.s0 = 3.0e-6f * A2 + 1.0e-9f;  // 44.2 u A^2 of evaluation error on both sides, rounded up, + an absolute floor
-    return r;
-}
-
-// conservative sphere test of one line against one STAGED tree node (centre, w = (Rs + se)^2 rounded up, or -inf for
-// an empty node; see the culling bound above): the node is kept when  d2 - 4e-6 q <= w,  evaluated as ONE FMA chain
-// whose SIGN BIT says "cannot be reached":  m = (a.d)^2 + (w - 0.999996 |a|^2)  (exactly the negation of the form
-// d2 - 4e-6 q - w; -0 cannot occur, -inf - ... stays negative)
-__device__ __forceinline__ float sphere_margin(const float4 nd, const float4 la, const float2 lb) {
-    const float ax = nd.x - la.w, ay = nd.y - lb.x, az = nd.z - lb.y;
-    const float dot = fmaf(az, la.z, fmaf(ay, la.y, ax * la.x));
-    const float q = fmaf(az, az, fmaf(ay, ay, ax * ax));
-    return fmaf(dot, dot, fmaf(-q, 0.999996f, nd.w));
-}
-
-template <bool COUNT>
-__device__ __forceinline__ void flush_cands(WaveCtx &c) {
-#ifdef CULL_NO_RESOLVE
-    c.ncand = 0;
-    return;
-#endif
-    wave_lds_fence();
-    const int nc = min(c.ncand, WCCAP);
-    if constexpr (COUNT) c.tcand += (unsigned)c.ncand;  // entries past WCCAP were resolved inline: counted here too
-#if CULL_REGLINES
-    for (int i0 = 0; i0 < nc; i0 += 64) {  // uniform trip count: every lane fetches (line_get), the live ones resolve
-        const int i = i0 + c.lane;
-        const unsigned cand = i < nc ? c.cands[i] : 0u;
-        const LineRow lrw = line_get(c, (int)(cand >> 16));
-        if (i < nc) resolve_candidate(c, cand, lrw);
-    }
-#else
-    for (int i = c.lane; i < nc; i += 64) { const unsigned cand = c.cands[i]; resolve_candidate(c, cand, line_row(c.lr, (int)(cand >> 16))); }
-#endif
-    c.ncand = 0;
-}
-
-// all = false: only while at least 64 entries wait (full lanes); all = true: drain.
-
-// level D: pops (line, half) pairs, ONE per lane (8 records = 32 registers in flight), and runs the point-0
-// PREFILTER on the half's 8 records: e = fl(Q(P0)) + c by FMAs, with the staged c = -(thr2 - 2e-4 + slack)
-// (see "Point-0 prefilter" above): 10 operations and one v_alignbit per record instead of the 16 + 3 of
-// the reference's unfused arithmetic.  e < 0 (sign bit) parks the triangle as a candidate; the exact test of
-// all three points happens there (resolve_candidate), on ~3 % of the records.
-template <bool COUNT>
-__device__ __forceinline__ void proc_c(WaveCtx &c, bool all) {
-#ifdef CULL_STOP_C  // timing experiments only (tools/knob_sweep.sh): the level is formed but not run
-    c.nc = 0;
-    return;
-#endif
-    while (c.nc >= 64 || (all && c.nc > 0)) {
-        const int take = min(c.nc, 64), base = c.nc - take;
-        c.nc = base;
-        if constexpr (COUNT) c.td += 8u * (unsigned)take;
-        wave_lds_fence();
-        uint32_t passbits = 0;
-        unsigned lh = 0;  // line << 16 | first sorted position of the half
-#if CULL_REGLINES
-        const unsigned e = c.lane < take ? c.qc[base + c.lane] : 0u;
-        const int ll = e >> HF_BITS, h = e & ((1 << HF_BITS) - 1);
-        const LineRow lrw = line_get(c, ll);  // (every lane)
-        if (c.lane < take) {
-#else
-        if (c.lane < take) {
-            const unsigned e = c.qc[base + c.lane];
-            const int ll = e >> HF_BITS, h = e & ((1 << HF_BITS) - 1);
-            const LineRow lrw = line_row(c.lr, ll);
-#endif
-            const float4 la = lrw.la;
-            const float2 lb = lrw.lb;
-            const float4 *row = c.recs + (h >> 1) * ROWS + (h & 1) * 8;
-#pragma unroll
-            for (int t = 7; t >= 0; --t) {  // record t ends up in bit t
-                const float4 rec = row[t];
-                const float ax = rec.x - la.w, ay = rec.y - lb.x, az = rec.z - lb.y;
-                const float dot = fmaf(az, la.z, fmaf(ay, la.y, ax * la.x));
-                const float q = fmaf(az, az, fmaf(ay, ay, fmaf(ax, ax, rec.w)));
-                const float ev = fmaf(-dot, dot, q);
-                passbits = __builtin_amdgcn_alignbit(passbits, __float_as_uint(ev), 31);  // passbits << 1 | sign(ev)
-            }
-            lh = ((unsigned)ll << 16) | (unsigned)(c.pos0 + h * 8);
-        }
-        while (__any(passbits != 0)) {
-#if CULL_REGLINES
-            if (c.ncand > WCCAP - 64) flush_cands<COUNT>(c);  // uniform: room for this round's <= 64 candidates (no inline resolve)
-#endif
-            const bool has = passbits != 0;
-            const unsigned long long m = __ballot(has);
-            const int t = has ? __ffs(passbits) - 1 : 0;
-            passbits &= passbits - 1;
-            const int pos = c.ncand + lane_rank(m);
-            const unsigned cand = lh + (unsigned)t;
-            if (has) {
-#if CULL_REGLINES
-                c.cands[pos] = cand;
-#else
-                if (pos < WCCAP) c.cands[pos] = cand;
-                else resolve_candidate(c, cand, line_row(c.lr, (int)(cand >> 16)));
-#endif
-            }
-            c.ncand += __popcll(m);
-        }
-        if (c.ncand > WCCAP - 64) flush_cands<COUNT>(c);  // uniform: keep room for the next pass
-    }
-}
-
-// The passing halves of one level-B pass (bit k of `pass`: half 8 sg + k of the lane's entry; e2 = line << HF_BITS |
-// 8 sg) go to queue C.  Usual case: every lane writes its own run of entries behind an exclusive prefix of the
-// counts (one DPP scan instead of eight ballot / rank rounds).  Too many for the queue (dense hits): half by half
-// with drains in between.
-template <bool COUNT>
-__device__ __forceinline__ void push_halves(WaveCtx &c, unsigned pass, unsigned e2) {
-    const int cnt = __popc(pass);
-    const int incl = wave_incl_scan(cnt);
-    const int total = __builtin_amdgcn_readlane(incl, 63);
-    if (total == 0) return;  // uniform
-    if constexpr (COUNT) c.tc += (unsigned)total;
-    if (c.nc + total > QC_CAP) proc_c<COUNT>(c, false);  // leaves < 64
-    if (c.nc + total > QC_CAP) {
-        for (int k = 0; k < 8; ++k) {  // uniform
-            const bool p = (pass >> k) & 1u;
-            const unsigned long long m = __ballot(p);
-            if (m == 0ull) continue;
-            if (c.nc > QC_CAP - 64) proc_c<COUNT>(c, false);
-            if (p) c.qc[c.nc + lane_rank(m)] = (unsigned short)(e2 | (unsigned)k);
-            c.nc += __popcll(m);
-        }
-        return;
-    }
-    int at = c.nc + incl - cnt;
-    while (pass) {
-        const int k = __ffs(pass) - 1;
-        pass &= pass - 1;
-        c.qc[at++] = (unsigned short)(e2 | (unsigned)k);
-    }
-    c.nc += total;
-}
-
-// level B: pops (line, supergroup) pairs, one per lane, and tests the supergroup's EIGHT half spheres directly
-// (round 3: the group level in between -- 4 group tests, then 2 half tests per passing group, 9 tests on average
-// -- cost a whole round of queue passes per wavefront for one test less)
-template <bool COUNT>
-__device__ __forceinline__ void proc_a(WaveCtx &c, bool all) {
-#ifdef CULL_STOP_A
-    c.na = 0;
-    return;
-#endif
-    while (c.na >= 64 || (all && c.na > 0)) {
-        const int take = min(c.na, 64), base = c.na - take;
-        c.na = base;
-        if constexpr (COUNT) c.tb += 8u * (unsigned)take;
-        wave_lds_fence();
-        unsigned fail = 0xffu;  // bit k: half k cannot be reached (idle lanes: none can)
-        unsigned e2 = 0;
-#if CULL_REGLINES
-        const unsigned e = c.lane < take ? c.qa[base + c.lane] : 0u;
-        const int ll = e >> SG_BITS, sg = e & ((1 << SG_BITS) - 1);
-        const LineRow lrw = line_get(c, ll);  // (every lane)
-        if (c.lane < take) {
-#else
-        if (c.lane < take) {
-            const unsigned e = c.qa[base + c.lane];
-            const int ll = e >> SG_BITS, sg = e & ((1 << SG_BITS) - 1);
-            const LineRow lrw = line_row(c.lr, ll);
-#endif
-            const float4 la = lrw.la;
-            const float2 lb = lrw.lb;
-            const float4 *nd = c.nodes + sg * NODE + 5;
-            fail = 0u;
-#pragma unroll
-            for (int k = 7; k >= 0; --k)  // half k ends up in bit k
-                fail = __builtin_amdgcn_alignbit(fail, __float_as_uint(sphere_margin(nd[k], la, lb)), 31);
-            e2 = ((unsigned)ll << HF_BITS) | (unsigned)(8 * sg);
-        }
-        push_halves<COUNT>(c, ~fail & 0xffu, e2);
-    }
-}
-
-// The strict loop of a wavefront that cannot be culled (a line with |dir|^2 > 1 + 1e-6 or non-finite
-// data): ALL pairs of its 128 lines with the records at sorted positions [s0, s1), the reference's
-// semantics, NaN included.  The lane's two lines arrive packed (.x = line l0, .y = line l1).
-__device__ __forceinline__ void strict_slice(const float *ptri, const int32_t *idx, bool psorted, int s0, int s1, v2f ux,
-                                                       v2f uy, v2f uz, v2f ox, v2f oy, v2f oz, int l0, int l1, int L,
-                                                       int32_t *cnt, int32_t *hit, int32_t *status) {
-    kptr tp0 = (kptr)(uintptr_t)ptri;
-    kiptr ik = (kiptr)(uintptr_t)idx;
-    uint32_t nanacc = 0;
-    for (int sp = s0; sp < s1; ++sp) {
-        kptr tp = tp0 + (size_t)(psorted ? sp : ik[sp]) * PTRI_STRIDE;
-        const uint32_t thr2 = __float_as_uint(tp[9]);
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const float dx = h ? ux.y : ux.x, dy = h ? uy.y : uy.x, dz = h ? uz.y : uz.x;
-            const float px = h ? ox.y : ox.x, py = h ? oy.y : oy.x, pz = h ? oz.y : oz.x;
-            const int l = h ? l1 : l0;
-            const uint32_t x0 = __float_as_uint(dist_sq<float>(tp[0], tp[1], tp[2], dx, dy, dz, px, py, pz));
-            const uint32_t x1 = __float_as_uint(dist_sq<float>(tp[3], tp[4], tp[5], dx, dy, dz, px, py, pz));
-            const uint32_t x2 = __float_as_uint(dist_sq<float>(tp[6], tp[7], tp[8], dx, dy, dz, px, py, pz));
-            const uint32_t mm = max(max(x0, x1), x2);  // negative or NaN: sign bit set -> huge
-            if (l < L) {
-                nanacc = max(nanacc, mm);
-                if (mm < thr2) {
-                    const int pos = atomicAdd(&cnt[l], 1);
-                    if (pos < RRL_MAX_HITS) hit[(size_t)l * RRL_MAX_HITS + pos] = __float_as_int(tp[11]);
-                }
-            }
+int rrl_launch_cull_scan(const float *line, void *ws, const WsLayout &w, int B, int N, int M, int L,
+                         int clouds, int lmax_ready, const RrlCall &o, hipStream_t s) {
+    // a workgroup = (cloud and sample, tile of <= WPB x 128 lines, slice of spw supergroups).  With
+    // few lines or small clouds the slices get thinner, so that the launch still has ~1000
+    // workgroups for the 256 CUs (measured with tools/geom_sweep.sh: thinner slices cost little,
+    // fewer wavefronts per workgroup cost more -- they are only reduced as a last resort)
+    constexpr int WPB_ = scan8::kWPB, LPW_ = scan8::kLPW;
+    const int nmax = clouds == 2 && M > N ? M : N;
+    const int nsgmax = (nmax + SGT - 1) / SGT;
+    const int lw = (L + LPW_ - 1) / LPW_;  // wavefronts' worth of lines
+    int waves = lw < WPB_ ? lw : WPB_, spw = scan8::kSPW;
+    auto wgs = [&]() { return (long)clouds * B * ((lw + waves - 1) / waves) * ((nsgmax + spw - 1) / spw); };
+    // FAT slices (scan16: 16 supergroups per workgroup, lines in registers, 4 workgroups per CU) as soon as the grid stays
+    // deep with them -- measured (tools/spw_exp2.sh, profiles/r05_experiments.txt): >= 960 fat workgroups win 6 .. 20 %
+    // (B = 12 .. 64 at C2's shape, N = 8192, L = 20000), <= 640 lose 7 .. 55 % (C2 itself, C4, the demo).  RRL_CULL_FAT=0 / 1 forces.
+    bool fat = (long)clouds * B * ((lw + waves - 1) / waves) * ((nsgmax + 15) / 16) >= 896 && lw >= WPB_;
+    if (const char *e = getenv("RRL_CULL_FAT")) fat = e[0] == '1' ? (nsgmax > 8) : (e[0] == '0' ? false : fat);
+    if (fat) spw = scan16::kSPW;
+    while (!fat && wgs() < 768 && spw > 1) spw >>= 1;
+    // (a riding Chamfer walk needs the scan's full 512-lane workgroups -- and brings workgroups of its own: no thinning then)
+    const bool may_ride = o.rider && !o.counters && (clouds == 2 || o.tar_ws) && lw >= WPB_ && B <= 32767 && N > 0 && M > 0;
+    while (!fat && !may_ride && wgs() < 256 && waves > 2) waves >>= 1;
+    if (const char *e = getenv("RRL_CULL_GEOM")) {  // experiments: "waves,spw" (spw > 8: the fat variant)
+        int w_ = 0, s_ = 0;
+        if (sscanf(e, "%d,%d", &w_, &s_) == 2 && w_ >= 1 && w_ <= WPB_ && s_ >= 1 && s_ <= scan16::kSPW) {
+            waves = w_ < lw ? w_ : lw; spw = s_; fat = s_ > scan8::kSPW;
         }
     }
-    if (nanacc >= 0x80000000u) atomicOr(&status[0], 1);
+    const int tiles = (lw + waves - 1) / waves, slices = (nsgmax + spw - 1) / spw;
+    if (!lmax_ready)  // the triangles were prepared without the lines: their partial maxima first (a tiny launch)
+        hipLaunchKernelGGL(line_max_kernel, dim3(LMAX_CHUNKS, (unsigned)B), dim3(REC_BLK), 0, s, line, L,
+                           (float2 *)w.f32(ws, RRL_WS_LMAX), o.problems);
+    // (A PERSISTENT variant -- as many workgroups as fit on the chip, each keeping one line tile staged and pulling
+    // (cloud, slice) items from per-tile work queues, the next slice's records prefetched during the walk -- was built
+    // and measured in round 3: exact, but 40.7 us against 30.4 at C2 and 29.0 against 13.8 at the demo's shape.  A slot
+    // is held for the SLOWEST of a workgroup's eight wavefronts either way (16.5 us per item against a mean wavefront
+    // lifetime of 12.4), so queueing the items removed no waiting, and the item barriers added some;
+    // profiles/r03_scan_experiments.txt.)
+    return fat ? scan16::launch_variant(line, ws, w, B, N, M, L, clouds, o, s, waves, spw, tiles, slices, may_ride)
+               : scan8::launch_variant(line, ws, w, B, N, M, L, clouds, o, s, waves, spw, tiles, slices, may_ride);
 }
-
-// The culled walk of one wavefront over the STAGED slice (node_lds / ctx.recs): level A on the lane's two lines,
-// level B, level D, candidate resolution.  stamps (COUNT): wall clock after level A, after level B's drain, after
-// level D's drain.
-template <bool COUNT>
-__device__ __forceinline__ void cull_walk(WaveCtx &ctx, const float4 *node_lds, int nsl, int lane, bool live0, bool live1,
-                                          v2f ux, v2f uy, v2f uz, v2f ox, v2f oy, v2f oz, unsigned long long *stamps) {
-    // ---- level A: conservative sphere test of every supergroup of the slice against the lane's two lines
-    //      (packed fp32; the staged supergroup nodes come as wave-uniform LDS reads).  No queue traffic inside the
-    //      loop: the outcome is one bit per (line, supergroup) in two lane-private masks (sign bits, v_alignbit).
-    unsigned f0m = 0u, f1m = 0u;  // bit s: supergroup s cannot be reached by line 0 / line 1 of the lane
-#pragma unroll
-    for (int s = SPW - 1; s >= 0; --s) {  // supergroup s ends up in bit s
-        float4 nd = node_lds[(s < nsl ? s : 0) * NODE];
-        if (s >= nsl) nd.w = -INFINITY;  // uniform: not part of this slice
-        const v2f ax = nd.x - ox, ay = nd.y - oy, az = nd.z - oz;
-        const v2f dot = __builtin_elementwise_fma(az, uz, __builtin_elementwise_fma(ay, uy, ax * ux));
-        const v2f q = __builtin_elementwise_fma(az, az, __builtin_elementwise_fma(ay, ay, ax * ax));
-        const v2f w2 = {nd.w, nd.w};
-        const v2f mg = __builtin_elementwise_fma(dot, dot, __builtin_elementwise_fma(-q, (v2f){0.999996f, 0.999996f}, w2));
-        f0m = __builtin_amdgcn_alignbit(f0m, __float_as_uint(mg.x), 31);
-        f1m = __builtin_amdgcn_alignbit(f1m, __float_as_uint(mg.y), 31);
-    }
-    unsigned m0 = live0 ? (~f0m & ((1u << SPW) - 1u)) : 0u, m1 = live1 ? (~f1m & ((1u << SPW) - 1u)) : 0u;
-    {
-        const int cnt_ = __popc(m0) + __popc(m1);
-        const int incl = wave_incl_scan(cnt_);
-        const int total = __builtin_amdgcn_readlane(incl, 63);
-        if (total <= QA_CAP) {  // the usual case (~128): every lane writes its own run of entries
-            int at = incl - cnt_;
-            while (m0) {
-                const int s = __ffs(m0) - 1;
-                m0 &= m0 - 1;
-                ctx.qa[at++] = (unsigned short)((lane << SG_BITS) | s);
-            }
-            while (m1) {
-                const int s = __ffs(m1) - 1;
-                m1 &= m1 - 1;
-                ctx.qa[at++] = (unsigned short)(((64 + lane) << SG_BITS) | s);
-            }
-            ctx.na = total;
-        } else {  // dense hits: supergroup by supergroup, level B in between
-            for (int s = 0; s < nsl; ++s) {
-                const bool p0 = (m0 >> s) & 1u, p1 = (m1 >> s) & 1u;
-                const unsigned long long b0 = __ballot(p0), b1 = __ballot(p1);
-                if ((b0 | b1) == 0ull) continue;
-                if (ctx.na > QA_CAP - 128) proc_a<COUNT>(ctx, false);
-                const int c0 = __popcll(b0);
-                if (p0) ctx.qa[ctx.na + lane_rank(b0)] = (unsigned short)((lane << SG_BITS) | s);
-                if (p1) ctx.qa[ctx.na + c0 + lane_rank(b1)] = (unsigned short)(((64 + lane) << SG_BITS) | s);
-                ctx.na += c0 + __popcll(b1);
-            }
-        }
-    }
-    if constexpr (COUNT) stamps[0] = wall_clock64();
-    proc_a<COUNT>(ctx, true);
-    if constexpr (COUNT) stamps[1] = wall_clock64();
-    proc_c<COUNT>(ctx, true);
-    if constexpr (COUNT) stamps[2] = wall_clock64();
-    flush_cands<COUNT>(ctx);
-}
-
-// COUNT = true: the same kernel with executed-work counters -- launched instead of the plain one while
-// rrl_scan_counters() holds a buffer.  Every wavefront WRITES one row of 16 u64 (plain stores: thousands of
-// same-address atomics serialise at ~12 ns each and distort the kernel they measure), row index = linear
-// workgroup id x wavefronts per workgroup + wavefront; rows past the buffer's capacity are dropped:
-//   row[0] level-A sphere tests (line x supergroup)   [1] level-B half-sphere tests (8 per (line, supergroup) pair)
-//           [2] halves that passed (line x half)           [3] point-0 prefilter tests (line x record)
-//           [4] candidates resolved (points 1, 2)          [5] wavefronts that ran
-//           [6] wavefronts that took the strict fallback   [7] (line, triangle) pairs of the fallback
-//           [8] start, [9] end of the wavefront on the 100 MHz wall clock (the kernel lasts as long as its
-//           slowest wavefront: tools/scan_tail.py prints the spread), [10..14] phase stamps
-// The scan's LDS (47 KiB per 8-wavefront workgroup) as ONE object: cull_scan_chamfer_kernel overlays it with the Chamfer
-// walk's (rrl_chamfer_walk.h ChamLds).
-struct CullLds {
-#if !CULL_REGLINES
-    __attribute__((aligned(16))) float2 line_lds[WPB][LPW * 3];    // 24 KiB: raw 24-byte line rows
-#endif
-    __attribute__((aligned(16))) float4 rec_lds[SPW * SGG * ROWS]; //  8.5 KiB
-    __attribute__((aligned(16))) float4 node_lds[SPW * NODE];      //  1.6 KiB
-    __attribute__((aligned(16))) unsigned short qa_lds[WPB][QA_CAP];
-    unsigned short qc_lds[WPB][QC_CAP];
-    __attribute__((aligned(16))) unsigned cands_lds[WPB][WCCAP];
-};
-
-// One workgroup of the culled scan: (bx, by, bz) = its place in the scan's grid (gx, gy: the grid's first two extents)
-// -- blockIdx / gridDim in cull_scan_kernel, decoded from a linear index in cull_scan_chamfer_kernel.
-template <bool COUNT>
-__device__ __forceinline__ void cull_scan_body(
-    CullLds &lds_, const float *__restrict__ ptri1, const float *__restrict__ ptri2, const float4 *__restrict__ p0s1,
-    const float4 *__restrict__ p0s2, const int32_t *__restrict__ idx1, const int32_t *__restrict__ idx2,
-    const float4 *__restrict__ tree1, const float4 *__restrict__ tree2, const float *__restrict__ line,
-    int32_t *__restrict__ count1, int32_t *__restrict__ hit1, int32_t *__restrict__ count2,
-    int32_t *__restrict__ hit2, int32_t *__restrict__ status, uint32_t *pmax,
-    const float *__restrict__ del1, const float *__restrict__ del2, const float2 *__restrict__ lmax,
-    const float *__restrict__ apart, const float *__restrict__ aflag, int nblk_apart, int B,
-    int N, int M, int L, int spw, unsigned long long *__restrict__ counters, long long counter_rows,
-    const int bx, const int by, const int bz, const int gx, const int gy, const int Bt) {
-#if !CULL_REGLINES
-    float2 (&line_lds)[WPB][LPW * 3] = lds_.line_lds;
-#endif
-    float4 (&rec_lds)[SPW * SGG * ROWS] = lds_.rec_lds;
-    float4 (&node_lds)[SPW * NODE] = lds_.node_lds;
-    unsigned short (&qa_lds)[WPB][QA_CAP] = lds_.qa_lds;
-    unsigned short (&qc_lds)[WPB][QC_CAP] = lds_.qc_lds;
-    unsigned (&cands_lds)[WPB][WCCAP] = lds_.cands_lds;
-    static_assert(WPB * WCCAP >= SPW * SGT, "the NaN-reach scratch aliases the (still unused) candidate buffers");
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform for the compiler
-    const unsigned long long wall0 = COUNT ? wall_clock64() : 0ull;
-    unsigned long long *crow = nullptr;
-    if constexpr (COUNT) {
-        const long long wid = (((long long)bz * gy + by) * gx + bx) * (blockDim.x >> 6) + wave;
-        if (wid < counter_rows) crow = counters + 16 * wid;
-    }
-    // XCD-aware mapping: workgroups go to the 8 XCDs round-robin by linear id, and x is the fast
-    // index -- with (cloud, sample) on x, all workgroups of one cloud land on the same XCD (when
-    // 2B is a multiple of 8), so each XCD's L2 holds 1/8 of the records instead of a copy of all
-    const int z = bx, cloud = z >= B ? 1 : 0, b = z - cloud * B;
-    const int n = cloud ? M : N;
-    const int nsg = (n + SGT - 1) / SGT;
-    const int sg0 = bz * spw;
-    if (sg0 >= nsg) return;  // uniform: the smaller cloud has fewer slices
-    // multi-pose evaluation (rrl_opts.problems): instance b has the target and lines of problem b % Bt -- the target's scan
-    // is the same for every pose, so only the first Bt instances scan cloud 2 (the per-line stage reads it there)
-    if (cloud && Bt > 0 && b >= Bt) return;  // uniform
-    const int nsl = min(spw, nsg - sg0);
-    const float4 *p0s = (cloud ? p0s2 : p0s1) + (size_t)b * nsg * SGT;
-    const float4 *tree = (cloud ? tree2 : tree1) + (size_t)b * nsg * NODE;
-
-    // ---- everything the prologue needs is requested up front, in one round of independent loads: the slice's
-    //      records and nodes (one per lane in the usual 8-wavefront workgroup), the sample's line maxima, this
-    //      wavefront's 128 lines
-    constexpr int RPT = (SPW * SGT + 64 * WPB - 1) / (64 * WPB);  // records per lane of a full workgroup
-    static_assert(SPW * NODE <= 64 * WPB, "one node per lane");
-    const bool one_each = (int)blockDim.x == 64 * WPB;
-    const int32_t *idx = (cloud ? idx2 : idx1) + (size_t)b * nsg * SGT;
-    float4 rec0[RPT], nd0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    static_assert(LMAX_CHUNKS == 64, "one partial row per lane");
-    // (the line maxima and max |P|^2 are requested FIRST: vector loads return in order, so the slack arithmetic below can
-    //  start while the records, nodes and lines requested after them are still in flight)
-    const float2 lm = lmax[(size_t)b * LMAX_CHUNKS + lane];  // (max |dir|^2, max |x0|^2) over 1/64 of the sample's cullable lines
-    // layout of this cloud's PTRI rows, left by the records launch that built it (slot 7 of its first partial row; not
-    // needed before the first candidate is resolved)
-    const float play = aflag[(size_t)(cloud * B + b) * nblk_apart * 8 + 7];
-    // max |P|^2 of the cloud: from the sort kernel (PMAX), or -- prepared clouds, whose build has no single-workgroup stage
-    // -- from the records kernel's per-workgroup partial rows, reduced here next to the line maxima (one more independent
-    // load of the prologue; one workgroup per cloud and sample leaves PMAX for the later consumers)
-    float pmv = 0.0f;
-    if (apart != nullptr) {  // uniform
-        const int nb = (n + REC_BLK - 1) / REC_BLK;
-        const float *ap = apart + (size_t)(cloud * B + b) * nblk_apart * 8 + 6;
-        for (int j = lane; j < nb; j += 64) pmv = fmaxf(pmv, ap[(size_t)j * 8]);
-    } else {
-        pmv = __uint_as_float(pmax[cloud * B + b]);
-    }
-    if (one_each) {
-#pragma unroll
-        for (int k = 0; k < RPT; ++k)
-            if (tid + 64 * WPB * k < nsl * SGT) rec0[k] = p0s[(size_t)sg0 * SGT + tid + 64 * WPB * k];
-        if (tid < nsl * NODE) nd0 = tree[(size_t)sg0 * NODE + tid];
-    }
-
-    // this wave's 128 lines: a full, 16-byte aligned tile arrives as three coalesced 16-byte loads per lane straight
-    // into its LDS rows; the lanes then pick up their own two lines from there
-    const float *ln = line + (size_t)input_of(b, Bt) * L * 6;
-    const int lw0 = (by * (int)(blockDim.x >> 6) + wave) * LPW;
-    const int l0 = lw0 + lane, l1 = l0 + 64;
-    const bool live0 = l0 < L, live1 = l1 < L;
-    const bool has_lines = lw0 < L;  // a wave without lines (the last tile of the line set) still stages records
-#if CULL_REGLINES
-    // each lane's own two lines straight into registers: three 8-byte loads per line (rows are 24 bytes, 8-byte aligned;
-    // the three instructions of a line cover the wavefront's 1536 contiguous bytes completely); rows past L: zero lines
-    float2 g0[3] = {make_float2(0.0f, 0.0f), make_float2(0.0f, 0.0f), make_float2(0.0f, 0.0f)}, g1[3] = {g0[0], g0[0], g0[0]};
-    {
-        const float2 *s2 = (const float2 *)ln;
-        if (live0) { g0[0] = s2[3 * (size_t)l0]; g0[1] = s2[3 * (size_t)l0 + 1]; g0[2] = s2[3 * (size_t)l0 + 2]; }
-        if (live1) { g1[0] = s2[3 * (size_t)l1]; g1[1] = s2[3 * (size_t)l1 + 1]; g1[2] = s2[3 * (size_t)l1 + 2]; }
-    }
-#else
-    float2 *lr = line_lds[wave];
-    const float *lsrc = ln + (size_t)lw0 * 6;
-    const bool full_tile = has_lines && lw0 + LPW <= L && (((uintptr_t)lsrc) & 15) == 0;  // uniform
-    float4 t0, t1, t2;
-    if (full_tile) {
-        const float4 *s4 = (const float4 *)lsrc;
-        t0 = s4[lane]; t1 = s4[64 + lane]; t2 = s4[128 + lane];
-    }
-#endif
-
-    // ---- slack of this (cloud, sample): the same values in every wavefront and workgroup (no exchange, no barrier)
-    float pm = pmv;
-    if (apart != nullptr) {  // uniform
-        pm = wave_max_nonneg(pmv);
-        if (by == 0 && bz == 0 && tid == 0) pmax[cloud * B + b] = __float_as_uint(pm);
-    }
-    const float smax = wave_max_nonneg(lm.x), o2max = wave_max_nonneg(lm.y);
-    const CloudSlack cs = cull_cloud_slack(smax, o2max, pm);
-    const float se = cs.se, s0 = cs.s0;
-    const bool nanwide = cs.nanwide;  // uniform over the launch's workgroups of this cloud and sample
-    // nanwide (header, "NaN"): the NaN reach del of this lane's records, requested while the lines are still in flight
-    float dv[RPT];
-    const bool psorted = __builtin_amdgcn_readfirstlane(__float_as_int(play)) != 0;  // (1.0f: PTRI / DEL rows at sorted positions)
-    if (nanwide && one_each) {
-        const float *del = (cloud ? del2 : del1) + (size_t)b * n;
-        if (psorted) {  // uniform: the prepared build left DEL at the sorted positions -- no dependent gather through IDX
-#pragma unroll
-            for (int k = 0; k < RPT; ++k) dv[k] = sg0 * SGT + tid + 64 * WPB * k < n ? del[sg0 * SGT + tid + 64 * WPB * k] : 0.0f;
-        } else {
-            int idx0[RPT];
-#pragma unroll
-            for (int k = 0; k < RPT; ++k) idx0[k] = tid + 64 * WPB * k < nsl * SGT ? idx[sg0 * SGT + tid + 64 * WPB * k] : 0;
-#pragma unroll
-            for (int k = 0; k < RPT; ++k) dv[k] = sg0 * SGT + tid + 64 * WPB * k < n ? del[idx0[k]] : 0.0f;
-        }
-    }
-#if CULL_REGLINES
-    const float v0[6] = {g0[0].x, g0[0].y, g0[1].x, g0[1].y, g0[2].x, g0[2].y};
-    const float v1[6] = {g1[0].x, g1[0].y, g1[1].x, g1[1].y, g1[2].x, g1[2].y};
-#else
-    if (full_tile) {
-        float4 *d4 = (float4 *)lr;
-        d4[lane] = t0; d4[64 + lane] = t1; d4[128 + lane] = t2;
-    } else if (has_lines) {  // ragged tail / odd alignment: 8-byte pieces (a row is 24 bytes), zeros past the end
-        const float2 *s2 = (const float2 *)lsrc;
-        const int nf2 = (L - lw0) * 3;
-        for (int i = lane; i < LPW * 3; i += 64) lr[i] = i < nf2 ? s2[i] : make_float2(0.0f, 0.0f);
-    }
-
-    wave_lds_fence();
-    float v0[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}, v1[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-    if (has_lines) {
-        const LineRow r0 = line_row(lr, lane), r1 = line_row(lr, 64 + lane);
-        v0[0] = r0.la.x; v0[1] = r0.la.y; v0[2] = r0.la.z; v0[3] = r0.la.w; v0[4] = r0.lb.x; v0[5] = r0.lb.y;
-        v1[0] = r1.la.x; v1[1] = r1.la.y; v1[2] = r1.la.z; v1[3] = r1.la.w; v1[4] = r1.lb.x; v1[5] = r1.lb.y;
-    }
-#endif
-    // Culling (and the lazy evaluation of points 1, 2) is only exact for lines with |dir|^2 <= 1 + 1e-6 and finite,
-    // moderate data.  A wavefront with an offending line evaluates ALL pairs of its lines with the slice's
-    // triangles strictly instead -- the reference's semantics, NaN included.
-    float sa, oa, sb, ob;
-    line_norms(v0[0], v0[1], v0[2], v0[3], v0[4], v0[5], sa, oa);
-    line_norms(v1[0], v1[1], v1[2], v1[3], v1[4], v1[5], sb, ob);
-    const bool fallback = !cs.ok || !__all(line_cullable(sa, oa) && line_cullable(sb, ob));
-    unsigned long long fb_pairs = 0;
-
-    const float *ptri = (cloud ? ptri2 : ptri1) + (size_t)b * n * PTRI_STRIDE;
-    int32_t *cnt = (cloud ? count2 : count1) + (size_t)b * L;
-    int32_t *hit = (cloud ? hit2 : hit1) + (size_t)b * L * RRL_MAX_HITS;
-
-    // nanwide: the slice's del values meet in LDS (a buffer the walk does not use yet) so that every node lane can
-    // take the maximum over ITS records -- one more barrier, only on this path
-    float *dl = (float *)&cands_lds[0][0];  // [SPW * SGT]
-    if (nanwide) {
-        if (one_each) {
-#pragma unroll
-            for (int k = 0; k < RPT; ++k)
-                if (tid + 64 * WPB * k < nsl * SGT) dl[tid + 64 * WPB * k] = dv[k];
-        } else {
-            const float *del = (cloud ? del2 : del1) + (size_t)b * n;
-            for (int i = tid; i < nsl * SGT; i += blockDim.x) {
-                const int sp = sg0 * SGT + i;
-                dl[i] = sp < n ? del[psorted ? sp : idx[sp]] : 0.0f;
-            }
-        }
-        __syncthreads();
-    }
-    // ---- stage the slice: records (padded rows) and tree nodes, slacks folded in
-    //   (P0, thr2) -> (P0, c): c = -(thr2 - 2e-4 + slack), slightly widened; pad records never pass
-    //   (centre, Rs) -> (centre, (Rs + se)^2 rounded up); an empty node (NaN radius) -> -inf: fails by its sign
-    auto stage_rec = [&](int i, float4 r, float d) {
-        float tp = r.w - RRL_EPS;
-        if (nanwide) {  // also a candidate when point 1 or 2 could see a negative argument: Q(P0) < (se + e01)^2
-            const float reach = se + sqrtf(r.w) * 1.000001f + d;  // e01 <= thr + del <= sqrt(thr2) + del
-            tp = fmaxf(tp, reach * reach * 1.000002f);
-        }
-        r.w = sg0 * SGT + i < n ? -(tp + 1.0e-6f * fabsf(tp) + s0) : INFINITY;
-        rec_lds[(i >> 4) * ROWS + (i & 15)] = r;
-    };
-    auto stage_node = [&](int i, float4 nd) {
-        float rt = nd.w + se;
-        if (nanwide) {  // node j of supergroup sg covers the records [0] all 64, [1..4] 16 each, [5..12] 8 each
-            const int sg = i / NODE, j = i - sg * NODE;
-            const int o = j == 0 ? 0 : (j < 5 ? (j - 1) * GRP : (j - 5) * (GRP / 2)), c4 = j == 0 ? SGT / 4 : (j < 5 ? GRP / 4 : GRP / 8);
-            const float4 *q = (const float4 *)(dl + sg * SGT + o);  // 32-byte aligned
-            float m = 0.0f;
-            for (int t = 0; t < c4; ++t) {
-                const float4 v = q[t];
-                m = fmaxf(m, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
-            }
-            rt += m;
-        }
-        const float w = rt * rt * 1.0000003f;
-        nd.w = w == w ? w : -INFINITY;
-        node_lds[i] = nd;
-    };
-    if (one_each) {
-#pragma unroll
-        for (int k = 0; k < RPT; ++k)
-            if (tid + 64 * WPB * k < nsl * SGT) stage_rec(tid + 64 * WPB * k, rec0[k], nanwide ? dv[k] : 0.0f);
-        if (tid < nsl * NODE) stage_node(tid, nd0);
-    } else {
-        for (int i = tid; i < nsl * SGT; i += blockDim.x) stage_rec(i, p0s[(size_t)sg0 * SGT + i], nanwide ? dl[i] : 0.0f);
-        for (int i = tid; i < nsl * NODE; i += blockDim.x) stage_node(i, tree[(size_t)sg0 * NODE + i]);
-    }
-    __syncthreads();  // the one barrier of the (usual) prologue
-#ifdef CULL_STOP_STAGE
-    return;
-#endif
-    if (!has_lines) return;  // uniform per wavefront
-    const unsigned long long wall_staged = COUNT ? wall_clock64() : 0ull;
-    unsigned long long wall_a = 0ull, wall_pa = 0ull, wall_pc = 0ull;
-
-    WaveCtx ctx;
-#if CULL_REGLINES
-#pragma unroll
-    for (int q = 0; q < 6; ++q) { ctx.v0[q] = v0[q]; ctx.v1[q] = v1[q]; }
-#else
-    ctx.lr = lr;
-#endif
-    ctx.recs = rec_lds;
-    ctx.nodes = node_lds;
-    ctx.qa = qa_lds[wave];
-    ctx.qc = qc_lds[wave];
-    ctx.cands = cands_lds[wave];
-    ctx.idx = idx;
-    ctx.ptri = ptri;
-    ctx.psorted = psorted;
-    ctx.cnt = cnt;
-    ctx.hit = hit;
-    ctx.lbase = lw0;
-    ctx.na = ctx.nc = ctx.ncand = 0;
-    ctx.lane = lane;
-    ctx.tb = ctx.tc = ctx.td = ctx.tcand = 0;
-    ctx.status = status;
-    ctx.pos0 = sg0 * SGT;
-    const v2f ux = {v0[0], v1[0]}, uy = {v0[1], v1[1]}, uz = {v0[2], v1[2]};
-    const v2f ox = {v0[3], v1[3]}, oy = {v0[4], v1[4]}, oz = {v0[5], v1[5]};
-    unsigned long long ta = 0;
-
-    if (fallback) {  // rare: kept out of line so that its registers do not count against the culled walk
-        const int f0 = sg0 * SGT, f1 = min(n, f0 + nsl * SGT);  // real records sit at sorted positions [0, n)
-        strict_slice(ptri, idx, ctx.psorted, f0, f1, ux, uy, uz, ox, oy, oz, l0, l1, L, cnt, hit, status);
-        if (lane == 0) atomicAdd(&status[1], 1);  // always on: wavefronts that left the culled path
-        fb_pairs = (unsigned long long)(f1 - f0) * (unsigned long long)min(LPW, L - lw0);
-    } else {
-    ta = (unsigned long long)nsl * (unsigned long long)min(LPW, L - lw0);
-
-    unsigned long long stamps[3] = {0ull, 0ull, 0ull};
-    cull_walk<COUNT>(ctx, node_lds, nsl, lane, live0, live1, ux, uy, uz, ox, oy, oz, stamps);
-    wall_a = stamps[0]; wall_pa = stamps[1]; wall_pc = stamps[2];
-    }
-    if constexpr (COUNT) {
-        if (lane == 0 && crow && has_lines) {
-            crow[0] = ta;
-            crow[1] = ctx.tb; crow[2] = ctx.tc; crow[3] = ctx.td; crow[4] = ctx.tcand;
-            crow[5] = 1ull;
-            crow[6] = fallback ? 1ull : 0ull;
-            crow[7] = fb_pairs;
-            crow[8] = wall0; crow[9] = wall_clock64();
-            // phase stamps of the culled walk: staged (after the staging barrier), level A done, the final drains
-            // of levels B and D done (the remainder up to [9] is the last candidate flush)
-            crow[10] = wall_staged; crow[11] = wall_a; crow[12] = wall_pa; crow[13] = wall_pa; crow[14] = wall_pc;
-        }
-    }
-}
-
-template <bool COUNT>
-__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(6, 8))) void cull_scan_kernel(
-    const float *__restrict__ ptri1, const float *__restrict__ ptri2, const float4 *__restrict__ p0s1,
-    const float4 *__restrict__ p0s2, const int32_t *__restrict__ idx1, const int32_t *__restrict__ idx2,
-    const float4 *__restrict__ tree1, const float4 *__restrict__ tree2, const float *__restrict__ line,
-    int32_t *__restrict__ count1, int32_t *__restrict__ hit1, int32_t *__restrict__ count2,
-    int32_t *__restrict__ hit2, int32_t *__restrict__ status, uint32_t *pmax,
-    const float *__restrict__ del1, const float *__restrict__ del2, const float2 *__restrict__ lmax,
-    const float *__restrict__ apart, const float *__restrict__ aflag, int nblk_apart, int B,
-    int N, int M, int L, int spw, unsigned long long *__restrict__ counters, long long counter_rows, int Bt) {
-    __shared__ CullLds lds_;
-    cull_scan_body<COUNT>(lds_, ptri1, ptri2, p0s1, p0s2, idx1, idx2, tree1, tree2, line, count1, hit1, count2, hit2, status,
-                          pmax, del1, del2, lmax, apart, aflag, nblk_apart, B, N, M, L, spw, counters, counter_rows,
-                          (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, (int)gridDim.y, Bt);
-}
-
-// ---------------------------------------------------------------------------------------
-// The culled scan AND the Chamfer walk of the same evaluation in ONE launch (round 4b; rrl_ws.h RrlChamRider, rrl_demo_epoch).
-// The walk (rrl_chamfer_from_loss: nearest neighbours between the moved source's and the target's first points through
-// the sorted records and sphere trees the records launch just left) depends on that launch only -- not on the scan -- but
-// consecutive launches of a stream never overlap on this stack (hipExtAnyOrderLaunch is ignored on gfx9, event edges
-// between streams cost tens of microseconds: profiles/r04_experiments.txt 4, 12), so the only way to run two independent
-// 512-lane kernels side by side is to issue them as one grid: workgroups [0, ncham) walk (the long ones start first),
-// the others scan.  Same bodies, same results as the two launches; the LDS of the two is overlaid.  The walk takes
-// max |P|^2 of its target from the partial rows (pm1 == NULL): PMAX is being rebuilt by this launch's scan.
-// ---------------------------------------------------------------------------------------
-struct CullKArgs {
-    const float *ptri1, *ptri2;
-    const float4 *p0s1, *p0s2;
-    const int32_t *idx1, *idx2;
-    const float4 *tree1, *tree2;
-    const float *line;
-    int32_t *count1, *hit1, *count2, *hit2, *status;
-    uint32_t *pmax;
-    const float *del1, *del2;
-    const float2 *lmax;
-    const float *apart, *aflag;
-    const float *aflag_tar;  // the partial rows of the workspace that holds cloud 2 (== aflag unless the target is carried over)
-    int nblk_apart, B, N, M, L, spw, gx, gy, Bt;
-};
-struct ChamKArgs {
-    unsigned long long *best_x, *best_y;
-    double *partial, *gpart;
-    float *value;
-    double denom;
-    ChamTick tick;
-    int gx, gy;
-};
-static_assert(NWV == WPB, "the walk and the scan share one launch: the same 512-lane workgroups");
-
-__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4, 8))) void cull_scan_chamfer_kernel(
-    const CullKArgs a, const ChamKArgs c) {
-    __shared__ union {
-        CullLds scan;
-        ChamLds walk;
-    } lds_;
-    const int ncham = c.gx * c.gy, lin = (int)blockIdx.x;
-    if (lin < ncham) {  // uniform per workgroup
-        chamfer_tree_body<false, true>(lds_.walk, a.p0s1, a.p0s2, a.tree1, a.tree2, a.aflag, a.nblk_apart, c.best_x, c.best_y,
-                                       c.partial, a.B, a.N, a.M, nullptr, 0, a.idx1, a.idx2, nullptr, nullptr, c.tick, c.gpart,
-                                       c.value, c.denom, lin % c.gx, lin / c.gx, c.gx, c.gy, a.aflag_tar);
-        return;
-    }
-    const int l2 = lin - ncham, bx = l2 % a.gx, r = l2 / a.gx;
-    cull_scan_body<false>(lds_.scan, a.ptri1, a.ptri2, a.p0s1, a.p0s2, a.idx1, a.idx2, a.tree1, a.tree2, a.line, a.count1,
-                          a.hit1, a.count2, a.hit2, a.status, a.pmax, a.del1, a.del2, a.lmax, a.apart, a.aflag, a.nblk_apart,
-                          a.B, a.N, a.M, a.L, a.spw, nullptr, 0, bx, r % a.gy, r / a.gy, a.gx, a.gy, a.Bt);
-}
-
 // Executed-work counters (profiling; include/rrl.h rrl_scan_counters): while a buffer is set,
 // culled scans launch the COUNT instantiation and add to it.
 static unsigned long long *g_cull_counters = nullptr;
@@ -1733,92 +993,6 @@ int rrl_launch_cloud_sort(const float *raw1, const float *raw2, float4 *crec1, f
         const dim3 gs((unsigned)((2 * ngpmax + 255) / 256), (unsigned)B, 2u);
         hipLaunchKernelGGL(big_sphere_kernel, gs, dim3(256), 0, s, a);
     }
-    hipError_t e = hipGetLastError();
-    return e == hipSuccess ? 0 : (int)e;
-}
-
-int rrl_launch_cull_scan(const float *line, void *ws, const WsLayout &w, int B, int N, int M, int L,
-                         int clouds, int lmax_ready, const RrlCall &o, hipStream_t s) {
-    // a workgroup = (cloud and sample, tile of <= WPB x 128 lines, slice of spw supergroups).  With
-    // few lines or small clouds the slices get thinner, so that the launch still has ~1000
-    // workgroups for the 256 CUs (measured with tools/geom_sweep.sh: thinner slices cost little,
-    // fewer wavefronts per workgroup cost more -- they are only reduced as a last resort)
-    const int nmax = clouds == 2 && M > N ? M : N;
-    const int nsgmax = (nmax + SGT - 1) / SGT;
-    const int lw = (L + LPW - 1) / LPW;  // wavefronts' worth of lines
-    int waves = lw < WPB ? lw : WPB, spw = SPW;
-    auto wgs = [&]() { return (long)clouds * B * ((lw + waves - 1) / waves) * ((nsgmax + spw - 1) / spw); };
-    while (wgs() < 768 && spw > 1) spw >>= 1;
-    // (a riding Chamfer walk needs the scan's full 512-lane workgroups -- and brings workgroups of its own: no thinning then)
-    const bool may_ride = o.rider && !o.counters && (clouds == 2 || o.tar_ws) && lw >= WPB && B <= 32767 && N > 0 && M > 0;
-    while (!may_ride && wgs() < 256 && waves > 2) waves >>= 1;
-    if (const char *e = getenv("RRL_CULL_GEOM")) {  // experiments: "waves,spw"
-        int w_ = 0, s_ = 0;
-        if (sscanf(e, "%d,%d", &w_, &s_) == 2 && w_ >= 1 && w_ <= WPB && s_ >= 1 && s_ <= SPW) { waves = w_ < lw ? w_ : lw; spw = s_; }
-    }
-    const int tiles = (lw + waves - 1) / waves, slices = (nsgmax + spw - 1) / spw;
-    if (!lmax_ready)  // the triangles were prepared without the lines: their partial maxima first (a tiny launch)
-        hipLaunchKernelGGL(line_max_kernel, dim3(LMAX_CHUNKS, (unsigned)B), dim3(REC_BLK), 0, s, line, L,
-                           (float2 *)w.f32(ws, RRL_WS_LMAX), o.problems);
-    // (A PERSISTENT variant -- as many workgroups as fit on the chip, each keeping one line tile staged and pulling
-    // (cloud, slice) items from per-tile work queues, the next slice's records prefetched during the walk -- was built
-    // and measured in round 3: exact, but 40.7 us against 30.4 at C2 and 29.0 against 13.8 at the demo's shape.  A slot
-    // is held for the SLOWEST of a workgroup's eight wavefronts either way (16.5 us per item against a mean wavefront
-    // lifetime of 12.4), so queueing the items removed no waiting, and the item barriers added some;
-    // profiles/r03_scan_experiments.txt.)
-    const int zslices = slices;
-#define RRL_CULL_LAUNCH(COUNT)                                                                              \
-    hipLaunchKernelGGL(cull_scan_kernel<COUNT>, dim3((unsigned)(clouds * B), (unsigned)tiles, (unsigned)zslices),   \
-                       dim3(64 * waves), 0, s, w.f32(ws, RRL_WS_PTRI1), w.f32(ws, RRL_WS_PTRI2),             \
-                       (const float4 *)w.f32(ws, RRL_WS_P0S1), (const float4 *)w.f32(ws, RRL_WS_P0S2),       \
-                       w.i32(ws, RRL_WS_IDX1), w.i32(ws, RRL_WS_IDX2), (const float4 *)w.f32(ws, RRL_WS_GRP1), \
-                       (const float4 *)w.f32(ws, RRL_WS_GRP2), line, w.i32(ws, RRL_WS_COUNT1),               \
-                       w.i32(ws, RRL_WS_HIT1), w.i32(ws, RRL_WS_COUNT2), w.i32(ws, RRL_WS_HIT2),             \
-                       w.i32(ws, RRL_WS_STATUS), (uint32_t *)w.i32(ws, RRL_WS_PMAX),                         \
-                       w.f32(ws, RRL_WS_DEL1), w.f32(ws, RRL_WS_DEL2), (const float2 *)w.f32(ws, RRL_WS_LMAX),   \
-                       apart, w.f32(ws, RRL_WS_APART), nblk_apart, B, N, M, L, spw,                          \
-                       o.counters, o.counter_rows, o.problems)
-    const float *apart = o.prepared() ? w.f32(ws, RRL_WS_APART) : nullptr;  // prepared build: PMAX comes from the partial rows
-    const int nblk_apart = ((N > M ? N : M) + REC_BLK - 1) / REC_BLK;
-    if (may_ride && waves == WPB) {
-        // the evaluation's Chamfer walk rides along (cull_scan_chamfer_kernel): ONE launch for both.  A carried-over target
-        // (clouds == 1: only the source is scanned here) is walked in the workspace that holds its records.
-        const void *tws = clouds == 2 ? ws : o.tar_ws;
-        const ChamLayout C(B, N, M);
-        if (o.rider->ws && o.rider->ws_bytes >= C.total && o.rider->best_x && o.rider->best_y && o.rider->value) {
-            CullKArgs a;
-            a.ptri1 = w.f32(ws, RRL_WS_PTRI1); a.ptri2 = w.f32(tws, RRL_WS_PTRI2);
-            a.p0s1 = (const float4 *)w.f32(ws, RRL_WS_P0S1); a.p0s2 = (const float4 *)w.f32(tws, RRL_WS_P0S2);
-            a.idx1 = w.i32(ws, RRL_WS_IDX1); a.idx2 = w.i32(tws, RRL_WS_IDX2);
-            a.tree1 = (const float4 *)w.f32(ws, RRL_WS_GRP1); a.tree2 = (const float4 *)w.f32(tws, RRL_WS_GRP2);
-            a.line = line;
-            a.count1 = w.i32(ws, RRL_WS_COUNT1); a.hit1 = w.i32(ws, RRL_WS_HIT1);
-            a.count2 = w.i32(ws, RRL_WS_COUNT2); a.hit2 = w.i32(ws, RRL_WS_HIT2);
-            a.status = w.i32(ws, RRL_WS_STATUS); a.pmax = (uint32_t *)w.i32(ws, RRL_WS_PMAX);
-            a.del1 = w.f32(ws, RRL_WS_DEL1); a.del2 = w.f32(ws, RRL_WS_DEL2);
-            a.lmax = (const float2 *)w.f32(ws, RRL_WS_LMAX);
-            a.apart = apart; a.aflag = w.f32(ws, RRL_WS_APART); a.aflag_tar = w.f32(tws, RRL_WS_APART);
-            a.nblk_apart = nblk_apart; a.B = B; a.N = N; a.M = M; a.L = L; a.spw = spw;
-            a.gx = clouds * B; a.gy = tiles; a.Bt = o.problems;
-            ChamKArgs c;
-            char *cw = (char *)o.rider->ws;
-            c.best_x = (unsigned long long *)o.rider->best_x; c.best_y = (unsigned long long *)o.rider->best_y;
-            c.partial = (double *)(cw + C.partial); c.gpart = (double *)(cw + C.gpart);
-            c.value = o.rider->value;
-            c.denom = (double)B * (double)(N + M);
-            uint32_t *mctl = w.u32(ws, RRL_WS_MCTL);  // arrival counters of the walk's mean (rrl_chamfer_from_loss_ex)
-            c.tick = ChamTick{mctl + 32, mctl + 30, 64, 1};
-            c.gx = 2 * B; c.gy = ((N > M ? N : M) + SGT - 1) / SGT;  // patches of the larger cloud (either direction)
-            const unsigned nwg = (unsigned)(c.gx * c.gy) + (unsigned)(a.gx * a.gy * zslices);
-            hipLaunchKernelGGL(cull_scan_chamfer_kernel, dim3(nwg), dim3(64 * WPB), 0, s, a, c);
-            hipError_t e = hipGetLastError();
-            if (e == hipSuccess) o.rider->done = 1;
-            return e == hipSuccess ? 0 : (int)e;
-        }
-    }
-    if (o.counters) RRL_CULL_LAUNCH(true);
-    else RRL_CULL_LAUNCH(false);
-#undef RRL_CULL_LAUNCH
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }

@@ -68,7 +68,7 @@ def csrc_sha():
     attached to the line when they were collected for exactly this build."""
     h = hashlib.sha256()
     d = os.path.join(PKG, "csrc")
-    for f in sorted(x for x in os.listdir(d) if x.endswith((".hip", ".h"))) + ["../../include/rrl.h"]:
+    for f in sorted(x for x in os.listdir(d) if x.endswith((".hip", ".h", ".inc"))) + ["../../include/rrl.h"]:
         h.update(open(os.path.join(d, f), "rb").read())
     try:  # an experimental build (RRL_HIPCC_FLAGS) names its flags in the version string: another hash
         from rrl_hip import _lib

@@ -637,3 +637,81 @@ def test_multi_pose_argument_errors(L):
     out = ops.registration_loss(s2, R.clone().requires_grad_(True), t, tar, ln)[0]
     with pytest.raises(RRLError, match="multi-pose"):
         out.sum().backward()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# round 5: the FAT geometry variant of the culled scan (csrc/rrl_cull_scan.inc scan16: slices of 16 supergroups, the lines in
+# registers) -- chosen automatically for deep grids (B >= 12 at C2's shape), forced here by RRL_CULL_FAT on small ones
+def _with_fat(flag, fn):
+    import os
+    old = os.environ.get("RRL_CULL_FAT")
+    os.environ["RRL_CULL_FAT"] = flag
+    try:
+        out = fn()
+        torch.cuda.synchronize()
+        return out
+    finally:
+        if old is None:
+            del os.environ["RRL_CULL_FAT"]
+        else:
+            os.environ["RRL_CULL_FAT"] = old
+
+
+@pytest.mark.parametrize("B,n,m,nl,prepared,scale", [(2, 1200, 1000, 6000, True, 1.0), (1, 5000, 4100, 1500, False, 1.0),
+                                                     (3, 4096, 4096, 10000, True, 1.0), (1, 16384, 16384, 1024, True, 1.0),
+                                                     (1, 1024, 1024, 4000, True, 12.0), (2, 700, 2100, 3000, False, 300.0),
+                                                     (16, 4096, 4096, 10000, True, 1.0)])
+def test_fat_scan_variant_equals_the_lean_one(L, B, n, m, nl, prepared, scale):
+    """Labels, hit lists, median, bucket sums, loss, NaN flag and the in-kernel work counters' totals that do not depend on
+    the slicing (candidates resolved, fallback wavefronts) of the fat variant equal the lean one's and the strict scan's --
+    sorted and prepared builds, unit scale and the demo's (NaN-widened walk), with the Chamfer walk riding in the launch."""
+    from rrl_hip import ops
+    prs, t1, t2 = _pairs(700, B, n, m)
+    t1, t2 = t1 * scale, t2 * scale
+    lns = []
+    for b, p in enumerate(prs):
+        torch.manual_seed(40 + b)
+        lns.append(L.Random_uniform_distribution_lines_batch_efficient_resample(
+            torch.tensor([[float(p["radius"]) * scale * (2.0 if scale > 1 else 1.0)]]), torch.from_numpy(p["center"] * scale).reshape(1, 3),
+            nl, t1[b:b + 1, :, :3].contiguous(), t2[b:b + 1, :, :3].contiguous(), "cuda")[0])
+    ln = torch.stack(lns)
+    o1, o2 = (ops.cloud_order(t1), ops.cloud_order(t2)) if prepared else (None, None)
+
+    def run(counters=None, chamfer=None):
+        return ops.loss_forward_raw(t1, t2, ln, mode="cull", opts=ops.make_opts(order1=o1, order2=o2, counters=counters, chamfer=chamfer))
+    lean = _with_fat("0", run)
+    fat = _with_fat("1", run)
+    strict = ops.loss_forward_raw(t1, t2, ln, mode="strict")
+    torch.cuda.synchronize()
+    _same_evaluation(lean, fat)
+    _same_evaluation(strict, fat)
+    assert int(fat.status[1]) == int(lean.status[1])
+    tl, tf = torch.zeros(1 << 16, 16, dtype=torch.int64, device="cuda"), torch.zeros(1 << 16, 16, dtype=torch.int64, device="cuda")
+    _with_fat("0", lambda: run(counters=tl))
+    _with_fat("1", lambda: run(counters=tf))
+    sl, sf = tl.sum(0), tf.sum(0)
+    assert int(sf[5]) > 0 and int(sf[5]) < int(sl[5]) or n <= 512   # fewer, fatter wavefronts really ran
+    assert int(sl[6]) == int(sf[6]) == 0
+    if nl >= 1024 and max(n, m) <= 65536:  # the riding walk: same keys and value from either variant
+        ra, rb = ops.ChamferRide(B, n, m, t1.device), ops.ChamferRide(B, n, m, t1.device)
+        a = _with_fat("0", lambda: run(chamfer=ra.arm()))
+        b_ = _with_fat("1", lambda: run(chamfer=rb.arm()))
+        assert ra.done and rb.done and torch.equal(ra.bx, rb.bx) and torch.equal(ra.by, rb.by) and torch.equal(ra.val, rb.val)
+        _same_evaluation(a, b_)
+
+
+def test_fat_variant_is_chosen_for_deep_grids(L):
+    """The automatic choice (rrl_launch_cull_scan): B = 16 at C2's shape runs the fat variant (half as many wavefronts as the
+    lean one would), C2 itself the lean one -- seen through the wavefront counter -- with identical results."""
+    from rrl_hip import ops
+    for B, want_fat in ((16, True), (8, False)):
+        prs, t1, t2 = _pairs(720, B, 4096, 4096)
+        ln = _lines(L, prs, 10000)
+        tab = torch.zeros(1 << 17, 16, dtype=torch.int64, device="cuda")
+        auto = ops.loss_forward_raw(t1, t2, ln, mode="cull", opts=ops.make_opts(counters=tab))
+        torch.cuda.synchronize()
+        waves = int(tab.sum(0)[5])
+        lean_waves = 2 * B * 79 * 8
+        assert waves == (lean_waves // 2 if want_fat else lean_waves), (B, waves, lean_waves)
+        other = _with_fat("0" if want_fat else "1", lambda: ops.loss_forward_raw(t1, t2, ln, mode="cull"))
+        _same_evaluation(auto, other)

@@ -8,7 +8,7 @@ SHA=$(python3 - <<'PY'
 import hashlib, os
 h = hashlib.sha256()
 d = "a-robust-registration-loss_amd/csrc"
-for f in sorted(x for x in os.listdir(d) if x.endswith((".hip", ".h"))) + ["../../include/rrl.h"]:
+for f in sorted(x for x in os.listdir(d) if x.endswith((".hip", ".h", ".inc"))) + ["../../include/rrl.h"]:
     h.update(open(os.path.join(d, f), "rb").read())
 print(h.hexdigest()[:16])
 PY

@@ -31,7 +31,7 @@ tag = sys.argv[1]
 def csrc_sha():  # == bench.py csrc_sha(): the profile is only attached to a bench line of the same build
     h = hashlib.sha256()
     d = "a-robust-registration-loss_amd/csrc"
-    for f in sorted(x for x in os.listdir(d) if x.endswith((".hip", ".h"))) + ["../../include/rrl.h"]:
+    for f in sorted(x for x in os.listdir(d) if x.endswith((".hip", ".h", ".inc"))) + ["../../include/rrl.h"]:
         h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 O = "gpurun_out"
@@ -40,11 +40,11 @@ def per_kernel(counter_dir):
     agg = collections.defaultdict(lambda: collections.defaultdict(lambda: collections.defaultdict(float)))
     for path in f:
         for r in csv.DictReader(open(path)):
-            name = re.sub(r"^void ", "", r["Kernel_Name"]).split("(")[0].split("<")[0]
+            name = re.sub(r"^void ", "", r["Kernel_Name"]).split("(")[0].split("<")[0].split("::")[-1]
             agg[name][r["Counter_Name"]][int(r["Dispatch_Id"])] += float(r["Counter_Value"])
     return {k: {c: sum(d.values()) / len(d) for c, d in v.items()} for k, v in agg.items()}
 def short(n):
-    return re.sub(r"^void ", "", n).split("(")[0].split("<")[0]
+    return re.sub(r"^void ", "", n).split("(")[0].split("<")[0].split("::")[-1]
 def summarise(sfx, B, what):
     STEP = f"bench.py --issue direct --no-extras --no-other --no-dist --steps 6{what} (the timed one-call step: ops.LossStep -> rrl_loss_step_ex, SURVEY 8(d): backward to points1.grad)"
     out = {"csrc_sha": csrc_sha(), "profiled_command": STEP,
