@@ -781,7 +781,7 @@ int rrl_launch_cull_scan(const float *line, void *ws, const WsLayout &w, int B, 
                          int clouds, int lmax_ready, const RrlCall &o, hipStream_t s) {
     // a workgroup = (cloud and sample, tile of <= WPB x 128 lines, slice of spw supergroups).  With
     // few lines or small clouds the slices get thinner, so that the launch still has ~1000
-    // workgroups for the 256 CUs (measured with tools/geom_sweep.sh: thinner slices cost little,
+    // workgroups for the 256 CUs (measured with tools/attic/geom_sweep.sh: thinner slices cost little,
     // fewer wavefronts per workgroup cost more -- they are only reduced as a last resort)
     constexpr int WPB_ = scan8::kWPB, LPW_ = scan8::kLPW;
     const int nmax = clouds == 2 && M > N ? M : N;

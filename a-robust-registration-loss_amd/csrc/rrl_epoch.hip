@@ -7,7 +7,7 @@
 // the Chamfer walk of the step's clouds riding in its scan launch (round 4b; a launch of its own before) -> pose step (1:
 // exp-map backward, gated Adam, next exp map, log row, next sampler box) -- so that a loop pays one
 // host call (~5 us) per epoch instead of a hipGraph replay (~8 us fixed + ~1.5 us per node on this stack,
-// tools/graph_node_cost.py) or eight Python-level calls.  No new arithmetic: the results are those of the four entries.
+// tools/attic/graph_node_cost.py) or eight Python-level calls.  No new arithmetic: the results are those of the four entries.
 #include <cstddef>
 #include <cstdint>
 #include <cstdlib>

@@ -1048,19 +1048,22 @@ extern "C" int rrl_sample_lines_rng(uint64_t *rng_state, const float *r, const f
 // ---------------------------------------------------------------------------------------
 // batch-shard payload: what one rank contributes to the all-reduce
 // ---------------------------------------------------------------------------------------
-__global__ void shard_payload_kernel(const float *__restrict__ loss, const int32_t *__restrict__ info,
-                                     const float *__restrict__ gR, const float *__restrict__ gt,
-                                     float *__restrict__ out, int B) {
-    const int q = threadIdx.x;
-    if (q >= 14) return;
+// 14 wavefronts, one per payload element: the lanes stride over the samples (a fixed order per lane) and meet in a
+// fixed shuffle tree -- double sums of <= a few thousand floats: exact, so the result does not depend on the association.
+// (Round 5: the 14 lanes of ONE wavefront looping over all samples took 16 us at B = 64.)
+__global__ __launch_bounds__(14 * 64) void shard_payload_kernel(const float *__restrict__ loss, const int32_t *__restrict__ info,
+                                                               const float *__restrict__ gR, const float *__restrict__ gt,
+                                                               float *__restrict__ out, int B) {
+    const int q = threadIdx.x >> 6, lane = threadIdx.x & 63;
     double s = 0.0;
-    for (int b = 0; b < B; ++b) {
+    for (int b = lane; b < B; b += 64) {
         if (q == 0) s += info[b * 4] > 0 ? (double)loss[b] : 0.0;
         else if (q == 1) s += info[b * 4] > 0 ? 1.0 : 0.0;
         else if (q < 11) s += gR ? (double)gR[b * 9 + (q - 2)] : 0.0;
         else s += gt ? (double)gt[b * 3 + (q - 11)] : 0.0;
     }
-    out[q] = (float)s;
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+    if (lane == 0) out[q] = (float)s;
 }
 
 extern "C" int rrl_shard_payload(const float *loss, const void *ws, size_t ws_bytes, const float *gR,
@@ -1069,7 +1072,7 @@ extern "C" int rrl_shard_payload(const float *loss, const void *ws, size_t ws_by
     if (!loss || !ws || !out || B < 0) return RRL_E_ARG;
     WsLayout w(B, N, M, L);
     if (ws_bytes < w.total) return RRL_E_WS;
-    hipLaunchKernelGGL(shard_payload_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, loss,
+    hipLaunchKernelGGL(shard_payload_kernel, dim3(1), dim3(14 * 64), 0, (hipStream_t)stream, loss,
                        w.i32(ws, RRL_WS_INFO), gR, gt, out, B);
     RRL_LAUNCH_CHECK();
     return 0;

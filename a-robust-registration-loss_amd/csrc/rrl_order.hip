@@ -12,7 +12,7 @@
 // coordinate along the longest axis of their bounding box (pads sort last), so its lower half of positions receives the
 // records below the median plane.  The sphere tree of the scan sits on aligned runs of 64 / 16 / 8 positions = k-d
 // cells: at the bench shape a line meets 5.1 instead of 8.1 supergroup spheres and 47 instead of 90 point-0 tests per
-// cloud (tools/order_sim.py; profiles/r04_kd_order.txt), and clouds beyond 4096 triangles get whole-cloud cells instead
+// cloud (tools/attic/order_sim.py; profiles/r04_kd_order.txt), and clouds beyond 4096 triangles get whole-cloud cells instead
 // of the four interleaved 4096-chunks of the per-step sort.
 // Any permutation gives the same labels, hit lists and loss -- the order only shapes the tree nodes.
 //

@@ -902,7 +902,7 @@ class RegistrationStep:
 
     Issued this way the C2 step is GPU-bound (about 30 us of host time per step); replaying the
     launches as a hipGraph costs ~6 us more (a replay has ~8 us of fixed cost + 1.5 us per node on this
-    stack, tools/graph_node_cost.py), and the autograd front end (registration_loss) is host-bound when
+    stack, tools/attic/graph_node_cost.py), and the autograd front end (registration_loss) is host-bound when
     issued eagerly.  Same kernels, same numbers as registration_loss.  The outputs are views of buffers
     that the next call overwrites.  want_payload: also the 14-float batch-shard payload (rrl_hip.dist).
 

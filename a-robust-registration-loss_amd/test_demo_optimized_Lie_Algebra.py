@@ -262,7 +262,7 @@ def _run_graphed(model, draw, src, src_nb, tar, tar_tri, Save_path, writer, n_ep
 
     # ONE C call per epoch (round 4, include/rrl.h rrl_demo_epoch: sampler -> fused step -> Chamfer from the step's state ->
     # pose step, issued back to back) instead of a hipGraph replay of the same launches: a replay costs ~8 us + ~1.5 us per
-    # node on this stack (tools/graph_node_cost.py), the call ~5 us of host time.  Same launches, same results.
+    # node on this stack (tools/attic/graph_node_cost.py), the call ~5 us of host time.  Same launches, same results.
     # RRL_DEMO_ISSUE=graph keeps the replay.
     epoch_call = None
     if box_from_step and hasattr(draw, "sampler") and reg.prepared and os.environ.get("RRL_DEMO_ISSUE", "call") != "graph":

@@ -73,9 +73,10 @@ def test_product_never_imports_oracle():
                 text = open(os.path.join(dirpath, f)).read()
                 assert "rrl_oracle" not in text and "import oracle" not in text, f
     # developer tools time the product only; bench.py may use the oracle in its cpu_baseline leg alone
-    for f in os.listdir(os.path.join(ROOT, "tools")):
-        text = open(os.path.join(ROOT, "tools", f), errors="ignore").read()
-        assert "rrl_oracle" not in text and "from oracle" not in text and "import oracle" not in text, f
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "tools")):  # (tools/attic too)
+        for f in files:
+            text = open(os.path.join(dirpath, f), errors="ignore").read()
+            assert "rrl_oracle" not in text and "from oracle" not in text and "import oracle" not in text, f
     bench = open(os.path.join(ROOT, "bench.py")).read()
     uses = [i for i in range(len(bench)) if bench.startswith("rrl_oracle", i)]
     lo, hi = bench.index("def cpu_baseline("), bench.index("def main(")
