@@ -39,3 +39,10 @@ if rows.shape[1] > 14 and rows[:, 10].max() > 0:
     first = culled[:, 8] - rows[:, 8].min() < 200  # started in the first 2 us: the full-occupancy generation
     print("  phase means us (all / first generation / later): " + "; ".join(
         f"{n} {ph[:, i].mean():.2f} / {ph[first, i].mean():.2f} / {ph[~first, i].mean() if (~first).any() else float('nan'):.2f}" for i, n in enumerate(names)))
+    if rows.shape[1] > 15 and culled[:, 15].max() > 0:  # round 5: inside the prologue
+        t_sl, t_pb = (culled[:, 15] & 0xffffffff) / 100.0, (culled[:, 15] >> 32) / 100.0
+        t_bar = (culled[:, 10] - culled[:, 8]) / 100.0
+        print("  inside the prologue, us after the wavefront's start (all / first generation / later): "
+              f"first loads back + slack {t_sl.mean():.2f} / {t_sl[first].mean():.2f} / {t_sl[~first].mean() if (~first).any() else float('nan'):.2f}; "
+              f"own share staged {t_pb.mean():.2f} / {t_pb[first].mean():.2f} / {t_pb[~first].mean() if (~first).any() else float('nan'):.2f}; "
+              f"past the barrier {t_bar.mean():.2f} / {t_bar[first].mean():.2f} / {t_bar[~first].mean() if (~first).any() else float('nan'):.2f}")
