@@ -790,7 +790,7 @@ int rrl_launch_cull_scan(const float *line, void *ws, const WsLayout &w, int B, 
     int waves = lw < WPB_ ? lw : WPB_, spw = scan8::kSPW;
     auto wgs = [&]() { return (long)clouds * B * ((lw + waves - 1) / waves) * ((nsgmax + spw - 1) / spw); };
     // FAT slices (scan16: 16 supergroups per workgroup, lines in registers, 4 workgroups per CU) as soon as the grid stays
-    // deep with them -- measured (tools/spw_exp2.sh, profiles/r05_experiments.txt): >= 960 fat workgroups win 6 .. 20 %
+    // deep with them -- measured (tools/attic/spw_exp2.sh, profiles/r05_experiments.txt): >= 960 fat workgroups win 6 .. 20 %
     // (B = 12 .. 64 at C2's shape, N = 8192, L = 20000), <= 640 lose 7 .. 55 % (C2 itself, C4, the demo).  RRL_CULL_FAT=0 / 1 forces.
     bool fat = (long)clouds * B * ((lw + waves - 1) / waves) * ((nsgmax + 15) / 16) >= 896 && lw >= WPB_;
     if (const char *e = getenv("RRL_CULL_FAT")) fat = e[0] == '1' ? (nsgmax > 8) : (e[0] == '0' ? false : fat);

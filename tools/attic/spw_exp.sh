@@ -1,5 +1,7 @@
 #!/bin/bash
-# usage (GPU box, repo root): tools/spw_exp.sh -- round 5: ONE generation of fatter workgroups for the culled scan?  The C2 grid
+# NOTE: written against the tree BEFORE the scan was split into two variants (commit "Culled scan: second geometry variant"): there -DSPW / -DCULL_REGLINES
+# configured the one scan kernel; today the shipped library holds both variants (rrl_cull_scan.inc) and RRL_CULL_FAT=0/1 selects one.
+# usage (GPU box, repo root): tools/attic/spw_exp.sh -- round 5: ONE generation of fatter workgroups for the culled scan?  The C2 grid
 # is 1280 workgroups of 8 wavefronts, 768 fit (3 per CU, LDS-bound): 1.67 generations, the launch lasts two wavefront
 # lifetimes.  Slices of 16 supergroups halve the grid (640 workgroups: one generation) at twice the work per wavefront and
 # one prologue instead of two.  Compile-time knobs, experimental builds in lib_exp/; "flags|geom" per case.

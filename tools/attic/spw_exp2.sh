@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (GPU box, repo root): tools/spw_exp2.sh -- where does the fat-slice variant (tools/spw_exp.sh) start to pay?
+# usage (GPU box, repo root): tools/attic/spw_exp2.sh -- where does the fat-slice variant (tools/attic/spw_exp.sh) start to pay?
 for case in "|" "-DSPW=16 -DCULL_REGLINES=1 -DQA_CAP=384 -DQC_CAP=256|8,16"; do
   flags="${case%%|*}"; geom="${case##*|}"
   if [ -n "$flags" ]; then export RRL_HIPCC_FLAGS="$flags"; else unset RRL_HIPCC_FLAGS; fi
