@@ -585,6 +585,53 @@ def main():
                 ride_ms[name + "_value"] = float(cv)
             extras["step_with_chamfer_monitor_ms"] = ride_ms
 
+        # ---- the iterative trainers (RPM num_iter = 2, rpm/Train_RPM.py:207-231): both poses as ONE multi-pose evaluation
+        # (rrl_opts.problems) against pose after pose with the target's scan carried over, and one pose alone -- the fused
+        # training op forward + backward through its autograd front end, as hipGraph replays (device time)
+        if prepared and args.mode == "cull" and not args.no_graph:
+            try:
+                g2 = torch.Generator().manual_seed(11 + rank)
+                from LieAlgebra import se3 as _se3
+                R2, T2 = _se3.exp3(0.05 * torch.randn(B, 6, generator=g2))
+                Rk = torch.cat([w["R"].detach(), R2.to(dev)]).requires_grad_(True)
+                Tk = torch.cat([w["T"].detach(), T2.to(dev)]).requires_grad_(True)
+                ones2 = torch.ones(2 * B, device=dev)
+                kept = {}
+
+                def multi():
+                    Rk.grad = Tk.grad = None
+                    l, _, _ = ops.registration_loss(w["tri1"], Rk, Tk, w["tri2"], w["lines"], order1=order1, order2=order2)
+                    torch.autograd.backward([l], [ones2])
+                    kept["m"] = l
+                    return l
+
+                def loop():
+                    Rk.grad = Tk.grad = None
+                    la, _, _ = ops.registration_loss(w["tri1"], Rk[:B], Tk[:B], w["tri2"], w["lines"], order1=order1, order2=order2)
+                    first = ops.last_state()
+                    lb, _, _ = ops.registration_loss(w["tri1"], Rk[B:], Tk[B:], w["tri2"], w["lines"], order1=order1, order2=order2,
+                                                     target_from=first)
+                    torch.autograd.backward([la, lb], [ones, ones])
+                    kept["l"] = (la, lb)
+                    return la
+
+                def single():
+                    Rk.grad = Tk.grad = None
+                    la, _, _ = ops.registration_loss(w["tri1"], Rk[:B], Tk[:B], w["tri2"], w["lines"], order1=order1, order2=order2)
+                    torch.autograd.backward([la], [ones])
+                    return la
+                mp = {}
+                for name, fn in (("two_poses_one_evaluation", multi), ("two_poses_one_after_the_other", loop), ("one_pose", single)):
+                    mp[name + "_ms"], _ = time_loop(GraphedStep(fn), max(50, args.steps // 2))
+                mp["loss_bits_equal"] = bool(torch.equal(kept["m"].detach(), torch.cat([x.detach() for x in kept["l"]])))
+                mp["ratio_to_one_pose"] = mp["two_poses_one_evaluation_ms"] / mp["one_pose_ms"]
+                mp["what"] = ("ops.registration_loss forward + backward to (dR, dT) at the timed shape, hipGraph replays: k = 2 poses of every "
+                              "problem evaluated as 2 B instances in one set of launches (target scanned once per problem) / as two "
+                              "evaluations, the second with the target's scan carried over (round 4) / one pose")
+                extras["multi_pose"] = mp
+            except Exception as exc:
+                extras["multi_pose"] = {"error": f"{type(exc).__name__}: {exc}"}
+
         # ---- a CHIP-FILLING shape: BASELINE configs[2] (B = 64) as one batch on this GPU -- separates the kernel's quality
         # from "B = 8 fills under half of the 256 CUs"
         if not args.no_b64 and args.mode == "cull" and B < 64:

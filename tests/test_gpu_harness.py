@@ -549,6 +549,8 @@ def test_bench_line_describes_what_it_times():
     assert v["dropin_loop"]["loss_sum"] == pytest.approx(ag["loss_sum"], rel=1e-6)
     assert v["dropin_loop"]["dR_max_rel_diff_vs_fused"] < 1e-5 and ag["dR_max_rel_diff_vs_fused"] < 1e-5
     assert run["extras"]["loss_sum"] == pytest.approx(ag["loss_sum"], rel=1e-6) and run["extras"]["valid"] == 8.0
+    mp = run["extras"]["multi_pose"]
+    assert mp.get("loss_bits_equal") is True and mp["two_poses_one_evaluation_ms"] > 0 and mp["one_pose_ms"] > 0, mp
     print("ms_per_step:", {"timed": run["ms_per_step"], "cold": run["ms_per_step_cold"], "B64": b64["ms_per_step"],
                            **{k: x["ms_per_step"] for k, x in v.items()}})
 
