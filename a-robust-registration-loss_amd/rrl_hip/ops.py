@@ -919,10 +919,14 @@ class RegistrationStep:
 
     def __init__(self, src_tri, tar_tri, n_lines, rng=(1, 1, 5, 5), transpose_r=True, mode="cull", chunk=0,
                  want_payload=False, prepared=None, src_order=None, tar_order=None, reduce_mode=None, deterministic=None,
-                 sort_parts=None, chamfer=False):
+                 sort_parts=None, chamfer=False, poses=1):
         """reduce_mode / deterministic / sort_parts: per-call options of THIS step object (include/rrl.h rrl_opts; None =
         the library default) -- they travel with every call, so two steps with different options can run from two
-        threads on two streams at the same time (tests/test_gpu_threads.py)."""
+        threads on two streams at the same time (tests/test_gpu_threads.py).
+        poses = k > 1 (round 5): a MULTI-POSE step (rrl_opts.problems) -- every call takes R (k * B, 3, 3), t (k * B, 3): k
+        poses of each of the B problems (instance i * B + b = pose i of problem b; RPM's num_iter, FMR's last estimates),
+        evaluated in ONE set of launches with the target scanned once per problem; loss (k * B,), gR (k * B, 3, 3),
+        gt (k * B, 3), bit-identical per instance to k single-pose steps.  Scan mode cull, clouds <= 65536 triangles."""
         dev = _home(src_tri, tar_tri)
         self.dev = dev
         self._extra = dict(reduce_mode=reduce_mode, deterministic=deterministic, sort_parts=sort_parts)
@@ -932,10 +936,17 @@ class RegistrationStep:
         self.tar = _prep(tar_tri, "tar_tri", 9, dev)
         if self.src.dim() != 3 or self.tar.dim() != 3 or self.src.shape[0] != self.tar.shape[0]:
             raise ValueError("src_tri/tar_tri must be (B, n, 9) with the same B")
-        B, N, _ = self.src.shape
+        Bt, N, _ = self.src.shape
         M, L = self.tar.shape[1], int(n_lines)
-        if B == 0 or L <= 0:
+        if Bt == 0 or L <= 0:
             raise ValueError("RegistrationStep needs a non-empty batch and line set")
+        self.poses = int(poses)
+        if self.poses < 1 or (self.poses > 1 and (mode != "cull" or max(N, M) > 65536)):
+            raise ValueError("poses must be >= 1; a multi-pose step runs scan mode cull on clouds <= 65536 triangles")
+        B = Bt * self.poses  # instances of one call
+        self.Bt = Bt
+        if self.poses > 1:
+            self._extra["problems"] = Bt
         self.dims = (B, N, M, L)
         self.rng = _check_range(rng)
         self.tr, self.mode, self.chunk = int(bool(transpose_r)), _MODES[mode], int(chunk)
@@ -962,8 +973,8 @@ class RegistrationStep:
         self.keep_target = True  # False: rebuild the target's records in every call (see invalidate_target)
         self.order1 = self.order2 = None
         if self.prepared:
-            self.order1 = _check_order(src_order, B, N, dev, "src_order") if src_order is not None else cloud_order(self.src)
-            self.order2 = _check_order(tar_order, B, M, dev, "tar_order") if tar_order is not None else cloud_order(self.tar)
+            self.order1 = _check_order(src_order, Bt, N, dev, "src_order") if src_order is not None else cloud_order(self.src)
+            self.order2 = _check_order(tar_order, Bt, M, dev, "tar_order") if tar_order is not None else cloud_order(self.tar)
         self._set_opts()
 
     def invalidate_target(self):
@@ -989,28 +1000,31 @@ class RegistrationStep:
         line -- RPM / FMR evaluate several poses against one target and one line set --: only the source is prepared,
         sorted and scanned here, the target's hit lists are taken from that state (bit-identical results)."""
         B, N, M, L = self.dims
+        Bt = self.Bt  # problems: the clouds, orders and lines have Bt entries; B = poses * Bt instances
         dev = self.dev
         if src_tri is not None:
             self.src = _prep(src_tri, "src_tri", 9, dev)
         if tar_tri is not None:
             self.tar = _prep(tar_tri, "tar_tri", 9, dev)
-        if tuple(self.src.shape) != (B, N, 9) or tuple(self.tar.shape) != (B, M, 9):
-            raise ValueError(f"src_tri {(B, N, 9)} / tar_tri {(B, M, 9)} expected")
+        if tuple(self.src.shape) != (Bt, N, 9) or tuple(self.tar.shape) != (Bt, M, 9):
+            raise ValueError(f"src_tri {(Bt, N, 9)} / tar_tri {(Bt, M, 9)} expected")
+        if self.poses > 1 and target_from is not None:
+            raise ValueError("a multi-pose step scans its target itself")
         op = self._optr
         if self.prepared:
             if src_tri is not None or src_order is not None or tar_tri is not None or tar_order is not None:
                 if src_tri is not None or src_order is not None:  # a new source: its order comes along, or is taken now
-                    self.order1 = _check_order(src_order, B, N, dev, "src_order") if src_order is not None else cloud_order(self.src)
+                    self.order1 = _check_order(src_order, Bt, N, dev, "src_order") if src_order is not None else cloud_order(self.src)
                 if tar_tri is not None or tar_order is not None:
-                    self.order2 = _check_order(tar_order, B, M, dev, "tar_order") if tar_order is not None else cloud_order(self.tar)
+                    self.order2 = _check_order(tar_order, Bt, M, dev, "tar_order") if tar_order is not None else cloud_order(self.tar)
                     self._kept_key = None
                 self._set_opts()
             key = _write_key(self.tar) if (self.keep_target and target_from is None) else None
             op = self._optr_kept if (key is not None and key == self._kept_key) else self._optr
             self._kept_key = None  # (set again below, once the call has been issued: a call that raises keeps nothing)
         Rm, tv, ln = _prep(R, "R", None, dev), _prep(t, "t", None, dev), _prep(line, "line", 6, dev)
-        if Rm.numel() != B * 9 or tv.numel() != B * 3 or tuple(ln.shape) != (B, L, 6):
-            raise ValueError("R (B,3,3), t (B,3), line (B, L, 6) expected")
+        if Rm.numel() != B * 9 or tv.numel() != B * 3 or tuple(ln.shape) != (Bt, L, 6):
+            raise ValueError("R (poses * B, 3, 3), t (poses * B, 3), line (B, L, 6) expected")
         g = self.ones if grad_loss is None else _prep(grad_loss, "grad_loss", None, dev)
         lib, s = self._lib, _stream(dev)
         tail_s, fixed_f = self._tail_s, self._fixed_f
@@ -1053,21 +1067,28 @@ class LossStep:
     gradient to the rounding of the scatter's float atomics.  prepared / src_order / tar_order as RegistrationStep."""
 
     def __init__(self, src_tri, tar_tri, n_lines, rng=(1, 1, 5, 5), transpose_r=True, mode="cull", chunk=0,
-                 prepared=None, src_order=None, tar_order=None, chamfer=False, want_payload=False):
+                 prepared=None, src_order=None, tar_order=None, chamfer=False, want_payload=False, poses=1):
         """chamfer=True: every step also leaves the Chamfer monitor of its clouds in .chamfer_value -- its walk rides in the
         step's scan launch (ChamferRide), as in RegistrationStep.
         want_payload=True: .payload (14,) = [sum of the valid losses, #valid, 0 x 12] after every step -- what a rank
-        contributes to the all-reduce of the scalar loss (rrl_hip.dist; points1.grad stays local)."""
+        contributes to the all-reduce of the scalar loss (rrl_hip.dist; points1.grad stays local).
+        poses = k > 1: a multi-pose step as RegistrationStep's -- R (k * B, 3, 3), t (k * B, 3) (required), loss (k * B,),
+        grad (k * B, N, 9) = dL/d(moved triangles) of every instance."""
         dev = _home(src_tri, tar_tri)
         self.dev = dev
         self.src = _prep(src_tri, "src_tri", 9, dev)
         self.tar = _prep(tar_tri, "tar_tri", 9, dev)
         if self.src.dim() != 3 or self.tar.dim() != 3 or self.src.shape[0] != self.tar.shape[0]:
             raise ValueError("src_tri/tar_tri must be (B, n, 9) with the same B")
-        B, N, _ = self.src.shape
+        Bt, N, _ = self.src.shape
         M, L = self.tar.shape[1], int(n_lines)
-        if B == 0 or L <= 0:
+        if Bt == 0 or L <= 0:
             raise ValueError("LossStep needs a non-empty batch and line set")
+        self.poses, self.Bt = int(poses), Bt
+        if self.poses < 1 or (self.poses > 1 and (mode != "cull" or max(N, M) > 65536)):
+            raise ValueError("poses must be >= 1; a multi-pose step runs scan mode cull on clouds <= 65536 triangles")
+        B = Bt * self.poses
+        prob = Bt if self.poses > 1 else None
         self.ride = ChamferRide(B, N, M, dev) if chamfer else None
         self.chamfer_value = None
         self.dims = (B, N, M, L)
@@ -1083,13 +1104,13 @@ class LossStep:
         self.keep_target = True  # see RegistrationStep.invalidate_target
         # (in the workspace's accumulator field: the step's first launch clears it, as for RegistrationStep)
         self.payload = self.st.gacc[B * 12:B * 12 + 14] if want_payload else None
-        self._opts = self._opts_kept = make_opts(chamfer=self.ride, payload=self.payload)  # (None without either)
+        self._opts = self._opts_kept = make_opts(chamfer=self.ride, payload=self.payload, problems=prob)  # (None without any)
         if self.prepared:
-            self.order1 = _check_order(src_order, B, N, dev, "src_order") if src_order is not None else cloud_order(self.src)
-            self.order2 = _check_order(tar_order, B, M, dev, "tar_order") if tar_order is not None else cloud_order(self.tar)
-            self._opts = make_opts(order1=self.order1, order2=self.order2, chamfer=self.ride, payload=self.payload)
+            self.order1 = _check_order(src_order, Bt, N, dev, "src_order") if src_order is not None else cloud_order(self.src)
+            self.order2 = _check_order(tar_order, Bt, M, dev, "tar_order") if tar_order is not None else cloud_order(self.tar)
+            self._opts = make_opts(order1=self.order1, order2=self.order2, chamfer=self.ride, payload=self.payload, problems=prob)
             self._opts_kept = make_opts(order1=self.order1, order2=self.order2, target_kept=True, chamfer=self.ride,
-                                        payload=self.payload)
+                                        payload=self.payload, problems=prob)
         self._optr, self._optr_kept = _optr(self._opts), _optr(self._opts_kept)
         self._lib = _lib.load()
 
@@ -1104,8 +1125,8 @@ class LossStep:
         tv = _prep(t, "t", None, dev) if t is not None else None
         ln = _prep(line, "line", 6, dev)
         if (Rm is None) != (tv is None) or (Rm is not None and (Rm.numel() != B * 9 or tv.numel() != B * 3)) \
-                or tuple(ln.shape) != (B, L, 6):
-            raise ValueError("R (B,3,3) and t (B,3) (or both None), line (B, L, 6) expected")
+                or tuple(ln.shape) != (self.Bt, L, 6) or (self.poses > 1 and Rm is None):
+            raise ValueError("R (poses * B, 3, 3) and t (poses * B, 3) (or both None for poses = 1), line (B, L, 6) expected")
         g = self.ones if grad_loss is None else _prep(grad_loss, "grad_loss", None, dev)
         op, key = self._optr, None
         if self.prepared:

@@ -621,6 +621,22 @@ def test_multi_pose_equals_pose_after_pose(L, Bt, k, n, m, nl, prepared):
             assert bool(((got - want).abs() <= 2e-5 * want.abs() + 2e-6 * float(want.abs().max())).all())
         assert abs(float(cms[i]) - float(cham)) <= 1e-6 * max(1e-6, abs(float(cham)))
     assert int((info[:, 0] > 0).sum()) == k * Bt
+    # the thin steps with poses = k (no autograd, one C call): the same instances
+    Rd, td = Rm.detach(), tm.detach()
+    rs = ops.RegistrationStep(src, tar, nl, prepared=prepared, src_order=o1, tar_order=o2, poses=k)
+    ls = ops.LossStep(src, tar, nl, prepared=prepared, src_order=o1, tar_order=o2, poses=k, want_payload=True)
+    for _ in range(2):  # (the second call: kept target)
+        r_out, l_out = rs(Rd, td, ln), ls(Rd, td, ln)
+    torch.cuda.synchronize()
+    assert torch.equal(r_out[0], loss.detach()) and torch.equal(l_out[0], loss.detach()) and torch.equal(r_out[4], info)
+    assert bool(((r_out[1] - Rm.grad).abs() <= 2e-5 * Rm.grad.abs() + 2e-6 * float(Rm.grad.abs().max())).all())
+    assert float(ls.payload[1]) == k * Bt and abs(float(ls.payload[0]) - float(loss.detach().double().sum())) <= 2e-6 * float(loss.detach().sum())
+    for i in range(k):
+        one = ops.LossStep(src, tar, nl, prepared=prepared, src_order=o1, tar_order=o2)
+        lo, go, _ = one(Rs[i].detach(), ts[i].detach(), ln)
+        gm = l_out[1][i * Bt:(i + 1) * Bt]
+        assert torch.equal(lo, loss.detach()[i * Bt:(i + 1) * Bt])
+        assert bool(((gm - go).abs() <= 2e-5 * go.abs() + 2e-6 * float(go.abs().max())).all())
 
 
 def test_multi_pose_argument_errors(L):
