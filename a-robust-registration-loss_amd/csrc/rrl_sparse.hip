@@ -1319,12 +1319,24 @@ __global__ __launch_bounds__(TAIL_LANES) void loss_tail_kernel(const TailArgs a)
     const bool scatter = a.grad_tri1 != nullptr;  // uniform: gradient to the points (rrl_loss_step), not to (R, t)
 
     // ---- round 1: the sample's tile counts, histogram and bucket counts; the compact tile of "this lane's" line
-    //      (lanes 0 .. 255, four per line: lane h of line r adds hit slot h's gradient, lane 0 the line's Welsch terms)
+    //      (lanes 0 .. 255, four per line: lane h of line r adds hit slot h's gradient, lane 0 the line's Welsch terms).
+    //      Round 5: EVERYTHING of this round is requested before the tile's own count is looked at -- the count only decides
+    //      whether the workgroup has lines at all and which of its line slots are real, never an address (a tile's compact
+    //      slots exist whether or not they are filled): the early exit used to cost every live workgroup one dependent
+    //      round trip (count -> the line's slot).  Vector loads return in order, so the wait for the count (requested
+    //      first) does not wait for the rest.
     const int mycnt = a.blkcnt[(size_t)b * nblk + tile];
-    if (sub * TAIL_LINES >= mycnt && !(tile == 0 && sub == 0)) return;  // uniform: no line for this workgroup
     const int bc = tid < nblk ? a.blkcnt[(size_t)b * nblk + tid] : 0;
     const int vraw = tid < nblk ? a.vlcnt[(size_t)b * nblk + tid] : 0;  // (-1: the per-line stage built no list -- a knob
     const int vc = vraw > 0 ? (vraw + 3) >> 2 : 0;                      // changed between the stages: flagged below)
+    const int h = tid & 3;
+    int r = sub * TAIL_LINES + (tid >> 2);  // compact rank within the tile of this lane's line (lanes < 256); first chunk
+    unsigned kl_raw = 0u;
+    float4 dr_raw = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
+    if (tid < 4 * TAIL_LINES) {  // (r <= 255: inside the tile's 1024 slots; a slot beyond the count holds stale data: masked below)
+        kl_raw = lidc[slot0 + r];
+        dr_raw = ((const float4 *)(dc + (slot0 + r) * 16))[h];
+    }
     unsigned hb[BPL];
     {
         const uint4 hq = ((const uint4 *)(a.mhist + (size_t)b * 2048))[tid];
@@ -1332,12 +1344,14 @@ __global__ __launch_bounds__(TAIL_LANES) void loss_tail_kernel(const TailArgs a)
         static_assert(BPL == 4, "one 16-byte load of the histogram per lane");
     }
     const unsigned bkt = tid < 16 ? ctl[tid] : 0u;
-    const int h = tid & 3;
-    int r = sub * TAIL_LINES + (tid >> 2);  // compact rank within the tile of this lane's line (lanes < 256); first chunk
+    const float gl_in0 = do_bwd ? a.grad_loss[b] : 0.0f;
+    if (sub * TAIL_LINES >= mycnt && !(tile == 0 && sub == 0)) return;  // uniform: no line for this workgroup
     bool mine_on = tid < 4 * TAIL_LINES && r < mycnt;
-    unsigned kl = 0u;
+    unsigned kl = mine_on ? kl_raw : 0u;
     float dr[4];  // row h of the line's canonical D tile (the four lanes of a line hold one row each)
-    auto load_line = [&]() {
+    dr[0] = mine_on ? dr_raw.x : INFINITY; dr[1] = mine_on ? dr_raw.y : INFINITY;
+    dr[2] = mine_on ? dr_raw.z : INFINITY; dr[3] = mine_on ? dr_raw.w : INFINITY;
+    auto load_line = [&]() {  // (the later chunks of a crowded tile: their slots depend on the count)
         kl = 0u;
 #pragma unroll
         for (int q = 0; q < 4; ++q) dr[q] = INFINITY;
@@ -1347,8 +1361,7 @@ __global__ __launch_bounds__(TAIL_LANES) void loss_tail_kernel(const TailArgs a)
             dr[0] = v.x; dr[1] = v.y; dr[2] = v.z; dr[3] = v.w;
         }
     };
-    load_line();
-    const float gl_in = do_bwd ? a.grad_loss[b] : 0.0f;
+    const float gl_in = gl_in0;
     if (tid < 32) s_sum[tid] = 0ull;
     if (tid < 2) s_flag[tid] = 0u;
     if (tid == 0) s_ncand = 0u;
