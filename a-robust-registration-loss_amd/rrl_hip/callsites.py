@@ -189,7 +189,7 @@ class _PackedPoses(torch.autograd.Function):
         if g is None:
             return (None,) * 7
         loss, R, t = ctx.inner
-        gR, gt = torch.autograd.grad([loss], [R, t], [g])
+        gR, gt = torch.autograd.grad([loss], [R, t], [g], retain_graph=True)  # (the caller may run backward() twice: retain_graph)
         return torch.cat([gR, gt.unsqueeze(-1)], -1).reshape(ctx.shape), None, None, None, None, None, None
 
 
