@@ -1813,7 +1813,7 @@ RrlCall rrl_resolve_opts(const rrl_opts *p) {
 }
 // Which reduce kernel: 0 one workgroup per sample, 1 tiled with the candidate exchange (loss_reduce_tiled_kernel), 2 the
 // tail kernel (no exchange: every workgroup streams its sample's dense value lists; one 512-lane workgroup or two
-// per compute unit, so it serves the small, latency-bound grids: B x tiles <= 128, <= 16 tiles per sample).
+// per compute unit, so it serves the small, latency-bound grids: B x tiles <= 256, <= 16 tiles per sample).
 // mode 0 (auto): the tail kernel where the direct backward rides along (with_bwd: rrl_registration_step -- measured
 // -1.9 .. -3.4 us per step at C2 / L = 4096 / C4; as a reduce alone it is 1.7 us SLOWER than the exchange kernel, and at
 // the demo's shape, one sample of 20 tiles, the two are even), else the exchange kernel for >= 2 tiles while the grid
@@ -1856,11 +1856,21 @@ static long xchg_capacity() {
     }
     return cap[dev];
 }
+// (sample, tile) pairs up to which the tail kernel serves a call (experiments: RRL_TAIL_MAX_WG)
+static long tail_max_wg() {
+    static long v = -1;
+    if (v < 0) {
+        const char *e = getenv("RRL_TAIL_MAX_WG");
+        v = e ? atol(e) : 256;  // measured at 10 tiles per sample (round 5): B = 16 78.5 -> 77.7, B = 24 98.0 -> 96.7 us per step with the
+        if (v < 1) v = 256;     // tail kernel, B = 32 121 -> 128, B = 64 200 -> 213 (the exchange reduce + a backward launch win there)
+    }
+    return v;
+}
 static int reduce_kind(int mode, int B, int nblk, int pool, bool with_bwd) {
     if (pool || mode == 1) return 0;
     const bool xchg_ok = (long)B * nblk <= xchg_capacity();
     if (mode == 3) return xchg_ok && nblk >= 1 ? 1 : 0;
-    const bool tail_ok = nblk <= TAIL_MAX_TILES && (long)B * nblk <= 128;
+    const bool tail_ok = nblk <= TAIL_MAX_TILES && (long)B * nblk <= tail_max_wg();
     if (mode == 2 && tail_ok && nblk >= 1) return 2;
     if (mode == 0 && tail_ok && with_bwd && nblk >= 2 && nblk <= 16) return 2;
     return xchg_ok && nblk >= 2 ? 1 : 0;

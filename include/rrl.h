@@ -286,7 +286,7 @@ int rrl_registration_backward(const float *src, const float *R, const float *tri
  * known up front (grad_loss [B], usually ones): rpm/Train_RPM.py:226-259, dcp/Train_DCP.py:246-270 compute the loss
  * and call backward() right away.  Same arguments and results as rrl_registration_forward_cached followed by
  * rrl_registration_backward(grad_src = NULL); where the tail kernel serves the shape (auto mode: 2 .. 16 line tiles per
- * sample and B x tiles <= 128; not in deterministic mode) the backward rides in the reduce's launch -- 4 launches per
+ * sample and B x tiles <= 256; not in deterministic mode) the backward rides in the reduce's launch -- 4 launches per
  * step with prepared orders (rrl_opts), 5 without -- and the two kernels' chains of dependent loads overlap; a single
  * tile of lines (L <= 1024) is finished by one workgroup per sample (per-line stage + reduce + backward); every other
  * shape runs the forward and then the backward launch.  gR [B][9], gt [B][3], payload [14] or NULL: ideally the
@@ -340,7 +340,7 @@ int rrl_registration_step_ex(const float *src, const float *R, const float *t, c
  * workspace field TRI1; R == t == NULL: points1 = tri1 as given.  grad_loss [B] = dL/dloss (usually ones),
  * grad_tri1 [B][N][9] = dL/dpoints1 -- cleared by the call's first launch, accumulated by float atomics like
  * rrl_loss_backward --, grad_tri2 [B][M][9] or NULL.  Where the tail kernel serves the shape (2 .. 16 line tiles,
- * B x tiles <= 128) and grad_tri2 == NULL the scatter rides in the reduce's launch: 4 launches per step with prepared
+ * B x tiles <= 256) and grad_tri2 == NULL the scatter rides in the reduce's launch: 4 launches per step with prepared
  * orders (opts), 5 without; otherwise forward + the scatter kernel of rrl_loss_backward.  Loss, median, bucket sums
  * bit-identical to rrl_loss_forward / rrl_registration_forward; gradients equal rrl_loss_backward's to the rounding of
  * the atomics.  pool semantics: independent samples (pool = 0). */
@@ -417,9 +417,9 @@ int rrl_loss_reduce_rows(const float *rows16, const uint8_t *kj, int nrows, int3
  *            device (compute units x occupancy, queried once per device; 1280 on a whole MI355X);
  *   tail     loss_tail_kernel: no exchange (every workgroup streams its sample's dense D-value lists and selects the
  *            median itself, one ticket, no spin), and the direct / scatter backward can ride in the same launch.
- *            Legal for <= 32 tiles per sample and B x tiles <= 128.
+ *            Legal for <= 32 tiles per sample and B x tiles <= 256.
  * mode 0 (auto): tail where a backward rides along (rrl_registration_step, rrl_loss_step), the sample has 2 .. 16 tiles
- *   and B x tiles <= 128; else xchg for >= 2 tiles within its capacity; else single.  A forward alone never takes the
+ *   and B x tiles <= 256; else xchg for >= 2 tiles within its capacity; else single.  A forward alone never takes the
  *   tail kernel in auto mode (as a reduce alone it is 1.7 us slower than xchg).  A single tile of lines (L <= 1024) is
  *   finished by one workgroup per sample together with the per-line stage (and the direct backward).
  * mode 1: single everywhere.  mode 2 ("tiled"): tail wherever it is legal (also forward only, also one tile), xchg
