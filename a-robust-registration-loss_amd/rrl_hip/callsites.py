@@ -165,32 +165,35 @@ MULTI_POSE = os.environ.get("RRL_MULTI_POSE", "1") != "0"  # the iterative train
 
 
 class _PackedPoses(torch.autograd.Function):
-    """k x B poses given as ONE (k, B, 3, 4) tensor [R | t] -> loss (k * B,), info (k * B, 4): the multi-pose evaluation
-    (ops.registration_loss with k * B poses for B problems) behind a node that takes and returns the PACKED transforms --
-    the fragment's own torch ops shrink to a stack in front and one product + sum behind (the fragments' device time was
-    half tiny torch kernels: 40 launches of ~2 us around 6 of ours; eager, their host time dominates)."""
+    """k x B poses given as ONE (k, B, 3, 4) tensor [R | t] -> loss (k * B,), info (k * B, 4): the (multi-pose) evaluation
+    behind a node that takes and returns the PACKED transforms -- the fragment's own torch ops shrink to a stack in front
+    and one product + sum behind (the fragments' device time was half tiny torch kernels: 40 launches of ~2 us around 6
+    of ours; eager, their host time dominates).  Forward AND backward of the evaluation are ONE C call in the forward
+    (ops.registration_step_raw: the gradients for dL/dloss = 1; the backward rides in the reduce's launch where the tail
+    kernel serves the shape): the loss is linear in the upstream gradient, so this node's backward only scales them."""
 
     @staticmethod
     def forward(ctx, P, src_tri, tar_tri, lines, o1, o2, ride):
         k, B = P.shape[:2]
         Pd = P.detach().reshape(k * B, 3, 4)
-        R = Pd[:, :, :3].contiguous().requires_grad_(True)
-        t = Pd[:, :, 3].contiguous().requires_grad_(True)
-        with torch.enable_grad():
-            loss, info, _ = _ops.registration_loss(src_tri, R, t, tar_tri, lines, RNG, transpose_r=True, mode="cull",
-                                                   order1=o1, order2=o2, chamfer=ride)
-        ctx.inner, ctx.shape = (loss, R, t), P.shape
+        dev = _ops._home(src_tri, tar_tri, lines, Pd)
+        R = _ops._prep(Pd[:, :, :3], "R", None, dev)
+        t = _ops._prep(Pd[:, :, 3], "t", None, dev)
+        loss, gR, gt, info, st = _ops.registration_step_raw(
+            _ops._prep(src_tri, "src_tri", 9, dev), R, t, _ops._prep(tar_tri, "tar_tri", 9, dev), _ops._prep(lines, "line", 6, dev),
+            RNG, True, o1, o2, ride)
+        ctx.grads, ctx.shape, ctx.st = (gR, gt), P.shape, st  # (views of the state's workspace: the state stays alive with the node)
         ctx.mark_non_differentiable(info)
         ctx.set_materialize_grads(False)
-        return loss.detach(), info
+        return loss.clone(), info  # (a fresh tensor: the state's loss buffer must not become an autograd output)
 
     @staticmethod
     def backward(ctx, g, _gi):
         if g is None:
             return (None,) * 7
-        loss, R, t = ctx.inner
-        gR, gt = torch.autograd.grad([loss], [R, t], [g], retain_graph=True)  # (the caller may run backward() twice: retain_graph)
-        return torch.cat([gR, gt.unsqueeze(-1)], -1).reshape(ctx.shape), None, None, None, None, None, None
+        gR, gt = ctx.grads
+        g = g.reshape(-1, 1, 1)
+        return torch.cat([gR * g, (gt * g.reshape(-1, 1)).unsqueeze(-1)], -1).reshape(ctx.shape), None, None, None, None, None, None
 
 
 _weights = {}  # (values, B, device) -> (k * B,) per-instance weights of a fragment's discounted sum
@@ -218,7 +221,7 @@ def multi_pose_loss(src_nb, transforms, tar_tri, lines, mode=None, data=None, ch
     k = len(transforms)
     B = src_nb.shape[0]
     src_tri, tar_tri = src_nb.reshape(B, -1, 9), tar_tri.reshape(B, -1, 9)
-    if not MULTI_POSE or k < 2 or _mode(mode) != "cull" or max(src_tri.shape[1], tar_tri.shape[1]) > _SORT_CAP:
+    if not MULTI_POSE or k < 1 or _mode(mode) != "cull" or max(src_tri.shape[1], tar_tri.shape[1]) > _SORT_CAP:
         return None
     o1, o2 = _orders(data, src_tri.shape[1], tar_tri.shape[1], B, src_tri.device if src_tri.is_cuda else None)
     P = torch.stack([x[..., :3, :] for x in transforms])  # (k, B, 3, 4)
@@ -244,7 +247,7 @@ def rpm_intersection_loss(pred_transforms, data, n_lines=10000, lines=None, mode
     src = data['points_src_sample'][..., :3]
     per_iter, chamfers, valid = [], [], []
     first = None  # LossState of iteration 0: target + lines are the same in every iteration
-    if num_iter > 1:  # all poses are known up front: ONE evaluation of num_iter * B instances (round 5, multi_pose_loss)
+    if num_iter >= 1:  # all poses are known up front: ONE evaluation of num_iter * B instances (round 5, multi_pose_loss)
         moved0 = None
         if lines is None:
             moved0 = _ops.rigid_apply(src, *_split(pred_transforms[0]), transpose_r=True)
@@ -323,7 +326,7 @@ def fmr_intersection_loss(g_series, data, n_lines=15000, lines=None, last=3, mod
                            moved.detach(), tar)
     total, valid, first = 0.0, [], None
     idx = list(range(max(maxiter - last, 0), maxiter))
-    if len(idx) > 1:  # the last estimates as ONE evaluation (round 5, multi_pose_loss)
+    if len(idx) >= 1:  # the last estimates as ONE evaluation (round 5, multi_pose_loss)
         got = multi_pose_loss(data['points_based_neighs_src'], [g_series[i] for i in idx], tar_tri, lines, mode, data=data,
                               chamfer=_ride_monitor(data))
         if got is not None:

@@ -1148,6 +1148,47 @@ class LossStep:
         return self.st.loss.view(-1), self.grad, self.st.info
 
 
+def registration_step_raw(src_tri, R, t, tar_tri, line, rng=(1, 1, 5, 5), transpose_r=True, order1=None, order2=None,
+                          chamfer=False):
+    """ONE evaluation of the fused training op, forward AND backward for dL/dloss = 1, as one C call on a FRESH state
+    (rrl_registration_step_ex: where the tail kernel serves the shape the backward rides in the reduce's launch): returns
+    (loss (B,), gR (B, 3, 3), gt (B, 3), info (B, 4), state) -- gR[s], gt[s] = d loss[s] / d(R[s], t[s]); the loss is
+    linear in the upstream gradient, so an autograd node scales them (callsites._PackedPoses) instead of running a
+    backward of its own.  R, t with k * B_t poses for B_t problems: a multi-pose evaluation (rrl_opts.problems).  Inputs
+    must be prepared GPU tensors (fp32, contiguous); scan mode cull.  The outputs live in the returned state's workspace."""
+    dev = src_tri.device
+    Bt, N, _ = src_tri.shape
+    M, L = tar_tri.shape[1], line.shape[1]
+    B = R.shape[0]
+    if not (tar_tri.shape[0] == line.shape[0] == Bt and t.shape[0] == B) or Bt == 0 or B % Bt or L <= 0:
+        raise ValueError("src_tri / tar_tri / line share B_t > 0; R, t hold k * B_t poses; L > 0")
+    problems = Bt if B != Bt else 0
+    s_m, s_n, e_m, e_n = _check_range(rng)
+    st = LossState(B, N, M, L, B, dev)
+    ride = ChamferRide(B, N, M, dev) if chamfer else None
+    opts = make_opts(order1=_check_order(order1, Bt, N, dev, "order1"), order2=_check_order(order2, Bt, M, dev, "order2"),
+                     chamfer=ride, problems=problems)
+    gacc = st.gacc
+    ones = _ones_cache.get((B, dev))
+    if ones is None:
+        if len(_ones_cache) > 32:
+            _ones_cache.clear()
+        ones = _ones_cache[(B, dev)] = torch.ones(B, dtype=torch.float32, device=dev)
+    _arm_ride(opts)
+    with _guard(dev):
+        check(_lib.load().rrl_registration_step_ex(
+            _p(src_tri), _p(R), _p(t), _p(tar_tri), _p(line), _p(st.ws), st.nbytes, _p(st.loss), _p(ones),
+            _p(gacc[:B * 9]), _p(gacc[B * 9:B * 12]), None, B, N, M, L, int(transpose_r), s_m, s_n, e_m, e_n, SCAN_CULL, 0, None,
+            _optr(opts), _stream(dev)), "rrl_registration_step")
+    st.target_state = None
+    _keep_ride(st, ride)
+    _IntersectionLoss.last_state = st
+    return st.loss.view(-1), gacc[:B * 9].view(B, 3, 3), gacc[B * 9:B * 12].view(B, 3), st.info, st
+
+
+_ones_cache = {}
+
+
 def set_deterministic(on):
     """Bit-reproducible direct backward of registration_loss (fixed-order partial sums, one more tiny
     launch) instead of float atomics; include/rrl.h rrl_set_deterministic.  Process-wide."""
