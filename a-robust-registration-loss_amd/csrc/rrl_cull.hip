@@ -768,11 +768,22 @@ namespace scan8 {
 #undef QA_CAP
 #undef QC_CAP
 #undef CULL_REGLINES
+// (experiments: the fat variant's knobs have names of their own -- -DSCAN16_QA_CAP=... -- the plain names configure scan8)
+#ifndef SCAN16_QA_CAP
+#define SCAN16_QA_CAP 384
+#endif
+#ifndef SCAN16_QC_CAP
+#define SCAN16_QC_CAP 256
+#endif
+#ifndef SCAN16_WCCAP
+#define SCAN16_WCCAP 128
+#endif
 namespace scan16 {
 #define SPW 16
 #define CULL_REGLINES 1
-#define QA_CAP 384
-#define QC_CAP 256
+#define QA_CAP SCAN16_QA_CAP
+#define QC_CAP SCAN16_QC_CAP
+#define WCCAP SCAN16_WCCAP
 #include "rrl_cull_scan.inc"
 }
 static_assert(scan8::kWPB == scan16::kWPB && scan8::kLPW == scan16::kLPW, "one line tiling for both variants");
