@@ -69,9 +69,45 @@ def run(seed=0, n_cases=150, log=print):
           for a, b in zip(res[False][4:], res[True][4:]):
               a, b = torch.nan_to_num(a, nan=-7.0), torch.nan_to_num(b, nan=-7.0)
               step = step and bool(((a - b).abs() <= 2e-5 * a.abs() + 2e-6 * float(a.abs().max()) + 1e-12).all())
-      if not (ok and fin and same and cached and step):
+      # ---- round 5 paths
+      # the FAT geometry variant of the culled scan (forced) == the lean one (forced): counts, hit lists' sizes, loss, NaN flag
+      fat = True
+      if max(N, M) > 512:
+          res5 = {}
+          for flag in ("0", "1"):
+              os.environ["RRL_CULL_FAT"] = flag
+              try:
+                  stf = ops.loss_forward_raw(src, tar, lines, mode="cull")
+                  torch.cuda.synchronize()
+              finally:
+                  del os.environ["RRL_CULL_FAT"]
+              res5[flag] = stf
+          a_, b_ = res5["0"], res5["1"]
+          fat = torch.equal(a_.count1, b_.count1) and torch.equal(a_.count2, b_.count2) and int(a_.status[0]) == int(b_.status[0]) and \
+              (torch.equal(a_.loss, b_.loss) or torch.equal(torch.nan_to_num(a_.loss, nan=-7.0), torch.nan_to_num(b_.loss, nan=-7.0))) and \
+              torch.equal(a_.count1, st_s.count1)
+      # the section-8(d) step with its shard payload == the forward's loss; its gradient finite; k poses as ONE multi-pose
+      # evaluation (thin step, poses = k) == the k single-pose steps, per instance (identity poses: every instance equal)
+      multi = True
+      if N >= 1 and M >= 1 and max(N, M) <= 65536:
+          k = int(rng.integers(2, 4))
+          ls = ops.LossStep(src, tar, Ln, want_payload=True)
+          lo = ls(R.detach(), t.detach(), lines)
+          mp = ops.LossStep(src, tar, Ln, poses=k, want_payload=True)
+          mo = mp(R.detach().repeat(k, 1, 1), t.detach().repeat(k, 1), lines)
+          torch.cuda.synchronize()
+          nn = lambda x: torch.nan_to_num(x, nan=-7.0)
+          valid = lo[2][:, 0] > 0
+          want = float(nn(lo[0])[valid].double().sum())
+          multi = torch.equal(nn(lo[0]), nn(st_c.loss)) and torch.equal(nn(mo[0]), nn(lo[0]).repeat(k)) and \
+              float(ls.payload[1]) == float(valid.sum()) and (abs(float(nn(ls.payload[:1])[0]) - want) <= 2e-6 * max(1.0, abs(want)) or int(st_c.status[0]) != 0) and \
+              float(mp.payload[1]) == k * float(valid.sum()) and bool(torch.isfinite(nn(lo[1])).all())
+          ga, gb = nn(lo[1]).repeat(k, 1, 1), nn(mo[1])
+          multi = multi and bool(((ga - gb).abs() <= 2e-5 * ga.abs() + 2e-6 * float(ga.abs().max()) + 1e-12).all())
+      if not (ok and fin and same and cached and step and fat and multi):
           bad += 1
-          log("MISMATCH " + str(dict(case=case, B=B, N=N, M=M, L=Ln, scale=scale, ok=ok, fin=fin, same=same, cached=cached, step=step)))
+          log("MISMATCH " + str(dict(case=case, B=B, N=N, M=M, L=Ln, scale=scale, ok=ok, fin=fin, same=same, cached=cached, step=step,
+                                      fat=fat, multi=multi)))
   log(f"{n_cases} cases, {bad} mismatches, {time.time() - t0:.1f} s")
   return bad
 
