@@ -137,6 +137,8 @@ struct BuildArgs {
     int nzwords;
     int B, N, M, transpose_r, nblk;
     int nchunk;                    // tri_sort_kernel: chunks of 4096 records per cloud (1: the whole cloud)
+    int xcd_align;                 // tri_records_sorted_kernel: run the workgroups of (cloud, sample) pair p on XCD p % 8 -- where
+                                   // the culled scan's workgroups of that pair run (its grid has the pair on the fast index)
     int Bt;                        // multi-pose evaluation (rrl_opts.problems): the INPUT clouds, orders and lines have Bt
                                    // entries and instance b uses entry b % Bt; 0 / B: every instance has its own
 };
@@ -256,15 +258,21 @@ __global__ __launch_bounds__(REC_BLK) void tri_records_kernel(const BuildArgs a)
     __shared__ float red[REC_BLK / 64][8];
     __shared__ float red2[REC_BLK / 64][2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int cloud = blockIdx.z, b = blockIdx.y, B = a.B;
+    const int B = a.B;
+    int cloud = blockIdx.z, b = blockIdx.y, bxr = blockIdx.x;
+    if (a.xcd_align) {  // (uniform) pair p = cloud * B + b on XCD p % 8, where its sort and scan workgroups run (see the sorted kernel)
+        const int gx = gridDim.x, lin = bxr + gx * (b + B * cloud), slot = lin >> 3;
+        const int p = (lin & 7) + 8 * (slot / gx);
+        bxr = slot % gx; cloud = p / B; b = p - cloud * B;
+    }
     build_clear_state(a);  // per-call state and gradient accumulator
     const int n = cloud ? a.M : a.N;
-    if ((int)blockIdx.x >= a.nblk_tri) {  // uniform: the launch's LMAX_CHUNKS extra workgroups per sample reduce its lines
+    if (bxr >= a.nblk_tri) {  // uniform: the launch's LMAX_CHUNKS extra workgroups per sample reduce its lines
         if (cloud == 0 && a.lmax != nullptr)  // (one chunk each: they run beside the triangle workgroups)
-            line_max_chunks(a.line, a.L, a.lmax, b, (int)blockIdx.x - a.nblk_tri, LMAX_CHUNKS, red2, input_of(b, a.Bt));
+            line_max_chunks(a.line, a.L, a.lmax, b, bxr - a.nblk_tri, LMAX_CHUNKS, red2, input_of(b, a.Bt));
         return;
     }
-    const int f = blockIdx.x * REC_BLK + tid;
+    const int f = bxr * REC_BLK + tid;
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY}, p2 = 0.0f;
     if (f < n) {
         float c[9], x;
@@ -274,7 +282,7 @@ __global__ __launch_bounds__(REC_BLK) void tri_records_kernel(const BuildArgs a)
 #pragma unroll
         for (int d = 0; d < 3; ++d) { mn[d] = c[d]; mx[d] = c[d]; }
     }
-    if (blockIdx.x * REC_BLK >= n) return;  // uniform: this workgroup has no triangle of the cloud
+    if (bxr * REC_BLK >= n) return;  // uniform: this workgroup has no triangle of the cloud
 #pragma unroll
     for (int c = 0; c < 3; ++c) { mn[c] = wave_min(mn[c]); mx[c] = wave_max(mx[c]); }
     p2 = wave_max(p2);
@@ -287,9 +295,9 @@ __global__ __launch_bounds__(REC_BLK) void tri_records_kernel(const BuildArgs a)
     if (tid < 7) {
         float r = red[0][tid];
         for (int w = 1; w < REC_BLK / 64; ++w) r = tid < 3 ? fminf(r, red[w][tid]) : fmaxf(r, red[w][tid]);
-        a.apart[(((size_t)cloud * B + b) * a.nblk + blockIdx.x) * 8 + tid] = r;
+        a.apart[(((size_t)cloud * B + b) * a.nblk + bxr) * 8 + tid] = r;
     } else if (tid == 7) {
-        a.apart[(((size_t)cloud * B + b) * a.nblk + blockIdx.x) * 8 + 7] = 0.0f;  // PTRI layout of this cloud: original order
+        a.apart[(((size_t)cloud * B + b) * a.nblk + bxr) * 8 + 7] = 0.0f;  // PTRI layout of this cloud: original order
     }
 }
 
@@ -317,17 +325,23 @@ __global__ __launch_bounds__(REC_BLK) void tri_records_sorted_kernel(const Build
     __shared__ float red[REC_BLK / 64][8];
     __shared__ float red2[REC_BLK / 64][2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int cloud = blockIdx.z, b = blockIdx.y, B = a.B;
+    const int B = a.B;
+    int cloud = blockIdx.z, b = blockIdx.y, bxr = blockIdx.x;
+    if (a.xcd_align) {  // (uniform) pair p = cloud * B + b on XCD p % 8: workgroups go to the XCDs round-robin by linear id
+        const int gx = gridDim.x, lin = bxr + gx * (b + B * cloud), slot = lin >> 3;
+        const int p = (lin & 7) + 8 * (slot / gx);
+        bxr = slot % gx; cloud = p / B; b = p - cloud * B;
+    }
     build_clear_state(a);
     const int n = cloud ? a.M : a.N;
-    if ((int)blockIdx.x >= a.nblk_tri) {  // uniform: the line maxima, beside the triangle workgroups (tri_records_kernel)
+    if (bxr >= a.nblk_tri) {  // uniform: the line maxima, beside the triangle workgroups (tri_records_kernel)
         if (cloud == 0 && a.lmax != nullptr)
-            line_max_chunks(a.line, a.L, a.lmax, b, (int)blockIdx.x - a.nblk_tri, LMAX_CHUNKS, red2, input_of(b, a.Bt));
+            line_max_chunks(a.line, a.L, a.lmax, b, bxr - a.nblk_tri, LMAX_CHUNKS, red2, input_of(b, a.Bt));
         return;
     }
     const int npad = (n + SGT - 1) / SGT * SGT;
-    if ((int)blockIdx.x * REC_BLK >= npad) return;  // uniform: the smaller cloud has fewer workgroups
-    const int s = blockIdx.x * REC_BLK + tid;
+    if (bxr * REC_BLK >= npad) return;  // uniform: the smaller cloud has fewer workgroups
+    const int s = bxr * REC_BLK + tid;
     const bool valid = s < n;  // real records occupy the sorted positions [0, n)
     float c[9] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}, x = 0.0f, p2 = 0.0f;
     int f = 0;
@@ -355,9 +369,9 @@ __global__ __launch_bounds__(REC_BLK) void tri_records_sorted_kernel(const Build
     if (tid < 7) {
         float r = red[0][tid];
         for (int w = 1; w < REC_BLK / 64; ++w) r = tid < 3 ? fminf(r, red[w][tid]) : fmaxf(r, red[w][tid]);
-        a.apart[(((size_t)cloud * B + b) * a.nblk + blockIdx.x) * 8 + tid] = r;
+        a.apart[(((size_t)cloud * B + b) * a.nblk + bxr) * 8 + tid] = r;
     } else if (tid == 7) {
-        a.apart[(((size_t)cloud * B + b) * a.nblk + blockIdx.x) * 8 + 7] = 1.0f;  // PTRI layout of this cloud: sorted positions
+        a.apart[(((size_t)cloud * B + b) * a.nblk + bxr) * 8 + 7] = 1.0f;  // PTRI layout of this cloud: sorted positions
     }
 }
 
@@ -931,10 +945,17 @@ int rrl_launch_tri_build(const float *tri1, const float *tri2, void *ws, const W
     a.B = B; a.N = N; a.M = M;
     a.transpose_r = xf ? xf->transpose_r : 0;
     a.Bt = o.problems;
+    a.xcd_align = 0;
     const int nall = N > M ? N : M;  // APART is laid out for the larger cloud
     a.nblk = (nall + REC_BLK - 1) / REC_BLK;
     a.nchunk = chunked ? (nmax + 4095) / 4096 : 1;
     a.nblk_tri = (nmax + REC_BLK - 1) / REC_BLK;
+    {   // producer and consumer of a cloud's records on the same XCD (round 5: -0.7 us on the records launch, -0.5 us on the
+        // scan at C2; RRL_XCD_ALIGN=0 turns it off)
+        static int xa = -1;
+        if (xa < 0) { const char *e = getenv("RRL_XCD_ALIGN"); xa = e && e[0] == '0' ? 0 : 1; }
+        a.xcd_align = xa && (clouds * B) % 8 == 0 ? 1 : 0;
+    }
     if (o.prepared()) {  // the order is known: ONE launch (records at their sorted positions + tree refit), no sort
         a.z2 = nullptr; a.z2_vec4 = 0;
         a.nblk_tri = (int)(((size_t)(nmax + SGT - 1) / SGT * SGT + REC_BLK - 1) / REC_BLK);

@@ -165,6 +165,22 @@ __device__ __forceinline__ void pair_hit(const float *__restrict__ tri1, const f
     ((float2 *)dc_slot)[sub] = make_float2(t2[0], t2[1]);
 }
 
+// XCD-aware placement of the per-sample stages (round 5).  Workgroups go to the 8 XCDs round-robin by linear id (observed;
+// a matter of speed only), each XCD has its own L2, and everything a sample's per-line stage, reduce and backward read was
+// written by workgroups of that sample: the culled scan runs the (cloud, sample) pair on the fast grid index, i.e. sample b
+// (both clouds, when B % 8 == 0) on XCD b % 8.  With B % 8 == 0 the stages below decode their place in the grid so that
+// sample b's workgroups run on XCD b % 8 too: (x, y) of a grid (gx fast, B samples) for linear id `lin`.
+__device__ __forceinline__ void xcd_sample_of(int lin, int gx, int &x, int &b) {
+    const int slot = lin >> 3;
+    x = slot % gx;
+    b = (lin & 7) + 8 * (slot / gx);
+}
+static int xcd_align_on() {  // RRL_XCD_ALIGN=0 turns it off (experiments)
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("RRL_XCD_ALIGN"); v = e && e[0] == '0' ? 0 : 1; }
+    return v;
+}
+
 struct PairArgs {
     const float *tri1, *tri2, *line;  // the triangles of both clouds (raw 36-byte rows: st1 = st2 = 9), the lines
     const int32_t *count1, *hit1, *count2, *hit2;
@@ -182,6 +198,7 @@ struct PairArgs {
     int B, N, M, L, s_m, s_n, e_m, e_n, st1, st2;
     int Bt;  // multi-pose evaluation (rrl_opts.problems): tri2, line and cloud 2's scan (count2, hit2) of instance b are those
              // of problem b % Bt; 0: every instance has its own
+    int xcd_align;  // line_pair_dist_kernel: sample b's workgroups on XCD b % 8 (xcd_sample_of; B % 8 == 0)
 };
 
 // One tile of 1024 lines of sample b by a 1024-lane workgroup.  Phase 1: every lane classifies its line
@@ -295,7 +312,9 @@ __device__ __forceinline__ void pair_body(const PairArgs &a, int b, int tile, in
 }
 
 __global__ __launch_bounds__(1024) void line_pair_dist_kernel(const PairArgs a) {
-    pair_body(a, (int)blockIdx.y, (int)blockIdx.x, (int)gridDim.x);
+    int tile = blockIdx.x, b = blockIdx.y;
+    if (a.xcd_align) xcd_sample_of(tile + (int)gridDim.x * b, (int)gridDim.x, tile, b);  // (uniform)
+    pair_body(a, b, tile, (int)gridDim.x);
 }
 
 // tri1 / tri2: the triangles as the loss sees them -- the caller's rows, or TRI1 (the moved source of the fused op) --, raw
@@ -350,6 +369,7 @@ static PairArgs pair_args(const float *tri1, const float *tri2, const float *lin
     a.s_m = s_m; a.s_n = s_n; a.e_m = e_m; a.e_n = e_n;
     a.st1 = 9; a.st2 = 9;
     a.Bt = Bt;  // multi-pose (RrlCall::problems)
+    a.xcd_align = B % 8 == 0 && xcd_align_on();
     return a;
 }
 
@@ -1276,6 +1296,7 @@ struct TailArgs {
     float *gR, *gt, *payload;
     float *grad_tri1;  // != NULL: the backward SCATTERS dL/dpoints1 [B][N][9] (rrl_loss_step) instead of summing (dR, dt)
     int Bt;            // multi-pose (rrl_opts.problems): src has Bt entries, instance b is a pose of entry b % Bt; 0: its own
+    int xcd_align;     // sample b's workgroups on XCD b % 8 (xcd_sample_of; B % 8 == 0)
 };
 
 // LDS-only workgroup barrier: this wavefront's LDS traffic is complete, its vector-memory loads stay in flight
@@ -1309,7 +1330,9 @@ __global__ __launch_bounds__(TAIL_LANES) void loss_tail_kernel(const TailArgs a)
     constexpr int NW = TAIL_LANES / 64, BPL = 2048 / TAIL_LANES;  // wavefronts; histogram bins per lane
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // (sub is the SLOW grid index: the workgroups that certainly have lines are dispatched first)
-    const int tile = blockIdx.x, sub = blockIdx.z, b = blockIdx.y, nblk = a.nblk;
+    const int nblk = a.nblk, sub = blockIdx.z;
+    int tile = blockIdx.x, b = blockIdx.y;
+    if (a.xcd_align) xcd_sample_of(tile + nblk * b, nblk, tile, b);  // (uniform; every sub-grid of nblk x B workgroups is a multiple of 8)
     const size_t Lp = (size_t)nblk * 1024;
     uint32_t *ctl = a.mctl + (size_t)b * 64;
     const float *__restrict__ dc = a.dc;
@@ -1921,6 +1944,7 @@ static int loss_reduce_impl(void *ws, size_t ws_bytes, float *loss, int B, int N
         t.gR = tb ? tb->gR : nullptr; t.gt = tb ? tb->gt : nullptr; t.payload = tb ? tb->payload : nullptr;
         t.grad_tri1 = tb ? tb->grad_tri1 : nullptr;
         t.Bt = o.problems;
+        t.xcd_align = B % 8 == 0 && xcd_align_on();
         hipLaunchKernelGGL(loss_tail_kernel, dim3((unsigned)nblk, (unsigned)B, TAIL_SUBS), dim3(TAIL_LANES), 0,
                            (hipStream_t)stream, t);
         RRL_LAUNCH_CHECK();
@@ -2003,7 +2027,7 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(
     const float *__restrict__ w2, const float4 *__restrict__ Q1, const float4 *__restrict__ Q2,
     const float *__restrict__ D, const float *__restrict__ med, const int32_t *__restrict__ bcnt,
     const int32_t *__restrict__ info, const float *__restrict__ grad_loss, float *__restrict__ g1,
-    float *__restrict__ g2, int B, int N, int M, int L, int pool) {
+    float *__restrict__ g2, int B, int N, int M, int L, int pool, int xcd_align) {
     // one lane per (selected line, side, hit slot): 8 lanes share a line, each owns one gradient row of <= 9 floats.  They
     // also SHARE the line's Welsch tile (round 3): the lane of (cloud 1, hit a) evaluates row a, the lane of (cloud 2, hit b)
     // column b -- <= 4 exponentials and divisions where every lane used to evaluate all 16 entries (welsch_block) -- and the
@@ -2011,7 +2035,9 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(
     // without a line or hit carry +inf.  Same expressions and tie-breaks as welsch_block on the whole tile.
     __shared__ unsigned s_scat[4][64 * SCAT_STRIDE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tile = blockIdx.x, b = blockIdx.y, sub = blockIdx.z, ntile = gridDim.x;
+    const int sub = blockIdx.z, ntile = gridDim.x;
+    int tile = blockIdx.x, b = blockIdx.y;
+    if (xcd_align) xcd_sample_of(tile + ntile * b, ntile, tile, b);  // (uniform) sample b's workgroups on XCD b % 8
     const int g = pool ? 0 : b;
     const int cnt = blkcnt[(size_t)b * ntile + tile];
     if (sub * BWDS_LINES >= cnt) return;  // uniform: no line for this workgroup
@@ -2485,7 +2511,8 @@ static int loss_backward_impl(const float *tri1, const float *tri2, const void *
                        w.f32(ws, RRL_WS_W1), w.f32(ws, RRL_WS_W2), (const float4 *)w.f32(ws, RRL_WS_Q1),
                        (const float4 *)w.f32(ws, RRL_WS_Q2),
                        w.f32(ws, RRL_WS_D), w.f32(ws, RRL_WS_MED), w.i32(ws, RRL_WS_BCNT),
-                       w.i32(ws, RRL_WS_INFO), grad_loss, grad_tri1, grad_tri2, B, N, M, L, pool);
+                       w.i32(ws, RRL_WS_INFO), grad_loss, grad_tri1, grad_tri2, B, N, M, L, pool,
+                       B % 8 == 0 && xcd_align_on() ? 1 : 0);
     RRL_LAUNCH_CHECK();
     return 0;
 }
