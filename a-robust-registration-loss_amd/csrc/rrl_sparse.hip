@@ -904,6 +904,7 @@ struct TiledArgs {
     int32_t *status;      // [0] the scan's NaN flag (read); [2] += samples repaired after a hand-off time-out
     int B, nblk, s_m, s_n, e_m, e_n;
     unsigned spin_limit;  // polls before a waiting workgroup gives up (rrl_set_spin_limit: tests set 0)
+    int xcd_align;        // sample b's workgroups on XCD b % 8 (xcd_sample_of; B % 8 == 0): its in-launch hand-offs stay in one L2
 };
 
 // Hand-offs between the workgroups of this launch (candidate list + TICK1, MEDRDY) are bounded spins.  A workgroup whose
@@ -923,7 +924,9 @@ __global__ __launch_bounds__(256) void loss_reduce_tiled_kernel(const TiledArgs 
     __shared__ float s_term[16];
     __shared__ int s_cnt[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tile = blockIdx.x, b = blockIdx.y, nblk = a.nblk;
+    const int nblk = a.nblk;
+    int tile = blockIdx.x, b = blockIdx.y;
+    if (a.xcd_align) xcd_sample_of(tile + nblk * b, nblk, tile, b);  // (uniform)
     const size_t Lp = (size_t)nblk * 1024;
     uint32_t *ctl = a.mctl + (size_t)b * 64;
     uint32_t *cand = a.mcand + (size_t)b * MCAND_CAP;
@@ -1960,6 +1963,7 @@ static int loss_reduce_impl(void *ws, size_t ws_bytes, float *loss, int B, int N
         t.info = w.i32(ws, RRL_WS_INFO); t.loss = loss; t.status = w.i32(ws, RRL_WS_STATUS);
         t.B = B; t.nblk = nblk; t.s_m = s_m; t.s_n = s_n; t.e_m = e_m; t.e_n = e_n;
         t.spin_limit = spin_limit();
+        t.xcd_align = B % 8 == 0 && xcd_align_on();
         hipLaunchKernelGGL(loss_reduce_tiled_kernel, dim3((unsigned)nblk, (unsigned)B), dim3(256), 0, (hipStream_t)stream, t);
         RRL_LAUNCH_CHECK();
         return 0;
@@ -2352,9 +2356,11 @@ __global__ __launch_bounds__(256) void loss_bwd_rt_kernel(
     const int32_t *__restrict__ bcnt, const int32_t *__restrict__ info,
     const float *__restrict__ grad_loss, const float *__restrict__ src, float *__restrict__ gR,
     float *__restrict__ gt, float *__restrict__ payload, const float *__restrict__ loss, int B, int N,
-    int L, int transpose_r, float *__restrict__ part, int Bt) {
+    int L, int transpose_r, float *__restrict__ part, int Bt, int xcd_align) {
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (xcd_align) xcd_sample_of(bx + (int)gridDim.x * by, (int)gridDim.x, bx, by);  // (uniform) sample `by` on XCD by % 8
     loss_bwd_rt_body<DET>(kj, sel, nsel, hs1, w1, Q1, Q2, D, med, bcnt, info, grad_loss, src, gR, gt, payload, loss, B, N, L,
-                          transpose_r, part, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x, Bt);
+                          transpose_r, part, bx, by, (int)gridDim.x, Bt);
 }
 
 // The direct backward AND the write pass of the next epoch's line sampler in ONE launch (round 4b; rrl_ws.h RrlWriteRider,
@@ -2858,7 +2864,7 @@ static int registration_backward_impl(const float *src, const float *R, const fl
                            w.f32(ws, RRL_WS_W1), (const float4 *)w.f32(ws, RRL_WS_Q1),                             \
                            (const float4 *)w.f32(ws, RRL_WS_Q2), w.f32(ws, RRL_WS_D), w.f32(ws, RRL_WS_MED),       \
                            w.i32(ws, RRL_WS_BCNT), w.i32(ws, RRL_WS_INFO), grad_loss, src, gR, gt, payload, loss,  \
-                           B, N, L, transpose_r, PART, o.problems)
+                           B, N, L, transpose_r, PART, o.problems, B % 8 == 0 && xcd_align_on() ? 1 : 0)
         // the next epoch's sampler write pass rides along (bwd_write_kernel; rrl_demo_epoch)
         RrlWriteRider *wr = o.write_rider;
         const int wtiles = wr ? (wr->n + 1023) / 1024 : 0;
