@@ -1316,7 +1316,9 @@ __device__ __forceinline__ void tail_payload(const TailArgs &a, float lv) {
     atomicMax((unsigned *)&a.payload[0], __float_as_uint(tot));
 }
 
-__global__ __launch_bounds__(TAIL_LANES) void loss_tail_kernel(const TailArgs a) {
+// (>= 4 wavefronts per SIMD = two 512-lane workgroups per CU: beyond 128 VGPRs a grid of more than 256 live workgroups -- B >= 16
+//  at ten tiles -- would run in two generations: measured 17 -> 23.6 us at B = 16 when an edit pushed the kernel to 132)
+__global__ __launch_bounds__(TAIL_LANES) __attribute__((amdgpu_waves_per_eu(4, 8))) void loss_tail_kernel(const TailArgs a) {
     __shared__ unsigned s_vals[MCAND_CAP];  // the bin's values (usual route) / histogram of the streaming passes
     __shared__ unsigned s_wtot[TAIL_LANES / 64];
     __shared__ unsigned s_pick[3];          // bin, rank inside it, its population
@@ -1571,6 +1573,78 @@ __global__ __launch_bounds__(TAIL_LANES) void loss_tail_kernel(const TailArgs a)
     int C = 0;
     for (int kk = a.s_m; kk < a.e_m; ++kk)
         for (int jj = a.s_n; jj < a.e_n; ++jj) C += s_cnt[(kk - 1) * 4 + (jj - 1)] > 0 ? 1 : 0;
+    // ---- the sample-wide part: this workgroup's fixed-point sums -> MSUM, one arrival ticket, and the LAST arriver of the
+    //      sample turns the sums into the loss.  ONE wavefront runs it.  Round 5: when all of the workgroup's lines sit in its
+    //      first chunk (<= 256 selected lines in the tile: always, at the shapes measured) the wavefront is the workgroup's
+    //      LAST one -- it holds no lines, so its vector-memory queue is empty -- and it starts as soon as the Welsch sums are
+    //      in LDS, while the wavefronts that hold lines go on with the gradient: the chain sums -> acknowledged -> ticket ->
+    //      read-back (5.3 us of a 14.8 us launch at C2: the same kernel returning before it takes 9.5) no longer waits for the
+    //      gradient's loads and the scatter's atomics in wavefront 0's queue.
+    auto finish = [&]() {
+    if (lane < 32) {
+        const unsigned long long v = s_sum[lane];
+        if (v) atomicAdd(&a.msum[(size_t)b * 32 + lane], v);
+    }
+    if (lane == 32 && s_flag[1]) atomicOr(&ctl[MCTL_BAD], 1u);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wavefront's sums have arrived before it takes its ticket
+    unsigned last = 0;
+    if (lane == 0)
+        last = __hip_atomic_fetch_add(&ctl[MCTL_TICK2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(nlive - 1) ? 1u : 0u;
+    if (!__builtin_amdgcn_readfirstlane((int)last)) return;
+
+    // ---- the last workgroup of the sample: loss = ( sum_{non-empty (k,j), k-major} exp(-|k-j|/2) (mean_row + mean_col) ) / C
+    unsigned long long tot = 0ull;
+    unsigned anybad = 0u;
+    if (lane < 32) {
+        tot = __hip_atomic_load(&a.msum[(size_t)b * 32 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        a.bsum_out[(size_t)b * 32 + lane] = (int64_t)tot;
+        __hip_atomic_store(&a.msum[(size_t)b * 32 + lane], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // a second reduce on this state starts clean
+    } else if (lane < 48) {
+        a.bcnt_out[b * 16 + lane - 32] = s_cnt[lane - 32];
+    } else if (lane == 48) {
+        anybad = ld_agent(&ctl[MCTL_BAD]);
+    }
+    const bool bad = __builtin_amdgcn_readlane((int)anybad, 48) != 0;
+    // lane 2 q + c holds sum c (row / column) of bucket q: one lane per bucket takes both (the double-precision means, as
+    // reduce_body)
+    const unsigned long long trow = __shfl(tot, (2 * lane) & 63), tcol = __shfl(tot, (2 * lane + 1) & 63);
+    float term = 0.0f;
+    if (lane < 16) {
+        const int kk = lane / 4 + 1, jj = lane % 4 + 1, S = s_cnt[lane];
+        if (S > 0 && kk >= a.s_m && kk < a.e_m && jj >= a.s_n && jj < a.e_n) {
+            const double sc = 1.0 / (double)(1ll << FIX_SHIFT);
+            float mrow = (float)((double)trow * sc / ((double)S * kk));
+            float mcol = (float)((double)tcol * sc / ((double)S * jj));
+            float wkj = expf(-0.5f * (float)abs(kk - jj));  // code/loss.py:215
+            term = wkj * (mrow + mcol);
+        }
+        s_term[lane] = term;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (lane == 0) {
+        float accl = 0.0f;
+        int Cn = 0, nselected = 0, nvalues = 0;
+        for (int kk = a.s_m; kk < a.e_m; ++kk)      // k-major, the reference's accumulation order
+            for (int jj = a.s_n; jj < a.e_n; ++jj) {
+                const int bi = (kk - 1) * 4 + (jj - 1);
+                if (s_cnt[bi] == 0) continue;
+                accl = accl + s_term[bi];
+                ++Cn;
+                nselected += s_cnt[bi];
+            }
+        for (int bi = 0; bi < 16; ++bi) nvalues += s_cnt[bi] * (bi / 4 + 1) * (bi % 4 + 1);
+        const float lv = bad ? __builtin_nanf("") : (Cn ? accl / (float)Cn : 0.0f);  // code/loss.py:230
+        a.med_out[b] = med;
+        a.loss[b] = lv;
+        a.info[b * 4 + 0] = Cn;
+        a.info[b * 4 + 1] = nselected;
+        a.info[b * 4 + 2] = nvalues;
+        a.info[b * 4 + 3] = a.status[0];
+        st_agent(&ctl[MCTL_TICK2], 0u); st_agent(&ctl[MCTL_BAD], 0u);
+        if (do_bwd && a.payload && Cn > 0) tail_payload(a, lv);
+    }
+    };
+    const bool single_chunk = mycnt <= TAIL_SUBS * TAIL_LINES;  // uniform
     float acc[12];
 #pragma unroll
     for (int q = 0; q < 12; ++q) acc[q] = 0.0f;
@@ -1648,6 +1722,10 @@ __global__ __launch_bounds__(TAIL_LANES) void loss_tail_kernel(const TailArgs a)
             atomicAdd(&s_sum[bi * 2 + 1], (unsigned long long)((double)col * (double)(1ll << FIX_SHIFT) + 0.5));
         }
     }
+    if (single_chunk) {  // (uniform) every wavefront's Welsch sums are in LDS: the finisher wavefront takes them from here
+        lds_barrier();
+        if (wave == NW - 1) finish();  // (then it falls through the rest like the other wavefronts without lines)
+    }
     float sv[9] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};  // this lane's gradient row (scatter)
     bool sc_live = false;
     if (bwd_live && C > 0) {
@@ -1705,6 +1783,9 @@ __global__ __launch_bounds__(TAIL_LANES) void loss_tail_kernel(const TailArgs a)
             for (int q = 0; q < 12; ++q) s_red[wave][q] = acc[q];
     }
     __syncthreads();
+#ifdef TAIL_EXP_NOFINAL  // timing experiment only (results invalid): what do the fixed-point sums -> ticket -> read-back cost?
+    return;
+#endif
     // ---- from here on wavefront 1 adds the workgroup's gradient sums and wavefront 0 does everything else by itself (its
     //      lanes see each other's LDS writes in program order: no workgroup barrier any more); the rest is done
     if (wave == 1 && do_bwd && !scatter && mycnt > 0 && lane < 12) {
@@ -1715,69 +1796,8 @@ __global__ __launch_bounds__(TAIL_LANES) void loss_tail_kernel(const TailArgs a)
         if (q < 9) atomicAdd(&a.gR[b * 9 + o], v); else atomicAdd(&a.gt[b * 3 + (q - 9)], v);
         if (a.payload) atomicAdd(&a.payload[2 + o], v);
     }
-    if (wave != 0) return;
-    if (lane < 32) {
-        const unsigned long long v = s_sum[lane];
-        if (v) atomicAdd(&a.msum[(size_t)b * 32 + lane], v);
-    }
-    if (lane == 32 && s_flag[1]) atomicOr(&ctl[MCTL_BAD], 1u);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wavefront's sums have arrived before it takes its ticket
-    unsigned last = 0;
-    if (lane == 0)
-        last = __hip_atomic_fetch_add(&ctl[MCTL_TICK2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(nlive - 1) ? 1u : 0u;
-    if (!__builtin_amdgcn_readfirstlane((int)last)) return;
-
-    // ---- the last workgroup of the sample: loss = ( sum_{non-empty (k,j), k-major} exp(-|k-j|/2) (mean_row + mean_col) ) / C
-    unsigned long long tot = 0ull;
-    unsigned anybad = 0u;
-    if (lane < 32) {
-        tot = __hip_atomic_load(&a.msum[(size_t)b * 32 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        a.bsum_out[(size_t)b * 32 + lane] = (int64_t)tot;
-        __hip_atomic_store(&a.msum[(size_t)b * 32 + lane], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // a second reduce on this state starts clean
-    } else if (lane < 48) {
-        a.bcnt_out[b * 16 + lane - 32] = s_cnt[lane - 32];
-    } else if (lane == 48) {
-        anybad = ld_agent(&ctl[MCTL_BAD]);
-    }
-    const bool bad = __builtin_amdgcn_readlane((int)anybad, 48) != 0;
-    // lane 2 q + c holds sum c (row / column) of bucket q: one lane per bucket takes both (the double-precision means, as
-    // reduce_body)
-    const unsigned long long trow = __shfl(tot, (2 * lane) & 63), tcol = __shfl(tot, (2 * lane + 1) & 63);
-    float term = 0.0f;
-    if (lane < 16) {
-        const int kk = lane / 4 + 1, jj = lane % 4 + 1, S = s_cnt[lane];
-        if (S > 0 && kk >= a.s_m && kk < a.e_m && jj >= a.s_n && jj < a.e_n) {
-            const double sc = 1.0 / (double)(1ll << FIX_SHIFT);
-            float mrow = (float)((double)trow * sc / ((double)S * kk));
-            float mcol = (float)((double)tcol * sc / ((double)S * jj));
-            float wkj = expf(-0.5f * (float)abs(kk - jj));  // code/loss.py:215
-            term = wkj * (mrow + mcol);
-        }
-        s_term[lane] = term;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    if (lane == 0) {
-        float accl = 0.0f;
-        int Cn = 0, nselected = 0, nvalues = 0;
-        for (int kk = a.s_m; kk < a.e_m; ++kk)      // k-major, the reference's accumulation order
-            for (int jj = a.s_n; jj < a.e_n; ++jj) {
-                const int bi = (kk - 1) * 4 + (jj - 1);
-                if (s_cnt[bi] == 0) continue;
-                accl = accl + s_term[bi];
-                ++Cn;
-                nselected += s_cnt[bi];
-            }
-        for (int bi = 0; bi < 16; ++bi) nvalues += s_cnt[bi] * (bi / 4 + 1) * (bi % 4 + 1);
-        const float lv = bad ? __builtin_nanf("") : (Cn ? accl / (float)Cn : 0.0f);  // code/loss.py:230
-        a.med_out[b] = med;
-        a.loss[b] = lv;
-        a.info[b * 4 + 0] = Cn;
-        a.info[b * 4 + 1] = nselected;
-        a.info[b * 4 + 2] = nvalues;
-        a.info[b * 4 + 3] = a.status[0];
-        st_agent(&ctl[MCTL_TICK2], 0u); st_agent(&ctl[MCTL_BAD], 0u);
-        if (do_bwd && a.payload && Cn > 0) tail_payload(a, lv);
-    }
+    if (wave != 0 || single_chunk) return;  // (single_chunk: the finisher wavefront took this part on long ago)
+    finish();
 }
 
 // K2 + K3 + K4 in ONE launch when a sample has a single tile of lines (L <= 1024) and the samples are not pooled:
