@@ -1318,6 +1318,9 @@ __device__ __forceinline__ void tail_payload(const TailArgs &a, float lv) {
 
 // (>= 4 wavefronts per SIMD = two 512-lane workgroups per CU: beyond 128 VGPRs a grid of more than 256 live workgroups -- B >= 16
 //  at ten tiles -- would run in two generations: measured 17 -> 23.6 us at B = 16 when an edit pushed the kernel to 132)
+//  SCATTER: the backward goes to points1.grad (rrl_loss_step) instead of (dR, dt) -- a template parameter, so that neither
+//  instantiation carries the other's registers (source coordinates and 12 sums / the 9-float gradient row).
+template <bool SCATTER>
 __global__ __launch_bounds__(TAIL_LANES) __attribute__((amdgpu_waves_per_eu(4, 8))) void loss_tail_kernel(const TailArgs a) {
     __shared__ unsigned s_vals[MCAND_CAP];  // the bin's values (usual route) / histogram of the streaming passes
     __shared__ unsigned s_wtot[TAIL_LANES / 64];
@@ -1344,7 +1347,7 @@ __global__ __launch_bounds__(TAIL_LANES) __attribute__((amdgpu_waves_per_eu(4, 8
     const uint32_t *__restrict__ lidc = a.lidc;
     const size_t slot0 = (size_t)b * Lp + (size_t)tile * 1024;
     const bool do_bwd = a.do_bwd != 0;  // uniform
-    const bool scatter = a.grad_tri1 != nullptr;  // uniform: gradient to the points (rrl_loss_step), not to (R, t)
+    constexpr bool scatter = SCATTER;  // gradient to the points (rrl_loss_step), not to (R, t)
 
     // ---- round 1: the sample's tile counts, histogram and bucket counts; the compact tile of "this lane's" line
     //      (lanes 0 .. 255, four per line: lane h of line r adds hit slot h's gradient, lane 0 the line's Welsch terms).
@@ -1968,8 +1971,12 @@ static int loss_reduce_impl(void *ws, size_t ws_bytes, float *loss, int B, int N
         t.grad_tri1 = tb ? tb->grad_tri1 : nullptr;
         t.Bt = o.problems;
         t.xcd_align = B % 8 == 0 && xcd_align_on();
-        hipLaunchKernelGGL(loss_tail_kernel, dim3((unsigned)nblk, (unsigned)B, TAIL_SUBS), dim3(TAIL_LANES), 0,
-                           (hipStream_t)stream, t);
+        if (t.grad_tri1)
+            hipLaunchKernelGGL(loss_tail_kernel<true>, dim3((unsigned)nblk, (unsigned)B, TAIL_SUBS), dim3(TAIL_LANES), 0,
+                               (hipStream_t)stream, t);
+        else
+            hipLaunchKernelGGL(loss_tail_kernel<false>, dim3((unsigned)nblk, (unsigned)B, TAIL_SUBS), dim3(TAIL_LANES), 0,
+                               (hipStream_t)stream, t);
         RRL_LAUNCH_CHECK();
         if (bwd_done) *bwd_done = tb != nullptr;
         return 0;
