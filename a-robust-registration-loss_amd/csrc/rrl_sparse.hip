@@ -1271,7 +1271,9 @@ __global__ __launch_bounds__(256) void loss_reduce_tiled_kernel(const TiledArgs 
 #define TAIL_MAX_TILES 32
 #define TAIL_LANES 512
 #define TAIL_LINES 64  // selected lines per workgroup (four lanes each)
+#ifndef TAIL_SUBS
 #define TAIL_SUBS 4    // workgroups per tile (grid z): workgroup s takes the tile's chunks s, s + 4, ... of TAIL_LINES lines
+#endif
 #define TAIL_RPL 4     // compact rows per lane and streaming round
 #define MCTL_LSUM 34   // (row of sample 0, 8-byte aligned) uint64: fixed-point sum of the valid samples' losses
 
