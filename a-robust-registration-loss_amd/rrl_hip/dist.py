@@ -23,8 +23,10 @@ def init_from_env(backend=None):
     # under torchrun (RANK set) the group is created even for one rank, so that a 1-GPU launch
     # exercises the same RCCL path as N > 1
     if (world > 1 or "RANK" in os.environ) and not dist.is_initialized():
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend is None:  # RRL_DIST_BACKEND=gloo: e.g. several ranks SHARING one GPU (RCCL refuses duplicate devices) -- the
+            backend = os.environ.get("RRL_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")  # N > 1 host logic
+        if torch.cuda.is_available() and os.environ.get("RRL_SHARE_GPU") == "1":  # validated on a 1-GPU box (tests/test_gpu_harness.py)
+            local = local % max(torch.cuda.device_count(), 1)
         if backend == "nccl":
             torch.cuda.set_device(local)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -587,3 +587,34 @@ def test_fragments_multi_pose_equals_the_loop(C, G):
     assert abs(float(a[2]) - float(b[2])) <= 1e-6 * abs(float(b[2])) and abs(float(a[7]) - float(b[7])) <= 1e-6 * abs(float(b[7]))
     for i in (4, 5, 9):
         assert bool(((a[i] - b[i]).abs() <= 2e-5 * b[i].abs() + 2e-6 * float(b[i].abs().max())).all())
+
+
+def test_bench_two_ranks_sharing_one_gpu():
+    """The N > 1 HOST LOGIC of bench.py on a 1-GPU box: two ranks under `python -m torch.distributed.run --nproc-per-node 2`,
+    both on cuda:0 (RRL_SHARE_GPU=1), the payload all-reduced over gloo (RRL_DIST_BACKEND=gloo: RCCL refuses two ranks on one
+    device) -- the shard bounds, the collective choice of the issue / reducer placement (max over ranks), the barrier-fenced
+    timing with its MAX all-reduce, rank 0's line with the WHOLE job's pairs and sums.  Throughput means nothing here (two
+    processes time-slice one GPU); the structure is what is checked.  (No multi-GPU node was available to any round.)"""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, RRL_SHARE_GPU="1", RRL_DIST_BACKEND="gloo")
+    out = {}
+    for name, extra in (("weak", []), ("strong", ["--global-batch", "8"])):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", "29741", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "40", "--warmup", "5",
+               "--no-cpu-baseline", "--no-extras", "--no-other", "--points", "1024", "--lines", "4000", "--batch", "4"] + extra
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, r.stdout[-1500:]  # rank 0 alone prints
+        out[name] = json.loads(lines[0])
+    w, s = out["weak"], out["strong"]
+    assert w["n_gpus"] == 2 and w["scaling"] == "weak" and w["config"]["global_batch"] == 8 and w["extras"]["valid"] == 8.0
+    assert w["config"]["allreduce"]["backend"] == "gloo" and w["config"]["allreduce"]["reducer"] == "PayloadReducer"
+    assert w["config"]["parallelism"] == "batch-shard dp2" and w["config"]["step"].startswith("loss_step")
+    assert w["value"] == pytest.approx(2 * 4 * 4000 * 3 * 2048 * w["steps"] / (w["ms_per_step"] * 1e-3 * w["steps"]), rel=1e-9)
+    assert s["scaling"] == "strong" and s["config"]["global_batch"] == 8 and s["extras"]["valid"] == 8.0
+    assert s["extras"]["loss_sum"] > 0 and w["extras"]["loss_sum"] > 0
+    print("two ranks on one GPU (gloo):", {k: round(v["ms_per_step"], 4) for k, v in out.items()})
