@@ -137,6 +137,7 @@ struct BuildArgs {
     int nzwords;
     int B, N, M, transpose_r, nblk;
     int nchunk;                    // tri_sort_kernel: chunks of 4096 records per cloud (1: the whole cloud)
+    int clouds;                    // clouds built by this launch (1: the target is kept)
     int xcd_align;                 // tri_records_sorted_kernel: run the workgroups of (cloud, sample) pair p on XCD p % 8 -- where
                                    // the culled scan's workgroups of that pair run (its grid has the pair on the fast index)
     int Bt;                        // multi-pose evaluation (rrl_opts.problems): the INPUT clouds, orders and lines have Bt
@@ -147,6 +148,18 @@ __device__ __forceinline__ int input_of(int b, int Bt) { return (Bt > 0 && b >= 
 
 #define REC_BLK 256
 #define LMAX_CHUNKS 64  // per-sample partial maxima of the lines' |dir|^2 and |x0|^2 (-> the culled scan's slack)
+
+#ifdef RRL_STAMPS  // experiments only (RRL_HIPCC_FLAGS=-DRRL_STAMPS -> lib_exp): per-workgroup 100 MHz time stamps of the records launch
+__device__ unsigned long long g_rstamps[8 * 2048];
+#define STAMPR(i) do { if ((threadIdx.x & 63) == 0) { const unsigned wg_ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z); \
+    if (wg_ < 2048u) g_rstamps[(i) * 2048 + wg_] = wall_clock64(); } } while (0)
+extern "C" int rrl_debug_rstamps(unsigned long long *out, int clear) {
+    if (clear) { void *p_ = nullptr; if (hipGetSymbolAddress(&p_, HIP_SYMBOL(g_rstamps)) != hipSuccess) return -1; return hipMemset(p_, 0, sizeof(unsigned long long) * 8 * 2048) == hipSuccess ? 0 : -1; }
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rstamps), sizeof(unsigned long long) * 8 * 2048) == hipSuccess ? 0 : -1;
+}
+#else
+#define STAMPR(i)
+#endif
 
 // |dir|^2 and |x0|^2 of a line as BOTH this pass (partial maxima) and the scan (per-line admission) evaluate them:
 // the same fp32 expressions, so a line the scan admits is covered by the maxima.
@@ -242,6 +255,38 @@ __device__ __forceinline__ void tri_record_row(const BuildArgs &a, int cloud, in
     if (!(p2 <= 3.0e38f)) p2 = INFINITY;  // NaN/inf coordinates: never "provably safe"
 }
 
+// Place of a workgroup in a records launch (1-D grid, round 5): the TRIANGLE workgroups -- nblk_tri per (cloud, sample) pair,
+// the launch's critical path: order -> raw row -> record -> stores -- take the lowest ids and so leave the dispatcher first; the
+// workgroups that reduce the lines' maxima (LMAX_CHUNKS per sample, one chunk each, a quarter of the time) follow.  The grid
+// used to interleave them per sample (16 + 64 at C2): the last sample's triangle workgroups entered 2 us after the first
+// (in-kernel time stamps, tools/stamps_records.py) behind 448 line workgroups.  xcd_align: pair p = cloud * B + b on XCD p % 8
+// -- workgroups go to the XCDs round-robin by linear id --, where its sort and scan workgroups run.
+struct RecPlace {
+    int cloud, b, bxr;  // triangle workgroup bxr of (cloud, sample b); or
+    int lch;            // >= 0: the line-maxima workgroup of chunk lch of sample b
+};
+__device__ __forceinline__ RecPlace rec_place(const BuildArgs &a, int clouds) {
+    const int lin = (int)blockIdx.x, T = a.nblk_tri * a.B * clouds;
+    RecPlace r;
+    r.lch = -1;
+    if (lin >= T) {  // uniform
+        const int j = lin - T;
+        r.cloud = 0; r.b = j / LMAX_CHUNKS; r.bxr = 0; r.lch = j - r.b * LMAX_CHUNKS;
+        return r;
+    }
+    int p;
+    if (a.xcd_align) {
+        const int slot = lin >> 3;
+        p = (lin & 7) + 8 * (slot / a.nblk_tri);
+        r.bxr = slot % a.nblk_tri;
+    } else {
+        p = lin / a.nblk_tri;
+        r.bxr = lin - p * a.nblk_tri;
+    }
+    r.cloud = p / a.B; r.b = p - r.cloud * a.B;
+    return r;
+}
+
 // the clearing of the per-call state (and of the small accumulators), spread over all workgroups of a records launch
 __device__ __forceinline__ void build_clear_state(const BuildArgs &a) {
     const size_t nthr = (size_t)gridDim.x * gridDim.y * gridDim.z * REC_BLK;
@@ -259,17 +304,13 @@ __global__ __launch_bounds__(REC_BLK) void tri_records_kernel(const BuildArgs a)
     __shared__ float red2[REC_BLK / 64][2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int B = a.B;
-    int cloud = blockIdx.z, b = blockIdx.y, bxr = blockIdx.x;
-    if (a.xcd_align) {  // (uniform) pair p = cloud * B + b on XCD p % 8, where its sort and scan workgroups run (see the sorted kernel)
-        const int gx = gridDim.x, lin = bxr + gx * (b + B * cloud), slot = lin >> 3;
-        const int p = (lin & 7) + 8 * (slot / gx);
-        bxr = slot % gx; cloud = p / B; b = p - cloud * B;
-    }
+    const RecPlace pl = rec_place(a, a.clouds);  // (uniform)
+    const int cloud = pl.cloud, b = pl.b, bxr = pl.bxr;
     build_clear_state(a);  // per-call state and gradient accumulator
     const int n = cloud ? a.M : a.N;
-    if (bxr >= a.nblk_tri) {  // uniform: the launch's LMAX_CHUNKS extra workgroups per sample reduce its lines
-        if (cloud == 0 && a.lmax != nullptr)  // (one chunk each: they run beside the triangle workgroups)
-            line_max_chunks(a.line, a.L, a.lmax, b, bxr - a.nblk_tri, LMAX_CHUNKS, red2, input_of(b, a.Bt));
+    if (pl.lch >= 0) {  // uniform: the launch's LMAX_CHUNKS extra workgroups per sample reduce its lines
+        if (a.lmax != nullptr)  // (one chunk each: they run beside the triangle workgroups)
+            line_max_chunks(a.line, a.L, a.lmax, b, pl.lch, LMAX_CHUNKS, red2, input_of(b, a.Bt));
         return;
     }
     const int f = bxr * REC_BLK + tid;
@@ -326,17 +367,16 @@ __global__ __launch_bounds__(REC_BLK) void tri_records_sorted_kernel(const Build
     __shared__ float red2[REC_BLK / 64][2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int B = a.B;
-    int cloud = blockIdx.z, b = blockIdx.y, bxr = blockIdx.x;
-    if (a.xcd_align) {  // (uniform) pair p = cloud * B + b on XCD p % 8: workgroups go to the XCDs round-robin by linear id
-        const int gx = gridDim.x, lin = bxr + gx * (b + B * cloud), slot = lin >> 3;
-        const int p = (lin & 7) + 8 * (slot / gx);
-        bxr = slot % gx; cloud = p / B; b = p - cloud * B;
-    }
+    const RecPlace pl = rec_place(a, a.clouds);  // (uniform)
+    const int cloud = pl.cloud, b = pl.b, bxr = pl.bxr;
+    if (threadIdx.x < 64) STAMPR(0);
     build_clear_state(a);
+    if (threadIdx.x < 64) STAMPR(1);
     const int n = cloud ? a.M : a.N;
-    if (bxr >= a.nblk_tri) {  // uniform: the line maxima, beside the triangle workgroups (tri_records_kernel)
-        if (cloud == 0 && a.lmax != nullptr)
-            line_max_chunks(a.line, a.L, a.lmax, b, bxr - a.nblk_tri, LMAX_CHUNKS, red2, input_of(b, a.Bt));
+    if (pl.lch >= 0) {  // uniform: the line maxima, beside the triangle workgroups (tri_records_kernel)
+        if (a.lmax != nullptr)
+            line_max_chunks(a.line, a.L, a.lmax, b, pl.lch, LMAX_CHUNKS, red2, input_of(b, a.Bt));
+        if (threadIdx.x < 64) STAMPR(5);
         return;
     }
     const int npad = (n + SGT - 1) / SGT * SGT;
@@ -350,11 +390,13 @@ __global__ __launch_bounds__(REC_BLK) void tri_records_sorted_kernel(const Build
         f = min(max(f, 0), n - 1);  // memory safety only: the order must be a permutation of [0, n)
         tri_record_row(a, cloud, b, n, f, s, c, x, p2);
     }
+    if (threadIdx.x < 64 && __float_as_int(c[0] + c[4] + c[8] + x) != 0x12345678) STAMPR(2);
     if (s - lane < npad) {  // wave-uniform: this wavefront holds a supergroup
         (cloud ? a.p0s2 : a.p0s1)[(size_t)b * npad + s] = valid ? make_float4(c[0], c[1], c[2], x) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         (cloud ? a.idx2 : a.idx1)[(size_t)b * npad + s] = f;
         wave_tree(c[0], c[1], c[2], x, valid, lane, (cloud ? a.grp2 : a.grp1) + ((size_t)b * (npad / SGT) + (s - lane) / SGT) * NODE);
     }
+    if (threadIdx.x < 64) STAMPR(3);
     // per-workgroup partial AABB of the P0s and max |P|^2, as tri_records_kernel leaves them
     float mn[3], mx[3];
 #pragma unroll
@@ -366,6 +408,7 @@ __global__ __launch_bounds__(REC_BLK) void tri_records_sorted_kernel(const Build
         red[wave][6] = p2;
     }
     __syncthreads();
+    if (threadIdx.x < 64) STAMPR(4);
     if (tid < 7) {
         float r = red[0][tid];
         for (int w = 1; w < REC_BLK / 64; ++w) r = tid < 3 ? fminf(r, red[w][tid]) : fmaxf(r, red[w][tid]);
@@ -942,7 +985,7 @@ int rrl_launch_tri_build(const float *tri1, const float *tri2, void *ws, const W
     a.line = line;
     a.lmax = line && L > 0 ? (float2 *)w.f32(ws, RRL_WS_LMAX) : nullptr;
     a.L = L;
-    a.B = B; a.N = N; a.M = M;
+    a.B = B; a.N = N; a.M = M; a.clouds = clouds;
     a.transpose_r = xf ? xf->transpose_r : 0;
     a.Bt = o.problems;
     a.xcd_align = 0;
@@ -959,12 +1002,12 @@ int rrl_launch_tri_build(const float *tri1, const float *tri2, void *ws, const W
     if (o.prepared()) {  // the order is known: ONE launch (records at their sorted positions + tree refit), no sort
         a.z2 = nullptr; a.z2_vec4 = 0;
         a.nblk_tri = (int)(((size_t)(nmax + SGT - 1) / SGT * SGT + REC_BLK - 1) / REC_BLK);
-        hipLaunchKernelGGL(tri_records_sorted_kernel, dim3((unsigned)(a.nblk_tri + (a.lmax ? LMAX_CHUNKS : 0)), (unsigned)B, (unsigned)clouds),
+        hipLaunchKernelGGL(tri_records_sorted_kernel, dim3((unsigned)(a.nblk_tri * B * clouds + (a.lmax ? LMAX_CHUNKS * B : 0))),
                            dim3(REC_BLK), 0, s, a, o.order1, o.order2);
         hipError_t e = hipGetLastError();
         return e == hipSuccess ? 0 : (int)e;
     }
-    hipLaunchKernelGGL(tri_records_kernel, dim3((unsigned)(a.nblk_tri + (a.lmax ? LMAX_CHUNKS : 0)), (unsigned)B, (unsigned)clouds),
+    hipLaunchKernelGGL(tri_records_kernel, dim3((unsigned)(a.nblk_tri * B * clouds + (a.lmax ? LMAX_CHUNKS * B : 0))),
                        dim3(REC_BLK), 0, s, a);
     if (nmax <= 4096 || chunked) {
         hipLaunchKernelGGL((tri_sort_kernel<4, false>), dim3((unsigned)(clouds * B * a.nchunk), (unsigned)parts), dim3(1024), lds, s, a);

@@ -16,6 +16,36 @@
 // sqrt(dist_sq) of the three points of triangle f and the detached weights of
 // code/loss.py:92: w_k = d_k / ((d0 + d1) + d2).  Same arithmetic as the scan, so the
 // distances are bit-identical to the ones that decided the label.
+#ifdef RRL_STAMPS  // experiments only (RRL_HIPCC_FLAGS=-DRRL_STAMPS -> lib_exp): 100 MHz time stamps of workgroup 0's lane 0
+__device__ unsigned long long g_stamps[32];
+#define STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) g_stamps[i] = wall_clock64(); } while (0)
+extern "C" int rrl_debug_stamps(unsigned long long *out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 32) == hipSuccess ? 0 : -1;
+}
+__device__ unsigned long long g_wstamps[12 * 2048];  // [stamp][workgroup]: per-workgroup stamps of the tail kernel
+#define STAMPW(i) do { if ((threadIdx.x & 63) == 0) { const unsigned wg_ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z); \
+    if (wg_ < 2048u) g_wstamps[(i) * 2048 + wg_] = wall_clock64(); } } while (0)
+extern "C" int rrl_debug_wstamps(unsigned long long *out, int clear) {
+    if (clear) { void *p_ = nullptr; if (hipGetSymbolAddress(&p_, HIP_SYMBOL(g_wstamps)) != hipSuccess) return -1; return hipMemset(p_, 0, sizeof(unsigned long long) * 12 * 2048) == hipSuccess ? 0 : -1; }
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wstamps), sizeof(unsigned long long) * 12 * 2048) == hipSuccess ? 0 : -1;
+}
+__device__ unsigned long long g_pstamps[8 * 2048];  // ... of the per-line stage
+#define STAMPP(i) do { if ((threadIdx.x & 63) == 0) { const unsigned wg_ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z); \
+    if (wg_ < 2048u) g_pstamps[(i) * 2048 + wg_] = wall_clock64(); } } while (0)
+extern "C" int rrl_debug_pstamps(unsigned long long *out, int clear) {
+    if (clear) { void *p_ = nullptr; if (hipGetSymbolAddress(&p_, HIP_SYMBOL(g_pstamps)) != hipSuccess) return -1; return hipMemset(p_, 0, sizeof(unsigned long long) * 8 * 2048) == hipSuccess ? 0 : -1; }
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pstamps), sizeof(unsigned long long) * 8 * 2048) == hipSuccess ? 0 : -1;
+}
+#else
+#define STAMP(i)
+#define STAMPW(i)
+#define STAMPP(i)
+#endif
+
+// LDS-only workgroup barrier: this wavefront's LDS traffic is complete, its vector-memory loads AND STORES stay in flight
+// (__syncthreads() waits for both: a barrier behind a store costs the store's acknowledgement, ~0.5 us)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ __forceinline__ void hit_weights(const float *p, const float *ln, float *w) {
     float d[3];
 #pragma unroll
@@ -102,6 +132,17 @@ __device__ __forceinline__ void wave_scatter_rows(bool live, const float (&v)[9]
 // points through LDS (same wavefront: no barrier) and each fills two entries of the k x j block
 // of squared distances -- by line for the backward kernels and as the canonical 4 x 4 tile
 // (+inf outside the block) at the line's compact slot for the reduce kernel.
+// What a lane of the per-line stage knows about its (selected line, cloud, hit slot) after the FIRST pass (ranks 0 .. 127) --
+// kept in registers for the single-tile kernels, whose backward then reads nothing of it back (pair_reduce_scatter_kernel).
+struct PairKeep {
+    int total;   // the tile's selected lines (uniform)
+    int k, j;    // the line's hit counts (0, 0: this lane's rank holds no line)
+    int f;       // this lane's triangle (hit slot a = lane & 3 of cloud (lane >> 2) & 1, ascending order), when a < count
+    float w[3];  // its weights
+    float4 q;    // its intersection point
+    float4 *sq;  // LDS: the 8 intersection points of the line (cloud 1: 0..3, cloud 2: 4..7)
+};
+
 __device__ __forceinline__ void pair_hit(const float *__restrict__ tri1, const float *__restrict__ tri2,
                                          const float *__restrict__ line, const int32_t *__restrict__ hit1,
                                          const int32_t *__restrict__ hit2, int32_t *__restrict__ hs1,
@@ -112,7 +153,8 @@ __device__ __forceinline__ void pair_hit(const float *__restrict__ tri1, const f
                                          unsigned *s_mh /* LDS [2048] or NULL */,
                                          int b, int N, int M, size_t gl, int k, int j, int sub, int st1,
                                          int st2, float *t2 /* out: this lane's two tile entries (+inf: outside the block) */,
-                                         int bi, size_t gli /* multi-pose: the instance's problem, its line's row there */) {
+                                         int bi, size_t gli /* multi-pose: the instance's problem, its line's row there */,
+                                         PairKeep *keep = nullptr) {
     const int cloud = sub >> 2, a = sub & 3;
     const int cnt = cloud ? j : k;
     float q[3] = {0.0f, 0.0f, 0.0f};
@@ -142,6 +184,12 @@ __device__ __forceinline__ void pair_hit(const float *__restrict__ tri1, const f
         float *wd = (cloud ? w2 : w1) + (gl * RRL_MAX_HITS + a) * 3;
 #pragma unroll
         for (int cc = 0; cc < 3; ++cc) wd[cc] = w[cc];
+        if (keep) {
+            keep->f = f;
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc) keep->w[cc] = w[cc];
+            keep->q = make_float4(q[0], q[1], q[2], 0.0f);
+        }
     }
     s_q[sub] = make_float4(q[0], q[1], q[2], 0.0f);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the 8 lanes share a wavefront: LDS is in order
@@ -204,7 +252,7 @@ struct PairArgs {
 // One tile of 1024 lines of sample b by a 1024-lane workgroup.  Phase 1: every lane classifies its line
 // and the selected ones (~9 %) are compacted through LDS, so that phase 2 -- the gather-heavy part -- runs
 // on dense wavefronts, eight lanes per line; the compacted line ids also go to SEL[b] for the backward.
-__device__ __forceinline__ void pair_body(const PairArgs &a, int b, int tile, int ntile) {
+__device__ __forceinline__ void pair_body(const PairArgs &a, int b, int tile, int ntile, PairKeep *keep = nullptr) {
     __shared__ int s_list[1024];
     __shared__ int s_wave[16];
     __shared__ int s_total;
@@ -216,6 +264,7 @@ __device__ __forceinline__ void pair_body(const PairArgs &a, int b, int tile, in
     const int L = a.L;
     const int bi = (a.Bt > 0 && b >= a.Bt) ? b % a.Bt : b;  // the instance's problem (multi-pose)
     int base_reg = 0;
+    if (wave == 0) STAMPP(0);
     const bool tally = a.mhist != nullptr;  // uniform
     if (tally) {  // (the barriers of phase 1 publish the clearing)
         s_mh[tid] = 0u;
@@ -236,20 +285,25 @@ __device__ __forceinline__ void pair_body(const PairArgs &a, int b, int tile, in
         }
         const unsigned long long mask = __ballot(sel);
         if (lane == 0) s_wave[wave] = __popcll(mask);
-        __syncthreads();
+        if (wave == 0) STAMPP(1);
+        // (LDS-only barriers in this stage: what they publish is LDS -- the KJ store above, and later the stage's stores, are
+        //  read by other launches, or by this workgroup behind a fence of its own in the single-tile kernels)
+        lds_barrier();
         if (sel && tally) atomicAdd(&s_bc[((kjb & 15u) - 1u) * 4u + ((kjb >> 4) - 1u)], 1u);
+        // every wavefront scans the 16 counts itself -- one LDS read, a DPP prefix -- for its own base and the total (round 5:
+        // lane 0 of the workgroup used to walk them, one LDS round trip after the other, between two barriers)
+        const int cw = lane < 16 ? s_wave[lane] : 0;
+        const int iw = wave_incl_scan(cw);
+        const int wbase = __builtin_amdgcn_readlane(iw - cw, wave), acc = __builtin_amdgcn_readlane(iw, 15);
         if (tid == 0) {
-            int acc = 0;
-            for (int w = 0; w < 16; ++w) { int c = s_wave[w]; s_wave[w] = acc; acc += c; }
             s_total = acc;
             // the slot range in SEL[b] is only needed for the last store of the kernel: the
             // atomic's round trip overlaps the gathers below
             base_reg = acc ? atomicAdd(&a.nsel[b], acc) : 0;
         }
-        __syncthreads();
         // the line id (L < 2^24) and its (k, j) byte travel together: phase 2 needs no second look at the counts
-        if (sel) s_list[s_wave[wave] + __popcll(mask & ((1ull << lane) - 1ull))] = (int)((unsigned)l | (kjb << 24));
-        __syncthreads();
+        if (sel) s_list[wbase + __popcll(mask & ((1ull << lane) - 1ull))] = (int)((unsigned)l | (kjb << 24));
+        lds_barrier();
     }
     // Compact copies for the reduce kernel live at slot = 1024 * tile + rank: no global
     // counter is needed to place them (BLKCNT[b][tile] tells the consumer how many each workgroup
@@ -258,6 +312,12 @@ __device__ __forceinline__ void pair_body(const PairArgs &a, int b, int tile, in
     // returned by the nsel atomic, whose round trip has long been hidden by the gathers.
     const size_t Lp = (size_t)ntile * 1024;
     const int total = s_total;
+    STAMP(1);
+    if (wave == 0) STAMPP(2);
+    if (keep) {
+        keep->total = total; keep->k = keep->j = 0; keep->f = 0; keep->sq = s_q[tid >> 3];
+        keep->w[0] = keep->w[1] = keep->w[2] = 0.0f; keep->q = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
     if (tid == 0) a.blkcnt[(size_t)b * ntile + tile] = total;
     float *vl = tally && a.vlist ? a.vlist + ((size_t)b * ntile + tile) * 16384 : nullptr;
     for (int r0 = 0; r0 < total; r0 += 128) {  // 128 selected lines per pass, 8 lanes each
@@ -274,7 +334,9 @@ __device__ __forceinline__ void pair_body(const PairArgs &a, int b, int tile, in
                 if (a.lidc) a.lidc[slot] = e;
             }
             pair_hit(a.tri1, a.tri2, a.line, a.hit1, a.hit2, a.hs1, a.hs2, a.w1, a.w2, a.Q1, a.Q2, a.D, a.dc + slot * 16,
-                     s_q[tid >> 3], tally ? s_mh : nullptr, b, a.N, a.M, gl, k, j, sub, a.st1, a.st2, t2, bi, (size_t)bi * L + l);
+                     s_q[tid >> 3], tally ? s_mh : nullptr, b, a.N, a.M, gl, k, j, sub, a.st1, a.st2, t2, bi, (size_t)bi * L + l,
+                     r0 == 0 ? keep : nullptr);
+            if (keep && r0 == 0) { keep->k = k; keep->j = j; }
             nvl = (((2 * sub) >> 2) < k && ((2 * sub) & 3) < j ? 1u : 0u) | (((2 * sub + 1) >> 2) < k && ((2 * sub + 1) & 3) < j ? 2u : 0u);
         }
         if (vl) {  // (all lanes: uniform) the valid entries join the tile's dense value list: one LDS cursor atomic per wavefront
@@ -288,8 +350,10 @@ __device__ __forceinline__ void pair_body(const PairArgs &a, int b, int tile, in
             if (nvl & 2u) vl[at] = t2[1];
         }
     }
+    STAMP(2);
+    if (wave == 0) STAMPP(3);
     if (tally) {  // flush the tile's tallies: <= one device atomic per populated bin and workgroup
-        __syncthreads();
+        lds_barrier();
         uint32_t *mh = a.mhist + (size_t)b * 2048;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
@@ -305,10 +369,12 @@ __device__ __forceinline__ void pair_body(const PairArgs &a, int b, int tile, in
             a.vlcnt[(size_t)b * ntile + tile] = -1;  // no list this time: a tail kernel run on this state reports it (NaN loss)
         }
     }
+    if (wave == 0) STAMPP(4);
     if (wave == 0) {
         const int base = __builtin_amdgcn_readfirstlane(base_reg);
         for (int i = lane; i < total; i += 64) a.sel_out[(size_t)b * L + base + i] = s_list[i] & 0xffffff;
     }
+    if (wave == 0) STAMPP(5);
 }
 
 __global__ __launch_bounds__(1024) void line_pair_dist_kernel(const PairArgs a) {
@@ -552,6 +618,7 @@ __device__ __forceinline__ void reduce_core(const uint8_t *__restrict__ kjc, con
     const unsigned n = s_nvals;
     if (tid == 0) s_rank[0] = n ? (n - 1) / 2 : 0;
     __syncthreads();
+    STAMP(9);
 
     // ---- lower median = element of rank (n-1)/2 (torch.median): MSB-first radix select on the
     //      bit patterns (D >= 0: unsigned order == float order).  Pass 0 (bits 30..20) is
@@ -599,6 +666,7 @@ __device__ __forceinline__ void reduce_core(const uint8_t *__restrict__ kjc, con
     };
     if (n > 0) {
         wg_pass(0);
+        STAMP(10);
         const unsigned ncand = L_.s_cand[0];
         if (ncand <= 2048u) {
             // gather the bin's values into s_hist (all zero now, free until the next evaluation)
@@ -672,6 +740,7 @@ __device__ __forceinline__ void reduce_core(const uint8_t *__restrict__ kjc, con
         }
     }
     const float med = n ? __uint_as_float(prefix) : 0.0f;
+    STAMP(11);
 
     // ---- Welsch + symmetric min per selected line, bucket sums in LDS (fixed point)
     // The forward needs the VALUES of the row / column minima only, and Welsch1 is non-decreasing
@@ -716,8 +785,44 @@ __device__ __forceinline__ void reduce_core(const uint8_t *__restrict__ kjc, con
             }
         }
     }
+    STAMP(12);
     med_o = med;
     n_o = n;
+}
+
+// The loss of a sample from its sixteen (k, j) buckets, by ONE wavefront (all 64 lanes call; lane bi < 16 brings bucket bi =
+// (k - 1) 4 + (j - 1): its line count S and fixed-point row / column sums): the double-precision means, the bucket terms
+// exp(-|k-j|/2) (mean_row + mean_col) (code/loss.py:215), and their sum in the reference's k-major order over the
+// non-empty buckets of the range -- taken lane by lane through v_readlane in bucket order: an empty or out-of-range
+// bucket's term is +0 and adding it changes nothing, so the sum has the bits of the loop that skips them.  (Round 5: that
+// loop, one lane walking s_cnt[] / s_term[] in LDS -- ~40 dependent LDS round trips -- took 3.2 us of the single-tile
+// kernel's 15.9, in-kernel time stamps of tools/stamps.py.)
+struct BucketFinal {
+    float acc;  // sum of the terms (the loss is acc / C)
+    int C, nselected, nvalues;
+};
+__device__ __forceinline__ BucketFinal bucket_final(unsigned long long srow, unsigned long long scol, int S, int lane, int s_m,
+                                                    int s_n, int e_m, int e_n) {
+    const int k = (lane & 15) / 4 + 1, j = (lane & 3) + 1;
+    const bool in = lane < 16 && S > 0 && k >= s_m && k < e_m && j >= s_n && j < e_n;
+    float term = 0.0f;
+    if (in) {
+        const double sc = 1.0 / (double)(1ll << FIX_SHIFT);
+        float mrow = (float)((double)srow * sc / ((double)S * k));
+        float mcol = (float)((double)scol * sc / ((double)S * j));
+        float wkj = expf(-0.5f * (float)abs(k - j));  // code/loss.py:215
+        term = wkj * (mrow + mcol);
+    }
+    BucketFinal r;
+    r.C = __popcll(__ballot(in));
+    r.nselected = wave_sum_i(in ? S : 0);
+    r.nvalues = wave_sum_i(lane < 16 ? S * k * j : 0);
+    float acc = 0.0f;
+#pragma unroll
+    for (int bi = 0; bi < 16; ++bi)  // k-major, the reference's accumulation order
+        acc = acc + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(term), bi));
+    r.acc = acc;
+    return r;
 }
 
 struct ReduceArgs {
@@ -754,10 +859,10 @@ __device__ __forceinline__ void reduce_body(const ReduceArgs &ra, int g) {
     __shared__ unsigned long long s_sum[32];
     __shared__ int s_cnt[16];
     __shared__ int s_bad;
-    __shared__ float s_term[16];
     const int tid = threadIdx.x;
     const int bm = pool ? B - 1 : g;  // whose values define the median
     const int b0 = pool ? 0 : g, b1 = pool ? B : g + 1;
+    const int st0 = status[0];  // (the scan's NaN flag, for the info row: requested now -- at the end it would be one more round trip)
     if (tid < 32) s_sum[tid] = 0ull;
     if (tid < 16) s_cnt[tid] = 0;
     if (tid == 0) { s_nvals = 0; s_cand[0] = 0; s_cand[1] = 0; s_bad = 0; }
@@ -765,6 +870,7 @@ __device__ __forceinline__ void reduce_body(const ReduceArgs &ra, int g) {
     s_hist[tid + 1024] = 0;
 
     const int ns_m = load_prefix(blkcnt + (size_t)bm * nblk, nblk, s_pref, tid);
+    STAMP(4);
     const ReduceLds lds = {s_pref, s_hist, s_wtot, s_prefix, s_rank, &s_nvals, s_cand, s_whist, s_sum, s_cnt, &s_bad};
     float med;
     unsigned n;
@@ -775,36 +881,17 @@ __device__ __forceinline__ void reduce_body(const ReduceArgs &ra, int g) {
     // ---- loss = ( sum_{non-empty (k,j), k-major} exp(-|k-j|/2) (mean_row + mean_col) ) / C
     if (tid < 16) bcnt_out[g * 16 + tid] = s_cnt[tid];
     if (tid < 32) bsum_out[(size_t)g * 32 + tid] = (int64_t)s_sum[tid];
-    if (tid < 16) {  // one lane per bucket: the double-precision means
-        const int k = tid / 4 + 1, j = tid % 4 + 1, S = s_cnt[tid];
-        float term = 0.0f;
-        if (S > 0 && k >= s_m && k < e_m && j >= s_n && j < e_n) {
-            const double sc = 1.0 / (double)(1ll << FIX_SHIFT);
-            float mrow = (float)((double)s_sum[tid * 2 + 0] * sc / ((double)S * k));
-            float mcol = (float)((double)s_sum[tid * 2 + 1] * sc / ((double)S * j));
-            float wkj = expf(-0.5f * (float)abs(k - j));  // code/loss.py:215
-            term = wkj * (mrow + mcol);
+    if (tid < 64) {  // wavefront 0: one lane per bucket
+        const BucketFinal f = bucket_final(tid < 16 ? s_sum[tid * 2 + 0] : 0ull, tid < 16 ? s_sum[tid * 2 + 1] : 0ull,
+                                           tid < 16 ? s_cnt[tid] : 0, tid, s_m, s_n, e_m, e_n);
+        if (tid == 0) {
+            med_out[g] = med;
+            loss[g] = s_bad ? __builtin_nanf("") : (f.C ? f.acc / (float)f.C : 0.0f);  // code/loss.py:230
+            info[g * 4 + 0] = f.C;
+            info[g * 4 + 1] = f.nselected;
+            info[g * 4 + 2] = (int)n;
+            info[g * 4 + 3] = st0;  // the scan's NaN flag next to the bucket count: one 16-byte read-back decides the call
         }
-        s_term[tid] = term;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        float acc = 0.0f;
-        int C = 0, nselected = 0;
-        for (int k = s_m; k < e_m; ++k)      // k-major, the reference's accumulation order
-            for (int j = s_n; j < e_n; ++j) {
-                const int bi = (k - 1) * 4 + (j - 1);
-                if (s_cnt[bi] == 0) continue;
-                acc = acc + s_term[bi];
-                ++C;
-                nselected += s_cnt[bi];
-            }
-        med_out[g] = med;
-        loss[g] = s_bad ? __builtin_nanf("") : (C ? acc / (float)C : 0.0f);  // code/loss.py:230
-        info[g * 4 + 0] = C;
-        info[g * 4 + 1] = nselected;
-        info[g * 4 + 2] = (int)n;
-        info[g * 4 + 3] = status[0];  // the scan's NaN flag next to the bucket count: one 16-byte read-back decides the call
     }
 }
 
@@ -921,7 +1008,6 @@ __global__ __launch_bounds__(256) void loss_reduce_tiled_kernel(const TiledArgs 
     __shared__ unsigned long long s_sum[32];
     __shared__ unsigned s_flag[3];          // [0] spin ok, [1] this workgroup arrived last, [2] non-finite Welsch term
     __shared__ unsigned s_med;
-    __shared__ float s_term[16];
     __shared__ int s_cnt[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nblk = a.nblk;
@@ -936,6 +1022,7 @@ __global__ __launch_bounds__(256) void loss_reduce_tiled_kernel(const TiledArgs 
     // ---- one round of independent loads: the tile's count, its first 256 compact rows (speculative: the slots
     //      exist whether or not they were written), the sample's histogram
     const int cnt = a.blkcnt[(size_t)b * nblk + tile];
+    const int st0 = a.status[0];  // (for the info row: requested with round 1)
     const size_t slot0 = (size_t)b * Lp + (size_t)tile * 1024;
     float tl[16];
     unsigned c0;
@@ -993,7 +1080,7 @@ __global__ __launch_bounds__(256) void loss_reduce_tiled_kernel(const TiledArgs 
             if (tid == 0) {
                 a.med_out[b] = 0.0f;
                 a.loss[b] = 0.0f;
-                a.info[b * 4 + 0] = 0; a.info[b * 4 + 1] = 0; a.info[b * 4 + 2] = 0; a.info[b * 4 + 3] = a.status[0];
+                a.info[b * 4 + 0] = 0; a.info[b * 4 + 1] = 0; a.info[b * 4 + 2] = 0; a.info[b * 4 + 3] = st0;
             }
         }
         return;
@@ -1204,38 +1291,19 @@ __global__ __launch_bounds__(256) void loss_reduce_tiled_kernel(const TiledArgs 
         }
     }
     __syncthreads();
-    if (tid < 16) {  // one lane per bucket: the double-precision means (as reduce_body)
-        const int k = tid / 4 + 1, j = tid % 4 + 1, S = s_cnt[tid];
-        float term = 0.0f;
-        if (S > 0 && k >= a.s_m && k < a.e_m && j >= a.s_n && j < a.e_n) {
-            const double sc = 1.0 / (double)(1ll << FIX_SHIFT);
-            float mrow = (float)((double)s_sum[tid * 2 + 0] * sc / ((double)S * k));
-            float mcol = (float)((double)s_sum[tid * 2 + 1] * sc / ((double)S * j));
-            float wkj = expf(-0.5f * (float)abs(k - j));  // code/loss.py:215
-            term = wkj * (mrow + mcol);
-        }
-        s_term[tid] = term;
-    }
-    __syncthreads();
+    if (tid >= 64) return;  // wavefront 0: one lane per bucket (bucket_final)
+    const BucketFinal f = bucket_final(tid < 16 ? s_sum[tid * 2 + 0] : 0ull, tid < 16 ? s_sum[tid * 2 + 1] : 0ull,
+                                       tid < 16 ? s_cnt[tid] : 0, tid, a.s_m, a.s_n, a.e_m, a.e_n);
     if (tid == 0) {
-        float acc = 0.0f;
-        int C = 0, nselected = 0, nvalues = 0;
-        for (int k = a.s_m; k < a.e_m; ++k)      // k-major, the reference's accumulation order
-            for (int j = a.s_n; j < a.e_n; ++j) {
-                const int bi = (k - 1) * 4 + (j - 1);
-                if (s_cnt[bi] == 0) continue;
-                acc = acc + s_term[bi];
-                ++C;
-                nselected += s_cnt[bi];
-            }
-        for (int bi = 0; bi < 16; ++bi) nvalues += s_cnt[bi] * (bi / 4 + 1) * (bi % 4 + 1);
+        const float acc = f.acc;
+        const int C = f.C, nselected = f.nselected, nvalues = f.nvalues;
         const bool bad = repair ? (s_flag[2] & 1u) != 0u : (s_flag[2] & 2u) != 0u;  // a non-finite Welsch term (median 0)
         a.med_out[b] = med;
         a.loss[b] = bad ? __builtin_nanf("") : (C ? acc / (float)C : 0.0f);  // code/loss.py:230
         a.info[b * 4 + 0] = C;
         a.info[b * 4 + 1] = nselected;
         a.info[b * 4 + 2] = nvalues;
-        a.info[b * 4 + 3] = a.status[0];
+        a.info[b * 4 + 3] = st0;
         st_agent(&ctl[MCTL_CURSOR], 0u); st_agent(&ctl[MCTL_TICK1], 0u); st_agent(&ctl[MCTL_TICK2], 0u);
         st_agent(&ctl[MCTL_MEDRDY], 0u); st_agent(&ctl[MCTL_BAD], 0u); st_agent(&ctl[MCTL_ERR], 0u);
     }
@@ -1304,8 +1372,6 @@ struct TailArgs {
     int xcd_align;     // sample b's workgroups on XCD b % 8 (xcd_sample_of; B % 8 == 0)
 };
 
-// LDS-only workgroup barrier: this wavefront's LDS traffic is complete, its vector-memory loads stay in flight
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // one sample's final loss into payload[0 .. 1] (header); one lane
 __device__ __forceinline__ void tail_payload(const TailArgs &a, float lv) {
@@ -1331,10 +1397,10 @@ __global__ __launch_bounds__(TAIL_LANES) __attribute__((amdgpu_waves_per_eu(4, 8
     __shared__ unsigned long long s_sum[32];
     __shared__ unsigned s_flag[2];          // [0] this workgroup arrived last, [1] non-finite Welsch term (bit 0 own, bit 1 anyone's)
     __shared__ unsigned s_med, s_ncand;
-    __shared__ float s_term[16];
     __shared__ int s_cnt[16];
     __shared__ int s_pref[TAIL_MAX_TILES + 1];
     __shared__ int s_vpref[TAIL_MAX_TILES + 1];  // prefix of the tiles' value lists, in 16-byte groups
+    __shared__ int s_misc[3];                    // live workgroups of the sample, its longest value list, its non-empty buckets
     __shared__ float s_red[4][12];
     __shared__ unsigned s_scat[4][64 * SCAT_STRIDE];  // wave_scatter_rows strips of the four wavefronts that hold lines
     constexpr int NW = TAIL_LANES / 64, BPL = 2048 / TAIL_LANES;  // wavefronts; histogram bins per lane
@@ -1350,6 +1416,7 @@ __global__ __launch_bounds__(TAIL_LANES) __attribute__((amdgpu_waves_per_eu(4, 8
     const size_t slot0 = (size_t)b * Lp + (size_t)tile * 1024;
     const bool do_bwd = a.do_bwd != 0;  // uniform
     constexpr bool scatter = SCATTER;  // gradient to the points (rrl_loss_step), not to (R, t)
+    if (wave == 0) STAMPW(0);
 
     // ---- round 1: the sample's tile counts, histogram and bucket counts; the compact tile of "this lane's" line
     //      (lanes 0 .. 255, four per line: lane h of line r adds hit slot h's gradient, lane 0 the line's Welsch terms).
@@ -1378,6 +1445,21 @@ __global__ __launch_bounds__(TAIL_LANES) __attribute__((amdgpu_waves_per_eu(4, 8
     }
     const unsigned bkt = tid < 16 ? ctl[tid] : 0u;
     const float gl_in0 = do_bwd ? a.grad_loss[b] : 0.0f;
+    const int st0 = a.status[0];  // (the scan's NaN flag, for the info row: at the end it would be one more round trip of the last arriver)
+    // ... and the sample's D values (the tiles' dense lists, VLIST), which the median's gather streams: lane (vt, vq) = (tile,
+    // slot) reads the 16-byte groups vq + LPT u of tile vt -- an address that needs no count either (a list's 16384 slots
+    // exist; a group beyond the list's length holds stale data and is masked by the count once it is here).  Round 5: the
+    // gather used to map a dense group index through the prefix of the counts -- its loads could only leave after round 1
+    // had come back and the bin was picked: one dependent round trip in front of the median (2.25 us of the kernel's 11.7 at
+    // C2, in-kernel time stamps of tools/stamps_tail.py).
+    const int LPT = TAIL_LANES / nblk;  // lanes per tile (uniform; nblk <= 32: >= 16)
+    const int vt = tid / LPT, vq = tid - vt * LPT;
+    const bool vlane = vt < nblk;
+    const float4 *__restrict__ vbase = (const float4 *)(a.vlist + ((size_t)b * nblk + (vlane ? vt : 0)) * 16384);
+    float4 vpre[TAIL_RPL];
+#pragma unroll
+    for (int u = 0; u < TAIL_RPL; ++u)
+        vpre[u] = vlane ? vbase[vq + LPT * u] : make_float4(-1.0f, -1.0f, -1.0f, -1.0f);
     if (sub * TAIL_LINES >= mycnt && !(tile == 0 && sub == 0)) return;  // uniform: no line for this workgroup
     bool mine_on = tid < 4 * TAIL_LINES && r < mycnt;
     unsigned kl = mine_on ? kl_raw : 0u;
@@ -1401,10 +1483,18 @@ __global__ __launch_bounds__(TAIL_LANES) __attribute__((amdgpu_waves_per_eu(4, 8
     if (tid < 16) s_cnt[tid] = (int)bkt;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     if (vraw < 0) atomicOr(&s_flag[1], 1u);  // (after the clearing above: same wavefront 0, LDS in order)
-    if (wave == 0) {  // exclusive prefix of the tile counts (nblk <= 32)
+    if (wave == 0) {  // exclusive prefix of the tile counts (nblk <= 32) -- and what every wavefront needs of them, once
         const int incl = wave_incl_scan(bc), vincl = wave_incl_scan(vc);
         if (lane < nblk) { s_pref[lane + 1] = incl; s_vpref[lane + 1] = vincl; }
         if (lane == 0) { s_pref[0] = 0; s_vpref[0] = 0; }
+        // workgroups of this sample that get past the test above (they all arrive at TICK2); the longest value list (16-byte
+        // groups); the non-empty buckets of the range
+        const int wl = min((bc + TAIL_LINES - 1) / TAIL_LINES, TAIL_SUBS);
+        const int nl = wave_sum_i(lane < nblk ? (lane == 0 && wl == 0 ? 1 : wl) : 0);
+        const int vm = (int)wave_max((float)vc);  // (vc <= 4096: exact in fp32)
+        const int kk = lane / 4 + 1, jj = (lane & 3) + 1;
+        const int cn = __popcll(__ballot(lane < 16 && bkt > 0u && kk >= a.s_m && kk < a.e_m && jj >= a.s_n && jj < a.e_n));
+        if (lane == 0) { s_misc[0] = nl; s_misc[1] = vm; s_misc[2] = cn; }
     }
     int k, j;  // 0, 0 for a lane without a line
 
@@ -1447,12 +1537,9 @@ __global__ __launch_bounds__(TAIL_LANES) __attribute__((amdgpu_waves_per_eu(4, 8
     };
     request_line();
     lds_barrier();  // s_pref, s_cnt
-    const int ngrp = s_vpref[nblk];  // 16-byte groups of D values in the sample's lists
-    int nlive = 0;  // workgroups of this sample that get past the test above: they all arrive at TICK2
-    for (int t = 0; t < nblk; ++t) {
-        const int c = s_pref[t + 1] - s_pref[t], w = min((c + TAIL_LINES - 1) / TAIL_LINES, TAIL_SUBS);
-        nlive += t == 0 && w == 0 ? 1 : w;
-    }
+    if (wave == 0) STAMPW(8);
+    const int myvc = vlane ? s_vpref[vt + 1] - s_vpref[vt] : 0;  // 16-byte groups of D values in this lane's tile's list
+    const int nlive = s_misc[0], vmax = s_misc[1];  // (uniform)
 
     // ---- pick the bin of a rank among 2048 counts held BPL per lane: exclusive scan over the workgroup, the lane whose
     //      range holds the rank reports (bin, rank inside, population).  Returns the total.
@@ -1461,7 +1548,7 @@ __global__ __launch_bounds__(TAIL_LANES) __attribute__((amdgpu_waves_per_eu(4, 8
 #pragma unroll
         for (int q = 0; q < BPL; ++q) tsum += hb[q];
         const unsigned incl = (unsigned)wave_incl_scan((int)tsum);
-        lds_barrier();  // s_wtot / s_pick free again
+        if (have_rank) lds_barrier();  // s_wtot / s_pick free again (a later call; the first one finds them unused)
         if (lane == 63) s_wtot[wave] = incl;
         lds_barrier();
         unsigned base = 0, total = 0;
@@ -1484,13 +1571,14 @@ __global__ __launch_bounds__(TAIL_LANES) __attribute__((amdgpu_waves_per_eu(4, 8
         return total;
     };
     const unsigned n = pick_bin(0u, false);
+    if (wave == 0) STAMPW(1);
     if (n == 0) {  // nothing selected in this sample: its only live workgroup is (tile 0, sub 0): loss 0, no bucket
         if (tid < 16) a.bcnt_out[b * 16 + tid] = 0;
         if (tid < 32) a.bsum_out[(size_t)b * 32 + tid] = 0;
         if (tid == 0) {
             a.med_out[b] = 0.0f;
             a.loss[b] = 0.0f;
-            a.info[b * 4 + 0] = 0; a.info[b * 4 + 1] = 0; a.info[b * 4 + 2] = 0; a.info[b * 4 + 3] = a.status[0];
+            a.info[b * 4 + 0] = 0; a.info[b * 4 + 1] = 0; a.info[b * 4 + 2] = 0; a.info[b * 4 + 3] = st0;
         }
         return;
     }
@@ -1498,19 +1586,19 @@ __global__ __launch_bounds__(TAIL_LANES) __attribute__((amdgpu_waves_per_eu(4, 8
     unsigned prefix = bin << 20;
 
     // ---- every D value of the sample from the tiles' dense lists (VLIST: only the valid entries, ~2 per line instead of the
-    //      16 slots of a canonical tile; -1 pads), TAIL_RPL 16-byte groups per lane and round: fn(groups) for each round;
-    //      after_issue() runs once, when the first round of loads is in flight
-    auto stream_rows = [&](auto &&after_issue, auto &&fn) {
+    //      16 slots of a canonical tile; -1 pads), TAIL_RPL 16-byte groups per lane and round, LPT TAIL_RPL groups of every tile
+    //      per round: fn(groups) for each round; the first round's groups are the ones requested in round 1 (pre = true: the
+    //      first sweep) or loaded again (a later sweep of the crowded-bin route); after_issue() runs once, when the first
+    //      round of loads is in flight
+    auto stream_rows = [&](bool pre, auto &&after_issue, auto &&fn) {
         bool first = true;
-        for (int i0 = 0; i0 < ngrp; i0 += TAIL_LANES * TAIL_RPL) {  // uniform trip count
+        for (int g0 = 0; g0 < vmax; g0 += LPT * TAIL_RPL) {  // uniform trip count
             float4 v[TAIL_RPL];
 #pragma unroll
             for (int u = 0; u < TAIL_RPL; ++u) {
-                const int i = i0 + tid + TAIL_LANES * u;
-                int t = 0;
-                for (int q = 1; q < nblk; ++q) t += i >= s_vpref[q] ? 1 : 0;  // the tile of group i
+                const int g = g0 + vq + LPT * u;
                 v[u] = make_float4(-1.0f, -1.0f, -1.0f, -1.0f);
-                if (i < ngrp) v[u] = ((const float4 *)(a.vlist + ((size_t)b * nblk + t) * 16384))[i - s_vpref[t]];
+                if (g < myvc) v[u] = pre && g0 == 0 ? vpre[u] : vbase[g];
             }
             if (first) { after_issue(); first = false; }
             fn(v);
@@ -1527,7 +1615,7 @@ __global__ __launch_bounds__(TAIL_LANES) __attribute__((amdgpu_waves_per_eu(4, 8
 
     if (pop <= MCAND_CAP) {
         // the bin's values into this workgroup's own list: count, ONE cursor atomic per wavefront and round, plain stores
-        stream_rows([&]() { request_source(); }, [&](const float4 *v) {
+        stream_rows(true, [&]() { request_source(); }, [&](const float4 *v) {
             unsigned mine = 0;
             each16(v, [&](unsigned x) { mine += (x >> 20) == bin ? 1u : 0u; });
             const unsigned incl = (unsigned)wave_incl_scan((int)mine);
@@ -1540,10 +1628,12 @@ __global__ __launch_bounds__(TAIL_LANES) __attribute__((amdgpu_waves_per_eu(4, 8
             });
         });
         lds_barrier();
+        if (wave == 0) STAMPW(9);
         if (tid < 64) {
             const unsigned m = wave_select20(s_vals, pop, prefix, r1, s_whist, tid);
             if (tid == 0) s_med = m;
         }
+        if (wave == 0) STAMPW(10);
         lds_barrier();
         prefix = s_med;
     } else {
@@ -1558,7 +1648,7 @@ __global__ __launch_bounds__(TAIL_LANES) __attribute__((amdgpu_waves_per_eu(4, 8
             for (int q = 0; q < BPL; ++q) s_vals[tid + TAIL_LANES * q] = 0u;
             lds_barrier();
             const unsigned pre = prefix;
-            stream_rows([&]() {}, [&](const float4 *v) {
+            stream_rows(false, [&]() {}, [&](const float4 *v) {
                 each16(v, [&](unsigned x) {
                     if (((x ^ pre) >> hi) == 0u) atomicAdd(&s_vals[(x >> sh) & dmask], 1u);
                 });
@@ -1572,12 +1662,11 @@ __global__ __launch_bounds__(TAIL_LANES) __attribute__((amdgpu_waves_per_eu(4, 8
         }
     }
     const float med = __uint_as_float(prefix);
+    if (wave == 0) STAMPW(2);
 
     // ---- the workgroup's lines: Welsch terms into the fixed-point sums (lane 0 of a line; as reduce_core::accumulate) and
     //      hit slot h's gradient terms (as loss_bwd_rt_kernel)
-    int C = 0;
-    for (int kk = a.s_m; kk < a.e_m; ++kk)
-        for (int jj = a.s_n; jj < a.e_n; ++jj) C += s_cnt[(kk - 1) * 4 + (jj - 1)] > 0 ? 1 : 0;
+    const int C = s_misc[2];
     // ---- the sample-wide part: this workgroup's fixed-point sums -> MSUM, one arrival ticket, and the LAST arriver of the
     //      sample turns the sums into the loss.  ONE wavefront runs it.  Round 5: when all of the workgroup's lines sit in its
     //      first chunk (<= 256 selected lines in the tile: always, at the shapes measured) the wavefront is the workgroup's
@@ -1586,15 +1675,18 @@ __global__ __launch_bounds__(TAIL_LANES) __attribute__((amdgpu_waves_per_eu(4, 8
     //      read-back (5.3 us of a 14.8 us launch at C2: the same kernel returning before it takes 9.5) no longer waits for the
     //      gradient's loads and the scatter's atomics in wavefront 0's queue.
     auto finish = [&]() {
+    STAMPW(3);
     if (lane < 32) {
         const unsigned long long v = s_sum[lane];
         if (v) atomicAdd(&a.msum[(size_t)b * 32 + lane], v);
     }
     if (lane == 32 && s_flag[1]) atomicOr(&ctl[MCTL_BAD], 1u);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wavefront's sums have arrived before it takes its ticket
+    STAMPW(4);
     unsigned last = 0;
     if (lane == 0)
         last = __hip_atomic_fetch_add(&ctl[MCTL_TICK2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(nlive - 1) ? 1u : 0u;
+    STAMPW(5);
     if (!__builtin_amdgcn_readfirstlane((int)last)) return;
 
     // ---- the last workgroup of the sample: loss = ( sum_{non-empty (k,j), k-major} exp(-|k-j|/2) (mean_row + mean_col) ) / C
@@ -1613,41 +1705,22 @@ __global__ __launch_bounds__(TAIL_LANES) __attribute__((amdgpu_waves_per_eu(4, 8
     // lane 2 q + c holds sum c (row / column) of bucket q: one lane per bucket takes both (the double-precision means, as
     // reduce_body)
     const unsigned long long trow = __shfl(tot, (2 * lane) & 63), tcol = __shfl(tot, (2 * lane + 1) & 63);
-    float term = 0.0f;
-    if (lane < 16) {
-        const int kk = lane / 4 + 1, jj = lane % 4 + 1, S = s_cnt[lane];
-        if (S > 0 && kk >= a.s_m && kk < a.e_m && jj >= a.s_n && jj < a.e_n) {
-            const double sc = 1.0 / (double)(1ll << FIX_SHIFT);
-            float mrow = (float)((double)trow * sc / ((double)S * kk));
-            float mcol = (float)((double)tcol * sc / ((double)S * jj));
-            float wkj = expf(-0.5f * (float)abs(kk - jj));  // code/loss.py:215
-            term = wkj * (mrow + mcol);
-        }
-        s_term[lane] = term;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const BucketFinal f = bucket_final(trow, tcol, lane < 16 ? s_cnt[lane] : 0, lane, a.s_m, a.s_n, a.e_m, a.e_n);
+    STAMPW(11);
     if (lane == 0) {
-        float accl = 0.0f;
-        int Cn = 0, nselected = 0, nvalues = 0;
-        for (int kk = a.s_m; kk < a.e_m; ++kk)      // k-major, the reference's accumulation order
-            for (int jj = a.s_n; jj < a.e_n; ++jj) {
-                const int bi = (kk - 1) * 4 + (jj - 1);
-                if (s_cnt[bi] == 0) continue;
-                accl = accl + s_term[bi];
-                ++Cn;
-                nselected += s_cnt[bi];
-            }
-        for (int bi = 0; bi < 16; ++bi) nvalues += s_cnt[bi] * (bi / 4 + 1) * (bi % 4 + 1);
+        const float accl = f.acc;
+        const int Cn = f.C, nselected = f.nselected, nvalues = f.nvalues;
         const float lv = bad ? __builtin_nanf("") : (Cn ? accl / (float)Cn : 0.0f);  // code/loss.py:230
         a.med_out[b] = med;
         a.loss[b] = lv;
         a.info[b * 4 + 0] = Cn;
         a.info[b * 4 + 1] = nselected;
         a.info[b * 4 + 2] = nvalues;
-        a.info[b * 4 + 3] = a.status[0];
+        a.info[b * 4 + 3] = st0;
         st_agent(&ctl[MCTL_TICK2], 0u); st_agent(&ctl[MCTL_BAD], 0u);
         if (do_bwd && a.payload && Cn > 0) tail_payload(a, lv);
     }
+    STAMPW(6);
     };
     const bool single_chunk = mycnt <= TAIL_SUBS * TAIL_LINES;  // uniform
     float acc[12];
@@ -1801,6 +1874,7 @@ __global__ __launch_bounds__(TAIL_LANES) __attribute__((amdgpu_waves_per_eu(4, 8
         if (q < 9) atomicAdd(&a.gR[b * 9 + o], v); else atomicAdd(&a.gt[b * 3 + (q - 9)], v);
         if (a.payload) atomicAdd(&a.payload[2 + o], v);
     }
+    if (wave == 0) STAMPW(7);
     if (wave != 0 || single_chunk) return;  // (single_chunk: the finisher wavefront took this part on long ago)
     finish();
 }
@@ -2054,56 +2128,26 @@ extern "C" int rrl_loss_reduce_rows(const float *rows16, const uint8_t *kj, int 
 // nine atomics itself (wave_scatter_rows above).
 #define BWDS_LINES 32  // selected lines per pass of a 256-lane workgroup
 #define BWDS_SUBS 4
-__global__ __launch_bounds__(256) void loss_bwd_kernel(
-    const uint32_t *__restrict__ lidc, const int32_t *__restrict__ blkcnt,
-    const int32_t *__restrict__ hs1, const int32_t *__restrict__ hs2, const float *__restrict__ w1,
-    const float *__restrict__ w2, const float4 *__restrict__ Q1, const float4 *__restrict__ Q2,
-    const float *__restrict__ D, const float *__restrict__ med, const int32_t *__restrict__ bcnt,
-    const int32_t *__restrict__ info, const float *__restrict__ grad_loss, float *__restrict__ g1,
-    float *__restrict__ g2, int B, int N, int M, int L, int pool, int xcd_align) {
-    // one lane per (selected line, side, hit slot): 8 lanes share a line, each owns one gradient row of <= 9 floats.  They
-    // also SHARE the line's Welsch tile (round 3): the lane of (cloud 1, hit a) evaluates row a, the lane of (cloud 2, hit b)
-    // column b -- <= 4 exponentials and divisions where every lane used to evaluate all 16 entries (welsch_block) -- and the
-    // two quads swap their first-occurrence minima by DPP.  All lanes take part (DPP reads active lanes only); lanes
-    // without a line or hit carry +inf.  Same expressions and tie-breaks as welsch_block on the whole tile.
-    __shared__ unsigned s_scat[4][64 * SCAT_STRIDE];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int sub = blockIdx.z, ntile = gridDim.x;
-    int tile = blockIdx.x, b = blockIdx.y;
-    if (xcd_align) xcd_sample_of(tile + ntile * b, ntile, tile, b);  // (uniform) sample b's workgroups on XCD b % 8
-    const int g = pool ? 0 : b;
-    const int cnt = blkcnt[(size_t)b * ntile + tile];
-    if (sub * BWDS_LINES >= cnt) return;  // uniform: no line for this workgroup
-    const int side = (tid >> 2) & 1, h = tid & 3;
-    const int C = info[g * 4];
-    const float m = med[g], gl_in = grad_loss[g];
-    const size_t slot0 = ((size_t)b * ntile + tile) * 1024;
-    for (int r0 = sub * BWDS_LINES; r0 < cnt; r0 += BWDS_LINES * BWDS_SUBS) {  // uniform; a second trip only beyond 128 lines
-    const int r = r0 + (tid >> 3);
-    const bool valid = r < cnt && C > 0;
-    const unsigned e = valid ? lidc[slot0 + r] : 0u;  // line | k << 24 | j << 28: no second look at the counts
-    const int k = (int)((e >> 24) & 15u), j = (int)(e >> 28);
-    const size_t gl = (size_t)b * L + (e & 0xffffffu);
-    const int mycnt = side ? j : k, ocnt = side ? k : j;  // this lane's hit slots, the other cloud's
-    const bool live = valid && h < mycnt && !(side && !g2);
-    float d[4] = {INFINITY, INFINITY, INFINITY, INFINITY};
-    if (valid && h < mycnt) {
-#pragma unroll
-        for (int o = 0; o < RRL_MAX_HITS; ++o)
-            if (o < ocnt) d[o] = D[gl * 16 + (side ? o * j + h : h * j + o)];  // row h (cloud 1) / column h (cloud 2)
-    }
-    // (requested now, used after the exchange: the loads of the gradient's own chain overlap the Welsch arithmetic)
-    int f = 0, S = 1;
-    float4 mine = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    float wq[3] = {0.0f, 0.0f, 0.0f};
-    if (live) {
-        S = bcnt[g * 16 + (k - 1) * 4 + (j - 1)];
-        mine = (side ? Q2 : Q1)[gl * 4 + h];
-        f = (side ? hs2 : hs1)[gl * 4 + h];
-        const float *w = (side ? w2 : w1) + (gl * 4 + h) * 3;
-#pragma unroll
-        for (int q = 0; q < 3; ++q) wq[q] = w[q];
-    }
+struct ScatArgs {
+    const uint32_t *lidc;
+    const int32_t *blkcnt, *hs1, *hs2, *bcnt, *info;
+    const float *w1, *w2, *D, *med, *grad_loss;
+    const float4 *Q1, *Q2;
+    float *g1, *g2;
+    int N, M, L;
+};
+
+// The arithmetic of the scatter backward for one lane = (selected line, side, hit slot h), 8 lanes per line ((side, h) =
+// lane bits 2 and 0..1); every lane of the wavefront calls (DPP exchange, LDS transpose).  valid: the lane has a line;
+// live: ... and a hit whose gradient row is wanted; d[o]: row h (cloud 1) / column h (cloud 2) of the line's D tile (+inf
+// outside the block); S: the (k, j) bucket's line count; mine / f / wq: this hit's intersection point, triangle and weights;
+// other_of(o): intersection point o of the OTHER cloud (asked for only where an entry carries gradient).
+template <class OtherF>
+__device__ __forceinline__ void bwd_scatter_math(bool live, int k, int j, int side, int h, const float (&d)[4], int S,
+                                                 float4 mine, int f, const float (&wq)[3], int C, float m, float gl_in,
+                                                 OtherF other_of, float *__restrict__ g1b, float *__restrict__ g2b,
+                                                 unsigned *strip, int lane) {
+    const int ocnt = side ? k : j;
     const int omax = (int)wave_max((float)(k > j ? k : j));  // uniform
     float er[4] = {0.0f, 0.0f, 0.0f, 0.0f}, wr[4];
 #pragma unroll
@@ -2150,7 +2194,7 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(
             if (sw == 0.0f) continue;
             // dWl/dD = exp(-D/(2 med)) / (2 med);  dD/dq1 = 2 (q1 - q2) = -dD/dq2
             const float gD = scale * sw * er[o] / (2.0f * m);
-            const float4 other = (side ? Q1 : Q2)[gl * 4 + o];
+            const float4 other = other_of(o);
             gq[0] += 2.0f * (mine.x - other.x) * gD;
             gq[1] += 2.0f * (mine.y - other.y) * gD;
             gq[2] += 2.0f * (mine.z - other.z) * gD;
@@ -2162,9 +2206,121 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(
             for (int cc = 0; cc < 3; ++cc) sv[3 * kk + cc] = wk * gq[cc];
         }
     }
-    wave_scatter_rows(live, sv, (unsigned)f | (side ? 0x80000000u : 0u), g1 + (size_t)b * N * 9,
-                      g2 ? g2 + (size_t)b * M * 9 : nullptr, s_scat[wave], lane);
+    wave_scatter_rows(live, sv, (unsigned)f | (side ? 0x80000000u : 0u), g1b, g2b, strip, lane);
+}
+
+// One pass of the scatter backward from the workspace: this lane = (the tile's selected line of rank r, side, hit slot h);
+// slot0: the tile's first compact slot, cnt its selected lines, C / m / gl_in the sample's valid count, median and upstream
+// gradient.  Every lane of the wavefront calls.
+__device__ __forceinline__ void bwd_scatter_pass(const ScatArgs &a, int b, size_t slot0, int cnt, int r, int g, int C, float m,
+                                                 float gl_in, unsigned *strip, int lane) {
+    const float *__restrict__ D = a.D;
+    const int side = (lane >> 2) & 1, h = lane & 3;
+    const bool valid = r < cnt && C > 0;
+    const unsigned e = valid ? a.lidc[slot0 + r] : 0u;  // line | k << 24 | j << 28: no second look at the counts
+    const int k = (int)((e >> 24) & 15u), j = (int)(e >> 28);
+    const size_t gl = (size_t)b * a.L + (e & 0xffffffu);
+    const int mycnt = side ? j : k, ocnt = side ? k : j;  // this lane's hit slots, the other cloud's
+    const bool live = valid && h < mycnt && !(side && !a.g2);
+    float d[4] = {INFINITY, INFINITY, INFINITY, INFINITY};
+    if (valid && h < mycnt) {
+#pragma unroll
+        for (int o = 0; o < RRL_MAX_HITS; ++o)
+            if (o < ocnt) d[o] = D[gl * 16 + (side ? o * j + h : h * j + o)];  // row h (cloud 1) / column h (cloud 2)
     }
+    // (requested now, used after the exchange: the loads of the gradient's own chain overlap the Welsch arithmetic)
+    int f = 0, S = 1;
+    float4 mine = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    float wq[3] = {0.0f, 0.0f, 0.0f};
+    if (live) {
+        S = a.bcnt[g * 16 + (k - 1) * 4 + (j - 1)];
+        mine = (side ? a.Q2 : a.Q1)[gl * 4 + h];
+        f = (side ? a.hs2 : a.hs1)[gl * 4 + h];
+        const float *w = (side ? a.w2 : a.w1) + (gl * 4 + h) * 3;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) wq[q] = w[q];
+    }
+    const float4 *__restrict__ Qo = side ? a.Q1 : a.Q2;
+    bwd_scatter_math(live, k, j, side, h, d, S, mine, f, wq, C, m, gl_in, [&](int o) { return Qo[gl * 4 + o]; },
+                     a.g1 + (size_t)b * a.N * 9, a.g2 ? a.g2 + (size_t)b * a.M * 9 : nullptr, strip, lane);
+}
+
+__global__ __launch_bounds__(256) void loss_bwd_kernel(const ScatArgs a, int B, int pool, int xcd_align) {
+    __shared__ unsigned s_scat[4][64 * SCAT_STRIDE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int sub = blockIdx.z, ntile = gridDim.x;
+    int tile = blockIdx.x, b = blockIdx.y;
+    if (xcd_align) xcd_sample_of(tile + ntile * b, ntile, tile, b);  // (uniform) sample b's workgroups on XCD b % 8
+    const int g = pool ? 0 : b;
+    const int cnt = a.blkcnt[(size_t)b * ntile + tile];
+    if (sub * BWDS_LINES >= cnt) return;  // uniform: no line for this workgroup
+    const int C = a.info[g * 4];
+    const float m = a.med[g], gl_in = a.grad_loss[g];
+    const size_t slot0 = ((size_t)b * ntile + tile) * 1024;
+    for (int r0 = sub * BWDS_LINES; r0 < cnt; r0 += BWDS_LINES * BWDS_SUBS)  // uniform; a second trip only beyond 128 lines
+        bwd_scatter_pass(a, b, slot0, cnt, r0 + (tid >> 3), g, C, m, gl_in, s_scat[wave], lane);
+}
+
+// K2 + K3 + K4 + K5 in ONE launch for a single tile of lines (L <= 1024; C5: N = M = 16384, L = 512) -- SURVEY 8(d)'s step
+// (rrl_loss_step_ex: backward to points1.grad) at the shapes pair_reduce_kernel serves: the workgroup of sample b ran the
+// per-line stage and the reduce of sample b, so it carries on with the scatter backward of the
+// sample's selected lines (loss_bwd_kernel's arithmetic, 8 lines per wavefront and pass).  Same bodies, same
+// results; payload[0 .. 1] as in the tail kernel.  grad_tri1 is zero on entry (the records launch cleared it).
+// At most 128 selected lines (one pass of the per-line stage: every (line, cloud, hit) lane still HOLDS its triangle, weights and
+// intersection point, and the line's eight points sit in the stage's LDS) the backward reads none of it back: the D row /
+// column is re-evaluated from the points with the stage's own expression (bit-identical to the stored tile) and only the
+// sample's median, valid count, bucket count and upstream gradient are fetched -- ONE round trip instead of four dependent
+// ones (compact list -> D / Q / hits / weights -> the other cloud's points).  More lines: from the workspace, as above.
+__global__ __launch_bounds__(1024) void pair_reduce_scatter_kernel(const PairArgs pa, const ReduceArgs ra, const ScatArgs a,
+                                                                    float *__restrict__ payload, uint32_t *__restrict__ mctl) {
+    __shared__ unsigned s_scat[16][64 * SCAT_STRIDE];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    PairKeep kp;
+    STAMP(0);
+    pair_body(pa, b, 0, 1, &kp);
+    __threadfence_block();  // this workgroup's KJC / VALS / BLKCNT / LIDC stores are complete ...
+    __syncthreads();        // ... before any of its lanes reads them back
+    STAMP(3);
+    reduce_body(ra, b);
+    STAMP(6);
+    __threadfence_block();  // ... and so are MED / BCNT / INFO / loss
+    __syncthreads();
+    STAMP(7);
+    if (tid == 1023 && payload && a.info[b * 4] > 0) {  // (order-independent: fixed-point sum of the valid samples' losses)
+        TailArgs t;
+        t.payload = payload; t.mctl = mctl;
+        tail_payload(t, ra.loss[b]);
+    }
+    const int cnt = kp.total, C = a.info[b * 4];  // (uniform)
+    const float m = a.med[b], gl_in = a.grad_loss[b];
+    if (cnt <= 128) {
+        if ((tid & ~63) >> 3 >= cnt) return;  // wave-uniform: none of this wavefront's eight ranks holds a line
+        const int side = (lane >> 2) & 1, h = lane & 3, k = kp.k, j = kp.j;
+        const int mycnt = side ? j : k, ocnt = side ? k : j;
+        const bool valid = (tid >> 3) < cnt && C > 0;
+        const bool live = valid && h < mycnt && !side;  // (grad_tri2 never rides here)
+        float d[4] = {INFINITY, INFINITY, INFINITY, INFINITY};
+        if (valid && h < mycnt) {
+#pragma unroll
+            for (int o = 0; o < RRL_MAX_HITS; ++o)
+                if (o < ocnt) {  // pair_hit's expression for entry (ra, rb) = (h, o) / (o, h): cloud 1's point minus cloud 2's
+                    const float4 p1 = kp.sq[side ? o : h], p2 = kp.sq[4 + (side ? h : o)];
+                    const float dx = p1.x - p2.x, dy = p1.y - p2.y, dz = p1.z - p2.z;
+                    float sq = dx * dx;
+                    sq = sq + dy * dy;
+                    sq = sq + dz * dz;
+                    d[o] = sq;
+                }
+        }
+        const int S = live ? a.bcnt[b * 16 + (k - 1) * 4 + (j - 1)] : 1;
+        const float4 *sq = kp.sq;
+        bwd_scatter_math(live, k, j, side, h, d, S, kp.q, kp.f, kp.w, C, m, gl_in, [&](int o) { return sq[side ? o : 4 + o]; },
+                         a.g1 + (size_t)b * a.N * 9, nullptr, s_scat[wave], lane);
+        STAMP(8);
+        return;
+    }
+    for (int r0 = 0; r0 < cnt; r0 += 128)  // uniform
+        bwd_scatter_pass(a, b, (size_t)b * 1024, cnt, r0 + (tid >> 3), b, C, m, gl_in, s_scat[wave], lane);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -2527,6 +2683,17 @@ static bool default_deterministic() {
     return g_deterministic == 1;
 }
 
+static ScatArgs scat_args(const void *ws, const WsLayout &w, const float *grad_loss, float *g1, float *g2, int N, int M, int L) {
+    ScatArgs a;
+    a.lidc = w.u32(ws, RRL_WS_LIDC); a.blkcnt = w.i32(ws, RRL_WS_BLKCNT);
+    a.hs1 = w.i32(ws, RRL_WS_HS1); a.hs2 = w.i32(ws, RRL_WS_HS2); a.bcnt = w.i32(ws, RRL_WS_BCNT); a.info = w.i32(ws, RRL_WS_INFO);
+    a.w1 = w.f32(ws, RRL_WS_W1); a.w2 = w.f32(ws, RRL_WS_W2); a.D = w.f32(ws, RRL_WS_D); a.med = w.f32(ws, RRL_WS_MED);
+    a.grad_loss = grad_loss;
+    a.Q1 = (const float4 *)w.f32(ws, RRL_WS_Q1); a.Q2 = (const float4 *)w.f32(ws, RRL_WS_Q2);
+    a.g1 = g1; a.g2 = g2; a.N = N; a.M = M; a.L = L;
+    return a;
+}
+
 static int loss_backward_impl(const float *tri1, const float *tri2, const void *ws,
                               size_t ws_bytes, const float *grad_loss, float *grad_tri1,
                               float *grad_tri2, int B, int N, int M, int L, int pool, bool zero1,
@@ -2540,13 +2707,8 @@ static int loss_backward_impl(const float *tri1, const float *tri2, const void *
     if (zero1 && (rc = rrl_fill(grad_tri1, 0u, sizeof(float) * 9 * (size_t)B * N, s))) return rc;
     if (grad_tri2 && (rc = rrl_fill(grad_tri2, 0u, sizeof(float) * 9 * (size_t)B * M, s))) return rc;
     if (B == 0 || L == 0) return 0;
-    hipLaunchKernelGGL(loss_bwd_kernel, dim3((unsigned)((L + 1023) / 1024), (unsigned)B, BWDS_SUBS),
-                       dim3(256), 0, s, w.u32(ws, RRL_WS_LIDC), w.i32(ws, RRL_WS_BLKCNT),
-                       w.i32(ws, RRL_WS_HS1), w.i32(ws, RRL_WS_HS2),
-                       w.f32(ws, RRL_WS_W1), w.f32(ws, RRL_WS_W2), (const float4 *)w.f32(ws, RRL_WS_Q1),
-                       (const float4 *)w.f32(ws, RRL_WS_Q2),
-                       w.f32(ws, RRL_WS_D), w.f32(ws, RRL_WS_MED), w.i32(ws, RRL_WS_BCNT),
-                       w.i32(ws, RRL_WS_INFO), grad_loss, grad_tri1, grad_tri2, B, N, M, L, pool,
+    hipLaunchKernelGGL(loss_bwd_kernel, dim3((unsigned)((L + 1023) / 1024), (unsigned)B, BWDS_SUBS), dim3(256), 0, s,
+                       scat_args(ws, w, grad_loss, grad_tri1, grad_tri2, N, M, L), B, pool,
                        B % 8 == 0 && xcd_align_on() ? 1 : 0);
     RRL_LAUNCH_CHECK();
     return 0;
@@ -2631,6 +2793,15 @@ static int loss_forward_impl(const float *tri1, const float *tri2, const float *
         RrlRange r("K2 + K3 + K4 (single tile)");
         WsLayout w(B, N, M, L);
         if (ws_bytes < w.total) return RRL_E_WS;
+        if (tb && tb->grad_tri1) {  // ... and the scatter backward to points1.grad too (rrl_loss_step_ex)
+            hipLaunchKernelGGL(pair_reduce_scatter_kernel, dim3((unsigned)B), dim3(1024), sizeof(int) * 2, (hipStream_t)stream,
+                               pair_args(tri1, tri2, line, ws, w, B, N, M, L, s_m, s_n, e_m, e_n, false, target_ws, o.problems),
+                               reduce_args(ws, w, loss, B, L, s_m, s_n, e_m, e_n, 0),
+                               scat_args(ws, w, tb->grad_loss, tb->grad_tri1, nullptr, N, M, L), tb->payload, w.u32(ws, RRL_WS_MCTL));
+            RRL_LAUNCH_CHECK();
+            if (bwd_done) *bwd_done = true;
+            return 0;
+        }
         if (tb && !tb->grad_tri1) {  // ... and the direct backward too (rrl_registration_step)
             SoloBwd sb;
             sb.kj = w.u8(ws, RRL_WS_KJ); sb.sel = w.i32(ws, RRL_WS_SEL); sb.nsel = w.i32(ws, RRL_WS_NSEL);
@@ -2837,7 +3008,9 @@ extern "C" int rrl_loss_step_ex(const float *tri1, const float *R, const float *
     }
     const RrlXform xf = {tri1, R, t, transpose_r, pay_in_ws ? 1 : 0};
     const float *p1 = R ? w.f32(ws, RRL_WS_TRI1) : tri1;  // points1: the moved source, or the caller's triangles as given
-    const bool ride = B > 0 && L > 0 && !grad_tri2 && L > 1024 && reduce_kind(o.reduce_mode, B, nblk, 0, true) == 2;
+    // (the tail kernel, or -- one tile of lines per sample -- the single-tile kernel: loss_forward_impl's own conditions)
+    const bool ride = B > 0 && L > 0 && !grad_tri2 &&
+                      (L > 1024 ? reduce_kind(o.reduce_mode, B, nblk, 0, true) == 2 : o.reduce_mode < 2);
     const TailBwd tb = {grad_loss, nullptr, nullptr, nullptr, payload, 0, grad_tri1};
     bool done = false;
     int rc = loss_forward_impl(p1, tri2, line, ws, ws_bytes, loss, B, N, M, L, s_m, s_n, e_m, e_n, 0, mode, chunk, target_ws,
