@@ -40,3 +40,8 @@ for i in range(6):
     mins = np.mean([r[i].min() for r in rows if len(r[i])]); meds = np.mean([np.median(r[i]) for r in rows if len(r[i])])
     maxs = np.mean([r[i].max() for r in rows if len(r[i])]); cnt = np.mean([len(r[i]) for r in rows])
     print(f"  {names[i]:48s} workgroups {cnt:6.1f}  first {mins:6.2f}  median {meds:6.2f}  last {maxs:6.2f} us")
+# workgroups in flight (entered, not done) over time, last run
+e, d = (v[0] - t0) / 100.0, (v[5] - t0) / 100.0
+ok = v[0] > 0
+e, d = e[ok], d[ok]
+print("  in flight at t us: " + "  ".join(f"{t_:.0f}: {int(((e <= t_) & (d > t_)).sum())}" for t_ in np.arange(1.0, d.max(), 2.0)))
