@@ -141,6 +141,10 @@ struct PairKeep {
     float w[3];  // its weights
     float4 q;    // its intersection point
     float4 *sq;  // LDS: the 8 intersection points of the line (cloud 1: 0..3, cloud 2: 4..7)
+    // in: LDS the caller provides for the first pass's compact rows (what the reduce reads back: the (k | j << 4) byte and
+    // the canonical 4 x 4 D tile of ranks 0 .. 127), or NULL
+    uint8_t *kjc_lds;  // [128]
+    float *dc_lds;     // [128][16]
 };
 
 __device__ __forceinline__ void pair_hit(const float *__restrict__ tri1, const float *__restrict__ tri2,
@@ -336,7 +340,13 @@ __device__ __forceinline__ void pair_body(const PairArgs &a, int b, int tile, in
             pair_hit(a.tri1, a.tri2, a.line, a.hit1, a.hit2, a.hs1, a.hs2, a.w1, a.w2, a.Q1, a.Q2, a.D, a.dc + slot * 16,
                      s_q[tid >> 3], tally ? s_mh : nullptr, b, a.N, a.M, gl, k, j, sub, a.st1, a.st2, t2, bi, (size_t)bi * L + l,
                      r0 == 0 ? keep : nullptr);
-            if (keep && r0 == 0) { keep->k = k; keep->j = j; }
+            if (keep && r0 == 0) {
+                keep->k = k; keep->j = j;
+                if (keep->dc_lds) {
+                    ((float2 *)(keep->dc_lds + rank * 16))[sub] = make_float2(t2[0], t2[1]);
+                    if (sub == 0) keep->kjc_lds[rank] = (uint8_t)(k | (j << 4));
+                }
+            }
             nvl = (((2 * sub) >> 2) < k && ((2 * sub) & 3) < j ? 1u : 0u) | (((2 * sub + 1) >> 2) < k && ((2 * sub + 1) & 3) < j ? 2u : 0u);
         }
         if (vl) {  // (all lanes: uniform) the valid entries join the tile's dense value list: one LDS cursor atomic per wavefront
@@ -664,7 +674,36 @@ __device__ __forceinline__ void reduce_core(const uint8_t *__restrict__ kjc, con
         __syncthreads();
         prefix = s_prefix[pass];
     };
-    if (n > 0) {
+    if (n > 0 && n <= 128u) {
+        // ---- a tiny sample (<= 128 values: C5's 512 lines select ~13): the values meet in LDS (s_hist is all zero and free
+        //      until the next evaluation) and every one counts the smaller ones itself -- the element of rank (n-1)/2 by
+        //      definition, ties broken by position (bit patterns of non-negative floats order like the values); two barriers instead of the radix select's five and its 2048-bin scans
+        //      (3.1 us of the single-tile kernel's 12.0 at C5, tools/stamps.py).
+        unsigned at = myvals ? atomicAdd(&L_.s_cand[1], myvals) : 0u;
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+#pragma unroll
+            for (int q = 0; q < 16; ++q)  // the k x j block of the canonical tile (myvals entries: the cursor's share)
+                if ((unsigned)(q >> 2) < (c0[r] & 15u) && (unsigned)(q & 3) < (c0[r] >> 4) && at < 128u) s_hist[at++] = __float_as_uint(tile[r][q]);
+        if ((unsigned)tid >= n && (unsigned)tid < n + 3u) s_hist[tid] = 0xffffffffu;  // pad to whole 16-byte groups: never counted
+        __syncthreads();
+        if ((unsigned)tid < n) {
+            const unsigned x = s_hist[tid];
+            unsigned c = 0;
+            for (unsigned u = 0; u < n; u += 4) {  // (uniform addresses: one LDS read serves the wavefront)
+                const uint4 y = *(const uint4 *)&s_hist[u];
+                c += (y.x < x || (y.x == x && u < (unsigned)tid)) ? 1u : 0u;
+                c += (y.y < x || (y.y == x && u + 1 < (unsigned)tid)) ? 1u : 0u;
+                c += (y.z < x || (y.z == x && u + 2 < (unsigned)tid)) ? 1u : 0u;
+                c += (y.w < x || (y.w == x && u + 3 < (unsigned)tid)) ? 1u : 0u;
+            }
+            if (c == s_rank[0]) s_prefix[2] = x;
+        }
+        __syncthreads();
+        prefix = s_prefix[2];
+        if ((unsigned)tid < 132u) s_hist[tid] = 0;
+        if (tid == 0) L_.s_cand[1] = 0;
+    } else if (n > 0) {
         wg_pass(0);
         STAMP(10);
         const unsigned ncand = L_.s_cand[0];
@@ -839,7 +878,22 @@ struct ReduceArgs {
 };
 
 // K3+K4 of one group g (a sample, or all samples with the last one's median when pool) by a 1024-lane workgroup
-__device__ __forceinline__ void reduce_body(const ReduceArgs &ra, int g) {
+// SOLO (the single-tile kernels, round 5): the workgroup has just run the per-line stage of sample g itself --
+//   total    its selected lines (no BLKCNT read-back),
+//   kjc / dc LDS copies of its compact rows when total <= 128 (no read-back of KJC / VALS and no fence in front of it), else NULL,
+//   fwave    the wavefront that turns the sums into the loss (the last one: at <= 120 lines it holds none), while the others
+//            return as soon as the bucket counts and the median exist -- all the backward needs: out_med, s_cnt (LDS [16]),
+//   out_loss the loss (lane 0 of wavefront fwave).
+struct SoloReduce {
+    int total;
+    const uint8_t *kjc;
+    const float *dc;
+    int fwave;
+    float out_med, out_loss;
+    const int *s_cnt;
+};
+
+__device__ __forceinline__ void reduce_body(const ReduceArgs &ra, int g, SoloReduce *solo = nullptr) {
     const uint8_t *__restrict__ kjc = ra.kjc;
     const float *__restrict__ dc = ra.dc;
     const int32_t *__restrict__ blkcnt = ra.blkcnt;
@@ -851,7 +905,7 @@ __device__ __forceinline__ void reduce_body(const ReduceArgs &ra, int g) {
     const int32_t *__restrict__ status = ra.status;
     const int B = ra.B, nblk = ra.nblk, s_m = ra.s_m, s_n = ra.s_n, e_m = ra.e_m, e_n = ra.e_n, pool = ra.pool;
     extern __shared__ int s_pref[];  // nblk + 1
-    __shared__ unsigned s_hist[2048];
+    __shared__ __attribute__((aligned(16))) unsigned s_hist[2048];
     __shared__ unsigned s_wtot[16];
     __shared__ unsigned s_prefix[3], s_rank[4];  // one slot per pass: no barrier between read and rewrite
     __shared__ unsigned s_nvals;
@@ -869,29 +923,41 @@ __device__ __forceinline__ void reduce_body(const ReduceArgs &ra, int g) {
     s_hist[tid] = 0;
     s_hist[tid + 1024] = 0;
 
-    const int ns_m = load_prefix(blkcnt + (size_t)bm * nblk, nblk, s_pref, tid);
+    int ns_m;
+    if (solo) {  // (one tile: the prefix is (0, total))
+        ns_m = solo->total;
+        if (tid == 0) { s_pref[0] = 0; s_pref[1] = ns_m; }
+        __syncthreads();
+    } else {
+        ns_m = load_prefix(blkcnt + (size_t)bm * nblk, nblk, s_pref, tid);
+    }
     STAMP(4);
     const ReduceLds lds = {s_pref, s_hist, s_wtot, s_prefix, s_rank, &s_nvals, s_cand, s_whist, s_sum, s_cnt, &s_bad};
     float med;
     unsigned n;
-    if (ns_m <= 1024) reduce_core<1>(kjc, dc, blkcnt, lds, ns_m, B, nblk, bm, b0, b1, tid, med, n);
+    if (solo && solo->kjc) reduce_core<1>(solo->kjc, solo->dc, blkcnt, lds, ns_m, 1, 1, 0, 0, 1, tid, med, n);  // (<= 128 rows, from LDS)
+    else if (ns_m <= 1024) reduce_core<1>(kjc, dc, blkcnt, lds, ns_m, B, nblk, bm, b0, b1, tid, med, n);
     else reduce_core<3>(kjc, dc, blkcnt, lds, ns_m, B, nblk, bm, b0, b1, tid, med, n);
     __syncthreads();
+    STAMP(5);
 
     // ---- loss = ( sum_{non-empty (k,j), k-major} exp(-|k-j|/2) (mean_row + mean_col) ) / C
-    if (tid < 16) bcnt_out[g * 16 + tid] = s_cnt[tid];
-    if (tid < 32) bsum_out[(size_t)g * 32 + tid] = (int64_t)s_sum[tid];
-    if (tid < 64) {  // wavefront 0: one lane per bucket
-        const BucketFinal f = bucket_final(tid < 16 ? s_sum[tid * 2 + 0] : 0ull, tid < 16 ? s_sum[tid * 2 + 1] : 0ull,
-                                           tid < 16 ? s_cnt[tid] : 0, tid, s_m, s_n, e_m, e_n);
-        if (tid == 0) {
-            med_out[g] = med;
-            loss[g] = s_bad ? __builtin_nanf("") : (f.C ? f.acc / (float)f.C : 0.0f);  // code/loss.py:230
-            info[g * 4 + 0] = f.C;
-            info[g * 4 + 1] = f.nselected;
-            info[g * 4 + 2] = (int)n;
-            info[g * 4 + 3] = st0;  // the scan's NaN flag next to the bucket count: one 16-byte read-back decides the call
-        }
+    const int ft = tid - (solo ? 64 * solo->fwave : 0);  // lane of the finishing wavefront (wavefront 0 but for SOLO)
+    if (solo) { solo->out_med = med; solo->s_cnt = s_cnt; solo->out_loss = 0.0f; }
+    if (ft < 0 || ft >= 64) return;
+    if (ft < 16) bcnt_out[g * 16 + ft] = s_cnt[ft];
+    if (ft < 32) bsum_out[(size_t)g * 32 + ft] = (int64_t)s_sum[ft];
+    const BucketFinal f = bucket_final(ft < 16 ? s_sum[ft * 2 + 0] : 0ull, ft < 16 ? s_sum[ft * 2 + 1] : 0ull,
+                                       ft < 16 ? s_cnt[ft] : 0, ft, s_m, s_n, e_m, e_n);  // one lane per bucket
+    if (ft == 0) {
+        const float lv = s_bad ? __builtin_nanf("") : (f.C ? f.acc / (float)f.C : 0.0f);  // code/loss.py:230
+        med_out[g] = med;
+        loss[g] = lv;
+        info[g * 4 + 0] = f.C;
+        info[g * 4 + 1] = f.nselected;
+        info[g * 4 + 2] = (int)n;
+        info[g * 4 + 3] = st0;  // the scan's NaN flag next to the bucket count: one 16-byte read-back decides the call
+        if (solo) solo->out_loss = lv;
     }
 }
 
@@ -1884,10 +1950,17 @@ __global__ __launch_bounds__(TAIL_LANES) __attribute__((amdgpu_waves_per_eu(4, 8
 // simply carries on (a launch and the reduce's first load round less: small-L shapes such as C5 are nothing
 // but launch latency).  Same bodies, same results.
 __global__ __launch_bounds__(1024) void pair_reduce_kernel(const PairArgs pa, const ReduceArgs ra) {
-    pair_body(pa, (int)blockIdx.x, 0, 1);
-    __threadfence_block();  // this workgroup's KJC / VALS / BLKCNT stores are complete ...
-    __syncthreads();        // ... before any of its lanes reads them back
-    reduce_body(ra, (int)blockIdx.x);
+    __shared__ __attribute__((aligned(16))) float s_dct[128 * 16];  // the first pass's compact D tiles and (k | j << 4) bytes:
+    __shared__ uint8_t s_kjct[128];                                 // at <= 128 selected lines the reduce reads nothing back
+    PairKeep kp;
+    kp.kjc_lds = s_kjct; kp.dc_lds = s_dct;
+    pair_body(pa, (int)blockIdx.x, 0, 1, &kp);
+    const bool small = kp.total <= 128;  // (uniform)
+    if (!small) __threadfence_block();   // this workgroup's KJC / VALS / BLKCNT stores are complete ...
+    __syncthreads();                     // ... before any of its lanes reads them back (small: the LDS copies are)
+    SoloReduce so;
+    so.total = kp.total; so.kjc = small ? s_kjct : nullptr; so.dc = small ? s_dct : nullptr; so.fwave = 0;
+    reduce_body(ra, (int)blockIdx.x, &so);
 }
 
 // The DEFAULT reduce mode (include/rrl.h rrl_set_reduce_mode; a call's rrl_opts.reduce_mode overrides it): 0 auto, 1 single,
@@ -2267,33 +2340,41 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(const ScatArgs a, int B, 
 // sample's selected lines (loss_bwd_kernel's arithmetic, 8 lines per wavefront and pass).  Same bodies, same
 // results; payload[0 .. 1] as in the tail kernel.  grad_tri1 is zero on entry (the records launch cleared it).
 // At most 128 selected lines (one pass of the per-line stage: every (line, cloud, hit) lane still HOLDS its triangle, weights and
-// intersection point, and the line's eight points sit in the stage's LDS) the backward reads none of it back: the D row /
-// column is re-evaluated from the points with the stage's own expression (bit-identical to the stored tile) and only the
-// sample's median, valid count, bucket count and upstream gradient are fetched -- ONE round trip instead of four dependent
-// ones (compact list -> D / Q / hits / weights -> the other cloud's points).  More lines: from the workspace, as above.
+// intersection point, and the line's eight points sit in the stage's LDS) nothing is read back: the reduce takes the compact
+// rows from an LDS copy, the backward re-evaluates its D row / column from the points with the stage's own expression
+// (bit-identical to the stored tile), takes the median from the reduce's registers and the bucket counts from its LDS -- and
+// starts as soon as those exist, while the workgroup's last wavefront turns the sums into the loss (SoloReduce).  More lines:
+// through the workspace, as above.
 __global__ __launch_bounds__(1024) void pair_reduce_scatter_kernel(const PairArgs pa, const ReduceArgs ra, const ScatArgs a,
                                                                     float *__restrict__ payload, uint32_t *__restrict__ mctl) {
     __shared__ unsigned s_scat[16][64 * SCAT_STRIDE];
+    __shared__ __attribute__((aligned(16))) float s_dct[128 * 16];  // the first pass's compact D tiles ...
+    __shared__ uint8_t s_kjct[128];                                 // ... and (k | j << 4) bytes, for the reduce
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float gl_in = a.grad_loss[b];  // (requested now)
     PairKeep kp;
+    kp.kjc_lds = s_kjct; kp.dc_lds = s_dct;
     STAMP(0);
     pair_body(pa, b, 0, 1, &kp);
-    __threadfence_block();  // this workgroup's KJC / VALS / BLKCNT / LIDC stores are complete ...
-    __syncthreads();        // ... before any of its lanes reads them back
+    const int cnt = kp.total;       // (uniform)
+    const bool small = cnt <= 128;  // one pass of the per-line stage: the reduce and the backward read nothing back
+    if (!small) __threadfence_block();  // this workgroup's KJC / VALS / BLKCNT / LIDC stores are complete ...
+    __syncthreads();                    // ... before any of its lanes reads them back (small: the LDS copies are)
     STAMP(3);
-    reduce_body(ra, b);
+    SoloReduce so;
+    so.total = cnt; so.kjc = small ? s_kjct : nullptr; so.dc = small ? s_dct : nullptr; so.fwave = 15;
+    reduce_body(ra, b, &so);  // (every wavefront but the last returns once the median and the bucket counts exist)
     STAMP(6);
-    __threadfence_block();  // ... and so are MED / BCNT / INFO / loss
-    __syncthreads();
-    STAMP(7);
-    if (tid == 1023 && payload && a.info[b * 4] > 0) {  // (order-independent: fixed-point sum of the valid samples' losses)
+    // the non-empty buckets of the range (code/loss.py:230's C), by every wavefront from the counts in LDS
+    const int sc = lane < 16 ? so.s_cnt[lane] : 0, kk = (lane & 15) / 4 + 1, jj = (lane & 3) + 1;
+    const int C = __popcll(__ballot(lane < 16 && sc > 0 && kk >= ra.s_m && kk < ra.e_m && jj >= ra.s_n && jj < ra.e_n));
+    const float m = so.out_med;
+    if (tid == 64 * 15 && payload && C > 0) {  // (order-independent: fixed-point sum of the valid samples' losses)
         TailArgs t;
         t.payload = payload; t.mctl = mctl;
-        tail_payload(t, ra.loss[b]);
+        tail_payload(t, so.out_loss);
     }
-    const int cnt = kp.total, C = a.info[b * 4];  // (uniform)
-    const float m = a.med[b], gl_in = a.grad_loss[b];
-    if (cnt <= 128) {
+    if (small) {
         if ((tid & ~63) >> 3 >= cnt) return;  // wave-uniform: none of this wavefront's eight ranks holds a line
         const int side = (lane >> 2) & 1, h = lane & 3, k = kp.k, j = kp.j;
         const int mycnt = side ? j : k, ocnt = side ? k : j;
@@ -2312,13 +2393,15 @@ __global__ __launch_bounds__(1024) void pair_reduce_scatter_kernel(const PairArg
                     d[o] = sq;
                 }
         }
-        const int S = live ? a.bcnt[b * 16 + (k - 1) * 4 + (j - 1)] : 1;
+        const int S = live ? so.s_cnt[(k - 1) * 4 + (j - 1)] : 1;
         const float4 *sq = kp.sq;
         bwd_scatter_math(live, k, j, side, h, d, S, kp.q, kp.f, kp.w, C, m, gl_in, [&](int o) { return sq[side ? o : 4 + o]; },
                          a.g1 + (size_t)b * a.N * 9, nullptr, s_scat[wave], lane);
         STAMP(8);
         return;
     }
+    __threadfence_block();  // (more than one pass: from the workspace -- the finishing wavefront's BCNT is read back)
+    __syncthreads();
     for (int r0 = 0; r0 < cnt; r0 += 128)  // uniform
         bwd_scatter_pass(a, b, (size_t)b * 1024, cnt, r0 + (tid >> 3), b, C, m, gl_in, s_scat[wave], lane);
 }
@@ -2343,6 +2426,76 @@ __device__ __forceinline__ int bwd_live_blocks(int ns) { return ns > 0 ? (ns + B
 // The (dL/dR, dL/dt) terms of ONE selected line's hit slot h (li: its index within sample b, or -1) added to acc[12]
 // (9 sums of x (x) g in m-index order, 3 of g).  ALL lanes of the wavefront must call it: the four lanes of a line share
 // its Welsch tile by quad DPP.
+// The arithmetic of the direct (dR, dt) backward for one lane = (selected line, hit slot h of cloud 1), four lanes per line (a
+// DPP quad); every lane of the wavefront calls, lanes without a line or hit carry +inf rows and k = j = 0.  dr: row h of the
+// line's D tile; S: the (k, j) bucket's line count; mine / wq / xs: this hit's intersection point, weights and SOURCE triangle
+// (unmoved); qx / qy / qz: cloud 2's intersection points; acc: 9 sums for dL/dm (m-index order) + 3 for dL/dt.
+__device__ __forceinline__ void bwd_rt_math(bool live, int k, int j, int h, const float (&dr)[4], int S, float4 mine,
+                                            const float (&qx)[4], const float (&qy)[4], const float (&qz)[4],
+                                            const float (&wq)[3], const float (&xs)[9], int C, float m, float gl_in, float *acc) {
+    const int jmax = (int)wave_max((float)j);  // uniform
+    float er[4] = {0.0f, 0.0f, 0.0f, 0.0f}, wr[4];
+#pragma unroll
+    for (int o = 0; o < RRL_MAX_HITS; ++o) {
+        wr[o] = INFINITY;
+        if (o < jmax) {
+            const float e = expf(-(dr[o] / m) / 2.0f);  // == welsch(): 1 - e
+            er[o] = e;
+            if (dr[o] < INFINITY) wr[o] = 1.0f - e;
+        }
+    }
+    int arg_b_own = 0, arg_a[4];
+    {
+        float bestw = wr[0];
+#pragma unroll
+        for (int o = 1; o < RRL_MAX_HITS; ++o)
+            if (wr[o] < bestw) { bestw = wr[o]; arg_b_own = o; }
+#pragma unroll
+        for (int o = 0; o < RRL_MAX_HITS; ++o) {
+            const float w0 = quad_bcast<0>(wr[o]), w1_ = quad_bcast<1>(wr[o]), w2_ = quad_bcast<2>(wr[o]), w3 = quad_bcast<3>(wr[o]);
+            float best = w0;
+            int mm = 0;
+            if (w1_ < best) { best = w1_; mm = 1; }
+            if (w2_ < best) { best = w2_; mm = 2; }
+            if (w3 < best) { best = w3; mm = 3; }
+            arg_a[o] = mm;
+        }
+    }
+    if (live) {
+        const float wkj = expf(-0.5f * (float)abs(k - j));
+        const float scale = gl_in * wkj / (float)C;
+        const float inv_row = 1.0f / ((float)S * (float)k), inv_col = 1.0f / ((float)S * (float)j);
+        float gq[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int o = 0; o < RRL_MAX_HITS; ++o) {
+            if (o >= j) continue;
+            float sw = 0.0f;
+            if (arg_b_own == o) sw += inv_row;
+            if (arg_a[o] == h) sw += inv_col;
+            if (sw == 0.0f) continue;
+            // same expressions as loss_bwd_kernel
+            const float gD = scale * sw * er[o] / (2.0f * m);
+            gq[0] += 2.0f * (mine.x - qx[o]) * gD;
+            gq[1] += 2.0f * (mine.y - qy[o]) * gD;
+            gq[2] += 2.0f * (mine.z - qz[o]) * gD;
+        }
+#pragma unroll
+        for (int kk = 0; kk < 3; ++kk) {
+            const float wk = wq[kk] / 3.0f;  // q = mean_k(w_k P_k)
+            float gv[3];
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc) gv[cc] = wk * gq[cc];
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc) {
+                const float xc = xs[3 * kk + cc];
+#pragma unroll
+                for (int jj = 0; jj < 3; ++jj) acc[cc * 3 + jj] = fmaf(xc, gv[jj], acc[cc * 3 + jj]);
+                acc[9 + cc] += gv[cc];
+            }
+        }
+    }
+}
+
 __device__ __forceinline__ void bwd_rt_line(int li, int h, int b, int L, int N, const uint8_t *__restrict__ kj,
                                             const int32_t *__restrict__ hs1, const float *__restrict__ w1,
                                             const float4 *__restrict__ Q1, const float4 *__restrict__ Q2,
@@ -2384,67 +2537,7 @@ __device__ __forceinline__ void bwd_rt_line(int li, int h, int b, int L, int N, 
 #pragma unroll
         for (int q = 0; q < 9; ++q) xs[q] = x[q];
     }
-    const int jmax = (int)wave_max((float)j);  // uniform
-    float er[4] = {0.0f, 0.0f, 0.0f, 0.0f}, wr[4];
-#pragma unroll
-    for (int o = 0; o < RRL_MAX_HITS; ++o) {
-        wr[o] = INFINITY;
-        if (o < jmax) {
-            const float e = expf(-(dr[o] / m) / 2.0f);  // == welsch(): 1 - e
-            er[o] = e;
-            if (dr[o] < INFINITY) wr[o] = 1.0f - e;
-        }
-    }
-    int arg_b_own = 0, arg_a[4];
-    {
-        float bestw = wr[0];
-#pragma unroll
-        for (int o = 1; o < RRL_MAX_HITS; ++o)
-            if (wr[o] < bestw) { bestw = wr[o]; arg_b_own = o; }
-#pragma unroll
-        for (int o = 0; o < RRL_MAX_HITS; ++o) {
-            const float w0 = quad_bcast<0>(wr[o]), w1_ = quad_bcast<1>(wr[o]), w2_ = quad_bcast<2>(wr[o]), w3 = quad_bcast<3>(wr[o]);
-            float best = w0;
-            int mm = 0;
-            if (w1_ < best) { best = w1_; mm = 1; }
-            if (w2_ < best) { best = w2_; mm = 2; }
-            if (w3 < best) { best = w3; mm = 3; }
-            arg_a[o] = mm;
-        }
-    }
-    if (live) {
-        const float wkj = expf(-0.5f * (float)abs(k - j));
-        const float scale = grad_loss[b] * wkj / (float)C;
-        const float inv_row = 1.0f / ((float)S * (float)k), inv_col = 1.0f / ((float)S * (float)j);
-        float gq[3] = {0.0f, 0.0f, 0.0f};
-#pragma unroll
-        for (int o = 0; o < RRL_MAX_HITS; ++o) {
-            if (o >= j) continue;
-            float sw = 0.0f;
-            if (arg_b_own == o) sw += inv_row;
-            if (arg_a[o] == h) sw += inv_col;
-            if (sw == 0.0f) continue;
-            // same expressions as loss_bwd_kernel
-            const float gD = scale * sw * er[o] / (2.0f * m);
-            gq[0] += 2.0f * (mine.x - qx[o]) * gD;
-            gq[1] += 2.0f * (mine.y - qy[o]) * gD;
-            gq[2] += 2.0f * (mine.z - qz[o]) * gD;
-        }
-#pragma unroll
-        for (int kk = 0; kk < 3; ++kk) {
-            const float wk = wq[kk] / 3.0f;  // q = mean_k(w_k P_k)
-            float gv[3];
-#pragma unroll
-            for (int cc = 0; cc < 3; ++cc) gv[cc] = wk * gq[cc];
-#pragma unroll
-            for (int cc = 0; cc < 3; ++cc) {
-                const float xc = xs[3 * kk + cc];
-#pragma unroll
-                for (int jj = 0; jj < 3; ++jj) acc[cc * 3 + jj] = fmaf(xc, gv[jj], acc[cc * 3 + jj]);
-                acc[9 + cc] += gv[cc];
-            }
-        }
-    }
+    bwd_rt_math(live, k, j, h, dr, S, mine, qx, qy, qz, wq, xs, C, m, live ? grad_loss[b] : 0.0f, acc);
 }
 
 // DET = true (rrl_set_deterministic): instead of the atomics every workgroup stores its 12 sums to
@@ -2632,22 +2725,70 @@ struct SoloBwd {
 
 __global__ __launch_bounds__(1024) void pair_reduce_bwd_kernel(const PairArgs pa, const ReduceArgs ra, const SoloBwd a) {
     __shared__ float s_red[16][12];
+    __shared__ __attribute__((aligned(16))) float s_dct[128 * 16];  // the first pass's compact D tiles and (k | j << 4) bytes
+    __shared__ uint8_t s_kjct[128];                                 // for the reduce (pair_reduce_scatter_kernel)
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    pair_body(pa, b, 0, 1);
-    __threadfence_block();  // this workgroup's KJC / VALS / BLKCNT stores are complete ...
-    __syncthreads();        // ... before any of its lanes reads them back
-    reduce_body(ra, b);
-    __threadfence_block();  // ... and so are MED / BCNT / INFO / loss, SEL / NSEL and the per-line arrays
-    __syncthreads();
-    const int ns = a.nsel[b], h = tid & 3;
+    const int bs = (a.Bt > 0 && b >= a.Bt) ? b % a.Bt : b;  // the instance's source entry (multi-pose)
+    const float gl_in = a.grad_loss[b];  // (requested now)
+    PairKeep kp;
+    kp.kjc_lds = s_kjct; kp.dc_lds = s_dct;
+    pair_body(pa, b, 0, 1, &kp);
+    const int ns = kp.total;       // (uniform)
+    const bool small = ns <= 128;  // one pass of the per-line stage: the reduce and the backward read nothing of it back
+    // small: this lane's SOURCE triangle (lanes of cloud 1 with a hit), requested now -- the only load of the backward
+    const int side = (lane >> 2) & 1, h = lane & 3;
+    float xs[9] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    if (small && !side && h < kp.k) {
+        const float *x = a.src + ((size_t)bs * a.N + kp.f) * 9;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) xs[q] = x[q];
+    }
+    if (!small) __threadfence_block();  // this workgroup's KJC / VALS / BLKCNT stores are complete ...
+    __syncthreads();                    // ... before any of its lanes reads them back (small: the LDS copies are)
+    SoloReduce so;
+    so.total = ns; so.kjc = small ? s_kjct : nullptr; so.dc = small ? s_dct : nullptr; so.fwave = 15;
+    reduce_body(ra, b, &so);
+    const int sc = lane < 16 ? so.s_cnt[lane] : 0, kk = (lane & 15) / 4 + 1, jj = (lane & 3) + 1;
+    const int C = __popcll(__ballot(lane < 16 && sc > 0 && kk >= ra.s_m && kk < ra.e_m && jj >= ra.s_n && jj < ra.e_n));
+    if (tid == 64 * 15 && a.payload && C > 0) {  // payload[0 .. 1] as in the tail kernel (order-independent)
+        TailArgs t;
+        t.payload = a.payload; t.mctl = a.mctl;
+        tail_payload(t, so.out_loss);
+    }
     float acc[12];
 #pragma unroll
     for (int q = 0; q < 12; ++q) acc[q] = 0.0f;
-    for (int i0 = 0; i0 < ns; i0 += 256) {  // uniform: 256 selected lines per pass, four lanes each
-        const int i = i0 + (tid >> 2);
-        const int li = i < ns ? a.sel[(size_t)b * a.L + i] : -1;
-        bwd_rt_line(li, h, b, a.L, a.N, a.kj, a.hs1, a.w1, a.Q1, a.Q2, a.D, a.med, a.bcnt, a.info, a.grad_loss, a.src, acc,
-                    (a.Bt > 0 && b >= a.Bt) ? b % a.Bt : b);
+    if (small) {
+        if ((tid & ~63) >> 3 < ns) {  // wave-uniform: this wavefront's eight ranks hold lines
+            const int k = kp.k, j = kp.j;  // (0, 0 beyond the last line)
+            const bool live = (tid >> 3) < ns && C > 0 && !side && h < k;
+            float dr[4] = {INFINITY, INFINITY, INFINITY, INFINITY};
+            float qx[4] = {0.0f, 0.0f, 0.0f, 0.0f}, qy[4] = {0.0f, 0.0f, 0.0f, 0.0f}, qz[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (live) {
+#pragma unroll
+                for (int o = 0; o < RRL_MAX_HITS; ++o)
+                    if (o < j) {  // pair_hit's expression for entry (h, o): cloud 1's point minus cloud 2's
+                        const float4 p1 = kp.sq[h], p2 = kp.sq[4 + o];
+                        const float dx = p1.x - p2.x, dy = p1.y - p2.y, dz = p1.z - p2.z;
+                        float sq = dx * dx;
+                        sq = sq + dy * dy;
+                        sq = sq + dz * dz;
+                        dr[o] = sq;
+                        qx[o] = p2.x; qy[o] = p2.y; qz[o] = p2.z;
+                    }
+            }
+            const int S = live ? so.s_cnt[(k - 1) * 4 + (j - 1)] : 1;
+            // (the cloud-2 lanes of a line form a quad of their own: they carry +inf rows and k = j = 0 like lanes without a line)
+            bwd_rt_math(live, side ? 0 : k, side ? 0 : j, h, dr, S, kp.q, qx, qy, qz, kp.w, xs, C, so.out_med, gl_in, acc);
+        }
+    } else {
+        __threadfence_block();  // (more than one pass: through the workspace -- MED / BCNT / INFO of the finishing wavefront too)
+        __syncthreads();
+        for (int i0 = 0; i0 < ns; i0 += 256) {  // uniform: 256 selected lines per pass, four lanes each
+            const int i = i0 + (tid >> 2);
+            const int li = i < ns ? a.sel[(size_t)b * a.L + i] : -1;
+            bwd_rt_line(li, tid & 3, b, a.L, a.N, a.kj, a.hs1, a.w1, a.Q1, a.Q2, a.D, a.med, a.bcnt, a.info, a.grad_loss, a.src, acc, bs);
+        }
     }
 #pragma unroll
     for (int q = 0; q < 12; ++q) acc[q] = wave_sum(acc[q]);
@@ -2662,11 +2803,6 @@ __global__ __launch_bounds__(1024) void pair_reduce_bwd_kernel(const PairArgs pa
         if (tid < 9 && a.transpose_r) o = (tid % 3) * 3 + tid / 3;
         if (tid < 9) atomicAdd(&a.gR[b * 9 + o], v); else atomicAdd(&a.gt[b * 3 + (tid - 9)], v);  // (zero on entry)
         if (a.payload) atomicAdd(&a.payload[2 + o], v);
-    }
-    if (tid == 64 && a.payload && a.info[b * 4] > 0) {  // payload[0 .. 1] as in the tail kernel (order-independent)
-        TailArgs t;
-        t.payload = a.payload; t.mctl = a.mctl;
-        tail_payload(t, a.loss[b]);
     }
 }
 
