@@ -285,7 +285,7 @@ int rrl_registration_backward(const float *src, const float *R, const float *tri
 /* Forward + direct backward of the fused training op in ONE call -- what a training step does when dL/dloss is
  * known up front (grad_loss [B], usually ones): rpm/Train_RPM.py:226-259, dcp/Train_DCP.py:246-270 compute the loss
  * and call backward() right away.  Same arguments and results as rrl_registration_forward_cached followed by
- * rrl_registration_backward(grad_src = NULL); where the tail kernel serves the shape (auto mode: 2 .. 16 line tiles per
+ * rrl_registration_backward(grad_src = NULL); where the tail kernel serves the shape (auto mode: 2 .. 32 line tiles per
  * sample and B x tiles <= 256; not in deterministic mode) the backward rides in the reduce's launch -- 4 launches per
  * step with prepared orders (rrl_opts), 5 without -- and the two kernels' chains of dependent loads overlap; a single
  * tile of lines (L <= 1024) is finished by one workgroup per sample (per-line stage + reduce + backward); every other
@@ -339,7 +339,7 @@ int rrl_registration_step_ex(const float *src, const float *R, const float *t, c
  * (code/loss.py:458-463, rpm/Train_RPM.py:205-212): points1 = tri1 R + t (x R^T + t when transpose_r), kept in the
  * workspace field TRI1; R == t == NULL: points1 = tri1 as given.  grad_loss [B] = dL/dloss (usually ones),
  * grad_tri1 [B][N][9] = dL/dpoints1 -- cleared by the call's first launch, accumulated by float atomics like
- * rrl_loss_backward --, grad_tri2 [B][M][9] or NULL.  Where the tail kernel serves the shape (2 .. 16 line tiles,
+ * rrl_loss_backward --, grad_tri2 [B][M][9] or NULL.  Where the tail kernel serves the shape (2 .. 32 line tiles,
  * B x tiles <= 256) and grad_tri2 == NULL the scatter rides in the reduce's launch: 4 launches per step with prepared
  * orders (opts), 5 without; otherwise forward + the scatter kernel of rrl_loss_backward.  Loss, median, bucket sums
  * bit-identical to rrl_loss_forward / rrl_registration_forward; gradients equal rrl_loss_backward's to the rounding of
@@ -418,7 +418,7 @@ int rrl_loss_reduce_rows(const float *rows16, const uint8_t *kj, int nrows, int3
  *   tail     loss_tail_kernel: no exchange (every workgroup streams its sample's dense D-value lists and selects the
  *            median itself, one ticket, no spin), and the direct / scatter backward can ride in the same launch.
  *            Legal for <= 32 tiles per sample and B x tiles <= 256.
- * mode 0 (auto): tail where a backward rides along (rrl_registration_step, rrl_loss_step), the sample has 2 .. 16 tiles
+ * mode 0 (auto): tail where a backward rides along (rrl_registration_step, rrl_loss_step), the sample has 2 .. 32 tiles
  *   and B x tiles <= 256; else xchg for >= 2 tiles within its capacity; else single.  A forward alone never takes the
  *   tail kernel in auto mode (as a reduce alone it is 1.7 us slower than xchg).  A single tile of lines (L <= 1024) is
  *   finished by one workgroup per sample together with the per-line stage (and the direct backward).

@@ -1877,12 +1877,12 @@ def test_step_in_one_call_at_the_bench_shape(L):
     (2, 1200, 1000, 6000, True, True), (2, 1200, 1000, 6000, True, False), (3, 700, 900, 3000, False, True),
     (1, 900, 800, 800, True, True), (20, 300, 260, 8000, True, True), (1, 5000, 4100, 2500, True, True),
     (40, 200, 180, 8000, True, True), (3, 700, 900, 1000, False, False), (4, 2000, 2000, 1024, True, True),
-    (2, 16384, 16384, 512, True, True)])
+    (2, 16384, 16384, 512, True, True), (1, 1024, 1024, 20000, True, True), (2, 900, 800, 32768, True, False)])
 def test_loss_step_equals_the_autograd_chain(L, B, n, m, nl, with_pose, prepared):
     """rrl_loss_step_ex (ops.LossStep): SURVEY 8(d)'s definition -- rigid apply + loss + backward to points1.grad -- in one
     C call.  Against the drop-in autograd chain rigid_apply -> intersection_loss -> backward: loss / median / info /
     bucket sums bit for bit, points1.grad to the rounding of the scatter's float atomics (1e-6 of the largest entry),
-    the same rows non-zero.  Shapes: the tail kernel carrying the scatter (2 .. 16 tiles), a single tile of lines (the
+    the same rows non-zero.  Shapes: the tail kernel carrying the scatter (2 .. 32 tiles), a single tile of lines (the
     single-tile kernel carrying it: pair_reduce_scatter_kernel; with / without a pose, cold / prepared, C5's shape), a
     grid at the edge of the tail kernel's (B x tiles = 160) and beyond it (320 > 256: exchange reduce + scatter launch), a chunked large cloud; without a pose (R = t = None); cold and
     prepared builds; a non-unit dL/dloss; repeated calls (the records launch clears the gradient each time)."""

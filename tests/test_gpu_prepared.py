@@ -406,7 +406,7 @@ def test_cloud_order_equals_its_host_twin(L, n):
                                                      (8, 4096, 4096, 10000, True, True)])
 def test_loss_step_payload(L, B, n, m, nl, prepared, pose):
     """ops.LossStep(want_payload=True) (include/rrl.h rrl_opts.payload): after every step .payload ==
-    [sum of the valid losses, #valid, 0 x 12] -- riding in the reduce's launch (2 .. 16 line tiles) or in the single-tile kernel
+    [sum of the valid losses, #valid, 0 x 12] -- riding in the reduce's launch (2 .. 32 line tiles) or in the single-tile kernel
     (one tile of lines), with and without the rigid apply in front, on the first (building) and on later
     (kept-target) calls -- and the step's loss / gradient are those of the step without a payload, bit for bit / to the
     rounding of the scatter's atomics."""
