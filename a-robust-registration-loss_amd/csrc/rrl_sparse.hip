@@ -1455,7 +1455,7 @@ __device__ __forceinline__ void tail_payload(const TailArgs &a, float lv) {
 //  SCATTER: the backward goes to points1.grad (rrl_loss_step) instead of (dR, dt) -- a template parameter, so that neither
 //  instantiation carries the other's registers (source coordinates and 12 sums / the 9-float gradient row).
 template <bool SCATTER>
-__global__ __launch_bounds__(TAIL_LANES) __attribute__((amdgpu_waves_per_eu(4, 8))) void loss_tail_kernel(const TailArgs a) {
+__device__ __forceinline__ void tail_body(const TailArgs &a, int tile_in, int b_in, int sub) {  // (tile, sample, sub): the workgroup's place
     __shared__ unsigned s_vals[MCAND_CAP];  // the bin's values (usual route) / histogram of the streaming passes
     __shared__ unsigned s_wtot[TAIL_LANES / 64];
     __shared__ unsigned s_pick[3];          // bin, rank inside it, its population
@@ -1472,8 +1472,8 @@ __global__ __launch_bounds__(TAIL_LANES) __attribute__((amdgpu_waves_per_eu(4, 8
     constexpr int NW = TAIL_LANES / 64, BPL = 2048 / TAIL_LANES;  // wavefronts; histogram bins per lane
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // (sub is the SLOW grid index: the workgroups that certainly have lines are dispatched first)
-    const int nblk = a.nblk, sub = blockIdx.z;
-    int tile = blockIdx.x, b = blockIdx.y;
+    const int nblk = a.nblk;
+    int tile = tile_in, b = b_in;
     if (a.xcd_align) xcd_sample_of(tile + nblk * b, nblk, tile, b);  // (uniform; every sub-grid of nblk x B workgroups is a multiple of 8)
     const size_t Lp = (size_t)nblk * 1024;
     uint32_t *ctl = a.mctl + (size_t)b * 64;
@@ -1945,6 +1945,37 @@ __global__ __launch_bounds__(TAIL_LANES) __attribute__((amdgpu_waves_per_eu(4, 8
     finish();
 }
 
+template <bool SCATTER>
+__global__ __launch_bounds__(TAIL_LANES) __attribute__((amdgpu_waves_per_eu(4, 8))) void loss_tail_kernel(const TailArgs a) {
+    tail_body<SCATTER>(a, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z);
+}
+
+// ... with the NEXT epoch's sampler write pass riding along (rrl_demo_epoch: RrlWriteRider; bwd_write_kernel does the same for
+// the direct backward's own launch): the first gx * gy workgroups of a 1-D grid run one (tile of 1024 candidates, round) of the
+// write pass each, the rest are the tail kernel's (tile fastest, sub slowest, as in its own grid).  The write pass touches the
+// sampler's buffers and the line buffer only -- nothing the tail kernel reads.
+struct WriteKArgs {
+    unsigned long long *rng_state;
+    const float *r, *centers;
+    const unsigned long long *accept;
+    float *lines;
+    int32_t *filled;
+    int n, rounds, gx, gy;
+};
+template <bool SCATTER>
+__global__ __launch_bounds__(TAIL_LANES) __attribute__((amdgpu_waves_per_eu(4, 8))) void tail_write_kernel(const TailArgs a,
+                                                                                                          const WriteKArgs c) {
+    extern __shared__ int s_tc_dyn[];  // the write pass's tile counts [rounds][tiles]
+    const int nwrite = c.gx * c.gy, lin = (int)blockIdx.x;
+    if (lin < nwrite) {  // uniform per workgroup
+        sample_write_body<TAIL_LANES>(s_tc_dyn, nullptr, c.rng_state, c.r, c.centers, nullptr, nullptr, c.accept, c.lines, c.filled, 1,
+                                      c.n, c.rounds, lin % c.gx, lin / c.gx, 0, c.gx, (unsigned)nwrite);
+        return;
+    }
+    const int l2 = lin - nwrite, per = a.nblk * a.B;
+    tail_body<SCATTER>(a, l2 % a.nblk, (l2 / a.nblk) % a.B, l2 / per);
+}
+
 // K2 + K3 + K4 in ONE launch when a sample has a single tile of lines (L <= 1024) and the samples are not pooled:
 // the workgroup that ran the per-line stage of sample b owns everything the reduce of sample b reads, so it
 // simply carries on (a launch and the reduce's first load round less: small-L shapes such as C5 are nothing
@@ -2121,7 +2152,20 @@ static int loss_reduce_impl(void *ws, size_t ws_bytes, float *loss, int B, int N
         t.grad_tri1 = tb ? tb->grad_tri1 : nullptr;
         t.Bt = o.problems;
         t.xcd_align = B % 8 == 0 && xcd_align_on();
-        if (t.grad_tri1)
+        // the next epoch's sampler write pass rides along (tail_write_kernel; rrl_demo_epoch) -- when this launch carries the
+        // backward (nothing after it reads the line buffer the pass overwrites) and the ballots of THAT count pass are there
+        RrlWriteRider *wr = tb ? o.write_rider : nullptr;
+        const int wtiles = wr ? (wr->n + 1023) / 1024 : 0;
+        const bool ride = wr && (!o.count_rider || o.count_rider->done) && B == 1 && wr->n > 0 && wr->rounds > 0 &&
+                          (long)wtiles * wr->rounds < 512 && sizeof(int32_t) * (size_t)wr->rounds * wtiles <= 32 * 1024;
+        if (ride) {
+            const WriteKArgs wk = {wr->rng_state, wr->r, wr->centers, wr->accept, wr->lines, wr->filled, wr->n, wr->rounds, wtiles, wr->rounds};
+            const dim3 g((unsigned)(wk.gx * wk.gy + nblk * B * TAIL_SUBS));
+            const size_t lds = sizeof(int32_t) * (size_t)wk.rounds * wk.gx;
+            if (t.grad_tri1) hipLaunchKernelGGL(tail_write_kernel<true>, g, dim3(TAIL_LANES), lds, (hipStream_t)stream, t, wk);
+            else hipLaunchKernelGGL(tail_write_kernel<false>, g, dim3(TAIL_LANES), lds, (hipStream_t)stream, t, wk);
+            wr->done = 1;
+        } else if (t.grad_tri1)
             hipLaunchKernelGGL(loss_tail_kernel<true>, dim3((unsigned)nblk, (unsigned)B, TAIL_SUBS), dim3(TAIL_LANES), 0,
                                (hipStream_t)stream, t);
         else
@@ -2657,14 +2701,6 @@ struct BwdKArgs {
     int B, N, L, transpose_r;
     float *part;
     int gx;
-};
-struct WriteKArgs {
-    unsigned long long *rng_state;
-    const float *r, *centers;
-    const unsigned long long *accept;
-    float *lines;
-    int32_t *filled;
-    int n, rounds, gx, gy;
 };
 template <bool DET>
 __global__ __launch_bounds__(256) void bwd_write_kernel(const BwdKArgs a, const WriteKArgs c) {
