@@ -202,6 +202,9 @@ struct SampleCountLds {
     unsigned char flag[1024];
     int wave_cnt[16];
 };
+#ifndef STAMPC
+#define STAMPC(i)
+#endif
 __device__ __forceinline__ void sample_count_body(
     SampleCountLds &lds_, const float *__restrict__ rands, const unsigned long long *__restrict__ rng_state,
     const float *__restrict__ r, const float *__restrict__ centers,
@@ -216,6 +219,7 @@ __device__ __forceinline__ void sample_count_body(
     int (&wave_cnt)[16] = lds_.wave_cnt;
     const int tile = bx, rd = rd0 + by, b = bz;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (wave == 0) STAMPC(0);
     if (rd0 > 0) {
         // Rounds rd0.. run as a second launch: the reference skips every round once more than n
         // candidates were accepted (code/loss.py:368-369), and the earlier launch's ballots say
@@ -260,6 +264,7 @@ __device__ __forceinline__ void sample_count_body(
             pre = !prefilter || (slab_maybe(g.bb1, ln, inv) && slab_maybe(g.bb2, ln, inv));
         }
         const unsigned long long m = __ballot(pre);
+        if (wave == 0) STAMPC(1);
         if (lane == 0) wave_cnt[wave] = __popcll(m);
         hits[tid] = 0;
         flag[tid] = 0;
@@ -273,11 +278,13 @@ __device__ __forceinline__ void sample_count_body(
             for (int c = 0; c < 6; ++c) lines_c[k][c] = ln[c];
         }
         __syncthreads();
+        if (wave == 0) STAMPC(2);
         for (int t = tid; t < total * 24; t += 1024) {
             const int k = t / 24, f = t % 24;
             if (face_hit(faces[f], lines_c[k])) atomicOr(&hits[k], f < 12 ? 1u : 2u);
         }
         __syncthreads();
+        if (wave == 0) STAMPC(3);
         if (tid < total && hits[tid] == 3u) flag[surv[tid]] = 1;
         __syncthreads();
         ok = flag[tid] != 0;
@@ -285,6 +292,7 @@ __device__ __forceinline__ void sample_count_body(
     const unsigned long long mask = __ballot(ok);
     // ballot of wave w of tile t sits at [b][rd][t][w]
     if (lane == 0) accept[(((size_t)b * rounds + rd) * gx + tile) * 16 + wave] = mask;
+    if (wave == 0) STAMPC(4);
 }
 
 // The WRITE pass of one (tile of 1024 candidates, round, sample) by a workgroup of LANES lanes (1024: sample_write_kernel;

@@ -9,7 +9,6 @@
 #include <string.h>
 
 #include "rrl_ws.h"
-#include "rrl_sampler.h"  // the sampler's count pass as a device function: pair_count_kernel carries it
 
 #define FIX_SHIFT 40  // bucket sums in 2^-40 fixed point: order-independent, bit-deterministic
 
@@ -36,11 +35,13 @@ extern "C" int rrl_debug_pstamps(unsigned long long *out, int clear) {
     if (clear) { void *p_ = nullptr; if (hipGetSymbolAddress(&p_, HIP_SYMBOL(g_pstamps)) != hipSuccess) return -1; return hipMemset(p_, 0, sizeof(unsigned long long) * 8 * 2048) == hipSuccess ? 0 : -1; }
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pstamps), sizeof(unsigned long long) * 8 * 2048) == hipSuccess ? 0 : -1;
 }
+#define STAMPC(i) STAMPP(i)  // (the sampler's count pass, rrl_sampler.h: stamps 6, 7 of the same table)
 #else
 #define STAMP(i)
 #define STAMPW(i)
 #define STAMPP(i)
 #endif
+#include "rrl_sampler.h"  // the sampler's count pass as a device function: pair_count_kernel carries it
 
 // LDS-only workgroup barrier: this wavefront's LDS traffic is complete, its vector-memory loads AND STORES stay in flight
 // (__syncthreads() waits for both: a barrier behind a store costs the store's acknowledgement, ~0.5 us)
