@@ -1409,7 +1409,9 @@ __global__ __launch_bounds__(256) void loss_reduce_tiled_kernel(const TiledArgs 
 #ifndef TAIL_SUBS
 #define TAIL_SUBS 4    // workgroups per tile (grid z): workgroup s takes the tile's chunks s, s + 4, ... of TAIL_LINES lines
 #endif
-#define TAIL_RPL 4     // compact rows per lane and streaming round
+#ifndef TAIL_RPL
+#define TAIL_RPL 4     // 16-byte groups of D values per lane and streaming round
+#endif
 #define MCTL_LSUM 34   // (row of sample 0, 8-byte aligned) uint64: fixed-point sum of the valid samples' losses
 
 struct TailArgs {
@@ -1455,7 +1457,9 @@ __device__ __forceinline__ void tail_payload(const TailArgs &a, float lv) {
 //  at ten tiles -- would run in two generations: measured 17 -> 23.6 us at B = 16 when an edit pushed the kernel to 132)
 //  SCATTER: the backward goes to points1.grad (rrl_loss_step) instead of (dR, dt) -- a template parameter, so that neither
 //  instantiation carries the other's registers (source coordinates and 12 sums / the 9-float gradient row).
-template <bool SCATTER>
+// RPL: 16-byte groups of D values per lane and streaming round -- 2 where 2 x (lanes per tile) groups cover a tile's list
+// (<= 10 tiles per sample: ~100 groups, a tile of ~100 selected lines holds ~50), else TAIL_RPL; chosen by the host.
+template <bool SCATTER, int RPL>
 __device__ __forceinline__ void tail_body(const TailArgs &a, int tile_in, int b_in, int sub) {  // (tile, sample, sub): the workgroup's place
     __shared__ unsigned s_vals[MCAND_CAP];  // the bin's values (usual route) / histogram of the streaming passes
     __shared__ unsigned s_wtot[TAIL_LANES / 64];
@@ -1523,9 +1527,9 @@ __device__ __forceinline__ void tail_body(const TailArgs &a, int tile_in, int b_
     const int vt = tid / LPT, vq = tid - vt * LPT;
     const bool vlane = vt < nblk;
     const float4 *__restrict__ vbase = (const float4 *)(a.vlist + ((size_t)b * nblk + (vlane ? vt : 0)) * 16384);
-    float4 vpre[TAIL_RPL];
+    float4 vpre[RPL];
 #pragma unroll
-    for (int u = 0; u < TAIL_RPL; ++u)
+    for (int u = 0; u < RPL; ++u)
         vpre[u] = vlane ? vbase[vq + LPT * u] : make_float4(-1.0f, -1.0f, -1.0f, -1.0f);
     if (sub * TAIL_LINES >= mycnt && !(tile == 0 && sub == 0)) return;  // uniform: no line for this workgroup
     bool mine_on = tid < 4 * TAIL_LINES && r < mycnt;
@@ -1653,16 +1657,16 @@ __device__ __forceinline__ void tail_body(const TailArgs &a, int tile_in, int b_
     unsigned prefix = bin << 20;
 
     // ---- every D value of the sample from the tiles' dense lists (VLIST: only the valid entries, ~2 per line instead of the
-    //      16 slots of a canonical tile; -1 pads), TAIL_RPL 16-byte groups per lane and round, LPT TAIL_RPL groups of every tile
+    //      16 slots of a canonical tile; -1 pads), RPL 16-byte groups per lane and round, LPT RPL groups of every tile
     //      per round: fn(groups) for each round; the first round's groups are the ones requested in round 1 (pre = true: the
     //      first sweep) or loaded again (a later sweep of the crowded-bin route); after_issue() runs once, when the first
     //      round of loads is in flight
     auto stream_rows = [&](bool pre, auto &&after_issue, auto &&fn) {
         bool first = true;
-        for (int g0 = 0; g0 < vmax; g0 += LPT * TAIL_RPL) {  // uniform trip count
-            float4 v[TAIL_RPL];
+        for (int g0 = 0; g0 < vmax; g0 += LPT * RPL) {  // uniform trip count
+            float4 v[RPL];
 #pragma unroll
-            for (int u = 0; u < TAIL_RPL; ++u) {
+            for (int u = 0; u < RPL; ++u) {
                 const int g = g0 + vq + LPT * u;
                 v[u] = make_float4(-1.0f, -1.0f, -1.0f, -1.0f);
                 if (g < myvc) v[u] = pre && g0 == 0 ? vpre[u] : vbase[g];
@@ -1674,7 +1678,7 @@ __device__ __forceinline__ void tail_body(const TailArgs &a, int tile_in, int b_
     };
     auto each16 = [](const float4 *v, auto &&g) {
 #pragma unroll
-        for (int u = 0; u < TAIL_RPL; ++u) {
+        for (int u = 0; u < RPL; ++u) {
             g(__float_as_uint(v[u].x)); g(__float_as_uint(v[u].y));
             g(__float_as_uint(v[u].z)); g(__float_as_uint(v[u].w));
         }
@@ -1946,9 +1950,9 @@ __device__ __forceinline__ void tail_body(const TailArgs &a, int tile_in, int b_
     finish();
 }
 
-template <bool SCATTER>
+template <bool SCATTER, int RPL>
 __global__ __launch_bounds__(TAIL_LANES) __attribute__((amdgpu_waves_per_eu(4, 8))) void loss_tail_kernel(const TailArgs a) {
-    tail_body<SCATTER>(a, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z);
+    tail_body<SCATTER, RPL>(a, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z);
 }
 
 // ... with the NEXT epoch's sampler write pass riding along (rrl_demo_epoch: RrlWriteRider; bwd_write_kernel does the same for
@@ -1974,7 +1978,7 @@ __global__ __launch_bounds__(TAIL_LANES) __attribute__((amdgpu_waves_per_eu(4, 8
         return;
     }
     const int l2 = lin - nwrite, per = a.nblk * a.B;
-    tail_body<SCATTER>(a, l2 % a.nblk, (l2 / a.nblk) % a.B, l2 / per);
+    tail_body<SCATTER, TAIL_RPL>(a, l2 % a.nblk, (l2 / a.nblk) % a.B, l2 / per);
 }
 
 // K2 + K3 + K4 in ONE launch when a sample has a single tile of lines (L <= 1024) and the samples are not pooled:
@@ -2166,12 +2170,14 @@ static int loss_reduce_impl(void *ws, size_t ws_bytes, float *loss, int B, int N
             if (t.grad_tri1) hipLaunchKernelGGL(tail_write_kernel<true>, g, dim3(TAIL_LANES), lds, (hipStream_t)stream, t, wk);
             else hipLaunchKernelGGL(tail_write_kernel<false>, g, dim3(TAIL_LANES), lds, (hipStream_t)stream, t, wk);
             wr->done = 1;
-        } else if (t.grad_tri1)
-            hipLaunchKernelGGL(loss_tail_kernel<true>, dim3((unsigned)nblk, (unsigned)B, TAIL_SUBS), dim3(TAIL_LANES), 0,
-                               (hipStream_t)stream, t);
-        else
-            hipLaunchKernelGGL(loss_tail_kernel<false>, dim3((unsigned)nblk, (unsigned)B, TAIL_SUBS), dim3(TAIL_LANES), 0,
-                               (hipStream_t)stream, t);
+        } else {
+            const dim3 g((unsigned)nblk, (unsigned)B, TAIL_SUBS);
+            const bool two = TAIL_LANES / nblk >= 48;  // (see tail_body: groups per lane and round)
+#define RRL_TAIL(S_, R_) hipLaunchKernelGGL((loss_tail_kernel<S_, R_>), g, dim3(TAIL_LANES), 0, (hipStream_t)stream, t)
+            if (t.grad_tri1) { if (two) RRL_TAIL(true, 2); else RRL_TAIL(true, TAIL_RPL); }
+            else { if (two) RRL_TAIL(false, 2); else RRL_TAIL(false, TAIL_RPL); }
+#undef RRL_TAIL
+        }
         RRL_LAUNCH_CHECK();
         if (bwd_done) *bwd_done = tb != nullptr;
         return 0;
