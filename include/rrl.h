@@ -341,7 +341,8 @@ int rrl_registration_step_ex(const float *src, const float *R, const float *t, c
  * grad_tri1 [B][N][9] = dL/dpoints1 -- cleared by the call's first launch, accumulated by float atomics like
  * rrl_loss_backward --, grad_tri2 [B][M][9] or NULL.  Where the tail kernel serves the shape (2 .. 32 line tiles,
  * B x tiles <= 256) and grad_tri2 == NULL the scatter rides in the reduce's launch: 4 launches per step with prepared
- * orders (opts), 5 without; otherwise forward + the scatter kernel of rrl_loss_backward.  Loss, median, bucket sums
+ * orders (opts), 5 without; a single tile of lines (L <= 1024) is finished by one workgroup per sample (per-line stage +
+ * reduce + scatter, one launch: 3 / 4 per step); otherwise forward + the scatter kernel of rrl_loss_backward.  Loss, median, bucket sums
  * bit-identical to rrl_loss_forward / rrl_registration_forward; gradients equal rrl_loss_backward's to the rounding of
  * the atomics.  pool semantics: independent samples (pool = 0). */
 int rrl_loss_step_ex(const float *tri1, const float *R, const float *t, const float *tri2, const float *line,
@@ -420,7 +421,7 @@ int rrl_loss_reduce_rows(const float *rows16, const uint8_t *kj, int nrows, int3
  *            Legal for <= 32 tiles per sample and B x tiles <= 256.
  * mode 0 (auto): tail where a backward rides along (rrl_registration_step, rrl_loss_step), the sample has 2 .. 32 tiles
  *   and B x tiles <= 256; else xchg for >= 2 tiles within its capacity; else single.  A forward alone never takes the
- *   tail kernel in auto mode (as a reduce alone it is 1.7 us slower than xchg).  A single tile of lines (L <= 1024) is
+ *   tail kernel in auto mode (as a reduce alone it is within +-1 % of xchg: the per-line stage then writes the value lists).  A single tile of lines (L <= 1024) is
  *   finished by one workgroup per sample together with the per-line stage (and the direct backward).
  * mode 1: single everywhere.  mode 2 ("tiled"): tail wherever it is legal (also forward only, also one tile), xchg
  * beyond, else single.  mode 3 ("xchg"): xchg wherever it is legal (also one tile), else single.
