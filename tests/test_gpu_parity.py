@@ -1625,23 +1625,25 @@ def test_tail_kernel_reports_a_missing_value_list(L):
         ops.set_reduce_mode("auto")
 
 
-@pytest.mark.parametrize("case", ["batch", "dense_tiles", "long_lists", "one_tile", "one_tile_forced", "empty_sample"])
+@pytest.mark.parametrize("case", ["batch", "dense_tiles", "long_lists", "one_tile", "one_tile_small", "one_tile_dense",
+                                  "one_tile_forced", "empty_sample"])
 def test_step_in_one_call_equals_forward_then_backward(L, case):
     """rrl_registration_step (the direct backward inside the tail kernel's launch) against rrl_registration_forward +
     rrl_registration_backward: loss, median, info, bucket sums bit for bit; dR, dt, payload to the rounding of their float
     atomics -- a batch with 3-5 line tiles per sample, tiles with more than 256 selected lines (the kernel's second
     pass over a tile, and the crowded-bin route of the median), value lists longer than one streaming round
     of the kernel (32 tiles per sample), a single tile (per-line stage + reduce + backward by one workgroup per sample: the
-    C5 route; and with the tail kernel forced), a sample whose lines hit nothing; with and without payload,
+    C5 route -- with more than 128 selected lines (through the workspace), with fewer (round 5: from the per-line stage's
+    registers and LDS, SoloReduce), with ~1000 near-identical ones; and with the tail kernel forced), a sample whose lines hit nothing; with and without payload,
     both R layouts, non-unit dL/dloss."""
     from rrl_hip import ops, synth
     from LieAlgebra import se3
     B = 3
-    nl = {"batch": 4500, "dense_tiles": 2600, "long_lists": 32000, "one_tile": 1000, "one_tile_forced": 900,
-          "empty_sample": 3000}[case]
+    nl = {"batch": 4500, "dense_tiles": 2600, "long_lists": 32000, "one_tile": 1000, "one_tile_small": 600,
+          "one_tile_dense": 1000, "one_tile_forced": 900, "empty_sample": 3000}[case]
     gen = torch.Generator().manual_seed(2)
     R, T = se3.exp3(0.03 * torch.randn(B, 6, generator=gen))
-    if case == "dense_tiles":  # two tiny triangles per cloud, every line through the first: ~1000 selected lines per tile,
+    if case in ("dense_tiles", "one_tile_dense"):  # two tiny triangles per cloud, every line through the first: ~1000 selected lines per tile,
         rng = np.random.default_rng(5)  # near-identical D values (the crowded-bin route of the median) -- no motion
         base = np.array([[0.0, 0.0, 0.0, 0.05, 0.0, 0.0, 0.0, 0.05, 0.0]], np.float32)
         t1 = np.concatenate([base, base + np.float32(3.0)]).astype(np.float32)
@@ -1686,6 +1688,12 @@ def test_step_in_one_call_equals_forward_then_backward(L, case):
             assert nsel[0] > 0 and (case != "empty_sample" or nsel[1] == 0)
             if case == "dense_tiles":
                 assert int(rs.st.blkcnt[:B * 3].max()) > 256
+            if case == "one_tile_dense":
+                assert int(rs.st.blkcnt[:B].max()) > 256
+            if case == "one_tile_small":
+                assert 0 < int(nsel.max()) <= 128
+            if case == "one_tile":
+                assert int(nsel.max()) > 128
             if case == "long_lists":  # more than the 8192 values one streaming round of the tail kernel covers, and a median
                 assert int(rs.st.vlcnt[:B * 32].reshape(B, 32).sum(1).max()) > 8192  # bin that is NOT crowded (the usual route)
                 assert int(rs.st.mhist.max()) <= 2048
