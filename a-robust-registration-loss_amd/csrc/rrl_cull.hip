@@ -479,6 +479,7 @@ __global__ __launch_bounds__(1024) void tri_sort_kernel(const BuildArgs a) {
     auto pad = [](int s) { return s + (s >> 4); };
     __shared__ int s_cb[2];          // the cells that straddle p0 / p1 (-1: the boundary falls between two cells)
     __shared__ unsigned s_bw[2][64]; // their records per (pass k, wavefront): exclusive prefix in index order
+    if (tid < 64) STAMPR(0);
     if (tid < 2) s_cb[tid] = -1;
     if (a.zwords != nullptr && blockIdx.x == 0 && blockIdx.y == 0)  // the Chamfer walk's arrival counters (next launch)
         for (int i = tid; i < a.nzwords; i += 1024) a.zwords[i] = 0u;
@@ -572,6 +573,7 @@ __global__ __launch_bounds__(1024) void tri_sort_kernel(const BuildArgs a) {
     }
     for (int i = tid; i < SORT_CELLS; i += 1024) hist[i] = 0;
     __syncthreads();
+    if (tid < 64) STAMPR(1);
 #if defined(SORT_STOP) && SORT_STOP == 1  // timing experiments only
     return;
 #endif
@@ -603,6 +605,7 @@ __global__ __launch_bounds__(1024) void tri_sort_kernel(const BuildArgs a) {
     for (int k = 0; k < NPT; ++k)
         if (tid + 1024 * k < n) { cell[k] = cell_of(rec[k]); atomicAdd(&hist[cell[k]], 1u); }
     __syncthreads();
+    if (tid < 64) STAMPR(2);
 #if defined(SORT_STOP) && SORT_STOP == 2  // timing experiments only
     return;
 #endif
@@ -626,6 +629,7 @@ __global__ __launch_bounds__(1024) void tri_sort_kernel(const BuildArgs a) {
         }
     }
     __syncthreads();
+    if (tid < 64) STAMPR(3);
 #if defined(SORT_STOP) && SORT_STOP == 3  // timing experiments only
     return;
 #endif
@@ -676,6 +680,7 @@ __global__ __launch_bounds__(1024) void tri_sort_kernel(const BuildArgs a) {
         sidx[s - p0] = 0;
     }
     __syncthreads();
+    if (tid < 64) STAMPR(4);
 #if defined(SORT_STOP) && SORT_STOP == 4  // timing experiments only
     return;
 #endif
@@ -683,12 +688,14 @@ __global__ __launch_bounds__(1024) void tri_sort_kernel(const BuildArgs a) {
         p0s[s] = srec[pad(s - p0)];
         idx[s] = sidx[s - p0];
     }
+    if (tid < 64) STAMPR(5);
 #if defined(SORT_STOP) && SORT_STOP == 5
     return;
 #endif
     // ---- sphere tree: one lane per half of 8 records
     for (int hh = 2 * SGG * S0 + tid; hh < 2 * SGG * S1; hh += 1024)
         half_tree([&](int s_) { return srec[pad(s_ - p0)]; }, hh, n, tree);
+    if (tid < 64) STAMPR(6);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -19,11 +19,13 @@ for b, p in enumerate(prs):
 ln = torch.stack(ln)
 R = torch.eye(3, device="cuda").repeat(B, 1, 1); t = torch.zeros(B, 3, device="cuda")
 Step = ops.LossStep if os.environ.get("RRL_STEP", "loss") == "loss" else ops.RegistrationStep
-rs = Step(src, tar, L, transpose_r=True)
+rs = Step(src, tar, L, transpose_r=True, prepared=os.environ.get("RRL_PREPARED", "1") != "0")
 lib = _lib.load()
 lib.rrl_debug_wstamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
 lib.rrl_debug_rstamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
-names = ["entry", "clearing stores issued", "order + raw row loaded, record computed", "record / tree stores issued", "stores acknowledged (barrier)", "line-maxima workgroup done"]
+names = ["entry", "clearing stores issued", "order + raw row loaded, record computed", "record / tree stores issued", "stores acknowledged (barrier)", "line-maxima workgroup done", "-"]
+if os.environ.get("RRL_PREPARED", "1") == "0":  # the cold build: the LAST launch that stamps is the cell sort (one workgroup per cloud)
+    names = ["sort: entry", "records + AABB loaded, histogram cleared", "cells tallied (LDS atomics)", "cells scanned", "records scattered (LDS)", "copied out", "tree built"]
 rows = []
 for it in range(40):
     for _ in range(3): rs(R, t, ln)
@@ -34,8 +36,8 @@ for it in range(40):
     assert lib.rrl_debug_rstamps(buf, 0) == 0
     v = np.array(list(buf), dtype=np.float64).reshape(8, 2048)
     t0 = v[0][v[0] > 0].min()
-    rows.append([((v[i][v[i] > 0] - t0) / 100.0) for i in range(6)])
-for i in range(6):
+    rows.append([((v[i][v[i] > 0] - t0) / 100.0) for i in range(7)])
+for i in range(7):
     mins = np.mean([r[i].min() for r in rows if len(r[i])]); meds = np.mean([np.median(r[i]) for r in rows if len(r[i])])
     maxs = np.mean([r[i].max() for r in rows if len(r[i])]); cnt = np.mean([len(r[i]) for r in rows])
     print(f"  {names[i]:48s} workgroups {cnt:6.1f}  first {mins:6.2f}  median {meds:6.2f}  last {maxs:6.2f} us")
