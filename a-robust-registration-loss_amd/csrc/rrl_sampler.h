@@ -269,8 +269,9 @@ __device__ __forceinline__ void sample_count_body(
         hits[tid] = 0;
         flag[tid] = 0;
         __syncthreads();
-        int woff = 0, total = 0;
-        for (int w = 0; w < 16; ++w) { woff += w < wave ? wave_cnt[w] : 0; total += wave_cnt[w]; }
+        // (every wavefront scans the 16 counts itself: one LDS read + a DPP prefix, not 16 reads per lane)
+        const int cw = lane < 16 ? wave_cnt[lane] : 0, iw = wave_incl_scan(cw);
+        const int woff = __builtin_amdgcn_readlane(iw - cw, wave), total = __builtin_amdgcn_readlane(iw, 15);
         if (pre) {
             const int k = woff + __popcll(m & ((1ull << lane) - 1ull));
             surv[k] = (unsigned short)tid;

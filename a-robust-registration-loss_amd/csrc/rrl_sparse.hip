@@ -1059,6 +1059,7 @@ struct TiledArgs {
     int B, nblk, s_m, s_n, e_m, e_n;
     unsigned spin_limit;  // polls before a waiting workgroup gives up (rrl_set_spin_limit: tests set 0)
     int xcd_align;        // sample b's workgroups on XCD b % 8 (xcd_sample_of; B % 8 == 0): its in-launch hand-offs stay in one L2
+    float *payload;       // != NULL (rrl_loss_step_ex): the sample's last workgroup adds its loss to payload[0 .. 1] (tail_payload)
 };
 
 // Hand-offs between the workgroups of this launch (candidate list + TICK1, MEDRDY) are bounded spins.  A workgroup whose
@@ -1067,6 +1068,7 @@ struct TiledArgs {
 // median from all tiles' values, Welsch sums over all its lines, the single-workgroup kernel's arithmetic on the same
 // multiset -- so the result is bit-identical to the undisturbed one instead of NaN (round 3), at the cost of one
 // workgroup's serial pass over ~1000 lines.  STATUS[2] counts such samples.
+__device__ __forceinline__ void tiled_payload(float *payload, uint32_t *mctl, float lv);  // (= tail_payload, defined with the tail kernel)
 __global__ __launch_bounds__(256) void loss_reduce_tiled_kernel(const TiledArgs a) {
     __shared__ unsigned s_vals[MCAND_CAP];  // the bin's values (usual route) / histogram of the streaming passes
     __shared__ unsigned s_wtot[4];
@@ -1365,14 +1367,16 @@ __global__ __launch_bounds__(256) void loss_reduce_tiled_kernel(const TiledArgs 
         const float acc = f.acc;
         const int C = f.C, nselected = f.nselected, nvalues = f.nvalues;
         const bool bad = repair ? (s_flag[2] & 1u) != 0u : (s_flag[2] & 2u) != 0u;  // a non-finite Welsch term (median 0)
+        const float lv = bad ? __builtin_nanf("") : (C ? acc / (float)C : 0.0f);  // code/loss.py:230
         a.med_out[b] = med;
-        a.loss[b] = bad ? __builtin_nanf("") : (C ? acc / (float)C : 0.0f);  // code/loss.py:230
+        a.loss[b] = lv;
         a.info[b * 4 + 0] = C;
         a.info[b * 4 + 1] = nselected;
         a.info[b * 4 + 2] = nvalues;
         a.info[b * 4 + 3] = st0;
         st_agent(&ctl[MCTL_CURSOR], 0u); st_agent(&ctl[MCTL_TICK1], 0u); st_agent(&ctl[MCTL_TICK2], 0u);
         st_agent(&ctl[MCTL_MEDRDY], 0u); st_agent(&ctl[MCTL_BAD], 0u); st_agent(&ctl[MCTL_ERR], 0u);
+        if (a.payload && C > 0) tiled_payload(a.payload, a.mctl, lv);  // (order-independent: tail_payload)
     }
 }
 
@@ -1451,6 +1455,12 @@ __device__ __forceinline__ void tail_payload(const TailArgs &a, float lv) {
                                                           __HIP_MEMORY_SCOPE_AGENT);
     const float tot = (float)((double)(old + mine) * (1.0 / (double)(1ll << FIX_SHIFT)));
     atomicMax((unsigned *)&a.payload[0], __float_as_uint(tot));
+}
+
+__device__ __forceinline__ void tiled_payload(float *payload, uint32_t *mctl, float lv) {
+    TailArgs t;
+    t.payload = payload; t.mctl = mctl;
+    tail_payload(t, lv);
 }
 
 // (>= 4 wavefronts per SIMD = two 512-lane workgroups per CU: beyond 128 VGPRs a grid of more than 256 live workgroups -- B >= 16
@@ -2042,15 +2052,16 @@ RrlCall rrl_resolve_opts(const rrl_opts *p) {
     else rrl_default_scan_counters(&o.counters, &o.counter_rows);
     o.rider = v.chamfer;  // (done is the caller's to clear; the scan's launcher sets it when the walk rides along)
     o.payload = v.payload;
+    o.payload_in_reduce = 0;
     o.problems = v.problems > 0 ? v.problems : 0;
     return o;
 }
 // Which reduce kernel: 0 one workgroup per sample, 1 tiled with the candidate exchange (loss_reduce_tiled_kernel), 2 the
 // tail kernel (no exchange: every workgroup streams its sample's dense value lists; one 512-lane workgroup or two
-// per compute unit, so it serves the small, latency-bound grids: B x tiles <= 256, <= 16 tiles per sample).
+// per compute unit, so it serves the small, latency-bound grids: B x tiles <= 256, <= 32 tiles per sample).
 // mode 0 (auto): the tail kernel where the direct backward rides along (with_bwd: rrl_registration_step -- measured
-// -1.9 .. -3.4 us per step at C2 / L = 4096 / C4; as a reduce alone it is 1.7 us SLOWER than the exchange kernel, and at
-// the demo's shape, one sample of 20 tiles, the two are even), else the exchange kernel for >= 2 tiles while the grid
+// -1.9 .. -3.4 us per step at C2 / L = 4096 / C4, round 5b: -6 us at the demo's 20 tiles; as a reduce alone it is within
+// +-1 % of the exchange kernel), else the exchange kernel for >= 2 tiles while the grid
 // is co-resident, else the single workgroup; 1: single; 2 ("tiled"): the tail kernel wherever it is legal (also forward
 // only, also one tile: tests), exchange beyond; 3 ("xchg"): the exchange kernel wherever it is legal.
 // Test hook: polls a waiting workgroup of the exchange reduce makes before it gives up (default 2^18, ~0.3 s); 0 makes
@@ -2192,6 +2203,7 @@ static int loss_reduce_impl(void *ws, size_t ws_bytes, float *loss, int B, int N
         t.B = B; t.nblk = nblk; t.s_m = s_m; t.s_n = s_n; t.e_m = e_m; t.e_n = e_n;
         t.spin_limit = spin_limit();
         t.xcd_align = B % 8 == 0 && xcd_align_on();
+        t.payload = o.payload_in_reduce ? o.payload : nullptr;
         hipLaunchKernelGGL(loss_reduce_tiled_kernel, dim3((unsigned)nblk, (unsigned)B), dim3(256), 0, (hipStream_t)stream, t);
         RRL_LAUNCH_CHECK();
         return 0;
@@ -3191,6 +3203,9 @@ extern "C" int rrl_loss_step_ex(const float *tri1, const float *R, const float *
     // (the tail kernel, or -- one tile of lines per sample -- the single-tile kernel: loss_forward_impl's own conditions)
     const bool ride = B > 0 && L > 0 && !grad_tri2 &&
                       (L > 1024 ? reduce_kind(o.reduce_mode, B, nblk, 0, true) == 2 : o.reduce_mode < 2);
+    // no riding backward, but the exchange reduce serves the call: its last arrivers add the payload (no payload launch)
+    const bool pay_in_reduce = payload && !ride && B > 0 && L > 1024 && reduce_kind(o.reduce_mode, B, nblk, 0, false) == 1;
+    o.payload_in_reduce = pay_in_reduce ? 1 : 0;
     const TailBwd tb = {grad_loss, nullptr, nullptr, nullptr, payload, 0, grad_tri1};
     bool done = false;
     int rc = loss_forward_impl(p1, tri2, line, ws, ws_bytes, loss, B, N, M, L, s_m, s_n, e_m, e_n, 0, mode, chunk, target_ws,
@@ -3200,7 +3215,7 @@ extern "C" int rrl_loss_step_ex(const float *tri1, const float *R, const float *
     //  cloud launches nothing: clear here)
     if (B == 0 || (N == 0 && M == 0)) return rrl_fill(grad_tri1, 0u, o.clear_bytes, (hipStream_t)stream);
     rc = loss_backward_impl(p1, tri2, ws, ws_bytes, grad_loss, grad_tri1, grad_tri2, B, N, M, L, 0, false, stream);
-    if (rc || !payload || L <= 0) return rc;
+    if (rc || !payload || L <= 0 || pay_in_reduce) return rc;
     return rrl_shard_payload(loss, ws, ws_bytes, nullptr, nullptr, payload, B, N, M, L, stream);
 }
 

@@ -132,6 +132,7 @@ struct RrlCall {
     RrlWriteRider *write_rider;  // (internal) see RrlWriteRider
     int problems;         // rrl_opts.problems (multi-pose evaluation): 0, or Bt < B with B % Bt == 0
     float *payload;       // rrl_opts.payload (rrl_loss_step_ex): [sum of valid losses, #valid, 0 x 12], or NULL
+    int payload_in_reduce;  // (internal) rrl_loss_step_ex: the tiled reduce's last arrivers add payload[0 .. 1] (no payload launch)
     const void *tar_ws;   // (internal) the workspace that holds cloud 2's records when the target's scan is carried over
                           // (rrl_*_forward_cached: `target_ws`): the riding walk takes the target from there
     __host__ bool prepared() const { return order1 != nullptr; }

@@ -403,11 +403,12 @@ def test_cloud_order_equals_its_host_twin(L, n):
 # round 5: the section-8(d) step's shard payload, order validation, explicit target invalidation, torch-internals fallbacks
 @pytest.mark.parametrize("B,n,m,nl,prepared,pose", [(3, 900, 1100, 4000, True, True), (2, 700, 600, 3000, False, True),
                                                      (2, 500, 400, 800, True, True), (2, 600, 500, 2500, True, False),
-                                                     (8, 4096, 4096, 10000, True, True)])
+                                                     (8, 4096, 4096, 10000, True, True), (40, 200, 180, 8000, True, True),
+                                                     (36, 300, 200, 7200, False, False)])
 def test_loss_step_payload(L, B, n, m, nl, prepared, pose):
     """ops.LossStep(want_payload=True) (include/rrl.h rrl_opts.payload): after every step .payload ==
-    [sum of the valid losses, #valid, 0 x 12] -- riding in the reduce's launch (2 .. 32 line tiles) or in the single-tile kernel
-    (one tile of lines), with and without the rigid apply in front, on the first (building) and on later
+    [sum of the valid losses, #valid, 0 x 12] -- riding in the reduce's launch (2 .. 32 line tiles: the tail kernel; grids beyond its 256 workgroups: the
+    exchange reduce's last arrivers) or in the single-tile kernel (one tile of lines), with and without the rigid apply in front, on the first (building) and on later
     (kept-target) calls -- and the step's loss / gradient are those of the step without a payload, bit for bit / to the
     rounding of the scatter's atomics."""
     from rrl_hip import ops
