@@ -128,6 +128,8 @@ struct BuildArgs {
     size_t z3_vec4;
     uint32_t *z4;                  // a caller-owned buffer to clear (RrlCall::clear_ptr: the scatter target of rrl_loss_step)
     size_t z4_words;
+    uint32_t *z5;                  // the CHAIN words (include/rrl.h RRL_WS_CHAIN): cleared by every records launch EXCEPT the
+    size_t z5_words;               //   chained step's fused one, whose scan workgroups are using them (NULL there)
     float *del1, *del2;            // NaN reach of every triangle (may be NULL: not stored)
     const float *line;             // the samples' lines [B][L][6] and where their partial maxima go (may be NULL:
     float2 *lmax;                  //   the scan entry computes them itself then)
@@ -265,8 +267,8 @@ struct RecPlace {
     int cloud, b, bxr;  // triangle workgroup bxr of (cloud, sample b); or
     int lch;            // >= 0: the line-maxima workgroup of chunk lch of sample b
 };
-__device__ __forceinline__ RecPlace rec_place(const BuildArgs &a, int clouds) {
-    const int lin = (int)blockIdx.x, T = a.nblk_tri * a.B * clouds;
+__device__ __forceinline__ RecPlace rec_place(const BuildArgs &a, int clouds, int lin) {
+    const int T = a.nblk_tri * a.B * clouds;
     RecPlace r;
     r.lch = -1;
     if (lin >= T) {  // uniform
@@ -288,15 +290,18 @@ __device__ __forceinline__ RecPlace rec_place(const BuildArgs &a, int clouds) {
 }
 
 // the clearing of the per-call state (and of the small accumulators), spread over all workgroups of a records launch
-__device__ __forceinline__ void build_clear_state(const BuildArgs &a) {
-    const size_t nthr = (size_t)gridDim.x * gridDim.y * gridDim.z * REC_BLK;
-    const size_t me = (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * REC_BLK + threadIdx.x;
+__device__ __forceinline__ void build_clear_state(const BuildArgs &a, size_t me, size_t nthr) {
     const uint4 z = make_uint4(0, 0, 0, 0);
     for (size_t i = me; i < a.zero_vec4; i += nthr) a.zero_base[i] = z;
     for (size_t i = me; i < a.g1_vec4; i += nthr) a.g1[i] = z;
     for (size_t i = me; i < a.z2_vec4; i += nthr) a.z2[i] = z;
     for (size_t i = me; i < a.z3_vec4; i += nthr) a.z3[i] = z;
     for (size_t i = me; i < a.z4_words; i += nthr) a.z4[i] = 0u;  // (4-byte stores: any alignment)
+    for (size_t i = me; i < a.z5_words; i += nthr) a.z5[i] = 0u;
+}
+__device__ __forceinline__ void build_clear_state(const BuildArgs &a) {  // ... of a records launch of REC_BLK-lane workgroups
+    build_clear_state(a, (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * REC_BLK + threadIdx.x,
+                      (size_t)gridDim.x * gridDim.y * gridDim.z * REC_BLK);
 }
 
 __global__ __launch_bounds__(REC_BLK) void tri_records_kernel(const BuildArgs a) {
@@ -304,7 +309,7 @@ __global__ __launch_bounds__(REC_BLK) void tri_records_kernel(const BuildArgs a)
     __shared__ float red2[REC_BLK / 64][2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int B = a.B;
-    const RecPlace pl = rec_place(a, a.clouds);  // (uniform)
+    const RecPlace pl = rec_place(a, a.clouds, (int)blockIdx.x);  // (uniform)
     const int cloud = pl.cloud, b = pl.b, bxr = pl.bxr;
     build_clear_state(a);  // per-call state and gradient accumulator
     const int n = cloud ? a.M : a.N;
@@ -361,27 +366,19 @@ __global__ __launch_bounds__(REC_BLK) void tri_records_kernel(const BuildArgs a)
 // PMAX (max |P|^2 per cloud and sample) is not reduced here -- that would take a hand-over between workgroups of
 // this launch --: the scan reduces the <= n / 256 partial rows (APART) in its prologue, next to the line maxima.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(REC_BLK) void tri_records_sorted_kernel(const BuildArgs a, const int32_t *__restrict__ order1,
-                                                                      const int32_t *__restrict__ order2) {
-    __shared__ float red[REC_BLK / 64][8];
-    __shared__ float red2[REC_BLK / 64][2];
+// The triangle part of the prepared records launch for one workgroup of blockDim.x = 256 or 512 lanes at place `pl`:
+// sorted positions [bxr * blockDim.x, + blockDim.x) of (cloud, sample).  red: LDS [blockDim.x / 64][8].  (One body for
+// tri_records_sorted_kernel and for the chained step's build + scan launch, cull_scan_build_kernel, whose leading workgroups
+// run it with the scan's 512 lanes.)
+__device__ __forceinline__ void records_sorted_body(const BuildArgs &a, const int32_t *__restrict__ order1,
+                                                    const int32_t *__restrict__ order2, const RecPlace &pl, float (*red)[8]) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int B = a.B;
-    const RecPlace pl = rec_place(a, a.clouds);  // (uniform)
     const int cloud = pl.cloud, b = pl.b, bxr = pl.bxr;
-    if (threadIdx.x < 64) STAMPR(0);
-    build_clear_state(a);
-    if (threadIdx.x < 64) STAMPR(1);
     const int n = cloud ? a.M : a.N;
-    if (pl.lch >= 0) {  // uniform: the line maxima, beside the triangle workgroups (tri_records_kernel)
-        if (a.lmax != nullptr)
-            line_max_chunks(a.line, a.L, a.lmax, b, pl.lch, LMAX_CHUNKS, red2, input_of(b, a.Bt));
-        if (threadIdx.x < 64) STAMPR(5);
-        return;
-    }
     const int npad = (n + SGT - 1) / SGT * SGT;
-    if (bxr * REC_BLK >= npad) return;  // uniform: the smaller cloud has fewer workgroups
-    const int s = bxr * REC_BLK + tid;
+    if (bxr * (int)blockDim.x >= npad) return;  // uniform: the smaller cloud has fewer workgroups
+    const int s = bxr * (int)blockDim.x + tid;
     const bool valid = s < n;  // real records occupy the sorted positions [0, n)
     float c[9] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}, x = 0.0f, p2 = 0.0f;
     int f = 0;
@@ -397,7 +394,7 @@ __global__ __launch_bounds__(REC_BLK) void tri_records_sorted_kernel(const Build
         wave_tree(c[0], c[1], c[2], x, valid, lane, (cloud ? a.grp2 : a.grp1) + ((size_t)b * (npad / SGT) + (s - lane) / SGT) * NODE);
     }
     if (threadIdx.x < 64) STAMPR(3);
-    // per-workgroup partial AABB of the P0s and max |P|^2, as tri_records_kernel leaves them
+    // partial AABB of the P0s and max |P|^2 per REC_BLK = 256 sorted positions (APART rows), as tri_records_kernel leaves them
     float mn[3], mx[3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) { mn[d] = wave_min(valid ? c[d] : INFINITY); mx[d] = wave_max(valid ? c[d] : -INFINITY); }
@@ -409,13 +406,33 @@ __global__ __launch_bounds__(REC_BLK) void tri_records_sorted_kernel(const Build
     }
     __syncthreads();
     if (threadIdx.x < 64) STAMPR(4);
-    if (tid < 7) {
-        float r = red[0][tid];
-        for (int w = 1; w < REC_BLK / 64; ++w) r = tid < 3 ? fminf(r, red[w][tid]) : fmaxf(r, red[w][tid]);
-        a.apart[(((size_t)cloud * B + b) * a.nblk + bxr) * 8 + tid] = r;
-    } else if (tid == 7) {
-        a.apart[(((size_t)cloud * B + b) * a.nblk + bxr) * 8 + 7] = 1.0f;  // PTRI layout of this cloud: sorted positions
+    const int q = tid & (REC_BLK - 1), w0 = (tid / REC_BLK) * (REC_BLK / 64);  // slot of the row; first wavefront of its 256 lanes
+    const int row = s / REC_BLK;
+    if (q < 8 && row * REC_BLK < npad) {
+        float r = 1.0f;  // slot 7: PTRI layout of this cloud = sorted positions
+        if (q < 7) {
+            r = red[w0][q];
+            for (int w = 1; w < REC_BLK / 64; ++w) r = q < 3 ? fminf(r, red[w0 + w][q]) : fmaxf(r, red[w0 + w][q]);
+        }
+        a.apart[(((size_t)cloud * B + b) * a.nblk + row) * 8 + q] = r;
     }
+}
+
+__global__ __launch_bounds__(REC_BLK) void tri_records_sorted_kernel(const BuildArgs a, const int32_t *__restrict__ order1,
+                                                                      const int32_t *__restrict__ order2) {
+    __shared__ float red[REC_BLK / 64][8];
+    __shared__ float red2[REC_BLK / 64][2];
+    const RecPlace pl = rec_place(a, a.clouds, (int)blockIdx.x);  // (uniform)
+    if (threadIdx.x < 64) STAMPR(0);
+    build_clear_state(a);
+    if (threadIdx.x < 64) STAMPR(1);
+    if (pl.lch >= 0) {  // uniform: the line maxima, beside the triangle workgroups (tri_records_kernel)
+        if (a.lmax != nullptr)
+            line_max_chunks(a.line, a.L, a.lmax, pl.b, pl.lch, LMAX_CHUNKS, red2, input_of(pl.b, a.Bt));
+        if (threadIdx.x < 64) STAMPR(5);
+        return;
+    }
+    records_sorted_body(a, order1, order2, pl, red);
 }
 
 // PMAX from the partial rows, for callers of the prepared build that do not run the culled scan next (rrl_tri_prepare_ex
@@ -818,6 +835,15 @@ __global__ __launch_bounds__(256) void big_sphere_kernel(const BuildArgs a) {
 typedef const float __attribute__((address_space(4))) * kptr;  // constant AS -> s_load
 typedef const int __attribute__((address_space(4))) * kiptr;
 
+static BuildArgs make_build_args(const float *tri1, const float *tri2, void *ws, const WsLayout &w, int B, int N, int M,
+                                 int clouds, const RrlXform *xf, const float *line, int L, const RrlCall &o, bool chunked);
+// polls (~1 us each) before a source-cloud workgroup of the chained step's launch gives up waiting for its records (RRL_CHAIN_SPIN)
+static unsigned rrl_chain_spin_limit(void) {
+    static long v = -1;
+    if (v < 0) { const char *e = getenv("RRL_CHAIN_SPIN"); v = e ? atol(e) : (1l << 18); if (v < 0 || v > 0x7fffffffl) v = 1l << 18; }
+    return (unsigned)v;
+}
+
 // The two geometry variants of the culled scan (rrl_cull_scan.inc): same source, two sets of compile-time knobs.
 namespace scan8 {
 #include "rrl_cull_scan.inc"
@@ -852,8 +878,12 @@ namespace scan16 {
 }
 static_assert(scan8::kWPB == scan16::kWPB && scan8::kLPW == scan16::kLPW, "one line tiling for both variants");
 
-int rrl_launch_cull_scan(const float *line, void *ws, const WsLayout &w, int B, int N, int M, int L,
-                         int clouds, int lmax_ready, const RrlCall &o, hipStream_t s) {
+// The grid of a culled scan: wavefronts per workgroup, supergroups per slice, the variant, line tiles, slices.
+struct CullGeom {
+    int waves, spw, tiles, slices;
+    bool fat, may_ride;
+};
+static CullGeom cull_geometry(int B, int N, int M, int L, int clouds, const RrlCall &o) {
     // a workgroup = (cloud and sample, tile of <= WPB x 128 lines, slice of spw supergroups).  With
     // few lines or small clouds the slices get thinner, so that the launch still has ~1000
     // workgroups for the 256 CUs (measured with tools/attic/geom_sweep.sh: thinner slices cost little,
@@ -880,8 +910,28 @@ int rrl_launch_cull_scan(const float *line, void *ws, const WsLayout &w, int B, 
             waves = w_ < lw ? w_ : lw; spw = s_; fat = s_ > scan8::kSPW;
         }
     }
-    const int tiles = (lw + waves - 1) / waves, slices = (nsgmax + spw - 1) / spw;
-    if (!lmax_ready)  // the triangles were prepared without the lines: their partial maxima first (a tiny launch)
+    CullGeom g;
+    g.waves = waves; g.spw = spw; g.fat = fat; g.may_ride = may_ride;
+    g.tiles = (lw + waves - 1) / waves; g.slices = (nsgmax + spw - 1) / spw;
+    return g;
+}
+
+// Can the chained step's ONE launch (source records + target scan + source scan: cull_scan_build_kernel) serve this call?
+// Both clouds scanned here with full 512-lane workgroups, no rider, no counters; the caller (loss_forward_impl) checks the
+// rest (prepared orders, kept target, the per-line stage + tail kernel behind it).
+int rrl_cull_scan_can_fuse(int B, int N, int M, int L, const RrlCall &o) {
+    if (B <= 0 || N <= 0 || M <= 0 || L <= 0 || (N > M ? N : M) > SORT_CAP) return 0;
+    if (o.rider || o.counters || o.problems || o.tar_ws) return 0;
+    if (const char *e = getenv("RRL_CHAIN")) if (e[0] == '0') return 0;  // (A/B runs)
+    const CullGeom g = cull_geometry(B, N, M, L, 2, o);
+    return g.waves == scan8::kWPB ? 1 : 0;
+}
+
+int rrl_launch_cull_scan(const float *line, void *ws, const WsLayout &w, int B, int N, int M, int L,
+                         int clouds, int lmax_ready, const RrlCall &o, hipStream_t s) {
+    const CullGeom g = cull_geometry(B, N, M, L, clouds, o);
+    if (o.fused_build && (clouds != 2 || g.waves != scan8::kWPB)) return RRL_E_ARG;  // (rrl_cull_scan_can_fuse said otherwise)
+    if (!lmax_ready && !o.fused_build)  // the triangles were prepared without the lines: their partial maxima first (a tiny launch)
         hipLaunchKernelGGL(line_max_kernel, dim3(LMAX_CHUNKS, (unsigned)B), dim3(REC_BLK), 0, s, line, L,
                            (float2 *)w.f32(ws, RRL_WS_LMAX), o.problems);
     // (A PERSISTENT variant -- as many workgroups as fit on the chip, each keeping one line tile staged and pulling
@@ -890,8 +940,8 @@ int rrl_launch_cull_scan(const float *line, void *ws, const WsLayout &w, int B, 
     // is held for the SLOWEST of a workgroup's eight wavefronts either way (16.5 us per item against a mean wavefront
     // lifetime of 12.4), so queueing the items removed no waiting, and the item barriers added some;
     // profiles/r03_scan_experiments.txt.)
-    return fat ? scan16::launch_variant(line, ws, w, B, N, M, L, clouds, o, s, waves, spw, tiles, slices, may_ride)
-               : scan8::launch_variant(line, ws, w, B, N, M, L, clouds, o, s, waves, spw, tiles, slices, may_ride);
+    return g.fat ? scan16::launch_variant(line, ws, w, B, N, M, L, clouds, o, s, g.waves, g.spw, g.tiles, g.slices, g.may_ride)
+                 : scan8::launch_variant(line, ws, w, B, N, M, L, clouds, o, s, g.waves, g.spw, g.tiles, g.slices, g.may_ride);
 }
 // Executed-work counters (profiling; include/rrl.h rrl_scan_counters): while a buffer is set,
 // culled scans launch the COUNT instantiation and add to it.
@@ -941,23 +991,10 @@ static size_t sort_lds_bytes(int nsg, int parts, int raw_points) {
 }
 
 // Launchers used by rrl_tri_prepare / rrl_line_tri_scan (rrl_scan.hip)
-int rrl_launch_tri_build(const float *tri1, const float *tri2, void *ws, const WsLayout &w, int B,
-                         int N, int M, int clouds, const RrlXform *xf, const float *line, int L, const RrlCall &o,
-                         hipStream_t s) {
+// The arguments of a records launch (rrl_launch_tri_build; the chained step's fused launch, launch_variant).
+static BuildArgs make_build_args(const float *tri1, const float *tri2, void *ws, const WsLayout &w, int B, int N, int M,
+                                 int clouds, const RrlXform *xf, const float *line, int L, const RrlCall &o, bool chunked) {
     const int nmax = clouds == 2 && M > N ? M : N;
-    const size_t ngpmax = (size_t)(nmax + SGT - 1) / SGT * SGG;  // groups, padded to whole supergroups
-    // Clouds of more than 4096 triangles: ONE launch of the single-workgroup sort per chunk of 4096 records
-    // (by original index) instead of the wide three-launch sort of the whole cloud (hist, scatter, spheres:
-    // ~19 us at N = 16384 against 9).  The chunks are interleaved subsets of the surface, each sorted on its
-    // own 16^3 grid; measured faster at every shape tried (C5 54.4 -> 44.1 us, C5 at B = 8 102 -> 62.5,
-    // B = 8 / N = 16384 / L = 10000 171 -> 140, N = 65536 / L = 512 77.5 -> 41.8: the whole-cloud grid holds
-    // ~27 triangles per cell at N = 16384, in arbitrary order, so its groups are no tighter).
-    // RRL_SORT_WIDE=1 keeps the wide sort (experiments / tests; it still serves the Chamfer path).
-    const char *wide_env = getenv("RRL_SORT_WIDE");
-    const bool chunked = nmax > 4096 && !(wide_env && atoi(wide_env) != 0);
-    const size_t ngps = nmax <= 4096 ? ngpmax : (size_t)(4096 / GRP);
-    const int parts = sort_parts((int)(ngps / SGG), o.sort_parts);
-    const size_t lds = nmax <= 4096 || chunked ? sort_lds_bytes((int)(ngps / SGG), parts, 0) : 16;
     BuildArgs a;
     a.tri1 = xf ? xf->src : tri1;
     a.tri2 = tri2;
@@ -986,6 +1023,8 @@ int rrl_launch_tri_build(const float *tri1, const float *tri2, void *ws, const W
     a.z3_vec4 = w.state_bytes / 16;
     a.z4 = (uint32_t *)o.clear_ptr;
     a.z4_words = o.clear_ptr ? o.clear_bytes / 4 : 0;
+    a.z5 = w.u32(ws, RRL_WS_CHAIN);
+    a.z5_words = (size_t)4 * B;
     a.del1 = w.f32(ws, RRL_WS_DEL1);
     a.del2 = w.f32(ws, RRL_WS_DEL2);
     a.zwords = nullptr; a.nzwords = 0;
@@ -1006,6 +1045,27 @@ int rrl_launch_tri_build(const float *tri1, const float *tri2, void *ws, const W
         if (xa < 0) { const char *e = getenv("RRL_XCD_ALIGN"); xa = e && e[0] == '0' ? 0 : 1; }
         a.xcd_align = xa && (clouds * B) % 8 == 0 ? 1 : 0;
     }
+    return a;
+}
+
+int rrl_launch_tri_build(const float *tri1, const float *tri2, void *ws, const WsLayout &w, int B,
+                         int N, int M, int clouds, const RrlXform *xf, const float *line, int L, const RrlCall &o,
+                         hipStream_t s) {
+    const int nmax = clouds == 2 && M > N ? M : N;
+    const size_t ngpmax = (size_t)(nmax + SGT - 1) / SGT * SGG;  // groups, padded to whole supergroups
+    // Clouds of more than 4096 triangles: ONE launch of the single-workgroup sort per chunk of 4096 records
+    // (by original index) instead of the wide three-launch sort of the whole cloud (hist, scatter, spheres:
+    // ~19 us at N = 16384 against 9).  The chunks are interleaved subsets of the surface, each sorted on its
+    // own 16^3 grid; measured faster at every shape tried (C5 54.4 -> 44.1 us, C5 at B = 8 102 -> 62.5,
+    // B = 8 / N = 16384 / L = 10000 171 -> 140, N = 65536 / L = 512 77.5 -> 41.8: the whole-cloud grid holds
+    // ~27 triangles per cell at N = 16384, in arbitrary order, so its groups are no tighter).
+    // RRL_SORT_WIDE=1 keeps the wide sort (experiments / tests; it still serves the Chamfer path).
+    const char *wide_env = getenv("RRL_SORT_WIDE");
+    const bool chunked = nmax > 4096 && !(wide_env && atoi(wide_env) != 0);
+    const size_t ngps = nmax <= 4096 ? ngpmax : (size_t)(4096 / GRP);
+    const int parts = sort_parts((int)(ngps / SGG), o.sort_parts);
+    const size_t lds = nmax <= 4096 || chunked ? sort_lds_bytes((int)(ngps / SGG), parts, 0) : 16;
+    BuildArgs a = make_build_args(tri1, tri2, ws, w, B, N, M, clouds, xf, line, L, o, chunked);
     if (o.prepared()) {  // the order is known: ONE launch (records at their sorted positions + tree refit), no sort
         a.z2 = nullptr; a.z2_vec4 = 0;
         a.nblk_tri = (int)(((size_t)(nmax + SGT - 1) / SGT * SGT + REC_BLK - 1) / REC_BLK);

@@ -252,6 +252,8 @@ struct PairArgs {
     int Bt;  // multi-pose evaluation (rrl_opts.problems): tri2, line and cloud 2's scan (count2, hit2) of instance b are those
              // of problem b % Bt; 0: every instance has its own
     int xcd_align;  // line_pair_dist_kernel: sample b's workgroups on XCD b % 8 (xcd_sample_of; B % 8 == 0)
+    int32_t *zc1, *zc2;  // chained steps (include/rrl.h RRL_F_CHAIN): COUNT1 / COUNT2 again, writable -- every lane zeroes its
+                         // line's two counts behind its own read, so that the NEXT step's scan finds them cleared; or NULL
 };
 
 // One tile of 1024 lines of sample b by a 1024-lane workgroup.  Phase 1: every lane classifies its line
@@ -284,6 +286,7 @@ __device__ __forceinline__ void pair_body(const PairArgs &a, int b, int tile, in
         if (l < L) {
             const size_t gl = (size_t)b * L + l;
             const int k = a.count1[gl], j = a.count2[(size_t)bi * L + l];
+            if (a.zc1) { a.zc1[gl] = 0; a.zc2[gl] = 0; }  // (chained steps; never multi-pose: bi == b)
             sel = k >= a.s_m && k < a.e_m && j >= a.s_n && j < a.e_n;
             kjb = sel ? (unsigned)(k | (j << 4)) : 0u;
             a.kj[gl] = (uint8_t)kjb;
@@ -447,6 +450,7 @@ static PairArgs pair_args(const float *tri1, const float *tri2, const float *lin
     a.st1 = 9; a.st2 = 9;
     a.Bt = Bt;  // multi-pose (RrlCall::problems)
     a.xcd_align = B % 8 == 0 && xcd_align_on();
+    a.zc1 = a.zc2 = nullptr;
     return a;
 }
 
@@ -464,6 +468,7 @@ static int line_pair_dist_impl(const float *tri1, const float *tri2, const float
     if (B == 0 || L == 0) return 0;
     PairArgs pa = pair_args(tri1, tri2, line, ws, w, B, N, M, L, s_m, s_n, e_m, e_n, true, o.tar_ws);
     pa.Bt = o.problems;
+    if (o.leave_clean && !o.problems && !o.tar_ws) { pa.zc1 = w.i32(ws, RRL_WS_COUNT1); pa.zc2 = w.i32(ws, RRL_WS_COUNT2); }
     if (reduce_kind(o.reduce_mode, B, (L + 1023) / 1024, pool, with_bwd) != 2) pa.vlist = nullptr;  // only the tail kernel reads VLIST
     if (RrlCountRider *cr = o.count_rider) {  // the next epoch's count pass rides along (pair_count_kernel)
         const int ctiles = (cr->n + 1023) / 1024;
@@ -1443,6 +1448,11 @@ struct TailArgs {
     float *grad_tri1;  // != NULL: the backward SCATTERS dL/dpoints1 [B][N][9] (rrl_loss_step) instead of summing (dR, dt)
     int Bt;            // multi-pose (rrl_opts.problems): src has Bt entries, instance b is a pose of entry b % Bt; 0: its own
     int xcd_align;     // sample b's workgroups on XCD b % 8 (xcd_sample_of; B % 8 == 0)
+    // chained steps (include/rrl.h RRL_F_CHAIN): the CHAIN words [B][4], which the sample's last workgroup zeroes on exit
+    // (or NULL); chain_flags != 0: this step's scan ran in the fused launch -- its NaN flag and time-outs are CHAIN[b][1],
+    // CHAIN[b][3], not STATUS[0]
+    uint32_t *chain;
+    int chain_flags;
 };
 
 
@@ -1526,7 +1536,17 @@ __device__ __forceinline__ void tail_body(const TailArgs &a, int tile_in, int b_
     }
     const unsigned bkt = tid < 16 ? ctl[tid] : 0u;
     const float gl_in0 = do_bwd ? a.grad_loss[b] : 0.0f;
-    const int st0 = a.status[0];  // (the scan's NaN flag, for the info row: at the end it would be one more round trip of the last arriver)
+    // (the scan's NaN flag, for the info row: at the end it would be one more round trip of the last arriver; a chained
+    //  step's fused launch keeps it per sample, next to the count of source workgroups that gave up waiting for their records)
+    int st0;
+    bool chain_tmo = false;
+    if (a.chain_flags) {
+        const uint4 cw = *(const uint4 *)(a.chain + 4 * (size_t)b);
+        st0 = (int)cw.y;
+        chain_tmo = cw.w != 0u;
+    } else {
+        st0 = a.status[0];
+    }
     // ... and the sample's D values (the tiles' dense lists, VLIST), which the median's gather streams: lane (vt, vq) = (tile,
     // slot) reads the 16-byte groups vq + LPT u of tile vt -- an address that needs no count either (a list's 16384 slots
     // exist; a group beyond the list's length holds stale data and is masked by the count once it is here).  Round 5: the
@@ -1660,6 +1680,8 @@ __device__ __forceinline__ void tail_body(const TailArgs &a, int tile_in, int b_
             a.med_out[b] = 0.0f;
             a.loss[b] = 0.0f;
             a.info[b * 4 + 0] = 0; a.info[b * 4 + 1] = 0; a.info[b * 4 + 2] = 0; a.info[b * 4 + 3] = st0;
+            if (chain_tmo) a.loss[b] = __builtin_nanf("");
+            if (a.chain) *(uint4 *)(a.chain + 4 * (size_t)b) = make_uint4(0u, 0u, 0u, 0u);
         }
         return;
     }
@@ -1791,7 +1813,7 @@ __device__ __forceinline__ void tail_body(const TailArgs &a, int tile_in, int b_
     if (lane == 0) {
         const float accl = f.acc;
         const int Cn = f.C, nselected = f.nselected, nvalues = f.nvalues;
-        const float lv = bad ? __builtin_nanf("") : (Cn ? accl / (float)Cn : 0.0f);  // code/loss.py:230
+        const float lv = bad || chain_tmo ? __builtin_nanf("") : (Cn ? accl / (float)Cn : 0.0f);  // code/loss.py:230
         a.med_out[b] = med;
         a.loss[b] = lv;
         a.info[b * 4 + 0] = Cn;
@@ -1799,6 +1821,7 @@ __device__ __forceinline__ void tail_body(const TailArgs &a, int tile_in, int b_
         a.info[b * 4 + 2] = nvalues;
         a.info[b * 4 + 3] = st0;
         st_agent(&ctl[MCTL_TICK2], 0u); st_agent(&ctl[MCTL_BAD], 0u);
+        if (a.chain) *(uint4 *)(a.chain + 4 * (size_t)b) = make_uint4(0u, 0u, 0u, 0u);  // the next chained step finds them cleared
         if (do_bwd && a.payload && Cn > 0) tail_payload(a, lv);
     }
     STAMPW(6);
@@ -2054,6 +2077,10 @@ RrlCall rrl_resolve_opts(const rrl_opts *p) {
     o.payload = v.payload;
     o.payload_in_reduce = 0;
     o.problems = v.problems > 0 ? v.problems : 0;
+    o.chain_left = v.chain_left;
+    o.leave_clean = o.fused_build = 0;
+    o.xf = nullptr;
+    o.tri1_in = nullptr;
     return o;
 }
 // Which reduce kernel: 0 one workgroup per sample, 1 tiled with the candidate exchange (loss_reduce_tiled_kernel), 2 the
@@ -2168,6 +2195,8 @@ static int loss_reduce_impl(void *ws, size_t ws_bytes, float *loss, int B, int N
         t.grad_tri1 = tb ? tb->grad_tri1 : nullptr;
         t.Bt = o.problems;
         t.xcd_align = B % 8 == 0 && xcd_align_on();
+        t.chain = o.leave_clean ? w.u32(ws, RRL_WS_CHAIN) : nullptr;
+        t.chain_flags = o.fused_build ? 1 : 0;
         // the next epoch's sampler write pass rides along (tail_write_kernel; rrl_demo_epoch) -- when this launch carries the
         // backward (nothing after it reads the line buffer the pass overwrites) and the ballots of THAT count pass are there
         RrlWriteRider *wr = tb ? o.write_rider : nullptr;
@@ -2937,6 +2966,7 @@ int rrl_tri_prepare_clouds(const float *tri1, const float *tri2, void *ws, size_
 int rrl_line_tri_scan_clouds(const float *line, void *ws, size_t ws_bytes, int B, int N, int M, int L,
                              int mode, int chunk, int clouds, int lmax_ready, const RrlCall &o, void *stream);
 int rrl_sort_capacity(void);
+int rrl_cull_scan_can_fuse(int B, int N, int M, int L, const RrlCall &o);  // rrl_cull.hip
 
 // target_ws != NULL: a workspace of the same (B, N, M, L) that already went through a forward with
 // the SAME tri2 and line (RPM / FMR evaluate several source poses against one target and one
@@ -2968,9 +2998,21 @@ static int loss_forward_impl(const float *tri1, const float *tri2, const float *
         o.order1 = o.order2 = nullptr;
     // a kept target: cloud 2's records / tree / partials stay as the previous call on this workspace left them
     const int build_clouds = o.target_kept() ? 1 : clouds;
+    // Chained steps (include/rrl.h RRL_F_CHAIN / RRL_F_CHAINED).  The chain lives where the per-line stage + tail kernel
+    // serve the call: they are the ones that leave COUNT1 / COUNT2 and the CHAIN words cleared.
+    const bool chain_path = B > 0 && L > 1024 && !pool && clouds == 2 && !o.problems && mode == RRL_SCAN_CULL &&
+                            (N > M ? N : M) <= rrl_sort_capacity() && N > 0 && M > 0 &&
+                            reduce_kind(o.reduce_mode, B, (L + 1023) / 1024, pool, tb != nullptr) == 2;
+    o.leave_clean = (o.flags & RRL_F_CHAIN) && chain_path ? 1 : 0;
+    if (o.chain_left) *o.chain_left = o.leave_clean;
+    // ... and a step that FINDS them cleared runs source records + target scan + source scan as ONE launch
+    o.fused_build = (o.flags & RRL_F_CHAINED) && chain_path && o.target_kept() && !o.count_rider && !o.write_rider &&
+                    rrl_cull_scan_can_fuse(B, N, M, L, o) ? 1 : 0;
+    o.xf = xf;
+    o.tri1_in = tri1;
     int rc;
     RrlRange step("rrl forward");
-    {
+    if (!o.fused_build) {
         RrlRange r("K1' records + sort + tree");
         if ((rc = rrl_tri_prepare_clouds(tri1, tri2, ws, ws_bytes, B, N, M, L, build_clouds, xf, line, o, stream))) return rc;
     }

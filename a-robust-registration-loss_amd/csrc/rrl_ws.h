@@ -63,6 +63,7 @@ struct WsLayout {
             4 * b * ((l + 1023) / 1024) * 1024,  // LIDC
             4 * b * ((l + 1023) / 1024) * 16384, // VLIST
             4 * b * ((l + 1023) / 1024 + 1),     // VLCNT
+            4 * b * 4,                           // CHAIN (chained steps: include/rrl.h RRL_F_CHAIN)
         };
         size_t o = 0;
         for (int i = 0; i < RRL_WS_FIELDS; ++i) {
@@ -114,6 +115,7 @@ struct RrlWriteRider {
     int done;
 };
 
+struct RrlXform;
 struct RrlCall {
     int flags;
     int reduce_mode;    // 0 auto, 1 single, 2 tiled, 3 xchg
@@ -135,6 +137,12 @@ struct RrlCall {
     int payload_in_reduce;  // (internal) rrl_loss_step_ex: the tiled reduce's last arrivers add payload[0 .. 1] (no payload launch)
     const void *tar_ws;   // (internal) the workspace that holds cloud 2's records when the target's scan is carried over
                           // (rrl_*_forward_cached: `target_ws`): the riding walk takes the target from there
+    int32_t *chain_left;  // rrl_opts.chain_left (host int, or NULL)
+    // (internal, chained steps: include/rrl.h RRL_F_CHAIN / RRL_F_CHAINED) decided once per call by loss_forward_impl:
+    int leave_clean;      //   the per-line stage zeroes COUNT1 / COUNT2 behind its read, the tail kernel the CHAIN words
+    int fused_build;      //   records + target scan + source scan as ONE launch (rrl_launch_cull_scan issues it; the
+    const RrlXform *xf;   //   source's transform for its records body)
+    const float *tri1_in; //   ... and the caller's source rows when there is no transform
     __host__ bool prepared() const { return order1 != nullptr; }
     __host__ bool target_kept() const { return order1 != nullptr && (flags & RRL_F_TARGET_KEPT); }
 };

@@ -82,6 +82,8 @@ EXPORTS = sorted(list(_SIGS) + ["rrl_version", "rrl_workspace_bytes", "rrl_chamf
                                  "rrl_cloud_order_workspace_bytes"])
 
 F_TARGET_KEPT = 1  # include/rrl.h RRL_F_TARGET_KEPT
+F_CHAIN = 2        # RRL_F_CHAIN: leave the hit counts / CHAIN words cleared for the next step on this workspace
+F_CHAINED = 4      # RRL_F_CHAINED: the previous step did (chain_left = 1): records + both scans as one launch
 
 
 class ChamferRider(ctypes.Structure):
@@ -94,13 +96,14 @@ class Opts(ctypes.Structure):
     _fields_ = [("struct_bytes", _c.c_int32), ("flags", _c.c_int32), ("reduce_mode", _c.c_int32),
                 ("deterministic", _c.c_int32), ("sort_parts", _c.c_int32), ("scan_variant", _c.c_int32),
                 ("order1", _P), ("order2", _P), ("scan_counters", _P), ("scan_counter_rows", _c.c_longlong),
-                ("chamfer", _P), ("payload", _P), ("problems", _c.c_int32)]
+                ("chamfer", _P), ("payload", _P), ("problems", _c.c_int32), ("chain_left", _P)]
 
     def __init__(self, flags=0, reduce_mode=-1, deterministic=-1, sort_parts=-1, scan_variant=-1, order1=None,
-                 order2=None, scan_counters=None, scan_counter_rows=0, chamfer=None, payload=None, problems=0):
+                 order2=None, scan_counters=None, scan_counter_rows=0, chamfer=None, payload=None, problems=0,
+                 chain_left=None):
         super().__init__(ctypes.sizeof(Opts), int(flags), int(reduce_mode), int(deterministic), int(sort_parts),
                          int(scan_variant), order1, order2, scan_counters, int(scan_counter_rows), chamfer, payload,
-                         int(problems))
+                         int(problems), chain_left)
 
 class DemoEpochArgs(ctypes.Structure):
     """include/rrl.h rrl_demo_epoch_args (same field order)."""

@@ -66,6 +66,7 @@ _WS_FIELDS = [
     ("lidc", torch.int32, lambda B, N, M, L, G: (B, (L + 1023) // 1024 * 1024)),
     ("vlist", torch.float32, lambda B, N, M, L, G: (B, (L + 1023) // 1024, 16384)),
     ("vlcnt", torch.int32, lambda B, N, M, L, G: (B * ((L + 1023) // 1024 + 1),)),
+    ("chain", torch.int32, lambda B, N, M, L, G: (B, 4)),
 ]
 _layout_cache = {}
 _FIELD_INDEX = {name: i for i, (name, _, _) in enumerate(_WS_FIELDS)}
@@ -351,14 +352,16 @@ class ChamferRide:
 
 
 def make_opts(order1=None, order2=None, target_kept=False, reduce_mode=None, deterministic=None, sort_parts=None,
-              scan_variant=None, counters=None, chamfer=None, payload=None, problems=None):
+              scan_variant=None, counters=None, chamfer=None, payload=None, problems=None, chain=0, chain_left=None):
     """include/rrl.h rrl_opts for one call (None = the library default everywhere); the returned object keeps the
-    tensors it points at alive (.keep)."""
+    tensors it points at alive (.keep).  chain: _lib.F_CHAIN [| _lib.F_CHAINED] (chained steps, include/rrl.h), chain_left:
+    the ctypes.c_int32 that receives "this call leaves the workspace chain-clean"."""
     if order1 is None and order2 is None and not target_kept and reduce_mode is None and deterministic is None \
             and sort_parts is None and scan_variant is None and counters is None and chamfer is None and payload is None \
-            and not problems:
+            and not problems and not chain:
         return None
-    o = _lib.Opts(flags=_lib.F_TARGET_KEPT if target_kept else 0,
+    o = _lib.Opts(flags=(_lib.F_TARGET_KEPT if target_kept else 0) | int(chain),
+                  chain_left=ctypes.addressof(chain_left) if chain_left is not None else None,
                   reduce_mode=-1 if reduce_mode is None else _REDUCE.get(reduce_mode, reduce_mode),
                   deterministic=-1 if deterministic is None else int(bool(deterministic)),
                   sort_parts=-1 if sort_parts is None else int(sort_parts),
@@ -369,7 +372,7 @@ def make_opts(order1=None, order2=None, target_kept=False, reduce_mode=None, det
                   scan_counter_rows=counters.shape[0] if counters is not None else 0,
                   chamfer=ctypes.addressof(chamfer.c) if chamfer is not None else None,
                   payload=payload.data_ptr() if payload is not None else None, problems=int(problems or 0))
-    o.keep = (order1, order2, counters, chamfer, payload)  # (o.problems: the ctypes field itself)
+    o.keep = (order1, order2, counters, chamfer, payload, chain_left)  # (o.problems: the ctypes field itself)
     o.ride = chamfer  # a ChamferRide (or None): the forwards arm it before the call and leave it on the LossState when it rode
     return o
 
@@ -1104,14 +1107,23 @@ class LossStep:
         self.keep_target = True  # see RegistrationStep.invalidate_target
         # (in the workspace's accumulator field: the step's first launch clears it, as for RegistrationStep)
         self.payload = self.st.gacc[B * 12:B * 12 + 14] if want_payload else None
-        self._opts = self._opts_kept = make_opts(chamfer=self.ride, payload=self.payload, problems=prob)  # (None without any)
+        self._opts = self._opts_kept = self._opts_chained = make_opts(chamfer=self.ride, payload=self.payload, problems=prob)  # (None without any)
+        # CHAINED steps (round 6; include/rrl.h RRL_F_CHAIN / RRL_F_CHAINED): every prepared step asks the library to leave
+        # the workspace's hit counts cleared (the library says through _chain_left whether it did); a step that follows such
+        # a step with the target still kept runs records + target scan + source scan as ONE launch.  chain = False turns
+        # it off for this object (RRL_CHAIN=0 for the process).
+        self.chain = True
+        self._chain_left = ctypes.c_int32(0)
+        self._chain_ready = False  # the previous call on self.st left it chain-clean and nothing has touched it since
         if self.prepared:
             self.order1 = _check_order(src_order, Bt, N, dev, "src_order") if src_order is not None else cloud_order(self.src)
             self.order2 = _check_order(tar_order, Bt, M, dev, "tar_order") if tar_order is not None else cloud_order(self.tar)
-            self._opts = make_opts(order1=self.order1, order2=self.order2, chamfer=self.ride, payload=self.payload, problems=prob)
-            self._opts_kept = make_opts(order1=self.order1, order2=self.order2, target_kept=True, chamfer=self.ride,
-                                        payload=self.payload, problems=prob)
-        self._optr, self._optr_kept = _optr(self._opts), _optr(self._opts_kept)
+            kw = dict(order1=self.order1, order2=self.order2, chamfer=self.ride, payload=self.payload, problems=prob,
+                      chain_left=self._chain_left)
+            self._opts = make_opts(chain=_lib.F_CHAIN, **kw)
+            self._opts_kept = make_opts(target_kept=True, chain=_lib.F_CHAIN, **kw)
+            self._opts_chained = make_opts(target_kept=True, chain=_lib.F_CHAIN | _lib.F_CHAINED, **kw)
+        self._optr, self._optr_kept, self._optr_chained = _optr(self._opts), _optr(self._opts_kept), _optr(self._opts_chained)
         self._lib = _lib.load()
 
     def invalidate_target(self):
@@ -1131,8 +1143,11 @@ class LossStep:
         op, key = self._optr, None
         if self.prepared:
             key = _write_key(self.tar) if self.keep_target else None
-            op = self._optr_kept if (key is not None and key == self._kept_key) else self._optr
+            if key is not None and key == self._kept_key:
+                op = self._optr_chained if (self._chain_ready and self.chain) else self._optr_kept
             self._kept_key = None  # (set below, once the call has been issued)
+        self._chain_ready = False
+        self._chain_left.value = 0
         if self.ride is not None:
             self.ride.arm()
         with _guard(dev):
@@ -1141,6 +1156,7 @@ class LossStep:
                                              self.tr, *self.rng, self.mode, self.chunk, None, op, _stream(dev)),
                   "rrl_loss_step")
         self._kept_key = key
+        self._chain_ready = self.prepared and self._chain_left.value == 1
         _IntersectionLoss.last_state = self.st
         if self.ride is not None:
             _keep_ride(self.st, self.ride)

@@ -136,6 +136,10 @@ enum {
     RRL_WS_VLIST,      /* float[B][ceil(L/1024)][16384]  the valid D values of each 1024-line tile as a dense list (arbitrary order,
                           padded with -1 to a multiple of 4): what the tail kernel streams to find the median                */
     RRL_WS_VLCNT,      /* int32[B][ceil(L/1024)]  their number per tile                                                     */
+    RRL_WS_CHAIN,      /* uint32[B][4]  per-sample words of a CHAINED step (RRL_F_CHAIN / RRL_F_CHAINED, round 6): [0] records
+                          workgroups of the sample that have finished in the step's build + scan launch, [1] the scan's NaN
+                          flag of the sample, [2] its wavefronts that fell back to the strict loop, [3] wait time-outs; all
+                          zero between calls (cleared on exit by the sample's last tail workgroup)                          */
     RRL_WS_FIELDS
 };
 
@@ -154,6 +158,23 @@ const char *rrl_version(void);
                                 the PREVIOUS call on this workspace built from the same tri2 -- the target has not moved
                                 (code/test_demo_optimized_Lie_Algebra.py:57-62, rpm/Train_RPM.py:207-231 move only the
                                 source) -- so nothing of cloud 2 is rebuilt; order2 is not read.  Same results bit for bit. */
+/* CHAINED steps (round 6): a loop that calls rrl_loss_step_ex / rrl_registration_step_ex again and again on ONE workspace
+ * with a kept target (the demo, code/test_demo_optimized_Lie_Algebra.py:48-62; a trainer's inner iterations).  The target
+ * half of the scan (code/loss.py:181-184: the two scans are independent) needs nothing this step's records launch
+ * produces -- only cleared hit counts.  RRL_F_CHAIN asks a step to LEAVE them cleared: the per-line stage zeroes
+ * COUNT1 / COUNT2 behind its own read, the sample's last tail workgroup zeroes the CHAIN words.  RRL_F_CHAINED tells a
+ * step that it FINDS them cleared: records, target scan and source scan then run as ONE launch -- the source records' body
+ * in the leading workgroups of the scan's grid, the target-cloud workgroups next, the source-cloud workgroups last, behind
+ * the sample's ready word (CHAIN[b][0]); the line slacks come from the scan tile's own lines instead of LMAX.  Three
+ * launches instead of four, same labels / hit lists / loss bits.
+ *   - *chain_left (rrl_opts, host memory, written when the call is ISSUED) = 1 when this call leaves the workspace
+ *     chain-clean (the shape is served by the per-line stage + tail kernel and RRL_F_CHAIN was set), else 0;
+ *   - RRL_F_CHAINED is valid only when the PREVIOUS call on this workspace reported chain_left = 1 and nothing else has
+ *     written the workspace since; it needs RRL_F_TARGET_KEPT and is ignored (plain 4-launch step) whenever the fused
+ *     launch cannot serve the call (rider, counters, multi-pose, other reduce kernels, thin grids);
+ *   - after a chained step COUNT1 / COUNT2 read zero, STATUS is not updated (INFO[b][3] carries the NaN flag per sample). */
+#define RRL_F_CHAIN 2
+#define RRL_F_CHAINED 4
 /* A Chamfer walk carried by the evaluation's own scan launch (round 4b).  rrl_chamfer_from_loss -- the monitor every caller
  * of the reference computes next to the loss (rpm/Train_RPM.py:223-224, dcp/Train_DCP.py:246, fmr/model.py:293,
  * test_demo_optimized_Lie_Algebra.py:68) -- needs the evaluation's records launch only, not its scan, but launches of one
@@ -207,6 +228,7 @@ typedef struct rrl_opts {
      * after the other; the target's scan runs ONCE per problem (instances < Bt), the sources' scans side by side in the same
      * launch.  Scan mode cull, clouds within the sort capacity, no target_ws, pool = 0; RRL_E_ARG otherwise. */
     int32_t problems;
+    int32_t *chain_left;     /* NULL, or a HOST int32 that receives 1 / 0 at issue time (RRL_F_CHAIN above) */
 } rrl_opts;
 
 size_t rrl_workspace_bytes(int B, int N, int M, int L);

@@ -20,7 +20,7 @@ def pytest_configure(config):
 # (fragments, demo, bench.py children), then threads / stress / soak -- with `-x` a failure late in the list must never
 # hide the kernels (round 4 lost 321 parity tests to one assertion in the harness file, which sorts first by name).
 _ORDER = ["test_oracle_golden", "test_host", "test_dataset", "test_dist_gloo",
-          "test_gpu_parity", "test_gpu_prepared", "test_gpu_callsites", "test_gpu_harness", "test_gpu_threads",
+          "test_gpu_parity", "test_gpu_prepared", "test_gpu_chain", "test_gpu_callsites", "test_gpu_harness", "test_gpu_threads",
           "test_gpu_stress", "test_gpu_soak"]
 
 

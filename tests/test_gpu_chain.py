@@ -1,0 +1,167 @@
+"""Chained steps (round 6; include/rrl.h RRL_F_CHAIN / RRL_F_CHAINED, csrc/rrl_cull_scan.inc cull_scan_build_kernel).
+
+A loop that evaluates the loss again and again on one workspace with a kept target (the demo,
+code/test_demo_optimized_Lie_Algebra.py:48-62: new lines and a new pose every step, the target never moves) runs, from its
+second step on, the source's records, the target's scan and the source's scan as ONE launch: the two scans of
+code/loss.py:181-184 are independent, and the target's needs nothing the records produce.  The bar is the one of the
+prepared build: hit counts, hit lists, median, bucket sums, info and loss BIT-IDENTICAL to the unchained step (whose own
+parity with the oracle and the reference fixtures is test_gpu_parity's business), points1.grad to the rounding of the
+scatter's float atomics -- for new lines and poses in every step, across target changes, with the scan's counters switched
+on in between, at unit scale and at the demo's (the NaN-widened walk), for clouds beyond 4096 triangles and ragged shapes.
+"""
+import numpy as np
+import pytest
+import torch
+
+from test_gpu_parity import cu
+from test_gpu_prepared import _lines, _pairs, _rot
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def L():
+    import loss
+    from rrl_hip import _lib
+    _lib.load()
+    assert torch.cuda.is_available()
+    return loss
+
+
+def _new_lines(L, prs, nl, it):
+    out = []
+    for b, p in enumerate(prs):
+        torch.manual_seed(1000 + 37 * it + b)  # (the CPU seed selects the sampler's uniform streams)
+        out.append(L.Random_uniform_distribution_lines_batch_efficient_resample(
+            torch.tensor([[float(p["radius"])]]), torch.from_numpy(np.asarray(p["center"], np.float32)).reshape(1, 3), nl,
+            cu(p["src"])[None], cu(p["tar"])[None], "cuda")[0])
+    return torch.stack(out)
+
+
+def _poses(B, it):
+    R = cu(np.stack([_rot((0, 0, 1) if (b + it) % 2 else (1, 0, 0), 2.0 + 1.5 * it + b) for b in range(B)]))
+    t = cu(np.full((B, 3), 0.01 * (it + 1), np.float32))
+    return R, t
+
+
+def _snapshot(step, out):
+    """Everything a step leaves that does not depend on the chain: the per-line stage's view of the hits (KJ = k | j << 4 per
+    line, the ascending hit lists of the selected lines), median, buckets, info, loss, gradient."""
+    st = step.st
+    kj = st.kj.clone()
+    sel = kj != 0
+    k, j = (kj & 15).long(), (kj >> 4).long()
+    a4 = torch.arange(4, device=kj.device)
+    hs1 = torch.where(sel[..., None] & (a4 < k[..., None]), st.hs1, torch.full_like(st.hs1, -1))
+    hs2 = torch.where(sel[..., None] & (a4 < j[..., None]), st.hs2, torch.full_like(st.hs2, -1))
+    return dict(loss=out[0].clone(), grad=out[1].clone(), info=out[2].clone(), kj=kj, hs1=hs1, hs2=hs2, med=st.med.clone(),
+                bsum=st.bsum.clone(), bcnt=st.bcnt.clone())
+
+
+def _assert_same(a, b, what):
+    for key in ("loss", "info", "kj", "hs1", "hs2", "med", "bsum", "bcnt"):
+        assert torch.equal(a[key], b[key]), (what, key)
+    ga, gb = a["grad"], b["grad"]
+    assert torch.equal(ga.abs().sum(-1) > 0, gb.abs().sum(-1) > 0), what
+    assert bool(((ga - gb).abs() <= 2e-5 * ga.abs() + 2e-6 * float(ga.abs().max())).all()), what
+
+
+@pytest.mark.parametrize("B,n,m,nl,scale", [(2, 1200, 1000, 6000, 1.0), (8, 4096, 4096, 10000, 1.0), (1, 1024, 1024, 20000, 1.0),
+                                            (3, 700, 900, 4000, 1.0), (1, 5000, 4100, 3000, 1.0), (2, 1000, 1200, 5000, 12.0),
+                                            (16, 500, 400, 2500, 1.0), (5, 330, 260, 1100, 1.0)])
+def test_chained_steps_equal_unchained_steps(L, B, n, m, nl, scale):
+    from rrl_hip import ops
+    prs, src, tar = _pairs(900, B, n, m)
+    src, tar = src * scale, tar * scale
+    for p in prs:
+        p.update(radius=float(p["radius"]) * scale, center=p["center"] * scale, src=p["src"] * scale, tar=p["tar"] * scale)
+    plain = ops.LossStep(src, tar, nl, want_payload=True)
+    plain.chain = False
+    chained = ops.LossStep(src, tar, nl, want_payload=True)
+    fused = 0
+    for it in range(5):
+        ln = _new_lines(L, prs, nl, it)  # (new lines in every step)
+        R, t = _poses(B, it)
+        chained.st.lmax.fill_(-7.0)  # the separate records launch rewrites LMAX; the fused launch has no use for it
+        a = _snapshot(plain, plain(R, t, ln))
+        b = _snapshot(chained, chained(R, t, ln))
+        torch.cuda.synchronize()
+        _assert_same(a, b, it)
+        assert torch.equal(plain.payload[:2], chained.payload[:2]) or abs(float(plain.payload[0] - chained.payload[0])) < 1e-5
+        was_fused = bool((chained.st.lmax == -7.0).all())
+        fused += was_fused
+        assert was_fused == (it > 0), (it, "the second and later steps of a chain run the fused launch")
+        # what a chained step leaves behind: cleared counts and CHAIN words; the unchained one keeps its counts
+        assert int(chained.st.count1.abs().max()) == 0 and int(chained.st.count2.abs().max()) == 0
+        assert int(chained.st.chain.abs().max()) == 0
+        assert int(plain.st.count1.max()) > 0
+    assert fused == 4
+    assert int(b["info"][:, 1].min()) > 0 and int(b["info"][:, 3].max()) == 0
+
+
+def test_chain_is_broken_by_a_new_target_and_resumes(L):
+    """The kept-target rules of the prepared step hold for the chain: an in-place write to the target (torch's version
+    counter), invalidate_target() and keep_target = False each break it for one step -- that step rebuilds the target with
+    the plain four launches -- and the chain resumes behind it; a step with the scan's counters on is unfused but keeps the
+    chain; chain = False stops it."""
+    from rrl_hip import ops
+    B, n, m, nl = 2, 1100, 900, 5000
+    prs, src, tar = _pairs(930, B, n, m)
+    ln = _lines(L, prs, nl)
+    ref = ops.LossStep(src, tar.clone(), nl)
+    ref.chain = False
+    st = ops.LossStep(src, tar, nl)
+    R, t = _poses(B, 0)
+
+    def run(expect_fused, what):
+        st.st.lmax.fill_(-7.0)
+        ref.tar.copy_(st.tar)
+        a = _snapshot(ref, ref(R, t, ln))
+        b = _snapshot(st, st(R, t, ln))
+        torch.cuda.synchronize()
+        _assert_same(a, b, what)
+        assert bool((st.st.lmax == -7.0).all()) == expect_fused, what
+
+    run(False, "first")
+    run(True, "second")
+    tar.mul_(1.01)  # the target moved (version counter)
+    run(False, "after an in-place write")
+    run(True, "resumed")
+    st.invalidate_target()
+    run(False, "invalidated")
+    run(True, "resumed again")
+    ops.scan_counters(True)
+    try:
+        run(False, "counters on: the counting instantiation of the plain scan")
+    finally:
+        ops.scan_counters(False)
+    run(True, "the counted step left the workspace chain-clean too")
+    st.chain = False
+    run(False, "chain off")
+    st.chain = True
+    run(True, "chain on again (the unfused step still left the counts cleared)")
+    st.keep_target = False
+    run(False, "keep_target off")
+
+
+def test_chained_step_under_graph_replay(L):
+    """A chained step captured into a hipGraph replays as a chained step: every replay finds the counts its predecessor
+    cleared (bench.py's --issue graph)."""
+    from rrl_hip import ops
+    from rrl_hip.graph import GraphedStep
+    B, n, m, nl = 2, 1000, 1000, 5000
+    prs, src, tar = _pairs(940, B, n, m)
+    ln = _lines(L, prs, nl)
+    R, t = _poses(B, 1)
+    ref = ops.LossStep(src, tar, nl)
+    ref.chain = False
+    want = _snapshot(ref, ref(R, t, ln))
+    st = ops.LossStep(src, tar, nl)
+    st(R, t, ln)
+    g = GraphedStep(lambda: st(R, t, ln))
+    for _ in range(4):
+        st.st.lmax.fill_(-7.0)
+        out = g()
+        torch.cuda.synchronize()
+        _assert_same(want, _snapshot(st, out), "replay")
+        assert bool((st.st.lmax == -7.0).all())
