@@ -82,6 +82,26 @@ __device__ __forceinline__ T dist_sq(float px, float py, float pz, T ux, T uy, T
     return x + RRL_EPS;
 }
 
+// ---- agent-coherent (sc1) accesses for data handed from one workgroup to another INSIDE a launch (the chained step's build +
+//      scan launch, rrl_cull_scan.inc; cdna_hip_programming.md Guideline 16 R1): the producer's 16-byte stores are
+//      WRITE-THROUGH (no release fence: every storing wave drains, barrier, one relaxed ticket), the consumer's loads bypass
+//      its CU's L1 (no acquire fence).  16-byte accesses go through a buffer descriptor built from wave-uniform values
+//      (base: kernel argument + blockIdx-derived offset; bytes < 2^31), 4-byte ones are relaxed agent-scope atomics.
+typedef unsigned int rrl_v4u __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rrl_rsrc(const void *base, size_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, (int)(bytes > 0x7ffffff0u ? 0x7ffffff0u : bytes), 0x00020000);
+}
+__device__ __forceinline__ void st16_sc1(__amdgpu_buffer_rsrc_t r, unsigned byte_off, float4 v) {
+    const rrl_v4u u = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+    __builtin_amdgcn_raw_buffer_store_b128(u, r, (int)byte_off, 0, 16);
+}
+__device__ __forceinline__ float4 ld16_sc1(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    const rrl_v4u u = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 16);
+    return make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
+}
+__device__ __forceinline__ void st4_sc1(float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld4_sc1(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 __device__ __forceinline__ float norm3(float x, float y, float z) {
     float s = x * x;
     s = s + y * y;

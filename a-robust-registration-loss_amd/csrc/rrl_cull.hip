@@ -215,6 +215,9 @@ __global__ __launch_bounds__(REC_BLK) void line_max_kernel(const float *__restri
 // (+inf for non-finite coordinates).
 // prow: the row of PTRI the record goes to -- f (original order: the cold build) or the triangle's SORTED position (prepared
 // build: the culled scan then resolves a candidate from its position alone, without the IDX hop; the record carries f).
+// PUB (the chained step's build + scan launch): the record and its NaN reach are read by other workgroups of the SAME launch
+// -- write-through (sc1) stores, rrl_common.h; TRI1 is read by later launches only: plain.
+template <bool PUB = false>
 __device__ __forceinline__ void tri_record_row(const BuildArgs &a, int cloud, int b, int n, int f, int prow, float (&c)[9],
                                                float &x, float &p2) {
     const float *raw = (cloud ? a.tri2 : a.tri1) + ((size_t)input_of(b, a.Bt) * n + f) * 9;
@@ -244,12 +247,23 @@ __device__ __forceinline__ void tri_record_row(const BuildArgs &a, int cloud, in
     tri_thresholds(c, &thr, &x, &e01);  // code/loss.py:94-110
     // NaN reach (culled scan, "NaN detection" in the header): points 1, 2 lie within e01 of point 0, and the
     // tree nodes carry thr: del >= e01 - thr in exact arithmetic (e01, thr as rounded here: <= 3u off)
-    if (float *del = cloud ? a.del2 : a.del1)  // (at the record's row, like PTRI)
-        del[(size_t)b * n + prow] = fmaxf(e01 * 1.000002f - thr, 0.0f) * 1.000001f;
+    if (float *del = cloud ? a.del2 : a.del1) {  // (at the record's row, like PTRI)
+        const float dv = fmaxf(e01 * 1.000002f - thr, 0.0f) * 1.000001f;
+        if constexpr (PUB) st4_sc1(&del[(size_t)b * n + prow], dv);
+        else del[(size_t)b * n + prow] = dv;
+    }
+    if constexpr (PUB) {
+        const __amdgpu_buffer_rsrc_t rs = rrl_rsrc((cloud ? a.ptri2 : a.ptri1) + (size_t)b * n * PTRI_STRIDE, (size_t)n * PTRI_STRIDE * 4);
+        const unsigned o = (unsigned)prow * (PTRI_STRIDE * 4);
+        st16_sc1(rs, o, make_float4(c[0], c[1], c[2], c[3]));
+        st16_sc1(rs, o + 16, make_float4(c[4], c[5], c[6], c[7]));
+        st16_sc1(rs, o + 32, make_float4(c[8], x, thr, __int_as_float(f)));
+    } else {
     float4 *row = (float4 *)((cloud ? a.ptri2 : a.ptri1) + ((size_t)b * n + prow) * PTRI_STRIDE);
     row[0] = make_float4(c[0], c[1], c[2], c[3]);
     row[1] = make_float4(c[4], c[5], c[6], c[7]);
     row[2] = make_float4(c[8], x, thr, __int_as_float(f));
+    }
     p2 = 0.0f;
 #pragma unroll
     for (int q = 0; q < 3; ++q)
@@ -370,6 +384,9 @@ __global__ __launch_bounds__(REC_BLK) void tri_records_kernel(const BuildArgs a)
 // sorted positions [bxr * blockDim.x, + blockDim.x) of (cloud, sample).  red: LDS [blockDim.x / 64][8].  (One body for
 // tri_records_sorted_kernel and for the chained step's build + scan launch, cull_scan_build_kernel, whose leading workgroups
 // run it with the scan's 512 lanes.)
+// PUB: everything the culled scan reads of this cloud -- PTRI, DEL, P0S, the tree nodes, the partial rows -- leaves by
+// write-through (sc1) stores: other workgroups of the same launch read it (cdna_hip_programming.md Guideline 16 R1).
+template <bool PUB = false>
 __device__ __forceinline__ void records_sorted_body(const BuildArgs &a, const int32_t *__restrict__ order1,
                                                     const int32_t *__restrict__ order2, const RecPlace &pl, float (*red)[8]) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -385,13 +402,22 @@ __device__ __forceinline__ void records_sorted_body(const BuildArgs &a, const in
     if (valid) {
         f = (cloud ? order2 : order1)[(size_t)input_of(b, a.Bt) * npad + s];
         f = min(max(f, 0), n - 1);  // memory safety only: the order must be a permutation of [0, n)
-        tri_record_row(a, cloud, b, n, f, s, c, x, p2);
+        tri_record_row<PUB>(a, cloud, b, n, f, s, c, x, p2);
     }
     if (threadIdx.x < 64 && __float_as_int(c[0] + c[4] + c[8] + x) != 0x12345678) STAMPR(2);
     if (s - lane < npad) {  // wave-uniform: this wavefront holds a supergroup
-        (cloud ? a.p0s2 : a.p0s1)[(size_t)b * npad + s] = valid ? make_float4(c[0], c[1], c[2], x) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        const float4 rec = valid ? make_float4(c[0], c[1], c[2], x) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         (cloud ? a.idx2 : a.idx1)[(size_t)b * npad + s] = f;
-        wave_tree(c[0], c[1], c[2], x, valid, lane, (cloud ? a.grp2 : a.grp1) + ((size_t)b * (npad / SGT) + (s - lane) / SGT) * NODE);
+        float4 *nodes = (cloud ? a.grp2 : a.grp1) + (size_t)b * (npad / SGT) * NODE;
+        if constexpr (PUB) {
+            st16_sc1(rrl_rsrc((cloud ? a.p0s2 : a.p0s1) + (size_t)b * npad, (size_t)npad * 16), (unsigned)s * 16u, rec);
+            const __amdgpu_buffer_rsrc_t ns = rrl_rsrc(nodes, (size_t)(npad / SGT) * NODE * 16);
+            const unsigned nb0 = (unsigned)((s - lane) / SGT) * (NODE * 16u);
+            wave_tree_put(c[0], c[1], c[2], x, valid, lane, [&](int j, float4 v) { st16_sc1(ns, nb0 + 16u * (unsigned)j, v); });
+        } else {
+            (cloud ? a.p0s2 : a.p0s1)[(size_t)b * npad + s] = rec;
+            wave_tree(c[0], c[1], c[2], x, valid, lane, nodes + (size_t)((s - lane) / SGT) * NODE);
+        }
     }
     if (threadIdx.x < 64) STAMPR(3);
     // partial AABB of the P0s and max |P|^2 per REC_BLK = 256 sorted positions (APART rows), as tri_records_kernel leaves them
@@ -414,7 +440,8 @@ __device__ __forceinline__ void records_sorted_body(const BuildArgs &a, const in
             r = red[w0][q];
             for (int w = 1; w < REC_BLK / 64; ++w) r = q < 3 ? fminf(r, red[w0 + w][q]) : fmaxf(r, red[w0 + w][q]);
         }
-        a.apart[(((size_t)cloud * B + b) * a.nblk + row) * 8 + q] = r;
+        float *dst = &a.apart[(((size_t)cloud * B + b) * a.nblk + row) * 8 + q];
+        if constexpr (PUB) st4_sc1(dst, r); else *dst = r;
     }
 }
 

@@ -162,7 +162,10 @@ __device__ __forceinline__ float xrow_max(float v) {
 // The 13 tree nodes of ONE supergroup by the wavefront whose lanes hold its 64 sorted records (valid: a real record).
 // Expressions and association as in half_tree (rrl_tree.h): centre = mid-point of the node's AABB, rho^2 = max squared
 // distance of its records, thr_max = sqrt(max thr2) (1 + 1e-6): min / max are exact, so the nodes are bit-identical.
-__device__ __forceinline__ void wave_tree(float px, float py, float pz, float thr2, bool valid, int lane, float4 *__restrict__ node) {
+// put(j, v): node j of the supergroup := v (a plain store, or the write-through one of a records body whose nodes another
+// workgroup of the same launch reads: records_sorted_body<true>)
+template <class Put>
+__device__ __forceinline__ void wave_tree_put(float px, float py, float pz, float thr2, bool valid, int lane, Put put) {
     float lo[3] = {valid ? px : INFINITY, valid ? py : INFINITY, valid ? pz : INFINITY};
     float hi[3] = {valid ? px : -INFINITY, valid ? py : -INFINITY, valid ? pz : -INFINITY};
     float tm2 = valid ? thr2 : 0.0f, any = valid ? 1.0f : 0.0f;
@@ -180,7 +183,7 @@ __device__ __forceinline__ void wave_tree(float px, float py, float pz, float th
         const float cx = 0.5f * lo[0] + 0.5f * hi[0], cy = 0.5f * lo[1] + 0.5f * hi[1], cz = 0.5f * lo[2] + 0.5f * hi[2];
         float d2 = dist2(cx, cy, cz);
         OCT_MAX(d2);
-        if ((lane & 7) == 0) node[5 + (lane >> 3)] = finish_sphere(cx, cy, cz, d2, tm, any > 0.0f);
+        if ((lane & 7) == 0) put(5 + (lane >> 3), finish_sphere(cx, cy, cz, d2, tm, any > 0.0f));
     }
 #pragma unroll
     for (int c = 0; c < 3; ++c) { lo[c] = fminf(lo[c], RRL_DPP_F(lo[c], 0x140)); hi[c] = fmaxf(hi[c], RRL_DPP_F(hi[c], 0x140)); }
@@ -189,7 +192,7 @@ __device__ __forceinline__ void wave_tree(float px, float py, float pz, float th
     {   // the group of 16 (one DPP row)
         const float cx = 0.5f * lo[0] + 0.5f * hi[0], cy = 0.5f * lo[1] + 0.5f * hi[1], cz = 0.5f * lo[2] + 0.5f * hi[2];
         const float d2 = row16_max(dist2(cx, cy, cz));
-        if ((lane & 15) == 0) node[1 + (lane >> 4)] = finish_sphere(cx, cy, cz, d2, tm, any > 0.0f);
+        if ((lane & 15) == 0) put(1 + (lane >> 4), finish_sphere(cx, cy, cz, d2, tm, any > 0.0f));
     }
 #pragma unroll
     for (int c = 0; c < 3; ++c) { lo[c] = xrow_min(lo[c]); hi[c] = xrow_max(hi[c]); }
@@ -198,8 +201,11 @@ __device__ __forceinline__ void wave_tree(float px, float py, float pz, float th
     {   // the supergroup
         const float cx = 0.5f * lo[0] + 0.5f * hi[0], cy = 0.5f * lo[1] + 0.5f * hi[1], cz = 0.5f * lo[2] + 0.5f * hi[2];
         const float d2 = wave_max(dist2(cx, cy, cz));
-        if (lane == 0) node[0] = finish_sphere(cx, cy, cz, d2, tm, any > 0.0f);
+        if (lane == 0) put(0, finish_sphere(cx, cy, cz, d2, tm, any > 0.0f));
     }
+}
+__device__ __forceinline__ void wave_tree(float px, float py, float pz, float thr2, bool valid, int lane, float4 *__restrict__ node) {
+    wave_tree_put(px, py, pz, thr2, valid, lane, [&](int j, float4 v) { node[j] = v; });
 }
 
 #define SORT_CELLS 4096  // 16^3 grid cells in Hilbert-curve order

@@ -269,6 +269,9 @@ def _target_ws(target_from, B, N, M, L):
     # the workspace that HOLDS the target's scan (records, hit counts and lists): of the full evaluation at the end of a chain
     # of carried-over ones
     tgt = getattr(target_from, "target_state", None) or target_from
+    if getattr(tgt, "counts_cleared", False):
+        raise ValueError("target_from: that state's hit counts were cleared by a chained step (RRL_F_CHAIN); build the step "
+                         "whose target is carried over with chain=False")
     return _p(tgt.ws)
 
 
@@ -922,7 +925,7 @@ class RegistrationStep:
 
     def __init__(self, src_tri, tar_tri, n_lines, rng=(1, 1, 5, 5), transpose_r=True, mode="cull", chunk=0,
                  want_payload=False, prepared=None, src_order=None, tar_order=None, reduce_mode=None, deterministic=None,
-                 sort_parts=None, chamfer=False, poses=1):
+                 sort_parts=None, chamfer=False, poses=1, chain=False):
         """reduce_mode / deterministic / sort_parts: per-call options of THIS step object (include/rrl.h rrl_opts; None =
         the library default) -- they travel with every call, so two steps with different options can run from two
         threads on two streams at the same time (tests/test_gpu_threads.py).
@@ -974,6 +977,11 @@ class RegistrationStep:
         self.prepared = bool(prepared) and mode == "cull" and max(N, M) <= 65536
         self._kept_key = None  # _write_key of the target whose records the workspace holds
         self.keep_target = True  # False: rebuild the target's records in every call (see invalidate_target)
+        # chained steps (round 6; include/rrl.h RRL_F_CHAIN / RRL_F_CHAINED; see LossStep).  OFF by default here: a chained
+        # step clears its hit counts on exit, and this step's state is what callers hand on as target_from= (RPM / FMR)
+        self.chain = bool(chain)
+        self._chain_left = ctypes.c_int32(0)
+        self._chain_ready = False
         self.order1 = self.order2 = None
         if self.prepared:
             self.order1 = _check_order(src_order, Bt, N, dev, "src_order") if src_order is not None else cloud_order(self.src)
@@ -994,6 +1002,12 @@ class RegistrationStep:
         self._opts_kept = make_opts(order1=self.order1, order2=self.order2, target_kept=True, **self._extra) if self.prepared else self._opts
         self._optr = ctypes.byref(self._opts) if self._opts is not None else None
         self._optr_kept = ctypes.byref(self._opts_kept) if self._opts_kept is not None else None
+        self._chain_ready = False
+        if self.prepared:  # first / kept / chained (as LossStep)
+            kw = dict(order1=self.order1, order2=self.order2, chain_left=self._chain_left, **self._extra)
+            self._opts_c = (make_opts(chain=_lib.F_CHAIN, **kw), make_opts(target_kept=True, chain=_lib.F_CHAIN, **kw),
+                            make_opts(target_kept=True, chain=_lib.F_CHAIN | _lib.F_CHAINED, **kw))
+            self._optr_c = tuple(ctypes.byref(o) for o in self._opts_c)
 
     def __call__(self, R, t, line, grad_loss=None, src_tri=None, tar_tri=None, target_from=None, src_order=None,
                  tar_order=None):
@@ -1023,8 +1037,14 @@ class RegistrationStep:
                     self._kept_key = None
                 self._set_opts()
             key = _write_key(self.tar) if (self.keep_target and target_from is None) else None
-            op = self._optr_kept if (key is not None and key == self._kept_key) else self._optr
+            kept = key is not None and key == self._kept_key
+            if self.chain and RegistrationStep.ONE_CALL and target_from is None:
+                op = self._optr_c[2 if (kept and self._chain_ready) else (1 if kept else 0)]
+            elif kept:
+                op = self._optr_kept
             self._kept_key = None  # (set again below, once the call has been issued: a call that raises keeps nothing)
+        self._chain_ready = False
+        self._chain_left.value = 0
         Rm, tv, ln = _prep(R, "R", None, dev), _prep(t, "t", None, dev), _prep(line, "line", 6, dev)
         if Rm.numel() != B * 9 or tv.numel() != B * 3 or tuple(ln.shape) != (Bt, L, 6):
             raise ValueError("R (poses * B, 3, 3), t (poses * B, 3), line (B, L, 6) expected")
@@ -1050,6 +1070,8 @@ class RegistrationStep:
                       "rrl_registration_backward")
         if self.prepared:
             self._kept_key = key  # (None for a carried-over target -- it is not built here -- and with keep_target off)
+            self._chain_ready = self._chain_left.value == 1
+        self.st.counts_cleared = self._chain_ready
         _IntersectionLoss.last_state = self.st
         if self.ride is not None:  # .chamfer_value: this step's monitor (it rode in the scan's launch, or one launch now)
             _keep_ride(self.st, self.ride)
@@ -1070,8 +1092,13 @@ class LossStep:
     gradient to the rounding of the scatter's float atomics.  prepared / src_order / tar_order as RegistrationStep."""
 
     def __init__(self, src_tri, tar_tri, n_lines, rng=(1, 1, 5, 5), transpose_r=True, mode="cull", chunk=0,
-                 prepared=None, src_order=None, tar_order=None, chamfer=False, want_payload=False, poses=1):
-        """chamfer=True: every step also leaves the Chamfer monitor of its clouds in .chamfer_value -- its walk rides in the
+                 prepared=None, src_order=None, tar_order=None, chamfer=False, want_payload=False, poses=1, chain=True):
+        """chain=True (default; round 6, include/rrl.h RRL_F_CHAIN / RRL_F_CHAINED): from its second call on, while the target is
+        kept, the step runs the source's records, the target's scan and the source's scan as ONE launch (three launches per
+        step instead of four, same loss bits).  A chained step leaves .st.count1 / .st.count2 CLEARED (the per-line stage
+        zeroes them behind its read; .st.kj / hs1 / hs2 hold what it read) and does not update .st.status -- info[:, 3] is then
+        each sample's OWN NaN flag instead of the batch-wide STATUS[0] --, and its state cannot serve as target_from=.
+        chamfer=True: every step also leaves the Chamfer monitor of its clouds in .chamfer_value -- its walk rides in the
         step's scan launch (ChamferRide), as in RegistrationStep.
         want_payload=True: .payload (14,) = [sum of the valid losses, #valid, 0 x 12] after every step -- what a rank
         contributes to the all-reduce of the scalar loss (rrl_hip.dist; points1.grad stays local).
@@ -1107,12 +1134,12 @@ class LossStep:
         self.keep_target = True  # see RegistrationStep.invalidate_target
         # (in the workspace's accumulator field: the step's first launch clears it, as for RegistrationStep)
         self.payload = self.st.gacc[B * 12:B * 12 + 14] if want_payload else None
-        self._opts = self._opts_kept = self._opts_chained = make_opts(chamfer=self.ride, payload=self.payload, problems=prob)  # (None without any)
+        self._opts = self._opts_kept = make_opts(chamfer=self.ride, payload=self.payload, problems=prob)  # (None without any)
         # CHAINED steps (round 6; include/rrl.h RRL_F_CHAIN / RRL_F_CHAINED): every prepared step asks the library to leave
         # the workspace's hit counts cleared (the library says through _chain_left whether it did); a step that follows such
         # a step with the target still kept runs records + target scan + source scan as ONE launch.  chain = False turns
         # it off for this object (RRL_CHAIN=0 for the process).
-        self.chain = True
+        self.chain = bool(chain)
         self._chain_left = ctypes.c_int32(0)
         self._chain_ready = False  # the previous call on self.st left it chain-clean and nothing has touched it since
         if self.prepared:
@@ -1120,10 +1147,12 @@ class LossStep:
             self.order2 = _check_order(tar_order, Bt, M, dev, "tar_order") if tar_order is not None else cloud_order(self.tar)
             kw = dict(order1=self.order1, order2=self.order2, chamfer=self.ride, payload=self.payload, problems=prob,
                       chain_left=self._chain_left)
-            self._opts = make_opts(chain=_lib.F_CHAIN, **kw)
-            self._opts_kept = make_opts(target_kept=True, chain=_lib.F_CHAIN, **kw)
-            self._opts_chained = make_opts(target_kept=True, chain=_lib.F_CHAIN | _lib.F_CHAINED, **kw)
-        self._optr, self._optr_kept, self._optr_chained = _optr(self._opts), _optr(self._opts_kept), _optr(self._opts_chained)
+            self._opts = make_opts(**kw)  # (.chain = False: no chain flags at all -- the hit counts stay readable)
+            self._opts_kept = make_opts(target_kept=True, **kw)
+            self._opts_c = (make_opts(chain=_lib.F_CHAIN, **kw), make_opts(target_kept=True, chain=_lib.F_CHAIN, **kw),
+                            make_opts(target_kept=True, chain=_lib.F_CHAIN | _lib.F_CHAINED, **kw))
+            self._optr_c = tuple(_optr(o) for o in self._opts_c)  # first / kept / chained
+        self._optr, self._optr_kept = _optr(self._opts), _optr(self._opts_kept)
         self._lib = _lib.load()
 
     def invalidate_target(self):
@@ -1143,8 +1172,11 @@ class LossStep:
         op, key = self._optr, None
         if self.prepared:
             key = _write_key(self.tar) if self.keep_target else None
-            if key is not None and key == self._kept_key:
-                op = self._optr_chained if (self._chain_ready and self.chain) else self._optr_kept
+            kept = key is not None and key == self._kept_key
+            if self.chain:
+                op = self._optr_c[2 if (kept and self._chain_ready) else (1 if kept else 0)]
+            elif kept:
+                op = self._optr_kept
             self._kept_key = None  # (set below, once the call has been issued)
         self._chain_ready = False
         self._chain_left.value = 0
@@ -1157,6 +1189,7 @@ class LossStep:
                   "rrl_loss_step")
         self._kept_key = key
         self._chain_ready = self.prepared and self._chain_left.value == 1
+        self.st.counts_cleared = self._chain_ready
         _IntersectionLoss.last_state = self.st
         if self.ride is not None:
             _keep_ride(self.st, self.ride)

@@ -111,7 +111,8 @@ enum {
     RRL_WS_MED,        /* float[G]  lower median (loss.py:223-224)                          */
     RRL_WS_BCNT,       /* int32[G][16] lines per (k,j) bucket                               */
     RRL_WS_BSUM,       /* int64[G][16][2] bucket sums of row / column minima, 2^-40 fixed pt */
-    RRL_WS_INFO,       /* int32[G][4] nbuckets, nselected, nvalues, STATUS[0] (the scan's NaN flag)  */
+    RRL_WS_INFO,       /* int32[G][4] nbuckets, nselected, nvalues, STATUS[0] (the scan's NaN flag; after a CHAINED step's fused
+                          launch: the sample's OWN flag, CHAIN[b][1])  */
     RRL_WS_TRI1,       /* float[B][N][9] transformed source triangles (rrl_registration_*)   */
     RRL_WS_G1,         /* float[B][N][9] gradient w.r.t. TRI1 (rrl_registration_backward)    */
     RRL_WS_RPART,      /* float[B][nblk][12] rigid-apply backward partial sums              */
@@ -172,7 +173,10 @@ const char *rrl_version(void);
  *   - RRL_F_CHAINED is valid only when the PREVIOUS call on this workspace reported chain_left = 1 and nothing else has
  *     written the workspace since; it needs RRL_F_TARGET_KEPT and is ignored (plain 4-launch step) whenever the fused
  *     launch cannot serve the call (rider, counters, multi-pose, other reduce kernels, thin grids);
- *   - after a chained step COUNT1 / COUNT2 read zero, STATUS is not updated (INFO[b][3] carries the NaN flag per sample). */
+ *   - after a step with RRL_F_CHAIN COUNT1 / COUNT2 read zero (KJ / HS1 / HS2 hold what the per-line stage read), so its
+ *     workspace cannot serve as another call's target_ws; after a step whose build was fused STATUS is not updated:
+ *     INFO[b][3] carries each sample's OWN NaN flag (the plain step reports the batch-wide STATUS[0] in every row), and a
+ *     source workgroup that gave up waiting for its records (RRL_CHAIN_SPIN polls; CHAIN[b][3]) makes that sample's loss NaN. */
 #define RRL_F_CHAIN 2
 #define RRL_F_CHAINED 4
 /* A Chamfer walk carried by the evaluation's own scan launch (round 4b).  rrl_chamfer_from_loss -- the monitor every caller

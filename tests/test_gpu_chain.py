@@ -66,10 +66,12 @@ def _assert_same(a, b, what):
     assert bool(((ga - gb).abs() <= 2e-5 * ga.abs() + 2e-6 * float(ga.abs().max())).all()), what
 
 
-@pytest.mark.parametrize("B,n,m,nl,scale", [(2, 1200, 1000, 6000, 1.0), (8, 4096, 4096, 10000, 1.0), (1, 1024, 1024, 20000, 1.0),
-                                            (3, 700, 900, 4000, 1.0), (1, 5000, 4100, 3000, 1.0), (2, 1000, 1200, 5000, 12.0),
-                                            (16, 500, 400, 2500, 1.0), (5, 330, 260, 1100, 1.0)])
-def test_chained_steps_equal_unchained_steps(L, B, n, m, nl, scale):
+@pytest.mark.parametrize("B,n,m,nl,scale,fusable", [
+    (2, 1200, 1000, 6000, 1.0, True), (8, 4096, 4096, 10000, 1.0, True), (1, 1024, 1024, 20000, 1.0, True),
+    (3, 700, 900, 4000, 1.0, True), (1, 5000, 4100, 3000, 1.0, True), (2, 1000, 1200, 5000, 12.0, True),
+    (16, 500, 400, 2500, 1.0, True), (12, 4096, 4096, 10000, 1.0, True),  # (the last one: the fat scan variant, scan16)
+    (5, 330, 260, 1100, 1.0, False)])  # (a grid so thin that the scan runs fewer than 8 wavefronts per workgroup: the plain four launches)
+def test_chained_steps_equal_unchained_steps(L, B, n, m, nl, scale, fusable):
     from rrl_hip import ops
     prs, src, tar = _pairs(900, B, n, m)
     src, tar = src * scale, tar * scale
@@ -90,12 +92,12 @@ def test_chained_steps_equal_unchained_steps(L, B, n, m, nl, scale):
         assert torch.equal(plain.payload[:2], chained.payload[:2]) or abs(float(plain.payload[0] - chained.payload[0])) < 1e-5
         was_fused = bool((chained.st.lmax == -7.0).all())
         fused += was_fused
-        assert was_fused == (it > 0), (it, "the second and later steps of a chain run the fused launch")
+        assert was_fused == (it > 0 and fusable), (it, "the second and later steps of a chain run the fused launch")
         # what a chained step leaves behind: cleared counts and CHAIN words; the unchained one keeps its counts
         assert int(chained.st.count1.abs().max()) == 0 and int(chained.st.count2.abs().max()) == 0
         assert int(chained.st.chain.abs().max()) == 0
         assert int(plain.st.count1.max()) > 0
-    assert fused == 4
+    assert fused == (4 if fusable else 0)
     assert int(b["info"][:, 1].min()) > 0 and int(b["info"][:, 3].max()) == 0
 
 
@@ -139,7 +141,8 @@ def test_chain_is_broken_by_a_new_target_and_resumes(L):
     st.chain = False
     run(False, "chain off")
     st.chain = True
-    run(True, "chain on again (the unfused step still left the counts cleared)")
+    run(False, "chain on again: the step before it left its counts in place")
+    run(True, "and resumed")
     st.keep_target = False
     run(False, "keep_target off")
 
@@ -165,3 +168,28 @@ def test_chained_step_under_graph_replay(L):
         torch.cuda.synchronize()
         _assert_same(want, _snapshot(st, out), "replay")
         assert bool((st.st.lmax == -7.0).all())
+
+
+@pytest.mark.parametrize("B,n,m,nl", [(2, 1200, 1000, 6000), (8, 4096, 4096, 10000), (1, 1024, 1024, 20000)])
+def test_chained_registration_steps(L, B, n, m, nl):
+    """The fused training op (ops.RegistrationStep: backward straight to (dR, dt) in the tail kernel) chains the same way:
+    loss / info / median bit for bit, (dR, dt) and the shard payload to the rounding of their float atomics."""
+    from rrl_hip import ops
+    prs, src, tar = _pairs(960, B, n, m)
+    plain = ops.RegistrationStep(src, tar, nl, want_payload=True)  # (chain=False is this class's default: its state is handed on as target_from=)
+    chained = ops.RegistrationStep(src, tar, nl, want_payload=True, chain=True)
+    for it in range(4):
+        ln = _new_lines(L, prs, nl, it)
+        R, t = _poses(B, it)
+        chained.st.lmax.fill_(-7.0)
+        a = [x.clone() for x in plain(R, t, ln)]
+        b = [x.clone() for x in chained(R, t, ln)]
+        torch.cuda.synchronize()
+        assert torch.equal(a[0], b[0]) and torch.equal(a[4], b[4]) and torch.equal(plain.st.med, chained.st.med)
+        assert torch.equal(plain.st.kj, chained.st.kj) and torch.equal(plain.st.bsum, chained.st.bsum)
+        for x, y in ((a[1], b[1]), (a[2], b[2]), (a[3], b[3])):
+            np.testing.assert_allclose(y.cpu().numpy(), x.cpu().numpy(), rtol=2e-4, atol=2e-6 * float(x.abs().max()))
+        assert bool((chained.st.lmax == -7.0).all()) == (it > 0)
+        assert int(chained.st.count1.abs().max()) == 0 and int(chained.st.chain.abs().max()) == 0
+    with pytest.raises(ValueError):
+        plain(R, t, ln, target_from=chained.st)  # a chained step's hit counts are gone: it cannot lend its target's scan

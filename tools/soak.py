@@ -56,7 +56,9 @@ def run(seed=0, n_cases=150, log=print):
                   ops.set_reduce_mode("tiled")
               for one in (False, True):
                   ops.RegistrationStep.ONE_CALL = one
-                  rs = ops.RegistrationStep(src, tar, Ln, transpose_r=bool(case & 2), want_payload=True, prepared=one)  # two calls + cold build vs one call + prepared build
+                  # two calls + cold build vs one call + prepared build, the latter CHAINED (round 6): its second and third call run
+                  # records + both scans as one launch
+                  rs = ops.RegistrationStep(src, tar, Ln, transpose_r=bool(case & 2), want_payload=True, prepared=one, chain=one)
                   for _ in range(3):
                       out = rs(R.detach(), t.detach(), lines)
                   torch.cuda.synchronize()
@@ -65,7 +67,13 @@ def run(seed=0, n_cases=150, log=print):
               ops.RegistrationStep.ONE_CALL = True
               ops.set_reduce_mode("auto")
           nanok = lambda a, b: torch.equal(a, b) or (a.dtype.is_floating_point and torch.equal(torch.nan_to_num(a, nan=-7.0), torch.nan_to_num(b, nan=-7.0)))
+          # (info[:, 3]: the batch-wide NaN flag after an unchained step, each sample's own after a chained one: compare "any")
+          for r_ in res.values():
+              r_[2] = torch.cat([r_[2][:, :3], r_[2][:, 3:].max().expand(r_[2].shape[0], 1)], 1)
           step = all(nanok(a, b) for a, b in zip(res[False][:4], res[True][:4]))
+          if not step and os.environ.get("RRL_SOAK_VERBOSE"):
+              log("  step items (loss, med, info, bsum): " + str([nanok(a, b) for a, b in zip(res[False][:4], res[True][:4])]) +
+                  " info " + str(res[False][2].tolist()) + " vs " + str(res[True][2].tolist()))
           for a, b in zip(res[False][4:], res[True][4:]):
               a, b = torch.nan_to_num(a, nan=-7.0), torch.nan_to_num(b, nan=-7.0)
               step = step and bool(((a - b).abs() <= 2e-5 * a.abs() + 2e-6 * float(a.abs().max()) + 1e-12).all())
