@@ -90,11 +90,11 @@ def make_workload(B, N, M, L, rank, dev):
         tar.append(pr["tar"]); rad.append(pr["radius"]); ctr.append(pr["center"])
     to = lambda a: torch.from_numpy(np.stack(a)).to(dev)  # noqa: E731
     w = dict(tri1=to(tri1), tri2=to(tri2), src=to(src), tar=to(tar))
+    w["radius"], w["center"] = torch.tensor(rad).reshape(B, 1), torch.from_numpy(np.stack(ctr))
     torch.manual_seed(1000 * rank)  # CPU seed selects the sampler's uniform streams
     t0 = time.perf_counter()
     w["lines"] = Lmod.Random_uniform_distribution_lines_batch_efficient_resample(
-        torch.tensor(rad).reshape(B, 1), torch.from_numpy(np.stack(ctr)), L, w["src"], w["tar"],
-        dev)
+        w["radius"], w["center"], L, w["src"], w["tar"], dev)
     torch.cuda.synchronize()
     w["sample_s"] = time.perf_counter() - t0
     # per-sample "predicted" transforms (what RPM/DCP/FMR hand to the loss): small rotations
@@ -127,6 +127,7 @@ def cpu_baseline(N, M, L, budget_s=12.0, eager_budget_s=8.0):
         done += 1
     pairs = done * L * 3 * (N + M)
     c_port = {"value": pairs / spent, "unit": "point-pairs/s", "cores": cores, "kind": "port",
+              "formulation": "oracle/rrl_oracle.c: fused C restatement (nothing of size L x N materialised), OpenMP over lines",
               "sample": f"{done} evaluation(s) of one N=M={N}, L={L} sample, loss fwd+bwd, oracle/rrl_oracle.c "
                         f"(fused C restatement) with OpenMP on {cores} threads, {spent:.1f} s"}
     try:
@@ -149,6 +150,11 @@ def cpu_baseline(N, M, L, budget_s=12.0, eager_budget_s=8.0):
         nl = int(max(probe, min(L, probe * eager_budget_s / max(tp, 1e-3))))
         te, val = run(nl)
         return {"value": nl * 3 * (N + M) / te, "unit": "point-pairs/s", "cores": eth, "kind": "port",
+                "formulation": "torch-eager: the reference's own op sequence (code/loss.py:68-232) in torch CPU ops + autograd, "
+                               "evaluated in CHUNKS of 64 lines (cache-resident temporaries; the reference materialises the whole "
+                               "(L, N, 3, 3) tensors at once and is slower: BASELINE.md ~14 s per sample on 8 cores) -- the chunking "
+                               "errs in the CPU's favour",
+                "chunk_lines": 64,
                 "sample": f"one N=M={N} sample, first {nl} of its {L} lines, loss fwd+bwd by autograd, "
                           f"oracle/torch_eager.py (the reference's materialising op sequence, code/loss.py:68-232) "
                           f"with torch.set_num_threads({eth}) (of {cores} host threads), {te:.1f} s",
@@ -159,6 +165,58 @@ def cpu_baseline(N, M, L, budget_s=12.0, eager_budget_s=8.0):
         out["torch_eager_error"] = f"{type(exc).__name__}: {exc}"
         out["c_port"] = c_port
         return out
+
+
+def parity_in_run(w, Rd, Td, moved_gpu, loss, grad, info, samples):
+    """The TIMED object against the oracle on the TIMED workload, for the given samples:
+    (W, G on identical inputs) the oracle evaluates code/loss.py:170-232 + the closed-form gradient on the triangles the timed
+        step itself moved (its TRI1 field): loss (rel 1e-5), the selected-line / D-value / bucket counts (EXACT: every label of
+        the 2 x L x N scan enters them), points1.grad per POINT (1e-4; sums over the rows that hold the same 3-D point:
+        independent of tie-breaks between duplicate pseudo-triangles, SURVEY hard part 3);
+    (T) the step's moved triangles against the oracle's own rigid apply x R^T + t (unfused mul/add; the kernel uses FMAs):
+        max abs difference relative to the cloud's extent (a few 1e-8: one rounding);
+    (end to end, reported, not gated) the oracle on ITS OWN moved triangles: a 1-ulp different input flips the few labels that
+        sit on a threshold (fragments 2e-4).
+    Checker only: outside the timed region."""
+    from oracle import rrl_oracle
+    rrl_oracle.build()
+    out = {"samples": list(samples), "loss_rel_max": 0.0, "grad_per_point_rel_max": 0.0, "labels_equal": True,
+           "rigid_apply_rel_max": 0.0, "per_sample": []}
+    t0 = time.perf_counter()
+    for b in samples:
+        src = w["tri1"][b].cpu().numpy()
+        tar, lines = w["tri2"][b].cpu().numpy(), w["lines"][b].cpu().numpy()
+        moved = moved_gpu[b].cpu().numpy().reshape(-1, 9)
+        ref = rrl_oracle.loss(moved, tar, lines, want_grad=True)
+        mine_loss, mine_info = float(loss[b]), [int(v) for v in info[b].tolist()]
+        rel = abs(mine_loss - float(ref["loss"])) / max(abs(float(ref["loss"])), 1e-30) if ref["loss"] is not None else float("nan")
+        same = mine_info[:3] == [ref["n_buckets"], ref["n_selected"], ref["n_values"]] and bool(mine_info[3]) == bool(ref["nan"])
+        _, inv = np.unique(moved.reshape(-1, 3), axis=0, return_inverse=True)
+        a_, b_ = np.zeros((inv.max() + 1, 3)), np.zeros((inv.max() + 1, 3))
+        np.add.at(a_, inv.reshape(-1), grad[b].cpu().numpy().astype(np.float64).reshape(-1, 3))
+        np.add.at(b_, inv.reshape(-1), np.asarray(ref["grad1"], np.float64).reshape(-1, 3))
+        grel = float(np.abs(a_ - b_).max() / max(np.abs(b_).max(), 1e-30))
+        moved_o = rrl_oracle.rigid_apply(src.reshape(-1, 3), Rd[b].cpu().numpy(), Td[b].cpu().numpy(), transpose_r=True).reshape(-1, 9)
+        trel = float(np.abs(moved_o - moved).max() / max(np.abs(moved_o).max(), 1e-30))
+        e2e = rrl_oracle.loss(moved_o, tar, lines, want_grad=False)
+        out["loss_rel_max"] = max(out["loss_rel_max"], rel)
+        out["grad_per_point_rel_max"] = max(out["grad_per_point_rel_max"], grel)
+        out["rigid_apply_rel_max"] = max(out["rigid_apply_rel_max"], trel)
+        out["labels_equal"] = out["labels_equal"] and same
+        out["per_sample"].append({"sample": b, "loss": mine_loss, "oracle_loss": float(ref["loss"]), "info": mine_info,
+                                  "oracle_counts": [ref["n_buckets"], ref["n_selected"], ref["n_values"], int(ref["nan"])],
+                                  "end_to_end": {"oracle_loss_on_its_own_rigid_apply": float(e2e["loss"]) if e2e["loss"] is not None else None,
+                                                 "counts": [e2e["n_buckets"], e2e["n_selected"], e2e["n_values"]],
+                                                 "loss_rel": abs(mine_loss - float(e2e["loss"])) / abs(float(e2e["loss"])) if e2e["loss"] else None}})
+    out["seconds"] = time.perf_counter() - t0
+    out["tolerances"] = {"loss_rel": 1e-5, "grad_per_point_rel": 1e-4, "counts": "exact", "rigid_apply_rel": 1e-6}
+    out["ok"] = bool(out["labels_equal"] and out["loss_rel_max"] <= 1e-5 and out["grad_per_point_rel_max"] <= 1e-4 and
+                     out["rigid_apply_rel_max"] <= 1e-6)
+    out["what"] = ("oracle/rrl_oracle.c (pinned to the reference's fixtures, tests/test_oracle_golden.py) on samples of the TIMED "
+                   "workload: W + G on the triangles the timed step moved (identical inputs: counts exact, loss 1e-5, per-point "
+                   "gradient 1e-4), T against the oracle's unfused rigid apply (1e-6 of the extent), and -- reported -- the oracle "
+                   "end to end on its own moved triangles")
+    return out
 
 
 def scan_roofline(ops, run_step, B, N, M, L, launches=20, counters=True):
@@ -243,11 +301,13 @@ def main():
                          "with the next step on a second stream (overlap), torch.distributed (torch); auto "
                          "measures inline vs overlap during warm-up when there is more than one rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip parity_in_run (the oracle's check of the timed workload)")
     ap.add_argument("--no-graph", action="store_true", help="never replay a hipGraph")
     ap.add_argument("--issue", choices=["auto", "graph", "direct"], default="auto",
                     help="how the step's launches are issued: the C call of ops.LossStep on the stream (direct), or one "
                          "hipGraph replay of it; auto measures both in warm-up")
     ap.add_argument("--no-extras", action="store_true", help="skip the variant / strict / counter / B=64 passes")
+    ap.add_argument("--no-fresh", action="store_true", help="skip variants.fresh_lines / fresh_clouds_cold")
     ap.add_argument("--no-other", action="store_true",
                     help="skip the other build of the step (value_cold / value_prepared): profiling passes want the timed "
                          "step's kernels only")
@@ -440,9 +500,17 @@ def main():
     dense_flops = FLOPS_PER_PAIR * pairs_step
     do_extras = rank == 0 and not args.no_extras
     other = None
+    parity = None
     if rank == 0:
         loss_default = ls.st.loss.clone()
         grad_default = ls.grad.clone()
+        info_default = ls.st.info.clone()
+        chained_step = bool(getattr(ls, "_chain_ready", False)) and ls.chain
+        if not args.no_parity:
+            try:
+                parity = parity_in_run(w, Rd, Td, ls.st.tri1t.clone(), loss_default, grad_default, info_default, sorted({0, B - 1}))
+            except Exception as exc:
+                parity = {"ok": False, "error": f"{type(exc).__name__}: {exc}"}
         # the OTHER build of the same step, always measured (round-over-round comparisons use the cold number): this rank's
         # step without the all-reduce
         if can_prepare and not args.no_other:
@@ -456,6 +524,62 @@ def main():
                              "the section-8(d) step with prepared orders (ops.LossStep, 4 launches)"}
             variants["loss_step_cold" if prepared else "loss_step_prepared"] = other
             del lo_
+        # ---- loops whose inputs CHANGE the way the callers' do: the timed region replays one (R, t, lines,
+        # clouds); these rotate pre-made inputs per step (made outside the loops, resident in HBM like the timed step's)
+        if not args.no_fresh and args.mode == "cull":
+            from LieAlgebra import se3 as _se3f
+            K = 8
+            gen_f = torch.Generator().manual_seed(1234 + rank)
+            lines_k, R_k, T_k = [], [], []
+            for k in range(K):
+                wk = w if k == 0 else None
+                if wk is None:
+                    torch.manual_seed(5000 + 17 * k + rank)  # (the CPU seed selects the sampler's uniform streams)
+                    lk = Lmod.Random_uniform_distribution_lines_batch_efficient_resample(
+                        w["radius"], w["center"], L, w["src"], w["tar"], dev)
+                else:
+                    lk = w["lines"]
+                Rk_, Tk_ = _se3f.exp3(0.05 * torch.randn(B, 6, generator=gen_f))
+                lines_k.append(lk); R_k.append(Rk_.to(dev).contiguous()); T_k.append(Tk_.to(dev).contiguous())
+            torch.cuda.synchronize()
+            if prepared:
+                lf = loss_step(True)
+                it = [0]
+
+                def fresh_lines_step():
+                    k = it[0] % K
+                    it[0] += 1
+                    return lf(R_k[k], T_k[k], lines_k[k])
+                fms, _ = time_loop(fresh_lines_step, max(args.steps, 4 * K), warm=2 * K)
+                variants["fresh_lines"] = {
+                    "ms_per_step": fms, "value": pairs_step / (fms * 1e-3), "unit": "point-pairs/s (this rank, no all-reduce)",
+                    "sets": K, "chained": bool(lf._chain_ready),
+                    "what": f"the timed step (prepared orders, kept target) with NEW lines and a NEW pose in every step: {K} pre-sampled "
+                            "line sets and poses rotated per step -- the demo's loop (code/test_demo_optimized_Lie_Algebra.py:48-57: "
+                            "lines re-sampled and the pose updated every epoch, the target never moves)"}
+                del lf
+            # ... and new CLOUDS in every step, through the cold build (a trainer's new batch: rpm/Train_RPM.py:45-81)
+            Kc = 4
+            clouds_k = [(w["tri1"], w["tri2"])]
+            for k in range(1, Kc):
+                wk = make_workload(B, N, M, 1, 100 + 10 * k + rank, dev)  # (one line: only the clouds are taken)
+                clouds_k.append((wk["tri1"], wk["tri2"]))
+            lcold = loss_step(False)
+            itc = [0]
+
+            def fresh_clouds_step():
+                k = itc[0] % Kc
+                itc[0] += 1
+                lcold.src, lcold.tar = clouds_k[k]
+                return lcold(R_k[k], T_k[k], lines_k[k])
+            cms, _ = time_loop(fresh_clouds_step, max(args.steps, 4 * Kc), warm=2 * Kc)
+            variants["fresh_clouds_cold"] = {
+                "ms_per_step": cms, "value": pairs_step / (cms * 1e-3), "unit": "point-pairs/s (this rank, no all-reduce)", "sets": Kc,
+                "what": f"the COLD step (records + cell sort + tree of both clouds every step) on {Kc} different cloud pairs rotated "
+                        "per step, with new lines and poses too -- a trainer whose every batch brings new clouds that are evaluated "
+                        "once (rpm/Train_RPM.py:45-81, RPM-Net's own re-cropping); (the lines of pairs 1.. were sampled for pair 0's "
+                        "geometry: same shapes and hit statistics, synthetic either way)"}
+            del lcold, clouds_k
         roofline = scan_roofline(ops, lambda: ls(Rd, Td, w["lines"]), B, N, M, L, launches=min(args.steps, 20),
                                  counters=do_extras and args.mode == "cull")
     if do_extras:
@@ -654,6 +778,8 @@ def main():
     if rank == 0:
         value = sum_pairs(world, B, args, L, N, M) * args.steps / dt
         alg_bytes = B * (N + M) * 48 + B * L * 24 + 2 * B * L * 4  # ptri + lines + counts
+        if chained_step:  # + the records body of the same launch: raw row in; record, (P0, thr2), index, NaN reach, moved row, tree out; clearing
+            alg_bytes += int(B * N * (36 + 48 + 16 + 4 + 4 + 36 + 13 * 16 / 64 + 36))
         cull_ms = roofline["launch_ms"]
         cull_s = cull_ms * 1e-3
         if "frac" not in roofline:
@@ -673,7 +799,10 @@ def main():
                     "SQ_INSTS_VALU x 64 of the committed PMC pass / launch time; the dense work this kernel decides "
                     "(18 flops per pair) is work_ratio x executed.",
             "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "kernel": "cull_scan_kernel<false> (scan mode cull: the dominant kernel of the timed step)" if args.mode == "cull"
+            "kernel": (("cull_scan_build_kernel (the CHAINED step's launch: the source's records body in its leading workgroups + the "
+                        "culled scan of both clouds; launch time = the whole launch, executed flops = the scan's, counted by the "
+                        "instrumented plain scan of the same step)") if chained_step else
+                       "cull_scan_kernel<false> (scan mode cull: the dominant kernel of the timed step)") if args.mode == "cull"
                       else f"scan_kernel (scan mode {args.mode})",
             "ops_per_test": {"sphere": OPS_SPHERE, "point0_prefilter": OPS_EXACT, "candidate": OPS_CAND,
                              "fallback_pair": OPS_FALLBACK},
@@ -698,12 +827,22 @@ def main():
                                    f"one C call per step (ops.LossStep -> rrl_loss_step_ex), then the all-reduce of "
                                    f"[loss sum, valid count]; scan mode {args.mode}; "
                                    + ("PREPARED: k-d order of each cloud computed once outside the timed region "
-                                      "(rrl_cloud_order: prepare_us), target records kept while it does not move; 4 launches; "
+                                      "(rrl_cloud_order: prepare_us), target records kept while it does not move"
+                                      + ("; CHAINED (round 6): source records + target scan + source scan as ONE launch, 3 launches per step; "
+                                         if chained_step else "; 4 launches; ")
+                                      + "applies to loops that evaluate many poses / line sets per cloud pair (the demo: 1000 epochs per "
+                                        "pair -- variants.fresh_lines --, RPM / FMR inner iterations, datasets that cache the orders: "
+                                        "pre_dataloader.kd_order); a trainer whose clouds are new in every step and evaluated once gets "
+                                        "value_cold / variants.fresh_clouds_cold (config.break_even_steps); "
                                       if prepared else "COLD: records + cell sort + sphere tree of both clouds every step; 5 launches; ")
                                    + ("hipGraph replay" if graphed is not None else "direct issue on the stream")
                                    + "; value counts dense-equivalent pairs",
                        "step": "loss_step (SURVEY 8(d): points1.grad)",
-                       "issue": issued, "prepared_order": prepared, "prepare_us": prepare_us,
+                       "issue": issued, "prepared_order": prepared, "chained": chained_step, "prepare_us": prepare_us,
+                       "break_even_steps": (2.0 * prepare_us / max((other["ms_per_step"] - ms_step) * 1e3, 1e-9)
+                                            if (prepared and other is not None and prepare_us and other["ms_per_step"] > ms_step) else None),
+                       "break_even_note": "steps per cloud pair from which computing both orders in-stream (2 x prepare_us) pays for "
+                                          "itself: 2 prepare_us / (ms_per_step_cold - ms_per_step)",
                        "prepare_note": "rrl_cloud_order of B clouds of N triangles, once per cloud (dataset item / demo start); a "
                                        "rigid motion keeps the order, so it serves every pose of the cloud",
                        "global_batch": args.global_batch if strong else B * world,
@@ -719,6 +858,7 @@ def main():
                         + " (this rank, no all-reduce); round-over-round comparisons with rounds 1-3 must use the cold number; "
                           "variants.fused_dRdT = the fused training op (rounds 3-4's headline)",
             "roofline": roofline,
+            "parity_in_run": parity,
             "variants": variants,
             "extras": extras,
         }

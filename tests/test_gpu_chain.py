@@ -193,3 +193,38 @@ def test_chained_registration_steps(L, B, n, m, nl):
         assert int(chained.st.count1.abs().max()) == 0 and int(chained.st.chain.abs().max()) == 0
     with pytest.raises(ValueError):
         plain(R, t, ln, target_from=chained.st)  # a chained step's hit counts are gone: it cannot lend its target's scan
+
+
+def test_the_timed_object_at_the_timed_size_vs_oracle(L, oracle):
+    """what bench.py times -- ops.LossStep(prepared, kept target, want_payload) at BASELINE configs[1]
+    (B = 8, N = M = 4096, L = 10000), THIRD call (the chained launch) -- directly against the pinned oracle for two samples:
+    T: the step's moved triangles (TRI1) against the oracle's unfused rigid apply (1e-6 of the extent: the kernel's FMAs round
+    once where mul + add round twice); W + G on those identical moved triangles: selected-line / D-value / bucket counts exact,
+    median equal, loss 1e-5, points1.grad per point 1e-4 (code/loss.py:170-232 + autograd on the same inputs)."""
+    from conftest import merge_by_point
+    from rrl_hip import ops, synth
+    from LieAlgebra import se3
+    B, N, M, nl = 8, 4096, 4096, 10000
+    prs = [synth.make_pair(1000 + b, N, M) for b in range(B)]  # (bench.py's rank-0 workload)
+    src, tar = cu(np.stack([p["src_tri"] for p in prs])), cu(np.stack([p["tar_tri"] for p in prs]))
+    ln = _new_lines(L, prs, nl, 3)
+    gen = torch.Generator().manual_seed(7)
+    R, t = (x.cuda().contiguous() for x in se3.exp3(0.05 * torch.randn(B, 6, generator=gen)))
+    step = ops.LossStep(src, tar, nl, want_payload=True)
+    for call in range(3):
+        step.st.lmax.fill_(-7.0)
+        loss, grad, info = step(R, t, ln)
+    torch.cuda.synchronize()
+    assert bool((step.st.lmax == -7.0).all()), "the third call runs the chained launch"
+    for b in (0, B - 1):
+        moved_o = oracle.rigid_apply(prs[b]["src_tri"].reshape(-1, 3), R[b].cpu().numpy(), t[b].cpu().numpy(), transpose_r=True).reshape(-1, 9)
+        moved = step.st.tri1t[b].cpu().numpy()
+        assert np.abs(moved - moved_o).max() <= 1e-6 * np.abs(moved_o).max()
+        ref = oracle.loss(moved, prs[b]["tar_tri"], ln[b].cpu().numpy(), want_grad=True)
+        assert [int(v) for v in info[b].tolist()] == [ref["n_buckets"], ref["n_selected"], ref["n_values"], int(ref["nan"])]
+        assert abs(float(loss[b]) - float(ref["loss"])) <= 1e-5 * abs(float(ref["loss"]))
+        assert float(step.st.med[b]) == float(ref["median"])
+        a, w = merge_by_point(moved, grad[b].cpu().numpy()), merge_by_point(moved, ref["grad1"])
+        assert np.abs(a - w).max() <= 1e-4 * np.abs(w).max()
+    valid = info[:, 0] > 0
+    assert float(step.payload[1]) == float(valid.sum()) and abs(float(step.payload[0]) - float(loss[valid].double().sum())) < 1e-5

@@ -73,12 +73,14 @@ def summarise(sfx, B, what):
     out["step_kernels_without_counters"] = missing
     out["step_hbm_bytes_corrected"] = sum(out["hbm_per_kernel"].get(k, {}).get("bytes_corrected", 0.0) for k in step_kernels)
     json.dump(out, open(f"{O}/{tag}_pmc_summary{sfx}.json", "w"), indent=1)
-    c_ = out["hbm_per_kernel"].get("cull_scan_kernel", {})
-    sq_ = out["sq_per_kernel"].get("cull_scan_kernel", {})
-    cull_avg = [float(r["AverageNs"]) / 1e3 for r in step_rows if "cull_scan_kernel" in r["Name"]]
+    # the step's scan launch: cull_scan_kernel, or -- a chained step (round 6) -- cull_scan_build_kernel (records + both scans)
+    scan_name = next((k for k in step_kernels if k.startswith("cull_scan")), "cull_scan_kernel")
+    c_ = out["hbm_per_kernel"].get(scan_name, {})
+    sq_ = out["sq_per_kernel"].get(scan_name, {})
+    cull_avg = [float(r["AverageNs"]) / 1e3 for r in step_rows if short(r["Name"]) == scan_name]
     ent = None
     if "FETCH_SIZE" in c_ and "WRITE_SIZE" in c_:  # the object bench.py reports under roofline (traffic, issue_frac, pmc)
-        ent = {"kernel": "cull_scan_kernel", "fetch_kb_raw": c_["FETCH_SIZE"], "write_kb_raw": c_["WRITE_SIZE"],
+        ent = {"kernel": scan_name, "fetch_kb_raw": c_["FETCH_SIZE"], "write_kb_raw": c_["WRITE_SIZE"],
                "bytes": int(c_["bytes_corrected"]),
                "correction": "FETCH_SIZE x2 (gfx950 wide-read undercount), WRITE_SIZE as reported",
                "source": f"profiles/{tag}_pmc_summary{sfx}.json (rocprofv3 --pmc, separate passes per counter group, of " + STEP +
