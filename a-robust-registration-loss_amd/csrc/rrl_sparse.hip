@@ -102,8 +102,13 @@ __device__ __forceinline__ void sort4(int *h, int n) {  // ascending, n <= 4
 // before; only WHICH lane issues an atomic changes (float atomics: the sums agree to their rounding order, as before).
 // rowkey = triangle index | (cloud 2 ? 1u << 31 : 0); g1b / g2b: the sample's gradient rows [n][9]; strip: 64 x 10 words.
 #define SCAT_STRIDE 10
+// fx1b / fx2b != NULL (deterministic mode, include/rrl.h rrl_set_deterministic): the element goes to the sample's 64-bit
+// fixed-point accumulators instead -- llrint(value * inv_unit), inv_unit a power of two: integer atomics commute, so the sums
+// do not depend on the order of arrival; a non-finite value raises *nonfinite (the conversion then writes NaN rows).
 __device__ __forceinline__ void wave_scatter_rows(bool live, const float (&v)[9], unsigned rowkey, float *__restrict__ g1b,
-                                                  float *__restrict__ g2b, unsigned *strip, int lane) {
+                                                  float *__restrict__ g2b, unsigned *strip, int lane,
+                                                  unsigned long long *fx1b = nullptr, unsigned long long *fx2b = nullptr,
+                                                  double inv_unit = 0.0, int32_t *nonfinite = nullptr) {
     const unsigned long long mask = __ballot(live);
     const int nlive = __popcll(mask);
     if (nlive == 0) return;  // uniform
@@ -119,6 +124,12 @@ __device__ __forceinline__ void wave_scatter_rows(bool live, const float (&v)[9]
         const int rk = p / 9, e = p - rk * 9;
         const unsigned key = strip[rk * SCAT_STRIDE];
         const float val = __uint_as_float(strip[rk * SCAT_STRIDE + 1 + e]);
+        if (fx1b) {  // uniform
+            if (!(fabsf(val) < INFINITY)) { atomicOr(&nonfinite[key >> 31], 1); continue; }
+            const long long q = __double2ll_rn((double)val * inv_unit);
+            if (q) atomicAdd(((key >> 31) ? fx2b : fx1b) + (size_t)(key & 0x7fffffffu) * 9 + e, (unsigned long long)q);
+            continue;
+        }
         float *dst = ((key >> 31) ? g2b : g1b) + (size_t)(key & 0x7fffffffu) * 9 + e;
         atomicAdd(dst, val);
     }
@@ -2301,7 +2312,25 @@ struct ScatArgs {
     const float4 *Q1, *Q2;
     float *g1, *g2;
     int N, M, L;
+    unsigned long long *fx;  // deterministic mode: GFIX -- [B][N + M][9] fixed-point accumulators, then int32 [B][2] non-finite flags; or NULL
+    int fxbits;              // ... fractional bits below the sample's bound exponent (scat_unit_exp)
+    int fxB;                 // ... samples (the flags sit behind the B accumulators)
 };
+// Deterministic scatter: the exponent e with |any single contribution| < 2^e for a sample with upstream gradient gl, C valid
+// buckets and median m.  A contribution is w/3 * sum_{o < 4} 2 (q1 - q2)_c * scale * sw * exp(-D / 2m) / (2m) with w <= 1,
+// scale <= |gl| / C, sw <= 2 and |q1 - q2| exp(-D / 2m) / m <= sqrt(D) exp(-D / 2m) / m <= 0.607 / sqrt(m): below
+// 1.62 |gl| / (C sqrt(m)); two more binades of slack.  Non-positive / non-finite bound: 0 (such a sample's contributions are
+// zero or non-finite).  The SAME expression in the scatter and in the conversion: same bits.
+__device__ __forceinline__ int scat_unit_exp(float gl, int C, float m) {
+    const float bnd = 1.62f * fabsf(gl) / ((float)(C > 0 ? C : 1) * sqrtf(m));
+    if (!(bnd > 0.0f) || !(bnd < INFINITY)) return 0;
+    return ilogbf(bnd) + 3;
+}
+__device__ __forceinline__ int scat_fx_bits(int L) {  // <= L contributions per element: 62 - ceil(log2 L) fractional bits
+    int lg = 1;
+    while ((1 << lg) < L && lg < 30) ++lg;
+    return 62 - lg;
+}
 
 // The arithmetic of the scatter backward for one lane = (selected line, side, hit slot h), 8 lanes per line ((side, h) =
 // lane bits 2 and 0..1); every lane of the wavefront calls (DPP exchange, LDS transpose).  valid: the lane has a line;
@@ -2312,7 +2341,8 @@ template <class OtherF>
 __device__ __forceinline__ void bwd_scatter_math(bool live, int k, int j, int side, int h, const float (&d)[4], int S,
                                                  float4 mine, int f, const float (&wq)[3], int C, float m, float gl_in,
                                                  OtherF other_of, float *__restrict__ g1b, float *__restrict__ g2b,
-                                                 unsigned *strip, int lane) {
+                                                 unsigned *strip, int lane, unsigned long long *fx1b = nullptr,
+                                                 unsigned long long *fx2b = nullptr, double inv_unit = 0.0, int32_t *nonfinite = nullptr) {
     const int ocnt = side ? k : j;
     const int omax = (int)wave_max((float)(k > j ? k : j));  // uniform
     float er[4] = {0.0f, 0.0f, 0.0f, 0.0f}, wr[4];
@@ -2372,7 +2402,7 @@ __device__ __forceinline__ void bwd_scatter_math(bool live, int k, int j, int si
             for (int cc = 0; cc < 3; ++cc) sv[3 * kk + cc] = wk * gq[cc];
         }
     }
-    wave_scatter_rows(live, sv, (unsigned)f | (side ? 0x80000000u : 0u), g1b, g2b, strip, lane);
+    wave_scatter_rows(live, sv, (unsigned)f | (side ? 0x80000000u : 0u), g1b, g2b, strip, lane, fx1b, fx2b, inv_unit, nonfinite);
 }
 
 // One pass of the scatter backward from the workspace: this lane = (the tile's selected line of rank r, side, hit slot h);
@@ -2407,8 +2437,29 @@ __device__ __forceinline__ void bwd_scatter_pass(const ScatArgs &a, int b, size_
         for (int q = 0; q < 3; ++q) wq[q] = w[q];
     }
     const float4 *__restrict__ Qo = side ? a.Q1 : a.Q2;
+    if (a.fx) {  // uniform: deterministic mode -- fixed-point accumulators, unit 2^(scat_unit_exp - fxbits)
+        unsigned long long *fx1b = a.fx + (size_t)b * (a.N + a.M) * 9, *fx2b = fx1b + (size_t)a.N * 9;
+        int32_t *flags = (int32_t *)(a.fx + (size_t)a.fxB * (a.N + a.M) * 9) + 2 * b;
+        bwd_scatter_math(live, k, j, side, h, d, S, mine, f, wq, C, m, gl_in, [&](int o) { return Qo[gl * 4 + o]; }, nullptr, nullptr,
+                         strip, lane, fx1b, fx2b, ldexp(1.0, a.fxbits - scat_unit_exp(gl_in, C, m)), flags);
+        return;
+    }
     bwd_scatter_math(live, k, j, side, h, d, S, mine, f, wq, C, m, gl_in, [&](int o) { return Qo[gl * 4 + o]; },
                      a.g1 + (size_t)b * a.N * 9, a.g2 ? a.g2 + (size_t)b * a.M * 9 : nullptr, strip, lane);
+}
+
+// Deterministic mode: the fixed-point accumulators -> fp32 gradients.  grid (ceil(max(N, M) * 9 / 256), B, clouds)
+__global__ __launch_bounds__(256) void scatter_fix_to_float_kernel(const ScatArgs a, int B, int pool) {
+    const int b = blockIdx.y, side = blockIdx.z, g = pool ? 0 : b;
+    const int n = side ? a.M : a.N;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)n * 9) return;
+    const int C = a.info[g * 4];
+    const float m = a.med[g], gl_in = a.grad_loss[g];
+    const double unit = ldexp(1.0, scat_unit_exp(gl_in, C, m) - a.fxbits);
+    const long long q = (long long)(a.fx + (size_t)b * (a.N + a.M) * 9 + (side ? (size_t)a.N * 9 : 0))[i];
+    const int32_t bad = ((const int32_t *)(a.fx + (size_t)B * (a.N + a.M) * 9))[2 * b + side];
+    (side ? a.g2 + (size_t)b * a.M * 9 : a.g1 + (size_t)b * a.N * 9)[i] = bad ? __builtin_nanf("") : (float)((double)q * unit);
 }
 
 __global__ __launch_bounds__(256) void loss_bwd_kernel(const ScatArgs a, int B, int pool, int xcd_align) {
@@ -2912,13 +2963,23 @@ static ScatArgs scat_args(const void *ws, const WsLayout &w, const float *grad_l
     a.grad_loss = grad_loss;
     a.Q1 = (const float4 *)w.f32(ws, RRL_WS_Q1); a.Q2 = (const float4 *)w.f32(ws, RRL_WS_Q2);
     a.g1 = g1; a.g2 = g2; a.N = N; a.M = M; a.L = L;
+    a.fx = nullptr; a.fxbits = 0; a.fxB = 0;
     return a;
 }
 
+static int scat_fx_bits_host(int L) {
+    int lg = 1;
+    while ((1 << lg) < L && lg < 30) ++lg;
+    return 62 - lg;
+}
+
+// deterministic: include/rrl.h rrl_set_deterministic -- the scatter accumulates in the workspace's fixed-point field (which this
+// call clears and therefore WRITES: the one entry that touches the workspace of a finished forward) and one more launch
+// converts; grad_tri1 / grad_tri2 are overwritten, not accumulated.
 static int loss_backward_impl(const float *tri1, const float *tri2, const void *ws,
                               size_t ws_bytes, const float *grad_loss, float *grad_tri1,
                               float *grad_tri2, int B, int N, int M, int L, int pool, bool zero1,
-                              void *stream) {
+                              void *stream, bool deterministic = false) {
     if (!tri1 || !tri2 || !ws || !grad_loss || !grad_tri1) return RRL_E_ARG;
     if (B < 0 || N < 0 || M < 0 || L < 0) return RRL_E_ARG;
     WsLayout w(B, N, M, L);
@@ -2928,10 +2989,22 @@ static int loss_backward_impl(const float *tri1, const float *tri2, const void *
     if (zero1 && (rc = rrl_fill(grad_tri1, 0u, sizeof(float) * 9 * (size_t)B * N, s))) return rc;
     if (grad_tri2 && (rc = rrl_fill(grad_tri2, 0u, sizeof(float) * 9 * (size_t)B * M, s))) return rc;
     if (B == 0 || L == 0) return 0;
-    hipLaunchKernelGGL(loss_bwd_kernel, dim3((unsigned)((L + 1023) / 1024), (unsigned)B, BWDS_SUBS), dim3(256), 0, s,
-                       scat_args(ws, w, grad_loss, grad_tri1, grad_tri2, N, M, L), B, pool,
+    ScatArgs sa = scat_args(ws, w, grad_loss, grad_tri1, grad_tri2, N, M, L);
+    if (deterministic && (N + M) > 0) {
+        sa.fx = (unsigned long long *)((char *)const_cast<void *>(ws) + w.off[RRL_WS_GFIX]);
+        sa.fxbits = scat_fx_bits_host(L);
+        sa.fxB = B;
+        if ((rc = rrl_fill(sa.fx, 0u, 8 * (size_t)B * (N + M) * 9 + 8 * (size_t)B, s))) return rc;
+    }
+    hipLaunchKernelGGL(loss_bwd_kernel, dim3((unsigned)((L + 1023) / 1024), (unsigned)B, BWDS_SUBS), dim3(256), 0, s, sa, B, pool,
                        B % 8 == 0 && xcd_align_on() ? 1 : 0);
     RRL_LAUNCH_CHECK();
+    if (sa.fx) {
+        const int nmax = grad_tri2 && M > N ? M : N;
+        hipLaunchKernelGGL(scatter_fix_to_float_kernel, dim3((unsigned)(((size_t)nmax * 9 + 255) / 256), (unsigned)B, grad_tri2 ? 2u : 1u),
+                           dim3(256), 0, s, sa, B, pool);
+        RRL_LAUNCH_CHECK();
+    }
     return 0;
 }
 
@@ -2940,7 +3013,7 @@ extern "C" int rrl_loss_backward(const float *tri1, const float *tri2, const voi
                                  float *grad_tri2, int B, int N, int M, int L, int pool,
                                  void *stream) {
     return loss_backward_impl(tri1, tri2, ws, ws_bytes, grad_loss, grad_tri1, grad_tri2, B, N, M, L,
-                              pool, true, stream);
+                              pool, true, stream, default_deterministic());
 }
 
 int rrl_fused_backward(int B, int N, int M);
@@ -3243,7 +3316,8 @@ extern "C" int rrl_loss_step_ex(const float *tri1, const float *R, const float *
     const RrlXform xf = {tri1, R, t, transpose_r, pay_in_ws ? 1 : 0};
     const float *p1 = R ? w.f32(ws, RRL_WS_TRI1) : tri1;  // points1: the moved source, or the caller's triangles as given
     // (the tail kernel, or -- one tile of lines per sample -- the single-tile kernel: loss_forward_impl's own conditions)
-    const bool ride = B > 0 && L > 0 && !grad_tri2 &&
+    // (deterministic: the fixed-point scatter of loss_bwd_kernel + its conversion launch, never the riding float atomics)
+    const bool ride = B > 0 && L > 0 && !grad_tri2 && !o.deterministic &&
                       (L > 1024 ? reduce_kind(o.reduce_mode, B, nblk, 0, true) == 2 : o.reduce_mode < 2);
     // no riding backward, but the exchange reduce serves the call: its last arrivers add the payload (no payload launch)
     const bool pay_in_reduce = payload && !ride && B > 0 && L > 1024 && reduce_kind(o.reduce_mode, B, nblk, 0, false) == 1;
@@ -3256,7 +3330,7 @@ extern "C" int rrl_loss_step_ex(const float *tri1, const float *R, const float *
     // (grad_tri1 was cleared by the build step's first launch -- or by its fill on the unsorted path; an empty batch /
     //  cloud launches nothing: clear here)
     if (B == 0 || (N == 0 && M == 0)) return rrl_fill(grad_tri1, 0u, o.clear_bytes, (hipStream_t)stream);
-    rc = loss_backward_impl(p1, tri2, ws, ws_bytes, grad_loss, grad_tri1, grad_tri2, B, N, M, L, 0, false, stream);
+    rc = loss_backward_impl(p1, tri2, ws, ws_bytes, grad_loss, grad_tri1, grad_tri2, B, N, M, L, 0, false, stream, o.deterministic != 0);
     if (rc || !payload || L <= 0 || pay_in_reduce) return rc;
     return rrl_shard_payload(loss, ws, ws_bytes, nullptr, nullptr, payload, B, N, M, L, stream);
 }

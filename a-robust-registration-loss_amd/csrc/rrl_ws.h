@@ -64,6 +64,7 @@ struct WsLayout {
             4 * b * ((l + 1023) / 1024) * 16384, // VLIST
             4 * b * ((l + 1023) / 1024 + 1),     // VLCNT
             4 * b * 4,                           // CHAIN (chained steps: include/rrl.h RRL_F_CHAIN)
+            8 * b * (n + m) * 9 + 4 * 2 * b,     // GFIX (deterministic scatter backward)
         };
         size_t o = 0;
         for (int i = 0; i < RRL_WS_FIELDS; ++i) {

@@ -67,6 +67,7 @@ _WS_FIELDS = [
     ("vlist", torch.float32, lambda B, N, M, L, G: (B, (L + 1023) // 1024, 16384)),
     ("vlcnt", torch.int32, lambda B, N, M, L, G: (B * ((L + 1023) // 1024 + 1),)),
     ("chain", torch.int32, lambda B, N, M, L, G: (B, 4)),
+    ("gfix", torch.int64, lambda B, N, M, L, G: (B * (N + M) * 9 + B,)),
 ]
 _layout_cache = {}
 _FIELD_INDEX = {name: i for i, (name, _, _) in enumerate(_WS_FIELDS)}
@@ -1092,8 +1093,12 @@ class LossStep:
     gradient to the rounding of the scatter's float atomics.  prepared / src_order / tar_order as RegistrationStep."""
 
     def __init__(self, src_tri, tar_tri, n_lines, rng=(1, 1, 5, 5), transpose_r=True, mode="cull", chunk=0,
-                 prepared=None, src_order=None, tar_order=None, chamfer=False, want_payload=False, poses=1, chain=True):
-        """chain=True (default; round 6, include/rrl.h RRL_F_CHAIN / RRL_F_CHAINED): from its second call on, while the target is
+                 prepared=None, src_order=None, tar_order=None, chamfer=False, want_payload=False, poses=1, chain=True,
+                 deterministic=None):
+        """deterministic=True (round 6; include/rrl.h rrl_set_deterministic): points1.grad accumulates in 64-bit fixed point and
+        reproduces BIT FOR BIT from call to call (the float atomics of the default scatter agree only to their rounding order);
+        the step then runs forward + scatter + a conversion launch (no chain, no riding backward).  None: the library default.
+        chain=True (default; round 6, include/rrl.h RRL_F_CHAIN / RRL_F_CHAINED): from its second call on, while the target is
         kept, the step runs the source's records, the target's scan and the source's scan as ONE launch (three launches per
         step instead of four, same loss bits).  A chained step leaves .st.count1 / .st.count2 CLEARED (the per-line stage
         zeroes them behind its read; .st.kj / hs1 / hs2 hold what it read) and does not update .st.status -- info[:, 3] is then
@@ -1134,7 +1139,7 @@ class LossStep:
         self.keep_target = True  # see RegistrationStep.invalidate_target
         # (in the workspace's accumulator field: the step's first launch clears it, as for RegistrationStep)
         self.payload = self.st.gacc[B * 12:B * 12 + 14] if want_payload else None
-        self._opts = self._opts_kept = make_opts(chamfer=self.ride, payload=self.payload, problems=prob)  # (None without any)
+        self._opts = self._opts_kept = make_opts(chamfer=self.ride, payload=self.payload, problems=prob, deterministic=deterministic)  # (None without any)
         # CHAINED steps (round 6; include/rrl.h RRL_F_CHAIN / RRL_F_CHAINED): every prepared step asks the library to leave
         # the workspace's hit counts cleared (the library says through _chain_left whether it did); a step that follows such
         # a step with the target still kept runs records + target scan + source scan as ONE launch.  chain = False turns
@@ -1146,7 +1151,7 @@ class LossStep:
             self.order1 = _check_order(src_order, Bt, N, dev, "src_order") if src_order is not None else cloud_order(self.src)
             self.order2 = _check_order(tar_order, Bt, M, dev, "tar_order") if tar_order is not None else cloud_order(self.tar)
             kw = dict(order1=self.order1, order2=self.order2, chamfer=self.ride, payload=self.payload, problems=prob,
-                      chain_left=self._chain_left)
+                      chain_left=self._chain_left, deterministic=deterministic)
             self._opts = make_opts(**kw)  # (.chain = False: no chain flags at all -- the hit counts stay readable)
             self._opts_kept = make_opts(target_kept=True, **kw)
             self._opts_c = (make_opts(chain=_lib.F_CHAIN, **kw), make_opts(target_kept=True, chain=_lib.F_CHAIN, **kw),

@@ -596,6 +596,22 @@ def main():
             "loss_bit_identical_to_timed_step": bool(torch.equal(fout[0], loss_default))}
         del rs
 
+        # ---- bit-reproducible points1.grad on request: the scatter in 64-bit fixed point + a conversion launch
+        ldet = ops.LossStep(w["tri1"], w["tri2"], L, transpose_r=True, mode=args.mode, prepared=prepared,
+                            src_order=order1 if prepared else None, tar_order=order2 if prepared else None, deterministic=True)
+        dms_, dout = time_loop(lambda: ldet(Rd, Td, w["lines"]), args.steps)
+        gdet = dout[1].clone()
+        ldet(Rd, Td, w["lines"])
+        variants["deterministic_grad"] = {
+            "ms_per_step": dms_, "value": pairs_step / (dms_ * 1e-3), "unit": "point-pairs/s (this rank, no all-reduce)",
+            "what": "ops.LossStep(deterministic=True): the same step with points1.grad accumulated in 64-bit fixed point (workspace "
+                    "field GFIX; integer atomics commute) and converted by one more launch -- forward + scatter + conversion, no "
+                    "chain, no riding backward; the reference's CPU autograd is deterministic",
+            "loss_bit_identical_to_timed_step": bool(torch.equal(dout[0], loss_default)),
+            "grad_bit_identical_between_calls": bool(torch.equal(ldet.grad, gdet)),
+            "grad_max_rel_diff_vs_timed_step": float((gdet - grad_default).abs().max() / grad_default.abs().max())}
+        del ldet
+
         # ---- the kernel that performs ALL counted flops: the strict scan of the same step
         lstrict = ops.LossStep(w["tri1"], w["tri2"], L, transpose_r=True, mode="strict")
         sroof = scan_roofline(ops, lambda: lstrict(Rd, Td, w["lines"]), B, N, M, L, launches=20, counters=False)

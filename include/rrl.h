@@ -141,6 +141,9 @@ enum {
                           workgroups of the sample that have finished in the step's build + scan launch, [1] the scan's NaN
                           flag of the sample, [2] its wavefronts that fell back to the strict loop, [3] wait time-outs; all
                           zero between calls (cleared on exit by the sample's last tail workgroup)                          */
+    RRL_WS_GFIX,       /* int64[B][N + M][9] + int32[2 B]  deterministic scatter backward (rrl_opts.deterministic with rrl_loss_step_ex /
+                          rrl_loss_backward): fixed-point accumulators of dL/dpoints1 (and dL/dpoints2), order-independent like MSUM;
+                          behind them one non-finite flag per sample and cloud                                              */
     RRL_WS_FIELDS
 };
 
@@ -298,10 +301,16 @@ int rrl_loss_forward_info(const float *tri1, const float *tri2, const float *lin
                           size_t ws_bytes, float *loss, int B, int N, int M, int L, int s_m, int s_n,
                           int e_m, int e_n, int pool, int mode, int chunk, const void *target_ws,
                           int32_t *host_info, void *stream);
-/* Opt-in bit-reproducible direct backward (grad_src == NULL): on != 0 replaces the float atomics of
- * rrl_registration_backward by per-workgroup partial sums added in a fixed order by a second, tiny
- * launch (the reference's CPU autograd is deterministic).  Env RRL_DETERMINISTIC=1 sets the initial
- * state.  The forward, and the d/dsrc route, are deterministic either way. */
+/* Opt-in bit-reproducible backward (the reference's CPU autograd is deterministic).  on != 0 (or rrl_opts.deterministic = 1)
+ *   - replaces the float atomics of rrl_registration_backward's direct route (grad_src == NULL) by per-workgroup partial
+ *     sums added in a fixed order by a second, tiny launch;
+ *   - (round 6) makes the SCATTER backward to points1.grad / points2.grad -- rrl_loss_backward, rrl_loss_step_ex -- accumulate
+ *     in 64-bit fixed point (workspace field GFIX; the unit is a power of two derived per sample from |dL/dloss|, the
+ *     bucket count and the median, so that 2^24 contributions cannot overflow): integer sums do not depend on the order of the
+ *     atomics.  One more launch converts them to fp32; rrl_loss_step_ex then runs forward + backward + conversion instead of
+ *     carrying the scatter in its reduce launch.  Every contribution is rounded to the unit (2^-38 .. 2^-61 of the largest
+ *     possible one): the result agrees with the float-atomic one to ~1e-6 of the largest entry and reproduces bit for bit.
+ * Env RRL_DETERMINISTIC=1 sets the initial state.  The forward is deterministic either way. */
 int rrl_set_deterministic(int on);
 int rrl_registration_backward(const float *src, const float *R, const float *tri2, void *ws,
                               size_t ws_bytes, const float *loss, const float *grad_loss,

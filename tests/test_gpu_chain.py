@@ -228,3 +228,49 @@ def test_the_timed_object_at_the_timed_size_vs_oracle(L, oracle):
         assert np.abs(a - w).max() <= 1e-4 * np.abs(w).max()
     valid = info[:, 0] > 0
     assert float(step.payload[1]) == float(valid.sum()) and abs(float(step.payload[0]) - float(loss[valid].double().sum())) < 1e-5
+
+
+@pytest.mark.parametrize("B,n,m,nl,prepared", [(8, 4096, 4096, 10000, True), (40, 300, 260, 7000, True), (2, 900, 800, 600, True),
+                                                (3, 700, 900, 4000, False)])
+def test_deterministic_points1_grad(L, B, n, m, nl, prepared):
+    """ops.LossStep(deterministic=True) -- the scatter backward in 64-bit fixed point (GFIX) -- reproduces
+    points1.grad BIT FOR BIT over 50 calls (the reference's CPU autograd is deterministic) at C2, on the path beyond the tail
+    kernel's 256 workgroups (B x tiles = 280), for a single tile of lines and on the cold build; loss bits equal the default
+    step's, the gradient agrees with the float-atomic one to 1e-6 of its largest entry; rrl_loss_backward (the autograd
+    backward of ops.intersection_loss) under ops.set_deterministic(True) reproduces too, including points2.grad."""
+    from rrl_hip import ops
+    prs, src, tar = _pairs(980, B, n, m)
+    ln = _new_lines(L, prs, nl, 1)
+    R, t = _poses(B, 2)
+    gl = (0.5 + torch.rand(B, generator=torch.Generator().manual_seed(3))).cuda()
+    ref = ops.LossStep(src, tar, nl, prepared=prepared)
+    l0, g0, i0 = (x.clone() for x in ref(R, t, ln, grad_loss=gl))
+    det = ops.LossStep(src, tar, nl, prepared=prepared, deterministic=True)
+    first = None
+    for it in range(50):
+        l1, g1, i1 = det(R, t, ln, grad_loss=gl)
+        if first is None:
+            first = g1.clone()
+            torch.cuda.synchronize()
+            assert torch.equal(l1, l0) and torch.equal(i1, i0)
+            # (entries below the fixed-point unit -- exp(-D / 2 med) of a far pair, 1e-14 of the largest possible
+            #  contribution -- round to zero: compared by value, not by which rows are non-zero)
+            assert float((g1 - g0).abs().max()) <= 2e-6 * float(g0.abs().max())
+            assert int((g1.abs().sum(-1) > 0).sum()) >= 0.98 * int((g0.abs().sum(-1) > 0).sum())
+        else:
+            assert torch.equal(g1, first), it
+    # the drop-in autograd route (rrl_loss_backward) with the process-wide switch, both clouds' gradients
+    ops.set_deterministic(True)
+    try:
+        outs = []
+        for it in range(6):
+            p1 = ops.rigid_apply(src.reshape(B, -1, 3), R, t, transpose_r=True).reshape(B, n, 9).detach().requires_grad_(True)
+            p2 = tar.clone().requires_grad_(True)
+            loss, info, _ = ops.intersection_loss(p1, p2, ln)
+            torch.autograd.backward([loss], [gl])
+            outs.append((p1.grad.clone(), p2.grad.clone()))
+        for a, b_ in outs[1:]:
+            assert torch.equal(a, outs[0][0]) and torch.equal(b_, outs[0][1])
+        assert torch.equal(outs[0][0], first)  # the same sums whichever entry issued them
+    finally:
+        ops.set_deterministic(False)

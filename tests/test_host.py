@@ -44,7 +44,7 @@ def test_abi_argument_errors(libpath):
     header = open(os.path.join(ROOT, "include", "rrl.h")).read()
     enum = header[header.index("RRL_WS_STATUS = 0"):header.index("RRL_WS_FIELDS")]
     n_fields = len(re.findall(r"RRL_WS_[A-Z0-9]+", enum))
-    assert n_fields == len(ops._WS_FIELDS) == 51  # python view table matches the C enum
+    assert n_fields == len(ops._WS_FIELDS) == 52  # python view table matches the C enum
     offs = (C.c_size_t * n_fields)()
     assert lib.rrl_workspace_layout(8, 4096, 4096, 10000, offs) == 0
     total = lib.rrl_workspace_bytes(8, 4096, 4096, 10000)
