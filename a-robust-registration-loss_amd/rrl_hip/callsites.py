@@ -223,6 +223,10 @@ def multi_pose_loss(src_nb, transforms, tar_tri, lines, mode=None, data=None, ch
     src_tri, tar_tri = src_nb.reshape(B, -1, 9), tar_tri.reshape(B, -1, 9)
     if not MULTI_POSE or k < 1 or _mode(mode) != "cull" or max(src_tri.shape[1], tar_tri.shape[1]) > _SORT_CAP:
         return None
+    #  the packed node differentiates with respect to the TRANSFORMS only: a source (or target) that requires grad
+    # takes the per-pose loop, whose registration_loss produces dL/dsrc (or raises for the target) -- never a silent None
+    if torch.is_grad_enabled() and (src_nb.requires_grad or tar_tri.requires_grad):
+        return None
     o1, o2 = _orders(data, src_tri.shape[1], tar_tri.shape[1], B, src_tri.device if src_tri.is_cuda else None)
     P = torch.stack([x[..., :3, :] for x in transforms])  # (k, B, 3, 4)
     loss, info = _PackedPoses.apply(P, src_tri, tar_tri, lines, o1, o2, bool(chamfer))

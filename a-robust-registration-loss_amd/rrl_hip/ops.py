@@ -153,13 +153,14 @@ def _run(dev, name, *args):
 
 _raw_writes = {}     # data_ptr -> serial of the library's latest raw-pointer write into that buffer
 _raw_serial = [0]    # monotone: a pruned map never repeats a key
+_raw_floor = [0]     # serial at the last prune: what a buffer missing from the map is keyed on (never the old default 0)
 
 
 def _write_key(t):
     """What this module's caches key a tensor's CONTENT on: (data_ptr, torch's version counter, the library's own
     raw-write serial of that buffer).  The third part makes the caches independent of the private version-bump hook."""
     p = t.data_ptr()
-    return (p, t._version, _raw_writes.get(p, 0))
+    return (p, t._version, _raw_writes.get(p, _raw_floor[0]))
 
 
 def _touched(*tensors):
@@ -170,8 +171,9 @@ def _touched(*tensors):
     ts = [t for t in tensors if isinstance(t, torch.Tensor)]
     if not ts:
         return
-    if len(_raw_writes) > 4096:  # bounded; the serial keeps growing, so old keys never come back
+    if len(_raw_writes) > 4096:  # bounded; the serial keeps growing and the floor moves with it, so old keys never come back
         _raw_writes.clear()
+        _raw_floor[0] = _raw_serial[0]
     for t in ts:
         _raw_serial[0] += 1
         _raw_writes[t.data_ptr()] = _raw_serial[0]

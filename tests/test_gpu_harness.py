@@ -470,9 +470,13 @@ def _bench_child(extra, launcher, base=("--steps", "200", "--warmup", "20", "--n
     import json
     import subprocess
     import sys
+    import socket
     from conftest import ROOT
+    with socket.socket() as so:  # a free port per launch
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
     cmd = ([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
-            "127.0.0.1", "--master-port", "29731"] if launcher else [sys.executable])
+            "127.0.0.1", "--master-port", str(port)] if launcher else [sys.executable])
     cmd += [os.path.join(ROOT, "bench.py"), "--gpus", "1", *base] + extra
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
@@ -601,9 +605,13 @@ def test_bench_two_ranks_sharing_one_gpu():
     from conftest import ROOT
     env = dict(os.environ, RRL_SHARE_GPU="1", RRL_DIST_BACKEND="gloo")
     out = {}
+    import socket
     for name, extra in (("weak", []), ("strong", ["--global-batch", "8"])):
+        with socket.socket() as so:  # a free port per launch (a lingering TIME_WAIT socket must not fail the suite)
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-               "--master-port", "29741", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "40", "--warmup", "5",
+               "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "40", "--warmup", "5",
                "--no-cpu-baseline", "--no-extras", "--no-other", "--points", "1024", "--lines", "4000", "--batch", "4"] + extra
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
         assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]

@@ -15,7 +15,7 @@ python3 tools/scan_tail.py > $O/${T}_scan_tail.txt 2>&1
 python3 tools/multi_pose_timing.py > $O/${T}_multi_pose.txt 2>&1
 python3 tools/fragment_timing.py > $O/${T}_fragments.txt 2>&1
 python3 tools/step_stress.py 100000 > $O/${T}_stress.txt 2>&1; echo "exit $?" >> $O/${T}_stress.txt
-for s in 0 1 2 3 4 5 6; do python3 tools/soak.py $s 300 2>&1 | tail -1; done > $O/${T}_soak.txt; echo "exit $?" >> $O/${T}_soak.txt
+rc=0; for s in 0 1 2 3 4 5 6; do python3 tools/soak.py $s 300 > $O/${T}_soak_$s.log 2>&1 || rc=1; tail -1 $O/${T}_soak_$s.log; done > $O/${T}_soak.txt; echo "exit $rc (1 = some soak.py run returned non-zero)" >> $O/${T}_soak.txt
 tail -3 $O/${T}_stress.txt; tail -3 $O/${T}_soak.txt
 python3 tools/ride_timing.py > $O/${T}_ride_timing.txt 2>&1; tail -3 $O/${T}_ride_timing.txt
 # ---- the suites, last, on this tree (csrc_sha in the first line of each log)
