@@ -931,12 +931,14 @@ static CullGeom cull_geometry(int B, int N, int M, int L, int clouds, const RrlC
     // (a riding Chamfer walk needs the scan's full 512-lane workgroups -- and brings workgroups of its own: no thinning then)
     const bool may_ride = o.rider && !o.counters && (clouds == 2 || o.tar_ws) && lw >= WPB_ && B <= 32767 && N > 0 && M > 0;
     while (!fat && !may_ride && wgs() < 256 && waves > 2) waves >>= 1;
-    if (const char *e = getenv("RRL_CULL_GEOM")) {  // experiments: "waves,spw" (spw > 8: the fat variant)
+#ifdef RRL_EXPERIMENT  // (experimental builds only, RRL_HIPCC_FLAGS=-DRRL_EXPERIMENT -> lib_exp: geometry sweeps)
+    if (const char *e = getenv("RRL_CULL_GEOM")) {  // "waves,spw" (spw > 8: the fat variant)
         int w_ = 0, s_ = 0;
         if (sscanf(e, "%d,%d", &w_, &s_) == 2 && w_ >= 1 && w_ <= WPB_ && s_ >= 1 && s_ <= scan16::kSPW) {
             waves = w_ < lw ? w_ : lw; spw = s_; fat = s_ > scan8::kSPW;
         }
     }
+#endif
     CullGeom g;
     g.waves = waves; g.spw = spw; g.fat = fat; g.may_ride = may_ride;
     g.tiles = (lw + waves - 1) / waves; g.slices = (nsgmax + spw - 1) / spw;
@@ -1069,7 +1071,12 @@ static BuildArgs make_build_args(const float *tri1, const float *tri2, void *ws,
     {   // producer and consumer of a cloud's records on the same XCD (round 5: -0.7 us on the records launch, -0.5 us on the
         // scan at C2; RRL_XCD_ALIGN=0 turns it off)
         static int xa = -1;
-        if (xa < 0) { const char *e = getenv("RRL_XCD_ALIGN"); xa = e && e[0] == '0' ? 0 : 1; }
+        if (xa < 0) {
+            xa = 1;
+#ifdef RRL_EXPERIMENT  // (A/B runs of the placement, experimental builds only)
+            if (const char *e = getenv("RRL_XCD_ALIGN")) xa = e[0] == '0' ? 0 : 1;
+#endif
+        }
         a.xcd_align = xa && (clouds * B) % 8 == 0 ? 1 : 0;
     }
     return a;

@@ -450,12 +450,18 @@ int rrl_line_tri_scan_clouds(const float *line, void *ws, size_t ws_bytes, int B
     }
     int R = o.scan_variant;
     if (R == 0) {
-        const char *v = getenv("RRL_SCAN_VARIANT");
+        const char *v = nullptr;
+#ifdef RRL_EXPERIMENT  // (sweeps of the dense scans' variants: experimental builds; rrl_set_scan_variant / rrl_opts.scan_variant ship)
+        v = getenv("RRL_SCAN_VARIANT");
+#endif
         R = v ? atoi(v) : 0;
         if (R != 1 && R != 2 && R != 4 && R != 8) R = 4;  // measured best for every mode (profiles/r02_scan_sweep.jsonl)
     }
     if (chunk == 0) {
-        const char *c = getenv("RRL_SCAN_CHUNK");
+        const char *c = nullptr;
+#ifdef RRL_EXPERIMENT
+        c = getenv("RRL_SCAN_CHUNK");
+#endif
         chunk = c ? atoi(c) : 0;
         if (chunk <= 0) chunk = mode == RRL_SCAN_STRICT ? 64 : 128;
     }

@@ -437,6 +437,70 @@ def callsites_moved():
                                        for j in range(B)] for ni in range(num_iter)])
 
 
+def callsites_moved_dcp_fmr():
+    """callsites_moved.npz for the OTHER two trainers (round 6): the DCP fragment moves CHANNEL-FIRST clouds
+    with code/utils.py:32-37 transform_point_cloud (rot @ cloud + t[:, :, None]; dcp/Train_DCP.py:233-270), the FMR fragment moves
+    them with its 4 x 4 matrices through fmr/se_math/se3.py:110-124 transform (R @ a[..., None] + p; fmr/model.py:265-313).
+    Both are imported from the reference and applied to callsites.npz's inputs with its poses and lines; stored: the
+    reference's MOVED pseudo-triangles, its per-line hit counts on them (labels), per-sample losses (before the trainers'
+    / 5.0) and dL/dpoints1 -- the HIP loss is then checked label-exact / 1e-5 on exactly the reference's inputs for these two
+    layouts too.  The fragments' totals are re-derived and checked against callsites.npz (same seeds: the same fragment)."""
+    import utils as RU  # code/utils.py (the reference's)
+    # (se_math/__init__.py imports its mesh module, which wants `plyfile` -- absent here and unused by the path: an empty stub,
+    #  like openmesh / trimesh above)
+    sys.modules.setdefault("plyfile", types.ModuleType("plyfile")).PlyData = object
+    sys.path.insert(0, os.path.join(REF, "exps_deep_learning", "fmr"))
+    from se_math import se3 as RSE3  # fmr/se_math/se3.py (the reference's)
+    old = np.load(os.path.join(HERE, "callsites.npz"))
+    B, num_iter = old["nb_tar"].shape[0], old["R"].shape[0]
+    src_nb, tar_nb = t(old["nb_src"]), t(old["nb_tar"])
+    Rs, ps = t(old["R"]), t(old["t"])
+    tar_tri = tar_nb.reshape(B, -1, 9)
+    c2 = {}
+
+    def evaluate(tri, lines):
+        tri = tri.detach().clone().requires_grad_(True)
+        row, acc = [], torch.zeros(1)
+        for j in range(B):
+            lj = RL.cal_loss_intersection_batch_whole_median_pts_lines(1, 1, 5, 5, tri[j:j + 1], tar_tri[j:j + 1], lines[j:j + 1], "cpu")
+            row.append(lj.item())
+            acc = acc + lj
+        acc.backward()
+        c1 = np.stack([ref_scan(tri[j].detach().numpy(), lines[j].numpy())["count"] for j in range(B)])
+        return tri.detach().numpy().copy(), tri.grad.numpy().copy(), np.array(row, np.float32), c1
+
+    # ---- DCP: channel-first clouds (B, 3, 3N), pose 0
+    lines = t(old["dcp_lines"])
+    moved_cf = RU.transform_point_cloud(src_nb.transpose(2, 1).contiguous(), Rs[0], ps[0])  # (B, 3, 3N)
+    dcp_tri = moved_cf.transpose(2, 1).reshape(B, -1, 9)
+    d_tri, d_grad, d_row, d_c1 = evaluate(dcp_tri, lines)
+    d_c2 = np.stack([ref_scan(tar_tri[j].numpy(), lines[j].numpy())["count"] for j in range(B)])
+    dcp_total = np.float32((d_row.astype(np.float64) / 5.0).sum() / B)
+    assert abs(float(dcp_total) - float(old["dcp_loss"])) <= 2e-6 * abs(float(old["dcp_loss"])), (dcp_total, old["dcp_loss"])
+    mg = min(margin(d_tri[j], lines[j].numpy()) for j in range(B))
+    # ---- FMR: 4 x 4 matrices, the last three estimates
+    lines_f = t(old["fmr_lines"])
+    bottom = torch.tensor([0.0, 0, 0, 1]).expand(B, 1, 4)
+    f_tri, f_grad, f_row, f_c1 = [], [], [], []
+    for i in range(num_iter - 3, num_iter):
+        g4 = torch.cat([torch.cat([Rs[i], ps[i][..., None]], dim=-1), bottom], dim=1)  # (B, 4, 4)
+        tri = RSE3.transform(g4.unsqueeze(1), src_nb).reshape(B, -1, 9)
+        a_, b_, c_, d_ = evaluate(tri, lines_f)
+        f_tri.append(a_); f_grad.append(b_); f_row.append(c_); f_c1.append(d_)
+        mg = min(mg, min(margin(a_[j], lines_f[j].numpy()) for j in range(B)))
+    f_c2 = np.stack([ref_scan(tar_tri[j].numpy(), lines_f[j].numpy())["count"] for j in range(B)])
+    fmr_total = sum((f_row[k].astype(np.float64) / 5.0).sum() * 0.5 ** (num_iter - i - 1)
+                    for k, i in enumerate(range(num_iter - 3, num_iter))) / B
+    assert abs(fmr_total - float(old["fmr_loss"])) <= 2e-6 * abs(float(old["fmr_loss"])), (fmr_total, old["fmr_loss"])
+    np.savez_compressed(os.path.join(HERE, "callsites_moved_dcp_fmr.npz"),
+                        dcp_moved_tri=d_tri.astype(np.float32), dcp_grad_tri=d_grad.astype(np.float32), dcp_per_sample=d_row,
+                        dcp_count1=d_c1.astype(np.int16), dcp_count2=d_c2.astype(np.int16),
+                        fmr_moved_tri=np.stack(f_tri).astype(np.float32), fmr_grad_tri=np.stack(f_grad).astype(np.float32),
+                        fmr_per_sample=np.stack(f_row), fmr_count1=np.stack(f_c1).astype(np.int16), fmr_count2=f_c2.astype(np.int16),
+                        margin=np.float64(mg), **{k: np.array(str(v)) for k, v in META.items()})
+    print("callsites_moved_dcp_fmr: dcp per-sample", d_row.tolist(), "fmr per-sample", [r.tolist() for r in f_row], "margin %.3g" % mg)
+
+
 def demo_trajectory():
     """test_demo_optimized_Lie_Algebra.py:27-75 (test_one_case) replayed with the reference's
     modules for a few epochs on a small synthetic pair; the sampled lines of every epoch are
@@ -651,6 +715,6 @@ def demo_trajectory_airplane():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["main", "neighs", "callsites", "demo_trajectory", "dataset", "accept", "refdata",
-                             "demo_trajectory_airplane", "refdata_rest", "callsites_moved"]
+                             "demo_trajectory_airplane", "refdata_rest", "callsites_moved", "callsites_moved_dcp_fmr"]
     for name in which:
         globals()[name]()

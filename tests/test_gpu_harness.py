@@ -128,6 +128,50 @@ def test_fragment_loss_on_the_references_moved_triangles(C, G):
             np.testing.assert_allclose(one.item(), M_["per_sample"][ni, j], rtol=1e-5)
 
 
+def test_dcp_and_fmr_losses_on_the_references_moved_triangles(C, G):
+    """round 6: callsites_moved.npz's tight check for the other two trainers' layouts --
+    tests/golden/callsites_moved_dcp_fmr.npz holds the reference's moved pseudo-triangles of the DCP fragment (CHANNEL-FIRST
+    clouds moved by code/utils.py:32-37 transform_point_cloud; dcp/Train_DCP.py:233-270) and of the FMR fragment's last three
+    estimates (4 x 4 matrices through fmr/se_math/se3.py:110-124; fmr/model.py:265-313), its labels, per-sample losses and
+    dL/dpoints1.  On those identical inputs: labels exact, 1e-5 per sample, per-point gradient 1e-4 -- the batched op and the
+    section-8(d) step (R = t = None); and the library's own rigid apply in those two layouts (ops.rigid_apply channel_first /
+    the 4 x 4 split) lands within 1e-6 of the extent of the reference's moved triangles."""
+    from conftest import merge_by_point
+    from rrl_hip import ops
+    M_ = load_golden("callsites_moved_dcp_fmr.npz")
+    assert M_["margin"] > 1e-6
+    B = G["nb_tar"].shape[0]
+    tar_tri = cu(G["nb_tar"]).reshape(B, -1, 9)
+    cases = [("dcp", M_["dcp_moved_tri"], M_["dcp_grad_tri"], M_["dcp_per_sample"], M_["dcp_count1"], M_["dcp_count2"], cu(G["dcp_lines"]), 0)]
+    k = M_["fmr_moved_tri"].shape[0]
+    cases += [("fmr", M_["fmr_moved_tri"][i], M_["fmr_grad_tri"][i], M_["fmr_per_sample"][i], M_["fmr_count1"][i], M_["fmr_count2"],
+               cu(G["fmr_lines"]), G["R"].shape[0] - k + i) for i in range(k)]
+    for name, tris, grads, per, c1, c2, lines, pose in cases:
+        tri = cu(tris, True)
+        loss, info, _ = ops.intersection_loss(tri, tar_tri, lines)
+        st = ops.last_state()
+        np.testing.assert_array_equal(st.count1.cpu().numpy(), c1)   # labels: exact
+        np.testing.assert_array_equal(st.count2.cpu().numpy(), c2)
+        np.testing.assert_allclose(loss.detach().cpu().numpy(), per, rtol=1e-5)
+        loss.sum().backward()
+        step = ops.LossStep(tri.detach(), tar_tri, lines.shape[1])
+        sl, sg, _ = step(None, None, lines)
+        assert torch.equal(sl, loss.detach())
+        for j in range(B):
+            ref = merge_by_point(tris[j], grads[j])
+            for got in (tri.grad[j], sg[j]):
+                np.testing.assert_allclose(merge_by_point(tris[j], got.cpu().numpy()), ref, rtol=1e-4, atol=1e-5 * np.abs(ref).max())
+        # T in this trainer's layout: the library's rigid apply against the reference's moved triangles
+        R, t = cu(G["R"][pose]), cu(G["t"][pose])
+        nb = cu(G["nb_src"])
+        if name == "dcp":  # channel-first (B, 3, 3N) through the drop-in utils.transform_point_cloud (rot @ cloud + t)
+            import utils
+            mine = utils.transform_point_cloud(nb.transpose(2, 1).contiguous(), R, t).transpose(2, 1).reshape(B, -1, 9)
+        else:              # R, t split out of the 4 x 4 matrix (callsites.fmr_intersection_loss)
+            mine = ops.rigid_apply(nb, R, t, transpose_r=True).reshape(B, -1, 9)
+        assert float((mine - tri.detach()).abs().max()) <= 1e-6 * float(tri.detach().abs().max())
+
+
 def test_fmr_fragment(C, G):
     R, t = cu(G["R"], True), cu(G["t"], True)
     bottom = torch.tensor([0.0, 0, 0, 1], device='cuda').expand(R.shape[1], 1, 4)
@@ -533,7 +577,8 @@ def test_bench_line_describes_what_it_times():
     assert run["config"]["prepared_order"] is True and run["config"]["prepare_us"] > 0 and "PREPARED" in run["config"]["workload"]
     assert run["config"]["allreduce"]["process_group"] is False
     rf = run["roofline"]
-    assert rf["kernel"].startswith("cull_scan_kernel") and rf["bound"] == "valu" and rf["peak"] == 78.6
+    assert run["config"]["chained"] is True and "CHAINED" in run["config"]["workload"]  # (round 6: records + both scans as ONE launch)
+    assert rf["kernel"].startswith("cull_scan_build_kernel") and rf["bound"] == "valu" and rf["peak"] == 78.6
     assert rf["launch_ms"] > 0 and rf["executed_flops"] > 0 and rf["work_ratio"] > 10
     assert abs(rf["frac"] - rf["executed_flops"] / (rf["launch_ms"] * 1e-3) / 1e12 / rf["peak"]) < 1e-9
     assert "launch_ms_rocprof" in rf and "frac_rocprof" in rf  # (null unless the committed PMC pass is of this build)
@@ -555,6 +600,13 @@ def test_bench_line_describes_what_it_times():
     assert run["extras"]["loss_sum"] == pytest.approx(ag["loss_sum"], rel=1e-6) and run["extras"]["valid"] == 8.0
     mp = run["extras"]["multi_pose"]
     assert mp.get("loss_bits_equal") is True and mp["two_poses_one_evaluation_ms"] > 0 and mp["one_pose_ms"] > 0, mp
+    # round 6: the line checks ITSELF against the oracle on its own workload, and times loops whose inputs change
+    pr = run["parity_in_run"]
+    assert pr["ok"] is True and pr["labels_equal"] is True and pr["loss_rel_max"] <= 1e-5 and pr["grad_per_point_rel_max"] <= 1e-4, pr
+    assert pr["samples"] == [0, 7] and pr["rigid_apply_rel_max"] <= 1e-6
+    assert v["fresh_lines"]["chained"] is True and v["fresh_lines"]["ms_per_step"] > 0 and v["fresh_clouds_cold"]["ms_per_step"] > 0
+    assert v["deterministic_grad"]["grad_bit_identical_between_calls"] is True and v["deterministic_grad"]["loss_bit_identical_to_timed_step"] is True
+    assert run["config"]["break_even_steps"] is None or run["config"]["break_even_steps"] > 0
     print("ms_per_step:", {"timed": run["ms_per_step"], "cold": run["ms_per_step_cold"], "B64": b64["ms_per_step"],
                            **{k: x["ms_per_step"] for k, x in v.items()}})
 
@@ -591,6 +643,33 @@ def test_fragments_multi_pose_equals_the_loop(C, G):
     assert abs(float(a[2]) - float(b[2])) <= 1e-6 * abs(float(b[2])) and abs(float(a[7]) - float(b[7])) <= 1e-6 * abs(float(b[7]))
     for i in (4, 5, 9):
         assert bool(((a[i] - b[i]).abs() <= 2e-5 * b[i].abs() + 2e-6 * float(b[i].abs().max())).all())
+
+
+def test_fragment_with_a_source_that_requires_grad(C, G):
+    """the multi-pose node differentiates with respect to the transforms only.  A source that requires grad must
+    not silently lose its gradient: multi_pose_loss declines (None) and the fragment takes the per-pose loop, whose fused op
+    returns dL/dsrc -- equal to the loop's with multi-pose switched off."""
+    R, t = cu(G["R"], True), cu(G["t"], True)
+    got = {}
+    for multi in (True, False):
+        C.MULTI_POSE = multi
+        try:
+            d = data_dict(G)
+            d['points_based_neighs_src'] = d['points_based_neighs_src'].detach().clone().requires_grad_(True)
+            pred = [torch.cat([R[i], t[i][..., None]], dim=-1) for i in range(R.shape[0])]
+            if multi:
+                B = d['points_tar_sample'].shape[0]
+                assert C.multi_pose_loss(d['points_based_neighs_src'], pred, d['points_based_neighs_tar'].reshape(B, -1, 9),
+                                         cu(G["rpm_lines"])) is None
+            out = C.rpm_intersection_loss(pred, d, lines=cu(G["rpm_lines"]))
+            out['loss_intersection'].backward()
+            g = d['points_based_neighs_src'].grad
+            assert g is not None and float(g.abs().sum()) > 0
+            got[multi] = (out['loss_intersection'].detach().clone(), g.clone())
+        finally:
+            C.MULTI_POSE = True
+    assert torch.equal(got[True][0], got[False][0])
+    assert bool(((got[True][1] - got[False][1]).abs() <= 2e-5 * got[False][1].abs() + 2e-6 * float(got[False][1].abs().max())).all())
 
 
 def test_bench_two_ranks_sharing_one_gpu():

@@ -1,6 +1,7 @@
 """The fused step (ops.RegistrationStep: forward + direct backward) in a plain loop at one shape -- the
 workload tools/kt.sh runs under rocprofv3 to get per-kernel averages.  usage: step_loop.py B,N,M,L [steps] [diag]
-Environment knobs of the library apply (RRL_REDUCE, RRL_SORT_PARTS, RRL_CULL_GEOM, ...); RRL_PREPARED=0: the cold
+Environment knobs of the library apply (RRL_REDUCE, RRL_SORT_PARTS, ...; RRL_CULL_GEOM / RRL_XCD_ALIGN / RRL_TAIL_MAX_WG only in an
+experimental build: RRL_HIPCC_FLAGS=-DRRL_EXPERIMENT); RRL_PREPARED=0: the cold
 (sorting) step instead of the prepared build."""
 import os, sys, time
 import numpy as np, torch
