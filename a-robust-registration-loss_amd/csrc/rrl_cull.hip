@@ -953,7 +953,23 @@ int rrl_cull_scan_can_fuse(int B, int N, int M, int L, const RrlCall &o) {
     if (o.rider || o.counters || o.problems || o.tar_ws) return 0;
     if (const char *e = getenv("RRL_CHAIN")) if (e[0] == '0') return 0;  // (A/B runs)
     const CullGeom g = cull_geometry(B, N, M, L, 2, o);
-    return g.waves == scan8::kWPB ? 1 : 0;
+    if (g.waves != scan8::kWPB) return 0;
+    // Where the ONE launch pays (measured, profiles/r06_experiments.txt 2; us per step chained / plain): C2 45.8 / 49.8, B = 4
+    // 40.9 / 42.9, B = 12 .. 32 at C2's shape 59.0 / 62.7 .. 110.8 / 116.5, the demo's shape 36.1 / 38.1, C4's 46.2 / 49.4 --
+    // and where it does not: B = 64 (5632 workgroups, ten generations deep: the 512 records workgroups are a small share and
+    // the launch they save was overlapped with nothing anyway; the tile-local maxima's barrier and the write-through records
+    // cost as much) 197.6 / 195.6, and 2 x 16384 triangles with 4096 lines (576 workgroups, ALL resident at once: the source
+    // workgroups wait for the 32 records pieces of their sample, which take longer inside the crowd than as a launch of
+    // their own; the launch cannot end before they are published + one source workgroup's lifetime) 38.5 / 35.6.  No source
+    // workgroup starts before its sample's records are out (8 .. 10 us into a crowded launch), so the launch pays where
+    // that wait hides behind target-cloud work: clouds up to 4096 triangles (<= 8 records pieces per sample) on any grid
+    // measured, larger clouds only on grids several generations deep.
+    const int spw = g.spw, nsg1 = (N + SGT - 1) / SGT, nsg2 = (M + SGT - 1) / SGT;
+    const int nrec_b = (int)(((size_t)nsg1 * SGT + 64 * scan8::kWPB - 1) / (64 * scan8::kWPB));
+    const long total = (long)B * (nrec_b + (long)g.tiles * ((nsg1 + spw - 1) / spw + (nsg2 + spw - 1) / spw));
+    if (g.fat && total > 4000) return 0;
+    if (nrec_b > 8 && total < 2048) return 0;
+    return 1;
 }
 
 int rrl_launch_cull_scan(const float *line, void *ws, const WsLayout &w, int B, int N, int M, int L,

@@ -332,6 +332,8 @@ static int loss_reduce_impl(void *ws, size_t ws_bytes, float *loss, int B, int N
         t.spin_limit = spin_limit();
         t.xcd_align = B % 8 == 0 && xcd_align_on();
         t.payload = o.payload_in_reduce ? o.payload : nullptr;
+        t.chain = o.leave_clean ? w.u32(ws, RRL_WS_CHAIN) : nullptr;
+        t.chain_flags = o.fused_build ? 1 : 0;
         hipLaunchKernelGGL(loss_reduce_tiled_kernel, dim3((unsigned)nblk, (unsigned)B), dim3(256), 0, (hipStream_t)stream, t);
         RRL_LAUNCH_CHECK();
         return 0;
@@ -510,11 +512,11 @@ static int loss_forward_impl(const float *tri1, const float *tri2, const float *
         o.order1 = o.order2 = nullptr;
     // a kept target: cloud 2's records / tree / partials stay as the previous call on this workspace left them
     const int build_clouds = o.target_kept() ? 1 : clouds;
-    // Chained steps (include/rrl.h RRL_F_CHAIN / RRL_F_CHAINED).  The chain lives where the per-line stage + tail kernel
-    // serve the call: they are the ones that leave COUNT1 / COUNT2 and the CHAIN words cleared.
+    // Chained steps (include/rrl.h RRL_F_CHAIN / RRL_F_CHAINED).  The chain lives where the per-line stage + the tail kernel or
+    // the exchange reduce serve the call: they are the ones that leave COUNT1 / COUNT2 and the CHAIN words cleared.
     const bool chain_path = B > 0 && L > 1024 && !pool && clouds == 2 && !o.problems && mode == RRL_SCAN_CULL &&
                             (N > M ? N : M) <= rrl_sort_capacity() && N > 0 && M > 0 &&
-                            reduce_kind(o.reduce_mode, B, (L + 1023) / 1024, pool, tb != nullptr) == 2;
+                            reduce_kind(o.reduce_mode, B, (L + 1023) / 1024, pool, tb != nullptr) >= 1;
     o.leave_clean = (o.flags & RRL_F_CHAIN) && chain_path ? 1 : 0;
     if (o.chain_left) *o.chain_left = o.leave_clean;
     // ... and a step that FINDS them cleared runs source records + target scan + source scan as ONE launch

@@ -66,11 +66,13 @@ def _assert_same(a, b, what):
     assert bool(((ga - gb).abs() <= 2e-5 * ga.abs() + 2e-6 * float(ga.abs().max())).all()), what
 
 
-@pytest.mark.parametrize("B,n,m,nl,scale,fusable", [
+@pytest.mark.parametrize("B,n,m,nl,scale,fusable", [  # (fusable: rrl_cull_scan_can_fuse's measured rule, csrc/rrl_cull.hip)
     (2, 1200, 1000, 6000, 1.0, True), (8, 4096, 4096, 10000, 1.0, True), (1, 1024, 1024, 20000, 1.0, True),
-    (3, 700, 900, 4000, 1.0, True), (1, 5000, 4100, 3000, 1.0, True), (2, 1000, 1200, 5000, 12.0, True),
+    (3, 700, 900, 4000, 1.0, True), (1, 5000, 4100, 3000, 1.0, False), (2, 1000, 1200, 5000, 12.0, True),
     (16, 500, 400, 2500, 1.0, True), (12, 4096, 4096, 10000, 1.0, True),  # (the last one: the fat scan variant, scan16)
-    (5, 330, 260, 1100, 1.0, False)])  # (a grid so thin that the scan runs fewer than 8 wavefronts per workgroup: the plain four launches)
+    (40, 300, 260, 7000, 1.0, True), (48, 2048, 2048, 10000, 1.0, True),  # (beyond the tail kernel's grid: exchange reduce + scatter launch; the second: scan16 too)
+    (5, 330, 260, 1100, 1.0, False),  # (a grid so thin that the scan runs fewer than 8 wavefronts per workgroup: the plain four launches)
+    (2, 9000, 9100, 4096, 1.0, False)])  # (few, large clouds on a shallow grid: the source workgroups would wait for 18 records pieces each -- measured slower fused: plain)
 def test_chained_steps_equal_unchained_steps(L, B, n, m, nl, scale, fusable):
     from rrl_hip import ops
     prs, src, tar = _pairs(900, B, n, m)
