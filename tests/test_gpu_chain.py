@@ -276,3 +276,32 @@ def test_deterministic_points1_grad(L, B, n, m, nl, prepared):
         assert torch.equal(outs[0][0], first)  # the same sums whichever entry issued them
     finally:
         ops.set_deterministic(False)
+
+
+@pytest.mark.timeout(300)
+def test_chained_launch_under_contention(L):
+    """The hand-off inside the chained launch (source records -> ready word -> source-cloud scan workgroups) with most of the
+    chip taken by another stream's filler kernel (ops.debug_occupy), so that the launch's workgroups become resident a few at a
+    time and in waves: the records workgroups lead the grid, the waiters are bounded -- same loss / info / hit lists as the plain
+    step every time, no time-out (a time-out would make the sample's loss NaN)."""
+    from rrl_hip import ops
+    B, n, m, nl = 4, 2048, 2048, 9000
+    prs, src, tar = _pairs(990, B, n, m)
+    ln = _new_lines(L, prs, nl, 2)
+    R, t = _poses(B, 1)
+    ref = ops.LossStep(src, tar, nl, chain=False)
+    want = _snapshot(ref, ref(R, t, ln))
+    st = ops.LossStep(src, tar, nl)
+    st(R, t, ln)
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    side = torch.cuda.Stream()
+    for rnd, free in enumerate((8, 12, 16, 24, 40, 64)):
+        # 2 workgroups of 1024 lanes fill a compute unit's wavefront slots: `free` half units stay for the step's launches
+        ops.debug_occupy(2 * cus - free, 1024, 0.05, side)
+        for _ in range(3):
+            st.st.lmax.fill_(-7.0)
+            got = _snapshot(st, st(R, t, ln))
+            torch.cuda.synchronize()
+            _assert_same(want, got, ("contention", free))
+            assert bool((st.st.lmax == -7.0).all())
+        side.synchronize()

@@ -19,6 +19,16 @@ ops.scan_counters(True)
 st = ops.loss_forward_raw(w["tri1"], w["tri2"], w["lines"], mode="cull", opts=opts)
 torch.cuda.synchronize()
 raw = ops.scan_counters(False, raw=True).cpu().numpy()
+if os.environ.get("RRL_DELAY_REPORT"):  # (experimental build -DCULL_DELAY_HALF: odd workgroups entered ~2 us late; wall0 is taken AFTER the sleep)
+    wg = np.arange(raw.shape[0]) // 8
+    t0 = raw[raw[:, 5] == 1][:, 8].min()
+    for par, name in ((0, "even workgroups (on time)"), (1, "odd workgroups (delayed)")):
+        r = raw[(raw[:, 5] == 1) & (wg % 2 == par) & (raw[:, 6] == 0)]
+        first = (r[:, 8] - t0) < 600  # entered within 6 us of the launch's first wavefront: the first generation
+        t_sl = (r[:, 15] & 0xffffffff) / 100.0
+        print(f"  {name}: {len(r)} wavefronts, first generation {int(first.sum())}: start {((r[first, 8] - t0) / 100.0).mean():.2f} us, "
+              f"first loads back + slack {t_sl[first].mean():.2f} us after the wavefront's start (later generations {t_sl[~first].mean():.2f}); "
+              f"prologue {((r[first, 10] - r[first, 8]) / 100.0).mean():.2f}")
 rows = raw[raw[:, 5] == 1]
 start = (rows[:, 8] - rows[:, 8].min()) / 100.0
 life = (rows[:, 9] - rows[:, 8]) / 100.0

@@ -31,7 +31,9 @@ def run(iters=3000, shapes=SHAPES, log=print):
             ref2 = [x.clone() for x in two(R, t, w["lines"])[:4]] + [two.st.med.clone(), two.st.bsum.clone()]
         finally:
             ops.RegistrationStep.ONE_CALL = True
-        one = ops.RegistrationStep(w["tri1"], w["tri2"], L, want_payload=True)  # one call, prepared build, kept target
+        # one call, prepared build, kept target; CHAINED like the LossStep below (round 6: from the second iteration on the source's
+        # records, the target's scan and the source's scan are one launch with an in-launch hand-off)
+        one = ops.RegistrationStep(w["tri1"], w["tri2"], L, want_payload=True, chain=True)
         ls = ops.LossStep(w["tri1"], w["tri2"], L)
         first = lfirst = None
         t0 = time.time()
