@@ -586,13 +586,15 @@ def main():
         # ---- the fused TRAINING op (rounds 3-4's headline): backward straight to (dR, dT), 14-float payload with the sums
         rs = ops.RegistrationStep(w["tri1"], w["tri2"], L, transpose_r=True, mode=args.mode, want_payload=True,
                                   prepared=prepared, src_order=order1 if prepared else None,
-                                  tar_order=order2 if prepared else None)
+                                  tar_order=order2 if prepared else None, chain=True)
         fms, fout = time_loop(lambda: rs(Rd, Td, w["lines"]), args.steps)
         fused_gR = fout[1].clone()
         variants["fused_dRdT"] = {
             "ms_per_step": fms, "value": pairs_step / (fms * 1e-3), "unit": "point-pairs/s (this rank, no all-reduce)",
-            "what": "ops.RegistrationStep -> rrl_registration_step: rigid apply + loss + backward straight to (dR, dT) "
-                    "(no points1.grad), one C call per step -- what a trainer whose pose comes out of a network needs",
+            "what": "ops.RegistrationStep(chain=True) -> rrl_registration_step: rigid apply + loss + backward straight to (dR, dT) "
+                    "(no points1.grad), one C call per step, chained like the timed step -- what a trainer whose pose comes out "
+                    "of a network needs",
+            "chained": bool(rs._chain_ready),
             "loss_bit_identical_to_timed_step": bool(torch.equal(fout[0], loss_default))}
         del rs
 
