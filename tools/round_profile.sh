@@ -12,7 +12,7 @@ R=$PWD; O=$R/gpurun_out; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 python3 $R/bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_stats -o s -- python3 $R/bench.py --no-cpu-baseline > $O/${TAG}_bench_prof.json 2> $O/${TAG}_bench_prof.err
-STEPARGS="--no-cpu-baseline --no-extras --no-other --issue direct --no-dist"
+STEPARGS="--no-cpu-baseline --no-extras --no-other --issue direct --no-dist --no-fresh --no-parity"
 passes() {  # $1 = suffix ("" or "_b64"), $2 = extra bench arguments
   # the timed step alone (no variant / strict / counter / drop-in / Chamfer passes): per-kernel averages of the headline path
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_stats_step$1 -o s -- python3 $R/bench.py $STEPARGS $2 > /dev/null 2> $O/${TAG}_bench_step$1.err
@@ -46,7 +46,7 @@ def per_kernel(counter_dir):
 def short(n):
     return re.sub(r"^void ", "", n).split("(")[0].split("<")[0].split("::")[-1]
 def summarise(sfx, B, what):
-    STEP = f"bench.py --issue direct --no-extras --no-other --no-dist --steps 6{what} (the timed one-call step: ops.LossStep -> rrl_loss_step_ex, SURVEY 8(d): backward to points1.grad)"
+    STEP = f"bench.py --issue direct --no-extras --no-other --no-dist --no-fresh --no-parity --steps 6{what} (the timed one-call step: ops.LossStep -> rrl_loss_step_ex, SURVEY 8(d): backward to points1.grad)"
     out = {"csrc_sha": csrc_sha(), "profiled_command": STEP,
            "note": "rocprofv3 --pmc, separate passes per counter group; per-launch means. "
                    "FETCH_SIZE / WRITE_SIZE in KB as reported; gfx950 correction for wide (16 B/lane) streaming reads: "

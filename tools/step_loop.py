@@ -37,11 +37,24 @@ ops.RegistrationStep.ONE_CALL = os.environ.get("RRL_ONE_CALL", "1") != "0"
 Step = ops.LossStep if os.environ.get("RRL_STEP", "reg") == "loss" else ops.RegistrationStep
 rs = Step(src, tar, L, transpose_r=True, mode=os.environ.get("RRL_SCAN_MODE", "cull"),
           prepared=os.environ.get("RRL_PREPARED", "1") != "0")
-for _ in range(10):
-    rs(R, t, ln)
+# RRL_LINE_SETS=K: K different line sets (and poses) rotated per step -- the demo's pattern: new lines every epoch
+K = int(os.environ.get("RRL_LINE_SETS", "1"))
+sets = [(R, t, ln)]
+for k in range(1, K):
+    lk = []
+    for b, p in enumerate(prs):
+        torch.manual_seed(1000 * k + b)
+        lk.append(Lmod.Random_uniform_distribution_lines_batch_efficient_resample(
+            torch.tensor([[float(p["radius"]) * (2.0 if diag is not None else 1.0)]]), torch.from_numpy(p["center"]).reshape(1, 3), L,
+            torch.from_numpy(p["src"])[None].cuda(), torch.from_numpy(p["tar"])[None].cuda(), "cuda")[0])
+    a = 0.01 * k
+    Rk = torch.tensor([[np.cos(a), -np.sin(a), 0.0], [np.sin(a), np.cos(a), 0.0], [0.0, 0.0, 1.0]], dtype=torch.float32, device="cuda").repeat(B, 1, 1)
+    sets.append((Rk, t + 0.001 * k, torch.stack(lk)))
+for i in range(10):
+    rs(*sets[i % K])
 torch.cuda.synchronize(); t0 = time.perf_counter()
-for _ in range(steps):
-    rs(R, t, ln)
+for i in range(steps):
+    rs(*sets[i % K])
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
 print(f"shape {B},{N},{M},{L} diag {diag}: {dt * 1e6:.1f} us per step (direct issue), loss_sum {float(rs.st.loss.sum()):.10f} "
       f"nsel {rs.st.info[:, 1].tolist()} status {rs.st.status.tolist()}")
