@@ -589,6 +589,18 @@ def main():
             del lcold, clouds_k
         roofline = scan_roofline(ops, lambda: ls(Rd, Td, w["lines"]), B, N, M, L, launches=min(args.steps, 20),
                                  counters=do_extras and args.mode == "cull")
+        if chained_step and "executed_flops" in roofline:
+            # the scan ALONE, as a launch of its own (the plain step: chain off), for the same executed arithmetic: the chained
+            # launch's fraction is taken over records + scan, this one over the scan kernel -- round 5's figure, like for like
+            lpl = loss_step(prepared)
+            lpl.chain = False
+            rpl = scan_roofline(ops, lambda: lpl(Rd, Td, w["lines"]), B, N, M, L, launches=min(args.steps, 20), counters=False)
+            roofline["plain_scan"] = {
+                "kernel": "cull_scan_kernel<false> of the PLAIN step (ops.LossStep(chain=False): records launch + this scan launch)",
+                "launch_ms": rpl["launch_ms"], "launches_timed": rpl["launches_timed"],
+                "frac": roofline["executed_flops"] / (rpl["launch_ms"] * 1e-3) / 1e12 / VALU_PEAK_TFLOPS,
+                "loss_bit_identical_to_timed_step": bool(torch.equal(lpl.st.loss, loss_default))}
+            del lpl
     if do_extras:
         # ---- the fused TRAINING op (rounds 3-4's headline): backward straight to (dR, dT), 14-float payload with the sums
         rs = ops.RegistrationStep(w["tri1"], w["tri2"], L, transpose_r=True, mode=args.mode, want_payload=True,

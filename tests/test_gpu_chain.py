@@ -305,3 +305,34 @@ def test_chained_launch_under_contention(L):
             _assert_same(want, got, ("contention", free))
             assert bool((st.st.lmax == -7.0).all())
         side.synchronize()
+
+
+@pytest.mark.parametrize("names", [["loss_ref_airplane%d.npz" % i for i in range(5)], ["loss_ref_real%d.npz" % i for i in range(3)],
+                                   ["loss_ref_human%d.npz" % i for i in range(3)]])
+def test_chained_step_on_the_references_own_pairs(L, oracle, names):
+    """The chained launch on the sample pairs the REFERENCE ships (tests/golden/loss_ref_*.npz: airplane, real scan, human; their
+    pseudo-triangles and the lines the reference sampled for them), batched: third call of ops.LossStep (R = t = None: the
+    triangles as given) against the pinned oracle per sample -- counts exact, median equal, loss 1e-5, per-point gradient 1e-4 --
+    and, where the fixture holds the reference's own result for exactly these lines, against that."""
+    from conftest import load_golden, merge_by_point
+    from rrl_hip import ops
+    gs = [load_golden(n) for n in names]
+    nl = min(g["lines"].shape[0] for g in gs)
+    src, tar = cu(np.stack([g["tri1"] for g in gs])), cu(np.stack([g["tri2"] for g in gs]))
+    ln = cu(np.stack([g["lines"][:nl] for g in gs]))
+    step = ops.LossStep(src, tar, nl)
+    for call in range(3):
+        step.st.lmax.fill_(-7.0)
+        loss, grad, info = step(None, None, ln)
+    torch.cuda.synchronize()
+    assert bool((step.st.lmax == -7.0).all()), "the third call runs the chained launch"
+    for b, g in enumerate(gs):
+        ref = oracle.loss(g["tri1"], g["tri2"], g["lines"][:nl], want_grad=True)
+        assert [int(v) for v in info[b].tolist()] == [ref["n_buckets"], ref["n_selected"], ref["n_values"], int(ref["nan"])]
+        assert float(step.st.med[b]) == float(ref["median"])
+        assert abs(float(loss[b]) - float(ref["loss"])) <= 1e-5 * abs(float(ref["loss"]))
+        a, w = merge_by_point(g["tri1"], grad[b].cpu().numpy()), merge_by_point(g["tri1"], ref["grad1"])
+        assert np.abs(a - w).max() <= 1e-4 * np.abs(w).max()
+        if g["lines"].shape[0] == nl:  # the reference evaluated exactly these lines: its own loss (default bucket range = ranges[0])
+            assert [int(v) for v in g["ranges"][0]] == [1, 1, 5, 5]
+            assert abs(float(loss[b]) - float(g["r0_loss"])) <= 1e-5 * abs(float(g["r0_loss"]))
