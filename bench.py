@@ -507,6 +507,20 @@ def main():
     dense_flops = FLOPS_PER_PAIR * pairs_step
     do_extras = rank == 0 and not args.no_extras
     other = None
+    # ---- host time per step: what the CPU spends inside the calls that issue one step (the C call of
+    # ops.LossStep + the reducer), measured while the GPU works through them asynchronously -- the step is GPU-bound as long as
+    # this stays below ms_per_step; every rank measures (no collective inside), rank 0 reports
+    host_us = None
+    if graphed is None:
+        torch.cuda.synchronize()
+        acc_h, nh = 0.0, 100
+        for _ in range(nh):
+            th = time.perf_counter()
+            step()
+            acc_h += time.perf_counter() - th
+        finish()
+        torch.cuda.synchronize()
+        host_us = acc_h / nh * 1e6
     parity = None
     if rank == 0:
         loss_default = ls.st.loss.clone()
@@ -850,7 +864,14 @@ def main():
         ms_step = dt / args.steps * 1e3
         extras.update({"loss_sum": float(payload[0]), "valid": float(payload[1]),
                        "line_sampling_s": w["sample_s"], "scan_launch_ms": cull_ms,
-                       "scan_share_of_step": cull_ms / ms_step})
+                       "scan_share_of_step": cull_ms / ms_step,
+                       "host_us_per_step": host_us,
+                       "host_margin": (1.0 - host_us / (ms_step * 1e3)) if host_us else None,
+                       "host_note": "CPU time inside the calls that issue one step (ops.LossStep's C call: 3 launches chained, + the "
+                                    "reducer), 100 steps issued asynchronously behind the timed region; host_margin = 1 - host / "
+                                    "ms_per_step: the step is GPU-bound while it is positive (a slower host moves the crossover; a "
+                                    "hipGraph replay costs ~8 us + 1.5 us per node on this stack and is measured in warm-up: "
+                                    "config.allreduce.warmup_ms_per_step)"})
         out = {
             "metric": "point-pairs/sec for loss fwd+bwd at B=8, N=M=4096",
             "value": value, "unit": "point-pairs/s", "n_gpus": world, "steps": args.steps,
