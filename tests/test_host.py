@@ -78,9 +78,16 @@ def test_product_never_imports_oracle():
             text = open(os.path.join(dirpath, f), errors="ignore").read()
             assert "rrl_oracle" not in text and "from oracle" not in text and "import oracle" not in text, f
     bench = open(os.path.join(ROOT, "bench.py")).read()
+    # bench.py: the oracle is the CHECKER, never the thing measured -- only inside cpu_baseline() (the reported CPU leg) and
+    # parity_in_run() (round 6: the oracle's check of the timed workload, run after the timed region)
     uses = [i for i in range(len(bench)) if bench.startswith("rrl_oracle", i)]
-    lo, hi = bench.index("def cpu_baseline("), bench.index("def main(")
-    assert uses and all(lo < i < hi for i in uses)
+    spans = []
+    for name in ("def cpu_baseline(", "def parity_in_run("):
+        lo = bench.index(name)
+        spans.append((lo, bench.index("\ndef ", lo + 1)))
+    assert uses and all(any(lo < i < hi for lo, hi in spans) for i in uses)
+    timed = bench[bench.index("    t0 = timed(step, args.steps)"):bench.index("    fence()  # closing barrier")]
+    assert "oracle" not in timed and "parity_in_run" not in timed
 
 
 def test_lie_algebra_vs_reference():
