@@ -240,9 +240,11 @@ __device__ __forceinline__ void tri_record_row(const BuildArgs &a, int cloud, in
             for (int j = 0; j < 3; ++j)
                 c[3 * q + j] = fmaf(v2, m[6 + j], fmaf(v1, m[3 + j], v0 * m[j])) + tv[j];
         }
-        float *moved = a.tri1_out + ((size_t)b * n + f) * 9;
+        if constexpr (!PUB) {  // (PUB: the caller stores TRI1 -- nine scattered 4-byte stores -- BEHIND its ticket: rec_late_stores)
+            float *moved = a.tri1_out + ((size_t)b * n + f) * 9;
 #pragma unroll
-        for (int i = 0; i < 9; ++i) moved[i] = c[i];
+            for (int i = 0; i < 9; ++i) moved[i] = c[i];
+        }
     }
     tri_thresholds(c, &thr, &x, &e01);  // code/loss.py:94-110
     // NaN reach (culled scan, "NaN detection" in the header): points 1, 2 lie within e01 of point 0, and the
@@ -386,9 +388,29 @@ __global__ __launch_bounds__(REC_BLK) void tri_records_kernel(const BuildArgs a)
 // run it with the scan's 512 lanes.)
 // PUB: everything the culled scan reads of this cloud -- PTRI, DEL, P0S, the tree nodes, the partial rows -- leaves by
 // write-through (sc1) stores: other workgroups of the same launch read it (cdna_hip_programming.md Guideline 16 R1).
+// What a PUBLISHING records body leaves for its caller to store once the ticket is out -- nothing in the launch reads it: the
+// moved row (TRI1, nine scattered 4-byte stores per lane: the per-line stage of the NEXT launch reads it) and the index
+// entry (IDX: not read when the rows sit at their sorted positions).  Off the hand-off's critical chain.
+struct RecLate {
+    float c[9];
+    int f, s;
+    bool valid, in_range;
+};
+__device__ __forceinline__ void rec_late_stores(const BuildArgs &a, const RecPlace &pl, const RecLate &l) {
+    const int n = pl.cloud ? a.M : a.N;
+    const int npad = (n + SGT - 1) / SGT * SGT;
+    if (l.in_range) (pl.cloud ? a.idx2 : a.idx1)[(size_t)pl.b * npad + l.s] = l.f;
+    if (l.valid && pl.cloud == 0 && a.R != nullptr) {
+        float *moved = a.tri1_out + ((size_t)pl.b * n + l.f) * 9;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) moved[i] = l.c[i];
+    }
+}
 template <bool PUB = false>
 __device__ __forceinline__ void records_sorted_body(const BuildArgs &a, const int32_t *__restrict__ order1,
-                                                    const int32_t *__restrict__ order2, const RecPlace &pl, float (*red)[8]) {
+                                                    const int32_t *__restrict__ order2, const RecPlace &pl, float (*red)[8],
+                                                    RecLate *late = nullptr) {
+    if (late) { late->valid = late->in_range = false; late->f = late->s = 0; }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int B = a.B;
     const int cloud = pl.cloud, b = pl.b, bxr = pl.bxr;
@@ -407,7 +429,12 @@ __device__ __forceinline__ void records_sorted_body(const BuildArgs &a, const in
     if (threadIdx.x < 64 && __float_as_int(c[0] + c[4] + c[8] + x) != 0x12345678) STAMPR(2);
     if (s - lane < npad) {  // wave-uniform: this wavefront holds a supergroup
         const float4 rec = valid ? make_float4(c[0], c[1], c[2], x) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        (cloud ? a.idx2 : a.idx1)[(size_t)b * npad + s] = f;
+        if constexpr (!PUB) (cloud ? a.idx2 : a.idx1)[(size_t)b * npad + s] = f;
+        if (late) {
+            late->in_range = true; late->valid = valid; late->f = f; late->s = s;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) late->c[i] = c[i];
+        }
         float4 *nodes = (cloud ? a.grp2 : a.grp1) + (size_t)b * (npad / SGT) * NODE;
         if constexpr (PUB) {
             st16_sc1(rrl_rsrc((cloud ? a.p0s2 : a.p0s1) + (size_t)b * npad, (size_t)npad * 16), (unsigned)s * 16u, rec);
