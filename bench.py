@@ -686,7 +686,7 @@ def main():
                     "pts_lines calls) -> backward to points1.grad (B,N,9), then rigid-apply backward to dR, dT; "
                     + ("hipGraph replay" if gd is not dropin_step else "eager launches"),
             "points1_grad_nonzero_rows": int((g1.abs().sum(-1) > 0).sum()),
-            "loss_sum": float(keep["loss"].sum()),
+            "loss_sum": float(keep["loss"].detach().sum()),
             "loss_bit_identical_to_timed_step": bool(torch.equal(keep["loss"].detach(), loss_default)),
             "points1_grad_max_rel_diff_vs_timed_step": float((grad_default - g1).abs().max() / g1.abs().max()),
             "dR_max_rel_diff_vs_fused": float((w["R"].grad - fused_gR).abs().max() / fused_gR.abs().max())}

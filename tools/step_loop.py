@@ -35,8 +35,16 @@ t = torch.zeros(B, 3, device="cuda")
 ops.RegistrationStep.ONE_CALL = os.environ.get("RRL_ONE_CALL", "1") != "0"
 # RRL_STEP=loss: SURVEY 8(d)'s step (ops.LossStep: backward to points1.grad) -- bench.py's timed step since round 5
 Step = ops.LossStep if os.environ.get("RRL_STEP", "reg") == "loss" else ops.RegistrationStep
+kw = {}
+if os.environ.get("RRL_PRESORT"):  # experiment: the source's rows stored in their sorted order (order = identity)
+    o1 = ops.cloud_order(src)
+    npad = o1.shape[1]
+    src = torch.stack([src[b][o1[b, :N].long()] for b in range(B)]).contiguous()
+    ident = torch.arange(npad, dtype=torch.int32, device="cuda").repeat(B, 1).contiguous()
+    ident[:, N:] = 0
+    kw["src_order"] = ident
 rs = Step(src, tar, L, transpose_r=True, mode=os.environ.get("RRL_SCAN_MODE", "cull"),
-          prepared=os.environ.get("RRL_PREPARED", "1") != "0")
+          prepared=os.environ.get("RRL_PREPARED", "1") != "0", **kw)
 # RRL_LINE_SETS=K: K different line sets (and poses) rotated per step -- the demo's pattern: new lines every epoch
 K = int(os.environ.get("RRL_LINE_SETS", "1"))
 sets = [(R, t, ln)]
