@@ -1083,7 +1083,7 @@ extern "C" int rrl_shard_payload(const float *loss, const void *ws, size_t ws_by
 #endif
 // experimental builds (RRL_HIPCC_FLAGS, rrl_hip/build.py) carry their flags in the version string
 extern "C" const char *rrl_version(void) {
-    return sizeof(RRL_BUILD_FLAGS) > 1 ? "rrl_hip 0.5 (gfx950) [" RRL_BUILD_FLAGS "]" : "rrl_hip 0.5 (gfx950)";
+    return sizeof(RRL_BUILD_FLAGS) > 1 ? "rrl_hip 0.6 (gfx950) [" RRL_BUILD_FLAGS "]" : "rrl_hip 0.6 (gfx950)";
 }
 
 // ---------------------------------------------------------------------------------------

@@ -518,10 +518,10 @@ static int loss_forward_impl(const float *tri1, const float *tri2, const float *
                             (N > M ? N : M) <= rrl_sort_capacity() && N > 0 && M > 0 &&
                             reduce_kind(o.reduce_mode, B, (L + 1023) / 1024, pool, tb != nullptr) >= 1;
     o.leave_clean = (o.flags & RRL_F_CHAIN) && chain_path ? 1 : 0;
-    if (o.chain_left) *o.chain_left = o.leave_clean;
     // ... and a step that FINDS them cleared runs source records + target scan + source scan as ONE launch
     o.fused_build = (o.flags & RRL_F_CHAINED) && chain_path && o.target_kept() && !o.count_rider && !o.write_rider &&
                     rrl_cull_scan_can_fuse(B, N, M, L, o) ? 1 : 0;
+    if (o.chain_left) *o.chain_left = o.leave_clean | (o.fused_build << 1);  // bit 0: leaves the workspace chain-clean; bit 1: THIS call's build is fused
     o.xf = xf;
     o.tri1_in = tri1;
     int rc;

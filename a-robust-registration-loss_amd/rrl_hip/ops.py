@@ -985,6 +985,7 @@ class RegistrationStep:
         self.chain = bool(chain)
         self._chain_left = ctypes.c_int32(0)
         self._chain_ready = False
+        self.fused = False
         self.order1 = self.order2 = None
         if self.prepared:
             self.order1 = _check_order(src_order, Bt, N, dev, "src_order") if src_order is not None else cloud_order(self.src)
@@ -1073,7 +1074,8 @@ class RegistrationStep:
                       "rrl_registration_backward")
         if self.prepared:
             self._kept_key = key  # (None for a carried-over target -- it is not built here -- and with keep_target off)
-            self._chain_ready = self._chain_left.value == 1
+            self._chain_ready = bool(self._chain_left.value & 1)
+            self.fused = bool(self._chain_left.value & 2)  # THIS call's records + scans ran as one launch
         self.st.counts_cleared = self._chain_ready
         _IntersectionLoss.last_state = self.st
         if self.ride is not None:  # .chamfer_value: this step's monitor (it rode in the scan's launch, or one launch now)
@@ -1149,6 +1151,7 @@ class LossStep:
         self.chain = bool(chain)
         self._chain_left = ctypes.c_int32(0)
         self._chain_ready = False  # the previous call on self.st left it chain-clean and nothing has touched it since
+        self.fused = False
         if self.prepared:
             self.order1 = _check_order(src_order, Bt, N, dev, "src_order") if src_order is not None else cloud_order(self.src)
             self.order2 = _check_order(tar_order, Bt, M, dev, "tar_order") if tar_order is not None else cloud_order(self.tar)
@@ -1195,7 +1198,8 @@ class LossStep:
                                              self.tr, *self.rng, self.mode, self.chunk, None, op, _stream(dev)),
                   "rrl_loss_step")
         self._kept_key = key
-        self._chain_ready = self.prepared and self._chain_left.value == 1
+        self._chain_ready = self.prepared and bool(self._chain_left.value & 1)
+        self.fused = bool(self._chain_left.value & 2)  # THIS call's records + scans ran as one launch
         self.st.counts_cleared = self._chain_ready
         _IntersectionLoss.last_state = self.st
         if self.ride is not None:

@@ -526,7 +526,7 @@ def main():
         loss_default = ls.st.loss.clone()
         grad_default = ls.grad.clone()
         info_default = ls.st.info.clone()
-        chained_step = bool(getattr(ls, "_chain_ready", False)) and ls.chain
+        chained_step = bool(getattr(ls, "fused", False))  # the library's own word: the timed calls' records + scans were ONE launch
         if not args.no_parity:
             try:
                 parity = parity_in_run(w, Rd, Td, ls.st.tri1t.clone(), loss_default, grad_default, info_default, sorted({0, B - 1}))
@@ -574,7 +574,7 @@ def main():
                 fms, _ = time_loop(fresh_lines_step, max(args.steps, 4 * K), warm=2 * K)
                 variants["fresh_lines"] = {
                     "ms_per_step": fms, "value": pairs_step / (fms * 1e-3), "unit": "point-pairs/s (this rank, no all-reduce)",
-                    "sets": K, "chained": bool(lf._chain_ready),
+                    "sets": K, "chained": bool(lf.fused),
                     "what": f"the timed step (prepared orders, kept target) with NEW lines and a NEW pose in every step: {K} pre-sampled "
                             "line sets and poses rotated per step -- the demo's loop (code/test_demo_optimized_Lie_Algebra.py:48-57: "
                             "lines re-sampled and the pose updated every epoch, the target never moves)"}
@@ -627,7 +627,7 @@ def main():
             "what": "ops.RegistrationStep(chain=True) -> rrl_registration_step: rigid apply + loss + backward straight to (dR, dT) "
                     "(no points1.grad), one C call per step, chained like the timed step -- what a trainer whose pose comes out "
                     "of a network needs",
-            "chained": bool(rs._chain_ready),
+            "chained": bool(rs.fused),
             "loss_bit_identical_to_timed_step": bool(torch.equal(fout[0], loss_default))}
         del rs
 

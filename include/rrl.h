@@ -171,9 +171,10 @@ const char *rrl_version(void);
  * in the leading workgroups of the scan's grid, the target-cloud workgroups next, the source-cloud workgroups last, behind
  * the sample's ready word (CHAIN[b][0]); the line slacks come from the scan tile's own lines instead of LMAX.  Three
  * launches instead of four, same labels / hit lists / loss bits.
- *   - *chain_left (rrl_opts, host memory, written when the call is ISSUED) = 1 when this call leaves the workspace
- *     chain-clean (the shape is served by the per-line stage + tail kernel and RRL_F_CHAIN was set), else 0;
- *   - RRL_F_CHAINED is valid only when the PREVIOUS call on this workspace reported chain_left = 1 and nothing else has
+ *   - *chain_left (rrl_opts, host memory, written when the call is ISSUED): bit 0 = this call leaves the workspace
+ *     chain-clean (the shape is served by the per-line stage + tail kernel / exchange reduce and RRL_F_CHAIN was set); bit 1 =
+ *     THIS call's build ran fused (RRL_F_CHAINED was honoured);
+ *   - RRL_F_CHAINED is valid only when the PREVIOUS call on this workspace reported chain_left bit 0 and nothing else has
  *     written the workspace since; it needs RRL_F_TARGET_KEPT and is ignored (plain 4-launch step) whenever the fused
  *     launch cannot serve the call (rider, counters, multi-pose, other reduce kernels, thin grids);
  *   - after a step with RRL_F_CHAIN COUNT1 / COUNT2 read zero (KJ / HS1 / HS2 hold what the per-line stage read), so its
@@ -235,7 +236,7 @@ typedef struct rrl_opts {
      * after the other; the target's scan runs ONCE per problem (instances < Bt), the sources' scans side by side in the same
      * launch.  Scan mode cull, clouds within the sort capacity, no target_ws, pool = 0; RRL_E_ARG otherwise. */
     int32_t problems;
-    int32_t *chain_left;     /* NULL, or a HOST int32 that receives 1 / 0 at issue time (RRL_F_CHAIN above) */
+    int32_t *chain_left;     /* NULL, or a HOST int32 that receives the two bits above at issue time (RRL_F_CHAIN) */
 } rrl_opts;
 
 size_t rrl_workspace_bytes(int B, int N, int M, int L);

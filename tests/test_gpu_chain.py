@@ -93,6 +93,7 @@ def test_chained_steps_equal_unchained_steps(L, B, n, m, nl, scale, fusable):
         _assert_same(a, b, it)
         assert torch.equal(plain.payload[:2], chained.payload[:2]) or abs(float(plain.payload[0] - chained.payload[0])) < 1e-5
         was_fused = bool((chained.st.lmax == -7.0).all())
+        assert chained.fused == was_fused and plain.fused is False  # the library's own word (rrl_opts.chain_left bit 1)
         fused += was_fused
         assert was_fused == (it > 0 and fusable), (it, "the second and later steps of a chain run the fused launch")
         # what a chained step leaves behind: cleared counts and CHAIN words; the unchained one keeps its counts
@@ -145,6 +146,15 @@ def test_chain_is_broken_by_a_new_target_and_resumes(L):
     st.chain = True
     run(False, "chain on again: the step before it left its counts in place")
     run(True, "and resumed")
+    import os
+    os.environ["RRL_CHAIN"] = "0"  # (read per call: the process-wide switch; the step stays chain-clean, only the fusing stops)
+    try:
+        run(False, "RRL_CHAIN=0")
+        assert st.fused is False and st._chain_ready
+    finally:
+        del os.environ["RRL_CHAIN"]
+    run(True, "RRL_CHAIN unset again")
+    assert st.fused is True
     st.keep_target = False
     run(False, "keep_target off")
 
