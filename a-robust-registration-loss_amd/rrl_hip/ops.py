@@ -978,6 +978,7 @@ class RegistrationStep:
         if prepared is None:  # default: on (RRL_PREPARED=0 turns the default off: A/B runs of unmodified callers)
             prepared = os.environ.get("RRL_PREPARED", "1") != "0"
         self.prepared = bool(prepared) and mode == "cull" and max(N, M) <= 65536
+        self._out = (self.st.loss.view(-1), self.gR, self.gt, self.payload, self.st.info)  # (static views: built once)
         self._kept_key = None  # _write_key of the target whose records the workspace holds
         self.keep_target = True  # False: rebuild the target's records in every call (see invalidate_target)
         # chained steps (round 6; include/rrl.h RRL_F_CHAIN / RRL_F_CHAINED; see LossStep).  OFF by default here: a chained
@@ -1081,7 +1082,7 @@ class RegistrationStep:
         if self.ride is not None:  # .chamfer_value: this step's monitor (it rode in the scan's launch, or one launch now)
             _keep_ride(self.st, self.ride)
             self.chamfer_value = chamfer_from_state(self.st)
-        return self.st.loss.view(-1), self.gR, self.gt, self.payload, self.st.info
+        return self._out
 
 
 class LossStep:
@@ -1164,6 +1165,12 @@ class LossStep:
             self._optr_c = tuple(_optr(o) for o in self._opts_c)  # first / kept / chained
         self._optr, self._optr_kept = _optr(self._opts), _optr(self._opts_kept)
         self._lib = _lib.load()
+        # what every call hands over / returns unchanged: built once (a LossState field is a fresh view per access: ~6 us of host
+        # time per step for `.info` alone)
+        self._out = (self.st.loss.view(-1), self.grad, self.st.info)
+        self._c_fixed = (_p(self.st.ws), self.st.nbytes, _p(self.st.loss))
+        self._c_tail = (_p(self.grad), None, B, N, M, L, self.tr, *self.rng, self.mode, self.chunk, None)
+        self._p_ones = _p(self.ones)
 
     def invalidate_target(self):
         """As RegistrationStep.invalidate_target: the next call rebuilds the target's records."""
@@ -1193,9 +1200,8 @@ class LossStep:
         if self.ride is not None:
             self.ride.arm()
         with _guard(dev):
-            check(self._lib.rrl_loss_step_ex(_p(self.src), _p(Rm), _p(tv), _p(self.tar), _p(ln), _p(self.st.ws),
-                                             self.st.nbytes, _p(self.st.loss), _p(g), _p(self.grad), None, B, N, M, L,
-                                             self.tr, *self.rng, self.mode, self.chunk, None, op, _stream(dev)),
+            check(self._lib.rrl_loss_step_ex(_p(self.src), _p(Rm), _p(tv), _p(self.tar), _p(ln), *self._c_fixed,
+                                             self._p_ones if g is self.ones else _p(g), *self._c_tail, op, _stream(dev)),
                   "rrl_loss_step")
         self._kept_key = key
         self._chain_ready = self.prepared and bool(self._chain_left.value & 1)
@@ -1205,7 +1211,7 @@ class LossStep:
         if self.ride is not None:
             _keep_ride(self.st, self.ride)
             self.chamfer_value = chamfer_from_state(self.st)
-        return self.st.loss.view(-1), self.grad, self.st.info
+        return self._out
 
 
 def registration_step_raw(src_tri, R, t, tar_tri, line, rng=(1, 1, 5, 5), transpose_r=True, order1=None, order2=None,
