@@ -346,3 +346,56 @@ def test_chained_step_on_the_references_own_pairs(L, oracle, names):
         if g["lines"].shape[0] == nl:  # the reference evaluated exactly these lines: its own loss (default bucket range = ranges[0])
             assert [int(v) for v in g["ranges"][0]] == [1, 1, 5, 5]
             assert abs(float(loss[b]) - float(g["r0_loss"])) <= 1e-5 * abs(float(g["r0_loss"]))
+
+
+_TIMEOUT_CHILD = r"""
+import sys
+sys.path[:0] = [{root!r}, {pkg!r}, {tests!r}]
+import numpy as np, torch
+import loss as L
+from rrl_hip import ops
+from test_gpu_prepared import _pairs
+from test_gpu_chain import _new_lines, _poses
+B, n, m, nl = 8, 4096, 4096, 10000
+prs, src, tar = _pairs(995, B, n, m)
+ln = _new_lines(L, prs, nl, 0)
+R, t = _poses(B, 0)
+ref = ops.LossStep(src, tar, nl, chain=False)
+want = ref(R, t, ln)[0].clone()
+st = ops.LossStep(src, tar, nl)
+st(R, t, ln)
+nan = same = other = 0
+for it in range(30):
+    got = st(R, t, ln)[0].clone()
+    torch.cuda.synchronize()
+    assert st.fused
+    for b in range(B):
+        if torch.isnan(got[b]):
+            nan += 1
+        elif got[b] == want[b]:
+            same += 1
+        else:
+            other += 1
+    assert int(st.st.chain.abs().max()) == 0  # the words are cleared on exit, time-out counts included
+print("RESULT", nan, same, other, flush=True)
+"""
+
+
+@pytest.mark.timeout(300)
+def test_a_wait_that_times_out_is_flagged_never_silent():
+    """RRL_CHAIN_SPIN=0 (a child process: the limit is read once): a source-cloud workgroup of the chained launch that finds its
+    sample's records not yet published gives up at once instead of waiting.  Every sample's loss must then be EITHER bit-equal to
+    the plain step's (all its source workgroups started after the records were out) OR NaN (a time-out was counted in
+    CHAIN[b][3]) -- never a finite wrong value --, the launch never hangs, and the CHAIN words are cleared for the next step."""
+    import os
+    import subprocess
+    import sys
+    from conftest import PKG, ROOT
+    code = _TIMEOUT_CHILD.format(root=ROOT, pkg=PKG, tests=os.path.join(ROOT, "tests"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=280, env=dict(os.environ, RRL_CHAIN_SPIN="0"))
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    line = [x for x in r.stdout.splitlines() if x.startswith("RESULT")][-1]
+    nan, same, other = (int(v) for v in line.split()[1:])
+    print(f"[time-out path] of 240 sample evaluations: {nan} NaN (timed out), {same} bit-equal, {other} finite but different")
+    assert other == 0 and nan + same == 240
+    assert nan > 0, "with a zero limit the first generation's source workgroups must time out"
