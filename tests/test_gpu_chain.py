@@ -317,6 +317,40 @@ def test_chained_launch_under_contention(L):
         side.synchronize()
 
 
+@pytest.mark.timeout(300)
+def test_two_chained_steps_on_two_streams_at_once(L):
+    """Two step objects (their own workspaces) issued on two streams so that their chained launches overlap on the chip: each
+    launch's records workgroups lead its OWN grid, so a launch never waits for the other one's -- every result equals that
+    object's plain step, nothing times out, both keep running the ONE-launch build."""
+    from rrl_hip import ops
+    shapes = [(4, 2048, 2048, 9000), (8, 4096, 4096, 10000)]
+    objs = []
+    for q, (B, n, m, nl) in enumerate(shapes):
+        prs, src, tar = _pairs(1200 + q, B, n, m)
+        ln = [_new_lines(L, prs, nl, it) for it in range(2)]
+        poses = [_poses(B, it) for it in range(2)]
+        ref = ops.LossStep(src, tar, nl, chain=False)
+        want = [_snapshot(ref, ref(*poses[it], ln[it])) for it in range(2)]
+        objs.append(dict(src=src, tar=tar, nl=nl, ln=ln, poses=poses, want=want, stream=torch.cuda.Stream()))
+    torch.cuda.synchronize()
+    for o in objs:
+        with torch.cuda.stream(o["stream"]):
+            o["st"] = ops.LossStep(o["src"], o["tar"], o["nl"])
+            o["st"](*o["poses"][0], o["ln"][0])
+    torch.cuda.synchronize()
+    for rnd in range(40):
+        it = rnd & 1
+        got = []
+        for o in objs:  # (issued back to back: the second object's launches queue while the first one's run)
+            with torch.cuda.stream(o["stream"]):
+                o["st"].st.lmax.fill_(-7.0)
+                got.append(_snapshot(o["st"], o["st"](*o["poses"][it], o["ln"][it])))
+        torch.cuda.synchronize()
+        for o, g in zip(objs, got):
+            _assert_same(o["want"][it], g, ("two streams", rnd))
+            assert bool((o["st"].st.lmax == -7.0).all()) and o["st"].fused
+
+
 @pytest.mark.parametrize("names", [["loss_ref_airplane%d.npz" % i for i in range(5)], ["loss_ref_real%d.npz" % i for i in range(3)],
                                    ["loss_ref_human%d.npz" % i for i in range(3)]])
 def test_chained_step_on_the_references_own_pairs(L, oracle, names):
